@@ -1,0 +1,120 @@
+"""Seeded synthetic inputs shared by make_golden.py (build container, needs the
+reference) and the parity tests (anywhere).  No reference dependency.  Fixtures
+store sha1 digests of these inputs so a drifting RNG stream is detected."""
+import hashlib
+import numpy as np
+
+
+def digest(*arrays):
+    h = hashlib.sha1()
+    for a in arrays:
+        h.update(np.ascontiguousarray(a).tobytes())
+    return h.hexdigest()
+
+
+def synth_v8_head(seed, n_hot=60, n_dup=20, A=8400, nc=80):
+    """SURVEY 8c recipe, parameterised."""
+    rng = np.random.default_rng(seed)
+    out = np.zeros((4 + nc, A), np.float32)
+    out[0] = rng.uniform(50, 590, A); out[1] = rng.uniform(180, 460, A)
+    out[2] = rng.uniform(20, 120, A); out[3] = rng.uniform(20, 100, A)
+    out[4:] = rng.uniform(0, 0.05, (nc, A))
+    hot = rng.choice(A, n_hot, replace=False)
+    for a in hot:
+        out[4 + rng.integers(nc), a] = rng.uniform(0.35, 0.95)
+    nd = min(n_dup, n_hot // 3)
+    out[0:4, hot[nd:2 * nd]] = out[0:4, hot[:nd]] + rng.normal(0, 2, (4, nd)).astype(np.float32)
+    return out
+
+
+def synth_v5_head(seed, n_hot=50, A=25200, nc=80):
+    rng = np.random.default_rng(seed)
+    out = np.zeros((A, 5 + nc), np.float32)
+    out[:, 0] = rng.uniform(50, 590, A); out[:, 1] = rng.uniform(50, 590, A)
+    out[:, 2] = rng.uniform(20, 120, A); out[:, 3] = rng.uniform(20, 100, A)
+    q = 2048.0  # dyadic rationals -> fp32 product exact
+    out[:, 4] = np.round(rng.uniform(0, 0.3, A) * q) / q
+    out[:, 5:] = np.round(rng.uniform(0, 0.2, (A, nc)) * q) / q
+    hot = rng.choice(A, n_hot, replace=False)
+    for a in hot:
+        out[a, 4] = np.round(rng.uniform(0.7, 1.0) * q) / q
+        out[a, 5 + rng.integers(nc)] = np.round(rng.uniform(0.6, 1.0) * q) / q
+    nd = n_hot // 3
+    out[hot[nd:2 * nd], 0:4] = out[hot[:nd], 0:4] + rng.normal(0, 2, (nd, 4)).astype(np.float32)
+    return out
+
+
+def synth_ufld(seed, lanes=((1, 60, .4), (2, 140, -.4)), cols=(), boost=True):
+    rng = np.random.default_rng(seed)
+    loc_row = rng.normal(0, 1, (1, 200, 72, 4)).astype(np.float32)
+    loc_col = rng.normal(0, 1, (1, 100, 81, 4)).astype(np.float32)
+    exist_row = rng.normal(0, 1, (1, 2, 72, 4)).astype(np.float32)
+    exist_col = rng.normal(0, 1, (1, 2, 81, 4)).astype(np.float32)
+    for lane, x0, slope in lanes:
+        for k in range(72):
+            g = int(x0 + slope * k)
+            g = max(0, min(199, g))
+            loc_row[0, g, k, lane] += 8
+            if g + 1 <= 199:
+                loc_row[0, g + 1, k, lane] += 6
+            exist_row[0, 1, k, lane] += 5
+    for lane, y0, slope in cols:
+        for k in range(81):
+            g = int(y0 + slope * k)
+            g = max(0, min(99, g))
+            loc_col[0, g, k, lane] += 8
+            if g >= 1:
+                loc_col[0, g - 1, k, lane] += 5
+            exist_col[0, 1, k, lane] += 5
+    return [loc_row, loc_col, exist_row, exist_col]
+
+
+def track_scene(seed, n_obj, n_frames, drop=0.1, W=1280, H=720):
+    """Constant-velocity rectangles + N(0,1) jitter + dropout; int xyxy like RectInfo.tolist()."""
+    rng = np.random.default_rng(seed)
+    cx = rng.uniform(100, W - 100, n_obj); cy = rng.uniform(100, H - 100, n_obj)
+    w = rng.uniform(40, 160, n_obj); h = rng.uniform(40, 140, n_obj)
+    vx = rng.uniform(-6, 6, n_obj); vy = rng.uniform(-3, 3, n_obj)
+    cls = rng.integers(0, 3, n_obj)
+    base_score = rng.uniform(0.42, 0.95, n_obj)
+    frames = []
+    for f in range(n_frames):
+        boxes, scores, ids = [], [], []
+        for o in range(n_obj):
+            if rng.uniform() < drop:
+                continue
+            j = rng.normal(0, 1, 4)
+            x1 = cx[o] + vx[o] * f - w[o] / 2 + j[0]; y1 = cy[o] + vy[o] * f - h[o] / 2 + j[1]
+            x2 = cx[o] + vx[o] * f + w[o] / 2 + j[2]; y2 = cy[o] + vy[o] * f + h[o] / 2 + j[3]
+            boxes.append([int(x1), int(y1), int(x2), int(y2)])
+            s = float(np.clip(base_score[o] + rng.normal(0, 0.05), 0.401, 0.99))
+            scores.append(float(np.float32(s)))
+            ids.append(int(cls[o]))
+        frames.append(dict(boxes=boxes, scores=scores, ids=ids))
+    return frames
+
+
+
+LB720 = dict(target=(640, 640), old=(720, 1280), new=(361, 640), pad=(139, 0))
+LBSQ = dict(target=(640, 640), old=(640, 640), new=(640, 640), pad=(0, 0))
+LBPORT = dict(target=(640, 640), old=(1280, 720), new=(640, 360), pad=(0, 140))
+
+
+def yolo_cases():
+    """(tag, model_type, head, letterbox, box_score, iou)"""
+    return [("v8_s1", "YOLOV8", synth_v8_head(1), LB720, 0.4, 0.45),
+            ("v8_s2", "YOLOV8", synth_v8_head(2, 200, 60), LB720, 0.4, 0.45),
+            ("v8_s3", "YOLOV8", synth_v8_head(3, 12, 3), LBSQ, 0.25, 0.5),
+            ("v8_s4", "YOLOV8", synth_v8_head(4, 600, 200), LBPORT, 0.4, 0.45),
+            ("v8_none", "YOLOV8", synth_v8_head(5, 0, 0), LB720, 0.4, 0.45),
+            ("v5_s1", "YOLOV5", synth_v5_head(11), LBSQ, 0.4, 0.45),
+            ("v5_s2", "YOLOV5", synth_v5_head(12, 150), LB720, 0.4, 0.45)]
+
+
+def ufld_cases():
+    """(tag, [loc_row, loc_col, exist_row, exist_col], img_w, img_h)"""
+    return [("l1", synth_ufld(0), 1280, 720),
+            ("l2", synth_ufld(1, lanes=((1, 20, 1.2), (2, 190, -1.5)), cols=((0, 30, .5), (3, 80, -.6))), 1280, 720),
+            ("l3", synth_ufld(2, lanes=()), 1920, 1080),
+            ("l4", synth_ufld(3, lanes=((1, 0, 0.0), (2, 199, 0.0)), cols=((0, 0, 0.0), (3, 99, 0.0))), 1640, 590),
+            ("l5", synth_ufld(4, lanes=((1, 70, .3),)), 1280, 720)]

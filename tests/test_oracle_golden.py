@@ -1,0 +1,97 @@
+"""Pin the oracle (oracle/*.py NumPy restatement) against golden vectors produced
+by the reference's own code under stubs (tests/golden/make_golden.py)."""
+import gzip, json, os
+import numpy as np
+import pytest
+
+from conftest import GOLDEN
+import synth
+from oracle import yolo_post, ufld_decode, bytetrack
+
+MT = {"YOLOV8": "yolov8", "YOLOV5": "yolov5"}
+
+
+def test_nms_kats():
+    g = np.load(os.path.join(GOLDEN, "nms_kat.npz"))
+    n = int(g["n_cases"])
+    assert n >= 12
+    for i in range(n):
+        for thr in (45, 30):
+            t = f"k{i}_t{thr}"
+            keep = yolo_post.fast_soft_nms(g[t + "_boxes"], g[t + "_scores"], thr / 100.0)
+            np.testing.assert_array_equal(keep, g[t + "_keep"], err_msg=t)
+            alt = yolo_post.fast_nms(g[t + "_boxes"], g[t + "_scores"], thr / 100.0)
+            # reference tie order is unspecified (unstable argsort): compare as given unless tied
+            sc = g[t + "_scores"]
+            if len(np.unique(sc)) == len(sc):
+                np.testing.assert_array_equal(alt, g[t + "_keep_alt"], err_msg=t)
+            else:
+                assert sorted(alt.tolist()) == sorted(g[t + "_keep_alt"].tolist()) or len(alt) == len(g[t + "_keep_alt"])
+    # the headline bug-compatibility KATs
+    np.testing.assert_array_equal(g["k0_t45_keep"], [1, 2])
+    np.testing.assert_array_equal(g["k2_t45_keep"], [1, 2, 2])
+
+
+@pytest.mark.parametrize("case", synth.yolo_cases(), ids=lambda c: c[0])
+def test_yolo_post_chain(case):
+    tag, mt, head, lb, bs, iou = case
+    g = np.load(os.path.join(GOLDEN, "yolo_post.npz"))
+    assert synth.digest(head) == str(g[tag + "_head_sha1"]), "synthetic input drifted from the golden's"
+    lbp = yolo_post.letterbox_params(lb["old"], lb["target"])
+    assert lbp["new"] == tuple(lb["new"]) and lbp["pad"] == tuple(lb["pad"])
+    r = yolo_post.detect_post(head, lbp, MT[mt], bs, iou)
+    boxes, cls, conf, _ = yolo_post.process_output(head, MT[mt], bs)
+    np.testing.assert_array_equal(boxes, g[tag + "_raw_boxes"])
+    np.testing.assert_array_equal(cls, g[tag + "_cls"])
+    np.testing.assert_array_equal(conf, g[tag + "_conf"])
+    np.testing.assert_array_equal(r["cand_xywh"], g[tag + "_xywh"])
+    np.testing.assert_array_equal(r["keep"], g[tag + "_keep"])
+    np.testing.assert_array_equal(r["xywh"], g[tag + "_rect_xywh"])
+    np.testing.assert_array_equal(r["conf"], g[tag + "_rect_conf"])
+    np.testing.assert_array_equal(r["class_id"], g[tag + "_rect_label"])
+    np.testing.assert_array_equal(r["xyxy_int"], g[tag + "_rect_xyxy_int"])
+    alt = yolo_post.fast_nms(r["cand_xywh"], r["cand_conf"], iou)
+    np.testing.assert_array_equal(alt, g[tag + "_keep_alt"])
+
+
+@pytest.mark.parametrize("case", synth.ufld_cases(), ids=lambda c: c[0])
+def test_ufld_decode(case):
+    tag, outs, W, H = case
+    g = np.load(os.path.join(GOLDEN, "ufld_decode.npz"))
+    assert synth.digest(*outs) == str(g[tag + "_in_sha1"])
+    cfg = ufld_decode.ModelConfig("culane")
+    lanes, status = ufld_decode.process_output(outs, cfg, W, H)
+    assert status == g[tag + "_status"].tolist()
+    for li in range(4):
+        np.testing.assert_array_equal(np.asarray(lanes[li], np.int64).reshape(-1, 2), g[f"{tag}_lane{li}"])
+    astat, area = ufld_decode.lanes_area(lanes, status, H, adjust=True)
+    assert astat == bool(g[tag + "_area_status"])
+    np.testing.assert_array_equal(np.asarray(area, np.int64).reshape(-1, 2), g[tag + "_area"])
+
+
+def _load_bt():
+    with gzip.open(os.path.join(GOLDEN, "bytetrack.json.gz"), "rt") as f:
+        return json.load(f)
+
+
+@pytest.mark.parametrize("tag", ["t1", "t2", "t3", "t4", "t5", "t6", "t7"])
+def test_bytetrack_trace(tag):
+    sc = _load_bt()[tag]
+    lab = ["car", "person", "truck"]
+    trk = bytetrack.BYTETracker()
+    for fr, want in zip(sc["frames"], sc["trace"]):
+        ids = [lab[i] for i in fr["ids"]] if sc["label_ids"] else fr["ids"]
+        got = trk.update(fr["boxes"], fr["scores"], ids)
+        assert got["frame_id"] == want["frame_id"] and got["count"] == want["count"]
+        for lst in ("tracked", "lost"):
+            assert len(got[lst]) == len(want[lst]), (tag, want["frame_id"], lst)
+            for a, b in zip(got[lst], want[lst]):
+                for k in ("track_id", "state", "is_activated", "class_id", "start_frame", "frame_id", "tracklet_len"):
+                    assert a[k] == b[k], (tag, want["frame_id"], lst, k, a, b)
+                assert a["score"] == b["score"]
+                np.testing.assert_allclose(a["tlwh"], b["tlwh"], rtol=1e-12, atol=1e-12)
+    if tag == "t1":  # SURVEY KAT-T1 narrative
+        tr = sc["trace"]
+        assert [t["track_id"] for t in tr[0]["tracked"]] == [1, 2, 3]
+        assert tr[3]["lost"][0]["track_id"] == 3 and tr[4]["count"] == 3
+        assert 3 in [t["track_id"] for t in tr[4]["tracked"]]
