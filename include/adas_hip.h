@@ -1,0 +1,230 @@
+/* adas_hip.h -- C ABI of libadas_hip.so: the MI355X-native per-frame ADAS inference path.
+ *
+ * The reference (jason-li-831202/Vehicle-CV-ADAS @ 2024_10_08) has no FFI: its engine seam is the
+ * Python class protocol of coreEngine.py.  Each entry point below names the reference interface it
+ * replaces (file:line, relative to the reference repo).  The ctypes stubs a reference maintainer
+ * would add are shown in INTEGRATION.md; the in-tree host mirror is vehicle-cv-adas_amd/.
+ *
+ * Conventions: plain pointers and sizes only; every function returns 0 on success or a negative
+ * adas_status; adas_last_error() gives the message of the calling thread's last failure.
+ * `stream` is a hipStream_t passed as void* (NULL = the library's own stream).  Pointers named d_*
+ * are device (HBM) pointers, h_* host pointers.  All objects are single-threaded like the
+ * reference engines (coreEngine.py:94-116): one caller at a time per handle.
+ */
+#ifndef ADAS_HIP_H
+#define ADAS_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+    ADAS_OK = 0,
+    ADAS_ERR_INVALID = -1,   /* bad argument */
+    ADAS_ERR_IO = -2,        /* model file missing / unreadable (coreEngine.py:12-13) */
+    ADAS_ERR_FORMAT = -3,    /* not a model container this library understands (coreEngine.py:14) */
+    ADAS_ERR_HIP = -4,       /* HIP runtime failure */
+    ADAS_ERR_CAPACITY = -5,  /* a fixed capacity (candidates, tracks, detections) was exceeded */
+    ADAS_ERR_NO_DEVICE = -6  /* no gfx950 device visible: the library never falls back to the CPU */
+} adas_status;
+
+const char* adas_last_error(void);
+int adas_version(void);
+/* Number of visible HIP devices (<=0: none) and selection of the device subsequent handles live on
+ * (reference: cuda.Device(0) hard-coded at coreEngine.py:47). */
+int adas_device_count(void);
+int adas_set_device(int index);
+/* Plain device-memory helpers so a ctypes/cgo caller can stage buffers without another runtime. */
+int adas_malloc(void** d_ptr, size_t bytes);
+int adas_free(void* d_ptr);
+int adas_memcpy_h2d(void* d_dst, const void* h_src, size_t bytes);
+int adas_memcpy_d2h(void* h_dst, const void* d_src, size_t bytes);
+int adas_synchronize(void);
+
+/* ===================================================================================
+ * Engine: replaces EngineBase / OnnxEngine / TensorRTEngine (coreEngine.py:7-39,120-186)
+ * =================================================================================== */
+typedef struct adas_engine adas_engine;
+
+#define ADAS_PREC_BF16 0 /* bf16 storage + bf16 MFMA, fp32 accumulate (bench precision) */
+#define ADAS_PREC_FP32 1 /* fp32 storage + fp32 MFMA (parity precision, 1e-3 vs the fp32 oracle) */
+
+/* OnnxEngine.__init__(path) / TensorRTEngine.__init__(path) (coreEngine.py:122-126,161-170).
+ * `max_batch` frames per call are planned in HBM (the reference is fixed at 1). */
+int adas_engine_create(const char* model_path, int precision, int max_batch, adas_engine** out);
+int adas_engine_destroy(adas_engine* e);
+/* get_engine_input_shape() -> [1,3,H,W] (coreEngine.py:144-145,178-179) */
+int adas_engine_input_shape(const adas_engine* e, int64_t dims[4]);
+/* get_engine_output_shape() -> (shapes, names) (coreEngine.py:147-148,181-182) */
+int adas_engine_num_outputs(const adas_engine* e);
+int adas_engine_output_shape(const adas_engine* e, int index, int64_t dims[4], int* ndim);
+const char* adas_engine_output_name(const adas_engine* e, int index);
+/* engine_inference(input_tensor) (coreEngine.py:150-157,184-186): NCHW fp32 host tensor in, fp32 host
+ * tensors out in graph output order.  h_outputs[i] must hold batch * prod(dims[1:]) floats. */
+int adas_engine_infer_host(adas_engine* e, const float* h_input_nchw, int batch, float* const* h_outputs);
+/* Device-resident form ("frames never round-trip to host"): input is NCHW fp32 already in HBM;
+ * outputs stay in HBM and are read through adas_engine_output_device(). Asynchronous on `stream`. */
+int adas_engine_infer_device(adas_engine* e, const float* d_input_nchw, int batch, void* stream);
+const float* adas_engine_output_device(const adas_engine* e, int index);
+/* Algorithmic work of one frame: 2*MACs over conv+linear layers and weight bytes. */
+int adas_engine_stats(const adas_engine* e, double* flops_per_frame, double* weight_bytes, int* num_layers);
+/* Per-layer device timing of the last adas_engine_profile() call (hipEvents on the engine stream). */
+int adas_engine_profile(adas_engine* e, const float* d_input_nchw, int batch, int iters, float* ms_per_layer,
+                        int max_layers, int* num_layers);
+int adas_engine_layer_info(const adas_engine* e, int layer, char* name, int name_cap, double* flops, int* kind);
+/* Debug/parity tap: copy an intermediate activation (by layer index) to the host as NCHW fp32. */
+int adas_engine_fetch_activation(adas_engine* e, int layer, int batch, float* h_out_nchw, int64_t dims[4]);
+
+/* ===================================================================================
+ * YOLO post-processing: replaces YoloDetector.__process_output (yoloDetector.py:104-133),
+ * Scaler.convert_boxes_coordinate (utils.py:70-87), NMS.fast_soft_nms / NMS.fast_nms
+ * (utils.py:161-256 / 105-159), get_nms_results + RectInfo.tolist (yoloDetector.py:135-157,
+ * core.py:18-23).  fp64 from the box corners onward; survivor indices bit-exact.
+ * =================================================================================== */
+typedef struct adas_yolo_post adas_yolo_post;
+
+#define ADAS_HEAD_V8 0 /* (4+nc, A) channel-major: YOLOv8/9/10 (yoloDetector.py:114-115,121-122) */
+#define ADAS_HEAD_V5 1 /* (A, 5+nc) row-major, conf = cls*obj in fp32: YOLOv5/6/7 (yoloDetector.py:123-124) */
+#define ADAS_NMS_REFERENCE 0 /* production call yoloDetector.py:139, bug-compatible (SURVEY finding 1) */
+#define ADAS_NMS_GREEDY 1    /* NMS.fast_nms, the commented alternative yoloDetector.py:138 */
+
+typedef struct {
+    int32_t layout;         /* ADAS_HEAD_V8 | ADAS_HEAD_V5 */
+    int32_t num_anchors;    /* 8400 | 25200 */
+    int32_t num_classes;    /* 80 */
+    int32_t nms_mode;       /* ADAS_NMS_* */
+    double box_score;       /* keep if conf > box_score (strict), >= 0 */
+    double iou_thr;         /* box_nms_iou */
+    int32_t pad_h, pad_w;   /* Scaler._pad_shape (utils.py:62) */
+    double ratio_h, ratio_w; /* Scaler.get_scale_ratio() (utils.py:65-68) */
+    int32_t max_candidates; /* capacity per frame; exceeding it sets ADAS_ERR_CAPACITY on fetch */
+    int32_t reserved;
+} adas_yolo_post_params;
+
+/* Scaler.process_image geometry without the pixels (utils.py:42-63): fills pad_* and ratio_*. */
+int adas_letterbox_params(int src_h, int src_w, int dst_h, int dst_w, int keep_ratio, adas_yolo_post_params* p);
+
+int adas_yolo_post_create(const adas_yolo_post_params* p, int max_batch, adas_yolo_post** out);
+int adas_yolo_post_destroy(adas_yolo_post* h);
+/* d_head: batch head tensors back to back in the reference layout, fp32, in HBM. Asynchronous. */
+int adas_yolo_post_run(adas_yolo_post* h, const float* d_head, int batch, void* stream);
+
+typedef struct {
+    int32_t n_found;       /* anchors over threshold (may exceed capacity) */
+    int32_t n_candidates;  /* stored */
+    int32_t n_keep;        /* survivors */
+    int32_t flags;         /* bit0: capacity overflow */
+} adas_yolo_counts;
+/* Synchronises, then copies frame `frame`'s results.  Any pointer may be NULL.  Arrays must hold
+ * max_candidates entries (x4 for boxes).  cand_*: thresholded rows in anchor order after the inverse
+ * letterbox (xywh fp64); keep: NMS result as indices into the candidates, in the reference's order;
+ * det_*: RectInfo fields of the survivors; det_xyxy_int = RectInfo.tolist(). */
+int adas_yolo_post_fetch(adas_yolo_post* h, int frame, adas_yolo_counts* counts, int32_t* cand_anchor,
+                         double* cand_xywh, double* cand_conf, int32_t* cand_cls, int32_t* keep, double* det_xywh,
+                         double* det_conf, int32_t* det_cls, int32_t* det_xyxy_int);
+/* Device views of the survivors for GPU-resident consumers (the tracker): per-frame strides are
+ * max_candidates entries.  xyxy as fp64 of the int-truncated corners, scores fp64, classes, counts[4]. */
+int adas_yolo_post_device_views(adas_yolo_post* h, const double** d_xyxy, const double** d_score,
+                                const int32_t** d_cls, const int32_t** d_counts);
+
+/* ===================================================================================
+ * UFLDv2 lane decode: replaces UltrafastLaneDetectorV2.__process_output
+ * (ultrafastLaneDetectorV2.py:114-181, _softmax :15-19, ModelConfig :21-55)
+ * =================================================================================== */
+typedef struct adas_ufld_decode adas_ufld_decode;
+#define ADAS_UFLD_MAX_POINTS 128
+
+typedef struct {
+    int32_t grid_row, cls_row, grid_col, cls_col; /* 200,72,100,81 (CULane) */
+    int32_t img_w, img_h;                         /* source image size the points are scaled to */
+    int32_t local_width;                          /* 1 */
+    int32_t reserved;
+    const double* h_row_anchor;                   /* [cls_row] cfg.row_anchor (host) */
+    const double* h_col_anchor;                   /* [cls_col] cfg.col_anchor (host) */
+} adas_ufld_params;
+
+int adas_ufld_decode_create(const adas_ufld_params* p, int max_batch, adas_ufld_decode** out);
+int adas_ufld_decode_destroy(adas_ufld_decode* h);
+/* Four device tensors in the engine's output layout (1,G,K,4); frame b is at ptr + b*batch_stride_* */
+int adas_ufld_decode_run(adas_ufld_decode* h, const float* d_loc_row, const float* d_loc_col,
+                         const float* d_exist_row, const float* d_exist_col, size_t stride_loc_row,
+                         size_t stride_loc_col, size_t stride_exist_row, size_t stride_exist_col, int batch,
+                         void* stream);
+/* lane order: left-side, left-ego, right-ego, right-side (ultrafastLaneDetectorV2.py:143-145).
+ * points: [4][ADAS_UFLD_MAX_POINTS][2] (x,y) int32; counts[4]; detected[4]. */
+int adas_ufld_decode_fetch(adas_ufld_decode* h, int frame, int32_t* points, int32_t* counts, int32_t* detected);
+
+/* ===================================================================================
+ * ByteTrack: replaces BYTETracker.__init__/update/reset (byteTracker.py:30-51,62-185,187-200)
+ * with matching.py, kalman_filter.py, strack.py, base_track.py, byteTrack/utils.py underneath.
+ * One independent tracker (own id counter) per stream; the whole update runs on the GPU.
+ * =================================================================================== */
+typedef struct adas_bytetrack adas_bytetrack;
+
+typedef struct {
+    double track_thresh;  /* 0.5 */
+    double match_thresh;  /* 0.8 */
+    double frame_rate;    /* 30 */
+    int32_t track_buffer; /* 30 */
+    int32_t max_tracks;   /* track-table capacity per stream (tracked + lost) */
+    int32_t max_dets;     /* detections per frame capacity */
+    int32_t reserved;
+} adas_bytetrack_params;
+
+typedef struct {          /* base_track.py:61-72 + strack.py:207-215 (crops/location not carried) */
+    double tlwh[4];       /* STrack.tlwh (Kalman-filtered) */
+    double score;
+    int32_t track_id, state, is_activated, class_id;
+    int32_t frame_id, start_frame, tracklet_len, pad;
+} adas_track;
+
+typedef struct {
+    int32_t frame_id, id_count, n_tracked, n_lost, err, pad[3];
+} adas_track_header;
+
+int adas_bytetrack_create(const adas_bytetrack_params* p, int n_streams, adas_bytetrack** out);
+int adas_bytetrack_destroy(adas_bytetrack* h);
+int adas_bytetrack_reset(adas_bytetrack* h, int stream_index /* -1 = all */);
+/* BYTETracker.update(bboxes, scores, class_ids, frame) for one stream from host arrays
+ * (xyxy fp64 [n][4], scores fp64, integer class ids). */
+int adas_bytetrack_update_host(adas_bytetrack* h, int stream_index, const double* h_xyxy, const double* h_scores,
+                               const int32_t* h_cls, int n);
+/* All streams at once from device-resident detections (e.g. adas_yolo_post_device_views):
+ * stream s reads n = d_counts[s*count_stride + count_index] rows at row offset s*det_stride. */
+int adas_bytetrack_update_device(adas_bytetrack* h, const double* d_xyxy, const double* d_scores,
+                                 const int32_t* d_cls, const int32_t* d_counts, int det_stride, int count_stride,
+                                 int count_index, int n_streams, void* stream);
+/* Synchronises; tracks[0..n_tracked) are tracked_stracks, then n_lost lost_stracks, list order kept. */
+int adas_bytetrack_fetch(adas_bytetrack* h, int stream_index, adas_track_header* hdr, adas_track* tracks,
+                         int max_tracks);
+
+/* ===================================================================================
+ * Fused per-frame pipeline (the path demo.py:261-281 drives): detector forward + decode/NMS,
+ * lane forward + decode, tracker update, for `n_streams` independent video streams per step,
+ * captured in a hipGraph.  Inputs are the two pre-processed NCHW fp32 tensors per stream in HBM.
+ * =================================================================================== */
+typedef struct adas_pipeline adas_pipeline;
+typedef struct {
+    adas_engine* detector;      /* may be NULL */
+    adas_engine* lane;          /* may be NULL */
+    adas_yolo_post* post;       /* required with detector */
+    adas_ufld_decode* decode;   /* required with lane */
+    adas_bytetrack* tracker;    /* may be NULL */
+    int32_t n_streams;
+    int32_t use_graph;          /* capture the step in a hipGraph */
+} adas_pipeline_desc;
+int adas_pipeline_create(const adas_pipeline_desc* d, adas_pipeline** out);
+int adas_pipeline_destroy(adas_pipeline* p);
+/* One step = one frame of every stream.  Asynchronous; adas_pipeline_sync() waits for it. */
+int adas_pipeline_step(adas_pipeline* p, const float* d_det_input_nchw, const float* d_lane_input_nchw);
+int adas_pipeline_sync(adas_pipeline* p);
+/* Device time of the last `n` steps' sections in ms (hipEvents on the pipeline stream):
+ * [0] detector net, [1] yolo post, [2] lane net, [3] lane decode, [4] tracker, [5] whole step. */
+int adas_pipeline_timings(adas_pipeline* p, float ms[6]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ADAS_HIP_H */

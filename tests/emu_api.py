@@ -1,0 +1,110 @@
+"""ctypes wrapper over tests/_build/libemu.so (host emulation of the device post-processing logic).
+Test scaffolding: lets the CPU suite check the logic of csrc/post_core.h + track_core.h."""
+import ctypes as C, os, subprocess
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SRC = os.path.join(ROOT, "tests", "hostemu", "emu.cpp")
+OUT = os.path.join(ROOT, "tests", "_build", "libemu.so")
+INC = os.path.join(ROOT, "vehicle-cv-adas_amd", "csrc")
+
+BTOUT = np.dtype([("tlwh", "f8", 4), ("score", "f8"), ("track_id", "i4"), ("state", "i4"), ("is_activated", "i4"),
+                  ("class_id", "i4"), ("frame_id", "i4"), ("start_frame", "i4"), ("tracklet_len", "i4"), ("pad", "i4")])
+
+
+def build():
+    deps = [SRC, os.path.join(INC, "post_core.h"), os.path.join(INC, "track_core.h")]
+    if os.path.exists(OUT) and all(os.path.getmtime(OUT) >= os.path.getmtime(d) for d in deps):
+        return OUT
+    os.makedirs(os.path.dirname(OUT), exist_ok=True)
+    subprocess.check_call(["g++", "-O1", "-ffp-contract=off", "-fPIC", "-shared", "-I", INC, SRC, "-o", OUT])
+    return OUT
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        _lib = C.CDLL(build())
+        _lib.emu_bt_create.restype = C.c_void_p
+        _lib.emu_bt_create.argtypes = [C.c_double, C.c_double, C.c_int, C.c_double, C.c_int, C.c_int]
+        for f in ("emu_bt_destroy", "emu_bt_reset"):
+            getattr(_lib, f).argtypes = [C.c_void_p]
+        _lib.emu_bt_update.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+        _lib.emu_bt_fetch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        assert _lib.emu_sizeof_btout() == BTOUT.itemsize
+    return _lib
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def yolo_post(head, layout, lb, box_score, iou, nms_mode=0, cap=1024):
+    head = np.ascontiguousarray(head, np.float32)
+    if layout == 0:
+        nc, A = head.shape[0] - 4, head.shape[1]
+    else:
+        A, nc = head.shape[0], head.shape[1] - 5
+    counts = np.zeros(4, np.int32)
+    o = dict(cand_anchor=np.zeros(cap, np.int32), cand_xywh=np.zeros((cap, 4)), cand_conf=np.zeros(cap),
+             cand_cls=np.zeros(cap, np.int32), keep=np.zeros(cap, np.int32), det_xywh=np.zeros((cap, 4)),
+             det_conf=np.zeros(cap), det_cls=np.zeros(cap, np.int32), det_xyxy_i=np.zeros((cap, 4), np.int32),
+             det_xyxy_d=np.zeros((cap, 4)))
+    lib().emu_yolo_post(_p(head), layout, A, nc, C.c_double(box_score), C.c_double(iou), nms_mode,
+                        int(lb["pad"][0]), int(lb["pad"][1]), C.c_double(lb["ratio"][0]), C.c_double(lb["ratio"][1]),
+                        cap, _p(counts), *[_p(o[k]) for k in ("cand_anchor", "cand_xywh", "cand_conf", "cand_cls",
+                                                               "keep", "det_xywh", "det_conf", "det_cls",
+                                                               "det_xyxy_i", "det_xyxy_d")])
+    n, k = int(counts[1]), int(counts[2])
+    return dict(n_found=int(counts[0]), overflow=bool(counts[3] & 1),
+                cand_anchor=o["cand_anchor"][:n], cand_xywh=o["cand_xywh"][:n], cand_conf=o["cand_conf"][:n],
+                cand_cls=o["cand_cls"][:n], keep=o["keep"][:k], xywh=o["det_xywh"][:k], conf=o["det_conf"][:k],
+                class_id=o["det_cls"][:k], xyxy_int=o["det_xyxy_i"][:k], xyxy_d=o["det_xyxy_d"][:k])
+
+
+def ufld(outs, cfg, W, H, lw=1):
+    lr, lc, er, ec = [np.ascontiguousarray(o, np.float32) for o in outs]
+    cnt = np.zeros(4, np.int32); det = np.zeros(4, np.int32); pts = np.zeros((4, 128, 2), np.int32)
+    ra = np.ascontiguousarray(cfg.row_anchor, np.float64); ca = np.ascontiguousarray(cfg.col_anchor, np.float64)
+    lib().emu_ufld(_p(lr), _p(lc), _p(er), _p(ec), lr.shape[1], lr.shape[2], lc.shape[1], lc.shape[2], W, H, lw,
+                   _p(ra), _p(ca), _p(cnt), _p(det), _p(pts))
+    return [[(int(x), int(y)) for x, y in pts[i, :cnt[i]]] for i in range(4)], [bool(d) for d in det]
+
+
+class Tracker:
+    def __init__(self, track_thresh=0.5, match_thresh=0.8, track_buffer=30, frame_rate=30, MT=256, MD=256):
+        self.h = lib().emu_bt_create(track_thresh, match_thresh, track_buffer, frame_rate, MT, MD)
+        self.MT = MT
+
+    def reset(self):
+        lib().emu_bt_reset(self.h)
+
+    def update(self, boxes, scores, cls):
+        b = np.ascontiguousarray(np.asarray(boxes, np.float64).reshape(-1, 4))
+        s = np.ascontiguousarray(np.asarray(scores, np.float64).reshape(-1))
+        c = np.ascontiguousarray(np.asarray(cls, np.int32).reshape(-1))
+        err = lib().emu_bt_update(self.h, _p(b), _p(s), _p(c), len(s))
+        hdr = np.zeros(5, np.int32); recs = np.zeros(2 * self.MT, BTOUT)
+        lib().emu_bt_fetch(self.h, _p(hdr), _p(recs))
+        return snapshot(hdr, recs), err
+
+    def __del__(self):
+        try:
+            lib().emu_bt_destroy(self.h)
+        except Exception:
+            pass
+
+
+def snapshot(hdr, recs):
+    nt, nl = int(hdr[2]), int(hdr[3])
+
+    def rec(r):
+        return dict(track_id=int(r["track_id"]), state=int(r["state"]), is_activated=bool(r["is_activated"]),
+                    score=float(r["score"]), class_id=int(r["class_id"]), start_frame=int(r["start_frame"]),
+                    frame_id=int(r["frame_id"]), tracklet_len=int(r["tracklet_len"]),
+                    tlwh=[float(v) for v in r["tlwh"]])
+    return dict(frame_id=int(hdr[0]), count=int(hdr[1]), tracked=[rec(r) for r in recs[:nt]],
+                lost=[rec(r) for r in recs[nt:nt + nl]])

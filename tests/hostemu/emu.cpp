@@ -1,0 +1,88 @@
+// TEST SCAFFOLDING ONLY -- never loaded by the product.
+// Compiles csrc/post_core.h + csrc/track_core.h with g++ as single-thread host
+// code (Ctx{tid=0,nthr=1}) so the *logic* of the device routines can be checked
+// against the golden vectors on the GPU-less build container.  Races and the
+// wave-shuffle reductions are only exercised by the real -m gpu tests.
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+#include "post_core.h"
+#include "track_core.h"
+using namespace adas;
+
+extern "C" {
+
+// scan: per-anchor first-argmax class + conf (device: yolo_scan_* kernels)
+static void scan_host(const float* head, int layout, int A, int nc, float* conf, int* cls) {
+    for (int a = 0; a < A; ++a) {
+        float best = 0; int bi = 0;
+        for (int k = 0; k < nc; ++k) {
+            float v = layout == 0 ? head[(size_t)(4 + k) * A + a]
+                                  : head[(size_t)a * (5 + nc) + 5 + k] * head[(size_t)a * (5 + nc) + 4];
+            if (k == 0 || v > best) { best = v; bi = k; }
+        }
+        conf[a] = best; cls[a] = bi;
+    }
+}
+
+int emu_yolo_post(const float* head, int layout, int A, int nc, double box_score, double iou, int nms_mode,
+                  int pad_h, int pad_w, double ratio_h, double ratio_w, int cap,
+                  int* counts, int* cand_anchor, double* cand_xywh, double* cand_conf, int* cand_cls, int* keep,
+                  double* det_xywh, double* det_conf, int* det_cls, int* det_xyxy_i, double* det_xyxy_d) {
+    std::vector<float> conf(A); std::vector<int> cls(A);
+    scan_host(head, layout, A, nc, conf.data(), cls.data());
+    YoloPostCfg cfg{layout, A, nc, box_score, iou, nms_mode, pad_h, pad_w, ratio_h, ratio_w, cap};
+    YoloPostFrame f{head, conf.data(), cls.data(), counts, cand_anchor, cand_xywh, cand_conf, cand_cls, keep,
+                    det_xywh, det_conf, det_cls, det_xyxy_i, det_xyxy_d};
+    std::vector<double> lds(YoloLds::bytes(cap, 1) / 8 + 2);
+    Ctx c{0, 1};
+    yolo_post_frame(c, cfg, f, lds.data());
+    return 0;
+}
+
+int emu_ufld(const float* loc_row, const float* loc_col, const float* exist_row, const float* exist_col,
+             int grid_row, int cls_row, int grid_col, int cls_col, int img_w, int img_h, int lw,
+             const double* row_anchor, const double* col_anchor, int* lane_cnt, int* lane_det, int* lane_pts) {
+    UfldCfg cfg{grid_row, cls_row, grid_col, cls_col, 4, img_w, img_h, lw, row_anchor, col_anchor};
+    UfldFrame f{loc_row, loc_col, exist_row, exist_col, lane_cnt, lane_det, lane_pts};
+    std::vector<double> lds(UfldLds::bytes(cls_row, cls_col) / 8 + 2);
+    Ctx c{0, 1};
+    ufld_decode_frame(c, cfg, f, lds.data());
+    return 0;
+}
+
+struct EmuBt { BtParams P; BtStream S; std::vector<char> mem; std::vector<double> lds; };
+
+void* emu_bt_create(double track_thresh, double match_thresh, int track_buffer, double frame_rate, int MT, int MD) {
+    EmuBt* e = new EmuBt;
+    e->P = BtParams{track_thresh, track_thresh + 0.1, match_thresh, (int)(frame_rate / 30.0 * track_buffer), MT, MD};
+    size_t sz = sizeof(BtHeader) + 2 * MT * sizeof(int) + MT * sizeof(BtTrack) + (size_t)MT * MD * 8 + 2 * MT * sizeof(BtOut) + 64;
+    e->mem.assign(sz, 0);
+    char* p = e->mem.data();
+    e->S.hdr = (BtHeader*)p; p += sizeof(BtHeader);
+    e->S.slots = (BtTrack*)p; p += MT * sizeof(BtTrack);
+    e->S.cost = (double*)p; p += (size_t)MT * MD * 8;
+    e->S.out = (BtOut*)p; p += 2 * MT * sizeof(BtOut);
+    e->S.tracked = (int*)p; p += MT * sizeof(int);
+    e->S.lost = (int*)p;
+    e->lds.assign(BtLds::bytes(MT, MD, 1) / 8 + 2, 0.0);
+    return e;
+}
+void emu_bt_destroy(void* h) { delete (EmuBt*)h; }
+void emu_bt_reset(void* h) { EmuBt* e = (EmuBt*)h; Ctx c{0, 1}; bytetrack_reset(c, e->P, e->S); }
+int emu_bt_update(void* h, const double* tlbr, const double* score, const int* cls, int nd) {
+    EmuBt* e = (EmuBt*)h;
+    BtDet d{tlbr, score, cls, nd};
+    Ctx c{0, 1};
+    bytetrack_update(c, e->P, e->S, d, e->lds.data());
+    return e->S.hdr->err;
+}
+// out: header ints [frame_id, id_count, n_tracked, n_lost, err]; recs: BtOut array
+void emu_bt_fetch(void* h, int* hdr, void* recs) {
+    EmuBt* e = (EmuBt*)h;
+    hdr[0] = e->S.hdr->frame_id; hdr[1] = e->S.hdr->id_count; hdr[2] = e->S.hdr->n_tracked;
+    hdr[3] = e->S.hdr->n_lost; hdr[4] = e->S.hdr->err;
+    memcpy(recs, e->S.out, (size_t)(hdr[2] + hdr[3]) * sizeof(BtOut));
+}
+int emu_sizeof_btout() { return (int)sizeof(BtOut); }
+}

@@ -1,0 +1,175 @@
+"""GPU parity: HIP post-processing (through the C ABI) vs the oracle and the reference goldens.
+Bit-exact for candidate rows, NMS survivor indices, RectInfo ints, lane points, track ids/states."""
+import gzip, json, os
+import numpy as np
+import pytest
+
+from conftest import GOLDEN
+import synth, parity_checks as pc
+from oracle import yolo_post, ufld_decode, bytetrack
+
+pytestmark = pytest.mark.gpu
+MT = {"YOLOV8": ("yolov8", 0), "YOLOV5": ("yolov5", 1)}
+
+
+@pytest.fixture(scope="module")
+def G():
+    import gpu_api
+    assert gpu_api.L.lib().adas_device_count() > 0, "no HIP device"
+    return gpu_api
+
+
+@pytest.mark.parametrize("case", synth.yolo_cases(), ids=lambda c: c[0])
+@pytest.mark.parametrize("mode", [0, 1])
+def test_yolo_post(G, case, mode):
+    tag, mt, head, lb, bs, iou = case
+    name, layout = MT[mt]
+    lbp = yolo_post.letterbox_params(lb["old"], lb["target"])
+    glb = G.PP.letterbox(lb["old"], lb["target"])
+    assert glb["pad"] == lbp["pad"] and glb["ratio"] == lbp["ratio"]
+    want = yolo_post.detect_post(head, lbp, name, bs, iou, "reference" if mode == 0 else "greedy")
+    got = G.yolo_post(head, layout, glb, bs, iou, mode)
+    assert got["rc"] == 0 and not got["overflow"]
+    pc.check_yolo(got, want)
+    if mode == 0:
+        g = np.load(os.path.join(GOLDEN, "yolo_post.npz"))
+        np.testing.assert_array_equal(got["keep"], g[tag + "_keep"])
+        np.testing.assert_array_equal(got["xyxy_int"], g[tag + "_rect_xyxy_int"])
+        np.testing.assert_array_equal(got["xywh"], g[tag + "_rect_xywh"])
+
+
+def test_yolo_post_batched_frames(G):
+    """Several frames per launch: every frame's block must give the single-frame result."""
+    cases = synth.yolo_cases()[:4]
+    lbp = yolo_post.letterbox_params((720, 1280), (640, 640))
+    heads = np.stack([c[2] for c in cases] * 4)
+    yp = G.PP.YoloPost(0, 8400, 80, 0.4, 0.45, lbp, 0, 1024, max_batch=len(heads))
+    res = yp.run_host(heads)
+    for i, r in enumerate(res):
+        want = yolo_post.detect_post(heads[i], lbp, "yolov8", 0.4, 0.45)
+        pc.check_yolo(r, want)
+    yp.close()
+
+
+def test_yolo_post_generic_v5_and_stress(G):
+    rng = np.random.default_rng(5)
+    head = rng.uniform(0, 1, (25200, 85)).astype(np.float32)
+    head[:, :4] = rng.uniform(20, 600, (25200, 4))
+    head[:, 4] *= (rng.uniform(0, 1, 25200) < 0.004)
+    lbp = yolo_post.letterbox_params((720, 1280), (640, 640))
+    want = yolo_post.detect_post(head, lbp, "yolov5", 0.4, 0.45)
+    got = G.yolo_post(head, 1, lbp, 0.4, 0.45, 0)
+    pc.check_yolo(got, want)
+    # post-proc stress mode: N in {16, 64, 256, 1024} candidates
+    for n in (16, 64, 256, 1000):
+        h8 = synth.synth_v8_head(100 + n, n, n // 3)
+        want = yolo_post.detect_post(h8, lbp, "yolov8", 0.3, 0.45)
+        got = G.yolo_post(h8, 0, lbp, 0.3, 0.45, 0, cap=1024)
+        pc.check_yolo(got, want)
+
+
+def test_yolo_post_overflow_is_loud(G):
+    head = synth.synth_v8_head(4, 600, 200)
+    lbp = yolo_post.letterbox_params((720, 1280), (640, 640))
+    got = G.yolo_post(head, 0, lbp, 0.4, 0.45, 0, cap=128)
+    assert got["overflow"] and got["rc"] == -5 and got["n_found"] > 128
+
+
+def test_nms_kats(G):
+    lbp = yolo_post.letterbox_params((640, 640), (640, 640))
+    kats = [([(0, 0, 10, 10), (100, 100, 10, 10), (200, 200, 10, 10)], [.5, .9, .7], [1, 2]),
+            ([(0, 0, 100, 100), (300, 300, 10, 10), (500, 500, 10, 10)], [.5, .9, .7], [1, 2, 2]),
+            ([(0, 0, 10, 10), (1, 1, 10, 10), (50, 50, 10, 10)], [.9, .8, .7], [0, 2]),
+            ([(5, 5, 20, 20)], [.8], [0])]
+    for boxes, scores, keep in kats:
+        head = np.zeros((84, 8400), np.float32)
+        for i, ((x, y, w, h), s) in enumerate(zip(boxes, scores)):
+            a = 100 * (i + 1)
+            head[0:4, a] = [x + w / 2, y + h / 2, w, h]
+            head[4 + i, a] = s
+        got = G.yolo_post(head, 0, lbp, 0.4, 0.45, 0)
+        assert got["keep"].tolist() == keep
+    # empty frame
+    got = G.yolo_post(np.zeros((84, 8400), np.float32), 0, lbp, 0.4, 0.45, 0)
+    assert len(got["keep"]) == 0 and got["n_found"] == 0
+
+
+@pytest.mark.parametrize("case", synth.ufld_cases(), ids=lambda c: c[0])
+def test_ufld(G, case):
+    tag, outs, W, H = case
+    cfg = ufld_decode.ModelConfig("culane")
+    want_l, want_s = ufld_decode.process_output(outs, cfg, W, H)
+    got_l, got_s = G.ufld(outs, cfg, W, H)
+    # softmax exp is fp32 in NumPy (SIMD, <=1ulp) and correctly-rounded here: tolerance +-1 px
+    n_off = pc.check_lanes(got_l, got_s, want_l, want_s, tol_px=1)
+    assert n_off <= 2
+    g = np.load(os.path.join(GOLDEN, "ufld_decode.npz"))
+    for li in range(4):
+        assert len(got_l[li]) == len(g[f"{tag}_lane{li}"])
+
+
+@pytest.mark.parametrize("tag", ["t1", "t2", "t3", "t4", "t5", "t6", "t7"])
+def test_bytetrack_goldens(G, tag):
+    with gzip.open(os.path.join(GOLDEN, "bytetrack.json.gz"), "rt") as f:
+        sc = json.load(f)[tag]
+    trk = G.PP.DeviceTracker(1)
+    lab = ["car", "person", "truck"]
+    for fr, want in zip(sc["frames"], sc["trace"]):
+        trk.update_host(0, fr["boxes"], fr["scores"], fr["ids"])
+        got = G.track_snapshot(*trk.fetch(0))
+        if sc["label_ids"]:
+            for lst in ("tracked", "lost"):
+                for t in got[lst]:
+                    t["class_id"] = lab[t["class_id"]]
+        pc.check_track_frame(got, want, ctx=(tag, want["frame_id"]))
+    trk.close()
+
+
+def test_bytetrack_multi_stream_reset(G):
+    """Independent per-stream id counters (the reference's is process-global, base_track.py:12)."""
+    S = 4
+    trk = G.PP.DeviceTracker(S)
+    oras = [bytetrack.BYTETracker() for _ in range(S)]
+    scenes = [synth.track_scene(200 + s, 10 + 5 * s, 40, 0.15) for s in range(S)]
+    for f in range(40):
+        for s in range(S):
+            fr = scenes[s][f]
+            trk.update_host(s, fr["boxes"], fr["scores"], fr["ids"])
+        for s in range(S):
+            fr = scenes[s][f]
+            want = oras[s].update(fr["boxes"], fr["scores"], fr["ids"])
+            pc.check_track_frame(G.track_snapshot(*trk.fetch(s)), want, ctx=(s, f))
+    trk.reset(1); oras[1].reset()
+    for f in range(10):
+        fr = scenes[1][f]
+        trk.update_host(1, fr["boxes"], fr["scores"], fr["ids"])
+        want = oras[1].update(fr["boxes"], fr["scores"], fr["ids"])
+        pc.check_track_frame(G.track_snapshot(*trk.fetch(1)), want, ctx=("reset", f))
+    trk.close()
+
+
+def test_detect_to_track_device_chain(G):
+    """yolo_post survivors feed the tracker without leaving HBM; equals oracle post + oracle tracker."""
+    lbp = yolo_post.letterbox_params((720, 1280), (640, 640))
+    S = 3
+    yp = G.PP.YoloPost(0, 8400, 80, 0.4, 0.45, lbp, 0, 256, max_batch=S)
+    trk = G.PP.DeviceTracker(S, max_dets=256)
+    oras = [bytetrack.BYTETracker() for _ in range(S)]
+    rng = np.random.default_rng(0)
+    base = [synth.synth_v8_head(300 + s, 25, 6) for s in range(S)]
+    for f in range(12):
+        heads = []
+        for s in range(S):
+            h = base[s].copy()
+            h[0] += 3.0 * f; h[1] += 1.0 * f
+            heads.append(h)
+        heads = np.stack(heads)
+        buf = G.L.DeviceBuffer.from_array(heads)
+        yp.run_device(buf.ptr, S)
+        trk.update_device(yp.device_views(), det_stride=256, n_streams=S)
+        for s in range(S):
+            r = yolo_post.detect_post(heads[s], lbp, "yolov8", 0.4, 0.45)
+            want = oras[s].update(r["xyxy_int"], r["conf"], r["class_id"])
+            pc.check_track_frame(G.track_snapshot(*trk.fetch(s)), want, ctx=(s, f))
+        buf.free()
+    yp.close(); trk.close()

@@ -1,0 +1,102 @@
+"""CPU: the device post-processing *logic* (csrc/post_core.h, track_core.h compiled for the host,
+single thread) against the oracle and the reference goldens.  The real HIP kernels are checked by
+tests/test_gpu_*.py with the same assertions."""
+import gzip, json, os
+import numpy as np
+import pytest
+
+from conftest import GOLDEN
+import synth, emu_api, parity_checks as pc
+from oracle import yolo_post, ufld_decode, bytetrack
+
+MT = {"YOLOV8": ("yolov8", 0), "YOLOV5": ("yolov5", 1)}
+
+
+@pytest.mark.parametrize("case", synth.yolo_cases(), ids=lambda c: c[0])
+@pytest.mark.parametrize("mode", [0, 1])
+def test_yolo_post(case, mode):
+    tag, mt, head, lb, bs, iou = case
+    name, layout = MT[mt]
+    lbp = yolo_post.letterbox_params(lb["old"], lb["target"])
+    want = yolo_post.detect_post(head, lbp, name, bs, iou, "reference" if mode == 0 else "greedy")
+    got = emu_api.yolo_post(head, layout, lbp, bs, iou, mode)
+    assert not got["overflow"]
+    pc.check_yolo(got, want)
+    if mode == 0:  # and directly against the reference's own output
+        g = np.load(os.path.join(GOLDEN, "yolo_post.npz"))
+        np.testing.assert_array_equal(got["keep"], g[tag + "_keep"])
+        np.testing.assert_array_equal(got["xyxy_int"], g[tag + "_rect_xyxy_int"])
+
+
+def test_yolo_post_generic_v5_product():
+    """v5 conf = cls*obj rounded in fp32 (yoloDetector.py:124) on non-dyadic values."""
+    rng = np.random.default_rng(5)
+    head = rng.uniform(0, 1, (25200, 85)).astype(np.float32)
+    head[:, :4] = rng.uniform(20, 600, (25200, 4))
+    head[:, 4] *= (rng.uniform(0, 1, 25200) < 0.004)
+    lbp = yolo_post.letterbox_params((720, 1280), (640, 640))
+    want = yolo_post.detect_post(head, lbp, "yolov5", 0.4, 0.45)
+    got = emu_api.yolo_post(head, 1, lbp, 0.4, 0.45, 0)
+    assert len(want["keep"]) > 5
+    pc.check_yolo(got, want)
+
+
+def test_yolo_post_overflow_flag():
+    head = synth.synth_v8_head(4, 600, 200)
+    lbp = yolo_post.letterbox_params((720, 1280), (640, 640))
+    got = emu_api.yolo_post(head, 0, lbp, 0.4, 0.45, 0, cap=128)
+    assert got["overflow"] and got["n_found"] > 128 and len(got["cand_anchor"]) == 128
+
+
+def test_nms_kats_via_head():
+    """SURVEY KATs 1-4 pushed through the whole device chain (square letterbox = identity)."""
+    lbp = yolo_post.letterbox_params((640, 640), (640, 640))
+    kats = [([(0, 0, 10, 10), (100, 100, 10, 10), (200, 200, 10, 10)], [.5, .9, .7], [1, 2]),
+            ([(0, 0, 100, 100), (300, 300, 10, 10), (500, 500, 10, 10)], [.5, .9, .7], [1, 2, 2]),
+            ([(0, 0, 10, 10), (1, 1, 10, 10), (50, 50, 10, 10)], [.9, .8, .7], [0, 2])]
+    for boxes, scores, keep in kats:
+        head = np.zeros((84, 8400), np.float32)
+        for i, ((x, y, w, h), s) in enumerate(zip(boxes, scores)):
+            a = 100 * (i + 1)
+            head[0:4, a] = [x + w / 2, y + h / 2, w, h]
+            head[4 + i, a] = s
+        got = emu_api.yolo_post(head, 0, lbp, 0.4, 0.45, 0)
+        assert got["keep"].tolist() == keep
+
+
+@pytest.mark.parametrize("case", synth.ufld_cases(), ids=lambda c: c[0])
+def test_ufld(case):
+    tag, outs, W, H = case
+    cfg = ufld_decode.ModelConfig("culane")
+    want_l, want_s = ufld_decode.process_output(outs, cfg, W, H)
+    got_l, got_s = emu_api.ufld(outs, cfg, W, H)
+    pc.check_lanes(got_l, got_s, want_l, want_s, tol_px=0)
+
+
+@pytest.mark.parametrize("tag", ["t1", "t2", "t3", "t4", "t5", "t6", "t7"])
+def test_bytetrack(tag):
+    with gzip.open(os.path.join(GOLDEN, "bytetrack.json.gz"), "rt") as f:
+        sc = json.load(f)[tag]
+    trk = emu_api.Tracker()
+    for fr, want in zip(sc["frames"], sc["trace"]):
+        got, err = trk.update(fr["boxes"], fr["scores"], fr["ids"])
+        assert err == 0
+        if sc["label_ids"]:
+            lab = ["car", "person", "truck"]
+            for lst in ("tracked", "lost"):
+                for t in got[lst]:
+                    t["class_id"] = lab[t["class_id"]]
+        pc.check_track_frame(got, want, ctx=(tag, want["frame_id"]))
+
+
+def test_bytetrack_reset_and_random_vs_oracle():
+    rng = np.random.default_rng(42)
+    trk = emu_api.Tracker(); ora = bytetrack.BYTETracker()
+    for rep in range(2):
+        frames = synth.track_scene(100 + rep, 25, 50, 0.2)
+        for f, fr in enumerate(frames):
+            got, err = trk.update(fr["boxes"], fr["scores"], fr["ids"])
+            want = ora.update(fr["boxes"], fr["scores"], fr["ids"])
+            assert err == 0
+            pc.check_track_frame(got, want, ctx=(rep, f))
+        trk.reset(); ora.reset()

@@ -1,0 +1,176 @@
+"""ctypes binding of libadas_hip.so -- the only way the Python host side reaches the GPU.
+
+Fails loudly: a missing/unloadable library is an ImportError-like RuntimeError, a missing device is
+reported by the library itself (ADAS_ERR_NO_DEVICE); nothing here computes on the CPU.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libadas_hip.so")
+
+UFLD_MAX_POINTS = 128
+HEAD_V8, HEAD_V5 = 0, 1
+NMS_REFERENCE, NMS_GREEDY = 0, 1
+PREC_BF16, PREC_FP32 = 0, 1
+
+
+class AdasError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"libadas_hip error {code}: {msg}")
+        self.code = code
+
+
+class YoloPostParams(C.Structure):
+    _fields_ = [("layout", C.c_int32), ("num_anchors", C.c_int32), ("num_classes", C.c_int32), ("nms_mode", C.c_int32),
+                ("box_score", C.c_double), ("iou_thr", C.c_double), ("pad_h", C.c_int32), ("pad_w", C.c_int32),
+                ("ratio_h", C.c_double), ("ratio_w", C.c_double), ("max_candidates", C.c_int32), ("reserved", C.c_int32)]
+
+
+class YoloCounts(C.Structure):
+    _fields_ = [("n_found", C.c_int32), ("n_candidates", C.c_int32), ("n_keep", C.c_int32), ("flags", C.c_int32)]
+
+
+class UfldParams(C.Structure):
+    _fields_ = [("grid_row", C.c_int32), ("cls_row", C.c_int32), ("grid_col", C.c_int32), ("cls_col", C.c_int32),
+                ("img_w", C.c_int32), ("img_h", C.c_int32), ("local_width", C.c_int32), ("reserved", C.c_int32),
+                ("h_row_anchor", C.c_void_p), ("h_col_anchor", C.c_void_p)]
+
+
+class BytetrackParams(C.Structure):
+    _fields_ = [("track_thresh", C.c_double), ("match_thresh", C.c_double), ("frame_rate", C.c_double),
+                ("track_buffer", C.c_int32), ("max_tracks", C.c_int32), ("max_dets", C.c_int32), ("reserved", C.c_int32)]
+
+
+class TrackHeader(C.Structure):
+    _fields_ = [("frame_id", C.c_int32), ("id_count", C.c_int32), ("n_tracked", C.c_int32), ("n_lost", C.c_int32),
+                ("err", C.c_int32), ("pad", C.c_int32 * 3)]
+
+
+class PipelineDesc(C.Structure):
+    _fields_ = [("detector", C.c_void_p), ("lane", C.c_void_p), ("post", C.c_void_p), ("decode", C.c_void_p),
+                ("tracker", C.c_void_p), ("n_streams", C.c_int32), ("use_graph", C.c_int32)]
+
+
+TRACK_DTYPE = np.dtype([("tlwh", "f8", 4), ("score", "f8"), ("track_id", "i4"), ("state", "i4"), ("is_activated", "i4"),
+                        ("class_id", "i4"), ("frame_id", "i4"), ("start_frame", "i4"), ("tracklet_len", "i4"), ("pad", "i4")])
+
+_P = C.c_void_p
+_SIGS = {
+    "adas_last_error": (C.c_char_p, []),
+    "adas_version": (C.c_int, []),
+    "adas_device_count": (C.c_int, []),
+    "adas_set_device": (C.c_int, [C.c_int]),
+    "adas_malloc": (C.c_int, [C.POINTER(_P), C.c_size_t]),
+    "adas_free": (C.c_int, [_P]),
+    "adas_memcpy_h2d": (C.c_int, [_P, _P, C.c_size_t]),
+    "adas_memcpy_d2h": (C.c_int, [_P, _P, C.c_size_t]),
+    "adas_synchronize": (C.c_int, []),
+    "adas_engine_create": (C.c_int, [C.c_char_p, C.c_int, C.c_int, C.POINTER(_P)]),
+    "adas_engine_destroy": (C.c_int, [_P]),
+    "adas_engine_input_shape": (C.c_int, [_P, C.POINTER(C.c_int64)]),
+    "adas_engine_num_outputs": (C.c_int, [_P]),
+    "adas_engine_output_shape": (C.c_int, [_P, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_int)]),
+    "adas_engine_output_name": (C.c_char_p, [_P, C.c_int]),
+    "adas_engine_infer_host": (C.c_int, [_P, _P, C.c_int, C.POINTER(_P)]),
+    "adas_engine_infer_device": (C.c_int, [_P, _P, C.c_int, _P]),
+    "adas_engine_output_device": (_P, [_P, C.c_int]),
+    "adas_engine_stats": (C.c_int, [_P, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int)]),
+    "adas_engine_profile": (C.c_int, [_P, _P, C.c_int, C.c_int, _P, C.c_int, C.POINTER(C.c_int)]),
+    "adas_engine_layer_info": (C.c_int, [_P, C.c_int, C.c_char_p, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int)]),
+    "adas_engine_fetch_activation": (C.c_int, [_P, C.c_int, C.c_int, _P, C.POINTER(C.c_int64)]),
+    "adas_letterbox_params": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(YoloPostParams)]),
+    "adas_yolo_post_create": (C.c_int, [C.POINTER(YoloPostParams), C.c_int, C.POINTER(_P)]),
+    "adas_yolo_post_destroy": (C.c_int, [_P]),
+    "adas_yolo_post_run": (C.c_int, [_P, _P, C.c_int, _P]),
+    "adas_yolo_post_fetch": (C.c_int, [_P, C.c_int, C.POINTER(YoloCounts)] + [_P] * 9),
+    "adas_yolo_post_device_views": (C.c_int, [_P] + [C.POINTER(_P)] * 4),
+    "adas_ufld_decode_create": (C.c_int, [C.POINTER(UfldParams), C.c_int, C.POINTER(_P)]),
+    "adas_ufld_decode_destroy": (C.c_int, [_P]),
+    "adas_ufld_decode_run": (C.c_int, [_P, _P, _P, _P, _P, C.c_size_t, C.c_size_t, C.c_size_t, C.c_size_t, C.c_int, _P]),
+    "adas_ufld_decode_fetch": (C.c_int, [_P, C.c_int, _P, _P, _P]),
+    "adas_bytetrack_create": (C.c_int, [C.POINTER(BytetrackParams), C.c_int, C.POINTER(_P)]),
+    "adas_bytetrack_destroy": (C.c_int, [_P]),
+    "adas_bytetrack_reset": (C.c_int, [_P, C.c_int]),
+    "adas_bytetrack_update_host": (C.c_int, [_P, C.c_int, _P, _P, _P, C.c_int]),
+    "adas_bytetrack_update_device": (C.c_int, [_P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
+    "adas_bytetrack_fetch": (C.c_int, [_P, C.c_int, C.POINTER(TrackHeader), _P, C.c_int]),
+    "adas_pipeline_create": (C.c_int, [C.POINTER(PipelineDesc), C.POINTER(_P)]),
+    "adas_pipeline_destroy": (C.c_int, [_P]),
+    "adas_pipeline_step": (C.c_int, [_P, _P, _P]),
+    "adas_pipeline_sync": (C.c_int, [_P]),
+    "adas_pipeline_timings": (C.c_int, [_P, C.POINTER(C.c_float)]),
+}
+
+_lib = None
+
+
+def exported_symbols():
+    return sorted(_SIGS)
+
+
+def lib():
+    """Load libadas_hip.so once and type its entry points.  Raises if it is not built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(f"{LIB_PATH} is not built; run `python vehicle-cv-adas_amd/build.py` "
+                               "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGS.items():
+            fn = getattr(L, name)          # AttributeError if the .so lacks a declared symbol
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def check(code):
+    if code != 0:
+        raise AdasError(code, lib().adas_last_error().decode("utf-8", "replace"))
+    return code
+
+
+def ptr(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+class DeviceBuffer:
+    """A raw HBM allocation owned by Python (adas_malloc / adas_free)."""
+
+    def __init__(self, nbytes):
+        self.nbytes = int(nbytes)
+        p = C.c_void_p()
+        check(lib().adas_malloc(C.byref(p), self.nbytes))
+        self.ptr = p.value
+
+    @classmethod
+    def from_array(cls, arr):
+        arr = np.ascontiguousarray(arr)
+        b = cls(arr.nbytes)
+        b.upload(arr)
+        return b
+
+    def upload(self, arr):
+        arr = np.ascontiguousarray(arr)
+        assert arr.nbytes <= self.nbytes
+        check(lib().adas_memcpy_h2d(self.ptr, ptr(arr), arr.nbytes))
+
+    def download(self, shape, dtype):
+        out = np.empty(shape, dtype)
+        assert out.nbytes <= self.nbytes
+        check(lib().adas_memcpy_d2h(ptr(out), self.ptr, out.nbytes))
+        return out
+
+    def free(self):
+        if self.ptr:
+            lib().adas_free(self.ptr)
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass

@@ -1,0 +1,61 @@
+"""Build libadas_hip.so (HIP kernels + C ABI) for gfx950 with hipcc, in-tree.
+
+    python vehicle-cv-adas_amd/build.py [--force]
+
+hipcc cross-compiles without a GPU.  The .so is git-ignored but travels to the GPU box with the
+gpurun snapshot.  The bit-exact post-processing units are compiled with -ffp-contract=off.
+"""
+import os, subprocess, sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+OUT = os.path.join(HERE, "libadas_hip.so")
+OBJ = os.path.join(HERE, "_obj")
+ARCH = "gfx950"
+
+# (source, extra flags)
+UNITS = [
+    ("api_common.cpp", []),
+    ("post_kernels.hip", ["-ffp-contract=off"]),
+    ("conv_kernels.hip", []),
+    ("aux_kernels.hip", []),
+    ("engine.cpp", []),
+    ("pipeline.cpp", []),
+]
+COMMON = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function",
+          "-Wno-unused-result", "-x", "hip"]
+
+
+def _deps():
+    hdrs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
+    hdrs.append(os.path.join(HERE, "..", "include", "adas_hip.h"))
+    return hdrs
+
+
+def build(force=False, verbose=True):
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    os.makedirs(OBJ, exist_ok=True)
+    hdr_t = max(os.path.getmtime(h) for h in _deps())
+    objs, rebuilt = [], False
+    for src, extra in UNITS:
+        sp = os.path.join(CSRC, src)
+        if not os.path.exists(sp):
+            continue
+        op = os.path.join(OBJ, os.path.splitext(src)[0] + ".o")
+        objs.append(op)
+        if force or not os.path.exists(op) or os.path.getmtime(op) < max(os.path.getmtime(sp), hdr_t):
+            cmd = [hipcc, *COMMON, *extra, "-c", sp, "-o", op]
+            if verbose:
+                print(" ".join(cmd), flush=True)
+            subprocess.check_call(cmd)
+            rebuilt = True
+    if rebuilt or not os.path.exists(OUT):
+        cmd = [hipcc, "-shared", "-fPIC", f"--offload-arch={ARCH}", *objs, "-o", OUT]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+    return OUT
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv))

@@ -1,0 +1,58 @@
+// api_common.cpp -- error state, device selection and raw memory helpers of the C ABI.
+#include "common.h"
+#include <string.h>
+
+namespace adas {
+static thread_local char g_err[512] = "";
+void set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+int hip_fail(hipError_t e, const char* what, const char* file, int line) {
+    set_error("HIP error %d (%s) at %s:%d: %s", (int)e, hipGetErrorString(e), file, line, what);
+    (void)hipGetLastError();
+    return ADAS_ERR_HIP;
+}
+}  // namespace adas
+
+extern "C" {
+const char* adas_last_error(void) { return adas::g_err; }
+int adas_version(void) { return 100; }
+int adas_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) {
+        (void)hipGetLastError();
+        return 0;
+    }
+    return n;
+}
+int adas_set_device(int index) {
+    ADAS_REQUIRE(adas_device_count() > 0, ADAS_ERR_NO_DEVICE, "no HIP device visible; this library has no CPU fallback");
+    ADAS_HIP_TRY(hipSetDevice(index));
+    return ADAS_OK;
+}
+int adas_malloc(void** d_ptr, size_t bytes) {
+    ADAS_REQUIRE(d_ptr, ADAS_ERR_INVALID, "adas_malloc: null out pointer");
+    ADAS_REQUIRE(adas_device_count() > 0, ADAS_ERR_NO_DEVICE, "no HIP device visible; this library has no CPU fallback");
+    ADAS_HIP_TRY(hipMalloc(d_ptr, bytes ? bytes : 16));
+    return ADAS_OK;
+}
+int adas_free(void* d_ptr) {
+    if (d_ptr) ADAS_HIP_TRY(hipFree(d_ptr));
+    return ADAS_OK;
+}
+int adas_memcpy_h2d(void* d, const void* h, size_t n) {
+    ADAS_HIP_TRY(hipMemcpy(d, h, n, hipMemcpyHostToDevice));
+    return ADAS_OK;
+}
+int adas_memcpy_d2h(void* h, const void* d, size_t n) {
+    ADAS_HIP_TRY(hipMemcpy(h, d, n, hipMemcpyDeviceToHost));
+    return ADAS_OK;
+}
+int adas_synchronize(void) {
+    ADAS_HIP_TRY(hipDeviceSynchronize());
+    return ADAS_OK;
+}
+}

@@ -1,0 +1,25 @@
+// common.h -- error plumbing shared by the C-ABI translation units.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include "../../include/adas_hip.h"
+
+namespace adas {
+void set_error(const char* fmt, ...);
+int hip_fail(hipError_t e, const char* what, const char* file, int line);
+}  // namespace adas
+
+#define ADAS_HIP_TRY(expr)                                                      \
+    do {                                                                        \
+        hipError_t e__ = (expr);                                                \
+        if (e__ != hipSuccess) return adas::hip_fail(e__, #expr, __FILE__, __LINE__); \
+    } while (0)
+
+#define ADAS_REQUIRE(cond, code, ...)      \
+    do {                                   \
+        if (!(cond)) {                     \
+            adas::set_error(__VA_ARGS__);  \
+            return (code);                 \
+        }                                  \
+    } while (0)

@@ -1,0 +1,492 @@
+// post_core.h -- GPU-resident post-processing logic of the per-frame ADAS path.
+//
+// One workgroup per frame / per video stream executes these routines.  All
+// decision arithmetic is IEEE fp64 with contraction OFF so that survivor
+// indices and track ids are bit-exact with the reference's pinned NumPy
+// environment (SURVEY.md finding 5, Appendix A3/A6/A7).
+//
+// The routines are written against a tiny block-execution context (tid,
+// nthr, sync).  hipcc instantiates them inside __global__ kernels
+// (post_kernels.hip).  tests/hostemu compiles the very same source with g++ and
+// nthr == 1 to debug the *logic* on the GPU-less build container; that build is
+// test scaffolding only and is never loaded by the product.
+#pragma once
+#include <stdint.h>
+#include <math.h>
+#include <float.h>
+
+#if defined(__HIPCC__)
+#define ADAS_DEV __device__ __forceinline__
+#define ADAS_HD __host__ __device__ inline
+#pragma clang fp contract(off)
+#else
+#define ADAS_DEV inline
+#define ADAS_HD inline
+#endif
+
+namespace adas {
+
+struct Ctx {
+    int tid, nthr;
+    ADAS_DEV void sync() const {
+#if defined(__HIP_DEVICE_COMPILE__)
+        __syncthreads();
+#endif
+    }
+};
+
+#define ADAS_PAR_FOR(c, i, lo, hi) for (int i = (lo) + (c).tid; i < (hi); i += (c).nthr)
+
+// ---------------------------------------------------------------------------
+// block-wide "first index of the maximum" over a[lo,hi)  (np.argmax semantics)
+// red_v/red_i: LDS scratch of nthr entries.
+// ---------------------------------------------------------------------------
+ADAS_DEV void block_argmax_first(const Ctx& c, const double* a, int lo, int hi, double* red_v, int* red_i,
+                                 double& out_v, int& out_i) {
+    double bv = -DBL_MAX;
+    int bi = 0x7fffffff;
+    for (int j = lo + c.tid; j < hi; j += c.nthr) {
+        double v = a[j];
+        if (v > bv || bi == 0x7fffffff) {
+            bv = v;
+            bi = j;
+        }
+    }
+#if defined(__HIP_DEVICE_COMPILE__)
+    // wave64 shuffle reduce, then one LDS hop across waves
+    for (int off = 32; off > 0; off >>= 1) {
+        double ov = __shfl_down(bv, off, 64);
+        int oi = __shfl_down(bi, off, 64);
+        if (ov > bv || (ov == bv && oi < bi)) {
+            bv = ov;
+            bi = oi;
+        }
+    }
+    int lane = c.tid & 63, wv = c.tid >> 6, nw = (c.nthr + 63) >> 6;
+    if (lane == 0) {
+        red_v[wv] = bv;
+        red_i[wv] = bi;
+    }
+    c.sync();
+    if (c.tid == 0) {
+        for (int w = 1; w < nw; ++w) {
+            double ov = red_v[w];
+            int oi = red_i[w];
+            if (oi != 0x7fffffff && (bi == 0x7fffffff || ov > bv || (ov == bv && oi < bi))) {
+                bv = ov;
+                bi = oi;
+            }
+        }
+        red_v[0] = bv;
+        red_i[0] = bi;
+    }
+    c.sync();
+    out_v = red_v[0];
+    out_i = red_i[0];
+    c.sync();
+#else
+    (void)red_v;
+    (void)red_i;
+    out_v = bv;
+    out_i = bi;
+#endif
+}
+
+// ===========================================================================
+// YOLO: ordered compaction -> box decode -> inverse letterbox -> NMS -> gather
+// replaces yoloDetector.py:120-133 (threshold + box), utils.py:70-87,
+// utils.py:161-256 / 105-159, yoloDetector.py:135-157 + core.py:18-23
+// ===========================================================================
+struct YoloPostCfg {
+    int layout;  // 0: v8-family head [4+nc][A];  1: v5-family head [A][5+nc]
+    int A, nc;
+    double box_score, iou_thr;
+    int nms_mode;  // 0: reference (fast_soft_nms as called in production); 1: greedy (fast_nms)
+    int pad_h, pad_w;
+    double ratio_h, ratio_w;
+    int cap;  // candidate capacity per frame
+};
+
+// counts[]: 0 = candidates found (uncapped), 1 = candidates stored, 2 = survivors, 3 = flags (bit0 overflow)
+struct YoloPostFrame {
+    const float* head;       // this frame's head tensor (reference layout)
+    const float* best_conf;  // [A] from the scan kernel
+    const int* best_cls;     // [A]
+    int* counts;
+    int* cand_anchor;
+    double* cand_xywh;  // [cap][4]
+    double* cand_conf;  // [cap]
+    int* cand_cls;      // [cap]
+    int* keep;          // [cap] indices into candidates (selection order; may repeat -- reference behaviour)
+    double* det_xywh;   // [cap][4] survivors
+    double* det_conf;
+    int* det_cls;
+    int* det_xyxy_i;     // [cap][4]  RectInfo.tolist(): int() truncation
+    double* det_xyxy_d;  // same values as fp64 (tracker input)
+};
+
+// LDS carve for yolo_post_frame: doubles first (8-byte aligned), then ints.
+struct YoloLds {
+    double *c0, *c1, *c2, *c3, *sc, *area, *red_v;
+    int *idx, *order, *red_i, *scan;
+    unsigned char* flag;
+    static ADAS_HD size_t bytes(int cap, int nthr) {
+        return (size_t)cap * (6 * 8 + 2 * 4) + (size_t)nthr * (8 + 4 + 4) + 1024 + 64;
+    }
+    ADAS_DEV void carve(void* base, int cap, int nthr) {
+        double* d = (double*)base;
+        c0 = d; d += cap;
+        c1 = d; d += cap;
+        c2 = d; d += cap;
+        c3 = d; d += cap;
+        sc = d; d += cap;
+        area = d; d += cap;
+        red_v = d; d += nthr;
+        int* q = (int*)d;
+        idx = q; q += cap;
+        order = q; q += cap;
+        red_i = q; q += nthr;
+        scan = q; q += nthr;
+        flag = (unsigned char*)q;  // 1024 bytes
+    }
+};
+
+ADAS_DEV void yolo_post_frame(const Ctx& c, const YoloPostCfg& cfg, const YoloPostFrame& f, void* lds_base) {
+    YoloLds L;
+    L.carve(lds_base, cfg.cap, c.nthr);
+    const int A = cfg.A, cap = cfg.cap;
+
+    // ---- phase A: ordered stream compaction of anchors with conf > box_score (anchor order preserved)
+    int base = 0;
+    for (int a0 = 0; a0 < A; a0 += 1024) {
+        int n = (A - a0 < 1024) ? (A - a0) : 1024;
+        ADAS_PAR_FOR(c, j, 0, 1024) L.flag[j] = (j < n && (double)f.best_conf[a0 + j] > cfg.box_score) ? 1 : 0;
+        c.sync();
+        // each thread owns a contiguous slice of the chunk
+        int per = (1024 + c.nthr - 1) / c.nthr;
+        int lo = c.tid * per, hi = lo + per;
+        if (hi > 1024) hi = 1024;
+        int cnt = 0;
+        for (int j = lo; j < hi; ++j) cnt += L.flag[j];
+        L.scan[c.tid] = cnt;
+        c.sync();
+        if (c.tid == 0) {
+            int run = 0;
+            for (int t = 0; t < c.nthr; ++t) {
+                int v = L.scan[t];
+                L.scan[t] = run;
+                run += v;
+            }
+            L.red_i[0] = run;
+        }
+        c.sync();
+        int slot = base + L.scan[c.tid];
+        for (int j = lo; j < hi; ++j)
+            if (L.flag[j]) {
+                if (slot < cap) f.cand_anchor[slot] = a0 + j;
+                ++slot;
+            }
+        base += L.red_i[0];
+        c.sync();
+    }
+    const int N = base < cap ? base : cap;
+    if (c.tid == 0) {
+        f.counts[0] = base;
+        f.counts[1] = N;
+        f.counts[3] = (base > cap) ? 1 : 0;
+    }
+
+    // ---- phase B: cxcywh -> xyxy (fp64, yoloDetector.py:132) -> inverse letterbox (utils.py:82-86)
+    //      -> NMS prep xywh -> xyxy round trip (utils.py:187), +1 areas (utils.py:211)
+    ADAS_PAR_FOR(c, j, 0, N) {
+        int a = f.cand_anchor[j];
+        double x, y, w, h;
+        if (cfg.layout == 0) {
+            x = (double)f.head[(size_t)0 * A + a];
+            y = (double)f.head[(size_t)1 * A + a];
+            w = (double)f.head[(size_t)2 * A + a];
+            h = (double)f.head[(size_t)3 * A + a];
+        } else {
+            const float* r = f.head + (size_t)a * (5 + cfg.nc);
+            x = (double)r[0];
+            y = (double)r[1];
+            w = (double)r[2];
+            h = (double)r[3];
+        }
+        double hw = 0.5 * w, hh = 0.5 * h;
+        double x1 = x - hw, y1 = y - hh, x2 = x + hw, y2 = y + hh;
+        x1 = (x1 - (double)cfg.pad_w) * cfg.ratio_w;
+        x2 = (x2 - (double)cfg.pad_w) * cfg.ratio_w;
+        y1 = (y1 - (double)cfg.pad_h) * cfg.ratio_h;
+        y2 = (y2 - (double)cfg.pad_h) * cfg.ratio_h;
+        double bw = x2 - x1, bh = y2 - y1;
+        f.cand_xywh[4 * j + 0] = x1;
+        f.cand_xywh[4 * j + 1] = y1;
+        f.cand_xywh[4 * j + 2] = bw;
+        f.cand_xywh[4 * j + 3] = bh;
+        double conf = (double)f.best_conf[a];
+        f.cand_conf[j] = conf;
+        f.cand_cls[j] = f.best_cls[a];
+        double r2 = x1 + bw, r3 = y1 + bh;  // _dets[:,2:4] = _dets[:,0:2] + _dets[:,2:4]
+        L.c0[j] = x1;
+        L.c1[j] = y1;
+        L.c2[j] = r2;
+        L.c3[j] = r3;
+        L.sc[j] = conf;
+        L.idx[j] = j;
+        if (cfg.nms_mode == 0)
+            L.area[j] = (r3 - y1 + 1) * (r2 - x1 + 1);
+        else
+            L.area[j] = (r2 - x1) * (r3 - y1);
+    }
+    c.sync();
+
+    int K = 0;
+    if (N == 1) {  // utils.py:197-198 / :131-132
+        if (c.tid == 0) f.keep[0] = 0;
+        K = 1;
+    } else if (N > 1 && cfg.nms_mode == 0) {
+        // ---- reference mode: selection sort with the lossy view-"swap" (Appendix A3)
+        for (int i = 0; i < N; ++i) {
+            const int pos = i + 1;
+            double maxscore;
+            int maxpos;
+            if (i != N - 1) {
+                block_argmax_first(c, L.sc, pos, N, L.red_v, L.red_i, maxscore, maxpos);
+            } else {
+                maxscore = L.sc[N - 1];
+                maxpos = 0;
+            }
+            if (i != N - 1 && maxscore == 0.0) break;  // scores are >= 0: nothing can change any more
+            if (c.tid == 0) {
+                double tscore = L.sc[i];
+                if (tscore < maxscore) {
+                    double tarea = L.area[i];
+                    L.c0[i] = L.c0[maxpos];
+                    L.c1[i] = L.c1[maxpos];
+                    L.c2[i] = L.c2[maxpos];
+                    L.c3[i] = L.c3[maxpos];
+                    L.idx[i] = L.idx[maxpos];
+                    L.sc[i] = L.sc[maxpos];
+                    L.sc[maxpos] = tscore;
+                    L.area[i] = L.area[maxpos];
+                    L.area[maxpos] = tarea;
+                }
+            }
+            c.sync();
+            const double i0 = L.c0[i], i1 = L.c1[i], i2 = L.c2[i], i3 = L.c3[i], ia = L.area[i];
+            ADAS_PAR_FOR(c, j, pos, N) {
+                double xx1 = fmax(i1, L.c1[j]);
+                double yy1 = fmax(i0, L.c0[j]);
+                double xx2 = fmin(i3, L.c3[j]);
+                double yy2 = fmin(i2, L.c2[j]);
+                double w = fmax(0.0, xx2 - xx1 + 1);
+                double h = fmax(0.0, yy2 - yy1 + 1);
+                double inter = w * h;
+                double ovr = inter / (ia + L.area[j] - inter);
+                if (ovr > cfg.iou_thr) L.sc[j] = 0.0;  // weight 0 (utils.py:247-251)
+            }
+            c.sync();
+        }
+        c.sync();
+        if (c.tid == 0) {
+            int k = 0;
+            for (int j = 0; j < N; ++j)
+                if (L.sc[j] > 0.001) f.keep[k++] = L.idx[j];
+            L.red_i[0] = k;
+        }
+        c.sync();
+        K = L.red_i[0];
+        c.sync();
+    } else if (N > 1) {
+        // ---- greedy mode (utils.py:105-159): order = argsort(scores)[::-1], ties -> higher index first
+        ADAS_PAR_FOR(c, j, 0, N) {
+            double s = L.sc[j];
+            int rank = 0;
+            for (int k = 0; k < N; ++k) {
+                double t = L.sc[k];
+                rank += (t > s || (t == s && k > j)) ? 1 : 0;
+            }
+            L.order[rank] = j;
+        }
+        c.sync();
+        // sc[] is reused as the alive flag of each *rank position*
+        ADAS_PAR_FOR(c, p, 0, N) L.sc[p] = 1.0;
+        c.sync();
+        for (int p = 0; p < N; ++p) {
+            if (L.sc[p] == 0.0) continue;  // uniform: LDS value, no writes to position p in flight
+            const int i = L.order[p];
+            const double i0 = L.c0[i], i1 = L.c1[i], i2 = L.c2[i], i3 = L.c3[i], ia = L.area[i];
+            ADAS_PAR_FOR(c, q, p + 1, N) {
+                if (L.sc[q] != 0.0) {
+                    int j = L.order[q];
+                    double xx1 = fmax(i0, L.c0[j]);
+                    double yy1 = fmax(i1, L.c1[j]);
+                    double xx2 = fmin(i2, L.c2[j]);
+                    double yy2 = fmin(i3, L.c3[j]);
+                    double w = fmax(0.0, xx2 - xx1);
+                    double h = fmax(0.0, yy2 - yy1);
+                    double inter = w * h;
+                    double ovr = inter / (ia + L.area[j] - inter);
+                    if (!(ovr <= cfg.iou_thr)) L.sc[q] = 0.0;
+                }
+            }
+            c.sync();
+        }
+        if (c.tid == 0) {
+            int k = 0;
+            for (int p = 0; p < N; ++p)
+                if (L.sc[p] != 0.0) f.keep[k++] = L.order[p];
+            L.red_i[0] = k;
+        }
+        c.sync();
+        K = L.red_i[0];
+        c.sync();
+    }
+    if (c.tid == 0) f.counts[2] = K;
+    c.sync();
+
+    // ---- gather survivors: RectInfo(x,y,w,h,conf,label) + tolist() int truncation
+    ADAS_PAR_FOR(c, k, 0, K) {
+        int j = f.keep[k];
+        double x = f.cand_xywh[4 * j + 0], y = f.cand_xywh[4 * j + 1];
+        double w = f.cand_xywh[4 * j + 2], h = f.cand_xywh[4 * j + 3];
+        f.det_xywh[4 * k + 0] = x;
+        f.det_xywh[4 * k + 1] = y;
+        f.det_xywh[4 * k + 2] = w;
+        f.det_xywh[4 * k + 3] = h;
+        f.det_conf[k] = f.cand_conf[j];
+        f.det_cls[k] = f.cand_cls[j];
+        double v[4] = {x, y, x + w, y + h};
+        for (int q = 0; q < 4; ++q) {
+            double t = trunc(v[q]);
+            f.det_xyxy_d[4 * k + q] = t;
+            f.det_xyxy_i[4 * k + q] = (int)t;
+        }
+    }
+}
+
+// ===========================================================================
+// UFLDv2 lane decode  (ultrafastLaneDetectorV2.py:114-181, _softmax :15-19)
+// ===========================================================================
+#define ADAS_UFLD_MAXPTS 128  // >= max(num_cls_row, num_cls_col)
+
+struct UfldCfg {
+    int grid_row, cls_row, grid_col, cls_col, lanes;  // 200,72,100,81,4 for CULane
+    int img_w, img_h;
+    int local_width;           // 1
+    const double* row_anchor;  // [cls_row] device
+    const double* col_anchor;  // [cls_col]
+};
+
+struct UfldFrame {
+    const float *loc_row, *loc_col, *exist_row, *exist_col;
+    int* lane_cnt;  // [4]   order left-side, left-ego, right-ego, right-side == lane index 0,1,2,3
+    int* lane_det;  // [4]
+    int* lane_pts;  // [4][ADAS_UFLD_MAXPTS][2]
+};
+
+struct UfldLds {
+    int* amax;           // [ (cls_row + cls_col) * 4 ]
+    unsigned char* val;  // same count
+    int* cnt;            // [8]: valid counts row lanes 0..3, col lanes 0..3
+    static ADAS_HD size_t bytes(int cr, int cc) { return (size_t)(cr + cc) * 4 * 5 + 64; }
+};
+
+ADAS_DEV double ufld_expect(const float* loc, int stride, int m, int G, int lw) {
+    // 3-tap (2*lw+1) softmax expectation around the argmax, fp32 softmax, fp64 expectation
+    int lo = m - lw < 0 ? 0 : m - lw;
+    int hi = m + lw > G - 1 ? G - 1 : m + lw;
+    float v[8], mx = -FLT_MAX;
+    int n = hi - lo + 1;
+    for (int t = 0; t < n; ++t) {
+        v[t] = loc[(size_t)(lo + t) * stride];
+        mx = v[t] > mx ? v[t] : mx;
+    }
+    float s = 0.f;
+    for (int t = 0; t < n; ++t) {
+        v[t] = (float)exp((double)(v[t] - mx));  // correctly-rounded fp32 exp
+        s = (t == 0) ? v[t] : s + v[t];
+    }
+    double acc = 0.0;
+    for (int t = 0; t < n; ++t) {
+        double p = (double)(v[t] / s) * (double)(lo + t);
+        acc = (t == 0) ? p : acc + p;
+    }
+    return acc + 0.5;
+}
+
+ADAS_DEV void ufld_decode_frame(const Ctx& c, const UfldCfg& cfg, const UfldFrame& f, void* lds_base) {
+    const int R = cfg.cls_row, C = cfg.cls_col, NL = cfg.lanes;
+    const int nr = R * NL, nc = C * NL;
+    UfldLds L;
+    L.amax = (int*)lds_base;
+    L.cnt = L.amax + (nr + nc);
+    L.val = (unsigned char*)(L.cnt + 16);
+    ADAS_PAR_FOR(c, q, 0, 8) L.cnt[q] = 0;
+    c.sync();
+    // argmax over the grid dimension (first max) + existence argmax over 2 (ties -> 0)
+    ADAS_PAR_FOR(c, t, 0, nr + nc) {
+        const bool row = t < nr;
+        const int q = row ? t : t - nr;
+        const int stride = row ? nr : nc;
+        const float* loc = (row ? f.loc_row : f.loc_col) + q;
+        const int G = row ? cfg.grid_row : cfg.grid_col;
+        float best = loc[0];
+        int m = 0;
+        for (int g = 1; g < G; ++g) {
+            float v = loc[(size_t)g * stride];
+            if (v > best) {
+                best = v;
+                m = g;
+            }
+        }
+        const float* ex = (row ? f.exist_row : f.exist_col) + q;
+        L.amax[t] = m;
+        L.val[t] = ex[stride] > ex[0] ? 1 : 0;
+    }
+    c.sync();
+    if (c.tid == 0) {
+        for (int t = 0; t < nr; ++t) L.cnt[t % NL] += L.val[t];
+        for (int t = 0; t < nc; ++t) L.cnt[4 + (t % NL)] += L.val[nr + t];
+    }
+    c.sync();
+    // lanes: row anchors feed lanes {1,2}; column anchors feed lanes {0,3}
+    ADAS_PAR_FOR(c, t, 0, nr + nc) {
+        const bool row = t < nr;
+        const int q = row ? t : t - nr;
+        const int k = q / NL, i = q % NL;
+        const bool lane_ok = row ? (i == 1 || i == 2) : (i == 0 || i == 3);
+        if (!lane_ok || !L.val[t]) continue;
+        const int cnt = L.cnt[(row ? 0 : 4) + i];
+        const bool enough = row ? ((double)cnt > (double)R / 2) : ((double)cnt > (double)C / 4);
+        if (!enough) continue;
+        int slot = 0;  // ordered position among valid anchors of this lane
+        for (int kk = 0; kk < k; ++kk) slot += L.val[(row ? 0 : nr) + kk * NL + i];
+        const int m = L.amax[t];
+        int px, py;
+        if (row) {
+            double o = ufld_expect(f.loc_row + q, nr, m, cfg.grid_row, cfg.local_width);
+            o = o / (double)(cfg.grid_row - 1) * (double)cfg.img_w;
+            px = (int)o;
+            py = (int)(cfg.row_anchor[k] * (double)cfg.img_h);
+        } else {
+            double o = ufld_expect(f.loc_col + q, nc, m, cfg.grid_col, cfg.local_width);
+            o = o / (double)(cfg.grid_col - 1) * (double)cfg.img_h;
+            px = (int)(cfg.col_anchor[k] * (double)cfg.img_w);
+            py = (int)o;
+        }
+        f.lane_pts[(i * ADAS_UFLD_MAXPTS + slot) * 2 + 0] = px;
+        f.lane_pts[(i * ADAS_UFLD_MAXPTS + slot) * 2 + 1] = py;
+    }
+    ADAS_PAR_FOR(c, i, 0, NL) {
+        const bool row = (i == 1 || i == 2);
+        const int cnt = L.cnt[(row ? 0 : 4) + i];
+        const bool enough = row ? ((double)cnt > (double)R / 2) : ((double)cnt > (double)C / 4);
+        const int n = enough ? cnt : 0;
+        f.lane_cnt[i] = n;
+        f.lane_det[i] = n > 2 ? 1 : 0;
+    }
+}
+
+}  // namespace adas

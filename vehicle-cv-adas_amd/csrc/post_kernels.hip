@@ -1,0 +1,580 @@
+// post_kernels.hip -- GPU-resident post-processing kernels + their C-ABI entry points.
+//   yolo_scan_v8 / yolo_scan_v5 : per-anchor class argmax + confidence  (yoloDetector.py:120-127)
+//   yolo_post_kernel            : compaction -> box -> inverse letterbox -> NMS -> RectInfo gather
+//   ufld_decode_kernel          : row/col-anchor lane decode           (ultrafastLaneDetectorV2.py:114-181)
+//   bytetrack_*_kernel          : BYTETracker.update / reset           (byteTracker.py:62-200)
+// Roofline: all HBM-bound by construction (2.82 MB fp32 head per v8 frame, 8.57 MB per v5 frame,
+// 365 KB of lane logits); at these sizes the honest KPI is us per frame.
+#include "common.h"
+#include "post_core.h"
+#include "track_core.h"
+#include <new>
+#include <string.h>
+#include <vector>
+
+using namespace adas;
+
+// -------------------------------------------------------------------------------------
+// scan, v8-family layout [4+nc][A]: wave w of the block owns class group w (ascending class
+// ranges), lanes own 4 consecutive anchors (one 16-byte load per class row -> 1 KiB per wave).
+// -------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void yolo_scan_v8(const float* __restrict__ head, int A, int nc,
+                                                    float* __restrict__ best_conf, int* __restrict__ best_cls) {
+    __shared__ float s_v[4][64][4];
+    __shared__ int s_i[4][64][4];
+    const int frame = blockIdx.y;
+    head += (size_t)frame * (size_t)(4 + nc) * A;
+    best_conf += (size_t)frame * A;
+    best_cls += (size_t)frame * A;
+    const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
+    const int a0 = (blockIdx.x * 64 + lane) * 4;
+    const int cpg = (nc + 3) / 4;
+    const int c_lo = grp * cpg, c_hi = min(nc, c_lo + cpg);
+    float bv[4] = {0.f, 0.f, 0.f, 0.f};
+    int bi[4] = {-1, -1, -1, -1};
+    const bool vec = (A & 3) == 0;
+    if (a0 < A) {
+        for (int c = c_lo; c < c_hi; ++c) {
+            const float* row = head + (size_t)(4 + c) * A + a0;
+            float v[4];
+            if (vec) {
+                float4 q = *reinterpret_cast<const float4*>(row);
+                v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
+            } else {
+#pragma unroll
+                for (int t = 0; t < 4; ++t) v[t] = (a0 + t < A) ? row[t] : 0.f;
+            }
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+                if (bi[t] < 0 || v[t] > bv[t]) {
+                    bv[t] = v[t];
+                    bi[t] = c;
+                }
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        s_v[grp][lane][t] = bv[t];
+        s_i[grp][lane][t] = bi[t];
+    }
+    __syncthreads();
+    if (grp == 0 && a0 < A) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            float v = bv[t];
+            int i = bi[t];
+            for (int g = 1; g < 4; ++g) {
+                int oi = s_i[g][lane][t];
+                float ov = s_v[g][lane][t];
+                if (oi >= 0 && (i < 0 || ov > v)) {  // later groups hold higher class ids: strict > keeps the first max
+                    v = ov;
+                    i = oi;
+                }
+            }
+            if (a0 + t < A) {
+                best_conf[a0 + t] = v;
+                best_cls[a0 + t] = i < 0 ? 0 : i;
+            }
+        }
+    }
+}
+
+// scan, v5-family layout [A][5+nc]: one wave per row, conf = cls * obj rounded in fp32.
+__global__ __launch_bounds__(256) void yolo_scan_v5(const float* __restrict__ head, int A, int nc,
+                                                    float* __restrict__ best_conf, int* __restrict__ best_cls) {
+    const int frame = blockIdx.y;
+    const int no = 5 + nc;
+    head += (size_t)frame * (size_t)A * no;
+    best_conf += (size_t)frame * A;
+    best_cls += (size_t)frame * A;
+    const int lane = threadIdx.x & 63;
+    const int wave = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int nwaves = gridDim.x * 4;
+    for (int a = wave; a < A; a += nwaves) {
+        const float* row = head + (size_t)a * no;
+        const float obj = row[4];
+        float bv = 0.f;
+        int bi = 0x7fffffff;
+        for (int c = lane; c < nc; c += 64) {
+            float p = row[5 + c] * obj;
+            if (bi == 0x7fffffff || p > bv) {
+                bv = p;
+                bi = c;
+            }
+        }
+        for (int off = 32; off > 0; off >>= 1) {
+            float ov = __shfl_down(bv, off, 64);
+            int oi = __shfl_down(bi, off, 64);
+            if (oi != 0x7fffffff && (bi == 0x7fffffff || ov > bv || (ov == bv && oi < bi))) {
+                bv = ov;
+                bi = oi;
+            }
+        }
+        if (lane == 0) {
+            best_conf[a] = bv;
+            best_cls[a] = bi == 0x7fffffff ? 0 : bi;
+        }
+    }
+}
+
+struct YoloPostDev {
+    YoloPostCfg cfg;
+    const float* head;
+    size_t head_stride;
+    float* best_conf;
+    int* best_cls;
+    int* counts;
+    int* cand_anchor;
+    double* cand_xywh;
+    double* cand_conf;
+    int* cand_cls;
+    int* keep;
+    double* det_xywh;
+    double* det_conf;
+    int* det_cls;
+    int* det_xyxy_i;
+    double* det_xyxy_d;
+};
+
+__global__ __launch_bounds__(256) void yolo_post_kernel(YoloPostDev d) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int b = blockIdx.x;
+    const size_t cap = d.cfg.cap;
+    YoloPostFrame f;
+    f.head = d.head + b * d.head_stride;
+    f.best_conf = d.best_conf + (size_t)b * d.cfg.A;
+    f.best_cls = d.best_cls + (size_t)b * d.cfg.A;
+    f.counts = d.counts + b * 4;
+    f.cand_anchor = d.cand_anchor + b * cap;
+    f.cand_xywh = d.cand_xywh + b * cap * 4;
+    f.cand_conf = d.cand_conf + b * cap;
+    f.cand_cls = d.cand_cls + b * cap;
+    f.keep = d.keep + b * cap;
+    f.det_xywh = d.det_xywh + b * cap * 4;
+    f.det_conf = d.det_conf + b * cap;
+    f.det_cls = d.det_cls + b * cap;
+    f.det_xyxy_i = d.det_xyxy_i + b * cap * 4;
+    f.det_xyxy_d = d.det_xyxy_d + b * cap * 4;
+    Ctx c{(int)threadIdx.x, (int)blockDim.x};
+    yolo_post_frame(c, d.cfg, f, smem);
+}
+
+// -------------------------------------------------------------------------------------
+struct UfldDev {
+    UfldCfg cfg;
+    const float *loc_row, *loc_col, *exist_row, *exist_col;
+    size_t s_lr, s_lc, s_er, s_ec;
+    int *lane_cnt, *lane_det, *lane_pts;
+};
+
+__global__ __launch_bounds__(640) void ufld_decode_kernel(UfldDev d) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int b = blockIdx.x;
+    UfldFrame f;
+    f.loc_row = d.loc_row + b * d.s_lr;
+    f.loc_col = d.loc_col + b * d.s_lc;
+    f.exist_row = d.exist_row + b * d.s_er;
+    f.exist_col = d.exist_col + b * d.s_ec;
+    f.lane_cnt = d.lane_cnt + b * 4;
+    f.lane_det = d.lane_det + b * 4;
+    f.lane_pts = d.lane_pts + (size_t)b * 4 * ADAS_UFLD_MAXPTS * 2;
+    Ctx c{(int)threadIdx.x, (int)blockDim.x};
+    ufld_decode_frame(c, d.cfg, f, smem);
+}
+
+// -------------------------------------------------------------------------------------
+struct BtDev {
+    BtParams P;
+    unsigned char* base;  // per-stream regions
+    size_t stream_bytes;
+    const double* xyxy;
+    const double* score;
+    const int* cls;
+    const int* counts;
+    int det_stride, count_stride, count_index, first_stream;
+};
+
+__host__ __device__ inline size_t bt_align(size_t x) { return (x + 63) & ~(size_t)63; }
+__host__ __device__ inline size_t bt_stream_bytes(int MT, int MD) {
+    return bt_align(sizeof(BtHeader)) + bt_align((size_t)MT * sizeof(BtTrack)) + bt_align((size_t)MT * MD * 8) +
+           bt_align((size_t)2 * MT * sizeof(BtOut)) + 2 * bt_align((size_t)MT * 4);
+}
+__host__ __device__ inline BtStream bt_view(unsigned char* p, int MT, int MD) {
+    BtStream S;
+    S.hdr = (BtHeader*)p; p += bt_align(sizeof(BtHeader));
+    S.slots = (BtTrack*)p; p += bt_align((size_t)MT * sizeof(BtTrack));
+    S.cost = (double*)p; p += bt_align((size_t)MT * MD * 8);
+    S.out = (BtOut*)p; p += bt_align((size_t)2 * MT * sizeof(BtOut));
+    S.tracked = (int*)p; p += bt_align((size_t)MT * 4);
+    S.lost = (int*)p;
+    return S;
+}
+
+__global__ __launch_bounds__(256) void bytetrack_update_kernel(BtDev d) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int s = d.first_stream + blockIdx.x;
+    BtStream S = bt_view(d.base + (size_t)s * d.stream_bytes, d.P.MT, d.P.MD);
+    const int q = blockIdx.x;  // detection slab index
+    BtDet det;
+    det.tlbr = d.xyxy + (size_t)q * d.det_stride * 4;
+    det.score = d.score + (size_t)q * d.det_stride;
+    det.cls = d.cls + (size_t)q * d.det_stride;
+    det.nd = d.counts[(size_t)q * d.count_stride + d.count_index];
+    Ctx c{(int)threadIdx.x, (int)blockDim.x};
+    bytetrack_update(c, d.P, S, det, smem);
+}
+
+__global__ __launch_bounds__(256) void bytetrack_reset_kernel(BtDev d) {
+    const int s = d.first_stream + blockIdx.x;
+    BtStream S = bt_view(d.base + (size_t)s * d.stream_bytes, d.P.MT, d.P.MD);
+    Ctx c{(int)threadIdx.x, (int)blockDim.x};
+    bytetrack_reset(c, d.P, S);
+}
+
+// =====================================================================================
+// C ABI
+// =====================================================================================
+struct adas_yolo_post {
+    adas_yolo_post_params p;
+    int max_batch;
+    YoloPostDev dev;
+    void* arena;
+    hipStream_t last;
+};
+struct adas_ufld_decode {
+    adas_ufld_params p;
+    int max_batch;
+    UfldDev dev;
+    void* arena;
+    hipStream_t last;
+};
+struct adas_bytetrack {
+    adas_bytetrack_params p;
+    int n_streams;
+    BtDev dev;
+    void* arena;
+    double* h_stage_d;  // device staging for update_host
+    hipStream_t last;
+};
+
+template <class T>
+static T* carve(unsigned char*& p, size_t n) {
+    T* r = (T*)p;
+    p += (n * sizeof(T) + 255) & ~(size_t)255;
+    return r;
+}
+
+extern "C" {
+
+int adas_letterbox_params(int src_h, int src_w, int dst_h, int dst_w, int keep_ratio, adas_yolo_post_params* p) {
+    ADAS_REQUIRE(p && src_h > 0 && src_w > 0 && dst_h > 0 && dst_w > 0, ADAS_ERR_INVALID, "adas_letterbox_params: bad argument");
+    int padh = 0, padw = 0, newh = dst_h, neww = dst_w;  // utils.py:43-52
+    if (keep_ratio && src_h != src_w) {
+        double hw = (double)src_h / (double)src_w;
+        if (hw > 1) {
+            neww = (int)((double)dst_w / hw);
+            padw = (int)((double)(dst_w - neww) * 0.5);
+        } else {
+            newh = (int)((double)dst_h * hw) + 1;
+            padh = (int)((double)(dst_h - newh) * 0.5);
+        }
+    }
+    p->pad_h = padh;
+    p->pad_w = padw;
+    p->ratio_h = (double)src_h / (double)newh;  // utils.py:65-68
+    p->ratio_w = (double)src_w / (double)neww;
+    return ADAS_OK;
+}
+
+int adas_yolo_post_create(const adas_yolo_post_params* p, int max_batch, adas_yolo_post** out) {
+    ADAS_REQUIRE(p && out && max_batch > 0, ADAS_ERR_INVALID, "adas_yolo_post_create: bad argument");
+    ADAS_REQUIRE(p->layout == ADAS_HEAD_V8 || p->layout == ADAS_HEAD_V5, ADAS_ERR_INVALID, "unknown head layout %d", p->layout);
+    ADAS_REQUIRE(p->nms_mode == ADAS_NMS_REFERENCE || p->nms_mode == ADAS_NMS_GREEDY, ADAS_ERR_INVALID, "unknown nms mode %d", p->nms_mode);
+    ADAS_REQUIRE(p->num_anchors > 0 && p->num_classes > 0, ADAS_ERR_INVALID, "bad head geometry");
+    ADAS_REQUIRE(p->box_score >= 0.0, ADAS_ERR_INVALID, "box_score must be >= 0");
+    ADAS_REQUIRE(p->max_candidates >= 16 && p->max_candidates <= 2048, ADAS_ERR_INVALID, "max_candidates must be in [16, 2048]");
+    ADAS_REQUIRE(adas_device_count() > 0, ADAS_ERR_NO_DEVICE, "no HIP device visible; this library has no CPU fallback");
+    adas_yolo_post* h = new (std::nothrow) adas_yolo_post();
+    ADAS_REQUIRE(h, ADAS_ERR_INVALID, "out of host memory");
+    h->p = *p;
+    h->max_batch = max_batch;
+    h->last = 0;
+    const size_t B = max_batch, A = p->num_anchors, cap = p->max_candidates;
+    size_t bytes = B * (A * 8 + 16 + cap * (4 + 32 + 8 + 4 + 4 + 32 + 8 + 4 + 16 + 32)) + 16 * 256;
+    if (hipMalloc(&h->arena, bytes) != hipSuccess) {
+        delete h;
+        return hip_fail(hipGetLastError(), "hipMalloc(yolo_post arena)", __FILE__, __LINE__);
+    }
+    hipMemset(h->arena, 0, bytes);
+    unsigned char* q = (unsigned char*)h->arena;
+    YoloPostDev& d = h->dev;
+    d.cfg = YoloPostCfg{p->layout, p->num_anchors, p->num_classes, p->box_score, p->iou_thr, p->nms_mode,
+                        p->pad_h, p->pad_w, p->ratio_h, p->ratio_w, p->max_candidates};
+    d.head = nullptr;
+    d.head_stride = p->layout == ADAS_HEAD_V8 ? (size_t)(4 + p->num_classes) * A : (size_t)(5 + p->num_classes) * A;
+    d.best_conf = carve<float>(q, B * A);
+    d.best_cls = carve<int>(q, B * A);
+    d.counts = carve<int>(q, B * 4);
+    d.cand_anchor = carve<int>(q, B * cap);
+    d.cand_xywh = carve<double>(q, B * cap * 4);
+    d.cand_conf = carve<double>(q, B * cap);
+    d.cand_cls = carve<int>(q, B * cap);
+    d.keep = carve<int>(q, B * cap);
+    d.det_xywh = carve<double>(q, B * cap * 4);
+    d.det_conf = carve<double>(q, B * cap);
+    d.det_cls = carve<int>(q, B * cap);
+    d.det_xyxy_i = carve<int>(q, B * cap * 4);
+    d.det_xyxy_d = carve<double>(q, B * cap * 4);
+    size_t lds = YoloLds::bytes(p->max_candidates, 256);
+    if (hipFuncSetAttribute((const void*)yolo_post_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+        hipFree(h->arena);
+        delete h;
+        return hip_fail(hipGetLastError(), "hipFuncSetAttribute(yolo_post_kernel)", __FILE__, __LINE__);
+    }
+    *out = h;
+    return ADAS_OK;
+}
+
+int adas_yolo_post_destroy(adas_yolo_post* h) {
+    if (!h) return ADAS_OK;
+    hipFree(h->arena);
+    delete h;
+    return ADAS_OK;
+}
+
+int adas_yolo_post_run(adas_yolo_post* h, const float* d_head, int batch, void* stream) {
+    ADAS_REQUIRE(h && d_head && batch > 0 && batch <= h->max_batch, ADAS_ERR_INVALID, "adas_yolo_post_run: bad argument (batch %d, max %d)", batch, h ? h->max_batch : 0);
+    hipStream_t st = (hipStream_t)stream;
+    h->last = st;
+    YoloPostDev d = h->dev;
+    d.head = d_head;
+    const int A = h->p.num_anchors, nc = h->p.num_classes;
+    if (h->p.layout == ADAS_HEAD_V8) {
+        dim3 grid(((A + 3) / 4 + 63) / 64, batch);
+        hipLaunchKernelGGL(yolo_scan_v8, grid, dim3(256), 0, st, d_head, A, nc, d.best_conf, d.best_cls);
+    } else {
+        dim3 grid(512, batch);
+        hipLaunchKernelGGL(yolo_scan_v5, grid, dim3(256), 0, st, d_head, A, nc, d.best_conf, d.best_cls);
+    }
+    size_t lds = YoloLds::bytes(h->p.max_candidates, 256);
+    hipLaunchKernelGGL(yolo_post_kernel, dim3(batch), dim3(256), lds, st, d);
+    ADAS_HIP_TRY(hipGetLastError());
+    return ADAS_OK;
+}
+
+int adas_yolo_post_fetch(adas_yolo_post* h, int frame, adas_yolo_counts* counts, int32_t* cand_anchor, double* cand_xywh,
+                         double* cand_conf, int32_t* cand_cls, int32_t* keep, double* det_xywh, double* det_conf,
+                         int32_t* det_cls, int32_t* det_xyxy_int) {
+    ADAS_REQUIRE(h && frame >= 0 && frame < h->max_batch, ADAS_ERR_INVALID, "adas_yolo_post_fetch: bad frame index");
+    ADAS_HIP_TRY(hipStreamSynchronize(h->last));
+    const YoloPostDev& d = h->dev;
+    const size_t cap = h->p.max_candidates, b = frame;
+    int c4[4];
+    ADAS_HIP_TRY(hipMemcpy(c4, d.counts + b * 4, 16, hipMemcpyDeviceToHost));
+    if (counts) {
+        counts->n_found = c4[0];
+        counts->n_candidates = c4[1];
+        counts->n_keep = c4[2];
+        counts->flags = c4[3];
+    }
+    const size_t n = c4[1], k = c4[2];
+#define CP(dst, src, cnt, T) \
+    if (dst && (cnt)) ADAS_HIP_TRY(hipMemcpy(dst, src, (cnt) * sizeof(T), hipMemcpyDeviceToHost))
+    CP(cand_anchor, d.cand_anchor + b * cap, n, int);
+    CP(cand_xywh, d.cand_xywh + b * cap * 4, n * 4, double);
+    CP(cand_conf, d.cand_conf + b * cap, n, double);
+    CP(cand_cls, d.cand_cls + b * cap, n, int);
+    CP(keep, d.keep + b * cap, k, int);
+    CP(det_xywh, d.det_xywh + b * cap * 4, k * 4, double);
+    CP(det_conf, d.det_conf + b * cap, k, double);
+    CP(det_cls, d.det_cls + b * cap, k, int);
+    CP(det_xyxy_int, d.det_xyxy_i + b * cap * 4, k * 4, int);
+#undef CP
+    if (c4[3] & 1) {
+        set_error("yolo_post: %d anchors over threshold exceed max_candidates=%d (frame %d)", c4[0], (int)cap, frame);
+        return ADAS_ERR_CAPACITY;
+    }
+    return ADAS_OK;
+}
+
+int adas_yolo_post_device_views(adas_yolo_post* h, const double** d_xyxy, const double** d_score, const int32_t** d_cls,
+                                const int32_t** d_counts) {
+    ADAS_REQUIRE(h, ADAS_ERR_INVALID, "null handle");
+    if (d_xyxy) *d_xyxy = h->dev.det_xyxy_d;
+    if (d_score) *d_score = h->dev.det_conf;
+    if (d_cls) *d_cls = h->dev.det_cls;
+    if (d_counts) *d_counts = h->dev.counts;
+    return ADAS_OK;
+}
+
+// ------------------------------------------------------------------------------- UFLD
+int adas_ufld_decode_create(const adas_ufld_params* p, int max_batch, adas_ufld_decode** out) {
+    ADAS_REQUIRE(p && out && max_batch > 0 && p->h_row_anchor && p->h_col_anchor, ADAS_ERR_INVALID, "adas_ufld_decode_create: bad argument");
+    ADAS_REQUIRE(p->cls_row > 0 && p->cls_col > 0 && p->cls_row <= ADAS_UFLD_MAXPTS && p->cls_col <= ADAS_UFLD_MAXPTS,
+                 ADAS_ERR_INVALID, "anchor counts must be in [1, %d]", ADAS_UFLD_MAXPTS);
+    ADAS_REQUIRE(p->grid_row > 1 && p->grid_col > 1 && p->local_width >= 0 && p->local_width <= 3, ADAS_ERR_INVALID, "bad grid / local_width");
+    ADAS_REQUIRE(adas_device_count() > 0, ADAS_ERR_NO_DEVICE, "no HIP device visible; this library has no CPU fallback");
+    adas_ufld_decode* h = new (std::nothrow) adas_ufld_decode();
+    ADAS_REQUIRE(h, ADAS_ERR_INVALID, "out of host memory");
+    h->p = *p;
+    h->max_batch = max_batch;
+    h->last = 0;
+    const size_t B = max_batch;
+    size_t bytes = (size_t)(p->cls_row + p->cls_col) * 8 + B * (32 + 4 * ADAS_UFLD_MAXPTS * 2 * 4) + 8 * 256;
+    if (hipMalloc(&h->arena, bytes) != hipSuccess) {
+        delete h;
+        return hip_fail(hipGetLastError(), "hipMalloc(ufld arena)", __FILE__, __LINE__);
+    }
+    hipMemset(h->arena, 0, bytes);
+    unsigned char* q = (unsigned char*)h->arena;
+    double* ra = carve<double>(q, p->cls_row);
+    double* ca = carve<double>(q, p->cls_col);
+    hipMemcpy(ra, p->h_row_anchor, p->cls_row * 8, hipMemcpyHostToDevice);
+    hipMemcpy(ca, p->h_col_anchor, p->cls_col * 8, hipMemcpyHostToDevice);
+    UfldDev& d = h->dev;
+    d.cfg = UfldCfg{p->grid_row, p->cls_row, p->grid_col, p->cls_col, 4, p->img_w, p->img_h, p->local_width, ra, ca};
+    d.lane_cnt = carve<int>(q, B * 4);
+    d.lane_det = carve<int>(q, B * 4);
+    d.lane_pts = carve<int>(q, B * 4 * ADAS_UFLD_MAXPTS * 2);
+    h->p.h_row_anchor = nullptr;
+    h->p.h_col_anchor = nullptr;
+    *out = h;
+    return ADAS_OK;
+}
+int adas_ufld_decode_destroy(adas_ufld_decode* h) {
+    if (!h) return ADAS_OK;
+    hipFree(h->arena);
+    delete h;
+    return ADAS_OK;
+}
+int adas_ufld_decode_run(adas_ufld_decode* h, const float* lr, const float* lc, const float* er, const float* ec,
+                         size_t s_lr, size_t s_lc, size_t s_er, size_t s_ec, int batch, void* stream) {
+    ADAS_REQUIRE(h && lr && lc && er && ec && batch > 0 && batch <= h->max_batch, ADAS_ERR_INVALID, "adas_ufld_decode_run: bad argument");
+    hipStream_t st = (hipStream_t)stream;
+    h->last = st;
+    UfldDev d = h->dev;
+    d.loc_row = lr; d.loc_col = lc; d.exist_row = er; d.exist_col = ec;
+    d.s_lr = s_lr; d.s_lc = s_lc; d.s_er = s_er; d.s_ec = s_ec;
+    size_t lds = UfldLds::bytes(h->p.cls_row, h->p.cls_col);
+    hipLaunchKernelGGL(ufld_decode_kernel, dim3(batch), dim3(640), lds, st, d);
+    ADAS_HIP_TRY(hipGetLastError());
+    return ADAS_OK;
+}
+int adas_ufld_decode_fetch(adas_ufld_decode* h, int frame, int32_t* points, int32_t* counts, int32_t* detected) {
+    ADAS_REQUIRE(h && frame >= 0 && frame < h->max_batch, ADAS_ERR_INVALID, "adas_ufld_decode_fetch: bad frame index");
+    ADAS_HIP_TRY(hipStreamSynchronize(h->last));
+    const UfldDev& d = h->dev;
+    if (points) ADAS_HIP_TRY(hipMemcpy(points, d.lane_pts + (size_t)frame * 4 * ADAS_UFLD_MAXPTS * 2, 4 * ADAS_UFLD_MAXPTS * 2 * 4, hipMemcpyDeviceToHost));
+    if (counts) ADAS_HIP_TRY(hipMemcpy(counts, d.lane_cnt + frame * 4, 16, hipMemcpyDeviceToHost));
+    if (detected) ADAS_HIP_TRY(hipMemcpy(detected, d.lane_det + frame * 4, 16, hipMemcpyDeviceToHost));
+    return ADAS_OK;
+}
+
+// ------------------------------------------------------------------------------- ByteTrack
+int adas_bytetrack_create(const adas_bytetrack_params* p, int n_streams, adas_bytetrack** out) {
+    ADAS_REQUIRE(p && out && n_streams > 0, ADAS_ERR_INVALID, "adas_bytetrack_create: bad argument");
+    ADAS_REQUIRE(p->max_tracks >= 8 && p->max_tracks <= 1024 && p->max_dets >= 8 && p->max_dets <= 2048, ADAS_ERR_INVALID,
+                 "max_tracks must be in [8,1024], max_dets in [8,2048]");
+    ADAS_REQUIRE(adas_device_count() > 0, ADAS_ERR_NO_DEVICE, "no HIP device visible; this library has no CPU fallback");
+    static_assert(sizeof(adas_track) == sizeof(BtOut), "adas_track layout");
+    static_assert(sizeof(adas_track_header) == sizeof(BtHeader), "adas_track_header layout");
+    adas_bytetrack* h = new (std::nothrow) adas_bytetrack();
+    ADAS_REQUIRE(h, ADAS_ERR_INVALID, "out of host memory");
+    h->p = *p;
+    h->n_streams = n_streams;
+    h->last = 0;
+    BtDev& d = h->dev;
+    d.P = BtParams{p->track_thresh, p->track_thresh + 0.1, p->match_thresh,
+                   (int)(p->frame_rate / 30.0 * p->track_buffer), p->max_tracks, p->max_dets};  // byteTracker.py:48-50
+    d.stream_bytes = bt_stream_bytes(p->max_tracks, p->max_dets);
+    size_t stage = (size_t)p->max_dets * (32 + 8 + 4) + 256 * 4;
+    size_t bytes = d.stream_bytes * n_streams + stage;
+    if (hipMalloc(&h->arena, bytes) != hipSuccess) {
+        delete h;
+        return hip_fail(hipGetLastError(), "hipMalloc(bytetrack arena)", __FILE__, __LINE__);
+    }
+    hipMemset(h->arena, 0, bytes);
+    d.base = (unsigned char*)h->arena;
+    h->h_stage_d = (double*)(d.base + d.stream_bytes * n_streams);
+    size_t lds = BtLds::bytes(p->max_tracks, p->max_dets, 256);
+    if (hipFuncSetAttribute((const void*)bytetrack_update_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+        hipFree(h->arena);
+        delete h;
+        return hip_fail(hipGetLastError(), "hipFuncSetAttribute(bytetrack_update_kernel)", __FILE__, __LINE__);
+    }
+    *out = h;
+    return ADAS_OK;
+}
+int adas_bytetrack_destroy(adas_bytetrack* h) {
+    if (!h) return ADAS_OK;
+    hipFree(h->arena);
+    delete h;
+    return ADAS_OK;
+}
+int adas_bytetrack_reset(adas_bytetrack* h, int stream_index) {
+    ADAS_REQUIRE(h && stream_index >= -1 && stream_index < h->n_streams, ADAS_ERR_INVALID, "adas_bytetrack_reset: bad stream index");
+    BtDev d = h->dev;
+    d.first_stream = stream_index < 0 ? 0 : stream_index;
+    int n = stream_index < 0 ? h->n_streams : 1;
+    hipLaunchKernelGGL(bytetrack_reset_kernel, dim3(n), dim3(256), 0, h->last, d);
+    ADAS_HIP_TRY(hipGetLastError());
+    return ADAS_OK;
+}
+int adas_bytetrack_update_host(adas_bytetrack* h, int stream_index, const double* xyxy, const double* scores,
+                               const int32_t* cls, int n) {
+    ADAS_REQUIRE(h && stream_index >= 0 && stream_index < h->n_streams && n >= 0, ADAS_ERR_INVALID, "adas_bytetrack_update_host: bad argument");
+    ADAS_REQUIRE(n == 0 || (xyxy && scores && cls), ADAS_ERR_INVALID, "null detection arrays");
+    ADAS_REQUIRE(n <= h->p.max_dets, ADAS_ERR_CAPACITY, "%d detections exceed max_dets=%d", n, h->p.max_dets);
+    const int MD = h->p.max_dets;
+    double* dx = h->h_stage_d;
+    double* ds = dx + (size_t)MD * 4;
+    int* dc = (int*)(ds + MD);
+    int* dn = dc + MD;
+    hipStream_t st = h->last;
+    if (n) {
+        ADAS_HIP_TRY(hipMemcpyAsync(dx, xyxy, (size_t)n * 32, hipMemcpyHostToDevice, st));
+        ADAS_HIP_TRY(hipMemcpyAsync(ds, scores, (size_t)n * 8, hipMemcpyHostToDevice, st));
+        ADAS_HIP_TRY(hipMemcpyAsync(dc, cls, (size_t)n * 4, hipMemcpyHostToDevice, st));
+    }
+    ADAS_HIP_TRY(hipMemcpyAsync(dn, &n, 4, hipMemcpyHostToDevice, st));
+    ADAS_HIP_TRY(hipStreamSynchronize(st));  // n lives on the caller's stack
+    BtDev d = h->dev;
+    d.xyxy = dx; d.score = ds; d.cls = dc; d.counts = dn;
+    d.det_stride = MD; d.count_stride = 1; d.count_index = 0; d.first_stream = stream_index;
+    size_t lds = BtLds::bytes(h->p.max_tracks, h->p.max_dets, 256);
+    hipLaunchKernelGGL(bytetrack_update_kernel, dim3(1), dim3(256), lds, st, d);
+    ADAS_HIP_TRY(hipGetLastError());
+    return ADAS_OK;
+}
+int adas_bytetrack_update_device(adas_bytetrack* h, const double* d_xyxy, const double* d_scores, const int32_t* d_cls,
+                                 const int32_t* d_counts, int det_stride, int count_stride, int count_index, int n_streams,
+                                 void* stream) {
+    ADAS_REQUIRE(h && d_xyxy && d_scores && d_cls && d_counts && n_streams > 0 && n_streams <= h->n_streams, ADAS_ERR_INVALID,
+                 "adas_bytetrack_update_device: bad argument");
+    hipStream_t st = (hipStream_t)stream;
+    h->last = st;
+    BtDev d = h->dev;
+    d.xyxy = d_xyxy; d.score = d_scores; d.cls = d_cls; d.counts = d_counts;
+    d.det_stride = det_stride; d.count_stride = count_stride; d.count_index = count_index; d.first_stream = 0;
+    size_t lds = BtLds::bytes(h->p.max_tracks, h->p.max_dets, 256);
+    hipLaunchKernelGGL(bytetrack_update_kernel, dim3(n_streams), dim3(256), lds, st, d);
+    ADAS_HIP_TRY(hipGetLastError());
+    return ADAS_OK;
+}
+int adas_bytetrack_fetch(adas_bytetrack* h, int stream_index, adas_track_header* hdr, adas_track* tracks, int max_tracks) {
+    ADAS_REQUIRE(h && hdr && stream_index >= 0 && stream_index < h->n_streams, ADAS_ERR_INVALID, "adas_bytetrack_fetch: bad argument");
+    ADAS_HIP_TRY(hipStreamSynchronize(h->last));
+    BtStream S = bt_view(h->dev.base + (size_t)stream_index * h->dev.stream_bytes, h->p.max_tracks, h->p.max_dets);
+    ADAS_HIP_TRY(hipMemcpy(hdr, S.hdr, sizeof(BtHeader), hipMemcpyDeviceToHost));
+    int n = hdr->n_tracked + hdr->n_lost;
+    if (tracks && n > 0) {
+        ADAS_REQUIRE(n <= max_tracks, ADAS_ERR_CAPACITY, "fetch buffer holds %d tracks, need %d", max_tracks, n);
+        ADAS_HIP_TRY(hipMemcpy(tracks, S.out, (size_t)n * sizeof(BtOut), hipMemcpyDeviceToHost));
+    }
+    if (hdr->err & (BT_ERR_DET_OVERFLOW | BT_ERR_TRACK_OVERFLOW | BT_ERR_HIST_OVERFLOW)) {
+        set_error("bytetrack stream %d: capacity exceeded (err bits 0x%x)", stream_index, hdr->err);
+        return ADAS_ERR_CAPACITY;
+    }
+    return ADAS_OK;
+}
+}  // extern "C"

@@ -1,0 +1,682 @@
+// track_core.h -- device-resident ByteTrack: one workgroup per video stream.
+//
+// Follows ObjectTracker/byteTrack/byteTracker.py:62-185 step by step on a
+// fixed-capacity track table kept in HBM (no host round trip per frame):
+//   matching.py:34-80,108-116  IoU cost (+ score fusion), fp64, no "+1"
+//   matching.py:20-31          lap.lapjv(extend_cost=True, cost_limit=t): exact
+//                              LAP; solved here by successive shortest augmenting
+//                              paths on rows x (cols + one always-free sink of
+//                              cost t), which is the extended (T+D)^2 problem
+//                              with its identical dummy rows/cols merged.
+//   kalman_filter.py:55-86,155-192,126-153,194-226   initiate / multi_predict / project / update
+//   strack.py:61-129           multi_predict, activate, re_activate, update, class vote
+//   byteTrack/utils.py:9-69    joint / sub / remove_duplicate_stracks
+// Not carried: image crops (strack.py:131-143, needs the host frame) and the
+// 30-deep trajectory list (drawing only); neither influences ids.
+#pragma once
+#include "post_core.h"
+
+namespace adas {
+
+enum { BT_NEW = 0, BT_TRACKED = 1, BT_LOST = 2, BT_REMOVED = 3 };
+#define ADAS_BT_HIST 8
+enum { BT_ERR_DET_OVERFLOW = 1, BT_ERR_TRACK_OVERFLOW = 2, BT_ERR_HIST_OVERFLOW = 4, BT_ERR_NAN_COST = 8 };
+
+struct BtTrack {
+    double mean[8];
+    double cov[64];
+    double score;
+    int track_id, state, is_activated, frame_id, start_frame, tracklet_len, class_id;
+    int ever_removed;  // id is a member of the reference's removed_stracks list
+    int used, tmp;
+    int hist_n;
+    int hist_cls[ADAS_BT_HIST];
+    int hist_cnt[ADAS_BT_HIST];
+};
+
+struct BtOut {  // compact per-track message (base_track.py:61-72 + strack.py:207-215)
+    double tlwh[4];
+    double score;
+    int track_id, state, is_activated, class_id, frame_id, start_frame, tracklet_len, pad;
+};
+
+struct BtHeader {
+    int frame_id, id_count, n_tracked, n_lost, err, pad[3];
+};
+
+struct BtParams {
+    double track_thresh, det_thresh, match_thresh;
+    int max_time_lost;
+    int MT, MD;  // capacities: tracks per stream, detections per frame
+};
+
+// per-stream views into one HBM allocation
+struct BtStream {
+    BtHeader* hdr;
+    int* tracked;  // [MT] slot ids, list order == reference list order
+    int* lost;     // [MT]
+    BtTrack* slots;  // [MT]
+    double* cost;    // [MT*MD] workspace
+    BtOut* out;      // [2*MT]: tracked then lost
+};
+
+struct BtDet {
+    const double* tlbr;  // [nd][4] xyxy
+    const double* score;
+    const int* cls;
+    int nd;
+};
+
+// ---------------------------------------------------------------- geometry
+ADAS_DEV void bt_track_tlbr(const BtTrack& t, double o[4]) {  // strack.py:151-173
+    double w = t.mean[2] * t.mean[3];
+    double h = t.mean[3];
+    double x1 = t.mean[0] - w / 2, y1 = t.mean[1] - h / 2;
+    o[0] = x1; o[1] = y1; o[2] = w + x1; o[3] = h + y1;
+}
+ADAS_DEV void bt_track_tlwh(const BtTrack& t, double o[4]) {
+    double w = t.mean[2] * t.mean[3];
+    double h = t.mean[3];
+    o[0] = t.mean[0] - w / 2; o[1] = t.mean[1] - h / 2; o[2] = w; o[3] = h;
+}
+ADAS_DEV void bt_det_tlbr(const double* in, double o[4]) {  // tlbr_to_tlwh then tlwh -> tlbr
+    double w = in[2] - in[0], h = in[3] - in[1];
+    o[0] = in[0]; o[1] = in[1]; o[2] = w + in[0]; o[3] = h + in[1];
+}
+ADAS_DEV double bt_iou(const double a[4], const double b[4]) {  // matching.py:34-53
+    double xx1 = fmax(a[0], b[0]), yy1 = fmax(a[1], b[1]);
+    double xx2 = fmin(a[2], b[2]), yy2 = fmin(a[3], b[3]);
+    double w = fmax(0.0, xx2 - xx1), h = fmax(0.0, yy2 - yy1);
+    double wh = w * h;
+    return wh / ((a[2] - a[0]) * (a[3] - a[1]) + (b[2] - b[0]) * (b[3] - b[1]) - wh);
+}
+
+// ---------------------------------------------------------------- Kalman
+#define BT_WPOS (1.0 / 20)
+#define BT_WVEL (1.0 / 160)
+
+ADAS_DEV void bt_kf_initiate(BtTrack& t, const double tlwh[4]) {  // kalman_filter.py:55-86
+    double h = tlwh[3];
+    t.mean[0] = tlwh[0] + tlwh[2] / 2;
+    t.mean[1] = tlwh[1] + tlwh[3] / 2;
+    t.mean[2] = tlwh[2] / tlwh[3];
+    t.mean[3] = h;
+    for (int i = 4; i < 8; ++i) t.mean[i] = 0.0;
+    double sp = 2 * BT_WPOS * h, sv = 10 * BT_WVEL * h;
+    double std[8] = {sp, sp, 1e-2, sp, sv, sv, 1e-5, sv};
+    for (int i = 0; i < 64; ++i) t.cov[i] = 0.0;
+    for (int i = 0; i < 8; ++i) t.cov[i * 9] = std[i] * std[i];
+}
+
+ADAS_DEV void bt_kf_predict(BtTrack& t) {  // strack.py:61-72 + kalman_filter.py:155-192
+    if (t.state != BT_TRACKED) t.mean[7] = 0.0;
+    double h = t.mean[3];
+    double sp = BT_WPOS * h, sv = BT_WVEL * h;
+    double q[8] = {sp * sp, sp * sp, 1e-2 * 1e-2, sp * sp, sv * sv, sv * sv, 1e-5 * 1e-5, sv * sv};
+    for (int i = 0; i < 4; ++i) t.mean[i] = t.mean[i] + t.mean[i + 4];
+    double fp[64];  // F P
+    for (int i = 0; i < 8; ++i)
+        for (int j = 0; j < 8; ++j) fp[i * 8 + j] = (i < 4) ? t.cov[i * 8 + j] + t.cov[(i + 4) * 8 + j] : t.cov[i * 8 + j];
+    for (int i = 0; i < 8; ++i)
+        for (int j = 0; j < 8; ++j) {
+            double v = (j < 4) ? fp[i * 8 + j] + fp[i * 8 + j + 4] : fp[i * 8 + j];
+            t.cov[i * 8 + j] = (i == j) ? v + q[i] : v;
+        }
+}
+
+ADAS_DEV void bt_kf_update(BtTrack& t, const double z[4]) {  // kalman_filter.py:126-153,194-226
+    double h = t.mean[3];
+    double sp = BT_WPOS * h;
+    double r[4] = {sp * sp, sp * sp, 1e-1 * 1e-1, sp * sp};
+    double S[16], Lc[16];
+    for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < 4; ++j) S[i * 4 + j] = t.cov[i * 8 + j] + ((i == j) ? r[i] : 0.0);
+    for (int i = 0; i < 16; ++i) Lc[i] = 0.0;
+    for (int j = 0; j < 4; ++j) {  // Cholesky, lower
+        double d = S[j * 4 + j];
+        for (int k = 0; k < j; ++k) d -= Lc[j * 4 + k] * Lc[j * 4 + k];
+        d = sqrt(d);
+        Lc[j * 4 + j] = d;
+        for (int i = j + 1; i < 4; ++i) {
+            double s = S[i * 4 + j];
+            for (int k = 0; k < j; ++k) s -= Lc[i * 4 + k] * Lc[j * 4 + k];
+            Lc[i * 4 + j] = s / d;
+        }
+    }
+    double K[32];  // K[c][r], 8x4 : solve S X = (P H^T)^T, K = X^T
+    for (int c = 0; c < 8; ++c) {
+        double y[4], x[4];
+        for (int i = 0; i < 4; ++i) {
+            double s = t.cov[c * 8 + i];
+            for (int k = 0; k < i; ++k) s -= Lc[i * 4 + k] * y[k];
+            y[i] = s / Lc[i * 4 + i];
+        }
+        for (int i = 3; i >= 0; --i) {
+            double s = y[i];
+            for (int k = i + 1; k < 4; ++k) s -= Lc[k * 4 + i] * x[k];
+            x[i] = s / Lc[i * 4 + i];
+        }
+        for (int i = 0; i < 4; ++i) K[c * 4 + i] = x[i];
+    }
+    double innov[4];
+    for (int i = 0; i < 4; ++i) innov[i] = z[i] - t.mean[i];
+    for (int c = 0; c < 8; ++c) {
+        double s = 0.0;
+        for (int i = 0; i < 4; ++i) s += innov[i] * K[c * 4 + i];
+        t.mean[c] = t.mean[c] + s;
+    }
+    double SK[32];  // S K^T : 4x8
+    for (int i = 0; i < 4; ++i)
+        for (int c = 0; c < 8; ++c) {
+            double s = 0.0;
+            for (int k = 0; k < 4; ++k) s += S[i * 4 + k] * K[c * 4 + k];
+            SK[i * 8 + c] = s;
+        }
+    for (int a = 0; a < 8; ++a)
+        for (int b = 0; b < 8; ++b) {
+            double s = 0.0;
+            for (int k = 0; k < 4; ++k) s += K[a * 4 + k] * SK[k * 8 + b];
+            t.cov[a * 8 + b] = t.cov[a * 8 + b] - s;
+        }
+}
+
+ADAS_DEV void bt_class_vote(BtTrack& t, int cls, int* err) {  // strack.py:122-129
+    int k = -1;
+    for (int i = 0; i < t.hist_n; ++i)
+        if (t.hist_cls[i] == cls) k = i;
+    if (k < 0) {
+        if (t.hist_n < ADAS_BT_HIST) {
+            k = t.hist_n++;
+            t.hist_cls[k] = cls;
+            t.hist_cnt[k] = 1;  // history.get(c, 1)
+        } else {
+            *err |= BT_ERR_HIST_OVERFLOW;
+            return;
+        }
+    }
+    t.hist_cnt[k] += 1;
+    int best = 0;
+    for (int i = 1; i < t.hist_n; ++i)
+        if (t.hist_cnt[i] > t.hist_cnt[best]) best = i;  // first max in insertion order
+    t.class_id = t.hist_cls[best];
+}
+
+// strack.py:88-120: update() when the track is Tracked, re_activate(new_id=False) otherwise
+ADAS_DEV void bt_apply_match(BtTrack& t, const double* det_in, double score, int cls, int fid, bool reactivate, int* err) {
+    double w = det_in[2] - det_in[0], h = det_in[3] - det_in[1];
+    double z[4] = {det_in[0] + w / 2, det_in[1] + h / 2, w / h, h};
+    bt_kf_update(t, z);
+    t.tracklet_len = reactivate ? 0 : t.tracklet_len + 1;
+    t.state = BT_TRACKED;
+    t.is_activated = 1;
+    t.frame_id = fid;
+    t.score = score;
+    bt_class_vote(t, cls, err);
+}
+
+// ---------------------------------------------------------------- LAP
+struct LapLds {
+    double *u, *v, *minv, *red_v;
+    int *way, *p, *red_i;
+    unsigned char* used;
+};
+
+// argmin over j in [0,n) with !used[j]; ties -> lowest j
+ADAS_DEV void block_argmin_unused(const Ctx& c, const double* a, const unsigned char* used, int n, double* red_v,
+                                  int* red_i, double& out_v, int& out_i) {
+    double bv = DBL_MAX;
+    int bi = 0x7fffffff;
+    for (int j = c.tid; j < n; j += c.nthr) {
+        if (used[j]) continue;
+        double v = a[j];
+        if (v < bv || bi == 0x7fffffff) {
+            bv = v;
+            bi = j;
+        }
+    }
+#if defined(__HIP_DEVICE_COMPILE__)
+    for (int off = 32; off > 0; off >>= 1) {
+        double ov = __shfl_down(bv, off, 64);
+        int oi = __shfl_down(bi, off, 64);
+        if (oi != 0x7fffffff && (bi == 0x7fffffff || ov < bv || (ov == bv && oi < bi))) {
+            bv = ov;
+            bi = oi;
+        }
+    }
+    int lane = c.tid & 63, wv = c.tid >> 6, nw = (c.nthr + 63) >> 6;
+    if (lane == 0) {
+        red_v[wv] = bv;
+        red_i[wv] = bi;
+    }
+    c.sync();
+    if (c.tid == 0) {
+        for (int w = 1; w < nw; ++w) {
+            double ov = red_v[w];
+            int oi = red_i[w];
+            if (oi != 0x7fffffff && (bi == 0x7fffffff || ov < bv || (ov == bv && oi < bi))) {
+                bv = ov;
+                bi = oi;
+            }
+        }
+        red_v[0] = bv;
+        red_i[0] = bi;
+    }
+    c.sync();
+    out_v = red_v[0];
+    out_i = red_i[0];
+    c.sync();
+#else
+    (void)red_v;
+    (void)red_i;
+    out_v = bv;
+    out_i = bi;
+#endif
+}
+
+// rows [0,T) x cols [0,D); cost row-major with leading dimension D.  x_row[i] = col or -1, y_col[j] = row or -1.
+ADAS_DEV void bt_lap(const Ctx& c, const double* cost, int T, int D, double limit, int* x_row, int* y_col,
+                     const LapLds& S) {
+    ADAS_PAR_FOR(c, j, 0, D + 1) {
+        S.v[j] = 0.0;
+        S.p[j] = -1;
+    }
+    ADAS_PAR_FOR(c, i, 0, T) {
+        S.u[i] = 0.0;
+        x_row[i] = -1;
+    }
+    c.sync();
+    if (D > 0) {
+        for (int r = 0; r < T; ++r) {
+            ADAS_PAR_FOR(c, j, 0, D + 1) {
+                S.minv[j] = DBL_MAX;
+                S.used[j] = 0;
+                S.way[j] = -1;
+            }
+            c.sync();
+            int i0 = r, j0 = -1;
+            for (;;) {
+                const double ui = S.u[i0];
+                const double* crow = cost + (size_t)i0 * D;
+                ADAS_PAR_FOR(c, j, 0, D + 1) {
+                    if (!S.used[j]) {
+                        double cur = ((j < D) ? crow[j] : limit) - ui - S.v[j];
+                        if (cur < S.minv[j]) {
+                            S.minv[j] = cur;
+                            S.way[j] = j0;
+                        }
+                    }
+                }
+                c.sync();
+                double delta;
+                int j1;
+                block_argmin_unused(c, S.minv, S.used, D + 1, S.red_v, S.red_i, delta, j1);
+                ADAS_PAR_FOR(c, j, 0, D + 1) {
+                    if (S.used[j]) {
+                        S.u[S.p[j]] += delta;
+                        S.v[j] -= delta;
+                    } else {
+                        S.minv[j] -= delta;
+                    }
+                }
+                if (c.tid == 0) S.u[r] += delta;
+                c.sync();
+                j0 = j1;
+                if (j1 == D || S.p[j1] < 0) break;
+                if (c.tid == 0) S.used[j1] = 1;
+                i0 = S.p[j1];
+                c.sync();
+            }
+            if (c.tid == 0) {  // augment along way[]
+                int j = j0;
+                for (;;) {
+                    int jp = S.way[j];
+                    int row = (jp < 0) ? r : S.p[jp];
+                    if (j == D) {
+                        x_row[row] = -1;
+                    } else {
+                        S.p[j] = row;
+                        x_row[row] = j;
+                    }
+                    if (jp < 0) break;
+                    j = jp;
+                }
+            }
+            c.sync();
+        }
+    }
+    ADAS_PAR_FOR(c, j, 0, D) y_col[j] = S.p[j];
+    c.sync();
+}
+
+// ---------------------------------------------------------------- LDS carve for the update
+struct BtLds {
+    LapLds lap;
+    int *hi, *lo, *rem, *pool, *unc, *rtr, *x, *y, *refind, *lostnew, *newtr, *la, *lb;
+    int* n;  // scalar mailbox [16]
+    static ADAS_HD size_t bytes(int MT, int MD, int nthr) {
+        size_t d = (size_t)MT + 2 * (size_t)(MD + 1) + nthr;           // u, v, minv, red_v
+        size_t i = 2 * (size_t)(MD + 1) + nthr                         // way, p, red_i
+                   + 4 * (size_t)MD                                    // hi lo rem y
+                   + 9 * (size_t)MT + 16;                              // pool unc rtr x refind lostnew newtr la lb
+        return d * 8 + i * 4 + (size_t)(MD + 1) + 64;
+    }
+    ADAS_DEV void carve(void* base, int MT, int MD, int nthr) {
+        double* d = (double*)base;
+        lap.u = d; d += MT;
+        lap.v = d; d += MD + 1;
+        lap.minv = d; d += MD + 1;
+        lap.red_v = d; d += nthr;
+        int* q = (int*)d;
+        lap.way = q; q += MD + 1;
+        lap.p = q; q += MD + 1;
+        lap.red_i = q; q += nthr;
+        hi = q; q += MD;
+        lo = q; q += MD;
+        rem = q; q += MD;
+        y = q; q += MD;
+        pool = q; q += MT;
+        unc = q; q += MT;
+        rtr = q; q += MT;
+        x = q; q += MT;
+        refind = q; q += MT;
+        lostnew = q; q += MT;
+        newtr = q; q += MT;
+        la = q; q += MT;
+        lb = q; q += MT;
+        n = q; q += 16;
+        lap.used = (unsigned char*)q;
+    }
+};
+
+enum { N_HI = 0, N_LO, N_POOL, N_UNC, N_RTR, N_REM, N_REF, N_LOSTNEW, N_NEW, N_T, N_L, N_ERR };
+
+ADAS_DEV bool bt_id_in(const BtTrack* slots, const int* list, int n, int id) {
+    for (int k = 0; k < n; ++k)
+        if (slots[list[k]].track_id == id) return true;
+    return false;
+}
+
+// ---------------------------------------------------------------- BYTETracker.update
+ADAS_DEV void bytetrack_update(const Ctx& c, const BtParams& P, const BtStream& S, const BtDet& det, void* lds_base) {
+    BtLds L;
+    L.carve(lds_base, P.MT, P.MD, c.nthr);
+    BtTrack* slots = S.slots;
+    const int MT = P.MT, MD = P.MD;
+    if (c.tid == 0) {
+        S.hdr->frame_id += 1;
+        int err = 0;
+        int nd = det.nd;
+        if (nd > MD) {
+            nd = MD;
+            err |= BT_ERR_DET_OVERFLOW;
+        }
+        // byteTracker.py:73-83 score bands (a score of exactly track_thresh is in neither)
+        int nh = 0, nl = 0;
+        for (int d = 0; d < nd; ++d) {
+            double s = det.score[d];
+            if (s > P.track_thresh) L.hi[nh++] = d;
+            if (s > 0.1 && s < P.track_thresh) L.lo[nl++] = d;
+        }
+        // :93-102 unconfirmed / tracked split, pool = joint(tracked, lost)
+        int np = 0, nu = 0;
+        for (int k = 0; k < S.hdr->n_tracked; ++k) {
+            int s = S.tracked[k];
+            if (slots[s].is_activated) {
+                if (!bt_id_in(slots, L.pool, np, slots[s].track_id)) L.pool[np++] = s;
+            } else
+                L.unc[nu++] = s;
+        }
+        for (int k = 0; k < S.hdr->n_lost; ++k) {
+            int s = S.lost[k];
+            if (!bt_id_in(slots, L.pool, np, slots[s].track_id)) L.pool[np++] = s;
+        }
+        L.n[N_HI] = nh; L.n[N_LO] = nl; L.n[N_POOL] = np; L.n[N_UNC] = nu; L.n[N_ERR] = err;
+    }
+    c.sync();
+    const int fid = S.hdr->frame_id;
+    const int n_hi = L.n[N_HI], n_lo = L.n[N_LO], n_pool = L.n[N_POOL], n_unc = L.n[N_UNC];
+
+    // :104 STrack.multi_predict(strack_pool)
+    ADAS_PAR_FOR(c, k, 0, n_pool) bt_kf_predict(slots[L.pool[k]]);
+    c.sync();
+
+    // :105-108 first association: IoU cost fused with detection score, cost_limit = match_thresh
+    ADAS_PAR_FOR(c, e, 0, n_pool * n_hi) {
+        int i = e / n_hi, j = e % n_hi, d = L.hi[j];
+        double a[4], b[4];
+        bt_track_tlbr(slots[L.pool[i]], a);
+        bt_det_tlbr(det.tlbr + 4 * d, b);
+        double cost = 1 - bt_iou(a, b);
+        double sim = 1 - cost;
+        double v = 1 - sim * det.score[d];
+        S.cost[e] = (v == v) ? v : DBL_MAX;
+    }
+    c.sync();
+    bt_lap(c, S.cost, n_pool, n_hi, P.match_thresh, L.x, L.y, L.lap);
+    if (c.tid == 0) {
+        int nr = 0, nq = 0;
+        for (int i = 0; i < n_pool; ++i) {
+            int s = L.pool[i];
+            slots[s].tmp = slots[s].state;  // state before this frame's updates
+            if (L.x[i] >= 0) {
+                if (slots[s].state != BT_TRACKED) L.refind[nr++] = s;
+            } else if (slots[s].state == BT_TRACKED)
+                L.rtr[nq++] = s;  // :128 r_tracked_stracks
+        }
+        int nm = 0;
+        for (int j = 0; j < n_hi; ++j)
+            if (L.y[j] < 0) L.rem[nm++] = L.hi[j];  // :148 detections = [detections[i] for i in u_detection]
+        L.n[N_REF] = nr; L.n[N_RTR] = nq; L.n[N_REM] = nm;
+    }
+    c.sync();
+    ADAS_PAR_FOR(c, i, 0, n_pool) {
+        if (L.x[i] >= 0) {
+            int s = L.pool[i], d = L.hi[L.x[i]];
+            bt_apply_match(slots[s], det.tlbr + 4 * d, det.score[d], det.cls[d], fid, slots[s].tmp != BT_TRACKED,
+                           &L.n[N_ERR]);
+        }
+    }
+    c.sync();
+    const int n_rtr = L.n[N_RTR], n_rem = L.n[N_REM];
+
+    // :122-145 second association: still-Tracked leftovers vs low-score detections, plain IoU, limit 0.5
+    ADAS_PAR_FOR(c, e, 0, n_rtr * n_lo) {
+        int i = e / n_lo, j = e % n_lo, d = L.lo[j];
+        double a[4], b[4];
+        bt_track_tlbr(slots[L.rtr[i]], a);
+        bt_det_tlbr(det.tlbr + 4 * d, b);
+        double v = 1 - bt_iou(a, b);
+        S.cost[e] = (v == v) ? v : DBL_MAX;
+    }
+    c.sync();
+    bt_lap(c, S.cost, n_rtr, n_lo, 0.5, L.x, L.y, L.lap);
+    ADAS_PAR_FOR(c, i, 0, n_rtr) {
+        if (L.x[i] >= 0) {
+            int s = L.rtr[i], d = L.lo[L.x[i]];
+            bt_apply_match(slots[s], det.tlbr + 4 * d, det.score[d], det.cls[d], fid, false, &L.n[N_ERR]);
+        }
+    }
+    c.sync();
+    if (c.tid == 0) {
+        int nl = 0;
+        for (int i = 0; i < n_rtr; ++i)
+            if (L.x[i] < 0) {
+                int s = L.rtr[i];
+                if (slots[s].state != BT_LOST) {
+                    slots[s].state = BT_LOST;
+                    L.lostnew[nl++] = s;
+                }
+            }
+        L.n[N_LOSTNEW] = nl;
+    }
+    c.sync();
+
+    // :147-159 unconfirmed tracks vs remaining high-score detections, fused cost, limit 0.7
+    ADAS_PAR_FOR(c, e, 0, n_unc * n_rem) {
+        int i = e / n_rem, j = e % n_rem, d = L.rem[j];
+        double a[4], b[4];
+        bt_track_tlbr(slots[L.unc[i]], a);
+        bt_det_tlbr(det.tlbr + 4 * d, b);
+        double cost = 1 - bt_iou(a, b);
+        double sim = 1 - cost;
+        double v = 1 - sim * det.score[d];
+        S.cost[e] = (v == v) ? v : DBL_MAX;
+    }
+    c.sync();
+    bt_lap(c, S.cost, n_unc, n_rem, 0.7, L.x, L.y, L.lap);
+    ADAS_PAR_FOR(c, i, 0, n_unc) {
+        int s = L.unc[i];
+        if (L.x[i] >= 0) {
+            int d = L.rem[L.x[i]];
+            bt_apply_match(slots[s], det.tlbr + 4 * d, det.score[d], det.cls[d], fid, false, &L.n[N_ERR]);
+        } else {
+            slots[s].state = BT_REMOVED;
+            slots[s].tmp = -1;  // joins removed_stracks at the end of this frame
+        }
+    }
+    c.sync();
+
+    if (c.tid == 0) {
+        int err = L.n[N_ERR];
+        // :162-168 new tracks from unmatched high-score detections
+        int nn = 0;
+        for (int j = 0; j < n_rem; ++j) {
+            if (L.y[j] >= 0) continue;
+            int d = L.rem[j];
+            if (det.score[d] < P.det_thresh) continue;
+            int s = -1;
+            for (int q = 0; q < MT; ++q)
+                if (!slots[q].used) {
+                    s = q;
+                    break;
+                }
+            if (s < 0) {
+                err |= BT_ERR_TRACK_OVERFLOW;
+                break;
+            }
+            BtTrack& t = slots[s];
+            const double* b = det.tlbr + 4 * d;
+            double tlwh[4] = {b[0], b[1], b[2] - b[0], b[3] - b[1]};
+            S.hdr->id_count += 1;
+            t.used = 1;
+            t.track_id = S.hdr->id_count;
+            bt_kf_initiate(t, tlwh);
+            t.score = det.score[d];
+            t.tracklet_len = 0;
+            t.state = BT_TRACKED;
+            t.is_activated = (fid == 1) ? 1 : 0;
+            t.frame_id = fid;
+            t.start_frame = fid;
+            t.class_id = det.cls[d];
+            t.hist_n = 1;
+            t.hist_cls[0] = det.cls[d];
+            t.hist_cnt[0] = 1;
+            t.ever_removed = 0;
+            t.tmp = 0;
+            L.newtr[nn++] = s;
+        }
+        // :171-174 age out lost tracks
+        for (int k = 0; k < S.hdr->n_lost; ++k) {
+            BtTrack& t = slots[S.lost[k]];
+            if (fid - t.frame_id > P.max_time_lost) {
+                t.state = BT_REMOVED;
+                t.tmp = -1;
+            }
+        }
+        // :176-182 list algebra
+        int nt = 0;
+        for (int k = 0; k < S.hdr->n_tracked; ++k) {
+            int s = S.tracked[k];
+            if (slots[s].state == BT_TRACKED && !bt_id_in(slots, L.la, nt, slots[s].track_id)) L.la[nt++] = s;
+        }
+        for (int k = 0; k < nn; ++k)
+            if (!bt_id_in(slots, L.la, nt, slots[L.newtr[k]].track_id)) L.la[nt++] = L.newtr[k];
+        for (int k = 0; k < L.n[N_REF]; ++k)
+            if (!bt_id_in(slots, L.la, nt, slots[L.refind[k]].track_id)) L.la[nt++] = L.refind[k];
+        int nl = 0;
+        for (int k = 0; k < S.hdr->n_lost; ++k) {
+            int s = S.lost[k];
+            if (!bt_id_in(slots, L.la, nt, slots[s].track_id)) L.lb[nl++] = s;
+        }
+        for (int k = 0; k < L.n[N_LOSTNEW]; ++k) L.lb[nl++] = L.lostnew[k];
+        int nl2 = 0;
+        for (int k = 0; k < nl; ++k)  // sub_stracks(lost, removed_stracks as of the previous frame)
+            if (!slots[L.lb[k]].ever_removed) L.lb[nl2++] = L.lb[k];
+        nl = nl2;
+        for (int q = 0; q < MT; ++q)
+            if (slots[q].used && slots[q].tmp == -1) {
+                slots[q].ever_removed = 1;  // removed_stracks.extend(removed)
+                slots[q].tmp = 0;
+            }
+        L.n[N_T] = nt; L.n[N_L] = nl; L.n[N_ERR] = err;
+    }
+    c.sync();
+    const int nt = L.n[N_T], nl = L.n[N_L];
+    // :183 remove_duplicate_stracks: pairs with IoU distance < 0.15; x/y reused as duplicate flags
+    ADAS_PAR_FOR(c, k, 0, nt) L.x[k] = 0;
+    ADAS_PAR_FOR(c, k, 0, nl) L.rtr[k] = 0;
+    c.sync();
+    ADAS_PAR_FOR(c, e, 0, nt * nl) {
+        int ia = e / nl, ib = e % nl;
+        const BtTrack& ta = slots[L.la[ia]];
+        const BtTrack& tb = slots[L.lb[ib]];
+        double a[4], b[4];
+        bt_track_tlbr(ta, a);
+        bt_track_tlbr(tb, b);
+        double dist = 1 - bt_iou(a, b);
+        if (dist < 0.15) {
+            int time_a = ta.frame_id - ta.start_frame, time_b = tb.frame_id - tb.start_frame;
+            if (time_a > time_b)
+                L.rtr[ib] = 1;
+            else
+                L.x[ia] = 1;
+        }
+    }
+    c.sync();
+    if (c.tid == 0) {
+        int a = 0, b = 0;
+        for (int k = 0; k < nt; ++k)
+            if (!L.x[k]) S.tracked[a++] = L.la[k];
+        for (int k = 0; k < nl; ++k)
+            if (!L.rtr[k]) S.lost[b++] = L.lb[k];
+        S.hdr->n_tracked = a;
+        S.hdr->n_lost = b;
+        S.hdr->err |= L.n[N_ERR];
+        // free slots that are in neither list
+        for (int q = 0; q < MT; ++q) slots[q].tmp = 0;
+        for (int k = 0; k < a; ++k) slots[S.tracked[k]].tmp = 1;
+        for (int k = 0; k < b; ++k) slots[S.lost[k]].tmp = 1;
+        for (int q = 0; q < MT; ++q)
+            if (slots[q].used && !slots[q].tmp) slots[q].used = 0;
+    }
+    c.sync();
+    // compact messages: tracked first, then lost
+    const int a = S.hdr->n_tracked, b = S.hdr->n_lost;
+    ADAS_PAR_FOR(c, k, 0, a + b) {
+        const BtTrack& t = slots[k < a ? S.tracked[k] : S.lost[k - a]];
+        BtOut& o = S.out[k];
+        bt_track_tlwh(t, o.tlwh);
+        o.score = t.score;
+        o.track_id = t.track_id;
+        o.state = t.state;
+        o.is_activated = t.is_activated;
+        o.class_id = t.class_id;
+        o.frame_id = t.frame_id;
+        o.start_frame = t.start_frame;
+        o.tracklet_len = t.tracklet_len;
+        o.pad = 0;
+    }
+}
+
+ADAS_DEV void bytetrack_reset(const Ctx& c, const BtParams& P, const BtStream& S) {  // byteTracker.py:187-200
+    ADAS_PAR_FOR(c, q, 0, P.MT) S.slots[q].used = 0;
+    if (c.tid == 0) {
+        S.hdr->frame_id = 0;
+        S.hdr->id_count = 0;
+        S.hdr->n_tracked = 0;
+        S.hdr->n_lost = 0;
+        S.hdr->err = 0;
+    }
+}
+
+}  // namespace adas

@@ -1,0 +1,157 @@
+"""Thin object wrappers over the post-processing entry points of the C ABI.
+
+YoloPost      <- YoloDetector.__process_output + Scaler.convert_boxes_coordinate + NMS + get_nms_results
+                 (ObjectDetector/yoloDetector.py:104-157, utils.py:70-87,105-256)
+UfldDecode    <- UltrafastLaneDetectorV2.__process_output (ultrafastLaneDetectorV2.py:114-181)
+DeviceTracker <- BYTETracker.update/reset (ObjectTracker/byteTrack/byteTracker.py:62-200)
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib as L
+
+
+def letterbox(src_hw, dst_hw, keep_ratio=True):
+    """Scaler.process_image geometry (utils.py:42-68) -> dict(pad=(h,w), ratio=(h,w))."""
+    p = L.YoloPostParams()
+    L.check(L.lib().adas_letterbox_params(int(src_hw[0]), int(src_hw[1]), int(dst_hw[0]), int(dst_hw[1]),
+                                          1 if keep_ratio else 0, C.byref(p)))
+    return dict(pad=(p.pad_h, p.pad_w), ratio=(p.ratio_h, p.ratio_w))
+
+
+class YoloPost:
+    def __init__(self, layout, num_anchors, num_classes, box_score, iou_thr, lb, nms_mode=L.NMS_REFERENCE,
+                 max_candidates=1024, max_batch=1):
+        p = L.YoloPostParams(layout, num_anchors, num_classes, nms_mode, box_score, iou_thr, int(lb["pad"][0]),
+                             int(lb["pad"][1]), float(lb["ratio"][0]), float(lb["ratio"][1]), max_candidates, 0)
+        self.params, self.max_batch, self.cap = p, max_batch, max_candidates
+        h = C.c_void_p()
+        L.check(L.lib().adas_yolo_post_create(C.byref(p), max_batch, C.byref(h)))
+        self.h = h.value
+        self.head_elems = (4 + num_classes) * num_anchors if layout == L.HEAD_V8 else (5 + num_classes) * num_anchors
+
+    def run_device(self, d_head_ptr, batch=1, stream=None):
+        L.check(L.lib().adas_yolo_post_run(self.h, d_head_ptr, batch, stream))
+
+    def run_host(self, heads):
+        """heads: [batch, ...] fp32 in the reference layout; uploaded, processed on the GPU."""
+        heads = np.ascontiguousarray(heads, np.float32)
+        batch = heads.shape[0]
+        assert heads[0].size == self.head_elems
+        buf = L.DeviceBuffer.from_array(heads)
+        try:
+            self.run_device(buf.ptr, batch)
+            return [self.fetch(b) for b in range(batch)]
+        finally:
+            buf.free()
+
+    def fetch(self, frame=0):
+        cap = self.cap
+        cnt = L.YoloCounts()
+        o = dict(cand_anchor=np.zeros(cap, np.int32), cand_xywh=np.zeros((cap, 4)), cand_conf=np.zeros(cap),
+                 cand_cls=np.zeros(cap, np.int32), keep=np.zeros(cap, np.int32), xywh=np.zeros((cap, 4)),
+                 conf=np.zeros(cap), class_id=np.zeros(cap, np.int32), xyxy_int=np.zeros((cap, 4), np.int32))
+        rc = L.lib().adas_yolo_post_fetch(self.h, frame, C.byref(cnt), *[L.ptr(o[k]) for k in (
+            "cand_anchor", "cand_xywh", "cand_conf", "cand_cls", "keep", "xywh", "conf", "class_id", "xyxy_int")])
+        n, k = cnt.n_candidates, cnt.n_keep
+        res = dict(n_found=cnt.n_found, overflow=bool(cnt.flags & 1))
+        for key in ("cand_anchor", "cand_xywh", "cand_conf", "cand_cls"):
+            res[key] = o[key][:n]
+        for key in ("keep", "xywh", "conf", "class_id", "xyxy_int"):
+            res[key] = o[key][:k]
+        res["rc"] = rc
+        return res
+
+    def device_views(self):
+        v = [C.c_void_p() for _ in range(4)]
+        L.check(L.lib().adas_yolo_post_device_views(self.h, *[C.byref(x) for x in v]))
+        return dict(xyxy=v[0].value, score=v[1].value, cls=v[2].value, counts=v[3].value)
+
+    def close(self):
+        if getattr(self, "h", None):
+            L.lib().adas_yolo_post_destroy(self.h)
+            self.h = None
+
+    __del__ = close
+
+
+class UfldDecode:
+    def __init__(self, grid_row, cls_row, grid_col, cls_col, img_w, img_h, row_anchor, col_anchor, local_width=1,
+                 max_batch=1):
+        ra = np.ascontiguousarray(row_anchor, np.float64)
+        ca = np.ascontiguousarray(col_anchor, np.float64)
+        p = L.UfldParams(grid_row, cls_row, grid_col, cls_col, img_w, img_h, local_width, 0, L.ptr(ra), L.ptr(ca))
+        self.dims = (grid_row, cls_row, grid_col, cls_col)
+        h = C.c_void_p()
+        L.check(L.lib().adas_ufld_decode_create(C.byref(p), max_batch, C.byref(h)))
+        self.h = h.value
+
+    def run_device(self, ptrs, strides, batch=1, stream=None):
+        L.check(L.lib().adas_ufld_decode_run(self.h, *ptrs, *strides, batch, stream))
+
+    def run_host(self, outs):
+        """outs = [loc_row (B,G,K,4), loc_col, exist_row, exist_col] fp32 arrays."""
+        outs = [np.ascontiguousarray(o, np.float32) for o in outs]
+        batch = outs[0].shape[0]
+        bufs = [L.DeviceBuffer.from_array(o) for o in outs]
+        try:
+            self.run_device([b.ptr for b in bufs], [o[0].size for o in outs], batch)
+            return [self.fetch(b) for b in range(batch)]
+        finally:
+            for b in bufs:
+                b.free()
+
+    def fetch(self, frame=0):
+        pts = np.zeros((4, L.UFLD_MAX_POINTS, 2), np.int32)
+        cnt = np.zeros(4, np.int32)
+        det = np.zeros(4, np.int32)
+        L.check(L.lib().adas_ufld_decode_fetch(self.h, frame, L.ptr(pts), L.ptr(cnt), L.ptr(det)))
+        lanes = [[(int(x), int(y)) for x, y in pts[i, :cnt[i]]] for i in range(4)]
+        return lanes, [bool(d) for d in det]
+
+    def close(self):
+        if getattr(self, "h", None):
+            L.lib().adas_ufld_decode_destroy(self.h)
+            self.h = None
+
+    __del__ = close
+
+
+class DeviceTracker:
+    """n_streams independent ByteTrack instances living on the GPU."""
+
+    def __init__(self, n_streams=1, track_thresh=0.5, track_buffer=30, match_thresh=0.8, frame_rate=30,
+                 max_tracks=256, max_dets=256):
+        p = L.BytetrackParams(track_thresh, match_thresh, float(frame_rate), track_buffer, max_tracks, max_dets, 0)
+        self.n_streams, self.max_tracks = n_streams, max_tracks
+        h = C.c_void_p()
+        L.check(L.lib().adas_bytetrack_create(C.byref(p), n_streams, C.byref(h)))
+        self.h = h.value
+
+    def reset(self, stream=-1):
+        L.check(L.lib().adas_bytetrack_reset(self.h, stream))
+
+    def update_host(self, stream, boxes, scores, cls):
+        b = np.ascontiguousarray(np.asarray(boxes, np.float64).reshape(-1, 4))
+        s = np.ascontiguousarray(np.asarray(scores, np.float64).reshape(-1))
+        c = np.ascontiguousarray(np.asarray(cls, np.int32).reshape(-1))
+        L.check(L.lib().adas_bytetrack_update_host(self.h, stream, L.ptr(b), L.ptr(s), L.ptr(c), len(s)))
+
+    def update_device(self, views, det_stride, n_streams=None, stream=None, count_stride=4, count_index=2):
+        L.check(L.lib().adas_bytetrack_update_device(self.h, views["xyxy"], views["score"], views["cls"],
+                                                     views["counts"], det_stride, count_stride, count_index,
+                                                     n_streams or self.n_streams, stream))
+
+    def fetch(self, stream=0):
+        hdr = L.TrackHeader()
+        recs = np.zeros(2 * self.max_tracks, L.TRACK_DTYPE)
+        L.check(L.lib().adas_bytetrack_fetch(self.h, stream, C.byref(hdr), L.ptr(recs), len(recs)))
+        return hdr, recs[:hdr.n_tracked], recs[hdr.n_tracked:hdr.n_tracked + hdr.n_lost]
+
+    def close(self):
+        if getattr(self, "h", None):
+            L.lib().adas_bytetrack_destroy(self.h)
+            self.h = None
+
+    __del__ = close
