@@ -128,6 +128,7 @@ int adas_yolo_post_fetch(adas_yolo_post* h, int frame, adas_yolo_counts* counts,
  * max_candidates entries.  xyxy as fp64 of the int-truncated corners, scores fp64, classes, counts[4]. */
 int adas_yolo_post_device_views(adas_yolo_post* h, const double** d_xyxy, const double** d_score,
                                 const int32_t** d_cls, const int32_t** d_counts);
+int adas_yolo_post_capacity(const adas_yolo_post* h, int* max_candidates);
 
 /* ===================================================================================
  * UFLDv2 lane decode: replaces UltrafastLaneDetectorV2.__process_output

@@ -1,0 +1,208 @@
+"""Oracle: torch-CPU fp32 forward passes of the detector / lane networks.
+
+TEST INFRASTRUCTURE (see oracle/__init__.py).  PARITY UNPINNED at the network boundary: the
+reference has no weights and no YOLO architecture; onnxruntime (its CPU path, coreEngine.py:159-186)
+is not installed.  These functions restate the upstream architectures the reference's exported
+models come from and stand in for "ONNXRuntime-CPU" (oneDNN fp32):
+  * YOLOv8: ultralytics 8.1.x (README.md:56) Conv/C2f/SPPF/Detect/DFL; output layout pinned by
+    ObjectDetector/yoloDetector.py:110-122 -> (1, 4+nc, 8400) [cx,cy,w,h,probs] in input pixels.
+  * YOLOv5 v6.2 (README.md:53) Conv/C3/SPPF/Detect; output (1, 25200, 5+nc), anchors
+    yoloDetector.py:23.
+  * UFLDv2: TrafficLaneDetector/ufldDetector/exportLib/ultrafastLaneV2/model_culane.py:7-63 on the
+    torchvision ResNet topology used by backbone.py:14-58 (BasicBlock, BN folded into conv+bias).
+Weights are a plain dict name -> ndarray (BatchNorm pre-folded: '<conv>.weight' OIHW, '<conv>.bias').
+"""
+import math
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+
+def _t(W, name):
+    return torch.from_numpy(np.ascontiguousarray(W[name]))
+
+
+def _conv(x, W, name, s=1, p=None, act="silu"):
+    w = _t(W, name + ".weight")
+    b = _t(W, name + ".bias")
+    k = w.shape[-1]
+    y = F.conv2d(x, w, b, stride=s, padding=(k // 2 if p is None else p))
+    if act == "silu":
+        y = F.silu(y)
+    elif act == "relu":
+        y = F.relu(y)
+    return y
+
+
+# ------------------------------------------------------------------ YOLOv8
+V8_SCALES = {"n": (0.33, 0.25, 1024), "s": (0.33, 0.50, 1024), "m": (0.67, 0.75, 768), "l": (1.0, 1.0, 512)}
+
+
+def _c2f(x, W, name, n, shortcut):
+    y = list(_conv(x, W, f"{name}.cv1.conv").chunk(2, 1))
+    for i in range(n):
+        t = _conv(_conv(y[-1], W, f"{name}.m.{i}.cv1.conv"), W, f"{name}.m.{i}.cv2.conv")
+        y.append(y[-1] + t if shortcut else t)
+    return _conv(torch.cat(y, 1), W, f"{name}.cv2.conv")
+
+
+def _sppf(x, W, name):
+    x = _conv(x, W, f"{name}.cv1.conv")
+    y1 = F.max_pool2d(x, 5, 1, 2)
+    y2 = F.max_pool2d(y1, 5, 1, 2)
+    y3 = F.max_pool2d(y2, 5, 1, 2)
+    return _conv(torch.cat((x, y1, y2, y3), 1), W, f"{name}.cv2.conv")
+
+
+def yolov8_forward(x, W, scale="n", nc=80, taps=None):
+    """x: (N,3,H,W) fp32 in [0,1].  Returns (N, 4+nc, A) fp32.  taps: optional dict filled with named activations."""
+    depth = V8_SCALES[scale][0]
+    dep = lambda n: max(round(n * depth), 1)
+    x = torch.as_tensor(x, dtype=torch.float32)
+    with torch.no_grad():
+        x = _conv(x, W, "model.0.conv", 2)
+        x = _conv(x, W, "model.1.conv", 2)
+        x = _c2f(x, W, "model.2", dep(3), True)
+        x = _conv(x, W, "model.3.conv", 2)
+        x4 = _c2f(x, W, "model.4", dep(6), True)
+        x = _conv(x4, W, "model.5.conv", 2)
+        x6 = _c2f(x, W, "model.6", dep(6), True)
+        x = _conv(x6, W, "model.7.conv", 2)
+        x = _c2f(x, W, "model.8", dep(3), True)
+        x9 = _sppf(x, W, "model.9")
+        x = torch.cat((F.interpolate(x9, scale_factor=2, mode="nearest"), x6), 1)
+        x12 = _c2f(x, W, "model.12", dep(3), False)
+        x = torch.cat((F.interpolate(x12, scale_factor=2, mode="nearest"), x4), 1)
+        x15 = _c2f(x, W, "model.15", dep(3), False)
+        x = torch.cat((_conv(x15, W, "model.16.conv", 2), x12), 1)
+        x18 = _c2f(x, W, "model.18", dep(3), False)
+        x = torch.cat((_conv(x18, W, "model.19.conv", 2), x9), 1)
+        x21 = _c2f(x, W, "model.21", dep(3), False)
+        if taps is not None:
+            taps.update(p3=x15, p4=x18, p5=x21, b4=x4, b6=x6, sppf=x9)
+        feats = [x15, x18, x21]
+        N = x.shape[0]
+        outs, anchors, strides = [], [], []
+        for i, f in enumerate(feats):
+            b = _conv(_conv(f, W, f"model.22.cv2.{i}.0.conv"), W, f"model.22.cv2.{i}.1.conv")
+            b = _conv(b, W, f"model.22.cv2.{i}.2", act=None)
+            c = _conv(_conv(f, W, f"model.22.cv3.{i}.0.conv"), W, f"model.22.cv3.{i}.1.conv")
+            c = _conv(c, W, f"model.22.cv3.{i}.2", act=None)
+            outs.append(torch.cat((b, c), 1).view(N, 64 + nc, -1))
+            h, w = f.shape[2:]
+            sy, sx = torch.meshgrid(torch.arange(h, dtype=torch.float32) + 0.5,
+                                    torch.arange(w, dtype=torch.float32) + 0.5, indexing="ij")
+            anchors.append(torch.stack((sx, sy), -1).view(-1, 2))
+            strides.append((h, w))
+        H_in = feats[0].shape[2] * 8
+        stride_t = torch.cat([torch.full((h * w, 1), float(H_in // h)) for h, w in strides])
+        xcat = torch.cat(outs, 2)
+        box, cls = xcat.split((64, nc), 1)
+        # DFL: softmax over 16 bins, expectation (ultralytics DFL module)
+        A = box.shape[2]
+        d = box.view(N, 4, 16, A).transpose(2, 1).softmax(1)
+        dist = (d * torch.arange(16, dtype=torch.float32).view(1, 16, 1, 1)).sum(1)      # (N,4,A)
+        anc = torch.cat(anchors).transpose(0, 1).unsqueeze(0)                                # (1,2,A)
+        lt, rb = dist.chunk(2, 1)
+        x1y1 = anc - lt
+        x2y2 = anc + rb
+        dbox = torch.cat(((x1y1 + x2y2) / 2, x2y2 - x1y1), 1) * stride_t.transpose(0, 1)
+        if taps is not None:
+            taps.update(box_logits=box, cls_logits=cls)
+        return torch.cat((dbox, cls.sigmoid()), 1).numpy()
+
+
+# ------------------------------------------------------------------ YOLOv5
+V5_SCALES = {"n": (0.33, 0.25), "s": (0.33, 0.50)}
+V5_ANCHORS = [[10, 13, 16, 30, 33, 23], [30, 61, 62, 45, 59, 119], [116, 90, 156, 198, 373, 326]]
+
+
+def _c3(x, W, name, n, shortcut):
+    y = _conv(x, W, f"{name}.cv1.conv")
+    for i in range(n):
+        t = _conv(_conv(y, W, f"{name}.m.{i}.cv1.conv"), W, f"{name}.m.{i}.cv2.conv")
+        y = y + t if shortcut else t
+    return _conv(torch.cat((y, _conv(x, W, f"{name}.cv2.conv")), 1), W, f"{name}.cv3.conv")
+
+
+def yolov5_forward(x, W, scale="n", nc=80):
+    depth = V5_SCALES[scale][0]
+    dep = lambda n: max(round(n * depth), 1)
+    x = torch.as_tensor(x, dtype=torch.float32)
+    with torch.no_grad():
+        x = _conv(x, W, "model.0.conv", 2, 2)
+        x = _conv(x, W, "model.1.conv", 2)
+        x = _c3(x, W, "model.2", dep(3), True)
+        x = _conv(x, W, "model.3.conv", 2)
+        x4 = _c3(x, W, "model.4", dep(6), True)
+        x = _conv(x4, W, "model.5.conv", 2)
+        x6 = _c3(x, W, "model.6", dep(9), True)
+        x = _conv(x6, W, "model.7.conv", 2)
+        x = _c3(x, W, "model.8", dep(3), True)
+        x = _sppf(x, W, "model.9")
+        x10 = _conv(x, W, "model.10.conv")
+        x = torch.cat((F.interpolate(x10, scale_factor=2, mode="nearest"), x6), 1)
+        x = _c3(x, W, "model.13", dep(3), False)
+        x14 = _conv(x, W, "model.14.conv")
+        x = torch.cat((F.interpolate(x14, scale_factor=2, mode="nearest"), x4), 1)
+        x17 = _c3(x, W, "model.17", dep(3), False)
+        x = torch.cat((_conv(x17, W, "model.18.conv", 2), x14), 1)
+        x20 = _c3(x, W, "model.20", dep(3), False)
+        x = torch.cat((_conv(x20, W, "model.21.conv", 2), x10), 1)
+        x23 = _c3(x, W, "model.23", dep(3), False)
+        no, z = nc + 5, []
+        H_in = x17.shape[2] * 8
+        for i, f in enumerate((x17, x20, x23)):
+            y = _conv(f, W, f"model.24.m.{i}", act=None)
+            bs, _, ny, nx = y.shape
+            y = y.view(bs, 3, no, ny, nx).permute(0, 1, 3, 4, 2).contiguous().sigmoid()
+            stride = float(H_in // ny)
+            yv, xv = torch.meshgrid(torch.arange(ny, dtype=torch.float32), torch.arange(nx, dtype=torch.float32), indexing="ij")
+            grid = torch.stack((xv, yv), 2).view(1, 1, ny, nx, 2)
+            ag = torch.tensor(V5_ANCHORS[i], dtype=torch.float32).view(1, 3, 1, 1, 2)
+            xy = (y[..., 0:2] * 2 - 0.5 + grid) * stride
+            wh = (y[..., 2:4] * 2) ** 2 * ag
+            z.append(torch.cat((xy, wh, y[..., 4:]), -1).view(bs, -1, no))
+        return torch.cat(z, 1).numpy()
+
+
+# ------------------------------------------------------------------ UFLDv2
+RESNET_DEPTHS = {"18": [2, 2, 2, 2], "34": [3, 4, 6, 3]}
+
+
+def ufldv2_forward(x, W, backbone="18", num_grid_row=200, num_cls_row=72, num_grid_col=100, num_cls_col=81,
+                   num_lanes=4, taps=None):
+    """Returns [loc_row, loc_col, exist_row, exist_col] (model_culane.py:56-59)."""
+    x = torch.as_tensor(x, dtype=torch.float32)
+    with torch.no_grad():
+        x = _conv(x, W, "model.conv1", 2, 3, "relu")
+        x = F.max_pool2d(x, 3, 2, 1)
+        cin = 64
+        for li, (planes, nblk) in enumerate(zip([64, 128, 256, 512], RESNET_DEPTHS[backbone])):
+            for bi in range(nblk):
+                s = 2 if (li > 0 and bi == 0) else 1
+                name = f"model.layer{li + 1}.{bi}"
+                idt = x
+                if s != 1 or cin != planes:
+                    idt = _conv(x, W, f"{name}.downsample.0", s, 0, None)
+                t = _conv(x, W, f"{name}.conv1", s, 1, "relu")
+                x = F.relu(_conv(t, W, f"{name}.conv2", 1, 1, None) + idt)
+                cin = planes
+        if taps is not None:
+            taps["layer4"] = x
+        fea = _conv(x, W, "pool", 1, 0, None)
+        fea = fea.reshape(fea.shape[0], -1)                                   # (C,H,W) flatten, model_culane.py:53
+        if taps is not None:
+            taps["fea"] = fea
+        fea = F.layer_norm(fea, (fea.shape[1],), _t(W, "cls.0.weight"), _t(W, "cls.0.bias"), 1e-5)
+        h = F.relu(F.linear(fea, _t(W, "cls.1.weight"), _t(W, "cls.1.bias")))
+        out = F.linear(h, _t(W, "cls.3.weight"), _t(W, "cls.3.bias"))
+        d1 = num_grid_row * num_cls_row * num_lanes
+        d2 = num_grid_col * num_cls_col * num_lanes
+        d3 = 2 * num_cls_row * num_lanes
+        d4 = 2 * num_cls_col * num_lanes
+        N = out.shape[0]
+        return [out[:, :d1].reshape(N, num_grid_row, num_cls_row, num_lanes).numpy(),
+                out[:, d1:d1 + d2].reshape(N, num_grid_col, num_cls_col, num_lanes).numpy(),
+                out[:, d1 + d2:d1 + d2 + d3].reshape(N, 2, num_cls_row, num_lanes).numpy(),
+                out[:, -d4:].reshape(N, 2, num_cls_col, num_lanes).numpy()]

@@ -1,0 +1,115 @@
+"""GPU parity of the network forward passes (HIP MFMA conv engine) against the torch-CPU fp32 oracle.
+
+Tolerances (stated per BASELINE.json north_star: "within 1e-3 on conv activations"):
+  * precision="fp32" (fp32 storage + fp32 MFMA, the parity mode): max |diff| <= 1e-3 on every tapped
+    activation and on the head outputs.
+  * precision="bf16" (bench mode): bf16 storage cannot meet an absolute 1e-3 on O(1..10) activations
+    (half-ulp at 1.0 is 3.9e-3); it is checked as relative L2 error <= 2e-2 end to end and by
+    per-layer checks where the input is the bf16-rounded oracle activation.
+"""
+import numpy as np
+import pytest
+
+import netutil
+from oracle import nets
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def CE():
+    import importlib
+    from conftest import load_pkg
+    load_pkg()
+    ce = importlib.import_module("adas_amd.coreEngine")
+    assert ce.L.lib().adas_device_count() > 0
+    return ce
+
+
+def rel_l2(a, b):
+    return float(np.linalg.norm(a.astype(np.float64) - b) / (np.linalg.norm(b) + 1e-30))
+
+
+def test_engine_surface_and_errors(CE, tmp_path):
+    with pytest.raises(Exception, match="can't not found"):
+        CE.HipEngine(str(tmp_path / "missing.onnx"))
+    bad = tmp_path / "real.onnx"
+    bad.write_bytes(b"\x08\x07not a container")
+    with pytest.raises(Exception, match="ADASHIP1"):
+        CE.OnnxEngine(str(bad))
+    path, W, g = netutil.model("yolov8n")
+    e = CE.TensorRTEngine(path, precision="fp32")
+    assert e.get_engine_input_shape() == [1, 3, 640, 640]
+    shapes, names = e.get_engine_output_shape()
+    assert shapes == [[1, 84, 8400]] and names == ["output0"]
+    assert e.framework_type == "hip" and e.engine_dtype == np.float32
+    st = e.stats()
+    assert abs(st["flops_per_frame"] / 1e9 - 8.74) < 0.01
+    e.close()
+
+
+@pytest.mark.parametrize("prec,tol_abs,tol_rel", [("fp32", 1e-3, 1e-4), ("bf16", None, 2e-2)])
+def test_yolov8n_vs_oracle(CE, prec, tol_abs, tol_rel):
+    path, W, g = netutil.model("yolov8n")
+    x = netutil.coco_like_frames(2)
+    taps = {}
+    want = nets.yolov8_forward(x, W, "n", taps=taps)
+    e = CE.HipEngine(path, precision=prec, max_batch=2)
+    got = e.engine_inference(x)[0]
+    assert got.shape == want.shape == (2, 84, 8400)
+    # intermediate activations (conv stacks)
+    for lname, key in (("model.15.cv2.conv", "p3"), ("model.18.cv2.conv", "p4"), ("model.21.cv2.conv", "p5"),
+                       ("model.9.cv2.conv", "sppf")):
+        a = e.fetch_activation(lname, 2)
+        ref = taps[key].numpy()
+        err = np.abs(a - ref).max()
+        print(prec, lname, "max|diff| %.3e  rel_l2 %.3e  max|ref| %.2f" % (err, rel_l2(a, ref), np.abs(ref).max()))
+        if tol_abs is not None:
+            assert err <= tol_abs, (lname, err)
+        assert rel_l2(a, ref) <= tol_rel, lname
+    box_err = np.abs(got[:, :4] - want[:, :4]).max()
+    cls_err = np.abs(got[:, 4:] - want[:, 4:]).max()
+    print(prec, "head: box max|diff| %.3e px, cls max|diff| %.3e" % (box_err, cls_err))
+    if tol_abs is not None:
+        assert cls_err <= tol_abs and box_err <= 2e-2      # boxes are in pixels (x stride up to 32)
+    else:
+        assert rel_l2(got, want) <= tol_rel
+    e.close()
+
+
+def test_yolov5n_plumbing_config_c1(CE):
+    """BASELINE config 1 shape: YOLOv5n 640x640 single frame through the coreEngine surface."""
+    path, W, g = netutil.model("yolov5n")
+    x = netutil.coco_like_frames(1, seed=0)
+    want = nets.yolov5_forward(x, W, "n")
+    e = CE.OnnxEngine(path, precision="fp32")
+    got = e.engine_inference(x)[0]
+    assert got.shape == want.shape == (1, 25200, 85)
+    err = np.abs(got[..., 4:] - want[..., 4:]).max()
+    berr = np.abs(got[..., :4] - want[..., :4]).max()
+    print("v5n fp32: score max|diff| %.3e, box max|diff| %.3e px" % (err, berr))
+    assert err <= 1e-3 and berr <= 5e-2
+    e.close()
+
+
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+def test_ufldv2_small_vs_oracle(CE, prec):
+    """Reduced geometry (160x800 input, 100/50 grid cells, 36/41 anchors) -- same layer types, seconds to run."""
+    kw = dict(in_h=160, in_w=800, num_grid_row=100, num_cls_row=36, num_grid_col=50, num_cls_col=41)
+    path, W, g = netutil.model("ufldv2_res18", **kw)
+    x = netutil.lane_frames(2, 160, 800)
+    taps = {}
+    want = nets.ufldv2_forward(x, W, "18", 100, 36, 50, 41, taps=taps)
+    e = CE.HipEngine(path, precision=prec, max_batch=2)
+    got = e.engine_inference(x)
+    assert [o.shape for o in got] == [w.shape for w in want]
+    a = e.fetch_activation("model.layer4.1.conv2", 2)
+    ref = taps["layer4"].numpy()
+    print(prec, "layer4 max|diff| %.3e rel %.3e max|ref| %.2f" % (np.abs(a - ref).max(), rel_l2(a, ref), np.abs(ref).max()))
+    for o, w, nm in zip(got, want, ("loc_row", "loc_col", "exist_row", "exist_col")):
+        print(prec, nm, "max|diff| %.3e rel %.3e" % (np.abs(o - w).max(), rel_l2(o, w)))
+        if prec == "fp32":
+            assert np.abs(o - w).max() <= 1e-3
+        else:
+            assert rel_l2(o, w) <= 3e-2
+    e.close()

@@ -87,6 +87,7 @@ _SIGS = {
     "adas_yolo_post_run": (C.c_int, [_P, _P, C.c_int, _P]),
     "adas_yolo_post_fetch": (C.c_int, [_P, C.c_int, C.POINTER(YoloCounts)] + [_P] * 9),
     "adas_yolo_post_device_views": (C.c_int, [_P] + [C.POINTER(_P)] * 4),
+    "adas_yolo_post_capacity": (C.c_int, [_P, C.POINTER(C.c_int)]),
     "adas_ufld_decode_create": (C.c_int, [C.POINTER(UfldParams), C.c_int, C.POINTER(_P)]),
     "adas_ufld_decode_destroy": (C.c_int, [_P]),
     "adas_ufld_decode_run": (C.c_int, [_P, _P, _P, _P, _P, C.c_size_t, C.c_size_t, C.c_size_t, C.c_size_t, C.c_int, _P]),

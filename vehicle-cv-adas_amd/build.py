@@ -23,7 +23,7 @@ UNITS = [
     ("pipeline.cpp", []),
 ]
 COMMON = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function",
-          "-Wno-unused-result", "-x", "hip"]
+          "-Wno-unused-result", "-Wno-unused-value", "-x", "hip"]
 
 
 def _deps():

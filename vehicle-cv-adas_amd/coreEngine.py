@@ -1,0 +1,168 @@
+"""Drop-in for the reference's engine seam (coreEngine.py:7-186) on MI355X.
+
+Reference callers do `from coreEngine import TensorRTEngine, OnnxEngine` and pick one by file
+suffix (ObjectDetector/yoloDetector.py:12,74-77; ufldDetector/ultrafastLaneDetectorV2.py:7,82-85).
+This module exports the same names, all bound to HipEngine, with the same surface:
+
+    Engine(model_path)                     raises Exception("The model path [...] can't not found!") if missing
+    .get_engine_input_shape()           -> [1, 3, H, W]
+    .get_engine_output_shape()          -> (shapes: list, names: list[str])
+    .engine_inference(ndarray NCHW)     -> list[ndarray], each with leading batch dim 1 (or B)
+    .framework_type / .providers / .engine_dtype
+
+Added (not in the reference): `.infer_device(d_ptr, batch)` keeps outputs in HBM for the GPU-resident
+post-processing; `precision=` ("bf16" bench / "fp32" parity) and `max_batch=` keyword arguments.
+There is no CPU execution path: construction fails if libadas_hip.so or a gfx950 device is missing.
+"""
+import abc
+import ctypes as C
+import os
+
+import numpy as np
+
+try:
+    from . import _lib as L
+except ImportError:  # imported as a top-level module named `coreEngine` (package dir on sys.path)
+    import _lib as L
+
+MODEL_SUFFIXES = ('.onnx', '.trt', '.hipm')
+
+
+class EngineBase(abc.ABC):
+    '''
+    Same contract as the reference EngineBase (coreEngine.py:7-39); `.hipm` is accepted next to .onnx/.trt.
+    '''
+
+    def __init__(self, model_path):
+        if not os.path.isfile(model_path):
+            raise Exception("The model path [%s] can't not found!" % model_path)
+        assert model_path.endswith(MODEL_SUFFIXES), 'Onnx/TensorRT/Hip Parameters must be a .onnx/.trt/.hipm file.'
+        self._framework_type = None
+
+    @property
+    def framework_type(self):
+        if (self._framework_type == None):
+            raise Exception("Framework type can't be None")
+        return self._framework_type
+
+    @framework_type.setter
+    def framework_type(self, value):
+        if (not isinstance(value, str)):
+            raise Exception("Framework type need be str")
+        self._framework_type = value
+
+    @abc.abstractmethod
+    def get_engine_input_shape(self):
+        return NotImplemented
+
+    @abc.abstractmethod
+    def get_engine_output_shape(self):
+        return NotImplemented
+
+    @abc.abstractmethod
+    def engine_inference(self):
+        return NotImplemented
+
+
+class HipEngine(EngineBase):
+    def __init__(self, model_path, precision="bf16", max_batch=1):
+        EngineBase.__init__(self, model_path)
+        prec = {"bf16": L.PREC_BF16, "fp32": L.PREC_FP32}[precision]
+        h = C.c_void_p()
+        L.check(L.lib().adas_engine_create(os.fsencode(model_path), prec, int(max_batch), C.byref(h)))
+        self._h = h.value
+        self.precision, self.max_batch = precision, int(max_batch)
+        self.providers = ['HIPExecutionProvider(gfx950)']
+        self.engine_dtype = np.float32        # the seam stays fp32; bf16 is internal
+        self.framework_type = "hip"
+        self.__load_engine_interface()
+
+    def __load_engine_interface(self):
+        lib = L.lib()
+        d = (C.c_int64 * 4)()
+        L.check(lib.adas_engine_input_shape(self._h, d))
+        self.__input_shape = [list(d)]
+        self.__output_shapes, self.__output_names = [], []
+        for i in range(lib.adas_engine_num_outputs(self._h)):
+            nd = C.c_int()
+            L.check(lib.adas_engine_output_shape(self._h, i, d, C.byref(nd)))
+            self.__output_shapes.append(list(d)[:nd.value])
+            self.__output_names.append(lib.adas_engine_output_name(self._h, i).decode())
+
+    # ---- reference surface
+    def get_engine_input_shape(self):
+        return self.__input_shape[0]
+
+    def get_engine_output_shape(self):
+        return self.__output_shapes, self.__output_names
+
+    def engine_inference(self, input_tensor):
+        x = np.ascontiguousarray(input_tensor, dtype=np.float32)
+        shp = self.__input_shape[0]
+        if x.ndim != 4 or list(x.shape[1:]) != shp[1:]:
+            raise Exception("input tensor shape %s does not match the engine input %s" % (list(x.shape), shp))
+        batch = x.shape[0]
+        outs = [np.empty([batch] + s[1:], np.float32) for s in self.__output_shapes]
+        ptrs = (C.c_void_p * len(outs))(*[o.ctypes.data for o in outs])
+        L.check(L.lib().adas_engine_infer_host(self._h, L.ptr(x), batch, ptrs))
+        return outs
+
+    # ---- device-resident extensions
+    @property
+    def handle(self):
+        return self._h
+
+    def infer_device(self, d_input_ptr, batch=1, stream=None):
+        L.check(L.lib().adas_engine_infer_device(self._h, d_input_ptr, int(batch), stream))
+
+    def output_device_ptr(self, index):
+        return L.lib().adas_engine_output_device(self._h, index)
+
+    def stats(self):
+        fl, wb, nl = C.c_double(), C.c_double(), C.c_int()
+        L.check(L.lib().adas_engine_stats(self._h, C.byref(fl), C.byref(wb), C.byref(nl)))
+        return dict(flops_per_frame=fl.value, weight_bytes=wb.value, num_layers=nl.value)
+
+    def layer_info(self, i):
+        name = C.create_string_buffer(64)
+        fl, kind = C.c_double(), C.c_int()
+        L.check(L.lib().adas_engine_layer_info(self._h, i, name, 64, C.byref(fl), C.byref(kind)))
+        return name.value.decode(), fl.value, kind.value
+
+    def layer_index(self, name):
+        for i in range(self.stats()["num_layers"]):
+            if self.layer_info(i)[0] == name:
+                return i
+        raise KeyError(name)
+
+    def profile(self, d_input_ptr, batch=1, iters=5):
+        n = self.stats()["num_layers"]
+        ms = np.zeros(n, np.float32)
+        nl = C.c_int()
+        L.check(L.lib().adas_engine_profile(self._h, d_input_ptr, int(batch), int(iters), L.ptr(ms), n, C.byref(nl)))
+        return [(self.layer_info(i) + (float(ms[i]),)) for i in range(n)]
+
+    def fetch_activation(self, layer, batch=1):
+        if isinstance(layer, str):
+            layer = self.layer_index(layer)
+        d = (C.c_int64 * 4)()
+        L.check(L.lib().adas_engine_fetch_activation(self._h, layer, batch, None, d))
+        out = np.empty(list(d), np.float32)
+        L.check(L.lib().adas_engine_fetch_activation(self._h, layer, batch, L.ptr(out), d))
+        return out
+
+    def close(self):
+        if getattr(self, "_h", None):
+            L.lib().adas_engine_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+# Names the reference's detector modules import (yoloDetector.py:12,16; ultrafastLaneDetectorV2.py:7,13)
+OnnxEngine = HipEngine
+TensorRTEngine = HipEngine

@@ -1,0 +1,326 @@
+// aux_kernels.hip -- the non-GEMM ops of the detector / lane graphs, all HBM-bound streaming kernels:
+//   input_nchw   NCHW fp32 (the coreEngine.py seam layout) -> NHWC compute type, channels padded to 8
+//   maxpool      k x k / stride s over a channel-sliced NHWC view (ResNet stem 3x3 s2, SPPF 5x5 s1)
+//   upsample2    nearest x2, written straight into the consumer's concat slice
+//   detect_v8    DFL softmax-expectation + dist2bbox + sigmoid -> (N, 4+nc, A)   (yoloDetector.py:110-122 layout)
+//   detect_v5    sigmoid + grid/anchor decode -> (N, A, 5+nc)                    (yoloDetector.py:23,111)
+//   layernorm    model_culane.py:34 (fc_norm), one workgroup per frame
+//   nhwc_to_nchw parity tap
+#include "kernels.h"
+
+namespace adas {
+
+__device__ __forceinline__ float a_bf2f(uint16_t h) { return __uint_as_float((uint32_t)h << 16); }
+__device__ __forceinline__ uint16_t a_f2bf(float f) {
+    uint32_t u = __float_as_uint(f);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
+template <typename T> __device__ __forceinline__ float ld(const T* p);
+template <> __device__ __forceinline__ float ld<float>(const float* p) { return *p; }
+template <> __device__ __forceinline__ float ld<uint16_t>(const uint16_t* p) { return a_bf2f(*p); }
+template <typename T> __device__ __forceinline__ void st(T* p, float v);
+template <> __device__ __forceinline__ void st<float>(float* p, float v) { *p = v; }
+template <> __device__ __forceinline__ void st<uint16_t>(uint16_t* p, float v) { *p = a_f2bf(v); }
+
+// ------------------------------------------------------------------------------------- input
+template <typename T>
+__global__ void input_nchw_kernel(const float* __restrict__ src, T* __restrict__ dst, int n, int c_true, int hw, int cs) {
+    size_t total = (size_t)n * hw;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        size_t b = i / hw, p = i - b * hw;
+        T* o = dst + i * cs;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            float v = (c < c_true) ? src[(b * c_true + c) * hw + p] : 0.0f;
+            st<T>(o + c, v);
+        }
+    }
+}
+hipError_t launch_input_nchw(const float* nchw, TView out, int n, int c_true, int prec, hipStream_t st_) {
+    int hw = out.h * out.w;
+    size_t total = (size_t)n * hw;
+    int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+    if (out.c != 8 || out.coff != 0 || c_true > 8) return hipErrorInvalidValue;
+    if (prec == PREC_FP32)
+        hipLaunchKernelGGL(input_nchw_kernel<float>, dim3(blocks), dim3(256), 0, st_, nchw, (float*)out.p, n, c_true, hw, out.cs);
+    else
+        hipLaunchKernelGGL(input_nchw_kernel<uint16_t>, dim3(blocks), dim3(256), 0, st_, nchw, (uint16_t*)out.p, n, c_true, hw, out.cs);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------- maxpool / upsample
+struct PoolDev {
+    const void* in;
+    void* out;
+    int in_cs, in_coff, out_cs, out_coff, c, H, W, Ho, Wo, k, s, p, n;
+};
+// thread = (pixel, 8-channel group); padding behaves as -inf (torch.nn.MaxPool2d)
+template <typename T>
+__global__ void maxpool_kernel(PoolDev d) {
+    const int c8n = d.c >> 3;
+    size_t total = (size_t)d.n * d.Ho * d.Wo * c8n;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        int c8 = (int)(i % c8n);
+        size_t pix = i / c8n;
+        int ox = (int)(pix % d.Wo);
+        size_t t = pix / d.Wo;
+        int oy = (int)(t % d.Ho), b = (int)(t / d.Ho);
+        float m[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) m[q] = -3.0e38f;
+        for (int r = 0; r < d.k; ++r) {
+            int iy = oy * d.s - d.p + r;
+            if ((unsigned)iy >= (unsigned)d.H) continue;
+            for (int s = 0; s < d.k; ++s) {
+                int ix = ox * d.s - d.p + s;
+                if ((unsigned)ix >= (unsigned)d.W) continue;
+                const T* ip = (const T*)d.in + ((size_t)(b * d.H + iy) * d.W + ix) * d.in_cs + d.in_coff + c8 * 8;
+#pragma unroll
+                for (int q = 0; q < 8; ++q) m[q] = fmaxf(m[q], ld<T>(ip + q));
+            }
+        }
+        T* op = (T*)d.out + pix * d.out_cs + d.out_coff + c8 * 8;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) st<T>(op + q, m[q]);
+    }
+}
+hipError_t launch_maxpool(TView in, TView out, int n, int k, int s, int p, int prec, hipStream_t st_) {
+    if (in.c != out.c || (in.c & 7)) return hipErrorInvalidValue;
+    PoolDev d{in.p, out.p, in.cs, in.coff, out.cs, out.coff, in.c, in.h, in.w, out.h, out.w, k, s, p, n};
+    size_t total = (size_t)n * out.h * out.w * (in.c >> 3);
+    int blocks = (int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
+    if (prec == PREC_FP32)
+        hipLaunchKernelGGL(maxpool_kernel<float>, dim3(blocks), dim3(256), 0, st_, d);
+    else
+        hipLaunchKernelGGL(maxpool_kernel<uint16_t>, dim3(blocks), dim3(256), 0, st_, d);
+    return hipGetLastError();
+}
+
+template <typename T>
+__global__ void upsample2_kernel(PoolDev d) {
+    const int c8n = d.c >> 3;
+    size_t total = (size_t)d.n * d.Ho * d.Wo * c8n;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        int c8 = (int)(i % c8n);
+        size_t pix = i / c8n;
+        int ox = (int)(pix % d.Wo);
+        size_t t = pix / d.Wo;
+        int oy = (int)(t % d.Ho), b = (int)(t / d.Ho);
+        const T* ip = (const T*)d.in + ((size_t)(b * d.H + (oy >> 1)) * d.W + (ox >> 1)) * d.in_cs + d.in_coff + c8 * 8;
+        T* op = (T*)d.out + pix * d.out_cs + d.out_coff + c8 * 8;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) op[q] = ip[q];
+    }
+}
+hipError_t launch_upsample2(TView in, TView out, int n, int prec, hipStream_t st_) {
+    if (in.c != out.c || (in.c & 7) || out.h != 2 * in.h || out.w != 2 * in.w) return hipErrorInvalidValue;
+    PoolDev d{in.p, out.p, in.cs, in.coff, out.cs, out.coff, in.c, in.h, in.w, out.h, out.w, 0, 0, 0, n};
+    size_t total = (size_t)n * out.h * out.w * (in.c >> 3);
+    int blocks = (int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
+    if (prec == PREC_FP32)
+        hipLaunchKernelGGL(upsample2_kernel<float>, dim3(blocks), dim3(256), 0, st_, d);
+    else
+        hipLaunchKernelGGL(upsample2_kernel<uint16_t>, dim3(blocks), dim3(256), 0, st_, d);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------- Detect (v8)
+struct DetV8Dev {
+    const float* box[3];
+    const float* cls[3];
+    int box_cs[3], cls_cs[3];
+    int hw[3], w[3], stride[3], a_off[3];
+    float* out;
+    int nc, A, n;
+};
+// workgroup = 64 consecutive anchors of one level of one frame.
+__global__ __launch_bounds__(256) void detect_v8_kernel(DetV8Dev d) {
+    __shared__ float s_box[64][65];
+    __shared__ float s_dist[64][4];
+    const int tid = threadIdx.x;
+    const int b = blockIdx.y;
+    // find level
+    int blk = blockIdx.x, lvl = 0;
+    for (; lvl < 3; ++lvl) {
+        int nb = (d.hw[lvl] + 63) / 64;
+        if (blk < nb) break;
+        blk -= nb;
+    }
+    const int p0 = blk * 64;
+    const int np = min(64, d.hw[lvl] - p0);
+    const float* box = d.box[lvl] + ((size_t)b * d.hw[lvl] + p0) * d.box_cs[lvl];
+    const float* cls = d.cls[lvl] + ((size_t)b * d.hw[lvl] + p0) * d.cls_cs[lvl];
+    for (int i = tid; i < np * 64; i += 256) s_box[i >> 6][i & 63] = box[(size_t)(i >> 6) * d.box_cs[lvl] + (i & 63)];
+    __syncthreads();
+    {   // DFL: softmax over 16 bins, expectation with arange(16)
+        int p = tid >> 2, side = tid & 3;
+        if (p < np) {
+            const float* v = &s_box[p][side * 16];
+            float mx = v[0];
+#pragma unroll
+            for (int k = 1; k < 16; ++k) mx = fmaxf(mx, v[k]);
+            float se = 0.f, sw = 0.f;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                float e = expf(v[k] - mx);
+                se += e;
+                sw += e * (float)k;
+            }
+            s_dist[p][side] = sw / se;
+        }
+    }
+    __syncthreads();
+    float* out = d.out + (size_t)b * (4 + d.nc) * d.A + d.a_off[lvl] + p0;
+    if (tid < 64 && tid < np) {
+        int p = p0 + tid;
+        float ax = (float)(p % d.w[lvl]) + 0.5f, ay = (float)(p / d.w[lvl]) + 0.5f;
+        float x1 = ax - s_dist[tid][0], y1 = ay - s_dist[tid][1];
+        float x2 = ax + s_dist[tid][2], y2 = ay + s_dist[tid][3];
+        float s = (float)d.stride[lvl];
+        out[(size_t)0 * d.A + tid] = (x1 + x2) / 2 * s;
+        out[(size_t)1 * d.A + tid] = (y1 + y2) / 2 * s;
+        out[(size_t)2 * d.A + tid] = (x2 - x1) * s;
+        out[(size_t)3 * d.A + tid] = (y2 - y1) * s;
+    }
+    // class probabilities: out[(4+c)*A + anchor] = sigmoid(cls[anchor][c]); stage through LDS for coalesced stores
+    for (int c0 = 0; c0 < d.nc; c0 += 64) {
+        __syncthreads();
+        int cw = min(64, d.nc - c0);
+        for (int i = tid; i < np * cw; i += 256) {
+            int p = i / cw, c = i - p * cw;
+            float v = cls[(size_t)p * d.cls_cs[lvl] + c0 + c];
+            s_box[c][p] = 1.0f / (1.0f + expf(-v));
+        }
+        __syncthreads();
+        for (int i = tid; i < cw * 64; i += 256) {
+            int c = i >> 6, p = i & 63;
+            if (p < np) out[(size_t)(4 + c0 + c) * d.A + p] = s_box[c][p];
+        }
+    }
+}
+hipError_t launch_detect_v8(const TView* ins, float* out, int n, int nc, int A, const int strides[3], hipStream_t st_) {
+    DetV8Dev d;
+    int off = 0, blocks = 0;
+    for (int l = 0; l < 3; ++l) {
+        const TView& b = ins[2 * l];
+        const TView& c = ins[2 * l + 1];
+        if (!b.f32 || !c.f32 || b.c != 64 || c.c != nc || b.coff || c.coff) return hipErrorInvalidValue;
+        d.box[l] = (const float*)b.p; d.cls[l] = (const float*)c.p;
+        d.box_cs[l] = b.cs; d.cls_cs[l] = c.cs;
+        d.hw[l] = b.h * b.w; d.w[l] = b.w; d.stride[l] = strides[l]; d.a_off[l] = off;
+        off += d.hw[l];
+        blocks += (d.hw[l] + 63) / 64;
+    }
+    if (off != A) return hipErrorInvalidValue;
+    d.out = out; d.nc = nc; d.A = A; d.n = n;
+    hipLaunchKernelGGL(detect_v8_kernel, dim3(blocks, n), dim3(256), 0, st_, d);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------- Detect (v5)
+struct DetV5Dev {
+    const float* in[3];
+    int cs[3], ny[3], nx[3], stride[3], row_off[3];
+    const float* anchors;
+    float* out;
+    int nc, A, n;
+};
+__global__ void detect_v5_kernel(DetV5Dev d) {
+    const int no = d.nc + 5;
+    const int b = blockIdx.y;
+    size_t per_frame = (size_t)d.A * no;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < per_frame; i += (size_t)gridDim.x * blockDim.x) {
+        int row = (int)(i / no), c = (int)(i - (size_t)row * no);
+        int l = (row >= d.row_off[2]) ? 2 : (row >= d.row_off[1] ? 1 : 0);
+        int r = row - d.row_off[l];
+        int hw = d.ny[l] * d.nx[l];
+        int a = r / hw, p = r - a * hw;
+        int y = p / d.nx[l], x = p - y * d.nx[l];
+        float v = d.in[l][((size_t)b * hw + p) * d.cs[l] + a * no + c];
+        float s = 1.0f / (1.0f + expf(-v));
+        float o;
+        if (c == 0) o = (s * 2.0f - 0.5f + (float)x) * (float)d.stride[l];
+        else if (c == 1) o = (s * 2.0f - 0.5f + (float)y) * (float)d.stride[l];
+        else if (c < 4) { float t = s * 2.0f; o = t * t * d.anchors[l * 6 + a * 2 + (c - 2)]; }
+        else o = s;
+        d.out[(size_t)b * per_frame + i] = o;
+    }
+}
+hipError_t launch_detect_v5(const TView* ins, float* out, int n, int nc, int A, const int strides[3], const float* d_anchors,
+                            hipStream_t st_) {
+    DetV5Dev d;
+    int off = 0;
+    for (int l = 0; l < 3; ++l) {
+        if (!ins[l].f32 || ins[l].c != 3 * (nc + 5) || ins[l].coff) return hipErrorInvalidValue;
+        d.in[l] = (const float*)ins[l].p; d.cs[l] = ins[l].cs; d.ny[l] = ins[l].h; d.nx[l] = ins[l].w;
+        d.stride[l] = strides[l]; d.row_off[l] = off;
+        off += 3 * ins[l].h * ins[l].w;
+    }
+    if (off != A) return hipErrorInvalidValue;
+    d.anchors = d_anchors; d.out = out; d.nc = nc; d.A = A; d.n = n;
+    hipLaunchKernelGGL(detect_v5_kernel, dim3(2048, n), dim3(256), 0, st_, d);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------- LayerNorm
+template <typename T>
+__global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ in, T* __restrict__ out,
+                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                        int len, float eps) {
+    __shared__ float red[8];
+    const float* x = in + (size_t)blockIdx.x * len;
+    T* y = out + (size_t)blockIdx.x * len;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    float s = 0.f;
+    for (int i = tid; i < len; i += 256) s += x[i];
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
+    if (lane == 0) red[wv] = s;
+    __syncthreads();
+    const float mean = (red[0] + red[1] + red[2] + red[3]) / (float)len;
+    __syncthreads();
+    float v = 0.f;
+    for (int i = tid; i < len; i += 256) {
+        float dlt = x[i] - mean;
+        v += dlt * dlt;
+    }
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    if (lane == 0) red[4 + wv] = v;
+    __syncthreads();
+    const float var = (red[4] + red[5] + red[6] + red[7]) / (float)len;
+    const float rstd = 1.0f / sqrtf(var + eps);
+    for (int i = tid; i < len; i += 256) st<T>(y + i, (x[i] - mean) * rstd * gamma[i] + beta[i]);
+}
+hipError_t launch_layernorm(const float* in, void* out, const float* gamma, const float* beta, int n, int len, float eps,
+                            int prec, hipStream_t st_) {
+    if (prec == PREC_FP32)
+        hipLaunchKernelGGL(layernorm_kernel<float>, dim3(n), dim3(256), 0, st_, in, (float*)out, gamma, beta, len, eps);
+    else
+        hipLaunchKernelGGL(layernorm_kernel<uint16_t>, dim3(n), dim3(256), 0, st_, in, (uint16_t*)out, gamma, beta, len, eps);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------- parity tap
+template <typename T>
+__global__ void nhwc_to_nchw_kernel(const T* __restrict__ in, float* __restrict__ out, int n, int hw, int c, int cs, int coff) {
+    size_t total = (size_t)n * c * hw;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        size_t p = i % hw;
+        size_t t = i / hw;
+        int ch = (int)(t % c);
+        size_t b = t / c;
+        out[i] = ld<T>(in + (b * hw + p) * cs + coff + ch);
+    }
+}
+hipError_t launch_nhwc_to_nchw(TView in, float* out, int n, int prec, hipStream_t st_) {
+    int hw = in.h * in.w;
+    size_t total = (size_t)n * in.c * hw;
+    int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+    if (in.f32 || prec == PREC_FP32)
+        hipLaunchKernelGGL(nhwc_to_nchw_kernel<float>, dim3(blocks), dim3(256), 0, st_, (const float*)in.p, out, n, hw, in.c, in.cs, in.coff);
+    else
+        hipLaunchKernelGGL(nhwc_to_nchw_kernel<uint16_t>, dim3(blocks), dim3(256), 0, st_, (const uint16_t*)in.p, out, n, hw, in.c, in.cs, in.coff);
+    return hipGetLastError();
+}
+
+}  // namespace adas

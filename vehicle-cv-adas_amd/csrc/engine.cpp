@@ -1,23 +1,383 @@
-// TEMPORARY: engine + pipeline entry points land in the next milestone.
-#include "common.h"
-#define NI(name) adas::set_error(name ": not implemented yet"); return ADAS_ERR_INVALID
-extern "C" {
-int adas_engine_create(const char*, int, int, adas_engine**) { NI("adas_engine_create"); }
-int adas_engine_destroy(adas_engine*) { return ADAS_OK; }
-int adas_engine_input_shape(const adas_engine*, int64_t*) { NI("adas_engine_input_shape"); }
-int adas_engine_num_outputs(const adas_engine*) { return 0; }
-int adas_engine_output_shape(const adas_engine*, int, int64_t*, int*) { NI("adas_engine_output_shape"); }
-const char* adas_engine_output_name(const adas_engine*, int) { return ""; }
-int adas_engine_infer_host(adas_engine*, const float*, int, float* const*) { NI("adas_engine_infer_host"); }
-int adas_engine_infer_device(adas_engine*, const float*, int, void*) { NI("adas_engine_infer_device"); }
-const float* adas_engine_output_device(const adas_engine*, int) { return nullptr; }
-int adas_engine_stats(const adas_engine*, double*, double*, int*) { NI("adas_engine_stats"); }
-int adas_engine_profile(adas_engine*, const float*, int, int, float*, int, int*) { NI("adas_engine_profile"); }
-int adas_engine_layer_info(const adas_engine*, int, char*, int, double*, int*) { NI("adas_engine_layer_info"); }
-int adas_engine_fetch_activation(adas_engine*, int, int, float*, int64_t*) { NI("adas_engine_fetch_activation"); }
-int adas_pipeline_create(const adas_pipeline_desc*, adas_pipeline**) { NI("adas_pipeline_create"); }
-int adas_pipeline_destroy(adas_pipeline*) { return ADAS_OK; }
-int adas_pipeline_step(adas_pipeline*, const float*, const float*) { NI("adas_pipeline_step"); }
-int adas_pipeline_sync(adas_pipeline*) { NI("adas_pipeline_sync"); }
-int adas_pipeline_timings(adas_pipeline*, float*) { NI("adas_pipeline_timings"); }
+// engine.cpp -- HipEngine: loads an ADASHIP1 model container and runs it on one MI355X.
+// Replaces EngineBase / OnnxEngine / TensorRTEngine (coreEngine.py:7-39,120-186): same surface
+// (input shape, output shapes+names, inference on an NCHW tensor), plus a device-resident form.
+// Memory plan: every graph buffer gets its own HBM allocation sized for max_batch frames (the nets
+// are tiny against 288 GB); weights are packed once on the device into the compute type with K
+// padded to 32 and Cout to 128 so the conv kernel needs no bounds checks on the weight side.
+#include "engine.h"
+#include <errno.h>
+#include <stdlib.h>
+#include <string.h>
+#include <string>
+#include <vector>
+
+using namespace adas;
+
+static size_t elem_size(const adas_engine* e, const EngBuf& b) { return (b.f32 || e->prec == PREC_FP32) ? 4 : 2; }
+
+static TView make_view(const adas_engine* e, int buf, int coff, int c) {
+    const EngBuf& b = e->bufs[buf];
+    TView v;
+    v.p = b.d;
+    v.cs = b.c;
+    v.coff = coff;
+    v.c = c;
+    v.h = b.h;
+    v.w = b.w;
+    v.f32 = b.f32 ? 1 : 0;
+    return v;
 }
+
+static int free_engine(adas_engine* e) {
+    if (!e) return ADAS_OK;
+    for (auto& b : e->bufs)
+        if (b.d) (void)hipFree(b.d);
+    if (e->d_weights) (void)hipFree(e->d_weights);
+    if (e->d_input) (void)hipFree(e->d_input);
+    for (auto& ev : e->events)
+        if (ev) (void)hipEventDestroy(ev);
+    delete e;
+    return ADAS_OK;
+}
+
+extern "C" {
+
+int adas_engine_create(const char* model_path, int precision, int max_batch, adas_engine** out) {
+    ADAS_REQUIRE(model_path && out && max_batch > 0, ADAS_ERR_INVALID, "adas_engine_create: bad argument");
+    ADAS_REQUIRE(precision == ADAS_PREC_BF16 || precision == ADAS_PREC_FP32, ADAS_ERR_INVALID, "unknown precision %d", precision);
+    FILE* f = fopen(model_path, "rb");
+    if (!f) {  // coreEngine.py:12-13
+        set_error("The model path [%s] can't not found! (%s)", model_path, strerror(errno));
+        return ADAS_ERR_IO;
+    }
+    FileHeader hd;
+    if (fread(&hd, sizeof(hd), 1, f) != 1 || memcmp(hd.magic, "ADASHIP1", 8) != 0 || hd.version != 1) {
+        fclose(f);
+        set_error("[%s] is not an ADASHIP1 model container (ONNX/TensorRT import is not implemented; "
+                  "build one with vehicle-cv-adas_amd/models.py)", model_path);
+        return ADAS_ERR_FORMAT;
+    }
+    ADAS_REQUIRE(adas_device_count() > 0, (fclose(f), ADAS_ERR_NO_DEVICE), "no HIP device visible; this library has no CPU fallback");
+    adas_engine* e = new adas_engine();
+    e->prec = precision;
+    e->max_batch = max_batch;
+    e->hdr = hd;
+    e->name = std::string(hd.name, strnlen(hd.name, sizeof(hd.name)));
+    std::vector<FileBuf> fb(hd.n_bufs);
+    std::vector<FileOp> fo(hd.n_ops);
+    std::vector<FileOut> fout(hd.n_outputs);
+    bool ok = fread(fb.data(), sizeof(FileBuf), hd.n_bufs, f) == hd.n_bufs && fread(fo.data(), sizeof(FileOp), hd.n_ops, f) == hd.n_ops &&
+              fread(fout.data(), sizeof(FileOut), hd.n_outputs, f) == hd.n_outputs;
+    if (!ok) {
+        fclose(f);
+        free_engine(e);
+        set_error("[%s]: truncated model container", model_path);
+        return ADAS_ERR_FORMAT;
+    }
+    // ---- buffers
+    for (auto& b : fb) {
+        EngBuf eb;
+        eb.h = b.h; eb.w = b.w; eb.c = b.c; eb.f32 = (b.flags & 1) != 0; eb.d = nullptr;
+        e->bufs.push_back(eb);
+    }
+    for (auto& b : e->bufs) {
+        size_t bytes = (size_t)max_batch * b.h * b.w * b.c * elem_size(e, b);
+        if (hipMalloc(&b.d, bytes + 256) != hipSuccess) {
+            fclose(f);
+            free_engine(e);
+            return hip_fail(hipGetLastError(), "hipMalloc(activation buffer)", __FILE__, __LINE__);
+        }
+        (void)hipMemset(b.d, 0, bytes + 256);
+        e->act_bytes += bytes;
+    }
+    // ---- weights: stream the fp32 blob through a staging buffer, pack on the device
+    size_t packed_total = 0;
+    const size_t esz = precision == PREC_FP32 ? 4 : 2;
+    for (auto& o : fo) {
+        EngOp op;
+        op.f = o;
+        op.name = std::string(o.name, strnlen(o.name, sizeof(o.name)));
+        op.w_off = op.b_off = 0;
+        if (o.type == OP_CONV) {
+            int cin = o.in_c[0], cout = o.out_c;
+            op.k = o.kh * o.kw * cin;
+            op.kpad = (op.k + 31) / 32 * 32;
+            op.cout_pad = (cout + 127) / 128 * 128;
+            op.w_off = packed_total;
+            packed_total += ((size_t)op.cout_pad * op.kpad * esz + 255) & ~(size_t)255;
+            op.b_off = packed_total;
+            packed_total += ((size_t)op.cout_pad * 4 + 255) & ~(size_t)255;
+        } else if (o.type == OP_LAYERNORM) {
+            op.w_off = packed_total;
+            packed_total += ((size_t)o.w_elems * 4 + 255) & ~(size_t)255;
+            op.b_off = packed_total;
+            packed_total += ((size_t)o.b_elems * 4 + 255) & ~(size_t)255;
+        } else if (o.type == OP_DETECT_V5) {
+            op.w_off = packed_total;
+            packed_total += 256;
+        }
+        e->ops.push_back(op);
+    }
+    e->weight_bytes = packed_total;
+    if (hipMalloc(&e->d_weights, packed_total + 256) != hipSuccess) {
+        fclose(f);
+        free_engine(e);
+        return hip_fail(hipGetLastError(), "hipMalloc(weights)", __FILE__, __LINE__);
+    }
+    (void)hipMemset(e->d_weights, 0, packed_total + 256);
+    size_t max_w = 0;
+    for (auto& o : fo) max_w = o.w_elems > max_w ? (size_t)o.w_elems : max_w;
+    float* d_stage = nullptr;
+    std::vector<float> h_stage(max_w ? max_w : 1);
+    if (hipMalloc((void**)&d_stage, max_w * 4 + 256) != hipSuccess) {
+        fclose(f);
+        free_engine(e);
+        return hip_fail(hipGetLastError(), "hipMalloc(weight staging)", __FILE__, __LINE__);
+    }
+    int rc = ADAS_OK;
+    for (auto& op : e->ops) {
+        const FileOp& o = op.f;
+        unsigned char* base = (unsigned char*)e->d_weights;
+        auto read_blob = [&](uint64_t off, uint64_t elems, float* dst) -> bool {
+            if (fseek(f, (long)(hd.weights_off + off), SEEK_SET) != 0) return false;
+            return fread(dst, 4, elems, f) == elems;
+        };
+        if (o.type == OP_CONV) {
+            if (!read_blob(o.w_off, o.w_elems, h_stage.data()) || o.w_elems != (uint64_t)o.out_c * op.k) { rc = ADAS_ERR_FORMAT; break; }
+            if (hipMemcpy(d_stage, h_stage.data(), o.w_elems * 4, hipMemcpyHostToDevice) != hipSuccess) { rc = ADAS_ERR_HIP; break; }
+            if (launch_pack_weights(d_stage, base + op.w_off, o.out_c, op.cout_pad, op.k, op.kpad, precision, 0) != hipSuccess) { rc = ADAS_ERR_HIP; break; }
+            if (hipDeviceSynchronize() != hipSuccess) { rc = ADAS_ERR_HIP; break; }
+            std::vector<float> b(op.cout_pad, 0.f);
+            if (!read_blob(o.b_off, o.b_elems, b.data())) { rc = ADAS_ERR_FORMAT; break; }
+            if (hipMemcpy(base + op.b_off, b.data(), (size_t)op.cout_pad * 4, hipMemcpyHostToDevice) != hipSuccess) { rc = ADAS_ERR_HIP; break; }
+        } else if (o.type == OP_LAYERNORM) {
+            if (!read_blob(o.w_off, o.w_elems, h_stage.data())) { rc = ADAS_ERR_FORMAT; break; }
+            if (hipMemcpy(base + op.w_off, h_stage.data(), o.w_elems * 4, hipMemcpyHostToDevice) != hipSuccess) { rc = ADAS_ERR_HIP; break; }
+            if (!read_blob(o.b_off, o.b_elems, h_stage.data())) { rc = ADAS_ERR_FORMAT; break; }
+            if (hipMemcpy(base + op.b_off, h_stage.data(), o.b_elems * 4, hipMemcpyHostToDevice) != hipSuccess) { rc = ADAS_ERR_HIP; break; }
+        } else if (o.type == OP_DETECT_V5) {
+            float anc[18];
+            if (o.w_elems != 18 || !read_blob(o.w_off, 18, anc)) { rc = ADAS_ERR_FORMAT; break; }
+            if (hipMemcpy(base + op.w_off, anc, sizeof(anc), hipMemcpyHostToDevice) != hipSuccess) { rc = ADAS_ERR_HIP; break; }
+        }
+    }
+    (void)hipFree(d_stage);
+    fclose(f);
+    if (rc != ADAS_OK) {
+        set_error("[%s]: failed while loading weights (%s)", model_path, rc == ADAS_ERR_HIP ? hipGetErrorString(hipGetLastError()) : "bad blob");
+        free_engine(e);
+        return rc;
+    }
+    // ---- outputs
+    for (auto& o : fout) {
+        EngOut eo;
+        eo.buf = o.buf; eo.offset = o.offset; eo.ndim = o.ndim;
+        for (int i = 0; i < 4; ++i) eo.dims[i] = o.dims[i];
+        eo.elems = 1;
+        for (int i = 1; i < (int)o.ndim; ++i) eo.elems *= o.dims[i];
+        eo.name = std::string(o.name, strnlen(o.name, sizeof(o.name)));
+        if (o.buf >= e->bufs.size() || !e->bufs[o.buf].f32) {
+            set_error("[%s]: output %s is not an fp32 buffer", model_path, eo.name.c_str());
+            free_engine(e);
+            return ADAS_ERR_FORMAT;
+        }
+        e->outs.push_back(eo);
+    }
+    size_t in_bytes = (size_t)max_batch * hd.in_c * hd.in_h * hd.in_w * 4;
+    if (hipMalloc((void**)&e->d_input, in_bytes) != hipSuccess) {
+        free_engine(e);
+        return hip_fail(hipGetLastError(), "hipMalloc(input staging)", __FILE__, __LINE__);
+    }
+    *out = e;
+    return ADAS_OK;
+}
+
+int adas_engine_destroy(adas_engine* e) { return free_engine(e); }
+
+int adas_engine_input_shape(const adas_engine* e, int64_t dims[4]) {
+    ADAS_REQUIRE(e && dims, ADAS_ERR_INVALID, "null argument");
+    dims[0] = 1; dims[1] = e->hdr.in_c; dims[2] = e->hdr.in_h; dims[3] = e->hdr.in_w;
+    return ADAS_OK;
+}
+int adas_engine_num_outputs(const adas_engine* e) { return e ? (int)e->outs.size() : 0; }
+int adas_engine_output_shape(const adas_engine* e, int index, int64_t dims[4], int* ndim) {
+    ADAS_REQUIRE(e && dims && ndim && index >= 0 && index < (int)e->outs.size(), ADAS_ERR_INVALID, "bad output index");
+    for (int i = 0; i < 4; ++i) dims[i] = e->outs[index].dims[i];
+    *ndim = e->outs[index].ndim;
+    return ADAS_OK;
+}
+const char* adas_engine_output_name(const adas_engine* e, int index) {
+    if (!e || index < 0 || index >= (int)e->outs.size()) return "";
+    return e->outs[index].name.c_str();
+}
+int adas_engine_stats(const adas_engine* e, double* flops, double* wbytes, int* nl) {
+    ADAS_REQUIRE(e, ADAS_ERR_INVALID, "null engine");
+    if (flops) *flops = e->hdr.flops;
+    if (wbytes) *wbytes = (double)e->weight_bytes;
+    if (nl) *nl = (int)e->ops.size();
+    return ADAS_OK;
+}
+int adas_engine_layer_info(const adas_engine* e, int layer, char* name, int cap, double* flops, int* kind) {
+    ADAS_REQUIRE(e && layer >= 0 && layer < (int)e->ops.size(), ADAS_ERR_INVALID, "bad layer index");
+    if (name && cap > 0) snprintf(name, cap, "%s", e->ops[layer].name.c_str());
+    if (flops) *flops = e->ops[layer].f.flops;
+    if (kind) *kind = (int)e->ops[layer].f.type;
+    return ADAS_OK;
+}
+
+}  // extern "C"
+
+// ------------------------------------------------------------------------------------- execution
+namespace adas {
+int engine_run_op(adas_engine* e, int i, const float* d_in, int batch, hipStream_t st) {
+    EngOp& op = e->ops[i];
+    const FileOp& o = op.f;
+    unsigned char* wb = (unsigned char*)e->d_weights;
+    hipError_t err = hipSuccess;
+    switch (o.type) {
+        case OP_INPUT:
+            err = launch_input_nchw(d_in, make_view(e, o.out_buf, 0, 8), batch, e->hdr.in_c, e->prec, st);
+            break;
+        case OP_CONV: {
+            ConvArgs a;
+            a.in = make_view(e, o.in_buf[0], o.in_coff[0], o.in_c[0]);
+            a.out = make_view(e, o.out_buf, o.out_coff, o.out_c);
+            if (o.res_mode != RES_NONE) a.res = make_view(e, o.res_buf, o.res_coff, o.out_c);
+            else { a.res = a.out; a.res.p = nullptr; }
+            a.wgt = wb + op.w_off;
+            a.bias = (const float*)(wb + op.b_off);
+            a.n = batch; a.kh = o.kh; a.kw = o.kw; a.stride = o.stride; a.pad = o.pad; a.act = o.act; a.res_mode = o.res_mode;
+            a.k = op.k; a.kpad = op.kpad; a.m = batch * a.out.h * a.out.w;
+            err = launch_conv(a, e->prec, st);
+            break;
+        }
+        case OP_MAXPOOL:
+            err = launch_maxpool(make_view(e, o.in_buf[0], o.in_coff[0], o.in_c[0]), make_view(e, o.out_buf, o.out_coff, o.out_c), batch,
+                                 o.kh, o.stride, o.pad, e->prec, st);
+            break;
+        case OP_UPSAMPLE2:
+            err = launch_upsample2(make_view(e, o.in_buf[0], o.in_coff[0], o.in_c[0]), make_view(e, o.out_buf, o.out_coff, o.out_c), batch,
+                                   e->prec, st);
+            break;
+        case OP_DETECT_V8: {
+            TView ins[6];
+            for (int k = 0; k < 6; ++k) ins[k] = make_view(e, o.in_buf[k], o.in_coff[k], o.in_c[k]);
+            int strides[3] = {(int)o.params[2], (int)o.params[3], (int)o.params[4]};
+            err = launch_detect_v8(ins, (float*)e->bufs[o.out_buf].d, batch, (int)o.params[0], (int)o.params[1], strides, st);
+            break;
+        }
+        case OP_DETECT_V5: {
+            TView ins[3];
+            for (int k = 0; k < 3; ++k) ins[k] = make_view(e, o.in_buf[k], o.in_coff[k], o.in_c[k]);
+            int strides[3] = {(int)o.params[2], (int)o.params[3], (int)o.params[4]};
+            err = launch_detect_v5(ins, (float*)e->bufs[o.out_buf].d, batch, (int)o.params[0], (int)o.params[1], strides,
+                                   (const float*)(wb + op.w_off), st);
+            break;
+        }
+        case OP_LAYERNORM: {
+            const EngBuf& ib = e->bufs[o.in_buf[0]];
+            int len = ib.h * ib.w * ib.c;
+            if (!ib.f32) { set_error("layernorm input must be fp32"); return ADAS_ERR_FORMAT; }
+            err = launch_layernorm((const float*)ib.d, e->bufs[o.out_buf].d, (const float*)(wb + op.w_off), (const float*)(wb + op.b_off),
+                                   batch, len, o.params[0], e->prec, st);
+            break;
+        }
+        default:
+            set_error("unknown op type %u in layer %d (%s)", o.type, i, op.name.c_str());
+            return ADAS_ERR_FORMAT;
+    }
+    if (err != hipSuccess) {
+        set_error("layer %d (%s): launch failed: %s", i, op.name.c_str(), hipGetErrorString(err));
+        (void)hipGetLastError();
+        return ADAS_ERR_HIP;
+    }
+    return ADAS_OK;
+}
+
+int engine_forward(adas_engine* e, const float* d_in, int batch, hipStream_t st) {
+    for (int i = 0; i < (int)e->ops.size(); ++i) {
+        int rc = engine_run_op(e, i, d_in, batch, st);
+        if (rc != ADAS_OK) return rc;
+    }
+    return ADAS_OK;
+}
+}  // namespace adas
+
+extern "C" {
+
+int adas_engine_infer_device(adas_engine* e, const float* d_input, int batch, void* stream) {
+    ADAS_REQUIRE(e && d_input && batch > 0 && batch <= e->max_batch, ADAS_ERR_INVALID, "adas_engine_infer_device: bad argument (batch %d, max %d)", batch,
+                 e ? e->max_batch : 0);
+    e->last = (hipStream_t)stream;
+    return engine_forward(e, d_input, batch, (hipStream_t)stream);
+}
+
+const float* adas_engine_output_device(const adas_engine* e, int index) {
+    if (!e || index < 0 || index >= (int)e->outs.size()) return nullptr;
+    const EngOut& o = e->outs[index];
+    return (const float*)e->bufs[o.buf].d + o.offset;
+}
+
+int adas_engine_infer_host(adas_engine* e, const float* h_input, int batch, float* const* h_outputs) {
+    ADAS_REQUIRE(e && h_input && h_outputs && batch > 0 && batch <= e->max_batch, ADAS_ERR_INVALID, "adas_engine_infer_host: bad argument");
+    size_t in_bytes = (size_t)batch * e->hdr.in_c * e->hdr.in_h * e->hdr.in_w * 4;
+    ADAS_HIP_TRY(hipMemcpyAsync(e->d_input, h_input, in_bytes, hipMemcpyHostToDevice, 0));
+    int rc = adas_engine_infer_device(e, e->d_input, batch, nullptr);
+    if (rc != ADAS_OK) return rc;
+    for (size_t i = 0; i < e->outs.size(); ++i) {
+        const EngOut& o = e->outs[i];
+        const EngBuf& b = e->bufs[o.buf];
+        size_t frame_stride = (size_t)b.h * b.w * b.c;  // floats per frame in the backing buffer
+        ADAS_HIP_TRY(hipMemcpy2DAsync(h_outputs[i], o.elems * 4, (const float*)b.d + o.offset, frame_stride * 4, o.elems * 4, batch,
+                                      hipMemcpyDeviceToHost, 0));
+    }
+    ADAS_HIP_TRY(hipStreamSynchronize(0));
+    return ADAS_OK;
+}
+
+int adas_engine_profile(adas_engine* e, const float* d_input, int batch, int iters, float* ms_per_layer, int max_layers, int* num_layers) {
+    ADAS_REQUIRE(e && d_input && batch > 0 && batch <= e->max_batch && iters > 0 && ms_per_layer, ADAS_ERR_INVALID, "adas_engine_profile: bad argument");
+    const int n = (int)e->ops.size();
+    ADAS_REQUIRE(max_layers >= n, ADAS_ERR_INVALID, "need room for %d layers", n);
+    if ((int)e->events.size() < n + 1) {
+        e->events.resize(n + 1, nullptr);
+        for (auto& ev : e->events)
+            if (!ev) ADAS_HIP_TRY(hipEventCreate(&ev));
+    }
+    for (int i = 0; i < n; ++i) ms_per_layer[i] = 0.f;
+    for (int it = 0; it < iters; ++it) {
+        ADAS_HIP_TRY(hipEventRecord(e->events[0], 0));
+        for (int i = 0; i < n; ++i) {
+            int rc = engine_run_op(e, i, d_input, batch, 0);
+            if (rc != ADAS_OK) return rc;
+            ADAS_HIP_TRY(hipEventRecord(e->events[i + 1], 0));
+        }
+        ADAS_HIP_TRY(hipStreamSynchronize(0));
+        for (int i = 0; i < n; ++i) {
+            float ms = 0.f;
+            ADAS_HIP_TRY(hipEventElapsedTime(&ms, e->events[i], e->events[i + 1]));
+            ms_per_layer[i] += ms / (float)iters;
+        }
+    }
+    if (num_layers) *num_layers = n;
+    return ADAS_OK;
+}
+
+int adas_engine_fetch_activation(adas_engine* e, int layer, int batch, float* h_out, int64_t dims[4]) {
+    ADAS_REQUIRE(e && layer >= 0 && layer < (int)e->ops.size() && batch > 0 && batch <= e->max_batch, ADAS_ERR_INVALID, "bad layer/batch");
+    const FileOp& o = e->ops[layer].f;
+    TView v = make_view(e, o.out_buf, o.out_coff, o.out_c);
+    if (o.type == OP_INPUT) v.c = 8;
+    if (dims) { dims[0] = batch; dims[1] = v.c; dims[2] = v.h; dims[3] = v.w; }
+    if (!h_out) return ADAS_OK;
+    size_t n = (size_t)batch * v.c * v.h * v.w;
+    float* d_tmp = nullptr;
+    ADAS_HIP_TRY(hipMalloc((void**)&d_tmp, n * 4));
+    hipError_t err = launch_nhwc_to_nchw(v, d_tmp, batch, e->prec, 0);
+    if (err == hipSuccess) err = hipMemcpy(h_out, d_tmp, n * 4, hipMemcpyDeviceToHost);
+    (void)hipFree(d_tmp);
+    if (err != hipSuccess) return hip_fail(err, "fetch_activation", __FILE__, __LINE__);
+    return ADAS_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,50 @@
+// kernels.h -- launch interfaces of the network kernels (conv_kernels.hip, aux_kernels.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace adas {
+
+enum { PREC_BF16 = 0, PREC_FP32 = 1 };
+enum { ACT_NONE = 0, ACT_SILU = 1, ACT_RELU = 2 };
+enum { RES_NONE = 0, RES_AFTER_ACT = 1, RES_BEFORE_ACT = 2 };
+
+// One NHWC tensor view: channel slice [coff, coff+c) of a buffer whose pixel stride is `cs` elements.
+struct TView {
+    void* p;
+    int cs, coff, c;
+    int h, w;
+    int f32;  // storage is fp32 regardless of the engine precision
+};
+
+struct ConvArgs {
+    TView in, out, res;
+    const void* wgt;    // [cout_pad][kpad] in the compute type, K = (r*kw+s)*cin + c
+    const float* bias;  // [cout_pad]
+    int n;              // batch
+    int kh, kw, stride, pad, act, res_mode;
+    int k, kpad, m;     // K = kh*kw*cin ; padded to 32 ; M = n*ho*wo
+};
+
+// returns hipSuccess or the launch error.  prec: PREC_*.
+hipError_t launch_conv(const ConvArgs& a, int prec, hipStream_t st);
+const char* conv_tile_name(const ConvArgs& a, int prec);
+
+hipError_t launch_input_nchw(const float* nchw, TView out, int n, int c_true, int prec, hipStream_t st);
+hipError_t launch_maxpool(TView in, TView out, int n, int k, int s, int p, int prec, hipStream_t st);
+hipError_t launch_upsample2(TView in, TView out, int n, int prec, hipStream_t st);
+// YOLOv8 Detect decode: ins = {box0, cls0, box1, cls1, box2, cls2} fp32 logits NHWC; out fp32 [n][4+nc][A]
+hipError_t launch_detect_v8(const TView* ins, float* out, int n, int nc, int A, const int strides[3], hipStream_t st);
+// YOLOv5 Detect decode: ins = 3 fp32 maps [n][ny][nx][3*(5+nc)]; out fp32 [n][A][5+nc]; anchors[18] device
+hipError_t launch_detect_v5(const TView* ins, float* out, int n, int nc, int A, const int strides[3],
+                            const float* d_anchors, hipStream_t st);
+// LayerNorm over the flat per-frame vector (len elements, fp32 in) -> compute type out
+hipError_t launch_layernorm(const float* in, void* out, const float* gamma, const float* beta, int n, int len, float eps,
+                            int prec, hipStream_t st);
+// fp32 -> compute-type weight packing on the device: src [cout][k] fp32, dst [cout_pad][kpad] (zero padded)
+hipError_t launch_pack_weights(const float* src, void* dst, int cout, int cout_pad, int k, int kpad, int prec,
+                               hipStream_t st);
+// NHWC (compute type or fp32) activation view -> NCHW fp32 (debug / parity tap)
+hipError_t launch_nhwc_to_nchw(TView in, float* out, int n, int prec, hipStream_t st);
+
+}  // namespace adas

@@ -407,6 +407,12 @@ int adas_yolo_post_device_views(adas_yolo_post* h, const double** d_xyxy, const 
     return ADAS_OK;
 }
 
+int adas_yolo_post_capacity(const adas_yolo_post* h, int* max_candidates) {
+    ADAS_REQUIRE(h && max_candidates, ADAS_ERR_INVALID, "null argument");
+    *max_candidates = h->p.max_candidates;
+    return ADAS_OK;
+}
+
 // ------------------------------------------------------------------------------- UFLD
 int adas_ufld_decode_create(const adas_ufld_params* p, int max_batch, adas_ufld_decode** out) {
     ADAS_REQUIRE(p && out && max_batch > 0 && p->h_row_anchor && p->h_col_anchor, ADAS_ERR_INVALID, "adas_ufld_decode_create: bad argument");

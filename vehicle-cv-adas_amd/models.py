@@ -1,0 +1,448 @@
+"""Network graphs for HipEngine + the `.hipm` model container.
+
+The reference ships no weights and (for YOLO) no architecture: it loads whatever `.onnx`/`.trt`
+the user exported (coreEngine.py:120-186; I/O contract yoloDetector.py:110-133).  HipEngine instead
+loads a self-describing container ("ADASHIP1") holding a flat list of NHWC ops over channel-sliced
+buffer views plus fp32 weights.  This module builds those graphs:
+
+  * YOLOv8 n/s/m/l  (ultralytics 8.1.x yolov8.yaml; README.md:56)       -> output (1, 4+nc, 8400)
+  * YOLOv5 n/s      (yolov5 v6.2 yolov5n.yaml; README.md:53)            -> output (1, 25200, 5+nc)
+  * UFLDv2 CULane ResNet-18/34 (exportLib/ultrafastLaneV2/model_culane.py:7-63,
+    backbone.py:14-58, configs/culane_res18.py)                        -> 4 outputs (a1 in SURVEY 8a)
+
+Concat / split / residual never copy: producers write straight into channel offsets of the consumer's
+concat buffer ("view" = buffer id + channel offset + channel count).  BatchNorm is pre-folded into conv
+weight + bias.  Weights come from a `wsrc(name, shape, kind)` callable; the default is a seeded
+synthetic generator (He-style, Detect biases as upstream: cls log(5/nc/(640/s)^2), box 1.0).
+"""
+import math
+import struct
+from collections import OrderedDict
+
+import numpy as np
+
+MAGIC = b"ADASHIP1"
+OP_INPUT, OP_CONV, OP_MAXPOOL, OP_UPSAMPLE2, OP_DETECT_V8, OP_DETECT_V5, OP_LAYERNORM = range(7)
+ACT_NONE, ACT_SILU, ACT_RELU = 0, 1, 2
+RES_NONE, RES_AFTER_ACT, RES_BEFORE_ACT = 0, 1, 2
+BUF_F32 = 1
+
+HDR_FMT = "<8sIIIIIIIIQQd64s"
+BUF_FMT = "<IIII"
+OP_FMT = "<II8i8i8iiiiIIIIIIiiIIIQQQQd8f48s"
+OUT_FMT = "<III4I32s4x"
+HDR_SIZE, BUF_SIZE, OP_SIZE, OUT_SIZE = (struct.calcsize(f) for f in (HDR_FMT, BUF_FMT, OP_FMT, OUT_FMT))
+
+
+class View:
+    """A channel slice [coff, coff+c) of NHWC buffer `buf`."""
+    __slots__ = ("buf", "coff", "c", "h", "w")
+
+    def __init__(self, buf, coff, c, h, w):
+        self.buf, self.coff, self.c, self.h, self.w = buf, coff, c, h, w
+
+    def slice(self, off, c):
+        assert 0 <= off and off + c <= self.c
+        return View(self.buf, self.coff + off, c, self.h, self.w)
+
+
+class SynthWeights:
+    """Seeded synthetic parameters.  kind: 'conv' (OIHW), 'bias', 'linear' (out,in), 'ln_w', 'ln_b'."""
+
+    def __init__(self, seed=0, gain=1.0):
+        self.rng = np.random.default_rng(seed)
+        self.gain = gain
+        self.store = OrderedDict()
+
+    def __call__(self, name, shape, kind, fill=None):
+        if name in self.store:
+            return self.store[name]
+        if fill is not None:
+            a = np.full(shape, fill, np.float32)
+        elif kind in ("conv", "linear"):
+            fan_in = int(np.prod(shape[1:]))
+            a = (self.rng.standard_normal(shape) * self.gain * math.sqrt(2.0 / fan_in)).astype(np.float32)
+        elif kind == "bias":
+            a = (self.rng.standard_normal(shape) * 0.05).astype(np.float32)
+        elif kind == "ln_w":
+            a = (1.0 + 0.05 * self.rng.standard_normal(shape)).astype(np.float32)
+        elif kind == "ln_b":
+            a = (0.05 * self.rng.standard_normal(shape)).astype(np.float32)
+        else:
+            raise ValueError(kind)
+        self.store[name] = a
+        return a
+
+
+class DictWeights:
+    """Weights supplied by name (e.g. converted from a real checkpoint)."""
+
+    def __init__(self, d):
+        self.store = d
+
+    def __call__(self, name, shape, kind, fill=None):
+        a = np.asarray(self.store[name], np.float32)
+        assert tuple(a.shape) == tuple(shape), (name, a.shape, shape)
+        return a
+
+
+class Graph:
+    def __init__(self, name, in_c, in_h, in_w, wsrc):
+        self.name, self.in_c, self.in_h, self.in_w = name, in_c, in_h, in_w
+        self.w = wsrc
+        self.bufs, self.ops, self.outs = [], [], []
+        self.blob = bytearray()
+        self.flops = 0.0
+        self.n_convs = 0
+        self.n_params = 0
+
+    # ---- buffers / views
+    def buf(self, h, w, c, f32=False):
+        self.bufs.append((h, w, c, BUF_F32 if f32 else 0))
+        return View(len(self.bufs) - 1, 0, c, h, w)
+
+    def _blob(self, arr):
+        arr = np.ascontiguousarray(arr, np.float32)
+        off = len(self.blob)
+        self.blob += arr.tobytes()
+        pad = (-len(self.blob)) % 64
+        self.blob += b"\0" * pad
+        return off, arr.size
+
+    def _op(self, typ, ins, out, kh=0, kw=0, stride=1, pad=0, act=0, res_mode=0, res=None, w=(0, 0), b=(0, 0),
+            flops=0.0, params=(), name=""):
+        ins = list(ins)
+        rec = dict(type=typ, ins=ins, out=out, kh=kh, kw=kw, stride=stride, pad=pad, act=act, res_mode=res_mode, res=res,
+                   w=w, b=b, flops=float(flops), params=list(params), name=name)
+        self.ops.append(rec)
+        self.flops += float(flops)
+        return rec
+
+    # ---- ops
+    def input(self):
+        """NCHW fp32 network input -> NHWC with channels zero-padded to 8."""
+        v = self.buf(self.in_h, self.in_w, 8)
+        self._op(OP_INPUT, [], v, name="input")
+        return View(v.buf, 0, 8, v.h, v.w), self.in_c
+
+    def conv(self, x, cout, k, s, name, act=ACT_SILU, out=None, res=None, res_mode=RES_NONE, true_cin=None, bias=True,
+             wname=None, bname=None, pad=None, f32_out=False, bias_fill=None, wkind="conv"):
+        """x: View (its .c may be zero-padded beyond true_cin).  Weight 'name.weight' is OIHW with I=true_cin."""
+        cin_true = true_cin if true_cin is not None else x.c
+        p = (k // 2) if pad is None else pad
+        ho = (x.h + 2 * p - k) // s + 1
+        wo = (x.w + 2 * p - k) // s + 1
+        if out is None:
+            out = self.buf(ho, wo, cout, f32=f32_out)
+        assert (out.h, out.w, out.c) == (ho, wo, cout), (name, (out.h, out.w, out.c), (ho, wo, cout))
+        wshape = (cout, cin_true, k, k) if wkind == "conv" else (cout, cin_true)
+        W = self.w(wname or name + ".weight", wshape, wkind)
+        W4 = W.reshape(cout, cin_true, k, k)
+        B = self.w(bname or name + ".bias", (cout,), "bias", fill=bias_fill) if bias else np.zeros(cout, np.float32)
+        if k == 1 and cin_true == x.c:
+            ohwi = W4.reshape(cout, cin_true)                     # 1x1 / linear: OIHW == OHWI
+        else:
+            ohwi = np.zeros((cout, k, k, x.c), np.float32)       # channel-padded OHWI
+            ohwi[..., :cin_true] = W4.transpose(0, 2, 3, 1)
+        woff = self._blob(ohwi)
+        boff = self._blob(B)
+        fl = 2.0 * ho * wo * cout * cin_true * k * k
+        self._op(OP_CONV, [x], out, kh=k, kw=k, stride=s, pad=p, act=act, res_mode=res_mode, res=res, w=woff, b=boff,
+                 flops=fl, name=name)
+        self.n_convs += 1
+        self.n_params += W.size + (B.size if bias else 0)
+        return out
+
+    def maxpool(self, x, k, s, p, out=None, name="maxpool"):
+        ho = (x.h + 2 * p - k) // s + 1
+        wo = (x.w + 2 * p - k) // s + 1
+        if out is None:
+            out = self.buf(ho, wo, x.c)
+        assert (out.h, out.w, out.c) == (ho, wo, x.c)
+        self._op(OP_MAXPOOL, [x], out, kh=k, kw=k, stride=s, pad=p, name=name)
+        return out
+
+    def upsample2(self, x, out=None, name="upsample"):
+        if out is None:
+            out = self.buf(x.h * 2, x.w * 2, x.c)
+        assert (out.h, out.w, out.c) == (x.h * 2, x.w * 2, x.c)
+        self._op(OP_UPSAMPLE2, [x], out, name=name)
+        return out
+
+    def output(self, view, offset, dims, name):
+        self.outs.append((view.buf, int(offset), list(dims), name))
+
+    # ---- serialisation
+    def tobytes(self):
+        parts = []
+        nb, no, nout = len(self.bufs), len(self.ops), len(self.outs)
+        woff = HDR_SIZE + nb * BUF_SIZE + no * OP_SIZE + nout * OUT_SIZE
+        woff += (-woff) % 256
+        parts.append(struct.pack(HDR_FMT, MAGIC, 1, nb, no, nout, self.in_c, self.in_h, self.in_w, 8, woff, len(self.blob),
+                                 self.flops, self.name.encode()[:63]))
+        for h, w, c, fl in self.bufs:
+            parts.append(struct.pack(BUF_FMT, h, w, c, fl))
+        for r in self.ops:
+            ins = r["ins"]
+            ib = [v.buf for v in ins] + [-1] * (8 - len(ins))
+            io = [v.coff for v in ins] + [0] * (8 - len(ins))
+            ic = [v.c for v in ins] + [0] * (8 - len(ins))
+            res = r["res"]
+            prm = (r["params"] + [0.0] * 8)[:8]
+            parts.append(struct.pack(OP_FMT, r["type"], len(ins), *ib, *io, *ic, r["out"].buf, r["out"].coff, r["out"].c,
+                                     r["kh"], r["kw"], r["stride"], r["pad"], r["act"], r["res_mode"],
+                                     res.buf if res else -1, res.coff if res else 0, 0, 0, 0,
+                                     r["w"][0], r["w"][1], r["b"][0], r["b"][1], r["flops"], *prm,
+                                     r["name"].encode()[:47]))
+        for buf, off, dims, name in self.outs:
+            d = (list(dims) + [1] * 4)[:4]
+            parts.append(struct.pack(OUT_FMT, buf, off, len(dims), *d, name.encode()[:31]))
+        head = b"".join(parts)
+        head += b"\0" * (woff - len(head))
+        return head + bytes(self.blob)
+
+    def save(self, path):
+        with open(path, "wb") as f:
+            f.write(self.tobytes())
+        return path
+
+
+# =====================================================================================
+# YOLOv8  (ultralytics yolov8.yaml)
+# =====================================================================================
+V8_SCALES = {"n": (0.33, 0.25, 1024), "s": (0.33, 0.50, 1024), "m": (0.67, 0.75, 768), "l": (1.0, 1.0, 512),
+             "x": (1.0, 1.25, 512)}
+
+
+def _mk(c, width, max_ch):
+    return int(math.ceil(min(c, max_ch) * width / 8) * 8)
+
+
+def _c2f(g, x, c2, n, shortcut, name, out=None):
+    """C2f: cv1 1x1 -> split; n Bottlenecks chained on the last chunk; cv2 1x1 over the concat."""
+    c = c2 // 2
+    cat = g.buf(x.h, x.w, (2 + n) * c)
+    g.conv(x, 2 * c, 1, 1, f"{name}.cv1.conv", out=cat.slice(0, 2 * c))
+    for i in range(n):
+        src = cat.slice((1 + i) * c, c)
+        t = g.conv(src, c, 3, 1, f"{name}.m.{i}.cv1.conv")
+        g.conv(t, c, 3, 1, f"{name}.m.{i}.cv2.conv", out=cat.slice((2 + i) * c, c),
+               res=src if shortcut else None, res_mode=RES_AFTER_ACT if shortcut else RES_NONE)
+    return g.conv(cat, c2, 1, 1, f"{name}.cv2.conv", out=out)
+
+
+def _sppf(g, x, c2, name, out=None):
+    c_ = x.c // 2
+    cat = g.buf(x.h, x.w, 4 * c_)
+    g.conv(x, c_, 1, 1, f"{name}.cv1.conv", out=cat.slice(0, c_))
+    for i in range(3):
+        g.maxpool(cat.slice(i * c_, c_), 5, 1, 2, out=cat.slice((i + 1) * c_, c_), name=f"{name}.m{i}")
+    return g.conv(cat, c2, 1, 1, f"{name}.cv2.conv", out=out)
+
+
+def yolov8(scale="n", nc=80, imgsz=640, wsrc=None, seed=0):
+    depth, width, max_ch = V8_SCALES[scale]
+    wsrc = wsrc or SynthWeights(seed)
+    g = Graph(f"yolov8{scale}", 3, imgsz, imgsz, wsrc)
+    ch = lambda c: _mk(c, width, max_ch)
+    dep = lambda n: max(round(n * depth), 1)
+    c1, c2, c3, c4, c5 = ch(64), ch(128), ch(256), ch(512), ch(1024)
+    x, cin = g.input()
+    H = imgsz
+    # concat buffers of the neck (producers write into them directly)
+    cat11 = g.buf(H // 16, H // 16, c5 + c4)   # [up(9), 6]
+    cat14 = g.buf(H // 8, H // 8, c4 + c3)     # [up(12), 4]
+    cat17 = g.buf(H // 16, H // 16, c3 + c4)   # [16, 12]
+    cat20 = g.buf(H // 32, H // 32, c4 + c5)   # [19, 9]
+    x = g.conv(x, c1, 3, 2, "model.0.conv", true_cin=cin)
+    x = g.conv(x, c2, 3, 2, "model.1.conv")
+    x = _c2f(g, x, c2, dep(3), True, "model.2")
+    x = g.conv(x, c3, 3, 2, "model.3.conv")
+    p3b = _c2f(g, x, c3, dep(6), True, "model.4", out=cat14.slice(c4, c3))
+    x = g.conv(p3b, c4, 3, 2, "model.5.conv")
+    p4b = _c2f(g, x, c4, dep(6), True, "model.6", out=cat11.slice(c5, c4))
+    x = g.conv(p4b, c5, 3, 2, "model.7.conv")
+    x = _c2f(g, x, c5, dep(3), True, "model.8")
+    p5b = _sppf(g, x, c5, "model.9", out=cat20.slice(c4, c5))
+    g.upsample2(p5b, out=cat11.slice(0, c5), name="model.10")
+    n12 = _c2f(g, cat11, c4, dep(3), False, "model.12", out=cat17.slice(c3, c4))
+    g.upsample2(n12, out=cat14.slice(0, c4), name="model.13")
+    p3 = _c2f(g, cat14, c3, dep(3), False, "model.15")
+    g.conv(p3, c3, 3, 2, "model.16.conv", out=cat17.slice(0, c3))
+    p4 = _c2f(g, cat17, c4, dep(3), False, "model.18")
+    g.conv(p4, c4, 3, 2, "model.19.conv", out=cat20.slice(0, c4))
+    p5 = _c2f(g, cat20, c5, dep(3), False, "model.21")
+    # Detect
+    feats = [p3, p4, p5]
+    cb = max(16, feats[0].c // 4, 64)
+    cc = max(feats[0].c, min(nc, 100))
+    ins, strides = [], []
+    for i, f in enumerate(feats):
+        s = imgsz // f.h
+        strides.append(s)
+        b = g.conv(f, cb, 3, 1, f"model.22.cv2.{i}.0.conv")
+        b = g.conv(b, cb, 3, 1, f"model.22.cv2.{i}.1.conv")
+        b = g.conv(b, 64, 1, 1, f"model.22.cv2.{i}.2", act=ACT_NONE, f32_out=True, bias_fill=1.0)
+        c = g.conv(f, cc, 3, 1, f"model.22.cv3.{i}.0.conv")
+        c = g.conv(c, cc, 3, 1, f"model.22.cv3.{i}.1.conv")
+        c = g.conv(c, nc, 1, 1, f"model.22.cv3.{i}.2", act=ACT_NONE, f32_out=True,
+                   bias_fill=math.log(5 / nc / (imgsz / s) ** 2))
+        ins += [b, c]
+    A = sum(f.h * f.w for f in feats)
+    head = g.buf(1, 1, (4 + nc) * A, f32=True)
+    g._op(OP_DETECT_V8, ins, head, params=[nc, A] + strides, name="model.22.decode")
+    g.output(head, 0, [1, 4 + nc, A], "output0")
+    g.meta = dict(kind="yolov8", nc=nc, anchors=A, strides=strides)
+    return g
+
+
+# =====================================================================================
+# YOLOv5 v6.2
+# =====================================================================================
+V5_SCALES = {"n": (0.33, 0.25), "s": (0.33, 0.50), "m": (0.67, 0.75), "l": (1.0, 1.0)}
+V5_ANCHORS = [[10, 13, 16, 30, 33, 23], [30, 61, 62, 45, 59, 119], [116, 90, 156, 198, 373, 326]]  # yoloDetector.py:23
+
+
+def _c3(g, x, c2, n, shortcut, name, out=None):
+    c_ = c2 // 2
+    cat = g.buf(x.h, x.w, 2 * c_)
+    y = g.conv(x, c_, 1, 1, f"{name}.cv1.conv")
+    g.conv(x, c_, 1, 1, f"{name}.cv2.conv", out=cat.slice(c_, c_))
+    for i in range(n):
+        t = g.conv(y, c_, 1, 1, f"{name}.m.{i}.cv1.conv")
+        last = (i == n - 1)
+        y = g.conv(t, c_, 3, 1, f"{name}.m.{i}.cv2.conv", out=cat.slice(0, c_) if last else None,
+                   res=y if shortcut else None, res_mode=RES_AFTER_ACT if shortcut else RES_NONE)
+    return g.conv(cat, c2, 1, 1, f"{name}.cv3.conv", out=out)
+
+
+def yolov5(scale="n", nc=80, imgsz=640, wsrc=None, seed=0):
+    depth, width = V5_SCALES[scale]
+    wsrc = wsrc or SynthWeights(seed)
+    g = Graph(f"yolov5{scale}", 3, imgsz, imgsz, wsrc)
+    ch = lambda c: int(math.ceil(c * width / 8) * 8)
+    dep = lambda n: max(round(n * depth), 1)
+    c1, c2, c3, c4, c5 = ch(64), ch(128), ch(256), ch(512), ch(1024)
+    H = imgsz
+    x, cin = g.input()
+    cat12 = g.buf(H // 16, H // 16, c4 + c4)   # [up(10), 6]
+    cat16 = g.buf(H // 8, H // 8, c3 + c3)     # [up(14), 4]
+    cat19 = g.buf(H // 16, H // 16, c3 + c3)   # [18, 14]
+    cat22 = g.buf(H // 32, H // 32, c4 + c4)   # [21, 10]
+    x = g.conv(x, c1, 6, 2, "model.0.conv", true_cin=cin, pad=2)
+    x = g.conv(x, c2, 3, 2, "model.1.conv")
+    x = _c3(g, x, c2, dep(3), True, "model.2")
+    x = g.conv(x, c3, 3, 2, "model.3.conv")
+    b4 = _c3(g, x, c3, dep(6), True, "model.4", out=cat16.slice(c3, c3))
+    x = g.conv(b4, c4, 3, 2, "model.5.conv")
+    b6 = _c3(g, x, c4, dep(9), True, "model.6", out=cat12.slice(c4, c4))
+    x = g.conv(b6, c5, 3, 2, "model.7.conv")
+    x = _c3(g, x, c5, dep(3), True, "model.8")
+    x = _sppf(g, x, c5, "model.9")
+    n10 = g.conv(x, c4, 1, 1, "model.10.conv", out=cat22.slice(c4, c4))
+    g.upsample2(n10, out=cat12.slice(0, c4), name="model.11")
+    x = _c3(g, cat12, c4, dep(3), False, "model.13")
+    n14 = g.conv(x, c3, 1, 1, "model.14.conv", out=cat19.slice(c3, c3))
+    g.upsample2(n14, out=cat16.slice(0, c3), name="model.15")
+    p3 = _c3(g, cat16, c3, dep(3), False, "model.17")
+    g.conv(p3, c3, 3, 2, "model.18.conv", out=cat19.slice(0, c3))
+    p4 = _c3(g, cat19, c4, dep(3), False, "model.20")
+    g.conv(p4, c4, 3, 2, "model.21.conv", out=cat22.slice(0, c4))
+    p5 = _c3(g, cat22, c5, dep(3), False, "model.23")
+    feats = [p3, p4, p5]
+    no = nc + 5
+    ins, strides = [], []
+    for i, f in enumerate(feats):
+        s = imgsz // f.h
+        strides.append(s)
+        # upstream bias init: obj log(8/(640/s)^2), cls log(0.6/(nc-0.999999)); synthetic -> keep scores sparse
+        bias = np.zeros((3, no), np.float32)
+        bias[:, 4] = math.log(8 / (640 / s) ** 2)
+        bias[:, 5:] = math.log(0.6 / (nc - 0.999999))
+        name = f"model.24.m.{i}"
+        if isinstance(wsrc, SynthWeights):
+            wsrc.store[name + ".bias"] = bias.reshape(-1) + 0.01 * wsrc.rng.standard_normal(3 * no).astype(np.float32)
+        ins.append(g.conv(f, 3 * no, 1, 1, name, act=ACT_NONE, f32_out=True))
+    A = 3 * sum(f.h * f.w for f in feats)
+    head = g.buf(1, 1, A * no, f32=True)
+    anchors = [a for lvl in V5_ANCHORS for a in lvl]
+    g._op(OP_DETECT_V5, ins, head, params=[nc, A] + strides, name="model.24.decode")
+    g.ops[-1]["w"] = g._blob(np.asarray(anchors, np.float32))
+    g.output(head, 0, [1, A, no], "output0")
+    g.meta = dict(kind="yolov5", nc=nc, anchors=A, strides=strides)
+    return g
+
+
+# =====================================================================================
+# UFLDv2 (CULane): torchvision ResNet-18/34 topology + parsingNet head
+# =====================================================================================
+RESNET_DEPTHS = {"18": [2, 2, 2, 2], "34": [3, 4, 6, 3]}
+
+
+def ufldv2(backbone="18", in_h=320, in_w=1600, num_grid_row=200, num_cls_row=72, num_grid_col=100, num_cls_col=81,
+           num_lanes=4, fc_norm=True, wsrc=None, seed=0):
+    wsrc = wsrc or SynthWeights(seed)
+    g = Graph(f"ufldv2_culane_res{backbone}", 3, in_h, in_w, wsrc)
+    x, cin = g.input()
+    x = g.conv(x, 64, 7, 2, "model.conv1", act=ACT_RELU, true_cin=cin, pad=3)      # conv1+bn1+relu (backbone.py:50-52)
+    x = g.maxpool(x, 3, 2, 1, name="model.maxpool")                                # :53
+    cinp = 64
+    for li, (planes, nblk) in enumerate(zip([64, 128, 256, 512], RESNET_DEPTHS[backbone])):
+        for bi in range(nblk):
+            s = 2 if (li > 0 and bi == 0) else 1
+            name = f"model.layer{li + 1}.{bi}"
+            idt = x
+            if s != 1 or cinp != planes:
+                idt = g.conv(x, planes, 1, s, f"{name}.downsample.0", act=ACT_NONE, pad=0)
+            t = g.conv(x, planes, 3, s, f"{name}.conv1", act=ACT_RELU)
+            x = g.conv(t, planes, 3, 1, f"{name}.conv2", act=ACT_RELU, res=idt, res_mode=RES_BEFORE_ACT)
+            cinp = planes
+    fea = g.conv(x, 8, 1, 1, "pool", act=ACT_NONE, f32_out=True, pad=0)           # model_culane.py:39,48
+    input_dim = in_h // 32 * in_w // 32 * 8                                        # :23
+    assert fea.h * fea.w * 8 == input_dim
+    mid = 2048
+    dims = [num_grid_row * num_cls_row * num_lanes, num_grid_col * num_cls_col * num_lanes,
+            2 * num_cls_row * num_lanes, 2 * num_cls_col * num_lanes]
+    total = sum(dims)
+    # torch flattens (C,H,W); our activation is (H,W,C): permute LN affine + FC1 input columns once, offline
+    hw = fea.h * fea.w
+    perm = (np.arange(8)[None, :] * hw + np.arange(hw)[:, None]).reshape(-1)      # ours[j] = torch[perm[j]]
+    x = fea                                                                        # LayerNorm reads it flat (h*w*c)
+    assert fc_norm, "the CULane config has fc_norm=True (configs/culane_res18.py:36)"
+    if fc_norm:                                                                    # cls.0 LayerNorm (:34)
+        lw = wsrc("cls.0.weight", (input_dim,), "ln_w")
+        lb = wsrc("cls.0.bias", (input_dim,), "ln_b")
+        ln = g.buf(1, 1, input_dim)
+        woff = g._blob(lw[perm]); boff = g._blob(lb[perm])
+        g._op(OP_LAYERNORM, [x], ln, w=woff, b=boff, params=[1e-5], name="cls.0")
+        g.n_params += 2 * input_dim
+        x = ln
+    W1 = wsrc("cls.1.weight", (mid, input_dim), "linear")
+    perm_src = DictWeights({"cls.1.weight.perm": np.ascontiguousarray(W1[:, perm])})
+    keep, g.w = g.w, perm_src
+    h1 = g.conv(x, mid, 1, 1, "cls.1", act=ACT_RELU, wname="cls.1.weight.perm", bias=False, wkind="linear")
+    g.w = keep
+    b1 = wsrc("cls.1.bias", (mid,), "bias")
+    g.ops[-1]["b"] = g._blob(b1)
+    g.n_params += mid
+    out = g.conv(h1, total, 1, 1, "cls.3", act=ACT_NONE, f32_out=True, wkind="linear")
+    off = 0
+    shapes = [[1, num_grid_row, num_cls_row, num_lanes], [1, num_grid_col, num_cls_col, num_lanes],
+              [1, 2, num_cls_row, num_lanes], [1, 2, num_cls_col, num_lanes]]
+    for nm, d, shp in zip(("loc_row", "loc_col", "exist_row", "exist_col"), dims, shapes):   # :56-59
+        g.output(out, off, shp, nm)
+        off += d
+    g.meta = dict(kind="ufldv2", dims=dims, total=total)
+    return g
+
+
+BUILDERS = {
+    "yolov8n": lambda **k: yolov8("n", **k), "yolov8s": lambda **k: yolov8("s", **k),
+    "yolov8m": lambda **k: yolov8("m", **k), "yolov8l": lambda **k: yolov8("l", **k),
+    "yolov5n": lambda **k: yolov5("n", **k), "yolov5s": lambda **k: yolov5("s", **k),
+    "ufldv2_res18": lambda **k: ufldv2("18", **k), "ufldv2_res34": lambda **k: ufldv2("34", **k),
+}
+
+
+def build(name, **kw):
+    return BUILDERS[name](**kw)
