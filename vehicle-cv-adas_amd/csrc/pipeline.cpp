@@ -10,10 +10,13 @@ struct adas_bytetrack;
 struct adas_pipeline {
     adas_pipeline_desc d;
     hipStream_t st = nullptr;
-    hipGraph_t graph = nullptr;
-    hipGraphExec_t exec = nullptr;
-    const float* cap_det = nullptr;
-    const float* cap_lane = nullptr;
+    struct Cached {
+        const float* det;
+        const float* lane;
+        hipGraph_t graph;
+        hipGraphExec_t exec;
+    };
+    std::vector<Cached> graphs;  // one captured step per distinct (detector input, lane input) pair
     hipEvent_t ev[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     bool timed = false;
 };
@@ -87,8 +90,10 @@ int adas_pipeline_create(const adas_pipeline_desc* d, adas_pipeline** out) {
 
 int adas_pipeline_destroy(adas_pipeline* p) {
     if (!p) return ADAS_OK;
-    if (p->exec) (void)hipGraphExecDestroy(p->exec);
-    if (p->graph) (void)hipGraphDestroy(p->graph);
+    for (auto& g : p->graphs) {
+        if (g.exec) (void)hipGraphExecDestroy(g.exec);
+        if (g.graph) (void)hipGraphDestroy(g.graph);
+    }
     for (auto& e : p->ev)
         if (e) (void)hipEventDestroy(e);
     if (p->st) (void)hipStreamDestroy(p->st);
@@ -104,20 +109,23 @@ int adas_pipeline_step(adas_pipeline* p, const float* d_det, const float* d_lane
         p->timed = true;
         return record_step(p, d_det, d_lane, true);
     }
-    if (!p->exec || p->cap_det != d_det || p->cap_lane != d_lane) {
-        if (p->exec) { (void)hipGraphExecDestroy(p->exec); p->exec = nullptr; }
-        if (p->graph) { (void)hipGraphDestroy(p->graph); p->graph = nullptr; }
+    hipGraphExec_t exec = nullptr;
+    for (auto& g : p->graphs)
+        if (g.det == d_det && g.lane == d_lane) exec = g.exec;
+    if (!exec) {
+        ADAS_REQUIRE(p->graphs.size() < 64, ADAS_ERR_CAPACITY, "more than 64 distinct input buffers: reuse staging buffers with use_graph");
+        adas_pipeline::Cached g{d_det, d_lane, nullptr, nullptr};
         ADAS_HIP_TRY(hipStreamBeginCapture(p->st, hipStreamCaptureModeThreadLocal));
         int rc = record_step(p, d_det, d_lane, false);
-        hipError_t ce = hipStreamEndCapture(p->st, &p->graph);
+        hipError_t ce = hipStreamEndCapture(p->st, &g.graph);
         if (rc) return rc;
         if (ce != hipSuccess) return hip_fail(ce, "hipStreamEndCapture", __FILE__, __LINE__);
-        ADAS_HIP_TRY(hipGraphInstantiate(&p->exec, p->graph, nullptr, nullptr, 0));
-        p->cap_det = d_det;
-        p->cap_lane = d_lane;
+        ADAS_HIP_TRY(hipGraphInstantiate(&g.exec, g.graph, nullptr, nullptr, 0));
+        p->graphs.push_back(g);
+        exec = g.exec;
     }
     ADAS_HIP_TRY(hipEventRecord(p->ev[0], p->st));
-    ADAS_HIP_TRY(hipGraphLaunch(p->exec, p->st));
+    ADAS_HIP_TRY(hipGraphLaunch(exec, p->st));
     ADAS_HIP_TRY(hipEventRecord(p->ev[5], p->st));
     p->timed = false;
     return ADAS_OK;

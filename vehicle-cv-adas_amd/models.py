@@ -34,6 +34,12 @@ OUT_FMT = "<III4I32s4x"
 HDR_SIZE, BUF_SIZE, OP_SIZE, OUT_SIZE = (struct.calcsize(f) for f in (HDR_FMT, BUF_FMT, OP_FMT, OUT_FMT))
 
 
+# He-style init assumes ReLU; SiLU halves less variance and residual adds double it -- these gains keep the
+# synthetic activations O(1) through the depth of the nets (measured on the torch oracle).
+SILU_GAIN = 1.15
+RELU_RES_GAIN = 0.8
+
+
 class View:
     """A channel slice [coff, coff+c) of NHWC buffer `buf`."""
     __slots__ = ("buf", "coff", "c", "h", "w")
@@ -242,7 +248,7 @@ def _sppf(g, x, c2, name, out=None):
 
 def yolov8(scale="n", nc=80, imgsz=640, wsrc=None, seed=0):
     depth, width, max_ch = V8_SCALES[scale]
-    wsrc = wsrc or SynthWeights(seed)
+    wsrc = wsrc or SynthWeights(seed, gain=SILU_GAIN)
     g = Graph(f"yolov8{scale}", 3, imgsz, imgsz, wsrc)
     ch = lambda c: _mk(c, width, max_ch)
     dep = lambda n: max(round(n * depth), 1)
@@ -318,7 +324,7 @@ def _c3(g, x, c2, n, shortcut, name, out=None):
 
 def yolov5(scale="n", nc=80, imgsz=640, wsrc=None, seed=0):
     depth, width = V5_SCALES[scale]
-    wsrc = wsrc or SynthWeights(seed)
+    wsrc = wsrc or SynthWeights(seed, gain=SILU_GAIN)
     g = Graph(f"yolov5{scale}", 3, imgsz, imgsz, wsrc)
     ch = lambda c: int(math.ceil(c * width / 8) * 8)
     dep = lambda n: max(round(n * depth), 1)
@@ -381,7 +387,7 @@ RESNET_DEPTHS = {"18": [2, 2, 2, 2], "34": [3, 4, 6, 3]}
 
 def ufldv2(backbone="18", in_h=320, in_w=1600, num_grid_row=200, num_cls_row=72, num_grid_col=100, num_cls_col=81,
            num_lanes=4, fc_norm=True, wsrc=None, seed=0):
-    wsrc = wsrc or SynthWeights(seed)
+    wsrc = wsrc or SynthWeights(seed, gain=RELU_RES_GAIN)
     g = Graph(f"ufldv2_culane_res{backbone}", 3, in_h, in_w, wsrc)
     x, cin = g.input()
     x = g.conv(x, 64, 7, 2, "model.conv1", act=ACT_RELU, true_cin=cin, pad=3)      # conv1+bn1+relu (backbone.py:50-52)

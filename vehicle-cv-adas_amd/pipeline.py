@@ -1,0 +1,73 @@
+"""Fused per-frame ADAS step for S independent video streams on one GPU (C ABI: adas_pipeline_*).
+
+What demo.py:261-281 drives per frame -- detector forward + decode/NMS, tracker update, lane forward +
+decode -- runs back to back on one HIP stream (optionally replayed from a hipGraph) with every
+intermediate resident in HBM.  Inputs are the engine-seam tensors (NCHW fp32) already on the device.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib as L
+from .coreEngine import HipEngine
+from .postproc import YoloPost, UfldDecode, DeviceTracker, letterbox
+
+CULANE = dict(grid_row=200, cls_row=72, grid_col=100, cls_col=81,
+              row_anchor=np.linspace(0.42, 1, 72), col_anchor=np.linspace(0, 1, 81))   # ultrafastLaneDetectorV2.py:49-55
+
+
+class AdasPipeline:
+    def __init__(self, det_model=None, lane_model=None, n_streams=1, precision="bf16", src_hw=(720, 1280),
+                 box_score=0.4, nms_iou=0.45, head_layout=L.HEAD_V8, num_classes=80, use_graph=True,
+                 max_candidates=512, track=True, lane_cfg=None, nms_mode=L.NMS_REFERENCE):
+        self.S = n_streams
+        self.det = self.lane = self.post = self.decode = self.tracker = None
+        if det_model:
+            self.det = HipEngine(det_model, precision, n_streams)
+            ishape = self.det.get_engine_input_shape()
+            oshape = self.det.get_engine_output_shape()[0][0]
+            A = oshape[2] if head_layout == L.HEAD_V8 else oshape[1]
+            lb = letterbox(src_hw, ishape[2:])
+            self.post = YoloPost(head_layout, A, num_classes, box_score, nms_iou, lb, nms_mode, max_candidates, n_streams)
+            if track:
+                self.tracker = DeviceTracker(n_streams, max_dets=max_candidates)
+        if lane_model:
+            self.lane = HipEngine(lane_model, precision, n_streams)
+            cfg = dict(CULANE)
+            cfg.update(lane_cfg or {})
+            self.decode = UfldDecode(cfg["grid_row"], cfg["cls_row"], cfg["grid_col"], cfg["cls_col"], src_hw[1], src_hw[0],
+                                     cfg["row_anchor"], cfg["col_anchor"], 1, n_streams)
+        d = L.PipelineDesc(self.det.handle if self.det else None, self.lane.handle if self.lane else None,
+                           self.post.h if self.post else None, self.decode.h if self.decode else None,
+                           self.tracker.h if self.tracker else None, n_streams, 1 if use_graph else 0)
+        h = C.c_void_p()
+        L.check(L.lib().adas_pipeline_create(C.byref(d), C.byref(h)))
+        self.h = h.value
+
+    def step(self, d_det_ptr=None, d_lane_ptr=None):
+        L.check(L.lib().adas_pipeline_step(self.h, d_det_ptr, d_lane_ptr))
+
+    def sync(self):
+        L.check(L.lib().adas_pipeline_sync(self.h))
+
+    def timings(self):
+        ms = (C.c_float * 6)()
+        L.check(L.lib().adas_pipeline_timings(self.h, ms))
+        return dict(zip(("det_net", "det_post", "lane_net", "lane_decode", "tracker", "step"), [float(v) for v in ms]))
+
+    def flops_per_frame(self):
+        f = 0.0
+        for e in (self.det, self.lane):
+            if e:
+                f += e.stats()["flops_per_frame"]
+        return f
+
+    def close(self):
+        if getattr(self, "h", None):
+            L.lib().adas_pipeline_destroy(self.h)
+            self.h = None
+        for o in (self.post, self.decode, self.tracker, self.det, self.lane):
+            if o:
+                o.close()
+
+    __del__ = close
