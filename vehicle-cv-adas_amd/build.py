@@ -18,6 +18,7 @@ UNITS = [
     ("api_common.cpp", []),
     ("post_kernels.hip", ["-ffp-contract=off"]),
     ("conv_kernels.hip", []),
+    ("conv_halo.hip", []),
     ("aux_kernels.hip", []),
     ("engine.cpp", []),
     ("pipeline.cpp", []),

@@ -13,6 +13,7 @@
 // one barrier per step).  Roofline: MFMA-bound for the ResNet stages, HBM/L2-bound for the
 // 16..64-channel YOLOv8n layers (arithmetic intensity < 312 FLOP/B).
 #include "kernels.h"
+#include <stdlib.h>
 
 namespace adas {
 
@@ -304,7 +305,36 @@ static hipError_t launch_typed(const ConvDev& d, Tile t, hipStream_t st) {
     return hipErrorInvalidValue;
 }
 
+hipError_t launch_conv_halo(const ConvArgs& a, hipStream_t st);  // conv_halo.hip
+
+static bool halo_enabled() {
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("ADAS_NO_HALO");
+        v = (e && e[0] == '1') ? 0 : 1;
+    }
+    return v == 1;
+}
+
+bool halo_applicable(int kh, int kw, int stride, int pad, const TView& in, const TView& out);  // conv_halo.hip
+
+ConvPlan plan_conv(int prec, int kh, int kw, int stride, int pad, const TView& in, const TView& out) {
+    ConvPlan p;
+    if (prec == PREC_BF16 && halo_enabled() && halo_applicable(kh, kw, stride, pad, in, out)) {
+        p.kernel = CONV_HALO;
+        p.cin_pad = (in.c + 31) / 32 * 32;
+    } else {
+        p.kernel = CONV_GATHER;
+        p.cin_pad = in.c;
+    }
+    p.kpad = (kh * kw * p.cin_pad + 31) / 32 * 32;
+    return p;
+}
+
 hipError_t launch_conv(const ConvArgs& a, int prec, hipStream_t st) {
+    ConvPlan pl = plan_conv(prec, a.kh, a.kw, a.stride, a.pad, a.in, a.out);
+    if (pl.kpad != a.kpad) return hipErrorInvalidValue;  // weights were packed for a different plan
+    if (pl.kernel == CONV_HALO) return launch_conv_halo(a, st);
     ConvDev d;
     d.in = a.in.p; d.wgt = a.wgt; d.bias = a.bias; d.out = a.out.p; d.res = a.res.p;
     d.in_cs = a.in.cs; d.in_coff = a.in.coff; d.cin = a.in.c; d.H = a.in.h; d.W = a.in.w;
@@ -322,24 +352,27 @@ hipError_t launch_conv(const ConvArgs& a, int prec, hipStream_t st) {
 }
 
 // -------------------------------------------------------------------------------------
-// weight packing: fp32 [cout][k] -> T [cout_pad][kpad], zero padded
+// weight packing: fp32 [cout][taps][cin] -> T [cout_pad][kpad], element (row, tap*cin_pad + c), zero padded
 template <typename T>
-__global__ void pack_weights_kernel(const float* __restrict__ src, T* __restrict__ dst, int cout, int k, int kpad, size_t total) {
+__global__ void pack_weights_kernel(const float* __restrict__ src, T* __restrict__ dst, int cout, int taps, int cin, int cin_pad,
+                                    int kpad, size_t total) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
         size_t row = i / kpad;
         int col = (int)(i - row * kpad);
-        float v = (row < (size_t)cout && col < k) ? src[row * k + col] : 0.0f;
+        int tap = col / cin_pad, c = col - tap * cin_pad;
+        float v = (row < (size_t)cout && tap < taps && c < cin) ? src[(row * taps + tap) * cin + c] : 0.0f;
         stf(dst + i, v);
     }
 }
 
-hipError_t launch_pack_weights(const float* src, void* dst, int cout, int cout_pad, int k, int kpad, int prec, hipStream_t st) {
+hipError_t launch_pack_weights(const float* src, void* dst, int cout, int cout_pad, int taps, int cin, int cin_pad, int kpad, int prec,
+                               hipStream_t st) {
     size_t total = (size_t)cout_pad * kpad;
     int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
     if (prec == PREC_FP32)
-        hipLaunchKernelGGL(pack_weights_kernel<float>, dim3(blocks), dim3(256), 0, st, src, (float*)dst, cout, k, kpad, total);
+        hipLaunchKernelGGL(pack_weights_kernel<float>, dim3(blocks), dim3(256), 0, st, src, (float*)dst, cout, taps, cin, cin_pad, kpad, total);
     else
-        hipLaunchKernelGGL(pack_weights_kernel<uint16_t>, dim3(blocks), dim3(256), 0, st, src, (uint16_t*)dst, cout, k, kpad, total);
+        hipLaunchKernelGGL(pack_weights_kernel<uint16_t>, dim3(blocks), dim3(256), 0, st, src, (uint16_t*)dst, cout, taps, cin, cin_pad, kpad, total);
     return hipGetLastError();
 }
 

@@ -101,7 +101,10 @@ int adas_engine_create(const char* model_path, int precision, int max_batch, ada
         if (o.type == OP_CONV) {
             int cin = o.in_c[0], cout = o.out_c;
             op.k = o.kh * o.kw * cin;
-            op.kpad = (op.k + 31) / 32 * 32;
+            ConvPlan pl = plan_conv(precision, o.kh, o.kw, o.stride, o.pad, make_view(e, o.in_buf[0], o.in_coff[0], o.in_c[0]),
+                                    make_view(e, o.out_buf, o.out_coff, o.out_c));
+            op.kpad = pl.kpad;
+            op.cin_pad = pl.cin_pad;
             op.cout_pad = (cout + 127) / 128 * 128;
             op.w_off = packed_total;
             packed_total += ((size_t)op.cout_pad * op.kpad * esz + 255) & ~(size_t)255;
@@ -145,7 +148,8 @@ int adas_engine_create(const char* model_path, int precision, int max_batch, ada
         if (o.type == OP_CONV) {
             if (!read_blob(o.w_off, o.w_elems, h_stage.data()) || o.w_elems != (uint64_t)o.out_c * op.k) { rc = ADAS_ERR_FORMAT; break; }
             if (hipMemcpy(d_stage, h_stage.data(), o.w_elems * 4, hipMemcpyHostToDevice) != hipSuccess) { rc = ADAS_ERR_HIP; break; }
-            if (launch_pack_weights(d_stage, base + op.w_off, o.out_c, op.cout_pad, op.k, op.kpad, precision, 0) != hipSuccess) { rc = ADAS_ERR_HIP; break; }
+            if (launch_pack_weights(d_stage, base + op.w_off, o.out_c, op.cout_pad, o.kh * o.kw, o.in_c[0], op.cin_pad, op.kpad, precision, 0) !=
+                hipSuccess) { rc = ADAS_ERR_HIP; break; }
             if (hipDeviceSynchronize() != hipSuccess) { rc = ADAS_ERR_HIP; break; }
             std::vector<float> b(op.cout_pad, 0.f);
             if (!read_blob(o.b_off, o.b_elems, b.data())) { rc = ADAS_ERR_FORMAT; break; }

@@ -50,7 +50,7 @@ struct EngOp {
     FileOp f;
     std::string name;
     size_t w_off, b_off;  // into the packed device weight arena
-    int k, kpad, cout_pad;
+    int k, kpad, cout_pad, cin_pad;
 };
 struct EngOut {
     uint32_t buf, offset, ndim, dims[4];

@@ -26,6 +26,16 @@ struct ConvArgs {
     int k, kpad, m;     // K = kh*kw*cin ; padded to 32 ; M = n*ho*wo
 };
 
+// Which kernel runs a conv and how its weights are packed.  Decided once at load time from static
+// shapes and re-derived identically at launch time.
+enum { CONV_GATHER = 0, CONV_HALO = 1 };
+struct ConvPlan {
+    int kernel;   // CONV_*
+    int cin_pad;  // channels per tap in the packed weights (halo: padded to 32 so the tail is zero)
+    int kpad;     // packed K extent = round32(kh*kw*cin_pad)
+};
+ConvPlan plan_conv(int prec, int kh, int kw, int stride, int pad, const TView& in, const TView& out);
+
 // returns hipSuccess or the launch error.  prec: PREC_*.
 hipError_t launch_conv(const ConvArgs& a, int prec, hipStream_t st);
 const char* conv_tile_name(const ConvArgs& a, int prec);
@@ -41,9 +51,10 @@ hipError_t launch_detect_v5(const TView* ins, float* out, int n, int nc, int A, 
 // LayerNorm over the flat per-frame vector (len elements, fp32 in) -> compute type out
 hipError_t launch_layernorm(const float* in, void* out, const float* gamma, const float* beta, int n, int len, float eps,
                             int prec, hipStream_t st);
-// fp32 -> compute-type weight packing on the device: src [cout][k] fp32, dst [cout_pad][kpad] (zero padded)
-hipError_t launch_pack_weights(const float* src, void* dst, int cout, int cout_pad, int k, int kpad, int prec,
-                               hipStream_t st);
+// fp32 -> compute-type weight packing on the device: src [cout][taps][cin] fp32,
+// dst [cout_pad][kpad] with element (row, tap*cin_pad + c), zero padded
+hipError_t launch_pack_weights(const float* src, void* dst, int cout, int cout_pad, int taps, int cin, int cin_pad, int kpad,
+                               int prec, hipStream_t st);
 // NHWC (compute type or fp32) activation view -> NCHW fp32 (debug / parity tap)
 hipError_t launch_nhwc_to_nchw(TView in, float* out, int n, int prec, hipStream_t st);
 
