@@ -214,7 +214,8 @@ typedef struct {
     adas_ufld_decode* decode;   /* required with lane */
     adas_bytetrack* tracker;    /* may be NULL */
     int32_t n_streams;
-    int32_t use_graph;          /* capture the step in a hipGraph */
+    int32_t use_graph;          /* bit0: capture the step in a hipGraph (the lane branch is then forked onto a second
+                                 * stream so the two nets overlap); bit1: keep both nets on one stream */
 } adas_pipeline_desc;
 int adas_pipeline_create(const adas_pipeline_desc* d, adas_pipeline** out);
 int adas_pipeline_destroy(adas_pipeline* p);

@@ -87,3 +87,42 @@ def test_halo_equals_gather_bitwise_shape(CE, monkeypatch):
     possible here, so compare both against the oracle at the tighter 5e-3)."""
     rel, mx = run_case(CE, 80, 80, 64, 64, 3, 1, M.ACT_SILU, M.RES_AFTER_ACT, "bf16")
     assert rel < 5e-3
+
+
+def run_fc_case(CE, batch, cin, cout, act, f32_out, seed=0):
+    """input (3,1,1) -> Linear(3, cin)+SiLU -> Linear(cin, cout) under test: both are 1x1-spatial convs and take the
+    weight-streaming FC kernel (conv_fc.hip) in bf16 mode."""
+    ws = M.SynthWeights(seed, gain=1.0)
+    g = M.Graph("fcunit", 3, 1, 1, ws)
+    x, c3 = g.input()
+    a = g.conv(x, cin, 1, 1, "expand", act=M.ACT_SILU, true_cin=c3)
+    y = g.conv(a, cout, 1, 1, "test", act=act, f32_out=f32_out)
+    g.output(y, 0, [1, cout], "o") if f32_out else None
+    if not f32_out:
+        z = g.conv(y, 8, 1, 1, "tap", act=M.ACT_NONE, f32_out=True)
+        g.output(z, 0, [1, 8], "o")
+    path = os.path.join(tempfile.gettempdir(), f"fcunit_{batch}_{cin}_{cout}_{act}_{int(f32_out)}.hipm")
+    g.save(path)
+    e = CE.HipEngine(path, "bf16", batch)
+    xin = np.random.default_rng(seed).uniform(-1, 1, (batch, 3, 1, 1)).astype(np.float32)
+    out = e.engine_inference(xin)
+    got = e.fetch_activation("test", batch).reshape(batch, cout)
+    if f32_out:
+        assert np.array_equal(out[0].reshape(batch, cout), got)
+    e.close(); os.remove(path)
+    Wt = {k_: torch.from_numpy(v) for k_, v in ws.store.items()}
+    with torch.no_grad():
+        t = torch.from_numpy(xin).reshape(batch, 3)
+        a_ = F.silu(F.linear(t, Wt["expand.weight"].reshape(cin, 3), Wt["expand.bias"]))
+        yv = F.linear(a_, Wt["test.weight"].reshape(cout, cin), Wt["test.bias"])
+        yv = {M.ACT_NONE: lambda v: v, M.ACT_SILU: F.silu, M.ACT_RELU: F.relu}[act](yv)
+    want = yv.numpy()
+    return float(np.linalg.norm(got - want) / (np.linalg.norm(want) + 1e-30))
+
+
+@pytest.mark.parametrize("batch", [1, 16, 17, 33, 64])
+def test_fc_weight_streaming_kernel(CE, batch):
+    # (cin, cout): split-K path (cout <= 8192, K = 4000 = 125 k-steps over 4 waves), wide path with a ragged last tile
+    for cin, cout, act, f32 in ((4000, 2048, M.ACT_RELU, False), (2048, 8200, M.ACT_NONE, True), (96, 20, M.ACT_SILU, True)):
+        rel = run_fc_case(CE, batch, cin, cout, act, f32)
+        assert rel < 1e-2, (batch, cin, cout, rel)

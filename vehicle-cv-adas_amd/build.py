@@ -19,6 +19,7 @@ UNITS = [
     ("post_kernels.hip", ["-ffp-contract=off"]),
     ("conv_kernels.hip", []),
     ("conv_halo.hip", []),
+    ("conv_fc.hip", []),
     ("aux_kernels.hip", []),
     ("engine.cpp", []),
     ("pipeline.cpp", []),

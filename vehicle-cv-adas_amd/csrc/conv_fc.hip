@@ -1,0 +1,219 @@
+// conv_fc.hip -- the two Linear layers of the UFLDv2 head (model_culane.py:33-37: 4000 -> 2048 -> 91,224)
+// at M = batch <= 64 rows: a weight-streaming kernel, HBM-bound on the bf16 weight matrix
+// (cls.3: 2048 x 91,224 x 2 B = 374 MB per step).
+//
+// The implicit-GEMM conv kernel tiles M = batch into 64/128-row blocks, which leaves cls.1 with 32
+// workgroups walking K = 4000 serially (123 us for 16 MB of weights) and cls.3 at 2.5 TB/s.  Here every
+// wave owns TN x 16 output features and streams its weight rows straight from HBM into MFMA A-operand
+// registers (no LDS: a 16x16x32 bf16 A fragment is 16 rows x 64 contiguous bytes, lane (row, kg) loads its
+// own 16 B); the activations (<= 64 x K bf16, L2-resident) are the B operand, loaded the same way.
+// The weights are packed at load time in fragment order ("CONV_FC" packing): the 1 KB a wave needs for
+// (feature tile t, K step s) is one contiguous block [t][s][lane][8], so every wave-level load is a fully
+// coalesced 1 KB read and a wave walks one contiguous 16-row slab of the matrix front to back.
+// A U-deep register ring keeps U K-steps of loads in flight per wave.  Layers with few output tiles
+// (cls.1) split K across the KS waves of a workgroup and reduce through LDS before the fused
+// bias + ReLU epilogue.
+#include "kernels.h"
+
+namespace adas {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 fbf16x8;
+typedef __attribute__((ext_vector_type(4))) float ff32x4;
+typedef __attribute__((ext_vector_type(4))) uint32_t fu32x4;
+typedef __attribute__((ext_vector_type(2))) float ff32x2;
+typedef __attribute__((ext_vector_type(2))) __bf16 fbf16x2;
+
+struct FcDev {
+    const uint16_t* x;    // [batch][x_cs] bf16 (+ x_coff)
+    const uint16_t* w;    // [cout_pad][kpad] bf16, zero padded
+    const float* bias;    // [cout_pad]
+    void* out;            // [batch][out_cs] (+ out_coff), bf16 or fp32
+    int x_cs, x_coff, out_cs, out_coff;
+    int batch, cout, kpad, act, out_f32;
+};
+
+__device__ __forceinline__ uint32_t fc_pack2(float a, float b) {
+    fbf16x2 r = __builtin_convertvector(ff32x2{a, b}, fbf16x2);
+    return __builtin_bit_cast(uint32_t, r);
+}
+
+template <int TN, int TM, int KS, int U>
+__global__ __launch_bounds__(64 * KS) void fc_kernel(FcDev a) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lrow = lane & 15, kg = lane >> 4;
+    const int n0 = blockIdx.x * (TN * 16);
+    const int KT = a.kpad >> 5;
+    const int ks0 = (int)((long)KT * wave / KS), ks1 = (int)((long)KT * (wave + 1) / KS);
+    const int n = ks1 - ks0;
+
+    // fragment-ordered weights: block (tile, ks) is 64 lanes x 8 bf16
+    const uint16_t* wp[TN];
+#pragma unroll
+    for (int i = 0; i < TN; ++i) wp[i] = a.w + ((size_t)(blockIdx.x * TN + i) * KT + ks0) * 512 + lane * 8;
+    const uint16_t* xp[TM];
+#pragma unroll
+    for (int j = 0; j < TM; ++j) {
+        const int m = j * 16 + lrow;
+        xp[j] = a.x + (size_t)(m < a.batch ? m : 0) * a.x_cs + a.x_coff + kg * 8 + ks0 * 32;
+    }
+
+    ff32x4 acc[TN][TM];
+#pragma unroll
+    for (int i = 0; i < TN; ++i)
+#pragma unroll
+        for (int j = 0; j < TM; ++j) acc[i][j] = ff32x4{0.f, 0.f, 0.f, 0.f};
+
+    fu32x4 wa[U][TN], xb[U][TM];
+    auto load = [&](int buf, int s) {  // s: K step relative to ks0
+#pragma unroll
+        for (int i = 0; i < TN; ++i) wa[buf][i] = __builtin_nontemporal_load(reinterpret_cast<const fu32x4*>(wp[i] + (size_t)s * 512));
+#pragma unroll
+        for (int j = 0; j < TM; ++j) xb[buf][j] = *reinterpret_cast<const fu32x4*>(xp[j] + s * 32);
+    };
+    auto mma = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < TN; ++i)
+#pragma unroll
+            for (int j = 0; j < TM; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(fbf16x8, wa[buf][i]),
+                                                                    __builtin_bit_cast(fbf16x8, xb[buf][j]), acc[i][j], 0, 0, 0);
+    };
+    if (n >= U) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) load(u, u);
+        const int main_steps = ((n - U) / U) * U;  // steps whose ring slot is refilled unconditionally
+        int s = 0;
+        for (; s < main_steps; s += U) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                mma(u);
+                load(u, s + u + U);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            mma(u);
+            if (s + u + U < n) load(u, s + u + U);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+            if (s + U + u < n) mma(u);
+    } else {
+        for (int s = 0; s < n; ++s) {
+            load(0, s);
+            mma(0);
+        }
+    }
+
+    // rows of batch entries that do not exist accumulated row 0's activations: never stored.
+    if constexpr (KS > 1) {
+        __shared__ float red[KS > 1 ? KS - 1 : 1][TN * TM * 4][64];
+        if (wave > 0) {
+#pragma unroll
+            for (int i = 0; i < TN; ++i)
+#pragma unroll
+                for (int j = 0; j < TM; ++j)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) red[wave - 1][(i * TM + j) * 4 + r][lane] = acc[i][j][r];
+        }
+        __syncthreads();
+        if (wave > 0) return;
+#pragma unroll
+        for (int s = 0; s < KS - 1; ++s)
+#pragma unroll
+            for (int i = 0; i < TN; ++i)
+#pragma unroll
+                for (int j = 0; j < TM; ++j)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc[i][j][r] += red[s][(i * TM + j) * 4 + r][lane];
+    }
+
+    // ---- epilogue: lane holds features c..c+3 of batch row m
+#pragma unroll
+    for (int i = 0; i < TN; ++i) {
+        const int c = n0 + i * 16 + kg * 4;
+        if (c >= a.cout) continue;
+        const float4 b4 = *reinterpret_cast<const float4*>(a.bias + c);
+#pragma unroll
+        for (int j = 0; j < TM; ++j) {
+            const int m = j * 16 + lrow;
+            if (m >= a.batch) continue;
+            float v[4] = {acc[i][j][0] + b4.x, acc[i][j][1] + b4.y, acc[i][j][2] + b4.z, acc[i][j][3] + b4.w};
+            if (a.act == ACT_RELU) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+            } else if (a.act == ACT_SILU) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = v[r] * __frcp_rn(1.0f + __expf(-v[r]));
+            }
+            const size_t o = (size_t)m * a.out_cs + a.out_coff + c;
+            if (a.out_f32) {
+                *reinterpret_cast<float4*>((float*)a.out + o) = make_float4(v[0], v[1], v[2], v[3]);
+            } else {
+                uint2 q;
+                q.x = fc_pack2(v[0], v[1]);
+                q.y = fc_pack2(v[2], v[3]);
+                *reinterpret_cast<uint2*>((uint16_t*)a.out + o) = q;
+            }
+        }
+    }
+}
+
+// Static-shape test used both at load time (weight packing) and at launch time: max_n = the engine's max_batch.
+bool fc_applicable(int prec, int kh, int kw, int stride, int max_n, const TView& in, const TView& out) {
+    if (prec != PREC_BF16 || in.f32) return false;
+    if (kh != 1 || kw != 1 || stride != 1 || in.h != 1 || in.w != 1 || out.h != 1 || out.w != 1) return false;
+    if (max_n > 64) return false;
+    if ((in.cs & 7) || (in.coff & 7) || (in.c & 7) || (out.c & 3) || (out.cs & 3) || (out.coff & 3)) return false;
+    return true;
+}
+
+template <int TN, int TM, int KS, int U>
+static hipError_t fc_launch(const FcDev& d, hipStream_t st) {
+    const int tiles = (d.cout + TN * 16 - 1) / (TN * 16);
+    hipLaunchKernelGGL((fc_kernel<TN, TM, KS, U>), dim3(tiles), dim3(64 * KS), 0, st, d);
+    return hipGetLastError();
+}
+
+hipError_t launch_fc(const ConvArgs& a, hipStream_t st) {
+    FcDev d;
+    d.x = (const uint16_t*)a.in.p; d.w = (const uint16_t*)a.wgt; d.bias = a.bias; d.out = a.out.p;
+    d.x_cs = a.in.cs; d.x_coff = a.in.coff; d.out_cs = a.out.cs; d.out_coff = a.out.coff;
+    d.batch = a.n; d.cout = a.out.c; d.kpad = a.kpad; d.act = a.act; d.out_f32 = a.out.f32;
+    const int tm = a.n <= 16 ? 1 : (a.n <= 32 ? 2 : 4);
+    // few output tiles (cls.1: 2048 features): 16 features per workgroup, K split over 4 waves
+    const bool split = a.out.c <= 8192;
+    if (split) {
+        if (tm == 1) return fc_launch<1, 1, 4, 4>(d, st);
+        if (tm == 2) return fc_launch<1, 2, 4, 4>(d, st);
+        return fc_launch<1, 4, 4, 4>(d, st);
+    }
+    if (tm == 1) return fc_launch<4, 1, 1, 4>(d, st);
+    if (tm == 2) return fc_launch<4, 2, 1, 4>(d, st);
+    return fc_launch<4, 4, 1, 3>(d, st);
+}
+
+// fp32 [cout][cin] -> bf16 fragment order [cout_pad/16][kpad/32][64 lanes][8]: lane = (k%32/8)*16 + row%16
+__global__ void pack_weights_fc_kernel(const float* __restrict__ src, uint16_t* __restrict__ dst, int cout, int cin, int kpad, size_t total) {
+    const int KT = kpad >> 5;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int e = (int)(i & 7), lane = (int)((i >> 3) & 63);
+        const size_t blk = i >> 9;
+        const int ks = (int)(blk % KT);
+        const size_t tile = blk / KT;
+        const size_t row = tile * 16 + (lane & 15);
+        const int k = ks * 32 + (lane >> 4) * 8 + e;
+        const float v = (row < (size_t)cout && k < cin) ? src[row * cin + k] : 0.0f;
+        fbf16x2 r = __builtin_convertvector(ff32x2{v, 0.f}, fbf16x2);
+        dst[i] = (uint16_t)(__builtin_bit_cast(uint32_t, r) & 0xffffu);
+    }
+}
+
+hipError_t launch_pack_weights_fc(const float* src, void* dst, int cout, int cout_pad, int cin, int kpad, hipStream_t st) {
+    size_t total = (size_t)cout_pad * kpad;
+    int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+    hipLaunchKernelGGL(pack_weights_fc_kernel, dim3(blocks), dim3(256), 0, st, src, (uint16_t*)dst, cout, cin, kpad, total);
+    return hipGetLastError();
+}
+
+}  // namespace adas

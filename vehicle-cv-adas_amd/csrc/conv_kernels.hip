@@ -317,10 +317,23 @@ static bool halo_enabled() {
 }
 
 bool halo_applicable(int kh, int kw, int stride, int pad, const TView& in, const TView& out);  // conv_halo.hip
+bool fc_applicable(int prec, int kh, int kw, int stride, int max_n, const TView& in, const TView& out);  // conv_fc.hip
+hipError_t launch_fc(const ConvArgs& a, hipStream_t st);
+static bool fc_enabled() {
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("ADAS_NO_FC");
+        v = (e && e[0] == '1') ? 0 : 1;
+    }
+    return v == 1;
+}
 
-ConvPlan plan_conv(int prec, int kh, int kw, int stride, int pad, const TView& in, const TView& out) {
+ConvPlan plan_conv(int prec, int kh, int kw, int stride, int pad, int max_n, const TView& in, const TView& out) {
     ConvPlan p;
-    if (prec == PREC_BF16 && halo_enabled() && halo_applicable(kh, kw, stride, pad, in, out)) {
+    if (fc_enabled() && fc_applicable(prec, kh, kw, stride, max_n, in, out)) {
+        p.kernel = CONV_FC;
+        p.cin_pad = in.c;
+    } else if (prec == PREC_BF16 && halo_enabled() && halo_applicable(kh, kw, stride, pad, in, out)) {
         p.kernel = CONV_HALO;
         p.cin_pad = (in.c + 31) / 32 * 32;
     } else {
@@ -332,9 +345,10 @@ ConvPlan plan_conv(int prec, int kh, int kw, int stride, int pad, const TView& i
 }
 
 hipError_t launch_conv(const ConvArgs& a, int prec, hipStream_t st) {
-    ConvPlan pl = plan_conv(prec, a.kh, a.kw, a.stride, a.pad, a.in, a.out);
+    ConvPlan pl = plan_conv(prec, a.kh, a.kw, a.stride, a.pad, a.max_n, a.in, a.out);
     if (pl.kpad != a.kpad) return hipErrorInvalidValue;  // weights were packed for a different plan
     if (pl.kernel == CONV_HALO) return launch_conv_halo(a, st);
+    if (pl.kernel == CONV_FC) return (a.res_mode == RES_NONE && a.n <= 64) ? launch_fc(a, st) : hipErrorInvalidValue;
     ConvDev d;
     d.in = a.in.p; d.wgt = a.wgt; d.bias = a.bias; d.out = a.out.p; d.res = a.res.p;
     d.in_cs = a.in.cs; d.in_coff = a.in.coff; d.cin = a.in.c; d.H = a.in.h; d.W = a.in.w;

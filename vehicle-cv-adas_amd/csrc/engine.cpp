@@ -101,8 +101,15 @@ int adas_engine_create(const char* model_path, int precision, int max_batch, ada
         if (o.type == OP_CONV) {
             int cin = o.in_c[0], cout = o.out_c;
             op.k = o.kh * o.kw * cin;
-            ConvPlan pl = plan_conv(precision, o.kh, o.kw, o.stride, o.pad, make_view(e, o.in_buf[0], o.in_coff[0], o.in_c[0]),
+            ConvPlan pl = plan_conv(precision, o.kh, o.kw, o.stride, o.pad, max_batch, make_view(e, o.in_buf[0], o.in_coff[0], o.in_c[0]),
                                     make_view(e, o.out_buf, o.out_coff, o.out_c));
+            if (pl.kernel == CONV_FC && o.res_mode != RES_NONE) {
+                fclose(f);
+                free_engine(e);
+                set_error("[%s]: layer %s: a Linear layer cannot carry a residual", model_path, op.name.c_str());
+                return ADAS_ERR_FORMAT;
+            }
+            op.kernel = pl.kernel;
             op.kpad = pl.kpad;
             op.cin_pad = pl.cin_pad;
             op.cout_pad = (cout + 127) / 128 * 128;
@@ -148,8 +155,10 @@ int adas_engine_create(const char* model_path, int precision, int max_batch, ada
         if (o.type == OP_CONV) {
             if (!read_blob(o.w_off, o.w_elems, h_stage.data()) || o.w_elems != (uint64_t)o.out_c * op.k) { rc = ADAS_ERR_FORMAT; break; }
             if (hipMemcpy(d_stage, h_stage.data(), o.w_elems * 4, hipMemcpyHostToDevice) != hipSuccess) { rc = ADAS_ERR_HIP; break; }
-            if (launch_pack_weights(d_stage, base + op.w_off, o.out_c, op.cout_pad, o.kh * o.kw, o.in_c[0], op.cin_pad, op.kpad, precision, 0) !=
-                hipSuccess) { rc = ADAS_ERR_HIP; break; }
+            hipError_t pe = op.kernel == CONV_FC
+                                ? launch_pack_weights_fc(d_stage, base + op.w_off, o.out_c, op.cout_pad, o.in_c[0], op.kpad, 0)
+                                : launch_pack_weights(d_stage, base + op.w_off, o.out_c, op.cout_pad, o.kh * o.kw, o.in_c[0], op.cin_pad, op.kpad, precision, 0);
+            if (pe != hipSuccess) { rc = ADAS_ERR_HIP; break; }
             if (hipDeviceSynchronize() != hipSuccess) { rc = ADAS_ERR_HIP; break; }
             std::vector<float> b(op.cout_pad, 0.f);
             if (!read_blob(o.b_off, o.b_elems, b.data())) { rc = ADAS_ERR_FORMAT; break; }
@@ -251,7 +260,7 @@ int engine_run_op(adas_engine* e, int i, const float* d_in, int batch, hipStream
             a.wgt = wb + op.w_off;
             a.bias = (const float*)(wb + op.b_off);
             a.n = batch; a.kh = o.kh; a.kw = o.kw; a.stride = o.stride; a.pad = o.pad; a.act = o.act; a.res_mode = o.res_mode;
-            a.k = op.k; a.kpad = op.kpad; a.m = batch * a.out.h * a.out.w;
+            a.k = op.k; a.kpad = op.kpad; a.m = batch * a.out.h * a.out.w; a.max_n = e->max_batch;
             err = launch_conv(a, e->prec, st);
             break;
         }

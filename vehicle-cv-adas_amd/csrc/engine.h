@@ -51,6 +51,7 @@ struct EngOp {
     std::string name;
     size_t w_off, b_off;  // into the packed device weight arena
     int k, kpad, cout_pad, cin_pad;
+    int kernel = 0;  // CONV_* (kernels.h): fixes the weight packing
 };
 struct EngOut {
     uint32_t buf, offset, ndim, dims[4];

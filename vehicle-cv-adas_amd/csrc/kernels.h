@@ -24,17 +24,18 @@ struct ConvArgs {
     int n;              // batch
     int kh, kw, stride, pad, act, res_mode;
     int k, kpad, m;     // K = kh*kw*cin ; padded to 32 ; M = n*ho*wo
+    int max_n;          // the engine's max_batch (static: decides the FC weight packing)
 };
 
 // Which kernel runs a conv and how its weights are packed.  Decided once at load time from static
 // shapes and re-derived identically at launch time.
-enum { CONV_GATHER = 0, CONV_HALO = 1 };
+enum { CONV_GATHER = 0, CONV_HALO = 1, CONV_FC = 2 };
 struct ConvPlan {
     int kernel;   // CONV_*
     int cin_pad;  // channels per tap in the packed weights (halo: padded to 32 so the tail is zero)
     int kpad;     // packed K extent = round32(kh*kw*cin_pad)
 };
-ConvPlan plan_conv(int prec, int kh, int kw, int stride, int pad, const TView& in, const TView& out);
+ConvPlan plan_conv(int prec, int kh, int kw, int stride, int pad, int max_n, const TView& in, const TView& out);
 
 // returns hipSuccess or the launch error.  prec: PREC_*.
 hipError_t launch_conv(const ConvArgs& a, int prec, hipStream_t st);
@@ -55,6 +56,8 @@ hipError_t launch_layernorm(const float* in, void* out, const float* gamma, cons
 // dst [cout_pad][kpad] with element (row, tap*cin_pad + c), zero padded
 hipError_t launch_pack_weights(const float* src, void* dst, int cout, int cout_pad, int taps, int cin, int cin_pad, int kpad,
                                int prec, hipStream_t st);
+// Linear-layer packing (CONV_FC): src [cout][cin] fp32 -> bf16 MFMA-fragment order [cout_pad/16][kpad/32][64][8]
+hipError_t launch_pack_weights_fc(const float* src, void* dst, int cout, int cout_pad, int cin, int kpad, hipStream_t st);
 // NHWC (compute type or fp32) activation view -> NCHW fp32 (debug / parity tap)
 hipError_t launch_nhwc_to_nchw(TView in, float* out, int n, int prec, hipStream_t st);
 

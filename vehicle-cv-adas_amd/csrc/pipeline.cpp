@@ -10,6 +10,8 @@ struct adas_bytetrack;
 struct adas_pipeline {
     adas_pipeline_desc d;
     hipStream_t st = nullptr;
+    hipStream_t st_lane = nullptr;  // graph mode: the lane branch is captured on its own stream so the two nets overlap
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     struct Cached {
         const float* det;
         const float* lane;
@@ -23,11 +25,21 @@ struct adas_pipeline {
 
 using namespace adas;
 
+// events == true: everything on one stream with section events (per-stage timing).
+// events == false: the lane branch (net + decode) runs on st_lane, forked/joined with events, so the
+// latency-bound detector layers and the MFMA-bound lane layers share the chip (independent work:
+// demo.py:261-281 runs them back to back only because the reference is single-threaded Python).
 static int record_step(adas_pipeline* p, const float* d_det, const float* d_lane, bool events) {
     const int S = p->d.n_streams;
     hipStream_t st = p->st;
+    const bool fork = !events && p->d.detector && p->d.lane && !(p->d.use_graph & 2);
+    hipStream_t sl = fork ? p->st_lane : st;
     int rc;
     if (events) ADAS_HIP_TRY(hipEventRecord(p->ev[0], st));
+    if (fork) {
+        ADAS_HIP_TRY(hipEventRecord(p->ev_fork, st));
+        ADAS_HIP_TRY(hipStreamWaitEvent(sl, p->ev_fork, 0));
+    }
     if (p->d.detector) {
         rc = adas_engine_infer_device(p->d.detector, d_det, S, st);
         if (rc) return rc;
@@ -37,13 +49,13 @@ static int record_step(adas_pipeline* p, const float* d_det, const float* d_lane
     } else if (events) ADAS_HIP_TRY(hipEventRecord(p->ev[1], st));
     if (events) ADAS_HIP_TRY(hipEventRecord(p->ev[2], st));
     if (p->d.lane) {
-        rc = adas_engine_infer_device(p->d.lane, d_lane, S, st);
+        rc = adas_engine_infer_device(p->d.lane, d_lane, S, sl);
         if (rc) return rc;
         if (events) ADAS_HIP_TRY(hipEventRecord(p->ev[3], st));
         const adas_engine* le = p->d.lane;
         size_t stride = (size_t)le->bufs[le->outs[0].buf].h * le->bufs[le->outs[0].buf].w * le->bufs[le->outs[0].buf].c;
         rc = adas_ufld_decode_run(p->d.decode, adas_engine_output_device(le, 0), adas_engine_output_device(le, 1),
-                                  adas_engine_output_device(le, 2), adas_engine_output_device(le, 3), stride, stride, stride, stride, S, st);
+                                  adas_engine_output_device(le, 2), adas_engine_output_device(le, 3), stride, stride, stride, stride, S, sl);
         if (rc) return rc;
     } else if (events) ADAS_HIP_TRY(hipEventRecord(p->ev[3], st));
     if (events) ADAS_HIP_TRY(hipEventRecord(p->ev[4], st));
@@ -57,6 +69,10 @@ static int record_step(adas_pipeline* p, const float* d_det, const float* d_lane
         if (rc) return rc;
         rc = adas_bytetrack_update_device(p->d.tracker, xy, sc, cl, cn, cap, 4, 2, S, st);
         if (rc) return rc;
+    }
+    if (fork) {
+        ADAS_HIP_TRY(hipEventRecord(p->ev_join, sl));
+        ADAS_HIP_TRY(hipStreamWaitEvent(st, p->ev_join, 0));
     }
     if (events) ADAS_HIP_TRY(hipEventRecord(p->ev[5], st));
     return ADAS_OK;
@@ -79,11 +95,20 @@ int adas_pipeline_create(const adas_pipeline_desc* d, adas_pipeline** out) {
         delete p;
         return hip_fail(hipGetLastError(), "hipStreamCreate", __FILE__, __LINE__);
     }
+    if (hipStreamCreateWithFlags(&p->st_lane, hipStreamNonBlocking) != hipSuccess) {
+        adas_pipeline_destroy(p);
+        return hip_fail(hipGetLastError(), "hipStreamCreate", __FILE__, __LINE__);
+    }
     for (auto& e : p->ev)
         if (hipEventCreate(&e) != hipSuccess) {
-            delete p;
+            adas_pipeline_destroy(p);
             return hip_fail(hipGetLastError(), "hipEventCreate", __FILE__, __LINE__);
         }
+    if (hipEventCreateWithFlags(&p->ev_fork, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&p->ev_join, hipEventDisableTiming) != hipSuccess) {
+        adas_pipeline_destroy(p);
+        return hip_fail(hipGetLastError(), "hipEventCreate", __FILE__, __LINE__);
+    }
     *out = p;
     return ADAS_OK;
 }
@@ -96,6 +121,9 @@ int adas_pipeline_destroy(adas_pipeline* p) {
     }
     for (auto& e : p->ev)
         if (e) (void)hipEventDestroy(e);
+    if (p->ev_fork) (void)hipEventDestroy(p->ev_fork);
+    if (p->ev_join) (void)hipEventDestroy(p->ev_join);
+    if (p->st_lane) (void)hipStreamDestroy(p->st_lane);
     if (p->st) (void)hipStreamDestroy(p->st);
     delete p;
     return ADAS_OK;
@@ -105,7 +133,7 @@ int adas_pipeline_step(adas_pipeline* p, const float* d_det, const float* d_lane
     ADAS_REQUIRE(p, ADAS_ERR_INVALID, "null pipeline");
     ADAS_REQUIRE(!p->d.detector || d_det, ADAS_ERR_INVALID, "detector input missing");
     ADAS_REQUIRE(!p->d.lane || d_lane, ADAS_ERR_INVALID, "lane input missing");
-    if (!p->d.use_graph) {
+    if (!(p->d.use_graph & 1)) {
         p->timed = true;
         return record_step(p, d_det, d_lane, true);
     }

@@ -19,7 +19,7 @@ CULANE = dict(grid_row=200, cls_row=72, grid_col=100, cls_col=81,
 class AdasPipeline:
     def __init__(self, det_model=None, lane_model=None, n_streams=1, precision="bf16", src_hw=(720, 1280),
                  box_score=0.4, nms_iou=0.45, head_layout=L.HEAD_V8, num_classes=80, use_graph=True,
-                 max_candidates=512, track=True, lane_cfg=None, nms_mode=L.NMS_REFERENCE):
+                 max_candidates=512, track=True, lane_cfg=None, nms_mode=L.NMS_REFERENCE, overlap=True):
         self.S = n_streams
         self.det = self.lane = self.post = self.decode = self.tracker = None
         if det_model:
@@ -39,7 +39,7 @@ class AdasPipeline:
                                      cfg["row_anchor"], cfg["col_anchor"], 1, n_streams)
         d = L.PipelineDesc(self.det.handle if self.det else None, self.lane.handle if self.lane else None,
                            self.post.h if self.post else None, self.decode.h if self.decode else None,
-                           self.tracker.h if self.tracker else None, n_streams, 1 if use_graph else 0)
+                           self.tracker.h if self.tracker else None, n_streams, (1 if use_graph else 0) | (0 if overlap else 2))
         h = C.c_void_p()
         L.check(L.lib().adas_pipeline_create(C.byref(d), C.byref(h)))
         self.h = h.value
