@@ -126,3 +126,50 @@ def test_fc_weight_streaming_kernel(CE, batch):
     for cin, cout, act, f32 in ((4000, 2048, M.ACT_RELU, False), (2048, 8200, M.ACT_NONE, True), (96, 20, M.ACT_SILU, True)):
         rel = run_fc_case(CE, batch, cin, cout, act, f32)
         assert rel < 1e-2, (batch, cin, cout, rel)
+
+
+def run_stem_case(CE, H, W, k, pad, cout, act, pool, batch=3, seed=0):
+    """NCHW fp32 input -> stride-2 kxk conv (+ 3x3 s2 p1 max-pool) through the fused stem kernel (conv_stem.hip)."""
+    ws = M.SynthWeights(seed, gain=1.0)
+    g = M.Graph("stemunit", 3, H, W, ws)
+    x, c3 = g.input()
+    y = g.conv(x, cout, k, 2, "stem", act=act, true_cin=c3, pad=pad)
+    last = g.maxpool(y, 3, 2, 1, name="pool") if pool else y
+    z = g.conv(last, 8, 1, 1, "tap", act=M.ACT_NONE, f32_out=True)
+    g.output(z, 0, [1, z.h * z.w * 8], "o")
+    path = os.path.join(tempfile.gettempdir(), f"stemunit_{H}_{W}_{k}_{cout}_{act}_{int(pool)}.hipm")
+    g.save(path)
+    e = CE.HipEngine(path, "bf16", batch)
+    xin = np.random.default_rng(seed).uniform(-1, 1, (batch, 3, H, W)).astype(np.float32)
+    e.engine_inference(xin)
+    got = e.fetch_activation("pool" if pool else "stem", batch)
+    if pool:
+        with pytest.raises(Exception, match="fused"):
+            e.fetch_activation("stem", batch)
+    e.close(); os.remove(path)
+    Wt = {k_: torch.from_numpy(v) for k_, v in ws.store.items()}
+    with torch.no_grad():
+        actf = {M.ACT_SILU: F.silu, M.ACT_RELU: F.relu}[act]
+        yv = actf(F.conv2d(torch.from_numpy(xin), Wt["stem.weight"], Wt["stem.bias"], stride=2, padding=pad))
+        if pool:
+            yv = F.max_pool2d(yv, 3, 2, 1)
+    want = yv.numpy()
+    assert got.shape == want.shape, (got.shape, want.shape)
+    return float(np.linalg.norm(got - want) / (np.linalg.norm(want) + 1e-30))
+
+
+@pytest.mark.parametrize("case", [
+    # H, W, k, pad, cout, act, pool
+    (64, 128, 7, 3, 64, M.ACT_RELU, True),      # ResNet stem, whole tiles
+    (62, 150, 7, 3, 64, M.ACT_RELU, True),      # ragged conv and pool tiles
+    (30, 34, 7, 3, 64, M.ACT_RELU, True),       # smaller than one tile
+    (64, 64, 3, 1, 16, M.ACT_SILU, False),      # YOLOv8n model.0
+    (70, 90, 3, 1, 32, M.ACT_SILU, False),      # YOLOv8s, ragged
+    (66, 130, 3, 1, 64, M.ACT_SILU, False),     # YOLOv8l
+    (64, 96, 6, 2, 16, M.ACT_SILU, False),      # YOLOv5n model.0 (6x6 s2 p2)
+    (62, 70, 6, 2, 32, M.ACT_SILU, False),
+    (48, 80, 7, 3, 64, M.ACT_SILU, False),      # 7x7 without a pool behind it
+], ids=str)
+def test_fused_stem_kernel(CE, case):
+    rel = run_stem_case(CE, *case)
+    assert rel < 1e-2, (case, rel)

@@ -98,7 +98,54 @@ int adas_engine_create(const char* model_path, int precision, int max_batch, ada
         op.f = o;
         op.name = std::string(o.name, strnlen(o.name, sizeof(o.name)));
         op.w_off = op.b_off = 0;
-        if (o.type == OP_CONV) {
+        e->ops.push_back(op);
+    }
+    // ---- first-layer fusion (conv_stem.hip): input conversion + stride-2 conv (+ the ResNet stem's max-pool) in one launch
+    {
+        const char* env = getenv("ADAS_NO_STEM");
+        const bool enabled = !(env && env[0] == '1');
+        auto reads_buf = [&](const FileOp& q, int buf) {
+            for (uint32_t k = 0; k < q.n_in && k < 8; ++k)
+                if (q.in_buf[k] == buf) return true;
+            return q.res_mode != RES_NONE && q.res_buf == buf;
+        };
+        auto is_output = [&](int buf) {
+            for (auto& q : fout)
+                if ((int)q.buf == buf) return true;
+            return false;
+        };
+        if (enabled && e->ops.size() >= 2 && fo[0].type == OP_INPUT && fo[1].type == OP_CONV && fo[1].in_buf[0] == fo[0].out_buf) {
+            bool only = true;
+            for (size_t i = 2; i < fo.size(); ++i) only = only && !reads_buf(fo[i], fo[0].out_buf);
+            bool pool = e->ops.size() >= 3 && fo[2].type == OP_MAXPOOL && fo[2].kh == 3 && fo[2].stride == 2 && fo[2].pad == 1 &&
+                        fo[2].in_buf[0] == fo[1].out_buf && fo[2].in_coff[0] == fo[1].out_coff && fo[2].in_c[0] == fo[1].out_c &&
+                        !is_output(fo[1].out_buf);
+            for (size_t i = 3; i < fo.size() && pool; ++i) pool = !reads_buf(fo[i], fo[1].out_buf);
+            TView cv = make_view(e, fo[1].out_buf, fo[1].out_coff, fo[1].out_c);
+            TView pv = pool ? make_view(e, fo[2].out_buf, fo[2].out_coff, fo[2].out_c) : cv;
+            if (pool && !stem_applicable(precision, hd.in_c, fo[1].kh, fo[1].kw, fo[1].stride, fo[1].pad, fo[1].act, fo[1].res_mode, cv, true, pv)) pool = false;
+            if (only && stem_applicable(precision, hd.in_c, fo[1].kh, fo[1].kw, fo[1].stride, fo[1].pad, fo[1].act, fo[1].res_mode, cv, pool, pool ? pv : cv)) {
+                e->ops[0].skip = true;
+                e->ops[1].kernel = CONV_STEM;
+                if (pool) {
+                    e->ops[1].fuse_pool = 2;
+                    e->ops[2].skip = true;
+                }
+            }
+        }
+    }
+    for (auto& op : e->ops) {
+        const FileOp& o = op.f;
+        if (o.type == OP_CONV && op.kernel == CONV_STEM) {
+            op.k = o.kh * o.kw * o.in_c[0];
+            op.kpad = 32 * o.kh;
+            op.cin_pad = 4;
+            op.cout_pad = (o.out_c + 127) / 128 * 128;
+            op.w_off = packed_total;
+            packed_total += (stem_weight_bytes(o.kh, o.out_c) + 255) & ~(size_t)255;
+            op.b_off = packed_total;
+            packed_total += ((size_t)op.cout_pad * 4 + 255) & ~(size_t)255;
+        } else if (o.type == OP_CONV) {
             int cin = o.in_c[0], cout = o.out_c;
             op.k = o.kh * o.kw * cin;
             ConvPlan pl = plan_conv(precision, o.kh, o.kw, o.stride, o.pad, max_batch, make_view(e, o.in_buf[0], o.in_coff[0], o.in_c[0]),
@@ -126,7 +173,6 @@ int adas_engine_create(const char* model_path, int precision, int max_batch, ada
             op.w_off = packed_total;
             packed_total += 256;
         }
-        e->ops.push_back(op);
     }
     e->weight_bytes = packed_total;
     if (hipMalloc(&e->d_weights, packed_total + 256) != hipSuccess) {
@@ -155,6 +201,15 @@ int adas_engine_create(const char* model_path, int precision, int max_batch, ada
         if (o.type == OP_CONV) {
             if (!read_blob(o.w_off, o.w_elems, h_stage.data()) || o.w_elems != (uint64_t)o.out_c * op.k) { rc = ADAS_ERR_FORMAT; break; }
             if (hipMemcpy(d_stage, h_stage.data(), o.w_elems * 4, hipMemcpyHostToDevice) != hipSuccess) { rc = ADAS_ERR_HIP; break; }
+            if (op.kernel == CONV_STEM) {
+                std::vector<uint16_t> frag(stem_weight_bytes(o.kh, o.out_c) / 2);
+                stem_pack_weights(h_stage.data(), o.out_c, o.kh, o.kw, o.in_c[0], hd.in_c, frag.data());
+                if (hipMemcpy(base + op.w_off, frag.data(), frag.size() * 2, hipMemcpyHostToDevice) != hipSuccess) { rc = ADAS_ERR_HIP; break; }
+                std::vector<float> b(op.cout_pad, 0.f);
+                if (!read_blob(o.b_off, o.b_elems, b.data())) { rc = ADAS_ERR_FORMAT; break; }
+                if (hipMemcpy(base + op.b_off, b.data(), (size_t)op.cout_pad * 4, hipMemcpyHostToDevice) != hipSuccess) { rc = ADAS_ERR_HIP; break; }
+                continue;
+            }
             hipError_t pe = op.kernel == CONV_FC
                                 ? launch_pack_weights_fc(d_stage, base + op.w_off, o.out_c, op.cout_pad, o.in_c[0], op.kpad, 0)
                                 : launch_pack_weights(d_stage, base + op.w_off, o.out_c, op.cout_pad, o.kh * o.kw, o.in_c[0], op.cin_pad, op.kpad, precision, 0);
@@ -247,6 +302,23 @@ int engine_run_op(adas_engine* e, int i, const float* d_in, int batch, hipStream
     const FileOp& o = op.f;
     unsigned char* wb = (unsigned char*)e->d_weights;
     hipError_t err = hipSuccess;
+    if (op.skip) return ADAS_OK;  // folded into the stem launch
+    if (o.type == OP_CONV && op.kernel == CONV_STEM) {
+        TView cv = make_view(e, o.out_buf, o.out_coff, o.out_c);
+        TView pv = cv;
+        if (op.fuse_pool >= 0) {
+            const FileOp& po = e->ops[op.fuse_pool].f;
+            pv = make_view(e, po.out_buf, po.out_coff, po.out_c);
+        }
+        err = launch_conv_stem(d_in, batch, e->hdr.in_c, e->hdr.in_h, e->hdr.in_w, o.kh, o.pad, o.act, wb + op.w_off,
+                               (const float*)(wb + op.b_off), cv, op.fuse_pool >= 0, pv, st);
+        if (err != hipSuccess) {
+            set_error("layer %d (%s): stem launch failed: %s", i, op.name.c_str(), hipGetErrorString(err));
+            (void)hipGetLastError();
+            return ADAS_ERR_HIP;
+        }
+        return ADAS_OK;
+    }
     switch (o.type) {
         case OP_INPUT:
             err = launch_input_nchw(d_in, make_view(e, o.out_buf, 0, 8), batch, e->hdr.in_c, e->prec, st);
@@ -379,6 +451,9 @@ int adas_engine_profile(adas_engine* e, const float* d_input, int batch, int ite
 int adas_engine_fetch_activation(adas_engine* e, int layer, int batch, float* h_out, int64_t dims[4]) {
     ADAS_REQUIRE(e && layer >= 0 && layer < (int)e->ops.size() && batch > 0 && batch <= e->max_batch, ADAS_ERR_INVALID, "bad layer/batch");
     const FileOp& o = e->ops[layer].f;
+    ADAS_REQUIRE(!(e->ops[layer].skip && o.type == OP_INPUT) && !(e->ops[layer].kernel == CONV_STEM && e->ops[layer].fuse_pool >= 0), ADAS_ERR_INVALID,
+                 "layer %d (%s) is fused into the stem launch and has no materialised activation (ADAS_NO_STEM=1 keeps it)", layer,
+                 e->ops[layer].name.c_str());
     TView v = make_view(e, o.out_buf, o.out_coff, o.out_c);
     if (o.type == OP_INPUT) v.c = 8;
     if (dims) { dims[0] = batch; dims[1] = v.c; dims[2] = v.h; dims[3] = v.w; }

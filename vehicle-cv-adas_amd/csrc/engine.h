@@ -52,6 +52,8 @@ struct EngOp {
     size_t w_off, b_off;  // into the packed device weight arena
     int k, kpad, cout_pad, cin_pad;
     int kernel = 0;  // CONV_* (kernels.h): fixes the weight packing
+    bool skip = false;       // fused into a neighbouring launch (input conversion / stem max-pool)
+    int fuse_pool = -1;      // CONV_STEM: index of the max-pool op folded into this conv, or -1
 };
 struct EngOut {
     uint32_t buf, offset, ndim, dims[4];

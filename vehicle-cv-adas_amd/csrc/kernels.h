@@ -29,7 +29,7 @@ struct ConvArgs {
 
 // Which kernel runs a conv and how its weights are packed.  Decided once at load time from static
 // shapes and re-derived identically at launch time.
-enum { CONV_GATHER = 0, CONV_HALO = 1, CONV_FC = 2 };
+enum { CONV_GATHER = 0, CONV_HALO = 1, CONV_FC = 2, CONV_STEM = 3 };
 struct ConvPlan {
     int kernel;   // CONV_*
     int cin_pad;  // channels per tap in the packed weights (halo: padded to 32 so the tail is zero)
@@ -56,6 +56,13 @@ hipError_t launch_layernorm(const float* in, void* out, const float* gamma, cons
 // dst [cout_pad][kpad] with element (row, tap*cin_pad + c), zero padded
 hipError_t launch_pack_weights(const float* src, void* dst, int cout, int cout_pad, int taps, int cin, int cin_pad, int kpad,
                                int prec, hipStream_t st);
+// Fused first layer (conv_stem.hip): NCHW fp32 seam tensor -> stride-2 conv + act [+ 3x3 s2 p1 max-pool] -> NHWC bf16.
+bool stem_applicable(int prec, int in_c_true, int kh, int kw, int stride, int pad, int act, int res_mode, const TView& out, bool pool,
+                     const TView& pool_out);
+size_t stem_weight_bytes(int kh, int cout);
+void stem_pack_weights(const float* w_ohwi, int cout, int kh, int kw, int cs, int c_true, uint16_t* dst_host);
+hipError_t launch_conv_stem(const float* nchw, int n, int c_true, int H, int W, int kh, int pad, int act, const void* wfrag,
+                            const float* bias, const TView& conv_out, bool pool, const TView& pool_out, hipStream_t st);
 // Linear-layer packing (CONV_FC): src [cout][cin] fp32 -> bf16 MFMA-fragment order [cout_pad/16][kpad/32][64][8]
 hipError_t launch_pack_weights_fc(const float* src, void* dst, int cout, int cout_pad, int cin, int kpad, hipStream_t st);
 // NHWC (compute type or fp32) activation view -> NCHW fp32 (debug / parity tap)
