@@ -78,6 +78,19 @@ int adas_engine_layer_info(const adas_engine* e, int layer, char* name, int name
 int adas_engine_fetch_activation(adas_engine* e, int layer, int batch, float* h_out_nchw, int64_t dims[4]);
 
 /* ===================================================================================
+ * Frame pre-processing on the device (the layer in front of the engine seam): `n` BGR u8 frames
+ * (H x W x 3, tightly packed, back to back) in HBM -> the (n,3,h,w) fp32 tensor engine_inference takes.
+ * adas_preprocess_yolo replaces YoloDetector.__prepare_input (yoloDetector.py:96-102) =
+ * Scaler.process_image (utils.py:42-63) + cv2.dnn.blobFromImage(1/255, swapRB);
+ * adas_preprocess_ufld replaces UltrafastLaneDetectorV2.__prepare_input (ultrafastLaneDetectorV2.py:96-112).
+ * cv2.resize INTER_LINEAR is restated from OpenCV's 8-bit fixed-point path (parity with cv2 unpinned).
+ * =================================================================================== */
+int adas_preprocess_yolo(const uint8_t* d_frames_bgr, int n, int src_h, int src_w, float* d_out_nchw, int dst_h,
+                         int dst_w, int keep_ratio, void* stream);
+int adas_preprocess_ufld(const uint8_t* d_frames_bgr, int n, int src_h, int src_w, float* d_out_nchw, int in_h,
+                         int in_w, double crop_ratio, void* stream);
+
+/* ===================================================================================
  * YOLO post-processing: replaces YoloDetector.__process_output (yoloDetector.py:104-133),
  * Scaler.convert_boxes_coordinate (utils.py:70-87), NMS.fast_soft_nms / NMS.fast_nms
  * (utils.py:161-256 / 105-159), get_nms_results + RectInfo.tolist (yoloDetector.py:135-157,

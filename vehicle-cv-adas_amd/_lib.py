@@ -81,6 +81,8 @@ _SIGS = {
     "adas_engine_profile": (C.c_int, [_P, _P, C.c_int, C.c_int, _P, C.c_int, C.POINTER(C.c_int)]),
     "adas_engine_layer_info": (C.c_int, [_P, C.c_int, C.c_char_p, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int)]),
     "adas_engine_fetch_activation": (C.c_int, [_P, C.c_int, C.c_int, _P, C.POINTER(C.c_int64)]),
+    "adas_preprocess_yolo": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, _P, C.c_int, C.c_int, C.c_int, _P]),
+    "adas_preprocess_ufld": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, _P, C.c_int, C.c_int, C.c_double, _P]),
     "adas_letterbox_params": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(YoloPostParams)]),
     "adas_yolo_post_create": (C.c_int, [C.POINTER(YoloPostParams), C.c_int, C.POINTER(_P)]),
     "adas_yolo_post_destroy": (C.c_int, [_P]),

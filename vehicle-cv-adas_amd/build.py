@@ -17,6 +17,7 @@ ARCH = "gfx950"
 UNITS = [
     ("api_common.cpp", []),
     ("post_kernels.hip", ["-ffp-contract=off"]),
+    ("pre_kernels.hip", ["-ffp-contract=off"]),
     ("conv_kernels.hip", []),
     ("conv_halo.hip", []),
     ("conv_fc.hip", []),

@@ -1,0 +1,164 @@
+// pre_kernels.hip -- frame pre-processing on the device: one BGR u8 frame per stream is
+// uploaded once (2.76 MB at 1280x720) and both networks' input tensors are produced from it in HBM.
+//
+//   adas_preprocess_yolo  <- YoloDetector.__prepare_input (yoloDetector.py:96-102) = Scaler.process_image
+//                            (utils.py:42-63: letterbox, cv2.resize INTER_LINEAR, canvas 114) +
+//                            cv2.dnn.blobFromImage(1/255, swapRB=True) -> (N,3,H,W) fp32
+//   adas_preprocess_ufld  <- UltrafastLaneDetectorV2.__prepare_input (ultrafastLaneDetectorV2.py:96-112):
+//                            BGR->RGB, resize to (W, int(H/crop_ratio)), keep the bottom H rows,
+//                            ((x/255 - mean)/std) with the reference's float32/float64 promotion -> fp32
+//
+// cv2.resize is third-party arithmetic (opencv-python==4.5.4.60, requirements.txt:1) and not available here:
+// the bilinear step restates OpenCV's 8-bit INTER_LINEAR reference path (imgproc/src/resize.cpp: float source
+// coordinate (dx+0.5)*scale-0.5, 11-bit fixed-point coefficients, two-pass HResize/VResize rounding
+// ((b0*(S0>>4))>>16 + (b1*(S1>>4))>>16 + 2)>>2).  Parity with a real cv2 build is UNPINNED; identity-size
+// resizes are exact by construction.  HBM-bound streaming kernels: one thread per output pixel.
+#include "common.h"
+#include <math.h>
+
+namespace {
+
+struct ResizeGeom {
+    int sh, sw;        // source
+    int rh, rw;        // resized image
+    double scale_y, scale_x;
+};
+
+__device__ __forceinline__ void lin_coef(int d, double scale, int ssize, int* s0, int* s1, int* c0, int* c1, bool horizontal) {
+    float f = (float)(((double)d + 0.5) * scale - 0.5);
+    int s = (int)floorf(f);
+    f -= (float)s;
+    if (horizontal) {  // resize.cpp: out-of-range taps collapse onto the border pixel with weight 1
+        if (s < 0) { f = 0.f; s = 0; }
+        if (s >= ssize - 1) { f = 0.f; s = ssize - 1; }
+    }
+    *c0 = (int)rintf((1.f - f) * 2048.f);
+    *c1 = (int)rintf(f * 2048.f);
+    int a = s, b = s + 1;
+    a = a < 0 ? 0 : (a > ssize - 1 ? ssize - 1 : a);
+    b = b < 0 ? 0 : (b > ssize - 1 ? ssize - 1 : b);
+    *s0 = a;
+    *s1 = b;
+}
+
+// resized pixel (ry, rx) of frame `src` (HWC u8, 3 channels) -> 3 u8 values (source channel order)
+__device__ __forceinline__ void resize_px(const uint8_t* __restrict__ src, const ResizeGeom& g, int ry, int rx, int out[3]) {
+    if (g.rh == g.sh && g.rw == g.sw) {  // cv2.resize with dsize == ssize copies
+        const uint8_t* p = src + ((size_t)ry * g.sw + rx) * 3;
+        out[0] = p[0]; out[1] = p[1]; out[2] = p[2];
+        return;
+    }
+    int x0, x1, a0, a1, y0, y1, b0, b1;
+    lin_coef(rx, g.scale_x, g.sw, &x0, &x1, &a0, &a1, true);
+    lin_coef(ry, g.scale_y, g.sh, &y0, &y1, &b0, &b1, false);
+    const uint8_t* r0 = src + (size_t)y0 * g.sw * 3;
+    const uint8_t* r1 = src + (size_t)y1 * g.sw * 3;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const int h0 = r0[x0 * 3 + c] * a0 + r0[x1 * 3 + c] * a1;
+        const int h1 = r1[x0 * 3 + c] * a0 + r1[x1 * 3 + c] * a1;
+        int v = (((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1 >> 4)) >> 16) + 2) >> 2;
+        out[c] = v < 0 ? 0 : (v > 255 ? 255 : v);
+    }
+}
+
+struct YoloPreDev {
+    const uint8_t* src;
+    float* dst;
+    ResizeGeom g;
+    int n, dh, dw, padh, padw;
+};
+__global__ void preprocess_yolo_kernel(YoloPreDev d) {
+    const size_t plane = (size_t)d.dh * d.dw;
+    const size_t total = (size_t)d.n * plane;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int b = (int)(i / plane);
+        const int p = (int)(i - (size_t)b * plane);
+        const int y = p / d.dw, x = p - y * d.dw;
+        int v[3] = {114, 114, 114};  // canvas (utils.py:54)
+        const int ry = y - d.padh, rx = x - d.padw;
+        if (ry >= 0 && ry < d.g.rh && rx >= 0 && rx < d.g.rw) resize_px(d.src + (size_t)b * d.g.sh * d.g.sw * 3, d.g, ry, rx, v);
+        float* o = d.dst + (size_t)b * 3 * plane + p;
+        // blobFromImage: float32(v) * (1/255.0) evaluated in double, swapRB: plane 0 = R = source channel 2
+        o[0] = (float)((double)v[2] * (1.0 / 255.0));
+        o[plane] = (float)((double)v[1] * (1.0 / 255.0));
+        o[2 * plane] = (float)((double)v[0] * (1.0 / 255.0));
+    }
+}
+
+struct UfldPreDev {
+    const uint8_t* src;
+    float* dst;
+    ResizeGeom g;
+    int n, ih, iw, row0;
+};
+__global__ void preprocess_ufld_kernel(UfldPreDev d) {
+    const size_t plane = (size_t)d.ih * d.iw;
+    const size_t total = (size_t)d.n * plane;
+    const double mean[3] = {0.485, 0.456, 0.406}, stdv[3] = {0.229, 0.224, 0.225};
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int b = (int)(i / plane);
+        const int p = (int)(i - (size_t)b * plane);
+        const int y = p / d.iw, x = p - y * d.iw;
+        int v[3];
+        resize_px(d.src + (size_t)b * d.g.sh * d.g.sw * 3, d.g, d.row0 + y, x, v);
+        float* o = d.dst + (size_t)b * 3 * plane + p;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {  // RGB plane c = BGR source channel 2-c
+            const float q = (float)v[2 - c] / 255.0f;                    // float32 array / Python float stays float32
+            o[(size_t)c * plane] = (float)(((double)q - mean[c]) / stdv[c]);  // - list, / list promote to float64
+        }
+    }
+}
+
+int grid_for(size_t total) {
+    size_t b = (total + 255) / 256;
+    return (int)(b < 16384 ? b : 16384);
+}
+
+}  // namespace
+
+extern "C" {
+
+int adas_preprocess_yolo(const uint8_t* d_frames_bgr, int n, int src_h, int src_w, float* d_out_nchw, int dst_h, int dst_w,
+                         int keep_ratio, void* stream) {
+    ADAS_REQUIRE(d_frames_bgr && d_out_nchw && n > 0 && src_h > 0 && src_w > 0 && dst_h > 0 && dst_w > 0, ADAS_ERR_INVALID,
+                 "adas_preprocess_yolo: bad argument");
+    adas_yolo_post_params lb;
+    int rc = adas_letterbox_params(src_h, src_w, dst_h, dst_w, keep_ratio, &lb);
+    if (rc) return rc;
+    YoloPreDev d;
+    d.src = d_frames_bgr; d.dst = d_out_nchw; d.n = n; d.dh = dst_h; d.dw = dst_w; d.padh = lb.pad_h; d.padw = lb.pad_w;
+    // resized extent = Scaler._new_shape (utils.py:43-52): recover it from the ratios' definition
+    int newh = dst_h, neww = dst_w;
+    if (keep_ratio && src_h != src_w) {
+        const double hw = (double)src_h / (double)src_w;
+        if (hw > 1) neww = (int)((double)dst_w / hw);
+        else newh = (int)((double)dst_h * hw) + 1;
+    }
+    d.g.sh = src_h; d.g.sw = src_w; d.g.rh = newh; d.g.rw = neww;
+    d.g.scale_y = 1.0 / ((double)newh / (double)src_h);
+    d.g.scale_x = 1.0 / ((double)neww / (double)src_w);
+    hipLaunchKernelGGL(preprocess_yolo_kernel, dim3(grid_for((size_t)n * dst_h * dst_w)), dim3(256), 0, (hipStream_t)stream, d);
+    ADAS_HIP_TRY(hipGetLastError());
+    return ADAS_OK;
+}
+
+int adas_preprocess_ufld(const uint8_t* d_frames_bgr, int n, int src_h, int src_w, float* d_out_nchw, int in_h, int in_w,
+                         double crop_ratio, void* stream) {
+    ADAS_REQUIRE(d_frames_bgr && d_out_nchw && n > 0 && src_h > 0 && src_w > 0 && in_h > 0 && in_w > 0 && crop_ratio > 0.0 &&
+                     crop_ratio <= 1.0, ADAS_ERR_INVALID, "adas_preprocess_ufld: bad argument");
+    UfldPreDev d;
+    d.src = d_frames_bgr; d.dst = d_out_nchw; d.n = n; d.ih = in_h; d.iw = in_w;
+    const int rh = (int)((double)in_h / crop_ratio);  // ultrafastLaneDetectorV2.py:101
+    ADAS_REQUIRE(rh >= in_h, ADAS_ERR_INVALID, "resized height %d is smaller than the network input %d", rh, in_h);
+    d.row0 = rh - in_h;                               // img_input[-input_height:, :, :]
+    d.g.sh = src_h; d.g.sw = src_w; d.g.rh = rh; d.g.rw = in_w;
+    d.g.scale_y = 1.0 / ((double)rh / (double)src_h);
+    d.g.scale_x = 1.0 / ((double)in_w / (double)src_w);
+    hipLaunchKernelGGL(preprocess_ufld_kernel, dim3(grid_for((size_t)n * in_h * in_w)), dim3(256), 0, (hipStream_t)stream, d);
+    ADAS_HIP_TRY(hipGetLastError());
+    return ADAS_OK;
+}
+
+}  // extern "C"

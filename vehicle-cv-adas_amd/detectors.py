@@ -1,0 +1,497 @@
+"""Drop-in equivalents of the reference's three per-frame task wrappers, GPU-resident end to end.
+
+    YoloDetector              <- ObjectDetector/yoloDetector.py:53-157 (+ core.py RectInfo/ObjectDetectBase, utils.py Scaler/NMS)
+    UltrafastLaneDetectorV2   <- TrafficLaneDetector/ufldDetector/ultrafastLaneDetectorV2.py:56-194 (+ core.py LaneInfo/LaneDetectBase)
+    BYTETracker               <- ObjectTracker/byteTrack/byteTracker.py:10-200
+
+Same public surface (`_defaults` / `set_defaults`, `DetectFrame(frame)`, `.object_info`, `.lane_info`,
+`update(bboxes, scores, class_ids, frame)`, `reset()`), but a frame makes one trip to the GPU: the BGR u8
+frame is uploaded, letterbox/normalise (pre_kernels.hip), the network (MFMA conv engine), decode + NMS /
+lane decode (post_kernels.hip) all run in HBM, and only the survivors (<= 2 KB) come back.
+Drawing (`Draw*OnFrame`) and everything cv2 is out of scope.
+
+What stays on the host is what the reference keeps there and SURVEY 8a marks "host": RectInfo construction and
+LaneDetectBase.__update_lanes_status/__update_lanes_area (core.py:102-158: ego-lane polyfit, <1 ms).
+There is no CPU fallback for the compute path.
+"""
+import abc
+import ctypes as C
+import os
+from dataclasses import dataclass, field
+from enum import Enum
+from typing import Any, Dict, List, Tuple
+
+import numpy as np
+
+from . import _lib as L
+from .coreEngine import OnnxEngine, TensorRTEngine
+from .postproc import YoloPost, UfldDecode, DeviceTracker, letterbox
+
+
+class ObjectModelType(Enum):       # ObjectDetector/utils.py:15-23
+    YOLOV5 = 0
+    YOLOV5_LITE = 1
+    YOLOV6 = 2
+    YOLOV7 = 3
+    YOLOV8 = 4
+    YOLOV9 = 5
+    YOLOV10 = 6
+    EfficientDet = 7
+
+
+class LaneModelType(Enum):         # ufldDetector/utils.py:3-8
+    UFLD_TUSIMPLE = 0
+    UFLD_CULANE = 1
+    UFLDV2_TUSIMPLE = 2
+    UFLDV2_CULANE = 3
+    UFLDV2_CURVELANES = 4
+
+
+@dataclass
+class RectInfo:                    # ObjectDetector/core.py:8-33
+    x: float
+    y: float
+    width: float
+    height: float
+    conf: float
+    label: str
+    kpss: List[Tuple[int, int]] = field(default_factory=list)
+
+    def tolist(self, dtype=int, format_type: str = "xyxy"):
+        if format_type == "xyxy":
+            temp = [self.x, self.y, self.x + self.width, self.y + self.height]
+        else:
+            temp = [self.x, self.y, self.width, self.height]
+        return list(map(dtype, temp))
+
+    def pad(self, padding: int) -> "RectInfo":
+        return RectInfo(x=self.x - padding, y=self.y - padding, width=self.width + 2 * padding,
+                        height=self.height + 2 * padding, conf=self.conf, label=self.label, kpss=self.kpss)
+
+
+class _Defaults:
+    """set_defaults / check_defaults / get_defaults of ObjectDetectBase and LaneDetectBase (core.py:36-55)."""
+    _defaults: Dict[str, Any] = {}
+
+    @classmethod
+    def set_defaults(cls, config):
+        cls._defaults = config
+
+    @classmethod
+    def check_defaults(cls):
+        return cls._defaults
+
+    @classmethod
+    def get_defaults(cls, n):
+        if n in cls._defaults:
+            return cls._defaults[n]
+        return "Unrecognized attribute name '" + n + "'"
+
+
+def _engine_for(model_path, **kw):
+    """Suffix dispatch of yoloDetector.py:74-77 / ultrafastLaneDetectorV2.py:82-85 (both names are HipEngine here)."""
+    model_path = os.path.expanduser(model_path)
+    return TensorRTEngine(model_path, **kw) if model_path.endswith('.trt') else OnnxEngine(model_path, **kw)
+
+
+class _FrameStage:
+    """Device staging of one BGR u8 frame + the network input tensor it is turned into."""
+
+    def __init__(self):
+        self.frame = None
+        self.tensor = None
+
+    def upload(self, img):
+        img = np.ascontiguousarray(img, dtype=np.uint8)
+        if img.ndim != 3 or img.shape[2] != 3:
+            raise Exception("frame must be an HxWx3 uint8 BGR image, got %s" % (img.shape,))
+        if self.frame is None or self.frame.nbytes < img.nbytes:
+            if self.frame is not None:
+                self.frame.free()
+            self.frame = L.DeviceBuffer(img.nbytes)
+        self.frame.upload(img)
+        return img.shape[0], img.shape[1]
+
+    def tensor_for(self, shape):
+        n = int(np.prod(shape)) * 4
+        if self.tensor is None or self.tensor.nbytes < n:
+            if self.tensor is not None:
+                self.tensor.free()
+            self.tensor = L.DeviceBuffer(n)
+        return self.tensor
+
+    def close(self):
+        for b in (self.frame, self.tensor):
+            if b is not None:
+                b.free()
+        self.frame = self.tensor = None
+
+
+# =====================================================================================
+class YoloDetector(_Defaults):
+    _defaults = {
+        "model_path": './models/yolov5n-coco.onnx',
+        "model_type": ObjectModelType.YOLOV5,
+        "classes_path": './models/coco_label.txt',
+        "box_score": 0.4,
+        "box_nms_iou": 0.45,
+    }
+    V8_LIKE = (ObjectModelType.YOLOV8, ObjectModelType.YOLOV9, ObjectModelType.YOLOV10)   # yoloDetector.py:114,121
+
+    def __init__(self, logger=None, **kwargs):
+        self.__dict__.update(self._defaults)
+        self.logger = logger
+        self.precision = "bf16"
+        self.nms_mode = L.NMS_REFERENCE          # the production call (yoloDetector.py:139); NMS_GREEDY = fast_nms (:138)
+        self.max_candidates = 1024
+        self.__dict__.update(kwargs)
+        if self.model_type in (ObjectModelType.YOLOV5_LITE, ObjectModelType.EfficientDet):
+            raise Exception("%s heads are not implemented by HipEngine (SURVEY.md 8f row f4)" % self.model_type.name)
+        self._initialize_class(self.classes_path)
+        self._initialize_model(self.model_path)
+        self._stage = _FrameStage()
+        self._post = None
+        self._post_key = None
+        self._object_info = []
+
+    def _initialize_model(self, model_path: str) -> None:
+        self.engine = _engine_for(model_path, precision=self.precision)
+        if self.logger:
+            self.logger.info(f'YoloDetector Type : [{self.engine.framework_type}] || Version : [{self.engine.providers}]')
+        self.input_shapes = self.engine.get_engine_input_shape()                 # core.py:73-82
+        self.input_types = self.engine.engine_dtype
+        self.channes, self.input_height, self.input_width = self.input_shapes[1:]
+        self.output_shapes, self.output_names = self.engine.get_engine_output_shape()
+
+    def _initialize_class(self, classes_path: str) -> None:
+        classes_path = os.path.expanduser(classes_path)
+        assert os.path.isfile(classes_path), Exception("%s is not exist." % classes_path)
+        with open(classes_path) as f:
+            self.class_names = [c.strip() for c in f.readlines()]
+
+    @property
+    def object_info(self):
+        return self._object_info
+
+    def _post_for(self, src_hw):
+        key = (int(src_hw[0]), int(src_hw[1]))
+        if self._post_key != key:
+            if self._post is not None:
+                self._post.close()
+            shp = self.output_shapes[0]
+            v8 = self.model_type in self.V8_LIKE
+            A, no = (shp[2], shp[1]) if v8 else (shp[1], shp[2])
+            nc = no - 4 if v8 else no - 5
+            lb = letterbox(key, self.input_shapes[-2:])
+            self._post = YoloPost(L.HEAD_V8 if v8 else L.HEAD_V5, A, nc, float(self.box_score), float(self.box_nms_iou), lb,
+                                  self.nms_mode, self.max_candidates, 1)
+            self._post_key = key
+        return self._post
+
+    def DetectFrame(self, srcimg) -> None:
+        """yoloDetector.py:159-168 with every step on the device."""
+        h, w = self._stage.upload(srcimg)
+        t = self._stage.tensor_for(self.input_shapes)
+        L.check(L.lib().adas_preprocess_yolo(self._stage.frame.ptr, 1, h, w, t.ptr, self.input_height, self.input_width, 1, None))
+        self.engine.infer_device(t.ptr, 1, None)
+        post = self._post_for((h, w))
+        post.run_device(self.engine.output_device_ptr(0), 1, None)
+        r = post.fetch(0)
+        if r["rc"] != 0:
+            L.check(r["rc"])
+        self._last = r
+        out = []
+        for (x, y, bw, bh), conf, cid in zip(r["xywh"], r["conf"], r["class_id"]):     # get_nms_results (:141-157)
+            label = self.class_names[cid] if 0 <= cid < len(self.class_names) else "unknown"
+            out.append(RectInfo(np.float64(x), np.float64(y), np.float64(bw), np.float64(bh), conf=float(conf), label=label, kpss=[]))
+        self._object_info = out
+
+    def close(self):
+        if getattr(self, "_post", None) is not None:
+            self._post.close()
+            self._post = None
+        if getattr(self, "_stage", None) is not None:
+            self._stage.close()
+        if getattr(self, "engine", None) is not None:
+            self.engine.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+# =====================================================================================
+@dataclass
+class LaneInfo:                    # ufldDetector/core.py:7-50
+    _lanes_points: np.ndarray
+    _lanes_status: Any
+    _area_points: np.ndarray
+    _area_status: bool
+
+    @property
+    def lanes_points(self):
+        return self._lanes_points
+
+    @lanes_points.setter
+    def lanes_points(self, arr):
+        if isinstance(arr, np.ndarray):
+            self._lanes_points = arr
+        else:
+            raise Exception("The 'lanes_points' must be np.array[List[Tuple[x, y], ...], ...].")
+
+    @property
+    def lanes_status(self):
+        return self._lanes_status
+
+    @lanes_status.setter
+    def lanes_status(self, value):
+        for v in value:
+            if type(v) != bool:
+                raise Exception("The elements of 'lanes_status' must be of type bool List[bool, ...].")
+        self._lanes_status = value
+
+    @property
+    def area_status(self):
+        return self._area_status
+
+    @area_status.setter
+    def area_status(self, value):
+        raise Exception("You need to use the '__update_lanes_status' API to modify it.")
+
+    @property
+    def area_points(self):
+        return self._area_points
+
+    @area_points.setter
+    def area_points(self, value):
+        raise Exception("You need to use the '__update_lanes_area' API to modify it.")
+
+
+class ModelConfig:                 # ultrafastLaneDetectorV2.py:21-55
+    def __init__(self, model_type):
+        if model_type == LaneModelType.UFLDV2_TUSIMPLE:
+            self.img_w, self.img_h, self.griding_num, self.crop_ratio = 800, 320, 100, 0.8
+            self.row_anchor = np.linspace(160, 710, 56) / 720
+            self.col_anchor = np.linspace(0, 1, 41)
+        elif model_type == LaneModelType.UFLDV2_CURVELANES:
+            self.img_w, self.img_h, self.griding_num, self.crop_ratio = 1600, 800, 200, 0.8
+            self.row_anchor = np.linspace(0.4, 1, 72)
+            self.col_anchor = np.linspace(0, 1, 81)
+        else:
+            self.img_w, self.img_h, self.griding_num, self.crop_ratio = 1600, 320, 200, 0.6
+            self.row_anchor = np.linspace(0.42, 1, 72)
+            self.col_anchor = np.linspace(0, 1, 81)
+        self.num_lanes = 4
+
+
+def adjust_lanes_points(left_lanes_points, right_lanes_points, image_height):
+    """LaneDetectBase.__adjust_lanes_points (core.py:102-141): degree-2 polyfit of both ego lanes."""
+    if len(left_lanes_points[1]) != 0:
+        leftx, lefty = list(zip(*left_lanes_points))
+        if len(lefty) > 10:
+            left_fit = np.polyfit(lefty, leftx, 2)
+        else:
+            return left_lanes_points, right_lanes_points
+    else:
+        return left_lanes_points, right_lanes_points
+    if len(right_lanes_points) != 0:
+        rightx, righty = list(zip(*right_lanes_points))
+        if len(righty) > 10:
+            right_fit = np.polyfit(righty, rightx, 2)
+        else:
+            return left_lanes_points, right_lanes_points
+    else:
+        return left_lanes_points, right_lanes_points
+    maxy = image_height - 1
+    miny = image_height // 3
+    if len(lefty):
+        maxy = max(maxy, np.max(lefty))
+        miny = min(miny, np.min(lefty))
+    if len(righty):
+        maxy = max(maxy, np.max(righty))
+        miny = min(miny, np.min(righty))
+    both_fity = np.linspace(miny, maxy, image_height)
+    left_fitx = left_fit[0] * both_fity ** 2 + left_fit[1] * both_fity + left_fit[2]
+    right_fitx = right_fit[0] * both_fity ** 2 + right_fit[1] * both_fity + right_fit[2]
+    fix_left = [(int(l), int(y)) for l, y in zip(left_fitx, both_fity) if (y >= min(lefty) and l >= 0)]
+    fix_right = [(int(r), int(y)) for r, y in zip(right_fitx, both_fity) if (y >= min(righty) and r >= 0)]
+    return fix_left, fix_right
+
+
+class UltrafastLaneDetectorV2(_Defaults):
+    _defaults = {
+        "model_path": "models/culane_res18.onnx",
+        "model_type": LaneModelType.UFLDV2_TUSIMPLE,
+    }
+
+    def __init__(self, model_path: str = None, model_type: LaneModelType = None, logger=None, precision="bf16"):
+        self.__dict__.update(self._defaults)
+        self.logger = logger
+        self.adjust_lanes = False
+        self.lane_info = LaneInfo(np.array([], dtype=object), np.array([], dtype=object), np.array([], dtype=object), False)
+        if None not in [model_path, model_type]:
+            self.model_path, self.model_type = model_path, model_type
+        if self.model_type not in [LaneModelType.UFLDV2_TUSIMPLE, LaneModelType.UFLDV2_CULANE]:
+            raise Exception("UltrafastLaneDetectorV2 can't use %s type." % self.model_type.name)
+        self.cfg = ModelConfig(self.model_type)
+        self.precision = precision
+        self._initialize_model(self.model_path)
+        self._stage = _FrameStage()
+        self._decode = None
+        self._decode_key = None
+
+    def _initialize_model(self, model_path: str) -> None:
+        self.engine = _engine_for(model_path, precision=self.precision)
+        if self.logger:
+            self.logger.info(f'UfldDetectorV2 Type : [{self.engine.framework_type}] || Version : [{self.engine.providers}]')
+        self.input_shape = self.engine.get_engine_input_shape()
+        self.input_types = self.engine.engine_dtype
+        self.channes, self.input_height, self.input_width = self.input_shape[1:]
+        self.output_shape, self.output_names = self.engine.get_engine_output_shape()
+        if len(self.output_names) != 4:
+            raise Exception("Output dims is error, please check model. load %d channels not match 4." % len(self.output_names))
+
+    def _decode_for(self, img_hw):
+        key = (int(img_hw[0]), int(img_hw[1]))
+        if self._decode_key != key:
+            if self._decode is not None:
+                self._decode.close()
+            lr, lc = self.output_shape[0], self.output_shape[1]
+            self._decode = UfldDecode(lr[1], lr[2], lc[1], lc[2], key[1], key[0], self.cfg.row_anchor, self.cfg.col_anchor, 1, 1)
+            self._decode_key = key
+        return self._decode
+
+    def DetectFrame(self, image, adjust_lanes: bool = True) -> None:
+        """ultrafastLaneDetectorV2.py:183-194."""
+        h, w = self._stage.upload(image)
+        self.img_height, self.img_width, self.img_channels = h, w, 3
+        t = self._stage.tensor_for(self.input_shape)
+        L.check(L.lib().adas_preprocess_ufld(self._stage.frame.ptr, 1, h, w, t.ptr, self.input_height, self.input_width,
+                                             float(self.cfg.crop_ratio), None))
+        self.engine.infer_device(t.ptr, 1, None)
+        dec = self._decode_for((h, w))
+        ptrs = [self.engine.output_device_ptr(i) for i in range(4)]
+        strides = [int(np.prod(s[1:])) for s in self.output_shape]
+        dec.run_device(ptrs, strides, 1, None)
+        lanes, status = dec.fetch(0)
+        self.lane_info.lanes_points = np.array(lanes + [None], dtype=object)[:4]      # ragged-safe object array of 4 lists
+        self.lane_info.lanes_status = [bool(s) for s in status]
+        self.adjust_lanes = adjust_lanes
+        self.__update_lanes_status(self.lane_info.lanes_status)
+        self.__update_lanes_area(self.lane_info.lanes_points, self.img_height)
+
+    def __update_lanes_status(self, lanes_status) -> None:          # core.py:143-148
+        self.lane_info._area_status = False
+        if lanes_status != [] and len(lanes_status) % 2 == 0:
+            index = len(lanes_status) // 2
+            if lanes_status[index - 1] and lanes_status[index]:
+                self.lane_info._area_status = True
+
+    def __update_lanes_area(self, lanes_points, img_height) -> None:  # core.py:150-158
+        self.lane_info._area_points = np.array([], dtype=object)
+        if self.lane_info._area_status:
+            index = len(lanes_points) // 2
+            if self.adjust_lanes:
+                l, r = adjust_lanes_points(lanes_points[index - 1], lanes_points[index], img_height)
+            else:
+                l, r = lanes_points[index - 1], lanes_points[index]
+            self.lane_info._area_points = np.vstack((l, np.flipud(r)))
+
+    def close(self):
+        if getattr(self, "_decode", None) is not None:
+            self._decode.close()
+            self._decode = None
+        if getattr(self, "_stage", None) is not None:
+            self._stage.close()
+        if getattr(self, "engine", None) is not None:
+            self.engine.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+# =====================================================================================
+class TrackState:                  # dtypes/base_track.py:5-9
+    New = 0
+    Tracked = 1
+    Lost = 2
+    Removed = 3
+
+
+class BYTETracker:
+    """byteTracker.py:30-51,62-200.  `class_ids` may be ints or the label strings demo.py:273-275 passes; strings are
+    numbered in order of first appearance (identity is all STrack.update's class vote needs, strack.py:122-129).
+    Each instance owns its id counter (the reference's BaseTrack._count is process-global, base_track.py:12)."""
+
+    def __init__(self, track_thresh: float = 0.5, track_buffer: int = 30, match_thresh: float = 0.8, frame_rate: int = 30,
+                 min_box_area: int = 10, max_tracks: int = 256, max_dets: int = 512, **kwargs: Any):
+        self.track_thresh, self.match_thresh, self.min_box_area = track_thresh, match_thresh, min_box_area
+        self.det_thresh = track_thresh + 0.1
+        self.buffer_size = int(frame_rate / 30.0 * track_buffer)
+        self.max_time_lost = self.buffer_size
+        self.frame_id = 0
+        self._labels: List[Any] = []
+        self._dev = DeviceTracker(1, track_thresh, track_buffer, match_thresh, frame_rate, max_tracks, max_dets)
+        self._tracked: List[Dict[str, Any]] = []
+        self._lost: List[Dict[str, Any]] = []
+
+    def _cls_index(self, c):
+        if isinstance(c, (int, np.integer)):
+            return int(c)
+        if c not in self._labels:
+            self._labels.append(c)
+        return 1_000_000 + self._labels.index(c)
+
+    def _cls_value(self, i):
+        return self._labels[i - 1_000_000] if i >= 1_000_000 else i
+
+    def _messages(self, recs, count):
+        out = []
+        for r in recs:
+            out.append({"track_id": int(r["track_id"]), "count": int(count), "is_activated": bool(r["is_activated"]),
+                        "state": int(r["state"]), "score": float(r["score"]), "start_frame_number": int(r["start_frame"]),
+                        "curr_frame_number": int(r["frame_id"]),
+                        "time_since_update": int(self.frame_id - r["frame_id"]), "location": str((np.inf, np.inf)),
+                        "crops": None, "class_id": self._cls_value(int(r["class_id"])),
+                        "tlwh": [float(v) for v in r["tlwh"]]})
+        return out
+
+    def update(self, bboxes, scores, class_ids, frame=None):
+        self.frame_id += 1
+        b = np.asarray(bboxes, np.float64).reshape(-1, 4)
+        s = np.asarray(scores, np.float64).reshape(-1)
+        c = np.asarray([self._cls_index(x) for x in class_ids], np.int32)
+        self._dev.update_host(0, b, s, c)
+        hdr, tracked, lost = self._dev.fetch(0)
+        self._tracked = self._messages(tracked, hdr.id_count)
+        self._lost = self._messages(lost, hdr.id_count)
+        return self._tracked
+
+    @property
+    def tracked_stracks(self):
+        return self._tracked
+
+    @property
+    def lost_stracks(self):
+        return self._lost
+
+    def reset(self):
+        self.frame_id = 0
+        self._tracked, self._lost = [], []
+        self._dev.reset(0)
+
+    def close(self):
+        if getattr(self, "_dev", None) is not None:
+            self._dev.close()
+            self._dev = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
