@@ -128,7 +128,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=40)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--streams", type=int, default=16, help="independent video streams (frames per step) per GPU")
+    ap.add_argument("--streams", type=int, default=64, help="independent video streams (frames per step) per GPU")
     ap.add_argument("--det", default="yolov8n")
     ap.add_argument("--lane", default="ufldv2_res18")
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
@@ -140,18 +140,15 @@ def main():
                     "every HOLD frames: gives ByteTrack confirmed, lost and re-found tracks to maintain)")
     args = ap.parse_args()
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    load_pkg()
+    SH = importlib.import_module("adas_amd.sharding")
+    env = SH.RankEnv.from_environ()
+    rank, local_rank, world = env.rank, env.local_rank, env.world
     import torch
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback for the measured path)")
     torch.cuda.set_device(local_rank)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    load_pkg()
+    dist = SH.init_process_group(env, "nccl", torch.device("cuda", local_rank))   # RCCL; None when world == 1
     L = importlib.import_module("adas_amd._lib")
     M = importlib.import_module("adas_amd.models")
     CE = importlib.import_module("adas_amd.coreEngine")
@@ -193,10 +190,10 @@ def main():
     pipe.sync()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    local_elapsed = elapsed
+    elapsed = SH.max_over_ranks(elapsed, dist, "cuda")          # RCCL: clock + stats only, no data-path collective
+    per_rank = SH.gather_stats({"frames": float(args.steps * S), "seconds": local_elapsed}, ("frames", "seconds"), dist, "cuda")
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)     # RCCL: stats only, no data-path collective
-        elapsed = float(t.item())
         dist.barrier()
 
     # ---- detections actually flowing (so the reader can judge the post-proc / tracker load)
@@ -207,15 +204,31 @@ def main():
     n_trk = float(np.mean([h.n_tracked for h in hdrs]))
     n_lost = float(np.mean([h.n_lost for h in hdrs]))
 
-    # ---- roofline of the dominant kernel (conv_igemm_kernel): per-layer hipEvent pass on the same batch
+    # ---- roofline: per-layer hipEvent pass (events on the stream the kernels are launched on) over the same batch,
+    # grouped by the kernel instantiation each conv layer resolves to; the dominant kernel = most device time.
     conv_ms, conv_flops, all_ms = 0.0, 0.0, 0.0
+    by_kernel = {}
     for eng, dptr in ((pipe.det, d_det[0].ptr), (pipe.lane, d_lane[0].ptr)):
-        for name, fl, kind, ms in eng.profile(dptr, S, iters=3):
+        for li, (name, fl, kind, ms) in enumerate(eng.profile(dptr, S, iters=3)):
             all_ms += ms
             if kind == 1:   # OP_CONV
                 conv_ms += ms
                 conv_flops += fl * S
-    achieved = conv_flops / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
+                k = by_kernel.setdefault(eng.layer_kernel(li, S), [0.0, 0.0, 0])
+                k[0] += ms; k[1] += fl * S; k[2] += 1
+    achieved_all = conv_flops / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
+    dom_name, (dom_ms, dom_fl, dom_n) = max(by_kernel.items(), key=lambda kv: kv[1][0])
+    achieved = dom_fl / (dom_ms * 1e-3) / 1e12 if dom_ms > 0 else 0.0
+    top = sorted(by_kernel.items(), key=lambda kv: -kv[1][0])[:6]
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "traffic.json")       # HBM bytes per launch from rocprofv3 --pmc passes (tools/pmc_traffic.sh)
+    if os.path.exists(tpath):
+        try:
+            tj = json.load(open(tpath))
+            if tj.get("kernel") == dom_name and tj.get("streams") == S:
+                traffic = tj.get("hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
     # second eager pass with section events for a per-stage breakdown
     stage = None
     try:
@@ -249,13 +262,19 @@ def main():
                    "det_lane_overlap": not args.no_overlap, "parallelism": f"stream-sharded x{world}",
                    "inputs": "engine-seam NCHW fp32 tensors resident in HBM", "model_build_s": round(t_build, 1)},
         "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                     "frac": round(achieved / PEAK_BF16_TFLOPS, 5), "traffic": None,
-                     "kernel": "conv_igemm_kernel (all tile instantiations)",
-                     "method": "sum of algorithmic conv FLOPs of one step / sum of conv-launch durations (hipEvents per layer, "
-                               "eager pass on the same batch after the timed region)",
+                     "frac": round(achieved / PEAK_BF16_TFLOPS, 5), "traffic": traffic,
+                     "kernel": dom_name, "launches_per_step": dom_n, "avg_launch_us": round(dom_ms / dom_n * 1e3, 2),
+                     "gflop_per_launch": round(dom_fl / dom_n / 1e9, 3),
+                     "method": "algorithmic conv FLOPs (2*MACs, SURVEY 8d) of the layers that launch this kernel / their summed "
+                               "launch durations (hipEvents around every layer on the launch stream, eager pass on the same "
+                               "batch after the timed region)",
+                     "all_conv_kernels_tflops": round(achieved_all, 2), "all_conv_frac": round(achieved_all / PEAK_BF16_TFLOPS, 5),
                      "conv_ms_per_step": round(conv_ms, 4), "all_layers_ms_per_step": round(all_ms, 4),
-                     "end_to_end_tflops": round(flops_frame * fps / world / 1e12, 2)},
+                     "end_to_end_tflops": round(flops_frame * fps / world / 1e12, 2),
+                     "top_kernels": [{"kernel": k, "ms": round(v[0], 4), "tflops": round(v[1] / (v[0] * 1e-3) / 1e12, 1) if v[0] > 0 else 0.0,
+                                      "launches": v[2]} for k, v in top]},
         "stages": stage,
+        "per_rank": [{"frames": r["frames"], "seconds": round(r["seconds"], 5)} for r in per_rank],
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import yolo_post

@@ -74,6 +74,8 @@ int adas_engine_stats(const adas_engine* e, double* flops_per_frame, double* wei
 int adas_engine_profile(adas_engine* e, const float* d_input_nchw, int batch, int iters, float* ms_per_layer,
                         int max_layers, int* num_layers);
 int adas_engine_layer_info(const adas_engine* e, int layer, char* name, int name_cap, double* flops, int* kind);
+/* Which kernel instantiation layer `layer` launches at `batch` frames (matches the rocprofv3 kernel name). */
+int adas_engine_layer_kernel(const adas_engine* e, int layer, int batch, char* name, int name_cap);
 /* Debug/parity tap: copy an intermediate activation (by layer index) to the host as NCHW fp32. */
 int adas_engine_fetch_activation(adas_engine* e, int layer, int batch, float* h_out_nchw, int64_t dims[4]);
 

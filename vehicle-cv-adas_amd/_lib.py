@@ -80,6 +80,7 @@ _SIGS = {
     "adas_engine_stats": (C.c_int, [_P, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int)]),
     "adas_engine_profile": (C.c_int, [_P, _P, C.c_int, C.c_int, _P, C.c_int, C.POINTER(C.c_int)]),
     "adas_engine_layer_info": (C.c_int, [_P, C.c_int, C.c_char_p, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int)]),
+    "adas_engine_layer_kernel": (C.c_int, [_P, C.c_int, C.c_int, C.c_char_p, C.c_int]),
     "adas_engine_fetch_activation": (C.c_int, [_P, C.c_int, C.c_int, _P, C.POINTER(C.c_int64)]),
     "adas_preprocess_yolo": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, _P, C.c_int, C.c_int, C.c_int, _P]),
     "adas_preprocess_ufld": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, _P, C.c_int, C.c_int, C.c_double, _P]),

@@ -129,6 +129,11 @@ class HipEngine(EngineBase):
         L.check(L.lib().adas_engine_layer_info(self._h, i, name, 64, C.byref(fl), C.byref(kind)))
         return name.value.decode(), fl.value, kind.value
 
+    def layer_kernel(self, i, batch=1):
+        name = C.create_string_buffer(96)
+        L.check(L.lib().adas_engine_layer_kernel(self._h, i, int(batch), name, 96))
+        return name.value.decode()
+
     def layer_index(self, name):
         for i in range(self.stats()["num_layers"]):
             if self.layer_info(i)[0] == name:

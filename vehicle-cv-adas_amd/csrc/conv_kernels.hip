@@ -286,6 +286,24 @@ const char* conv_tile_name(const ConvArgs& a, int prec) {
     return buf;
 }
 
+// Name of the kernel instantiation a conv launch resolves to (as rocprofv3 --kernel-trace prints it, minus namespaces).
+const char* conv_kernel_name(const ConvArgs& a, int prec, int kernel) {
+    static thread_local char buf[96];
+    const char* actn = a.act == ACT_SILU ? "SILU" : (a.act == ACT_RELU ? "RELU" : "NONE");
+    if (kernel == CONV_HALO) {
+        snprintf(buf, sizeof(buf), "conv_halo_kernel<%d,%s>", a.out.c <= 16 ? 16 : (a.out.c <= 32 ? 32 : 64), actn);
+    } else if (kernel == CONV_FC) {
+        snprintf(buf, sizeof(buf), "fc_kernel");
+    } else if (kernel == CONV_STEM) {
+        snprintf(buf, sizeof(buf), "conv_stem_kernel<%d,%d,%s>", a.kh, (a.out.c + 15) / 16, actn);
+    } else {
+        Tile t = pick_tile(a, prec);
+        const bool of32 = a.out.f32 || prec == PREC_FP32;
+        snprintf(buf, sizeof(buf), "conv_igemm_kernel<%s,%s,%d,%d>", prec == PREC_FP32 ? "f32" : "bf16", of32 ? "f32" : "bf16", t.bm, t.bn);
+    }
+    return buf;
+}
+
 template <typename T, typename OutT>
 static hipError_t launch_typed(const ConvDev& d, Tile t, hipStream_t st) {
     dim3 grid((d.M + t.bm - 1) / t.bm, (d.cout + t.bn - 1) / t.bn);

@@ -285,6 +285,26 @@ int adas_engine_stats(const adas_engine* e, double* flops, double* wbytes, int* 
     if (nl) *nl = (int)e->ops.size();
     return ADAS_OK;
 }
+int adas_engine_layer_kernel(const adas_engine* e, int layer, int batch, char* name, int cap) {
+    ADAS_REQUIRE(e && name && cap > 0 && layer >= 0 && layer < (int)e->ops.size() && batch > 0, ADAS_ERR_INVALID, "bad layer index");
+    const EngOp& op = e->ops[layer];
+    const FileOp& o = op.f;
+    static const char* kOther[] = {"input_nchw_kernel", "", "maxpool_kernel", "upsample2_kernel", "detect_v8_kernel", "detect_v5_kernel",
+                                   "layernorm_kernel"};
+    if (op.skip) {
+        snprintf(name, cap, "(fused into the stem launch)");
+    } else if (o.type == OP_CONV) {
+        ConvArgs a;
+        a.in = make_view(e, o.in_buf[0], o.in_coff[0], o.in_c[0]);
+        a.out = make_view(e, o.out_buf, o.out_coff, o.out_c);
+        a.n = batch; a.kh = o.kh; a.kw = o.kw; a.stride = o.stride; a.pad = o.pad; a.act = o.act; a.res_mode = o.res_mode;
+        a.k = op.k; a.kpad = op.kpad; a.m = batch * a.out.h * a.out.w; a.max_n = e->max_batch;
+        snprintf(name, cap, "%s%s", conv_kernel_name(a, e->prec, op.kernel), op.fuse_pool >= 0 ? "+pool" : "");
+    } else {
+        snprintf(name, cap, "%s", o.type < 7 ? kOther[o.type] : "?");
+    }
+    return ADAS_OK;
+}
 int adas_engine_layer_info(const adas_engine* e, int layer, char* name, int cap, double* flops, int* kind) {
     ADAS_REQUIRE(e && layer >= 0 && layer < (int)e->ops.size(), ADAS_ERR_INVALID, "bad layer index");
     if (name && cap > 0) snprintf(name, cap, "%s", e->ops[layer].name.c_str());

@@ -40,6 +40,7 @@ ConvPlan plan_conv(int prec, int kh, int kw, int stride, int pad, int max_n, con
 // returns hipSuccess or the launch error.  prec: PREC_*.
 hipError_t launch_conv(const ConvArgs& a, int prec, hipStream_t st);
 const char* conv_tile_name(const ConvArgs& a, int prec);
+const char* conv_kernel_name(const ConvArgs& a, int prec, int kernel);
 
 hipError_t launch_input_nchw(const float* nchw, TView out, int n, int c_true, int prec, hipStream_t st);
 hipError_t launch_maxpool(TView in, TView out, int n, int k, int s, int p, int prec, hipStream_t st);

@@ -1,0 +1,79 @@
+"""Multi-GPU batched-video mode: independent video streams are the unit of parallelism.
+
+Each stream owns its frames, its tracker state and (per GPU) a replica of the weights, so stream s simply lives on
+rank s mod world: one process per GPU (torchrun), NO data-path collective.  RCCL (torch.distributed backend "nccl";
+"gloo" in the CPU tests) is used only to agree on the wall-clock of a timed region and to gather per-rank throughput
+statistics -- a few dozen bytes per rank, so xGMI bandwidth is irrelevant by construction.
+"""
+import os
+from dataclasses import dataclass
+from typing import Dict, List, Optional, Sequence
+
+
+@dataclass
+class RankEnv:
+    rank: int
+    local_rank: int
+    world: int
+
+    @classmethod
+    def from_environ(cls, env=None):
+        env = os.environ if env is None else env
+        return cls(int(env.get("RANK", "0")), int(env.get("LOCAL_RANK", "0")), int(env.get("WORLD_SIZE", "1")))
+
+
+def assign_streams(n_streams: int, world: int) -> List[List[int]]:
+    """Round-robin placement stream s -> rank s mod world (every rank gets floor or ceil of n/world streams)."""
+    if world <= 0 or n_streams < 0:
+        raise ValueError("world must be > 0 and n_streams >= 0")
+    return [list(range(r, n_streams, world)) for r in range(world)]
+
+
+def streams_of_rank(n_streams: int, env: RankEnv) -> List[int]:
+    return assign_streams(n_streams, env.world)[env.rank]
+
+
+def init_process_group(env: RankEnv, backend: Optional[str] = None, device=None):
+    """One process per GPU.  Returns torch.distributed (initialised) or None when world == 1."""
+    if env.world <= 1:
+        return None
+    import torch.distributed as dist
+    if not dist.is_initialized():
+        kw = {}
+        if backend is None:
+            import torch
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend == "nccl" and device is not None:
+            kw["device_id"] = device
+        dist.init_process_group(backend, rank=env.rank, world_size=env.world, **kw)
+    return dist
+
+
+def max_over_ranks(value: float, dist, device="cpu") -> float:
+    """The timed region ends when the slowest rank does."""
+    if dist is None:
+        return float(value)
+    import torch
+    t = torch.tensor([float(value)], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def gather_stats(local: Dict[str, float], keys: Sequence[str], dist, device="cpu") -> List[Dict[str, float]]:
+    """all_gather of one small fp64 vector per rank -> list (by rank) of dicts.  The only collective of the job."""
+    if dist is None:
+        return [dict((k, float(local[k])) for k in keys)]
+    import torch
+    mine = torch.tensor([float(local[k]) for k in keys], dtype=torch.float64, device=device)
+    out = [torch.zeros_like(mine) for _ in range(dist.get_world_size())]
+    dist.all_gather(out, mine)
+    return [dict(zip(keys, (float(v) for v in t.cpu()))) for t in out]
+
+
+def aggregate_throughput(per_rank: List[Dict[str, float]]) -> Dict[str, float]:
+    """Whole-job frames/s = all frames / slowest rank's seconds; per-rank rates kept for the scaling report."""
+    frames = sum(r["frames"] for r in per_rank)
+    seconds = max(r["seconds"] for r in per_rank)
+    return {"frames": frames, "seconds": seconds, "fps": frames / seconds if seconds > 0 else 0.0,
+            "min_rank_fps": min(r["frames"] / r["seconds"] for r in per_rank),
+            "max_rank_fps": max(r["frames"] / r["seconds"] for r in per_rank)}
