@@ -173,3 +173,14 @@ def run_stem_case(CE, H, W, k, pad, cout, act, pool, batch=3, seed=0):
 def test_fused_stem_kernel(CE, case):
     rel = run_stem_case(CE, *case)
     assert rel < 1e-2, (case, rel)
+
+
+@pytest.mark.parametrize("case", [(32, 32, 1), (48, 32, 1), (80, 80, 1), (96, 64, 1), (192, 64, 1), (384, 128, 1), (512, 256, 1),
+                                  (64, 128, 2), (128, 256, 2), (256, 16, 1)], ids=str)
+def test_pointwise_kernel(CE, case):
+    """1x1 convs (conv_pw.hip): LDS-resident fragment-ordered weights, activations straight into MFMA registers;
+    ragged pixel count (23*37*2 is not a multiple of 16), channel tails (48, 80), stride 2."""
+    cin, cout, s = case
+    for hw in ((23, 37), (40, 56)):
+        rel, mx = run_case(CE, hw[0], hw[1], cin, cout, 1, s, M.ACT_SILU, M.RES_NONE, "bf16")
+        assert rel < 1e-2, (case, hw, rel, mx)

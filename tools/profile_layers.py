@@ -24,12 +24,14 @@ ops = {o["name"]: o for o in g.ops}
 tot = sum(r[3] for r in rows); totf = sum(r[1] for r in rows) * a.batch
 print(f"{a.model} batch {a.batch} {a.precision}: {tot:.3f} ms/step, {totf/1e9:.1f} GFLOP/step, {totf/tot/1e9:.1f} TFLOP/s overall")
 out = []
+kern = {r[0]: e.layer_kernel(i, a.batch) for i, r in enumerate(rows)}
 for name, fl, kind, ms in rows:
     o = ops.get(name)
     desc = ""
     if o is not None and o["type"] == 1:
         v = o["ins"][0]; ov = o["out"]
         desc = f"{v.h}x{v.w}x{v.c}->{ov.c} k{o['kh']}s{o['stride']}"
+    desc = f"{desc:28s} {kern[name]}"
     out.append(dict(name=name, ms=ms, gflop=fl * a.batch / 1e9, tflops=(fl * a.batch / (ms * 1e-3) / 1e12 if ms > 0 else 0), desc=desc, kind=kind))
 for r in sorted(out, key=lambda r: -r["ms"])[:a.top]:
     print(f"{r['ms']:8.4f} ms {100*r['ms']/tot:5.1f}%  {r['gflop']:8.2f} GF {r['tflops']:7.1f} TF/s  {r['name']:28s} {r['desc']}")

@@ -294,6 +294,8 @@ const char* conv_kernel_name(const ConvArgs& a, int prec, int kernel) {
         snprintf(buf, sizeof(buf), "conv_halo_kernel<%d,%s>", a.out.c <= 16 ? 16 : (a.out.c <= 32 ? 32 : 64), actn);
     } else if (kernel == CONV_FC) {
         snprintf(buf, sizeof(buf), "fc_kernel");
+    } else if (kernel == CONV_PW) {
+        snprintf(buf, sizeof(buf), "conv_pw_kernel<%d>", (a.in.c + 31) / 32);
     } else if (kernel == CONV_STEM) {
         snprintf(buf, sizeof(buf), "conv_stem_kernel<%d,%d,%s>", a.kh, (a.out.c + 15) / 16, actn);
     } else {
@@ -337,6 +339,16 @@ static bool halo_enabled() {
 bool halo_applicable(int kh, int kw, int stride, int pad, const TView& in, const TView& out);  // conv_halo.hip
 bool fc_applicable(int prec, int kh, int kw, int stride, int max_n, const TView& in, const TView& out);  // conv_fc.hip
 hipError_t launch_fc(const ConvArgs& a, hipStream_t st);
+bool pw_applicable(int prec, int kh, int kw, int stride, int pad, int res_mode, const TView& in, const TView& out);  // conv_pw.hip
+hipError_t launch_conv_pw(const ConvArgs& a, hipStream_t st);
+static bool pw_enabled() {
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("ADAS_NO_PW");
+        v = (e && e[0] == '1') ? 0 : 1;
+    }
+    return v == 1;
+}
 static bool fc_enabled() {
     static int v = -1;
     if (v < 0) {
@@ -346,10 +358,13 @@ static bool fc_enabled() {
     return v == 1;
 }
 
-ConvPlan plan_conv(int prec, int kh, int kw, int stride, int pad, int max_n, const TView& in, const TView& out) {
+ConvPlan plan_conv(int prec, int kh, int kw, int stride, int pad, int max_n, int res_mode, const TView& in, const TView& out) {
     ConvPlan p;
     if (fc_enabled() && fc_applicable(prec, kh, kw, stride, max_n, in, out)) {
         p.kernel = CONV_FC;
+        p.cin_pad = in.c;
+    } else if (pw_enabled() && pw_applicable(prec, kh, kw, stride, pad, res_mode, in, out)) {
+        p.kernel = CONV_PW;
         p.cin_pad = in.c;
     } else if (prec == PREC_BF16 && halo_enabled() && halo_applicable(kh, kw, stride, pad, in, out)) {
         p.kernel = CONV_HALO;
@@ -363,9 +378,10 @@ ConvPlan plan_conv(int prec, int kh, int kw, int stride, int pad, int max_n, con
 }
 
 hipError_t launch_conv(const ConvArgs& a, int prec, hipStream_t st) {
-    ConvPlan pl = plan_conv(prec, a.kh, a.kw, a.stride, a.pad, a.max_n, a.in, a.out);
+    ConvPlan pl = plan_conv(prec, a.kh, a.kw, a.stride, a.pad, a.max_n, a.res_mode, a.in, a.out);
     if (pl.kpad != a.kpad) return hipErrorInvalidValue;  // weights were packed for a different plan
     if (pl.kernel == CONV_HALO) return launch_conv_halo(a, st);
+    if (pl.kernel == CONV_PW) return launch_conv_pw(a, st);
     if (pl.kernel == CONV_FC) return (a.res_mode == RES_NONE && a.n <= 64) ? launch_fc(a, st) : hipErrorInvalidValue;
     ConvDev d;
     d.in = a.in.p; d.wgt = a.wgt; d.bias = a.bias; d.out = a.out.p; d.res = a.res.p;

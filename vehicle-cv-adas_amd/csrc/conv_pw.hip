@@ -1,0 +1,161 @@
+// conv_pw.hip -- pointwise (1x1) convolution, stride 1 or 2: the C2f/SPPF/Detect 1x1 layers of the YOLO graphs and the
+// ResNet projection shortcuts.  These layers are HBM/L2-bound (arithmetic intensity = 2*Cin*Cout/(2*(Cin+Cout)) FLOP/B
+// <= 128 for every YOLOv8n instance, ridge ~312), so the kernel is organised around streaming, not tiles:
+//   * the whole weight matrix sits in LDS in MFMA-fragment order (one contiguous 1 KB ds_read_b128 per (feature tile,
+//     K step), conflict-free by construction), loaded once per persistent workgroup;
+//   * every wave owns 16 consecutive output pixels at a time and loads their activations straight from HBM into
+//     MFMA B-operand registers (lane = (pixel, 8-channel group): 16 B per lane, 64 contiguous bytes per pixel per
+//     K step) -- no LDS staging, no barrier in the pixel loop, latency hidden by 16-32 resident waves per CU;
+//   * loop over feature tiles: KS MFMAs each, fused bias + SiLU/ReLU, 8 B (bf16) / 16 B (fp32) store per lane.
+// Algorithmic bytes per launch: pixels * (Cin + Cout) * 2 B (+ Cout*Cin*2 B of weights, L2-resident).
+#include "kernels.h"
+
+namespace adas {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 pbf16x8;
+typedef __attribute__((ext_vector_type(4))) float pf32x4;
+typedef __attribute__((ext_vector_type(4))) uint32_t pu32x4;
+typedef __attribute__((ext_vector_type(2))) float pf32x2;
+typedef __attribute__((ext_vector_type(2))) __bf16 pbf16x2;
+
+__device__ __forceinline__ uint32_t pw_pack2(float a, float b) {
+    pbf16x2 r = __builtin_convertvector(pf32x2{a, b}, pbf16x2);
+    return __builtin_bit_cast(uint32_t, r);
+}
+
+struct PwDev {
+    const uint16_t* in;
+    const uint16_t* wfrag;  // [NT][KS][64][8] bf16 fragment order (same packing as CONV_FC)
+    const float* bias;
+    void* out;
+    int in_cs, in_coff, cin;
+    int out_cs, out_coff, cout, out_f32;
+    int M;                  // output pixels (all frames)
+    int stride, Wo, HoWo, W, HW;  // stride-2 address mapping
+    int act;
+    int NT;                 // feature tiles (cout_pad16 / 16)
+    int mtiles;
+};
+
+template <int KS, bool TAIL>
+__global__ __launch_bounds__(512) void conv_pw_kernel(PwDev a) {
+    extern __shared__ __attribute__((aligned(16))) uint16_t wl[];  // [NT][KS][64][8]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lrow = lane & 15, kg = lane >> 4;
+    {   // weights: contiguous copy, 16 B per thread per trip
+        const int n16 = a.NT * KS * 64;
+        for (int i = tid; i < n16; i += 512) *reinterpret_cast<pu32x4*>(wl + (size_t)i * 8) = *reinterpret_cast<const pu32x4*>(a.wfrag + (size_t)i * 8);
+    }
+    __syncthreads();
+    const int tail_valid = a.cin - (KS - 1) * 32;  // channels that exist in the last K step
+    const bool tail_zero = TAIL && kg * 8 >= tail_valid;
+
+    for (int mt = blockIdx.x * 8 + wave; mt < a.mtiles; mt += gridDim.x * 8) {
+        const int m = mt * 16 + lrow;
+        const bool ok = m < a.M;
+        size_t ipix;
+        if (a.stride == 1) {
+            ipix = (size_t)(ok ? m : 0);
+        } else {
+            const int mm = ok ? m : 0;
+            const int n = mm / a.HoWo, rem = mm - n * a.HoWo;
+            const int oy = rem / a.Wo, ox = rem - oy * a.Wo;
+            ipix = (size_t)n * a.HW + (size_t)(oy * a.stride) * a.W + ox * a.stride;
+        }
+        const uint16_t* ip = a.in + ipix * a.in_cs + a.in_coff + kg * 8;
+        pu32x4 xb[KS];
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) xb[ks] = __builtin_nontemporal_load(reinterpret_cast<const pu32x4*>(ip + ks * 32));
+        if (tail_zero) xb[KS - 1] = pu32x4{0u, 0u, 0u, 0u};
+
+        const size_t obase = (size_t)(ok ? m : 0) * a.out_cs + a.out_coff + kg * 4;
+        for (int nt = 0; nt < a.NT; ++nt) {
+            pf32x4 acc{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const pu32x4 wf = *reinterpret_cast<const pu32x4*>(wl + ((size_t)(nt * KS + ks) * 64 + lane) * 8);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(pbf16x8, wf), __builtin_bit_cast(pbf16x8, xb[ks]), acc, 0, 0, 0);
+            }
+            const int c = nt * 16 + kg * 4;
+            if (!ok || c >= a.cout) continue;
+            const float4 b4 = *reinterpret_cast<const float4*>(a.bias + c);
+            float v[4] = {acc[0] + b4.x, acc[1] + b4.y, acc[2] + b4.z, acc[3] + b4.w};
+            if (a.act == ACT_SILU) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = v[r] * __frcp_rn(1.0f + __expf(-v[r]));
+            } else if (a.act == ACT_RELU) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+            }
+            if (a.out_f32) {
+                *reinterpret_cast<float4*>((float*)a.out + obase + nt * 16) = make_float4(v[0], v[1], v[2], v[3]);
+            } else {
+                uint2 q;
+                q.x = pw_pack2(v[0], v[1]);
+                q.y = pw_pack2(v[2], v[3]);
+                *reinterpret_cast<uint2*>((uint16_t*)a.out + obase + nt * 16) = q;
+            }
+        }
+    }
+}
+
+static const int PW_MAX_LDS = 150 * 1024;
+
+bool pw_applicable(int prec, int kh, int kw, int stride, int pad, int res_mode, const TView& in, const TView& out) {
+    if (prec != PREC_BF16 || in.f32) return false;
+    if (kh != 1 || kw != 1 || pad != 0 || (stride != 1 && stride != 2) || res_mode != RES_NONE) return false;
+    if (in.h == 1 && in.w == 1) return false;  // Linear layers have their own kernel
+    if ((in.c & 7) || (in.cs & 7) || (in.coff & 7) || (out.c & 3) || (out.cs & 3) || (out.coff & 3)) return false;
+    const int ks = (in.c + 31) / 32, nt = (out.c + 15) / 16;
+    if (ks > 16) return false;
+    if (!(ks <= 4 || ks == 6 || ks == 8 || ks == 12 || ks == 16)) return false;
+    if ((size_t)nt * ks * 1024 > (size_t)PW_MAX_LDS) return false;
+    return true;
+}
+
+template <int KS>
+static hipError_t pw_launch(const PwDev& d, bool tail, int grid, size_t lds, hipStream_t st) {
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute((const void*)conv_pw_kernel<KS, false>, hipFuncAttributeMaxDynamicSharedMemorySize, PW_MAX_LDS);
+        (void)hipFuncSetAttribute((const void*)conv_pw_kernel<KS, true>, hipFuncAttributeMaxDynamicSharedMemorySize, PW_MAX_LDS);
+        attr_done = true;
+    }
+    if (tail) hipLaunchKernelGGL((conv_pw_kernel<KS, true>), dim3(grid), dim3(512), lds, st, d);
+    else hipLaunchKernelGGL((conv_pw_kernel<KS, false>), dim3(grid), dim3(512), lds, st, d);
+    return hipGetLastError();
+}
+
+hipError_t launch_conv_pw(const ConvArgs& a, hipStream_t st) {
+    PwDev d;
+    d.in = (const uint16_t*)a.in.p; d.wfrag = (const uint16_t*)a.wgt; d.bias = a.bias; d.out = a.out.p;
+    d.in_cs = a.in.cs; d.in_coff = a.in.coff; d.cin = a.in.c;
+    d.out_cs = a.out.cs; d.out_coff = a.out.coff; d.cout = a.out.c; d.out_f32 = a.out.f32;
+    d.M = a.m; d.stride = a.stride; d.Wo = a.out.w; d.HoWo = a.out.h * a.out.w; d.W = a.in.w; d.HW = a.in.h * a.in.w;
+    d.act = a.act;
+    const int ks = (a.in.c + 31) / 32;
+    d.NT = (a.out.c + 15) / 16;
+    d.mtiles = (a.m + 15) / 16;
+    const size_t lds = (size_t)d.NT * ks * 1024;
+    // persistent grid: as many 8-wave workgroups as fit the LDS budget of 256 CUs, never more than the work
+    int per_cu = (int)((160 * 1024) / (lds > 4096 ? lds : 4096));
+    if (per_cu > 4) per_cu = 4;
+    if (per_cu < 1) per_cu = 1;
+    int grid = 256 * per_cu;
+    const int need = (d.mtiles + 7) / 8;
+    if (grid > need) grid = need;
+    const bool tail = (a.in.c & 31) != 0;
+    switch (ks) {
+        case 1: return pw_launch<1>(d, tail, grid, lds, st);
+        case 2: return pw_launch<2>(d, tail, grid, lds, st);
+        case 3: return pw_launch<3>(d, tail, grid, lds, st);
+        case 4: return pw_launch<4>(d, tail, grid, lds, st);
+        case 6: return pw_launch<6>(d, tail, grid, lds, st);
+        case 8: return pw_launch<8>(d, tail, grid, lds, st);
+        case 12: return pw_launch<12>(d, tail, grid, lds, st);
+        case 16: return pw_launch<16>(d, tail, grid, lds, st);
+    }
+    return hipErrorInvalidValue;
+}
+
+}  // namespace adas

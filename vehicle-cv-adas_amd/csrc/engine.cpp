@@ -148,7 +148,7 @@ int adas_engine_create(const char* model_path, int precision, int max_batch, ada
         } else if (o.type == OP_CONV) {
             int cin = o.in_c[0], cout = o.out_c;
             op.k = o.kh * o.kw * cin;
-            ConvPlan pl = plan_conv(precision, o.kh, o.kw, o.stride, o.pad, max_batch, make_view(e, o.in_buf[0], o.in_coff[0], o.in_c[0]),
+            ConvPlan pl = plan_conv(precision, o.kh, o.kw, o.stride, o.pad, max_batch, o.res_mode, make_view(e, o.in_buf[0], o.in_coff[0], o.in_c[0]),
                                     make_view(e, o.out_buf, o.out_coff, o.out_c));
             if (pl.kernel == CONV_FC && o.res_mode != RES_NONE) {
                 fclose(f);
@@ -210,7 +210,7 @@ int adas_engine_create(const char* model_path, int precision, int max_batch, ada
                 if (hipMemcpy(base + op.b_off, b.data(), (size_t)op.cout_pad * 4, hipMemcpyHostToDevice) != hipSuccess) { rc = ADAS_ERR_HIP; break; }
                 continue;
             }
-            hipError_t pe = op.kernel == CONV_FC
+            hipError_t pe = (op.kernel == CONV_FC || op.kernel == CONV_PW)
                                 ? launch_pack_weights_fc(d_stage, base + op.w_off, o.out_c, op.cout_pad, o.in_c[0], op.kpad, 0)
                                 : launch_pack_weights(d_stage, base + op.w_off, o.out_c, op.cout_pad, o.kh * o.kw, o.in_c[0], op.cin_pad, op.kpad, precision, 0);
             if (pe != hipSuccess) { rc = ADAS_ERR_HIP; break; }

@@ -29,13 +29,13 @@ struct ConvArgs {
 
 // Which kernel runs a conv and how its weights are packed.  Decided once at load time from static
 // shapes and re-derived identically at launch time.
-enum { CONV_GATHER = 0, CONV_HALO = 1, CONV_FC = 2, CONV_STEM = 3 };
+enum { CONV_GATHER = 0, CONV_HALO = 1, CONV_FC = 2, CONV_STEM = 3, CONV_PW = 4 };
 struct ConvPlan {
     int kernel;   // CONV_*
     int cin_pad;  // channels per tap in the packed weights (halo: padded to 32 so the tail is zero)
     int kpad;     // packed K extent = round32(kh*kw*cin_pad)
 };
-ConvPlan plan_conv(int prec, int kh, int kw, int stride, int pad, int max_n, const TView& in, const TView& out);
+ConvPlan plan_conv(int prec, int kh, int kw, int stride, int pad, int max_n, int res_mode, const TView& in, const TView& out);
 
 // returns hipSuccess or the launch error.  prec: PREC_*.
 hipError_t launch_conv(const ConvArgs& a, int prec, hipStream_t st);
