@@ -184,3 +184,12 @@ def test_pointwise_kernel(CE, case):
     for hw in ((23, 37), (40, 56)):
         rel, mx = run_case(CE, hw[0], hw[1], cin, cout, 1, s, M.ACT_SILU, M.RES_NONE, "bf16")
         assert rel < 1e-2, (case, hw, rel, mx)
+
+
+@pytest.mark.parametrize("hw", [(80, 400), (160, 160), (40, 200), (46, 74), (15, 300), (20, 20)], ids=lambda s: f"{s[0]}x{s[1]}")
+def test_conv3x3_s2_halo_shapes(CE, hw):
+    """Stride-2 3x3 through the halo kernel (128-pixel tiles): even/odd extents, ragged strips, channel tails."""
+    H, W = hw
+    for cin, cout, act in ((64, 128, M.ACT_RELU), (32, 64, M.ACT_SILU), (128, 48, M.ACT_NONE), (80, 80, M.ACT_SILU)):
+        rel, mx = run_case(CE, H, W, cin, cout, 3, 2, act, M.RES_NONE, "bf16")
+        assert rel < 1e-2, (hw, cin, cout, rel, mx)

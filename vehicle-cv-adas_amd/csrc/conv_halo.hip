@@ -21,6 +21,12 @@
 // for every alignment of 16 consecutive window pixels.  (A 96 B padded pitch is also conflict-free but costs
 // 61 KB for the window; 40 KB + 36 KB of weights lets two workgroups share a CU, so one's staging, barriers
 // and epilogue hide under the other's MFMAs.)
+//
+// Stride 2 (template S = 2: the down-sampling 3x3 convs of both networks): same structure on 128-pixel tiles
+// (TM = 2); the window is ((rows-1)*2+3) x ((SW-1)*2+3) input pixels and a lane's 16 output pixels read every
+// second window pixel.  At a 64 B pitch that is inherently a 2-way conflict on the activation reads (only two
+// of the four 64-byte residues are touched; an 80 B pitch would be conflict-free but does not leave room for two
+// workgroups per CU) -- LDS is ~20 % utilised in this kernel, so the smaller footprint wins.
 #include "kernels.h"
 #include <map>
 #include <mutex>
@@ -56,24 +62,26 @@ struct HaloDev {
     int res_cs, res_coff, res_mode;
     int pad, kpad, cin_pad;
     int SW, NS, TPS, WW, maxpix;  // strip width, strips per row, tiles per strip, window width, LDS pixels
+    int Ho, Wo;                   // output extent (== H, W at stride 1)
     int out_f32;
     uint32_t mg_ww, mg_sw;        // n / WW == (n * mg_ww) >> 20 and n / SW == (n * mg_sw) >> 20 for every n the kernel divides
 };
 
-constexpr int HALO_BM = 256;
 constexpr int HALO_CK = 32;
+__host__ __device__ constexpr int halo_bm(int S) { return S == 1 ? 256 : 128; }
+__host__ __device__ constexpr int halo_maxpix(int S) { return S == 1 ? 640 : 704; }  // window pixels (2 workgroups per CU)
 constexpr int HALO_PIX = HALO_CK;       // elements per LDS window pixel (64 B, chunk-swizzled)
 constexpr int HALO_WPIX = HALO_CK;      // weight rows are unpadded (64 B) and XOR-swizzled instead: their
                                         // fragment reads always start at a 16-aligned row, so chunk kg of row r is
                                         // stored at position kg ^ g[(r>>2)&3], g = {0,2,3,1} -> all 4 lane groups
                                         // of ds_read_b128 hit 16 distinct 16-byte slots
-constexpr int HALO_MAXPIX = 640;        // window pixels: NA = 640*4/256 = 10 prefetch registers
-constexpr int HALO_NA = HALO_MAXPIX * 4 / 256;
 
-template <int BN, int ACT>
+template <int BN, int ACT, int S>
 __global__ __launch_bounds__(256, 2) void conv_halo_kernel(HaloDev a) {
     constexpr int TAPS = 9;
-    constexpr int TM = 4, TN = BN / 16;
+    constexpr int HALO_BM = halo_bm(S);
+    constexpr int HALO_NA = halo_maxpix(S) * 4 / 256;
+    constexpr int TM = HALO_BM / 64, TN = BN / 16;
     constexpr int NW = (TAPS * BN * 4 + 255) / 256;  // weight chunk loads per thread per channel chunk
     constexpr int WROWS = TAPS * BN;
     extern __shared__ __attribute__((aligned(16))) uint16_t lds[];
@@ -91,8 +99,8 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(HaloDev a) {
     const int sx0 = strip * a.SW, p0 = t * HALO_BM;
     const int y_first = (int)(((uint32_t)p0 * a.mg_sw) >> 20);
     const int y_lastp = (int)(((uint32_t)(p0 + HALO_BM - 1) * a.mg_sw) >> 20);
-    const int WH = y_lastp - y_first + 1 + 2 * a.pad;
-    const int wy0 = y_first - a.pad, wx0 = sx0 - a.pad;
+    const int WH = (y_lastp - y_first) * S + 3;
+    const int wy0 = y_first * S - a.pad, wx0 = sx0 * S - a.pad;
     const int npix4 = WH * a.WW * 4;
 
     // ---- per-thread staging addresses (identical for every channel chunk).  The window is read with
@@ -132,7 +140,7 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(HaloDev a) {
         int y = (int)(((uint32_t)p * a.mg_sw) >> 20), xs = p - y * a.SW;
         oy[j] = y;
         ox[j] = sx0 + xs;
-        apix[j] = (y - y_first) * a.WW + xs;
+        apix[j] = (y - y_first) * S * a.WW + xs * S;
     }
 
     hf32x4 acc[TN][TM];
@@ -199,8 +207,8 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(HaloDev a) {
     const bool full_n = n0 + BN <= a.cout;
 #pragma unroll
     for (int j = 0; j < TM; ++j) {
-        if (oy[j] >= a.H || ox[j] >= a.W) continue;
-        const size_t m = ((size_t)img * a.H + oy[j]) * a.W + ox[j];
+        if (oy[j] >= a.Ho || ox[j] >= a.Wo) continue;
+        const size_t m = ((size_t)img * a.Ho + oy[j]) * a.Wo + ox[j];
         const size_t ob = m * a.out_cs + a.out_coff + n0 + kg * 4;
         const size_t rb = m * a.res_cs + a.res_coff + n0 + kg * 4;
 #pragma unroll
@@ -251,22 +259,24 @@ static bool magic_ok(int d, int nmax, uint32_t* magic) {
     return true;
 }
 
-static bool plan_halo_uncached(int H, int W, int pad, HaloPlan* best) {
-    int cand[6] = {16, 32, 64, 128, 256, W};
+// Ho x Wo: OUTPUT extent; S: stride (1 or 2); pad = 1, 3x3.
+static bool plan_halo_uncached(int Ho, int Wo, int S, HaloPlan* best) {
+    const int BM = halo_bm(S), MAXPIX = halo_maxpix(S);
+    int cand[6] = {16, 32, 64, 128, 256, Wo};
     bool found = false;
     for (int k = 0; k < 6; ++k) {
         int SW = cand[k];
-        if (SW > W && k != 5) continue;
-        if (k == 5 && (W == 16 || W == 32 || W == 64 || W == 128 || W == 256)) continue;
-        int rows = (HALO_BM + SW - 1) / SW + ((HALO_BM % SW) ? 1 : 0);
-        int WW = SW + 2 * pad;
-        int maxpix = (rows + 2 * pad) * WW;
-        if (maxpix > HALO_MAXPIX) continue;
-        int NS = (W + SW - 1) / SW;
-        int TPS = (H * SW + HALO_BM - 1) / HALO_BM;
-        double eff = (double)H * W / ((double)NS * TPS * HALO_BM);
+        if (SW > Wo && k != 5) continue;
+        if (k == 5 && (Wo == 16 || Wo == 32 || Wo == 64 || Wo == 128 || Wo == 256)) continue;
+        int rows = (BM + SW - 1) / SW + ((BM % SW) ? 1 : 0);
+        int WW = (SW - 1) * S + 3;
+        int maxpix = ((rows - 1) * S + 3) * WW;
+        if (maxpix > MAXPIX) continue;
+        int NS = (Wo + SW - 1) / SW;
+        int TPS = (Ho * SW + BM - 1) / BM;
+        double eff = (double)Ho * Wo / ((double)NS * TPS * BM);
         uint32_t mw, ms;
-        if (!magic_ok(WW, HALO_MAXPIX + 64, &mw) || !magic_ok(SW, TPS * HALO_BM + HALO_BM, &ms)) continue;
+        if (!magic_ok(WW, MAXPIX + 64, &mw) || !magic_ok(SW, TPS * BM + BM, &ms)) continue;
         if (!found || eff > best->eff + 1e-9 || (eff > best->eff - 1e-9 && SW > best->SW)) {
             *best = HaloPlan{SW, NS, TPS, WW, maxpix, eff, mw, ms};
             found = true;
@@ -275,51 +285,61 @@ static bool plan_halo_uncached(int H, int W, int pad, HaloPlan* best) {
     return found;
 }
 
-// plans are pure functions of (H, W, pad): memoised so eager launches do not redo the exhaustive checks
-static bool plan_halo(int H, int W, int pad, HaloPlan* out) {
+// plans are pure functions of (Ho, Wo, S): memoised so eager launches do not redo the exhaustive checks
+static bool plan_halo(int Ho, int Wo, int S, HaloPlan* out) {
     static std::mutex mu;
     static std::map<std::tuple<int, int, int>, std::pair<bool, HaloPlan>> cache;
     std::lock_guard<std::mutex> lk(mu);
-    auto key = std::make_tuple(H, W, pad);
+    auto key = std::make_tuple(Ho, Wo, S);
     auto it = cache.find(key);
     if (it == cache.end()) {
         HaloPlan p{};
-        bool ok = plan_halo_uncached(H, W, pad, &p);
+        bool ok = plan_halo_uncached(Ho, Wo, S, &p);
         it = cache.emplace(key, std::make_pair(ok, p)).first;
     }
     *out = it->second.second;
     return it->second.first;
 }
 
-template <int BN>
+template <int BN, int S>
 static hipError_t launch_bn(const HaloDev& d, int act, dim3 grid, size_t lds, hipStream_t st) {
     static bool attr_done = false;
     if (!attr_done) {
-        (void)hipFuncSetAttribute((const void*)conv_halo_kernel<BN, ACT_NONE>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute((const void*)conv_halo_kernel<BN, ACT_SILU>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute((const void*)conv_halo_kernel<BN, ACT_RELU>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)conv_halo_kernel<BN, ACT_NONE, S>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)conv_halo_kernel<BN, ACT_SILU, S>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)conv_halo_kernel<BN, ACT_RELU, S>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_done = true;
     }
-    if (act == ACT_SILU) hipLaunchKernelGGL((conv_halo_kernel<BN, ACT_SILU>), grid, dim3(256), lds, st, d);
-    else if (act == ACT_RELU) hipLaunchKernelGGL((conv_halo_kernel<BN, ACT_RELU>), grid, dim3(256), lds, st, d);
-    else hipLaunchKernelGGL((conv_halo_kernel<BN, ACT_NONE>), grid, dim3(256), lds, st, d);
+    if (act == ACT_SILU) hipLaunchKernelGGL((conv_halo_kernel<BN, ACT_SILU, S>), grid, dim3(256), lds, st, d);
+    else if (act == ACT_RELU) hipLaunchKernelGGL((conv_halo_kernel<BN, ACT_RELU, S>), grid, dim3(256), lds, st, d);
+    else hipLaunchKernelGGL((conv_halo_kernel<BN, ACT_NONE, S>), grid, dim3(256), lds, st, d);
     return hipGetLastError();
 }
 
-// Returns hipErrorNotSupported when this kernel does not apply (caller falls back to the gather kernel).
+static bool halo_s2_enabled() {
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("ADAS_NO_HALO_S2");
+        v = (e && e[0] == '1') ? 0 : 1;
+    }
+    return v == 1;
+}
+
+// Returns false when this kernel does not apply (caller falls back to the gather kernel).
 bool halo_applicable(int kh, int kw, int stride, int pad, const TView& in, const TView& out) {
-    if (stride != 1 || kh != 3 || kw != 3 || pad != 1) return false;
-    if (in.f32 || out.h != in.h || out.w != in.w) return false;
+    if ((stride != 1 && stride != 2) || kh != 3 || kw != 3 || pad != 1) return false;
+    if (stride == 2 && !halo_s2_enabled()) return false;
+    if (in.f32 || out.h != (in.h + 2 - 3) / stride + 1 || out.w != (in.w + 2 - 3) / stride + 1) return false;
     if ((in.c & 7) || (in.cs & 7) || (in.coff & 7) || (out.c & 3) || (out.cs & 3) || (out.coff & 3)) return false;
     if (in.c < 32) return false;  // 16-channel layers would waste half of every MFMA
     if ((long)in.h * in.w * in.cs >= (1L << 30)) return false;  // 31-bit per-image byte offsets
     HaloPlan pl;
-    return plan_halo(in.h, in.w, pad, &pl) && pl.eff >= 0.6;
+    return plan_halo(out.h, out.w, stride, &pl) && pl.eff >= 0.6;
 }
 
 hipError_t launch_conv_halo(const ConvArgs& a, hipStream_t st) {
     HaloPlan pl;
-    if (!halo_applicable(a.kh, a.kw, a.stride, a.pad, a.in, a.out) || !plan_halo(a.in.h, a.in.w, a.pad, &pl)) return hipErrorNotSupported;
+    if (!halo_applicable(a.kh, a.kw, a.stride, a.pad, a.in, a.out) || !plan_halo(a.out.h, a.out.w, a.stride, &pl)) return hipErrorNotSupported;
     HaloDev d;
     d.in = (const uint16_t*)a.in.p; d.wgt = (const uint16_t*)a.wgt; d.bias = a.bias; d.out = a.out.p;
     d.res = (const uint16_t*)a.res.p;
@@ -328,15 +348,21 @@ hipError_t launch_conv_halo(const ConvArgs& a, hipStream_t st) {
     d.res_cs = a.res.cs; d.res_coff = a.res.coff; d.res_mode = a.res_mode;
     d.pad = a.pad; d.kpad = a.kpad; d.cin_pad = (a.in.c + 31) / 32 * 32;
     d.SW = pl.SW; d.NS = pl.NS; d.TPS = pl.TPS; d.WW = pl.WW; d.maxpix = pl.maxpix;
+    d.Ho = a.out.h; d.Wo = a.out.w;
     d.out_f32 = a.out.f32;
     d.mg_ww = pl.mg_ww;
     d.mg_sw = pl.mg_sw;
     const int bn = a.out.c <= 16 ? 16 : (a.out.c <= 32 ? 32 : 64);
     dim3 grid(a.n * pl.NS * pl.TPS, (a.out.c + bn - 1) / bn);
     size_t lds = ((size_t)pl.maxpix * HALO_PIX + (size_t)9 * bn * HALO_WPIX) * 2;
-    if (bn == 64) return launch_bn<64>(d, a.act, grid, lds, st);
-    if (bn == 32) return launch_bn<32>(d, a.act, grid, lds, st);
-    return launch_bn<16>(d, a.act, grid, lds, st);
+    if (a.stride == 2) {
+        if (bn == 64) return launch_bn<64, 2>(d, a.act, grid, lds, st);
+        if (bn == 32) return launch_bn<32, 2>(d, a.act, grid, lds, st);
+        return launch_bn<16, 2>(d, a.act, grid, lds, st);
+    }
+    if (bn == 64) return launch_bn<64, 1>(d, a.act, grid, lds, st);
+    if (bn == 32) return launch_bn<32, 1>(d, a.act, grid, lds, st);
+    return launch_bn<16, 1>(d, a.act, grid, lds, st);
 }
 
 }  // namespace adas

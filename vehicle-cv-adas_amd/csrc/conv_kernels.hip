@@ -291,7 +291,7 @@ const char* conv_kernel_name(const ConvArgs& a, int prec, int kernel) {
     static thread_local char buf[96];
     const char* actn = a.act == ACT_SILU ? "SILU" : (a.act == ACT_RELU ? "RELU" : "NONE");
     if (kernel == CONV_HALO) {
-        snprintf(buf, sizeof(buf), "conv_halo_kernel<%d,%s>", a.out.c <= 16 ? 16 : (a.out.c <= 32 ? 32 : 64), actn);
+        snprintf(buf, sizeof(buf), "conv_halo_kernel<%d,%s,s%d>", a.out.c <= 16 ? 16 : (a.out.c <= 32 ? 32 : 64), actn, a.stride);
     } else if (kernel == CONV_FC) {
         snprintf(buf, sizeof(buf), "fc_kernel");
     } else if (kernel == CONV_PW) {
