@@ -267,7 +267,8 @@ def main():
                      "gflop_per_launch": round(dom_fl / dom_n / 1e9, 3),
                      "method": "algorithmic conv FLOPs (2*MACs, SURVEY 8d) of the layers that launch this kernel / their summed "
                                "launch durations (hipEvents around every layer on the launch stream, eager pass on the same "
-                               "batch after the timed region)",
+                               "batch after the timed region; nets NOT overlapped in this pass -- the matching rocprofv3 summary is "
+                               "profiles/rNN/bench_no_overlap_kernel_stats.csv, the default command's is bench_default_kernel_stats.csv)",
                      "all_conv_kernels_tflops": round(achieved_all, 2), "all_conv_frac": round(achieved_all / PEAK_BF16_TFLOPS, 5),
                      "conv_ms_per_step": round(conv_ms, 4), "all_layers_ms_per_step": round(all_ms, 4),
                      "end_to_end_tflops": round(flops_frame * fps / world / 1e12, 2),

@@ -16,3 +16,15 @@ f=$(find $out/prof -name '*kernel_stats.csv' | head -1)
 [ -n "$f" ] && cp $f $out/kernel_stats.csv && head -25 $f
 # drop the bulky per-dispatch trace, keep the stats
 find $out/prof -name '*kernel_trace.csv' -size +8M -delete
+# the same bench with both nets on one stream: per-kernel durations comparable with bench.py's own hipEvent pass
+( timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof_noov -o bench -- python bench.py --no-cpu-baseline --no-overlap > $out/bench_noov.json 2> $out/bench_noov.err )
+f=$(find $out/prof_noov -name '*kernel_stats.csv' | head -1)
+[ -n "$f" ] && cp $f $out/kernel_stats_no_overlap.csv
+find $out/prof_noov -name '*kernel_trace.csv' -size +8M -delete
+# HBM traffic of the dominant kernel: two PMC passes (FETCH_SIZE costs 3 of 4 TCC slots)
+for C in FETCH_SIZE WRITE_SIZE; do
+  ( timeout 600 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $out/pmc_$C -o p -- python bench.py --no-cpu-baseline --no-overlap --steps 5 --warmup 2 > /dev/null 2> $out/pmc_$C.err )
+done
+python tools/traffic_summary.py $out "conv_halo_kernel<64, 2, 1>" "conv_halo_kernel<64,RELU,s1>" 64 > $out/traffic.json
+cat $out/traffic.json
+find $out -name '*kernel_trace.csv' -size +8M -delete

@@ -28,6 +28,7 @@
 // of the four 64-byte residues are touched; an 80 B pitch would be conflict-free but does not leave room for two
 // workgroups per CU) -- LDS is ~20 % utilised in this kernel, so the smaller footprint wins.
 #include "kernels.h"
+#include <stdlib.h>
 #include <map>
 #include <mutex>
 #include <tuple>
@@ -200,23 +201,36 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(HaloDev a) {
         }
     }
 
-    // ---- epilogue: lane holds channels c..c+3 of pixel (oy, ox); bias hoisted per channel group
+    // ---- epilogue: lane holds channels c..c+3 of pixel (oy, ox).  All residual loads are issued up front from clamped
+    // (always valid) addresses -- a load inside the bounds-check branches costs one exposed memory round trip per
+    // (pixel, channel group), 16 in a row.
     float4 bias4[TN];
 #pragma unroll
     for (int i = 0; i < TN; ++i) bias4[i] = *reinterpret_cast<const float4*>(a.bias + n0 + i * 16 + kg * 4);  // bias is padded to 128
     const bool full_n = n0 + BN <= a.cout;
+    bool pok[TM];
+    size_t mpix[TM];
 #pragma unroll
     for (int j = 0; j < TM; ++j) {
-        if (oy[j] >= a.Ho || ox[j] >= a.Wo) continue;
-        const size_t m = ((size_t)img * a.Ho + oy[j]) * a.Wo + ox[j];
-        const size_t ob = m * a.out_cs + a.out_coff + n0 + kg * 4;
-        const size_t rb = m * a.res_cs + a.res_coff + n0 + kg * 4;
+        pok[j] = oy[j] < a.Ho && ox[j] < a.Wo;
+        mpix[j] = pok[j] ? ((size_t)img * a.Ho + oy[j]) * a.Wo + ox[j] : 0;
+    }
+    uint2 rq[TM][TN];
+    if (a.res_mode != RES_NONE) {
+#pragma unroll
+        for (int j = 0; j < TM; ++j)
+#pragma unroll
+            for (int i = 0; i < TN; ++i)
+                rq[j][i] = *reinterpret_cast<const uint2*>(a.res + mpix[j] * a.res_cs + a.res_coff + n0 + kg * 4 + i * 16);
+    }
+#pragma unroll
+    for (int j = 0; j < TM; ++j) {
+        const size_t ob = mpix[j] * a.out_cs + a.out_coff + n0 + kg * 4;
 #pragma unroll
         for (int i = 0; i < TN; ++i) {
-            if (!full_n && n0 + i * 16 + kg * 4 >= a.cout) continue;
             float v[4] = {acc[i][j][0] + bias4[i].x, acc[i][j][1] + bias4[i].y, acc[i][j][2] + bias4[i].z, acc[i][j][3] + bias4[i].w};
             if (a.res_mode != RES_NONE) {
-                const uint2 q = *reinterpret_cast<const uint2*>(a.res + rb + i * 16);
+                const uint2 q = rq[j][i];
                 const float rv[4] = {__uint_as_float(q.x << 16), __uint_as_float(q.x & 0xffff0000u),
                                      __uint_as_float(q.y << 16), __uint_as_float(q.y & 0xffff0000u)};
                 if (a.res_mode == RES_BEFORE_ACT) {
@@ -230,13 +244,14 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(HaloDev a) {
 #pragma unroll
                 for (int k = 0; k < 4; ++k) v[k] = h_act<ACT>(v[k]);
             }
+            const bool st_ok = pok[j] && (full_n || n0 + i * 16 + kg * 4 < a.cout);
             if (a.out_f32) {
-                *reinterpret_cast<float4*>((float*)a.out + ob + i * 16) = make_float4(v[0], v[1], v[2], v[3]);
+                if (st_ok) *reinterpret_cast<float4*>((float*)a.out + ob + i * 16) = make_float4(v[0], v[1], v[2], v[3]);
             } else {
                 uint2 q;
                 q.x = h_pack2(v[0], v[1]);
                 q.y = h_pack2(v[2], v[3]);
-                *reinterpret_cast<uint2*>((uint16_t*)a.out + ob + i * 16) = q;
+                if (st_ok) *reinterpret_cast<uint2*>((uint16_t*)a.out + ob + i * 16) = q;
             }
         }
     }
@@ -316,6 +331,15 @@ static hipError_t launch_bn(const HaloDev& d, int act, dim3 grid, size_t lds, hi
     return hipGetLastError();
 }
 
+static int halo_min_cin() {
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("ADAS_HALO_MIN_CIN");
+        v = e ? atoi(e) : 16;
+    }
+    return v;
+}
+
 static bool halo_s2_enabled() {
     static int v = -1;
     if (v < 0) {
@@ -331,7 +355,7 @@ bool halo_applicable(int kh, int kw, int stride, int pad, const TView& in, const
     if (stride == 2 && !halo_s2_enabled()) return false;
     if (in.f32 || out.h != (in.h + 2 - 3) / stride + 1 || out.w != (in.w + 2 - 3) / stride + 1) return false;
     if ((in.c & 7) || (in.cs & 7) || (in.coff & 7) || (out.c & 3) || (out.cs & 3) || (out.coff & 3)) return false;
-    if (in.c < 32) return false;  // 16-channel layers would waste half of every MFMA
+    if (in.c < halo_min_cin()) return false;  // 16-channel layers waste half of every MFMA K step but are HBM-bound anyway
     if ((long)in.h * in.w * in.cs >= (1L << 30)) return false;  // 31-bit per-image byte offsets
     HaloPlan pl;
     return plan_halo(out.h, out.w, stride, &pl) && pl.eff >= 0.6;
