@@ -27,7 +27,8 @@ UNITS = [
     ("engine.cpp", []),
     ("pipeline.cpp", []),
 ]
-COMMON = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function",
+EXTRA = os.environ.get("ADAS_CFLAGS", "").split()   # scratch builds only (e.g. -DADAS_HALO_PROF)
+COMMON = EXTRA + ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function",
           "-Wno-unused-result", "-Wno-unused-value", "-x", "hip"]
 
 

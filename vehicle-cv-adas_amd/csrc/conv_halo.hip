@@ -29,6 +29,7 @@
 // workgroups per CU) -- LDS is ~20 % utilised in this kernel, so the smaller footprint wins.
 #include "kernels.h"
 #include <stdlib.h>
+#include <string.h>
 #include <map>
 #include <mutex>
 #include <tuple>
@@ -77,6 +78,30 @@ constexpr int HALO_WPIX = HALO_CK;      // weight rows are unpadded (64 B) and X
                                         // stored at position kg ^ g[(r>>2)&3], g = {0,2,3,1} -> all 4 lane groups
                                         // of ds_read_b128 hit 16 distinct 16-byte slots
 
+#ifdef ADAS_HALO_PROF  // scratch instrumentation (tools/scratch/halo_prof.py): per-phase shader cycles of wave 0, accumulated in
+// registers and flushed once per workgroup into one of 256 counter banks (so the atomics do not serialise the chip)
+__device__ unsigned long long g_halo_prof[256][16];
+#define HPROF(i)                                    \
+    if (tid == 0) {                                 \
+        const unsigned long long t__ = clock64();   \
+        pacc__[i] += t__ - tprev__;                 \
+        tprev__ = t__;                              \
+    }
+#define HPROF_INIT                               \
+    unsigned long long tprev__ = clock64();      \
+    unsigned long long pacc__[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#define HPROF_FLUSH                                                                      \
+    if (tid == 0) {                                                                      \
+        unsigned long long* b__ = g_halo_prof[(blockIdx.x + 7 * blockIdx.y) & 255];      \
+        for (int i__ = 0; i__ < 10; ++i__) atomicAdd(&b__[i__], pacc__[i__]);            \
+        atomicAdd(&b__[15], 1ull);                                                       \
+    }
+#else
+#define HPROF(i)
+#define HPROF_INIT
+#define HPROF_FLUSH
+#endif
+
 template <int BN, int ACT, int S>
 __global__ __launch_bounds__(256, 2) void conv_halo_kernel(HaloDev a) {
     constexpr int TAPS = 9;
@@ -90,6 +115,7 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(HaloDev a) {
     uint16_t* Ww = lds + (size_t)a.maxpix * HALO_PIX;  // [TAPS*BN][HALO_WPIX], swizzled
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    HPROF_INIT
     const int lrow = lane & 15, kg = lane >> 4;
     const int n0 = blockIdx.y * BN;
     int tile = blockIdx.x;
@@ -103,6 +129,7 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(HaloDev a) {
     const int WH = (y_lastp - y_first) * S + 3;
     const int wy0 = y_first * S - a.pad, wx0 = sx0 * S - a.pad;
     const int npix4 = WH * a.WW * 4;
+    const int na = (npix4 + 255) >> 8;  // window load slots this tile uses (workgroup-uniform)
 
     // ---- per-thread staging addresses (identical for every channel chunk).  The window is read with
     // buffer loads: an out-of-range byte offset makes the hardware return zeros, so halo pixels outside
@@ -155,7 +182,8 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(HaloDev a) {
     // outside the image come back as zeros from the buffer bounds check.
     auto gload = [&](int c0) {
 #pragma unroll
-        for (int i = 0; i < HALO_NA; ++i) ra[i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, goff[i] + (uint32_t)c0 * 2u, 0, 0);
+        for (int i = 0; i < HALO_NA; ++i)
+            if (i < na) ra[i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, goff[i] + (uint32_t)c0 * 2u, 0, 0);
 #pragma unroll
         for (int i = 0; i < NW; ++i) rw[i] = *reinterpret_cast<const hu32x4*>(wbase + (woff[i] < 0 ? 0 : woff[i]) + c0);
     };
@@ -163,7 +191,7 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(HaloDev a) {
 #pragma unroll
         for (int i = 0; i < HALO_NA; ++i) {
             int e = tid + 256 * i;
-            if (e < npix4) *reinterpret_cast<hu32x4*>(Aw + (e >> 2) * HALO_PIX + (((e & 3) ^ ((e >> 3) & 2)) << 3)) = ra[i];
+            if (i < na && e < npix4) *reinterpret_cast<hu32x4*>(Aw + (e >> 2) * HALO_PIX + (((e & 3) ^ ((e >> 3) & 2)) << 3)) = ra[i];
         }
 #pragma unroll
         for (int i = 0; i < NW; ++i)
@@ -171,11 +199,16 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(HaloDev a) {
     };
 
     const int nchunk = (a.cin + HALO_CK - 1) / HALO_CK;
+    HPROF(0)  // setup
     gload(0);
+    HPROF(1)  // first loads issued
     lstore();
+    HPROF(2)  // first loads landed + LDS stores
     __syncthreads();
+    HPROF(3)
     for (int cc = 0; cc < nchunk; ++cc) {
         if (cc + 1 < nchunk) gload((cc + 1) * HALO_CK);
+        HPROF(4)  // prefetch issue
 #pragma unroll
         for (int tap = 0; tap < TAPS; ++tap) {
             const int r = tap / 3, s = tap - r * 3;
@@ -194,10 +227,14 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(HaloDev a) {
                 for (int j = 0; j < TM; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], xf[j], acc[i][j], 0, 0, 0);
         }
+        HPROF(5)  // tap loop (LDS reads + MFMA issue)
         if (cc + 1 < nchunk) {
             __syncthreads();
+            HPROF(6)  // barrier: everyone done reading
             lstore();
+            HPROF(7)  // LDS stores (incl. waiting for the prefetched loads)
             __syncthreads();
+            HPROF(8)
         }
     }
 
@@ -223,39 +260,89 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(HaloDev a) {
             for (int i = 0; i < TN; ++i)
                 rq[j][i] = *reinterpret_cast<const uint2*>(a.res + mpix[j] * a.res_cs + a.res_coff + n0 + kg * 4 + i * 16);
     }
+    // value of (pixel j, channel group i) after bias / residual / activation
+    auto finish = [&](int i, int j, float v[4]) {
+        v[0] = acc[i][j][0] + bias4[i].x; v[1] = acc[i][j][1] + bias4[i].y; v[2] = acc[i][j][2] + bias4[i].z; v[3] = acc[i][j][3] + bias4[i].w;
+        if (a.res_mode != RES_NONE) {
+            const uint2 q = rq[j][i];
+            const float rv[4] = {__uint_as_float(q.x << 16), __uint_as_float(q.x & 0xffff0000u),
+                                 __uint_as_float(q.y << 16), __uint_as_float(q.y & 0xffff0000u)};
+            if (a.res_mode == RES_BEFORE_ACT) {
 #pragma unroll
-    for (int j = 0; j < TM; ++j) {
-        const size_t ob = mpix[j] * a.out_cs + a.out_coff + n0 + kg * 4;
-#pragma unroll
-        for (int i = 0; i < TN; ++i) {
-            float v[4] = {acc[i][j][0] + bias4[i].x, acc[i][j][1] + bias4[i].y, acc[i][j][2] + bias4[i].z, acc[i][j][3] + bias4[i].w};
-            if (a.res_mode != RES_NONE) {
-                const uint2 q = rq[j][i];
-                const float rv[4] = {__uint_as_float(q.x << 16), __uint_as_float(q.x & 0xffff0000u),
-                                     __uint_as_float(q.y << 16), __uint_as_float(q.y & 0xffff0000u)};
-                if (a.res_mode == RES_BEFORE_ACT) {
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) v[k] = h_act<ACT>(v[k] + rv[k]);
-                } else {
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) v[k] = h_act<ACT>(v[k]) + rv[k];
-                }
+                for (int k = 0; k < 4; ++k) v[k] = h_act<ACT>(v[k] + rv[k]);
             } else {
 #pragma unroll
-                for (int k = 0; k < 4; ++k) v[k] = h_act<ACT>(v[k]);
+                for (int k = 0; k < 4; ++k) v[k] = h_act<ACT>(v[k]) + rv[k];
             }
-            const bool st_ok = pok[j] && (full_n || n0 + i * 16 + kg * 4 < a.cout);
-            if (a.out_f32) {
-                if (st_ok) *reinterpret_cast<float4*>((float*)a.out + ob + i * 16) = make_float4(v[0], v[1], v[2], v[3]);
-            } else {
-                uint2 q;
-                q.x = h_pack2(v[0], v[1]);
-                q.y = h_pack2(v[2], v[3]);
-                if (st_ok) *reinterpret_cast<uint2*>((uint16_t*)a.out + ob + i * 16) = q;
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[k] = h_act<ACT>(v[k]);
+        }
+    };
+    const bool wide = TN >= 2 && !a.out_f32 && (((a.out_cs | a.out_coff) & 7) == 0);
+    if (wide) {
+        // 16-byte stores: v_permlane16_swap exchanges the odd 16-lane rows of X (channel tile i) with the even rows of Y
+        // (tile i+1), after which a lane owns 8 consecutive channels: tile i + (kg&1), channels (kg>>1)*8 .. +7.
+#pragma unroll
+        for (int j = 0; j < TM; ++j) {
+#pragma unroll
+            for (int i = 0; i + 1 < TN + 0; i += 2) {
+                float vx[4], vy[4];
+                finish(i, j, vx);
+                finish(i + 1, j, vy);
+                const uint32_t x0 = h_pack2(vx[0], vx[1]), x1 = h_pack2(vx[2], vx[3]);
+                const uint32_t y0 = h_pack2(vy[0], vy[1]), y1 = h_pack2(vy[2], vy[3]);
+                const auto s0 = __builtin_amdgcn_permlane16_swap(x0, y0, false, false);
+                const auto s1 = __builtin_amdgcn_permlane16_swap(x1, y1, false, false);
+                const int c = n0 + (i + (kg & 1)) * 16 + (kg >> 1) * 8;
+                uint16_t* op = (uint16_t*)a.out + mpix[j] * a.out_cs + a.out_coff + c;
+                if (pok[j]) {
+                    if (full_n || c + 8 <= a.cout) *reinterpret_cast<hu32x4*>(op) = hu32x4{s0[0], s1[0], s0[1], s1[1]};
+                    else if (c + 4 <= a.cout) *reinterpret_cast<uint2*>(op) = make_uint2(s0[0], s1[0]);
+                }
+            }
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < TM; ++j) {
+            const size_t ob = mpix[j] * a.out_cs + a.out_coff + n0 + kg * 4;
+#pragma unroll
+            for (int i = 0; i < TN; ++i) {
+                float v[4];
+                finish(i, j, v);
+                const bool st_ok = pok[j] && (full_n || n0 + i * 16 + kg * 4 < a.cout);
+                if (a.out_f32) {
+                    if (st_ok) *reinterpret_cast<float4*>((float*)a.out + ob + i * 16) = make_float4(v[0], v[1], v[2], v[3]);
+                } else {
+                    uint2 q;
+                    q.x = h_pack2(v[0], v[1]);
+                    q.y = h_pack2(v[2], v[3]);
+                    if (st_ok) *reinterpret_cast<uint2*>((uint16_t*)a.out + ob + i * 16) = q;
+                }
             }
         }
     }
+    HPROF(9)  // epilogue
+    HPROF_FLUSH
 }
+
+#ifdef ADAS_HALO_PROF
+extern "C" int adas_debug_halo_prof(unsigned long long* out16, int reset) {
+    static unsigned long long h[256][16];
+    if (out16) {
+        if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_halo_prof), sizeof(h)) != hipSuccess) return -1;
+        for (int i = 0; i < 16; ++i) {
+            out16[i] = 0;
+            for (int b = 0; b < 256; ++b) out16[i] += h[b][i];
+        }
+    }
+    if (reset) {
+        memset(h, 0, sizeof(h));
+        if (hipMemcpyToSymbol(HIP_SYMBOL(g_halo_prof), h, sizeof(h)) != hipSuccess) return -1;
+    }
+    return 0;
+}
+#endif
 
 // -------------------------------------------------------------------------------------
 struct HaloPlan {
