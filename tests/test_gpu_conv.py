@@ -193,3 +193,14 @@ def test_conv3x3_s2_halo_shapes(CE, hw):
     for cin, cout, act in ((64, 128, M.ACT_RELU), (32, 64, M.ACT_SILU), (128, 48, M.ACT_NONE), (80, 80, M.ACT_SILU)):
         rel, mx = run_case(CE, H, W, cin, cout, 3, 2, act, M.RES_NONE, "bf16")
         assert rel < 1e-2, (hw, cin, cout, rel, mx)
+
+
+@pytest.mark.parametrize("case", [(80, 400, 64, 64, M.ACT_RELU, M.RES_BEFORE_ACT), (80, 80, 64, 80, M.ACT_SILU, M.RES_NONE),
+                                  (160, 160, 32, 64, M.ACT_SILU, M.RES_NONE), (46, 74, 48, 64, M.ACT_SILU, M.RES_AFTER_ACT),
+                                  (80, 80, 16, 128, M.ACT_NONE, M.RES_NONE)], ids=str)
+def test_conv3x3_resident_weights_kernel(CE, case):
+    """Cin <= 64, Cout > 32 at a batch large enough (>= 1024 tiles) to take the persistent weights-resident kernel
+    (conv_halo_rw.hip): several tiles per workgroup, both LDS window buffers, ragged strips, residual modes."""
+    H, W, cin, cout, act, rm = case
+    rel, mx = run_case(CE, H, W, cin, cout, 3, 1, act, rm, "bf16", batch=max(2, (1024 * 256) // (H * W) + 1))
+    assert rel < 1e-2, (case, rel, mx)

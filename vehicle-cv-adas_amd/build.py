@@ -20,6 +20,7 @@ UNITS = [
     ("pre_kernels.hip", ["-ffp-contract=off"]),
     ("conv_kernels.hip", []),
     ("conv_halo.hip", []),
+    ("conv_halo_rw.hip", []),
     ("conv_fc.hip", []),
     ("conv_pw.hip", []),
     ("conv_stem.hip", []),

@@ -182,8 +182,8 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(HaloDev a) {
     // outside the image come back as zeros from the buffer bounds check.
     auto gload = [&](int c0) {
 #pragma unroll
-        for (int i = 0; i < HALO_NA; ++i)
-            if (i < na) ra[i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, goff[i] + (uint32_t)c0 * 2u, 0, 0);
+        for (int i = 0; i < HALO_NA; ++i)  // unconditional: a branch around a load makes hipcc wait vmcnt(0) at the join, serialising them
+            ra[i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, goff[i] + (uint32_t)c0 * 2u, 0, 0);
 #pragma unroll
         for (int i = 0; i < NW; ++i) rw[i] = *reinterpret_cast<const hu32x4*>(wbase + (woff[i] < 0 ? 0 : woff[i]) + c0);
     };

@@ -290,7 +290,9 @@ const char* conv_tile_name(const ConvArgs& a, int prec) {
 const char* conv_kernel_name(const ConvArgs& a, int prec, int kernel) {
     static thread_local char buf[96];
     const char* actn = a.act == ACT_SILU ? "SILU" : (a.act == ACT_RELU ? "RELU" : "NONE");
-    if (kernel == CONV_HALO) {
+    if (kernel == CONV_HALO && halo_rw_applicable(a.kh, a.kw, a.stride, a.pad, a.n, a.in, a.out)) {
+        snprintf(buf, sizeof(buf), "conv_halo_rw_kernel<%d,%s>", (a.in.c + 31) / 32, actn);
+    } else if (kernel == CONV_HALO) {
         snprintf(buf, sizeof(buf), "conv_halo_kernel<%d,%s,s%d>", a.out.c <= 16 ? 16 : (a.out.c <= 32 ? 32 : 64), actn, a.stride);
     } else if (kernel == CONV_FC) {
         snprintf(buf, sizeof(buf), "fc_kernel");
@@ -380,7 +382,8 @@ ConvPlan plan_conv(int prec, int kh, int kw, int stride, int pad, int max_n, int
 hipError_t launch_conv(const ConvArgs& a, int prec, hipStream_t st) {
     ConvPlan pl = plan_conv(prec, a.kh, a.kw, a.stride, a.pad, a.max_n, a.res_mode, a.in, a.out);
     if (pl.kpad != a.kpad) return hipErrorInvalidValue;  // weights were packed for a different plan
-    if (pl.kernel == CONV_HALO) return launch_conv_halo(a, st);
+    if (pl.kernel == CONV_HALO)
+        return halo_rw_applicable(a.kh, a.kw, a.stride, a.pad, a.n, a.in, a.out) ? launch_conv_halo_rw(a, st) : launch_conv_halo(a, st);
     if (pl.kernel == CONV_PW) return launch_conv_pw(a, st);
     if (pl.kernel == CONV_FC) return (a.res_mode == RES_NONE && a.n <= 64) ? launch_fc(a, st) : hipErrorInvalidValue;
     ConvDev d;
