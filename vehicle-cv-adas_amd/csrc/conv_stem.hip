@@ -8,8 +8,8 @@
 // feeds the MFMAs from it without im2col: with 4-channel pixels one 16x16x32 B fragment is 8 consecutive
 // window pixels of one tap row (2 pixels = 16 B per lane), stride 2 makes the per-lane LDS address
 // (wy*WW + 2*ox + 2*kg) * 8 B, always 16 B aligned and conflict free; a KH-row kernel is KH K-steps
-// (K = 32*KH, 7x7: 224 vs 147 useful).  Weights live in registers in fragment order for the whole
-// (persistent) workgroup.  With POOL the conv tile (9 x 33 pixels incl. the pool halo) goes to LDS as bf16 and
+// (K = 32*KH, 7x7: 224 vs 147 useful).  Weights sit in LDS in fragment order for the whole (persistent) workgroup;
+// the next tile's window is fetched into registers under the current tile's MFMAs.  With POOL the conv tile (9 x 33 pixels incl. the pool halo) goes to LDS as bf16 and
 // only the 4 x 16 pooled pixels are written to HBM.
 // Roofline: UFLDv2 stem + pool per frame: 6.1 MB in + 4.1 MB out (HBM) vs 3.67 GFLOP padded MFMA work ->
 // MFMA-bound; YOLO stems are HBM-bound (4.9 MB in, 3.3 MB out, 0.3 GFLOP).
@@ -64,60 +64,71 @@ __global__ __launch_bounds__(256, 2) void conv_stem_kernel(StemDev a) {
     constexpr int WW = STEM_WW, WH = 2 * (CTH - 1) + KH;
     constexpr int NQ = (WH * WW + 255) / 256;
     constexpr int CP = NT * 16 + 4;  // conv-tile pixel pitch in elements (pad: conflict-free 8 B writes, 8 B aligned)
-    __shared__ __attribute__((aligned(16))) uint16_t win[WH * WW * 4];
-    __shared__ __attribute__((aligned(16))) uint16_t ctile[POOL ? NPIX * CP : 4];
+    constexpr int WIN_E = WH * WW * 4, CT_E = POOL ? NPIX * CP : 0;
+    // weights: fragment order, one contiguous 1 KB block per (channel tile, tap row) -> conflict-free ds_read_b128.
+    // (Held in registers they cost 112 VGPRs at <7,4>, which put the kernel at the 256-VGPR limit with spills.)
+    __shared__ __attribute__((aligned(16))) uint16_t wl[NT * KH * 512];
+    // the window and the pooled-conv tile are never live at the same time: one region
+    __shared__ __attribute__((aligned(16))) uint16_t wc[WIN_E > CT_E ? WIN_E : CT_E];
+    uint16_t* win = wc;
+    uint16_t* ctile = wc;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lrow = lane & 15, kg = lane >> 4;
-
-    su32x4 wf[NT][KH];
-#pragma unroll
-    for (int i = 0; i < NT; ++i)
-#pragma unroll
-        for (int r = 0; r < KH; ++r) wf[i][r] = *reinterpret_cast<const su32x4*>(a.wfrag + ((size_t)(i * KH + r) * 64 + lane) * 8);
-    float4 bias4[NT];
-#pragma unroll
-    for (int i = 0; i < NT; ++i) bias4[i] = *reinterpret_cast<const float4*>(a.bias + i * 16 + kg * 4);
+    for (int i = tid; i < NT * KH * 64; i += 256) *reinterpret_cast<su32x4*>(wl + i * 8) = *reinterpret_cast<const su32x4*>(a.wfrag + (size_t)i * 8);
 
     // per-lane window offsets of this wave's M tiles (tile-invariant)
-    int boff[MT], pcy[MT], pcx[MT];
+    int boff[MT];
 #pragma unroll
     for (int j = 0; j < MT; ++j) {
         const int p = (wave * MT + j) * 16 + lrow;
         const int pc = p < NPIX ? p : NPIX - 1;
-        pcy[j] = pc / CTW;
-        pcx[j] = pc - pcy[j] * CTW;
-        boff[j] = ((2 * pcy[j]) * WW + 2 * pcx[j] + 2 * kg) * 4;
+        const int cy = pc / CTW, cx = pc - cy * CTW;
+        boff[j] = ((2 * cy) * WW + 2 * cx + 2 * kg) * 4;
     }
     const int per_img = a.tiles_x * a.tiles_y;
     const int plane = a.H * a.W;
 
-    for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
-        const int img = tile / per_img;
-        const int t2 = tile - img * per_img;
+    // window fetch of one tile into registers: fp32 planes, branch-free (buffer loads: offset 0x80000000 is out of range,
+    // the hardware returns 0 = zero padding; a tile index past the end turns every lane out of range)
+    float px[NQ][3];
+    auto fetch = [&](int tile) {
+        const bool live = tile < a.ntiles;
+        const int tl = live ? tile : 0;
+        const int img = tl / per_img;
+        const int t2 = tl - img * per_img;
         const int ty = t2 / a.tiles_x, tx = t2 - ty * a.tiles_x;
-        // conv-tile origin in conv-output coordinates, window origin in input coordinates
         const int cy0 = POOL ? 2 * (ty * 4) - 1 : ty * CTH;
         const int cx0 = POOL ? 2 * (tx * 16) - 1 : tx * CTW;
         const int iy0 = 2 * cy0 - a.pad, ix0 = 2 * cx0 - a.pad;
-
-        // ---- stage the window: fp32 planes -> (c0,c1,c2,0) bf16 pixels.  Buffer loads: offset 0x80000000 is out of
-        // range, the hardware returns 0 (zero padding without branches).
         const float* in_img = a.in + (size_t)img * a.C * plane;
         __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)in_img, 0, a.C * plane * 4, 0x00020000);
-        float px[NQ][3];
 #pragma unroll
         for (int i = 0; i < NQ; ++i) {
             const int q = tid + 256 * i;
             const int wy = q / WW, wx = q - wy * WW;
             const int iy = iy0 + wy, ix = ix0 + wx;
-            const bool ok = q < WH * WW && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
-            const uint32_t off = ok ? (uint32_t)((iy * a.W + ix) * 4) : 0x80000000u;
+            const bool ok = live && q < WH * WW && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+            const uint32_t off = (uint32_t)((iy * a.W + ix) * 4);
 #pragma unroll
-            for (int c = 0; c < 3; ++c)
-                px[i][c] = (c < a.C) ? __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, off + (uint32_t)(c * plane * 4), 0, 0)) : 0.f;
+            for (int c = 0; c < 3; ++c) {
+                const uint32_t oc = (ok && c < a.C) ? off + (uint32_t)(c * plane * 4) : 0x80000000u;
+                px[i][c] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, oc, 0, 0));
+            }
         }
-        __syncthreads();  // previous tile's readers of win / ctile are done
+    };
+
+    int tile = blockIdx.x;
+    if (tile >= a.ntiles) return;
+    fetch(tile);
+    for (;;) {
+        const int img = tile / per_img;
+        const int t2 = tile - img * per_img;
+        const int ty = t2 / a.tiles_x, tx = t2 - ty * a.tiles_x;
+        const int cy0 = POOL ? 2 * (ty * 4) - 1 : ty * CTH;
+        const int cx0 = POOL ? 2 * (tx * 16) - 1 : tx * CTW;
+
+        __syncthreads();  // previous tile's readers of the window / conv tile are done (first trip: the weights are in LDS)
 #pragma unroll
         for (int i = 0; i < NQ; ++i) {
             const int q = tid + 256 * i;
@@ -129,8 +140,11 @@ __global__ __launch_bounds__(256, 2) void conv_stem_kernel(StemDev a) {
             }
         }
         __syncthreads();
+        const int next = tile + gridDim.x;
+        fetch(next);  // in flight under this tile's MFMAs and pooling
 
-        // ---- MFMA: KH K-steps, weights from registers, activations straight from the window
+        // ---- MFMA: KH K-steps.  No guard on M tiles past the end (the last wave's surplus tile reads a clamped, valid window
+        // address and is dropped at store time): a branch per tile stops hipcc from overlapping LDS reads with MFMAs.
         sf32x4 acc[MT][NT];
 #pragma unroll
         for (int j = 0; j < MT; ++j)
@@ -138,18 +152,29 @@ __global__ __launch_bounds__(256, 2) void conv_stem_kernel(StemDev a) {
             for (int i = 0; i < NT; ++i) acc[j][i] = sf32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int r = 0; r < KH; ++r) {
+            sbf16x8 wf[NT], xf[MT];
 #pragma unroll
-            for (int j = 0; j < MT; ++j) {
-                if (wave * MT + j < NMT) {
-                    const sbf16x8 xf = *reinterpret_cast<const sbf16x8*>(win + boff[j] + r * WW * 4);
+            for (int i = 0; i < NT; ++i) wf[i] = *reinterpret_cast<const sbf16x8*>(wl + ((i * KH + r) * 64 + lane) * 8);
 #pragma unroll
-                    for (int i = 0; i < NT; ++i)
-                        acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(sbf16x8, wf[i][r]), xf, acc[j][i], 0, 0, 0);
-                }
-            }
+            for (int j = 0; j < MT; ++j) xf[j] = *reinterpret_cast<const sbf16x8*>(win + boff[j] + r * WW * 4);
+#pragma unroll
+            for (int j = 0; j < MT; ++j)
+#pragma unroll
+                for (int i = 0; i < NT; ++i) acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], xf[j], acc[j][i], 0, 0, 0);
         }
 
         // ---- epilogue: lane holds channels i*16 + kg*4 .. +3 of conv pixel (pcy, pcx)
+        float4 bias4[NT];
+#pragma unroll
+        for (int i = 0; i < NT; ++i) bias4[i] = *reinterpret_cast<const float4*>(a.bias + i * 16 + kg * 4);
+        int pcy[MT], pcx[MT];
+#pragma unroll
+        for (int j = 0; j < MT; ++j) {
+            const int p = (wave * MT + j) * 16 + lrow;
+            const int pc = p < NPIX ? p : NPIX - 1;
+            pcy[j] = pc / CTW;
+            pcx[j] = pc - pcy[j] * CTW;
+        }
         if (!POOL) {
 #pragma unroll
             for (int j = 0; j < MT; ++j) {
@@ -167,6 +192,7 @@ __global__ __launch_bounds__(256, 2) void conv_stem_kernel(StemDev a) {
                 }
             }
         } else {
+            __syncthreads();  // every wave is done reading the window: the conv tile may overwrite it
 #pragma unroll
             for (int j = 0; j < MT; ++j) {
                 const int p = (wave * MT + j) * 16 + lrow;
@@ -204,6 +230,8 @@ __global__ __launch_bounds__(256, 2) void conv_stem_kernel(StemDev a) {
                 *reinterpret_cast<su32x4*>(op) = su32x4{m0.x, m0.y, m1.x, m1.y};
             }
         }
+        if (next >= a.ntiles) break;
+        tile = next;
     }
 }
 
