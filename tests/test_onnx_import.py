@@ -1,0 +1,156 @@
+"""CPU: ONNX import (vehicle-cv-adas_amd/onnx_import.py) on files written by tests/onnx_writer.py in the conventions of the
+reference's two exporters: ultralytics (fused, PyTorch parameter names kept) and torch.onnx.export of the eval-mode UFLDv2
+model (BN folded by constant folding: anonymous `onnx::Conv_N` weights in execution order; BN kept: names kept)."""
+import importlib, os
+import numpy as np
+import pytest
+
+import onnx_writer as OW
+from conftest import load_pkg
+
+load_pkg()
+M = importlib.import_module("adas_amd.models")
+OI = importlib.import_module("adas_amd.onnx_import")
+CE = importlib.import_module("adas_amd.coreEngine")
+
+
+def synth(arch, **kw):
+    ws = M.SynthWeights(3, gain=1.0)
+    g = M.build(arch, wsrc=ws, **kw)
+    return dict(ws.store), g
+
+
+def conv_node(i, wname, bname, x, y):
+    return OW.node("Conv", [x, wname] + ([bname] if bname else []), [y], "Conv_%d" % i, [OW.attr_ints("kernel_shape", [3, 3])])
+
+
+def test_yolov8n_fused_names(tmp_path):
+    W, g = synth("yolov8n")
+    names = [k[:-7] for k in W if k.endswith(".weight")]
+    inits, nodes = [], []
+    for i, base in enumerate(names):                       # graph order = builder order; names carry the mapping
+        inits.append(OW.tensor(base + ".weight", W[base + ".weight"], raw=(i % 2 == 0)))
+        inits.append(OW.tensor(base + ".bias", W[base + ".bias"].astype(np.float32)))
+        nodes.append(conv_node(i, base + ".weight", base + ".bias", "t%d" % i, "t%d" % (i + 1)))
+    p = tmp_path / "yolov8n.onnx"
+    p.write_bytes(OW.model(nodes, inits, [("images", [1, 3, 640, 640])], [("output0", [1, 84, 8400])]))
+    m = OI.read_onnx(str(p))
+    assert OI.detect_arch(m) == ("yolov8n", dict(nc=80, imgsz=640))
+    out, g2 = OI.convert(str(p), str(tmp_path / "y.hipm"))
+    assert g2.tobytes() == M.build("yolov8n", wsrc=M.DictWeights(W)).tobytes()
+    assert abs(g2.flops / 1e9 - 8.74) < 0.01
+
+
+def test_yolov8s_unfused_bn_and_fp16(tmp_path):
+    """Conv + BatchNorm kept separate under their PyTorch names, half-precision initializers: BN folded with eps 1e-3."""
+    W, g = synth("yolov8s")
+    rng = np.random.default_rng(0)
+    inits, nodes, folded = [], [], {}
+    for i, base in enumerate(k[:-7] for k in list(W) if k.endswith(".weight")):
+        w, b = W[base + ".weight"], W[base + ".bias"]
+        if base.endswith(".conv"):
+            stem = base[:-5]
+            c = w.shape[0]
+            gmm, bt, mu, var = (rng.uniform(0.5, 1.5, c), rng.normal(0, .1, c), rng.normal(0, .1, c), rng.uniform(0.5, 1.5, c))
+            gmm, bt, mu, var = (a.astype(np.float16).astype(np.float32) for a in (gmm, bt, mu, var))
+            w16 = w.astype(np.float16)
+            inits.append(OW.tensor(base + ".weight", w16))
+            for suf, a in ((".weight", gmm), (".bias", bt), (".running_mean", mu), (".running_var", var)):
+                inits.append(OW.tensor(stem + ".bn" + suf, a.astype(np.float16)))
+            folded[base + ".weight"], folded[base + ".bias"] = OI.fold_bn(w16.astype(np.float32), None, gmm, bt, mu, var, 1e-3)
+            nodes.append(conv_node(i, base + ".weight", None, "t%d" % i, "t%d" % (i + 1)))
+        else:
+            inits.append(OW.tensor(base + ".weight", w)); inits.append(OW.tensor(base + ".bias", b))
+            folded[base + ".weight"], folded[base + ".bias"] = w, b
+            nodes.append(conv_node(i, base + ".weight", base + ".bias", "t%d" % i, "t%d" % (i + 1)))
+    p = tmp_path / "v8s.onnx"
+    p.write_bytes(OW.model(nodes, inits, [("images", [1, 3, 640, 640])], [("output0", [1, 84, 8400])]))
+    out, g2 = OI.convert(str(p), str(tmp_path / "s.hipm"))
+    assert g2.name == "yolov8s"
+    assert g2.tobytes() == M.build("yolov8s", wsrc=M.DictWeights(folded)).tobytes()
+
+
+UFLD_KW = dict(in_h=160, in_w=800, num_grid_row=100, num_cls_row=36, num_grid_col=50, num_cls_col=41)
+
+
+def torch_conv_order(depth="18"):
+    names, cin = ["model.conv1"], 64
+    for li, (planes, nblk) in enumerate(zip([64, 128, 256, 512], M.RESNET_DEPTHS[depth])):
+        for bi in range(nblk):
+            base = "model.layer%d.%d" % (li + 1, bi)
+            names += [base + ".conv1", base + ".conv2"]
+            if (li > 0 and bi == 0) or cin != planes:
+                names.append(base + ".downsample.0")
+            cin = planes
+    return names + ["pool"]
+
+
+def test_ufldv2_anonymous_convs_in_execution_order(tmp_path):
+    """torch.onnx.export of the eval-mode model: BN constant-folded into `onnx::Conv_N` tensors (names gone), Linear layers
+    as Gemm(transB=1) under their own names, LayerNorm affine under its own name."""
+    W, g = synth("ufldv2_res18", **UFLD_KW)
+    inits, nodes = [], []
+    for i, base in enumerate(torch_conv_order()):
+        wn, bn = ("onnx::Conv_%d" % (200 + 2 * i), "onnx::Conv_%d" % (201 + 2 * i)) if base != "pool" else ("pool.weight", "pool.bias")
+        inits += [OW.tensor(wn, W[base + ".weight"]), OW.tensor(bn, W[base + ".bias"])]
+        nodes.append(conv_node(i, wn, bn, "t%d" % i, "t%d" % (i + 1)))
+    for nm in ("cls.0.weight", "cls.0.bias", "cls.1.bias", "cls.3.bias"):
+        inits.append(OW.tensor(nm, W[nm]))
+    inits.append(OW.tensor("cls.1.weight", W["cls.1.weight"]))
+    nodes.append(OW.node("Gemm", ["f", "cls.1.weight", "cls.1.bias"], ["h"], "Gemm_0", [OW.attr_int("transB", 1)]))
+    inits.append(OW.tensor("onnx::MatMul_900", np.ascontiguousarray(W["cls.3.weight"].T)))       # (in, out), name lost
+    nodes.append(OW.node("MatMul", ["h", "onnx::MatMul_900"], ["o"], "MatMul_0"))
+    outs = [("loc_row", [1, 100, 36, 4]), ("loc_col", [1, 50, 41, 4]), ("exist_row", [1, 2, 36, 4]), ("exist_col", [1, 2, 41, 4])]
+    p = tmp_path / "culane_res18.onnx"
+    p.write_bytes(OW.model(nodes, inits, [("input", [1, 3, 160, 800])], outs))
+    m = OI.read_onnx(str(p))
+    arch, kw = OI.detect_arch(m)
+    assert arch == "ufldv2_res18" and kw["num_grid_row"] == 100 and kw["in_w"] == 800
+    out, g2 = OI.convert(str(p), str(tmp_path / "l.hipm"))
+    assert g2.tobytes() == M.build("ufldv2_res18", wsrc=M.DictWeights(W), **UFLD_KW).tobytes()
+
+
+def test_ufldv2_named_convs_with_batchnorm_nodes(tmp_path):
+    """Export without constant folding: Conv (no bias) + BatchNormalization nodes, PyTorch names kept: BN folded (eps 1e-5)."""
+    W, g = synth("ufldv2_res18", **UFLD_KW)
+    rng = np.random.default_rng(1)
+    inits, nodes, folded = [], [], dict(W)
+    for i, base in enumerate(torch_conv_order()):
+        w, b = W[base + ".weight"], W[base + ".bias"]
+        if base == "pool":
+            inits += [OW.tensor("pool.weight", w), OW.tensor("pool.bias", b)]
+            nodes.append(conv_node(i, "pool.weight", "pool.bias", "t%d" % i, "t%d" % (i + 1)))
+            continue
+        bn = base.replace(".downsample.0", ".downsample.1") if "downsample" in base else base[:-5] + "bn" + base[-1]
+        c = w.shape[0]
+        gmm, bt, mu, var = (rng.uniform(0.5, 1.5, c).astype(np.float32), rng.normal(0, .1, c).astype(np.float32),
+                            rng.normal(0, .1, c).astype(np.float32), rng.uniform(0.5, 1.5, c).astype(np.float32))
+        inits.append(OW.tensor(base + ".weight", w))
+        for suf, a in ((".weight", gmm), (".bias", bt), (".running_mean", mu), (".running_var", var)):
+            inits.append(OW.tensor(bn + suf, a))
+        nodes.append(conv_node(i, base + ".weight", None, "t%d" % i, "c%d" % i))
+        nodes.append(OW.node("BatchNormalization", ["c%d" % i] + [bn + s for s in (".weight", ".bias", ".running_mean", ".running_var")],
+                             ["t%d" % (i + 1)], "BN_%d" % i, [OW.attr_float("epsilon", 1e-5)]))
+        folded[base + ".weight"], folded[base + ".bias"] = OI.fold_bn(w, None, gmm, bt, mu, var, 1e-5)
+    for nm in ("cls.0.weight", "cls.0.bias", "cls.1.weight", "cls.1.bias", "cls.3.weight", "cls.3.bias"):
+        inits.append(OW.tensor(nm, W[nm]))
+    outs = [("loc_row", [1, 100, 36, 4]), ("loc_col", [1, 50, 41, 4]), ("exist_row", [1, 2, 36, 4]), ("exist_col", [1, 2, 41, 4])]
+    p = tmp_path / "named.onnx"
+    p.write_bytes(OW.model(nodes, inits, [("input", [1, 3, 160, 800])], outs))
+    out, g2 = OI.convert(str(p), str(tmp_path / "n.hipm"))
+    ref = M.build("ufldv2_res18", wsrc=M.DictWeights(folded), **UFLD_KW)
+    assert g2.tobytes() == ref.tobytes()
+
+
+def test_unsupported_and_garbage_fail_loudly(tmp_path):
+    bad = tmp_path / "x.onnx"
+    bad.write_bytes(b"\x08\x07not a container")
+    with pytest.raises(ValueError):
+        OI.read_onnx(str(bad))
+    w = np.zeros((24, 3, 5, 5), np.float32)
+    p = tmp_path / "other.onnx"
+    p.write_bytes(OW.model([conv_node(0, "w", None, "x", "y")], [OW.tensor("w", w)], [("x", [1, 3, 224, 224])], [("y", [1, 1000])]))
+    with pytest.raises(ValueError, match="not a supported architecture"):
+        OI.convert(str(p))
+    # HipEngine hands a non-ONNX '.onnx' file to the library untouched (it reports ADAS_ERR_FORMAT on a GPU box)
+    assert CE.HipEngine._resolve_container(str(bad)) == str(bad)

@@ -68,6 +68,7 @@ class HipEngine(EngineBase):
     def __init__(self, model_path, precision="bf16", max_batch=1):
         EngineBase.__init__(self, model_path)
         prec = {"bf16": L.PREC_BF16, "fp32": L.PREC_FP32}[precision]
+        model_path = self._resolve_container(model_path)
         h = C.c_void_p()
         L.check(L.lib().adas_engine_create(os.fsencode(model_path), prec, int(max_batch), C.byref(h)))
         self._h = h.value
@@ -76,6 +77,33 @@ class HipEngine(EngineBase):
         self.engine_dtype = np.float32        # the seam stays fp32; bf16 is internal
         self.framework_type = "hip"
         self.__load_engine_interface()
+
+    @staticmethod
+    def _resolve_container(model_path):
+        """An actual ONNX file (what the reference passes OnnxEngine, coreEngine.py:161-170) is converted once to the
+        `.hipm` container next to it (or in the temp dir) by onnx_import; an ADASHIP1 container is used as is."""
+        with open(model_path, "rb") as f:
+            magic = f.read(8)
+        if magic == b"ADASHIP1" or not model_path.endswith(".onnx"):
+            return model_path
+        try:
+            from . import onnx_import
+        except ImportError:
+            import onnx_import
+        st = os.stat(model_path)
+        tag = "%s.%d.%d.hipm" % (os.path.basename(model_path), st.st_size, int(st.st_mtime))
+        import tempfile
+        for d in (os.path.dirname(os.path.abspath(model_path)), tempfile.gettempdir()):
+            cached = os.path.join(d, "." + tag)
+            if os.path.isfile(cached):
+                return cached
+            if os.access(d, os.W_OK):
+                try:
+                    onnx_import.convert(model_path, cached)
+                except ValueError:
+                    return model_path      # not ONNX either: let the library report the format error (ADAS_ERR_FORMAT)
+                return cached
+        return model_path
 
     def __load_engine_interface(self):
         lib = L.lib()
