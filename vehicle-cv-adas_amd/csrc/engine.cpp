@@ -53,8 +53,8 @@ int adas_engine_create(const char* model_path, int precision, int max_batch, ada
     FileHeader hd;
     if (fread(&hd, sizeof(hd), 1, f) != 1 || memcmp(hd.magic, "ADASHIP1", 8) != 0 || hd.version != 1) {
         fclose(f);
-        set_error("[%s] is not an ADASHIP1 model container (ONNX/TensorRT import is not implemented; "
-                  "build one with vehicle-cv-adas_amd/models.py)", model_path);
+        set_error("[%s] is not an ADASHIP1 model container (convert an ONNX export with vehicle-cv-adas_amd/onnx_import.py or "
+                  "build one with models.py; TensorRT plans cannot be imported)", model_path);
         return ADAS_ERR_FORMAT;
     }
     ADAS_REQUIRE(adas_device_count() > 0, (fclose(f), ADAS_ERR_NO_DEVICE), "no HIP device visible; this library has no CPU fallback");
