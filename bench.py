@@ -147,8 +147,13 @@ def main():
     import torch
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback for the measured path)")
+    # ADAS_BENCH_BACKEND=gloo + ADAS_BENCH_SHARE_GPU=1 exist only to rehearse the N-rank control flow on a 1-GPU box
+    backend = os.environ.get("ADAS_BENCH_BACKEND", "nccl")
+    if os.environ.get("ADAS_BENCH_SHARE_GPU") == "1":
+        local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
-    dist = SH.init_process_group(env, "nccl", torch.device("cuda", local_rank))   # RCCL; None when world == 1
+    dist = SH.init_process_group(env, backend, torch.device("cuda", local_rank))   # "nccl" = RCCL; None when world == 1
+    stat_dev = "cuda" if backend == "nccl" else "cpu"
     L = importlib.import_module("adas_amd._lib")
     M = importlib.import_module("adas_amd.models")
     CE = importlib.import_module("adas_amd.coreEngine")
@@ -191,8 +196,8 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     local_elapsed = elapsed
-    elapsed = SH.max_over_ranks(elapsed, dist, "cuda")          # RCCL: clock + stats only, no data-path collective
-    per_rank = SH.gather_stats({"frames": float(args.steps * S), "seconds": local_elapsed}, ("frames", "seconds"), dist, "cuda")
+    elapsed = SH.max_over_ranks(elapsed, dist, stat_dev)        # RCCL: clock + stats only, no data-path collective
+    per_rank = SH.gather_stats({"frames": float(args.steps * S), "seconds": local_elapsed}, ("frames", "seconds"), dist, stat_dev)
     if dist is not None:
         dist.barrier()
 
