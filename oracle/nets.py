@@ -171,7 +171,7 @@ RESNET_DEPTHS = {"18": [2, 2, 2, 2], "34": [3, 4, 6, 3]}
 
 
 def ufldv2_forward(x, W, backbone="18", num_grid_row=200, num_cls_row=72, num_grid_col=100, num_cls_col=81,
-                   num_lanes=4, taps=None):
+                   num_lanes=4, taps=None, fc_norm=True):
     """Returns [loc_row, loc_col, exist_row, exist_col] (model_culane.py:56-59)."""
     x = torch.as_tensor(x, dtype=torch.float32)
     with torch.no_grad():
@@ -194,7 +194,8 @@ def ufldv2_forward(x, W, backbone="18", num_grid_row=200, num_cls_row=72, num_gr
         fea = fea.reshape(fea.shape[0], -1)                                   # (C,H,W) flatten, model_culane.py:53
         if taps is not None:
             taps["fea"] = fea
-        fea = F.layer_norm(fea, (fea.shape[1],), _t(W, "cls.0.weight"), _t(W, "cls.0.bias"), 1e-5)
+        if fc_norm:                                                           # LayerNorm | Identity (model_culane.py:34; tusimple: fc_norm=False)
+            fea = F.layer_norm(fea, (fea.shape[1],), _t(W, "cls.0.weight"), _t(W, "cls.0.bias"), 1e-5)
         h = F.relu(F.linear(fea, _t(W, "cls.1.weight"), _t(W, "cls.1.bias")))
         out = F.linear(h, _t(W, "cls.3.weight"), _t(W, "cls.3.bias"))
         d1 = num_grid_row * num_cls_row * num_lanes

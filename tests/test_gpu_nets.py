@@ -138,3 +138,24 @@ def test_hipengine_loads_a_real_onnx_file(CE, tmp_path):
     np.testing.assert_array_equal(e1.engine_inference(x)[0], e2.engine_inference(x)[0])
     assert any(f.endswith(".hipm") for f in __import__("os").listdir(tmp_path))      # cached conversion next to the .onnx
     e1.close(); e2.close()
+
+
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+def test_ufldv2_tusimple_variant_vs_oracle(CE, prec):
+    """Tusimple configuration (configs/tusimple_res18.py: 800x320, 100/100 cells, 56/41 anchors, fc_norm=False): the 1x1 `pool`
+    conv output is re-viewed as the flat FC input through a buffer alias instead of going through LayerNorm."""
+    path, W, g = netutil.model("ufldv2_tusimple_res18")
+    assert g.meta["fc_norm"] is False and g.in_h == 320 and g.in_w == 800
+    x = netutil.lane_frames(3, 320, 800)
+    want = nets.ufldv2_forward(x, W, "18", 100, 56, 100, 41, fc_norm=False)
+    e = CE.HipEngine(path, precision=prec, max_batch=3)
+    shapes, names = e.get_engine_output_shape()
+    assert shapes == [[1, 100, 56, 4], [1, 100, 41, 4], [1, 2, 56, 4], [1, 2, 41, 4]] and names == ["loc_row", "loc_col", "exist_row", "exist_col"]
+    got = e.engine_inference(x)
+    for o, w, nm in zip(got, want, names):
+        print(prec, nm, "max|diff| %.3e rel %.3e" % (np.abs(o - w).max(), rel_l2(o, w)))
+        if prec == "fp32":
+            assert np.abs(o - w).max() <= 1e-3
+        else:
+            assert rel_l2(o, w) <= 6e-2
+    e.close()

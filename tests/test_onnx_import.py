@@ -154,3 +154,22 @@ def test_unsupported_and_garbage_fail_loudly(tmp_path):
         OI.convert(str(p))
     # HipEngine hands a non-ONNX '.onnx' file to the library untouched (it reports ADAS_ERR_FORMAT on a GPU box)
     assert CE.HipEngine._resolve_container(str(bad)) == str(bad)
+
+
+def test_ufldv2_tusimple_detected_without_layernorm(tmp_path):
+    kw = dict(in_h=64, in_w=160, num_grid_row=20, num_cls_row=8, num_grid_col=20, num_cls_col=6, fc_norm=False)
+    W, g = synth("ufldv2_res18", **kw)
+    assert "cls.0.weight" not in W
+    inits, nodes = [], []
+    for i, base in enumerate(torch_conv_order()):
+        inits += [OW.tensor(base + ".weight", W[base + ".weight"]), OW.tensor(base + ".bias", W[base + ".bias"])]
+        nodes.append(conv_node(i, base + ".weight", base + ".bias", "t%d" % i, "t%d" % (i + 1)))
+    for nm in ("cls.1.weight", "cls.1.bias", "cls.3.weight", "cls.3.bias"):
+        inits.append(OW.tensor(nm, W[nm]))
+    outs = [("loc_row", [1, 20, 8, 4]), ("loc_col", [1, 20, 6, 4]), ("exist_row", [1, 2, 8, 4]), ("exist_col", [1, 2, 6, 4])]
+    p = tmp_path / "tusimple_res18.onnx"
+    p.write_bytes(OW.model(nodes, inits, [("input", [1, 3, 64, 160])], outs))
+    arch, got_kw = OI.detect_arch(OI.read_onnx(str(p)))
+    assert arch == "ufldv2_res18" and got_kw["fc_norm"] is False
+    out, g2 = OI.convert(str(p), str(tmp_path / "t.hipm"))
+    assert g2.tobytes() == M.build("ufldv2_res18", wsrc=M.DictWeights(W), **kw).tobytes()

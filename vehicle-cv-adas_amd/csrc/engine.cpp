@@ -31,7 +31,7 @@ static TView make_view(const adas_engine* e, int buf, int coff, int c) {
 static int free_engine(adas_engine* e) {
     if (!e) return ADAS_OK;
     for (auto& b : e->bufs)
-        if (b.d) (void)hipFree(b.d);
+        if (b.d && b.alias_of < 0) (void)hipFree(b.d);
     if (e->d_weights) (void)hipFree(e->d_weights);
     if (e->d_input) (void)hipFree(e->d_input);
     for (auto& ev : e->events)
@@ -78,9 +78,24 @@ int adas_engine_create(const char* model_path, int precision, int max_batch, ada
     for (auto& b : fb) {
         EngBuf eb;
         eb.h = b.h; eb.w = b.w; eb.c = b.c; eb.f32 = (b.flags & 1) != 0; eb.d = nullptr;
+        eb.alias_of = (b.flags & 2) ? (int)(b.flags >> 8) : -1;
         e->bufs.push_back(eb);
     }
+    for (size_t bi = 0; bi < e->bufs.size(); ++bi) {  // an alias re-declares the shape of an EARLIER buffer's memory (torch .view)
+        EngBuf& b = e->bufs[bi];
+        if (b.alias_of < 0) continue;
+        const bool ok = b.alias_of < (int)bi && e->bufs[b.alias_of].alias_of < 0 &&
+                        (size_t)b.h * b.w * b.c == (size_t)e->bufs[b.alias_of].h * e->bufs[b.alias_of].w * e->bufs[b.alias_of].c &&
+                        b.f32 == e->bufs[b.alias_of].f32;
+        if (!ok) {
+            fclose(f);
+            free_engine(e);
+            set_error("[%s]: buffer %zu is not a valid alias", model_path, bi);
+            return ADAS_ERR_FORMAT;
+        }
+    }
     for (auto& b : e->bufs) {
+        if (b.alias_of >= 0) continue;
         size_t bytes = (size_t)max_batch * b.h * b.w * b.c * elem_size(e, b);
         if (hipMalloc(&b.d, bytes + 256) != hipSuccess) {
             fclose(f);
@@ -90,6 +105,8 @@ int adas_engine_create(const char* model_path, int precision, int max_batch, ada
         (void)hipMemset(b.d, 0, bytes + 256);
         e->act_bytes += bytes;
     }
+    for (auto& b : e->bufs)
+        if (b.alias_of >= 0) b.d = e->bufs[b.alias_of].d;
     // ---- weights: stream the fp32 blob through a staging buffer, pack on the device
     size_t packed_total = 0;
     const size_t esz = precision == PREC_FP32 ? 4 : 2;

@@ -45,6 +45,7 @@ struct EngBuf {
     int h, w, c;
     bool f32;
     void* d;
+    int alias_of = -1;  // >= 0: shares the device memory of that buffer (FileBuf.flags bit 1, target in flags >> 8)
 };
 struct EngOp {
     FileOp f;

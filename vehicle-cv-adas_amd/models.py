@@ -26,6 +26,7 @@ OP_INPUT, OP_CONV, OP_MAXPOOL, OP_UPSAMPLE2, OP_DETECT_V8, OP_DETECT_V5, OP_LAYE
 ACT_NONE, ACT_SILU, ACT_RELU = 0, 1, 2
 RES_NONE, RES_AFTER_ACT, RES_BEFORE_ACT = 0, 1, 2
 BUF_F32 = 1
+BUF_ALIAS = 2      # flags bit 1: this buffer is another view of buffer (flags >> 8) - same bytes, different (h, w, c)
 
 HDR_FMT = "<8sIIIIIIIIQQd64s"
 BUF_FMT = "<IIII"
@@ -105,6 +106,13 @@ class Graph:
     # ---- buffers / views
     def buf(self, h, w, c, f32=False):
         self.bufs.append((h, w, c, BUF_F32 if f32 else 0))
+        return View(len(self.bufs) - 1, 0, c, h, w)
+
+    def alias(self, view, h, w, c):
+        """The same memory as `view`'s buffer, re-declared as an (h, w, c) tensor (torch .view(-1, N), model_culane.py:53)."""
+        hh, ww, cc, fl = self.bufs[view.buf]
+        assert view.coff == 0 and view.c == cc and hh * ww * cc == h * w * c
+        self.bufs.append((h, w, c, (fl & BUF_F32) | BUF_ALIAS | (view.buf << 8)))
         return View(len(self.bufs) - 1, 0, c, h, w)
 
     def _blob(self, arr):
@@ -403,7 +411,7 @@ def ufldv2(backbone="18", in_h=320, in_w=1600, num_grid_row=200, num_cls_row=72,
             t = g.conv(x, planes, 3, s, f"{name}.conv1", act=ACT_RELU)
             x = g.conv(t, planes, 3, 1, f"{name}.conv2", act=ACT_RELU, res=idt, res_mode=RES_BEFORE_ACT)
             cinp = planes
-    fea = g.conv(x, 8, 1, 1, "pool", act=ACT_NONE, f32_out=True, pad=0)           # model_culane.py:39,48
+    fea = g.conv(x, 8, 1, 1, "pool", act=ACT_NONE, f32_out=fc_norm, pad=0)        # model_culane.py:39,48
     input_dim = in_h // 32 * in_w // 32 * 8                                        # :23
     assert fea.h * fea.w * 8 == input_dim
     mid = 2048
@@ -414,7 +422,8 @@ def ufldv2(backbone="18", in_h=320, in_w=1600, num_grid_row=200, num_cls_row=72,
     hw = fea.h * fea.w
     perm = (np.arange(8)[None, :] * hw + np.arange(hw)[:, None]).reshape(-1)      # ours[j] = torch[perm[j]]
     x = fea                                                                        # LayerNorm reads it flat (h*w*c)
-    assert fc_norm, "the CULane config has fc_norm=True (configs/culane_res18.py:36)"
+    if not fc_norm:                                                                # Tusimple: cls.0 = Identity (configs/tusimple_res18.py:35)
+        x = g.alias(fea, 1, 1, input_dim)
     if fc_norm:                                                                    # cls.0 LayerNorm (:34)
         lw = wsrc("cls.0.weight", (input_dim,), "ln_w")
         lb = wsrc("cls.0.bias", (input_dim,), "ln_b")
@@ -438,16 +447,21 @@ def ufldv2(backbone="18", in_h=320, in_w=1600, num_grid_row=200, num_cls_row=72,
     for nm, d, shp in zip(("loc_row", "loc_col", "exist_row", "exist_col"), dims, shapes):   # :56-59
         g.output(out, off, shp, nm)
         off += d
-    g.meta = dict(kind="ufldv2", dims=dims, total=total)
+    g.meta = dict(kind="ufldv2", dims=dims, total=total, fc_norm=fc_norm)
     return g
 
+
+TUSIMPLE = dict(in_h=320, in_w=800, num_grid_row=100, num_cls_row=56, num_grid_col=100, num_cls_col=41, fc_norm=False)
 
 BUILDERS = {
     "yolov8n": lambda **k: yolov8("n", **k), "yolov8s": lambda **k: yolov8("s", **k),
     "yolov8m": lambda **k: yolov8("m", **k), "yolov8l": lambda **k: yolov8("l", **k),
     "yolov5n": lambda **k: yolov5("n", **k), "yolov5s": lambda **k: yolov5("s", **k),
     "ufldv2_res18": lambda **k: ufldv2("18", **k), "ufldv2_res34": lambda **k: ufldv2("34", **k),
+    # Tusimple configuration (configs/tusimple_res18.py:28-35): 800x320 input, 100/100 grid cells, 56/41 anchors, no LayerNorm
+    "ufldv2_tusimple_res18": lambda **k: ufldv2("18", **dict(TUSIMPLE, **k)), "ufldv2_tusimple_res34": lambda **k: ufldv2("34", **dict(TUSIMPLE, **k)),
 }
+
 
 
 def build(name, **kw):

@@ -270,7 +270,9 @@ def detect_arch(m):
         if depth is None:
             raise ValueError("ResNet depth not 18/34 (%d convs): %s" % (len(convs), found))
         (_, gr, cr, nl), (_, gc, cc, _) = outs[0], outs[1]
-        return "ufldv2_res" + depth, dict(in_h=H, in_w=W, num_grid_row=gr, num_cls_row=cr, num_grid_col=gc, num_cls_col=cc, num_lanes=nl)
+        fc_norm = "cls.0.weight" in m.initializers or any(nd["op"] == "LayerNormalization" for nd in m.nodes)   # Tusimple exports have cls.0 = Identity
+        return "ufldv2_res" + depth, dict(in_h=H, in_w=W, num_grid_row=gr, num_cls_row=cr, num_grid_col=gc, num_cls_col=cc, num_lanes=nl,
+                                          fc_norm=fc_norm)
     if len(outs) == 1 and len(outs[0]) == 3:
         o = outs[0]
         if c0[2] == 3 and o[2] > o[1]:                      # (1, 4+nc, A): YOLOv8/9/10-style head
