@@ -148,14 +148,13 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(HaloDev a) {
         bool ok = e < npix4 && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
         goff[i] = ok ? (uint32_t)(((iy * a.W + ix) * a.in_cs + c8 * 8) * 2) : 0x80000000u;
     }
-    const uint16_t* wbase = a.wgt + (size_t)n0 * a.kpad + (tid & 3) * 8;
+    // weights: slab (cout tile, chunk) = WROWS rows of 64 B, contiguous (kernels.h: CONV_HALO packing); thread e = tid + 256*i
+    // fetches 16 B number e of the slab -> every wave-level load is 1 KB of consecutive bytes
+    const int nchunk_w = a.cin_pad >> 5;
+    const uint16_t* wbase = a.wgt + (size_t)blockIdx.y * nchunk_w * WROWS * 32 + tid * 8;
     int woff[NW];
 #pragma unroll
-    for (int i = 0; i < NW; ++i) {
-        int row = (tid >> 2) + 64 * i;  // tap*BN + n
-        int tap = row / BN, n = row - tap * BN;
-        woff[i] = (row < WROWS) ? n * a.kpad + tap * a.cin_pad : -1;  // per-tap channel runs are zero-padded to 32
-    }
+    for (int i = 0; i < NW; ++i) woff[i] = ((tid >> 2) + 64 * i < WROWS) ? 256 * 8 * i : -1;
     const int gsw[4] = {0, 2, 3, 1};
     const int wst = (((tid & 3) ^ gsw[(tid >> 4) & 3])) * 8;             // swizzled store position (row>>2 == tid>>4 mod 4)
     const int wrd = lrow * HALO_WPIX + ((kg ^ gsw[(lrow >> 2) & 3])) * 8;  // swizzled per-lane fragment read offset
@@ -185,7 +184,7 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(HaloDev a) {
         for (int i = 0; i < HALO_NA; ++i)  // unconditional: a branch around a load makes hipcc wait vmcnt(0) at the join, serialising them
             ra[i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, goff[i] + (uint32_t)c0 * 2u, 0, 0);
 #pragma unroll
-        for (int i = 0; i < NW; ++i) rw[i] = *reinterpret_cast<const hu32x4*>(wbase + (woff[i] < 0 ? 0 : woff[i]) + c0);
+        for (int i = 0; i < NW; ++i) rw[i] = *reinterpret_cast<const hu32x4*>(wbase + (woff[i] < 0 ? 0 : woff[i]) + (size_t)(c0 >> 5) * WROWS * 32);
     };
     auto lstore = [&]() {
 #pragma unroll

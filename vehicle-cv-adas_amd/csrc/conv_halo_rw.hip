@@ -77,6 +77,7 @@ __global__ __launch_bounds__(RW_THR, RW_NW / 4) void conv_halo_rw_kernel(RwDev a
     const int n0 = nt * RW_BN;
     const int first = blockIdx.x / a.NT, step = gridDim.x / a.NT;
     const int per_img = a.NS * a.TPS;
+    const int NCH_PACK = a.cin_pad >> 5;  // chunks in the packed weights (== NCH)
     if (first >= a.n_spatial) return;
 
     // ---- weights: once.  row = tap*64 + n; chunk kg of row r lives at position kg ^ g[(r>>2)&3], g = {0,2,3,1}
@@ -88,8 +89,8 @@ __global__ __launch_bounds__(RW_THR, RW_NW / 4) void conv_halo_rw_kernel(RwDev a
             const int pl = e / (WROWS * 4), rem = e - pl * (WROWS * 4);
             const int row = rem >> 2, pc = rem & 3;
             if (pl < NCH) {
-                const int tap = row / RW_BN, n = row - tap * RW_BN;
-                const ru32x4 v = *reinterpret_cast<const ru32x4*>(a.wgt + (size_t)(n0 + n) * a.kpad + tap * a.cin_pad + pl * 32 + pc * 8);
+                // CONV_HALO packing (kernels.h): slab (cout tile nt, chunk pl) is WROWS contiguous 64-byte rows
+                const ru32x4 v = *reinterpret_cast<const ru32x4*>(a.wgt + ((size_t)(nt * NCH_PACK + pl) * WROWS + row) * 32 + pc * 8);
                 *reinterpret_cast<ru32x4*>(Ww + (pl * WROWS + row) * 32 + ((pc ^ gsw[(row >> 2) & 3]) << 3)) = v;
             }
         }

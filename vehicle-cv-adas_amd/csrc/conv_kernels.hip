@@ -416,6 +416,30 @@ __global__ void pack_weights_kernel(const float* __restrict__ src, T* __restrict
     }
 }
 
+// fp32 [cout][9][cin] -> bf16 [cout_pad/BN][cin_pad/32][9][BN][32], zero padded (halo kernels, BN = halo_bn(cout))
+__global__ void pack_weights_halo_kernel(const float* __restrict__ src, uint16_t* __restrict__ dst, int cout, int cin, int cin_pad, int bn,
+                                         size_t total) {
+    const int nchunk = cin_pad >> 5;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i & 31);
+        size_t r = i >> 5;
+        const int nl = (int)(r % bn); r /= bn;
+        const int tap = (int)(r % 9); r /= 9;
+        const int chunk = (int)(r % nchunk);
+        const size_t tile = r / nchunk;
+        const size_t n = tile * bn + nl;
+        const int ch = chunk * 32 + c;
+        const float v = (n < (size_t)cout && ch < cin) ? src[(n * 9 + tap) * cin + ch] : 0.0f;
+        stf(dst + i, v);
+    }
+}
+hipError_t launch_pack_weights_halo(const float* src, void* dst, int cout, int cout_pad, int cin, int cin_pad, hipStream_t st) {
+    const size_t total = (size_t)cout_pad * 9 * cin_pad;
+    const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+    hipLaunchKernelGGL(pack_weights_halo_kernel, dim3(blocks), dim3(256), 0, st, src, (uint16_t*)dst, cout, cin, cin_pad, halo_bn(cout), total);
+    return hipGetLastError();
+}
+
 hipError_t launch_pack_weights(const float* src, void* dst, int cout, int cout_pad, int taps, int cin, int cin_pad, int kpad, int prec,
                                hipStream_t st) {
     size_t total = (size_t)cout_pad * kpad;

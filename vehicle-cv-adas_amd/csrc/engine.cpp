@@ -229,6 +229,8 @@ int adas_engine_create(const char* model_path, int precision, int max_batch, ada
             }
             hipError_t pe = (op.kernel == CONV_FC || op.kernel == CONV_PW)
                                 ? launch_pack_weights_fc(d_stage, base + op.w_off, o.out_c, op.cout_pad, o.in_c[0], op.kpad, 0)
+                                : op.kernel == CONV_HALO
+                                ? launch_pack_weights_halo(d_stage, base + op.w_off, o.out_c, op.cout_pad, o.in_c[0], op.cin_pad, 0)
                                 : launch_pack_weights(d_stage, base + op.w_off, o.out_c, op.cout_pad, o.kh * o.kw, o.in_c[0], op.cin_pad, op.kpad, precision, 0);
             if (pe != hipSuccess) { rc = ADAS_ERR_HIP; break; }
             if (hipDeviceSynchronize() != hipSuccess) { rc = ADAS_ERR_HIP; break; }

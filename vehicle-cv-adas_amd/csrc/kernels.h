@@ -67,6 +67,10 @@ size_t stem_weight_bytes(int kh, int cout);
 void stem_pack_weights(const float* w_ohwi, int cout, int kh, int kw, int cs, int c_true, uint16_t* dst_host);
 hipError_t launch_conv_stem(const float* nchw, int n, int c_true, int H, int W, int kh, int pad, int act, const void* wfrag,
                             const float* bias, const TView& conv_out, bool pool, const TView& pool_out, hipStream_t st);
+// CONV_HALO packing: slab order [cout tile of halo_bn(cout)][32-channel chunk][tap][n within tile][32] -- the 9*BN*64 B a
+// workgroup stages per chunk are one contiguous run (every wave-level staging load reads 1 KB of consecutive bytes).
+inline int halo_bn(int cout) { return cout <= 16 ? 16 : (cout <= 32 ? 32 : 64); }
+hipError_t launch_pack_weights_halo(const float* src, void* dst, int cout, int cout_pad, int cin, int cin_pad, hipStream_t st);
 // Linear-layer packing (CONV_FC): src [cout][cin] fp32 -> bf16 MFMA-fragment order [cout_pad/16][kpad/32][64][8]
 hipError_t launch_pack_weights_fc(const float* src, void* dst, int cout, int cout_pad, int cin, int kpad, hipStream_t st);
 // NHWC (compute type or fp32) activation view -> NCHW fp32 (debug / parity tap)
