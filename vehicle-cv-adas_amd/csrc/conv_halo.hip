@@ -253,11 +253,26 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(HaloDev a) {
     }
     uint2 rq[TM][TN];
     if (a.res_mode != RES_NONE) {
+        // 16-byte residual loads in the layout of the wide stores below (channel tile i + (kg&1), channels (kg>>1)*8..+7);
+        // v_permlane16_swap is its own inverse, so the same exchange hands every lane its two 4-channel groups back
+        const bool wide_res = TN >= 2 && (((a.res_cs | a.res_coff) & 7) == 0);
 #pragma unroll
-        for (int j = 0; j < TM; ++j)
+        for (int j = 0; j < TM; ++j) {
+            if (wide_res) {
 #pragma unroll
-            for (int i = 0; i < TN; ++i)
-                rq[j][i] = *reinterpret_cast<const uint2*>(a.res + mpix[j] * a.res_cs + a.res_coff + n0 + kg * 4 + i * 16);
+                for (int i = 0; i + 1 < TN; i += 2) {
+                    const hu32x4 w = *reinterpret_cast<const hu32x4*>(a.res + mpix[j] * a.res_cs + a.res_coff + n0 + (i + (kg & 1)) * 16 + (kg >> 1) * 8);
+                    const auto s0 = __builtin_amdgcn_permlane16_swap(w[0], w[2], false, false);
+                    const auto s1 = __builtin_amdgcn_permlane16_swap(w[1], w[3], false, false);
+                    rq[j][i] = make_uint2(s0[0], s1[0]);
+                    rq[j][i + 1] = make_uint2(s0[1], s1[1]);
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < TN; ++i)
+                    rq[j][i] = *reinterpret_cast<const uint2*>(a.res + mpix[j] * a.res_cs + a.res_coff + n0 + kg * 4 + i * 16);
+            }
+        }
     }
     // value of (pixel j, channel group i) after bias / residual / activation
     auto finish = [&](int i, int j, float v[4]) {

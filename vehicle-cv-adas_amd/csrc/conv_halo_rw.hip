@@ -60,7 +60,8 @@ constexpr int RW_NW = 8;            // waves per workgroup: two per SIMD (one wo
 constexpr int RW_THR = 64 * RW_NW;
 constexpr int RW_NA = RW_ELEMS / RW_THR + 1;
 
-template <int NCH, int ACT>  // NCH = 32-channel planes (1 | 2)
+template <int NCH, int ACT, bool HAS_RES>  // NCH = 32-channel planes (1 | 2); HAS_RES is a template flag because a runtime branch
+                                          // around the residual loads makes hipcc drain vmcnt(0) at the join -- and with it the window prefetch
 __global__ __launch_bounds__(RW_THR, RW_NW / 4) void conv_halo_rw_kernel(RwDev a) {
     constexpr int TAPS = 9, TM = RW_BM / 16 / RW_NW, TN = 4;
     constexpr int WROWS = TAPS * RW_BN;               // 576 weight rows of 64 B per plane
@@ -176,13 +177,15 @@ __global__ __launch_bounds__(RW_THR, RW_NW / 4) void conv_halo_rw_kernel(RwDev a
             pok[j] = oy[j] < a.H && ox[j] < a.W;
             mpix[j] = pok[j] ? ((size_t)cur.img * a.H + oy[j]) * a.W + ox[j] : 0;
         }
-        uint2 rq[TM][TN];
-        if (a.res_mode != RES_NONE) {
+        // residual: 16-byte loads in the wide-store layout (channel tile i + (kg&1), channels (kg>>1)*8..+7), issued here so they
+        // fly under the MFMAs; the (self-inverse) permlane16 swap that hands each lane its own channel groups waits for the epilogue
+        ru32x4 rwide[TM][TN / 2];
+        if (HAS_RES) {
 #pragma unroll
             for (int j = 0; j < TM; ++j)
 #pragma unroll
-                for (int i = 0; i < TN; ++i)
-                    rq[j][i] = *reinterpret_cast<const uint2*>(a.res + mpix[j] * a.res_cs + a.res_coff + n0 + kg * 4 + i * 16);
+                for (int i = 0; i < TN; i += 2)
+                    rwide[j][i / 2] = *reinterpret_cast<const ru32x4*>(a.res + mpix[j] * a.res_cs + a.res_coff + n0 + (i + (kg & 1)) * 16 + (kg >> 1) * 8);
         }
         rf32x4 acc[TN][TM];
 #pragma unroll
@@ -209,10 +212,23 @@ __global__ __launch_bounds__(RW_THR, RW_NW / 4) void conv_halo_rw_kernel(RwDev a
                         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], xf[j], acc[i][j], 0, 0, 0);
             }
         }
+        uint2 rq[TM][TN];
+        if (HAS_RES) {
+#pragma unroll
+            for (int j = 0; j < TM; ++j)
+#pragma unroll
+                for (int i = 0; i < TN; i += 2) {
+                    const ru32x4 w = rwide[j][i / 2];
+                    const auto s0 = __builtin_amdgcn_permlane16_swap(w[0], w[2], false, false);
+                    const auto s1 = __builtin_amdgcn_permlane16_swap(w[1], w[3], false, false);
+                    rq[j][i] = make_uint2(s0[0], s1[0]);
+                    rq[j][i + 1] = make_uint2(s0[1], s1[1]);
+                }
+        }
         // ---- epilogue (conv_halo.hip): 16-byte stores after a v_permlane16_swap between channel tiles i and i+1
         auto finish = [&](int i, int j, float v[4]) {
             v[0] = acc[i][j][0] + bias4[i].x; v[1] = acc[i][j][1] + bias4[i].y; v[2] = acc[i][j][2] + bias4[i].z; v[3] = acc[i][j][3] + bias4[i].w;
-            if (a.res_mode != RES_NONE) {
+            if (HAS_RES) {
                 const uint2 q = rq[j][i];
                 const float rv[4] = {__uint_as_float(q.x << 16), __uint_as_float(q.x & 0xffff0000u),
                                      __uint_as_float(q.y << 16), __uint_as_float(q.y & 0xffff0000u)};
@@ -350,18 +366,18 @@ bool halo_rw_applicable(int kh, int kw, int stride, int pad, int n, const TView&
     return tiles >= 4 * 256;
 }
 
-template <int NCH>
+template <int NCH, bool HAS_RES>
 static hipError_t rw_launch(const RwDev& d, int act, int grid, size_t lds, hipStream_t st) {
     static bool attr_done = false;
     if (!attr_done) {
-        (void)hipFuncSetAttribute((const void*)conv_halo_rw_kernel<NCH, ACT_NONE>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute((const void*)conv_halo_rw_kernel<NCH, ACT_SILU>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute((const void*)conv_halo_rw_kernel<NCH, ACT_RELU>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)conv_halo_rw_kernel<NCH, ACT_NONE, HAS_RES>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)conv_halo_rw_kernel<NCH, ACT_SILU, HAS_RES>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)conv_halo_rw_kernel<NCH, ACT_RELU, HAS_RES>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_done = true;
     }
-    if (act == ACT_SILU) hipLaunchKernelGGL((conv_halo_rw_kernel<NCH, ACT_SILU>), dim3(grid), dim3(RW_THR), lds, st, d);
-    else if (act == ACT_RELU) hipLaunchKernelGGL((conv_halo_rw_kernel<NCH, ACT_RELU>), dim3(grid), dim3(RW_THR), lds, st, d);
-    else hipLaunchKernelGGL((conv_halo_rw_kernel<NCH, ACT_NONE>), dim3(grid), dim3(RW_THR), lds, st, d);
+    if (act == ACT_SILU) hipLaunchKernelGGL((conv_halo_rw_kernel<NCH, ACT_SILU, HAS_RES>), dim3(grid), dim3(RW_THR), lds, st, d);
+    else if (act == ACT_RELU) hipLaunchKernelGGL((conv_halo_rw_kernel<NCH, ACT_RELU, HAS_RES>), dim3(grid), dim3(RW_THR), lds, st, d);
+    else hipLaunchKernelGGL((conv_halo_rw_kernel<NCH, ACT_NONE, HAS_RES>), dim3(grid), dim3(RW_THR), lds, st, d);
     return hipGetLastError();
 }
 
@@ -382,8 +398,10 @@ hipError_t launch_conv_halo_rw(const ConvArgs& a, hipStream_t st) {
     d.mg_ww = pl.mg_ww; d.mg_sw = pl.mg_sw;
     int grid = 256 / d.NT * d.NT;  // one workgroup per CU, a multiple of the channel tiles
     const size_t lds = ((size_t)nch * 9 * RW_BN * 32 + (size_t)2 * nch * pl.maxpix * 32) * 2;
-    if (nch == 1) return rw_launch<1>(d, a.act, grid, lds, st);
-    return rw_launch<2>(d, a.act, grid, lds, st);
+    const bool res = a.res_mode != RES_NONE;
+    if (res && (((a.res.cs | a.res.coff) & 7) != 0)) return hipErrorNotSupported;  // halo_rw_applicable() keeps such layers on conv_halo
+    if (nch == 1) return res ? rw_launch<1, true>(d, a.act, grid, lds, st) : rw_launch<1, false>(d, a.act, grid, lds, st);
+    return res ? rw_launch<2, true>(d, a.act, grid, lds, st) : rw_launch<2, false>(d, a.act, grid, lds, st);
 }
 
 }  // namespace adas

@@ -382,8 +382,13 @@ ConvPlan plan_conv(int prec, int kh, int kw, int stride, int pad, int max_n, int
 hipError_t launch_conv(const ConvArgs& a, int prec, hipStream_t st) {
     ConvPlan pl = plan_conv(prec, a.kh, a.kw, a.stride, a.pad, a.max_n, a.res_mode, a.in, a.out);
     if (pl.kpad != a.kpad) return hipErrorInvalidValue;  // weights were packed for a different plan
-    if (pl.kernel == CONV_HALO)
-        return halo_rw_applicable(a.kh, a.kw, a.stride, a.pad, a.n, a.in, a.out) ? launch_conv_halo_rw(a, st) : launch_conv_halo(a, st);
+    if (pl.kernel == CONV_HALO) {
+        if (halo_rw_applicable(a.kh, a.kw, a.stride, a.pad, a.n, a.in, a.out)) {
+            hipError_t e = launch_conv_halo_rw(a, st);
+            if (e != hipErrorNotSupported) return e;  // e.g. a residual view that is not 16-byte aligned: same packing, other kernel
+        }
+        return launch_conv_halo(a, st);
+    }
     if (pl.kernel == CONV_PW) return launch_conv_pw(a, st);
     if (pl.kernel == CONV_FC) return (a.res_mode == RES_NONE && a.n <= 64) ? launch_fc(a, st) : hipErrorInvalidValue;
     ConvDev d;
