@@ -42,9 +42,12 @@ __global__ __launch_bounds__(512) void conv_pw_kernel(PwDev a) {
     extern __shared__ __attribute__((aligned(16))) uint16_t wl[];  // [NT][KS][64][8]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lrow = lane & 15, kg = lane >> 4;
-    {   // weights: contiguous copy, 16 B per thread per trip
+    float* bl = reinterpret_cast<float*>(wl + (size_t)a.NT * KS * 512);  // [NT*16] bias, behind the weights
+    {   // weights: contiguous copy, 16 B per thread per trip; bias too (a global bias load inside the feature-tile loop
+        // costs one exposed L2 round trip per tile: hipcc waits vmcnt(0) right behind it)
         const int n16 = a.NT * KS * 64;
         for (int i = tid; i < n16; i += 512) *reinterpret_cast<pu32x4*>(wl + (size_t)i * 8) = *reinterpret_cast<const pu32x4*>(a.wfrag + (size_t)i * 8);
+        for (int i = tid; i < a.NT * 16; i += 512) bl[i] = a.bias[i];   // bias is padded to 128 entries
     }
     __syncthreads();
     const int tail_valid = a.cin - (KS - 1) * 32;  // channels that exist in the last K step
@@ -78,7 +81,7 @@ __global__ __launch_bounds__(512) void conv_pw_kernel(PwDev a) {
             }
             const int c = nt * 16 + kg * 4;
             if (!ok || c >= a.cout) continue;
-            const float4 b4 = *reinterpret_cast<const float4*>(a.bias + c);
+            const float4 b4 = *reinterpret_cast<const float4*>(bl + c);
             float v[4] = {acc[0] + b4.x, acc[1] + b4.y, acc[2] + b4.z, acc[3] + b4.w};
             if (a.act == ACT_SILU) {
 #pragma unroll
@@ -109,7 +112,7 @@ bool pw_applicable(int prec, int kh, int kw, int stride, int pad, int res_mode, 
     const int ks = (in.c + 31) / 32, nt = (out.c + 15) / 16;
     if (ks > 16) return false;
     if (!(ks <= 4 || ks == 6 || ks == 8 || ks == 12 || ks == 16)) return false;
-    if ((size_t)nt * ks * 1024 > (size_t)PW_MAX_LDS) return false;
+    if ((size_t)nt * ks * 1024 + (size_t)nt * 64 > (size_t)PW_MAX_LDS) return false;
     return true;
 }
 
@@ -136,7 +139,7 @@ hipError_t launch_conv_pw(const ConvArgs& a, hipStream_t st) {
     const int ks = (a.in.c + 31) / 32;
     d.NT = (a.out.c + 15) / 16;
     d.mtiles = (a.m + 15) / 16;
-    const size_t lds = (size_t)d.NT * ks * 1024;
+    const size_t lds = (size_t)d.NT * ks * 1024 + (size_t)d.NT * 64;
     // persistent grid: as many 8-wave workgroups as fit the LDS budget of 256 CUs, never more than the work
     int per_cu = (int)((160 * 1024) / (lds > 4096 ? lds : 4096));
     if (per_cu > 4) per_cu = 4;
