@@ -55,7 +55,33 @@ struct PoolDev {
     void* out;
     int in_cs, in_coff, out_cs, out_coff, c, H, W, Ho, Wo, k, s, p, n;
 };
-// thread = (pixel, 8-channel group); padding behaves as -inf (torch.nn.MaxPool2d)
+// thread = (pixel, 8-channel group); padding behaves as -inf (torch.nn.MaxPool2d).  bf16: one 16-byte load per tap and
+// one 16-byte store (views are 8-channel aligned); the max is taken on the exact f32 images of the bf16 values.
+__device__ __forceinline__ void max8(float m[8], const uint16_t* ip) {
+    const uint4 q = *reinterpret_cast<const uint4*>(ip);
+    const uint32_t w[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        m[2 * k] = fmaxf(m[2 * k], __uint_as_float(w[k] << 16));
+        m[2 * k + 1] = fmaxf(m[2 * k + 1], __uint_as_float(w[k] & 0xffff0000u));
+    }
+}
+__device__ __forceinline__ void max8(float m[8], const float* ip) {
+#pragma unroll
+    for (int q = 0; q < 8; ++q) m[q] = fmaxf(m[q], ip[q]);
+}
+__device__ __forceinline__ void put8(uint16_t* op, const float m[8]) {
+    uint4 q;  // the maxima are bf16 values: truncation is exact
+    q.x = (__float_as_uint(m[0]) >> 16) | (__float_as_uint(m[1]) & 0xffff0000u);
+    q.y = (__float_as_uint(m[2]) >> 16) | (__float_as_uint(m[3]) & 0xffff0000u);
+    q.z = (__float_as_uint(m[4]) >> 16) | (__float_as_uint(m[5]) & 0xffff0000u);
+    q.w = (__float_as_uint(m[6]) >> 16) | (__float_as_uint(m[7]) & 0xffff0000u);
+    *reinterpret_cast<uint4*>(op) = q;
+}
+__device__ __forceinline__ void put8(float* op, const float m[8]) {
+#pragma unroll
+    for (int q = 0; q < 8; ++q) op[q] = m[q];
+}
 template <typename T>
 __global__ void maxpool_kernel(PoolDev d) {
     const int c8n = d.c >> 3;
@@ -75,18 +101,14 @@ __global__ void maxpool_kernel(PoolDev d) {
             for (int s = 0; s < d.k; ++s) {
                 int ix = ox * d.s - d.p + s;
                 if ((unsigned)ix >= (unsigned)d.W) continue;
-                const T* ip = (const T*)d.in + ((size_t)(b * d.H + iy) * d.W + ix) * d.in_cs + d.in_coff + c8 * 8;
-#pragma unroll
-                for (int q = 0; q < 8; ++q) m[q] = fmaxf(m[q], ld<T>(ip + q));
+                max8(m, (const T*)d.in + ((size_t)(b * d.H + iy) * d.W + ix) * d.in_cs + d.in_coff + c8 * 8);
             }
         }
-        T* op = (T*)d.out + pix * d.out_cs + d.out_coff + c8 * 8;
-#pragma unroll
-        for (int q = 0; q < 8; ++q) st<T>(op + q, m[q]);
+        put8((T*)d.out + pix * d.out_cs + d.out_coff + c8 * 8, m);
     }
 }
 hipError_t launch_maxpool(TView in, TView out, int n, int k, int s, int p, int prec, hipStream_t st_) {
-    if (in.c != out.c || (in.c & 7)) return hipErrorInvalidValue;
+    if (in.c != out.c || (in.c & 7) || ((in.cs | in.coff | out.cs | out.coff) & 7)) return hipErrorInvalidValue;
     PoolDev d{in.p, out.p, in.cs, in.coff, out.cs, out.coff, in.c, in.h, in.w, out.h, out.w, k, s, p, n};
     size_t total = (size_t)n * out.h * out.w * (in.c >> 3);
     int blocks = (int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
@@ -109,12 +131,16 @@ __global__ void upsample2_kernel(PoolDev d) {
         int oy = (int)(t % d.Ho), b = (int)(t / d.Ho);
         const T* ip = (const T*)d.in + ((size_t)(b * d.H + (oy >> 1)) * d.W + (ox >> 1)) * d.in_cs + d.in_coff + c8 * 8;
         T* op = (T*)d.out + pix * d.out_cs + d.out_coff + c8 * 8;
+        if (sizeof(T) == 2) {  // 8 bf16 = one 16-byte move (views are 8-channel aligned)
+            *reinterpret_cast<uint4*>(op) = *reinterpret_cast<const uint4*>(ip);
+        } else {
 #pragma unroll
-        for (int q = 0; q < 8; ++q) op[q] = ip[q];
+            for (int q = 0; q < 8; ++q) op[q] = ip[q];
+        }
     }
 }
 hipError_t launch_upsample2(TView in, TView out, int n, int prec, hipStream_t st_) {
-    if (in.c != out.c || (in.c & 7) || out.h != 2 * in.h || out.w != 2 * in.w) return hipErrorInvalidValue;
+    if (in.c != out.c || (in.c & 7) || ((in.cs | in.coff | out.cs | out.coff) & 7) || out.h != 2 * in.h || out.w != 2 * in.w) return hipErrorInvalidValue;
     PoolDev d{in.p, out.p, in.cs, in.coff, out.cs, out.coff, in.c, in.h, in.w, out.h, out.w, 0, 0, 0, n};
     size_t total = (size_t)n * out.h * out.w * (in.c >> 3);
     int blocks = (int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
