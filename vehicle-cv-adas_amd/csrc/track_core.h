@@ -348,17 +348,197 @@ ADAS_DEV void bt_lap(const Ctx& c, const double* cost, int T, int D, double limi
     c.sync();
 }
 
+// ---------------------------------------------------------------- LAP, single-wave form
+// Same successive-shortest-path iteration as bt_lap, for D + 1 <= 64 * NC columns: wave 0 keeps the per-column state
+// (v, minv, way, p, used) in registers, lane l owning columns l, l + 64, ...; the per-step argmin is a 6-step butterfly
+// and no workgroup barrier is needed inside the search.  Element arithmetic, comparison order and tie rule (lowest
+// column) are those of bt_lap, so the assignment is the same one.
+#if defined(__HIP_DEVICE_COMPILE__)
+template <int NC>
+ADAS_DEV int lap_pick(const int (&a)[NC], int k) {
+    int r = a[0];
+#pragma unroll
+    for (int q = 1; q < NC; ++q) r = (k == q) ? a[q] : r;
+    return r;
+}
+
+template <int NC>
+ADAS_DEV void bt_lap_wave(const Ctx& c, const double* cost, int T, int D, double limit, int* x_row, int* y_col,
+                          const LapLds& S) {
+    if (c.tid < 64) {
+        const int lane = c.tid;
+        double v[NC], minv[NC];
+        int way[NC], p[NC], used[NC];
+#pragma unroll
+        for (int k = 0; k < NC; ++k) {
+            v[k] = 0.0;
+            p[k] = -1;
+        }
+        for (int i = lane; i < T; i += 64) {
+            S.u[i] = 0.0;
+            x_row[i] = -1;
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (D > 0) {
+            for (int r = 0; r < T; ++r) {
+#pragma unroll
+                for (int k = 0; k < NC; ++k) {
+                    minv[k] = DBL_MAX;
+                    used[k] = 0;
+                    way[k] = -1;
+                }
+                int i0 = r, j0 = -1;
+                for (;;) {
+                    const double ui = S.u[i0];
+                    const double* crow = cost + (size_t)i0 * D;
+                    double bv = DBL_MAX;
+                    int bi = 0x7fffffff;
+#pragma unroll
+                    for (int k = 0; k < NC; ++k) {
+                        const int j = lane + 64 * k;
+                        if (j <= D && !used[k]) {
+                            double cur = ((j < D) ? crow[j] : limit) - ui - v[k];
+                            if (cur < minv[k]) {
+                                minv[k] = cur;
+                                way[k] = j0;
+                            }
+                            if (minv[k] < bv || bi == 0x7fffffff) {
+                                bv = minv[k];
+                                bi = j;
+                            }
+                        }
+                    }
+#pragma unroll
+                    for (int off = 1; off < 64; off <<= 1) {
+                        double ov = __shfl_xor(bv, off, 64);
+                        int oi = __shfl_xor(bi, off, 64);
+                        if (oi != 0x7fffffff && (bi == 0x7fffffff || ov < bv || (ov == bv && oi < bi))) {
+                            bv = ov;
+                            bi = oi;
+                        }
+                    }
+                    const double delta = bv;
+                    const int j1 = bi;
+#pragma unroll
+                    for (int k = 0; k < NC; ++k) {
+                        const int j = lane + 64 * k;
+                        if (j <= D) {
+                            if (used[k]) {
+                                S.u[p[k]] += delta;
+                                v[k] -= delta;
+                            } else {
+                                minv[k] -= delta;
+                            }
+                        }
+                    }
+                    if (lane == 0) S.u[r] += delta;
+                    __builtin_amdgcn_wave_barrier();
+                    j0 = j1;
+                    const int pj1 = __shfl(lap_pick<NC>(p, j1 >> 6), j1 & 63, 64);
+                    if (j1 == D || pj1 < 0) break;
+#pragma unroll
+                    for (int k = 0; k < NC; ++k)
+                        if (lane + 64 * k == j1) used[k] = 1;
+                    i0 = pj1;
+                }
+                int j = j0;  // augment along way[]
+                for (;;) {
+                    const int jp = __shfl(lap_pick<NC>(way, j >> 6), j & 63, 64);
+                    const int jq = jp < 0 ? 0 : jp;
+                    const int pjp = __shfl(lap_pick<NC>(p, jq >> 6), jq & 63, 64);
+                    const int row = (jp < 0) ? r : pjp;
+                    if (j == D) {
+                        if (lane == 0) x_row[row] = -1;
+                    } else {
+#pragma unroll
+                        for (int k = 0; k < NC; ++k)
+                            if (lane + 64 * k == j) p[k] = row;
+                        if (lane == 0) x_row[row] = j;
+                    }
+                    if (jp < 0) break;
+                    j = jp;
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < NC; ++k) {
+            const int j = lane + 64 * k;
+            if (j < D) y_col[j] = p[k];
+        }
+    }
+    c.sync();
+}
+#endif
+
+// dispatcher: the register form whenever the columns fit 8 per lane, the block-wide form otherwise (and on the host)
+ADAS_DEV void bt_assign(const Ctx& c, const double* cost, int T, int D, double limit, int* x_row, int* y_col,
+                        const LapLds& S) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (D + 1 <= 64) return bt_lap_wave<1>(c, cost, T, D, limit, x_row, y_col, S);
+    if (D + 1 <= 128) return bt_lap_wave<2>(c, cost, T, D, limit, x_row, y_col, S);
+    if (D + 1 <= 256) return bt_lap_wave<4>(c, cost, T, D, limit, x_row, y_col, S);
+    if (D + 1 <= 512) return bt_lap_wave<8>(c, cost, T, D, limit, x_row, y_col, S);
+#endif
+    bt_lap(c, cost, T, D, limit, x_row, y_col, S);
+}
+
+// ---------------------------------------------------------------- ordered compaction
+// out[base + rank] = val(k) for every k in [0,n) with keep(k), list order preserved; returns base + count in every
+// thread.  keep/val may read anything written before the call's first barrier; out is complete on return.
+template <class Keep, class Val>
+ADAS_DEV int bt_compact(const Ctx& c, int n, int* out, int base, int* wsum, Keep keep, Val val) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const int lane = c.tid & 63, wv = c.tid >> 6, nw = (c.nthr + 63) >> 6;
+    for (int k0 = 0; k0 < n; k0 += c.nthr) {
+        const int k = k0 + c.tid;
+        const bool f = (k < n) && keep(k);
+        const unsigned long long m = __ballot(f);
+        if (lane == 0) wsum[wv] = __popcll(m);
+        c.sync();
+        int pos = base + __popcll(m & ((1ull << lane) - 1ull));
+        int tot = 0;
+        for (int w = 0; w < nw; ++w) {
+            const int cw = wsum[w];
+            if (w < wv) pos += cw;
+            tot += cw;
+        }
+        if (f) out[pos] = val(k);
+        base += tot;
+        c.sync();
+    }
+    return base;
+#else
+    (void)wsum;
+    for (int k = 0; k < n; ++k)
+        if (keep(k)) out[base++] = val(k);
+    return base;
+#endif
+}
+
 // ---------------------------------------------------------------- LDS carve for the update
+#define ADAS_BT_LDS_BUDGET (156 * 1024)
 struct BtLds {
     LapLds lap;
-    int *hi, *lo, *rem, *pool, *unc, *rtr, *x, *y, *refind, *lostnew, *newtr, *la, *lb;
+    int *hi, *lo, *rem, *pool, *unc, *rtr, *x, *y, *refind, *lostnew, *newtr, *la, *lb, *mark, *pst, *wsum;
     int* n;  // scalar mailbox [16]
-    static ADAS_HD size_t bytes(int MT, int MD, int nthr) {
+    double* cost;   // association cost matrix when it fits (cost_cap doubles), else BtStream.cost in HBM
+    size_t cost_cap;
+    static ADAS_HD size_t fixed_bytes(int MT, int MD, int nthr) {
         size_t d = (size_t)MT + 2 * (size_t)(MD + 1) + nthr;           // u, v, minv, red_v
         size_t i = 2 * (size_t)(MD + 1) + nthr                         // way, p, red_i
                    + 4 * (size_t)MD                                    // hi lo rem y
-                   + 9 * (size_t)MT + 16;                              // pool unc rtr x refind lostnew newtr la lb
+                   + 11 * (size_t)MT + 16 + 16;                        // pool unc rtr x refind lostnew newtr la lb mark pst, n, wsum
         return d * 8 + i * 4 + (size_t)(MD + 1) + 64;
+    }
+    static ADAS_HD size_t cost_doubles(int MT, int MD, int nthr) {
+        size_t f = (fixed_bytes(MT, MD, nthr) + 15) & ~(size_t)15;
+        size_t room = f < (size_t)ADAS_BT_LDS_BUDGET ? ((size_t)ADAS_BT_LDS_BUDGET - f) / 8 : 0;
+        size_t want = (size_t)MT * MD;
+        return want < room ? want : room;
+    }
+    static ADAS_HD size_t bytes(int MT, int MD, int nthr) {
+        return ((fixed_bytes(MT, MD, nthr) + 15) & ~(size_t)15) + cost_doubles(MT, MD, nthr) * 8;
     }
     ADAS_DEV void carve(void* base, int MT, int MD, int nthr) {
         double* d = (double*)base;
@@ -383,64 +563,77 @@ struct BtLds {
         newtr = q; q += MT;
         la = q; q += MT;
         lb = q; q += MT;
+        mark = q; q += MT;
+        pst = q; q += MT;
         n = q; q += 16;
+        wsum = q; q += 16;
         lap.used = (unsigned char*)q;
+        cost = (double*)((unsigned char*)base + ((fixed_bytes(MT, MD, nthr) + 15) & ~(size_t)15));
+        cost_cap = cost_doubles(MT, MD, nthr);
     }
 };
 
-enum { N_HI = 0, N_LO, N_POOL, N_UNC, N_RTR, N_REM, N_REF, N_LOSTNEW, N_NEW, N_T, N_L, N_ERR };
+enum { N_ERR = 0 };
 
-ADAS_DEV bool bt_id_in(const BtTrack* slots, const int* list, int n, int id) {
-    for (int k = 0; k < n; ++k)
-        if (slots[list[k]].track_id == id) return true;
-    return false;
-}
+// phase timers for tools/scratch/bt_bench.hip (scratch builds only)
+#if defined(ADAS_BT_PROF) && defined(__HIP_DEVICE_COMPILE__)
+#define BT_MARK_INIT unsigned long long bt_t0_ = wall_clock64()
+#define BT_MARK(i)                                      \
+    do {                                                \
+        if (c.tid == 0) {                               \
+            unsigned long long t_ = wall_clock64();     \
+            atomicAdd(&g_bt_prof[i], t_ - bt_t0_);      \
+            bt_t0_ = t_;                                \
+        }                                               \
+    } while (0)
+#else
+#define BT_MARK_INIT
+#define BT_MARK(i)
+#endif
 
 // ---------------------------------------------------------------- BYTETracker.update
+// List membership tests of the reference compare track ids (byteTrack/utils.py:9-40).  A table slot keeps one id for
+// as long as it is in use and ids are never reissued, so "same id" == "same slot" and the tests become per-slot marks
+// in LDS; every filtered list is then an ordered compaction over the workgroup (bt_compact) instead of a serial scan.
 ADAS_DEV void bytetrack_update(const Ctx& c, const BtParams& P, const BtStream& S, const BtDet& det, void* lds_base) {
     BtLds L;
     L.carve(lds_base, P.MT, P.MD, c.nthr);
     BtTrack* slots = S.slots;
     const int MT = P.MT, MD = P.MD;
-    if (c.tid == 0) {
-        S.hdr->frame_id += 1;
-        int err = 0;
-        int nd = det.nd;
-        if (nd > MD) {
-            nd = MD;
-            err |= BT_ERR_DET_OVERFLOW;
-        }
-        // byteTracker.py:73-83 score bands (a score of exactly track_thresh is in neither)
-        int nh = 0, nl = 0;
-        for (int d = 0; d < nd; ++d) {
-            double s = det.score[d];
-            if (s > P.track_thresh) L.hi[nh++] = d;
-            if (s > 0.1 && s < P.track_thresh) L.lo[nl++] = d;
-        }
-        // :93-102 unconfirmed / tracked split, pool = joint(tracked, lost)
-        int np = 0, nu = 0;
-        for (int k = 0; k < S.hdr->n_tracked; ++k) {
-            int s = S.tracked[k];
-            if (slots[s].is_activated) {
-                if (!bt_id_in(slots, L.pool, np, slots[s].track_id)) L.pool[np++] = s;
-            } else
-                L.unc[nu++] = s;
-        }
-        for (int k = 0; k < S.hdr->n_lost; ++k) {
-            int s = S.lost[k];
-            if (!bt_id_in(slots, L.pool, np, slots[s].track_id)) L.pool[np++] = s;
-        }
-        L.n[N_HI] = nh; L.n[N_LO] = nl; L.n[N_POOL] = np; L.n[N_UNC] = nu; L.n[N_ERR] = err;
+    BT_MARK_INIT;
+    const int fid = S.hdr->frame_id + 1;
+    const int n_tr0 = S.hdr->n_tracked, n_lost0 = S.hdr->n_lost, id0 = S.hdr->id_count;
+    int nd = det.nd;
+    if (c.tid == 0) L.n[N_ERR] = (nd > MD) ? BT_ERR_DET_OVERFLOW : 0;
+    if (nd > MD) nd = MD;
+    ADAS_PAR_FOR(c, q, 0, MT) L.mark[q] = 0;
+    c.sync();
+    if (c.tid == 0) S.hdr->frame_id = fid;
+    // byteTracker.py:73-83 score bands (a score of exactly track_thresh is in neither)
+    const int n_hi = bt_compact(c, nd, L.hi, 0, L.wsum, [&](int d) { return det.score[d] > P.track_thresh; }, [&](int d) { return d; });
+    const int n_lo = bt_compact(c, nd, L.lo, 0, L.wsum,
+                                [&](int d) { double s = det.score[d]; return s > 0.1 && s < P.track_thresh; }, [&](int d) { return d; });
+    // :93-102 unconfirmed / tracked split, pool = joint(tracked, lost)
+    int n_pool = bt_compact(c, n_tr0, L.pool, 0, L.wsum, [&](int k) { return slots[S.tracked[k]].is_activated != 0; },
+                            [&](int k) { return S.tracked[k]; });
+    const int n_unc = bt_compact(c, n_tr0, L.unc, 0, L.wsum, [&](int k) { return slots[S.tracked[k]].is_activated == 0; },
+                                 [&](int k) { return S.tracked[k]; });
+    ADAS_PAR_FOR(c, k, 0, n_pool) L.mark[L.pool[k]] = 1;
+    c.sync();
+    n_pool = bt_compact(c, n_lost0, L.pool, n_pool, L.wsum, [&](int k) { return !L.mark[S.lost[k]]; }, [&](int k) { return S.lost[k]; });
+    BT_MARK(0);
+
+    // :104 STrack.multi_predict(strack_pool); pst = state before this frame's updates
+    ADAS_PAR_FOR(c, k, 0, n_pool) {
+        BtTrack& t = slots[L.pool[k]];
+        L.pst[k] = t.state;
+        bt_kf_predict(t);
     }
     c.sync();
-    const int fid = S.hdr->frame_id;
-    const int n_hi = L.n[N_HI], n_lo = L.n[N_LO], n_pool = L.n[N_POOL], n_unc = L.n[N_UNC];
-
-    // :104 STrack.multi_predict(strack_pool)
-    ADAS_PAR_FOR(c, k, 0, n_pool) bt_kf_predict(slots[L.pool[k]]);
-    c.sync();
+    BT_MARK(1);
 
     // :105-108 first association: IoU cost fused with detection score, cost_limit = match_thresh
+    double* cm = ((size_t)n_pool * n_hi <= L.cost_cap) ? L.cost : S.cost;
     ADAS_PAR_FOR(c, e, 0, n_pool * n_hi) {
         int i = e / n_hi, j = e % n_hi, d = L.hi[j];
         double a[4], b[4];
@@ -449,47 +642,42 @@ ADAS_DEV void bytetrack_update(const Ctx& c, const BtParams& P, const BtStream& 
         double cost = 1 - bt_iou(a, b);
         double sim = 1 - cost;
         double v = 1 - sim * det.score[d];
-        S.cost[e] = (v == v) ? v : DBL_MAX;
+        cm[e] = (v == v) ? v : DBL_MAX;
     }
     c.sync();
-    bt_lap(c, S.cost, n_pool, n_hi, P.match_thresh, L.x, L.y, L.lap);
-    if (c.tid == 0) {
-        int nr = 0, nq = 0;
-        for (int i = 0; i < n_pool; ++i) {
-            int s = L.pool[i];
-            slots[s].tmp = slots[s].state;  // state before this frame's updates
-            if (L.x[i] >= 0) {
-                if (slots[s].state != BT_TRACKED) L.refind[nr++] = s;
-            } else if (slots[s].state == BT_TRACKED)
-                L.rtr[nq++] = s;  // :128 r_tracked_stracks
-        }
-        int nm = 0;
-        for (int j = 0; j < n_hi; ++j)
-            if (L.y[j] < 0) L.rem[nm++] = L.hi[j];  // :148 detections = [detections[i] for i in u_detection]
-        L.n[N_REF] = nr; L.n[N_RTR] = nq; L.n[N_REM] = nm;
-    }
-    c.sync();
+    BT_MARK(2);
+    bt_assign(c, cm, n_pool, n_hi, P.match_thresh, L.x, L.y, L.lap);
+    BT_MARK(3);
+    const int n_ref = bt_compact(c, n_pool, L.refind, 0, L.wsum, [&](int i) { return L.x[i] >= 0 && L.pst[i] != BT_TRACKED; },
+                                 [&](int i) { return L.pool[i]; });
+    const int n_rtr = bt_compact(c, n_pool, L.rtr, 0, L.wsum, [&](int i) { return L.x[i] < 0 && L.pst[i] == BT_TRACKED; },
+                                 [&](int i) { return L.pool[i]; });  // :128 r_tracked_stracks
+    const int n_rem = bt_compact(c, n_hi, L.rem, 0, L.wsum, [&](int j) { return L.y[j] < 0; },
+                                 [&](int j) { return L.hi[j]; });  // :148 detections = [detections[i] for i in u_detection]
+    BT_MARK(4);
     ADAS_PAR_FOR(c, i, 0, n_pool) {
         if (L.x[i] >= 0) {
             int s = L.pool[i], d = L.hi[L.x[i]];
-            bt_apply_match(slots[s], det.tlbr + 4 * d, det.score[d], det.cls[d], fid, slots[s].tmp != BT_TRACKED,
-                           &L.n[N_ERR]);
+            bt_apply_match(slots[s], det.tlbr + 4 * d, det.score[d], det.cls[d], fid, L.pst[i] != BT_TRACKED, &L.n[N_ERR]);
         }
     }
     c.sync();
-    const int n_rtr = L.n[N_RTR], n_rem = L.n[N_REM];
+    BT_MARK(5);
 
     // :122-145 second association: still-Tracked leftovers vs low-score detections, plain IoU, limit 0.5
+    cm = ((size_t)n_rtr * n_lo <= L.cost_cap) ? L.cost : S.cost;
     ADAS_PAR_FOR(c, e, 0, n_rtr * n_lo) {
         int i = e / n_lo, j = e % n_lo, d = L.lo[j];
         double a[4], b[4];
         bt_track_tlbr(slots[L.rtr[i]], a);
         bt_det_tlbr(det.tlbr + 4 * d, b);
         double v = 1 - bt_iou(a, b);
-        S.cost[e] = (v == v) ? v : DBL_MAX;
+        cm[e] = (v == v) ? v : DBL_MAX;
     }
     c.sync();
-    bt_lap(c, S.cost, n_rtr, n_lo, 0.5, L.x, L.y, L.lap);
+    BT_MARK(6);
+    bt_assign(c, cm, n_rtr, n_lo, 0.5, L.x, L.y, L.lap);
+    BT_MARK(7);
     ADAS_PAR_FOR(c, i, 0, n_rtr) {
         if (L.x[i] >= 0) {
             int s = L.rtr[i], d = L.lo[L.x[i]];
@@ -497,21 +685,15 @@ ADAS_DEV void bytetrack_update(const Ctx& c, const BtParams& P, const BtStream& 
         }
     }
     c.sync();
-    if (c.tid == 0) {
-        int nl = 0;
-        for (int i = 0; i < n_rtr; ++i)
-            if (L.x[i] < 0) {
-                int s = L.rtr[i];
-                if (slots[s].state != BT_LOST) {
-                    slots[s].state = BT_LOST;
-                    L.lostnew[nl++] = s;
-                }
-            }
-        L.n[N_LOSTNEW] = nl;
-    }
+    BT_MARK(8);
+    const int n_lostnew = bt_compact(c, n_rtr, L.lostnew, 0, L.wsum,
+                                     [&](int i) { return L.x[i] < 0 && slots[L.rtr[i]].state != BT_LOST; }, [&](int i) { return L.rtr[i]; });
+    ADAS_PAR_FOR(c, k, 0, n_lostnew) slots[L.lostnew[k]].state = BT_LOST;
     c.sync();
+    BT_MARK(9);
 
     // :147-159 unconfirmed tracks vs remaining high-score detections, fused cost, limit 0.7
+    cm = ((size_t)n_unc * n_rem <= L.cost_cap) ? L.cost : S.cost;
     ADAS_PAR_FOR(c, e, 0, n_unc * n_rem) {
         int i = e / n_rem, j = e % n_rem, d = L.rem[j];
         double a[4], b[4];
@@ -520,10 +702,12 @@ ADAS_DEV void bytetrack_update(const Ctx& c, const BtParams& P, const BtStream& 
         double cost = 1 - bt_iou(a, b);
         double sim = 1 - cost;
         double v = 1 - sim * det.score[d];
-        S.cost[e] = (v == v) ? v : DBL_MAX;
+        cm[e] = (v == v) ? v : DBL_MAX;
     }
     c.sync();
-    bt_lap(c, S.cost, n_unc, n_rem, 0.7, L.x, L.y, L.lap);
+    BT_MARK(10);
+    bt_assign(c, cm, n_unc, n_rem, 0.7, L.x, L.y, L.lap);
+    BT_MARK(11);
     ADAS_PAR_FOR(c, i, 0, n_unc) {
         int s = L.unc[i];
         if (L.x[i] >= 0) {
@@ -535,84 +719,73 @@ ADAS_DEV void bytetrack_update(const Ctx& c, const BtParams& P, const BtStream& 
         }
     }
     c.sync();
+    BT_MARK(12);
 
-    if (c.tid == 0) {
-        int err = L.n[N_ERR];
-        // :162-168 new tracks from unmatched high-score detections
-        int nn = 0;
-        for (int j = 0; j < n_rem; ++j) {
-            if (L.y[j] >= 0) continue;
-            int d = L.rem[j];
-            if (det.score[d] < P.det_thresh) continue;
-            int s = -1;
-            for (int q = 0; q < MT; ++q)
-                if (!slots[q].used) {
-                    s = q;
-                    break;
-                }
-            if (s < 0) {
-                err |= BT_ERR_TRACK_OVERFLOW;
-                break;
-            }
-            BtTrack& t = slots[s];
-            const double* b = det.tlbr + 4 * d;
-            double tlwh[4] = {b[0], b[1], b[2] - b[0], b[3] - b[1]};
-            S.hdr->id_count += 1;
-            t.used = 1;
-            t.track_id = S.hdr->id_count;
-            bt_kf_initiate(t, tlwh);
-            t.score = det.score[d];
-            t.tracklet_len = 0;
-            t.state = BT_TRACKED;
-            t.is_activated = (fid == 1) ? 1 : 0;
-            t.frame_id = fid;
-            t.start_frame = fid;
-            t.class_id = det.cls[d];
-            t.hist_n = 1;
-            t.hist_cls[0] = det.cls[d];
-            t.hist_cnt[0] = 1;
-            t.ever_removed = 0;
-            t.tmp = 0;
-            L.newtr[nn++] = s;
-        }
-        // :171-174 age out lost tracks
-        for (int k = 0; k < S.hdr->n_lost; ++k) {
-            BtTrack& t = slots[S.lost[k]];
-            if (fid - t.frame_id > P.max_time_lost) {
-                t.state = BT_REMOVED;
-                t.tmp = -1;
-            }
-        }
-        // :176-182 list algebra
-        int nt = 0;
-        for (int k = 0; k < S.hdr->n_tracked; ++k) {
-            int s = S.tracked[k];
-            if (slots[s].state == BT_TRACKED && !bt_id_in(slots, L.la, nt, slots[s].track_id)) L.la[nt++] = s;
-        }
-        for (int k = 0; k < nn; ++k)
-            if (!bt_id_in(slots, L.la, nt, slots[L.newtr[k]].track_id)) L.la[nt++] = L.newtr[k];
-        for (int k = 0; k < L.n[N_REF]; ++k)
-            if (!bt_id_in(slots, L.la, nt, slots[L.refind[k]].track_id)) L.la[nt++] = L.refind[k];
-        int nl = 0;
-        for (int k = 0; k < S.hdr->n_lost; ++k) {
-            int s = S.lost[k];
-            if (!bt_id_in(slots, L.la, nt, slots[s].track_id)) L.lb[nl++] = s;
-        }
-        for (int k = 0; k < L.n[N_LOSTNEW]; ++k) L.lb[nl++] = L.lostnew[k];
-        int nl2 = 0;
-        for (int k = 0; k < nl; ++k)  // sub_stracks(lost, removed_stracks as of the previous frame)
-            if (!slots[L.lb[k]].ever_removed) L.lb[nl2++] = L.lb[k];
-        nl = nl2;
-        for (int q = 0; q < MT; ++q)
-            if (slots[q].used && slots[q].tmp == -1) {
-                slots[q].ever_removed = 1;  // removed_stracks.extend(removed)
-                slots[q].tmp = 0;
-            }
-        L.n[N_T] = nt; L.n[N_L] = nl; L.n[N_ERR] = err;
+    // :162-168 new tracks from unmatched high-score detections: the k-th of them takes the k-th free slot and id
+    // id_count + k + 1 (L.lo is free again and holds the candidate detections)
+    const int n_cand = bt_compact(c, n_rem, L.lo, 0, L.wsum, [&](int j) { return L.y[j] < 0 && !(det.score[L.rem[j]] < P.det_thresh); },
+                                  [&](int j) { return L.rem[j]; });
+    const int n_free = bt_compact(c, MT, L.newtr, 0, L.wsum, [&](int q) { return !slots[q].used; }, [&](int q) { return q; });
+    const int n_new = n_cand < n_free ? n_cand : n_free;
+    ADAS_PAR_FOR(c, k, 0, n_new) {
+        const int d = L.lo[k];
+        BtTrack& t = slots[L.newtr[k]];
+        const double* b = det.tlbr + 4 * d;
+        double tlwh[4] = {b[0], b[1], b[2] - b[0], b[3] - b[1]};
+        t.used = 1;
+        t.track_id = id0 + k + 1;
+        bt_kf_initiate(t, tlwh);
+        t.score = det.score[d];
+        t.tracklet_len = 0;
+        t.state = BT_TRACKED;
+        t.is_activated = (fid == 1) ? 1 : 0;
+        t.frame_id = fid;
+        t.start_frame = fid;
+        t.class_id = det.cls[d];
+        t.hist_n = 1;
+        t.hist_cls[0] = det.cls[d];
+        t.hist_cnt[0] = 1;
+        t.ever_removed = 0;
+        t.tmp = 0;
     }
+    if (c.tid == 0) {
+        S.hdr->id_count = id0 + n_new;
+        if (n_cand > n_free) L.n[N_ERR] |= BT_ERR_TRACK_OVERFLOW;
+    }
+    // :171-174 age out lost tracks
+    ADAS_PAR_FOR(c, k, 0, n_lost0) {
+        BtTrack& t = slots[S.lost[k]];
+        if (fid - t.frame_id > P.max_time_lost) {
+            t.state = BT_REMOVED;
+            t.tmp = -1;
+        }
+    }
+    ADAS_PAR_FOR(c, q, 0, MT) L.mark[q] = 0;
     c.sync();
-    const int nt = L.n[N_T], nl = L.n[N_L];
-    // :183 remove_duplicate_stracks: pairs with IoU distance < 0.15; x/y reused as duplicate flags
+    // :176-182 list algebra: tracked = joint(joint(tracked & Tracked, activated), refind)
+    int nt = bt_compact(c, n_tr0, L.la, 0, L.wsum, [&](int k) { return slots[S.tracked[k]].state == BT_TRACKED; },
+                        [&](int k) { return S.tracked[k]; });
+    ADAS_PAR_FOR(c, k, 0, n_new) L.la[nt + k] = L.newtr[k];
+    nt += n_new;
+    c.sync();
+    ADAS_PAR_FOR(c, k, 0, nt) L.mark[L.la[k]] = 1;
+    c.sync();
+    nt = bt_compact(c, n_ref, L.la, nt, L.wsum, [&](int k) { return !L.mark[L.refind[k]]; }, [&](int k) { return L.refind[k]; });
+    ADAS_PAR_FOR(c, k, 0, n_ref) L.mark[L.refind[k]] = 1;
+    c.sync();
+    // lost = sub(sub(lost, tracked) + newly lost, removed_stracks as of the previous frame)
+    int nl = bt_compact(c, n_lost0, L.lb, 0, L.wsum, [&](int k) { int s = S.lost[k]; return !L.mark[s] && !slots[s].ever_removed; },
+                        [&](int k) { return S.lost[k]; });
+    nl = bt_compact(c, n_lostnew, L.lb, nl, L.wsum, [&](int k) { return !slots[L.lostnew[k]].ever_removed; },
+                    [&](int k) { return L.lostnew[k]; });
+    ADAS_PAR_FOR(c, q, 0, MT) {
+        if (slots[q].used && slots[q].tmp == -1) {
+            slots[q].ever_removed = 1;  // removed_stracks.extend(removed)
+            slots[q].tmp = 0;
+        }
+    }
+    BT_MARK(13);
+    // :183 remove_duplicate_stracks: pairs with IoU distance < 0.15; x/rtr reused as duplicate flags
     ADAS_PAR_FOR(c, k, 0, nt) L.x[k] = 0;
     ADAS_PAR_FOR(c, k, 0, nl) L.rtr[k] = 0;
     c.sync();
@@ -633,25 +806,26 @@ ADAS_DEV void bytetrack_update(const Ctx& c, const BtParams& P, const BtStream& 
         }
     }
     c.sync();
+    BT_MARK(14);
+    const int a = bt_compact(c, nt, S.tracked, 0, L.wsum, [&](int k) { return !L.x[k]; }, [&](int k) { return L.la[k]; });
+    const int b = bt_compact(c, nl, S.lost, 0, L.wsum, [&](int k) { return !L.rtr[k]; }, [&](int k) { return L.lb[k]; });
     if (c.tid == 0) {
-        int a = 0, b = 0;
-        for (int k = 0; k < nt; ++k)
-            if (!L.x[k]) S.tracked[a++] = L.la[k];
-        for (int k = 0; k < nl; ++k)
-            if (!L.rtr[k]) S.lost[b++] = L.lb[k];
         S.hdr->n_tracked = a;
         S.hdr->n_lost = b;
         S.hdr->err |= L.n[N_ERR];
-        // free slots that are in neither list
-        for (int q = 0; q < MT; ++q) slots[q].tmp = 0;
-        for (int k = 0; k < a; ++k) slots[S.tracked[k]].tmp = 1;
-        for (int k = 0; k < b; ++k) slots[S.lost[k]].tmp = 1;
-        for (int q = 0; q < MT; ++q)
-            if (slots[q].used && !slots[q].tmp) slots[q].used = 0;
     }
+    // free slots that are in neither list
+    ADAS_PAR_FOR(c, q, 0, MT) L.mark[q] = 0;
     c.sync();
+    ADAS_PAR_FOR(c, k, 0, a + b) L.mark[k < a ? S.tracked[k] : S.lost[k - a]] = 1;
+    c.sync();
+    ADAS_PAR_FOR(c, q, 0, MT) {
+        const int m = L.mark[q];
+        slots[q].tmp = m;
+        if (slots[q].used && !m) slots[q].used = 0;
+    }
+    BT_MARK(15);
     // compact messages: tracked first, then lost
-    const int a = S.hdr->n_tracked, b = S.hdr->n_lost;
     ADAS_PAR_FOR(c, k, 0, a + b) {
         const BtTrack& t = slots[k < a ? S.tracked[k] : S.lost[k - a]];
         BtOut& o = S.out[k];
@@ -666,6 +840,7 @@ ADAS_DEV void bytetrack_update(const Ctx& c, const BtParams& P, const BtStream& 
         o.tracklet_len = t.tracklet_len;
         o.pad = 0;
     }
+    BT_MARK(16);
 }
 
 ADAS_DEV void bytetrack_reset(const Ctx& c, const BtParams& P, const BtStream& S) {  // byteTracker.py:187-200
