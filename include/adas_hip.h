@@ -102,11 +102,12 @@ typedef struct adas_yolo_post adas_yolo_post;
 
 #define ADAS_HEAD_V8 0 /* (4+nc, A) channel-major: YOLOv8/9/10 (yoloDetector.py:114-115,121-122) */
 #define ADAS_HEAD_V5 1 /* (A, 5+nc) row-major, conf = cls*obj in fp32: YOLOv5/6/7 (yoloDetector.py:123-124) */
+#define ADAS_HEAD_V5_LITE 2 /* V5 layout holding raw grid offsets: adds YoloLiteParameters.lite_postprocess (yoloDetector.py:35-49) */
 #define ADAS_NMS_REFERENCE 0 /* production call yoloDetector.py:139, bug-compatible (SURVEY finding 1) */
 #define ADAS_NMS_GREEDY 1    /* NMS.fast_nms, the commented alternative yoloDetector.py:138 */
 
 typedef struct {
-    int32_t layout;         /* ADAS_HEAD_V8 | ADAS_HEAD_V5 */
+    int32_t layout;         /* ADAS_HEAD_V8 | ADAS_HEAD_V5 | ADAS_HEAD_V5_LITE */
     int32_t num_anchors;    /* 8400 | 25200 */
     int32_t num_classes;    /* 80 */
     int32_t nms_mode;       /* ADAS_NMS_* */
@@ -123,6 +124,9 @@ int adas_letterbox_params(int src_h, int src_w, int dst_h, int dst_w, int keep_r
 
 int adas_yolo_post_create(const adas_yolo_post_params* p, int max_batch, adas_yolo_post** out);
 int adas_yolo_post_destroy(adas_yolo_post* h);
+/* Network input size (YoloLiteParameters.input_shape, yoloDetector.py:30): the v5-lite grid decode derives its three
+ * grids from it; required before the first run of an ADAS_HEAD_V5_LITE handle, ignored by the other layouts. */
+int adas_yolo_post_set_input_size(adas_yolo_post* h, int in_h, int in_w);
 /* d_head: batch head tensors back to back in the reference layout, fp32, in HBM. Asynchronous. */
 int adas_yolo_post_run(adas_yolo_post* h, const float* d_head, int batch, void* stream);
 

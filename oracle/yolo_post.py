@@ -38,9 +38,43 @@ def letterbox_params(src_hw, target_hw, keep_ratio=True):
 
 
 # --------------------------------------------------------------------------
+# yoloDetector.py:18-49  YoloLiteParameters.lite_postprocess (YOLOv5-lite heads)
+# --------------------------------------------------------------------------
+LITE_ANCHORS = np.asarray([[10, 13, 16, 30, 33, 23], [30, 61, 62, 45, 59, 119], [116, 90, 156, 198, 373, 326]],
+                          np.float32).reshape(3, 3, 2)                      # :23,29
+LITE_STRIDES = (8, 16, 32)                                                  # :28
+
+
+def lite_postprocess(outs, input_hw):
+    """Grid decode of a raw v5-lite head (A, 5+nc) float32 -> new array, fp32 arithmetic in the
+    reference's order.  Level i holds na=3 blocks of h*w rows; the reference's grid is
+    meshgrid(arange(h), arange(w)) flattened (:32-34 with the (w, h) call of :43), so cell n maps
+    to (n % h, n // h) -- the textbook (n % w, n // w) only when h == w."""
+    o = np.array(outs, dtype=np.float32, copy=True)
+    row = 0
+    two, half = np.float32(2.0), np.float32(0.5)
+    for i, stride in enumerate(LITE_STRIDES):
+        h, w = int(input_hw[0] / stride), int(input_hw[1] / stride)          # :40
+        cells = h * w
+        length = 3 * cells
+        n = np.arange(cells)
+        grid = np.stack([n % h, n // h], 1).astype(np.float32)             # :32-34
+        sl = slice(row, row + length)
+        blk = o[sl]
+        if blk.shape[0] != length:
+            raise ValueError("head has %d rows, level %d needs %d more" % (o.shape[0], i, length))
+        xy = ((blk[:, 0:2] * two - half) + np.tile(grid, (3, 1))) * np.float32(stride)          # :45-46
+        wh = ((blk[:, 2:4] * two) * (blk[:, 2:4] * two)) * np.repeat(LITE_ANCHORS[i], cells, axis=0)   # :47-48
+        o[sl, 0:2] = xy
+        o[sl, 2:4] = wh
+        row += length
+    return o
+
+
+# --------------------------------------------------------------------------
 # yoloDetector.py:104-133  __process_output
 # --------------------------------------------------------------------------
-def process_output(output, model_type="yolov8", box_score=0.4):
+def process_output(output, model_type="yolov8", box_score=0.4, input_hw=None):
     """output: the engine's tensor after squeeze(0): (4+nc, A) for v8-family,
     (A, 5+nc) for v5-family, float32.
 
@@ -53,6 +87,8 @@ def process_output(output, model_type="yolov8", box_score=0.4):
         probs = det[:, 4:]                            # :122
     else:
         det = out
+        if model_type == "yolov5_lite":
+            det = lite_postprocess(det, input_hw)         # :117
         probs = det[:, 5:] * det[:, 4:5]              # :124  fp32 product
     if det.shape[0] == 0:
         z = np.zeros((0,), np.int64)
@@ -181,9 +217,9 @@ def rect_infos(boxes_xywh, confs, class_ids, keep):
     return dict(xywh=b, conf=conf, class_id=cid, xyxy_int=xyxy_int)
 
 
-def detect_post(output, lb, model_type="yolov8", box_score=0.4, iou_thr=0.45, nms_mode="reference"):
+def detect_post(output, lb, model_type="yolov8", box_score=0.4, iou_thr=0.45, nms_mode="reference", input_hw=None):
     """Full chain of YoloDetector.DetectFrame after the engine (yoloDetector.py:164-168)."""
-    boxes, cls, conf, aidx = process_output(output, model_type, box_score)
+    boxes, cls, conf, aidx = process_output(output, model_type, box_score, input_hw)
     xywh = convert_boxes_coordinate(boxes, lb)
     if nms_mode == "reference":
         keep = fast_soft_nms(xywh, conf, iou_thr)

@@ -42,7 +42,7 @@ def _p(a):
     return a.ctypes.data_as(C.c_void_p)
 
 
-def yolo_post(head, layout, lb, box_score, iou, nms_mode=0, cap=1024):
+def yolo_post(head, layout, lb, box_score, iou, nms_mode=0, cap=1024, input_hw=(0, 0)):
     head = np.ascontiguousarray(head, np.float32)
     if layout == 0:
         nc, A = head.shape[0] - 4, head.shape[1]
@@ -55,7 +55,7 @@ def yolo_post(head, layout, lb, box_score, iou, nms_mode=0, cap=1024):
              det_xyxy_d=np.zeros((cap, 4)))
     lib().emu_yolo_post(_p(head), layout, A, nc, C.c_double(box_score), C.c_double(iou), nms_mode,
                         int(lb["pad"][0]), int(lb["pad"][1]), C.c_double(lb["ratio"][0]), C.c_double(lb["ratio"][1]),
-                        cap, _p(counts), *[_p(o[k]) for k in ("cand_anchor", "cand_xywh", "cand_conf", "cand_cls",
+                        cap, int(input_hw[0]), int(input_hw[1]), _p(counts), *[_p(o[k]) for k in ("cand_anchor", "cand_xywh", "cand_conf", "cand_cls",
                                                                "keep", "det_xywh", "det_conf", "det_cls",
                                                                "det_xyxy_i", "det_xyxy_d")])
     n, k = int(counts[1]), int(counts[2])

@@ -100,6 +100,33 @@ LBSQ = dict(target=(640, 640), old=(640, 640), new=(640, 640), pad=(0, 0))
 LBPORT = dict(target=(640, 640), old=(1280, 720), new=(640, 360), pad=(0, 140))
 
 
+def synth_lite_head(seed, input_hw=(640, 640), n_hot=60, nc=80):
+    """Raw YOLOv5-lite head (A, 5+nc): sigmoid-range xy/wh offsets (not yet grid-decoded), dyadic obj/cls."""
+    rng = np.random.default_rng(seed)
+    A = sum(3 * (input_hw[0] // s) * (input_hw[1] // s) for s in (8, 16, 32))
+    out = np.zeros((A, 5 + nc), np.float32)
+    out[:, 0:2] = rng.uniform(0.02, 0.98, (A, 2))
+    out[:, 2:4] = rng.uniform(0.05, 0.95, (A, 2))
+    q = 2048.0
+    out[:, 4] = np.round(rng.uniform(0, 0.3, A) * q) / q
+    out[:, 5:] = np.round(rng.uniform(0, 0.2, (A, nc)) * q) / q
+    hot = rng.choice(A, n_hot, replace=False)
+    hot[:6] = [0, A - 1, 3 * (input_hw[0] // 8) * (input_hw[1] // 8) - 1, 3 * (input_hw[0] // 8) * (input_hw[1] // 8),
+               (input_hw[0] // 8) * (input_hw[1] // 8), A - 3 * (input_hw[0] // 32) * (input_hw[1] // 32)]   # level / anchor seams
+    for a in hot:
+        out[a, 4] = np.round(rng.uniform(0.7, 1.0) * q) / q
+        out[a, 5 + rng.integers(nc)] = np.round(rng.uniform(0.6, 1.0) * q) / q
+    return out
+
+
+def lite_cases():
+    """(tag, head, input_hw, letterbox, box_score, iou); the 384x640 case exercises the reference's (n % h, n // h) grid."""
+    lb_wide = dict(target=(384, 640), old=(720, 1280), new=(217, 640), pad=(83, 0))
+    return [("lite_sq", synth_lite_head(21), (640, 640), LB720, 0.4, 0.45),
+            ("lite_sq2", synth_lite_head(22, (640, 640), 300), (640, 640), LBSQ, 0.4, 0.45),
+            ("lite_wide", synth_lite_head(23, (384, 640), 120), (384, 640), lb_wide, 0.4, 0.45)]
+
+
 def yolo_cases():
     """(tag, model_type, head, letterbox, box_score, iou)"""
     return [("v8_s1", "YOLOV8", synth_v8_head(1), LB720, 0.4, 0.45),

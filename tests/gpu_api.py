@@ -8,13 +8,13 @@ L = importlib.import_module("adas_amd._lib")
 PP = importlib.import_module("adas_amd.postproc")
 
 
-def yolo_post(head, layout, lb, box_score, iou, nms_mode=0, cap=1024, batch_copies=1):
+def yolo_post(head, layout, lb, box_score, iou, nms_mode=0, cap=1024, batch_copies=1, input_hw=None):
     head = np.ascontiguousarray(head, np.float32)
     if layout == 0:
         nc, A = head.shape[0] - 4, head.shape[1]
     else:
         A, nc = head.shape[0], head.shape[1] - 5
-    yp = PP.YoloPost(layout, A, nc, box_score, iou, lb, nms_mode, cap, max_batch=batch_copies)
+    yp = PP.YoloPost(layout, A, nc, box_score, iou, lb, nms_mode, cap, max_batch=batch_copies, input_hw=input_hw)
     try:
         res = yp.run_host(np.stack([head] * batch_copies))
     finally:

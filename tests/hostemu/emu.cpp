@@ -26,12 +26,12 @@ static void scan_host(const float* head, int layout, int A, int nc, float* conf,
 }
 
 int emu_yolo_post(const float* head, int layout, int A, int nc, double box_score, double iou, int nms_mode,
-                  int pad_h, int pad_w, double ratio_h, double ratio_w, int cap,
+                  int pad_h, int pad_w, double ratio_h, double ratio_w, int cap, int in_h, int in_w,
                   int* counts, int* cand_anchor, double* cand_xywh, double* cand_conf, int* cand_cls, int* keep,
                   double* det_xywh, double* det_conf, int* det_cls, int* det_xyxy_i, double* det_xyxy_d) {
     std::vector<float> conf(A); std::vector<int> cls(A);
     scan_host(head, layout, A, nc, conf.data(), cls.data());
-    YoloPostCfg cfg{layout, A, nc, box_score, iou, nms_mode, pad_h, pad_w, ratio_h, ratio_w, cap};
+    YoloPostCfg cfg{layout, A, nc, box_score, iou, nms_mode, pad_h, pad_w, ratio_h, ratio_w, cap, in_h, in_w};
     YoloPostFrame f{head, conf.data(), cls.data(), counts, cand_anchor, cand_xywh, cand_conf, cand_cls, keep,
                     det_xywh, det_conf, det_cls, det_xyxy_i, det_xyxy_d};
     std::vector<double> lds(YoloLds::bytes(cap, 1) / 8 + 2);

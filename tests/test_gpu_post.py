@@ -38,6 +38,37 @@ def test_yolo_post(G, case, mode):
         np.testing.assert_array_equal(got["xywh"], g[tag + "_rect_xywh"])
 
 
+@pytest.mark.parametrize("case", synth.lite_cases(), ids=lambda c: c[0])
+@pytest.mark.parametrize("mode", [0, 1])
+def test_yolo_lite_post(G, case, mode):
+    """YOLOv5-lite head (ADAS_HEAD_V5_LITE): grid decode + v5 chain on the device vs oracle and reference goldens."""
+    tag, head, hw, lb, bs, iou = case
+    lbp = yolo_post.letterbox_params(lb["old"], lb["target"])
+    glb = G.PP.letterbox(lb["old"], lb["target"])
+    assert glb["pad"] == lbp["pad"] and glb["ratio"] == lbp["ratio"]
+    want = yolo_post.detect_post(head, lbp, "yolov5_lite", bs, iou, "reference" if mode == 0 else "greedy", input_hw=hw)
+    got = G.yolo_post(head, 2, glb, bs, iou, mode, input_hw=hw)
+    assert got["rc"] == 0 and not got["overflow"]
+    pc.check_yolo(got, want)
+    if mode == 0:
+        g = np.load(os.path.join(GOLDEN, "yolo_lite.npz"))
+        np.testing.assert_array_equal(got["keep"], g[tag + "_keep"])
+        np.testing.assert_array_equal(got["xyxy_int"], g[tag + "_rect_xyxy_int"])
+        np.testing.assert_array_equal(got["cand_xywh"], g[tag + "_xywh"])
+
+
+def test_yolo_lite_requires_input_size(G):
+    lb = G.PP.letterbox((640, 640), (640, 640))
+    yp = G.PP.YoloPost(2, 25200, 80, 0.4, 0.45, lb)
+    try:
+        with pytest.raises(Exception, match="set_input_size"):
+            yp.run_host(np.zeros((1, 25200, 85), np.float32))
+    finally:
+        yp.close()
+    with pytest.raises(Exception, match="grid rows"):
+        G.PP.YoloPost(2, 1000, 80, 0.4, 0.45, lb, input_hw=(640, 640))
+
+
 def test_yolo_post_batched_frames(G):
     """Several frames per launch: every frame's block must give the single-frame result."""
     cases = synth.yolo_cases()[:4]

@@ -28,6 +28,23 @@ def test_yolo_post(case, mode):
         np.testing.assert_array_equal(got["xyxy_int"], g[tag + "_rect_xyxy_int"])
 
 
+@pytest.mark.parametrize("case", synth.lite_cases(), ids=lambda c: c[0])
+@pytest.mark.parametrize("mode", [0, 1])
+def test_yolo_lite_post(case, mode):
+    """v5-lite grid decode inside the candidate stage (layout 2) vs the oracle and the reference's own run."""
+    tag, head, hw, lb, bs, iou = case
+    lbp = yolo_post.letterbox_params(lb["old"], lb["target"])
+    want = yolo_post.detect_post(head, lbp, "yolov5_lite", bs, iou, "reference" if mode == 0 else "greedy", input_hw=hw)
+    got = emu_api.yolo_post(head, 2, lbp, bs, iou, mode, input_hw=hw)
+    assert not got["overflow"]
+    pc.check_yolo(got, want)
+    if mode == 0:
+        g = np.load(os.path.join(GOLDEN, "yolo_lite.npz"))
+        np.testing.assert_array_equal(got["keep"], g[tag + "_keep"])
+        np.testing.assert_array_equal(got["xyxy_int"], g[tag + "_rect_xyxy_int"])
+        np.testing.assert_array_equal(got["cand_xywh"], g[tag + "_xywh"])
+
+
 def test_yolo_post_generic_v5_product():
     """v5 conf = cls*obj rounded in fp32 (yoloDetector.py:124) on non-dyadic values."""
     rng = np.random.default_rng(5)

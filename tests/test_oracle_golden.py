@@ -54,6 +54,30 @@ def test_yolo_post_chain(case):
     np.testing.assert_array_equal(alt, g[tag + "_keep_alt"])
 
 
+@pytest.mark.parametrize("case", synth.lite_cases(), ids=lambda c: c[0])
+def test_yolo_lite_chain(case):
+    """YOLOv5-lite: grid decode (yoloDetector.py:35-49) + the v5 chain, against the reference's own run."""
+    tag, head, hw, lb, bs, iou = case
+    g = np.load(os.path.join(GOLDEN, "yolo_lite.npz"))
+    assert synth.digest(head) == str(g[tag + "_head_sha1"]), "synthetic input drifted from the golden's"
+    dec = yolo_post.lite_postprocess(head, hw)
+    np.testing.assert_array_equal(dec[::50, :4], g[tag + "_decoded_every50"])
+    assert synth.digest(dec[:, :4].copy()) == str(g[tag + "_decoded_sha1"])
+    np.testing.assert_array_equal(dec[:, 4:], head[:, 4:])
+    lbp = yolo_post.letterbox_params(lb["old"], lb["target"])
+    assert lbp["new"] == tuple(lb["new"]) and lbp["pad"] == tuple(lb["pad"])
+    r = yolo_post.detect_post(head, lbp, "yolov5_lite", bs, iou, input_hw=hw)
+    boxes, cls, conf, _ = yolo_post.process_output(head, "yolov5_lite", bs, hw)
+    np.testing.assert_array_equal(boxes, g[tag + "_raw_boxes"])
+    np.testing.assert_array_equal(cls, g[tag + "_cls"])
+    np.testing.assert_array_equal(conf, g[tag + "_conf"])
+    np.testing.assert_array_equal(r["cand_xywh"], g[tag + "_xywh"])
+    np.testing.assert_array_equal(r["keep"], g[tag + "_keep"])
+    np.testing.assert_array_equal(r["xywh"], g[tag + "_rect_xywh"])
+    np.testing.assert_array_equal(r["xyxy_int"], g[tag + "_rect_xyxy_int"])
+    np.testing.assert_array_equal(yolo_post.fast_nms(r["cand_xywh"], r["cand_conf"], iou), g[tag + "_keep_alt"])
+
+
 @pytest.mark.parametrize("case", synth.ufld_cases(), ids=lambda c: c[0])
 def test_ufld_decode(case):
     tag, outs, W, H = case

@@ -12,7 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libadas_hip.so")
 
 UFLD_MAX_POINTS = 128
-HEAD_V8, HEAD_V5 = 0, 1
+HEAD_V8, HEAD_V5, HEAD_V5_LITE = 0, 1, 2
 NMS_REFERENCE, NMS_GREEDY = 0, 1
 PREC_BF16, PREC_FP32 = 0, 1
 
@@ -87,6 +87,7 @@ _SIGS = {
     "adas_letterbox_params": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(YoloPostParams)]),
     "adas_yolo_post_create": (C.c_int, [C.POINTER(YoloPostParams), C.c_int, C.POINTER(_P)]),
     "adas_yolo_post_destroy": (C.c_int, [_P]),
+    "adas_yolo_post_set_input_size": (C.c_int, [_P, C.c_int, C.c_int]),
     "adas_yolo_post_run": (C.c_int, [_P, _P, C.c_int, _P]),
     "adas_yolo_post_fetch": (C.c_int, [_P, C.c_int, C.POINTER(YoloCounts)] + [_P] * 9),
     "adas_yolo_post_device_views": (C.c_int, [_P] + [C.POINTER(_P)] * 4),

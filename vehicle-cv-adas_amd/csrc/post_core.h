@@ -98,14 +98,39 @@ ADAS_DEV void block_argmax_first(const Ctx& c, const double* a, int lo, int hi, 
 // utils.py:161-256 / 105-159, yoloDetector.py:135-157 + core.py:18-23
 // ===========================================================================
 struct YoloPostCfg {
-    int layout;  // 0: v8-family head [4+nc][A];  1: v5-family head [A][5+nc]
+    int layout;  // 0: v8-family head [4+nc][A];  1: v5-family head [A][5+nc];  2: v5-lite (layout 1 + grid decode)
     int A, nc;
     double box_score, iou_thr;
     int nms_mode;  // 0: reference (fast_soft_nms as called in production); 1: greedy (fast_nms)
     int pad_h, pad_w;
     double ratio_h, ratio_w;
     int cap;  // candidate capacity per frame
+    int in_h, in_w;  // network input size; only the v5-lite grid decode reads it
 };
+
+// YoloLiteParameters.lite_postprocess (yoloDetector.py:35-49) for one head row: three levels (stride 8/16/32) of
+// na = 3 anchors x (h*w) cells, fp32 arithmetic in the reference's operation order.  The reference builds its grid as
+// meshgrid(arange(h), arange(w)) flattened, i.e. cell n -> (n % h, n / h); that equals the usual (n % w, n / w) only
+// for square inputs and is reproduced as is.  Rows past the three levels are left untouched, as there.
+ADAS_DEV void yolo_lite_decode(int in_h, int in_w, int row, float& x, float& y, float& w, float& h) {
+    const float anchors[3][6] = {{10, 13, 16, 30, 33, 23}, {30, 61, 62, 45, 59, 119}, {116, 90, 156, 198, 373, 326}};
+    for (int i = 0; i < 3; ++i) {
+        const int stride = 8 << i;
+        const int gh = in_h / stride, gw = in_w / stride, cells = gh * gw;
+        if (row < 3 * cells) {
+            const int ai = row / cells, n = row % cells;
+            const float gx = (float)(n % gh), gy = (float)(n / gh);
+            const float fs = (float)stride;
+            x = ((x * 2.f - 0.5f) + gx) * fs;
+            y = ((y * 2.f - 0.5f) + gy) * fs;
+            const float w2 = w * 2.f, h2 = h * 2.f;
+            w = (w2 * w2) * anchors[i][2 * ai];
+            h = (h2 * h2) * anchors[i][2 * ai + 1];
+            return;
+        }
+        row -= 3 * cells;
+    }
+}
 
 // counts[]: 0 = candidates found (uncapped), 1 = candidates stored, 2 = survivors, 3 = flags (bit0 overflow)
 struct YoloPostFrame {
@@ -208,10 +233,12 @@ ADAS_DEV void yolo_post_frame(const Ctx& c, const YoloPostCfg& cfg, const YoloPo
             h = (double)f.head[(size_t)3 * A + a];
         } else {
             const float* r = f.head + (size_t)a * (5 + cfg.nc);
-            x = (double)r[0];
-            y = (double)r[1];
-            w = (double)r[2];
-            h = (double)r[3];
+            float xf = r[0], yf = r[1], wf = r[2], hf = r[3];
+            if (cfg.layout == 2) yolo_lite_decode(cfg.in_h, cfg.in_w, a, xf, yf, wf, hf);
+            x = (double)xf;
+            y = (double)yf;
+            w = (double)wf;
+            h = (double)hf;
         }
         double hw = 0.5 * w, hh = 0.5 * h;
         double x1 = x - hw, y1 = y - hh, x2 = x + hw, y2 = y + hh;

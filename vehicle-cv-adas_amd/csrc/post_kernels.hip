@@ -288,7 +288,8 @@ int adas_letterbox_params(int src_h, int src_w, int dst_h, int dst_w, int keep_r
 
 int adas_yolo_post_create(const adas_yolo_post_params* p, int max_batch, adas_yolo_post** out) {
     ADAS_REQUIRE(p && out && max_batch > 0, ADAS_ERR_INVALID, "adas_yolo_post_create: bad argument");
-    ADAS_REQUIRE(p->layout == ADAS_HEAD_V8 || p->layout == ADAS_HEAD_V5, ADAS_ERR_INVALID, "unknown head layout %d", p->layout);
+    ADAS_REQUIRE(p->layout == ADAS_HEAD_V8 || p->layout == ADAS_HEAD_V5 || p->layout == ADAS_HEAD_V5_LITE, ADAS_ERR_INVALID,
+                 "unknown head layout %d", p->layout);
     ADAS_REQUIRE(p->nms_mode == ADAS_NMS_REFERENCE || p->nms_mode == ADAS_NMS_GREEDY, ADAS_ERR_INVALID, "unknown nms mode %d", p->nms_mode);
     ADAS_REQUIRE(p->num_anchors > 0 && p->num_classes > 0, ADAS_ERR_INVALID, "bad head geometry");
     ADAS_REQUIRE(p->box_score >= 0.0, ADAS_ERR_INVALID, "box_score must be >= 0");
@@ -309,7 +310,7 @@ int adas_yolo_post_create(const adas_yolo_post_params* p, int max_batch, adas_yo
     unsigned char* q = (unsigned char*)h->arena;
     YoloPostDev& d = h->dev;
     d.cfg = YoloPostCfg{p->layout, p->num_anchors, p->num_classes, p->box_score, p->iou_thr, p->nms_mode,
-                        p->pad_h, p->pad_w, p->ratio_h, p->ratio_w, p->max_candidates};
+                        p->pad_h, p->pad_w, p->ratio_h, p->ratio_w, p->max_candidates, 0, 0};
     d.head = nullptr;
     d.head_stride = p->layout == ADAS_HEAD_V8 ? (size_t)(4 + p->num_classes) * A : (size_t)(5 + p->num_classes) * A;
     d.best_conf = carve<float>(q, B * A);
@@ -342,8 +343,23 @@ int adas_yolo_post_destroy(adas_yolo_post* h) {
     return ADAS_OK;
 }
 
+int adas_yolo_post_set_input_size(adas_yolo_post* h, int in_h, int in_w) {
+    ADAS_REQUIRE(h && in_h >= 32 && in_w >= 32, ADAS_ERR_INVALID, "adas_yolo_post_set_input_size: bad argument");
+    if (h->p.layout == ADAS_HEAD_V5_LITE) {
+        long rows = 0;
+        for (int i = 0; i < 3; ++i) rows += 3L * (in_h / (8 << i)) * (in_w / (8 << i));
+        ADAS_REQUIRE(rows <= h->p.num_anchors, ADAS_ERR_INVALID, "a %dx%d input has %ld grid rows but the head has only %d", in_h, in_w,
+                     rows, h->p.num_anchors);
+    }
+    h->dev.cfg.in_h = in_h;
+    h->dev.cfg.in_w = in_w;
+    return ADAS_OK;
+}
+
 int adas_yolo_post_run(adas_yolo_post* h, const float* d_head, int batch, void* stream) {
     ADAS_REQUIRE(h && d_head && batch > 0 && batch <= h->max_batch, ADAS_ERR_INVALID, "adas_yolo_post_run: bad argument (batch %d, max %d)", batch, h ? h->max_batch : 0);
+    ADAS_REQUIRE(h->p.layout != ADAS_HEAD_V5_LITE || h->dev.cfg.in_h > 0, ADAS_ERR_INVALID,
+                 "v5-lite head: call adas_yolo_post_set_input_size first");
     hipStream_t st = (hipStream_t)stream;
     h->last = st;
     YoloPostDev d = h->dev;

@@ -145,7 +145,7 @@ class YoloDetector(_Defaults):
         self.nms_mode = L.NMS_REFERENCE          # the production call (yoloDetector.py:139); NMS_GREEDY = fast_nms (:138)
         self.max_candidates = 1024
         self.__dict__.update(kwargs)
-        if self.model_type in (ObjectModelType.YOLOV5_LITE, ObjectModelType.EfficientDet):
+        if self.model_type == ObjectModelType.EfficientDet:
             raise Exception("%s heads are not implemented by HipEngine (SURVEY.md 8f row f4)" % self.model_type.name)
         self._initialize_class(self.classes_path)
         self._initialize_model(self.model_path)
@@ -183,8 +183,10 @@ class YoloDetector(_Defaults):
             A, no = (shp[2], shp[1]) if v8 else (shp[1], shp[2])
             nc = no - 4 if v8 else no - 5
             lb = letterbox(key, self.input_shapes[-2:])
-            self._post = YoloPost(L.HEAD_V8 if v8 else L.HEAD_V5, A, nc, float(self.box_score), float(self.box_nms_iou), lb,
-                                  self.nms_mode, self.max_candidates, 1)
+            lite = self.model_type == ObjectModelType.YOLOV5_LITE      # yoloDetector.py:21-22,116
+            layout = L.HEAD_V8 if v8 else (L.HEAD_V5_LITE if lite else L.HEAD_V5)
+            self._post = YoloPost(layout, A, nc, float(self.box_score), float(self.box_nms_iou), lb, self.nms_mode,
+                                  self.max_candidates, 1, input_hw=tuple(self.input_shapes[-2:]) if lite else None)
             self._post_key = key
         return self._post
 

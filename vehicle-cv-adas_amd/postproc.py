@@ -22,13 +22,20 @@ def letterbox(src_hw, dst_hw, keep_ratio=True):
 
 class YoloPost:
     def __init__(self, layout, num_anchors, num_classes, box_score, iou_thr, lb, nms_mode=L.NMS_REFERENCE,
-                 max_candidates=1024, max_batch=1):
+                 max_candidates=1024, max_batch=1, input_hw=None):
+        """input_hw: network input size; required for HEAD_V5_LITE (the grid decode of yoloDetector.py:35-49)."""
         p = L.YoloPostParams(layout, num_anchors, num_classes, nms_mode, box_score, iou_thr, int(lb["pad"][0]),
                              int(lb["pad"][1]), float(lb["ratio"][0]), float(lb["ratio"][1]), max_candidates, 0)
         self.params, self.max_batch, self.cap = p, max_batch, max_candidates
         h = C.c_void_p()
         L.check(L.lib().adas_yolo_post_create(C.byref(p), max_batch, C.byref(h)))
         self.h = h.value
+        if input_hw is not None:
+            try:
+                L.check(L.lib().adas_yolo_post_set_input_size(self.h, int(input_hw[0]), int(input_hw[1])))
+            except Exception:
+                self.close()
+                raise
         self.head_elems = (4 + num_classes) * num_anchors if layout == L.HEAD_V8 else (5 + num_classes) * num_anchors
 
     def run_device(self, d_head_ptr, batch=1, stream=None):
