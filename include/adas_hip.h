@@ -176,6 +176,22 @@ int adas_ufld_decode_run(adas_ufld_decode* h, const float* d_loc_row, const floa
  * points: [4][ADAS_UFLD_MAX_POINTS][2] (x,y) int32; counts[4]; detected[4]. */
 int adas_ufld_decode_fetch(adas_ufld_decode* h, int frame, int32_t* points, int32_t* counts, int32_t* detected);
 
+/* -----------------------------------------------------------------------------------
+ * UFLD (v1) lane decode: replaces UltrafastLaneDetector.__process_output (ultrafastLaneDetector.py:96-139,
+ * ModelConfig :16-40).  One (1, griding_num+1, cls_num_per_lane, 4) tensor per frame; the handle type, fetch and
+ * destroy are shared with the v2 decoder (lane index = the tensor's lane axis, points in the reference's order).
+ * ----------------------------------------------------------------------------------- */
+typedef struct {
+    int32_t griding_num, cls_num_per_lane; /* 100,56 (Tusimple) | 200,18 (CULane) */
+    int32_t cfg_img_w, cfg_img_h;          /* ModelConfig.img_w/img_h: 1280x720 | 1640x590 */
+    int32_t input_w, input_h;              /* network input, 800x288 */
+    int32_t src_w, src_h;                  /* source frame size: w_ratio/h_ratio of ultrafastLaneDetector.py:80 */
+    const double* h_row_anchor;            /* [cls_num_per_lane] cfg.row_anchor (host) */
+} adas_ufld1_params;
+int adas_ufld1_decode_create(const adas_ufld1_params* p, int max_batch, adas_ufld_decode** out);
+int adas_ufld1_decode_set_source_size(adas_ufld_decode* h, int src_w, int src_h);
+int adas_ufld1_decode_run(adas_ufld_decode* h, const float* d_out, size_t batch_stride, int batch, void* stream);
+
 /* ===================================================================================
  * ByteTrack: replaces BYTETracker.__init__/update/reset (byteTracker.py:30-51,62-185,187-200)
  * with matching.py, kalman_filter.py, strack.py, base_track.py, byteTrack/utils.py underneath.

@@ -207,3 +207,29 @@ def ufldv2_forward(x, W, backbone="18", num_grid_row=200, num_cls_row=72, num_gr
                 out[:, d1:d1 + d2].reshape(N, num_grid_col, num_cls_col, num_lanes).numpy(),
                 out[:, d1 + d2:d1 + d2 + d3].reshape(N, 2, num_cls_row, num_lanes).numpy(),
                 out[:, -d4:].reshape(N, 2, num_cls_col, num_lanes).numpy()]
+
+
+def ufld_v1_forward(x, W, backbone="18", griding_num=100, cls_num_per_lane=56, num_lanes=4):
+    """UFLD (v1) parsingNet (upstream Ultra-Fast-Lane-Detection model/model.py, not vendored): ResNet trunk, `pool` 1x1
+    conv to 8 channels, (C,H,W) flatten, Linear-ReLU-Linear, view (N, G+1, K, L) -- the tensor
+    ultrafastLaneDetector.py:99-109 consumes."""
+    x = torch.as_tensor(x, dtype=torch.float32)
+    with torch.no_grad():
+        x = _conv(x, W, "model.conv1", 2, 3, "relu")
+        x = F.max_pool2d(x, 3, 2, 1)
+        cin = 64
+        for li, (planes, nblk) in enumerate(zip([64, 128, 256, 512], RESNET_DEPTHS[backbone])):
+            for bi in range(nblk):
+                s = 2 if (li > 0 and bi == 0) else 1
+                name = f"model.layer{li + 1}.{bi}"
+                idt = x
+                if s != 1 or cin != planes:
+                    idt = _conv(x, W, f"{name}.downsample.0", s, 0, None)
+                t = _conv(x, W, f"{name}.conv1", s, 1, "relu")
+                x = F.relu(_conv(t, W, f"{name}.conv2", 1, 1, None) + idt)
+                cin = planes
+        fea = _conv(x, W, "pool", 1, 0, None)
+        fea = fea.reshape(fea.shape[0], -1)
+        h = F.relu(F.linear(fea, _t(W, "cls.0.weight"), _t(W, "cls.0.bias")))
+        out = F.linear(h, _t(W, "cls.2.weight"), _t(W, "cls.2.bias"))
+        return out.reshape(out.shape[0], griding_num + 1, cls_num_per_lane, num_lanes).numpy()

@@ -5,6 +5,7 @@ TEST INFRASTRUCTURE (see oracle/__init__.py).  NumPy restatement of
   .../ultrafastLaneDetectorV2.py:21-55                                (ModelConfig)
   .../ultrafastLaneDetectorV2.py:114-181                              (__process_output)
   TrafficLaneDetector/ufldDetector/core.py:102-158                    (status / area / polyfit adjust)
+  .../ultrafastLaneDetector.py:16-40, 96-139                          (UFLD v1: ModelConfig, __process_output)
 """
 import numpy as np
 
@@ -125,3 +126,53 @@ def lanes_area(lanes_points, lanes_status, img_height, adjust=True):
             l, r = lanes_points[index - 1], lanes_points[index]
         area = np.vstack((l, np.flipud(r)))
     return status, area
+
+
+# ------------------------------------------------------------------------------------------------
+# UFLD (v1)
+# ------------------------------------------------------------------------------------------------
+class ModelConfigV1:
+    """ultrafastLaneDetector.py:16-40"""
+
+    def __init__(self, name="tusimple"):
+        if name == "tusimple":
+            self.img_w, self.img_h, self.griding_num, self.cls_num_per_lane = 1280, 720, 100, 56
+            self.row_anchor = np.linspace(64, 284, 56)
+        elif name == "culane":
+            self.img_w, self.img_h, self.griding_num, self.cls_num_per_lane = 1640, 590, 200, 18
+            self.row_anchor = [round(v) for v in np.linspace(121, 287, 18)]
+        else:
+            raise ValueError(name)
+        self.num_lanes = 4
+
+
+def process_output_v1(output, cfg, input_w, input_h, src_w, src_h):
+    """output: the engine's single tensor (1, G+1, K, L) fp32.  Returns (lanes: L lists of (x, y) ints, detected: L bools).
+
+    :101-109  flip the anchor axis; softmax over the G real cells in fp32 (scipy.special.softmax = exp(x - max) / sum);
+              location = sum(prob * (1..G)) in fp64; rows whose argmax over all G+1 cells is the last ("no lane") -> 0
+    :113-139  a lane is detected when more than 2 anchors are non-zero; points in flipped-anchor order."""
+    G, K = cfg.griding_num, cfg.cls_num_per_lane
+    raw = np.asarray(output, np.float32).reshape(G + 1, K, -1)[:, ::-1, :]
+    z = raw[:G]
+    e = np.exp(z - z.max(axis=0, keepdims=True))
+    prob = e / e.sum(axis=0, keepdims=True)
+    loc = (prob * np.arange(1, G + 1).reshape(-1, 1, 1)).sum(axis=0)
+    loc[raw.argmax(axis=0) == G] = 0
+    step = np.linspace(0, input_w - 1, G)
+    col_w = step[1] - step[0]
+    w_ratio, h_ratio = src_w / cfg.img_w, src_h / cfg.img_h              # :80
+    lanes, detected = [], []
+    for lane in range(loc.shape[1]):
+        pts = []
+        ok = int((loc[:, lane] != 0).sum()) > 2
+        if ok:
+            for k in range(K):
+                v = loc[k, lane]
+                if v > 0:
+                    x = v * col_w * cfg.img_w / input_w - 1
+                    y = cfg.img_h * (cfg.row_anchor[K - 1 - k] / input_h) - 1
+                    pts.append((int(x * w_ratio), int(y * h_ratio)))
+        lanes.append(pts)
+        detected.append(ok)
+    return lanes, detected

@@ -74,6 +74,15 @@ def ufld(outs, cfg, W, H, lw=1):
     return [[(int(x), int(y)) for x, y in pts[i, :cnt[i]]] for i in range(4)], [bool(d) for d in det]
 
 
+def ufld1(head, cfg, input_wh, src_wh):
+    out = np.ascontiguousarray(head, np.float32)
+    cnt = np.zeros(4, np.int32); det = np.zeros(4, np.int32); pts = np.zeros((4, 128, 2), np.int32)
+    ra = np.ascontiguousarray(cfg.row_anchor, np.float64)
+    lib().emu_ufld1(_p(out), cfg.griding_num, cfg.cls_num_per_lane, cfg.img_w, cfg.img_h, input_wh[0], input_wh[1],
+                    src_wh[0], src_wh[1], _p(ra), _p(cnt), _p(det), _p(pts))
+    return [[(int(x), int(y)) for x, y in pts[i, :cnt[i]]] for i in range(4)], [bool(d) for d in det]
+
+
 class Tracker:
     def __init__(self, track_thresh=0.5, match_thresh=0.8, track_buffer=30, frame_rate=30, MT=256, MD=256):
         self.h = lib().emu_bt_create(track_thresh, match_thresh, track_buffer, frame_rate, MT, MD)

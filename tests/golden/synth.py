@@ -127,6 +127,31 @@ def lite_cases():
             ("lite_wide", synth_lite_head(23, (384, 640), 120), (384, 640), lb_wide, 0.4, 0.45)]
 
 
+def synth_ufld1(seed, G=100, K=56, spans=((0, 56), (10, 40), (20, 22), (0, 0))):
+    """UFLD v1 head (1, G+1, K, 4): lane l has a softmax bump drifting across the grid on anchors [spans[l]) and votes
+    "no lane" (cell G) elsewhere; the third default lane has only two points (not detected, ultrafastLaneDetector.py:123)."""
+    rng = np.random.default_rng(seed)
+    out = rng.normal(0, 0.6, (1, G + 1, K, 4)).astype(np.float32)
+    g = np.arange(G, dtype=np.float64)
+    for l, (a, b) in enumerate(spans):
+        for k in range(K):
+            if a <= k < b:
+                c = (0.15 + 0.2 * l + 0.5 * (k - a) / max(1, b - a)) * G + rng.normal(0, 0.4)
+                out[0, :G, k, l] += (9.0 * np.exp(-0.5 * ((g - c) / 1.3) ** 2)).astype(np.float32)
+                out[0, G, k, l] -= 2.0
+            else:
+                out[0, G, k, l] += 7.0
+    return out
+
+
+def ufld1_cases():
+    """(tag, config name, head, input (w, h), source (w, h))"""
+    return [("u1_tu", "tusimple", synth_ufld1(31), (800, 288), (1280, 720)),
+            ("u1_tu_hd", "tusimple", synth_ufld1(32, spans=((3, 50), (0, 56), (0, 3), (30, 56))), (800, 288), (1920, 1080)),
+            ("u1_cu", "culane", synth_ufld1(33, 200, 18, ((0, 18), (2, 15), (5, 7), (0, 0))), (800, 288), (1640, 590)),
+            ("u1_none", "tusimple", synth_ufld1(34, spans=((0, 0), (0, 0), (0, 2), (0, 1))), (800, 288), (1280, 720))]
+
+
 def yolo_cases():
     """(tag, model_type, head, letterbox, box_score, iou)"""
     return [("v8_s1", "YOLOV8", synth_v8_head(1), LB720, 0.4, 0.45),

@@ -31,6 +31,15 @@ def ufld(outs, cfg, W, H, lw=1):
         ud.close()
 
 
+def ufld1(head, cfg, input_wh, src_wh):
+    ud = PP.Ufld1Decode(cfg.griding_num, cfg.cls_num_per_lane, cfg.img_w, cfg.img_h, input_wh[0], input_wh[1], src_wh[0], src_wh[1],
+                        cfg.row_anchor)
+    try:
+        return ud.run_host(np.asarray(head, np.float32).reshape(1, cfg.griding_num + 1, cfg.cls_num_per_lane, 4))[0]
+    finally:
+        ud.close()
+
+
 def track_snapshot(hdr, tracked, lost):
     def rec(r):
         return dict(track_id=int(r["track_id"]), state=int(r["state"]), is_activated=bool(r["is_activated"]),

@@ -51,6 +51,15 @@ int emu_ufld(const float* loc_row, const float* loc_col, const float* exist_row,
     return 0;
 }
 
+int emu_ufld1(const float* out, int G, int K, int cfg_w, int cfg_h, int in_w, int in_h, int src_w, int src_h,
+              const double* row_anchor, int* lane_cnt, int* lane_det, int* lane_pts) {
+    Ufld1Cfg cfg{G, K, 4, cfg_w, cfg_h, in_w, in_h, src_w, src_h, row_anchor};
+    std::vector<double> lds((size_t)K * 4 + 16);
+    Ctx c{0, 1};
+    ufld1_decode_frame(c, cfg, out, lane_cnt, lane_det, lane_pts, lds.data());
+    return 0;
+}
+
 struct EmuBt { BtParams P; BtStream S; std::vector<char> mem; std::vector<double> lds; };
 
 void* emu_bt_create(double track_thresh, double match_thresh, int track_buffer, double frame_rate, int MT, int MD) {

@@ -96,6 +96,29 @@ def test_lane_detector_dropin():
     ld.close(); eng.close()
 
 
+def test_lane_detector_v1_dropin():
+    """UltrafastLaneDetector (UFLD v1): device pre-processing (plain resize, crop_ratio 1) + network + v1 decode vs the
+    oracle chain on the same engine's logits; two source sizes so w_ratio/h_ratio (ultrafastLaneDetector.py:80) change."""
+    path, W, g = netutil.model("ufld_v1_res18")
+    ld = D.UltrafastLaneDetector(path, D.LaneModelType.UFLD_TUSIMPLE, precision="fp32")
+    eng = CE.OnnxEngine(path, precision="fp32")
+    cfg = ufld_decode.ModelConfigV1("tusimple")
+    n_pts = 0
+    for (h, w) in ((720, 1280), (1080, 1920)):
+        for f in frames(1, h, w, 13):
+            ld.DetectFrame(f)
+            out = eng.engine_inference(preprocess.ufld_prepare_input(f, (288, 800), 1.0))
+            wl, ws = ufld_decode.process_output_v1(out[0], cfg, 800, 288, w, h)
+            pc.check_lanes(list(ld.lane_info.lanes_points), ld.lane_info.lanes_status, wl, ws, tol_px=1)
+            st, area = ufld_decode.lanes_area(wl, ws, h, True)
+            assert ld.lane_info.area_status == st
+            n_pts += sum(len(l) for l in wl)
+    assert n_pts > 50
+    with pytest.raises(Exception, match="can't use"):
+        D.UltrafastLaneDetector(path, D.LaneModelType.UFLDV2_CULANE)
+    ld.close(); eng.close()
+
+
 def test_bytetracker_dropin_with_label_strings():
     """demo.py:273-277 call shape: int xyxy boxes, float confs, label strings, frame."""
     rng = np.random.default_rng(11)

@@ -159,3 +159,23 @@ def test_ufldv2_tusimple_variant_vs_oracle(CE, prec):
         else:
             assert rel_l2(o, w) <= 6e-2
     e.close()
+
+
+@pytest.mark.parametrize("name,prec,G,K", [("ufld_v1_res18", "fp32", 100, 56), ("ufld_v1_res18", "bf16", 100, 56),
+                                           ("ufld_v1_culane_res18", "fp32", 200, 18)])
+def test_ufld_v1_vs_oracle(CE, name, prec, G, K):
+    """UFLD v1 network (800x288 -> one (1, G+1, K, 4) tensor, ultrafastLaneDetector.py:73-75,99) vs the torch fp32 restatement."""
+    path, W, g = netutil.model(name)
+    assert g.in_h == 288 and g.in_w == 800
+    x = netutil.lane_frames(2, 288, 800)
+    want = nets.ufld_v1_forward(x, W, "18", G, K)
+    e = CE.HipEngine(path, precision=prec, max_batch=2)
+    shapes, names = e.get_engine_output_shape()
+    assert shapes == [[1, G + 1, K, 4]] and len(names) == 1
+    got = e.engine_inference(x)[0]
+    print(name, prec, "max|diff| %.3e rel %.3e" % (np.abs(got - want).max(), rel_l2(got, want)))
+    if prec == "fp32":
+        assert np.abs(got - want).max() <= 1e-3
+    else:
+        assert rel_l2(got, want) <= 6e-2
+    e.close()

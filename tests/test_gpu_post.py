@@ -139,6 +139,24 @@ def test_ufld(G, case):
         assert len(got_l[li]) == len(g[f"{tag}_lane{li}"])
 
 
+@pytest.mark.parametrize("case", synth.ufld1_cases(), ids=lambda c: c[0])
+def test_ufld_v1(G, case):
+    """UFLD v1 decoder (adas_ufld1_decode_*) vs the oracle and the reference's own output; +-1 px for the fp32 exp."""
+    tag, cfgname, head, iwh, swh = case
+    cfg = ufld_decode.ModelConfigV1(cfgname)
+    want_l, want_s = ufld_decode.process_output_v1(head, cfg, iwh[0], iwh[1], swh[0], swh[1])
+    got_l, got_s = G.ufld1(head, cfg, iwh, swh)
+    n_off = pc.check_lanes(got_l, got_s, want_l, want_s, tol_px=1)
+    assert n_off <= 2
+    g = np.load(os.path.join(GOLDEN, "ufld1_decode.npz"))
+    assert got_s == g[tag + "_status"].tolist()
+    for li in range(4):
+        ref = g[f"{tag}_lane{li}"]
+        assert len(got_l[li]) == len(ref)
+        if len(ref):
+            assert np.abs(np.asarray(got_l[li], np.int64) - ref).max() <= 1
+
+
 @pytest.mark.parametrize("tag", ["t1", "t2", "t3", "t4", "t5", "t6", "t7"])
 def test_bytetrack_goldens(G, tag):
     with gzip.open(os.path.join(GOLDEN, "bytetrack.json.gz"), "rt") as f:

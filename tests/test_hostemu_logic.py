@@ -90,6 +90,17 @@ def test_ufld(case):
     pc.check_lanes(got_l, got_s, want_l, want_s, tol_px=0)
 
 
+@pytest.mark.parametrize("case", synth.ufld1_cases(), ids=lambda c: c[0])
+def test_ufld_v1(case):
+    """UFLD v1 decode logic (host build; exp in libm double then rounded, NumPy's is fp32 SIMD): +-1 px."""
+    tag, cfgname, head, iwh, swh = case
+    cfg = ufld_decode.ModelConfigV1(cfgname)
+    want_l, want_s = ufld_decode.process_output_v1(head, cfg, iwh[0], iwh[1], swh[0], swh[1])
+    got_l, got_s = emu_api.ufld1(head, cfg, iwh, swh)
+    n_off = pc.check_lanes(got_l, got_s, want_l, want_s, tol_px=1)
+    assert n_off <= 2
+
+
 @pytest.mark.parametrize("tag", ["t1", "t2", "t3", "t4", "t5", "t6", "t7"])
 def test_bytetrack(tag):
     with gzip.open(os.path.join(GOLDEN, "bytetrack.json.gz"), "rt") as f:

@@ -173,3 +173,24 @@ def test_ufldv2_tusimple_detected_without_layernorm(tmp_path):
     assert arch == "ufldv2_res18" and got_kw["fc_norm"] is False
     out, g2 = OI.convert(str(p), str(tmp_path / "t.hipm"))
     assert g2.tobytes() == M.build("ufldv2_res18", wsrc=M.DictWeights(W), **kw).tobytes()
+
+
+def test_ufld_v1_single_output_detected(tmp_path):
+    """UFLD v1 export (tusimple_18.onnx style): ResNet stem, one (1, G+1, K, 4) output, Linear layers cls.0 / cls.2 as Gemm."""
+    kw = dict(in_h=96, in_w=160, griding_num=20, cls_num_per_lane=8)
+    W, g = synth("ufld_v1_res18", **kw)
+    inits, nodes = [], []
+    for i, base in enumerate(torch_conv_order()):
+        wn, bn = ("onnx::Conv_%d" % (300 + 2 * i), "onnx::Conv_%d" % (301 + 2 * i)) if base != "pool" else ("pool.weight", "pool.bias")
+        inits += [OW.tensor(wn, W[base + ".weight"]), OW.tensor(bn, W[base + ".bias"])]
+        nodes.append(conv_node(i, wn, bn, "t%d" % i, "t%d" % (i + 1)))
+    for nm in ("cls.0.weight", "cls.0.bias", "cls.2.weight", "cls.2.bias"):
+        inits.append(OW.tensor(nm, W[nm]))
+    nodes.append(OW.node("Gemm", ["f", "cls.0.weight", "cls.0.bias"], ["h"], "Gemm_0", [OW.attr_int("transB", 1)]))
+    nodes.append(OW.node("Gemm", ["h", "cls.2.weight", "cls.2.bias"], ["o"], "Gemm_1", [OW.attr_int("transB", 1)]))
+    p = tmp_path / "tusimple_18.onnx"
+    p.write_bytes(OW.model(nodes, inits, [("input", [1, 3, 96, 160])], [("output", [1, 21, 8, 4])]))
+    arch, got = OI.detect_arch(OI.read_onnx(str(p)))
+    assert arch == "ufld_v1_res18" and got == dict(in_h=96, in_w=160, griding_num=20, cls_num_per_lane=8, num_lanes=4)
+    out, g2 = OI.convert(str(p), str(tmp_path / "u1.hipm"))
+    assert g2.tobytes() == M.build("ufld_v1_res18", wsrc=M.DictWeights(W), **kw).tobytes()

@@ -119,3 +119,16 @@ def test_bytetrack_trace(tag):
         assert [t["track_id"] for t in tr[0]["tracked"]] == [1, 2, 3]
         assert tr[3]["lost"][0]["track_id"] == 3 and tr[4]["count"] == 3
         assert 3 in [t["track_id"] for t in tr[4]["tracked"]]
+
+
+@pytest.mark.parametrize("case", synth.ufld1_cases(), ids=lambda c: c[0])
+def test_ufld_v1_decode(case):
+    """UFLD v1 decoder restatement vs the reference's own __process_output (ultrafastLaneDetector.py:96-139)."""
+    tag, cfgname, head, iwh, swh = case
+    g = np.load(os.path.join(GOLDEN, "ufld1_decode.npz"))
+    assert synth.digest(head) == str(g[tag + "_in_sha1"])
+    cfg = ufld_decode.ModelConfigV1(cfgname)
+    lanes, status = ufld_decode.process_output_v1(head, cfg, iwh[0], iwh[1], swh[0], swh[1])
+    assert status == g[tag + "_status"].tolist()
+    for li in range(4):
+        np.testing.assert_array_equal(np.asarray(lanes[li], np.int64).reshape(-1, 2), g[f"{tag}_lane{li}"])

@@ -39,6 +39,12 @@ class UfldParams(C.Structure):
                 ("h_row_anchor", C.c_void_p), ("h_col_anchor", C.c_void_p)]
 
 
+class Ufld1Params(C.Structure):
+    _fields_ = [("griding_num", C.c_int32), ("cls_num_per_lane", C.c_int32), ("cfg_img_w", C.c_int32), ("cfg_img_h", C.c_int32),
+                ("input_w", C.c_int32), ("input_h", C.c_int32), ("src_w", C.c_int32), ("src_h", C.c_int32),
+                ("h_row_anchor", C.c_void_p)]
+
+
 class BytetrackParams(C.Structure):
     _fields_ = [("track_thresh", C.c_double), ("match_thresh", C.c_double), ("frame_rate", C.c_double),
                 ("track_buffer", C.c_int32), ("max_tracks", C.c_int32), ("max_dets", C.c_int32), ("reserved", C.c_int32)]
@@ -96,6 +102,9 @@ _SIGS = {
     "adas_ufld_decode_destroy": (C.c_int, [_P]),
     "adas_ufld_decode_run": (C.c_int, [_P, _P, _P, _P, _P, C.c_size_t, C.c_size_t, C.c_size_t, C.c_size_t, C.c_int, _P]),
     "adas_ufld_decode_fetch": (C.c_int, [_P, C.c_int, _P, _P, _P]),
+    "adas_ufld1_decode_create": (C.c_int, [C.POINTER(Ufld1Params), C.c_int, C.POINTER(_P)]),
+    "adas_ufld1_decode_set_source_size": (C.c_int, [_P, C.c_int, C.c_int]),
+    "adas_ufld1_decode_run": (C.c_int, [_P, _P, C.c_size_t, C.c_int, _P]),
     "adas_bytetrack_create": (C.c_int, [C.POINTER(BytetrackParams), C.c_int, C.POINTER(_P)]),
     "adas_bytetrack_destroy": (C.c_int, [_P]),
     "adas_bytetrack_reset": (C.c_int, [_P, C.c_int]),

@@ -516,4 +516,78 @@ ADAS_DEV void ufld_decode_frame(const Ctx& c, const UfldCfg& cfg, const UfldFram
     }
 }
 
+// ===========================================================================
+// UFLD (v1) lane decode  (ultrafastLaneDetector.py:96-139, ModelConfig :16-40)
+// one (G+1, K, L) fp32 tensor per frame: softmax over the first G grid cells (scipy.special.softmax
+// on float32), expectation sum(prob * (g+1)) in fp64, argmax over all G+1 cells (cell G = "no lane").
+// ===========================================================================
+struct Ufld1Cfg {
+    int G, K, L;             // griding_num, cls_num_per_lane, lanes (4)
+    int cfg_w, cfg_h;        // ModelConfig.img_w / img_h
+    int in_w, in_h;          // network input (800 x 288)
+    int src_w, src_h;        // source frame: w_ratio = src_w / cfg_w, h_ratio = src_h / cfg_h (:80)
+    const double* row_anchor;  // [K] device
+};
+
+ADAS_DEV void ufld1_decode_frame(const Ctx& c, const Ufld1Cfg& cfg, const float* out, int* lane_cnt, int* lane_det,
+                                 int* lane_pts, void* lds_base) {
+    const int G = cfg.G, K = cfg.K, NL = cfg.L, stride = K * NL;
+    double* loc = (double*)lds_base;  // [K][L], index k' = K-1-r (the [:, ::-1, :] flip of :102)
+    int* cnt = (int*)(loc + K * NL);  // [L] nonzero count, [L] positive count
+    ADAS_PAR_FOR(c, t, 0, K * NL) {
+        const int kf = t / NL, l = t % NL;
+        const float* col = out + (size_t)(K - 1 - kf) * NL + l;
+        float mx = col[0], best = col[0];
+        int am = 0;
+        for (int g = 1; g < G; ++g) {
+            const float v = col[(size_t)g * stride];
+            mx = v > mx ? v : mx;
+            if (v > best) {
+                best = v;
+                am = g;
+            }
+        }
+        if (col[(size_t)G * stride] > best) am = G;  // np.argmax over all G+1 cells, first max (:108)
+        float ssum = 0.f;
+        for (int g = 0; g < G; ++g) {
+            const float e = (float)exp((double)(col[(size_t)g * stride] - mx));  // correctly-rounded fp32 exp
+            ssum = (g == 0) ? e : ssum + e;
+        }
+        double acc = 0.0;
+        for (int g = 0; g < G; ++g) {
+            const float e = (float)exp((double)(col[(size_t)g * stride] - mx));
+            const double pv = (double)(e / ssum) * (double)(g + 1);  // prob * idx (:104-107)
+            acc = (g == 0) ? pv : acc + pv;
+        }
+        loc[t] = (am == G) ? 0.0 : acc;  // :109
+    }
+    c.sync();
+    ADAS_PAR_FOR(c, l, 0, NL) {
+        int nz = 0, pos = 0;
+        for (int k = 0; k < K; ++k) {
+            const double v = loc[k * NL + l];
+            nz += (v != 0.0) ? 1 : 0;
+            pos += (v > 0.0) ? 1 : 0;
+        }
+        const bool det = nz > 2;  // :123
+        cnt[l] = det ? 1 : 0;
+        lane_det[l] = det ? 1 : 0;
+        lane_cnt[l] = det ? pos : 0;
+    }
+    c.sync();
+    const double csw = (double)(cfg.in_w - 1) / (double)(G - 1);  // np.linspace(0, input_width-1, G) step (:113-114)
+    const double w_ratio = (double)cfg.src_w / (double)cfg.cfg_w, h_ratio = (double)cfg.src_h / (double)cfg.cfg_h;
+    ADAS_PAR_FOR(c, t, 0, K * NL) {
+        const int kf = t / NL, l = t % NL;
+        const double v = loc[t];
+        if (!cnt[l] || !(v > 0.0)) continue;
+        int slot = 0;
+        for (int kk = 0; kk < kf; ++kk) slot += (loc[kk * NL + l] > 0.0) ? 1 : 0;
+        const double x = v * csw * (double)cfg.cfg_w / (double)cfg.in_w - 1;                            // :129
+        const double y = (double)cfg.cfg_h * (cfg.row_anchor[K - 1 - kf] / (double)cfg.in_h) - 1;      // :130
+        lane_pts[(l * ADAS_UFLD_MAXPTS + slot) * 2 + 0] = (int)(x * w_ratio);                           // :131
+        lane_pts[(l * ADAS_UFLD_MAXPTS + slot) * 2 + 1] = (int)(y * h_ratio);
+    }
+}
+
 }  // namespace adas

@@ -182,6 +182,21 @@ __global__ __launch_bounds__(640) void ufld_decode_kernel(UfldDev d) {
     ufld_decode_frame(c, d.cfg, f, smem);
 }
 
+struct Ufld1Dev {
+    Ufld1Cfg cfg;
+    const float* out;
+    size_t stride;
+    int *lane_cnt, *lane_det, *lane_pts;
+};
+
+__global__ __launch_bounds__(256) void ufld1_decode_kernel(Ufld1Dev d) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int b = blockIdx.x;
+    Ctx c{(int)threadIdx.x, (int)blockDim.x};
+    ufld1_decode_frame(c, d.cfg, d.out + b * d.stride, d.lane_cnt + b * 4, d.lane_det + b * 4,
+                       d.lane_pts + (size_t)b * 4 * ADAS_UFLD_MAXPTS * 2, smem);
+}
+
 // -------------------------------------------------------------------------------------
 struct BtDev {
     BtParams P;
@@ -244,7 +259,9 @@ struct adas_yolo_post {
 struct adas_ufld_decode {
     adas_ufld_params p;
     int max_batch;
+    int v1;  // created by adas_ufld1_decode_create
     UfldDev dev;
+    Ufld1Dev dev1;
     void* arena;
     hipStream_t last;
 };
@@ -440,6 +457,7 @@ int adas_ufld_decode_create(const adas_ufld_params* p, int max_batch, adas_ufld_
     ADAS_REQUIRE(h, ADAS_ERR_INVALID, "out of host memory");
     h->p = *p;
     h->max_batch = max_batch;
+    h->v1 = 0;
     h->last = 0;
     const size_t B = max_batch;
     size_t bytes = (size_t)(p->cls_row + p->cls_col) * 8 + B * (32 + 4 * ADAS_UFLD_MAXPTS * 2 * 4) + 8 * 256;
@@ -469,9 +487,61 @@ int adas_ufld_decode_destroy(adas_ufld_decode* h) {
     delete h;
     return ADAS_OK;
 }
+int adas_ufld1_decode_create(const adas_ufld1_params* p, int max_batch, adas_ufld_decode** out) {
+    ADAS_REQUIRE(p && out && max_batch > 0 && p->h_row_anchor, ADAS_ERR_INVALID, "adas_ufld1_decode_create: bad argument");
+    ADAS_REQUIRE(p->griding_num > 2 && p->cls_num_per_lane > 0 && p->cls_num_per_lane <= ADAS_UFLD_MAXPTS, ADAS_ERR_INVALID,
+                 "griding_num must be > 2 and cls_num_per_lane in [1, %d]", ADAS_UFLD_MAXPTS);
+    ADAS_REQUIRE(p->cfg_img_w > 0 && p->cfg_img_h > 0 && p->input_w > 1 && p->input_h > 0 && p->src_w > 0 && p->src_h > 0, ADAS_ERR_INVALID,
+                 "bad image geometry");
+    ADAS_REQUIRE(adas_device_count() > 0, ADAS_ERR_NO_DEVICE, "no HIP device visible; this library has no CPU fallback");
+    adas_ufld_decode* h = new (std::nothrow) adas_ufld_decode();
+    ADAS_REQUIRE(h, ADAS_ERR_INVALID, "out of host memory");
+    memset(&h->p, 0, sizeof(h->p));
+    h->max_batch = max_batch;
+    h->v1 = 1;
+    h->last = 0;
+    const size_t B = max_batch;
+    size_t bytes = (size_t)p->cls_num_per_lane * 8 + B * (32 + 4 * ADAS_UFLD_MAXPTS * 2 * 4) + 8 * 256;
+    if (hipMalloc(&h->arena, bytes) != hipSuccess) {
+        delete h;
+        return hip_fail(hipGetLastError(), "hipMalloc(ufld1 arena)", __FILE__, __LINE__);
+    }
+    hipMemset(h->arena, 0, bytes);
+    unsigned char* q = (unsigned char*)h->arena;
+    double* ra = carve<double>(q, p->cls_num_per_lane);
+    hipMemcpy(ra, p->h_row_anchor, p->cls_num_per_lane * 8, hipMemcpyHostToDevice);
+    Ufld1Dev& d = h->dev1;
+    d.cfg = Ufld1Cfg{p->griding_num, p->cls_num_per_lane, 4, p->cfg_img_w, p->cfg_img_h, p->input_w, p->input_h, p->src_w, p->src_h, ra};
+    d.lane_cnt = carve<int>(q, B * 4);
+    d.lane_det = carve<int>(q, B * 4);
+    d.lane_pts = carve<int>(q, B * 4 * ADAS_UFLD_MAXPTS * 2);
+    h->dev.lane_cnt = d.lane_cnt;  // shared fetch path
+    h->dev.lane_det = d.lane_det;
+    h->dev.lane_pts = d.lane_pts;
+    *out = h;
+    return ADAS_OK;
+}
+int adas_ufld1_decode_set_source_size(adas_ufld_decode* h, int src_w, int src_h) {
+    ADAS_REQUIRE(h && h->v1 && src_w > 0 && src_h > 0, ADAS_ERR_INVALID, "adas_ufld1_decode_set_source_size: bad argument");
+    h->dev1.cfg.src_w = src_w;
+    h->dev1.cfg.src_h = src_h;
+    return ADAS_OK;
+}
+int adas_ufld1_decode_run(adas_ufld_decode* h, const float* d_out, size_t batch_stride, int batch, void* stream) {
+    ADAS_REQUIRE(h && h->v1 && d_out && batch > 0 && batch <= h->max_batch, ADAS_ERR_INVALID, "adas_ufld1_decode_run: bad argument");
+    hipStream_t st = (hipStream_t)stream;
+    h->last = st;
+    Ufld1Dev d = h->dev1;
+    d.out = d_out;
+    d.stride = batch_stride;
+    size_t lds = (size_t)d.cfg.K * d.cfg.L * 8 + 64;
+    hipLaunchKernelGGL(ufld1_decode_kernel, dim3(batch), dim3(256), lds, st, d);
+    ADAS_HIP_TRY(hipGetLastError());
+    return ADAS_OK;
+}
 int adas_ufld_decode_run(adas_ufld_decode* h, const float* lr, const float* lc, const float* er, const float* ec,
                          size_t s_lr, size_t s_lc, size_t s_er, size_t s_ec, int batch, void* stream) {
-    ADAS_REQUIRE(h && lr && lc && er && ec && batch > 0 && batch <= h->max_batch, ADAS_ERR_INVALID, "adas_ufld_decode_run: bad argument");
+    ADAS_REQUIRE(h && !h->v1 && lr && lc && er && ec && batch > 0 && batch <= h->max_batch, ADAS_ERR_INVALID, "adas_ufld_decode_run: bad argument");
     hipStream_t st = (hipStream_t)stream;
     h->last = st;
     UfldDev d = h->dev;

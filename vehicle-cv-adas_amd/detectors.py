@@ -25,7 +25,7 @@ import numpy as np
 
 from . import _lib as L
 from .coreEngine import OnnxEngine, TensorRTEngine
-from .postproc import YoloPost, UfldDecode, DeviceTracker, letterbox
+from .postproc import YoloPost, UfldDecode, Ufld1Decode, DeviceTracker, letterbox
 
 
 class ObjectModelType(Enum):       # ObjectDetector/utils.py:15-23
@@ -415,6 +415,84 @@ class UltrafastLaneDetectorV2(_Defaults):
             self.close()
         except Exception:
             pass
+
+
+class ModelConfigV1:               # ultrafastLaneDetector.py:16-40
+    def __init__(self, model_type):
+        if model_type == LaneModelType.UFLD_TUSIMPLE:
+            self.img_w, self.img_h, self.griding_num, self.cls_num_per_lane = 1280, 720, 100, 56
+            self.row_anchor = np.linspace(64, 284, self.cls_num_per_lane)
+        else:
+            self.img_w, self.img_h, self.griding_num, self.cls_num_per_lane = 1640, 590, 200, 18
+            self.row_anchor = [round(value) for value in np.linspace(121, 287, self.cls_num_per_lane)]
+        self.num_lanes = 4
+
+
+class UltrafastLaneDetector(UltrafastLaneDetectorV2):
+    """UFLD (v1) drop-in: ultrafastLaneDetector.py:42-139 with pre-processing, network and decode on the device.
+    Pre-processing is the v2 kernel with crop_ratio 1 (plain resize to 800x288 + ImageNet normalisation, :79-94)."""
+    _defaults = {
+        "model_path": "models/tusimple_18.onnx",
+        "model_type": LaneModelType.UFLD_TUSIMPLE,
+    }
+
+    def __init__(self, model_path: str = None, model_type: LaneModelType = None, logger=None, precision="bf16"):
+        self.__dict__.update(self._defaults)
+        self.logger = logger
+        self.adjust_lanes = False
+        self.lane_info = LaneInfo(np.array([], dtype=object), np.array([], dtype=object), np.array([], dtype=object), False)
+        if None not in [model_path, model_type]:
+            self.model_path, self.model_type = model_path, model_type
+        if self.model_type not in [LaneModelType.UFLD_TUSIMPLE, LaneModelType.UFLD_CULANE]:
+            raise Exception("UltrafastLaneDetector can't use %s type." % self.model_type.name)
+        self.cfg = ModelConfigV1(self.model_type)
+        self.precision = precision
+        self._initialize_model(self.model_path)
+        self._stage = _FrameStage()
+        self._decode = None
+        self._decode_key = None
+
+    def _initialize_model(self, model_path: str) -> None:
+        self.engine = _engine_for(model_path, precision=self.precision)
+        if self.logger:
+            self.logger.info(f'UfldDetector Type : [{self.engine.framework_type}] || Version : {self.engine.providers}')
+        self.input_shape = self.engine.get_engine_input_shape()
+        self.input_types = self.engine.engine_dtype
+        self.channes, self.input_height, self.input_width = self.input_shape[1:]
+        self.output_shape, self.output_names = self.engine.get_engine_output_shape()
+        if len(self.output_names) != 1:
+            raise Exception("Output dims is error, please check model. load %d channels not match 1." % len(self.output_names))
+        o = self.output_shape[0]
+        if list(o[1:3]) != [self.cfg.griding_num + 1, self.cfg.cls_num_per_lane]:
+            raise Exception("model output %s does not fit the %s configuration" % (o, self.model_type.name))
+
+    def _decode_for(self, img_hw):
+        key = (int(img_hw[0]), int(img_hw[1]))
+        if self._decode is None:
+            c = self.cfg
+            self._decode = Ufld1Decode(c.griding_num, c.cls_num_per_lane, c.img_w, c.img_h, self.input_width, self.input_height,
+                                       key[1], key[0], c.row_anchor, 1)
+        elif self._decode_key != key:
+            self._decode.set_source_size(key[1], key[0])
+        self._decode_key = key
+        return self._decode
+
+    def DetectFrame(self, image, adjust_lanes: bool = True) -> None:
+        """ultrafastLaneDetector.py:141-153."""
+        h, w = self._stage.upload(image)
+        self.img_height, self.img_width, self.img_channels = h, w, 3
+        self.h_ratio, self.w_ratio = h / self.cfg.img_h, w / self.cfg.img_w
+        t = self._stage.tensor_for(self.input_shape)
+        L.check(L.lib().adas_preprocess_ufld(self._stage.frame.ptr, 1, h, w, t.ptr, self.input_height, self.input_width, 1.0, None))
+        self.engine.infer_device(t.ptr, 1, None)
+        dec = self._decode_for((h, w))
+        dec.run_device(self.engine.output_device_ptr(0), int(np.prod(self.output_shape[0][1:])), 1, None)
+        lanes, status = dec.fetch(0)
+        self.lane_info.lanes_points = np.array(lanes + [None], dtype=object)[:4]
+        self.lane_info.lanes_status = [bool(s) for s in status]
+        self.adjust_lanes = adjust_lanes
+        self._UltrafastLaneDetectorV2__update_lanes_status(self.lane_info.lanes_status)
+        self._UltrafastLaneDetectorV2__update_lanes_area(self.lane_info.lanes_points, self.img_height)
 
 
 # =====================================================================================

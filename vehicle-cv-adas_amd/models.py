@@ -451,6 +451,46 @@ def ufldv2(backbone="18", in_h=320, in_w=1600, num_grid_row=200, num_cls_row=72,
     return g
 
 
+def ufld_v1(backbone="18", in_h=288, in_w=800, griding_num=100, cls_num_per_lane=56, num_lanes=4, wsrc=None, seed=0):
+    """UFLD (v1) parsingNet: ResNet trunk -> 1x1 `pool` conv 512->8 -> view(-1, 1800) -> Linear 2048 -> ReLU ->
+    Linear (G+1)*K*L -> one (1, G+1, K, L) tensor.  The network source is upstream (Ultra-Fast-Lane-Detection
+    model/model.py), not vendored by the reference; what the reference pins is the single output and its layout
+    (ultrafastLaneDetector.py:73-75,96-109) and the 800x288 input (:84)."""
+    wsrc = wsrc or SynthWeights(seed, gain=RELU_RES_GAIN)
+    g = Graph(f"ufld_v1_res{backbone}", 3, in_h, in_w, wsrc)
+    x, cin = g.input()
+    x = g.conv(x, 64, 7, 2, "model.conv1", act=ACT_RELU, true_cin=cin, pad=3)
+    x = g.maxpool(x, 3, 2, 1, name="model.maxpool")
+    cinp = 64
+    for li, (planes, nblk) in enumerate(zip([64, 128, 256, 512], RESNET_DEPTHS[backbone])):
+        for bi in range(nblk):
+            s = 2 if (li > 0 and bi == 0) else 1
+            name = f"model.layer{li + 1}.{bi}"
+            idt = x
+            if s != 1 or cinp != planes:
+                idt = g.conv(x, planes, 1, s, f"{name}.downsample.0", act=ACT_NONE, pad=0)
+            t = g.conv(x, planes, 3, s, f"{name}.conv1", act=ACT_RELU)
+            x = g.conv(t, planes, 3, 1, f"{name}.conv2", act=ACT_RELU, res=idt, res_mode=RES_BEFORE_ACT)
+            cinp = planes
+    fea = g.conv(x, 8, 1, 1, "pool", act=ACT_NONE, pad=0)
+    input_dim = fea.h * fea.w * 8                                                   # 1800 at 288x800
+    mid, total = 2048, (griding_num + 1) * cls_num_per_lane * num_lanes
+    hw = fea.h * fea.w
+    perm = (np.arange(8)[None, :] * hw + np.arange(hw)[:, None]).reshape(-1)       # ours (h,w,c) <- torch (c,h,w)
+    x = g.alias(fea, 1, 1, input_dim)
+    W1 = wsrc("cls.0.weight", (mid, input_dim), "linear")
+    keep, g.w = g.w, DictWeights({"cls.0.weight.perm": np.ascontiguousarray(W1[:, perm])})
+    h1 = g.conv(x, mid, 1, 1, "cls.0", act=ACT_RELU, wname="cls.0.weight.perm", bias=False, wkind="linear")
+    g.w = keep
+    g.ops[-1]["b"] = g._blob(wsrc("cls.0.bias", (mid,), "bias"))
+    g.n_params += mid
+    out = g.conv(h1, total, 1, 1, "cls.2", act=ACT_NONE, f32_out=True, wkind="linear")
+    g.output(out, 0, [1, griding_num + 1, cls_num_per_lane, num_lanes], "output")
+    g.meta = dict(kind="ufld_v1", total=total)
+    return g
+
+
+UFLD1_CULANE = dict(griding_num=200, cls_num_per_lane=18)
 TUSIMPLE = dict(in_h=320, in_w=800, num_grid_row=100, num_cls_row=56, num_grid_col=100, num_cls_col=41, fc_norm=False)
 
 BUILDERS = {
@@ -459,6 +499,9 @@ BUILDERS = {
     "yolov5n": lambda **k: yolov5("n", **k), "yolov5s": lambda **k: yolov5("s", **k),
     "ufldv2_res18": lambda **k: ufldv2("18", **k), "ufldv2_res34": lambda **k: ufldv2("34", **k),
     # Tusimple configuration (configs/tusimple_res18.py:28-35): 800x320 input, 100/100 grid cells, 56/41 anchors, no LayerNorm
+    # UFLD v1 (ultrafastLaneDetector.py): Tusimple 100 cells x 56 anchors, CULane 200 x 18, both 800x288
+    "ufld_v1_res18": lambda **k: ufld_v1("18", **k), "ufld_v1_res34": lambda **k: ufld_v1("34", **k),
+    "ufld_v1_culane_res18": lambda **k: ufld_v1("18", **dict(UFLD1_CULANE, **k)),
     "ufldv2_tusimple_res18": lambda **k: ufldv2("18", **dict(TUSIMPLE, **k)), "ufldv2_tusimple_res34": lambda **k: ufldv2("34", **dict(TUSIMPLE, **k)),
 }
 

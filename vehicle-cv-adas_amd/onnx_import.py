@@ -273,6 +273,12 @@ def detect_arch(m):
         fc_norm = "cls.0.weight" in m.initializers or any(nd["op"] == "LayerNormalization" for nd in m.nodes)   # Tusimple exports have cls.0 = Identity
         return "ufldv2_res" + depth, dict(in_h=H, in_w=W, num_grid_row=gr, num_cls_row=cr, num_grid_col=gc, num_cls_col=cc, num_lanes=nl,
                                           fc_norm=fc_norm)
+    if len(outs) == 1 and len(outs[0]) == 4 and c0[2] == 7 and c0[0] == 64:     # UFLD v1: one (1, G+1, K, L) tensor
+        depth = {20: "18", 36: "34"}.get(len(convs) - 1)
+        if depth is None:
+            raise ValueError("ResNet depth not 18/34 (%d convs): %s" % (len(convs), found))
+        _, g1, k, nl = outs[0]
+        return "ufld_v1_res" + depth, dict(in_h=H, in_w=W, griding_num=g1 - 1, cls_num_per_lane=k, num_lanes=nl)
     if len(outs) == 1 and len(outs[0]) == 3:
         o = outs[0]
         if c0[2] == 3 and o[2] > o[1]:                      # (1, 4+nc, A): YOLOv8/9/10-style head
@@ -350,7 +356,7 @@ class OnnxWeights:
                 if nd["op"] == "MatMul" or not nd["attrs"].get("transB", 0):
                     w = w.T
                 lin.append(w)
-        order = {"cls.1.weight": 0, "cls.3.weight": 1}.get(name)
+        order = {"cls.1.weight": 0, "cls.3.weight": 1, "cls.0.weight": 0, "cls.2.weight": 1}.get(name)   # v2 | v1 module indices
         if order is None or order >= len(lin) or lin[order].shape != tuple(shape):
             return None
         return np.ascontiguousarray(lin[order])

@@ -125,6 +125,35 @@ class UfldDecode:
     __del__ = close
 
 
+class Ufld1Decode(UfldDecode):
+    """UFLD (v1) decoder: UltrafastLaneDetector.__process_output (ultrafastLaneDetector.py:96-139) on the device."""
+
+    def __init__(self, griding_num, cls_num_per_lane, cfg_img_w, cfg_img_h, input_w, input_h, src_w, src_h, row_anchor,
+                 max_batch=1):
+        ra = np.ascontiguousarray(row_anchor, np.float64)
+        p = L.Ufld1Params(griding_num, cls_num_per_lane, cfg_img_w, cfg_img_h, input_w, input_h, src_w, src_h, L.ptr(ra))
+        self.dims = (griding_num, cls_num_per_lane)
+        h = C.c_void_p()
+        L.check(L.lib().adas_ufld1_decode_create(C.byref(p), max_batch, C.byref(h)))
+        self.h = h.value
+
+    def set_source_size(self, src_w, src_h):
+        L.check(L.lib().adas_ufld1_decode_set_source_size(self.h, int(src_w), int(src_h)))
+
+    def run_device(self, ptr, stride, batch=1, stream=None):
+        L.check(L.lib().adas_ufld1_decode_run(self.h, ptr, stride, batch, stream))
+
+    def run_host(self, out):
+        """out: (B, G+1, K, 4) fp32."""
+        out = np.ascontiguousarray(out, np.float32)
+        buf = L.DeviceBuffer.from_array(out)
+        try:
+            self.run_device(buf.ptr, out[0].size, out.shape[0])
+            return [self.fetch(b) for b in range(out.shape[0])]
+        finally:
+            buf.free()
+
+
 class DeviceTracker:
     """n_streams independent ByteTrack instances living on the GPU."""
 
