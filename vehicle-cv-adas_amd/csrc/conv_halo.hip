@@ -67,6 +67,7 @@ struct HaloDev {
     int Ho, Wo;                   // output extent (== H, W at stride 1)
     int out_f32;
     uint32_t mg_ww, mg_sw;        // n / WW == (n * mg_ww) >> 20 and n / SW == (n * mg_sw) >> 20 for every n the kernel divides
+    int ntiles, tiles8, ncb, cbg;  // workgroup id -> (tile, cout block) map: tiles, ceil(tiles/8), cout blocks, blocks kept adjacent
 };
 
 constexpr int HALO_CK = 32;
@@ -92,7 +93,7 @@ __device__ unsigned long long g_halo_prof[256][16];
     unsigned long long pacc__[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #define HPROF_FLUSH                                                                      \
     if (tid == 0) {                                                                      \
-        unsigned long long* b__ = g_halo_prof[(blockIdx.x + 7 * blockIdx.y) & 255];      \
+        unsigned long long* b__ = g_halo_prof[blockIdx.x & 255];      \
         for (int i__ = 0; i__ < 10; ++i__) atomicAdd(&b__[i__], pacc__[i__]);            \
         atomicAdd(&b__[15], 1ull);                                                       \
     }
@@ -117,8 +118,15 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(HaloDev a) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     HPROF_INIT
     const int lrow = lane & 15, kg = lane >> 4;
-    const int n0 = blockIdx.y * BN;
-    int tile = blockIdx.x;
+    // Workgroup id -> (tile, cout block).  Block b is observed to run on XCD b % 8 (MI355X_MICROARCH.md, workgroup
+    // dispatch); the cbg cout blocks of one tile take consecutive slots of ONE XCD, so the window they all read comes
+    // from HBM once and is re-read from that XCD's L2 (x-fastest 2-D order streamed the whole input once per cout block).
+    const int xslot = blockIdx.x >> 3;
+    const int xr = xslot / a.cbg;
+    const int cb = (xr / a.tiles8) * a.cbg + (xslot - xr * a.cbg);
+    int tile = (xr % a.tiles8) * 8 + (blockIdx.x & 7);
+    if (cb >= a.ncb || tile >= a.ntiles) return;
+    const int n0 = cb * BN;
     const int per_img = a.NS * a.TPS;
     const int img = tile / per_img;
     tile -= img * per_img;
@@ -151,7 +159,7 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(HaloDev a) {
     // weights: slab (cout tile, chunk) = WROWS rows of 64 B, contiguous (kernels.h: CONV_HALO packing); thread e = tid + 256*i
     // fetches 16 B number e of the slab -> every wave-level load is 1 KB of consecutive bytes
     const int nchunk_w = a.cin_pad >> 5;
-    const uint16_t* wbase = a.wgt + (size_t)blockIdx.y * nchunk_w * WROWS * 32 + tid * 8;
+    const uint16_t* wbase = a.wgt + (size_t)cb * nchunk_w * WROWS * 32 + tid * 8;
     int woff[NW];
 #pragma unroll
     for (int i = 0; i < NW; ++i) woff[i] = ((tid >> 2) + 64 * i < WROWS) ? 256 * 8 * i : -1;
@@ -450,6 +458,23 @@ static bool halo_s2_enabled() {
     return v == 1;
 }
 
+// cout blocks of a tile that run back to back on one XCD: the largest divisor of ncb whose weight slabs together stay
+// within half of the XCD's 4 MiB L2 (every tile re-reads them).  Measured at 64 frames (tools/scratch/cbg_sweep.sh):
+// 256->256 20x100 188 -> 168 us, its stride-2 sibling 330 -> 300 us, 128->128 194 -> 190 us, 512->512 neutral at 2 or 8
+// and 11 % slower with a non-divisor (the padded last group skews the dispatch order).  ADAS_HALO_CBG overrides.
+static int halo_cb_group(int ncb, size_t slab_bytes) {
+    static int forced = -1;
+    if (forced < 0) {
+        const char* e = getenv("ADAS_HALO_CBG");
+        forced = e ? atoi(e) : 0;
+    }
+    int g = forced > 0 ? forced : (int)((2u << 20) / (slab_bytes ? slab_bytes : 1));
+    if (g < 1) g = 1;
+    if (g > ncb) g = ncb;
+    while (ncb % g) --g;
+    return g;
+}
+
 // Returns false when this kernel does not apply (caller falls back to the gather kernel).
 bool halo_applicable(int kh, int kw, int stride, int pad, const TView& in, const TView& out) {
     if ((stride != 1 && stride != 2) || kh != 3 || kw != 3 || pad != 1) return false;
@@ -478,7 +503,11 @@ hipError_t launch_conv_halo(const ConvArgs& a, hipStream_t st) {
     d.mg_ww = pl.mg_ww;
     d.mg_sw = pl.mg_sw;
     const int bn = a.out.c <= 16 ? 16 : (a.out.c <= 32 ? 32 : 64);
-    dim3 grid(a.n * pl.NS * pl.TPS, (a.out.c + bn - 1) / bn);
+    d.ntiles = a.n * pl.NS * pl.TPS;
+    d.tiles8 = (d.ntiles + 7) / 8;
+    d.ncb = (a.out.c + bn - 1) / bn;
+    d.cbg = halo_cb_group(d.ncb, (size_t)d.cin_pad * 9 * bn * 2);
+    dim3 grid(8 * d.tiles8 * d.cbg * ((d.ncb + d.cbg - 1) / d.cbg));
     size_t lds = ((size_t)pl.maxpix * HALO_PIX + (size_t)9 * bn * HALO_WPIX) * 2;
     if (a.stride == 2) {
         if (bn == 64) return launch_bn<64, 2>(d, a.act, grid, lds, st);
