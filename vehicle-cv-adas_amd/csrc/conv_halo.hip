@@ -67,6 +67,7 @@ struct HaloDev {
     int Ho, Wo;                   // output extent (== H, W at stride 1)
     int out_f32;
     uint32_t mg_ww, mg_sw;        // n / WW == (n * mg_ww) >> 20 and n / SW == (n * mg_sw) >> 20 for every n the kernel divides
+    int xmap;
     int ntiles, tiles8, ncb, cbg;  // workgroup id -> (tile, cout block) map: tiles, ceil(tiles/8), cout blocks, blocks kept adjacent
 };
 
@@ -121,10 +122,12 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(HaloDev a) {
     // Workgroup id -> (tile, cout block).  Block b is observed to run on XCD b % 8 (MI355X_MICROARCH.md, workgroup
     // dispatch); the cbg cout blocks of one tile take consecutive slots of ONE XCD, so the window they all read comes
     // from HBM once and is re-read from that XCD's L2 (x-fastest 2-D order streamed the whole input once per cout block).
+    // xmap: each XCD walks a contiguous range of tiles, so the halo rows shared by consecutive tiles hit its L2 too
+    // (0-1.6 % over the interleaved map; ADAS_HALO_XMAP=0 restores that one).
     const int xslot = blockIdx.x >> 3;
     const int xr = xslot / a.cbg;
     const int cb = (xr / a.tiles8) * a.cbg + (xslot - xr * a.cbg);
-    int tile = (xr % a.tiles8) * 8 + (blockIdx.x & 7);
+    int tile = a.xmap ? (int)(blockIdx.x & 7) * a.tiles8 + (xr % a.tiles8) : (xr % a.tiles8) * 8 + (blockIdx.x & 7);
     if (cb >= a.ncb || tile >= a.ntiles) return;
     const int n0 = cb * BN;
     const int per_img = a.NS * a.TPS;
@@ -504,6 +507,7 @@ hipError_t launch_conv_halo(const ConvArgs& a, hipStream_t st) {
     d.mg_sw = pl.mg_sw;
     const int bn = a.out.c <= 16 ? 16 : (a.out.c <= 32 ? 32 : 64);
     d.ntiles = a.n * pl.NS * pl.TPS;
+    { static int xm = -1; if (xm < 0) { const char* e = getenv("ADAS_HALO_XMAP"); xm = e ? atoi(e) : 1; } d.xmap = xm; }
     d.tiles8 = (d.ntiles + 7) / 8;
     d.ncb = (a.out.c + bn - 1) / bn;
     d.cbg = halo_cb_group(d.ncb, (size_t)d.cin_pad * 9 * bn * 2);
