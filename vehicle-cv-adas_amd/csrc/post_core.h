@@ -461,7 +461,20 @@ ADAS_DEV void ufld_decode_frame(const Ctx& c, const UfldCfg& cfg, const UfldFram
         const int G = row ? cfg.grid_row : cfg.grid_col;
         float best = loc[0];
         int m = 0;
-        for (int g = 1; g < G; ++g) {
+        // eight independent loads in flight per trip (the scan itself stays sequential: first maximum wins)
+        int g = 1;
+        for (; g + 8 <= G; g += 8) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = loc[(size_t)(g + u) * stride];
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (v[u] > best) {
+                    best = v[u];
+                    m = g + u;
+                }
+        }
+        for (; g < G; ++g) {
             float v = loc[(size_t)g * stride];
             if (v > best) {
                 best = v;
@@ -473,9 +486,12 @@ ADAS_DEV void ufld_decode_frame(const Ctx& c, const UfldCfg& cfg, const UfldFram
         L.val[t] = ex[stride] > ex[0] ? 1 : 0;
     }
     c.sync();
-    if (c.tid == 0) {
-        for (int t = 0; t < nr; ++t) L.cnt[t % NL] += L.val[t];
-        for (int t = 0; t < nc; ++t) L.cnt[4 + (t % NL)] += L.val[nr + t];
+    ADAS_PAR_FOR(c, q, 0, 2 * NL) {  // valid-anchor count per (row | column, lane)
+        const bool row = q < NL;
+        const int i = row ? q : q - NL, K = row ? R : C, base = row ? 0 : nr;
+        int n = 0;
+        for (int k = 0; k < K; ++k) n += L.val[base + k * NL + i];
+        L.cnt[(row ? 0 : 4) + i] = n;
     }
     c.sync();
     // lanes: row anchors feed lanes {1,2}; column anchors feed lanes {0,3}
