@@ -92,6 +92,60 @@ ADAS_DEV void block_argmax_first(const Ctx& c, const double* a, int lo, int hi, 
 #endif
 }
 
+// ---------------------------------------------------------------------------
+// wave64 all-lanes reductions / broadcasts on VALU lane exchanges: DPP inside the 16-lane rows, v_permlane16_swap and
+// v_permlane32_swap across them, v_readlane for uniform-source broadcasts.  About 30 VALU instructions per reduction
+// instead of six dependent ds_bpermute round trips (~150 cycles each) -- these sit inside the sequential loops of the
+// NMS and of the assignment solver.
+// ---------------------------------------------------------------------------
+#if defined(__HIP_DEVICE_COMPILE__)
+ADAS_DEV unsigned long long wv_pack(int hi, int lo) { return ((unsigned long long)(unsigned)hi << 32) | (unsigned)lo; }
+template <int CTRL>
+ADAS_DEV unsigned long long wv_dpp64(unsigned long long v) {
+    int lo = (int)(unsigned)v, hi = (int)(unsigned)(v >> 32);
+    lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xF, 0xF, false);
+    hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xF, 0xF, false);
+    return wv_pack(hi, lo);
+}
+template <class Op>
+ADAS_DEV unsigned long long wave_allreduce_u64(unsigned long long v, Op op) {
+    v = op(v, wv_dpp64<0xB1>(v));   // quad_perm [1,0,3,2]: lane ^ 1
+    v = op(v, wv_dpp64<0x4E>(v));   // quad_perm [2,3,0,1]: lane ^ 2
+    v = op(v, wv_dpp64<0x141>(v));  // row_half_mirror: quads of each half row
+    v = op(v, wv_dpp64<0x140>(v));  // row_mirror: the two halves of a row
+    {
+        const unsigned lo = (unsigned)v, hi = (unsigned)(v >> 32);
+        const auto a = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+        const auto b = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+        v = op(wv_pack((int)b[0], (int)a[0]), wv_pack((int)b[1], (int)a[1]));  // rows 0|1 and 2|3
+    }
+    {
+        const unsigned lo = (unsigned)v, hi = (unsigned)(v >> 32);
+        const auto a = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+        const auto b = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+        v = op(wv_pack((int)b[0], (int)a[0]), wv_pack((int)b[1], (int)a[1]));  // the two half waves
+    }
+    return v;
+}
+ADAS_DEV unsigned long long wave_max_u64(unsigned long long v) {
+    return wave_allreduce_u64(v, [](unsigned long long a, unsigned long long b) { return a > b ? a : b; });
+}
+ADAS_DEV double wave_min_f64(double v) {  // no NaNs expected; of two equal values either bit pattern may come back
+    const unsigned long long r = wave_allreduce_u64((unsigned long long)__double_as_longlong(v), [](unsigned long long a, unsigned long long b) {
+        return __longlong_as_double((long long)a) <= __longlong_as_double((long long)b) ? a : b;
+    });
+    return __longlong_as_double((long long)r);
+}
+// value of lane `src` (wave-uniform) in every lane
+ADAS_DEV int wave_read_i32(int v, int src) { return __builtin_amdgcn_readlane(v, __builtin_amdgcn_readfirstlane(src)); }
+ADAS_DEV double wave_read_f64(double v, int src) {
+    const long long b = __double_as_longlong(v);
+    const int s = __builtin_amdgcn_readfirstlane(src);
+    const int lo = __builtin_amdgcn_readlane((int)(unsigned)b, s), hi = __builtin_amdgcn_readlane((int)(unsigned)((unsigned long long)b >> 32), s);
+    return __longlong_as_double((long long)wv_pack(hi, lo));
+}
+#endif
+
 // ===========================================================================
 // YOLO: ordered compaction -> box decode -> inverse letterbox -> NMS -> gather
 // replaces yoloDetector.py:120-133 (threshold + box), utils.py:70-87,
@@ -176,13 +230,177 @@ struct YoloLds {
     }
 };
 
+// ---------------------------------------------------------------------------
+// Reference-mode NMS in one wave: candidate j lives in lane j % 64, register slot j / 64 (N <= 64 * NC).  Same
+// selection sort, lossy "swap", IoU arithmetic and comparison order as the block-wide loop in yolo_post_frame, without its
+// five workgroup barriers per selected box; row broadcasts are lane shuffles.  keep[] receives the survivors in j order.
+// ---------------------------------------------------------------------------
+#if defined(__HIP_DEVICE_COMPILE__)
+template <int NC>
+ADAS_DEV double nms_pick(const double (&a)[NC], int k) {
+    double r = a[0];
+#pragma unroll
+    for (int q = 1; q < NC; ++q) r = (k == q) ? a[q] : r;
+    return r;
+}
+template <int NC>
+ADAS_DEV int nms_picki(const int (&a)[NC], int k) {
+    int r = a[0];
+#pragma unroll
+    for (int q = 1; q < NC; ++q) r = (k == q) ? a[q] : r;
+    return r;
+}
+
+template <int NC>
+ADAS_DEV void yolo_nms_reference_wave(const Ctx& c, const double* lc0, const double* lc1, const double* lc2, const double* lc3,
+                                      const double* lsc, const double* larea, const int* lidx, int N, double iou_thr, int* keep,
+                                      int* n_keep) {
+    if (c.tid < 64) {
+        const int lane = c.tid;
+        double c0[NC], c1[NC], c2[NC], c3[NC], sc[NC], ar[NC];
+        int idx[NC];
+#pragma unroll
+        for (int k = 0; k < NC; ++k) {
+            const int j = lane + 64 * k, jj = j < N ? j : 0;
+            c0[k] = lc0[jj]; c1[k] = lc1[jj]; c2[k] = lc2[jj]; c3[k] = lc3[jj];
+            sc[k] = lsc[jj]; ar[k] = larea[jj]; idx[k] = lidx[jj];
+        }
+        for (int i = 0; i < N; ++i) {
+            const int pos = i + 1;
+            double maxscore;
+            int maxpos;
+            if (i != N - 1) {
+                // Scores are float confidences widened to double (or 0.0), so the low 29 mantissa bits are zero and,
+                // being non-negative, the bit patterns order like the values: key = bits | ~j packs "highest score, then
+                // lowest index" (np.argmax's first maximum) into one 64-bit maximum.
+                unsigned long long key = 0;
+#pragma unroll
+                for (int k = 0; k < NC; ++k) {
+                    const int j = lane + 64 * k;
+                    if (j >= pos && j < N) {
+                        const unsigned long long kk = (unsigned long long)__double_as_longlong(sc[k]) | (unsigned long long)(~j & 0x1fffffff);
+                        key = kk > key ? kk : key;
+                    }
+                }
+                key = wave_max_u64(key);
+                maxscore = __longlong_as_double((long long)(key & ~0x1fffffffull));
+                maxpos = (int)(~key & 0x1fffffffull);
+            } else {
+                maxscore = wave_read_f64(nms_pick<NC>(sc, (N - 1) >> 6), (N - 1) & 63);
+                maxpos = 0;
+            }
+            if (i != N - 1 && maxscore == 0.0) break;  // scores are >= 0: nothing can change any more
+            const int li = i & 63, ki = i >> 6, lm = maxpos & 63, km = maxpos >> 6;
+            const double tscore = wave_read_f64(nms_pick<NC>(sc, ki), li);
+            if (tscore < maxscore) {  // utils.py:218-231: rows "swapped" through a view (boxes + index copied one way only)
+                const double tarea = wave_read_f64(nms_pick<NC>(ar, ki), li);
+                const double m0 = wave_read_f64(nms_pick<NC>(c0, km), lm), m1 = wave_read_f64(nms_pick<NC>(c1, km), lm);
+                const double m2 = wave_read_f64(nms_pick<NC>(c2, km), lm), m3 = wave_read_f64(nms_pick<NC>(c3, km), lm);
+                const double ma = wave_read_f64(nms_pick<NC>(ar, km), lm);
+                const int mi = wave_read_i32(nms_picki<NC>(idx, km), lm);
+#pragma unroll
+                for (int k = 0; k < NC; ++k)
+                    if (lane == li && k == ki) {
+                        c0[k] = m0; c1[k] = m1; c2[k] = m2; c3[k] = m3;
+                        idx[k] = mi; sc[k] = maxscore; ar[k] = ma;
+                    }
+#pragma unroll
+                for (int k = 0; k < NC; ++k)
+                    if (lane == lm && k == km) {
+                        sc[k] = tscore;
+                        ar[k] = tarea;
+                    }
+            }
+            const double i0 = wave_read_f64(nms_pick<NC>(c0, ki), li), i1 = wave_read_f64(nms_pick<NC>(c1, ki), li);
+            const double i2 = wave_read_f64(nms_pick<NC>(c2, ki), li), i3 = wave_read_f64(nms_pick<NC>(c3, ki), li);
+            const double ia = wave_read_f64(nms_pick<NC>(ar, ki), li);
+#pragma unroll
+            for (int k = 0; k < NC; ++k) {
+                const int j = lane + 64 * k;
+                if (j >= pos && j < N) {
+                    double xx1 = fmax(i1, c1[k]);
+                    double yy1 = fmax(i0, c0[k]);
+                    double xx2 = fmin(i3, c3[k]);
+                    double yy2 = fmin(i2, c2[k]);
+                    double w = fmax(0.0, xx2 - xx1 + 1);
+                    double h = fmax(0.0, yy2 - yy1 + 1);
+                    double inter = w * h;
+                    double ovr = inter / (ia + ar[k] - inter);
+                    if (ovr > iou_thr) sc[k] = 0.0;  // weight 0 (utils.py:247-251)
+                }
+            }
+        }
+        int nk = 0;
+#pragma unroll
+        for (int k = 0; k < NC; ++k) {
+            const int j = lane + 64 * k;
+            const bool fl = j < N && sc[k] > 0.001;
+            const unsigned long long m = __ballot(fl);
+            if (fl) keep[nk + __popcll(m & ((1ull << lane) - 1ull))] = idx[k];
+            nk += __popcll(m);
+        }
+        if (lane == 0) *n_keep = nk;
+    }
+    c.sync();
+}
+#endif
+
+// phase timers for scratch builds (ADAS_CFLAGS=-DADAS_YP_PROF, read back with adas_debug_yolo_prof)
+#if defined(ADAS_YP_PROF) && defined(__HIP_DEVICE_COMPILE__)
+#define YP_MARK_INIT unsigned long long yp_t0_ = wall_clock64()
+#define YP_MARK(i)                                        \
+    do {                                                  \
+        if (c.tid == 0) {                                 \
+            unsigned long long t_ = wall_clock64();       \
+            atomicAdd(&g_yp_prof[i], t_ - yp_t0_);        \
+            yp_t0_ = t_;                                  \
+        }                                                 \
+    } while (0)
+#else
+#define YP_MARK_INIT
+#define YP_MARK(i)
+#endif
+
 ADAS_DEV void yolo_post_frame(const Ctx& c, const YoloPostCfg& cfg, const YoloPostFrame& f, void* lds_base) {
     YoloLds L;
     L.carve(lds_base, cfg.cap, c.nthr);
     const int A = cfg.A, cap = cfg.cap;
+    YP_MARK_INIT;
 
     // ---- phase A: ordered stream compaction of anchors with conf > box_score (anchor order preserved)
     int base = 0;
+#if defined(__HIP_DEVICE_COMPILE__)
+    {   // four anchors per thread per trip (sub-pass u covers a0 + u*nthr + tid): one ballot each, two barriers per trip
+        const int lane = c.tid & 63, wv = c.tid >> 6, nw = (c.nthr + 63) >> 6;  // nw <= 16 (scan[] holds 4*nw wave counts)
+        for (int a0 = 0; a0 < A; a0 += 4 * c.nthr) {
+            bool fl[4];
+            int below[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int a = a0 + u * c.nthr + c.tid;
+                fl[u] = a < A && (double)f.best_conf[a] > cfg.box_score;
+                const unsigned long long m = __ballot(fl[u]);
+                below[u] = __popcll(m & ((1ull << lane) - 1ull));
+                if (lane == 0) L.scan[u * nw + wv] = __popcll(m);
+            }
+            c.sync();
+            int run = base;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                int mine = run;
+                for (int w = 0; w < nw; ++w) {
+                    const int cw = L.scan[u * nw + w];
+                    if (w < wv) mine += cw;
+                    run += cw;
+                }
+                const int slot = mine + below[u];
+                if (fl[u] && slot < cap) f.cand_anchor[slot] = a0 + u * c.nthr + c.tid;
+            }
+            base = run;
+            c.sync();
+        }
+    }
+#else
     for (int a0 = 0; a0 < A; a0 += 1024) {
         int n = (A - a0 < 1024) ? (A - a0) : 1024;
         ADAS_PAR_FOR(c, j, 0, 1024) L.flag[j] = (j < n && (double)f.best_conf[a0 + j] > cfg.box_score) ? 1 : 0;
@@ -214,7 +432,9 @@ ADAS_DEV void yolo_post_frame(const Ctx& c, const YoloPostCfg& cfg, const YoloPo
         base += L.red_i[0];
         c.sync();
     }
+#endif
     const int N = base < cap ? base : cap;
+    YP_MARK(0);
     if (c.tid == 0) {
         f.counts[0] = base;
         f.counts[1] = N;
@@ -267,11 +487,22 @@ ADAS_DEV void yolo_post_frame(const Ctx& c, const YoloPostCfg& cfg, const YoloPo
             L.area[j] = (r2 - x1) * (r3 - y1);
     }
     c.sync();
+    YP_MARK(1);
 
     int K = 0;
     if (N == 1) {  // utils.py:197-198 / :131-132
         if (c.tid == 0) f.keep[0] = 0;
         K = 1;
+#if defined(__HIP_DEVICE_COMPILE__)
+    } else if (N > 1 && cfg.nms_mode == 0 && N <= 512) {
+        // ---- reference mode, register-resident in one wave (same arithmetic as the block-wide loop below)
+        if (N <= 64) yolo_nms_reference_wave<1>(c, L.c0, L.c1, L.c2, L.c3, L.sc, L.area, L.idx, N, cfg.iou_thr, f.keep, &L.red_i[0]);
+        else if (N <= 128) yolo_nms_reference_wave<2>(c, L.c0, L.c1, L.c2, L.c3, L.sc, L.area, L.idx, N, cfg.iou_thr, f.keep, &L.red_i[0]);
+        else if (N <= 256) yolo_nms_reference_wave<4>(c, L.c0, L.c1, L.c2, L.c3, L.sc, L.area, L.idx, N, cfg.iou_thr, f.keep, &L.red_i[0]);
+        else yolo_nms_reference_wave<8>(c, L.c0, L.c1, L.c2, L.c3, L.sc, L.area, L.idx, N, cfg.iou_thr, f.keep, &L.red_i[0]);
+        K = L.red_i[0];
+        c.sync();
+#endif
     } else if (N > 1 && cfg.nms_mode == 0) {
         // ---- reference mode: selection sort with the lossy view-"swap" (Appendix A3)
         for (int i = 0; i < N; ++i) {
@@ -372,6 +603,7 @@ ADAS_DEV void yolo_post_frame(const Ctx& c, const YoloPostCfg& cfg, const YoloPo
     }
     if (c.tid == 0) f.counts[2] = K;
     c.sync();
+    YP_MARK(2);
 
     // ---- gather survivors: RectInfo(x,y,w,h,conf,label) + tolist() int truncation
     ADAS_PAR_FOR(c, k, 0, K) {
@@ -391,6 +623,7 @@ ADAS_DEV void yolo_post_frame(const Ctx& c, const YoloPostCfg& cfg, const YoloPo
             f.det_xyxy_i[4 * k + q] = (int)t;
         }
     }
+    YP_MARK(3);
 }
 
 // ===========================================================================

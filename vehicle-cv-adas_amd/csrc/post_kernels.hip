@@ -6,6 +6,12 @@
 // Roofline: all HBM-bound by construction (2.82 MB fp32 head per v8 frame, 8.57 MB per v5 frame,
 // 365 KB of lane logits); at these sizes the honest KPI is us per frame.
 #include "common.h"
+#ifdef ADAS_YP_PROF
+__device__ unsigned long long g_yp_prof[8];
+extern "C" int adas_debug_yolo_prof(unsigned long long* out8) {
+    return hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_yp_prof), 64) == hipSuccess ? 0 : -1;
+}
+#endif
 #include "post_core.h"
 #include "track_core.h"
 #include <new>

@@ -363,6 +363,14 @@ ADAS_DEV int lap_pick(const int (&a)[NC], int k) {
 }
 
 template <int NC>
+ADAS_DEV double lap_pickd(const double (&a)[NC], int k) {
+    double r = a[0];
+#pragma unroll
+    for (int q = 1; q < NC; ++q) r = (k == q) ? a[q] : r;
+    return r;
+}
+
+template <int NC>
 ADAS_DEV void bt_lap_wave(const Ctx& c, const double* cost, int T, int D, double limit, int* x_row, int* y_col,
                           const LapLds& S) {
     if (c.tid < 64) {
@@ -391,8 +399,7 @@ ADAS_DEV void bt_lap_wave(const Ctx& c, const double* cost, int T, int D, double
                 for (;;) {
                     const double ui = S.u[i0];
                     const double* crow = cost + (size_t)i0 * D;
-                    double bv = DBL_MAX;
-                    int bi = 0x7fffffff;
+                    double lv = HUGE_VAL;  // this lane's smallest slack among its unused columns
 #pragma unroll
                     for (int k = 0; k < NC; ++k) {
                         const int j = lane + 64 * k;
@@ -402,23 +409,19 @@ ADAS_DEV void bt_lap_wave(const Ctx& c, const double* cost, int T, int D, double
                                 minv[k] = cur;
                                 way[k] = j0;
                             }
-                            if (minv[k] < bv || bi == 0x7fffffff) {
-                                bv = minv[k];
-                                bi = j;
-                            }
+                            lv = minv[k] < lv ? minv[k] : lv;
                         }
                     }
+                    // argmin with the lowest column on ties: wave minimum, then the first column that attains it
+                    const double gmin = wave_min_f64(lv);
+                    int j1 = -1;
 #pragma unroll
-                    for (int off = 1; off < 64; off <<= 1) {
-                        double ov = __shfl_xor(bv, off, 64);
-                        int oi = __shfl_xor(bi, off, 64);
-                        if (oi != 0x7fffffff && (bi == 0x7fffffff || ov < bv || (ov == bv && oi < bi))) {
-                            bv = ov;
-                            bi = oi;
-                        }
+                    for (int k = 0; k < NC; ++k) {
+                        const int j = lane + 64 * k;
+                        const unsigned long long m = __ballot(j <= D && !used[k] && minv[k] == gmin);
+                        if (j1 < 0 && m) j1 = __builtin_ctzll(m) + 64 * k;
                     }
-                    const double delta = bv;
-                    const int j1 = bi;
+                    const double delta = wave_read_f64(lap_pickd<NC>(minv, j1 >> 6), j1 & 63);  // the selected element's own value
 #pragma unroll
                     for (int k = 0; k < NC; ++k) {
                         const int j = lane + 64 * k;
@@ -434,7 +437,7 @@ ADAS_DEV void bt_lap_wave(const Ctx& c, const double* cost, int T, int D, double
                     if (lane == 0) S.u[r] += delta;
                     __builtin_amdgcn_wave_barrier();
                     j0 = j1;
-                    const int pj1 = __shfl(lap_pick<NC>(p, j1 >> 6), j1 & 63, 64);
+                    const int pj1 = wave_read_i32(lap_pick<NC>(p, j1 >> 6), j1 & 63);
                     if (j1 == D || pj1 < 0) break;
 #pragma unroll
                     for (int k = 0; k < NC; ++k)
@@ -443,9 +446,9 @@ ADAS_DEV void bt_lap_wave(const Ctx& c, const double* cost, int T, int D, double
                 }
                 int j = j0;  // augment along way[]
                 for (;;) {
-                    const int jp = __shfl(lap_pick<NC>(way, j >> 6), j & 63, 64);
+                    const int jp = wave_read_i32(lap_pick<NC>(way, j >> 6), j & 63);
                     const int jq = jp < 0 ? 0 : jp;
-                    const int pjp = __shfl(lap_pick<NC>(p, jq >> 6), jq & 63, 64);
+                    const int pjp = wave_read_i32(lap_pick<NC>(p, jq >> 6), jq & 63);
                     const int row = (jp < 0) ? r : pjp;
                     if (j == D) {
                         if (lane == 0) x_row[row] = -1;
