@@ -252,9 +252,8 @@ ADAS_DEV int nms_picki(const int (&a)[NC], int k) {
 }
 
 template <int NC>
-ADAS_DEV void yolo_nms_reference_wave(const Ctx& c, const double* lc0, const double* lc1, const double* lc2, const double* lc3,
-                                      const double* lsc, const double* larea, const int* lidx, int N, double iou_thr, int* keep,
-                                      int* n_keep) {
+ADAS_DEV void yolo_nms_reference_wave(const Ctx& c, double* lc0, double* lc1, double* lc2, double* lc3, const double* lsc,
+                                      double* larea, int* lidx, int N, double iou_thr, int* keep, int* n_keep) {
     if (c.tid < 64) {
         const int lane = c.tid;
         double c0[NC], c1[NC], c2[NC], c3[NC], sc[NC], ar[NC];
@@ -292,17 +291,19 @@ ADAS_DEV void yolo_nms_reference_wave(const Ctx& c, const double* lc0, const dou
             if (i != N - 1 && maxscore == 0.0) break;  // scores are >= 0: nothing can change any more
             const int li = i & 63, ki = i >> 6, lm = maxpos & 63, km = maxpos >> 6;
             const double tscore = wave_read_f64(nms_pick<NC>(sc, ki), li);
+            // Row broadcasts come from the LDS copy of the boxes/areas/indices (one uniform-address read each; picking a
+            // register slot by a run-time index costs NC selects per value), which lane 0 keeps in step with the "swap".
+            double i0, i1, i2, i3, ia;
             if (tscore < maxscore) {  // utils.py:218-231: rows "swapped" through a view (boxes + index copied one way only)
-                const double tarea = wave_read_f64(nms_pick<NC>(ar, ki), li);
-                const double m0 = wave_read_f64(nms_pick<NC>(c0, km), lm), m1 = wave_read_f64(nms_pick<NC>(c1, km), lm);
-                const double m2 = wave_read_f64(nms_pick<NC>(c2, km), lm), m3 = wave_read_f64(nms_pick<NC>(c3, km), lm);
-                const double ma = wave_read_f64(nms_pick<NC>(ar, km), lm);
-                const int mi = wave_read_i32(nms_picki<NC>(idx, km), lm);
+                const double tarea = larea[i];
+                i0 = lc0[maxpos]; i1 = lc1[maxpos]; i2 = lc2[maxpos]; i3 = lc3[maxpos];
+                ia = larea[maxpos];
+                const int mi = lidx[maxpos];
 #pragma unroll
                 for (int k = 0; k < NC; ++k)
                     if (lane == li && k == ki) {
-                        c0[k] = m0; c1[k] = m1; c2[k] = m2; c3[k] = m3;
-                        idx[k] = mi; sc[k] = maxscore; ar[k] = ma;
+                        c0[k] = i0; c1[k] = i1; c2[k] = i2; c3[k] = i3;
+                        idx[k] = mi; sc[k] = maxscore; ar[k] = ia;
                     }
 #pragma unroll
                 for (int k = 0; k < NC; ++k)
@@ -310,13 +311,21 @@ ADAS_DEV void yolo_nms_reference_wave(const Ctx& c, const double* lc0, const dou
                         sc[k] = tscore;
                         ar[k] = tarea;
                     }
+                if (lane == 0) {
+                    lc0[i] = i0; lc1[i] = i1; lc2[i] = i2; lc3[i] = i3;
+                    lidx[i] = mi;
+                    larea[i] = ia;
+                    larea[maxpos] = tarea;
+                }
+            } else {
+                i0 = lc0[i]; i1 = lc1[i]; i2 = lc2[i]; i3 = lc3[i];
+                ia = larea[i];
             }
-            const double i0 = wave_read_f64(nms_pick<NC>(c0, ki), li), i1 = wave_read_f64(nms_pick<NC>(c1, ki), li);
-            const double i2 = wave_read_f64(nms_pick<NC>(c2, ki), li), i3 = wave_read_f64(nms_pick<NC>(c3, ki), li);
-            const double ia = wave_read_f64(nms_pick<NC>(ar, ki), li);
 #pragma unroll
             for (int k = 0; k < NC; ++k) {
                 const int j = lane + 64 * k;
+                const bool live = j >= pos && j < N && sc[k] != 0.0;  // a suppressed box can only be "suppressed" again
+                if (__ballot(live) == 0) continue;
                 if (j >= pos && j < N) {
                     double xx1 = fmax(i1, c1[k]);
                     double yy1 = fmax(i0, c0[k]);
