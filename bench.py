@@ -219,7 +219,8 @@ def main():
     conv_ms, conv_flops, all_ms = 0.0, 0.0, 0.0
     by_kernel = {}
     for eng, dptr in ((pipe.det, d_det[0].ptr), (pipe.lane, d_lane[0].ptr)):
-        for li, (name, fl, kind, ms) in enumerate(eng.profile(dptr, S, iters=3)):
+        eng.profile(dptr, S, iters=3)            # the device idled while the stats were fetched: let the clocks come back first
+        for li, (name, fl, kind, ms) in enumerate(eng.profile(dptr, S, iters=10)):
             all_ms += ms
             if kind == 1:   # OP_CONV
                 conv_ms += ms
