@@ -14,7 +14,7 @@ load_pkg()
 M = importlib.import_module("adas_amd.models")
 
 
-def run_case(CE, H, W, cin, cout, k, s, act, res_mode, prec, batch=2, seed=0):
+def run_case(CE, H, W, cin, cout, k, s, act, res_mode, prec, batch=2, seed=0, expect_kernel=None):
     ws = M.SynthWeights(seed, gain=1.0)
     g = M.Graph("unit", 3, H, W, ws)
     x, c3 = g.input()
@@ -34,6 +34,9 @@ def run_case(CE, H, W, cin, cout, k, s, act, res_mode, prec, batch=2, seed=0):
     xin = rng.uniform(0, 1, (batch, 3, H, W)).astype(np.float32)
     e.engine_inference(xin)
     got = e.fetch_activation("test", batch)
+    if expect_kernel is not None:
+        kn = e.layer_kernel(e.layer_index("test"), batch)
+        assert expect_kernel in kn, (kn, expect_kernel)
     e.close(); os.remove(path)
     Wt = {k_: torch.from_numpy(v) for k_, v in ws.store.items()}
     with torch.no_grad():
@@ -184,6 +187,15 @@ def test_pointwise_kernel(CE, case):
     for hw in ((23, 37), (40, 56)):
         rel, mx = run_case(CE, hw[0], hw[1], cin, cout, 1, s, M.ACT_SILU, M.RES_NONE, "bf16")
         assert rel < 1e-2, (case, hw, rel, mx)
+
+
+@pytest.mark.parametrize("case", [(384, 256), (512, 256), (384, 272), (512, 512)], ids=str)
+def test_pointwise_kernel_split_output_ranges(CE, case):
+    """1x1 convs whose weight matrix exceeds the LDS budget (YOLOv8n model.8/9/21 cv2: 384|512 -> 256): the output tiles are
+    split into ranges over blockIdx.y, incl. an uneven split (17 tiles) and a 4-way one."""
+    cin, cout = case
+    rel, mx = run_case(CE, 20, 20, cin, cout, 1, 1, M.ACT_SILU, M.RES_NONE, "bf16", batch=3, expect_kernel="conv_pw_kernel")
+    assert rel < 1e-2, (case, rel, mx)
 
 
 @pytest.mark.parametrize("hw", [(80, 400), (160, 160), (40, 200), (46, 74), (15, 300), (20, 20)], ids=lambda s: f"{s[0]}x{s[1]}")

@@ -34,20 +34,26 @@ struct PwDev {
     int stride, Wo, HoWo, W, HW;  // stride-2 address mapping
     int act;
     int NT;                 // feature tiles (cout_pad16 / 16)
+    int NTL;                // feature tiles one workgroup owns (blockIdx.y selects the range; NT when the weights fit LDS whole)
     int mtiles;
 };
 
 template <int KS, bool TAIL>
 __global__ __launch_bounds__(512) void conv_pw_kernel(PwDev a) {
-    extern __shared__ __attribute__((aligned(16))) uint16_t wl[];  // [NT][KS][64][8]
+    extern __shared__ __attribute__((aligned(16))) uint16_t wl[];  // [NTL][KS][64][8]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lrow = lane & 15, kg = lane >> 4;
-    float* bl = reinterpret_cast<float*>(wl + (size_t)a.NT * KS * 512);  // [NT*16] bias, behind the weights
+    // feature tiles [nt0, nt0 + ntl) belong to this workgroup: layers whose whole weight matrix exceeds the LDS budget are
+    // split over blockIdx.y (the activations are then read once per range; on the small maps this happens they sit in L2)
+    const int nt0 = blockIdx.y * a.NTL;
+    const int ntl = a.NT - nt0 < a.NTL ? a.NT - nt0 : a.NTL;
+    float* bl = reinterpret_cast<float*>(wl + (size_t)a.NTL * KS * 512);  // [NTL*16] bias, behind the weights
     {   // weights: contiguous copy, 16 B per thread per trip; bias too (a global bias load inside the feature-tile loop
         // costs one exposed L2 round trip per tile: hipcc waits vmcnt(0) right behind it)
-        const int n16 = a.NT * KS * 64;
-        for (int i = tid; i < n16; i += 512) *reinterpret_cast<pu32x4*>(wl + (size_t)i * 8) = *reinterpret_cast<const pu32x4*>(a.wfrag + (size_t)i * 8);
-        for (int i = tid; i < a.NT * 16; i += 512) bl[i] = a.bias[i];   // bias is padded to 128 entries
+        const int n16 = ntl * KS * 64;
+        const uint16_t* wsrc = a.wfrag + (size_t)nt0 * KS * 512;
+        for (int i = tid; i < n16; i += 512) *reinterpret_cast<pu32x4*>(wl + (size_t)i * 8) = *reinterpret_cast<const pu32x4*>(wsrc + (size_t)i * 8);
+        for (int i = tid; i < ntl * 16; i += 512) bl[i] = a.bias[nt0 * 16 + i];   // bias is padded to a multiple of 128 entries
     }
     __syncthreads();
     const int tail_valid = a.cin - (KS - 1) * 32;  // channels that exist in the last K step
@@ -71,8 +77,8 @@ __global__ __launch_bounds__(512) void conv_pw_kernel(PwDev a) {
         for (int ks = 0; ks < KS; ++ks) xb[ks] = __builtin_nontemporal_load(reinterpret_cast<const pu32x4*>(ip + ks * 32));
         if (tail_zero) xb[KS - 1] = pu32x4{0u, 0u, 0u, 0u};
 
-        const size_t obase = (size_t)(ok ? m : 0) * a.out_cs + a.out_coff + kg * 4;
-        for (int nt = 0; nt < a.NT; ++nt) {
+        const size_t obase = (size_t)(ok ? m : 0) * a.out_cs + a.out_coff + kg * 4 + nt0 * 16;
+        for (int nt = 0; nt < ntl; ++nt) {
             pf32x4 acc{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
@@ -80,7 +86,7 @@ __global__ __launch_bounds__(512) void conv_pw_kernel(PwDev a) {
                 acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(pbf16x8, wf), __builtin_bit_cast(pbf16x8, xb[ks]), acc, 0, 0, 0);
             }
             const int c = nt * 16 + kg * 4;
-            if (!ok || c >= a.cout) continue;
+            if (!ok || nt0 * 16 + c >= a.cout) continue;
             const float4 b4 = *reinterpret_cast<const float4*>(bl + c);
             float v[4] = {acc[0] + b4.x, acc[1] + b4.y, acc[2] + b4.z, acc[3] + b4.w};
             if (a.act == ACT_SILU) {
@@ -104,6 +110,15 @@ __global__ __launch_bounds__(512) void conv_pw_kernel(PwDev a) {
 
 static const int PW_MAX_LDS = 150 * 1024;
 
+// feature tiles per workgroup: all of them when the weights fit, otherwise an even split into at most 4 ranges
+static int pw_tiles_per_wg(int nt, int ks) {
+    for (int split = 1; split <= 4; ++split) {
+        const int ntl = (nt + split - 1) / split;
+        if ((size_t)ntl * ks * 1024 + (size_t)ntl * 64 <= (size_t)PW_MAX_LDS) return ntl;
+    }
+    return 0;
+}
+
 bool pw_applicable(int prec, int kh, int kw, int stride, int pad, int res_mode, const TView& in, const TView& out) {
     if (prec != PREC_BF16 || in.f32) return false;
     if (kh != 1 || kw != 1 || pad != 0 || (stride != 1 && stride != 2) || res_mode != RES_NONE) return false;
@@ -112,20 +127,19 @@ bool pw_applicable(int prec, int kh, int kw, int stride, int pad, int res_mode, 
     const int ks = (in.c + 31) / 32, nt = (out.c + 15) / 16;
     if (ks > 16) return false;
     if (!(ks <= 4 || ks == 6 || ks == 8 || ks == 12 || ks == 16)) return false;
-    if ((size_t)nt * ks * 1024 + (size_t)nt * 64 > (size_t)PW_MAX_LDS) return false;
-    return true;
+    return pw_tiles_per_wg(nt, ks) > 0;
 }
 
 template <int KS>
-static hipError_t pw_launch(const PwDev& d, bool tail, int grid, size_t lds, hipStream_t st) {
+static hipError_t pw_launch(const PwDev& d, bool tail, dim3 grid, size_t lds, hipStream_t st) {
     static bool attr_done = false;
     if (!attr_done) {
         (void)hipFuncSetAttribute((const void*)conv_pw_kernel<KS, false>, hipFuncAttributeMaxDynamicSharedMemorySize, PW_MAX_LDS);
         (void)hipFuncSetAttribute((const void*)conv_pw_kernel<KS, true>, hipFuncAttributeMaxDynamicSharedMemorySize, PW_MAX_LDS);
         attr_done = true;
     }
-    if (tail) hipLaunchKernelGGL((conv_pw_kernel<KS, true>), dim3(grid), dim3(512), lds, st, d);
-    else hipLaunchKernelGGL((conv_pw_kernel<KS, false>), dim3(grid), dim3(512), lds, st, d);
+    if (tail) hipLaunchKernelGGL((conv_pw_kernel<KS, true>), grid, dim3(512), lds, st, d);
+    else hipLaunchKernelGGL((conv_pw_kernel<KS, false>), grid, dim3(512), lds, st, d);
     return hipGetLastError();
 }
 
@@ -139,14 +153,19 @@ hipError_t launch_conv_pw(const ConvArgs& a, hipStream_t st) {
     const int ks = (a.in.c + 31) / 32;
     d.NT = (a.out.c + 15) / 16;
     d.mtiles = (a.m + 15) / 16;
-    const size_t lds = (size_t)d.NT * ks * 1024 + (size_t)d.NT * 64;
+    d.NTL = pw_tiles_per_wg(d.NT, ks);
+    if (d.NTL <= 0) return hipErrorNotSupported;
+    const int nsplit = (d.NT + d.NTL - 1) / d.NTL;
+    const size_t lds = (size_t)d.NTL * ks * 1024 + (size_t)d.NTL * 64;
     // persistent grid: as many 8-wave workgroups as fit the LDS budget of 256 CUs, never more than the work
     int per_cu = (int)((160 * 1024) / (lds > 4096 ? lds : 4096));
     if (per_cu > 4) per_cu = 4;
     if (per_cu < 1) per_cu = 1;
-    int grid = 256 * per_cu;
+    int gx = 256 * per_cu / nsplit;
+    if (gx < 1) gx = 1;
     const int need = (d.mtiles + 7) / 8;
-    if (grid > need) grid = need;
+    if (gx > need) gx = need;
+    const dim3 grid(gx, nsplit);
     const bool tail = (a.in.c & 31) != 0;
     switch (ks) {
         case 1: return pw_launch<1>(d, tail, grid, lds, st);
