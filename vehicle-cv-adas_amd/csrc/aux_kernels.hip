@@ -107,6 +107,53 @@ __global__ void maxpool_kernel(PoolDev d) {
         put8((T*)d.out + pix * d.out_cs + d.out_coff + c8 * 8, m);
     }
 }
+// bf16, compile-time window: every tap is loaded unconditionally from a clamped (always valid) address and out-of-image
+// taps are turned into -inf afterwards, so all K*K 16-byte loads of a thread are in flight together (a branch around a
+// load makes hipcc wait for it at the join: the generic kernel above pays K*K sequential L2 round trips).
+template <int K>
+__global__ void maxpool_bf16_kernel(PoolDev d) {
+    const int c8n = d.c >> 3;
+    size_t total = (size_t)d.n * d.Ho * d.Wo * c8n;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        int c8 = (int)(i % c8n);
+        size_t pix = i / c8n;
+        int ox = (int)(pix % d.Wo);
+        size_t t = pix / d.Wo;
+        int oy = (int)(t % d.Ho), b = (int)(t / d.Ho);
+        const uint16_t* base = (const uint16_t*)d.in + (size_t)b * d.H * d.W * d.in_cs + d.in_coff + c8 * 8;
+        uint4 v[K * K];
+#pragma unroll
+        for (int r = 0; r < K; ++r) {
+            const int iy = oy * d.s - d.p + r, iyc = iy < 0 ? 0 : (iy >= d.H ? d.H - 1 : iy);
+#pragma unroll
+            for (int q = 0; q < K; ++q) {
+                const int ix = ox * d.s - d.p + q, ixc = ix < 0 ? 0 : (ix >= d.W ? d.W - 1 : ix);
+                v[r * K + q] = *reinterpret_cast<const uint4*>(base + ((size_t)iyc * d.W + ixc) * d.in_cs);
+            }
+        }
+        float m[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) m[q] = -3.0e38f;
+#pragma unroll
+        for (int r = 0; r < K; ++r) {
+            const int iy = oy * d.s - d.p + r;
+#pragma unroll
+            for (int q = 0; q < K; ++q) {
+                const int ix = ox * d.s - d.p + q;
+                const bool in = (unsigned)iy < (unsigned)d.H && (unsigned)ix < (unsigned)d.W;
+                const uint4 u = v[r * K + q];
+                const uint32_t w[4] = {in ? u.x : 0xff80ff80u, in ? u.y : 0xff80ff80u, in ? u.z : 0xff80ff80u, in ? u.w : 0xff80ff80u};
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    m[2 * k] = fmaxf(m[2 * k], __uint_as_float(w[k] << 16));
+                    m[2 * k + 1] = fmaxf(m[2 * k + 1], __uint_as_float(w[k] & 0xffff0000u));
+                }
+            }
+        }
+        put8((uint16_t*)d.out + pix * d.out_cs + d.out_coff + c8 * 8, m);
+    }
+}
+
 hipError_t launch_maxpool(TView in, TView out, int n, int k, int s, int p, int prec, hipStream_t st_) {
     if (in.c != out.c || (in.c & 7) || ((in.cs | in.coff | out.cs | out.coff) & 7)) return hipErrorInvalidValue;
     PoolDev d{in.p, out.p, in.cs, in.coff, out.cs, out.coff, in.c, in.h, in.w, out.h, out.w, k, s, p, n};
@@ -114,6 +161,10 @@ hipError_t launch_maxpool(TView in, TView out, int n, int k, int s, int p, int p
     int blocks = (int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
     if (prec == PREC_FP32)
         hipLaunchKernelGGL(maxpool_kernel<float>, dim3(blocks), dim3(256), 0, st_, d);
+    else if (k == 5)
+        hipLaunchKernelGGL(maxpool_bf16_kernel<5>, dim3(blocks), dim3(256), 0, st_, d);
+    else if (k == 3)
+        hipLaunchKernelGGL(maxpool_bf16_kernel<3>, dim3(blocks), dim3(256), 0, st_, d);
     else
         hipLaunchKernelGGL(maxpool_kernel<uint16_t>, dim3(blocks), dim3(256), 0, st_, d);
     return hipGetLastError();
