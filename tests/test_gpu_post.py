@@ -197,6 +197,23 @@ def test_bytetrack_multi_stream_reset(G):
     trk.close()
 
 
+@pytest.mark.parametrize("n_obj,W,H", [(100, 1920, 1080), (220, 3840, 2160), (420, 7680, 4320)], ids=["d100", "d220", "d420"])
+def test_bytetrack_large_scenes(G, n_obj, W, H):
+    """Assignment problems of 64..511 columns take the register-resident solver with 2, 4 and 8 columns per lane
+    (track_core.h bt_lap_wave); ids, states and boxes must stay those of the oracle, frame by frame."""
+    frames = synth.track_scene(300 + n_obj, n_obj, 10, 0.08, W, H)
+    trk = G.PP.DeviceTracker(1, max_tracks=1024, max_dets=512)
+    ora = bytetrack.BYTETracker()
+    n_hi = 0
+    for f, fr in enumerate(frames):
+        trk.update_host(0, fr["boxes"], fr["scores"], fr["ids"])
+        want = ora.update(fr["boxes"], fr["scores"], fr["ids"])
+        pc.check_track_frame(G.track_snapshot(*trk.fetch(0)), want, ctx=(n_obj, f))
+        n_hi = max(n_hi, sum(1 for s in fr["scores"] if s > 0.5))
+    assert n_hi > (64 if n_obj == 100 else 128 if n_obj == 220 else 256)
+    trk.close()
+
+
 def test_detect_to_track_device_chain(G):
     """yolo_post survivors feed the tracker without leaving HBM; equals oracle post + oracle tracker."""
     lbp = yolo_post.letterbox_params((720, 1280), (640, 640))

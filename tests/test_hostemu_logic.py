@@ -128,3 +128,14 @@ def test_bytetrack_reset_and_random_vs_oracle():
             assert err == 0
             pc.check_track_frame(got, want, ctx=(rep, f))
         trk.reset(); ora.reset()
+
+
+def test_bytetrack_large_scene_logic():
+    """Same scenario family as the GPU test of the register-resident solver (here the block-wide form, one thread)."""
+    frames = synth.track_scene(400, 100, 8, 0.08, 1920, 1080)
+    trk = emu_api.Tracker(MT=512, MD=256)
+    ora = bytetrack.BYTETracker()
+    for f, fr in enumerate(frames):
+        got, err = trk.update(fr["boxes"], fr["scores"], fr["ids"])
+        assert err == 0
+        pc.check_track_frame(got, ora.update(fr["boxes"], fr["scores"], fr["ids"]), ctx=f)
