@@ -35,7 +35,8 @@ def _conv(x, W, name, s=1, p=None, act="silu"):
 
 
 # ------------------------------------------------------------------ YOLOv8
-V8_SCALES = {"n": (0.33, 0.25, 1024), "s": (0.33, 0.50, 1024), "m": (0.67, 0.75, 768), "l": (1.0, 1.0, 512)}
+V8_SCALES = {"n": (0.33, 0.25, 1024), "s": (0.33, 0.50, 1024), "m": (0.67, 0.75, 768), "l": (1.0, 1.0, 512),
+             "x": (1.0, 1.25, 512)}
 
 
 def _c2f(x, W, name, n, shortcut):
@@ -113,7 +114,7 @@ def yolov8_forward(x, W, scale="n", nc=80, taps=None):
 
 
 # ------------------------------------------------------------------ YOLOv5
-V5_SCALES = {"n": (0.33, 0.25), "s": (0.33, 0.50)}
+V5_SCALES = {"n": (0.33, 0.25), "s": (0.33, 0.50), "m": (0.67, 0.75), "l": (1.0, 1.0), "x": (1.33, 1.25)}
 V5_ANCHORS = [[10, 13, 16, 30, 33, 23], [30, 61, 62, 45, 59, 119], [116, 90, 156, 198, 373, 326]]
 
 

@@ -95,7 +95,7 @@ __device__ __forceinline__ float apply_act(float v, int act) {
     return v;
 }
 
-#define ADAS_MAX_Q 640  // K/8 chunks: 3*3*512/8 = 576, 4000/8 = 500
+#define ADAS_MAX_Q 1152  // K/8 chunks: 3*3*1024/8 (YOLOv8m/x and YOLOv5x reach 3*3*640/8 = 720; UFLDv2 cls.1 4000/8 = 500)
 
 struct ConvDev {
     const void* in;

@@ -313,7 +313,7 @@ def yolov8(scale="n", nc=80, imgsz=640, wsrc=None, seed=0):
 # =====================================================================================
 # YOLOv5 v6.2
 # =====================================================================================
-V5_SCALES = {"n": (0.33, 0.25), "s": (0.33, 0.50), "m": (0.67, 0.75), "l": (1.0, 1.0)}
+V5_SCALES = {"n": (0.33, 0.25), "s": (0.33, 0.50), "m": (0.67, 0.75), "l": (1.0, 1.0), "x": (1.33, 1.25)}
 V5_ANCHORS = [[10, 13, 16, 30, 33, 23], [30, 61, 62, 45, 59, 119], [116, 90, 156, 198, 373, 326]]  # yoloDetector.py:23
 
 
@@ -496,7 +496,9 @@ TUSIMPLE = dict(in_h=320, in_w=800, num_grid_row=100, num_cls_row=56, num_grid_c
 BUILDERS = {
     "yolov8n": lambda **k: yolov8("n", **k), "yolov8s": lambda **k: yolov8("s", **k),
     "yolov8m": lambda **k: yolov8("m", **k), "yolov8l": lambda **k: yolov8("l", **k),
+    "yolov8x": lambda **k: yolov8("x", **k),
     "yolov5n": lambda **k: yolov5("n", **k), "yolov5s": lambda **k: yolov5("s", **k),
+    "yolov5m": lambda **k: yolov5("m", **k), "yolov5l": lambda **k: yolov5("l", **k), "yolov5x": lambda **k: yolov5("x", **k),
     "ufldv2_res18": lambda **k: ufldv2("18", **k), "ufldv2_res34": lambda **k: ufldv2("34", **k),
     # Tusimple configuration (configs/tusimple_res18.py:28-35): 800x320 input, 100/100 grid cells, 56/41 anchors, no LayerNorm
     # UFLD v1 (ultrafastLaneDetector.py): Tusimple 100 cells x 56 anchors, CULane 200 x 18, both 800x288

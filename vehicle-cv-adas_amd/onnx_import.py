@@ -283,12 +283,12 @@ def detect_arch(m):
         o = outs[0]
         if c0[2] == 3 and o[2] > o[1]:                      # (1, 4+nc, A): YOLOv8/9/10-style head
             scale = {16: "n", 32: "s", 48: "m", 64: "l", 80: "x"}.get(c0[0])
-            if scale is None or scale == "x":
+            if scale is None:
                 raise ValueError("YOLOv8 width not supported: " + found)
             return "yolov8" + scale, dict(nc=o[1] - 4, imgsz=H)
         if c0[2] == 6 and o[1] > o[2]:                      # (1, A, 5+nc): YOLOv5 v6.x
-            scale = {16: "n", 32: "s", 48: "m", 64: "l"}.get(c0[0])
-            if scale not in ("n", "s"):
+            scale = {16: "n", 32: "s", 48: "m", 64: "l", 80: "x"}.get(c0[0])
+            if scale is None:
                 raise ValueError("YOLOv5 width not supported: " + found)
             return "yolov5" + scale, dict(nc=o[2] - 5, imgsz=H)
     raise ValueError("not a supported architecture: " + found)
