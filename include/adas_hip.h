@@ -175,6 +175,9 @@ int adas_ufld_decode_run(adas_ufld_decode* h, const float* d_loc_row, const floa
 /* lane order: left-side, left-ego, right-ego, right-side (ultrafastLaneDetectorV2.py:143-145).
  * points: [4][ADAS_UFLD_MAX_POINTS][2] (x,y) int32; counts[4]; detected[4]. */
 int adas_ufld_decode_fetch(adas_ufld_decode* h, int frame, int32_t* points, int32_t* counts, int32_t* detected);
+/* The inverse of fetch: places lane points decoded elsewhere into frame `frame`'s slot (same array shapes), e.g. to run
+ * adas_lane_geometry on them. */
+int adas_ufld_decode_upload(adas_ufld_decode* h, int frame, const int32_t* points, const int32_t* counts, const int32_t* detected);
 
 /* -----------------------------------------------------------------------------------
  * UFLD (v1) lane decode: replaces UltrafastLaneDetector.__process_output (ultrafastLaneDetector.py:96-139,
@@ -191,6 +194,37 @@ typedef struct {
 int adas_ufld1_decode_create(const adas_ufld1_params* p, int max_batch, adas_ufld_decode** out);
 int adas_ufld1_decode_set_source_size(adas_ufld_decode* h, int src_w, int src_h);
 int adas_ufld1_decode_run(adas_ufld_decode* h, const float* d_out, size_t batch_stride, int batch, void* stream);
+
+/* -----------------------------------------------------------------------------------
+ * Ego-lane geometry on the decoder's device-resident points: replaces
+ * LaneDetectBase.__update_lanes_status / __update_lanes_area / __adjust_lanes_points (ufldDetector/core.py:102-158),
+ * PerspectiveTransformation.transformToBirdViewPoints and .calcCurveAndOffset (perspectiveTransformation.py:120-214,
+ * without the drawing calls).  The homography itself stays a host decision (updateTransformParams, :39-86).
+ * ----------------------------------------------------------------------------------- */
+typedef struct adas_lane_geometry adas_lane_geometry;
+typedef struct {
+    int32_t img_h;         /* source frame height = resampling count of __adjust_lanes_points (core.py:130) */
+    int32_t bird_w, bird_h; /* PerspectiveTransformation.img_size (bird-view image); bird_h must exceed 719 for the curvature
+                              (the reference reads row 719, perspectiveTransformation.py:196-199) */
+    int32_t adjust_lanes;  /* default for run() */
+    double M[9];           /* frontal -> bird-view homography, row-major (cv2.getPerspectiveTransform, :33) */
+} adas_lane_geometry_params;
+typedef struct {
+    int32_t area_status;          /* both ego lanes detected (core.py:143-148) */
+    int32_t n_area_left, n_area_right; /* area_points = left points then the reversed right points (core.py:158) */
+    int32_t direction;            /* 0: no curve estimate, 1 "L", 2 "R", 3 "F" (perspectiveTransformation.py:170-175) */
+    int32_t bird_counts[4];       /* points per lane in the bird view */
+    double curvature;             /* metres (:193) */
+    double offset;                /* metres from the lane centre (:201-202) */
+} adas_lane_geometry_result;
+int adas_lane_geometry_create(const adas_lane_geometry_params* p, int max_batch, adas_lane_geometry** out);
+int adas_lane_geometry_destroy(adas_lane_geometry* h);
+int adas_lane_geometry_set_matrix(adas_lane_geometry* h, const double* M9);
+/* Reads the lane points the decoder (v1 or v2 handle) left in HBM for frames [0, batch). Asynchronous. */
+int adas_lane_geometry_run(adas_lane_geometry* h, const adas_ufld_decode* decode, int adjust_lanes, int batch, void* stream);
+/* area_points: room for [2*img_h][2] int32 (x,y); bird_points: [4][ADAS_UFLD_MAX_POINTS][2]; either may be NULL. */
+int adas_lane_geometry_fetch(adas_lane_geometry* h, int frame, adas_lane_geometry_result* res, int32_t* area_points,
+                             int32_t* bird_points);
 
 /* ===================================================================================
  * ByteTrack: replaces BYTETracker.__init__/update/reset (byteTracker.py:30-51,62-185,187-200)

@@ -13,7 +13,7 @@ BTOUT = np.dtype([("tlwh", "f8", 4), ("score", "f8"), ("track_id", "i4"), ("stat
 
 
 def build():
-    deps = [SRC, os.path.join(INC, "post_core.h"), os.path.join(INC, "track_core.h")]
+    deps = [SRC, os.path.join(INC, "post_core.h"), os.path.join(INC, "track_core.h"), os.path.join(INC, "lane_core.h")]
     if os.path.exists(OUT) and all(os.path.getmtime(OUT) >= os.path.getmtime(d) for d in deps):
         return OUT
     os.makedirs(os.path.dirname(OUT), exist_ok=True)
@@ -81,6 +81,23 @@ def ufld1(head, cfg, input_wh, src_wh):
     lib().emu_ufld1(_p(out), cfg.griding_num, cfg.cls_num_per_lane, cfg.img_w, cfg.img_h, input_wh[0], input_wh[1],
                     src_wh[0], src_wh[1], _p(ra), _p(cnt), _p(det), _p(pts))
     return [[(int(x), int(y)) for x, y in pts[i, :cnt[i]]] for i in range(4)], [bool(d) for d in det]
+
+
+def lane_geometry(lanes, status, img_h, bird_wh, M, adjust=True):
+    """lanes: 4 lists of (x, y); status: 4 bools (a lane decoder's output)."""
+    cnt = np.asarray([len(l) for l in lanes], np.int32); det = np.asarray([1 if s else 0 for s in status], np.int32)
+    pts = np.zeros((4, 128, 2), np.int32)
+    for i, l in enumerate(lanes):
+        if len(l):
+            pts[i, :len(l)] = np.asarray(l, np.int32)
+    hdr = np.zeros(8, np.int32); vals = np.zeros(2); area = np.zeros((2 * img_h, 2), np.int32); bird = np.zeros((4, 128, 2), np.int32)
+    m = np.ascontiguousarray(M, np.float64).reshape(9)
+    lib().emu_lane_geometry(_p(cnt), _p(det), _p(pts), int(img_h), int(bird_wh[0]), int(bird_wh[1]), 1 if adjust else 0, _p(m),
+                            _p(hdr), _p(vals), _p(area), _p(bird))
+    n = int(hdr[1] + hdr[2])
+    return dict(area_status=bool(hdr[0]), area_points=area[:n].copy(), n_left=int(hdr[1]), n_right=int(hdr[2]),
+                bird_points=[bird[i, :cnt[i]].copy() for i in range(4)], direction=(None, "L", "R", "F")[hdr[3]],
+                curvature=float(vals[0]) if hdr[3] else None, offset=float(vals[1]) if hdr[3] else None)
 
 
 class Tracker:

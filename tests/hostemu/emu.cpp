@@ -8,6 +8,7 @@
 #include <vector>
 #include "post_core.h"
 #include "track_core.h"
+#include "lane_core.h"
 using namespace adas;
 
 extern "C" {
@@ -57,6 +58,20 @@ int emu_ufld1(const float* out, int G, int K, int cfg_w, int cfg_h, int in_w, in
     std::vector<double> lds((size_t)K * 4 + 16);
     Ctx c{0, 1};
     ufld1_decode_frame(c, cfg, out, lane_cnt, lane_det, lane_pts, lds.data());
+    return 0;
+}
+
+int emu_lane_geometry(const int* lane_cnt, const int* lane_det, const int* lane_pts, int img_h, int bird_w, int bird_h, int adjust,
+                       const double* M, int* hdr, double* vals, int* area, int* bird) {
+    LaneGeomCfg cfg;
+    cfg.img_h = img_h; cfg.bird_w = bird_w; cfg.bird_h = bird_h; cfg.adjust = adjust;
+    for (int i = 0; i < 9; ++i) cfg.M[i] = M[i];
+    std::vector<double> fx(2 * (size_t)img_h);
+    std::vector<int> idx(2 * (size_t)img_h);
+    LaneGeomFrame f{lane_cnt, lane_det, lane_pts, hdr, vals, area, bird, fx.data(), idx.data()};
+    std::vector<double> lds(lane_lds_bytes(img_h, bird_h) / 8 + 2);
+    Ctx c{0, 1};
+    lane_geometry_frame(c, cfg, f, lds.data());
     return 0;
 }
 

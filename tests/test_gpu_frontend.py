@@ -96,6 +96,32 @@ def test_lane_detector_dropin():
     ld.close(); eng.close()
 
 
+def test_lane_detector_device_geometry():
+    """enable_device_geometry: area polygon / bird-view points / curvature from the device equal the host route
+    (LaneInfo from the decoder + PerspectiveTransformation on the host), frame by frame."""
+    A = importlib.import_module("adas_amd.analysis")
+    path, W, g = netutil.model("ufldv2_res18")
+    ld_host = D.UltrafastLaneDetectorV2(path, D.LaneModelType.UFLDV2_CULANE, precision="fp32")
+    ld_dev = D.UltrafastLaneDetectorV2(path, D.LaneModelType.UFLDV2_CULANE, precision="fp32")
+    tv = A.PerspectiveTransformation((1280, 720))
+    ld_dev.enable_device_geometry(tv)
+    for f in frames(2, 720, 1280, 21):
+        ld_host.DetectFrame(f)
+        ld_dev.DetectFrame(f)
+        assert ld_dev.lane_info.area_status == ld_host.lane_info.area_status
+        a, b = np.asarray(ld_dev.lane_info.area_points, np.int64).reshape(-1, 2), np.asarray(ld_host.lane_info.area_points, np.int64).reshape(-1, 2)
+        assert a.shape == b.shape and np.abs(a - b).max(initial=0) <= 1
+        bird = [np.asarray(tv.transformToBirdViewPoints(l), np.int64).reshape(-1, 2) for l in ld_host.lane_info.lanes_points]
+        for i in range(4):
+            np.testing.assert_array_equal(np.asarray(ld_dev.birdview_lanes_points[i], np.int64).reshape(-1, 2), bird[i])
+        (d, c), off = tv.calcCurveAndOffset((720, 1280), bird[1], bird[2])
+        (d2, c2), off2 = ld_dev.curve_and_offset
+        assert d2 == d
+        if d is not None:
+            assert c2 == pytest.approx(c, rel=1e-7) and off2 == pytest.approx(off, rel=1e-7, abs=1e-9)
+    ld_host.close(); ld_dev.close()
+
+
 def test_lane_detector_v1_dropin():
     """UltrafastLaneDetector (UFLD v1): device pre-processing (plain resize, crop_ratio 1) + network + v1 decode vs the
     oracle chain on the same engine's logits; two source sizes so w_ratio/h_ratio (ultrafastLaneDetector.py:80) change."""

@@ -239,3 +239,54 @@ def test_detect_to_track_device_chain(G):
             pc.check_track_frame(G.track_snapshot(*trk.fetch(s)), want, ctx=(s, f))
         buf.free()
     yp.close(); trk.close()
+
+
+# ------------------------------------------------------------------------------------------------ lane geometry (f2)
+def _geometry(G, lanes, status, W, H, M, adjust, decode_outs=None):
+    """Device geometry on lane points that are either decoded on the device from `decode_outs` or uploaded."""
+    cfg = ufld_decode.ModelConfig("culane")
+    if decode_outs is not None:
+        lr, lc = decode_outs[0], decode_outs[1]
+        ud = G.PP.UfldDecode(lr.shape[1], lr.shape[2], lc.shape[1], lc.shape[2], W, H, cfg.row_anchor, cfg.col_anchor, 1)
+        ud.run_host(decode_outs)
+    else:
+        ud = G.PP.UfldDecode(200, 72, 100, 81, W, H, cfg.row_anchor, cfg.col_anchor, 1)
+        ud.upload(lanes, status)
+    lg = G.PP.LaneGeometry(H, (W, H), M, adjust)
+    try:
+        lg.run(ud, adjust)
+        return lg.fetch(0)
+    finally:
+        lg.close(); ud.close()
+
+
+@pytest.mark.parametrize("case", synth.ufld_cases(), ids=lambda c: c[0])
+@pytest.mark.parametrize("adjust", [True, False])
+def test_lane_geometry_on_device_decoded_lanes(G, case, adjust):
+    """decode -> area polygon / bird view / curvature without leaving the device, vs the host mirror of the reference."""
+    import test_hostemu_logic as TH
+    import importlib
+    A = importlib.import_module("adas_amd.analysis")
+    tag, outs, W, H = case
+    cfg = ufld_decode.ModelConfig("culane")
+    dev_lanes, dev_status = G.ufld(outs, cfg, W, H)             # what the device decoder hands to the geometry kernel
+    M = A.PerspectiveTransformation((W, H)).M
+    got = _geometry(G, None, None, W, H, M, adjust, decode_outs=outs)
+    TH.check_geometry(got, TH._geometry_reference(dev_lanes, dev_status, W, H, M, adjust))
+
+
+def test_lane_geometry_reference_goldens_on_device(G):
+    with gzip.open(os.path.join(GOLDEN, "analysis.json.gz"), "rt") as f:
+        g = json.load(f)["perspective"]
+    lanes = [[], [tuple(p) for p in g["left"]], [tuple(p) for p in g["right"]], []]
+    for st in g["steps"]:
+        got = _geometry(G, lanes, [False, True, True, False], 1280, 720, st["M"], True)
+        np.testing.assert_array_equal(got["bird_points"][1], np.array(st["bird_left"]))
+        np.testing.assert_array_equal(got["bird_points"][2], np.array(st["bird_right"]))
+        assert got["direction"] == st["direction"]
+        assert got["curvature"] == pytest.approx(st["curvature"], rel=1e-7) and got["offset"] == pytest.approx(st["offset"], rel=1e-7, abs=1e-9)
+    cv = g["curvy"]
+    lanes = [[], [tuple(p) for p in cv["left"]], [tuple(p) for p in cv["right"]], []]
+    got = _geometry(G, lanes, [False, True, True, False], 1280, 720, np.eye(3), False)
+    assert got["direction"] == cv["direction"] and got["curvature"] == pytest.approx(cv["curvature"], rel=1e-7)
+    assert got["offset"] == pytest.approx(cv["offset"], rel=1e-7)

@@ -139,3 +139,70 @@ def test_bytetrack_large_scene_logic():
         got, err = trk.update(fr["boxes"], fr["scores"], fr["ids"])
         assert err == 0
         pc.check_track_frame(got, ora.update(fr["boxes"], fr["scores"], fr["ids"]), ctx=f)
+
+
+# ------------------------------------------------------------------------------------------------ lane geometry (f2)
+def _geometry_reference(lanes, status, W, H, M, adjust=True):
+    """The host mirror of the reference's lane geometry (analysis.py / oracle), pinned by tests/test_analysis.py and
+    tests/test_oracle_golden.py against the reference's own runs."""
+    import importlib
+    from conftest import load_pkg
+    load_pkg()
+    A = importlib.import_module("adas_amd.analysis")
+    st, area = ufld_decode.lanes_area(lanes, status, H, adjust=adjust)
+    tv = A.PerspectiveTransformation((W, H))
+    tv.M = np.asarray(M, np.float64).reshape(3, 3)
+    bird = [np.asarray(tv.transformToBirdViewPoints(l), np.int64).reshape(-1, 2) for l in lanes]
+    try:
+        (d, cv), off = tv.calcCurveAndOffset((H, W), bird[1], bird[2])
+    except IndexError:          # bird view lower than 720 rows: the reference reads row 719 (perspectiveTransformation.py:196)
+        d, cv, off = None, None, None      # the device routine reports "no estimate" there
+    return st, np.asarray(area, np.int64).reshape(-1, 2), bird, d, cv, off
+
+
+def check_geometry(got, want, max_off_points=2):
+    st, area, bird, d, cv, off = want
+    assert got["area_status"] == st
+    assert got["area_points"].shape == area.shape
+    diff = np.abs(got["area_points"].astype(np.int64) - area)
+    assert diff.max(initial=0) <= 1 and int((diff > 0).sum()) <= max_off_points     # QR vs LAPACK SVD at an integer boundary
+    for i in range(4):
+        np.testing.assert_array_equal(got["bird_points"][i], bird[i])
+    assert got["direction"] == d
+    if d is not None:
+        assert got["curvature"] == pytest.approx(cv, rel=1e-7) and got["offset"] == pytest.approx(off, rel=1e-7, abs=1e-9)
+
+
+@pytest.mark.parametrize("case", synth.ufld_cases(), ids=lambda c: c[0])
+@pytest.mark.parametrize("adjust", [True, False])
+def test_lane_geometry_on_decoded_lanes(case, adjust):
+    import importlib
+    from conftest import load_pkg
+    load_pkg()
+    A = importlib.import_module("adas_amd.analysis")
+    tag, outs, W, H = case
+    lanes, status = ufld_decode.process_output(outs, ufld_decode.ModelConfig("culane"), W, H)
+    M = A.PerspectiveTransformation((W, H)).M
+    got = emu_api.lane_geometry(lanes, status, H, (W, H), M, adjust)
+    check_geometry(got, _geometry_reference(lanes, status, W, H, M, adjust))
+
+
+def test_lane_geometry_reference_goldens():
+    """Bird-view points, direction, curvature and offset of the reference's own PerspectiveTransformation runs
+    (tests/golden/analysis.json.gz), through the device routine."""
+    with gzip.open(os.path.join(GOLDEN, "analysis.json.gz"), "rt") as f:
+        g = json.load(f)["perspective"]
+    lanes = [[], [tuple(p) for p in g["left"]], [tuple(p) for p in g["right"]], []]
+    for st in g["steps"]:
+        got = emu_api.lane_geometry(lanes, [False, True, True, False], 720, (1280, 720), st["M"], True)
+        np.testing.assert_array_equal(got["bird_points"][1], np.array(st["bird_left"]))
+        np.testing.assert_array_equal(got["bird_points"][2], np.array(st["bird_right"]))
+        assert got["direction"] == st["direction"]
+        assert got["curvature"] == pytest.approx(st["curvature"], rel=1e-7) and got["offset"] == pytest.approx(st["offset"], rel=1e-7, abs=1e-9)
+    cv = g["curvy"]   # bird-view lanes given directly: identity homography
+    lanes = [[], [tuple(p) for p in cv["left"]], [tuple(p) for p in cv["right"]], []]
+    got = emu_api.lane_geometry(lanes, [False, True, True, False], 720, (1280, 720), np.eye(3), False)
+    assert got["direction"] == cv["direction"] and got["curvature"] == pytest.approx(cv["curvature"], rel=1e-7)
+    assert got["offset"] == pytest.approx(cv["offset"], rel=1e-7)
+    empty = emu_api.lane_geometry([[], [], [], []], [False] * 4, 720, (1280, 720), np.eye(3), True)
+    assert empty["direction"] is None and not empty["area_status"] and len(empty["area_points"]) == 0

@@ -45,6 +45,15 @@ class Ufld1Params(C.Structure):
                 ("h_row_anchor", C.c_void_p)]
 
 
+class LaneGeometryParams(C.Structure):
+    _fields_ = [("img_h", C.c_int32), ("bird_w", C.c_int32), ("bird_h", C.c_int32), ("adjust_lanes", C.c_int32), ("M", C.c_double * 9)]
+
+
+class LaneGeometryResult(C.Structure):
+    _fields_ = [("area_status", C.c_int32), ("n_area_left", C.c_int32), ("n_area_right", C.c_int32), ("direction", C.c_int32),
+                ("bird_counts", C.c_int32 * 4), ("curvature", C.c_double), ("offset", C.c_double)]
+
+
 class BytetrackParams(C.Structure):
     _fields_ = [("track_thresh", C.c_double), ("match_thresh", C.c_double), ("frame_rate", C.c_double),
                 ("track_buffer", C.c_int32), ("max_tracks", C.c_int32), ("max_dets", C.c_int32), ("reserved", C.c_int32)]
@@ -102,9 +111,15 @@ _SIGS = {
     "adas_ufld_decode_destroy": (C.c_int, [_P]),
     "adas_ufld_decode_run": (C.c_int, [_P, _P, _P, _P, _P, C.c_size_t, C.c_size_t, C.c_size_t, C.c_size_t, C.c_int, _P]),
     "adas_ufld_decode_fetch": (C.c_int, [_P, C.c_int, _P, _P, _P]),
+    "adas_ufld_decode_upload": (C.c_int, [_P, C.c_int, _P, _P, _P]),
     "adas_ufld1_decode_create": (C.c_int, [C.POINTER(Ufld1Params), C.c_int, C.POINTER(_P)]),
     "adas_ufld1_decode_set_source_size": (C.c_int, [_P, C.c_int, C.c_int]),
     "adas_ufld1_decode_run": (C.c_int, [_P, _P, C.c_size_t, C.c_int, _P]),
+    "adas_lane_geometry_create": (C.c_int, [C.POINTER(LaneGeometryParams), C.c_int, C.POINTER(_P)]),
+    "adas_lane_geometry_destroy": (C.c_int, [_P]),
+    "adas_lane_geometry_set_matrix": (C.c_int, [_P, _P]),
+    "adas_lane_geometry_run": (C.c_int, [_P, _P, C.c_int, C.c_int, _P]),
+    "adas_lane_geometry_fetch": (C.c_int, [_P, C.c_int, C.POINTER(LaneGeometryResult), _P, _P]),
     "adas_bytetrack_create": (C.c_int, [C.POINTER(BytetrackParams), C.c_int, C.POINTER(_P)]),
     "adas_bytetrack_destroy": (C.c_int, [_P]),
     "adas_bytetrack_reset": (C.c_int, [_P, C.c_int]),

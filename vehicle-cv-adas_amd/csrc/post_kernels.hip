@@ -14,6 +14,7 @@ extern "C" int adas_debug_yolo_prof(unsigned long long* out8) {
 #endif
 #include "post_core.h"
 #include "track_core.h"
+#include "lane_core.h"
 #include <new>
 #include <string.h>
 #include <vector>
@@ -203,6 +204,34 @@ __global__ __launch_bounds__(256) void ufld1_decode_kernel(Ufld1Dev d) {
                        d.lane_pts + (size_t)b * 4 * ADAS_UFLD_MAXPTS * 2, smem);
 }
 
+struct LaneGeomDev {
+    LaneGeomCfg cfg;
+    const int *lane_cnt, *lane_det, *lane_pts;  // the decoder's arrays
+    int* hdr;       // [B][8]
+    double* vals;   // [B][2]
+    int* area;      // [B][2*img_h][2]
+    int* bird;      // [B][4][MAXPTS][2]
+    double* fx;     // [B][2*img_h]
+    int* idx;       // [B][2*img_h]
+};
+
+__global__ __launch_bounds__(256) void lane_geometry_kernel(LaneGeomDev d) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const size_t b = blockIdx.x, H = d.cfg.img_h;
+    LaneGeomFrame f;
+    f.lane_cnt = d.lane_cnt + b * 4;
+    f.lane_det = d.lane_det + b * 4;
+    f.lane_pts = d.lane_pts + b * 4 * ADAS_LANE_MAXPTS * 2;
+    f.hdr = d.hdr + b * 8;
+    f.vals = d.vals + b * 2;
+    f.area = d.area + b * 4 * H;
+    f.bird = d.bird + b * 4 * ADAS_LANE_MAXPTS * 2;
+    f.fx = d.fx + b * 2 * H;
+    f.idx = d.idx + b * 2 * H;
+    Ctx c{(int)threadIdx.x, (int)blockDim.x};
+    lane_geometry_frame(c, d.cfg, f, smem);
+}
+
 // -------------------------------------------------------------------------------------
 struct BtDev {
     BtParams P;
@@ -268,6 +297,12 @@ struct adas_ufld_decode {
     int v1;  // created by adas_ufld1_decode_create
     UfldDev dev;
     Ufld1Dev dev1;
+    void* arena;
+    hipStream_t last;
+};
+struct adas_lane_geometry {
+    int max_batch;
+    LaneGeomDev dev;
     void* arena;
     hipStream_t last;
 };
@@ -565,6 +600,99 @@ int adas_ufld_decode_fetch(adas_ufld_decode* h, int frame, int32_t* points, int3
     if (points) ADAS_HIP_TRY(hipMemcpy(points, d.lane_pts + (size_t)frame * 4 * ADAS_UFLD_MAXPTS * 2, 4 * ADAS_UFLD_MAXPTS * 2 * 4, hipMemcpyDeviceToHost));
     if (counts) ADAS_HIP_TRY(hipMemcpy(counts, d.lane_cnt + frame * 4, 16, hipMemcpyDeviceToHost));
     if (detected) ADAS_HIP_TRY(hipMemcpy(detected, d.lane_det + frame * 4, 16, hipMemcpyDeviceToHost));
+    return ADAS_OK;
+}
+
+int adas_ufld_decode_upload(adas_ufld_decode* h, int frame, const int32_t* points, const int32_t* counts, const int32_t* detected) {
+    ADAS_REQUIRE(h && points && counts && detected && frame >= 0 && frame < h->max_batch, ADAS_ERR_INVALID, "adas_ufld_decode_upload: bad argument");
+    for (int l = 0; l < 4; ++l)
+        ADAS_REQUIRE(counts[l] >= 0 && counts[l] <= ADAS_UFLD_MAXPTS, ADAS_ERR_INVALID, "lane %d: %d points (max %d)", l, counts[l], ADAS_UFLD_MAXPTS);
+    ADAS_HIP_TRY(hipStreamSynchronize(h->last));
+    const UfldDev& d = h->dev;
+    ADAS_HIP_TRY(hipMemcpy(d.lane_pts + (size_t)frame * 4 * ADAS_UFLD_MAXPTS * 2, points, 4 * ADAS_UFLD_MAXPTS * 2 * 4, hipMemcpyHostToDevice));
+    ADAS_HIP_TRY(hipMemcpy(d.lane_cnt + frame * 4, counts, 16, hipMemcpyHostToDevice));
+    ADAS_HIP_TRY(hipMemcpy(d.lane_det + frame * 4, detected, 16, hipMemcpyHostToDevice));
+    return ADAS_OK;
+}
+
+// ------------------------------------------------------------------------------- lane geometry
+int adas_lane_geometry_create(const adas_lane_geometry_params* p, int max_batch, adas_lane_geometry** out) {
+    ADAS_REQUIRE(p && out && max_batch > 0, ADAS_ERR_INVALID, "adas_lane_geometry_create: bad argument");
+    ADAS_REQUIRE(p->img_h >= 8 && p->img_h <= 4320 && p->bird_h >= 8 && p->bird_h <= 4320 && p->bird_w > 0, ADAS_ERR_INVALID,
+                 "image heights must be in [8, 4320]");
+    ADAS_REQUIRE(adas_device_count() > 0, ADAS_ERR_NO_DEVICE, "no HIP device visible; this library has no CPU fallback");
+    const size_t lds = lane_lds_bytes(p->img_h, p->bird_h);
+    ADAS_REQUIRE(lds <= 150 * 1024, ADAS_ERR_CAPACITY, "image height %d needs %zu bytes of LDS", p->img_h > p->bird_h ? p->img_h : p->bird_h, lds);
+    adas_lane_geometry* h = new (std::nothrow) adas_lane_geometry();
+    ADAS_REQUIRE(h, ADAS_ERR_INVALID, "out of host memory");
+    h->max_batch = max_batch;
+    h->last = 0;
+    const size_t B = max_batch, H = p->img_h;
+    size_t bytes = B * (8 * 4 + 2 * 8 + 4 * H * 4 + 4 * ADAS_LANE_MAXPTS * 2 * 4 + 2 * H * 8 + 2 * H * 4) + 16 * 256;
+    if (hipMalloc(&h->arena, bytes) != hipSuccess) {
+        delete h;
+        return hip_fail(hipGetLastError(), "hipMalloc(lane geometry arena)", __FILE__, __LINE__);
+    }
+    hipMemset(h->arena, 0, bytes);
+    unsigned char* q = (unsigned char*)h->arena;
+    LaneGeomDev& d = h->dev;
+    d.cfg.img_h = p->img_h; d.cfg.bird_w = p->bird_w; d.cfg.bird_h = p->bird_h; d.cfg.adjust = p->adjust_lanes ? 1 : 0;
+    for (int i = 0; i < 9; ++i) d.cfg.M[i] = p->M[i];
+    d.vals = carve<double>(q, B * 2);
+    d.fx = carve<double>(q, B * 2 * H);
+    d.hdr = carve<int>(q, B * 8);
+    d.area = carve<int>(q, B * 4 * H);
+    d.bird = carve<int>(q, B * 4 * ADAS_LANE_MAXPTS * 2);
+    d.idx = carve<int>(q, B * 2 * H);
+    if (hipFuncSetAttribute((const void*)lane_geometry_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) != hipSuccess) {
+        hipFree(h->arena);
+        delete h;
+        return hip_fail(hipGetLastError(), "hipFuncSetAttribute(lane_geometry_kernel)", __FILE__, __LINE__);
+    }
+    *out = h;
+    return ADAS_OK;
+}
+int adas_lane_geometry_destroy(adas_lane_geometry* h) {
+    if (!h) return ADAS_OK;
+    hipFree(h->arena);
+    delete h;
+    return ADAS_OK;
+}
+int adas_lane_geometry_set_matrix(adas_lane_geometry* h, const double* M9) {
+    ADAS_REQUIRE(h && M9, ADAS_ERR_INVALID, "adas_lane_geometry_set_matrix: bad argument");
+    for (int i = 0; i < 9; ++i) h->dev.cfg.M[i] = M9[i];
+    return ADAS_OK;
+}
+int adas_lane_geometry_run(adas_lane_geometry* h, const adas_ufld_decode* decode, int adjust_lanes, int batch, void* stream) {
+    ADAS_REQUIRE(h && decode && batch > 0 && batch <= h->max_batch && batch <= decode->max_batch, ADAS_ERR_INVALID,
+                 "adas_lane_geometry_run: bad argument");
+    hipStream_t st = (hipStream_t)stream;
+    h->last = st;
+    LaneGeomDev d = h->dev;
+    d.cfg.adjust = adjust_lanes ? 1 : 0;
+    d.lane_cnt = decode->dev.lane_cnt;
+    d.lane_det = decode->dev.lane_det;
+    d.lane_pts = decode->dev.lane_pts;
+    hipLaunchKernelGGL(lane_geometry_kernel, dim3(batch), dim3(256), lane_lds_bytes(d.cfg.img_h, d.cfg.bird_h), st, d);
+    ADAS_HIP_TRY(hipGetLastError());
+    return ADAS_OK;
+}
+int adas_lane_geometry_fetch(adas_lane_geometry* h, int frame, adas_lane_geometry_result* res, int32_t* area_points, int32_t* bird_points) {
+    ADAS_REQUIRE(h && res && frame >= 0 && frame < h->max_batch, ADAS_ERR_INVALID, "adas_lane_geometry_fetch: bad argument");
+    ADAS_HIP_TRY(hipStreamSynchronize(h->last));
+    const LaneGeomDev& d = h->dev;
+    int hdr[8];
+    double vals[2];
+    ADAS_HIP_TRY(hipMemcpy(hdr, d.hdr + (size_t)frame * 8, sizeof(hdr), hipMemcpyDeviceToHost));
+    ADAS_HIP_TRY(hipMemcpy(vals, d.vals + (size_t)frame * 2, sizeof(vals), hipMemcpyDeviceToHost));
+    res->area_status = hdr[0]; res->n_area_left = hdr[1]; res->n_area_right = hdr[2]; res->direction = hdr[3];
+    for (int l = 0; l < 4; ++l) res->bird_counts[l] = hdr[4 + l];
+    res->curvature = vals[0]; res->offset = vals[1];
+    const size_t H = d.cfg.img_h;
+    if (area_points && hdr[1] + hdr[2] > 0)
+        ADAS_HIP_TRY(hipMemcpy(area_points, d.area + (size_t)frame * 4 * H, (size_t)(hdr[1] + hdr[2]) * 8, hipMemcpyDeviceToHost));
+    if (bird_points)
+        ADAS_HIP_TRY(hipMemcpy(bird_points, d.bird + (size_t)frame * 4 * ADAS_LANE_MAXPTS * 2, 4 * ADAS_LANE_MAXPTS * 2 * 4, hipMemcpyDeviceToHost));
     return ADAS_OK;
 }
 

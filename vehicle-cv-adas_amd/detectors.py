@@ -25,7 +25,7 @@ import numpy as np
 
 from . import _lib as L
 from .coreEngine import OnnxEngine, TensorRTEngine
-from .postproc import YoloPost, UfldDecode, Ufld1Decode, DeviceTracker, letterbox
+from .postproc import YoloPost, UfldDecode, Ufld1Decode, LaneGeometry, DeviceTracker, letterbox
 
 
 class ObjectModelType(Enum):       # ObjectDetector/utils.py:15-23
@@ -381,8 +381,40 @@ class UltrafastLaneDetectorV2(_Defaults):
         self.lane_info.lanes_points = np.array(lanes + [None], dtype=object)[:4]      # ragged-safe object array of 4 lists
         self.lane_info.lanes_status = [bool(s) for s in status]
         self.adjust_lanes = adjust_lanes
+        if self._device_geometry(dec, h, w):
+            return
         self.__update_lanes_status(self.lane_info.lanes_status)
         self.__update_lanes_area(self.lane_info.lanes_points, self.img_height)
+
+    # ---- optional: area polygon, bird-view points, curvature and offset straight from the decoder's device buffers
+    def enable_device_geometry(self, transform_view) -> None:
+        """transform_view: a PerspectiveTransformation (analysis.py); its current M is read at every DetectFrame.  After
+        DetectFrame, `lane_info.area_*` come from the device and `birdview_lanes_points` / `curve_and_offset` hold what
+        demo.py:290-291 computes with transformToBirdViewPoints / calcCurveAndOffset."""
+        self._transform_view = transform_view
+        self._geometry = None
+        self._geometry_key = None
+        self.birdview_lanes_points = [[], [], [], []]
+        self.curve_and_offset = ((None, None), None)
+
+    def _device_geometry(self, dec, h, w) -> bool:
+        tv = getattr(self, "_transform_view", None)
+        if tv is None:
+            return False
+        key = (h, tuple(tv.img_size))
+        if self._geometry_key != key:
+            if self._geometry is not None:
+                self._geometry.close()
+            self._geometry = LaneGeometry(h, tv.img_size, tv.M, self.adjust_lanes, 1)
+            self._geometry_key = key
+        self._geometry.set_matrix(tv.M)
+        self._geometry.run(dec, self.adjust_lanes, 1, None)
+        r = self._geometry.fetch(0)
+        self.lane_info._area_status = r["area_status"]
+        self.lane_info._area_points = r["area_points"].astype(np.int64) if r["area_status"] else np.array([], dtype=object)
+        self.birdview_lanes_points = [p if len(p) else [] for p in r["bird_points"]]
+        self.curve_and_offset = ((r["direction"], r["curvature"]), r["offset"])
+        return True
 
     def __update_lanes_status(self, lanes_status) -> None:          # core.py:143-148
         self.lane_info._area_status = False
@@ -402,6 +434,9 @@ class UltrafastLaneDetectorV2(_Defaults):
             self.lane_info._area_points = np.vstack((l, np.flipud(r)))
 
     def close(self):
+        if getattr(self, "_geometry", None) is not None:
+            self._geometry.close()
+            self._geometry = None
         if getattr(self, "_decode", None) is not None:
             self._decode.close()
             self._decode = None
@@ -491,6 +526,8 @@ class UltrafastLaneDetector(UltrafastLaneDetectorV2):
         self.lane_info.lanes_points = np.array(lanes + [None], dtype=object)[:4]
         self.lane_info.lanes_status = [bool(s) for s in status]
         self.adjust_lanes = adjust_lanes
+        if self._device_geometry(dec, h, w):
+            return
         self._UltrafastLaneDetectorV2__update_lanes_status(self.lane_info.lanes_status)
         self._UltrafastLaneDetectorV2__update_lanes_area(self.lane_info.lanes_points, self.img_height)
 

@@ -117,6 +117,16 @@ class UfldDecode:
         lanes = [[(int(x), int(y)) for x, y in pts[i, :cnt[i]]] for i in range(4)]
         return lanes, [bool(d) for d in det]
 
+    def upload(self, lanes, detected, frame=0):
+        """Place lane points decoded elsewhere into a frame slot (4 lists of (x, y), 4 bools)."""
+        pts = np.zeros((4, L.UFLD_MAX_POINTS, 2), np.int32)
+        cnt = np.asarray([len(l) for l in lanes], np.int32)
+        for i, l in enumerate(lanes):
+            if len(l):
+                pts[i, :len(l)] = np.asarray(l, np.int32).reshape(-1, 2)
+        det = np.asarray([1 if d else 0 for d in detected], np.int32)
+        L.check(L.lib().adas_ufld_decode_upload(self.h, frame, L.ptr(pts), L.ptr(cnt), L.ptr(det)))
+
     def close(self):
         if getattr(self, "h", None):
             L.lib().adas_ufld_decode_destroy(self.h)
@@ -152,6 +162,45 @@ class Ufld1Decode(UfldDecode):
             return [self.fetch(b) for b in range(out.shape[0])]
         finally:
             buf.free()
+
+
+class LaneGeometry:
+    """Ego-lane area polygon, bird-view points, curvature and offset computed on the device from a lane decoder's
+    device-resident points (core.py:102-158, perspectiveTransformation.py:120-214)."""
+    DIRECTIONS = (None, "L", "R", "F")
+
+    def __init__(self, img_h, bird_wh, M, adjust_lanes=True, max_batch=1):
+        p = L.LaneGeometryParams(int(img_h), int(bird_wh[0]), int(bird_wh[1]), 1 if adjust_lanes else 0,
+                                 (C.c_double * 9)(*np.asarray(M, np.float64).reshape(9)))
+        self.img_h = int(img_h)
+        h = C.c_void_p()
+        L.check(L.lib().adas_lane_geometry_create(C.byref(p), max_batch, C.byref(h)))
+        self.h = h.value
+
+    def set_matrix(self, M):
+        m = np.ascontiguousarray(M, np.float64).reshape(9)
+        L.check(L.lib().adas_lane_geometry_set_matrix(self.h, L.ptr(m)))
+
+    def run(self, decode, adjust_lanes=True, batch=1, stream=None):
+        L.check(L.lib().adas_lane_geometry_run(self.h, decode.h, 1 if adjust_lanes else 0, batch, stream))
+
+    def fetch(self, frame=0):
+        res = L.LaneGeometryResult()
+        area = np.zeros((2 * self.img_h, 2), np.int32)
+        bird = np.zeros((4, L.UFLD_MAX_POINTS, 2), np.int32)
+        L.check(L.lib().adas_lane_geometry_fetch(self.h, frame, C.byref(res), L.ptr(area), L.ptr(bird)))
+        n = res.n_area_left + res.n_area_right
+        return dict(area_status=bool(res.area_status), area_points=area[:n].copy(), n_left=res.n_area_left, n_right=res.n_area_right,
+                    bird_points=[bird[i, :res.bird_counts[i]].copy() for i in range(4)],
+                    direction=self.DIRECTIONS[res.direction], curvature=res.curvature if res.direction else None,
+                    offset=res.offset if res.direction else None)
+
+    def close(self):
+        if getattr(self, "h", None):
+            L.lib().adas_lane_geometry_destroy(self.h)
+            self.h = None
+
+    __del__ = close
 
 
 class DeviceTracker:
