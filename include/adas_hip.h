@@ -220,7 +220,8 @@ typedef struct {
 int adas_lane_geometry_create(const adas_lane_geometry_params* p, int max_batch, adas_lane_geometry** out);
 int adas_lane_geometry_destroy(adas_lane_geometry* h);
 int adas_lane_geometry_set_matrix(adas_lane_geometry* h, const double* M9);
-/* Reads the lane points the decoder (v1 or v2 handle) left in HBM for frames [0, batch). Asynchronous. */
+/* Reads the lane points the decoder (v1 or v2 handle) left in HBM for frames [0, batch). Asynchronous.
+ * adjust_lanes < 0: the value given at create. */
 int adas_lane_geometry_run(adas_lane_geometry* h, const adas_ufld_decode* decode, int adjust_lanes, int batch, void* stream);
 /* area_points: room for [2*img_h][2] int32 (x,y); bird_points: [4][ADAS_UFLD_MAX_POINTS][2]; either may be NULL. */
 int adas_lane_geometry_fetch(adas_lane_geometry* h, int frame, adas_lane_geometry_result* res, int32_t* area_points,
@@ -285,6 +286,7 @@ typedef struct {
     int32_t n_streams;
     int32_t use_graph;          /* bit0: capture the step in a hipGraph (the lane branch is then forked onto a second
                                  * stream so the two nets overlap); bit1: keep both nets on one stream */
+    adas_lane_geometry* geometry; /* may be NULL; with lane: area polygon / bird view / curvature right behind the decode */
 } adas_pipeline_desc;
 int adas_pipeline_create(const adas_pipeline_desc* d, adas_pipeline** out);
 int adas_pipeline_destroy(adas_pipeline* p);

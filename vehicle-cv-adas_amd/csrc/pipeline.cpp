@@ -57,6 +57,10 @@ static int record_step(adas_pipeline* p, const float* d_det, const float* d_lane
         rc = adas_ufld_decode_run(p->d.decode, adas_engine_output_device(le, 0), adas_engine_output_device(le, 1),
                                   adas_engine_output_device(le, 2), adas_engine_output_device(le, 3), stride, stride, stride, stride, S, sl);
         if (rc) return rc;
+        if (p->d.geometry) {
+            rc = adas_lane_geometry_run(p->d.geometry, p->d.decode, -1, S, sl);
+            if (rc) return rc;
+        }
     } else if (events) ADAS_HIP_TRY(hipEventRecord(p->ev[3], st));
     if (events) ADAS_HIP_TRY(hipEventRecord(p->ev[4], st));
     if (p->d.tracker && p->d.detector) {

@@ -669,7 +669,7 @@ int adas_lane_geometry_run(adas_lane_geometry* h, const adas_ufld_decode* decode
     hipStream_t st = (hipStream_t)stream;
     h->last = st;
     LaneGeomDev d = h->dev;
-    d.cfg.adjust = adjust_lanes ? 1 : 0;
+    if (adjust_lanes >= 0) d.cfg.adjust = adjust_lanes ? 1 : 0;
     d.lane_cnt = decode->dev.lane_cnt;
     d.lane_det = decode->dev.lane_det;
     d.lane_pts = decode->dev.lane_pts;

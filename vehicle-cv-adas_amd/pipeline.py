@@ -10,7 +10,7 @@ import numpy as np
 
 from . import _lib as L
 from .coreEngine import HipEngine
-from .postproc import YoloPost, UfldDecode, DeviceTracker, letterbox
+from .postproc import YoloPost, UfldDecode, LaneGeometry, DeviceTracker, letterbox
 
 CULANE = dict(grid_row=200, cls_row=72, grid_col=100, cls_col=81,
               row_anchor=np.linspace(0.42, 1, 72), col_anchor=np.linspace(0, 1, 81))   # ultrafastLaneDetectorV2.py:49-55
@@ -19,9 +19,10 @@ CULANE = dict(grid_row=200, cls_row=72, grid_col=100, cls_col=81,
 class AdasPipeline:
     def __init__(self, det_model=None, lane_model=None, n_streams=1, precision="bf16", src_hw=(720, 1280),
                  box_score=0.4, nms_iou=0.45, head_layout=L.HEAD_V8, num_classes=80, use_graph=True,
-                 max_candidates=512, track=True, lane_cfg=None, nms_mode=L.NMS_REFERENCE, overlap=True):
+                 max_candidates=512, track=True, lane_cfg=None, nms_mode=L.NMS_REFERENCE, overlap=True, geometry=None):
+        """geometry: None, or dict(bird_wh=(w, h), M=3x3, adjust_lanes=True) to run the lane-geometry kernel behind the decode."""
         self.S = n_streams
-        self.det = self.lane = self.post = self.decode = self.tracker = None
+        self.det = self.lane = self.post = self.decode = self.tracker = self.geometry = None
         if det_model:
             self.det = HipEngine(det_model, precision, n_streams)
             ishape = self.det.get_engine_input_shape()
@@ -37,9 +38,12 @@ class AdasPipeline:
             cfg.update(lane_cfg or {})
             self.decode = UfldDecode(cfg["grid_row"], cfg["cls_row"], cfg["grid_col"], cfg["cls_col"], src_hw[1], src_hw[0],
                                      cfg["row_anchor"], cfg["col_anchor"], 1, n_streams)
+            if geometry is not None:
+                self.geometry = LaneGeometry(src_hw[0], geometry["bird_wh"], geometry["M"], geometry.get("adjust_lanes", True), n_streams)
         d = L.PipelineDesc(self.det.handle if self.det else None, self.lane.handle if self.lane else None,
                            self.post.h if self.post else None, self.decode.h if self.decode else None,
-                           self.tracker.h if self.tracker else None, n_streams, (1 if use_graph else 0) | (0 if overlap else 2))
+                           self.tracker.h if self.tracker else None, n_streams, (1 if use_graph else 0) | (0 if overlap else 2),
+                           self.geometry.h if self.geometry else None)
         h = C.c_void_p()
         L.check(L.lib().adas_pipeline_create(C.byref(d), C.byref(h)))
         self.h = h.value
@@ -66,7 +70,7 @@ class AdasPipeline:
         if getattr(self, "h", None):
             L.lib().adas_pipeline_destroy(self.h)
             self.h = None
-        for o in (self.post, self.decode, self.tracker, self.det, self.lane):
+        for o in (self.geometry, self.post, self.decode, self.tracker, self.det, self.lane):
             if o:
                 o.close()
 
