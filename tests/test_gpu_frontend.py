@@ -172,3 +172,19 @@ def test_bytetracker_dropin_with_label_strings():
     trk.reset()
     assert trk.update([[10, 10, 50, 50]], [0.9], ["car"], None)[0]["track_id"] == 1     # per-instance counter restarts
     trk.close()
+
+
+def test_headless_demo_loop(capsys):
+    """tools/demo_headless.py: the reference's demo.py loop (detector -> tracker, lanes + device geometry, distance,
+    FCWS/LDWS/LKAS state machine) runs end to end on the drop-in classes."""
+    import os, runpy, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    argv = sys.argv
+    sys.argv = ["demo_headless.py", "--frames", "6"]
+    try:
+        mod = runpy.run_path(os.path.join(root, "tools", "demo_headless.py"), run_name="demo_headless")
+        assert mod["main"]() == 6
+    finally:
+        sys.argv = argv
+    out = capsys.readouterr().out
+    assert out.count("frame ") == 6 and "FCWS" in out and "frames/s" in out
