@@ -295,6 +295,160 @@ hipError_t launch_detect_v8(const TView* ins, float* out, int n, int nc, int A, 
     return hipGetLastError();
 }
 
+// ------------------------------------------------------------------------------------- Detect (v8), fused with its last 1x1 convs
+// model.22.cv2.i.2 (cb -> 64 DFL logits) and model.22.cv3.i.2 (cc -> nc class logits) feed nothing but the decode: run here as
+// MFMA GEMMs (fragment-ordered weights in LDS, activations straight from HBM into B registers, as in conv_pw.hip) they keep
+// 310 MB of fp32 logits per 64-frame step out of HBM and save six launches.  A workgroup owns 64 anchors of one level of one
+// frame; wave w owns anchors 16w..16w+15.  With weights as the A operand a lane ends with 4 consecutive outputs of one
+// anchor, so the 16 DFL bins of a box side sit in the 4 lanes {lrow, lrow+16, lrow+32, lrow+48} x 4 registers.
+typedef __attribute__((ext_vector_type(8))) __bf16 dbf16x8;
+typedef __attribute__((ext_vector_type(4))) float df32x4;
+typedef __attribute__((ext_vector_type(4))) uint32_t du32x4;
+#define ADAS_DETF_MAXKS 12  // hidden widths up to 384 channels (YOLOv8x: 320)
+
+struct DetFuseDev {
+    const uint16_t* hb[3];  // inputs of cv2.i.2 (bf16 NHWC views)
+    const uint16_t* hc[3];  // inputs of cv3.i.2
+    int hb_cs[3], hb_coff[3], hc_cs[3], hc_coff[3];
+    const uint16_t* wb[3];  // [4][KSb][64][8] fragment order
+    const uint16_t* wc[3];  // [NTc][KSc][64][8]
+    const float* bb[3];
+    const float* bc[3];
+    int cb, cc;             // hidden widths (same on every level)
+    int hw[3], w[3], stride[3], a_off[3];
+    float* out;
+    int nc, A, n;
+};
+
+__device__ __forceinline__ float detf_quad(float v, int m) { return __shfl_xor(v, m, 64); }
+
+__global__ __launch_bounds__(256) void detect_v8_fused_kernel(DetFuseDev d) {
+    extern __shared__ __attribute__((aligned(16))) uint16_t wl[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lrow = lane & 15, kg = lane >> 4;
+    const int b = blockIdx.y;
+    int blk = blockIdx.x, lvl = 0;
+    for (; lvl < 2; ++lvl) {
+        const int nb = (d.hw[lvl] + 63) / 64;
+        if (blk < nb) break;
+        blk -= nb;
+    }
+    const int KSb = (d.cb + 31) >> 5, KSc = (d.cc + 31) >> 5, NTc = (d.nc + 15) >> 4;
+    uint16_t* wbox = wl;                                  // [4][KSb][512]
+    uint16_t* wcls = wl + (size_t)4 * KSb * 512;          // [NTc][KSc][512]
+    float* bias = reinterpret_cast<float*>(wcls + (size_t)NTc * KSc * 512);  // [64 + NTc*16]
+    for (int i = tid; i < 4 * KSb * 64; i += 256) *reinterpret_cast<du32x4*>(wbox + (size_t)i * 8) = *reinterpret_cast<const du32x4*>(d.wb[lvl] + (size_t)i * 8);
+    for (int i = tid; i < NTc * KSc * 64; i += 256) *reinterpret_cast<du32x4*>(wcls + (size_t)i * 8) = *reinterpret_cast<const du32x4*>(d.wc[lvl] + (size_t)i * 8);
+    for (int i = tid; i < 64 + NTc * 16; i += 256) bias[i] = i < 64 ? d.bb[lvl][i] : d.bc[lvl][i - 64];
+    __syncthreads();
+
+    const int p = blk * 64 + wave * 16 + lrow;
+    const bool ok = p < d.hw[lvl];
+    const size_t pix = (size_t)b * d.hw[lvl] + (ok ? p : 0);
+    float* out = d.out + (size_t)b * (4 + d.nc) * d.A + d.a_off[lvl];
+
+    // ---- box branch: 64 DFL logits = 4 feature tiles (one per box side)
+    {
+        const uint16_t* ip = d.hb[lvl] + pix * d.hb_cs[lvl] + d.hb_coff[lvl] + kg * 8;
+        df32x4 acc[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc[t] = df32x4{0.f, 0.f, 0.f, 0.f};
+        for (int ks = 0; ks < KSb; ++ks) {
+            du32x4 xb = du32x4{0u, 0u, 0u, 0u};
+            if (ok && ks * 32 + kg * 8 < d.cb) xb = *reinterpret_cast<const du32x4*>(ip + ks * 32);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const du32x4 wf = *reinterpret_cast<const du32x4*>(wbox + ((size_t)(t * KSb + ks) * 64 + lane) * 8);
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(dbf16x8, wf), __builtin_bit_cast(dbf16x8, xb), acc[t], 0, 0, 0);
+            }
+        }
+        float dist[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {  // DFL: softmax over the side's 16 bins, expectation with arange(16)
+            float v[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = acc[t][r] + bias[t * 16 + kg * 4 + r];
+            float mx = fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3]));
+            mx = fmaxf(mx, detf_quad(mx, 16));
+            mx = fmaxf(mx, detf_quad(mx, 32));
+            float se = 0.f, sw = 0.f;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float e = expf(v[r] - mx);
+                se += e;
+                sw += e * (float)(kg * 4 + r);
+            }
+            se += detf_quad(se, 16); sw += detf_quad(sw, 16);
+            se += detf_quad(se, 32); sw += detf_quad(sw, 32);
+            dist[t] = sw / se;
+        }
+        if (ok) {
+            const float ax = (float)(p % d.w[lvl]) + 0.5f, ay = (float)(p / d.w[lvl]) + 0.5f;
+            const float x1 = ax - dist[0], y1 = ay - dist[1], x2 = ax + dist[2], y2 = ay + dist[3];
+            const float s = (float)d.stride[lvl];
+            const float comp = kg == 0 ? (x1 + x2) / 2 * s : kg == 1 ? (y1 + y2) / 2 * s : kg == 2 ? (x2 - x1) * s : (y2 - y1) * s;
+            out[(size_t)kg * d.A + p] = comp;
+        }
+    }
+    // ---- class branch: sigmoid(cv3.i.2)
+    {
+        const uint16_t* ip = d.hc[lvl] + pix * d.hc_cs[lvl] + d.hc_coff[lvl] + kg * 8;
+        du32x4 xc[ADAS_DETF_MAXKS];
+#pragma unroll
+        for (int ks = 0; ks < ADAS_DETF_MAXKS; ++ks) {
+            xc[ks] = du32x4{0u, 0u, 0u, 0u};
+            if (ks < KSc && ok && ks * 32 + kg * 8 < d.cc) xc[ks] = *reinterpret_cast<const du32x4*>(ip + ks * 32);
+        }
+        for (int nt = 0; nt < NTc; ++nt) {
+            df32x4 acc = df32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < ADAS_DETF_MAXKS; ++ks) {
+                if (ks < KSc) {
+                    const du32x4 wf = *reinterpret_cast<const du32x4*>(wcls + ((size_t)(nt * KSc + ks) * 64 + lane) * 8);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(dbf16x8, wf), __builtin_bit_cast(dbf16x8, xc[ks]), acc, 0, 0, 0);
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int c = nt * 16 + kg * 4 + r;
+                if (ok && c < d.nc) out[(size_t)(4 + c) * d.A + p] = 1.0f / (1.0f + expf(-(acc[r] + bias[64 + c])));
+            }
+        }
+    }
+}
+
+// hidden[2l] / hidden[2l+1]: inputs of cv2.l.2 / cv3.l.2; wfrag/bias: their packed (CONV_PW order) weights and biases
+hipError_t launch_detect_v8_fused(const TView* hidden, const void* const* wfrag, const float* const* bias, float* out, int n, int nc, int A,
+                                  const int strides[3], hipStream_t st_) {
+    DetFuseDev d;
+    int off = 0, blocks = 0;
+    d.cb = hidden[0].c; d.cc = hidden[1].c;
+    for (int l = 0; l < 3; ++l) {
+        const TView& hb = hidden[2 * l];
+        const TView& hc = hidden[2 * l + 1];
+        if (hb.f32 || hc.f32 || hb.c != d.cb || hc.c != d.cc || hb.h != hc.h || hb.w != hc.w) return hipErrorInvalidValue;
+        if (((hb.cs | hb.coff | hc.cs | hc.coff | hb.c | hc.c) & 7) != 0) return hipErrorInvalidValue;
+        d.hb[l] = (const uint16_t*)hb.p; d.hc[l] = (const uint16_t*)hc.p;
+        d.hb_cs[l] = hb.cs; d.hb_coff[l] = hb.coff; d.hc_cs[l] = hc.cs; d.hc_coff[l] = hc.coff;
+        d.wb[l] = (const uint16_t*)wfrag[2 * l]; d.wc[l] = (const uint16_t*)wfrag[2 * l + 1];
+        d.bb[l] = bias[2 * l]; d.bc[l] = bias[2 * l + 1];
+        d.hw[l] = hb.h * hb.w; d.w[l] = hb.w; d.stride[l] = strides[l]; d.a_off[l] = off;
+        off += d.hw[l];
+        blocks += (d.hw[l] + 63) / 64;
+    }
+    if (off != A || (d.cc + 31) / 32 > ADAS_DETF_MAXKS) return hipErrorInvalidValue;
+    d.out = out; d.nc = nc; d.A = A; d.n = n;
+    const int KSb = (d.cb + 31) / 32, KSc = (d.cc + 31) / 32, NTc = (nc + 15) / 16;
+    const size_t lds = ((size_t)4 * KSb + (size_t)NTc * KSc) * 1024 + (64 + (size_t)NTc * 16) * 4;
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute((const void*)detect_v8_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+        attr_done = true;
+    }
+    if (lds > 150 * 1024) return hipErrorNotSupported;
+    hipLaunchKernelGGL(detect_v8_fused_kernel, dim3(blocks, n), dim3(256), lds, st_, d);
+    return hipGetLastError();
+}
+
 // ------------------------------------------------------------------------------------- Detect (v5)
 struct DetV5Dev {
     const float* in[3];

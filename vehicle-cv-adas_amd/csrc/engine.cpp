@@ -191,6 +191,45 @@ int adas_engine_create(const char* model_path, int precision, int max_batch, ada
             packed_total += 256;
         }
     }
+    // ---- Detect fusion (aux_kernels.hip detect_v8_fused_kernel): the last 1x1 convs of both head branches feed only the decode
+    {
+        const char* env = getenv("ADAS_NO_DETECT_FUSE");
+        const bool enabled = precision == PREC_BF16 && !(env && env[0] == '1');
+        for (size_t di = 0; enabled && di < e->ops.size(); ++di) {
+            EngOp& dop = e->ops[di];
+            if (dop.f.type != OP_DETECT_V8 || dop.f.n_in != 6) continue;
+            int src[6];
+            bool ok = true;
+            for (int k = 0; k < 6 && ok; ++k) {
+                src[k] = -1;
+                for (size_t j = 0; j < di; ++j) {
+                    const FileOp& q = e->ops[j].f;
+                    if (q.type == OP_CONV && q.out_buf == dop.f.in_buf[k] && q.out_coff == dop.f.in_coff[k] && q.out_c == dop.f.in_c[k]) src[k] = (int)j;
+                }
+                ok = src[k] >= 0;
+                if (!ok) break;
+                const EngOp& c = e->ops[src[k]];
+                const FileOp& q = c.f;
+                ok = q.kh == 1 && q.kw == 1 && q.stride == 1 && q.act == ACT_NONE && q.res_mode == RES_NONE && c.kernel == CONV_PW && !c.skip &&
+                     e->bufs[q.out_buf].f32 && !e->bufs[q.in_buf[0]].f32 && (q.in_c[0] & 7) == 0 && q.out_c == (k % 2 == 0 ? 64u : (uint32_t)dop.f.params[0]);
+                for (size_t j = 0; j < e->ops.size() && ok; ++j) {  // nobody else reads the logits
+                    if (j == di) continue;
+                    const FileOp& r = e->ops[j].f;
+                    for (uint32_t t = 0; t < r.n_in && t < 8; ++t) ok = ok && r.in_buf[t] != q.out_buf;
+                    ok = ok && !(r.res_mode != RES_NONE && r.res_buf == q.out_buf);
+                }
+                for (auto& out : fout) ok = ok && out.buf != q.out_buf;
+            }
+            for (int l = 1; l < 3 && ok; ++l)  // one hidden width per branch
+                ok = e->ops[src[2 * l]].f.in_c[0] == e->ops[src[0]].f.in_c[0] && e->ops[src[2 * l + 1]].f.in_c[0] == e->ops[src[1]].f.in_c[0];
+            if (ok && (e->ops[src[1]].f.in_c[0] + 31) / 32 > 12) ok = false;
+            if (!ok) continue;
+            for (int k = 0; k < 6; ++k) {
+                dop.det_src[k] = src[k];
+                e->ops[src[k]].skip = true;
+            }
+        }
+    }
     e->weight_bytes = packed_total;
     if (hipMalloc(&e->d_weights, packed_total + 256) != hipSuccess) {
         fclose(f);
@@ -311,7 +350,7 @@ int adas_engine_layer_kernel(const adas_engine* e, int layer, int batch, char* n
     static const char* kOther[] = {"input_nchw_kernel", "", "maxpool_kernel", "upsample2_kernel", "detect_v8_kernel", "detect_v5_kernel",
                                    "layernorm_kernel"};
     if (op.skip) {
-        snprintf(name, cap, "(fused into the stem launch)");
+        snprintf(name, cap, o.type == OP_CONV && o.kh == 1 && op.kernel == CONV_PW ? "(fused into the Detect launch)" : "(fused into the stem launch)");
     } else if (o.type == OP_CONV) {
         ConvArgs a;
         a.in = make_view(e, o.in_buf[0], o.in_coff[0], o.in_c[0]);
@@ -319,6 +358,8 @@ int adas_engine_layer_kernel(const adas_engine* e, int layer, int batch, char* n
         a.n = batch; a.kh = o.kh; a.kw = o.kw; a.stride = o.stride; a.pad = o.pad; a.act = o.act; a.res_mode = o.res_mode;
         a.k = op.k; a.kpad = op.kpad; a.m = batch * a.out.h * a.out.w; a.max_n = e->max_batch;
         snprintf(name, cap, "%s%s", conv_kernel_name(a, e->prec, op.kernel), op.fuse_pool >= 0 ? "+pool" : "");
+    } else if (o.type == OP_DETECT_V8 && op.det_src[0] >= 0) {
+        snprintf(name, cap, "detect_v8_fused_kernel");
     } else {
         snprintf(name, cap, "%s", o.type < 7 ? kOther[o.type] : "?");
     }
@@ -385,8 +426,20 @@ int engine_run_op(adas_engine* e, int i, const float* d_in, int batch, hipStream
             break;
         case OP_DETECT_V8: {
             TView ins[6];
-            for (int k = 0; k < 6; ++k) ins[k] = make_view(e, o.in_buf[k], o.in_coff[k], o.in_c[k]);
             int strides[3] = {(int)o.params[2], (int)o.params[3], (int)o.params[4]};
+            if (op.det_src[0] >= 0) {  // decode + the six 1x1 convs in front of it
+                const void* wf[6];
+                const float* bs[6];
+                for (int k = 0; k < 6; ++k) {
+                    const EngOp& c = e->ops[op.det_src[k]];
+                    ins[k] = make_view(e, c.f.in_buf[0], c.f.in_coff[0], c.f.in_c[0]);
+                    wf[k] = wb + c.w_off;
+                    bs[k] = (const float*)(wb + c.b_off);
+                }
+                err = launch_detect_v8_fused(ins, wf, bs, (float*)e->bufs[o.out_buf].d, batch, (int)o.params[0], (int)o.params[1], strides, st);
+                break;
+            }
+            for (int k = 0; k < 6; ++k) ins[k] = make_view(e, o.in_buf[k], o.in_coff[k], o.in_c[k]);
             err = launch_detect_v8(ins, (float*)e->bufs[o.out_buf].d, batch, (int)o.params[0], (int)o.params[1], strides, st);
             break;
         }
@@ -490,6 +543,9 @@ int adas_engine_profile(adas_engine* e, const float* d_input, int batch, int ite
 int adas_engine_fetch_activation(adas_engine* e, int layer, int batch, float* h_out, int64_t dims[4]) {
     ADAS_REQUIRE(e && layer >= 0 && layer < (int)e->ops.size() && batch > 0 && batch <= e->max_batch, ADAS_ERR_INVALID, "bad layer/batch");
     const FileOp& o = e->ops[layer].f;
+    ADAS_REQUIRE(!(e->ops[layer].skip && o.type == OP_CONV && e->ops[layer].kernel == CONV_PW), ADAS_ERR_INVALID,
+                 "layer %d (%s) is fused into the Detect launch and has no materialised activation (ADAS_NO_DETECT_FUSE=1 keeps it)", layer,
+                 e->ops[layer].name.c_str());
     ADAS_REQUIRE(!(e->ops[layer].skip && o.type == OP_INPUT) && !(e->ops[layer].kernel == CONV_STEM && e->ops[layer].fuse_pool >= 0), ADAS_ERR_INVALID,
                  "layer %d (%s) is fused into the stem launch and has no materialised activation (ADAS_NO_STEM=1 keeps it)", layer,
                  e->ops[layer].name.c_str());

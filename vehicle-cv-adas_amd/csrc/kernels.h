@@ -50,6 +50,8 @@ hipError_t launch_maxpool(TView in, TView out, int n, int k, int s, int p, int p
 hipError_t launch_upsample2(TView in, TView out, int n, int prec, hipStream_t st);
 // YOLOv8 Detect decode: ins = {box0, cls0, box1, cls1, box2, cls2} fp32 logits NHWC; out fp32 [n][4+nc][A]
 hipError_t launch_detect_v8(const TView* ins, float* out, int n, int nc, int A, const int strides[3], hipStream_t st);
+hipError_t launch_detect_v8_fused(const TView* hidden, const void* const* wfrag, const float* const* bias, float* out, int n, int nc, int A,
+                                  const int strides[3], hipStream_t st);
 // YOLOv5 Detect decode: ins = 3 fp32 maps [n][ny][nx][3*(5+nc)]; out fp32 [n][A][5+nc]; anchors[18] device
 hipError_t launch_detect_v5(const TView* ins, float* out, int n, int nc, int A, const int strides[3],
                             const float* d_anchors, hipStream_t st);
