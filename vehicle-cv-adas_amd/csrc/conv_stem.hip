@@ -52,19 +52,28 @@ struct StemDev {
     int Hp, Wp;             // pooled output (POOL)
     int pad;
     int tiles_x, tiles_y, ntiles;
+    const uint16_t* wfrag2;  // CONV2: [2][5][64 lanes][8] bf16 (3x3 s2 p1, 16 -> 32 channels), K-step = two taps x 16 channels
+    const float* bias2;
 };
 
 constexpr int STEM_WW = 72;  // window row pitch in pixels (even: 16 B aligned fragment reads)
 
-template <int KH, int NT, int ACT, bool POOL>
+// CONV2: the YOLO stems are followed by a 3x3 s2 p1 conv on their 16 channels (model.1); the 17 x 33 stem pixels an
+// 8 x 16 tile of that conv needs are kept in LDS (geometry of the pooled case with 8 rows) and the second conv runs from
+// there -- the 16-channel stem output (3.3 MB per 640^2 frame, written and read back) never reaches HBM.  Hp/Wp are then
+// the second conv's output extent and `out` its view.
+template <int KH, int NT, int ACT, bool POOL, bool CONV2 = false>
 __global__ __launch_bounds__(256, 2) void conv_stem_kernel(StemDev a) {
-    constexpr int CTH = POOL ? 9 : 8, CTW = POOL ? 33 : 32;  // conv tile (POOL: 4x16 pooled + halo)
+    constexpr bool TILE2 = POOL || CONV2;
+    constexpr int CTH = CONV2 ? 17 : (POOL ? 9 : 8), CTW = TILE2 ? 33 : 32;  // conv tile (POOL: 4x16 pooled + halo)
     constexpr int NPIX = CTH * CTW;
     constexpr int NMT = (NPIX + 15) / 16, MT = (NMT + 3) / 4;
     constexpr int WW = STEM_WW, WH = 2 * (CTH - 1) + KH;
     constexpr int NQ = (WH * WW + 255) / 256;
-    constexpr int CP = NT * 16 + 4;  // conv-tile pixel pitch in elements (pad: conflict-free 8 B writes, 8 B aligned)
-    constexpr int WIN_E = WH * WW * 4, CT_E = POOL ? NPIX * CP : 0;
+    constexpr int CP = CONV2 ? 24 : NT * 16 + 4;  // conv-tile pixel pitch in elements (pad: conflict-free 8 B writes, 8 B aligned;
+                                                  // CONV2: 48 B so that its 16-byte fragment reads stay aligned)
+    constexpr int WIN_E = WH * WW * 4, CT_E = TILE2 ? NPIX * CP : 0;
+    __shared__ __attribute__((aligned(16))) uint16_t w2l[CONV2 ? 2 * 5 * 512 : 8];
     // weights: fragment order, one contiguous 1 KB block per (channel tile, tap row) -> conflict-free ds_read_b128.
     // (Held in registers they cost 112 VGPRs at <7,4>, which put the kernel at the 256-VGPR limit with spills.)
     __shared__ __attribute__((aligned(16))) uint16_t wl[NT * KH * 512];
@@ -76,6 +85,8 @@ __global__ __launch_bounds__(256, 2) void conv_stem_kernel(StemDev a) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lrow = lane & 15, kg = lane >> 4;
     for (int i = tid; i < NT * KH * 64; i += 256) *reinterpret_cast<su32x4*>(wl + i * 8) = *reinterpret_cast<const su32x4*>(a.wfrag + (size_t)i * 8);
+    if (CONV2)
+        for (int i = tid; i < 2 * 5 * 64; i += 256) *reinterpret_cast<su32x4*>(w2l + i * 8) = *reinterpret_cast<const su32x4*>(a.wfrag2 + (size_t)i * 8);
 
     // per-lane window offsets of this wave's M tiles (tile-invariant)
     int boff[MT];
@@ -91,6 +102,8 @@ __global__ __launch_bounds__(256, 2) void conv_stem_kernel(StemDev a) {
 
     // window fetch of one tile into registers: fp32 planes, branch-free (buffer loads: offset 0x80000000 is out of range,
     // the hardware returns 0 = zero padding; a tile index past the end turns every lane out of range)
+    // (a second register set -- tile t+2 requested while t+1 is in flight -- measured no gain: the YOLO stems are bound by VALU
+    // issue, SiLU and index arithmetic, not by bytes in flight)
     float px[NQ][3];
     auto fetch = [&](int tile) {
         const bool live = tile < a.ntiles;
@@ -98,8 +111,8 @@ __global__ __launch_bounds__(256, 2) void conv_stem_kernel(StemDev a) {
         const int img = tl / per_img;
         const int t2 = tl - img * per_img;
         const int ty = t2 / a.tiles_x, tx = t2 - ty * a.tiles_x;
-        const int cy0 = POOL ? 2 * (ty * 4) - 1 : ty * CTH;
-        const int cx0 = POOL ? 2 * (tx * 16) - 1 : tx * CTW;
+        const int cy0 = CONV2 ? 2 * (ty * 8) - 1 : (POOL ? 2 * (ty * 4) - 1 : ty * CTH);
+        const int cx0 = TILE2 ? 2 * (tx * 16) - 1 : tx * CTW;
         const int iy0 = 2 * cy0 - a.pad, ix0 = 2 * cx0 - a.pad;
         const float* in_img = a.in + (size_t)img * a.C * plane;
         __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)in_img, 0, a.C * plane * 4, 0x00020000);
@@ -118,15 +131,13 @@ __global__ __launch_bounds__(256, 2) void conv_stem_kernel(StemDev a) {
         }
     };
 
-    int tile = blockIdx.x;
-    if (tile >= a.ntiles) return;
-    fetch(tile);
-    for (;;) {
+    const int gstride = gridDim.x;
+    auto step = [&](const int tile) {
         const int img = tile / per_img;
         const int t2 = tile - img * per_img;
         const int ty = t2 / a.tiles_x, tx = t2 - ty * a.tiles_x;
-        const int cy0 = POOL ? 2 * (ty * 4) - 1 : ty * CTH;
-        const int cx0 = POOL ? 2 * (tx * 16) - 1 : tx * CTW;
+        const int cy0 = CONV2 ? 2 * (ty * 8) - 1 : (POOL ? 2 * (ty * 4) - 1 : ty * CTH);
+        const int cx0 = TILE2 ? 2 * (tx * 16) - 1 : tx * CTW;
 
         __syncthreads();  // previous tile's readers of the window / conv tile are done (first trip: the weights are in LDS)
 #pragma unroll
@@ -140,8 +151,7 @@ __global__ __launch_bounds__(256, 2) void conv_stem_kernel(StemDev a) {
             }
         }
         __syncthreads();
-        const int next = tile + gridDim.x;
-        fetch(next);  // in flight under this tile's MFMAs and pooling
+        fetch(tile + gstride);  // in flight under this tile's MFMAs and pooling
 
         // ---- MFMA: KH K-steps.  No guard on M tiles past the end (the last wave's surplus tile reads a clamped, valid window
         // address and is dropped at store time): a branch per tile stops hipcc from overlapping LDS reads with MFMAs.
@@ -175,7 +185,7 @@ __global__ __launch_bounds__(256, 2) void conv_stem_kernel(StemDev a) {
             pcy[j] = pc / CTW;
             pcx[j] = pc - pcy[j] * CTW;
         }
-        if (!POOL) {
+        if (!TILE2) {
 #pragma unroll
             for (int j = 0; j < MT; ++j) {
                 const int p = (wave * MT + j) * 16 + lrow;
@@ -204,11 +214,56 @@ __global__ __launch_bounds__(256, 2) void conv_stem_kernel(StemDev a) {
                     su32x2 q;
                     q.x = s_pack2(s_act<ACT>(acc[j][i][0] + bias4[i].x), s_act<ACT>(acc[j][i][1] + bias4[i].y));
                     q.y = s_pack2(s_act<ACT>(acc[j][i][2] + bias4[i].z), s_act<ACT>(acc[j][i][3] + bias4[i].w));
-                    if (!valid) q.x = q.y = 0xff80ff80u;
+                    if (!valid) q.x = q.y = CONV2 ? 0u : 0xff80ff80u;  // conv zero padding | pool padding
                     *reinterpret_cast<su32x2*>(ctile + p * CP + i * 16 + kg * 4) = q;
                 }
             }
             __syncthreads();
+            if (CONV2) {
+                // ---- second conv from the LDS tile: K-step s2 = taps 2*s2 and 2*s2+1 x 16 channels (the tenth tap slot has zero weights)
+                constexpr int MT2 = 2;  // 8 M tiles of 16 output pixels over 4 waves
+                sf32x4 acc2[MT2][2];
+                int py2[MT2], px2[MT2];
+#pragma unroll
+                for (int j = 0; j < MT2; ++j) {
+                    const int p = (wave * MT2 + j) * 16 + lrow;
+                    py2[j] = p >> 4;
+                    px2[j] = p & 15;
+                    acc2[j][0] = acc2[j][1] = sf32x4{0.f, 0.f, 0.f, 0.f};
+                }
+#pragma unroll
+                for (int s2 = 0; s2 < 5; ++s2) {
+                    const int t = 2 * s2 + (kg >> 1) < 9 ? 2 * s2 + (kg >> 1) : 8;
+                    const int kh2 = t / 3, kw2 = t - kh2 * 3;
+                    sbf16x8 wf2[2], xf2[MT2];
+#pragma unroll
+                    for (int n = 0; n < 2; ++n) wf2[n] = *reinterpret_cast<const sbf16x8*>(w2l + ((n * 5 + s2) * 64 + lane) * 8);
+#pragma unroll
+                    for (int j = 0; j < MT2; ++j)
+                        xf2[j] = *reinterpret_cast<const sbf16x8*>(ctile + ((2 * py2[j] + kh2) * CTW + 2 * px2[j] + kw2) * CP + (kg & 1) * 8);
+#pragma unroll
+                    for (int j = 0; j < MT2; ++j)
+#pragma unroll
+                        for (int n = 0; n < 2; ++n) acc2[j][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf2[n], xf2[j], acc2[j][n], 0, 0, 0);
+                }
+                float4 b2[2];
+#pragma unroll
+                for (int n = 0; n < 2; ++n) b2[n] = *reinterpret_cast<const float4*>(a.bias2 + n * 16 + kg * 4);
+#pragma unroll
+                for (int j = 0; j < MT2; ++j) {
+                    const int oy = ty * 8 + py2[j], ox = tx * 16 + px2[j];
+                    if (oy >= a.Hp || ox >= a.Wp) continue;
+                    uint16_t* op = a.out + ((size_t)(img * a.Hp + oy) * a.Wp + ox) * a.out_cs + a.out_coff + kg * 4;
+#pragma unroll
+                    for (int n = 0; n < 2; ++n) {
+                        su32x2 q;
+                        q.x = s_pack2(s_act<ACT>(acc2[j][n][0] + b2[n].x), s_act<ACT>(acc2[j][n][1] + b2[n].y));
+                        q.y = s_pack2(s_act<ACT>(acc2[j][n][2] + b2[n].z), s_act<ACT>(acc2[j][n][3] + b2[n].w));
+                        *reinterpret_cast<su32x2*>(op + n * 16) = q;
+                    }
+                }
+                return;
+            }
             constexpr int CG = NT * 2;  // 8-channel groups per pixel
             for (int it = tid; it < 64 * CG; it += 256) {
                 const int pp = it / CG, cg = it - pp * CG;
@@ -230,9 +285,11 @@ __global__ __launch_bounds__(256, 2) void conv_stem_kernel(StemDev a) {
                 *reinterpret_cast<su32x4*>(op) = su32x4{m0.x, m0.y, m1.x, m1.y};
             }
         }
-        if (next >= a.ntiles) break;
-        tile = next;
-    }
+    };
+    int tile = blockIdx.x;
+    if (tile >= a.ntiles) return;
+    fetch(tile);
+    for (; tile < a.ntiles; tile += gstride) step(tile);
 }
 
 // -------------------------------------------------------------------------------------
@@ -272,6 +329,46 @@ void stem_pack_weights(const float* w, int cout, int kh, int kw, int cs, int c_t
                 }
 }
 
+// second conv of the fused YOLO stem: w = [32][3][3][16] fp32 (OHWI) -> [2][5][64 lanes][8] bf16; lane (cout row, k group),
+// K index kk = 8*kgroup + e of step s: tap 2s + (kk >> 4), channel kk & 15; the tenth tap slot is zero
+size_t stem2_weight_bytes() { return (size_t)2 * 5 * 64 * 8 * 2; }
+void stem2_pack_weights(const float* w, uint16_t* dst) {
+    for (int n = 0; n < 2; ++n)
+        for (int s = 0; s < 5; ++s)
+            for (int lane = 0; lane < 64; ++lane)
+                for (int e = 0; e < 8; ++e) {
+                    const int co = n * 16 + (lane & 15), kk = (lane >> 4) * 8 + e;
+                    const int tap = 2 * s + (kk >> 4), ch = kk & 15;
+                    const float v = tap < 9 ? w[((size_t)co * 9 + tap) * 16 + ch] : 0.f;
+                    dst[((size_t)(n * 5 + s) * 64 + lane) * 8 + e] = h_f2bf(v);
+                }
+}
+bool stem2_applicable(int prec, int kh, int pad, int act, const TView& stem_out, int kh2, int kw2, int stride2, int pad2, int act2, int res_mode2,
+                      const TView& out2) {
+    if (prec != PREC_BF16 || !(kh == 3 || kh == 6) || act != ACT_SILU || act2 != ACT_SILU || res_mode2 != RES_NONE) return false;
+    if (stem_out.c != 16 || stem_out.f32 || out2.c != 32 || out2.f32 || (out2.cs & 7) || (out2.coff & 7)) return false;
+    if (kh2 != 3 || kw2 != 3 || stride2 != 2 || pad2 != 1 || pad > kh / 2) return false;
+    return out2.h == (stem_out.h + 2 - 3) / 2 + 1 && out2.w == (stem_out.w + 2 - 3) / 2 + 1;
+}
+hipError_t launch_conv_stem2(const float* nchw, int n, int c_true, int H, int W, int kh, int pad, const void* wfrag, const float* bias,
+                             const TView& stem_out, const void* wfrag2, const float* bias2, const TView& out2, hipStream_t st) {
+    StemDev d;
+    d.in = nchw; d.wfrag = (const uint16_t*)wfrag; d.bias = bias;
+    d.out = (uint16_t*)out2.p; d.out_cs = out2.cs; d.out_coff = out2.coff; d.cout = stem_out.c;
+    d.N = n; d.C = c_true; d.H = H; d.W = W; d.Ho = stem_out.h; d.Wo = stem_out.w;
+    d.Hp = out2.h; d.Wp = out2.w;
+    d.pad = pad;
+    d.tiles_x = (d.Wp + 15) / 16; d.tiles_y = (d.Hp + 7) / 8;
+    d.ntiles = n * d.tiles_x * d.tiles_y;
+    d.wfrag2 = (const uint16_t*)wfrag2; d.bias2 = bias2;
+    if ((size_t)c_true * H * W * 4 >= (1ull << 31)) return hipErrorInvalidValue;
+    const int grid = d.ntiles < 1024 ? d.ntiles : 1024;
+    if (kh == 3) hipLaunchKernelGGL((conv_stem_kernel<3, 1, ACT_SILU, false, true>), dim3(grid), dim3(256), 0, st, d);
+    else if (kh == 6) hipLaunchKernelGGL((conv_stem_kernel<6, 1, ACT_SILU, false, true>), dim3(grid), dim3(256), 0, st, d);
+    else return hipErrorInvalidValue;
+    return hipGetLastError();
+}
+
 template <int KH, int NT, bool POOL>
 static hipError_t stem_launch_act(const StemDev& d, int act, hipStream_t st) {
     const int grid = d.ntiles < 1024 ? d.ntiles : 1024;
@@ -289,6 +386,7 @@ hipError_t launch_conv_stem(const float* nchw, int n, int c_true, int H, int W, 
     d.N = n; d.C = c_true; d.H = H; d.W = W; d.Ho = conv_out.h; d.Wo = conv_out.w;
     d.Hp = pool ? pool_out.h : 0; d.Wp = pool ? pool_out.w : 0;
     d.pad = pad;
+    d.wfrag2 = nullptr; d.bias2 = nullptr;
     if (pool) {
         d.tiles_x = (d.Wp + 15) / 16; d.tiles_y = (d.Hp + 3) / 4;
     } else {

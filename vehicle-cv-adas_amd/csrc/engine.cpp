@@ -148,6 +148,20 @@ int adas_engine_create(const char* model_path, int precision, int max_batch, ada
                     e->ops[1].fuse_pool = 2;
                     e->ops[2].skip = true;
                 }
+                // YOLO stems: the 3x3 s2 conv on the stem's 16 channels joins the launch when nothing else reads the stem output
+                const char* env2 = getenv("ADAS_NO_STEM2");
+                if (!pool && !(env2 && env2[0] == '1') && e->ops.size() >= 3 && fo[2].type == OP_CONV && fo[2].in_buf[0] == fo[1].out_buf &&
+                    fo[2].in_coff[0] == fo[1].out_coff && fo[2].in_c[0] == fo[1].out_c && !is_output(fo[1].out_buf)) {
+                    bool sole = true;
+                    for (size_t i = 3; i < fo.size(); ++i) sole = sole && !reads_buf(fo[i], fo[1].out_buf);
+                    TView o2 = make_view(e, fo[2].out_buf, fo[2].out_coff, fo[2].out_c);
+                    if (sole && stem2_applicable(precision, fo[1].kh, fo[1].pad, fo[1].act, cv, fo[2].kh, fo[2].kw, fo[2].stride, fo[2].pad, fo[2].act,
+                                                 fo[2].res_mode, o2)) {
+                        e->ops[1].fuse_conv2 = 2;
+                        e->ops[2].skip = true;
+                        e->ops[2].kernel = CONV_STEM2;
+                    }
+                }
             }
         }
     }
@@ -160,6 +174,15 @@ int adas_engine_create(const char* model_path, int precision, int max_batch, ada
             op.cout_pad = (o.out_c + 127) / 128 * 128;
             op.w_off = packed_total;
             packed_total += (stem_weight_bytes(o.kh, o.out_c) + 255) & ~(size_t)255;
+            op.b_off = packed_total;
+            packed_total += ((size_t)op.cout_pad * 4 + 255) & ~(size_t)255;
+        } else if (o.type == OP_CONV && op.kernel == CONV_STEM2) {
+            op.k = o.kh * o.kw * o.in_c[0];
+            op.kpad = 160;
+            op.cin_pad = 16;
+            op.cout_pad = (o.out_c + 127) / 128 * 128;
+            op.w_off = packed_total;
+            packed_total += (stem2_weight_bytes() + 255) & ~(size_t)255;
             op.b_off = packed_total;
             packed_total += ((size_t)op.cout_pad * 4 + 255) & ~(size_t)255;
         } else if (o.type == OP_CONV) {
@@ -257,9 +280,10 @@ int adas_engine_create(const char* model_path, int precision, int max_batch, ada
         if (o.type == OP_CONV) {
             if (!read_blob(o.w_off, o.w_elems, h_stage.data()) || o.w_elems != (uint64_t)o.out_c * op.k) { rc = ADAS_ERR_FORMAT; break; }
             if (hipMemcpy(d_stage, h_stage.data(), o.w_elems * 4, hipMemcpyHostToDevice) != hipSuccess) { rc = ADAS_ERR_HIP; break; }
-            if (op.kernel == CONV_STEM) {
-                std::vector<uint16_t> frag(stem_weight_bytes(o.kh, o.out_c) / 2);
-                stem_pack_weights(h_stage.data(), o.out_c, o.kh, o.kw, o.in_c[0], hd.in_c, frag.data());
+            if (op.kernel == CONV_STEM || op.kernel == CONV_STEM2) {
+                std::vector<uint16_t> frag((op.kernel == CONV_STEM2 ? stem2_weight_bytes() : stem_weight_bytes(o.kh, o.out_c)) / 2);
+                if (op.kernel == CONV_STEM2) stem2_pack_weights(h_stage.data(), frag.data());
+                else stem_pack_weights(h_stage.data(), o.out_c, o.kh, o.kw, o.in_c[0], hd.in_c, frag.data());
                 if (hipMemcpy(base + op.w_off, frag.data(), frag.size() * 2, hipMemcpyHostToDevice) != hipSuccess) { rc = ADAS_ERR_HIP; break; }
                 std::vector<float> b(op.cout_pad, 0.f);
                 if (!read_blob(o.b_off, o.b_elems, b.data())) { rc = ADAS_ERR_FORMAT; break; }
@@ -351,6 +375,8 @@ int adas_engine_layer_kernel(const adas_engine* e, int layer, int batch, char* n
                                    "layernorm_kernel"};
     if (op.skip) {
         snprintf(name, cap, o.type == OP_CONV && o.kh == 1 && op.kernel == CONV_PW ? "(fused into the Detect launch)" : "(fused into the stem launch)");
+    } else if (o.type == OP_CONV && op.kernel == CONV_STEM && op.fuse_conv2 >= 0) {
+        snprintf(name, cap, "conv_stem_kernel<%d,1,SILU>+conv3x3s2", (int)o.kh);
     } else if (o.type == OP_CONV) {
         ConvArgs a;
         a.in = make_view(e, o.in_buf[0], o.in_coff[0], o.in_c[0]);
@@ -390,8 +416,13 @@ int engine_run_op(adas_engine* e, int i, const float* d_in, int batch, hipStream
             const FileOp& po = e->ops[op.fuse_pool].f;
             pv = make_view(e, po.out_buf, po.out_coff, po.out_c);
         }
-        err = launch_conv_stem(d_in, batch, e->hdr.in_c, e->hdr.in_h, e->hdr.in_w, o.kh, o.pad, o.act, wb + op.w_off,
-                               (const float*)(wb + op.b_off), cv, op.fuse_pool >= 0, pv, st);
+        if (op.fuse_conv2 >= 0) {
+            const EngOp& c2 = e->ops[op.fuse_conv2];
+            err = launch_conv_stem2(d_in, batch, e->hdr.in_c, e->hdr.in_h, e->hdr.in_w, o.kh, o.pad, wb + op.w_off, (const float*)(wb + op.b_off), cv,
+                                    wb + c2.w_off, (const float*)(wb + c2.b_off), make_view(e, c2.f.out_buf, c2.f.out_coff, c2.f.out_c), st);
+        } else
+            err = launch_conv_stem(d_in, batch, e->hdr.in_c, e->hdr.in_h, e->hdr.in_w, o.kh, o.pad, o.act, wb + op.w_off,
+                                   (const float*)(wb + op.b_off), cv, op.fuse_pool >= 0, pv, st);
         if (err != hipSuccess) {
             set_error("layer %d (%s): stem launch failed: %s", i, op.name.c_str(), hipGetErrorString(err));
             (void)hipGetLastError();
@@ -546,7 +577,8 @@ int adas_engine_fetch_activation(adas_engine* e, int layer, int batch, float* h_
     ADAS_REQUIRE(!(e->ops[layer].skip && o.type == OP_CONV && e->ops[layer].kernel == CONV_PW), ADAS_ERR_INVALID,
                  "layer %d (%s) is fused into the Detect launch and has no materialised activation (ADAS_NO_DETECT_FUSE=1 keeps it)", layer,
                  e->ops[layer].name.c_str());
-    ADAS_REQUIRE(!(e->ops[layer].skip && o.type == OP_INPUT) && !(e->ops[layer].kernel == CONV_STEM && e->ops[layer].fuse_pool >= 0), ADAS_ERR_INVALID,
+    ADAS_REQUIRE(!(e->ops[layer].skip && o.type == OP_INPUT) &&
+                     !(e->ops[layer].kernel == CONV_STEM && (e->ops[layer].fuse_pool >= 0 || e->ops[layer].fuse_conv2 >= 0)), ADAS_ERR_INVALID,
                  "layer %d (%s) is fused into the stem launch and has no materialised activation (ADAS_NO_STEM=1 keeps it)", layer,
                  e->ops[layer].name.c_str());
     TView v = make_view(e, o.out_buf, o.out_coff, o.out_c);

@@ -29,7 +29,7 @@ struct ConvArgs {
 
 // Which kernel runs a conv and how its weights are packed.  Decided once at load time from static
 // shapes and re-derived identically at launch time.
-enum { CONV_GATHER = 0, CONV_HALO = 1, CONV_FC = 2, CONV_STEM = 3, CONV_PW = 4 };
+enum { CONV_GATHER = 0, CONV_HALO = 1, CONV_FC = 2, CONV_STEM = 3, CONV_PW = 4, CONV_STEM2 = 5 /* second conv of a fused YOLO stem */ };
 struct ConvPlan {
     int kernel;   // CONV_*
     int cin_pad;  // channels per tap in the packed weights (halo: padded to 32 so the tail is zero)
@@ -66,6 +66,13 @@ hipError_t launch_pack_weights(const float* src, void* dst, int cout, int cout_p
 bool stem_applicable(int prec, int in_c_true, int kh, int kw, int stride, int pad, int act, int res_mode, const TView& out, bool pool,
                      const TView& pool_out);
 size_t stem_weight_bytes(int kh, int cout);
+// YOLO stem + the 3x3 s2 16->32 conv behind it in one launch (conv_stem.hip, CONV2)
+size_t stem2_weight_bytes();
+void stem2_pack_weights(const float* w_ohwi_32x3x3x16, uint16_t* dst_host);
+bool stem2_applicable(int prec, int kh, int pad, int act, const TView& stem_out, int kh2, int kw2, int stride2, int pad2, int act2, int res_mode2,
+                      const TView& out2);
+hipError_t launch_conv_stem2(const float* nchw, int n, int c_true, int H, int W, int kh, int pad, const void* wfrag, const float* bias,
+                             const TView& stem_out, const void* wfrag2, const float* bias2, const TView& out2, hipStream_t st);
 void stem_pack_weights(const float* w_ohwi, int cout, int kh, int kw, int cs, int c_true, uint16_t* dst_host);
 hipError_t launch_conv_stem(const float* nchw, int n, int c_true, int H, int W, int kh, int pad, int act, const void* wfrag,
                             const float* bias, const TView& conv_out, bool pool, const TView& pool_out, hipStream_t st);
