@@ -209,10 +209,13 @@ def test_conv3x3_s2_halo_shapes(CE, hw):
 
 @pytest.mark.parametrize("case", [(80, 400, 64, 64, M.ACT_RELU, M.RES_BEFORE_ACT), (80, 80, 64, 80, M.ACT_SILU, M.RES_NONE),
                                   (160, 160, 32, 64, M.ACT_SILU, M.RES_NONE), (46, 74, 48, 64, M.ACT_SILU, M.RES_AFTER_ACT),
-                                  (80, 80, 16, 128, M.ACT_NONE, M.RES_NONE)], ids=str)
+                                  (80, 80, 16, 128, M.ACT_NONE, M.RES_NONE), (80, 80, 32, 32, M.ACT_SILU, M.RES_AFTER_ACT),
+                                  (160, 160, 16, 32, M.ACT_SILU, M.RES_NONE), (46, 74, 64, 24, M.ACT_RELU, M.RES_BEFORE_ACT)], ids=str)
 def test_conv3x3_resident_weights_kernel(CE, case):
-    """Cin <= 64, Cout > 32 at a batch large enough (>= 1024 tiles) to take the persistent weights-resident kernel
-    (conv_halo_rw.hip): several tiles per workgroup, both LDS window buffers, ragged strips, residual modes."""
+    """Cin <= 64, Cout > 16 at a batch large enough (>= 1024 tiles) to take the persistent weights-resident kernel
+    (conv_halo_rw.hip): several tiles per workgroup, both LDS window buffers, ragged strips, residual modes, and the
+    32-output-channel packing (cout <= 32)."""
     H, W, cin, cout, act, rm = case
-    rel, mx = run_case(CE, H, W, cin, cout, 3, 1, act, rm, "bf16", batch=max(2, (1024 * 256) // (H * W) + 1))
+    rel, mx = run_case(CE, H, W, cin, cout, 3, 1, act, rm, "bf16", batch=max(2, (1024 * 256) // (H * W) + 1),
+                       expect_kernel="conv_halo_rw_kernel")
     assert rel < 1e-2, (case, rel, mx)

@@ -60,11 +60,12 @@ constexpr int RW_NW = 8;            // waves per workgroup: two per SIMD (one wo
 constexpr int RW_THR = 64 * RW_NW;
 constexpr int RW_NA = RW_ELEMS / RW_THR + 1;
 
-template <int NCH, int ACT, bool HAS_RES>  // NCH = 32-channel planes (1 | 2); HAS_RES is a template flag because a runtime branch
+template <int NCH, int ACT, bool HAS_RES, int BN = 64>  // NCH = 32-channel planes (1 | 2); BN = output channels per workgroup (64 | 32,
+                                                       // the CONV_HALO packing of the layer: halo_bn(cout)); HAS_RES is a template flag because a runtime branch
                                           // around the residual loads makes hipcc drain vmcnt(0) at the join -- and with it the window prefetch
 __global__ __launch_bounds__(RW_THR, RW_NW / 4) void conv_halo_rw_kernel(RwDev a) {
-    constexpr int TAPS = 9, TM = RW_BM / 16 / RW_NW, TN = 4;
-    constexpr int WROWS = TAPS * RW_BN;               // 576 weight rows of 64 B per plane
+    constexpr int TAPS = 9, TM = RW_BM / 16 / RW_NW, TN = BN / 16;
+    constexpr int WROWS = TAPS * BN;                  // weight rows of 64 B per plane (576 at BN = 64)
     constexpr int NWL = (NCH * WROWS * 4 + RW_THR - 1) / RW_THR;  // one-time weight loads per thread
     extern __shared__ __attribute__((aligned(16))) uint16_t lds[];
     uint16_t* Ww = lds;                                  // [NCH][WROWS][32], row-swizzled
@@ -75,7 +76,7 @@ __global__ __launch_bounds__(RW_THR, RW_NW / 4) void conv_halo_rw_kernel(RwDev a
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lrow = lane & 15, kg = lane >> 4;
     const int nt = blockIdx.x % a.NT;
-    const int n0 = nt * RW_BN;
+    const int n0 = nt * BN;
     const int first = blockIdx.x / a.NT, step = gridDim.x / a.NT;
     const int per_img = a.NS * a.TPS;
     const int NCH_PACK = a.cin_pad >> 5;  // chunks in the packed weights (== NCH)
@@ -100,7 +101,7 @@ __global__ __launch_bounds__(RW_THR, RW_NW / 4) void conv_halo_rw_kernel(RwDev a
     float4 bias4[TN];
 #pragma unroll
     for (int i = 0; i < TN; ++i) bias4[i] = *reinterpret_cast<const float4*>(a.bias + n0 + i * 16 + kg * 4);  // bias is padded to 128
-    const bool full_n = n0 + RW_BN <= a.cout;
+    const bool full_n = n0 + BN <= a.cout;
     const bool wide = ((a.out_cs | a.out_coff) & 7) == 0;
 
     struct Geo {
@@ -199,7 +200,7 @@ __global__ __launch_bounds__(RW_THR, RW_NW / 4) void conv_halo_rw_kernel(RwDev a
                 const int r = tap / 3, s = tap - r * 3;
                 rbf16x8 wf[TN], xf[TM];
 #pragma unroll
-                for (int i = 0; i < TN; ++i) wf[i] = *reinterpret_cast<const rbf16x8*>(Ww + (pl * WROWS + tap * RW_BN + i * 16) * 32 + wrd);
+                for (int i = 0; i < TN; ++i) wf[i] = *reinterpret_cast<const rbf16x8*>(Ww + (pl * WROWS + tap * BN + i * 16) * 32 + wrd);
 #pragma unroll
                 for (int j = 0; j < TM; ++j) {
                     const int pw = apix[j] + r * a.WW + s;
@@ -294,15 +295,15 @@ static bool rw_magic_ok(int d, int nmax, uint32_t* magic) {
     return true;
 }
 
-static int rw_pix_cap(int nch) {  // window pixels per buffer that leave room for the resident weights
-    const int lds = 160 * 1024 - nch * 9 * RW_BN * 64;
+static int rw_pix_cap(int nch, int bn, int per_cu) {  // window pixels per buffer that leave room for the resident weights
+    const int lds = 160 * 1024 / per_cu - nch * 9 * bn * 64;
     int cap = lds / (2 * nch * 64);
     const int reg = RW_ELEMS / (4 * nch);  // register staging slots
     return cap < reg ? cap : reg;
 }
 
-static bool plan_rw_uncached(int H, int W, int nch, RwPlan* best) {
-    const int cap = rw_pix_cap(nch);
+static bool plan_rw_uncached(int H, int W, int nch, int bn, int per_cu, RwPlan* best) {
+    const int cap = rw_pix_cap(nch, bn, per_cu);
     int cand[6] = {16, 32, 64, 128, 256, W};
     bool found = false;
     for (int k = 0; k < 6; ++k) {
@@ -326,19 +327,25 @@ static bool plan_rw_uncached(int H, int W, int nch, RwPlan* best) {
     return found;
 }
 
-static bool plan_rw(int H, int W, int nch, RwPlan* out) {
+// per_cu (out): workgroups per CU the plan leaves LDS for.  The 32-output-channel variant needs <= 128 VGPRs, so two of its
+// 8-wave workgroups fit a CU when each stays within 80 KB: these layers (Cin, Cout <= 32) are bound by bytes in flight --
+// one 22 KB window per CU at a time -- and a second resident workgroup doubles them.
+static bool plan_rw(int H, int W, int nch, int bn, RwPlan* out, int* per_cu) {
     static std::mutex mu;
-    static std::map<std::tuple<int, int, int>, std::pair<bool, RwPlan>> cache;
+    static std::map<std::tuple<int, int, int, int>, std::tuple<bool, RwPlan, int>> cache;
     std::lock_guard<std::mutex> lk(mu);
-    auto key = std::make_tuple(H, W, nch);
+    auto key = std::make_tuple(H, W, nch, bn);
     auto it = cache.find(key);
     if (it == cache.end()) {
-        RwPlan p{};
-        bool ok = plan_rw_uncached(H, W, nch, &p);
-        it = cache.emplace(key, std::make_pair(ok, p)).first;
+        RwPlan p1{}, p2{};
+        const bool ok1 = plan_rw_uncached(H, W, nch, bn, 1, &p1);
+        const bool ok2 = bn == 32 && plan_rw_uncached(H, W, nch, bn, 2, &p2);
+        const bool two = ok2 && (!ok1 || p2.eff >= p1.eff - 0.05);
+        it = cache.emplace(key, std::make_tuple(two || ok1, two ? p2 : p1, two ? 2 : 1)).first;
     }
-    *out = it->second.second;
-    return it->second.first;
+    *out = std::get<1>(it->second);
+    if (per_cu) *per_cu = std::get<2>(it->second);
+    return std::get<0>(it->second);
 }
 
 static bool rw_enabled() {
@@ -356,35 +363,39 @@ bool halo_rw_applicable(int kh, int kw, int stride, int pad, int n, const TView&
     if (stride != 1 || kh != 3 || kw != 3 || pad != 1) return false;
     if (in.f32 || out.f32 || out.h != in.h || out.w != in.w) return false;
     if ((in.c & 7) || (in.cs & 7) || (in.coff & 7) || (out.c & 3) || (out.cs & 3) || (out.coff & 3)) return false;
-    if (in.c < 16 || in.c > 64 || out.c <= 32) return false;  // cout <= 32: conv_halo's BN = 32/16 tiles waste less
+    if (in.c < 16 || in.c > 64 || out.c <= 16) return false;  // cout <= 16 (BN = 16 packing) stays on conv_halo
     if ((long)in.h * in.w * in.cs >= (1L << 30)) return false;
     RwPlan pl;
     const int nch = (in.c + 31) / 32;
-    if (!plan_rw(in.h, in.w, nch, &pl) || pl.eff < 0.6) return false;
+    const int bn = out.c <= 32 ? 32 : RW_BN;
+    if (!plan_rw(in.h, in.w, nch, bn, &pl, nullptr) || pl.eff < 0.6) return false;
     // persistence pays only when every workgroup sees several tiles
-    const long tiles = (long)n * pl.NS * pl.TPS * ((out.c + RW_BN - 1) / RW_BN);
+    const long tiles = (long)n * pl.NS * pl.TPS * ((out.c + bn - 1) / bn);
     return tiles >= 4 * 256;
 }
 
-template <int NCH, bool HAS_RES>
+template <int NCH, bool HAS_RES, int BN>
 static hipError_t rw_launch(const RwDev& d, int act, int grid, size_t lds, hipStream_t st) {
     static bool attr_done = false;
     if (!attr_done) {
-        (void)hipFuncSetAttribute((const void*)conv_halo_rw_kernel<NCH, ACT_NONE, HAS_RES>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute((const void*)conv_halo_rw_kernel<NCH, ACT_SILU, HAS_RES>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute((const void*)conv_halo_rw_kernel<NCH, ACT_RELU, HAS_RES>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)conv_halo_rw_kernel<NCH, ACT_NONE, HAS_RES, BN>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)conv_halo_rw_kernel<NCH, ACT_SILU, HAS_RES, BN>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)conv_halo_rw_kernel<NCH, ACT_RELU, HAS_RES, BN>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_done = true;
     }
-    if (act == ACT_SILU) hipLaunchKernelGGL((conv_halo_rw_kernel<NCH, ACT_SILU, HAS_RES>), dim3(grid), dim3(RW_THR), lds, st, d);
-    else if (act == ACT_RELU) hipLaunchKernelGGL((conv_halo_rw_kernel<NCH, ACT_RELU, HAS_RES>), dim3(grid), dim3(RW_THR), lds, st, d);
-    else hipLaunchKernelGGL((conv_halo_rw_kernel<NCH, ACT_NONE, HAS_RES>), dim3(grid), dim3(RW_THR), lds, st, d);
+    if (act == ACT_SILU) hipLaunchKernelGGL((conv_halo_rw_kernel<NCH, ACT_SILU, HAS_RES, BN>), dim3(grid), dim3(RW_THR), lds, st, d);
+    else if (act == ACT_RELU) hipLaunchKernelGGL((conv_halo_rw_kernel<NCH, ACT_RELU, HAS_RES, BN>), dim3(grid), dim3(RW_THR), lds, st, d);
+    else hipLaunchKernelGGL((conv_halo_rw_kernel<NCH, ACT_NONE, HAS_RES, BN>), dim3(grid), dim3(RW_THR), lds, st, d);
     return hipGetLastError();
 }
 
 hipError_t launch_conv_halo_rw(const ConvArgs& a, hipStream_t st) {
     RwPlan pl;
     const int nch = (a.in.c + 31) / 32;
-    if (!halo_rw_applicable(a.kh, a.kw, a.stride, a.pad, a.n, a.in, a.out) || !plan_rw(a.in.h, a.in.w, nch, &pl)) return hipErrorNotSupported;
+    int per_cu = 1;
+    if (!halo_rw_applicable(a.kh, a.kw, a.stride, a.pad, a.n, a.in, a.out) ||
+        !plan_rw(a.in.h, a.in.w, nch, a.out.c <= 32 ? 32 : RW_BN, &pl, &per_cu))
+        return hipErrorNotSupported;
     RwDev d;
     d.in = (const uint16_t*)a.in.p; d.wgt = (const uint16_t*)a.wgt; d.bias = a.bias; d.out = (uint16_t*)a.out.p;
     d.res = (const uint16_t*)a.res.p;
@@ -394,14 +405,19 @@ hipError_t launch_conv_halo_rw(const ConvArgs& a, hipStream_t st) {
     d.kpad = a.kpad; d.cin_pad = nch * 32;
     d.SW = pl.SW; d.NS = pl.NS; d.TPS = pl.TPS; d.WW = pl.WW; d.maxpix = pl.maxpix;
     d.n_spatial = a.n * pl.NS * pl.TPS;
-    d.NT = (a.out.c + RW_BN - 1) / RW_BN;
+    const int bn = a.out.c <= 32 ? 32 : RW_BN;  // == halo_bn(cout): the packing the weights were given
+    d.NT = (a.out.c + bn - 1) / bn;
     d.mg_ww = pl.mg_ww; d.mg_sw = pl.mg_sw;
-    int grid = 256 / d.NT * d.NT;  // one workgroup per CU, a multiple of the channel tiles
-    const size_t lds = ((size_t)nch * 9 * RW_BN * 32 + (size_t)2 * nch * pl.maxpix * 32) * 2;
+    int grid = 256 * per_cu / d.NT * d.NT;  // one (or two, see plan_rw) workgroups per CU, a multiple of the channel tiles
+    const size_t lds = ((size_t)nch * 9 * bn * 32 + (size_t)2 * nch * pl.maxpix * 32) * 2;
     const bool res = a.res_mode != RES_NONE;
     if (res && (((a.res.cs | a.res.coff) & 7) != 0)) return hipErrorNotSupported;  // halo_rw_applicable() keeps such layers on conv_halo
-    if (nch == 1) return res ? rw_launch<1, true>(d, a.act, grid, lds, st) : rw_launch<1, false>(d, a.act, grid, lds, st);
-    return res ? rw_launch<2, true>(d, a.act, grid, lds, st) : rw_launch<2, false>(d, a.act, grid, lds, st);
+    if (bn == 32) {
+        if (nch == 1) return res ? rw_launch<1, true, 32>(d, a.act, grid, lds, st) : rw_launch<1, false, 32>(d, a.act, grid, lds, st);
+        return res ? rw_launch<2, true, 32>(d, a.act, grid, lds, st) : rw_launch<2, false, 32>(d, a.act, grid, lds, st);
+    }
+    if (nch == 1) return res ? rw_launch<1, true, 64>(d, a.act, grid, lds, st) : rw_launch<1, false, 64>(d, a.act, grid, lds, st);
+    return res ? rw_launch<2, true, 64>(d, a.act, grid, lds, st) : rw_launch<2, false, 64>(d, a.act, grid, lds, st);
 }
 
 }  // namespace adas

@@ -291,7 +291,7 @@ const char* conv_kernel_name(const ConvArgs& a, int prec, int kernel) {
     static thread_local char buf[96];
     const char* actn = a.act == ACT_SILU ? "SILU" : (a.act == ACT_RELU ? "RELU" : "NONE");
     if (kernel == CONV_HALO && halo_rw_applicable(a.kh, a.kw, a.stride, a.pad, a.n, a.in, a.out)) {
-        snprintf(buf, sizeof(buf), "conv_halo_rw_kernel<%d,%s>", (a.in.c + 31) / 32, actn);
+        snprintf(buf, sizeof(buf), a.out.c <= 32 ? "conv_halo_rw_kernel<%d,%s,bn32>" : "conv_halo_rw_kernel<%d,%s>", (a.in.c + 31) / 32, actn);
     } else if (kernel == CONV_HALO) {
         snprintf(buf, sizeof(buf), "conv_halo_kernel<%d,%s,s%d>", a.out.c <= 16 ? 16 : (a.out.c <= 32 ? 32 : 64), actn, a.stride);
     } else if (kernel == CONV_FC) {
