@@ -67,6 +67,9 @@ int adas_engine_infer_host(adas_engine* e, const float* h_input_nchw, int batch,
 /* Device-resident form ("frames never round-trip to host"): input is NCHW fp32 already in HBM;
  * outputs stay in HBM and are read through adas_engine_output_device(). Asynchronous on `stream`. */
 int adas_engine_infer_device(adas_engine* e, const float* d_input_nchw, int batch, void* stream);
+/* 1 when the engine's first layer is the fused stem (bf16 mode) and so can read the packed tensor of adas_preprocess_*_packed */
+int adas_engine_accepts_packed_input(const adas_engine* e);
+int adas_engine_infer_device_packed(adas_engine* e, const uint16_t* d_input_nhwc4, int batch, void* stream);
 const float* adas_engine_output_device(const adas_engine* e, int index);
 /* Algorithmic work of one frame: 2*MACs over conv+linear layers and weight bytes. */
 int adas_engine_stats(const adas_engine* e, double* flops_per_frame, double* weight_bytes, int* num_layers);
@@ -91,6 +94,13 @@ int adas_preprocess_yolo(const uint8_t* d_frames_bgr, int n, int src_h, int src_
                          int dst_w, int keep_ratio, void* stream);
 int adas_preprocess_ufld(const uint8_t* d_frames_bgr, int n, int src_h, int src_w, float* d_out_nchw, int in_h,
                          int in_w, double crop_ratio, void* stream);
+/* The same two conversions into the layout the fused first layer stages anyway: (c0, c1, c2, 0) bf16 pixels, NHWC, 8 bytes per
+ * pixel, rounded exactly as the engine rounds the fp32 tensor -- for adas_engine_infer_device_packed (device-resident path:
+ * the tensor between pre-processing and the first conv shrinks from 12 to 8 bytes per pixel, same network values). */
+int adas_preprocess_yolo_packed(const uint8_t* d_frames_bgr, int n, int src_h, int src_w, uint16_t* d_out_nhwc4, int dst_h,
+                                int dst_w, int keep_ratio, void* stream);
+int adas_preprocess_ufld_packed(const uint8_t* d_frames_bgr, int n, int src_h, int src_w, uint16_t* d_out_nhwc4, int in_h,
+                                int in_w, double crop_ratio, void* stream);
 
 /* ===================================================================================
  * YOLO post-processing: replaces YoloDetector.__process_output (yoloDetector.py:104-133),
@@ -292,6 +302,11 @@ int adas_pipeline_create(const adas_pipeline_desc* d, adas_pipeline** out);
 int adas_pipeline_destroy(adas_pipeline* p);
 /* One step = one frame of every stream.  Asynchronous; adas_pipeline_sync() waits for it. */
 int adas_pipeline_step(adas_pipeline* p, const float* d_det_input_nchw, const float* d_lane_input_nchw);
+/* The same step from camera frames: n_streams BGR u8 frames (src_h x src_w x 3, back to back) in HBM; each branch runs its
+ * pre-processing (adas_preprocess_yolo / adas_preprocess_ufld with lane_crop_ratio = ModelConfig.crop_ratio) into seam
+ * tensors the pipeline owns, so one upload per stream and frame feeds both nets (yoloDetector.py:96-102,
+ * ultrafastLaneDetectorV2.py:96-112 + the body of demo.py:261-281). */
+int adas_pipeline_step_frames(adas_pipeline* p, const uint8_t* d_frames_bgr, int src_h, int src_w, double lane_crop_ratio);
 int adas_pipeline_sync(adas_pipeline* p);
 /* Device time of the last `n` steps' sections in ms (hipEvents on the pipeline stream):
  * [0] detector net, [1] yolo post, [2] lane net, [3] lane decode, [4] tracker, [5] whole step. */

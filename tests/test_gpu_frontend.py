@@ -188,3 +188,58 @@ def test_headless_demo_loop(capsys):
         sys.argv = argv
     out = capsys.readouterr().out
     assert out.count("frame ") == 6 and "FCWS" in out and "frames/s" in out
+
+
+def _bf16_rne(x):
+    u = np.ascontiguousarray(x, np.float32).view(np.uint32).astype(np.uint64)
+    return ((u + 0x7fff + ((u >> 16) & 1)) >> 16).astype(np.uint16)
+
+
+@pytest.mark.parametrize("hw", [(720, 1280), (533, 1600)], ids=str)
+def test_packed_preprocess_equals_rounded_fp32(hw):
+    """adas_preprocess_*_packed = the fp32 tensors of adas_preprocess_* rounded to bf16 (nearest even), as (c0,c1,c2,0) NHWC."""
+    import ctypes as C
+    f = np.stack(list(frames(2, hw[0], hw[1], 17)))
+    dc = L.DeviceBuffer.from_array(f)
+    for kind, (H, W) in (("yolo", (640, 640)), ("ufld", (320, 1600))):
+        d32 = L.DeviceBuffer(2 * 3 * H * W * 4); d16 = L.DeviceBuffer(2 * H * W * 8)
+        if kind == "yolo":
+            L.check(L.lib().adas_preprocess_yolo(dc.ptr, 2, hw[0], hw[1], d32.ptr, H, W, 1, None))
+            L.check(L.lib().adas_preprocess_yolo_packed(dc.ptr, 2, hw[0], hw[1], d16.ptr, H, W, 1, None))
+        else:
+            L.check(L.lib().adas_preprocess_ufld(dc.ptr, 2, hw[0], hw[1], d32.ptr, H, W, C.c_double(0.6), None))
+            L.check(L.lib().adas_preprocess_ufld_packed(dc.ptr, 2, hw[0], hw[1], d16.ptr, H, W, C.c_double(0.6), None))
+        a = d32.download((2, 3, H, W), np.float32)
+        b = d16.download((2, H, W, 4), np.uint16)
+        np.testing.assert_array_equal(b[..., :3], _bf16_rne(a).transpose(0, 2, 3, 1))
+        assert not b[..., 3].any()
+        d32.free(); d16.free()
+    dc.free()
+
+
+@pytest.mark.parametrize("name,kind,hw,layer", [("yolov8n", "yolo", (640, 640), "model.1.conv"), ("yolov5n", "yolo", (640, 640), "model.1.conv"),
+                                                ("yolov8s", "yolo", (640, 640), "model.0.conv"), ("ufldv2_res18", "ufld", (320, 1600), "model.maxpool")])
+def test_engine_packed_input_equals_fp32_input(name, kind, hw, layer):
+    """The fused first layer fed the packed bf16 tensor computes exactly what it computes from the fp32 seam tensor
+    (compared on the first materialised activation behind it)."""
+    import ctypes as C
+    path, W, g = netutil.model(name)
+    e = CE.HipEngine(path, precision="bf16", max_batch=2)
+    assert L.lib().adas_engine_accepts_packed_input(e._h) == 1
+    dc = L.DeviceBuffer.from_array(np.stack(list(frames(2, 720, 1280, 23))))
+    H, Wd = hw
+    d32 = L.DeviceBuffer(2 * 3 * H * Wd * 4); d16 = L.DeviceBuffer(2 * H * Wd * 8)
+    if kind == "yolo":
+        L.check(L.lib().adas_preprocess_yolo(dc.ptr, 2, 720, 1280, d32.ptr, H, Wd, 1, None))
+        L.check(L.lib().adas_preprocess_yolo_packed(dc.ptr, 2, 720, 1280, d16.ptr, H, Wd, 1, None))
+    else:
+        L.check(L.lib().adas_preprocess_ufld(dc.ptr, 2, 720, 1280, d32.ptr, H, Wd, C.c_double(0.6), None))
+        L.check(L.lib().adas_preprocess_ufld_packed(dc.ptr, 2, 720, 1280, d16.ptr, H, Wd, C.c_double(0.6), None))
+    e.infer_device(d32.ptr, 2, None)
+    a = e.fetch_activation(layer, 2)
+    e.infer_device_packed(d16.ptr, 2, None)
+    b = e.fetch_activation(layer, 2)
+    d = np.abs(a - b)
+    print(name, layer, a.shape, "max|diff|", float(d.max()), "differing", int((d > 0).sum()), "of", d.size, "max|a|", float(np.abs(a).max()))
+    np.testing.assert_array_equal(a, b)
+    e.close(); dc.free(); d32.free(); d16.free()

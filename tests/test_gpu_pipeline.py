@@ -72,3 +72,30 @@ def test_pipeline_equals_components(tmp_path, use_graph, overlap):
     t = pipe.timings()
     assert t["step"] > 0
     pipe.close(); det.close(); lane.close(); post.close(); dec.close(); trk.close(); geo.close()
+
+
+def test_pipeline_step_from_camera_frames(tmp_path):
+    """adas_pipeline_step_frames: u8 frames -> both pre-processings inside the (graph-captured) step == pre-processing the
+    frames with the stand-alone kernels and stepping from the seam tensors."""
+    import bench
+    S = 2
+    cam = [bench.cam_frames(S, 70 + i) for i in range(2)]
+    lane_path, _, _ = netutil.model("ufldv2_res18")
+    det_path = M.build("yolov8n").save(str(tmp_path / "d.hipm"))
+    pa = PL.AdasPipeline(det_path, lane_path, n_streams=S, precision="bf16", src_hw=(720, 1280), use_graph=True)
+    pb = PL.AdasPipeline(det_path, lane_path, n_streams=S, precision="bf16", src_hw=(720, 1280), use_graph=False)
+    dt = L.DeviceBuffer(S * 3 * 640 * 640 * 4); lt = L.DeviceBuffer(S * 3 * 320 * 1600 * 4)
+    import ctypes as C
+    for k in (0, 1, 0):
+        dc = L.DeviceBuffer.from_array(cam[k])
+        pa.step_frames(dc.ptr, (720, 1280), 0.6); pa.sync()
+        L.check(L.lib().adas_preprocess_yolo(dc.ptr, S, 720, 1280, dt.ptr, 640, 640, 1, None))
+        L.check(L.lib().adas_preprocess_ufld(dc.ptr, S, 720, 1280, lt.ptr, 320, 1600, C.c_double(0.6), None))
+        pb.step(dt.ptr, lt.ptr); pb.sync()
+        for s in range(S):
+            a, b = PP.YoloPost.fetch(pa.post, s), PP.YoloPost.fetch(pb.post, s)
+            for key in ("cand_anchor", "cand_conf", "keep", "xyxy_int"):
+                np.testing.assert_array_equal(a[key], b[key])
+            assert pa.decode.fetch(s) == pb.decode.fetch(s)
+        dc.free()
+    pa.close(); pb.close(); dt.free(); lt.free()

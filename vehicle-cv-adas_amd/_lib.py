@@ -91,6 +91,8 @@ _SIGS = {
     "adas_engine_output_name": (C.c_char_p, [_P, C.c_int]),
     "adas_engine_infer_host": (C.c_int, [_P, _P, C.c_int, C.POINTER(_P)]),
     "adas_engine_infer_device": (C.c_int, [_P, _P, C.c_int, _P]),
+    "adas_engine_accepts_packed_input": (C.c_int, [_P]),
+    "adas_engine_infer_device_packed": (C.c_int, [_P, _P, C.c_int, _P]),
     "adas_engine_output_device": (_P, [_P, C.c_int]),
     "adas_engine_stats": (C.c_int, [_P, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int)]),
     "adas_engine_profile": (C.c_int, [_P, _P, C.c_int, C.c_int, _P, C.c_int, C.POINTER(C.c_int)]),
@@ -99,6 +101,8 @@ _SIGS = {
     "adas_engine_fetch_activation": (C.c_int, [_P, C.c_int, C.c_int, _P, C.POINTER(C.c_int64)]),
     "adas_preprocess_yolo": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, _P, C.c_int, C.c_int, C.c_int, _P]),
     "adas_preprocess_ufld": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, _P, C.c_int, C.c_int, C.c_double, _P]),
+    "adas_preprocess_yolo_packed": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, _P, C.c_int, C.c_int, C.c_int, _P]),
+    "adas_preprocess_ufld_packed": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, _P, C.c_int, C.c_int, C.c_double, _P]),
     "adas_letterbox_params": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(YoloPostParams)]),
     "adas_yolo_post_create": (C.c_int, [C.POINTER(YoloPostParams), C.c_int, C.POINTER(_P)]),
     "adas_yolo_post_destroy": (C.c_int, [_P]),
@@ -129,6 +133,7 @@ _SIGS = {
     "adas_pipeline_create": (C.c_int, [C.POINTER(PipelineDesc), C.POINTER(_P)]),
     "adas_pipeline_destroy": (C.c_int, [_P]),
     "adas_pipeline_step": (C.c_int, [_P, _P, _P]),
+    "adas_pipeline_step_frames": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_double]),
     "adas_pipeline_sync": (C.c_int, [_P]),
     "adas_pipeline_timings": (C.c_int, [_P, C.POINTER(C.c_float)]),
 }

@@ -143,6 +143,10 @@ class HipEngine(EngineBase):
     def infer_device(self, d_input_ptr, batch=1, stream=None):
         L.check(L.lib().adas_engine_infer_device(self._h, d_input_ptr, int(batch), stream))
 
+    def infer_device_packed(self, d_input_ptr, batch=1, stream=None):
+        """Input = the (c0,c1,c2,0) bf16 NHWC tensor of adas_preprocess_*_packed (fused first layer only)."""
+        L.check(L.lib().adas_engine_infer_device_packed(self._h, d_input_ptr, int(batch), stream))
+
     def output_device_ptr(self, index):
         return L.lib().adas_engine_output_device(self._h, index)
 

@@ -62,7 +62,9 @@ constexpr int STEM_WW = 72;  // window row pitch in pixels (even: 16 B aligned f
 // 8 x 16 tile of that conv needs are kept in LDS (geometry of the pooled case with 8 rows) and the second conv runs from
 // there -- the 16-channel stem output (3.3 MB per 640^2 frame, written and read back) never reaches HBM.  Hp/Wp are then
 // the second conv's output extent and `out` its view.
-template <int KH, int NT, int ACT, bool POOL, bool CONV2 = false>
+// PACKED: the input is the (c0, c1, c2, 0) bf16 NHWC tensor adas_preprocess_*_packed writes (8 B per pixel, one load per window
+// pixel) instead of the fp32 NCHW seam tensor (three loads + a conversion); same values either way.
+template <int KH, int NT, int ACT, bool POOL, bool CONV2 = false, bool PACKED = false>
 __global__ __launch_bounds__(256, 2) void conv_stem_kernel(StemDev a) {
     constexpr bool TILE2 = POOL || CONV2;
     constexpr int CTH = CONV2 ? 17 : (POOL ? 9 : 8), CTW = TILE2 ? 33 : 32;  // conv tile (POOL: 4x16 pooled + halo)
@@ -104,7 +106,7 @@ __global__ __launch_bounds__(256, 2) void conv_stem_kernel(StemDev a) {
     // the hardware returns 0 = zero padding; a tile index past the end turns every lane out of range)
     // (a second register set -- tile t+2 requested while t+1 is in flight -- measured no gain: the YOLO stems are bound by VALU
     // issue, SiLU and index arithmetic, not by bytes in flight)
-    float px[NQ][3];
+    uint32_t px[NQ][3];  // raw bits: three fp32 planes, or (PACKED) the pixel's two bf16x2 words
     auto fetch = [&](int tile) {
         const bool live = tile < a.ntiles;
         const int tl = live ? tile : 0;
@@ -114,19 +116,26 @@ __global__ __launch_bounds__(256, 2) void conv_stem_kernel(StemDev a) {
         const int cy0 = CONV2 ? 2 * (ty * 8) - 1 : (POOL ? 2 * (ty * 4) - 1 : ty * CTH);
         const int cx0 = TILE2 ? 2 * (tx * 16) - 1 : tx * CTW;
         const int iy0 = 2 * cy0 - a.pad, ix0 = 2 * cx0 - a.pad;
-        const float* in_img = a.in + (size_t)img * a.C * plane;
-        __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)in_img, 0, a.C * plane * 4, 0x00020000);
+        const void* in_img = PACKED ? (const void*)(reinterpret_cast<const uint16_t*>(a.in) + (size_t)img * plane * 4)
+                                    : (const void*)(a.in + (size_t)img * a.C * plane);
+        __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)in_img, 0, PACKED ? plane * 8 : a.C * plane * 4, 0x00020000);
 #pragma unroll
         for (int i = 0; i < NQ; ++i) {
             const int q = tid + 256 * i;
             const int wy = q / WW, wx = q - wy * WW;
             const int iy = iy0 + wy, ix = ix0 + wx;
             const bool ok = live && q < WH * WW && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
-            const uint32_t off = (uint32_t)((iy * a.W + ix) * 4);
+            if (PACKED) {
+                const su32x2 v = __builtin_bit_cast(su32x2, __builtin_amdgcn_raw_buffer_load_b64(rsrc, ok ? (uint32_t)((iy * a.W + ix) * 8) : 0x80000000u, 0, 0));
+                px[i][0] = v.x;
+                px[i][1] = v.y;
+            } else {
+                const uint32_t off = (uint32_t)((iy * a.W + ix) * 4);
 #pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                const uint32_t oc = (ok && c < a.C) ? off + (uint32_t)(c * plane * 4) : 0x80000000u;
-                px[i][c] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, oc, 0, 0));
+                for (int c = 0; c < 3; ++c) {
+                    const uint32_t oc = (ok && c < a.C) ? off + (uint32_t)(c * plane * 4) : 0x80000000u;
+                    px[i][c] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rsrc, oc, 0, 0);
+                }
             }
         }
     };
@@ -145,8 +154,13 @@ __global__ __launch_bounds__(256, 2) void conv_stem_kernel(StemDev a) {
             const int q = tid + 256 * i;
             if (q < WH * WW) {
                 su32x2 v;
-                v.x = s_pack2(px[i][0], px[i][1]);
-                v.y = s_pack2(px[i][2], 0.f);
+                if (PACKED) {
+                    v.x = px[i][0];
+                    v.y = px[i][1];
+                } else {
+                    v.x = s_pack2(__uint_as_float(px[i][0]), __uint_as_float(px[i][1]));
+                    v.y = s_pack2(__uint_as_float(px[i][2]), 0.f);
+                }
                 *reinterpret_cast<su32x2*>(win + q * 4) = v;
             }
         }
@@ -351,7 +365,7 @@ bool stem2_applicable(int prec, int kh, int pad, int act, const TView& stem_out,
     return out2.h == (stem_out.h + 2 - 3) / 2 + 1 && out2.w == (stem_out.w + 2 - 3) / 2 + 1;
 }
 hipError_t launch_conv_stem2(const float* nchw, int n, int c_true, int H, int W, int kh, int pad, const void* wfrag, const float* bias,
-                             const TView& stem_out, const void* wfrag2, const float* bias2, const TView& out2, hipStream_t st) {
+                             const TView& stem_out, const void* wfrag2, const float* bias2, const TView& out2, bool packed_in, hipStream_t st) {
     StemDev d;
     d.in = nchw; d.wfrag = (const uint16_t*)wfrag; d.bias = bias;
     d.out = (uint16_t*)out2.p; d.out_cs = out2.cs; d.out_coff = out2.coff; d.cout = stem_out.c;
@@ -363,22 +377,29 @@ hipError_t launch_conv_stem2(const float* nchw, int n, int c_true, int H, int W,
     d.wfrag2 = (const uint16_t*)wfrag2; d.bias2 = bias2;
     if ((size_t)c_true * H * W * 4 >= (1ull << 31)) return hipErrorInvalidValue;
     const int grid = d.ntiles < 1024 ? d.ntiles : 1024;
-    if (kh == 3) hipLaunchKernelGGL((conv_stem_kernel<3, 1, ACT_SILU, false, true>), dim3(grid), dim3(256), 0, st, d);
-    else if (kh == 6) hipLaunchKernelGGL((conv_stem_kernel<6, 1, ACT_SILU, false, true>), dim3(grid), dim3(256), 0, st, d);
+    if (kh == 3 && packed_in) hipLaunchKernelGGL((conv_stem_kernel<3, 1, ACT_SILU, false, true, true>), dim3(grid), dim3(256), 0, st, d);
+    else if (kh == 3) hipLaunchKernelGGL((conv_stem_kernel<3, 1, ACT_SILU, false, true, false>), dim3(grid), dim3(256), 0, st, d);
+    else if (kh == 6 && packed_in) hipLaunchKernelGGL((conv_stem_kernel<6, 1, ACT_SILU, false, true, true>), dim3(grid), dim3(256), 0, st, d);
+    else if (kh == 6) hipLaunchKernelGGL((conv_stem_kernel<6, 1, ACT_SILU, false, true, false>), dim3(grid), dim3(256), 0, st, d);
     else return hipErrorInvalidValue;
     return hipGetLastError();
 }
 
 template <int KH, int NT, bool POOL>
-static hipError_t stem_launch_act(const StemDev& d, int act, hipStream_t st) {
+static hipError_t stem_launch_act(const StemDev& d, int act, bool packed_in, hipStream_t st) {
     const int grid = d.ntiles < 1024 ? d.ntiles : 1024;
-    if (act == ACT_RELU) hipLaunchKernelGGL((conv_stem_kernel<KH, NT, ACT_RELU, POOL>), dim3(grid), dim3(256), 0, st, d);
-    else hipLaunchKernelGGL((conv_stem_kernel<KH, NT, ACT_SILU, POOL>), dim3(grid), dim3(256), 0, st, d);
+    if (packed_in) {
+        if (act == ACT_RELU) hipLaunchKernelGGL((conv_stem_kernel<KH, NT, ACT_RELU, POOL, false, true>), dim3(grid), dim3(256), 0, st, d);
+        else hipLaunchKernelGGL((conv_stem_kernel<KH, NT, ACT_SILU, POOL, false, true>), dim3(grid), dim3(256), 0, st, d);
+    } else {
+        if (act == ACT_RELU) hipLaunchKernelGGL((conv_stem_kernel<KH, NT, ACT_RELU, POOL, false, false>), dim3(grid), dim3(256), 0, st, d);
+        else hipLaunchKernelGGL((conv_stem_kernel<KH, NT, ACT_SILU, POOL, false, false>), dim3(grid), dim3(256), 0, st, d);
+    }
     return hipGetLastError();
 }
 
 hipError_t launch_conv_stem(const float* nchw, int n, int c_true, int H, int W, int kh, int pad, int act, const void* wfrag,
-                            const float* bias, const TView& conv_out, bool pool, const TView& pool_out, hipStream_t st) {
+                            const float* bias, const TView& conv_out, bool pool, const TView& pool_out, bool packed_in, hipStream_t st) {
     StemDev d;
     const TView& o = pool ? pool_out : conv_out;
     d.in = nchw; d.wfrag = (const uint16_t*)wfrag; d.bias = bias;
@@ -395,9 +416,9 @@ hipError_t launch_conv_stem(const float* nchw, int n, int c_true, int H, int W, 
     d.ntiles = n * d.tiles_x * d.tiles_y;
     if ((size_t)c_true * H * W * 4 >= (1ull << 31)) return hipErrorInvalidValue;
     const int nt = (conv_out.c + 15) / 16;
-    if (pool) return stem_launch_act<7, 4, true>(d, act, st);
+    if (pool) return stem_launch_act<7, 4, true>(d, act, packed_in, st);
 #define STEM_CASE(KH_, NT_) \
-    if (kh == KH_ && nt == NT_) return stem_launch_act<KH_, NT_, false>(d, act, st);
+    if (kh == KH_ && nt == NT_) return stem_launch_act<KH_, NT_, false>(d, act, packed_in, st);
     STEM_CASE(3, 1) STEM_CASE(3, 2) STEM_CASE(3, 4)
     STEM_CASE(6, 1) STEM_CASE(6, 2) STEM_CASE(6, 4)
     STEM_CASE(7, 4)

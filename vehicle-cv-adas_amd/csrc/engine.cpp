@@ -403,7 +403,7 @@ int adas_engine_layer_info(const adas_engine* e, int layer, char* name, int cap,
 
 // ------------------------------------------------------------------------------------- execution
 namespace adas {
-int engine_run_op(adas_engine* e, int i, const float* d_in, int batch, hipStream_t st) {
+int engine_run_op(adas_engine* e, int i, const float* d_in, int batch, hipStream_t st, bool packed_in) {
     EngOp& op = e->ops[i];
     const FileOp& o = op.f;
     unsigned char* wb = (unsigned char*)e->d_weights;
@@ -419,10 +419,10 @@ int engine_run_op(adas_engine* e, int i, const float* d_in, int batch, hipStream
         if (op.fuse_conv2 >= 0) {
             const EngOp& c2 = e->ops[op.fuse_conv2];
             err = launch_conv_stem2(d_in, batch, e->hdr.in_c, e->hdr.in_h, e->hdr.in_w, o.kh, o.pad, wb + op.w_off, (const float*)(wb + op.b_off), cv,
-                                    wb + c2.w_off, (const float*)(wb + c2.b_off), make_view(e, c2.f.out_buf, c2.f.out_coff, c2.f.out_c), st);
+                                    wb + c2.w_off, (const float*)(wb + c2.b_off), make_view(e, c2.f.out_buf, c2.f.out_coff, c2.f.out_c), packed_in, st);
         } else
             err = launch_conv_stem(d_in, batch, e->hdr.in_c, e->hdr.in_h, e->hdr.in_w, o.kh, o.pad, o.act, wb + op.w_off,
-                                   (const float*)(wb + op.b_off), cv, op.fuse_pool >= 0, pv, st);
+                                   (const float*)(wb + op.b_off), cv, op.fuse_pool >= 0, pv, packed_in, st);
         if (err != hipSuccess) {
             set_error("layer %d (%s): stem launch failed: %s", i, op.name.c_str(), hipGetErrorString(err));
             (void)hipGetLastError();
@@ -502,9 +502,9 @@ int engine_run_op(adas_engine* e, int i, const float* d_in, int batch, hipStream
     return ADAS_OK;
 }
 
-int engine_forward(adas_engine* e, const float* d_in, int batch, hipStream_t st) {
+int engine_forward(adas_engine* e, const float* d_in, int batch, hipStream_t st, bool packed_in) {
     for (int i = 0; i < (int)e->ops.size(); ++i) {
-        int rc = engine_run_op(e, i, d_in, batch, st);
+        int rc = engine_run_op(e, i, d_in, batch, st, packed_in);
         if (rc != ADAS_OK) return rc;
     }
     return ADAS_OK;
@@ -518,6 +518,18 @@ int adas_engine_infer_device(adas_engine* e, const float* d_input, int batch, vo
                  e ? e->max_batch : 0);
     e->last = (hipStream_t)stream;
     return engine_forward(e, d_input, batch, (hipStream_t)stream);
+}
+
+int adas_engine_accepts_packed_input(const adas_engine* e) {
+    return (e && e->ops.size() >= 2 && e->ops[0].skip && e->ops[1].kernel == CONV_STEM) ? 1 : 0;
+}
+
+int adas_engine_infer_device_packed(adas_engine* e, const uint16_t* d_input_nhwc4, int batch, void* stream) {
+    ADAS_REQUIRE(e && d_input_nhwc4 && batch > 0 && batch <= e->max_batch, ADAS_ERR_INVALID, "adas_engine_infer_device_packed: bad argument");
+    ADAS_REQUIRE(adas_engine_accepts_packed_input(e), ADAS_ERR_INVALID,
+                 "this engine's first layer is not the fused stem (fp32 mode or ADAS_NO_STEM): feed the fp32 NCHW tensor instead");
+    e->last = (hipStream_t)stream;
+    return engine_forward(e, reinterpret_cast<const float*>(d_input_nhwc4), batch, (hipStream_t)stream, true);
 }
 
 const float* adas_engine_output_device(const adas_engine* e, int index) {

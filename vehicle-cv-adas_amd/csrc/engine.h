@@ -64,8 +64,9 @@ struct EngOut {
     std::string name;
 };
 
-int engine_run_op(struct ::adas_engine* e, int i, const float* d_in, int batch, hipStream_t st);
-int engine_forward(struct ::adas_engine* e, const float* d_in, int batch, hipStream_t st);
+// packed_in: d_in is the (c0,c1,c2,0) bf16 NHWC tensor of adas_preprocess_*_packed (fused first layer only)
+int engine_run_op(struct ::adas_engine* e, int i, const float* d_in, int batch, hipStream_t st, bool packed_in = false);
+int engine_forward(struct ::adas_engine* e, const float* d_in, int batch, hipStream_t st, bool packed_in = false);
 
 }  // namespace adas
 

@@ -72,10 +72,10 @@ void stem2_pack_weights(const float* w_ohwi_32x3x3x16, uint16_t* dst_host);
 bool stem2_applicable(int prec, int kh, int pad, int act, const TView& stem_out, int kh2, int kw2, int stride2, int pad2, int act2, int res_mode2,
                       const TView& out2);
 hipError_t launch_conv_stem2(const float* nchw, int n, int c_true, int H, int W, int kh, int pad, const void* wfrag, const float* bias,
-                             const TView& stem_out, const void* wfrag2, const float* bias2, const TView& out2, hipStream_t st);
+                             const TView& stem_out, const void* wfrag2, const float* bias2, const TView& out2, bool packed_in, hipStream_t st);
 void stem_pack_weights(const float* w_ohwi, int cout, int kh, int kw, int cs, int c_true, uint16_t* dst_host);
 hipError_t launch_conv_stem(const float* nchw, int n, int c_true, int H, int W, int kh, int pad, int act, const void* wfrag,
-                            const float* bias, const TView& conv_out, bool pool, const TView& pool_out, hipStream_t st);
+                            const float* bias, const TView& conv_out, bool pool, const TView& pool_out, bool packed_in, hipStream_t st);
 // CONV_HALO packing: slab order [cout tile of halo_bn(cout)][32-channel chunk][tap][n within tile][32] -- the 9*BN*64 B a
 // workgroup stages per chunk are one contiguous run (every wave-level staging load reads 1 KB of consecutive bytes).
 inline int halo_bn(int cout) { return cout <= 16 ? 16 : (cout <= 32 ? 32 : 64); }

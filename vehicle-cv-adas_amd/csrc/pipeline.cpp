@@ -21,6 +21,16 @@ struct adas_pipeline {
     std::vector<Cached> graphs;  // one captured step per distinct (detector input, lane input) pair
     hipEvent_t ev[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     bool timed = false;
+    // step_frames: u8 camera frames in, the engine-seam tensors live here
+    float* det_in = nullptr;
+    float* lane_in = nullptr;
+    struct FrameSrc {
+        const uint8_t* frames;
+        int h, w;
+        double crop;
+    };
+    FrameSrc fsrc{nullptr, 0, 0, 0.0};  // set while a step_frames call records
+    bool packed = false;  // both first layers are the fused stem: the seam tensors are (c0,c1,c2,0) bf16 NHWC, 8 B per pixel
 };
 
 using namespace adas;
@@ -40,8 +50,25 @@ static int record_step(adas_pipeline* p, const float* d_det, const float* d_lane
         ADAS_HIP_TRY(hipEventRecord(p->ev_fork, st));
         ADAS_HIP_TRY(hipStreamWaitEvent(sl, p->ev_fork, 0));
     }
+    if (p->fsrc.frames) {  // pre-processing inside the step: each branch converts the shared u8 frames for its own net
+        if (p->d.detector) {
+            int64_t is[4];
+            adas_engine_input_shape(p->d.detector, is);
+            rc = p->packed ? adas_preprocess_yolo_packed(p->fsrc.frames, S, p->fsrc.h, p->fsrc.w, (uint16_t*)p->det_in, (int)is[2], (int)is[3], 1, st)
+                           : adas_preprocess_yolo(p->fsrc.frames, S, p->fsrc.h, p->fsrc.w, p->det_in, (int)is[2], (int)is[3], 1, st);
+            if (rc) return rc;
+        }
+        if (p->d.lane) {
+            int64_t is[4];
+            adas_engine_input_shape(p->d.lane, is);
+            rc = p->packed ? adas_preprocess_ufld_packed(p->fsrc.frames, S, p->fsrc.h, p->fsrc.w, (uint16_t*)p->lane_in, (int)is[2], (int)is[3], p->fsrc.crop, sl)
+                           : adas_preprocess_ufld(p->fsrc.frames, S, p->fsrc.h, p->fsrc.w, p->lane_in, (int)is[2], (int)is[3], p->fsrc.crop, sl);
+            if (rc) return rc;
+        }
+    }
+    const bool packed_now = p->fsrc.frames && p->packed;
     if (p->d.detector) {
-        rc = adas_engine_infer_device(p->d.detector, d_det, S, st);
+        rc = packed_now ? adas_engine_infer_device_packed(p->d.detector, (const uint16_t*)d_det, S, st) : adas_engine_infer_device(p->d.detector, d_det, S, st);
         if (rc) return rc;
         if (events) ADAS_HIP_TRY(hipEventRecord(p->ev[1], st));
         rc = adas_yolo_post_run(p->d.post, adas_engine_output_device(p->d.detector, 0), S, st);
@@ -49,7 +76,7 @@ static int record_step(adas_pipeline* p, const float* d_det, const float* d_lane
     } else if (events) ADAS_HIP_TRY(hipEventRecord(p->ev[1], st));
     if (events) ADAS_HIP_TRY(hipEventRecord(p->ev[2], st));
     if (p->d.lane) {
-        rc = adas_engine_infer_device(p->d.lane, d_lane, S, sl);
+        rc = packed_now ? adas_engine_infer_device_packed(p->d.lane, (const uint16_t*)d_lane, S, sl) : adas_engine_infer_device(p->d.lane, d_lane, S, sl);
         if (rc) return rc;
         if (events) ADAS_HIP_TRY(hipEventRecord(p->ev[3], st));
         const adas_engine* le = p->d.lane;
@@ -129,6 +156,8 @@ int adas_pipeline_destroy(adas_pipeline* p) {
     if (p->ev_join) (void)hipEventDestroy(p->ev_join);
     if (p->st_lane) (void)hipStreamDestroy(p->st_lane);
     if (p->st) (void)hipStreamDestroy(p->st);
+    if (p->det_in) (void)hipFree(p->det_in);
+    if (p->lane_in) (void)hipFree(p->lane_in);
     delete p;
     return ADAS_OK;
 }
@@ -150,6 +179,61 @@ int adas_pipeline_step(adas_pipeline* p, const float* d_det, const float* d_lane
         ADAS_HIP_TRY(hipStreamBeginCapture(p->st, hipStreamCaptureModeThreadLocal));
         int rc = record_step(p, d_det, d_lane, false);
         hipError_t ce = hipStreamEndCapture(p->st, &g.graph);
+        if (rc) return rc;
+        if (ce != hipSuccess) return hip_fail(ce, "hipStreamEndCapture", __FILE__, __LINE__);
+        ADAS_HIP_TRY(hipGraphInstantiate(&g.exec, g.graph, nullptr, nullptr, 0));
+        p->graphs.push_back(g);
+        exec = g.exec;
+    }
+    ADAS_HIP_TRY(hipEventRecord(p->ev[0], p->st));
+    ADAS_HIP_TRY(hipGraphLaunch(exec, p->st));
+    ADAS_HIP_TRY(hipEventRecord(p->ev[5], p->st));
+    p->timed = false;
+    return ADAS_OK;
+}
+
+int adas_pipeline_step_frames(adas_pipeline* p, const uint8_t* d_frames_bgr, int src_h, int src_w, double lane_crop_ratio) {
+    ADAS_REQUIRE(p && d_frames_bgr && src_h > 0 && src_w > 0, ADAS_ERR_INVALID, "adas_pipeline_step_frames: bad argument");
+    ADAS_REQUIRE(!p->d.lane || (lane_crop_ratio > 0.0 && lane_crop_ratio <= 1.0), ADAS_ERR_INVALID, "lane crop ratio must be in (0, 1]");
+    const size_t S = p->d.n_streams;
+    if (!p->det_in && !p->lane_in) {
+        const char* env = getenv("ADAS_NO_PACKED_SEAM");
+        p->packed = !(env && env[0] == '1') && (!p->d.detector || adas_engine_accepts_packed_input(p->d.detector)) &&
+                    (!p->d.lane || adas_engine_accepts_packed_input(p->d.lane));
+    }
+    if (p->d.detector && !p->det_in) {
+        int64_t is[4];
+        adas_engine_input_shape(p->d.detector, is);
+        ADAS_HIP_TRY(hipMalloc((void**)&p->det_in, S * (size_t)(is[1] * is[2] * is[3]) * 4));
+    }
+    if (p->d.lane && !p->lane_in) {
+        int64_t is[4];
+        adas_engine_input_shape(p->d.lane, is);
+        ADAS_HIP_TRY(hipMalloc((void**)&p->lane_in, S * (size_t)(is[1] * is[2] * is[3]) * 4));
+    }
+    const adas_pipeline::FrameSrc fs{d_frames_bgr, src_h, src_w, lane_crop_ratio};
+    if (!(p->d.use_graph & 1)) {
+        p->fsrc = fs;
+        p->timed = true;
+        int rc = record_step(p, p->det_in, p->lane_in, true);
+        p->fsrc.frames = nullptr;
+        return rc;
+    }
+    // graph mode: one captured step per distinct frame buffer / geometry (cache entries of this kind carry the frames pointer
+    // in `det` and the geometry in `lane`'s place through a tagged key)
+    hipGraphExec_t exec = nullptr;
+    const float* key_a = reinterpret_cast<const float*>(d_frames_bgr);
+    const float* key_b = reinterpret_cast<const float*>((uintptr_t)(((uint64_t)(uint32_t)src_h << 32) | (uint32_t)src_w | 0x8000000000000000ull));
+    for (auto& g : p->graphs)
+        if (g.det == key_a && g.lane == key_b) exec = g.exec;
+    if (!exec) {
+        ADAS_REQUIRE(p->graphs.size() < 64, ADAS_ERR_CAPACITY, "more than 64 distinct input buffers: reuse staging buffers with use_graph");
+        adas_pipeline::Cached g{key_a, key_b, nullptr, nullptr};
+        p->fsrc = fs;
+        ADAS_HIP_TRY(hipStreamBeginCapture(p->st, hipStreamCaptureModeThreadLocal));
+        int rc = record_step(p, p->det_in, p->lane_in, false);
+        hipError_t ce = hipStreamEndCapture(p->st, &g.graph);
+        p->fsrc.frames = nullptr;
         if (rc) return rc;
         if (ce != hipSuccess) return hip_fail(ce, "hipStreamEndCapture", __FILE__, __LINE__);
         ADAS_HIP_TRY(hipGraphInstantiate(&g.exec, g.graph, nullptr, nullptr, 0));

@@ -62,12 +62,22 @@ __device__ __forceinline__ void resize_px(const uint8_t* __restrict__ src, const
     }
 }
 
+// PACK: write the frame as the fused first layer stages it anyway -- (c0, c1, c2, 0) bf16 pixels, 8 B each, NHWC -- instead of
+// three fp32 planes: the same round-to-nearest-even conversion conv_stem.hip applies to the fp32 seam tensor, so the network sees
+// identical values while the tensor between pre-processing and stem shrinks from 12 to 8 bytes per pixel.
+__device__ __forceinline__ uint32_t pre_bf16(float f) {  // round to nearest even on the bits (finite inputs): what v_cvt_pk_bf16_f32 does;
+    const uint32_t u = __float_as_uint(f);                 // written out so that the float result above is materialised first and the
+    return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;         // double -> float -> bf16 roundings cannot be merged into one
+}
+__device__ __forceinline__ uint32_t pre_pack2(float a, float b) { return pre_bf16(a) | (pre_bf16(b) << 16); }
+
 struct YoloPreDev {
     const uint8_t* src;
     float* dst;
     ResizeGeom g;
     int n, dh, dw, padh, padw;
 };
+template <bool PACK>
 __global__ void preprocess_yolo_kernel(YoloPreDev d) {
     const size_t plane = (size_t)d.dh * d.dw;
     const size_t total = (size_t)d.n * plane;
@@ -78,11 +88,16 @@ __global__ void preprocess_yolo_kernel(YoloPreDev d) {
         int v[3] = {114, 114, 114};  // canvas (utils.py:54)
         const int ry = y - d.padh, rx = x - d.padw;
         if (ry >= 0 && ry < d.g.rh && rx >= 0 && rx < d.g.rw) resize_px(d.src + (size_t)b * d.g.sh * d.g.sw * 3, d.g, ry, rx, v);
-        float* o = d.dst + (size_t)b * 3 * plane + p;
         // blobFromImage: float32(v) * (1/255.0) evaluated in double, swapRB: plane 0 = R = source channel 2
-        o[0] = (float)((double)v[2] * (1.0 / 255.0));
-        o[plane] = (float)((double)v[1] * (1.0 / 255.0));
-        o[2 * plane] = (float)((double)v[0] * (1.0 / 255.0));
+        const float c0 = (float)((double)v[2] * (1.0 / 255.0)), c1 = (float)((double)v[1] * (1.0 / 255.0)), c2 = (float)((double)v[0] * (1.0 / 255.0));
+        if (PACK) {
+            reinterpret_cast<uint2*>(d.dst)[i] = make_uint2(pre_pack2(c0, c1), pre_pack2(c2, 0.f));
+        } else {
+            float* o = d.dst + (size_t)b * 3 * plane + p;
+            o[0] = c0;
+            o[plane] = c1;
+            o[2 * plane] = c2;
+        }
     }
 }
 
@@ -92,6 +107,7 @@ struct UfldPreDev {
     ResizeGeom g;
     int n, ih, iw, row0;
 };
+template <bool PACK>
 __global__ void preprocess_ufld_kernel(UfldPreDev d) {
     const size_t plane = (size_t)d.ih * d.iw;
     const size_t total = (size_t)d.n * plane;
@@ -102,11 +118,18 @@ __global__ void preprocess_ufld_kernel(UfldPreDev d) {
         const int y = p / d.iw, x = p - y * d.iw;
         int v[3];
         resize_px(d.src + (size_t)b * d.g.sh * d.g.sw * 3, d.g, d.row0 + y, x, v);
-        float* o = d.dst + (size_t)b * 3 * plane + p;
+        float cv[3];
 #pragma unroll
         for (int c = 0; c < 3; ++c) {  // RGB plane c = BGR source channel 2-c
             const float q = (float)v[2 - c] / 255.0f;                    // float32 array / Python float stays float32
-            o[(size_t)c * plane] = (float)(((double)q - mean[c]) / stdv[c]);  // - list, / list promote to float64
+            cv[c] = (float)(((double)q - mean[c]) / stdv[c]);             // - list, / list promote to float64
+        }
+        if (PACK) {
+            reinterpret_cast<uint2*>(d.dst)[i] = make_uint2(pre_pack2(cv[0], cv[1]), pre_pack2(cv[2], 0.f));
+        } else {
+            float* o = d.dst + (size_t)b * 3 * plane + p;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) o[(size_t)c * plane] = cv[c];
         }
     }
 }
@@ -120,8 +143,8 @@ int grid_for(size_t total) {
 
 extern "C" {
 
-int adas_preprocess_yolo(const uint8_t* d_frames_bgr, int n, int src_h, int src_w, float* d_out_nchw, int dst_h, int dst_w,
-                         int keep_ratio, void* stream) {
+static int preprocess_yolo_impl(const uint8_t* d_frames_bgr, int n, int src_h, int src_w, float* d_out_nchw, int dst_h, int dst_w,
+                                int keep_ratio, void* stream, bool pack) {
     ADAS_REQUIRE(d_frames_bgr && d_out_nchw && n > 0 && src_h > 0 && src_w > 0 && dst_h > 0 && dst_w > 0, ADAS_ERR_INVALID,
                  "adas_preprocess_yolo: bad argument");
     adas_yolo_post_params lb;
@@ -139,13 +162,22 @@ int adas_preprocess_yolo(const uint8_t* d_frames_bgr, int n, int src_h, int src_
     d.g.sh = src_h; d.g.sw = src_w; d.g.rh = newh; d.g.rw = neww;
     d.g.scale_y = 1.0 / ((double)newh / (double)src_h);
     d.g.scale_x = 1.0 / ((double)neww / (double)src_w);
-    hipLaunchKernelGGL(preprocess_yolo_kernel, dim3(grid_for((size_t)n * dst_h * dst_w)), dim3(256), 0, (hipStream_t)stream, d);
+    if (pack) hipLaunchKernelGGL(preprocess_yolo_kernel<true>, dim3(grid_for((size_t)n * dst_h * dst_w)), dim3(256), 0, (hipStream_t)stream, d);
+    else hipLaunchKernelGGL(preprocess_yolo_kernel<false>, dim3(grid_for((size_t)n * dst_h * dst_w)), dim3(256), 0, (hipStream_t)stream, d);
     ADAS_HIP_TRY(hipGetLastError());
     return ADAS_OK;
 }
+int adas_preprocess_yolo(const uint8_t* d_frames_bgr, int n, int src_h, int src_w, float* d_out_nchw, int dst_h, int dst_w,
+                         int keep_ratio, void* stream) {
+    return preprocess_yolo_impl(d_frames_bgr, n, src_h, src_w, d_out_nchw, dst_h, dst_w, keep_ratio, stream, false);
+}
+int adas_preprocess_yolo_packed(const uint8_t* d_frames_bgr, int n, int src_h, int src_w, uint16_t* d_out_nhwc4, int dst_h, int dst_w,
+                                int keep_ratio, void* stream) {
+    return preprocess_yolo_impl(d_frames_bgr, n, src_h, src_w, reinterpret_cast<float*>(d_out_nhwc4), dst_h, dst_w, keep_ratio, stream, true);
+}
 
-int adas_preprocess_ufld(const uint8_t* d_frames_bgr, int n, int src_h, int src_w, float* d_out_nchw, int in_h, int in_w,
-                         double crop_ratio, void* stream) {
+static int preprocess_ufld_impl(const uint8_t* d_frames_bgr, int n, int src_h, int src_w, float* d_out_nchw, int in_h, int in_w,
+                                double crop_ratio, void* stream, bool pack) {
     ADAS_REQUIRE(d_frames_bgr && d_out_nchw && n > 0 && src_h > 0 && src_w > 0 && in_h > 0 && in_w > 0 && crop_ratio > 0.0 &&
                      crop_ratio <= 1.0, ADAS_ERR_INVALID, "adas_preprocess_ufld: bad argument");
     UfldPreDev d;
@@ -156,9 +188,18 @@ int adas_preprocess_ufld(const uint8_t* d_frames_bgr, int n, int src_h, int src_
     d.g.sh = src_h; d.g.sw = src_w; d.g.rh = rh; d.g.rw = in_w;
     d.g.scale_y = 1.0 / ((double)rh / (double)src_h);
     d.g.scale_x = 1.0 / ((double)in_w / (double)src_w);
-    hipLaunchKernelGGL(preprocess_ufld_kernel, dim3(grid_for((size_t)n * in_h * in_w)), dim3(256), 0, (hipStream_t)stream, d);
+    if (pack) hipLaunchKernelGGL(preprocess_ufld_kernel<true>, dim3(grid_for((size_t)n * in_h * in_w)), dim3(256), 0, (hipStream_t)stream, d);
+    else hipLaunchKernelGGL(preprocess_ufld_kernel<false>, dim3(grid_for((size_t)n * in_h * in_w)), dim3(256), 0, (hipStream_t)stream, d);
     ADAS_HIP_TRY(hipGetLastError());
     return ADAS_OK;
+}
+int adas_preprocess_ufld(const uint8_t* d_frames_bgr, int n, int src_h, int src_w, float* d_out_nchw, int in_h, int in_w,
+                         double crop_ratio, void* stream) {
+    return preprocess_ufld_impl(d_frames_bgr, n, src_h, src_w, d_out_nchw, in_h, in_w, crop_ratio, stream, false);
+}
+int adas_preprocess_ufld_packed(const uint8_t* d_frames_bgr, int n, int src_h, int src_w, uint16_t* d_out_nhwc4, int in_h, int in_w,
+                                double crop_ratio, void* stream) {
+    return preprocess_ufld_impl(d_frames_bgr, n, src_h, src_w, reinterpret_cast<float*>(d_out_nhwc4), in_h, in_w, crop_ratio, stream, true);
 }
 
 }  // extern "C"

@@ -51,6 +51,10 @@ class AdasPipeline:
     def step(self, d_det_ptr=None, d_lane_ptr=None):
         L.check(L.lib().adas_pipeline_step(self.h, d_det_ptr, d_lane_ptr))
 
+    def step_frames(self, d_frames_ptr, src_hw, lane_crop_ratio=0.6):
+        """One step from n_streams BGR u8 frames (H x W x 3, back to back) in HBM: pre-processing runs inside the step."""
+        L.check(L.lib().adas_pipeline_step_frames(self.h, d_frames_ptr, int(src_hw[0]), int(src_hw[1]), float(lane_crop_ratio)))
+
     def sync(self):
         L.check(L.lib().adas_pipeline_sync(self.h))
 
