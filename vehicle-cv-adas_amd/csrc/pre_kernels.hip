@@ -53,6 +53,20 @@ __device__ __forceinline__ void resize_px(const uint8_t* __restrict__ src, const
     lin_coef(ry, g.scale_y, g.sh, &y0, &y1, &b0, &b1, false);
     const uint8_t* r0 = src + (size_t)y0 * g.sw * 3;
     const uint8_t* r1 = src + (size_t)y1 * g.sw * 3;
+    if (x1 == x0 + 1 && x0 * 3 + 8 <= g.sw * 3) {
+        // both taps of a row are 6 consecutive bytes: one (unaligned) 8-byte load per row instead of six byte loads
+        unsigned long long w0, w1;
+        __builtin_memcpy(&w0, r0 + x0 * 3, 8);
+        __builtin_memcpy(&w1, r1 + x0 * 3, 8);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const int h0 = (int)((w0 >> (8 * c)) & 0xff) * a0 + (int)((w0 >> (8 * (3 + c))) & 0xff) * a1;
+            const int h1 = (int)((w1 >> (8 * c)) & 0xff) * a0 + (int)((w1 >> (8 * (3 + c))) & 0xff) * a1;
+            int v = (((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1 >> 4)) >> 16) + 2) >> 2;
+            out[c] = v < 0 ? 0 : (v > 255 ? 255 : v);
+        }
+        return;
+    }
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
         const int h0 = r0[x0 * 3 + c] * a0 + r0[x1 * 3 + c] * a1;
@@ -81,6 +95,11 @@ template <bool PACK>
 __global__ void preprocess_yolo_kernel(YoloPreDev d) {
     const size_t plane = (size_t)d.dh * d.dw;
     const size_t total = (size_t)d.n * plane;
+    // a u8 value has 256 images under the normalisation: tabulate them once per workgroup with the reference's arithmetic
+    // (blobFromImage: float32(v) * (1/255.0) evaluated in double) instead of redoing the double-precision step per pixel
+    __shared__ float lut[256];
+    for (int t = threadIdx.x; t < 256; t += blockDim.x) lut[t] = (float)((double)t * (1.0 / 255.0));
+    __syncthreads();
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
         const int b = (int)(i / plane);
         const int p = (int)(i - (size_t)b * plane);
@@ -88,8 +107,8 @@ __global__ void preprocess_yolo_kernel(YoloPreDev d) {
         int v[3] = {114, 114, 114};  // canvas (utils.py:54)
         const int ry = y - d.padh, rx = x - d.padw;
         if (ry >= 0 && ry < d.g.rh && rx >= 0 && rx < d.g.rw) resize_px(d.src + (size_t)b * d.g.sh * d.g.sw * 3, d.g, ry, rx, v);
-        // blobFromImage: float32(v) * (1/255.0) evaluated in double, swapRB: plane 0 = R = source channel 2
-        const float c0 = (float)((double)v[2] * (1.0 / 255.0)), c1 = (float)((double)v[1] * (1.0 / 255.0)), c2 = (float)((double)v[0] * (1.0 / 255.0));
+        // swapRB: plane 0 = R = source channel 2
+        const float c0 = lut[v[2]], c1 = lut[v[1]], c2 = lut[v[0]];
         if (PACK) {
             reinterpret_cast<uint2*>(d.dst)[i] = make_uint2(pre_pack2(c0, c1), pre_pack2(c2, 0.f));
         } else {
@@ -112,6 +131,15 @@ __global__ void preprocess_ufld_kernel(UfldPreDev d) {
     const size_t plane = (size_t)d.ih * d.iw;
     const size_t total = (size_t)d.n * plane;
     const double mean[3] = {0.485, 0.456, 0.406}, stdv[3] = {0.229, 0.224, 0.225};
+    // 256 possible u8 values per channel: the reference's float32 / float64 normalisation is tabulated once per workgroup
+    // (three double-precision divisions per pixel otherwise: the kernel was ALU-bound at 1.9 TB/s)
+    __shared__ float lut[3][256];
+    for (int t = threadIdx.x; t < 768; t += blockDim.x) {
+        const int c = t >> 8, u = t & 255;
+        const float q = (float)u / 255.0f;                                 // float32 array / Python float stays float32
+        lut[c][u] = (float)(((double)q - mean[c]) / stdv[c]);             // - list, / list promote to float64
+    }
+    __syncthreads();
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
         const int b = (int)(i / plane);
         const int p = (int)(i - (size_t)b * plane);
@@ -120,10 +148,7 @@ __global__ void preprocess_ufld_kernel(UfldPreDev d) {
         resize_px(d.src + (size_t)b * d.g.sh * d.g.sw * 3, d.g, d.row0 + y, x, v);
         float cv[3];
 #pragma unroll
-        for (int c = 0; c < 3; ++c) {  // RGB plane c = BGR source channel 2-c
-            const float q = (float)v[2 - c] / 255.0f;                    // float32 array / Python float stays float32
-            cv[c] = (float)(((double)q - mean[c]) / stdv[c]);             // - list, / list promote to float64
-        }
+        for (int c = 0; c < 3; ++c) cv[c] = lut[c][v[2 - c]];  // RGB plane c = BGR source channel 2-c
         if (PACK) {
             reinterpret_cast<uint2*>(d.dst)[i] = make_uint2(pre_pack2(cv[0], cv[1]), pre_pack2(cv[2], 0.f));
         } else {
