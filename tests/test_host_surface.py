@@ -22,6 +22,33 @@ def test_library_exports_every_declared_symbol():
     assert declared == set(L.exported_symbols()), declared ^ set(L.exported_symbols())
 
 
+def test_ctypes_structs_match_the_header_layout(tmp_path):
+    """Every struct of include/adas_hip.h compiled by gcc has the size and field offsets of its ctypes mirror in _lib.py
+    (an ABI drift between the two would otherwise only show up as garbage on a GPU box)."""
+    import ctypes as C, subprocess
+    pairs = [("adas_yolo_post_params", L.YoloPostParams), ("adas_yolo_counts", L.YoloCounts), ("adas_ufld_params", L.UfldParams),
+             ("adas_ufld1_params", L.Ufld1Params), ("adas_lane_geometry_params", L.LaneGeometryParams),
+             ("adas_lane_geometry_result", L.LaneGeometryResult), ("adas_bytetrack_params", L.BytetrackParams),
+             ("adas_track_header", L.TrackHeader), ("adas_pipeline_desc", L.PipelineDesc)]
+    lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "adas_hip.h"', 'int main(void) {']
+    for cname, cls in pairs:
+        lines.append('  printf("%s size %%zu\\n", sizeof(%s));' % (cname, cname))
+        for fname, _ in cls._fields_:
+            lines.append('  printf("%s.%s %%zu\\n", offsetof(%s, %s));' % (cname, fname, cname, fname))
+    lines.append('  printf("adas_track size %zu\\n", sizeof(adas_track));')
+    lines += ['  return 0;', '}']
+    src = tmp_path / "layout.c"
+    src.write_text("\n".join(lines))
+    exe = tmp_path / "layout"
+    subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
+    got = dict(l.rsplit(" ", 1) for l in subprocess.check_output([str(exe)], text=True).strip().splitlines())
+    for cname, cls in pairs:
+        assert int(got[cname + " size"]) == C.sizeof(cls), cname
+        for fname, _ in cls._fields_:
+            assert int(got["%s.%s" % (cname, fname)]) == getattr(cls, fname).offset, (cname, fname)
+    assert int(got["adas_track size"]) == L.TRACK_DTYPE.itemsize
+
+
 def test_rectinfo_and_defaults_surface():
     r = D.RectInfo(10.7, 20.2, 30.6, 40.9, conf=0.9, label="car")
     assert r.tolist() == [10, 20, 41, 61]                       # int(x + w) evaluated before truncation (core.py:18-23)
@@ -95,3 +122,10 @@ def test_preprocess_oracle_invariants():
     y = preprocess.ufld_prepare_input(lane, (320, 1600), 0.6)
     ref = ((lane[-320:, :, ::-1].astype(np.float32) / 255.0 - [0.485, 0.456, 0.406]) / [0.229, 0.224, 0.225]).astype(np.float32)
     np.testing.assert_array_equal(y[0], ref.transpose(2, 0, 1))
+
+
+def test_bench_synthetic_camera_frames_are_seeded():
+    import bench
+    a, b = bench.cam_frames(2, 5, 90, 160), bench.cam_frames(2, 5, 90, 160)
+    assert a.shape == (2, 90, 160, 3) and a.dtype == np.uint8 and np.array_equal(a, b)
+    assert not np.array_equal(a, bench.cam_frames(2, 6, 90, 160))
