@@ -56,7 +56,7 @@ def cam_frames(n, seed, h=720, w=1280):
     rng = np.random.default_rng(seed)
     out = np.empty((n, h, w, 3), np.uint8)
     for i in range(n):
-        base = np.repeat(np.repeat(rng.integers(0, 255, (h // 16, w // 16, 3)), 16, 0), 16, 1)
+        base = np.repeat(np.repeat(rng.integers(0, 255, ((h + 15) // 16, (w + 15) // 16, 3)), 16, 0), 16, 1)[:h, :w]
         img = (base + rng.integers(0, 255, (h, w, 3))) // 2
         for _ in range(rng.integers(5, 40)):
             x0, y0 = rng.integers(0, w - 20), rng.integers(0, h - 20)
