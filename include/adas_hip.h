@@ -203,6 +203,8 @@ typedef struct {
 } adas_ufld1_params;
 int adas_ufld1_decode_create(const adas_ufld1_params* p, int max_batch, adas_ufld_decode** out);
 int adas_ufld1_decode_set_source_size(adas_ufld_decode* h, int src_w, int src_h);
+/* 1: handle made by adas_ufld1_decode_create (UFLD v1), 2: by adas_ufld_decode_create (UFLDv2), 0: NULL */
+int adas_ufld_decode_kind(const adas_ufld_decode* h);
 int adas_ufld1_decode_run(adas_ufld_decode* h, const float* d_out, size_t batch_stride, int batch, void* stream);
 
 /* -----------------------------------------------------------------------------------

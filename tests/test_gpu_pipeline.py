@@ -99,3 +99,23 @@ def test_pipeline_step_from_camera_frames(tmp_path):
             assert pa.decode.fetch(s) == pb.decode.fetch(s)
         dc.free()
     pa.close(); pb.close(); dt.free(); lt.free()
+
+
+def test_pipeline_with_ufld_v1_lane_model():
+    """The fused step with a UFLD v1 lane model (one output tensor, v1 decoder): lane results equal the stand-alone path."""
+    from oracle import ufld_decode as UD
+    S = 2
+    lane_path, _, _ = netutil.model("ufld_v1_res18")
+    c = UD.ModelConfigV1("tusimple")
+    cfg = dict(griding_num=c.griding_num, cls_num_per_lane=c.cls_num_per_lane, img_w=c.img_w, img_h=c.img_h, row_anchor=c.row_anchor)
+    pipe = PL.AdasPipeline(None, lane_path, n_streams=S, precision="bf16", src_hw=(720, 1280), use_graph=True, lane_cfg=cfg, track=False)
+    x = netutil.lane_frames(S, 288, 800, seed=5)
+    dx = L.DeviceBuffer.from_array(x)
+    pipe.step(None, dx.ptr); pipe.sync()
+    eng = CE.HipEngine(lane_path, "bf16", S)
+    dec = PP.Ufld1Decode(c.griding_num, c.cls_num_per_lane, c.img_w, c.img_h, 800, 288, 1280, 720, c.row_anchor, S)
+    want = dec.run_host(eng.engine_inference(x)[0])
+    for s in range(S):
+        assert pipe.decode.fetch(s) == want[s]
+    assert sum(len(l) for l in want[0][0]) > 20
+    pipe.close(); eng.close(); dec.close(); dx.free()

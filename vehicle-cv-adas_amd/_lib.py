@@ -118,6 +118,7 @@ _SIGS = {
     "adas_ufld_decode_upload": (C.c_int, [_P, C.c_int, _P, _P, _P]),
     "adas_ufld1_decode_create": (C.c_int, [C.POINTER(Ufld1Params), C.c_int, C.POINTER(_P)]),
     "adas_ufld1_decode_set_source_size": (C.c_int, [_P, C.c_int, C.c_int]),
+    "adas_ufld_decode_kind": (C.c_int, [_P]),
     "adas_ufld1_decode_run": (C.c_int, [_P, _P, C.c_size_t, C.c_int, _P]),
     "adas_lane_geometry_create": (C.c_int, [C.POINTER(LaneGeometryParams), C.c_int, C.POINTER(_P)]),
     "adas_lane_geometry_destroy": (C.c_int, [_P]),

@@ -81,8 +81,11 @@ static int record_step(adas_pipeline* p, const float* d_det, const float* d_lane
         if (events) ADAS_HIP_TRY(hipEventRecord(p->ev[3], st));
         const adas_engine* le = p->d.lane;
         size_t stride = (size_t)le->bufs[le->outs[0].buf].h * le->bufs[le->outs[0].buf].w * le->bufs[le->outs[0].buf].c;
-        rc = adas_ufld_decode_run(p->d.decode, adas_engine_output_device(le, 0), adas_engine_output_device(le, 1),
-                                  adas_engine_output_device(le, 2), adas_engine_output_device(le, 3), stride, stride, stride, stride, S, sl);
+        if (adas_ufld_decode_kind(p->d.decode) == 1)  // UFLD v1: one (G+1, K, 4) tensor per frame
+            rc = adas_ufld1_decode_run(p->d.decode, adas_engine_output_device(le, 0), stride, S, sl);
+        else
+            rc = adas_ufld_decode_run(p->d.decode, adas_engine_output_device(le, 0), adas_engine_output_device(le, 1),
+                                      adas_engine_output_device(le, 2), adas_engine_output_device(le, 3), stride, stride, stride, stride, S, sl);
         if (rc) return rc;
         if (p->d.geometry) {
             rc = adas_lane_geometry_run(p->d.geometry, p->d.decode, -1, S, sl);
@@ -116,8 +119,9 @@ int adas_pipeline_create(const adas_pipeline_desc* d, adas_pipeline** out) {
     ADAS_REQUIRE(d->detector || d->lane, ADAS_ERR_INVALID, "pipeline needs a detector and/or a lane engine");
     ADAS_REQUIRE(!d->detector || d->post, ADAS_ERR_INVALID, "detector engine needs a yolo_post handle");
     ADAS_REQUIRE(!d->lane || d->decode, ADAS_ERR_INVALID, "lane engine needs a ufld_decode handle");
-    ADAS_REQUIRE(!d->lane || adas_engine_num_outputs(d->lane) == 4, ADAS_ERR_INVALID,
-                 "Output dims is error, please check model. load %d channels not match 4.", d->lane ? adas_engine_num_outputs(d->lane) : 0);
+    const int lane_outs = d->lane ? (adas_ufld_decode_kind(d->decode) == 1 ? 1 : 4) : 0;  // ultrafastLaneDetector.py:73-75 | V2:93-94
+    ADAS_REQUIRE(!d->lane || adas_engine_num_outputs(d->lane) == lane_outs, ADAS_ERR_INVALID,
+                 "Output dims is error, please check model. load %d channels not match %d.", d->lane ? adas_engine_num_outputs(d->lane) : 0, lane_outs);
     ADAS_REQUIRE(!d->detector || d->n_streams <= d->detector->max_batch, ADAS_ERR_INVALID, "n_streams exceeds detector max_batch");
     ADAS_REQUIRE(!d->lane || d->n_streams <= d->lane->max_batch, ADAS_ERR_INVALID, "n_streams exceeds lane max_batch");
     adas_pipeline* p = new adas_pipeline();

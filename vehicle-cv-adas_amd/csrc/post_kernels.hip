@@ -562,6 +562,7 @@ int adas_ufld1_decode_create(const adas_ufld1_params* p, int max_batch, adas_ufl
     *out = h;
     return ADAS_OK;
 }
+int adas_ufld_decode_kind(const adas_ufld_decode* h) { return h ? (h->v1 ? 1 : 2) : 0; }
 int adas_ufld1_decode_set_source_size(adas_ufld_decode* h, int src_w, int src_h) {
     ADAS_REQUIRE(h && h->v1 && src_w > 0 && src_h > 0, ADAS_ERR_INVALID, "adas_ufld1_decode_set_source_size: bad argument");
     h->dev1.cfg.src_w = src_w;

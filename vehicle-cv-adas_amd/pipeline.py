@@ -10,7 +10,7 @@ import numpy as np
 
 from . import _lib as L
 from .coreEngine import HipEngine
-from .postproc import YoloPost, UfldDecode, LaneGeometry, DeviceTracker, letterbox
+from .postproc import YoloPost, UfldDecode, Ufld1Decode, LaneGeometry, DeviceTracker, letterbox
 
 CULANE = dict(grid_row=200, cls_row=72, grid_col=100, cls_col=81,
               row_anchor=np.linspace(0.42, 1, 72), col_anchor=np.linspace(0, 1, 81))   # ultrafastLaneDetectorV2.py:49-55
@@ -36,8 +36,13 @@ class AdasPipeline:
             self.lane = HipEngine(lane_model, precision, n_streams)
             cfg = dict(CULANE)
             cfg.update(lane_cfg or {})
-            self.decode = UfldDecode(cfg["grid_row"], cfg["cls_row"], cfg["grid_col"], cfg["cls_col"], src_hw[1], src_hw[0],
-                                     cfg["row_anchor"], cfg["col_anchor"], 1, n_streams)
+            if "griding_num" in cfg:          # UFLD v1 (ultrafastLaneDetector.py ModelConfig): one output tensor
+                ish = self.lane.get_engine_input_shape()
+                self.decode = Ufld1Decode(cfg["griding_num"], cfg["cls_num_per_lane"], cfg["img_w"], cfg["img_h"], ish[3], ish[2],
+                                          src_hw[1], src_hw[0], cfg["row_anchor"], n_streams)
+            else:
+                self.decode = UfldDecode(cfg["grid_row"], cfg["cls_row"], cfg["grid_col"], cfg["cls_col"], src_hw[1], src_hw[0],
+                                         cfg["row_anchor"], cfg["col_anchor"], 1, n_streams)
             if geometry is not None:
                 self.geometry = LaneGeometry(src_hw[0], geometry["bird_wh"], geometry["M"], geometry.get("adjust_lanes", True), n_streams)
         d = L.PipelineDesc(self.det.handle if self.det else None, self.lane.handle if self.lane else None,
