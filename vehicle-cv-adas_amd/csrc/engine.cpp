@@ -245,7 +245,11 @@ int adas_engine_create(const char* model_path, int precision, int max_batch, ada
             }
             for (int l = 1; l < 3 && ok; ++l)  // one hidden width per branch
                 ok = e->ops[src[2 * l]].f.in_c[0] == e->ops[src[0]].f.in_c[0] && e->ops[src[2 * l + 1]].f.in_c[0] == e->ops[src[1]].f.in_c[0];
-            if (ok && (e->ops[src[1]].f.in_c[0] + 31) / 32 > 12) ok = false;
+            if (ok) {  // the fused launch keeps both weight matrices in LDS: leave very wide heads / class counts to the separate kernels
+                const size_t ksb = (e->ops[src[0]].f.in_c[0] + 31) / 32, ksc = (e->ops[src[1]].f.in_c[0] + 31) / 32;
+                const size_t ntc = ((size_t)dop.f.params[0] + 15) / 16;
+                if (ksc > 12 || (4 * ksb + ntc * ksc) * 1024 + (64 + ntc * 16) * 4 > 150 * 1024) ok = false;
+            }
             if (!ok) continue;
             for (int k = 0; k < 6; ++k) {
                 dop.det_src[k] = src[k];
