@@ -271,14 +271,15 @@ def main():
                 label = eng.layer_kernel(li, S)
                 if label.startswith("(fused into the Detect"):
                     continue            # runs inside the Detect launch (not a conv kernel): its FLOPs are left out of the conv totals
+                launches = 1
                 if label.startswith("(fused into the stem") and stem_label:
-                    label = stem_label  # the stem launch does this layer's work: its FLOPs belong to that launch
+                    label, launches = stem_label, 0   # the stem launch does this layer's work: its FLOPs belong to that launch
                 elif label.startswith("conv_stem_kernel"):
                     stem_label = label
                 conv_ms += ms
                 conv_flops += fl * S
                 k = by_kernel.setdefault(label, [0.0, 0.0, 0])
-                k[0] += ms; k[1] += fl * S; k[2] += 0 if label is stem_label and not eng.layer_kernel(li, S).startswith("conv_stem") else 1
+                k[0] += ms; k[1] += fl * S; k[2] += launches
     achieved_all = conv_flops / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
     dom_name, (dom_ms, dom_fl, dom_n) = max(by_kernel.items(), key=lambda kv: kv[1][0])
     achieved = dom_fl / (dom_ms * 1e-3) / 1e12 if dom_ms > 0 else 0.0
