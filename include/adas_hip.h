@@ -158,6 +158,9 @@ int adas_yolo_post_fetch(adas_yolo_post* h, int frame, adas_yolo_counts* counts,
 int adas_yolo_post_device_views(adas_yolo_post* h, const double** d_xyxy, const double** d_score,
                                 const int32_t** d_cls, const int32_t** d_counts);
 int adas_yolo_post_capacity(const adas_yolo_post* h, int* max_candidates);
+/* The head tensor this handle reads: layout (ADAS_HEAD_*), anchors A, classes nc -- (1, 4+nc, A) for V8, (1, A, 5+nc) for V5 /
+ * V5_LITE (yoloDetector.py:110-124).  adas_pipeline_create checks the detector engine's output against it. */
+int adas_yolo_post_head_shape(const adas_yolo_post* h, int32_t* layout, int32_t* num_anchors, int32_t* num_classes);
 
 /* ===================================================================================
  * UFLDv2 lane decode: replaces UltrafastLaneDetectorV2.__process_output
@@ -205,6 +208,9 @@ int adas_ufld1_decode_create(const adas_ufld1_params* p, int max_batch, adas_ufl
 int adas_ufld1_decode_set_source_size(adas_ufld_decode* h, int src_w, int src_h);
 /* 1: handle made by adas_ufld1_decode_create (UFLD v1), 2: by adas_ufld_decode_create (UFLDv2), 0: NULL */
 int adas_ufld_decode_kind(const adas_ufld_decode* h);
+/* The tensors this handle decodes, in engine output order: returns their number (4 for UFLDv2: loc_row, loc_col, exist_row,
+ * exist_col, ultrafastLaneDetectorV2.py:118; 1 for UFLD v1) and fills dims[i] = (1, G, K, 4).  < 0: error. */
+int adas_ufld_decode_expected_outputs(const adas_ufld_decode* h, int64_t dims[4][4]);
 int adas_ufld1_decode_run(adas_ufld_decode* h, const float* d_out, size_t batch_stride, int batch, void* stream);
 
 /* -----------------------------------------------------------------------------------

@@ -1,9 +1,14 @@
 """Oracle: torch-CPU fp32 forward passes of the detector / lane networks.
 
-TEST INFRASTRUCTURE (see oracle/__init__.py).  PARITY UNPINNED at the network boundary: the
-reference has no weights and no YOLO architecture; onnxruntime (its CPU path, coreEngine.py:159-186)
-is not installed.  These functions restate the upstream architectures the reference's exported
-models come from and stand in for "ONNXRuntime-CPU" (oneDNN fp32):
+TEST INFRASTRUCTURE (see oracle/__init__.py).  Pinning status:
+  * UFLDv2 / UFLD v1 forward: PINNED to the reference's own network modules (exportLib/ultrafastLaneV2/model_culane.py,
+    exportLib/ultrafastLane/model.py, imported unmodified under a torchvision stub and fed seeded un-folded parameters;
+    tests/golden/make_golden_ufldnet.py -> tests/golden/ufld_net.npz; tests/test_oracle_golden.py compares at <= 2e-5 of the
+    output range, measured ~1e-6): reduced geometry, CULane R18 and R34 at 1600x320, the Tusimple head, UFLD v1.
+  * YOLOv8 / YOLOv5 forward: PARITY UNPINNED -- the reference has no weights and no YOLO architecture; onnxruntime (its CPU
+    path, coreEngine.py:159-186) is not installed.
+These functions restate the architectures the reference's exported models come from and stand in for "ONNXRuntime-CPU"
+(oneDNN fp32):
   * YOLOv8: ultralytics 8.1.x (README.md:56) Conv/C2f/SPPF/Detect/DFL; output layout pinned by
     ObjectDetector/yoloDetector.py:110-122 -> (1, 4+nc, 8400) [cx,cy,w,h,probs] in input pixels.
   * YOLOv5 v6.2 (README.md:53) Conv/C3/SPPF/Detect; output (1, 25200, 5+nc), anchors
@@ -211,7 +216,7 @@ def ufldv2_forward(x, W, backbone="18", num_grid_row=200, num_cls_row=72, num_gr
 
 
 def ufld_v1_forward(x, W, backbone="18", griding_num=100, cls_num_per_lane=56, num_lanes=4):
-    """UFLD (v1) parsingNet (upstream Ultra-Fast-Lane-Detection model/model.py, not vendored): ResNet trunk, `pool` 1x1
+    """UFLD (v1) parsingNet (exportLib/ultrafastLane/model.py:19-89): ResNet trunk, `pool` 1x1
     conv to 8 channels, (C,H,W) flatten, Linear-ReLU-Linear, view (N, G+1, K, L) -- the tensor
     ultrafastLaneDetector.py:99-109 consumes."""
     x = torch.as_tensor(x, dtype=torch.float32)

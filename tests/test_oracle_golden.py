@@ -132,3 +132,46 @@ def test_ufld_v1_decode(case):
     assert status == g[tag + "_status"].tolist()
     for li in range(4):
         np.testing.assert_array_equal(np.asarray(lanes[li], np.int64).reshape(-1, 2), g[f"{tag}_lane{li}"])
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Lane networks: oracle/nets.py (BN-folded weights, restated forward) against the reference's OWN parsingNet modules
+# (exportLib/ultrafastLaneV2/model_culane.py, exportLib/ultrafastLane/model.py) run un-folded under a torchvision stub
+# (tests/golden/make_golden_ufldnet.py).  Pins flatten order, LayerNorm, head slicing / view order and the BN fold.
+import ufldnet_params as UP
+
+
+@pytest.mark.parametrize("case", UP.CASES, ids=lambda c: c[0])
+def test_lane_net_oracle_matches_reference_module(case):
+    from oracle import nets
+    tag, kind, depth, kw = case
+    g = np.load(os.path.join(GOLDEN, "ufld_net.npz"))
+    if kind == "v2":
+        W = UP.fold(UP.ufldv2_state(UP.SEED, depth, **kw))
+        x = UP.lane_frame(UP.SEED + 1, kw["in_h"], kw["in_w"])
+        taps = {}
+        outs = nets.ufldv2_forward(x, W, depth, kw["grid_row"], kw["cls_row"], kw["grid_col"], kw["cls_col"], 4, taps=taps,
+                                   fc_norm=kw["fc_norm"])
+        pool = taps["fea"].numpy()
+    else:
+        W = UP.fold(UP.ufld1_state(UP.SEED, depth, **kw))
+        x = UP.lane_frame(UP.SEED + 1, 288, 800)
+        outs = [nets.ufld_v1_forward(x, W, depth, kw["griding_num"], kw["cls_per_lane"], 4)]
+        pool = None
+    assert int(g[f"{tag}_n_outputs"]) == len(outs)
+    worst = 0.0
+    for i, o in enumerate(outs):
+        assert tuple(g[f"{tag}_out{i}_shape"]) == tuple(o.shape)
+        flat = o.reshape(-1)
+        want = g[f"{tag}_out{i}_sample"]
+        got = flat[UP.sample_idx(flat.size)]
+        scale = float(np.abs(want).max())
+        # fp32 on both sides; the BN fold (fp64 -> fp32 weights) and oneDNN's blocking change the rounding, nothing else
+        np.testing.assert_allclose(got, want, rtol=0, atol=2e-5 * max(scale, 1.0), err_msg=f"{tag} out{i}")
+        assert abs(float(flat.astype(np.float64).sum()) - float(g[f"{tag}_out{i}_sum"])) <= 2e-4 * float(g[f"{tag}_out{i}_abssum"])
+        worst = max(worst, float(np.abs(got - want).max()) / max(scale, 1.0))
+    if pool is not None:   # the (C, H, W) flatten of model_culane.py:53 feeds the head in exactly this order
+        want = g[f"{tag}_pool_sample"]
+        flat = pool.reshape(-1)
+        np.testing.assert_allclose(flat[UP.sample_idx(flat.size)], want, rtol=0, atol=2e-4 * max(float(np.abs(want).max()), 1.0))
+    print(f"{tag}: max |oracle - reference module| / max|ref| = {worst:.2e}")

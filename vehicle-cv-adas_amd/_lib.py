@@ -111,6 +111,7 @@ _SIGS = {
     "adas_yolo_post_fetch": (C.c_int, [_P, C.c_int, C.POINTER(YoloCounts)] + [_P] * 9),
     "adas_yolo_post_device_views": (C.c_int, [_P] + [C.POINTER(_P)] * 4),
     "adas_yolo_post_capacity": (C.c_int, [_P, C.POINTER(C.c_int)]),
+    "adas_yolo_post_head_shape": (C.c_int, [_P, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "adas_ufld_decode_create": (C.c_int, [C.POINTER(UfldParams), C.c_int, C.POINTER(_P)]),
     "adas_ufld_decode_destroy": (C.c_int, [_P]),
     "adas_ufld_decode_run": (C.c_int, [_P, _P, _P, _P, _P, C.c_size_t, C.c_size_t, C.c_size_t, C.c_size_t, C.c_int, _P]),
@@ -119,6 +120,7 @@ _SIGS = {
     "adas_ufld1_decode_create": (C.c_int, [C.POINTER(Ufld1Params), C.c_int, C.POINTER(_P)]),
     "adas_ufld1_decode_set_source_size": (C.c_int, [_P, C.c_int, C.c_int]),
     "adas_ufld_decode_kind": (C.c_int, [_P]),
+    "adas_ufld_decode_expected_outputs": (C.c_int, [_P, C.POINTER(C.c_int64)]),
     "adas_ufld1_decode_run": (C.c_int, [_P, _P, C.c_size_t, C.c_int, _P]),
     "adas_lane_geometry_create": (C.c_int, [C.POINTER(LaneGeometryParams), C.c_int, C.POINTER(_P)]),
     "adas_lane_geometry_destroy": (C.c_int, [_P]),

@@ -91,17 +91,27 @@ class HipEngine(EngineBase):
         except ImportError:
             import onnx_import
         st = os.stat(model_path)
-        tag = "%s.%d.%d.hipm" % (os.path.basename(model_path), st.st_size, int(st.st_mtime))
+        # the tag names the source file state AND the importer/container revision, so a cache written by an older importer is
+        # never picked up by a newer one
+        tag = "%s.%d.%d.v%d.hipm" % (os.path.basename(model_path), st.st_size, int(st.st_mtime), onnx_import.IMPORTER_VERSION)
         import tempfile
         for d in (os.path.dirname(os.path.abspath(model_path)), tempfile.gettempdir()):
             cached = os.path.join(d, "." + tag)
             if os.path.isfile(cached):
                 return cached
             if os.access(d, os.W_OK):
+                # one process per GPU loads the same model at the same time (torchrun): convert into a private temp file and
+                # publish it with an atomic rename, so no rank ever opens a half-written container
+                fd, tmp = tempfile.mkstemp(prefix="." + tag + ".", suffix=".part", dir=d)
+                os.close(fd)
                 try:
-                    onnx_import.convert(model_path, cached)
+                    onnx_import.convert(model_path, tmp)
+                    os.replace(tmp, cached)
                 except ValueError:
                     return model_path      # not ONNX either: let the library report the format error (ADAS_ERR_FORMAT)
+                finally:
+                    if os.path.exists(tmp):
+                        os.remove(tmp)
                 return cached
         return model_path
 

@@ -1,6 +1,7 @@
 // api_common.cpp -- error state, device selection and raw memory helpers of the C ABI.
 #include "common.h"
 #include <string.h>
+#include <atomic>
 
 namespace adas {
 static thread_local char g_err[512] = "";
@@ -15,6 +16,9 @@ int hip_fail(hipError_t e, const char* what, const char* file, int line) {
     (void)hipGetLastError();
     return ADAS_ERR_HIP;
 }
+static std::atomic<unsigned long long> g_cfg_gen{1};
+unsigned long long config_generation() { return g_cfg_gen.load(std::memory_order_acquire); }
+void bump_config_generation() { g_cfg_gen.fetch_add(1, std::memory_order_acq_rel); }
 }  // namespace adas
 
 extern "C" {

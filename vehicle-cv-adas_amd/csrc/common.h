@@ -8,6 +8,10 @@
 namespace adas {
 void set_error(const char* fmt, ...);
 int hip_fail(hipError_t e, const char* what, const char* file, int line);
+// Parameters that a captured pipeline step bakes into its kernel arguments (post / decode / geometry configuration) carry a
+// process-wide generation: every setter bumps it, adas_pipeline_* re-captures when it moved since the capture.
+unsigned long long config_generation();
+void bump_config_generation();
 }  // namespace adas
 
 #define ADAS_HIP_TRY(expr)                                                      \

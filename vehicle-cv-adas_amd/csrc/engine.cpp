@@ -74,6 +74,27 @@ int adas_engine_create(const char* model_path, int precision, int max_batch, ada
         set_error("[%s]: truncated model container", model_path);
         return ADAS_ERR_FORMAT;
     }
+    // ---- every buffer index an op or output names must exist (a damaged container must not index past e->bufs)
+    {
+        auto bad = [&](int64_t b) { return b < 0 || b >= (int64_t)hd.n_bufs; };
+        const char* what = nullptr;
+        for (auto& o : fo) {
+            if (o.n_in > 8) { what = "more than 8 inputs"; break; }
+            for (uint32_t k = 0; k < o.n_in; ++k)
+                if (bad(o.in_buf[k])) what = "input buffer";
+            if (bad(o.out_buf)) what = "output buffer";
+            if (o.res_mode != RES_NONE && bad(o.res_buf)) what = "residual buffer";
+            if (what) break;
+        }
+        for (auto& q : fout)
+            if (bad(q.buf)) what = "graph output buffer";
+        if (what) {
+            fclose(f);
+            free_engine(e);
+            set_error("[%s]: %s index out of range (container has %u buffers)", model_path, what, hd.n_bufs);
+            return ADAS_ERR_FORMAT;
+        }
+    }
     // ---- buffers
     for (auto& b : fb) {
         EngBuf eb;

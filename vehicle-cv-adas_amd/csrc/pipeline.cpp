@@ -12,13 +12,24 @@ struct adas_pipeline {
     hipStream_t st = nullptr;
     hipStream_t st_lane = nullptr;  // graph mode: the lane branch is captured on its own stream so the two nets overlap
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    // A captured step bakes every kernel argument in: the input pointers, the source geometry, the lane crop ratio and the
+    // post / decode / geometry configuration (the latter through adas::config_generation()).  All of them are the cache key.
+    struct GraphKey {
+        const void* in_a;   // detector seam tensor, or the u8 frames
+        const void* in_b;   // lane seam tensor (null for a step_frames entry)
+        int src_h, src_w;   // step_frames: camera geometry (0 for a seam-tensor entry)
+        double crop;        // step_frames: lane crop ratio
+        bool operator==(const GraphKey& o) const {
+            return in_a == o.in_a && in_b == o.in_b && src_h == o.src_h && src_w == o.src_w && crop == o.crop;
+        }
+    };
     struct Cached {
-        const float* det;
-        const float* lane;
+        GraphKey key;
         hipGraph_t graph;
         hipGraphExec_t exec;
     };
-    std::vector<Cached> graphs;  // one captured step per distinct (detector input, lane input) pair
+    std::vector<Cached> graphs;              // one captured step per distinct key
+    unsigned long long graphs_gen = 0;       // config generation the cached captures were recorded under
     hipEvent_t ev[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     bool timed = false;
     // step_frames: u8 camera frames in, the engine-seam tensors live here
@@ -112,6 +123,14 @@ static int record_step(adas_pipeline* p, const float* d_det, const float* d_lane
     return ADAS_OK;
 }
 
+static void drop_graphs(adas_pipeline* p) {
+    for (auto& g : p->graphs) {
+        if (g.exec) (void)hipGraphExecDestroy(g.exec);
+        if (g.graph) (void)hipGraphDestroy(g.graph);
+    }
+    p->graphs.clear();
+}
+
 extern "C" {
 
 int adas_pipeline_create(const adas_pipeline_desc* d, adas_pipeline** out) {
@@ -122,6 +141,30 @@ int adas_pipeline_create(const adas_pipeline_desc* d, adas_pipeline** out) {
     const int lane_outs = d->lane ? (adas_ufld_decode_kind(d->decode) == 1 ? 1 : 4) : 0;  // ultrafastLaneDetector.py:73-75 | V2:93-94
     ADAS_REQUIRE(!d->lane || adas_engine_num_outputs(d->lane) == lane_outs, ADAS_ERR_INVALID,
                  "Output dims is error, please check model. load %d channels not match %d.", d->lane ? adas_engine_num_outputs(d->lane) : 0, lane_outs);
+    if (d->detector) {  // the post kernel indexes the head by ITS (layout, A, nc): a mismatch would read past the engine's buffer
+        int32_t layout = 0, A = 0, nc = 0;
+        int rc0 = adas_yolo_post_head_shape(d->post, &layout, &A, &nc);
+        if (rc0) return rc0;
+        int64_t od[4] = {0, 0, 0, 0};
+        int nd = 0;
+        ADAS_REQUIRE(adas_engine_num_outputs(d->detector) >= 1 && adas_engine_output_shape(d->detector, 0, od, &nd) == ADAS_OK && nd == 3,
+                     ADAS_ERR_INVALID, "detector engine has no (1, C, A) / (1, A, C) head output");
+        const int64_t want1 = layout == ADAS_HEAD_V8 ? 4 + nc : A, want2 = layout == ADAS_HEAD_V8 ? A : 5 + nc;
+        ADAS_REQUIRE(od[1] == want1 && od[2] == want2, ADAS_ERR_INVALID,
+                     "detector head is (1,%lld,%lld) but the post-processor was created for (1,%lld,%lld) [layout %d, %d anchors, %d classes]",
+                     (long long)od[1], (long long)od[2], (long long)want1, (long long)want2, layout, A, nc);
+    }
+    if (d->lane) {
+        int64_t want[4][4];
+        const int n = adas_ufld_decode_expected_outputs(d->decode, want);
+        for (int i = 0; i < n; ++i) {
+            int64_t od[4] = {0, 0, 0, 0};
+            int nd = 0;
+            ADAS_REQUIRE(adas_engine_output_shape(d->lane, i, od, &nd) == ADAS_OK && nd == 4 && od[1] == want[i][1] && od[2] == want[i][2] && od[3] == want[i][3],
+                         ADAS_ERR_INVALID, "lane output %d is (1,%lld,%lld,%lld) but the decoder was created for (1,%lld,%lld,%lld)", i, (long long)od[1],
+                         (long long)od[2], (long long)od[3], (long long)want[i][1], (long long)want[i][2], (long long)want[i][3]);
+        }
+    }
     ADAS_REQUIRE(!d->detector || d->n_streams <= d->detector->max_batch, ADAS_ERR_INVALID, "n_streams exceeds detector max_batch");
     ADAS_REQUIRE(!d->lane || d->n_streams <= d->lane->max_batch, ADAS_ERR_INVALID, "n_streams exceeds lane max_batch");
     adas_pipeline* p = new adas_pipeline();
@@ -150,10 +193,7 @@ int adas_pipeline_create(const adas_pipeline_desc* d, adas_pipeline** out) {
 
 int adas_pipeline_destroy(adas_pipeline* p) {
     if (!p) return ADAS_OK;
-    for (auto& g : p->graphs) {
-        if (g.exec) (void)hipGraphExecDestroy(g.exec);
-        if (g.graph) (void)hipGraphDestroy(g.graph);
-    }
+    drop_graphs(p);
     for (auto& e : p->ev)
         if (e) (void)hipEventDestroy(e);
     if (p->ev_fork) (void)hipEventDestroy(p->ev_fork);
@@ -166,26 +206,36 @@ int adas_pipeline_destroy(adas_pipeline* p) {
     return ADAS_OK;
 }
 
-int adas_pipeline_step(adas_pipeline* p, const float* d_det, const float* d_lane) {
-    ADAS_REQUIRE(p, ADAS_ERR_INVALID, "null pipeline");
-    ADAS_REQUIRE(!p->d.detector || d_det, ADAS_ERR_INVALID, "detector input missing");
-    ADAS_REQUIRE(!p->d.lane || d_lane, ADAS_ERR_INVALID, "lane input missing");
-    if (!(p->d.use_graph & 1)) {
-        p->timed = true;
-        return record_step(p, d_det, d_lane, true);
+// Replays the captured step for `key`, capturing it first when no capture of the current configuration exists.
+static int replay_step(adas_pipeline* p, const adas_pipeline::GraphKey& key, const float* d_det, const float* d_lane,
+                       const adas_pipeline::FrameSrc* fs) {
+    const unsigned long long gen = adas::config_generation();
+    if (gen != p->graphs_gen) {  // a post / decode / geometry setter ran since the captures were made: their arguments are stale
+        ADAS_HIP_TRY(hipStreamSynchronize(p->st));
+        drop_graphs(p);
+        p->graphs_gen = gen;
     }
     hipGraphExec_t exec = nullptr;
     for (auto& g : p->graphs)
-        if (g.det == d_det && g.lane == d_lane) exec = g.exec;
+        if (g.key == key) exec = g.exec;
     if (!exec) {
         ADAS_REQUIRE(p->graphs.size() < 64, ADAS_ERR_CAPACITY, "more than 64 distinct input buffers: reuse staging buffers with use_graph");
-        adas_pipeline::Cached g{d_det, d_lane, nullptr, nullptr};
+        adas_pipeline::Cached g{key, nullptr, nullptr};
+        if (fs) p->fsrc = *fs;
         ADAS_HIP_TRY(hipStreamBeginCapture(p->st, hipStreamCaptureModeThreadLocal));
         int rc = record_step(p, d_det, d_lane, false);
         hipError_t ce = hipStreamEndCapture(p->st, &g.graph);
-        if (rc) return rc;
-        if (ce != hipSuccess) return hip_fail(ce, "hipStreamEndCapture", __FILE__, __LINE__);
-        ADAS_HIP_TRY(hipGraphInstantiate(&g.exec, g.graph, nullptr, nullptr, 0));
+        p->fsrc.frames = nullptr;
+        if (rc == ADAS_OK && ce != hipSuccess) rc = hip_fail(ce, "hipStreamEndCapture", __FILE__, __LINE__);
+        if (rc == ADAS_OK) {
+            hipError_t ie = hipGraphInstantiate(&g.exec, g.graph, nullptr, nullptr, 0);
+            if (ie != hipSuccess) rc = hip_fail(ie, "hipGraphInstantiate", __FILE__, __LINE__);
+        }
+        if (rc != ADAS_OK) {  // nothing half-built stays behind
+            if (g.graph) (void)hipGraphDestroy(g.graph);
+            (void)hipGetLastError();
+            return rc;
+        }
         p->graphs.push_back(g);
         exec = g.exec;
     }
@@ -194,6 +244,17 @@ int adas_pipeline_step(adas_pipeline* p, const float* d_det, const float* d_lane
     ADAS_HIP_TRY(hipEventRecord(p->ev[5], p->st));
     p->timed = false;
     return ADAS_OK;
+}
+
+int adas_pipeline_step(adas_pipeline* p, const float* d_det, const float* d_lane) {
+    ADAS_REQUIRE(p, ADAS_ERR_INVALID, "null pipeline");
+    ADAS_REQUIRE(!p->d.detector || d_det, ADAS_ERR_INVALID, "detector input missing");
+    ADAS_REQUIRE(!p->d.lane || d_lane, ADAS_ERR_INVALID, "lane input missing");
+    if (!(p->d.use_graph & 1)) {
+        p->timed = true;
+        return record_step(p, d_det, d_lane, true);
+    }
+    return replay_step(p, adas_pipeline::GraphKey{d_det, d_lane, 0, 0, 0.0}, d_det, d_lane, nullptr);
 }
 
 int adas_pipeline_step_frames(adas_pipeline* p, const uint8_t* d_frames_bgr, int src_h, int src_w, double lane_crop_ratio) {
@@ -223,32 +284,7 @@ int adas_pipeline_step_frames(adas_pipeline* p, const uint8_t* d_frames_bgr, int
         p->fsrc.frames = nullptr;
         return rc;
     }
-    // graph mode: one captured step per distinct frame buffer / geometry (cache entries of this kind carry the frames pointer
-    // in `det` and the geometry in `lane`'s place through a tagged key)
-    hipGraphExec_t exec = nullptr;
-    const float* key_a = reinterpret_cast<const float*>(d_frames_bgr);
-    const float* key_b = reinterpret_cast<const float*>((uintptr_t)(((uint64_t)(uint32_t)src_h << 32) | (uint32_t)src_w | 0x8000000000000000ull));
-    for (auto& g : p->graphs)
-        if (g.det == key_a && g.lane == key_b) exec = g.exec;
-    if (!exec) {
-        ADAS_REQUIRE(p->graphs.size() < 64, ADAS_ERR_CAPACITY, "more than 64 distinct input buffers: reuse staging buffers with use_graph");
-        adas_pipeline::Cached g{key_a, key_b, nullptr, nullptr};
-        p->fsrc = fs;
-        ADAS_HIP_TRY(hipStreamBeginCapture(p->st, hipStreamCaptureModeThreadLocal));
-        int rc = record_step(p, p->det_in, p->lane_in, false);
-        hipError_t ce = hipStreamEndCapture(p->st, &g.graph);
-        p->fsrc.frames = nullptr;
-        if (rc) return rc;
-        if (ce != hipSuccess) return hip_fail(ce, "hipStreamEndCapture", __FILE__, __LINE__);
-        ADAS_HIP_TRY(hipGraphInstantiate(&g.exec, g.graph, nullptr, nullptr, 0));
-        p->graphs.push_back(g);
-        exec = g.exec;
-    }
-    ADAS_HIP_TRY(hipEventRecord(p->ev[0], p->st));
-    ADAS_HIP_TRY(hipGraphLaunch(exec, p->st));
-    ADAS_HIP_TRY(hipEventRecord(p->ev[5], p->st));
-    p->timed = false;
-    return ADAS_OK;
+    return replay_step(p, adas_pipeline::GraphKey{d_frames_bgr, nullptr, src_h, src_w, lane_crop_ratio}, p->det_in, p->lane_in, &fs);
 }
 
 int adas_pipeline_sync(adas_pipeline* p) {

@@ -401,6 +401,14 @@ int adas_yolo_post_destroy(adas_yolo_post* h) {
     return ADAS_OK;
 }
 
+int adas_yolo_post_head_shape(const adas_yolo_post* h, int32_t* layout, int32_t* num_anchors, int32_t* num_classes) {
+    ADAS_REQUIRE(h, ADAS_ERR_INVALID, "adas_yolo_post_head_shape: null handle");
+    if (layout) *layout = h->p.layout;
+    if (num_anchors) *num_anchors = h->p.num_anchors;
+    if (num_classes) *num_classes = h->p.num_classes;
+    return ADAS_OK;
+}
+
 int adas_yolo_post_set_input_size(adas_yolo_post* h, int in_h, int in_w) {
     ADAS_REQUIRE(h && in_h >= 32 && in_w >= 32, ADAS_ERR_INVALID, "adas_yolo_post_set_input_size: bad argument");
     if (h->p.layout == ADAS_HEAD_V5_LITE) {
@@ -411,6 +419,7 @@ int adas_yolo_post_set_input_size(adas_yolo_post* h, int in_h, int in_w) {
     }
     h->dev.cfg.in_h = in_h;
     h->dev.cfg.in_w = in_w;
+    adas::bump_config_generation();
     return ADAS_OK;
 }
 
@@ -563,10 +572,22 @@ int adas_ufld1_decode_create(const adas_ufld1_params* p, int max_batch, adas_ufl
     return ADAS_OK;
 }
 int adas_ufld_decode_kind(const adas_ufld_decode* h) { return h ? (h->v1 ? 1 : 2) : 0; }
+int adas_ufld_decode_expected_outputs(const adas_ufld_decode* h, int64_t dims[4][4]) {
+    ADAS_REQUIRE(h && dims, ADAS_ERR_INVALID, "adas_ufld_decode_expected_outputs: null argument");
+    if (h->v1) {  // ultrafastLaneDetector.py:73-75: one (1, griding_num + 1, cls_num_per_lane, 4) tensor
+        dims[0][0] = 1; dims[0][1] = h->dev1.cfg.G + 1; dims[0][2] = h->dev1.cfg.K; dims[0][3] = h->dev1.cfg.L;
+        return 1;
+    }
+    // model_culane.py:56-59: loc_row (1,G_r,K_r,4), loc_col (1,G_c,K_c,4), exist_row (1,2,K_r,4), exist_col (1,2,K_c,4)
+    const int64_t g[4] = {h->p.grid_row, h->p.grid_col, 2, 2}, k[4] = {h->p.cls_row, h->p.cls_col, h->p.cls_row, h->p.cls_col};
+    for (int i = 0; i < 4; ++i) { dims[i][0] = 1; dims[i][1] = g[i]; dims[i][2] = k[i]; dims[i][3] = 4; }
+    return 4;
+}
 int adas_ufld1_decode_set_source_size(adas_ufld_decode* h, int src_w, int src_h) {
     ADAS_REQUIRE(h && h->v1 && src_w > 0 && src_h > 0, ADAS_ERR_INVALID, "adas_ufld1_decode_set_source_size: bad argument");
     h->dev1.cfg.src_w = src_w;
     h->dev1.cfg.src_h = src_h;
+    adas::bump_config_generation();
     return ADAS_OK;
 }
 int adas_ufld1_decode_run(adas_ufld_decode* h, const float* d_out, size_t batch_stride, int batch, void* stream) {
@@ -662,6 +683,7 @@ int adas_lane_geometry_destroy(adas_lane_geometry* h) {
 int adas_lane_geometry_set_matrix(adas_lane_geometry* h, const double* M9) {
     ADAS_REQUIRE(h && M9, ADAS_ERR_INVALID, "adas_lane_geometry_set_matrix: bad argument");
     for (int i = 0; i < 9; ++i) h->dev.cfg.M[i] = M9[i];
+    adas::bump_config_generation();
     return ADAS_OK;
 }
 int adas_lane_geometry_run(adas_lane_geometry* h, const adas_ufld_decode* decode, int adjust_lanes, int batch, void* stream) {

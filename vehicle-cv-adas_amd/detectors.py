@@ -288,38 +288,34 @@ class ModelConfig:                 # ultrafastLaneDetectorV2.py:21-55
         self.num_lanes = 4
 
 
+def _ego_lane_fit(points, min_points=10):
+    """(quadratic x(y) coefficients, y samples) of one ego lane, or None when the lane carries too few points to refit."""
+    pts = np.asarray(points, dtype=np.float64).reshape(-1, 2)
+    if pts.shape[0] <= min_points:
+        return None
+    return np.polyfit(pts[:, 1], pts[:, 0], 2), pts[:, 1]
+
+
 def adjust_lanes_points(left_lanes_points, right_lanes_points, image_height):
-    """LaneDetectBase.__adjust_lanes_points (core.py:102-141): degree-2 polyfit of both ego lanes."""
-    if len(left_lanes_points[1]) != 0:
-        leftx, lefty = list(zip(*left_lanes_points))
-        if len(lefty) > 10:
-            left_fit = np.polyfit(lefty, leftx, 2)
-        else:
-            return left_lanes_points, right_lanes_points
-    else:
+    """Ego-lane smoothing of the drivable-area polygon: each ego lane is replaced by its least-squares parabola x(y),
+    sampled at `image_height` rows spanning both lanes.  Same results as LaneDetectBase.__adjust_lanes_points
+    (ufldDetector/core.py:102-141): either lane with <= 10 points leaves both untouched; the common row range starts at
+    min(H // 3, lowest lane row) and ends at max(H - 1, highest lane row); a sample is kept from the lane's first row down and
+    only while x >= 0; coordinates are truncated.  (The device path is lane_core.h; this is the host form.)"""
+    fits = [_ego_lane_fit(left_lanes_points), _ego_lane_fit(right_lanes_points)]
+    if fits[0] is None or fits[1] is None:
         return left_lanes_points, right_lanes_points
-    if len(right_lanes_points) != 0:
-        rightx, righty = list(zip(*right_lanes_points))
-        if len(righty) > 10:
-            right_fit = np.polyfit(righty, rightx, 2)
-        else:
-            return left_lanes_points, right_lanes_points
-    else:
-        return left_lanes_points, right_lanes_points
-    maxy = image_height - 1
-    miny = image_height // 3
-    if len(lefty):
-        maxy = max(maxy, np.max(lefty))
-        miny = min(miny, np.min(lefty))
-    if len(righty):
-        maxy = max(maxy, np.max(righty))
-        miny = min(miny, np.min(righty))
-    both_fity = np.linspace(miny, maxy, image_height)
-    left_fitx = left_fit[0] * both_fity ** 2 + left_fit[1] * both_fity + left_fit[2]
-    right_fitx = right_fit[0] * both_fity ** 2 + right_fit[1] * both_fity + right_fit[2]
-    fix_left = [(int(l), int(y)) for l, y in zip(left_fitx, both_fity) if (y >= min(lefty) and l >= 0)]
-    fix_right = [(int(r), int(y)) for r, y in zip(right_fitx, both_fity) if (y >= min(righty) and r >= 0)]
-    return fix_left, fix_right
+    rows = np.concatenate([fits[0][1], fits[1][1]])
+    lo = min(image_height // 3, rows.min())
+    hi = max(image_height - 1, rows.max())
+    ys = np.linspace(lo, hi, image_height)
+    resampled = []
+    for (c2, c1, c0), lane_rows in fits:
+        xs = c2 * ys ** 2 + c1 * ys + c0
+        sel = (ys >= lane_rows.min()) & (xs >= 0)
+        # int() truncation of the reference == astype toward zero for these magnitudes
+        resampled.append(list(zip(xs[sel].astype(np.int64).tolist(), ys[sel].astype(np.int64).tolist())))
+    return resampled[0], resampled[1]
 
 
 class UltrafastLaneDetectorV2(_Defaults):

@@ -228,6 +228,14 @@ V8_SCALES = {"n": (0.33, 0.25, 1024), "s": (0.33, 0.50, 1024), "m": (0.67, 0.75,
              "x": (1.0, 1.25, 512)}
 
 
+def _hw(imgsz):
+    """imgsz: one int (square) or (H, W); both sides must be multiples of the largest stride (32)."""
+    H, W = (int(imgsz), int(imgsz)) if np.isscalar(imgsz) else (int(imgsz[0]), int(imgsz[1]))
+    if H <= 0 or W <= 0 or H % 32 or W % 32:
+        raise ValueError("YOLO input size must be positive multiples of 32, got %sx%s" % (H, W))
+    return H, W
+
+
 def _mk(c, width, max_ch):
     return int(math.ceil(min(c, max_ch) * width / 8) * 8)
 
@@ -257,17 +265,17 @@ def _sppf(g, x, c2, name, out=None):
 def yolov8(scale="n", nc=80, imgsz=640, wsrc=None, seed=0):
     depth, width, max_ch = V8_SCALES[scale]
     wsrc = wsrc or SynthWeights(seed, gain=SILU_GAIN)
-    g = Graph(f"yolov8{scale}", 3, imgsz, imgsz, wsrc)
+    H, W = _hw(imgsz)
+    g = Graph(f"yolov8{scale}", 3, H, W, wsrc)
     ch = lambda c: _mk(c, width, max_ch)
     dep = lambda n: max(round(n * depth), 1)
     c1, c2, c3, c4, c5 = ch(64), ch(128), ch(256), ch(512), ch(1024)
     x, cin = g.input()
-    H = imgsz
     # concat buffers of the neck (producers write into them directly)
-    cat11 = g.buf(H // 16, H // 16, c5 + c4)   # [up(9), 6]
-    cat14 = g.buf(H // 8, H // 8, c4 + c3)     # [up(12), 4]
-    cat17 = g.buf(H // 16, H // 16, c3 + c4)   # [16, 12]
-    cat20 = g.buf(H // 32, H // 32, c4 + c5)   # [19, 9]
+    cat11 = g.buf(H // 16, W // 16, c5 + c4)   # [up(9), 6]
+    cat14 = g.buf(H // 8, W // 8, c4 + c3)     # [up(12), 4]
+    cat17 = g.buf(H // 16, W // 16, c3 + c4)   # [16, 12]
+    cat20 = g.buf(H // 32, W // 32, c4 + c5)   # [19, 9]
     x = g.conv(x, c1, 3, 2, "model.0.conv", true_cin=cin)
     x = g.conv(x, c2, 3, 2, "model.1.conv")
     x = _c2f(g, x, c2, dep(3), True, "model.2")
@@ -292,7 +300,7 @@ def yolov8(scale="n", nc=80, imgsz=640, wsrc=None, seed=0):
     cc = max(feats[0].c, min(nc, 100))
     ins, strides = [], []
     for i, f in enumerate(feats):
-        s = imgsz // f.h
+        s = H // f.h
         strides.append(s)
         b = g.conv(f, cb, 3, 1, f"model.22.cv2.{i}.0.conv")
         b = g.conv(b, cb, 3, 1, f"model.22.cv2.{i}.1.conv")
@@ -300,7 +308,7 @@ def yolov8(scale="n", nc=80, imgsz=640, wsrc=None, seed=0):
         c = g.conv(f, cc, 3, 1, f"model.22.cv3.{i}.0.conv")
         c = g.conv(c, cc, 3, 1, f"model.22.cv3.{i}.1.conv")
         c = g.conv(c, nc, 1, 1, f"model.22.cv3.{i}.2", act=ACT_NONE, f32_out=True,
-                   bias_fill=math.log(5 / nc / (imgsz / s) ** 2))
+                   bias_fill=math.log(5 / nc / (640 / s) ** 2))      # upstream Detect.bias_init: the constant 640
         ins += [b, c]
     A = sum(f.h * f.w for f in feats)
     head = g.buf(1, 1, (4 + nc) * A, f32=True)
@@ -333,16 +341,16 @@ def _c3(g, x, c2, n, shortcut, name, out=None):
 def yolov5(scale="n", nc=80, imgsz=640, wsrc=None, seed=0):
     depth, width = V5_SCALES[scale]
     wsrc = wsrc or SynthWeights(seed, gain=SILU_GAIN)
-    g = Graph(f"yolov5{scale}", 3, imgsz, imgsz, wsrc)
+    H, W = _hw(imgsz)
+    g = Graph(f"yolov5{scale}", 3, H, W, wsrc)
     ch = lambda c: int(math.ceil(c * width / 8) * 8)
     dep = lambda n: max(round(n * depth), 1)
     c1, c2, c3, c4, c5 = ch(64), ch(128), ch(256), ch(512), ch(1024)
-    H = imgsz
     x, cin = g.input()
-    cat12 = g.buf(H // 16, H // 16, c4 + c4)   # [up(10), 6]
-    cat16 = g.buf(H // 8, H // 8, c3 + c3)     # [up(14), 4]
-    cat19 = g.buf(H // 16, H // 16, c3 + c3)   # [18, 14]
-    cat22 = g.buf(H // 32, H // 32, c4 + c4)   # [21, 10]
+    cat12 = g.buf(H // 16, W // 16, c4 + c4)   # [up(10), 6]
+    cat16 = g.buf(H // 8, W // 8, c3 + c3)     # [up(14), 4]
+    cat19 = g.buf(H // 16, W // 16, c3 + c3)   # [18, 14]
+    cat22 = g.buf(H // 32, W // 32, c4 + c4)   # [21, 10]
     x = g.conv(x, c1, 6, 2, "model.0.conv", true_cin=cin, pad=2)
     x = g.conv(x, c2, 3, 2, "model.1.conv")
     x = _c3(g, x, c2, dep(3), True, "model.2")
@@ -367,7 +375,7 @@ def yolov5(scale="n", nc=80, imgsz=640, wsrc=None, seed=0):
     no = nc + 5
     ins, strides = [], []
     for i, f in enumerate(feats):
-        s = imgsz // f.h
+        s = H // f.h
         strides.append(s)
         # upstream bias init: obj log(8/(640/s)^2), cls log(0.6/(nc-0.999999)); synthetic -> keep scores sparse
         bias = np.zeros((3, no), np.float32)
@@ -453,9 +461,9 @@ def ufldv2(backbone="18", in_h=320, in_w=1600, num_grid_row=200, num_cls_row=72,
 
 def ufld_v1(backbone="18", in_h=288, in_w=800, griding_num=100, cls_num_per_lane=56, num_lanes=4, wsrc=None, seed=0):
     """UFLD (v1) parsingNet: ResNet trunk -> 1x1 `pool` conv 512->8 -> view(-1, 1800) -> Linear 2048 -> ReLU ->
-    Linear (G+1)*K*L -> one (1, G+1, K, L) tensor.  The network source is upstream (Ultra-Fast-Lane-Detection
-    model/model.py), not vendored by the reference; what the reference pins is the single output and its layout
-    (ultrafastLaneDetector.py:73-75,96-109) and the 800x288 input (:84)."""
+    Linear (G+1)*K*L -> one (1, G+1, K, L) tensor.  Follows the network source the reference vendors for its ONNX export
+    (TrafficLaneDetector/ufldDetector/exportLib/ultrafastLane/model.py:19-89, backbone.py); the detector side pins the single
+    output and its layout (ultrafastLaneDetector.py:73-75,96-109) and the 800x288 input (:84)."""
     wsrc = wsrc or SynthWeights(seed, gain=RELU_RES_GAIN)
     g = Graph(f"ufld_v1_res{backbone}", 3, in_h, in_w, wsrc)
     x, cin = g.input()

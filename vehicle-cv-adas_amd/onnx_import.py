@@ -30,6 +30,10 @@ try:
 except ImportError:  # executed as a script
     import models as M
 
+# Revision of this importer + the container it writes: part of the name of HipEngine's converted-model cache
+# (coreEngine.HipEngine._resolve_container), so containers written by an older importer are not reused.
+IMPORTER_VERSION = 2
+
 
 # ------------------------------------------------------------------------------------- protobuf wire format
 def _varint(buf, pos):
@@ -263,6 +267,8 @@ def detect_arch(m):
         raise ValueError("not a supported architecture: " + found)
     c0 = convs[0][0].shape
     H, W = ins[0][2], ins[0][3]
+    if not (isinstance(H, int) and isinstance(W, int) and H > 0 and W > 0):
+        raise ValueError("dynamic input size (export with fixed H and W; the engine plans its kernels on static shapes): " + found)
     if len(outs) == 4:                                      # UFLDv2: loc_row, loc_col, exist_row, exist_col
         if c0[2] != 7 or c0[0] != 64:
             raise ValueError("4 outputs but no ResNet stem: " + found)
@@ -285,12 +291,16 @@ def detect_arch(m):
             scale = {16: "n", 32: "s", 48: "m", 64: "l", 80: "x"}.get(c0[0])
             if scale is None:
                 raise ValueError("YOLOv8 width not supported: " + found)
-            return "yolov8" + scale, dict(nc=o[1] - 4, imgsz=H)
+            if H % 32 or W % 32:
+                raise ValueError("YOLO input size must be multiples of 32: " + found)
+            return "yolov8" + scale, dict(nc=o[1] - 4, imgsz=(H, W))
         if c0[2] == 6 and o[1] > o[2]:                      # (1, A, 5+nc): YOLOv5 v6.x
             scale = {16: "n", 32: "s", 48: "m", 64: "l", 80: "x"}.get(c0[0])
             if scale is None:
                 raise ValueError("YOLOv5 width not supported: " + found)
-            return "yolov5" + scale, dict(nc=o[2] - 5, imgsz=H)
+            if H % 32 or W % 32:
+                raise ValueError("YOLO input size must be multiples of 32: " + found)
+            return "yolov5" + scale, dict(nc=o[2] - 5, imgsz=(H, W))
     raise ValueError("not a supported architecture: " + found)
 
 
