@@ -35,7 +35,7 @@ def test_yolov8n_fused_names(tmp_path):
     p = tmp_path / "yolov8n.onnx"
     p.write_bytes(OW.model(nodes, inits, [("images", [1, 3, 640, 640])], [("output0", [1, 84, 8400])]))
     m = OI.read_onnx(str(p))
-    assert OI.detect_arch(m) == ("yolov8n", dict(nc=80, imgsz=640))
+    assert OI.detect_arch(m) == ("yolov8n", dict(nc=80, imgsz=(640, 640)))
     out, g2 = OI.convert(str(p), str(tmp_path / "y.hipm"))
     assert g2.tobytes() == M.build("yolov8n", wsrc=M.DictWeights(W)).tobytes()
     assert abs(g2.flops / 1e9 - 8.74) < 0.01
