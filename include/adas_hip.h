@@ -42,6 +42,9 @@ int adas_free(void* d_ptr);
 int adas_memcpy_h2d(void* d_dst, const void* h_src, size_t bytes);
 int adas_memcpy_d2h(void* h_dst, const void* d_src, size_t bytes);
 int adas_synchronize(void);
+/* Page-locked host memory for frames that adas_pipeline_step_frames_host uploads asynchronously. */
+int adas_host_alloc(void** h_ptr, size_t bytes);
+int adas_host_free(void* h_ptr);
 
 /* ===================================================================================
  * Engine: replaces EngineBase / OnnxEngine / TensorRTEngine (coreEngine.py:7-39,120-186)
@@ -50,6 +53,8 @@ typedef struct adas_engine adas_engine;
 
 #define ADAS_PREC_BF16 0 /* bf16 storage + bf16 MFMA, fp32 accumulate (bench precision) */
 #define ADAS_PREC_FP32 1 /* fp32 storage + fp32 MFMA (parity precision, 1e-3 vs the fp32 oracle) */
+#define ADAS_PREC_FP16 2 /* IEEE half storage + f16 MFMA (bf16's rate, 11 significant bits), fp32 accumulate: the precision the
+                          * reference ships (demo.py:18-29 *_fp16.trt; coreEngine.py:168 fp16 engine_dtype) */
 
 /* OnnxEngine.__init__(path) / TensorRTEngine.__init__(path) (coreEngine.py:122-126,161-170).
  * `max_batch` frames per call are planned in HBM (the reference is fixed at 1). */
@@ -69,6 +74,11 @@ int adas_engine_infer_host(adas_engine* e, const float* h_input_nchw, int batch,
 int adas_engine_infer_device(adas_engine* e, const float* d_input_nchw, int batch, void* stream);
 /* 1 when the engine's first layer is the fused stem (bf16 mode) and so can read the packed tensor of adas_preprocess_*_packed */
 int adas_engine_accepts_packed_input(const adas_engine* e);
+/* ADAS_PREC_* the engine was created with */
+int adas_engine_precision(const adas_engine* e);
+/* 1 when the model file declared float16 graph inputs (an fp16 ONNX export): the reference's OnnxEngine then reports
+ * engine_dtype float16 and exchanges float16 arrays (coreEngine.py:168); the C seam stays fp32 either way. */
+int adas_engine_model_io_half(const adas_engine* e);
 int adas_engine_infer_device_packed(adas_engine* e, const uint16_t* d_input_nhwc4, int batch, void* stream);
 const float* adas_engine_output_device(const adas_engine* e, int index);
 /* Algorithmic work of one frame: 2*MACs over conv+linear layers and weight bytes. */
@@ -101,6 +111,12 @@ int adas_preprocess_yolo_packed(const uint8_t* d_frames_bgr, int n, int src_h, i
                                 int dst_w, int keep_ratio, void* stream);
 int adas_preprocess_ufld_packed(const uint8_t* d_frames_bgr, int n, int src_h, int src_w, uint16_t* d_out_nhwc4, int in_h,
                                 int in_w, double crop_ratio, void* stream);
+/* The packed form in the 16-bit type of the engine that will consume it: precision = ADAS_PREC_BF16 (what the two calls above
+ * write) or ADAS_PREC_FP16. */
+int adas_preprocess_yolo_packed_prec(const uint8_t* d_frames_bgr, int n, int src_h, int src_w, uint16_t* d_out_nhwc4, int dst_h,
+                                     int dst_w, int keep_ratio, int precision, void* stream);
+int adas_preprocess_ufld_packed_prec(const uint8_t* d_frames_bgr, int n, int src_h, int src_w, uint16_t* d_out_nhwc4, int in_h,
+                                     int in_w, double crop_ratio, int precision, void* stream);
 
 /* ===================================================================================
  * YOLO post-processing: replaces YoloDetector.__process_output (yoloDetector.py:104-133),
@@ -315,6 +331,11 @@ int adas_pipeline_step(adas_pipeline* p, const float* d_det_input_nchw, const fl
  * tensors the pipeline owns, so one upload per stream and frame feeds both nets (yoloDetector.py:96-102,
  * ultrafastLaneDetectorV2.py:96-112 + the body of demo.py:261-281). */
 int adas_pipeline_step_frames(adas_pipeline* p, const uint8_t* d_frames_bgr, int src_h, int src_w, double lane_crop_ratio);
+/* The same step from HOST frames (what a capture thread hands over, demo.py:261-270): the frames of this step are copied to one
+ * of two device staging buffers on a dedicated copy stream while the previous step still computes (double buffering: copy k+1
+ * overlaps compute k; the compute stream waits for its copy, the copy stream for the step that last read its buffer).
+ * h_frames_bgr should come from adas_host_alloc (pinned): pageable memory works but the copy then cannot overlap. */
+int adas_pipeline_step_frames_host(adas_pipeline* p, const uint8_t* h_frames_bgr, int src_h, int src_w, double lane_crop_ratio);
 int adas_pipeline_sync(adas_pipeline* p);
 /* Device time of the last `n` steps' sections in ms (hipEvents on the pipeline stream):
  * [0] detector net, [1] yolo post, [2] lane net, [3] lane decode, [4] tracker, [5] whole step. */

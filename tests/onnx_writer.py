@@ -56,13 +56,14 @@ def node(op, inputs, outputs, name="", attrs=()):
     return out
 
 
-def value_info(name, shape):
+def value_info(name, shape, elem_type=1):
     dims = b"".join(_ld(1, _vi(1, d)) for d in shape)
-    ttype = _vi(1, 1) + _ld(2, dims)
+    ttype = _vi(1, elem_type) + _ld(2, dims)
     return _ld(1, name.encode()) + _ld(2, _ld(1, ttype))
 
 
-def model(nodes, initializers, inputs, outputs):
+def model(nodes, initializers, inputs, outputs, elem_type=1):
+    """elem_type: TensorProto.DataType of the graph inputs/outputs (1 float32, 10 float16 = an fp16 export)."""
     g = b"".join(_ld(1, n) for n in nodes) + _ld(2, b"g") + b"".join(_ld(5, t) for t in initializers)
-    g += b"".join(_ld(11, value_info(n, s)) for n, s in inputs) + b"".join(_ld(12, value_info(n, s)) for n, s in outputs)
+    g += b"".join(_ld(11, value_info(n, s, elem_type)) for n, s in inputs) + b"".join(_ld(12, value_info(n, s, elem_type)) for n, s in outputs)
     return _vi(1, 8) + _ld(2, b"adas-hip-tests") + _ld(7, g)

@@ -92,7 +92,7 @@ def test_halo_equals_gather_bitwise_shape(CE, monkeypatch):
     assert rel < 5e-3
 
 
-def run_fc_case(CE, batch, cin, cout, act, f32_out, seed=0):
+def run_fc_case(CE, batch, cin, cout, act, f32_out, seed=0, prec="bf16"):
     """input (3,1,1) -> Linear(3, cin)+SiLU -> Linear(cin, cout) under test: both are 1x1-spatial convs and take the
     weight-streaming FC kernel (conv_fc.hip) in bf16 mode."""
     ws = M.SynthWeights(seed, gain=1.0)
@@ -106,7 +106,7 @@ def run_fc_case(CE, batch, cin, cout, act, f32_out, seed=0):
         g.output(z, 0, [1, 8], "o")
     path = os.path.join(tempfile.gettempdir(), f"fcunit_{batch}_{cin}_{cout}_{act}_{int(f32_out)}.hipm")
     g.save(path)
-    e = CE.HipEngine(path, "bf16", batch)
+    e = CE.HipEngine(path, prec, batch)
     xin = np.random.default_rng(seed).uniform(-1, 1, (batch, 3, 1, 1)).astype(np.float32)
     out = e.engine_inference(xin)
     got = e.fetch_activation("test", batch).reshape(batch, cout)
@@ -131,7 +131,7 @@ def test_fc_weight_streaming_kernel(CE, batch):
         assert rel < 1e-2, (batch, cin, cout, rel)
 
 
-def run_stem_case(CE, H, W, k, pad, cout, act, pool, batch=3, seed=0):
+def run_stem_case(CE, H, W, k, pad, cout, act, pool, batch=3, seed=0, prec="bf16"):
     """NCHW fp32 input -> stride-2 kxk conv (+ 3x3 s2 p1 max-pool) through the fused stem kernel (conv_stem.hip)."""
     ws = M.SynthWeights(seed, gain=1.0)
     g = M.Graph("stemunit", 3, H, W, ws)
@@ -142,7 +142,7 @@ def run_stem_case(CE, H, W, k, pad, cout, act, pool, batch=3, seed=0):
     g.output(z, 0, [1, z.h * z.w * 8], "o")
     path = os.path.join(tempfile.gettempdir(), f"stemunit_{H}_{W}_{k}_{cout}_{act}_{int(pool)}.hipm")
     g.save(path)
-    e = CE.HipEngine(path, "bf16", batch)
+    e = CE.HipEngine(path, prec, batch)
     xin = np.random.default_rng(seed).uniform(-1, 1, (batch, 3, H, W)).astype(np.float32)
     e.engine_inference(xin)
     got = e.fetch_activation("pool" if pool else "stem", batch)
@@ -219,3 +219,41 @@ def test_conv3x3_resident_weights_kernel(CE, case):
     rel, mx = run_case(CE, H, W, cin, cout, 3, 1, act, rm, "bf16", batch=max(2, (1024 * 256) // (H * W) + 1),
                        expect_kernel="conv_halo_rw_kernel")
     assert rel < 1e-2, (case, rel, mx)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# fp16 (ADAS_PREC_FP16): the same kernels instantiated on the half element tag (elem16.h).  Two half-precision layers in a
+# row leave ~5e-4 rel-L2 (11 significant bits); bound 1.5e-3, seven times tighter than the bf16 bound.
+FP16_TOL = 1.5e-3
+
+
+@pytest.mark.parametrize("case", [
+    # H, W, cin, cout, k, s, act, res_mode, batch, kernel it must resolve to
+    (40, 200, 128, 128, 3, 1, M.ACT_RELU, M.RES_BEFORE_ACT, 2, "conv_halo_kernel"),
+    (23, 37, 80, 80, 3, 1, M.ACT_SILU, M.RES_NONE, 2, "conv_halo_kernel"),
+    (46, 74, 64, 128, 3, 2, M.ACT_RELU, M.RES_NONE, 2, "conv_halo_kernel"),
+    (80, 80, 32, 32, 3, 1, M.ACT_SILU, M.RES_AFTER_ACT, 42, "conv_halo_rw_kernel"),
+    (80, 400, 64, 64, 3, 1, M.ACT_RELU, M.RES_BEFORE_ACT, 9, "conv_halo_rw_kernel"),
+    (40, 56, 96, 64, 1, 1, M.ACT_SILU, M.RES_NONE, 2, "conv_pw_kernel"),
+    (40, 56, 64, 128, 1, 2, M.ACT_SILU, M.RES_NONE, 2, "conv_pw_kernel"),
+    (40, 56, 16, 16, 3, 1, M.ACT_SILU, M.RES_AFTER_ACT, 2, None),
+], ids=str)
+def test_fp16_conv_kernels(CE, case):
+    H, W, cin, cout, k, s, act, rm, batch, kern = case
+    rel, mx = run_case(CE, H, W, cin, cout, k, s, act, rm, "fp16", batch=batch, expect_kernel=kern)
+    print("fp16", case, "rel_l2 %.2e max|diff| %.2e" % (rel, mx))
+    assert rel < FP16_TOL, (case, rel, mx)
+
+
+@pytest.mark.parametrize("batch", [1, 17, 64])
+def test_fp16_fc_kernel(CE, batch):
+    for cin, cout, act, f32 in ((4000, 2048, M.ACT_RELU, False), (2048, 8200, M.ACT_NONE, True)):
+        rel = run_fc_case(CE, batch, cin, cout, act, f32, prec="fp16")
+        assert rel < FP16_TOL, (batch, cin, cout, rel)
+
+
+@pytest.mark.parametrize("case", [(62, 150, 7, 3, 64, M.ACT_RELU, True), (64, 64, 3, 1, 16, M.ACT_SILU, False),
+                                  (64, 96, 6, 2, 16, M.ACT_SILU, False), (66, 130, 3, 1, 64, M.ACT_SILU, False)], ids=str)
+def test_fp16_fused_stem_kernel(CE, case):
+    rel = run_stem_case(CE, *case, prec="fp16")
+    assert rel < FP16_TOL, (case, rel)

@@ -194,3 +194,39 @@ def test_ufld_v1_single_output_detected(tmp_path):
     assert arch == "ufld_v1_res18" and got == dict(in_h=96, in_w=160, griding_num=20, cls_num_per_lane=8, num_lanes=4)
     out, g2 = OI.convert(str(p), str(tmp_path / "u1.hipm"))
     assert g2.tobytes() == M.build("ufld_v1_res18", wsrc=M.DictWeights(W), **kw).tobytes()
+
+
+def test_fp16_export_and_input_size_checks(tmp_path):
+    """An fp16 export (float16 graph input, onnxQuantization.py:11-41) is flagged in the container header (HipEngine.engine_dtype
+    follows it, coreEngine.py:168); non-square inputs reach the builder as (H, W); dynamic or non-multiple-of-32 sizes fail loudly."""
+    import struct
+    W = {}
+    g0 = M.build("yolov8n", wsrc=M.SynthWeights(0, gain=M.SILU_GAIN))
+    ws = M.SynthWeights(0, gain=M.SILU_GAIN)
+    M.build("yolov8n", wsrc=ws)
+    inits, nodes = [], []
+    for i, base in enumerate(k[:-7] for k in ws.store if k.endswith(".weight")):
+        inits += [OW.tensor(base + ".weight", ws.store[base + ".weight"].astype(np.float16)),
+                  OW.tensor(base + ".bias", ws.store[base + ".bias"].astype(np.float16))]
+        nodes.append(OW.node("Conv", ["t%d" % i, base + ".weight", base + ".bias"], ["t%d" % (i + 1)], "Conv_%d" % i))
+    p = tmp_path / "half.onnx"
+    p.write_bytes(OW.model(nodes, inits, [("images", [1, 3, 640, 640])], [("output0", [1, 84, 8400])], elem_type=10))
+    m = OI.read_onnx(str(p))
+    assert m.elem_types["images"] == 10
+    out, g = OI.convert(str(p), str(tmp_path / "half.hipm"))
+    assert g.io_half
+    hdr = struct.unpack(M.HDR_FMT, open(out, "rb").read(M.HDR_SIZE))
+    assert hdr[8] == (8 | (1 << 16))                      # in_cpad word: bit 16 = float16 model I/O
+    assert struct.unpack(M.HDR_FMT, g0.tobytes()[:M.HDR_SIZE])[8] == 8
+    # non-square
+    q = tmp_path / "rect.onnx"
+    A = 48 * 80 + 24 * 40 + 12 * 20
+    q.write_bytes(OW.model(nodes, inits, [("images", [1, 3, 384, 640])], [("output0", [1, 84, A])]))
+    assert OI.detect_arch(OI.read_onnx(str(q))) == ("yolov8n", dict(nc=80, imgsz=(384, 640)))
+    gq = M.build("yolov8n", imgsz=(384, 640))
+    assert (gq.in_h, gq.in_w) == (384, 640) and gq.meta["anchors"] == A
+    for bad in ([1, 3, -1, -1], [1, 3, 0, 640], [1, 3, 600, 600]):
+        r = tmp_path / "bad.onnx"
+        r.write_bytes(OW.model(nodes, inits, [("images", bad)], [("output0", [1, 84, 8400])]))
+        with pytest.raises(ValueError):
+            OI.detect_arch(OI.read_onnx(str(r)))

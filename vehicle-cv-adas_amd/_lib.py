@@ -14,7 +14,8 @@ LIB_PATH = os.path.join(HERE, "libadas_hip.so")
 UFLD_MAX_POINTS = 128
 HEAD_V8, HEAD_V5, HEAD_V5_LITE = 0, 1, 2
 NMS_REFERENCE, NMS_GREEDY = 0, 1
-PREC_BF16, PREC_FP32 = 0, 1
+PREC_BF16, PREC_FP32, PREC_FP16 = 0, 1, 2
+PRECISIONS = {"bf16": PREC_BF16, "fp32": PREC_FP32, "fp16": PREC_FP16}
 
 
 class AdasError(RuntimeError):
@@ -83,6 +84,8 @@ _SIGS = {
     "adas_memcpy_h2d": (C.c_int, [_P, _P, C.c_size_t]),
     "adas_memcpy_d2h": (C.c_int, [_P, _P, C.c_size_t]),
     "adas_synchronize": (C.c_int, []),
+    "adas_host_alloc": (C.c_int, [C.POINTER(_P), C.c_size_t]),
+    "adas_host_free": (C.c_int, [_P]),
     "adas_engine_create": (C.c_int, [C.c_char_p, C.c_int, C.c_int, C.POINTER(_P)]),
     "adas_engine_destroy": (C.c_int, [_P]),
     "adas_engine_input_shape": (C.c_int, [_P, C.POINTER(C.c_int64)]),
@@ -92,6 +95,8 @@ _SIGS = {
     "adas_engine_infer_host": (C.c_int, [_P, _P, C.c_int, C.POINTER(_P)]),
     "adas_engine_infer_device": (C.c_int, [_P, _P, C.c_int, _P]),
     "adas_engine_accepts_packed_input": (C.c_int, [_P]),
+    "adas_engine_precision": (C.c_int, [_P]),
+    "adas_engine_model_io_half": (C.c_int, [_P]),
     "adas_engine_infer_device_packed": (C.c_int, [_P, _P, C.c_int, _P]),
     "adas_engine_output_device": (_P, [_P, C.c_int]),
     "adas_engine_stats": (C.c_int, [_P, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int)]),
@@ -103,6 +108,8 @@ _SIGS = {
     "adas_preprocess_ufld": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, _P, C.c_int, C.c_int, C.c_double, _P]),
     "adas_preprocess_yolo_packed": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, _P, C.c_int, C.c_int, C.c_int, _P]),
     "adas_preprocess_ufld_packed": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, _P, C.c_int, C.c_int, C.c_double, _P]),
+    "adas_preprocess_yolo_packed_prec": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
+    "adas_preprocess_ufld_packed_prec": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, _P, C.c_int, C.c_int, C.c_double, C.c_int, _P]),
     "adas_letterbox_params": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(YoloPostParams)]),
     "adas_yolo_post_create": (C.c_int, [C.POINTER(YoloPostParams), C.c_int, C.POINTER(_P)]),
     "adas_yolo_post_destroy": (C.c_int, [_P]),
@@ -137,6 +144,7 @@ _SIGS = {
     "adas_pipeline_destroy": (C.c_int, [_P]),
     "adas_pipeline_step": (C.c_int, [_P, _P, _P]),
     "adas_pipeline_step_frames": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_double]),
+    "adas_pipeline_step_frames_host": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_double]),
     "adas_pipeline_sync": (C.c_int, [_P]),
     "adas_pipeline_timings": (C.c_int, [_P, C.POINTER(C.c_float)]),
 }
@@ -204,6 +212,31 @@ class DeviceBuffer:
     def free(self):
         if self.ptr:
             lib().adas_free(self.ptr)
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class PinnedBuffer:
+    """Page-locked host memory (adas_host_alloc) viewed as a NumPy array: frames that adas_pipeline_step_frames_host uploads
+    asynchronously must live here for the copy to overlap the previous step."""
+
+    def __init__(self, shape, dtype=np.uint8):
+        self.shape, self.dtype = tuple(int(x) for x in shape), np.dtype(dtype)
+        self.nbytes = int(np.prod(self.shape)) * self.dtype.itemsize
+        p = C.c_void_p()
+        check(lib().adas_host_alloc(C.byref(p), self.nbytes))
+        self.ptr = p.value
+        self.array = np.ctypeslib.as_array((C.c_uint8 * self.nbytes).from_address(self.ptr)).view(self.dtype).reshape(self.shape)
+
+    def free(self):
+        if getattr(self, "ptr", None):
+            self.array = None
+            lib().adas_host_free(self.ptr)
             self.ptr = None
 
     def __del__(self):

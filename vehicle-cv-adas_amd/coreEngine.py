@@ -11,7 +11,8 @@ This module exports the same names, all bound to HipEngine, with the same surfac
     .framework_type / .providers / .engine_dtype
 
 Added (not in the reference): `.infer_device(d_ptr, batch)` keeps outputs in HBM for the GPU-resident
-post-processing; `precision=` ("bf16" bench / "fp32" parity) and `max_batch=` keyword arguments.
+post-processing; `precision=` ("fp16" default: half storage + f16 MFMA, what the reference ships as *_fp16.trt; "bf16";
+"fp32" parity mode) and `max_batch=` keyword arguments.
 There is no CPU execution path: construction fails if libadas_hip.so or a gfx950 device is missing.
 """
 import abc
@@ -26,6 +27,7 @@ except ImportError:  # imported as a top-level module named `coreEngine` (packag
     import _lib as L
 
 MODEL_SUFFIXES = ('.onnx', '.trt', '.hipm')
+DEFAULT_PRECISION = os.environ.get("ADAS_PRECISION", "fp16")
 
 
 class EngineBase(abc.ABC):
@@ -65,16 +67,21 @@ class EngineBase(abc.ABC):
 
 
 class HipEngine(EngineBase):
-    def __init__(self, model_path, precision="bf16", max_batch=1):
+    def __init__(self, model_path, precision=None, max_batch=1):
         EngineBase.__init__(self, model_path)
-        prec = {"bf16": L.PREC_BF16, "fp32": L.PREC_FP32}[precision]
+        precision = precision or DEFAULT_PRECISION
+        if precision not in L.PRECISIONS:
+            raise Exception("precision must be one of %s, got %r" % (sorted(L.PRECISIONS), precision))
+        prec = L.PRECISIONS[precision]
         model_path = self._resolve_container(model_path)
         h = C.c_void_p()
         L.check(L.lib().adas_engine_create(os.fsencode(model_path), prec, int(max_batch), C.byref(h)))
         self._h = h.value
         self.precision, self.max_batch = precision, int(max_batch)
         self.providers = ['HIPExecutionProvider(gfx950)']
-        self.engine_dtype = np.float32        # the seam stays fp32; bf16 is internal
+        # coreEngine.py:168: a model whose graph input is float16 makes the callers cast their tensor to float16 and hands float16
+        # arrays back; every other model is a float32 seam (the 16-bit compute types are internal)
+        self.engine_dtype = np.float16 if L.lib().adas_engine_model_io_half(self._h) else np.float32
         self.framework_type = "hip"
         self.__load_engine_interface()
 
@@ -143,6 +150,8 @@ class HipEngine(EngineBase):
         outs = [np.empty([batch] + s[1:], np.float32) for s in self.__output_shapes]
         ptrs = (C.c_void_p * len(outs))(*[o.ctypes.data for o in outs])
         L.check(L.lib().adas_engine_infer_host(self._h, L.ptr(x), batch, ptrs))
+        if self.engine_dtype is not np.float32:      # an fp16 model returns fp16 arrays, as ONNXRuntime does
+            outs = [o.astype(self.engine_dtype) for o in outs]
         return outs
 
     # ---- device-resident extensions
@@ -154,7 +163,8 @@ class HipEngine(EngineBase):
         L.check(L.lib().adas_engine_infer_device(self._h, d_input_ptr, int(batch), stream))
 
     def infer_device_packed(self, d_input_ptr, batch=1, stream=None):
-        """Input = the (c0,c1,c2,0) bf16 NHWC tensor of adas_preprocess_*_packed (fused first layer only)."""
+        """Input = the (c0,c1,c2,0) 16-bit NHWC tensor of adas_preprocess_*_packed_prec in this engine's precision (fused first
+        layer only)."""
         L.check(L.lib().adas_engine_infer_device_packed(self._h, d_input_ptr, int(batch), stream))
 
     def output_device_ptr(self, index):

@@ -55,6 +55,16 @@ int adas_memcpy_d2h(void* h, const void* d, size_t n) {
     ADAS_HIP_TRY(hipMemcpy(h, d, n, hipMemcpyDeviceToHost));
     return ADAS_OK;
 }
+int adas_host_alloc(void** h_ptr, size_t bytes) {
+    ADAS_REQUIRE(h_ptr, ADAS_ERR_INVALID, "adas_host_alloc: null out pointer");
+    ADAS_REQUIRE(adas_device_count() > 0, ADAS_ERR_NO_DEVICE, "no HIP device visible; this library has no CPU fallback");
+    ADAS_HIP_TRY(hipHostMalloc(h_ptr, bytes ? bytes : 16, hipHostMallocDefault));
+    return ADAS_OK;
+}
+int adas_host_free(void* h_ptr) {
+    if (h_ptr) ADAS_HIP_TRY(hipHostFree(h_ptr));
+    return ADAS_OK;
+}
 int adas_synchronize(void) {
     ADAS_HIP_TRY(hipDeviceSynchronize());
     return ADAS_OK;

@@ -7,6 +7,7 @@
 //   layernorm    model_culane.py:34 (fc_norm), one workgroup per frame
 //   nhwc_to_nchw parity tap
 #include "kernels.h"
+#include "elem16.h"
 
 namespace adas {
 
@@ -19,9 +20,26 @@ __device__ __forceinline__ uint16_t a_f2bf(float f) {
 template <typename T> __device__ __forceinline__ float ld(const T* p);
 template <> __device__ __forceinline__ float ld<float>(const float* p) { return *p; }
 template <> __device__ __forceinline__ float ld<uint16_t>(const uint16_t* p) { return a_bf2f(*p); }
+template <> __device__ __forceinline__ float ld<f16s>(const f16s* p) { return Fp16::to_f32(p->v); }
 template <typename T> __device__ __forceinline__ void st(T* p, float v);
 template <> __device__ __forceinline__ void st<float>(float* p, float v) { *p = v; }
 template <> __device__ __forceinline__ void st<uint16_t>(uint16_t* p, float v) { *p = a_f2bf(v); }
+template <> __device__ __forceinline__ void st<f16s>(f16s* p, float v) { p->v = Fp16::from_f32(v); }
+
+// launch `KERNEL<T>` with T = the storage type of an engine precision
+#define ADAS_DISPATCH_STORAGE(prec, T, ...) \
+    do {                                    \
+        if ((prec) == PREC_FP32) {          \
+            using T = float;                \
+            __VA_ARGS__;                    \
+        } else if ((prec) == PREC_FP16) {   \
+            using T = f16s;                 \
+            __VA_ARGS__;                    \
+        } else {                            \
+            using T = uint16_t;             \
+            __VA_ARGS__;                    \
+        }                                   \
+    } while (0)
 
 // ------------------------------------------------------------------------------------- input
 template <typename T>
@@ -42,10 +60,7 @@ hipError_t launch_input_nchw(const float* nchw, TView out, int n, int c_true, in
     size_t total = (size_t)n * hw;
     int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
     if (out.c != 8 || out.coff != 0 || c_true > 8) return hipErrorInvalidValue;
-    if (prec == PREC_FP32)
-        hipLaunchKernelGGL(input_nchw_kernel<float>, dim3(blocks), dim3(256), 0, st_, nchw, (float*)out.p, n, c_true, hw, out.cs);
-    else
-        hipLaunchKernelGGL(input_nchw_kernel<uint16_t>, dim3(blocks), dim3(256), 0, st_, nchw, (uint16_t*)out.p, n, c_true, hw, out.cs);
+    ADAS_DISPATCH_STORAGE(prec, T, hipLaunchKernelGGL(input_nchw_kernel<T>, dim3(blocks), dim3(256), 0, st_, nchw, (T*)out.p, n, c_true, hw, out.cs));
     return hipGetLastError();
 }
 
@@ -65,6 +80,18 @@ __device__ __forceinline__ void max8(float m[8], const uint16_t* ip) {
         m[2 * k] = fmaxf(m[2 * k], __uint_as_float(w[k] << 16));
         m[2 * k + 1] = fmaxf(m[2 * k + 1], __uint_as_float(w[k] & 0xffff0000u));
     }
+}
+__device__ __forceinline__ void max8(float m[8], const f16s* ip) {
+    const uint4 q = *reinterpret_cast<const uint4*>(ip);
+    const uint32_t w[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        m[2 * k] = fmaxf(m[2 * k], Fp16::lo(w[k]));
+        m[2 * k + 1] = fmaxf(m[2 * k + 1], Fp16::hi(w[k]));
+    }
+}
+__device__ __forceinline__ void put8(f16s* op, const float m[8]) {   // the maxima are half values: the conversion is exact
+    *reinterpret_cast<uint4*>(op) = make_uint4(Fp16::pack2(m[0], m[1]), Fp16::pack2(m[2], m[3]), Fp16::pack2(m[4], m[5]), Fp16::pack2(m[6], m[7]));
 }
 __device__ __forceinline__ void max8(float m[8], const float* ip) {
 #pragma unroll
@@ -107,11 +134,12 @@ __global__ void maxpool_kernel(PoolDev d) {
         put8((T*)d.out + pix * d.out_cs + d.out_coff + c8 * 8, m);
     }
 }
-// bf16, compile-time window: every tap is loaded unconditionally from a clamped (always valid) address and out-of-image
+// 16-bit elements, compile-time window: every tap is loaded unconditionally from a clamped (always valid) address and out-of-image
 // taps are turned into -inf afterwards, so all K*K 16-byte loads of a thread are in flight together (a branch around a
 // load makes hipcc wait for it at the join: the generic kernel above pays K*K sequential L2 round trips).
-template <int K>
-__global__ void maxpool_bf16_kernel(PoolDev d) {
+template <typename E, int K>
+__global__ void maxpool16_kernel(PoolDev d) {
+    typedef typename E::storage T;
     const int c8n = d.c >> 3;
     size_t total = (size_t)d.n * d.Ho * d.Wo * c8n;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
@@ -142,15 +170,15 @@ __global__ void maxpool_bf16_kernel(PoolDev d) {
                 const int ix = ox * d.s - d.p + q;
                 const bool in = (unsigned)iy < (unsigned)d.H && (unsigned)ix < (unsigned)d.W;
                 const uint4 u = v[r * K + q];
-                const uint32_t w[4] = {in ? u.x : 0xff80ff80u, in ? u.y : 0xff80ff80u, in ? u.z : 0xff80ff80u, in ? u.w : 0xff80ff80u};
+                const uint32_t w[4] = {in ? u.x : E::kNegInf2, in ? u.y : E::kNegInf2, in ? u.z : E::kNegInf2, in ? u.w : E::kNegInf2};
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
-                    m[2 * k] = fmaxf(m[2 * k], __uint_as_float(w[k] << 16));
-                    m[2 * k + 1] = fmaxf(m[2 * k + 1], __uint_as_float(w[k] & 0xffff0000u));
+                    m[2 * k] = fmaxf(m[2 * k], E::lo(w[k]));
+                    m[2 * k + 1] = fmaxf(m[2 * k + 1], E::hi(w[k]));
                 }
             }
         }
-        put8((uint16_t*)d.out + pix * d.out_cs + d.out_coff + c8 * 8, m);
+        put8((T*)d.out + pix * d.out_cs + d.out_coff + c8 * 8, m);
     }
 }
 
@@ -159,14 +187,14 @@ hipError_t launch_maxpool(TView in, TView out, int n, int k, int s, int p, int p
     PoolDev d{in.p, out.p, in.cs, in.coff, out.cs, out.coff, in.c, in.h, in.w, out.h, out.w, k, s, p, n};
     size_t total = (size_t)n * out.h * out.w * (in.c >> 3);
     int blocks = (int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
-    if (prec == PREC_FP32)
-        hipLaunchKernelGGL(maxpool_kernel<float>, dim3(blocks), dim3(256), 0, st_, d);
-    else if (k == 5)
-        hipLaunchKernelGGL(maxpool_bf16_kernel<5>, dim3(blocks), dim3(256), 0, st_, d);
-    else if (k == 3)
-        hipLaunchKernelGGL(maxpool_bf16_kernel<3>, dim3(blocks), dim3(256), 0, st_, d);
-    else
-        hipLaunchKernelGGL(maxpool_kernel<uint16_t>, dim3(blocks), dim3(256), 0, st_, d);
+    if (prec == PREC_FP32 || (k != 5 && k != 3)) {
+        ADAS_DISPATCH_STORAGE(prec, T, hipLaunchKernelGGL(maxpool_kernel<T>, dim3(blocks), dim3(256), 0, st_, d));
+    } else {
+        ADAS_DISPATCH_E16(prec == PREC_FP16, E, {
+            if (k == 5) hipLaunchKernelGGL((maxpool16_kernel<E, 5>), dim3(blocks), dim3(256), 0, st_, d);
+            else hipLaunchKernelGGL((maxpool16_kernel<E, 3>), dim3(blocks), dim3(256), 0, st_, d);
+        });
+    }
     return hipGetLastError();
 }
 
@@ -301,7 +329,6 @@ hipError_t launch_detect_v8(const TView* ins, float* out, int n, int nc, int A, 
 // 310 MB of fp32 logits per 64-frame step out of HBM and save six launches.  A workgroup owns 64 anchors of one level of one
 // frame; wave w owns anchors 16w..16w+15.  With weights as the A operand a lane ends with 4 consecutive outputs of one
 // anchor, so the 16 DFL bins of a box side sit in the 4 lanes {lrow, lrow+16, lrow+32, lrow+48} x 4 registers.
-typedef __attribute__((ext_vector_type(8))) __bf16 dbf16x8;
 typedef __attribute__((ext_vector_type(4))) float df32x4;
 typedef __attribute__((ext_vector_type(4))) uint32_t du32x4;
 #define ADAS_DETF_MAXKS 12  // hidden widths up to 384 channels (YOLOv8x: 320)
@@ -322,6 +349,7 @@ struct DetFuseDev {
 
 __device__ __forceinline__ float detf_quad(float v, int m) { return __shfl_xor(v, m, 64); }
 
+template <typename E>
 __global__ __launch_bounds__(256) void detect_v8_fused_kernel(DetFuseDev d) {
     extern __shared__ __attribute__((aligned(16))) uint16_t wl[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lrow = lane & 15, kg = lane >> 4;
@@ -358,7 +386,7 @@ __global__ __launch_bounds__(256) void detect_v8_fused_kernel(DetFuseDev d) {
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
                 const du32x4 wf = *reinterpret_cast<const du32x4*>(wbox + ((size_t)(t * KSb + ks) * 64 + lane) * 8);
-                acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(dbf16x8, wf), __builtin_bit_cast(dbf16x8, xb), acc[t], 0, 0, 0);
+                acc[t] = E::mfma(wf, xb, acc[t]);
             }
         }
         float dist[4];
@@ -404,7 +432,7 @@ __global__ __launch_bounds__(256) void detect_v8_fused_kernel(DetFuseDev d) {
             for (int ks = 0; ks < ADAS_DETF_MAXKS; ++ks) {
                 if (ks < KSc) {
                     const du32x4 wf = *reinterpret_cast<const du32x4*>(wcls + ((size_t)(nt * KSc + ks) * 64 + lane) * 8);
-                    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(dbf16x8, wf), __builtin_bit_cast(dbf16x8, xc[ks]), acc, 0, 0, 0);
+                    acc = E::mfma(wf, xc[ks], acc);
                 }
             }
 #pragma unroll
@@ -418,7 +446,7 @@ __global__ __launch_bounds__(256) void detect_v8_fused_kernel(DetFuseDev d) {
 
 // hidden[2l] / hidden[2l+1]: inputs of cv2.l.2 / cv3.l.2; wfrag/bias: their packed (CONV_PW order) weights and biases
 hipError_t launch_detect_v8_fused(const TView* hidden, const void* const* wfrag, const float* const* bias, float* out, int n, int nc, int A,
-                                  const int strides[3], hipStream_t st_) {
+                                  const int strides[3], int prec, hipStream_t st_) {
     DetFuseDev d;
     int off = 0, blocks = 0;
     d.cb = hidden[0].c; d.cc = hidden[1].c;
@@ -441,11 +469,12 @@ hipError_t launch_detect_v8_fused(const TView* hidden, const void* const* wfrag,
     const size_t lds = ((size_t)4 * KSb + (size_t)NTc * KSc) * 1024 + (64 + (size_t)NTc * 16) * 4;
     static bool attr_done = false;
     if (!attr_done) {
-        (void)hipFuncSetAttribute((const void*)detect_v8_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+        (void)hipFuncSetAttribute((const void*)detect_v8_fused_kernel<Bf16>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+        (void)hipFuncSetAttribute((const void*)detect_v8_fused_kernel<Fp16>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
         attr_done = true;
     }
     if (lds > 150 * 1024) return hipErrorNotSupported;
-    hipLaunchKernelGGL(detect_v8_fused_kernel, dim3(blocks, n), dim3(256), lds, st_, d);
+    ADAS_DISPATCH_E16(prec == PREC_FP16, E, hipLaunchKernelGGL(detect_v8_fused_kernel<E>, dim3(blocks, n), dim3(256), lds, st_, d));
     return hipGetLastError();
 }
 
@@ -524,10 +553,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
 }
 hipError_t launch_layernorm(const float* in, void* out, const float* gamma, const float* beta, int n, int len, float eps,
                             int prec, hipStream_t st_) {
-    if (prec == PREC_FP32)
-        hipLaunchKernelGGL(layernorm_kernel<float>, dim3(n), dim3(256), 0, st_, in, (float*)out, gamma, beta, len, eps);
-    else
-        hipLaunchKernelGGL(layernorm_kernel<uint16_t>, dim3(n), dim3(256), 0, st_, in, (uint16_t*)out, gamma, beta, len, eps);
+    ADAS_DISPATCH_STORAGE(prec, T, hipLaunchKernelGGL(layernorm_kernel<T>, dim3(n), dim3(256), 0, st_, in, (T*)out, gamma, beta, len, eps));
     return hipGetLastError();
 }
 
@@ -547,10 +573,8 @@ hipError_t launch_nhwc_to_nchw(TView in, float* out, int n, int prec, hipStream_
     int hw = in.h * in.w;
     size_t total = (size_t)n * in.c * hw;
     int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
-    if (in.f32 || prec == PREC_FP32)
-        hipLaunchKernelGGL(nhwc_to_nchw_kernel<float>, dim3(blocks), dim3(256), 0, st_, (const float*)in.p, out, n, hw, in.c, in.cs, in.coff);
-    else
-        hipLaunchKernelGGL(nhwc_to_nchw_kernel<uint16_t>, dim3(blocks), dim3(256), 0, st_, (const uint16_t*)in.p, out, n, hw, in.c, in.cs, in.coff);
+    ADAS_DISPATCH_STORAGE(in.f32 ? PREC_FP32 : prec, T,
+                          hipLaunchKernelGGL(nhwc_to_nchw_kernel<T>, dim3(blocks), dim3(256), 0, st_, (const T*)in.p, out, n, hw, in.c, in.cs, in.coff));
     return hipGetLastError();
 }
 

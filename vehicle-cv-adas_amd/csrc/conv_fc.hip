@@ -14,14 +14,12 @@
 // (cls.1) split K across the KS waves of a workgroup and reduce through LDS before the fused
 // bias + ReLU epilogue.
 #include "kernels.h"
+#include "elem16.h"
 
 namespace adas {
 
-typedef __attribute__((ext_vector_type(8))) __bf16 fbf16x8;
 typedef __attribute__((ext_vector_type(4))) float ff32x4;
 typedef __attribute__((ext_vector_type(4))) uint32_t fu32x4;
-typedef __attribute__((ext_vector_type(2))) float ff32x2;
-typedef __attribute__((ext_vector_type(2))) __bf16 fbf16x2;
 
 struct FcDev {
     const uint16_t* x;    // [batch][x_cs] bf16 (+ x_coff)
@@ -32,12 +30,7 @@ struct FcDev {
     int batch, cout, kpad, act, out_f32;
 };
 
-__device__ __forceinline__ uint32_t fc_pack2(float a, float b) {
-    fbf16x2 r = __builtin_convertvector(ff32x2{a, b}, fbf16x2);
-    return __builtin_bit_cast(uint32_t, r);
-}
-
-template <int TN, int TM, int KS, int U>
+template <typename E, int TN, int TM, int KS, int U>
 __global__ __launch_bounds__(64 * KS) void fc_kernel(FcDev a) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lrow = lane & 15, kg = lane >> 4;
@@ -75,8 +68,7 @@ __global__ __launch_bounds__(64 * KS) void fc_kernel(FcDev a) {
         for (int i = 0; i < TN; ++i)
 #pragma unroll
             for (int j = 0; j < TM; ++j)
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(fbf16x8, wa[buf][i]),
-                                                                    __builtin_bit_cast(fbf16x8, xb[buf][j]), acc[i][j], 0, 0, 0);
+                acc[i][j] = E::mfma(wa[buf][i], xb[buf][j], acc[i][j]);
     };
     if (n >= U) {
 #pragma unroll
@@ -151,8 +143,8 @@ __global__ __launch_bounds__(64 * KS) void fc_kernel(FcDev a) {
                 *reinterpret_cast<float4*>((float*)a.out + o) = make_float4(v[0], v[1], v[2], v[3]);
             } else {
                 uint2 q;
-                q.x = fc_pack2(v[0], v[1]);
-                q.y = fc_pack2(v[2], v[3]);
+                q.x = E::pack2(v[0], v[1]);
+                q.y = E::pack2(v[2], v[3]);
                 *reinterpret_cast<uint2*>((uint16_t*)a.out + o) = q;
             }
         }
@@ -161,17 +153,17 @@ __global__ __launch_bounds__(64 * KS) void fc_kernel(FcDev a) {
 
 // Static-shape test used both at load time (weight packing) and at launch time: max_n = the engine's max_batch.
 bool fc_applicable(int prec, int kh, int kw, int stride, int max_n, const TView& in, const TView& out) {
-    if (prec != PREC_BF16 || in.f32) return false;
+    if (!prec_is16(prec) || in.f32) return false;
     if (kh != 1 || kw != 1 || stride != 1 || in.h != 1 || in.w != 1 || out.h != 1 || out.w != 1) return false;
     if (max_n > 64) return false;
     if ((in.cs & 7) || (in.coff & 7) || (in.c & 7) || (out.c & 3) || (out.cs & 3) || (out.coff & 3)) return false;
     return true;
 }
 
-template <int TN, int TM, int KS, int U>
+template <typename E, int TN, int TM, int KS, int U>
 static hipError_t fc_launch(const FcDev& d, hipStream_t st) {
     const int tiles = (d.cout + TN * 16 - 1) / (TN * 16);
-    hipLaunchKernelGGL((fc_kernel<TN, TM, KS, U>), dim3(tiles), dim3(64 * KS), 0, st, d);
+    hipLaunchKernelGGL((fc_kernel<E, TN, TM, KS, U>), dim3(tiles), dim3(64 * KS), 0, st, d);
     return hipGetLastError();
 }
 
@@ -183,17 +175,21 @@ hipError_t launch_fc(const ConvArgs& a, hipStream_t st) {
     const int tm = a.n <= 16 ? 1 : (a.n <= 32 ? 2 : 4);
     // few output tiles (cls.1: 2048 features): 16 features per workgroup, K split over 4 waves
     const bool split = a.out.c <= 8192;
-    if (split) {
-        if (tm == 1) return fc_launch<1, 1, 4, 4>(d, st);
-        if (tm == 2) return fc_launch<1, 2, 4, 4>(d, st);
-        return fc_launch<1, 4, 4, 4>(d, st);
-    }
-    if (tm == 1) return fc_launch<4, 1, 1, 4>(d, st);
-    if (tm == 2) return fc_launch<4, 2, 1, 4>(d, st);
-    return fc_launch<4, 4, 1, 3>(d, st);
+    ADAS_DISPATCH_E16(a.prec == PREC_FP16, E, {
+        if (split) {
+            if (tm == 1) return fc_launch<E, 1, 1, 4, 4>(d, st);
+            if (tm == 2) return fc_launch<E, 1, 2, 4, 4>(d, st);
+            return fc_launch<E, 1, 4, 4, 4>(d, st);
+        }
+        if (tm == 1) return fc_launch<E, 4, 1, 1, 4>(d, st);
+        if (tm == 2) return fc_launch<E, 4, 2, 1, 4>(d, st);
+        return fc_launch<E, 4, 4, 1, 3>(d, st);
+    });
+    return hipErrorInvalidValue;
 }
 
 // fp32 [cout][cin] -> bf16 fragment order [cout_pad/16][kpad/32][64 lanes][8]: lane = (k%32/8)*16 + row%16
+template <typename E>
 __global__ void pack_weights_fc_kernel(const float* __restrict__ src, uint16_t* __restrict__ dst, int cout, int cin, int kpad, size_t total) {
     const int KT = kpad >> 5;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
@@ -204,15 +200,15 @@ __global__ void pack_weights_fc_kernel(const float* __restrict__ src, uint16_t* 
         const size_t row = tile * 16 + (lane & 15);
         const int k = ks * 32 + (lane >> 4) * 8 + e;
         const float v = (row < (size_t)cout && k < cin) ? src[row * cin + k] : 0.0f;
-        fbf16x2 r = __builtin_convertvector(ff32x2{v, 0.f}, fbf16x2);
-        dst[i] = (uint16_t)(__builtin_bit_cast(uint32_t, r) & 0xffffu);
+        dst[i] = E::from_f32(v);
     }
 }
 
-hipError_t launch_pack_weights_fc(const float* src, void* dst, int cout, int cout_pad, int cin, int kpad, hipStream_t st) {
+hipError_t launch_pack_weights_fc(const float* src, void* dst, int cout, int cout_pad, int cin, int kpad, int prec, hipStream_t st) {
     size_t total = (size_t)cout_pad * kpad;
     int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
-    hipLaunchKernelGGL(pack_weights_fc_kernel, dim3(blocks), dim3(256), 0, st, src, (uint16_t*)dst, cout, cin, kpad, total);
+    ADAS_DISPATCH_E16(prec == PREC_FP16, E,
+                      hipLaunchKernelGGL(pack_weights_fc_kernel<E>, dim3(blocks), dim3(256), 0, st, src, (uint16_t*)dst, cout, cin, kpad, total));
     return hipGetLastError();
 }
 

@@ -28,6 +28,7 @@
 // of the four 64-byte residues are touched; an 80 B pitch would be conflict-free but does not leave room for two
 // workgroups per CU) -- LDS is ~20 % utilised in this kernel, so the smaller footprint wins.
 #include "kernels.h"
+#include "elem16.h"
 #include <stdlib.h>
 #include <string.h>
 #include <map>
@@ -36,16 +37,9 @@
 
 namespace adas {
 
-typedef __attribute__((ext_vector_type(8))) __bf16 hbf16x8;
 typedef __attribute__((ext_vector_type(4))) float hf32x4;
 typedef __attribute__((ext_vector_type(4))) uint32_t hu32x4;
 
-typedef __attribute__((ext_vector_type(2))) float hf32x2;
-typedef __attribute__((ext_vector_type(2))) __bf16 hbf16x2;
-__device__ __forceinline__ uint32_t h_pack2(float a, float b) {  // v_cvt_pk_bf16_f32 (round to nearest even)
-    hbf16x2 r = __builtin_convertvector(hf32x2{a, b}, hbf16x2);
-    return __builtin_bit_cast(uint32_t, r);
-}
 template <int ACT>
 __device__ __forceinline__ float h_act(float v) {
     if (ACT == ACT_SILU) return v * __frcp_rn(1.0f + __expf(-v));
@@ -104,8 +98,9 @@ __device__ unsigned long long g_halo_prof[256][16];
 #define HPROF_FLUSH
 #endif
 
-template <int BN, int ACT, int S>
+template <typename E, int BN, int ACT, int S>   // E: element tag (elem16.h)
 __global__ __launch_bounds__(256, 2) void conv_halo_kernel(HaloDev a) {
+    typedef typename E::vec8 hvec8;
     constexpr int TAPS = 9;
     constexpr int HALO_BM = halo_bm(S);
     constexpr int HALO_NA = halo_maxpix(S) * 4 / 256;
@@ -222,20 +217,20 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(HaloDev a) {
 #pragma unroll
         for (int tap = 0; tap < TAPS; ++tap) {
             const int r = tap / 3, s = tap - r * 3;
-            hbf16x8 wf[TN], xf[TM];
+            hvec8 wf[TN], xf[TM];
 #pragma unroll
             for (int i = 0; i < TN; ++i)
-                wf[i] = *reinterpret_cast<const hbf16x8*>(Ww + (tap * BN + i * 16) * HALO_WPIX + wrd);
+                wf[i] = *reinterpret_cast<const hvec8*>(Ww + (tap * BN + i * 16) * HALO_WPIX + wrd);
 #pragma unroll
             for (int j = 0; j < TM; ++j) {
                 const int pw = apix[j] + r * a.WW + s;
-                xf[j] = *reinterpret_cast<const hbf16x8*>(Aw + pw * HALO_PIX + ((kg ^ ((pw >> 1) & 2)) << 3));
+                xf[j] = *reinterpret_cast<const hvec8*>(Aw + pw * HALO_PIX + ((kg ^ ((pw >> 1) & 2)) << 3));
             }
 #pragma unroll
             for (int i = 0; i < TN; ++i)
 #pragma unroll
                 for (int j = 0; j < TM; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], xf[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = E::mfma(wf[i], xf[j], acc[i][j]);
         }
         HPROF(5)  // tap loop (LDS reads + MFMA issue)
         if (cc + 1 < nchunk) {
@@ -290,8 +285,7 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(HaloDev a) {
         v[0] = acc[i][j][0] + bias4[i].x; v[1] = acc[i][j][1] + bias4[i].y; v[2] = acc[i][j][2] + bias4[i].z; v[3] = acc[i][j][3] + bias4[i].w;
         if (a.res_mode != RES_NONE) {
             const uint2 q = rq[j][i];
-            const float rv[4] = {__uint_as_float(q.x << 16), __uint_as_float(q.x & 0xffff0000u),
-                                 __uint_as_float(q.y << 16), __uint_as_float(q.y & 0xffff0000u)};
+            const float rv[4] = {E::lo(q.x), E::hi(q.x), E::lo(q.y), E::hi(q.y)};
             if (a.res_mode == RES_BEFORE_ACT) {
 #pragma unroll
                 for (int k = 0; k < 4; ++k) v[k] = h_act<ACT>(v[k] + rv[k]);
@@ -315,8 +309,8 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(HaloDev a) {
                 float vx[4], vy[4];
                 finish(i, j, vx);
                 finish(i + 1, j, vy);
-                const uint32_t x0 = h_pack2(vx[0], vx[1]), x1 = h_pack2(vx[2], vx[3]);
-                const uint32_t y0 = h_pack2(vy[0], vy[1]), y1 = h_pack2(vy[2], vy[3]);
+                const uint32_t x0 = E::pack2(vx[0], vx[1]), x1 = E::pack2(vx[2], vx[3]);
+                const uint32_t y0 = E::pack2(vy[0], vy[1]), y1 = E::pack2(vy[2], vy[3]);
                 const auto s0 = __builtin_amdgcn_permlane16_swap(x0, y0, false, false);
                 const auto s1 = __builtin_amdgcn_permlane16_swap(x1, y1, false, false);
                 const int c = n0 + (i + (kg & 1)) * 16 + (kg >> 1) * 8;
@@ -340,8 +334,8 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(HaloDev a) {
                     if (st_ok) *reinterpret_cast<float4*>((float*)a.out + ob + i * 16) = make_float4(v[0], v[1], v[2], v[3]);
                 } else {
                     uint2 q;
-                    q.x = h_pack2(v[0], v[1]);
-                    q.y = h_pack2(v[2], v[3]);
+                    q.x = E::pack2(v[0], v[1]);
+                    q.y = E::pack2(v[2], v[3]);
                     if (st_ok) *reinterpret_cast<uint2*>((uint16_t*)a.out + ob + i * 16) = q;
                 }
             }
@@ -428,19 +422,30 @@ static bool plan_halo(int Ho, int Wo, int S, HaloPlan* out) {
     return it->second.first;
 }
 
-template <int BN, int S>
+template <typename E, int BN, int S>
 static hipError_t launch_bn(const HaloDev& d, int act, dim3 grid, size_t lds, hipStream_t st) {
     static bool attr_done = false;
     if (!attr_done) {
-        (void)hipFuncSetAttribute((const void*)conv_halo_kernel<BN, ACT_NONE, S>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute((const void*)conv_halo_kernel<BN, ACT_SILU, S>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute((const void*)conv_halo_kernel<BN, ACT_RELU, S>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)conv_halo_kernel<E, BN, ACT_NONE, S>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)conv_halo_kernel<E, BN, ACT_SILU, S>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)conv_halo_kernel<E, BN, ACT_RELU, S>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_done = true;
     }
-    if (act == ACT_SILU) hipLaunchKernelGGL((conv_halo_kernel<BN, ACT_SILU, S>), grid, dim3(256), lds, st, d);
-    else if (act == ACT_RELU) hipLaunchKernelGGL((conv_halo_kernel<BN, ACT_RELU, S>), grid, dim3(256), lds, st, d);
-    else hipLaunchKernelGGL((conv_halo_kernel<BN, ACT_NONE, S>), grid, dim3(256), lds, st, d);
+    if (act == ACT_SILU) hipLaunchKernelGGL((conv_halo_kernel<E, BN, ACT_SILU, S>), grid, dim3(256), lds, st, d);
+    else if (act == ACT_RELU) hipLaunchKernelGGL((conv_halo_kernel<E, BN, ACT_RELU, S>), grid, dim3(256), lds, st, d);
+    else hipLaunchKernelGGL((conv_halo_kernel<E, BN, ACT_NONE, S>), grid, dim3(256), lds, st, d);
     return hipGetLastError();
+}
+template <typename E>
+static hipError_t launch_e(const HaloDev& d, int act, int stride, int bn, dim3 grid, size_t lds, hipStream_t st) {
+    if (stride == 2) {
+        if (bn == 64) return launch_bn<E, 64, 2>(d, act, grid, lds, st);
+        if (bn == 32) return launch_bn<E, 32, 2>(d, act, grid, lds, st);
+        return launch_bn<E, 16, 2>(d, act, grid, lds, st);
+    }
+    if (bn == 64) return launch_bn<E, 64, 1>(d, act, grid, lds, st);
+    if (bn == 32) return launch_bn<E, 32, 1>(d, act, grid, lds, st);
+    return launch_bn<E, 16, 1>(d, act, grid, lds, st);
 }
 
 static int halo_min_cin() {
@@ -513,14 +518,8 @@ hipError_t launch_conv_halo(const ConvArgs& a, hipStream_t st) {
     d.cbg = halo_cb_group(d.ncb, (size_t)d.cin_pad * 9 * bn * 2);
     dim3 grid(8 * d.tiles8 * d.cbg * ((d.ncb + d.cbg - 1) / d.cbg));
     size_t lds = ((size_t)pl.maxpix * HALO_PIX + (size_t)9 * bn * HALO_WPIX) * 2;
-    if (a.stride == 2) {
-        if (bn == 64) return launch_bn<64, 2>(d, a.act, grid, lds, st);
-        if (bn == 32) return launch_bn<32, 2>(d, a.act, grid, lds, st);
-        return launch_bn<16, 2>(d, a.act, grid, lds, st);
-    }
-    if (bn == 64) return launch_bn<64, 1>(d, a.act, grid, lds, st);
-    if (bn == 32) return launch_bn<32, 1>(d, a.act, grid, lds, st);
-    return launch_bn<16, 1>(d, a.act, grid, lds, st);
+    if (a.prec == PREC_FP16) return launch_e<Fp16>(d, a.act, a.stride, bn, grid, lds, st);
+    return launch_e<Bf16>(d, a.act, a.stride, bn, grid, lds, st);
 }
 
 }  // namespace adas

@@ -13,6 +13,7 @@
 // strip-linear tiling and the 16-byte permlane epilogue are those of conv_halo.hip; weights use the same packing
 // (per-tap channel runs padded to 32), so the choice between the two kernels is a launch-time decision.
 #include "kernels.h"
+#include "elem16.h"
 #include <stdlib.h>
 #include <map>
 #include <mutex>
@@ -20,16 +21,9 @@
 
 namespace adas {
 
-typedef __attribute__((ext_vector_type(8))) __bf16 rbf16x8;
 typedef __attribute__((ext_vector_type(4))) float rf32x4;
 typedef __attribute__((ext_vector_type(4))) uint32_t ru32x4;
-typedef __attribute__((ext_vector_type(2))) float rf32x2;
-typedef __attribute__((ext_vector_type(2))) __bf16 rbf16x2;
 
-__device__ __forceinline__ uint32_t r_pack2(float a, float b) {
-    rbf16x2 r = __builtin_convertvector(rf32x2{a, b}, rbf16x2);
-    return __builtin_bit_cast(uint32_t, r);
-}
 template <int ACT>
 __device__ __forceinline__ float r_act(float v) {
     if (ACT == ACT_SILU) return v * __frcp_rn(1.0f + __expf(-v));
@@ -60,10 +54,11 @@ constexpr int RW_NW = 8;            // waves per workgroup: two per SIMD (one wo
 constexpr int RW_THR = 64 * RW_NW;
 constexpr int RW_NA = RW_ELEMS / RW_THR + 1;
 
-template <int NCH, int ACT, bool HAS_RES, int BN = 64>  // NCH = 32-channel planes (1 | 2); BN = output channels per workgroup (64 | 32,
+template <typename E, int NCH, int ACT, bool HAS_RES, int BN = 64>  // NCH = 32-channel planes (1 | 2); BN = output channels per workgroup (64 | 32,
                                                        // the CONV_HALO packing of the layer: halo_bn(cout)); HAS_RES is a template flag because a runtime branch
                                           // around the residual loads makes hipcc drain vmcnt(0) at the join -- and with it the window prefetch
 __global__ __launch_bounds__(RW_THR, RW_NW / 4) void conv_halo_rw_kernel(RwDev a) {
+    typedef typename E::vec8 rvec8;
     constexpr int TAPS = 9, TM = RW_BM / 16 / RW_NW, TN = BN / 16;
     constexpr int WROWS = TAPS * BN;                  // weight rows of 64 B per plane (576 at BN = 64)
     constexpr int NWL = (NCH * WROWS * 4 + RW_THR - 1) / RW_THR;  // one-time weight loads per thread
@@ -198,19 +193,19 @@ __global__ __launch_bounds__(RW_THR, RW_NW / 4) void conv_halo_rw_kernel(RwDev a
 #pragma unroll
             for (int tap = 0; tap < TAPS; ++tap) {
                 const int r = tap / 3, s = tap - r * 3;
-                rbf16x8 wf[TN], xf[TM];
+                rvec8 wf[TN], xf[TM];
 #pragma unroll
-                for (int i = 0; i < TN; ++i) wf[i] = *reinterpret_cast<const rbf16x8*>(Ww + (pl * WROWS + tap * BN + i * 16) * 32 + wrd);
+                for (int i = 0; i < TN; ++i) wf[i] = *reinterpret_cast<const rvec8*>(Ww + (pl * WROWS + tap * BN + i * 16) * 32 + wrd);
 #pragma unroll
                 for (int j = 0; j < TM; ++j) {
                     const int pw = apix[j] + r * a.WW + s;
-                    xf[j] = *reinterpret_cast<const rbf16x8*>(Win + pl * plane + pw * 32 + ((kg ^ ((pw >> 1) & 2)) << 3));
+                    xf[j] = *reinterpret_cast<const rvec8*>(Win + pl * plane + pw * 32 + ((kg ^ ((pw >> 1) & 2)) << 3));
                 }
 #pragma unroll
                 for (int i = 0; i < TN; ++i)
 #pragma unroll
                     for (int j = 0; j < TM; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], xf[j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = E::mfma(wf[i], xf[j], acc[i][j]);
             }
         }
         uint2 rq[TM][TN];
@@ -231,8 +226,7 @@ __global__ __launch_bounds__(RW_THR, RW_NW / 4) void conv_halo_rw_kernel(RwDev a
             v[0] = acc[i][j][0] + bias4[i].x; v[1] = acc[i][j][1] + bias4[i].y; v[2] = acc[i][j][2] + bias4[i].z; v[3] = acc[i][j][3] + bias4[i].w;
             if (HAS_RES) {
                 const uint2 q = rq[j][i];
-                const float rv[4] = {__uint_as_float(q.x << 16), __uint_as_float(q.x & 0xffff0000u),
-                                     __uint_as_float(q.y << 16), __uint_as_float(q.y & 0xffff0000u)};
+                const float rv[4] = {E::lo(q.x), E::hi(q.x), E::lo(q.y), E::hi(q.y)};
                 if (a.res_mode == RES_BEFORE_ACT) {
 #pragma unroll
                     for (int k = 0; k < 4; ++k) v[k] = r_act<ACT>(v[k] + rv[k]);
@@ -252,8 +246,8 @@ __global__ __launch_bounds__(RW_THR, RW_NW / 4) void conv_halo_rw_kernel(RwDev a
                 float vx[4], vy[4];
                 finish(i, j, vx);
                 finish(i + 1, j, vy);
-                const uint32_t x0 = r_pack2(vx[0], vx[1]), x1 = r_pack2(vx[2], vx[3]);
-                const uint32_t y0 = r_pack2(vy[0], vy[1]), y1 = r_pack2(vy[2], vy[3]);
+                const uint32_t x0 = E::pack2(vx[0], vx[1]), x1 = E::pack2(vx[2], vx[3]);
+                const uint32_t y0 = E::pack2(vy[0], vy[1]), y1 = E::pack2(vy[2], vy[3]);
                 if (wide) {
                     const auto s0 = __builtin_amdgcn_permlane16_swap(x0, y0, false, false);
                     const auto s1 = __builtin_amdgcn_permlane16_swap(x1, y1, false, false);
@@ -374,18 +368,18 @@ bool halo_rw_applicable(int kh, int kw, int stride, int pad, int n, const TView&
     return tiles >= 4 * 256;
 }
 
-template <int NCH, bool HAS_RES, int BN>
+template <typename E, int NCH, bool HAS_RES, int BN>
 static hipError_t rw_launch(const RwDev& d, int act, int grid, size_t lds, hipStream_t st) {
     static bool attr_done = false;
     if (!attr_done) {
-        (void)hipFuncSetAttribute((const void*)conv_halo_rw_kernel<NCH, ACT_NONE, HAS_RES, BN>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute((const void*)conv_halo_rw_kernel<NCH, ACT_SILU, HAS_RES, BN>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute((const void*)conv_halo_rw_kernel<NCH, ACT_RELU, HAS_RES, BN>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)conv_halo_rw_kernel<E, NCH, ACT_NONE, HAS_RES, BN>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)conv_halo_rw_kernel<E, NCH, ACT_SILU, HAS_RES, BN>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)conv_halo_rw_kernel<E, NCH, ACT_RELU, HAS_RES, BN>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_done = true;
     }
-    if (act == ACT_SILU) hipLaunchKernelGGL((conv_halo_rw_kernel<NCH, ACT_SILU, HAS_RES, BN>), dim3(grid), dim3(RW_THR), lds, st, d);
-    else if (act == ACT_RELU) hipLaunchKernelGGL((conv_halo_rw_kernel<NCH, ACT_RELU, HAS_RES, BN>), dim3(grid), dim3(RW_THR), lds, st, d);
-    else hipLaunchKernelGGL((conv_halo_rw_kernel<NCH, ACT_NONE, HAS_RES, BN>), dim3(grid), dim3(RW_THR), lds, st, d);
+    if (act == ACT_SILU) hipLaunchKernelGGL((conv_halo_rw_kernel<E, NCH, ACT_SILU, HAS_RES, BN>), dim3(grid), dim3(RW_THR), lds, st, d);
+    else if (act == ACT_RELU) hipLaunchKernelGGL((conv_halo_rw_kernel<E, NCH, ACT_RELU, HAS_RES, BN>), dim3(grid), dim3(RW_THR), lds, st, d);
+    else hipLaunchKernelGGL((conv_halo_rw_kernel<E, NCH, ACT_NONE, HAS_RES, BN>), dim3(grid), dim3(RW_THR), lds, st, d);
     return hipGetLastError();
 }
 
@@ -412,12 +406,15 @@ hipError_t launch_conv_halo_rw(const ConvArgs& a, hipStream_t st) {
     const size_t lds = ((size_t)nch * 9 * bn * 32 + (size_t)2 * nch * pl.maxpix * 32) * 2;
     const bool res = a.res_mode != RES_NONE;
     if (res && (((a.res.cs | a.res.coff) & 7) != 0)) return hipErrorNotSupported;  // halo_rw_applicable() keeps such layers on conv_halo
-    if (bn == 32) {
-        if (nch == 1) return res ? rw_launch<1, true, 32>(d, a.act, grid, lds, st) : rw_launch<1, false, 32>(d, a.act, grid, lds, st);
-        return res ? rw_launch<2, true, 32>(d, a.act, grid, lds, st) : rw_launch<2, false, 32>(d, a.act, grid, lds, st);
-    }
-    if (nch == 1) return res ? rw_launch<1, true, 64>(d, a.act, grid, lds, st) : rw_launch<1, false, 64>(d, a.act, grid, lds, st);
-    return res ? rw_launch<2, true, 64>(d, a.act, grid, lds, st) : rw_launch<2, false, 64>(d, a.act, grid, lds, st);
+    ADAS_DISPATCH_E16(a.prec == PREC_FP16, E, {
+        if (bn == 32) {
+            if (nch == 1) return res ? rw_launch<E, 1, true, 32>(d, a.act, grid, lds, st) : rw_launch<E, 1, false, 32>(d, a.act, grid, lds, st);
+            return res ? rw_launch<E, 2, true, 32>(d, a.act, grid, lds, st) : rw_launch<E, 2, false, 32>(d, a.act, grid, lds, st);
+        }
+        if (nch == 1) return res ? rw_launch<E, 1, true, 64>(d, a.act, grid, lds, st) : rw_launch<E, 1, false, 64>(d, a.act, grid, lds, st);
+        return res ? rw_launch<E, 2, true, 64>(d, a.act, grid, lds, st) : rw_launch<E, 2, false, 64>(d, a.act, grid, lds, st);
+    });
+    return hipErrorInvalidValue;
 }
 
 }  // namespace adas

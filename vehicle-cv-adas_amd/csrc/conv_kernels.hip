@@ -13,12 +13,14 @@
 // one barrier per step).  Roofline: MFMA-bound for the ResNet stages, HBM/L2-bound for the
 // 16..64-channel YOLOv8n layers (arithmetic intensity < 312 FLOP/B).
 #include "kernels.h"
+#include "elem16.h"
 #include <stdlib.h>
 
 namespace adas {
 
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+// Element types of this generic kernel: `uint16_t` = bf16 bits, `f16s` = IEEE-half bits (elem16.h), `float` = the fp32 parity mode.
 
 struct alignas(16) U4 {
     uint32_t x, y, z, w;
@@ -32,6 +34,13 @@ struct Chunk<uint16_t> {
     __device__ void zero() { v = U4{0, 0, 0, 0}; }
     __device__ void load(const uint16_t* p) { v = *reinterpret_cast<const U4*>(p); }
     __device__ void store(uint16_t* p) const { *reinterpret_cast<U4*>(p) = v; }
+};
+template <>
+struct Chunk<f16s> {
+    U4 v;
+    __device__ void zero() { v = U4{0, 0, 0, 0}; }
+    __device__ void load(const f16s* p) { v = *reinterpret_cast<const U4*>(p); }
+    __device__ void store(f16s* p) const { *reinterpret_cast<U4*>(p) = v; }
 };
 template <>
 struct Chunk<float> {
@@ -48,8 +57,10 @@ struct Chunk<float> {
 };
 
 __device__ __forceinline__ f32x4 mma(const Chunk<uint16_t>& w, const Chunk<uint16_t>& x, f32x4 acc) {
-    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8*>(&w.v),
-                                                   *reinterpret_cast<const bf16x8*>(&x.v), acc, 0, 0, 0);
+    return Bf16::mfma(__builtin_bit_cast(e_u32x4, w.v), __builtin_bit_cast(e_u32x4, x.v), acc);
+}
+__device__ __forceinline__ f32x4 mma(const Chunk<f16s>& w, const Chunk<f16s>& x, f32x4 acc) {
+    return Fp16::mfma(__builtin_bit_cast(e_u32x4, w.v), __builtin_bit_cast(e_u32x4, x.v), acc);
 }
 __device__ __forceinline__ f32x4 mma(const Chunk<float>& w, const Chunk<float>& x, f32x4 acc) {
     const float* a = reinterpret_cast<const float*>(w.v);
@@ -67,8 +78,10 @@ __device__ __forceinline__ uint16_t f2bf(float f) {
 }
 __device__ __forceinline__ float ldf(const float* p) { return *p; }
 __device__ __forceinline__ float ldf(const uint16_t* p) { return bf2f(*p); }
+__device__ __forceinline__ float ldf(const f16s* p) { return Fp16::to_f32(p->v); }
 __device__ __forceinline__ void stf(float* p, float v) { *p = v; }
 __device__ __forceinline__ void stf(uint16_t* p, float v) { *p = f2bf(v); }
+__device__ __forceinline__ void stf(f16s* p, float v) { p->v = Fp16::from_f32(v); }
 
 __device__ __forceinline__ void load4(const float* p, float o[4]) {
     float4 q = *reinterpret_cast<const float4*>(p);
@@ -78,6 +91,14 @@ __device__ __forceinline__ void load4(const uint16_t* p, float o[4]) {
     uint2 q = *reinterpret_cast<const uint2*>(p);
     o[0] = __uint_as_float(q.x << 16); o[1] = __uint_as_float(q.x & 0xffff0000u);
     o[2] = __uint_as_float(q.y << 16); o[3] = __uint_as_float(q.y & 0xffff0000u);
+}
+__device__ __forceinline__ void load4(const f16s* p, float o[4]) {
+    uint2 q = *reinterpret_cast<const uint2*>(p);
+    o[0] = Fp16::lo(q.x); o[1] = Fp16::hi(q.x);
+    o[2] = Fp16::lo(q.y); o[3] = Fp16::hi(q.y);
+}
+__device__ __forceinline__ void store4(f16s* p, const float v[4]) {
+    *reinterpret_cast<uint2*>(p) = make_uint2(Fp16::pack2(v[0], v[1]), Fp16::pack2(v[2], v[3]));
 }
 __device__ __forceinline__ void store4(float* p, const float v[4]) {
     *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
@@ -303,7 +324,8 @@ const char* conv_kernel_name(const ConvArgs& a, int prec, int kernel) {
     } else {
         Tile t = pick_tile(a, prec);
         const bool of32 = a.out.f32 || prec == PREC_FP32;
-        snprintf(buf, sizeof(buf), "conv_igemm_kernel<%s,%s,%d,%d>", prec == PREC_FP32 ? "f32" : "bf16", of32 ? "f32" : "bf16", t.bm, t.bn);
+        const char* en = prec == PREC_FP32 ? "f32" : (prec == PREC_FP16 ? "f16" : "bf16");
+        snprintf(buf, sizeof(buf), "conv_igemm_kernel<%s,%s,%d,%d>", en, of32 ? "f32" : en, t.bm, t.bn);
     }
     return buf;
 }
@@ -368,7 +390,7 @@ ConvPlan plan_conv(int prec, int kh, int kw, int stride, int pad, int max_n, int
     } else if (pw_enabled() && pw_applicable(prec, kh, kw, stride, pad, res_mode, in, out)) {
         p.kernel = CONV_PW;
         p.cin_pad = in.c;
-    } else if (prec == PREC_BF16 && halo_enabled() && halo_applicable(kh, kw, stride, pad, in, out)) {
+    } else if (prec_is16(prec) && halo_enabled() && halo_applicable(kh, kw, stride, pad, in, out)) {
         p.kernel = CONV_HALO;
         p.cin_pad = (in.c + 31) / 32 * 32;
     } else {
@@ -403,6 +425,7 @@ hipError_t launch_conv(const ConvArgs& a, int prec, hipStream_t st) {
     Tile t = pick_tile(a, prec);
     const bool out_f32 = a.out.f32 || prec == PREC_FP32;
     if (prec == PREC_FP32) return launch_typed<float, float>(d, t, st);
+    if (prec == PREC_FP16) return out_f32 ? launch_typed<f16s, float>(d, t, st) : launch_typed<f16s, f16s>(d, t, st);
     if (out_f32) return launch_typed<uint16_t, float>(d, t, st);
     return launch_typed<uint16_t, uint16_t>(d, t, st);
 }
@@ -421,8 +444,9 @@ __global__ void pack_weights_kernel(const float* __restrict__ src, T* __restrict
     }
 }
 
-// fp32 [cout][9][cin] -> bf16 [cout_pad/BN][cin_pad/32][9][BN][32], zero padded (halo kernels, BN = halo_bn(cout))
-__global__ void pack_weights_halo_kernel(const float* __restrict__ src, uint16_t* __restrict__ dst, int cout, int cin, int cin_pad, int bn,
+// fp32 [cout][9][cin] -> 16-bit [cout_pad/BN][cin_pad/32][9][BN][32], zero padded (halo kernels, BN = halo_bn(cout))
+template <typename T>
+__global__ void pack_weights_halo_kernel(const float* __restrict__ src, T* __restrict__ dst, int cout, int cin, int cin_pad, int bn,
                                          size_t total) {
     const int nchunk = cin_pad >> 5;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
@@ -438,10 +462,13 @@ __global__ void pack_weights_halo_kernel(const float* __restrict__ src, uint16_t
         stf(dst + i, v);
     }
 }
-hipError_t launch_pack_weights_halo(const float* src, void* dst, int cout, int cout_pad, int cin, int cin_pad, hipStream_t st) {
+hipError_t launch_pack_weights_halo(const float* src, void* dst, int cout, int cout_pad, int cin, int cin_pad, int prec, hipStream_t st) {
     const size_t total = (size_t)cout_pad * 9 * cin_pad;
     const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
-    hipLaunchKernelGGL(pack_weights_halo_kernel, dim3(blocks), dim3(256), 0, st, src, (uint16_t*)dst, cout, cin, cin_pad, halo_bn(cout), total);
+    if (prec == PREC_FP16)
+        hipLaunchKernelGGL(pack_weights_halo_kernel<f16s>, dim3(blocks), dim3(256), 0, st, src, (f16s*)dst, cout, cin, cin_pad, halo_bn(cout), total);
+    else
+        hipLaunchKernelGGL(pack_weights_halo_kernel<uint16_t>, dim3(blocks), dim3(256), 0, st, src, (uint16_t*)dst, cout, cin, cin_pad, halo_bn(cout), total);
     return hipGetLastError();
 }
 
@@ -451,6 +478,8 @@ hipError_t launch_pack_weights(const float* src, void* dst, int cout, int cout_p
     int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
     if (prec == PREC_FP32)
         hipLaunchKernelGGL(pack_weights_kernel<float>, dim3(blocks), dim3(256), 0, st, src, (float*)dst, cout, taps, cin, cin_pad, kpad, total);
+    else if (prec == PREC_FP16)
+        hipLaunchKernelGGL(pack_weights_kernel<f16s>, dim3(blocks), dim3(256), 0, st, src, (f16s*)dst, cout, taps, cin, cin_pad, kpad, total);
     else
         hipLaunchKernelGGL(pack_weights_kernel<uint16_t>, dim3(blocks), dim3(256), 0, st, src, (uint16_t*)dst, cout, taps, cin, cin_pad, kpad, total);
     return hipGetLastError();

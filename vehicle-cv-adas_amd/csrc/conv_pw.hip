@@ -9,19 +9,12 @@
 //   * loop over feature tiles: KS MFMAs each, fused bias + SiLU/ReLU, 8 B (bf16) / 16 B (fp32) store per lane.
 // Algorithmic bytes per launch: pixels * (Cin + Cout) * 2 B (+ Cout*Cin*2 B of weights, L2-resident).
 #include "kernels.h"
+#include "elem16.h"
 
 namespace adas {
 
-typedef __attribute__((ext_vector_type(8))) __bf16 pbf16x8;
 typedef __attribute__((ext_vector_type(4))) float pf32x4;
 typedef __attribute__((ext_vector_type(4))) uint32_t pu32x4;
-typedef __attribute__((ext_vector_type(2))) float pf32x2;
-typedef __attribute__((ext_vector_type(2))) __bf16 pbf16x2;
-
-__device__ __forceinline__ uint32_t pw_pack2(float a, float b) {
-    pbf16x2 r = __builtin_convertvector(pf32x2{a, b}, pbf16x2);
-    return __builtin_bit_cast(uint32_t, r);
-}
 
 struct PwDev {
     const uint16_t* in;
@@ -38,7 +31,7 @@ struct PwDev {
     int mtiles;
 };
 
-template <int KS, bool TAIL>
+template <typename E, int KS, bool TAIL>
 __global__ __launch_bounds__(512) void conv_pw_kernel(PwDev a) {
     extern __shared__ __attribute__((aligned(16))) uint16_t wl[];  // [NTL][KS][64][8]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -83,7 +76,7 @@ __global__ __launch_bounds__(512) void conv_pw_kernel(PwDev a) {
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
                 const pu32x4 wf = *reinterpret_cast<const pu32x4*>(wl + ((size_t)(nt * KS + ks) * 64 + lane) * 8);
-                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(pbf16x8, wf), __builtin_bit_cast(pbf16x8, xb[ks]), acc, 0, 0, 0);
+                acc = E::mfma(wf, xb[ks], acc);
             }
             const int c = nt * 16 + kg * 4;
             if (!ok || nt0 * 16 + c >= a.cout) continue;
@@ -100,8 +93,8 @@ __global__ __launch_bounds__(512) void conv_pw_kernel(PwDev a) {
                 *reinterpret_cast<float4*>((float*)a.out + obase + nt * 16) = make_float4(v[0], v[1], v[2], v[3]);
             } else {
                 uint2 q;
-                q.x = pw_pack2(v[0], v[1]);
-                q.y = pw_pack2(v[2], v[3]);
+                q.x = E::pack2(v[0], v[1]);
+                q.y = E::pack2(v[2], v[3]);
                 *reinterpret_cast<uint2*>((uint16_t*)a.out + obase + nt * 16) = q;
             }
         }
@@ -120,7 +113,7 @@ static int pw_tiles_per_wg(int nt, int ks) {
 }
 
 bool pw_applicable(int prec, int kh, int kw, int stride, int pad, int res_mode, const TView& in, const TView& out) {
-    if (prec != PREC_BF16 || in.f32) return false;
+    if (!prec_is16(prec) || in.f32) return false;
     if (kh != 1 || kw != 1 || pad != 0 || (stride != 1 && stride != 2) || res_mode != RES_NONE) return false;
     if (in.h == 1 && in.w == 1) return false;  // Linear layers have their own kernel
     if ((in.c & 7) || (in.cs & 7) || (in.coff & 7) || (out.c & 3) || (out.cs & 3) || (out.coff & 3)) return false;
@@ -130,17 +123,31 @@ bool pw_applicable(int prec, int kh, int kw, int stride, int pad, int res_mode, 
     return pw_tiles_per_wg(nt, ks) > 0;
 }
 
-template <int KS>
+template <typename E, int KS>
 static hipError_t pw_launch(const PwDev& d, bool tail, dim3 grid, size_t lds, hipStream_t st) {
     static bool attr_done = false;
     if (!attr_done) {
-        (void)hipFuncSetAttribute((const void*)conv_pw_kernel<KS, false>, hipFuncAttributeMaxDynamicSharedMemorySize, PW_MAX_LDS);
-        (void)hipFuncSetAttribute((const void*)conv_pw_kernel<KS, true>, hipFuncAttributeMaxDynamicSharedMemorySize, PW_MAX_LDS);
+        (void)hipFuncSetAttribute((const void*)conv_pw_kernel<E, KS, false>, hipFuncAttributeMaxDynamicSharedMemorySize, PW_MAX_LDS);
+        (void)hipFuncSetAttribute((const void*)conv_pw_kernel<E, KS, true>, hipFuncAttributeMaxDynamicSharedMemorySize, PW_MAX_LDS);
         attr_done = true;
     }
-    if (tail) hipLaunchKernelGGL((conv_pw_kernel<KS, true>), grid, dim3(512), lds, st, d);
-    else hipLaunchKernelGGL((conv_pw_kernel<KS, false>), grid, dim3(512), lds, st, d);
+    if (tail) hipLaunchKernelGGL((conv_pw_kernel<E, KS, true>), grid, dim3(512), lds, st, d);
+    else hipLaunchKernelGGL((conv_pw_kernel<E, KS, false>), grid, dim3(512), lds, st, d);
     return hipGetLastError();
+}
+template <typename E>
+static hipError_t pw_launch_ks(const PwDev& d, int ks, bool tail, dim3 grid, size_t lds, hipStream_t st) {
+    switch (ks) {
+        case 1: return pw_launch<E, 1>(d, tail, grid, lds, st);
+        case 2: return pw_launch<E, 2>(d, tail, grid, lds, st);
+        case 3: return pw_launch<E, 3>(d, tail, grid, lds, st);
+        case 4: return pw_launch<E, 4>(d, tail, grid, lds, st);
+        case 6: return pw_launch<E, 6>(d, tail, grid, lds, st);
+        case 8: return pw_launch<E, 8>(d, tail, grid, lds, st);
+        case 12: return pw_launch<E, 12>(d, tail, grid, lds, st);
+        case 16: return pw_launch<E, 16>(d, tail, grid, lds, st);
+    }
+    return hipErrorInvalidValue;
 }
 
 hipError_t launch_conv_pw(const ConvArgs& a, hipStream_t st) {
@@ -167,17 +174,8 @@ hipError_t launch_conv_pw(const ConvArgs& a, hipStream_t st) {
     if (gx > need) gx = need;
     const dim3 grid(gx, nsplit);
     const bool tail = (a.in.c & 31) != 0;
-    switch (ks) {
-        case 1: return pw_launch<1>(d, tail, grid, lds, st);
-        case 2: return pw_launch<2>(d, tail, grid, lds, st);
-        case 3: return pw_launch<3>(d, tail, grid, lds, st);
-        case 4: return pw_launch<4>(d, tail, grid, lds, st);
-        case 6: return pw_launch<6>(d, tail, grid, lds, st);
-        case 8: return pw_launch<8>(d, tail, grid, lds, st);
-        case 12: return pw_launch<12>(d, tail, grid, lds, st);
-        case 16: return pw_launch<16>(d, tail, grid, lds, st);
-    }
-    return hipErrorInvalidValue;
+    if (a.prec == PREC_FP16) return pw_launch_ks<Fp16>(d, ks, tail, grid, lds, st);
+    return pw_launch_ks<Bf16>(d, ks, tail, grid, lds, st);
 }
 
 }  // namespace adas

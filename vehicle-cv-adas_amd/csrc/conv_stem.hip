@@ -14,31 +14,20 @@
 // Roofline: UFLDv2 stem + pool per frame: 6.1 MB in + 4.1 MB out (HBM) vs 3.67 GFLOP padded MFMA work ->
 // MFMA-bound; YOLO stems are HBM-bound (4.9 MB in, 3.3 MB out, 0.3 GFLOP).
 #include "kernels.h"
+#include "elem16.h"
 #include <string.h>
 
 namespace adas {
 
-typedef __attribute__((ext_vector_type(8))) __bf16 sbf16x8;
 typedef __attribute__((ext_vector_type(4))) float sf32x4;
 typedef __attribute__((ext_vector_type(4))) uint32_t su32x4;
 typedef __attribute__((ext_vector_type(2))) uint32_t su32x2;
-typedef __attribute__((ext_vector_type(2))) float sf32x2;
-typedef __attribute__((ext_vector_type(2))) __bf16 sbf16x2;
 
-__device__ __forceinline__ uint32_t s_pack2(float a, float b) {
-    sbf16x2 r = __builtin_convertvector(sf32x2{a, b}, sbf16x2);
-    return __builtin_bit_cast(uint32_t, r);
-}
 template <int ACT>
 __device__ __forceinline__ float s_act(float v) {
     if (ACT == ACT_SILU) return v * __frcp_rn(1.0f + __expf(-v));
     if (ACT == ACT_RELU) return fmaxf(v, 0.0f);
     return v;
-}
-__device__ __forceinline__ float s_lo(uint32_t u) { return __uint_as_float(u << 16); }
-__device__ __forceinline__ float s_hi(uint32_t u) { return __uint_as_float(u & 0xffff0000u); }
-__device__ __forceinline__ uint32_t s_max2(uint32_t a, uint32_t b) {  // per-half bf16 max (exact: bf16 <-> f32 is lossless)
-    return s_pack2(fmaxf(s_lo(a), s_lo(b)), fmaxf(s_hi(a), s_hi(b)));
 }
 
 struct StemDev {
@@ -64,8 +53,9 @@ constexpr int STEM_WW = 72;  // window row pitch in pixels (even: 16 B aligned f
 // the second conv's output extent and `out` its view.
 // PACKED: the input is the (c0, c1, c2, 0) bf16 NHWC tensor adas_preprocess_*_packed writes (8 B per pixel, one load per window
 // pixel) instead of the fp32 NCHW seam tensor (three loads + a conversion); same values either way.
-template <int KH, int NT, int ACT, bool POOL, bool CONV2 = false, bool PACKED = false>
+template <typename E, int KH, int NT, int ACT, bool POOL, bool CONV2 = false, bool PACKED = false>
 __global__ __launch_bounds__(256, 2) void conv_stem_kernel(StemDev a) {
+    typedef typename E::vec8 svec8;
     constexpr bool TILE2 = POOL || CONV2;
     constexpr int CTH = CONV2 ? 17 : (POOL ? 9 : 8), CTW = TILE2 ? 33 : 32;  // conv tile (POOL: 4x16 pooled + halo)
     constexpr int NPIX = CTH * CTW;
@@ -158,8 +148,8 @@ __global__ __launch_bounds__(256, 2) void conv_stem_kernel(StemDev a) {
                     v.x = px[i][0];
                     v.y = px[i][1];
                 } else {
-                    v.x = s_pack2(__uint_as_float(px[i][0]), __uint_as_float(px[i][1]));
-                    v.y = s_pack2(__uint_as_float(px[i][2]), 0.f);
+                    v.x = E::pack2(__uint_as_float(px[i][0]), __uint_as_float(px[i][1]));
+                    v.y = E::pack2(__uint_as_float(px[i][2]), 0.f);
                 }
                 *reinterpret_cast<su32x2*>(win + q * 4) = v;
             }
@@ -176,15 +166,15 @@ __global__ __launch_bounds__(256, 2) void conv_stem_kernel(StemDev a) {
             for (int i = 0; i < NT; ++i) acc[j][i] = sf32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int r = 0; r < KH; ++r) {
-            sbf16x8 wf[NT], xf[MT];
+            svec8 wf[NT], xf[MT];
 #pragma unroll
-            for (int i = 0; i < NT; ++i) wf[i] = *reinterpret_cast<const sbf16x8*>(wl + ((i * KH + r) * 64 + lane) * 8);
+            for (int i = 0; i < NT; ++i) wf[i] = *reinterpret_cast<const svec8*>(wl + ((i * KH + r) * 64 + lane) * 8);
 #pragma unroll
-            for (int j = 0; j < MT; ++j) xf[j] = *reinterpret_cast<const sbf16x8*>(win + boff[j] + r * WW * 4);
+            for (int j = 0; j < MT; ++j) xf[j] = *reinterpret_cast<const svec8*>(win + boff[j] + r * WW * 4);
 #pragma unroll
             for (int j = 0; j < MT; ++j)
 #pragma unroll
-                for (int i = 0; i < NT; ++i) acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], xf[j], acc[j][i], 0, 0, 0);
+                for (int i = 0; i < NT; ++i) acc[j][i] = E::mfma(wf[i], xf[j], acc[j][i]);
         }
 
         // ---- epilogue: lane holds channels i*16 + kg*4 .. +3 of conv pixel (pcy, pcx)
@@ -210,8 +200,8 @@ __global__ __launch_bounds__(256, 2) void conv_stem_kernel(StemDev a) {
                 for (int i = 0; i < NT; ++i) {
                     if (i * 16 + kg * 4 >= a.cout) continue;
                     su32x2 q;
-                    q.x = s_pack2(s_act<ACT>(acc[j][i][0] + bias4[i].x), s_act<ACT>(acc[j][i][1] + bias4[i].y));
-                    q.y = s_pack2(s_act<ACT>(acc[j][i][2] + bias4[i].z), s_act<ACT>(acc[j][i][3] + bias4[i].w));
+                    q.x = E::pack2(s_act<ACT>(acc[j][i][0] + bias4[i].x), s_act<ACT>(acc[j][i][1] + bias4[i].y));
+                    q.y = E::pack2(s_act<ACT>(acc[j][i][2] + bias4[i].z), s_act<ACT>(acc[j][i][3] + bias4[i].w));
                     *reinterpret_cast<su32x2*>(op + i * 16) = q;
                 }
             }
@@ -226,9 +216,9 @@ __global__ __launch_bounds__(256, 2) void conv_stem_kernel(StemDev a) {
 #pragma unroll
                 for (int i = 0; i < NT; ++i) {
                     su32x2 q;
-                    q.x = s_pack2(s_act<ACT>(acc[j][i][0] + bias4[i].x), s_act<ACT>(acc[j][i][1] + bias4[i].y));
-                    q.y = s_pack2(s_act<ACT>(acc[j][i][2] + bias4[i].z), s_act<ACT>(acc[j][i][3] + bias4[i].w));
-                    if (!valid) q.x = q.y = CONV2 ? 0u : 0xff80ff80u;  // conv zero padding | pool padding
+                    q.x = E::pack2(s_act<ACT>(acc[j][i][0] + bias4[i].x), s_act<ACT>(acc[j][i][1] + bias4[i].y));
+                    q.y = E::pack2(s_act<ACT>(acc[j][i][2] + bias4[i].z), s_act<ACT>(acc[j][i][3] + bias4[i].w));
+                    if (!valid) q.x = q.y = CONV2 ? 0u : E::kNegInf2;  // conv zero padding | pool padding
                     *reinterpret_cast<su32x2*>(ctile + p * CP + i * 16 + kg * 4) = q;
                 }
             }
@@ -249,16 +239,16 @@ __global__ __launch_bounds__(256, 2) void conv_stem_kernel(StemDev a) {
                 for (int s2 = 0; s2 < 5; ++s2) {
                     const int t = 2 * s2 + (kg >> 1) < 9 ? 2 * s2 + (kg >> 1) : 8;
                     const int kh2 = t / 3, kw2 = t - kh2 * 3;
-                    sbf16x8 wf2[2], xf2[MT2];
+                    svec8 wf2[2], xf2[MT2];
 #pragma unroll
-                    for (int n = 0; n < 2; ++n) wf2[n] = *reinterpret_cast<const sbf16x8*>(w2l + ((n * 5 + s2) * 64 + lane) * 8);
-#pragma unroll
-                    for (int j = 0; j < MT2; ++j)
-                        xf2[j] = *reinterpret_cast<const sbf16x8*>(ctile + ((2 * py2[j] + kh2) * CTW + 2 * px2[j] + kw2) * CP + (kg & 1) * 8);
+                    for (int n = 0; n < 2; ++n) wf2[n] = *reinterpret_cast<const svec8*>(w2l + ((n * 5 + s2) * 64 + lane) * 8);
 #pragma unroll
                     for (int j = 0; j < MT2; ++j)
+                        xf2[j] = *reinterpret_cast<const svec8*>(ctile + ((2 * py2[j] + kh2) * CTW + 2 * px2[j] + kw2) * CP + (kg & 1) * 8);
 #pragma unroll
-                        for (int n = 0; n < 2; ++n) acc2[j][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf2[n], xf2[j], acc2[j][n], 0, 0, 0);
+                    for (int j = 0; j < MT2; ++j)
+#pragma unroll
+                        for (int n = 0; n < 2; ++n) acc2[j][n] = E::mfma(wf2[n], xf2[j], acc2[j][n]);
                 }
                 float4 b2[2];
 #pragma unroll
@@ -271,8 +261,8 @@ __global__ __launch_bounds__(256, 2) void conv_stem_kernel(StemDev a) {
 #pragma unroll
                     for (int n = 0; n < 2; ++n) {
                         su32x2 q;
-                        q.x = s_pack2(s_act<ACT>(acc2[j][n][0] + b2[n].x), s_act<ACT>(acc2[j][n][1] + b2[n].y));
-                        q.y = s_pack2(s_act<ACT>(acc2[j][n][2] + b2[n].z), s_act<ACT>(acc2[j][n][3] + b2[n].w));
+                        q.x = E::pack2(s_act<ACT>(acc2[j][n][0] + b2[n].x), s_act<ACT>(acc2[j][n][1] + b2[n].y));
+                        q.y = E::pack2(s_act<ACT>(acc2[j][n][2] + b2[n].z), s_act<ACT>(acc2[j][n][3] + b2[n].w));
                         *reinterpret_cast<su32x2*>(op + n * 16) = q;
                     }
                 }
@@ -284,7 +274,7 @@ __global__ __launch_bounds__(256, 2) void conv_stem_kernel(StemDev a) {
                 const int py = pp >> 4, pxx = pp & 15;
                 const int gpy = ty * 4 + py, gpx = tx * 16 + pxx;
                 if (gpy >= a.Hp || gpx >= a.Wp || cg * 8 >= a.cout) continue;
-                su32x2 m0{0xff80ff80u, 0xff80ff80u}, m1 = m0;
+                su32x2 m0{E::kNegInf2, E::kNegInf2}, m1 = m0;
 #pragma unroll
                 for (int dy = 0; dy < 3; ++dy)
 #pragma unroll
@@ -292,8 +282,8 @@ __global__ __launch_bounds__(256, 2) void conv_stem_kernel(StemDev a) {
                         const uint16_t* cp = ctile + ((2 * py + dy) * CTW + 2 * pxx + dx) * CP + cg * 8;
                         const su32x2 v0 = *reinterpret_cast<const su32x2*>(cp);
                         const su32x2 v1 = *reinterpret_cast<const su32x2*>(cp + 4);
-                        m0.x = s_max2(m0.x, v0.x); m0.y = s_max2(m0.y, v0.y);
-                        m1.x = s_max2(m1.x, v1.x); m1.y = s_max2(m1.y, v1.y);
+                        m0.x = E::max2(m0.x, v0.x); m0.y = E::max2(m0.y, v0.y);
+                        m1.x = E::max2(m1.x, v1.x); m1.y = E::max2(m1.y, v1.y);
                     }
                 uint16_t* op = a.out + ((size_t)(img * a.Hp + gpy) * a.Wp + gpx) * a.out_cs + a.out_coff + cg * 8;
                 *reinterpret_cast<su32x4*>(op) = su32x4{m0.x, m0.y, m1.x, m1.y};
@@ -309,7 +299,7 @@ __global__ __launch_bounds__(256, 2) void conv_stem_kernel(StemDev a) {
 // -------------------------------------------------------------------------------------
 bool stem_applicable(int prec, int in_c_true, int kh, int kw, int stride, int pad, int act, int res_mode, const TView& out, bool pool,
                      const TView& pool_out) {
-    if (prec != PREC_BF16 || in_c_true > 3 || stride != 2 || res_mode != RES_NONE) return false;
+    if (!prec_is16(prec) || in_c_true > 3 || stride != 2 || res_mode != RES_NONE) return false;
     if (!(kh == 3 || kh == 6 || kh == 7) || kw != kh) return false;  // kw <= 8 pixel slots per K step
     if (pad > kh / 2) return false;
     if (out.f32 || !(out.c == 16 || out.c == 32 || out.c == 64)) return false;
@@ -323,13 +313,8 @@ bool stem_applicable(int prec, int in_c_true, int kh, int kw, int stride, int pa
 size_t stem_weight_bytes(int kh, int cout) { return (size_t)((cout + 15) / 16) * kh * 64 * 8 * 2; }
 
 // host-side packing: w = [cout][kh][kw][cs] fp32 (OHWI, channel pitch cs) -> fragment order bf16 bits
-static uint16_t h_f2bf(float f) {
-    uint32_t u;
-    memcpy(&u, &f, 4);
-    u += 0x7fffu + ((u >> 16) & 1u);
-    return (uint16_t)(u >> 16);
-}
-void stem_pack_weights(const float* w, int cout, int kh, int kw, int cs, int c_true, uint16_t* dst) {
+static uint16_t h_f2e(float f, int prec) { return prec == PREC_FP16 ? Fp16::host_from_f32(f) : Bf16::host_from_f32(f); }
+void stem_pack_weights(const float* w, int cout, int kh, int kw, int cs, int c_true, uint16_t* dst, int prec) {
     const int NT = (cout + 15) / 16;
     for (int nt = 0; nt < NT; ++nt)
         for (int r = 0; r < kh; ++r)
@@ -339,14 +324,14 @@ void stem_pack_weights(const float* w, int cout, int kh, int kw, int cs, int c_t
                     const int s = 2 * kg + e / 4, ch = e & 3;
                     float v = 0.f;
                     if (co < cout && s < kw && ch < c_true) v = w[(((size_t)co * kh + r) * kw + s) * cs + ch];
-                    dst[((size_t)(nt * kh + r) * 64 + lane) * 8 + e] = h_f2bf(v);
+                    dst[((size_t)(nt * kh + r) * 64 + lane) * 8 + e] = h_f2e(v, prec);
                 }
 }
 
 // second conv of the fused YOLO stem: w = [32][3][3][16] fp32 (OHWI) -> [2][5][64 lanes][8] bf16; lane (cout row, k group),
 // K index kk = 8*kgroup + e of step s: tap 2s + (kk >> 4), channel kk & 15; the tenth tap slot is zero
 size_t stem2_weight_bytes() { return (size_t)2 * 5 * 64 * 8 * 2; }
-void stem2_pack_weights(const float* w, uint16_t* dst) {
+void stem2_pack_weights(const float* w, uint16_t* dst, int prec) {
     for (int n = 0; n < 2; ++n)
         for (int s = 0; s < 5; ++s)
             for (int lane = 0; lane < 64; ++lane)
@@ -354,18 +339,18 @@ void stem2_pack_weights(const float* w, uint16_t* dst) {
                     const int co = n * 16 + (lane & 15), kk = (lane >> 4) * 8 + e;
                     const int tap = 2 * s + (kk >> 4), ch = kk & 15;
                     const float v = tap < 9 ? w[((size_t)co * 9 + tap) * 16 + ch] : 0.f;
-                    dst[((size_t)(n * 5 + s) * 64 + lane) * 8 + e] = h_f2bf(v);
+                    dst[((size_t)(n * 5 + s) * 64 + lane) * 8 + e] = h_f2e(v, prec);
                 }
 }
 bool stem2_applicable(int prec, int kh, int pad, int act, const TView& stem_out, int kh2, int kw2, int stride2, int pad2, int act2, int res_mode2,
                       const TView& out2) {
-    if (prec != PREC_BF16 || !(kh == 3 || kh == 6) || act != ACT_SILU || act2 != ACT_SILU || res_mode2 != RES_NONE) return false;
+    if (!prec_is16(prec) || !(kh == 3 || kh == 6) || act != ACT_SILU || act2 != ACT_SILU || res_mode2 != RES_NONE) return false;
     if (stem_out.c != 16 || stem_out.f32 || out2.c != 32 || out2.f32 || (out2.cs & 7) || (out2.coff & 7)) return false;
     if (kh2 != 3 || kw2 != 3 || stride2 != 2 || pad2 != 1 || pad > kh / 2) return false;
     return out2.h == (stem_out.h + 2 - 3) / 2 + 1 && out2.w == (stem_out.w + 2 - 3) / 2 + 1;
 }
 hipError_t launch_conv_stem2(const float* nchw, int n, int c_true, int H, int W, int kh, int pad, const void* wfrag, const float* bias,
-                             const TView& stem_out, const void* wfrag2, const float* bias2, const TView& out2, bool packed_in, hipStream_t st) {
+                             const TView& stem_out, const void* wfrag2, const float* bias2, const TView& out2, bool packed_in, int prec, hipStream_t st) {
     StemDev d;
     d.in = nchw; d.wfrag = (const uint16_t*)wfrag; d.bias = bias;
     d.out = (uint16_t*)out2.p; d.out_cs = out2.cs; d.out_coff = out2.coff; d.cout = stem_out.c;
@@ -377,29 +362,43 @@ hipError_t launch_conv_stem2(const float* nchw, int n, int c_true, int H, int W,
     d.wfrag2 = (const uint16_t*)wfrag2; d.bias2 = bias2;
     if ((size_t)c_true * H * W * 4 >= (1ull << 31)) return hipErrorInvalidValue;
     const int grid = d.ntiles < 1024 ? d.ntiles : 1024;
-    if (kh == 3 && packed_in) hipLaunchKernelGGL((conv_stem_kernel<3, 1, ACT_SILU, false, true, true>), dim3(grid), dim3(256), 0, st, d);
-    else if (kh == 3) hipLaunchKernelGGL((conv_stem_kernel<3, 1, ACT_SILU, false, true, false>), dim3(grid), dim3(256), 0, st, d);
-    else if (kh == 6 && packed_in) hipLaunchKernelGGL((conv_stem_kernel<6, 1, ACT_SILU, false, true, true>), dim3(grid), dim3(256), 0, st, d);
-    else if (kh == 6) hipLaunchKernelGGL((conv_stem_kernel<6, 1, ACT_SILU, false, true, false>), dim3(grid), dim3(256), 0, st, d);
-    else return hipErrorInvalidValue;
+    if (kh != 3 && kh != 6) return hipErrorInvalidValue;
+    ADAS_DISPATCH_E16(prec == PREC_FP16, E, {
+        if (kh == 3 && packed_in) hipLaunchKernelGGL((conv_stem_kernel<E, 3, 1, ACT_SILU, false, true, true>), dim3(grid), dim3(256), 0, st, d);
+        else if (kh == 3) hipLaunchKernelGGL((conv_stem_kernel<E, 3, 1, ACT_SILU, false, true, false>), dim3(grid), dim3(256), 0, st, d);
+        else if (packed_in) hipLaunchKernelGGL((conv_stem_kernel<E, 6, 1, ACT_SILU, false, true, true>), dim3(grid), dim3(256), 0, st, d);
+        else hipLaunchKernelGGL((conv_stem_kernel<E, 6, 1, ACT_SILU, false, true, false>), dim3(grid), dim3(256), 0, st, d);
+    });
     return hipGetLastError();
 }
 
-template <int KH, int NT, bool POOL>
+template <typename E, int KH, int NT, bool POOL>
 static hipError_t stem_launch_act(const StemDev& d, int act, bool packed_in, hipStream_t st) {
     const int grid = d.ntiles < 1024 ? d.ntiles : 1024;
     if (packed_in) {
-        if (act == ACT_RELU) hipLaunchKernelGGL((conv_stem_kernel<KH, NT, ACT_RELU, POOL, false, true>), dim3(grid), dim3(256), 0, st, d);
-        else hipLaunchKernelGGL((conv_stem_kernel<KH, NT, ACT_SILU, POOL, false, true>), dim3(grid), dim3(256), 0, st, d);
+        if (act == ACT_RELU) hipLaunchKernelGGL((conv_stem_kernel<E, KH, NT, ACT_RELU, POOL, false, true>), dim3(grid), dim3(256), 0, st, d);
+        else hipLaunchKernelGGL((conv_stem_kernel<E, KH, NT, ACT_SILU, POOL, false, true>), dim3(grid), dim3(256), 0, st, d);
     } else {
-        if (act == ACT_RELU) hipLaunchKernelGGL((conv_stem_kernel<KH, NT, ACT_RELU, POOL, false, false>), dim3(grid), dim3(256), 0, st, d);
-        else hipLaunchKernelGGL((conv_stem_kernel<KH, NT, ACT_SILU, POOL, false, false>), dim3(grid), dim3(256), 0, st, d);
+        if (act == ACT_RELU) hipLaunchKernelGGL((conv_stem_kernel<E, KH, NT, ACT_RELU, POOL, false, false>), dim3(grid), dim3(256), 0, st, d);
+        else hipLaunchKernelGGL((conv_stem_kernel<E, KH, NT, ACT_SILU, POOL, false, false>), dim3(grid), dim3(256), 0, st, d);
     }
     return hipGetLastError();
 }
 
+template <typename E>
+static hipError_t stem_launch_shape(const StemDev& d, int kh, int nt, bool pool, int act, bool packed_in, hipStream_t st) {
+    if (pool) return stem_launch_act<E, 7, 4, true>(d, act, packed_in, st);
+#define STEM_CASE(KH_, NT_) \
+    if (kh == KH_ && nt == NT_) return stem_launch_act<E, KH_, NT_, false>(d, act, packed_in, st);
+    STEM_CASE(3, 1) STEM_CASE(3, 2) STEM_CASE(3, 4)
+    STEM_CASE(6, 1) STEM_CASE(6, 2) STEM_CASE(6, 4)
+    STEM_CASE(7, 4)
+#undef STEM_CASE
+    return hipErrorInvalidValue;
+}
+
 hipError_t launch_conv_stem(const float* nchw, int n, int c_true, int H, int W, int kh, int pad, int act, const void* wfrag,
-                            const float* bias, const TView& conv_out, bool pool, const TView& pool_out, bool packed_in, hipStream_t st) {
+                            const float* bias, const TView& conv_out, bool pool, const TView& pool_out, bool packed_in, int prec, hipStream_t st) {
     StemDev d;
     const TView& o = pool ? pool_out : conv_out;
     d.in = nchw; d.wfrag = (const uint16_t*)wfrag; d.bias = bias;
@@ -416,14 +415,8 @@ hipError_t launch_conv_stem(const float* nchw, int n, int c_true, int H, int W, 
     d.ntiles = n * d.tiles_x * d.tiles_y;
     if ((size_t)c_true * H * W * 4 >= (1ull << 31)) return hipErrorInvalidValue;
     const int nt = (conv_out.c + 15) / 16;
-    if (pool) return stem_launch_act<7, 4, true>(d, act, packed_in, st);
-#define STEM_CASE(KH_, NT_) \
-    if (kh == KH_ && nt == NT_) return stem_launch_act<KH_, NT_, false>(d, act, packed_in, st);
-    STEM_CASE(3, 1) STEM_CASE(3, 2) STEM_CASE(3, 4)
-    STEM_CASE(6, 1) STEM_CASE(6, 2) STEM_CASE(6, 4)
-    STEM_CASE(7, 4)
-#undef STEM_CASE
-    return hipErrorInvalidValue;
+    if (prec == PREC_FP16) return stem_launch_shape<Fp16>(d, kh, nt, pool, act, packed_in, st);
+    return stem_launch_shape<Bf16>(d, kh, nt, pool, act, packed_in, st);
 }
 
 }  // namespace adas

@@ -44,7 +44,8 @@ extern "C" {
 
 int adas_engine_create(const char* model_path, int precision, int max_batch, adas_engine** out) {
     ADAS_REQUIRE(model_path && out && max_batch > 0, ADAS_ERR_INVALID, "adas_engine_create: bad argument");
-    ADAS_REQUIRE(precision == ADAS_PREC_BF16 || precision == ADAS_PREC_FP32, ADAS_ERR_INVALID, "unknown precision %d", precision);
+    ADAS_REQUIRE(precision == ADAS_PREC_BF16 || precision == ADAS_PREC_FP32 || precision == ADAS_PREC_FP16, ADAS_ERR_INVALID, "unknown precision %d",
+                 precision);
     FILE* f = fopen(model_path, "rb");
     if (!f) {  // coreEngine.py:12-13
         set_error("The model path [%s] can't not found! (%s)", model_path, strerror(errno));
@@ -238,7 +239,7 @@ int adas_engine_create(const char* model_path, int precision, int max_batch, ada
     // ---- Detect fusion (aux_kernels.hip detect_v8_fused_kernel): the last 1x1 convs of both head branches feed only the decode
     {
         const char* env = getenv("ADAS_NO_DETECT_FUSE");
-        const bool enabled = precision == PREC_BF16 && !(env && env[0] == '1');
+        const bool enabled = prec_is16(precision) && !(env && env[0] == '1');
         for (size_t di = 0; enabled && di < e->ops.size(); ++di) {
             EngOp& dop = e->ops[di];
             if (dop.f.type != OP_DETECT_V8 || dop.f.n_in != 6) continue;
@@ -307,8 +308,8 @@ int adas_engine_create(const char* model_path, int precision, int max_batch, ada
             if (hipMemcpy(d_stage, h_stage.data(), o.w_elems * 4, hipMemcpyHostToDevice) != hipSuccess) { rc = ADAS_ERR_HIP; break; }
             if (op.kernel == CONV_STEM || op.kernel == CONV_STEM2) {
                 std::vector<uint16_t> frag((op.kernel == CONV_STEM2 ? stem2_weight_bytes() : stem_weight_bytes(o.kh, o.out_c)) / 2);
-                if (op.kernel == CONV_STEM2) stem2_pack_weights(h_stage.data(), frag.data());
-                else stem_pack_weights(h_stage.data(), o.out_c, o.kh, o.kw, o.in_c[0], hd.in_c, frag.data());
+                if (op.kernel == CONV_STEM2) stem2_pack_weights(h_stage.data(), frag.data(), precision);
+                else stem_pack_weights(h_stage.data(), o.out_c, o.kh, o.kw, o.in_c[0], hd.in_c, frag.data(), precision);
                 if (hipMemcpy(base + op.w_off, frag.data(), frag.size() * 2, hipMemcpyHostToDevice) != hipSuccess) { rc = ADAS_ERR_HIP; break; }
                 std::vector<float> b(op.cout_pad, 0.f);
                 if (!read_blob(o.b_off, o.b_elems, b.data())) { rc = ADAS_ERR_FORMAT; break; }
@@ -316,9 +317,9 @@ int adas_engine_create(const char* model_path, int precision, int max_batch, ada
                 continue;
             }
             hipError_t pe = (op.kernel == CONV_FC || op.kernel == CONV_PW)
-                                ? launch_pack_weights_fc(d_stage, base + op.w_off, o.out_c, op.cout_pad, o.in_c[0], op.kpad, 0)
+                                ? launch_pack_weights_fc(d_stage, base + op.w_off, o.out_c, op.cout_pad, o.in_c[0], op.kpad, precision, 0)
                                 : op.kernel == CONV_HALO
-                                ? launch_pack_weights_halo(d_stage, base + op.w_off, o.out_c, op.cout_pad, o.in_c[0], op.cin_pad, 0)
+                                ? launch_pack_weights_halo(d_stage, base + op.w_off, o.out_c, op.cout_pad, o.in_c[0], op.cin_pad, precision, 0)
                                 : launch_pack_weights(d_stage, base + op.w_off, o.out_c, op.cout_pad, o.kh * o.kw, o.in_c[0], op.cin_pad, op.kpad, precision, 0);
             if (pe != hipSuccess) { rc = ADAS_ERR_HIP; break; }
             if (hipDeviceSynchronize() != hipSuccess) { rc = ADAS_ERR_HIP; break; }
@@ -407,7 +408,7 @@ int adas_engine_layer_kernel(const adas_engine* e, int layer, int batch, char* n
         a.in = make_view(e, o.in_buf[0], o.in_coff[0], o.in_c[0]);
         a.out = make_view(e, o.out_buf, o.out_coff, o.out_c);
         a.n = batch; a.kh = o.kh; a.kw = o.kw; a.stride = o.stride; a.pad = o.pad; a.act = o.act; a.res_mode = o.res_mode;
-        a.k = op.k; a.kpad = op.kpad; a.m = batch * a.out.h * a.out.w; a.max_n = e->max_batch;
+        a.k = op.k; a.kpad = op.kpad; a.m = batch * a.out.h * a.out.w; a.max_n = e->max_batch; a.prec = e->prec;
         snprintf(name, cap, "%s%s", conv_kernel_name(a, e->prec, op.kernel), op.fuse_pool >= 0 ? "+pool" : "");
     } else if (o.type == OP_DETECT_V8 && op.det_src[0] >= 0) {
         snprintf(name, cap, "detect_v8_fused_kernel");
@@ -444,10 +445,10 @@ int engine_run_op(adas_engine* e, int i, const float* d_in, int batch, hipStream
         if (op.fuse_conv2 >= 0) {
             const EngOp& c2 = e->ops[op.fuse_conv2];
             err = launch_conv_stem2(d_in, batch, e->hdr.in_c, e->hdr.in_h, e->hdr.in_w, o.kh, o.pad, wb + op.w_off, (const float*)(wb + op.b_off), cv,
-                                    wb + c2.w_off, (const float*)(wb + c2.b_off), make_view(e, c2.f.out_buf, c2.f.out_coff, c2.f.out_c), packed_in, st);
+                                    wb + c2.w_off, (const float*)(wb + c2.b_off), make_view(e, c2.f.out_buf, c2.f.out_coff, c2.f.out_c), packed_in, e->prec, st);
         } else
             err = launch_conv_stem(d_in, batch, e->hdr.in_c, e->hdr.in_h, e->hdr.in_w, o.kh, o.pad, o.act, wb + op.w_off,
-                                   (const float*)(wb + op.b_off), cv, op.fuse_pool >= 0, pv, packed_in, st);
+                                   (const float*)(wb + op.b_off), cv, op.fuse_pool >= 0, pv, packed_in, e->prec, st);
         if (err != hipSuccess) {
             set_error("layer %d (%s): stem launch failed: %s", i, op.name.c_str(), hipGetErrorString(err));
             (void)hipGetLastError();
@@ -468,7 +469,7 @@ int engine_run_op(adas_engine* e, int i, const float* d_in, int batch, hipStream
             a.wgt = wb + op.w_off;
             a.bias = (const float*)(wb + op.b_off);
             a.n = batch; a.kh = o.kh; a.kw = o.kw; a.stride = o.stride; a.pad = o.pad; a.act = o.act; a.res_mode = o.res_mode;
-            a.k = op.k; a.kpad = op.kpad; a.m = batch * a.out.h * a.out.w; a.max_n = e->max_batch;
+            a.k = op.k; a.kpad = op.kpad; a.m = batch * a.out.h * a.out.w; a.max_n = e->max_batch; a.prec = e->prec;
             err = launch_conv(a, e->prec, st);
             break;
         }
@@ -492,7 +493,7 @@ int engine_run_op(adas_engine* e, int i, const float* d_in, int batch, hipStream
                     wf[k] = wb + c.w_off;
                     bs[k] = (const float*)(wb + c.b_off);
                 }
-                err = launch_detect_v8_fused(ins, wf, bs, (float*)e->bufs[o.out_buf].d, batch, (int)o.params[0], (int)o.params[1], strides, st);
+                err = launch_detect_v8_fused(ins, wf, bs, (float*)e->bufs[o.out_buf].d, batch, (int)o.params[0], (int)o.params[1], strides, e->prec, st);
                 break;
             }
             for (int k = 0; k < 6; ++k) ins[k] = make_view(e, o.in_buf[k], o.in_coff[k], o.in_c[k]);
@@ -544,6 +545,9 @@ int adas_engine_infer_device(adas_engine* e, const float* d_input, int batch, vo
     e->last = (hipStream_t)stream;
     return engine_forward(e, d_input, batch, (hipStream_t)stream);
 }
+
+int adas_engine_precision(const adas_engine* e) { return e ? e->prec : -1; }
+int adas_engine_model_io_half(const adas_engine* e) { return e ? (int)((e->hdr.in_cpad >> 16) & 1u) : 0; }
 
 int adas_engine_accepts_packed_input(const adas_engine* e) {
     return (e && e->ops.size() >= 2 && e->ops[0].skip && e->ops[1].kernel == CONV_STEM) ? 1 : 0;

@@ -12,7 +12,7 @@ enum { OP_INPUT = 0, OP_CONV, OP_MAXPOOL, OP_UPSAMPLE2, OP_DETECT_V8, OP_DETECT_
 
 struct FileHeader {
     char magic[8];
-    uint32_t version, n_bufs, n_ops, n_outputs, in_c, in_h, in_w, in_cpad;
+    uint32_t version, n_bufs, n_ops, n_outputs, in_c, in_h, in_w, in_cpad;  // in_cpad: low 16 bits = 8; bit 16 = the source model's I/O was float16
     uint64_t weights_off, weights_bytes;
     double flops;
     char name[64];

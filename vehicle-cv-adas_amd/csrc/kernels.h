@@ -5,7 +5,8 @@
 
 namespace adas {
 
-enum { PREC_BF16 = 0, PREC_FP32 = 1 };
+enum { PREC_BF16 = 0, PREC_FP32 = 1, PREC_FP16 = 2 };  // == ADAS_PREC_* (include/adas_hip.h)
+inline bool prec_is16(int prec) { return prec != PREC_FP32; }   // bf16 and fp16 share every 16-bit kernel (elem16.h)
 enum { ACT_NONE = 0, ACT_SILU = 1, ACT_RELU = 2 };
 enum { RES_NONE = 0, RES_AFTER_ACT = 1, RES_BEFORE_ACT = 2 };
 
@@ -25,6 +26,7 @@ struct ConvArgs {
     int kh, kw, stride, pad, act, res_mode;
     int k, kpad, m;     // K = kh*kw*cin ; padded to 32 ; M = n*ho*wo
     int max_n;          // the engine's max_batch (static: decides the FC weight packing)
+    int prec;           // PREC_*: the 16-bit kernels pick their operand type (bf16 | fp16) from it
 };
 
 // Which kernel runs a conv and how its weights are packed.  Decided once at load time from static
@@ -51,7 +53,7 @@ hipError_t launch_upsample2(TView in, TView out, int n, int prec, hipStream_t st
 // YOLOv8 Detect decode: ins = {box0, cls0, box1, cls1, box2, cls2} fp32 logits NHWC; out fp32 [n][4+nc][A]
 hipError_t launch_detect_v8(const TView* ins, float* out, int n, int nc, int A, const int strides[3], hipStream_t st);
 hipError_t launch_detect_v8_fused(const TView* hidden, const void* const* wfrag, const float* const* bias, float* out, int n, int nc, int A,
-                                  const int strides[3], hipStream_t st);
+                                  const int strides[3], int prec, hipStream_t st);
 // YOLOv5 Detect decode: ins = 3 fp32 maps [n][ny][nx][3*(5+nc)]; out fp32 [n][A][5+nc]; anchors[18] device
 hipError_t launch_detect_v5(const TView* ins, float* out, int n, int nc, int A, const int strides[3],
                             const float* d_anchors, hipStream_t st);
@@ -68,20 +70,20 @@ bool stem_applicable(int prec, int in_c_true, int kh, int kw, int stride, int pa
 size_t stem_weight_bytes(int kh, int cout);
 // YOLO stem + the 3x3 s2 16->32 conv behind it in one launch (conv_stem.hip, CONV2)
 size_t stem2_weight_bytes();
-void stem2_pack_weights(const float* w_ohwi_32x3x3x16, uint16_t* dst_host);
+void stem2_pack_weights(const float* w_ohwi_32x3x3x16, uint16_t* dst_host, int prec);
 bool stem2_applicable(int prec, int kh, int pad, int act, const TView& stem_out, int kh2, int kw2, int stride2, int pad2, int act2, int res_mode2,
                       const TView& out2);
 hipError_t launch_conv_stem2(const float* nchw, int n, int c_true, int H, int W, int kh, int pad, const void* wfrag, const float* bias,
-                             const TView& stem_out, const void* wfrag2, const float* bias2, const TView& out2, bool packed_in, hipStream_t st);
-void stem_pack_weights(const float* w_ohwi, int cout, int kh, int kw, int cs, int c_true, uint16_t* dst_host);
+                             const TView& stem_out, const void* wfrag2, const float* bias2, const TView& out2, bool packed_in, int prec, hipStream_t st);
+void stem_pack_weights(const float* w_ohwi, int cout, int kh, int kw, int cs, int c_true, uint16_t* dst_host, int prec);
 hipError_t launch_conv_stem(const float* nchw, int n, int c_true, int H, int W, int kh, int pad, int act, const void* wfrag,
-                            const float* bias, const TView& conv_out, bool pool, const TView& pool_out, bool packed_in, hipStream_t st);
+                            const float* bias, const TView& conv_out, bool pool, const TView& pool_out, bool packed_in, int prec, hipStream_t st);
 // CONV_HALO packing: slab order [cout tile of halo_bn(cout)][32-channel chunk][tap][n within tile][32] -- the 9*BN*64 B a
 // workgroup stages per chunk are one contiguous run (every wave-level staging load reads 1 KB of consecutive bytes).
 inline int halo_bn(int cout) { return cout <= 16 ? 16 : (cout <= 32 ? 32 : 64); }
-hipError_t launch_pack_weights_halo(const float* src, void* dst, int cout, int cout_pad, int cin, int cin_pad, hipStream_t st);
+hipError_t launch_pack_weights_halo(const float* src, void* dst, int cout, int cout_pad, int cin, int cin_pad, int prec, hipStream_t st);
 // Linear-layer packing (CONV_FC): src [cout][cin] fp32 -> bf16 MFMA-fragment order [cout_pad/16][kpad/32][64][8]
-hipError_t launch_pack_weights_fc(const float* src, void* dst, int cout, int cout_pad, int cin, int kpad, hipStream_t st);
+hipError_t launch_pack_weights_fc(const float* src, void* dst, int cout, int cout_pad, int cin, int kpad, int prec, hipStream_t st);
 // NHWC (compute type or fp32) activation view -> NCHW fp32 (debug / parity tap)
 hipError_t launch_nhwc_to_nchw(TView in, float* out, int n, int prec, hipStream_t st);
 

@@ -41,7 +41,13 @@ struct adas_pipeline {
         double crop;
     };
     FrameSrc fsrc{nullptr, 0, 0, 0.0};  // set while a step_frames call records
-    bool packed = false;  // both first layers are the fused stem: the seam tensors are (c0,c1,c2,0) bf16 NHWC, 8 B per pixel
+    bool packed = false;  // both first layers are the fused stem: the seam tensors are (c0,c1,c2,0) 16-bit NHWC, 8 B per pixel
+    // step_frames_host: two device frame buffers filled by a copy stream
+    hipStream_t st_copy = nullptr;
+    uint8_t* host_stage[2] = {nullptr, nullptr};
+    size_t host_stage_bytes = 0;
+    hipEvent_t ev_copied[2] = {nullptr, nullptr}, ev_consumed[2] = {nullptr, nullptr};
+    unsigned long long host_steps = 0;
 };
 
 using namespace adas;
@@ -65,14 +71,16 @@ static int record_step(adas_pipeline* p, const float* d_det, const float* d_lane
         if (p->d.detector) {
             int64_t is[4];
             adas_engine_input_shape(p->d.detector, is);
-            rc = p->packed ? adas_preprocess_yolo_packed(p->fsrc.frames, S, p->fsrc.h, p->fsrc.w, (uint16_t*)p->det_in, (int)is[2], (int)is[3], 1, st)
+            rc = p->packed ? adas_preprocess_yolo_packed_prec(p->fsrc.frames, S, p->fsrc.h, p->fsrc.w, (uint16_t*)p->det_in, (int)is[2], (int)is[3], 1,
+                                                              p->d.detector->prec, st)
                            : adas_preprocess_yolo(p->fsrc.frames, S, p->fsrc.h, p->fsrc.w, p->det_in, (int)is[2], (int)is[3], 1, st);
             if (rc) return rc;
         }
         if (p->d.lane) {
             int64_t is[4];
             adas_engine_input_shape(p->d.lane, is);
-            rc = p->packed ? adas_preprocess_ufld_packed(p->fsrc.frames, S, p->fsrc.h, p->fsrc.w, (uint16_t*)p->lane_in, (int)is[2], (int)is[3], p->fsrc.crop, sl)
+            rc = p->packed ? adas_preprocess_ufld_packed_prec(p->fsrc.frames, S, p->fsrc.h, p->fsrc.w, (uint16_t*)p->lane_in, (int)is[2], (int)is[3], p->fsrc.crop,
+                                                              p->d.lane->prec, sl)
                            : adas_preprocess_ufld(p->fsrc.frames, S, p->fsrc.h, p->fsrc.w, p->lane_in, (int)is[2], (int)is[3], p->fsrc.crop, sl);
             if (rc) return rc;
         }
@@ -202,6 +210,12 @@ int adas_pipeline_destroy(adas_pipeline* p) {
     if (p->st) (void)hipStreamDestroy(p->st);
     if (p->det_in) (void)hipFree(p->det_in);
     if (p->lane_in) (void)hipFree(p->lane_in);
+    for (int k = 0; k < 2; ++k) {
+        if (p->host_stage[k]) (void)hipFree(p->host_stage[k]);
+        if (p->ev_copied[k]) (void)hipEventDestroy(p->ev_copied[k]);
+        if (p->ev_consumed[k]) (void)hipEventDestroy(p->ev_consumed[k]);
+    }
+    if (p->st_copy) (void)hipStreamDestroy(p->st_copy);
     delete p;
     return ADAS_OK;
 }
@@ -285,6 +299,40 @@ int adas_pipeline_step_frames(adas_pipeline* p, const uint8_t* d_frames_bgr, int
         return rc;
     }
     return replay_step(p, adas_pipeline::GraphKey{d_frames_bgr, nullptr, src_h, src_w, lane_crop_ratio}, p->det_in, p->lane_in, &fs);
+}
+
+int adas_pipeline_step_frames_host(adas_pipeline* p, const uint8_t* h_frames_bgr, int src_h, int src_w, double lane_crop_ratio) {
+    ADAS_REQUIRE(p && h_frames_bgr && src_h > 0 && src_w > 0, ADAS_ERR_INVALID, "adas_pipeline_step_frames_host: bad argument");
+    const size_t bytes = (size_t)p->d.n_streams * src_h * src_w * 3;
+    if (!p->st_copy) {
+        ADAS_HIP_TRY(hipStreamCreateWithFlags(&p->st_copy, hipStreamNonBlocking));
+        for (int k = 0; k < 2; ++k) {
+            ADAS_HIP_TRY(hipEventCreateWithFlags(&p->ev_copied[k], hipEventDisableTiming));
+            ADAS_HIP_TRY(hipEventCreateWithFlags(&p->ev_consumed[k], hipEventDisableTiming));
+        }
+    }
+    if (bytes > p->host_stage_bytes) {  // (re)size both staging buffers; captured steps that read the old ones are dropped
+        ADAS_HIP_TRY(hipStreamSynchronize(p->st));
+        ADAS_HIP_TRY(hipStreamSynchronize(p->st_copy));
+        drop_graphs(p);
+        for (int k = 0; k < 2; ++k) {
+            if (p->host_stage[k]) (void)hipFree(p->host_stage[k]);
+            p->host_stage[k] = nullptr;
+            ADAS_HIP_TRY(hipMalloc((void**)&p->host_stage[k], bytes));
+        }
+        p->host_stage_bytes = bytes;
+        p->host_steps = 0;
+    }
+    const int k = (int)(p->host_steps & 1);
+    if (p->host_steps >= 2) ADAS_HIP_TRY(hipStreamWaitEvent(p->st_copy, p->ev_consumed[k], 0));  // the step two back is done with buffer k
+    ADAS_HIP_TRY(hipMemcpyAsync(p->host_stage[k], h_frames_bgr, bytes, hipMemcpyHostToDevice, p->st_copy));
+    ADAS_HIP_TRY(hipEventRecord(p->ev_copied[k], p->st_copy));
+    ADAS_HIP_TRY(hipStreamWaitEvent(p->st, p->ev_copied[k], 0));
+    int rc = adas_pipeline_step_frames(p, p->host_stage[k], src_h, src_w, lane_crop_ratio);
+    if (rc) return rc;
+    ADAS_HIP_TRY(hipEventRecord(p->ev_consumed[k], p->st));
+    ++p->host_steps;
+    return ADAS_OK;
 }
 
 int adas_pipeline_sync(adas_pipeline* p) {

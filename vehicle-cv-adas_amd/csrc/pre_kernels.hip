@@ -14,6 +14,7 @@
 // ((b0*(S0>>4))>>16 + (b1*(S1>>4))>>16 + 2)>>2).  Parity with a real cv2 build is UNPINNED; identity-size
 // resizes are exact by construction.  HBM-bound streaming kernels: one thread per output pixel.
 #include "common.h"
+#include "elem16.h"
 #include <math.h>
 
 namespace {
@@ -91,7 +92,7 @@ struct YoloPreDev {
     ResizeGeom g;
     int n, dh, dw, padh, padw;
 };
-template <bool PACK>
+template <int PACK>   // 0: fp32 NCHW planes; 1: packed bf16 pixels; 2: packed fp16 pixels
 __global__ void preprocess_yolo_kernel(YoloPreDev d) {
     const size_t plane = (size_t)d.dh * d.dw;
     const size_t total = (size_t)d.n * plane;
@@ -109,7 +110,9 @@ __global__ void preprocess_yolo_kernel(YoloPreDev d) {
         if (ry >= 0 && ry < d.g.rh && rx >= 0 && rx < d.g.rw) resize_px(d.src + (size_t)b * d.g.sh * d.g.sw * 3, d.g, ry, rx, v);
         // swapRB: plane 0 = R = source channel 2
         const float c0 = lut[v[2]], c1 = lut[v[1]], c2 = lut[v[0]];
-        if (PACK) {
+        if (PACK == 2) {
+            reinterpret_cast<uint2*>(d.dst)[i] = make_uint2(adas::Fp16::pack2(c0, c1), adas::Fp16::pack2(c2, 0.f));
+        } else if (PACK == 1) {
             reinterpret_cast<uint2*>(d.dst)[i] = make_uint2(pre_pack2(c0, c1), pre_pack2(c2, 0.f));
         } else {
             float* o = d.dst + (size_t)b * 3 * plane + p;
@@ -126,7 +129,7 @@ struct UfldPreDev {
     ResizeGeom g;
     int n, ih, iw, row0;
 };
-template <bool PACK>
+template <int PACK>
 __global__ void preprocess_ufld_kernel(UfldPreDev d) {
     const size_t plane = (size_t)d.ih * d.iw;
     const size_t total = (size_t)d.n * plane;
@@ -149,7 +152,9 @@ __global__ void preprocess_ufld_kernel(UfldPreDev d) {
         float cv[3];
 #pragma unroll
         for (int c = 0; c < 3; ++c) cv[c] = lut[c][v[2 - c]];  // RGB plane c = BGR source channel 2-c
-        if (PACK) {
+        if (PACK == 2) {
+            reinterpret_cast<uint2*>(d.dst)[i] = make_uint2(adas::Fp16::pack2(cv[0], cv[1]), adas::Fp16::pack2(cv[2], 0.f));
+        } else if (PACK == 1) {
             reinterpret_cast<uint2*>(d.dst)[i] = make_uint2(pre_pack2(cv[0], cv[1]), pre_pack2(cv[2], 0.f));
         } else {
             float* o = d.dst + (size_t)b * 3 * plane + p;
@@ -169,7 +174,7 @@ int grid_for(size_t total) {
 extern "C" {
 
 static int preprocess_yolo_impl(const uint8_t* d_frames_bgr, int n, int src_h, int src_w, float* d_out_nchw, int dst_h, int dst_w,
-                                int keep_ratio, void* stream, bool pack) {
+                                int keep_ratio, void* stream, int pack) {
     ADAS_REQUIRE(d_frames_bgr && d_out_nchw && n > 0 && src_h > 0 && src_w > 0 && dst_h > 0 && dst_w > 0, ADAS_ERR_INVALID,
                  "adas_preprocess_yolo: bad argument");
     adas_yolo_post_params lb;
@@ -187,22 +192,29 @@ static int preprocess_yolo_impl(const uint8_t* d_frames_bgr, int n, int src_h, i
     d.g.sh = src_h; d.g.sw = src_w; d.g.rh = newh; d.g.rw = neww;
     d.g.scale_y = 1.0 / ((double)newh / (double)src_h);
     d.g.scale_x = 1.0 / ((double)neww / (double)src_w);
-    if (pack) hipLaunchKernelGGL(preprocess_yolo_kernel<true>, dim3(grid_for((size_t)n * dst_h * dst_w)), dim3(256), 0, (hipStream_t)stream, d);
-    else hipLaunchKernelGGL(preprocess_yolo_kernel<false>, dim3(grid_for((size_t)n * dst_h * dst_w)), dim3(256), 0, (hipStream_t)stream, d);
+    if (pack == 2) hipLaunchKernelGGL(preprocess_yolo_kernel<2>, dim3(grid_for((size_t)n * dst_h * dst_w)), dim3(256), 0, (hipStream_t)stream, d);
+    else if (pack == 1) hipLaunchKernelGGL(preprocess_yolo_kernel<1>, dim3(grid_for((size_t)n * dst_h * dst_w)), dim3(256), 0, (hipStream_t)stream, d);
+    else hipLaunchKernelGGL(preprocess_yolo_kernel<0>, dim3(grid_for((size_t)n * dst_h * dst_w)), dim3(256), 0, (hipStream_t)stream, d);
     ADAS_HIP_TRY(hipGetLastError());
     return ADAS_OK;
 }
 int adas_preprocess_yolo(const uint8_t* d_frames_bgr, int n, int src_h, int src_w, float* d_out_nchw, int dst_h, int dst_w,
                          int keep_ratio, void* stream) {
-    return preprocess_yolo_impl(d_frames_bgr, n, src_h, src_w, d_out_nchw, dst_h, dst_w, keep_ratio, stream, false);
+    return preprocess_yolo_impl(d_frames_bgr, n, src_h, src_w, d_out_nchw, dst_h, dst_w, keep_ratio, stream, 0);
 }
 int adas_preprocess_yolo_packed(const uint8_t* d_frames_bgr, int n, int src_h, int src_w, uint16_t* d_out_nhwc4, int dst_h, int dst_w,
                                 int keep_ratio, void* stream) {
-    return preprocess_yolo_impl(d_frames_bgr, n, src_h, src_w, reinterpret_cast<float*>(d_out_nhwc4), dst_h, dst_w, keep_ratio, stream, true);
+    return preprocess_yolo_impl(d_frames_bgr, n, src_h, src_w, reinterpret_cast<float*>(d_out_nhwc4), dst_h, dst_w, keep_ratio, stream, 1);
+}
+int adas_preprocess_yolo_packed_prec(const uint8_t* d_frames_bgr, int n, int src_h, int src_w, uint16_t* d_out_nhwc4, int dst_h, int dst_w,
+                                     int keep_ratio, int precision, void* stream) {
+    ADAS_REQUIRE(precision == ADAS_PREC_BF16 || precision == ADAS_PREC_FP16, ADAS_ERR_INVALID, "packed pixels are bf16 or fp16 (precision %d)", precision);
+    return preprocess_yolo_impl(d_frames_bgr, n, src_h, src_w, reinterpret_cast<float*>(d_out_nhwc4), dst_h, dst_w, keep_ratio, stream,
+                                precision == ADAS_PREC_FP16 ? 2 : 1);
 }
 
 static int preprocess_ufld_impl(const uint8_t* d_frames_bgr, int n, int src_h, int src_w, float* d_out_nchw, int in_h, int in_w,
-                                double crop_ratio, void* stream, bool pack) {
+                                double crop_ratio, void* stream, int pack) {
     ADAS_REQUIRE(d_frames_bgr && d_out_nchw && n > 0 && src_h > 0 && src_w > 0 && in_h > 0 && in_w > 0 && crop_ratio > 0.0 &&
                      crop_ratio <= 1.0, ADAS_ERR_INVALID, "adas_preprocess_ufld: bad argument");
     UfldPreDev d;
@@ -213,18 +225,25 @@ static int preprocess_ufld_impl(const uint8_t* d_frames_bgr, int n, int src_h, i
     d.g.sh = src_h; d.g.sw = src_w; d.g.rh = rh; d.g.rw = in_w;
     d.g.scale_y = 1.0 / ((double)rh / (double)src_h);
     d.g.scale_x = 1.0 / ((double)in_w / (double)src_w);
-    if (pack) hipLaunchKernelGGL(preprocess_ufld_kernel<true>, dim3(grid_for((size_t)n * in_h * in_w)), dim3(256), 0, (hipStream_t)stream, d);
-    else hipLaunchKernelGGL(preprocess_ufld_kernel<false>, dim3(grid_for((size_t)n * in_h * in_w)), dim3(256), 0, (hipStream_t)stream, d);
+    if (pack == 2) hipLaunchKernelGGL(preprocess_ufld_kernel<2>, dim3(grid_for((size_t)n * in_h * in_w)), dim3(256), 0, (hipStream_t)stream, d);
+    else if (pack == 1) hipLaunchKernelGGL(preprocess_ufld_kernel<1>, dim3(grid_for((size_t)n * in_h * in_w)), dim3(256), 0, (hipStream_t)stream, d);
+    else hipLaunchKernelGGL(preprocess_ufld_kernel<0>, dim3(grid_for((size_t)n * in_h * in_w)), dim3(256), 0, (hipStream_t)stream, d);
     ADAS_HIP_TRY(hipGetLastError());
     return ADAS_OK;
 }
 int adas_preprocess_ufld(const uint8_t* d_frames_bgr, int n, int src_h, int src_w, float* d_out_nchw, int in_h, int in_w,
                          double crop_ratio, void* stream) {
-    return preprocess_ufld_impl(d_frames_bgr, n, src_h, src_w, d_out_nchw, in_h, in_w, crop_ratio, stream, false);
+    return preprocess_ufld_impl(d_frames_bgr, n, src_h, src_w, d_out_nchw, in_h, in_w, crop_ratio, stream, 0);
 }
 int adas_preprocess_ufld_packed(const uint8_t* d_frames_bgr, int n, int src_h, int src_w, uint16_t* d_out_nhwc4, int in_h, int in_w,
                                 double crop_ratio, void* stream) {
-    return preprocess_ufld_impl(d_frames_bgr, n, src_h, src_w, reinterpret_cast<float*>(d_out_nhwc4), in_h, in_w, crop_ratio, stream, true);
+    return preprocess_ufld_impl(d_frames_bgr, n, src_h, src_w, reinterpret_cast<float*>(d_out_nhwc4), in_h, in_w, crop_ratio, stream, 1);
+}
+int adas_preprocess_ufld_packed_prec(const uint8_t* d_frames_bgr, int n, int src_h, int src_w, uint16_t* d_out_nhwc4, int in_h, int in_w,
+                                     double crop_ratio, int precision, void* stream) {
+    ADAS_REQUIRE(precision == ADAS_PREC_BF16 || precision == ADAS_PREC_FP16, ADAS_ERR_INVALID, "packed pixels are bf16 or fp16 (precision %d)", precision);
+    return preprocess_ufld_impl(d_frames_bgr, n, src_h, src_w, reinterpret_cast<float*>(d_out_nhwc4), in_h, in_w, crop_ratio, stream,
+                                precision == ADAS_PREC_FP16 ? 2 : 1);
 }
 
 }  // extern "C"

@@ -128,6 +128,9 @@ class _FrameStage:
 
 
 # =====================================================================================
+MAX_CANDIDATE_LIMIT = 2048     # adas_yolo_post_create's upper bound (post_kernels.hip)
+
+
 class YoloDetector(_Defaults):
     _defaults = {
         "model_path": './models/yolov5n-coco.onnx',
@@ -141,7 +144,7 @@ class YoloDetector(_Defaults):
     def __init__(self, logger=None, **kwargs):
         self.__dict__.update(self._defaults)
         self.logger = logger
-        self.precision = "bf16"
+        self.precision = None                    # None -> coreEngine.DEFAULT_PRECISION ("fp16")
         self.nms_mode = L.NMS_REFERENCE          # the production call (yoloDetector.py:139); NMS_GREEDY = fast_nms (:138)
         self.max_candidates = 1024
         self.__dict__.update(kwargs)
@@ -199,7 +202,25 @@ class YoloDetector(_Defaults):
         post = self._post_for((h, w))
         post.run_device(self.engine.output_device_ptr(0), 1, None)
         r = post.fetch(0)
-        if r["rc"] != 0:
+        # The reference's candidate lists are unbounded (yoloDetector.py:120-133); the device arena is not.  A frame with more
+        # anchors over box_score than the arena holds is re-run with a larger arena (the head tensor is still in HBM); past the
+        # library's limit the frame is reported with its first `max_candidates` anchors and a warning -- never an exception
+        # in the middle of a video loop.
+        while r["overflow"] and self.max_candidates < MAX_CANDIDATE_LIMIT:
+            self.max_candidates = min(MAX_CANDIDATE_LIMIT, max(2 * self.max_candidates, int(r["n_found"])))
+            self._post_key = None
+            post = self._post_for((h, w))
+            post.run_device(self.engine.output_device_ptr(0), 1, None)
+            r = post.fetch(0)
+        if r["overflow"]:
+            msg = "YoloDetector: %d anchors over box_score exceed the %d-candidate arena; NMS ran on the first %d" % (
+                r["n_found"], self.max_candidates, self.max_candidates)
+            if self.logger:
+                self.logger.warning(msg)
+            else:
+                import warnings
+                warnings.warn(msg, RuntimeWarning)
+        elif r["rc"] != 0:
             L.check(r["rc"])
         self._last = r
         out = []
@@ -324,7 +345,7 @@ class UltrafastLaneDetectorV2(_Defaults):
         "model_type": LaneModelType.UFLDV2_TUSIMPLE,
     }
 
-    def __init__(self, model_path: str = None, model_type: LaneModelType = None, logger=None, precision="bf16"):
+    def __init__(self, model_path: str = None, model_type: LaneModelType = None, logger=None, precision=None):
         self.__dict__.update(self._defaults)
         self.logger = logger
         self.adjust_lanes = False
@@ -467,7 +488,7 @@ class UltrafastLaneDetector(UltrafastLaneDetectorV2):
         "model_type": LaneModelType.UFLD_TUSIMPLE,
     }
 
-    def __init__(self, model_path: str = None, model_type: LaneModelType = None, logger=None, precision="bf16"):
+    def __init__(self, model_path: str = None, model_type: LaneModelType = None, logger=None, precision=None):
         self.__dict__.update(self._defaults)
         self.logger = logger
         self.adjust_lanes = False

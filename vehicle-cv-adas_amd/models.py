@@ -102,6 +102,7 @@ class Graph:
         self.flops = 0.0
         self.n_convs = 0
         self.n_params = 0
+        self.io_half = False   # the source model's graph I/O is float16 (header flag; HipEngine.engine_dtype follows it)
 
     # ---- buffers / views
     def buf(self, h, w, c, f32=False):
@@ -192,7 +193,7 @@ class Graph:
         nb, no, nout = len(self.bufs), len(self.ops), len(self.outs)
         woff = HDR_SIZE + nb * BUF_SIZE + no * OP_SIZE + nout * OUT_SIZE
         woff += (-woff) % 256
-        parts.append(struct.pack(HDR_FMT, MAGIC, 1, nb, no, nout, self.in_c, self.in_h, self.in_w, 8, woff, len(self.blob),
+        parts.append(struct.pack(HDR_FMT, MAGIC, 1, nb, no, nout, self.in_c, self.in_h, self.in_w, 8 | (int(self.io_half) << 16), woff, len(self.blob),
                                  self.flops, self.name.encode()[:63]))
         for h, w, c, fl in self.bufs:
             parts.append(struct.pack(BUF_FMT, h, w, c, fl))

@@ -168,7 +168,7 @@ def _node(buf):
     return n
 
 
-def _value_info(buf):
+def _value_info(buf, elem_types=None):
     name, shape = "", []
     for f, wt, v in _fields(buf):
         if f == 1:
@@ -177,6 +177,8 @@ def _value_info(buf):
             for f2, _, v2 in _fields(v):
                 if f2 == 1:  # tensor_type
                     for f3, _, v3 in _fields(v2):
+                        if f3 == 1 and elem_types is not None:  # elem_type (TensorProto.DataType: 1 float, 10 float16)
+                            elem_types[name] = int(v3)
                         if f3 == 2:  # shape
                             for f4, _, v4 in _fields(v3):
                                 if f4 == 1:  # dim
@@ -194,6 +196,7 @@ class OnnxModel:
         self.nodes = []
         self.inputs = []   # (name, shape) excluding initializers
         self.outputs = []
+        self.elem_types = {}   # graph input / output name -> TensorProto.DataType
 
 
 def read_onnx(path):
@@ -220,9 +223,9 @@ def read_onnx(path):
             else:
                 m.initializers[name] = arr
         elif f == 11:
-            m.inputs.append(_value_info(v))
+            m.inputs.append(_value_info(v, m.elem_types))
         elif f == 12:
-            m.outputs.append(_value_info(v))
+            m.outputs.append(_value_info(v, m.elem_types))
     if unsupported and not m.initializers:
         raise ValueError("[%s]: initializers use external data or unsupported types: %s" % (path, unsupported[:4]))
     m.inputs = [(n, s) for n, s in m.inputs if n not in m.initializers]
@@ -403,6 +406,9 @@ def convert(onnx_path, hipm_path=None):
     m = read_onnx(onnx_path)
     arch, kw = detect_arch(m)
     g = M.build(arch, wsrc=OnnxWeights(m, arch), **kw)
+    # an fp16 export (onnxQuantization.py:11-41 / ultralytics half=True) declares float16 graph inputs: the reference then feeds and
+    # receives float16 arrays (coreEngine.py:168); recorded in the container so HipEngine can report the same engine_dtype
+    g.io_half = bool(m.inputs) and m.elem_types.get(m.inputs[0][0]) == 10
     hipm_path = hipm_path or os.path.splitext(onnx_path)[0] + ".hipm"
     g.save(hipm_path)
     return hipm_path, g

@@ -17,8 +17,8 @@ CULANE = dict(grid_row=200, cls_row=72, grid_col=100, cls_col=81,
 
 
 class AdasPipeline:
-    def __init__(self, det_model=None, lane_model=None, n_streams=1, precision="bf16", src_hw=(720, 1280),
-                 box_score=0.4, nms_iou=0.45, head_layout=L.HEAD_V8, num_classes=80, use_graph=True,
+    def __init__(self, det_model=None, lane_model=None, n_streams=1, precision=None, src_hw=(720, 1280),
+                 box_score=0.4, nms_iou=0.45, head_layout=L.HEAD_V8, num_classes=None, use_graph=True,
                  max_candidates=512, track=True, lane_cfg=None, nms_mode=L.NMS_REFERENCE, overlap=True, geometry=None):
         """geometry: None, or dict(bird_wh=(w, h), M=3x3, adjust_lanes=True) to run the lane-geometry kernel behind the decode."""
         self.S = n_streams
@@ -28,6 +28,11 @@ class AdasPipeline:
             ishape = self.det.get_engine_input_shape()
             oshape = self.det.get_engine_output_shape()[0][0]
             A = oshape[2] if head_layout == L.HEAD_V8 else oshape[1]
+            nc_model = oshape[1] - 4 if head_layout == L.HEAD_V8 else oshape[2] - 5     # yoloDetector.py:110-124
+            if num_classes is None:
+                num_classes = nc_model
+            elif num_classes != nc_model:
+                raise ValueError("num_classes=%d but the detector head %s carries %d classes" % (num_classes, oshape, nc_model))
             lb = letterbox(src_hw, ishape[2:])
             self.post = YoloPost(head_layout, A, num_classes, box_score, nms_iou, lb, nms_mode, max_candidates, n_streams)
             if track:
@@ -59,6 +64,11 @@ class AdasPipeline:
     def step_frames(self, d_frames_ptr, src_hw, lane_crop_ratio=0.6):
         """One step from n_streams BGR u8 frames (H x W x 3, back to back) in HBM: pre-processing runs inside the step."""
         L.check(L.lib().adas_pipeline_step_frames(self.h, d_frames_ptr, int(src_hw[0]), int(src_hw[1]), float(lane_crop_ratio)))
+
+    def step_frames_host(self, h_frames_ptr, src_hw, lane_crop_ratio=0.6):
+        """The same step from HOST frames (pinned: _lib.PinnedBuffer): the upload runs on a copy stream into one of two device
+        staging buffers, overlapped with the previous step's compute."""
+        L.check(L.lib().adas_pipeline_step_frames_host(self.h, h_frames_ptr, int(src_hw[0]), int(src_hw[1]), float(lane_crop_ratio)))
 
     def sync(self):
         L.check(L.lib().adas_pipeline_sync(self.h))
