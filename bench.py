@@ -80,58 +80,81 @@ def lane_frames(n, seed, h=320, w=1600):
     return ((x - mean) / std).astype(np.float32)
 
 
-def build_detector(M, CE, name, frames, workdir, tag, target_per_frame=30.0, sharpen=4.0, capacity=None):
-    """Seeded synthetic detector whose Detect cls biases are calibrated so that the MEDIAN calibration frame has ~target anchors
-    over box_score (random weights otherwise give 0 or thousands of boxes) and -- when `capacity` is given -- NO calibration frame
-    has more than 0.8 * capacity of them: random weights respond to whole uniform regions, so the per-frame count is heavy-tailed,
-    and a frame past the post-processor's candidate capacity would be truncated there (work the reference would not skip: its
-    lists are unbounded).  bench.py calibrates on every frame it times and asserts that none overflowed.
-    The last cls conv is scaled by `sharpen` first so that the surviving scores spread over (0.4, 1) the way a
-    trained head's do -- otherwise every score sits just above 0.4 and ByteTrack (new tracks need >= 0.6,
-    byteTracker.py:43,162) never starts a track."""
-    ws = M.SynthWeights(0, gain=M.SILU_GAIN)
-    M.build(name, wsrc=ws)                      # populates ws.store
-    for i in range(3):
-        ws.store[f"model.22.cv3.{i}.2.weight"] = ws.store[f"model.22.cv3.{i}.2.weight"] * np.float32(sharpen)
-    g = M.build(name, wsrc=ws)
-    path = os.path.join(workdir, f"{name}_{tag}_uncal.hipm")
-    g.save(path)
-    nb = min(len(frames), 16)
-    e = CE.HipEngine(path, "fp32", nb)
-    # per frame: every anchor's best class logit without its bias (the bias is one value for all classes and levels, so
-    # "conf > box_score" <=> "best logit > logit(box_score) - bias")
-    best = []
-    for f0 in range(0, len(frames), nb):
-        chunk = frames[f0:f0 + nb]
-        e.engine_inference(chunk)
-        per_level = []
+class SynthDetector:
+    """Seeded synthetic detector with a calibratable Detect class bias.
+
+    Random weights give 0 or thousands of boxes per frame; a trained detector gives tens.  The Detect cls biases (one value for all
+    classes and levels) are therefore set from the frames' own logits: "conf > box_score" <=> "an anchor's best class logit (without
+    bias) > t", so t fixes how many anchors of each frame become candidates.  The last cls conv is scaled by `sharpen` first so that
+    the surviving scores spread over (0.4, 1) the way a trained head's do -- otherwise every score sits just above 0.4 and ByteTrack
+    (new tracks need >= 0.6, byteTracker.py:43,162) never starts a track."""
+
+    def __init__(self, M, CE, name, workdir, tag, sharpen=8.0, batch=16):
+        self.M, self.CE, self.name, self.workdir, self.tag, self.batch = M, CE, name, workdir, tag, batch
+        ws = M.SynthWeights(0, gain=M.synth_gain(name))
+        M.build(name, wsrc=ws)                      # populates ws.store
+        for i in range(3):
+            ws.store[f"model.22.cv3.{i}.2.weight"] = ws.store[f"model.22.cv3.{i}.2.weight"] * np.float32(sharpen)
+        self.ws = ws
+        g = M.build(name, wsrc=ws)
+        self._uncal = os.path.join(workdir, f"{name}_{tag}_uncal.hipm")
+        g.save(self._uncal)
+        self._eng = CE.HipEngine(self._uncal, "fp32", batch)
+
+    def best_logits(self, seam):
+        """seam: (n,3,H,W) fp32 -> (n, A) every anchor's best class logit without its bias, ascending per frame."""
+        out = []
+        for f0 in range(0, len(seam), self.batch):
+            chunk = seam[f0:f0 + self.batch]
+            self._eng.engine_inference(chunk)
+            per_level = []
+            for i in range(3):
+                lname = f"model.22.cv3.{i}.2"
+                z = self._eng.fetch_activation(lname, len(chunk))
+                b = self.ws.store[lname + ".bias"]
+                per_level.append((z - b.reshape(1, -1, 1, 1)).max(axis=1).reshape(len(chunk), -1))
+            out.append(np.concatenate(per_level, axis=1))
+        best = np.concatenate(out, axis=0)
+        best.sort(axis=1)
+        return best
+
+    @staticmethod
+    def threshold(best, target_per_frame, capacity=None):
+        """t such that the MEDIAN frame has ~target anchors over it and (capacity given) no frame more than 0.8 * capacity."""
+        A = best.shape[1]
+        k_med = min(A - 1, max(1, int(round(target_per_frame))))
+        t = float(np.median(best[:, A - k_med]))
+        if capacity is not None:
+            k_cap = min(A - 1, max(1, int(0.8 * capacity)))
+            t = max(t, float(best[:, A - k_cap].max()))
+        return t
+
+    @staticmethod
+    def counts(best, t):
+        return (best > t).sum(axis=1)
+
+    def finish(self, t):
+        """-> (path of the calibrated container, its weights, Graph)."""
+        M = self.M
+        self._eng.close()
+        os.remove(self._uncal)
+        ws2 = M.SynthWeights(0, gain=M.synth_gain(self.name))
+        ws2.store.update(self.ws.store)
         for i in range(3):
             lname = f"model.22.cv3.{i}.2"
-            z = e.fetch_activation(lname, len(chunk))
-            b = ws.store[lname + ".bias"]
-            per_level.append((z - b.reshape(1, -1, 1, 1)).max(axis=1).reshape(len(chunk), -1))
-        best.append(np.concatenate(per_level, axis=1))
-    e.close()
-    os.remove(path)
-    best = np.concatenate(best, axis=0)                    # (frames, anchors)
-    best.sort(axis=1)
-    A = best.shape[1]
-    k_med = min(A - 1, max(1, int(round(target_per_frame))))
-    t = float(np.median(best[:, A - k_med]))               # the median frame gets ~target anchors over the threshold
-    if capacity is not None:
-        k_cap = min(A - 1, max(1, int(0.8 * capacity)))
-        t = max(t, float(best[:, A - k_cap].max()))        # ... and the hottest frame stays under 0.8 * capacity
-    over = {}
-    for i in range(3):
-        lname = f"model.22.cv3.{i}.2"
-        over[lname + ".bias"] = np.full_like(ws.store[lname + ".bias"], math.log(0.4 / 0.6) - t)
-    ws2 = M.SynthWeights(0, gain=M.SILU_GAIN)
-    ws2.store.update(ws.store)
-    ws2.store.update(over)
-    g2 = M.build(name, wsrc=ws2)
-    path = os.path.join(workdir, f"{name}_{tag}.hipm")
-    g2.save(path)
-    return path, dict(ws2.store), g2
+            ws2.store[lname + ".bias"] = np.full_like(self.ws.store[lname + ".bias"], math.log(0.4 / 0.6) - t)
+        g2 = M.build(self.name, wsrc=ws2)
+        path = os.path.join(self.workdir, f"{self.name}_{self.tag}.hipm")
+        g2.save(path)
+        return path, dict(ws2.store), g2
+
+
+def build_detector(M, CE, name, frames, workdir, tag, target_per_frame=30.0, sharpen=8.0, capacity=None):
+    """Calibrated synthetic detector for the given seam frames (see SynthDetector): the median frame gets ~target candidates and,
+    with `capacity`, no frame more than 0.8 * capacity."""
+    sd = SynthDetector(M, CE, name, workdir, tag, sharpen, batch=min(len(frames), 16))
+    best = sd.best_logits(frames)
+    return sd.finish(SynthDetector.threshold(best, target_per_frame, capacity))
 
 
 def measure_parity(det_eng, lane_eng, det_name, lane_name, Wd, Wl, dframes, lframes, precision):
@@ -288,26 +311,53 @@ def main():
     workdir = os.environ.get("ADAS_MODEL_DIR") or tempfile.mkdtemp(prefix=f"adas_bench_r{rank}_")
     from_frames = not args.from_seam
     d_cam, h_cam = [], []
+    t_build = time.time()
+    sd = SynthDetector(M, CE, args.det, workdir, f"r{rank}", batch=16)
+    TARGET, LO, HI = 40.0, 8, int(0.7 * CAP)
+    sel = None
     if from_frames:
-        # camera frames live in HBM as u8; the seam tensors (for calibration, the per-layer pass, parity and the CPU baseline)
-        # come from the same device pre-processing the timed step runs
-        h_cam = [cam_frames(S, 1000 * rank + 10 + p) for p in range(P)]
+        # Camera frames live in HBM as u8; the seam tensors (calibration, per-layer pass, parity, CPU baseline) come from the same
+        # device pre-processing the timed step runs.  The workload's frames are DRAWN from the seeded generator and KEPT when their
+        # candidate count at the calibrated threshold lies in [LO, HI]: random weights fire on whole uniform regions, so some
+        # generated frames would carry thousands of candidates (past any arena -- work truncated) and others none (no work for NMS
+        # and ByteTrack); a detector on road scenes gives tens per frame.  The threshold is the median frame's (TARGET anchors).
+        def seam_of(cam):
+            dc = L.DeviceBuffer.from_array(cam)
+            dt_ = L.DeviceBuffer(len(cam) * 3 * 640 * 640 * 4)
+            lt_ = L.DeviceBuffer(len(cam) * 3 * 320 * 1600 * 4)
+            L.check(L.lib().adas_preprocess_yolo(dc.ptr, len(cam), 720, 1280, dt_.ptr, 640, 640, 1, None))
+            L.check(L.lib().adas_preprocess_ufld(dc.ptr, len(cam), 720, 1280, lt_.ptr, 320, 1600, C.c_double(0.6), None))
+            a = dt_.download((len(cam), 3, 640, 640), np.float32)      # (download synchronises with the null stream)
+            b = lt_.download((len(cam), 3, 320, 1600), np.float32)
+            dc.free(); dt_.free(); lt_.free()
+            return a, b
+        cams, dseam, lseam, bests = [], [], [], []
+        t_cal, need, drawn = None, S * P, 0
+        per_draw = max(S, 32)                       # enough frames for the median that sets the threshold
+        for batch_i in range(8):
+            cam = cam_frames(per_draw, 1000 * rank + 10 + batch_i)
+            drawn += per_draw
+            a, b = seam_of(cam)
+            best = sd.best_logits(a)
+            if t_cal is None:
+                t_cal = SynthDetector.threshold(best, TARGET)
+            ok = np.nonzero((SynthDetector.counts(best, t_cal) >= LO) & (SynthDetector.counts(best, t_cal) <= HI))[0]
+            cams.append(cam[ok]); dseam.append(a[ok]); lseam.append(b[ok]); bests.append(best[ok])
+            if sum(len(c) for c in cams) >= need:
+                break
+        cams, dseam, lseam = (np.concatenate(x)[:need] for x in (cams, dseam, lseam))
+        if len(cams) < need:
+            raise SystemExit(f"bench.py: only {len(cams)} of {drawn} generated frames carry {LO}..{HI} candidates")
+        sel = {"frames_drawn": drawn, "frames_kept": int(need), "kept_if_candidates_in": [LO, HI], "threshold_from": "median of the first batch"}
+        h_cam = [np.ascontiguousarray(cams[p_ * S:(p_ + 1) * S]) for p_ in range(P)]
+        dpool = [np.ascontiguousarray(dseam[p_ * S:(p_ + 1) * S]) for p_ in range(P)]
+        lpool = [np.ascontiguousarray(lseam[p_ * S:(p_ + 1) * S]) for p_ in range(P)]
         d_cam = [L.DeviceBuffer.from_array(a) for a in h_cam]
-        dpool, lpool = [], []
-        for p_ in range(P):
-            dt_ = L.DeviceBuffer(S * 3 * 640 * 640 * 4)
-            lt_ = L.DeviceBuffer(S * 3 * 320 * 1600 * 4)
-            L.check(L.lib().adas_preprocess_yolo(d_cam[p_].ptr, S, 720, 1280, dt_.ptr, 640, 640, 1, None))
-            L.check(L.lib().adas_preprocess_ufld(d_cam[p_].ptr, S, 720, 1280, lt_.ptr, 320, 1600, C.c_double(0.6), None))
-            dpool.append(dt_.download((S, 3, 640, 640), np.float32))      # (download synchronises with the null stream)
-            lpool.append(lt_.download((S, 3, 320, 1600), np.float32))
-            dt_.free(); lt_.free()
     else:
         dpool = [det_frames(S, 1000 * rank + 10 + p) for p in range(P)]
         lpool = [lane_frames(S, 1000 * rank + 50 + p) for p in range(P)]
-    t_build = time.time()
-    # calibrated on EVERY frame that will be timed: none may exceed the post-processor's capacity
-    det_path, Wd, gd = build_detector(M, CE, args.det, np.concatenate(dpool), workdir, f"r{rank}", capacity=CAP)
+        t_cal = SynthDetector.threshold(sd.best_logits(np.concatenate(dpool)), TARGET, CAP)
+    det_path, Wd, gd = sd.finish(t_cal)
     wl = M.SynthWeights(1, gain=M.RELU_RES_GAIN)
     gl = M.build(args.lane, wsrc=wl)
     lane_path = gl.save(os.path.join(workdir, f"{args.lane}_r{rank}.hipm"))
@@ -501,7 +551,7 @@ def main():
                    "kernel_launches_per_step_nets": n_launches,
                    "inputs": ("1280x720 BGR u8 camera frames resident in HBM; letterbox/resize/normalise for both nets run inside the step"
                               if from_frames else "engine-seam NCHW fp32 tensors resident in HBM (pre-processing outside the step)"),
-                   "model_build_s": round(t_build, 1)},
+                   "frame_selection": sel, "model_build_s": round(t_build, 1)},
         "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                      "frac": round(achieved / PEAK_BF16_TFLOPS, 5), "traffic": traffic, "traffic_source": traffic_src,
                      "kernel": dom_name, "launches_per_step": dom_n, "avg_launch_us": round(dom_ms / dom_n * 1e3, 2),

@@ -12,7 +12,7 @@ def model(name, seed=0, **kw):
     """-> (path to .hipm, weights dict name->ndarray, Graph)."""
     key = (name, seed, tuple(sorted(kw.items())))
     if key not in _cache:
-        ws = M.SynthWeights(seed, gain=M.RELU_RES_GAIN if name.startswith("ufld") else M.SILU_GAIN)
+        ws = M.SynthWeights(seed, gain=M.synth_gain(name))
         g = M.build(name, wsrc=ws, **kw)
         d = os.environ.get("ADAS_MODEL_DIR") or tempfile.gettempdir()
         path = os.path.join(d, f"adas_{name}_{seed}_{abs(hash(key)) % 10**8}.hipm")

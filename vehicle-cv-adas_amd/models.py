@@ -39,6 +39,16 @@ HDR_SIZE, BUF_SIZE, OP_SIZE, OUT_SIZE = (struct.calcsize(f) for f in (HDR_FMT, B
 # synthetic activations O(1) through the depth of the nets (measured on the torch oracle).
 SILU_GAIN = 1.15
 RELU_RES_GAIN = 0.8
+# The deeper YOLOv8 scales compound the gain over 2-3x more residual bottlenecks: with 1.15 the synthetic activations of the l
+# scale reach 2e5 (past the fp16 range, and meaningless for a parity test); these keep them at O(100) (measured on the oracle).
+SYNTH_GAINS = {"yolov8m": 1.06, "yolov8l": 1.02, "yolov8x": 1.02}
+
+
+def synth_gain(name):
+    """Gain of the seeded synthetic weights for graph `name` (a trained checkpoint needs none of this)."""
+    if name in SYNTH_GAINS:
+        return SYNTH_GAINS[name]
+    return RELU_RES_GAIN if name.startswith("ufld") else SILU_GAIN
 
 
 class View:
