@@ -15,6 +15,7 @@
 // bias + ReLU epilogue.
 #include "kernels.h"
 #include "elem16.h"
+#include <stdlib.h>
 
 namespace adas {
 
@@ -155,7 +156,7 @@ __global__ __launch_bounds__(64 * KS) void fc_kernel(FcDev a) {
 bool fc_applicable(int prec, int kh, int kw, int stride, int max_n, const TView& in, const TView& out) {
     if (!prec_is16(prec) || in.f32) return false;
     if (kh != 1 || kw != 1 || stride != 1 || in.h != 1 || in.w != 1 || out.h != 1 || out.w != 1) return false;
-    if (max_n > 64) return false;
+    (void)max_n;  // any batch: launches walk the batch in groups of <= 64 rows (the weights stream once per group)
     if ((in.cs & 7) || (in.coff & 7) || (in.c & 7) || (out.c & 3) || (out.cs & 3) || (out.coff & 3)) return false;
     return true;
 }
@@ -167,25 +168,49 @@ static hipError_t fc_launch(const FcDev& d, hipStream_t st) {
     return hipGetLastError();
 }
 
-hipError_t launch_fc(const ConvArgs& a, hipStream_t st) {
-    FcDev d;
-    d.x = (const uint16_t*)a.in.p; d.w = (const uint16_t*)a.wgt; d.bias = a.bias; d.out = a.out.p;
-    d.x_cs = a.in.cs; d.x_coff = a.in.coff; d.out_cs = a.out.cs; d.out_coff = a.out.coff;
-    d.batch = a.n; d.cout = a.out.c; d.kpad = a.kpad; d.act = a.act; d.out_f32 = a.out.f32;
-    const int tm = a.n <= 16 ? 1 : (a.n <= 32 ? 2 : 4);
+static int fc_wide_ks() {  // K split of the wide (weight-streaming) path at 33..64 rows; ADAS_FC_KS overrides (1 | 2 | 4)
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("ADAS_FC_KS");
+        v = e ? atoi(e) : 1;   // measured at 64 rows on cls.3 (374 MB of weights): 1 -> 95.7 us, 2 -> 98.9 us, 4 -> 120.9 us
+        if (v != 1 && v != 2 && v != 4) v = 1;
+    }
+    return v;
+}
+
+template <typename E>
+static hipError_t fc_launch_rows(const FcDev& d, int cout, hipStream_t st) {
+    const int tm = d.batch <= 16 ? 1 : (d.batch <= 32 ? 2 : 4);
     // few output tiles (cls.1: 2048 features): 16 features per workgroup, K split over 4 waves
-    const bool split = a.out.c <= 8192;
-    ADAS_DISPATCH_E16(a.prec == PREC_FP16, E, {
-        if (split) {
-            if (tm == 1) return fc_launch<E, 1, 1, 4, 4>(d, st);
-            if (tm == 2) return fc_launch<E, 1, 2, 4, 4>(d, st);
-            return fc_launch<E, 1, 4, 4, 4>(d, st);
-        }
-        if (tm == 1) return fc_launch<E, 4, 1, 1, 4>(d, st);
-        if (tm == 2) return fc_launch<E, 4, 2, 1, 4>(d, st);
-        return fc_launch<E, 4, 4, 1, 3>(d, st);
-    });
-    return hipErrorInvalidValue;
+    if (cout <= 8192) {
+        if (tm == 1) return fc_launch<E, 1, 1, 4, 4>(d, st);
+        if (tm == 2) return fc_launch<E, 1, 2, 4, 4>(d, st);
+        return fc_launch<E, 1, 4, 4, 4>(d, st);
+    }
+    if (tm == 1) return fc_launch<E, 4, 1, 1, 4>(d, st);
+    if (tm == 2) return fc_launch<E, 4, 2, 1, 4>(d, st);
+    // 33..64 rows: 3.9 TB/s on cls.3.  Splitting K over the waves of a workgroup (more resident waves, partial sums through LDS)
+    // was measured and does not help (see fc_wide_ks): the launch is not short of bytes in flight.
+    const int ks = fc_wide_ks();
+    if (ks == 4) return fc_launch<E, 4, 4, 4, 3>(d, st);
+    if (ks == 2) return fc_launch<E, 4, 4, 2, 3>(d, st);
+    return fc_launch<E, 4, 4, 1, 3>(d, st);
+}
+
+hipError_t launch_fc(const ConvArgs& a, hipStream_t st) {
+    for (int r0 = 0; r0 < a.n; r0 += 64) {  // groups of <= 64 batch rows
+        FcDev d;
+        const int rows = a.n - r0 < 64 ? a.n - r0 : 64;
+        const size_t osz = a.out.f32 ? 4 : 2;
+        d.x = (const uint16_t*)a.in.p + (size_t)r0 * a.in.cs;
+        d.w = (const uint16_t*)a.wgt; d.bias = a.bias;
+        d.out = (char*)a.out.p + (size_t)r0 * a.out.cs * osz;
+        d.x_cs = a.in.cs; d.x_coff = a.in.coff; d.out_cs = a.out.cs; d.out_coff = a.out.coff;
+        d.batch = rows; d.cout = a.out.c; d.kpad = a.kpad; d.act = a.act; d.out_f32 = a.out.f32;
+        hipError_t e = a.prec == PREC_FP16 ? fc_launch_rows<Fp16>(d, a.out.c, st) : fc_launch_rows<Bf16>(d, a.out.c, st);
+        if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
 }
 
 // fp32 [cout][cin] -> bf16 fragment order [cout_pad/16][kpad/32][64 lanes][8]: lane = (k%32/8)*16 + row%16

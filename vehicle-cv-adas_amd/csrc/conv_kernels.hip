@@ -412,7 +412,7 @@ hipError_t launch_conv(const ConvArgs& a, int prec, hipStream_t st) {
         return launch_conv_halo(a, st);
     }
     if (pl.kernel == CONV_PW) return launch_conv_pw(a, st);
-    if (pl.kernel == CONV_FC) return (a.res_mode == RES_NONE && a.n <= 64) ? launch_fc(a, st) : hipErrorInvalidValue;
+    if (pl.kernel == CONV_FC) return a.res_mode == RES_NONE ? launch_fc(a, st) : hipErrorInvalidValue;
     ConvDev d;
     d.in = a.in.p; d.wgt = a.wgt; d.bias = a.bias; d.out = a.out.p; d.res = a.res.p;
     d.in_cs = a.in.cs; d.in_coff = a.in.coff; d.cin = a.in.c; d.H = a.in.h; d.W = a.in.w;
