@@ -189,7 +189,9 @@ typedef struct {
     int32_t grid_row, cls_row, grid_col, cls_col; /* 200,72,100,81 (CULane) */
     int32_t img_w, img_h;                         /* source image size the points are scaled to */
     int32_t local_width;                          /* 1 */
-    int32_t reserved;
+    int32_t num_lanes;                            /* last tensor dimension: 4 (CULane / Tusimple), 10 (CurveLanes configs,
+                                                   * configs/curvelanes_res18.py:25); 0 = 4.  Lanes 1,2 (rows) and 0,3 (columns)
+                                                   * are decoded whatever the count (ultrafastLaneDetectorV2.py:141-142) */
     const double* h_row_anchor;                   /* [cls_row] cfg.row_anchor (host) */
     const double* h_col_anchor;                   /* [cls_col] cfg.col_anchor (host) */
 } adas_ufld_params;

@@ -22,6 +22,10 @@ class ModelConfig:
             self.img_w, self.img_h, self.griding_num, self.crop_ratio = 1600, 320, 200, 0.6
             self.row_anchor = np.linspace(0.42, 1, 72)
             self.col_anchor = np.linspace(0, 1, 81)
+        elif name == "curvelanes":                          # :41-47
+            self.img_w, self.img_h, self.griding_num, self.crop_ratio = 1600, 800, 200, 0.8
+            self.row_anchor = np.linspace(0.4, 1, 72)
+            self.col_anchor = np.linspace(0, 1, 81)
         else:
             raise ValueError(name)
         self.num_lanes = 4

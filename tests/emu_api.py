@@ -70,7 +70,7 @@ def ufld(outs, cfg, W, H, lw=1):
     cnt = np.zeros(4, np.int32); det = np.zeros(4, np.int32); pts = np.zeros((4, 128, 2), np.int32)
     ra = np.ascontiguousarray(cfg.row_anchor, np.float64); ca = np.ascontiguousarray(cfg.col_anchor, np.float64)
     lib().emu_ufld(_p(lr), _p(lc), _p(er), _p(ec), lr.shape[1], lr.shape[2], lc.shape[1], lc.shape[2], W, H, lw,
-                   _p(ra), _p(ca), _p(cnt), _p(det), _p(pts))
+                   _p(ra), _p(ca), _p(cnt), _p(det), _p(pts), int(lr.shape[3]))
     return [[(int(x), int(y)) for x, y in pts[i, :cnt[i]]] for i in range(4)], [bool(d) for d in det]
 
 

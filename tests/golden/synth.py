@@ -69,6 +69,40 @@ def synth_ufld(seed, lanes=((1, 60, .4), (2, 140, -.4)), cols=(), boost=True):
     return [loc_row, loc_col, exist_row, exist_col]
 
 
+def synth_ufld_curve(seed, lanes=((1, 60, .4), (2, 140, -.4)), cols=((0, 30, .5),), extra=((5, 100, .2), (9, 20, .1))):
+    """CurveLanes-configuration heads (configs/curvelanes_res18.py): (1,200,72,10), (1,100,41,10), (1,2,72,10), (1,2,41,10).  `extra`
+    lanes (index >= 4) carry strong responses too: the reference ignores them (it decodes lanes 1,2 / 0,3 only)."""
+    rng = np.random.default_rng(seed)
+    R, C, NL = 72, 41, 10
+    loc_row = rng.normal(0, 1, (1, 200, R, NL)).astype(np.float32)
+    loc_col = rng.normal(0, 1, (1, 100, C, NL)).astype(np.float32)
+    exist_row = rng.normal(0, 1, (1, 2, R, NL)).astype(np.float32)
+    exist_col = rng.normal(0, 1, (1, 2, C, NL)).astype(np.float32)
+    for lane, x0, slope in tuple(lanes) + tuple(extra):
+        for k in range(R):
+            g = max(0, min(199, int(x0 + slope * k)))
+            loc_row[0, g, k, lane] += 8
+            if g + 1 <= 199:
+                loc_row[0, g + 1, k, lane] += 6
+            exist_row[0, 1, k, lane] += 5
+    for lane, y0, slope in cols:
+        for k in range(C):
+            g = max(0, min(99, int(y0 + slope * k)))
+            loc_col[0, g, k, lane] += 8
+            if g >= 1:
+                loc_col[0, g - 1, k, lane] += 5
+            exist_col[0, 1, k, lane] += 5
+    return [loc_row, loc_col, exist_row, exist_col]
+
+
+def curve_cases():
+    """(tag, heads, img_w, img_h)"""
+    return [("c1", synth_ufld_curve(40), 1280, 720),
+            ("c2", synth_ufld_curve(41, lanes=((1, 20, 1.2), (2, 190, -1.5)), cols=((0, 30, .5), (3, 80, -.6))), 1920, 1080),
+            ("c3", synth_ufld_curve(42, lanes=(), cols=()), 1280, 720),
+            ("c4", synth_ufld_curve(43, lanes=((2, 100, 0.0),), cols=((3, 99, 0.0),), extra=((4, 50, .3), (7, 150, -.3))), 2560, 1440)]
+
+
 def track_scene(seed, n_obj, n_frames, drop=0.1, W=1280, H=720):
     """Constant-velocity rectangles + N(0,1) jitter + dropout; int xyxy like RectInfo.tolist()."""
     rng = np.random.default_rng(seed)

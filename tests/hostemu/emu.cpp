@@ -43,10 +43,10 @@ int emu_yolo_post(const float* head, int layout, int A, int nc, double box_score
 
 int emu_ufld(const float* loc_row, const float* loc_col, const float* exist_row, const float* exist_col,
              int grid_row, int cls_row, int grid_col, int cls_col, int img_w, int img_h, int lw,
-             const double* row_anchor, const double* col_anchor, int* lane_cnt, int* lane_det, int* lane_pts) {
-    UfldCfg cfg{grid_row, cls_row, grid_col, cls_col, 4, img_w, img_h, lw, row_anchor, col_anchor};
+             const double* row_anchor, const double* col_anchor, int* lane_cnt, int* lane_det, int* lane_pts, int num_lanes) {
+    UfldCfg cfg{grid_row, cls_row, grid_col, cls_col, num_lanes, img_w, img_h, lw, row_anchor, col_anchor};
     UfldFrame f{loc_row, loc_col, exist_row, exist_col, lane_cnt, lane_det, lane_pts};
-    std::vector<double> lds(UfldLds::bytes(cls_row, cls_col) / 8 + 2);
+    std::vector<double> lds(UfldLds::bytes(cls_row, cls_col, num_lanes) / 8 + 2);
     Ctx c{0, 1};
     ufld_decode_frame(c, cfg, f, lds.data());
     return 0;

@@ -36,7 +36,7 @@ class YoloCounts(C.Structure):
 
 class UfldParams(C.Structure):
     _fields_ = [("grid_row", C.c_int32), ("cls_row", C.c_int32), ("grid_col", C.c_int32), ("cls_col", C.c_int32),
-                ("img_w", C.c_int32), ("img_h", C.c_int32), ("local_width", C.c_int32), ("reserved", C.c_int32),
+                ("img_w", C.c_int32), ("img_h", C.c_int32), ("local_width", C.c_int32), ("num_lanes", C.c_int32),
                 ("h_row_anchor", C.c_void_p), ("h_col_anchor", C.c_void_p)]
 
 

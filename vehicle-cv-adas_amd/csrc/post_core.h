@@ -659,7 +659,7 @@ struct UfldLds {
     int* amax;           // [ (cls_row + cls_col) * 4 ]
     unsigned char* val;  // same count
     int* cnt;            // [8]: valid counts row lanes 0..3, col lanes 0..3
-    static ADAS_HD size_t bytes(int cr, int cc) { return (size_t)(cr + cc) * 4 * 5 + 64; }
+    static ADAS_HD size_t bytes(int cr, int cc, int lanes = 4) { return (size_t)(cr + cc) * lanes * 5 + 64; }
 };
 
 ADAS_DEV double ufld_expect(const float* loc, int stride, int m, int G, int lw) {
@@ -728,9 +728,9 @@ ADAS_DEV void ufld_decode_frame(const Ctx& c, const UfldCfg& cfg, const UfldFram
         L.val[t] = ex[stride] > ex[0] ? 1 : 0;
     }
     c.sync();
-    ADAS_PAR_FOR(c, q, 0, 2 * NL) {  // valid-anchor count per (row | column, lane)
-        const bool row = q < NL;
-        const int i = row ? q : q - NL, K = row ? R : C, base = row ? 0 : nr;
+    ADAS_PAR_FOR(c, q, 0, 2 * 4) {  // valid-anchor count per (row | column, lane) for the four decoded lanes (NL >= 4 may be larger)
+        const bool row = q < 4;
+        const int i = row ? q : q - 4, K = row ? R : C, base = row ? 0 : nr;
         int n = 0;
         for (int k = 0; k < K; ++k) n += L.val[base + k * NL + i];
         L.cnt[(row ? 0 : 4) + i] = n;
@@ -764,7 +764,7 @@ ADAS_DEV void ufld_decode_frame(const Ctx& c, const UfldCfg& cfg, const UfldFram
         f.lane_pts[(i * ADAS_UFLD_MAXPTS + slot) * 2 + 0] = px;
         f.lane_pts[(i * ADAS_UFLD_MAXPTS + slot) * 2 + 1] = py;
     }
-    ADAS_PAR_FOR(c, i, 0, NL) {
+    ADAS_PAR_FOR(c, i, 0, 4) {
         const bool row = (i == 1 || i == 2);
         const int cnt = L.cnt[(row ? 0 : 4) + i];
         const bool enough = row ? ((double)cnt > (double)R / 2) : ((double)cnt > (double)C / 4);

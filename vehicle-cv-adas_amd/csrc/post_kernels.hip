@@ -502,10 +502,12 @@ int adas_ufld_decode_create(const adas_ufld_params* p, int max_batch, adas_ufld_
     ADAS_REQUIRE(p->cls_row > 0 && p->cls_col > 0 && p->cls_row <= ADAS_UFLD_MAXPTS && p->cls_col <= ADAS_UFLD_MAXPTS,
                  ADAS_ERR_INVALID, "anchor counts must be in [1, %d]", ADAS_UFLD_MAXPTS);
     ADAS_REQUIRE(p->grid_row > 1 && p->grid_col > 1 && p->local_width >= 0 && p->local_width <= 3, ADAS_ERR_INVALID, "bad grid / local_width");
+    ADAS_REQUIRE(p->num_lanes == 0 || (p->num_lanes >= 4 && p->num_lanes <= 16), ADAS_ERR_INVALID, "num_lanes must be 0 (= 4) or in [4, 16]");
     ADAS_REQUIRE(adas_device_count() > 0, ADAS_ERR_NO_DEVICE, "no HIP device visible; this library has no CPU fallback");
     adas_ufld_decode* h = new (std::nothrow) adas_ufld_decode();
     ADAS_REQUIRE(h, ADAS_ERR_INVALID, "out of host memory");
     h->p = *p;
+    if (h->p.num_lanes == 0) h->p.num_lanes = 4;
     h->max_batch = max_batch;
     h->v1 = 0;
     h->last = 0;
@@ -522,7 +524,7 @@ int adas_ufld_decode_create(const adas_ufld_params* p, int max_batch, adas_ufld_
     hipMemcpy(ra, p->h_row_anchor, p->cls_row * 8, hipMemcpyHostToDevice);
     hipMemcpy(ca, p->h_col_anchor, p->cls_col * 8, hipMemcpyHostToDevice);
     UfldDev& d = h->dev;
-    d.cfg = UfldCfg{p->grid_row, p->cls_row, p->grid_col, p->cls_col, 4, p->img_w, p->img_h, p->local_width, ra, ca};
+    d.cfg = UfldCfg{p->grid_row, p->cls_row, p->grid_col, p->cls_col, h->p.num_lanes, p->img_w, p->img_h, p->local_width, ra, ca};
     d.lane_cnt = carve<int>(q, B * 4);
     d.lane_det = carve<int>(q, B * 4);
     d.lane_pts = carve<int>(q, B * 4 * ADAS_UFLD_MAXPTS * 2);
@@ -580,7 +582,7 @@ int adas_ufld_decode_expected_outputs(const adas_ufld_decode* h, int64_t dims[4]
     }
     // model_culane.py:56-59: loc_row (1,G_r,K_r,4), loc_col (1,G_c,K_c,4), exist_row (1,2,K_r,4), exist_col (1,2,K_c,4)
     const int64_t g[4] = {h->p.grid_row, h->p.grid_col, 2, 2}, k[4] = {h->p.cls_row, h->p.cls_col, h->p.cls_row, h->p.cls_col};
-    for (int i = 0; i < 4; ++i) { dims[i][0] = 1; dims[i][1] = g[i]; dims[i][2] = k[i]; dims[i][3] = 4; }
+    for (int i = 0; i < 4; ++i) { dims[i][0] = 1; dims[i][1] = g[i]; dims[i][2] = k[i]; dims[i][3] = h->p.num_lanes; }
     return 4;
 }
 int adas_ufld1_decode_set_source_size(adas_ufld_decode* h, int src_w, int src_h) {
@@ -610,7 +612,7 @@ int adas_ufld_decode_run(adas_ufld_decode* h, const float* lr, const float* lc, 
     UfldDev d = h->dev;
     d.loc_row = lr; d.loc_col = lc; d.exist_row = er; d.exist_col = ec;
     d.s_lr = s_lr; d.s_lc = s_lc; d.s_er = s_er; d.s_ec = s_ec;
-    size_t lds = UfldLds::bytes(h->p.cls_row, h->p.cls_col);
+    size_t lds = UfldLds::bytes(h->p.cls_row, h->p.cls_col, h->p.num_lanes);
     hipLaunchKernelGGL(ufld_decode_kernel, dim3(batch), dim3(640), lds, st, d);
     ADAS_HIP_TRY(hipGetLastError());
     return ADAS_OK;

@@ -352,7 +352,10 @@ class UltrafastLaneDetectorV2(_Defaults):
         self.lane_info = LaneInfo(np.array([], dtype=object), np.array([], dtype=object), np.array([], dtype=object), False)
         if None not in [model_path, model_type]:
             self.model_path, self.model_type = model_path, model_type
-        if self.model_type not in [LaneModelType.UFLDV2_TUSIMPLE, LaneModelType.UFLDV2_CULANE]:
+        # The reference class rejects everything but Tusimple / CULane (ultrafastLaneDetectorV2.py:69-72) although its ModelConfig
+        # carries a CurveLanes entry (:41-47) and exportLib ships the CurveLanes configs; that model type is accepted here (a
+        # superset: the engine + decoder handle its 800x1600 input and 10-lane heads), any other type fails as in the reference.
+        if self.model_type not in [LaneModelType.UFLDV2_TUSIMPLE, LaneModelType.UFLDV2_CULANE, LaneModelType.UFLDV2_CURVELANES]:
             raise Exception("UltrafastLaneDetectorV2 can't use %s type." % self.model_type.name)
         self.cfg = ModelConfig(self.model_type)
         self.precision = precision
@@ -378,7 +381,8 @@ class UltrafastLaneDetectorV2(_Defaults):
             if self._decode is not None:
                 self._decode.close()
             lr, lc = self.output_shape[0], self.output_shape[1]
-            self._decode = UfldDecode(lr[1], lr[2], lc[1], lc[2], key[1], key[0], self.cfg.row_anchor, self.cfg.col_anchor, 1, 1)
+            self._decode = UfldDecode(lr[1], lr[2], lc[1], lc[2], key[1], key[0], self.cfg.row_anchor, self.cfg.col_anchor, 1, 1,
+                                      num_lanes=lr[3])
             self._decode_key = key
         return self._decode
 

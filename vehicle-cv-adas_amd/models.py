@@ -511,6 +511,11 @@ def ufld_v1(backbone="18", in_h=288, in_w=800, griding_num=100, cls_num_per_lane
 
 UFLD1_CULANE = dict(griding_num=200, cls_num_per_lane=18)
 TUSIMPLE = dict(in_h=320, in_w=800, num_grid_row=100, num_cls_row=56, num_grid_col=100, num_cls_col=41, fc_norm=False)
+# CurveLanes configuration (configs/curvelanes_res18.py:25-36): 1600x800 input, 200/100 grid cells, 72/41 anchors, 10 lanes, LayerNorm.
+# The reference exports every UFLDv2 config through model_culane.parsingNet (convertPytorchToONNX.py:65-70: the model_curvelanes
+# branch is commented out "TODO : not done"), so this is the same graph at another geometry: 25x50 layer4 maps, Linear 10000 -> 2048
+# -> 187,260.
+CURVELANES = dict(in_h=800, in_w=1600, num_grid_row=200, num_cls_row=72, num_grid_col=100, num_cls_col=41, num_lanes=10, fc_norm=True)
 
 BUILDERS = {
     "yolov8n": lambda **k: yolov8("n", **k), "yolov8s": lambda **k: yolov8("s", **k),
@@ -524,6 +529,7 @@ BUILDERS = {
     "ufld_v1_res18": lambda **k: ufld_v1("18", **k), "ufld_v1_res34": lambda **k: ufld_v1("34", **k),
     "ufld_v1_culane_res18": lambda **k: ufld_v1("18", **dict(UFLD1_CULANE, **k)),
     "ufldv2_tusimple_res18": lambda **k: ufldv2("18", **dict(TUSIMPLE, **k)), "ufldv2_tusimple_res34": lambda **k: ufldv2("34", **dict(TUSIMPLE, **k)),
+    "ufldv2_curvelanes_res18": lambda **k: ufldv2("18", **dict(CURVELANES, **k)), "ufldv2_curvelanes_res34": lambda **k: ufldv2("34", **dict(CURVELANES, **k)),
 }
 
 

@@ -46,8 +46,9 @@ class AdasPipeline:
                 self.decode = Ufld1Decode(cfg["griding_num"], cfg["cls_num_per_lane"], cfg["img_w"], cfg["img_h"], ish[3], ish[2],
                                           src_hw[1], src_hw[0], cfg["row_anchor"], n_streams)
             else:
+                nl = self.lane.get_engine_output_shape()[0][0][3]
                 self.decode = UfldDecode(cfg["grid_row"], cfg["cls_row"], cfg["grid_col"], cfg["cls_col"], src_hw[1], src_hw[0],
-                                         cfg["row_anchor"], cfg["col_anchor"], 1, n_streams)
+                                         cfg["row_anchor"], cfg["col_anchor"], 1, n_streams, num_lanes=nl)
             if geometry is not None:
                 self.geometry = LaneGeometry(src_hw[0], geometry["bird_wh"], geometry["M"], geometry.get("adjust_lanes", True), n_streams)
         d = L.PipelineDesc(self.det.handle if self.det else None, self.lane.handle if self.lane else None,

@@ -85,10 +85,14 @@ class YoloPost:
 
 class UfldDecode:
     def __init__(self, grid_row, cls_row, grid_col, cls_col, img_w, img_h, row_anchor, col_anchor, local_width=1,
-                 max_batch=1):
-        ra = np.ascontiguousarray(row_anchor, np.float64)
-        ca = np.ascontiguousarray(col_anchor, np.float64)
-        p = L.UfldParams(grid_row, cls_row, grid_col, cls_col, img_w, img_h, local_width, 0, L.ptr(ra), L.ptr(ca))
+                 max_batch=1, num_lanes=4):
+        """row_anchor / col_anchor: at least cls_row / cls_col entries; the first cls_* are used, as the reference indexes
+        cfg.*_anchor[k] with the network's own k (ultrafastLaneDetectorV2.py:152,170 -- its CurveLanes ModelConfig carries 81
+        column anchors for a 41-anchor head).  num_lanes: the tensors' last dimension (4; 10 for the CurveLanes configs)."""
+        ra = np.ascontiguousarray(np.asarray(row_anchor, np.float64)[:cls_row])
+        ca = np.ascontiguousarray(np.asarray(col_anchor, np.float64)[:cls_col])
+        assert len(ra) == cls_row and len(ca) == cls_col, "anchor arrays shorter than the head's anchor counts"
+        p = L.UfldParams(grid_row, cls_row, grid_col, cls_col, img_w, img_h, local_width, int(num_lanes), L.ptr(ra), L.ptr(ca))
         self.dims = (grid_row, cls_row, grid_col, cls_col)
         h = C.c_void_p()
         L.check(L.lib().adas_ufld_decode_create(C.byref(p), max_batch, C.byref(h)))
