@@ -115,8 +115,9 @@ def run_case(tag, kind, depth, kw):
     import torch
     if kind == "v2":
         from exportLib.ultrafastLaneV2.model_culane import parsingNet
+        nl = kw.get("lanes", 4)
         net = parsingNet(pretrained=False, backbone=depth, num_grid_row=kw["grid_row"], num_cls_row=kw["cls_row"],
-                         num_grid_col=kw["grid_col"], num_cls_col=kw["cls_col"], num_lane_on_row=4, num_lane_on_col=4, use_aux=False,
+                         num_grid_col=kw["grid_col"], num_cls_col=kw["cls_col"], num_lane_on_row=nl, num_lane_on_col=nl, use_aux=False,
                          input_height=kw["in_h"], input_width=kw["in_w"], fc_norm=kw["fc_norm"])
         sd = UP.ufldv2_state(UP.SEED, depth, **kw)
         h, w = kw["in_h"], kw["in_w"]

@@ -124,6 +124,8 @@ CASES = [
     ("v2_r34_culane", "v2", "34", dict(in_h=320, in_w=1600, grid_row=200, cls_row=72, grid_col=100, cls_col=81, fc_norm=True)),
     ("v2_r18_tusimple", "v2", "18", dict(in_h=320, in_w=800, grid_row=100, cls_row=56, grid_col=100, cls_col=41, fc_norm=False)),
     ("v1_r18_tusimple", "v1", "18", dict(griding_num=100, cls_per_lane=56)),
+    # CurveLanes configuration (configs/curvelanes_res18.py: 72/41 anchors, 10 lanes, LayerNorm) at a reduced input
+    ("v2_r18_curvelanes_small", "v2", "18", dict(in_h=256, in_w=512, grid_row=200, cls_row=72, grid_col=100, cls_col=41, lanes=10, fc_norm=True)),
 ]
 SEED = 20240
 SAMPLE = 4096   # values kept per output tensor (evenly strided over the flattened tensor)

@@ -24,7 +24,7 @@ def yolo_post(head, layout, lb, box_score, iou, nms_mode=0, cap=1024, batch_copi
 
 def ufld(outs, cfg, W, H, lw=1):
     lr, lc = outs[0], outs[1]
-    ud = PP.UfldDecode(lr.shape[1], lr.shape[2], lc.shape[1], lc.shape[2], W, H, cfg.row_anchor, cfg.col_anchor, lw)
+    ud = PP.UfldDecode(lr.shape[1], lr.shape[2], lc.shape[1], lc.shape[2], W, H, cfg.row_anchor, cfg.col_anchor, lw, num_lanes=lr.shape[3])
     try:
         return ud.run_host(outs)[0]
     finally:

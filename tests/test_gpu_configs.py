@@ -145,6 +145,37 @@ def test_yolov8n_and_ufld_small_16bit_modes(prec, tol):
     le.close()
 
 
+def test_ufldv2_curvelanes_configuration_net_and_drop_in(tmp_path):
+    """The CurveLanes configuration (configs/curvelanes_res18.py: 10 lanes, 41 column anchors, LayerNorm; same parsingNet as CULane,
+    convertPytorchToONNX.py:65-70) at a reduced input: network vs oracle in fp32, then frame -> lanes through the drop-in class with
+    LaneModelType.UFLDV2_CURVELANES vs the oracle chain."""
+    from oracle import preprocess, ufld_decode
+    D = importlib.import_module("adas_amd.detectors")
+    kw = dict(in_h=256, in_w=512)
+    path, W, g = netutil.model("ufldv2_curvelanes_res18", **kw)
+    x = netutil.lane_frames(2, 256, 512, seed=4)
+    want = nets.ufldv2_forward(x, W, "18", 200, 72, 100, 41, num_lanes=10)
+    e = CE.HipEngine(path, precision="fp32", max_batch=2)
+    shapes, names = e.get_engine_output_shape()
+    assert shapes == [[1, 200, 72, 10], [1, 100, 41, 10], [1, 2, 72, 10], [1, 2, 41, 10]]
+    for o, w, nm in zip(e.engine_inference(x), want, names):
+        err, rel = report("ufldv2-curvelanes fp32 " + nm, o, w)
+        assert err <= 1e-3 * max(1.0, float(np.abs(w).max())), nm
+    e.close()
+    det = D.UltrafastLaneDetectorV2(path, D.LaneModelType.UFLDV2_CURVELANES, precision="fp32")
+    assert det.cfg.crop_ratio == 0.8 and len(det.cfg.col_anchor) == 81
+    rng = np.random.default_rng(5)
+    frame = rng.integers(0, 255, (720, 1280, 3), dtype=np.uint8)
+    det.DetectFrame(frame, adjust_lanes=False)
+    outs = nets.ufldv2_forward(preprocess.ufld_prepare_input(frame, (256, 512), 0.8), W, "18", 200, 72, 100, 41, num_lanes=10)
+    wl, ws = ufld_decode.process_output(outs, ufld_decode.ModelConfig("curvelanes"), 1280, 720)
+    assert [bool(s) for s in det.lane_info.lanes_status] == list(ws)
+    for a, b in zip(det.lane_info.lanes_points, wl):
+        a = np.asarray(a, np.int64).reshape(-1, 2); b = np.asarray(b, np.int64).reshape(-1, 2)
+        assert a.shape == b.shape and np.abs(a - b).max(initial=0) <= 1
+    det.close()
+
+
 def test_fp16_packed_input_equals_fp32_seam_input():
     """adas_preprocess_*_packed_prec(FP16) writes exactly the half pixels the fp16 stem makes of the fp32 seam tensor."""
     import ctypes as C

@@ -139,6 +139,21 @@ def test_ufld(G, case):
         assert len(got_l[li]) == len(g[f"{tag}_lane{li}"])
 
 
+@pytest.mark.parametrize("case", synth.curve_cases(), ids=lambda c: c[0])
+def test_ufld_curvelanes_geometry(G, case):
+    """CurveLanes configuration (configs/curvelanes_res18.py: 72/41 anchors, 10 lanes) through adas_ufld_decode_* with
+    num_lanes = 10, vs the oracle and the reference's own run (ufld_curve_decode.npz)."""
+    tag, outs, W, H = case
+    cfg = ufld_decode.ModelConfig("curvelanes")
+    want_l, want_s = ufld_decode.process_output(outs, cfg, W, H)
+    got_l, got_s = G.ufld(outs, cfg, W, H)
+    assert pc.check_lanes(got_l, got_s, want_l, want_s, tol_px=1) <= 2
+    g = np.load(os.path.join(GOLDEN, "ufld_curve_decode.npz"))
+    assert got_s == g[tag + "_status"].tolist()
+    for li in range(4):
+        assert len(got_l[li]) == len(g[f"{tag}_lane{li}"])
+
+
 @pytest.mark.parametrize("case", synth.ufld1_cases(), ids=lambda c: c[0])
 def test_ufld_v1(G, case):
     """UFLD v1 decoder (adas_ufld1_decode_*) vs the oracle and the reference's own output; +-1 px for the fp32 exp."""

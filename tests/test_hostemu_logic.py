@@ -90,6 +90,16 @@ def test_ufld(case):
     pc.check_lanes(got_l, got_s, want_l, want_s, tol_px=0)
 
 
+@pytest.mark.parametrize("case", synth.curve_cases(), ids=lambda c: c[0])
+def test_ufld_curvelanes_ten_lane_heads(case):
+    """The decoder logic on 10-lane tensors (CurveLanes configuration): lane stride 10, lanes 1,2 / 0,3 decoded."""
+    tag, outs, W, H = case
+    cfg = ufld_decode.ModelConfig("curvelanes")
+    want_l, want_s = ufld_decode.process_output(outs, cfg, W, H)
+    got_l, got_s = emu_api.ufld(outs, cfg, W, H)
+    pc.check_lanes(got_l, got_s, want_l, want_s, tol_px=1)
+
+
 @pytest.mark.parametrize("case", synth.ufld1_cases(), ids=lambda c: c[0])
 def test_ufld_v1(case):
     """UFLD v1 decode logic (host build; exp in libm double then rounded, NumPy's is fp32 SIMD): +-1 px."""

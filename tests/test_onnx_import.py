@@ -218,6 +218,15 @@ def test_fp16_export_and_input_size_checks(tmp_path):
     hdr = struct.unpack(M.HDR_FMT, open(out, "rb").read(M.HDR_SIZE))
     assert hdr[8] == (8 | (1 << 16))                      # in_cpad word: bit 16 = float16 model I/O
     assert struct.unpack(M.HDR_FMT, g0.tobytes()[:M.HDR_SIZE])[8] == 8
+    # an fp32 file converted with io_half=True: the onnxQuantization.py counterpart
+    f32 = tmp_path / "full.onnx"
+    inits32 = []
+    for base in (k[:-7] for k in ws.store if k.endswith(".weight")):
+        inits32 += [OW.tensor(base + ".weight", ws.store[base + ".weight"]), OW.tensor(base + ".bias", ws.store[base + ".bias"])]
+    f32.write_bytes(OW.model(nodes, inits32, [("images", [1, 3, 640, 640])], [("output0", [1, 84, 8400])]))
+    _, g32 = OI.convert(str(f32), str(tmp_path / "full.hipm"))
+    _, g16 = OI.convert(str(f32), str(tmp_path / "full_fp16.hipm"), io_half=True)
+    assert not g32.io_half and g16.io_half
     # non-square
     q = tmp_path / "rect.onnx"
     A = 48 * 80 + 24 * 40 + 12 * 20

@@ -93,6 +93,20 @@ def test_ufld_decode(case):
     np.testing.assert_array_equal(np.asarray(area, np.int64).reshape(-1, 2), g[tag + "_area"])
 
 
+@pytest.mark.parametrize("case", synth.curve_cases(), ids=lambda c: c[0])
+def test_ufld_decode_curvelanes_geometry(case):
+    """10-lane heads of the CurveLanes configuration through the reference's own __process_output (make_golden_curvelanes.py):
+    lanes 1,2 / 0,3 decoded, the other six ignored, the 81-entry column-anchor table indexed by the 41-anchor head."""
+    tag, outs, W, H = case
+    g = np.load(os.path.join(GOLDEN, "ufld_curve_decode.npz"))
+    assert "".join(synth.digest(o) for o in outs) == str(g[tag + "_sha1"])
+    cfg = ufld_decode.ModelConfig("curvelanes")
+    lanes, status = ufld_decode.process_output(outs, cfg, W, H)
+    assert status == g[tag + "_status"].tolist()
+    for li in range(4):
+        np.testing.assert_array_equal(np.asarray(lanes[li], np.int64).reshape(-1, 2), g[f"{tag}_lane{li}"])
+
+
 def _load_bt():
     with gzip.open(os.path.join(GOLDEN, "bytetrack.json.gz"), "rt") as f:
         return json.load(f)
@@ -150,7 +164,7 @@ def test_lane_net_oracle_matches_reference_module(case):
         W = UP.fold(UP.ufldv2_state(UP.SEED, depth, **kw))
         x = UP.lane_frame(UP.SEED + 1, kw["in_h"], kw["in_w"])
         taps = {}
-        outs = nets.ufldv2_forward(x, W, depth, kw["grid_row"], kw["cls_row"], kw["grid_col"], kw["cls_col"], 4, taps=taps,
+        outs = nets.ufldv2_forward(x, W, depth, kw["grid_row"], kw["cls_row"], kw["grid_col"], kw["cls_col"], kw.get("lanes", 4), taps=taps,
                                    fc_norm=kw["fc_norm"])
         pool = taps["fea"].numpy()
     else:

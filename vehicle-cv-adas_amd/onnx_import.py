@@ -401,21 +401,32 @@ class OnnxWeights:
         return arr
 
 
-def convert(onnx_path, hipm_path=None):
-    """model.onnx -> model.hipm (returns the path and the Graph)."""
+def convert(onnx_path, hipm_path=None, io_half=None):
+    """model.onnx -> model.hipm (returns the path and the Graph).
+
+    io_half: None = follow the file (an fp16 export declares float16 graph inputs); True = mark the container as a float16 model
+    whatever the file's type -- the counterpart of the reference's onnxQuantization.py:11-41, which rewrites an fp32 ONNX file as
+    `<name>_fp16.onnx` with onnxconverter_common so that OnnxEngine reports engine_dtype float16 (coreEngine.py:168).  Here the
+    weights stay fp32 in the container (the engine converts them to its compute type at load: `precision="fp16"` rounds them to
+    half exactly as the converted file would hold them) and only the I/O contract changes."""
     m = read_onnx(onnx_path)
     arch, kw = detect_arch(m)
     g = M.build(arch, wsrc=OnnxWeights(m, arch), **kw)
     # an fp16 export (onnxQuantization.py:11-41 / ultralytics half=True) declares float16 graph inputs: the reference then feeds and
     # receives float16 arrays (coreEngine.py:168); recorded in the container so HipEngine can report the same engine_dtype
-    g.io_half = bool(m.inputs) and m.elem_types.get(m.inputs[0][0]) == 10
+    g.io_half = (bool(m.inputs) and m.elem_types.get(m.inputs[0][0]) == 10) if io_half is None else bool(io_half)
     hipm_path = hipm_path or os.path.splitext(onnx_path)[0] + ".hipm"
     g.save(hipm_path)
     return hipm_path, g
 
 
 if __name__ == "__main__":
-    if len(sys.argv) < 2:
-        raise SystemExit("usage: python onnx_import.py model.onnx [model.hipm]")
-    p, g = convert(*sys.argv[1:3])
-    print("%s: %s, %d convs, %.2f GFLOP/frame, %.2f M parameters" % (p, g.name, g.n_convs, g.flops / 1e9, g.n_params / 1e6))
+    argv = [a for a in sys.argv[1:] if a != "--half"]
+    half = True if "--half" in sys.argv[1:] else None
+    if len(argv) < 1:
+        raise SystemExit("usage: python onnx_import.py [--half] model.onnx [model.hipm]\n"
+                         "  --half  write `<name>_fp16.hipm`: a float16-I/O model (what onnxQuantization.py produces as <name>_fp16.onnx)")
+    dst = argv[1] if len(argv) > 1 else (os.path.splitext(argv[0])[0] + ("_fp16" if half else "") + ".hipm")
+    p, g = convert(argv[0], dst, io_half=half)
+    print("%s: %s, %d convs, %.2f GFLOP/frame, %.2f M parameters%s" % (p, g.name, g.n_convs, g.flops / 1e9, g.n_params / 1e6,
+                                                                       ", float16 I/O" if g.io_half else ""))
