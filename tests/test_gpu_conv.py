@@ -257,3 +257,18 @@ def test_fp16_fc_kernel(CE, batch):
 def test_fp16_fused_stem_kernel(CE, case):
     rel = run_stem_case(CE, *case, prec="fp16")
     assert rel < FP16_TOL, (case, rel)
+
+
+@pytest.mark.parametrize("case", [
+    # H, W (input), cin, cout, act, batch: the ResNet down-sampling convs with Cin >= 128 and YOLO's, ragged extents, a channel
+    # tail (160 = 5 chunks), at batches that fill the chip (the kernel is chosen only then)
+    (40, 200, 128, 256, M.ACT_RELU, 32), (20, 100, 256, 512, M.ACT_RELU, 72), (40, 40, 128, 256, M.ACT_SILU, 136),
+    (23, 37, 160, 256, M.ACT_SILU, 256), (46, 74, 136, 128, M.ACT_NONE, 136),
+], ids=str)
+@pytest.mark.parametrize("prec,tol", [("bf16", 1e-2), ("fp16", 1.5e-3)])
+def test_conv3x3_s2_parity_plane_kernel(CE, case, prec, tol):
+    """Stride-2 3x3 with Cout % 128 == 0 and Cin >= 128 through conv_halo_s2.hip (window de-interleaved into four parity planes in
+    LDS, 8 waves, 256 output pixels x 128 channels per workgroup)."""
+    H, W, cin, cout, act, batch = case
+    rel, mx = run_case(CE, H, W, cin, cout, 3, 2, act, M.RES_NONE, prec, batch=batch, expect_kernel="conv_s2p_kernel")
+    assert rel < tol, (case, prec, rel, mx)

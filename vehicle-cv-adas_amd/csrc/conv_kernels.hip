@@ -313,6 +313,8 @@ const char* conv_kernel_name(const ConvArgs& a, int prec, int kernel) {
     const char* actn = a.act == ACT_SILU ? "SILU" : (a.act == ACT_RELU ? "RELU" : "NONE");
     if (kernel == CONV_HALO && halo_rw_applicable(a.kh, a.kw, a.stride, a.pad, a.n, a.in, a.out)) {
         snprintf(buf, sizeof(buf), a.out.c <= 32 ? "conv_halo_rw_kernel<%d,%s,bn32>" : "conv_halo_rw_kernel<%d,%s>", (a.in.c + 31) / 32, actn);
+    } else if (kernel == CONV_HALO && halo_s2p_applicable(a.kh, a.kw, a.stride, a.pad, a.res_mode, a.n, a.in, a.out)) {
+        snprintf(buf, sizeof(buf), "conv_s2p_kernel<%s>", actn);
     } else if (kernel == CONV_HALO) {
         snprintf(buf, sizeof(buf), "conv_halo_kernel<%d,%s,s%d>", a.out.c <= 16 ? 16 : (a.out.c <= 32 ? 32 : 64), actn, a.stride);
     } else if (kernel == CONV_FC) {
@@ -408,6 +410,10 @@ hipError_t launch_conv(const ConvArgs& a, int prec, hipStream_t st) {
         if (halo_rw_applicable(a.kh, a.kw, a.stride, a.pad, a.n, a.in, a.out)) {
             hipError_t e = launch_conv_halo_rw(a, st);
             if (e != hipErrorNotSupported) return e;  // e.g. a residual view that is not 16-byte aligned: same packing, other kernel
+        }
+        if (halo_s2p_applicable(a.kh, a.kw, a.stride, a.pad, a.res_mode, a.n, a.in, a.out)) {
+            hipError_t e = launch_conv_halo_s2p(a, st);
+            if (e != hipErrorNotSupported) return e;
         }
         return launch_conv_halo(a, st);
     }

@@ -42,6 +42,9 @@ ConvPlan plan_conv(int prec, int kh, int kw, int stride, int pad, int max_n, int
 // conv_halo_rw.hip: persistent, weights-resident variant of the stride-1 halo kernel for Cin <= 64 (same weight packing)
 bool halo_rw_applicable(int kh, int kw, int stride, int pad, int n, const TView& in, const TView& out);
 hipError_t launch_conv_halo_rw(const ConvArgs& a, hipStream_t st);
+// conv_halo_s2.hip: stride-2 3x3 for Cout % 128 == 0 (parity-plane LDS window, 8 waves, same weight packing)
+bool halo_s2p_applicable(int kh, int kw, int stride, int pad, int res_mode, int n, const TView& in, const TView& out);
+hipError_t launch_conv_halo_s2p(const ConvArgs& a, hipStream_t st);
 // returns hipSuccess or the launch error.  prec: PREC_*.
 hipError_t launch_conv(const ConvArgs& a, int prec, hipStream_t st);
 const char* conv_tile_name(const ConvArgs& a, int prec);
