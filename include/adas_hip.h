@@ -179,6 +179,34 @@ int adas_yolo_post_capacity(const adas_yolo_post* h, int* max_candidates);
 int adas_yolo_post_head_shape(const adas_yolo_post* h, int32_t* layout, int32_t* num_anchors, int32_t* num_classes);
 
 /* ===================================================================================
+ * EfficientDet post-processing: replaces EfficientdetDetector.__process_output (efficientdetDetector.py:67-85) with
+ * Scaler.convert_boxes_coordinate (utils.py:70-87).  Inputs are the exported graph's three outputs (decode and NMS live inside
+ * it): boxes (n, 4) xyxy float32 in input pixels, class ids (n) int32, confidences (n) float32.  float32 arithmetic, as in the
+ * reference; order kept; a detection is dropped iff conf < box_score.
+ * =================================================================================== */
+typedef struct adas_effdet_post adas_effdet_post;
+typedef struct {
+    double box_score;        /* 0.6 in the reference's defaults */
+    int32_t pad_h, pad_w;    /* Scaler._pad_shape (fill with adas_letterbox_params) */
+    double ratio_h, ratio_w; /* Scaler.get_scale_ratio() */
+    int32_t max_boxes;       /* per frame, <= 4096 */
+    int32_t reserved;
+} adas_effdet_post_params;
+int adas_effdet_post_create(const adas_effdet_post_params* p, int max_batch, adas_effdet_post** out);
+int adas_effdet_post_destroy(adas_effdet_post* h);
+/* Frame b reads h_counts[b] detections at row offset b * max_boxes of the three device arrays. */
+int adas_effdet_post_run(adas_effdet_post* h, const float* d_boxes, const int32_t* d_ids, const float* d_confs,
+                         const int32_t* h_counts, int batch, void* stream);
+/* Synchronises.  xywh [k][4] float32 (RectInfo x, y, width, height), conf [k], class_id [k], xyxy_int [k][4]; returns k in *n_keep. */
+int adas_effdet_post_fetch(adas_effdet_post* h, int frame, int32_t* n_keep, float* xywh, float* conf, int32_t* class_id,
+                           int32_t* xyxy_int);
+/* EfficientdetDetector.__prepare_input (efficientdetDetector.py:57-65): Scaler.process_image letterbox (canvas 114), then
+ * (pixel / 255 - mean) / std per BGR channel -- NO channel swap -- with mean (0.406, 0.456, 0.485), std (0.225, 0.224, 0.229),
+ * evaluated in double and cast to float32; NCHW. */
+int adas_preprocess_effdet(const uint8_t* d_frames_bgr, int n, int src_h, int src_w, float* d_out_nchw, int dst_h, int dst_w,
+                           int keep_ratio, void* stream);
+
+/* ===================================================================================
  * UFLDv2 lane decode: replaces UltrafastLaneDetectorV2.__process_output
  * (ultrafastLaneDetectorV2.py:114-181, _softmax :15-19, ModelConfig :21-55)
  * =================================================================================== */

@@ -74,6 +74,18 @@ def ufld(outs, cfg, W, H, lw=1):
     return [[(int(x), int(y)) for x, y in pts[i, :cnt[i]]] for i in range(4)], [bool(d) for d in det]
 
 
+def effdet(boxes, ids, confs, lb, box_score, cap=256):
+    import ctypes as C
+    boxes = np.ascontiguousarray(boxes, np.float32).reshape(-1, 4); ids = np.ascontiguousarray(ids, np.int32); confs = np.ascontiguousarray(confs, np.float32)
+    n = len(confs)
+    cnt = np.zeros(1, np.int32); xywh = np.zeros((cap, 4), np.float32); conf = np.zeros(cap, np.float32)
+    cls = np.zeros(cap, np.int32); xi = np.zeros((cap, 4), np.int32)
+    lib().emu_effdet(_p(boxes), _p(ids), _p(confs), n, int(lb["pad"][0]), int(lb["pad"][1]), C.c_double(lb["ratio"][0]), C.c_double(lb["ratio"][1]),
+                     C.c_double(box_score), cap, _p(cnt), _p(xywh), _p(conf), _p(cls), _p(xi))
+    k = int(cnt[0])
+    return dict(xywh=xywh[:k], conf=conf[:k], class_id=cls[:k].astype(np.int64), xyxy_int=xi[:k].astype(np.int64))
+
+
 def ufld1(head, cfg, input_wh, src_wh):
     out = np.ascontiguousarray(head, np.float32)
     cnt = np.zeros(4, np.int32); det = np.zeros(4, np.int32); pts = np.zeros((4, 128, 2), np.int32)

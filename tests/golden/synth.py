@@ -103,6 +103,24 @@ def curve_cases():
             ("c4", synth_ufld_curve(43, lanes=((2, 100, 0.0),), cols=((3, 99, 0.0),), extra=((4, 50, .3), (7, 150, -.3))), 2560, 1440)]
 
 
+def effdet_cases():
+    """(tag, boxes (n,4) f32 xyxy in input pixels, ids (n,) i32, confs (n,) f32, source (h, w), input (h, w), box_score)"""
+    out = []
+    for tag, seed, n, src, inp, thr in (("e1", 50, 40, (720, 1280), (512, 512), 0.6), ("e2", 51, 100, (1080, 1920), (640, 640), 0.3),
+                                        ("e3", 52, 0, (720, 1280), (512, 512), 0.6), ("e4", 53, 17, (900, 600), (768, 768), 0.6),
+                                        ("e5", 54, 64, (512, 512), (512, 512), 0.5)):
+        rng = np.random.default_rng(seed)
+        x1 = rng.uniform(0, inp[1] - 40, n); y1 = rng.uniform(0, inp[0] - 40, n)
+        boxes = np.stack([x1, y1, x1 + rng.uniform(5, 200, n), y1 + rng.uniform(5, 200, n)], 1).astype(np.float32)
+        ids = rng.integers(0, 90, n).astype(np.int32)
+        confs = np.sort(rng.uniform(0.05, 0.99, n).astype(np.float32))[::-1].copy()      # the graph's NMS returns them by score
+        if n > 4:
+            confs[3] = np.float32(thr)            # exactly at the threshold: kept (`conf < box_score` is false)
+            confs[4] = np.nextafter(np.float32(thr), np.float32(0))   # one ulp below the float32 image of the threshold
+        out.append((tag, boxes, ids, confs, src, inp, thr))
+    return out
+
+
 def track_scene(seed, n_obj, n_frames, drop=0.1, W=1280, H=720):
     """Constant-velocity rectangles + N(0,1) jitter + dropout; int xyxy like RectInfo.tolist()."""
     rng = np.random.default_rng(seed)

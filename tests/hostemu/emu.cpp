@@ -52,6 +52,16 @@ int emu_ufld(const float* loc_row, const float* loc_col, const float* exist_row,
     return 0;
 }
 
+int emu_effdet(const float* boxes, const int* ids, const float* confs, int n, int pad_h, int pad_w, double ratio_h, double ratio_w,
+               double box_score, int cap, int* count, float* xywh, float* conf, int* cls, int* xyxy_i) {
+    EffdetCfg cfg{pad_h, pad_w, (float)ratio_h, (float)ratio_w, box_score, cap};
+    EffdetFrame f{boxes, ids, confs, n, count, xywh, conf, cls, xyxy_i};
+    std::vector<int> pre((size_t)cap + 2);
+    Ctx c{0, 1};
+    effdet_post_frame(c, cfg, f, pre.data());
+    return 0;
+}
+
 int emu_ufld1(const float* out, int G, int K, int cfg_w, int cfg_h, int in_w, int in_h, int src_w, int src_h,
               const double* row_anchor, int* lane_cnt, int* lane_det, int* lane_pts) {
     Ufld1Cfg cfg{G, K, 4, cfg_w, cfg_h, in_w, in_h, src_w, src_h, row_anchor};

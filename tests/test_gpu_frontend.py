@@ -1,11 +1,13 @@
 """GPU: device pre-processing (pre_kernels.hip) against the oracle restatement, bit-exact, and the drop-in
 YoloDetector / UltrafastLaneDetectorV2 / BYTETracker classes end to end (frame in, RectInfo / LaneInfo / tracks out)."""
 import importlib
+import os
 import numpy as np
 import pytest
 
 import netutil, parity_checks as pc
-from conftest import load_pkg
+from conftest import load_pkg, GOLDEN
+import synth
 from oracle import preprocess, yolo_post, ufld_decode, bytetrack
 
 pytestmark = pytest.mark.gpu
@@ -243,3 +245,47 @@ def test_engine_packed_input_equals_fp32_input(name, kind, hw, layer):
     print(name, layer, a.shape, "max|diff|", float(d.max()), "differing", int((d > 0).sum()), "of", d.size, "max|a|", float(np.abs(a).max()))
     np.testing.assert_array_equal(a, b)
     e.close(); dc.free(); d32.free(); d16.free()
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+class _StubEffdetEngine:
+    """Stands in for an EfficientDet engine (EngineBase surface only): returns the seeded (boxes, ids, confs) of a golden case
+    and records the tensor it was handed, so the test can check the device pre-processing too."""
+
+    def __init__(self, case, hw):
+        self.case, self.hw = case, hw
+        self.engine_dtype = np.float32
+        self.framework_type, self.providers = "stub", ["test"]
+        self.seen = None
+
+    def get_engine_input_shape(self):
+        return [1, 3, self.hw[0], self.hw[1]]
+
+    def get_engine_output_shape(self):
+        return [[-1, 4], [-1], [-1]], ["boxes", "ids", "scores"]
+
+    def engine_inference(self, x):
+        self.seen = np.array(x)
+        return [self.case[1].copy(), self.case[2].copy(), self.case[3].copy()]
+
+
+@pytest.mark.parametrize("case", synth.effdet_cases(), ids=lambda c: c[0])
+def test_efficientdet_detector_dropin(case, tmp_path):
+    """EfficientdetDetector (efficientdetDetector.py:18-111): device letterbox + BGR mean/std normalisation bit-exact with the oracle,
+    device inverse letterbox + score filter bit-exact with the REFERENCE's own outputs (effdet_post.npz), labels incl. 'unknown'."""
+    from oracle import effdet_post
+    tag, boxes, ids, confs, src, inp, thr = case
+    lab = tmp_path / "labels.txt"
+    lab.write_text("\n".join("c%d" % i for i in range(80)))
+    eng = _StubEffdetEngine(case, inp)
+    det = D.EfficientdetDetector(engine=eng, classes_path=str(lab), box_score=thr)
+    frame = frames(1, src[0], src[1], 31)[0]
+    det.DetectFrame(frame)
+    np.testing.assert_array_equal(eng.seen, effdet_post.prepare_input(frame, inp))
+    g = np.load(os.path.join(GOLDEN, "effdet_post.npz"))
+    info = det.object_info
+    assert len(info) == len(g[tag + "_conf"])
+    for r, xywh, conf, label, xyxy in zip(info, g[tag + "_xywh"], g[tag + "_conf"], g[tag + "_label"], g[tag + "_xyxy_int"]):
+        assert (r.x, r.y, r.width, r.height) == tuple(xywh) and r.conf == conf and r.label == str(label)
+        assert r.tolist() == list(xyxy)
+    det.close()

@@ -100,6 +100,17 @@ def test_ufld_curvelanes_ten_lane_heads(case):
     pc.check_lanes(got_l, got_s, want_l, want_s, tol_px=1)
 
 
+@pytest.mark.parametrize("case", synth.effdet_cases(), ids=lambda c: c[0])
+def test_effdet_post(case):
+    from oracle import effdet_post
+    tag, boxes, ids, confs, src, inp, thr = case
+    lb = yolo_post.letterbox_params(src, inp)
+    want = effdet_post.process_output(boxes, ids, confs, lb, thr)
+    got = emu_api.effdet(boxes, ids, confs, lb, thr)
+    for k in ("xywh", "conf", "class_id", "xyxy_int"):
+        np.testing.assert_array_equal(got[k], want[k], err_msg=k)
+
+
 @pytest.mark.parametrize("case", synth.ufld1_cases(), ids=lambda c: c[0])
 def test_ufld_v1(case):
     """UFLD v1 decode logic (host build; exp in libm double then rounded, NumPy's is fp32 SIMD): +-1 px."""

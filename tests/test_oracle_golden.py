@@ -107,6 +107,21 @@ def test_ufld_decode_curvelanes_geometry(case):
         np.testing.assert_array_equal(np.asarray(lanes[li], np.int64).reshape(-1, 2), g[f"{tag}_lane{li}"])
 
 
+@pytest.mark.parametrize("case", synth.effdet_cases(), ids=lambda c: c[0])
+def test_effdet_post_chain(case):
+    """EfficientDet wrapper restatement vs the reference's own __process_output + Scaler (make_golden_effdet.py)."""
+    from oracle import effdet_post
+    tag, boxes, ids, confs, src, inp, thr = case
+    g = np.load(os.path.join(GOLDEN, "effdet_post.npz"))
+    assert synth.digest(boxes, ids, confs) == str(g[tag + "_sha1"])
+    r = effdet_post.process_output(boxes, ids, confs, yolo_post.letterbox_params(src, inp), thr)
+    np.testing.assert_array_equal(r["xywh"], g[tag + "_xywh"])                # float32, bit-exact
+    np.testing.assert_array_equal(r["conf"], g[tag + "_conf"])
+    np.testing.assert_array_equal(r["xyxy_int"], g[tag + "_xyxy_int"])
+    labels = ["c%d" % i if i < 80 else "unknown" for i in r["class_id"]]
+    assert labels == g[tag + "_label"].tolist()
+
+
 def _load_bt():
     with gzip.open(os.path.join(GOLDEN, "bytetrack.json.gz"), "rt") as f:
         return json.load(f)

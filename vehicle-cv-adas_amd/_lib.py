@@ -34,6 +34,11 @@ class YoloCounts(C.Structure):
     _fields_ = [("n_found", C.c_int32), ("n_candidates", C.c_int32), ("n_keep", C.c_int32), ("flags", C.c_int32)]
 
 
+class EffdetPostParams(C.Structure):
+    _fields_ = [("box_score", C.c_double), ("pad_h", C.c_int32), ("pad_w", C.c_int32), ("ratio_h", C.c_double), ("ratio_w", C.c_double),
+                ("max_boxes", C.c_int32), ("reserved", C.c_int32)]
+
+
 class UfldParams(C.Structure):
     _fields_ = [("grid_row", C.c_int32), ("cls_row", C.c_int32), ("grid_col", C.c_int32), ("cls_col", C.c_int32),
                 ("img_w", C.c_int32), ("img_h", C.c_int32), ("local_width", C.c_int32), ("num_lanes", C.c_int32),
@@ -119,6 +124,11 @@ _SIGS = {
     "adas_yolo_post_device_views": (C.c_int, [_P] + [C.POINTER(_P)] * 4),
     "adas_yolo_post_capacity": (C.c_int, [_P, C.POINTER(C.c_int)]),
     "adas_yolo_post_head_shape": (C.c_int, [_P, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+    "adas_effdet_post_create": (C.c_int, [C.POINTER(EffdetPostParams), C.c_int, C.POINTER(_P)]),
+    "adas_effdet_post_destroy": (C.c_int, [_P]),
+    "adas_effdet_post_run": (C.c_int, [_P, _P, _P, _P, _P, C.c_int, _P]),
+    "adas_effdet_post_fetch": (C.c_int, [_P, C.c_int, C.POINTER(C.c_int32), _P, _P, _P, _P]),
+    "adas_preprocess_effdet": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, _P, C.c_int, C.c_int, C.c_int, _P]),
     "adas_ufld_decode_create": (C.c_int, [C.POINTER(UfldParams), C.c_int, C.POINTER(_P)]),
     "adas_ufld_decode_destroy": (C.c_int, [_P]),
     "adas_ufld_decode_run": (C.c_int, [_P, _P, _P, _P, _P, C.c_size_t, C.c_size_t, C.c_size_t, C.c_size_t, C.c_int, _P]),

@@ -848,4 +848,55 @@ ADAS_DEV void ufld1_decode_frame(const Ctx& c, const Ufld1Cfg& cfg, const float*
     }
 }
 
+// ===========================================================================
+// EfficientDet: replaces EfficientdetDetector.__process_output (efficientdetDetector.py:67-85) + Scaler.convert_boxes_coordinate
+// (utils.py:70-87).  The exported graph already holds the decode and the NMS: its three outputs are boxes (n, 4) xyxy in input
+// pixels, class ids (n) and confidences (n).  What the reference does on top is the inverse letterbox IN FLOAT32 (a float32 array
+// combined with Python scalars stays float32: x = (x - padw) * ratiow, w = x2 - x1), the `conf < box_score` filter (a float32
+// scalar against a Python float compares in double) and the label lookup (host).  Order is kept.
+// ===========================================================================
+struct EffdetCfg {
+    int pad_h, pad_w;
+    float ratio_h, ratio_w;  // float32(old / new): what NumPy makes of the Python float when it meets the float32 array
+    double box_score;
+    int cap;
+};
+struct EffdetFrame {
+    const float* boxes;  // [n][4] x1, y1, x2, y2
+    const int* ids;      // [n]
+    const float* confs;  // [n]
+    int n;
+    int* count;          // [1] survivors
+    float* xywh;         // [cap][4]
+    float* conf;         // [cap]
+    int* cls;            // [cap]
+    int* xyxy_i;         // [cap][4] RectInfo.tolist(): int() of x, y, x + w, y + h evaluated in float32
+};
+// lds: int[cap + 1] exclusive prefix of the keep flags
+ADAS_DEV void effdet_post_frame(const Ctx& c, const EffdetCfg& cfg, const EffdetFrame& f, int* pre) {
+    const int n = f.n < cfg.cap ? f.n : cfg.cap;
+    ADAS_PAR_FOR(c, i, 0, n) pre[i + 1] = ((double)f.confs[i] < cfg.box_score) ? 0 : 1;   // `if (conf < box_score): continue` -- NaN is kept, as there
+    c.sync();
+    if (c.tid == 0) {
+        pre[0] = 0;
+        for (int i = 0; i < n; ++i) pre[i + 1] += pre[i];
+        f.count[0] = pre[n];
+    }
+    c.sync();
+    ADAS_PAR_FOR(c, i, 0, n) {
+        if (pre[i + 1] == pre[i]) continue;
+        const int k = pre[i];
+        const float x1 = (f.boxes[i * 4 + 0] - (float)cfg.pad_w) * cfg.ratio_w;
+        const float x2 = (f.boxes[i * 4 + 2] - (float)cfg.pad_w) * cfg.ratio_w;
+        const float y1 = (f.boxes[i * 4 + 1] - (float)cfg.pad_h) * cfg.ratio_h;
+        const float y2 = (f.boxes[i * 4 + 3] - (float)cfg.pad_h) * cfg.ratio_h;
+        const float w = x2 - x1, h = y2 - y1;
+        f.xywh[k * 4 + 0] = x1; f.xywh[k * 4 + 1] = y1; f.xywh[k * 4 + 2] = w; f.xywh[k * 4 + 3] = h;
+        f.conf[k] = f.confs[i];
+        f.cls[k] = f.ids[i];
+        f.xyxy_i[k * 4 + 0] = (int)x1; f.xyxy_i[k * 4 + 1] = (int)y1;
+        f.xyxy_i[k * 4 + 2] = (int)(x1 + w); f.xyxy_i[k * 4 + 3] = (int)(y1 + h);
+    }
+}
+
 }  // namespace adas

@@ -300,6 +300,34 @@ struct adas_ufld_decode {
     void* arena;
     hipStream_t last;
 };
+struct EffdetDev {
+    EffdetCfg cfg;
+    const float* boxes;
+    const int* ids;
+    const float* confs;
+    const int* counts_in;  // [B] device copy of the caller's per-frame counts
+    int* count;            // [B]
+    float* xywh;           // [B][cap][4]
+    float* conf;           // [B][cap]
+    int* cls;              // [B][cap]
+    int* xyxy_i;           // [B][cap][4]
+};
+__global__ __launch_bounds__(256) void effdet_post_kernel(EffdetDev d) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const size_t b = blockIdx.x, cap = d.cfg.cap;
+    EffdetFrame f{d.boxes + b * cap * 4, d.ids + b * cap, d.confs + b * cap, d.counts_in[b], d.count + b,
+                  d.xywh + b * cap * 4, d.conf + b * cap, d.cls + b * cap, d.xyxy_i + b * cap * 4};
+    Ctx c{(int)threadIdx.x, (int)blockDim.x};
+    effdet_post_frame(c, d.cfg, f, (int*)smem);
+}
+struct adas_effdet_post {
+    adas_effdet_post_params p;
+    int max_batch;
+    EffdetDev dev;
+    int* d_counts_in;
+    void* arena;
+    hipStream_t last;
+};
 struct adas_lane_geometry {
     int max_batch;
     LaneGeomDev dev;
@@ -497,6 +525,75 @@ int adas_yolo_post_capacity(const adas_yolo_post* h, int* max_candidates) {
 }
 
 // ------------------------------------------------------------------------------- UFLD
+int adas_effdet_post_create(const adas_effdet_post_params* p, int max_batch, adas_effdet_post** out) {
+    ADAS_REQUIRE(p && out && max_batch > 0, ADAS_ERR_INVALID, "adas_effdet_post_create: bad argument");
+    ADAS_REQUIRE(p->max_boxes >= 1 && p->max_boxes <= 4096, ADAS_ERR_INVALID, "max_boxes must be in [1, 4096]");
+    ADAS_REQUIRE(p->ratio_h > 0 && p->ratio_w > 0, ADAS_ERR_INVALID, "scale ratios must be positive (fill them with adas_letterbox_params)");
+    ADAS_REQUIRE(adas_device_count() > 0, ADAS_ERR_NO_DEVICE, "no HIP device visible; this library has no CPU fallback");
+    adas_effdet_post* h = new (std::nothrow) adas_effdet_post();
+    ADAS_REQUIRE(h, ADAS_ERR_INVALID, "out of host memory");
+    h->p = *p;
+    h->max_batch = max_batch;
+    h->last = 0;
+    const size_t B = max_batch, cap = p->max_boxes;
+    const size_t bytes = B * (cap * (16 + 4 + 4 + 16) + 8) + 8 * 256;
+    if (hipMalloc(&h->arena, bytes) != hipSuccess) {
+        delete h;
+        return hip_fail(hipGetLastError(), "hipMalloc(effdet arena)", __FILE__, __LINE__);
+    }
+    hipMemset(h->arena, 0, bytes);
+    unsigned char* q = (unsigned char*)h->arena;
+    EffdetDev& d = h->dev;
+    d.cfg = EffdetCfg{p->pad_h, p->pad_w, (float)p->ratio_h, (float)p->ratio_w, p->box_score, (int)cap};
+    d.count = carve<int>(q, B);
+    h->d_counts_in = carve<int>(q, B);
+    d.counts_in = h->d_counts_in;
+    d.xywh = carve<float>(q, B * cap * 4);
+    d.conf = carve<float>(q, B * cap);
+    d.cls = carve<int>(q, B * cap);
+    d.xyxy_i = carve<int>(q, B * cap * 4);
+    *out = h;
+    return ADAS_OK;
+}
+int adas_effdet_post_destroy(adas_effdet_post* h) {
+    if (!h) return ADAS_OK;
+    hipFree(h->arena);
+    delete h;
+    return ADAS_OK;
+}
+int adas_effdet_post_run(adas_effdet_post* h, const float* d_boxes, const int32_t* d_ids, const float* d_confs, const int32_t* h_counts,
+                         int batch, void* stream) {
+    ADAS_REQUIRE(h && d_boxes && d_ids && d_confs && h_counts && batch > 0 && batch <= h->max_batch, ADAS_ERR_INVALID,
+                 "adas_effdet_post_run: bad argument");
+    for (int b = 0; b < batch; ++b)
+        ADAS_REQUIRE(h_counts[b] >= 0 && h_counts[b] <= h->p.max_boxes, ADAS_ERR_CAPACITY, "frame %d carries %d detections, max_boxes is %d", b,
+                     h_counts[b], h->p.max_boxes);
+    hipStream_t st = (hipStream_t)stream;
+    h->last = st;
+    ADAS_HIP_TRY(hipMemcpyAsync(h->d_counts_in, h_counts, (size_t)batch * 4, hipMemcpyHostToDevice, st));
+    EffdetDev d = h->dev;
+    d.boxes = d_boxes; d.ids = d_ids; d.confs = d_confs;
+    hipLaunchKernelGGL(effdet_post_kernel, dim3(batch), dim3(256), ((size_t)h->p.max_boxes + 1) * 4, st, d);
+    ADAS_HIP_TRY(hipGetLastError());
+    return ADAS_OK;
+}
+int adas_effdet_post_fetch(adas_effdet_post* h, int frame, int32_t* n_keep, float* xywh, float* conf, int32_t* class_id, int32_t* xyxy_int) {
+    ADAS_REQUIRE(h && n_keep && frame >= 0 && frame < h->max_batch, ADAS_ERR_INVALID, "adas_effdet_post_fetch: bad argument");
+    ADAS_HIP_TRY(hipStreamSynchronize(h->last));
+    const EffdetDev& d = h->dev;
+    const size_t cap = h->p.max_boxes, b = frame;
+    int k = 0;
+    ADAS_HIP_TRY(hipMemcpy(&k, d.count + b, 4, hipMemcpyDeviceToHost));
+    *n_keep = k;
+    if (k > 0) {
+        if (xywh) ADAS_HIP_TRY(hipMemcpy(xywh, d.xywh + b * cap * 4, (size_t)k * 16, hipMemcpyDeviceToHost));
+        if (conf) ADAS_HIP_TRY(hipMemcpy(conf, d.conf + b * cap, (size_t)k * 4, hipMemcpyDeviceToHost));
+        if (class_id) ADAS_HIP_TRY(hipMemcpy(class_id, d.cls + b * cap, (size_t)k * 4, hipMemcpyDeviceToHost));
+        if (xyxy_int) ADAS_HIP_TRY(hipMemcpy(xyxy_int, d.xyxy_i + b * cap * 4, (size_t)k * 16, hipMemcpyDeviceToHost));
+    }
+    return ADAS_OK;
+}
+
 int adas_ufld_decode_create(const adas_ufld_params* p, int max_batch, adas_ufld_decode** out) {
     ADAS_REQUIRE(p && out && max_batch > 0 && p->h_row_anchor && p->h_col_anchor, ADAS_ERR_INVALID, "adas_ufld_decode_create: bad argument");
     ADAS_REQUIRE(p->cls_row > 0 && p->cls_col > 0 && p->cls_row <= ADAS_UFLD_MAXPTS && p->cls_col <= ADAS_UFLD_MAXPTS,

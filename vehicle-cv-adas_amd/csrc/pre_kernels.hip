@@ -123,6 +123,31 @@ __global__ void preprocess_yolo_kernel(YoloPreDev d) {
     }
 }
 
+// EfficientdetDetector.__prepare_input (efficientdetDetector.py:57-65): the letterboxed u8 canvas, then (image / 255 - mean) / std
+// on the BGR channels in place (no swap), all in float64 (uint8 array / int -> float64), cast to float32 at the end.
+__global__ void preprocess_effdet_kernel(YoloPreDev d) {
+    const size_t plane = (size_t)d.dh * d.dw;
+    const size_t total = (size_t)d.n * plane;
+    const double mean[3] = {0.406, 0.456, 0.485}, stdv[3] = {0.225, 0.224, 0.229};
+    __shared__ float lut[3][256];
+    for (int t = threadIdx.x; t < 768; t += blockDim.x) {
+        const int c = t >> 8, u = t & 255;
+        lut[c][u] = (float)(((double)u / 255.0 - mean[c]) / stdv[c]);
+    }
+    __syncthreads();
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int b = (int)(i / plane);
+        const int p = (int)(i - (size_t)b * plane);
+        const int y = p / d.dw, x = p - y * d.dw;
+        int v[3] = {114, 114, 114};  // canvas (utils.py:54)
+        const int ry = y - d.padh, rx = x - d.padw;
+        if (ry >= 0 && ry < d.g.rh && rx >= 0 && rx < d.g.rw) resize_px(d.src + (size_t)b * d.g.sh * d.g.sw * 3, d.g, ry, rx, v);
+        float* o = d.dst + (size_t)b * 3 * plane + p;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) o[(size_t)c * plane] = lut[c][v[c]];
+    }
+}
+
 struct UfldPreDev {
     const uint8_t* src;
     float* dst;
@@ -174,7 +199,7 @@ int grid_for(size_t total) {
 extern "C" {
 
 static int preprocess_yolo_impl(const uint8_t* d_frames_bgr, int n, int src_h, int src_w, float* d_out_nchw, int dst_h, int dst_w,
-                                int keep_ratio, void* stream, int pack) {
+                                int keep_ratio, void* stream, int pack /* 0 fp32 planes | 1 bf16 pixels | 2 fp16 pixels | 3 EfficientDet normalisation */) {
     ADAS_REQUIRE(d_frames_bgr && d_out_nchw && n > 0 && src_h > 0 && src_w > 0 && dst_h > 0 && dst_w > 0, ADAS_ERR_INVALID,
                  "adas_preprocess_yolo: bad argument");
     adas_yolo_post_params lb;
@@ -192,7 +217,8 @@ static int preprocess_yolo_impl(const uint8_t* d_frames_bgr, int n, int src_h, i
     d.g.sh = src_h; d.g.sw = src_w; d.g.rh = newh; d.g.rw = neww;
     d.g.scale_y = 1.0 / ((double)newh / (double)src_h);
     d.g.scale_x = 1.0 / ((double)neww / (double)src_w);
-    if (pack == 2) hipLaunchKernelGGL(preprocess_yolo_kernel<2>, dim3(grid_for((size_t)n * dst_h * dst_w)), dim3(256), 0, (hipStream_t)stream, d);
+    if (pack == 3) hipLaunchKernelGGL(preprocess_effdet_kernel, dim3(grid_for((size_t)n * dst_h * dst_w)), dim3(256), 0, (hipStream_t)stream, d);
+    else if (pack == 2) hipLaunchKernelGGL(preprocess_yolo_kernel<2>, dim3(grid_for((size_t)n * dst_h * dst_w)), dim3(256), 0, (hipStream_t)stream, d);
     else if (pack == 1) hipLaunchKernelGGL(preprocess_yolo_kernel<1>, dim3(grid_for((size_t)n * dst_h * dst_w)), dim3(256), 0, (hipStream_t)stream, d);
     else hipLaunchKernelGGL(preprocess_yolo_kernel<0>, dim3(grid_for((size_t)n * dst_h * dst_w)), dim3(256), 0, (hipStream_t)stream, d);
     ADAS_HIP_TRY(hipGetLastError());
@@ -201,6 +227,10 @@ static int preprocess_yolo_impl(const uint8_t* d_frames_bgr, int n, int src_h, i
 int adas_preprocess_yolo(const uint8_t* d_frames_bgr, int n, int src_h, int src_w, float* d_out_nchw, int dst_h, int dst_w,
                          int keep_ratio, void* stream) {
     return preprocess_yolo_impl(d_frames_bgr, n, src_h, src_w, d_out_nchw, dst_h, dst_w, keep_ratio, stream, 0);
+}
+int adas_preprocess_effdet(const uint8_t* d_frames_bgr, int n, int src_h, int src_w, float* d_out_nchw, int dst_h, int dst_w, int keep_ratio,
+                           void* stream) {
+    return preprocess_yolo_impl(d_frames_bgr, n, src_h, src_w, d_out_nchw, dst_h, dst_w, keep_ratio, stream, 3);
 }
 int adas_preprocess_yolo_packed(const uint8_t* d_frames_bgr, int n, int src_h, int src_w, uint16_t* d_out_nhwc4, int dst_h, int dst_w,
                                 int keep_ratio, void* stream) {

@@ -3,6 +3,8 @@
     YoloDetector              <- ObjectDetector/yoloDetector.py:53-157 (+ core.py RectInfo/ObjectDetectBase, utils.py Scaler/NMS)
     UltrafastLaneDetectorV2   <- TrafficLaneDetector/ufldDetector/ultrafastLaneDetectorV2.py:56-194 (+ core.py LaneInfo/LaneDetectBase)
     BYTETracker               <- ObjectTracker/byteTrack/byteTracker.py:10-200
+    EfficientdetDetector      <- ObjectDetector/efficientdetDetector.py:18-111 (pre- and post-processing; the EfficientDet graph itself is
+                                 not one of HipEngine's architectures: the class takes any EngineBase-conforming engine)
 
 Same public surface (`_defaults` / `set_defaults`, `DetectFrame(frame)`, `.object_info`, `.lane_info`,
 `update(bboxes, scores, class_ids, frame)`, `reset()`), but a frame makes one trip to the GPU: the BGR u8
@@ -25,7 +27,7 @@ import numpy as np
 
 from . import _lib as L
 from .coreEngine import OnnxEngine, TensorRTEngine
-from .postproc import YoloPost, UfldDecode, Ufld1Decode, LaneGeometry, DeviceTracker, letterbox
+from .postproc import YoloPost, EffdetPost, UfldDecode, Ufld1Decode, LaneGeometry, DeviceTracker, letterbox
 
 
 class ObjectModelType(Enum):       # ObjectDetector/utils.py:15-23
@@ -237,6 +239,84 @@ class YoloDetector(_Defaults):
             self._stage.close()
         if getattr(self, "engine", None) is not None:
             self.engine.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+# =====================================================================================
+class EfficientdetDetector(_Defaults):
+    """efficientdetDetector.py:18-111.  The exported EfficientDet graph carries its own decode + NMS; around it the reference does
+    letterbox + BGR mean/std normalisation (:57-65) and inverse letterbox + score filter + label lookup (:67-85).  Both run on the
+    device here (adas_preprocess_effdet, adas_effdet_post_*).  HipEngine builds YOLO / UFLD graphs only (depth-wise convs, BiFPN and
+    the in-graph NMS of EfficientDet have no kernels): pass `engine=` -- any object with the EngineBase surface
+    (get_engine_input_shape / get_engine_output_shape / engine_inference / engine_dtype) -- or a model path HipEngine can load;
+    an EfficientDet .onnx fails loudly in onnx_import.detect_arch."""
+    _defaults = {
+        "model_path": './models/efficientdet-d0-coco_fp32.onnx',
+        "model_type": ObjectModelType.EfficientDet,
+        "classes_path": './models/coco_label.txt',
+        "box_score": 0.6,
+    }
+
+    def __init__(self, logger=None, engine=None, **kwargs):
+        self.__dict__.update(self._defaults)
+        self.logger = logger
+        self.max_boxes = 256
+        self.__dict__.update(kwargs)
+        classes_path = os.path.expanduser(self.classes_path)
+        assert os.path.isfile(classes_path), Exception("%s is not exist." % classes_path)
+        with open(classes_path) as f:
+            self.class_names = [c.strip() for c in f.readlines()]
+        self.engine = engine if engine is not None else OnnxEngine(os.path.expanduser(self.model_path))
+        self.input_shapes = self.engine.get_engine_input_shape()                 # core.py:73-82
+        self.input_types = self.engine.engine_dtype
+        self.channes, self.input_height, self.input_width = self.input_shapes[1:]
+        self.output_shapes, self.output_names = self.engine.get_engine_output_shape()
+        self._stage = _FrameStage()
+        self._post = None
+        self._post_key = None
+        self._object_info = []
+
+    @property
+    def object_info(self):
+        return self._object_info
+
+    def DetectFrame(self, srcimg) -> None:
+        h, w = self._stage.upload(srcimg)
+        t = self._stage.tensor_for(self.input_shapes)
+        L.check(L.lib().adas_preprocess_effdet(self._stage.frame.ptr, 1, h, w, t.ptr, self.input_height, self.input_width, 1, None))
+        x = t.download((1, 3, self.input_height, self.input_width), np.float32).astype(self.input_types)
+        out = self.engine.engine_inference(x)                                    # boxes, class ids, confidences (:68-70)
+        key = (h, w)
+        if self._post_key != key:
+            if self._post is not None:
+                self._post.close()
+            self._post = EffdetPost(float(self.box_score), letterbox(key, self.input_shapes[-2:]), self.max_boxes, 1)
+            self._post_key = key
+        r = self._post.run_host([(np.asarray(out[0]).reshape(-1, 4), np.asarray(out[1]).reshape(-1), np.asarray(out[2]).reshape(-1))])[0]
+        self._last = r
+        info = []
+        for (x0, y0, bw, bh), conf, cid in zip(r["xywh"], r["conf"], r["class_id"]):
+            try:
+                label = self.class_names[int(cid)]        # Python indexing, as there: a negative id wraps, one past the end is "unknown"
+            except Exception:
+                label = "unknown"
+            info.append(RectInfo(np.float32(x0), np.float32(y0), np.float32(bw), np.float32(bh), conf=np.float32(conf), label=label))
+        self._object_info = info
+
+    def close(self):
+        if getattr(self, "_post", None) is not None:
+            self._post.close()
+            self._post = None
+        if getattr(self, "_stage", None) is not None:
+            self._stage.close()
+        eng = getattr(self, "engine", None)
+        if eng is not None and hasattr(eng, "close"):
+            eng.close()
 
     def __del__(self):
         try:

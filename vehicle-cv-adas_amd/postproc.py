@@ -83,6 +83,53 @@ class YoloPost:
     __del__ = close
 
 
+class EffdetPost:
+    """EfficientdetDetector.__process_output on the device (adas_effdet_post_*): inverse letterbox in float32 + `conf < box_score`
+    filter over the exported graph's (boxes, ids, confs) outputs."""
+
+    def __init__(self, box_score, lb, max_boxes=256, max_batch=1):
+        p = L.EffdetPostParams(float(box_score), int(lb["pad"][0]), int(lb["pad"][1]), float(lb["ratio"][0]), float(lb["ratio"][1]),
+                               int(max_boxes), 0)
+        self.cap, self.max_batch = int(max_boxes), int(max_batch)
+        h = C.c_void_p()
+        L.check(L.lib().adas_effdet_post_create(C.byref(p), max_batch, C.byref(h)))
+        self.h = h.value
+
+    def run_host(self, frames):
+        """frames: list (<= max_batch) of (boxes (n,4), ids (n,), confs (n,)) host arrays -> list of result dicts."""
+        B, cap = len(frames), self.cap
+        boxes = np.zeros((B, cap, 4), np.float32); ids = np.zeros((B, cap), np.int32); confs = np.zeros((B, cap), np.float32)
+        counts = np.zeros(B, np.int32)
+        for b, (bx, i_, cf) in enumerate(frames):
+            n = len(cf)
+            if n > cap:
+                raise L.AdasError(-1, "frame %d carries %d detections, max_boxes is %d" % (b, n, cap))
+            counts[b] = n
+            boxes[b, :n] = np.asarray(bx, np.float32).reshape(-1, 4); ids[b, :n] = np.asarray(i_).astype(np.int32); confs[b, :n] = cf
+        bufs = [L.DeviceBuffer.from_array(a) for a in (boxes, ids, confs)]
+        try:
+            L.check(L.lib().adas_effdet_post_run(self.h, bufs[0].ptr, bufs[1].ptr, bufs[2].ptr, L.ptr(counts), B, None))
+            return [self.fetch(b) for b in range(B)]
+        finally:
+            for x in bufs:
+                x.free()
+
+    def fetch(self, frame=0):
+        cap = self.cap
+        k = C.c_int32()
+        xywh = np.zeros((cap, 4), np.float32); conf = np.zeros(cap, np.float32); cls = np.zeros(cap, np.int32); xi = np.zeros((cap, 4), np.int32)
+        L.check(L.lib().adas_effdet_post_fetch(self.h, frame, C.byref(k), L.ptr(xywh), L.ptr(conf), L.ptr(cls), L.ptr(xi)))
+        n = k.value
+        return dict(xywh=xywh[:n], conf=conf[:n], class_id=cls[:n].astype(np.int64), xyxy_int=xi[:n].astype(np.int64))
+
+    def close(self):
+        if getattr(self, "h", None):
+            L.lib().adas_effdet_post_destroy(self.h)
+            self.h = None
+
+    __del__ = close
+
+
 class UfldDecode:
     def __init__(self, grid_row, cls_row, grid_col, cls_col, img_w, img_h, row_anchor, col_anchor, local_width=1,
                  max_batch=1, num_lanes=4):
