@@ -134,9 +134,18 @@ def test_ufld(G, case):
     # softmax exp is fp32 in NumPy (SIMD, <=1ulp) and correctly-rounded here: tolerance +-1 px
     n_off = pc.check_lanes(got_l, got_s, want_l, want_s, tol_px=1)
     assert n_off <= 2
+    # against the REFERENCE's own outputs: same point counts, and the number of coordinates that differ (by 1 px) is printed --
+    # the only source is the last ulp of exp() in the <= 3-tap softmax (device expf vs NumPy's SIMD float32 exp) before int()
     g = np.load(os.path.join(GOLDEN, "ufld_decode.npz"))
+    n_ref_off = n_pts = 0
     for li in range(4):
-        assert len(got_l[li]) == len(g[f"{tag}_lane{li}"])
+        ref = g[f"{tag}_lane{li}"]
+        assert len(got_l[li]) == len(ref)
+        if len(ref):
+            d = np.abs(np.asarray(got_l[li], np.int64).reshape(-1, 2) - ref)
+            assert d.max() <= 1
+            n_ref_off += int((d > 0).sum()); n_pts += d.size
+    print("ufld decode %s: %d of %d coordinates differ from the reference's goldens (by 1 px)" % (tag, n_ref_off, n_pts))
 
 
 @pytest.mark.parametrize("case", synth.curve_cases(), ids=lambda c: c[0])
