@@ -146,6 +146,7 @@ def test_ufld(G, case):
             assert d.max() <= 1
             n_ref_off += int((d > 0).sum()); n_pts += d.size
     print("ufld decode %s: %d of %d coordinates differ from the reference's goldens (by 1 px)" % (tag, n_ref_off, n_pts))
+    assert n_ref_off == 0      # measured on MI355X: 0 of 2,280 golden coordinates differ; the +-1 px above guards arbitrary inputs
 
 
 @pytest.mark.parametrize("case", synth.curve_cases(), ids=lambda c: c[0])
