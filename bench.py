@@ -272,6 +272,8 @@ def main():
     ap.add_argument("--no-extras", action="store_true", help="skip the parity / other-precision / host-ingest legs (profiling runs)")
     ap.add_argument("--from-seam", action="store_true", help="start each step at the engine seam (pre-processed NCHW fp32 tensors resident "
                     "in HBM) instead of at the u8 camera frames")
+    ap.add_argument("--candidates", type=float, default=100.0, help="anchors over box_score on the median generated frame (the detector's class "
+                    "bias is calibrated to it); frames outside [8, 0.7 * capacity] are not used")
     ap.add_argument("--pool", type=int, default=2, help="distinct frame sets cycled through")
     ap.add_argument("--hold", type=int, default=4, help="consecutive steps each frame set is shown for (a scene that changes "
                     "every HOLD frames: gives ByteTrack confirmed, lost and re-found tracks to maintain)")
@@ -313,7 +315,7 @@ def main():
     d_cam, h_cam = [], []
     t_build = time.time()
     sd = SynthDetector(M, CE, args.det, workdir, f"r{rank}", batch=16)
-    TARGET, LO, HI = 40.0, 8, int(0.7 * CAP)
+    TARGET, LO, HI = float(args.candidates), 8, int(0.7 * CAP)
     sel = None
     if from_frames:
         # Camera frames live in HBM as u8; the seam tensors (calibration, per-layer pass, parity, CPU baseline) come from the same
