@@ -366,6 +366,9 @@ int adas_pipeline_step_frames(adas_pipeline* p, const uint8_t* d_frames_bgr, int
  * overlaps compute k; the compute stream waits for its copy, the copy stream for the step that last read its buffer).
  * h_frames_bgr should come from adas_host_alloc (pinned): pageable memory works but the copy then cannot overlap. */
 int adas_pipeline_step_frames_host(adas_pipeline* p, const uint8_t* h_frames_bgr, int src_h, int src_w, double lane_crop_ratio);
+/* The call above returns when the upload is ENQUEUED: the host buffer must not be rewritten before the copy has read it.  This waits
+ * for exactly that (the copy stream only, not the compute): call it before refilling a host buffer that the last step was given. */
+int adas_pipeline_wait_upload(adas_pipeline* p);
 int adas_pipeline_sync(adas_pipeline* p);
 /* Device time of the last `n` steps' sections in ms (hipEvents on the pipeline stream):
  * [0] detector net, [1] yolo post, [2] lane net, [3] lane decode, [4] tracker, [5] whole step. */

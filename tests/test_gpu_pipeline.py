@@ -156,8 +156,14 @@ def test_pipeline_step_frames_host_equals_device_frames(tmp_path):
     for b, c in zip(pinned, cam):
         b.array[...] = c
     dev = [L.DeviceBuffer.from_array(c) for c in cam]
-    for k in (0, 1, 2, 0, 2, 1, 1):
-        pa.step_frames_host(pinned[k].ptr, (720, 1280), 0.6)
+    one = L.PinnedBuffer(cam[0].shape)                 # a single host buffer refilled for every step: wait_upload() before each refill
+    for i, k in enumerate((0, 1, 2, 0, 2, 1, 1)):
+        if i % 2:
+            pa.wait_upload()
+            one.array[...] = cam[k]
+            pa.step_frames_host(one.ptr, (720, 1280), 0.6)
+        else:
+            pa.step_frames_host(pinned[k].ptr, (720, 1280), 0.6)
         pb.step_frames(dev[k].ptr, (720, 1280), 0.6)
     pa.sync(); pb.sync()
     for s in range(S):
@@ -167,7 +173,7 @@ def test_pipeline_step_frames_host_equals_device_frames(tmp_path):
         assert pa.decode.fetch(s) == pb.decode.fetch(s)
         pc.check_track_frame(gpu_api.track_snapshot(*pa.tracker.fetch(s)), gpu_api.track_snapshot(*pb.tracker.fetch(s)), ctx=s)
     pa.close(); pb.close()
-    for b in pinned:
+    for b in pinned + [one]:
         b.free()
     for d in dev:
         d.free()

@@ -155,6 +155,7 @@ _SIGS = {
     "adas_pipeline_step": (C.c_int, [_P, _P, _P]),
     "adas_pipeline_step_frames": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_double]),
     "adas_pipeline_step_frames_host": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_double]),
+    "adas_pipeline_wait_upload": (C.c_int, [_P]),
     "adas_pipeline_sync": (C.c_int, [_P]),
     "adas_pipeline_timings": (C.c_int, [_P, C.POINTER(C.c_float)]),
 }

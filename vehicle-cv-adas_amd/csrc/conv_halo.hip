@@ -383,12 +383,14 @@ static bool magic_ok(int d, int nmax, uint32_t* magic) {
 // Ho x Wo: OUTPUT extent; S: stride (1 or 2); pad = 1, 3x3.
 static bool plan_halo_uncached(int Ho, int Wo, int S, HaloPlan* best) {
     const int BM = halo_bm(S), MAXPIX = halo_maxpix(S);
-    int cand[6] = {16, 32, 64, 128, 256, Wo};
+    // strip widths: powers of two, the whole row, and the row cut into 2 / 3 / 4 equal strips (40x200 maps: 100-wide strips fill
+    // 97.7 % of their tiles' pixels, 32-wide ones 89.3 %)
+    int cand[9] = {16, 32, 64, 128, 256, Wo, (Wo + 1) / 2, (Wo + 2) / 3, (Wo + 3) / 4};
     bool found = false;
-    for (int k = 0; k < 6; ++k) {
+    for (int k = 0; k < 9; ++k) {
         int SW = cand[k];
-        if (SW > Wo && k != 5) continue;
-        if (k == 5 && (Wo == 16 || Wo == 32 || Wo == 64 || Wo == 128 || Wo == 256)) continue;
+        if (SW < 8 || (SW > Wo && k != 5)) continue;
+        if (k >= 5 && (SW == 16 || SW == 32 || SW == 64 || SW == 128 || SW == 256)) continue;
         int rows = (BM + SW - 1) / SW + ((BM % SW) ? 1 : 0);
         int WW = (SW - 1) * S + 3;
         int maxpix = ((rows - 1) * S + 3) * WW;

@@ -335,6 +335,12 @@ int adas_pipeline_step_frames_host(adas_pipeline* p, const uint8_t* h_frames_bgr
     return ADAS_OK;
 }
 
+int adas_pipeline_wait_upload(adas_pipeline* p) {
+    ADAS_REQUIRE(p, ADAS_ERR_INVALID, "null pipeline");
+    if (p->st_copy) ADAS_HIP_TRY(hipStreamSynchronize(p->st_copy));
+    return ADAS_OK;
+}
+
 int adas_pipeline_sync(adas_pipeline* p) {
     ADAS_REQUIRE(p, ADAS_ERR_INVALID, "null pipeline");
     ADAS_HIP_TRY(hipStreamSynchronize(p->st));

@@ -71,6 +71,10 @@ class AdasPipeline:
         staging buffers, overlapped with the previous step's compute."""
         L.check(L.lib().adas_pipeline_step_frames_host(self.h, h_frames_ptr, int(src_hw[0]), int(src_hw[1]), float(lane_crop_ratio)))
 
+    def wait_upload(self):
+        """Block until the last step_frames_host upload has read its host buffer (then the buffer may be refilled)."""
+        L.check(L.lib().adas_pipeline_wait_upload(self.h))
+
     def sync(self):
         L.check(L.lib().adas_pipeline_sync(self.h))
 
