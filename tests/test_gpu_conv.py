@@ -272,3 +272,46 @@ def test_conv3x3_s2_parity_plane_kernel(CE, case, prec, tol):
     H, W, cin, cout, act, batch = case
     rel, mx = run_case(CE, H, W, cin, cout, 3, 2, act, M.RES_NONE, prec, batch=batch, expect_kernel="conv_s2p_kernel")
     assert rel < tol, (case, prec, rel, mx)
+
+
+@pytest.mark.parametrize("case", [
+    # H, W, cin, cout, act, res_mode, batch: the ResNet layer2-4 blocks (identity residual), ragged extents with uneven item
+    # lists per workgroup and a short last XCD, an odd chunk count (the window buffers swap parity from item to item), a
+    # projected residual.  Batches fill the chip in nearly whole rounds of items (the kernel is chosen only then).
+    (20, 100, 256, 256, M.ACT_RELU, M.RES_BEFORE_ACT, 16), (10, 50, 512, 512, M.ACT_RELU, M.RES_NONE, 32),
+    (40, 200, 128, 128, M.ACT_RELU, M.RES_BEFORE_ACT, 8), (23, 37, 64, 128, M.ACT_SILU, M.RES_NONE, 119),
+    (40, 40, 96, 256, M.ACT_SILU, M.RES_AFTER_ACT, 36), (7, 300, 128, 128, M.ACT_NONE, M.RES_NONE, 56),
+], ids=str)
+@pytest.mark.parametrize("prec,tol", [("bf16", 1e-2), ("fp16", 1.5e-3)])
+def test_conv3x3_s1_dma_fed_kernel(CE, case, prec, tol):
+    """Stride-1 3x3 with Cout % 128 == 0 through conv_halo8.hip (persistent workgroups, LDS-DMA staging with counted waits, two
+    synchronisation variants picked by the chunk count)."""
+    H, W, cin, cout, act, res_mode, batch = case
+    rel, mx = run_case(CE, H, W, cin, cout, 3, 1, act, res_mode, prec, batch=batch, expect_kernel="conv_h8_kernel")
+    assert rel < tol, (case, prec, rel, mx)
+
+
+@pytest.mark.parametrize("case", [(20, 100, 256, 256, 16), (10, 50, 512, 512, 32), (40, 200, 128, 128, 8)], ids=str)
+def test_conv3x3_s1_dma_fed_kernel_is_deterministic(CE, case):
+    """Race screen for the counted-wait schedule: a DMA piece read before it landed, or a buffer re-filled while still being read,
+    shows up as run-to-run differences.  The same launch, 25 times, has to return identical bits."""
+    H, W, cin, cout, batch = case
+    ws = M.SynthWeights(3, gain=1.0)
+    g = M.Graph("unit", 3, H, W, ws)
+    x, c3 = g.input()
+    a = g.conv(x, cin, 1, 1, "expand", act=M.ACT_SILU, true_cin=c3)
+    y = g.conv(a, cout, 3, 1, "test", act=M.ACT_RELU, res=a, res_mode=M.RES_BEFORE_ACT, f32_out=False)
+    z = g.conv(y, 8, 1, 1, "tap", act=M.ACT_NONE, f32_out=True)
+    g.output(z, 0, [1, z.h * z.w * 8], "o")
+    path = os.path.join(tempfile.gettempdir(), f"unit_det_{H}_{W}_{cin}.hipm")
+    g.save(path)
+    e = CE.HipEngine(path, "fp16", batch)
+    assert "conv_h8_kernel" in e.layer_kernel(e.layer_index("test"), batch)
+    xin = np.random.default_rng(5).uniform(0, 1, (batch, 3, H, W)).astype(np.float32)
+    e.engine_inference(xin)
+    first = e.fetch_activation("test", batch).copy()
+    for it in range(24):
+        e.engine_inference(xin)
+        again = e.fetch_activation("test", batch)
+        assert np.array_equal(first, again), (case, it, float(np.abs(first - again).max()))
+    e.close(); os.remove(path)

@@ -364,12 +364,6 @@ extern "C" int adas_debug_halo_prof(unsigned long long* out16, int reset) {
 #endif
 
 // -------------------------------------------------------------------------------------
-struct HaloPlan {
-    int SW, NS, TPS, WW, maxpix;
-    double eff;
-    uint32_t mg_ww, mg_sw;
-};
-
 // n / d == (n * magic) >> 20 for all n < nmax ?  (verified exhaustively; the kernel divides only such n)
 static bool magic_ok(int d, int nmax, uint32_t* magic) {
     uint32_t m = ((1u << 20) + d - 1) / d;
@@ -409,7 +403,7 @@ static bool plan_halo_uncached(int Ho, int Wo, int S, HaloPlan* best) {
 }
 
 // plans are pure functions of (Ho, Wo, S): memoised so eager launches do not redo the exhaustive checks
-static bool plan_halo(int Ho, int Wo, int S, HaloPlan* out) {
+bool plan_halo(int Ho, int Wo, int S, HaloPlan* out) {
     static std::mutex mu;
     static std::map<std::tuple<int, int, int>, std::pair<bool, HaloPlan>> cache;
     std::lock_guard<std::mutex> lk(mu);

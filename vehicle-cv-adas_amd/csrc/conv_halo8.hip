@@ -1,0 +1,465 @@
+// conv_halo8.hip -- stride-1 3x3 convolution for Cout % 128 == 0: a persistent, LDS-DMA fed, two-wave-group form of the halo kernel.
+//
+// conv_halo.hip stages every 32-channel chunk through registers and synchronises twice per chunk with nothing in flight across
+// the barriers; it tops out at ~0.9-1.0 PFLOP/s ("what bounds conv_halo").  This kernel keeps the tiling (strip-linear
+// 256-pixel tiles, 64-byte swizzled window pixels, swizzled 64-byte weight rows, the same CONV_HALO weight packing) and changes
+// the synchronisation structure:
+//   * one 8-wave workgroup per CU owns 256 pixels x 128 output channels (waves 0-3 / 4-7 = the two 64-channel halves, each wave
+//     4 x 4 MFMA tiles) and walks a list of (tile, channel block) items: the stream of taps never stops at a tile boundary;
+//   * window and weights arrive by LDS-DMA (`buffer_load_dwordx4 ... lds`, 1 KiB per wave instruction): no staging registers, no
+//     ds_write pass.  The swizzle is applied on the SOURCE address (lane l of a piece fetches the 16 bytes that belong at LDS
+//     position l), out-of-image window pixels are out-of-range buffer offsets (the DMA writes zeros);
+//   * LDS holds two window buffers (chunk c is read while chunk c+1 lands) and a 9-slot ring of per-tap weight tiles (2 x 64 rows
+//     x 64 B); at tap T every wave issues its 1 KiB of the weights of tap T+4 and, on taps 1-5 of a chunk, 1 KiB of the next
+//     chunk's (or the next item's first) window.  Waits are COUNTED (`s_waitcnt vmcnt(N)`, N = the pieces issued in the last
+//     three taps): nothing ever drains the queue inside the stream;
+//   * the two wave groups run one barrier apart (group 1 takes one extra barrier up front): while one group issues the 8 fragment
+//     reads + DMA pieces of a tap, the other group's 16 MFMAs of the previous tap occupy the matrix pipe of the same SIMDs.
+// Ordering rules the schedule relies on (cdna_hip_programming.md, "256^2 8-phase template"): a DMA piece is visible to a reader
+// that has passed a barrier which every issuing wave reached after its counted wait; with the groups one barrier apart that is
+// "wait at the end of tap T's read segment, read in tap T+1's".  A buffer is re-filled no earlier than the read segment two taps
+// after its last read.
+#include "kernels.h"
+#include "elem16.h"
+#include <stdlib.h>
+#include <string.h>
+#include <type_traits>
+
+namespace adas {
+
+typedef __attribute__((ext_vector_type(4))) float qf32x4;
+typedef __attribute__((ext_vector_type(4))) uint32_t qu32x4;
+typedef __attribute__((address_space(3))) void* lds_vp;
+
+struct H8Dev {
+    const uint16_t* in;
+    const uint16_t* wgt;
+    const float* bias;
+    uint16_t* out;
+    const uint16_t* res;
+    uint32_t in_bytes, wgt_bytes, out_bytes, res_bytes;
+    int in_cs, in_coff, cin, H, W;
+    int out_cs, out_coff, cout;
+    int res_cs, res_coff, res_mode;
+    int nchunk;               // 32-channel chunks of the packed weights
+    int SW, NS, TPS, WW;      // strip width, strips per row, tiles per strip, window width (conv_halo.hip's plan)
+    uint32_t mg_ww, mg_sw;
+    int ntiles, tiles8, ncb;  // tiles, ceil(tiles / 8) (one contiguous range per XCD), 128-channel blocks
+};
+
+constexpr int H8_THR = 512;
+constexpr int H8_BM = 256;
+constexpr int H8_MAXPIX = 640;
+constexpr int H8_WIN = H8_MAXPIX * 64;          // bytes of one window buffer
+constexpr int H8_TAP = 2 * 64 * 64;             // bytes of one tap's weights (two 64-row blocks)
+constexpr int H8_WR = 2 * H8_WIN;               // byte offset of the weight ring
+constexpr int H8_LDS = H8_WR + 9 * H8_TAP;      // 155,648 B
+constexpr int H8_NWP = H8_MAXPIX / 16 / 8;      // window pieces per wave (5)
+constexpr int H8_SLAB = 9 * 64 * 64;            // bytes of one (64-channel block, chunk) weight slab
+constexpr uint32_t H8_OOB = 0xF0000000u;
+constexpr int H8_SLOTS = 32;                    // workgroups per XCD = CUs per XCD (MI355X: 8 x 32)
+
+// Synchronisation variants (template MODE): 1 = two barriers per tap, the two wave groups one barrier apart (the read segment of
+// one group runs under the MFMA segment of the other); 2 = one barrier per tap ROW (three taps), all waves free-running in
+// between.  Weight pieces are issued `look` taps ahead of their first read.  Measured in the lane network at 64 frames
+// (profiles/r02/h8_modes.txt): 1 wins from 16 chunks per item up (512 -> 512: 0.369 vs 0.389 ms for the three layers), 2 below
+// (128 -> 128: 0.494 vs 0.551 ms); a one-barrier-per-tap free-running form was never the best and is not kept.
+__host__ __device__ constexpr int h8_look(int mode) { return mode == 2 ? 6 : 4; }
+
+template <int N>
+__device__ __forceinline__ void h8_wait_vm() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+template <int ACT>
+__device__ __forceinline__ float h8_act(float v) {
+    if (ACT == ACT_SILU) return v * __frcp_rn(1.0f + __expf(-v));
+    if (ACT == ACT_RELU) return fmaxf(v, 0.0f);
+    return v;
+}
+
+// pieces a wave issues in the read segment of tap k of a chunk: one weight piece, plus one window piece on taps 1..5
+__host__ __device__ constexpr int h8_issued(int k) { return 1 + ((k >= 1 && k <= H8_NWP) ? 1 : 0); }
+// pieces that may still be in flight after the wait of tap k: per-tap barriers -> those issued in taps k-2, k-1, k (the piece a
+// tap k+1 read needs was issued at k+1-4); per-row barriers -> those issued in k's own row (row R+1 reads what row R-1 issued)
+__host__ __device__ constexpr int h8_allow(int mode, int k) {
+    return mode == 2 ? h8_issued(k) + h8_issued(k - 1) + h8_issued(k - 2)
+                     : h8_issued(k) + h8_issued((k + 8) % 9) + h8_issued((k + 7) % 9);
+}
+
+#ifdef ADAS_H8_PROF   // scratch instrumentation (tools/scratch/h8_prof.py): shader cycles of waves 0 and 4 per item phase
+__device__ unsigned long long g_h8_prof[256][16];
+#define H8P(i)                                      \
+    if (lane == 0 && grp == 0) {                    \
+        const unsigned long long t__ = clock64();   \
+        pacc__[i] += t__ - tprev__;                 \
+        tprev__ = t__;                              \
+    }
+#else
+#define H8P(i)
+#endif
+
+template <typename E, int ACT, int MODE>
+__global__ __launch_bounds__(H8_THR, 1) void conv_h8_kernel(H8Dev a) {
+    typedef typename E::vec8 hvec8;
+    constexpr int LOOK = h8_look(MODE);
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds8[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lrow = lane & 15, kg = lane >> 4;
+    const int hb = wave >> 2, grp = wave & 3;   // 64-channel half (= wave group), pixel quarter
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, nslot = gridDim.x >> 3;
+    // items of this XCD: tiles [xcd * tiles8, ...) x ncb channel blocks, channel block fastest (the blocks of a tile run on
+    // neighbouring CUs of one XCD at the same time: its window comes from HBM once)
+    int tiles_here = a.ntiles - xcd * a.tiles8;
+    tiles_here = tiles_here < 0 ? 0 : (tiles_here > a.tiles8 ? a.tiles8 : tiles_here);
+    const int nitem = tiles_here * a.ncb;
+    if (slot >= nitem) return;
+
+    __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc((void*)a.in, 0, a.in_bytes, 0x00020000);
+    __amdgpu_buffer_rsrc_t rwg = __builtin_amdgcn_make_buffer_rsrc((void*)a.wgt, 0, a.wgt_bytes, 0x00020000);
+    __amdgpu_buffer_rsrc_t rout = __builtin_amdgcn_make_buffer_rsrc((void*)a.out, 0, a.out_bytes, 0x00020000);
+    __amdgpu_buffer_rsrc_t rres = __builtin_amdgcn_make_buffer_rsrc((void*)(a.res_mode != RES_NONE ? a.res : a.out), 0,
+                                                                    a.res_mode != RES_NONE ? a.res_bytes : 0u, 0x00020000);
+    const int per_img = a.NS * a.TPS;
+    const int gsw[4] = {0, 2, 3, 1};
+    // lane part of a weight piece: rows (lane >> 2) of the wave's 16-row group, 16-byte position swizzled by the row key
+    const uint32_t wlane = (uint32_t)((lane >> 2) * 64 + (((lane & 3) ^ gsw[(lane >> 4) & 3]) << 4));
+    const uint32_t wpiece = (uint32_t)((lane & 3) ^ (((lane >> 4) & 1) << 1)) << 4;   // window: position -> source 16-byte chunk
+    // per-lane fragment read offset into the weight ring (bytes)
+    const uint32_t wrd = (uint32_t)(H8_WR + hb * 4096 + lrow * 64 + ((kg ^ gsw[(lrow >> 2) & 3]) << 4));
+    // epilogue: after the 16-lane row exchange a lane owns 8 consecutive channels: tile i + (kg & 1), channels (kg >> 1) * 8 ..
+    const uint32_t ch_lane = (uint32_t)((hb * 64 + (kg & 1) * 16 + (kg >> 1) * 8) * 2);
+
+    struct Item {
+        int img, sx0, p0, y_first, cb;
+    };
+    auto decode = [&](int k) {
+        Item it;
+        int tile = xcd * a.tiles8 + k / a.ncb;
+        it.cb = k % a.ncb;
+        it.img = tile / per_img;
+        tile -= it.img * per_img;
+        const int strip = tile / a.TPS, t = tile - strip * a.TPS;
+        it.sx0 = strip * a.SW;
+        it.p0 = t * H8_BM;
+        it.y_first = (int)(((uint32_t)it.p0 * a.mg_sw) >> 20);
+        return it;
+    };
+    // source byte offsets of this lane's 16 bytes in each of the wave's window pieces (chunk 0); H8_OOB -> the DMA writes zeros
+    auto win_offsets = [&](const Item& it, uint32_t* g) {
+        const int y_lastp = (int)(((uint32_t)(it.p0 + H8_BM - 1) * a.mg_sw) >> 20);
+        const int npix = (y_lastp - it.y_first + 3) * a.WW;
+        const int wy0 = it.y_first - 1, wx0 = it.sx0 - 1;
+#pragma unroll
+        for (int i = 0; i < H8_NWP; ++i) {
+            const int pix = (wave + 8 * i) * 16 + (lane >> 2);
+            const int wy = (int)(((uint32_t)pix * a.mg_ww) >> 20), wx = pix - wy * a.WW;
+            const int iy = wy0 + wy, ix = wx0 + wx;
+            const bool ok = pix < npix && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+            g[i] = ok ? ((uint32_t)((it.img * a.H + iy) * a.W + ix) * (uint32_t)a.in_cs + (uint32_t)a.in_coff) * 2u + wpiece : H8_OOB;
+        }
+    };
+    // scalar byte offset of this wave's 16 rows of (channel block cb, half hb, chunk 0, tap 0)
+    auto wgt_base = [&](int cb) { return (uint32_t)(((2 * cb + hb) * a.nchunk) * H8_SLAB + grp * 1024); };
+    auto load_bias = [&](int cb, float4* b) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) b[i] = *reinterpret_cast<const float4*>(a.bias + cb * 128 + hb * 64 + i * 16 + kg * 4);
+    };
+
+    int k = slot;
+    Item cur = decode(k);
+    uint32_t gcur[H8_NWP], gnxt[H8_NWP];
+    win_offsets(cur, gcur);
+    uint32_t wcur = wgt_base(cur.cb);
+    int par = 0;
+    float4 bias4[4];
+    load_bias(cur.cb, bias4);
+
+    // ---- prologue: window of chunk 0 into buffer 0, weights of taps 0 .. LOOK-1
+#pragma unroll
+    for (int i = 0; i < H8_NWP; ++i)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rin, (lds_vp)(lds8 + (wave + 8 * i) * 1024), 16, gcur[i], 0, 0, 0);
+#pragma unroll
+    for (int t = 0; t < LOOK; ++t)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rwg, (lds_vp)(lds8 + H8_WR + t * H8_TAP + wave * 1024), 16, wlane, wcur + t * 4096, 0, 0);
+    h8_wait_vm<0>();
+    __builtin_amdgcn_s_barrier();
+    if (MODE == 1 && hb) __builtin_amdgcn_s_barrier();   // group 1 runs one segment behind group 0
+
+#ifdef ADAS_H8_PROF
+    unsigned long long tprev__ = clock64();
+    unsigned long long pacc__[6] = {0, 0, 0, 0, 0, 0};
+    int nit__ = 0;
+#endif
+    for (;;) {
+        H8P(5)
+        const int kn = k + nslot;
+        const bool has_next = kn < nitem;
+        const Item nxt = decode(has_next ? kn : k);
+        win_offsets(nxt, gnxt);
+        if (!has_next) {
+#pragma unroll
+            for (int i = 0; i < H8_NWP; ++i) gnxt[i] = H8_OOB;
+        }
+        const uint32_t wnxt_item = wgt_base(nxt.cb);   // no next item: re-reads this item's weights into slots nobody reads
+
+        // byte offset (within a window buffer) of this lane's 16 bytes of output pixel j at each tap
+        uint32_t xoff[4][9];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int p = cur.p0 + (grp * 4 + j) * 16 + lrow;
+            const int y = (int)(((uint32_t)p * a.mg_sw) >> 20), xs = p - y * a.SW;
+            const int ap = (y - cur.y_first) * a.WW + xs;
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const int pw = ap + (t / 3) * a.WW + (t % 3);
+                xoff[j][t] = (uint32_t)(pw * 64 + ((kg ^ ((pw >> 1) & 2)) << 4));
+            }
+        }
+
+        uint32_t po[4];   // pixel index of the lane's output pixel j (H8_OOB outside the image: loads return 0, stores are dropped)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int p = cur.p0 + (grp * 4 + j) * 16 + lrow;
+            const int y = (int)(((uint32_t)p * a.mg_sw) >> 20), x = cur.sx0 + (p - y * a.SW);
+            po[j] = (y < a.H && x < a.W) ? (uint32_t)((cur.img * a.H + y) * a.W + x) : H8_OOB;
+        }
+        const uint32_t ch0 = (uint32_t)(cur.cb * 256) + ch_lane;
+        const bool has_res = a.res_mode != RES_NONE;
+        qu32x4 rraw[4][2];   // residual, fetched under the last row of taps of the last chunk
+
+        qf32x4 acc[4][4];   // starts at the bias
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = qf32x4{bias4[i].x, bias4[i].y, bias4[i].z, bias4[i].w};
+
+        H8P(0)
+        auto chunk = [&](auto last_c, const int c) {
+            constexpr bool lastc = decltype(last_c)::value;
+            if (!lastc) {
+#pragma unroll
+                for (int i = 0; i < H8_NWP; ++i) gcur[i] += 64u;   // the next chunk of the same window (H8_OOB + 64 * chunks stays out of range)
+            }
+            const uint32_t wthis = wcur + (uint32_t)c * H8_SLAB;
+            const uint32_t wnext = lastc ? wnxt_item : wthis + H8_SLAB;
+            const uint32_t winr = (uint32_t)(((par + c) & 1) * H8_WIN), winw = H8_WIN - winr;   // window buffer read / filled
+            auto tap = [&](auto kk_c) {
+                constexpr int kk = decltype(kk_c)::value;
+                // ---------------- read segment: fragments of tap kk, DMA pieces, counted wait
+                if (lastc && kk == 6 && has_res) {
+                    // 16-byte residual loads in the layout of the epilogue's stores.  They sit in the in-order queue between the
+                    // pieces of taps 5 and 6: the waits of taps 6-8 allow 8 more outstanding operations
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const uint32_t ro = po[j] == H8_OOB ? H8_OOB : (po[j] * (uint32_t)a.res_cs + (uint32_t)a.res_coff) * 2u + ch0;
+                        rraw[j][0] = __builtin_amdgcn_raw_buffer_load_b128(rres, ro, 0, 0);
+                        rraw[j][1] = __builtin_amdgcn_raw_buffer_load_b128(rres, ro + 64, 0, 0);
+                    }
+                }
+                hvec8 wf[4], xf[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) wf[i] = *reinterpret_cast<const hvec8*>(lds8 + wrd + kk * H8_TAP + i * 1024);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) xf[j] = *reinterpret_cast<const hvec8*>(lds8 + xoff[j][kk] + winr);
+                {
+                    constexpr int kt = (kk + LOOK) % 9;
+                    const uint32_t src = (kk + LOOK < 9 ? wthis : wnext) + (uint32_t)kt * 4096u;
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rwg, (lds_vp)(lds8 + H8_WR + kt * H8_TAP + wave * 1024), 16, wlane, src, 0, 0);
+                }
+                if (kk >= 1 && kk <= H8_NWP)
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rin, (lds_vp)(lds8 + winw + (wave + 8 * (kk - 1)) * 1024), 16, lastc ? gnxt[kk - 1] : gcur[kk - 1], 0, 0, 0);
+                constexpr bool sync_here = MODE != 2 || kk % 3 == 2;
+                // an item starts drained (the epilogue's vmcnt(0)): its first taps need no wait
+                if (sync_here && (c > 0 || kk >= 3)) {
+                    if (lastc && kk >= 6 && has_res) h8_wait_vm<h8_allow(MODE, kk) + 8>();
+                    else h8_wait_vm<h8_allow(MODE, kk)>();
+                }
+                if (MODE == 1) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    __builtin_amdgcn_s_barrier();
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                // ---------------- MFMA segment
+                __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[i][j] = E::mfma(wf[i], xf[j], acc[i][j]);
+                __builtin_amdgcn_s_setprio(0);
+                if (sync_here) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    __builtin_amdgcn_s_barrier();
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            };
+            tap(std::integral_constant<int, 0>{}); tap(std::integral_constant<int, 1>{}); tap(std::integral_constant<int, 2>{});
+            tap(std::integral_constant<int, 3>{}); tap(std::integral_constant<int, 4>{}); tap(std::integral_constant<int, 5>{});
+            tap(std::integral_constant<int, 6>{}); tap(std::integral_constant<int, 7>{}); tap(std::integral_constant<int, 8>{});
+        };
+        for (int c = 0; c + 1 < a.nchunk; ++c) chunk(std::false_type{}, c);
+        chunk(std::true_type{}, a.nchunk - 1);
+
+        H8P(1)
+        // ---------------- epilogue: lane holds channels kg*4..+3 of pixel lrow of every (i, j) tile (bias already in)
+        float4 biasn[4];
+        load_bias(nxt.cb, biasn);
+        // value of (pixel j, channel tile i) after residual / activation; q: the lane's 4 residual channels of that tile
+        auto finish = [&](int i, int j, uint2 q, float v[4]) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = acc[i][j][e];
+            if (has_res) {
+                const float rv[4] = {E::lo(q.x), E::hi(q.x), E::lo(q.y), E::hi(q.y)};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = a.res_mode == RES_BEFORE_ACT ? h8_act<ACT>(v[e] + rv[e]) : h8_act<ACT>(v[e]) + rv[e];
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = h8_act<ACT>(v[e]);
+            }
+        };
+        H8P(2)
+        h8_wait_vm<0>();   // the stream's pieces retire before the stores join the queue: the counted waits of the next item then
+                           // never depend on how stores and loads retire relative to each other
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const uint32_t oo = po[j] == H8_OOB ? H8_OOB : (po[j] * (uint32_t)a.out_cs + (uint32_t)a.out_coff) * 2u + ch0;
+#pragma unroll
+            for (int i = 0; i < 4; i += 2) {
+                uint2 qx = make_uint2(0u, 0u), qy = qx;
+                if (has_res) {
+                    // v_permlane16_swap is its own inverse: the exchange that forms the 16-byte stores hands a lane its two
+                    // 4-channel groups of the 16 bytes it loaded in that layout
+                    const qu32x4 w = rraw[j][i >> 1];
+                    const auto r0 = __builtin_amdgcn_permlane16_swap(w[0], w[2], false, false);
+                    const auto r1 = __builtin_amdgcn_permlane16_swap(w[1], w[3], false, false);
+                    qx = make_uint2(r0[0], r1[0]);
+                    qy = make_uint2(r0[1], r1[1]);
+                }
+                float vx[4], vy[4];
+                finish(i, j, qx, vx);
+                finish(i + 1, j, qy, vy);
+                const uint32_t x0 = E::pack2(vx[0], vx[1]), x1 = E::pack2(vx[2], vx[3]);
+                const uint32_t y0 = E::pack2(vy[0], vy[1]), y1 = E::pack2(vy[2], vy[3]);
+                const auto s0 = __builtin_amdgcn_permlane16_swap(x0, y0, false, false);
+                const auto s1 = __builtin_amdgcn_permlane16_swap(x1, y1, false, false);
+                __builtin_amdgcn_raw_buffer_store_b128(qu32x4{s0[0], s1[0], s0[1], s1[1]}, rout, oo + i * 32, 0, 0);
+            }
+        }
+
+        H8P(3)
+#ifdef ADAS_H8_PROF
+        ++nit__;
+#endif
+        if (!has_next) break;
+        k = kn;
+        cur = nxt;
+#pragma unroll
+        for (int i = 0; i < H8_NWP; ++i) gcur[i] = gnxt[i];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) bias4[i] = biasn[i];
+        wcur = wnxt_item;
+        par = (par + a.nchunk) & 1;
+    }
+    if (MODE == 1 && !hb) __builtin_amdgcn_s_barrier();   // pairs with group 1's extra barrier
+#ifdef ADAS_H8_PROF
+    if (lane == 0 && grp == 0) {
+        unsigned long long* b__ = g_h8_prof[blockIdx.x & 255];
+        for (int i__ = 0; i__ < 6; ++i__) atomicAdd(&b__[i__ + 8 * hb], pacc__[i__]);
+        atomicAdd(&b__[7 + 8 * hb], (unsigned long long)nit__);
+    }
+#endif
+}
+
+#ifdef ADAS_H8_PROF
+extern "C" int adas_debug_h8_prof(unsigned long long* out16, int reset) {
+    static unsigned long long h[256][16];
+    if (out16) {
+        if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_h8_prof), sizeof(h)) != hipSuccess) return -1;
+        for (int i = 0; i < 16; ++i) {
+            out16[i] = 0;
+            for (int b = 0; b < 256; ++b) out16[i] += h[b][i];
+        }
+    }
+    if (reset) {
+        memset(h, 0, sizeof(h));
+        if (hipMemcpyToSymbol(HIP_SYMBOL(g_h8_prof), h, sizeof(h)) != hipSuccess) return -1;
+    }
+    return 0;
+}
+#endif
+
+// -------------------------------------------------------------------------------------
+static int h8_mode() {   // ADAS_HALO8: 0 off, 1 on (default: synchronisation variant picked per layer), 2 / 3 force variant 2 / 1
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("ADAS_HALO8");
+        v = e ? atoi(e) : 1;
+    }
+    return v;
+}
+
+bool halo8_applicable(int kh, int kw, int stride, int pad, int n, const TView& in, const TView& out, const TView& res, int res_mode) {
+    if (!h8_mode()) return false;
+    if (kh != 3 || kw != 3 || stride != 1 || pad != 1) return false;
+    if (in.f32 || out.f32 || out.h != in.h || out.w != in.w) return false;
+    if ((out.c & 127) || (in.c & 31) || in.c < 64) return false;
+    if ((in.cs & 7) || (in.coff & 7) || (out.cs & 7) || (out.coff & 7)) return false;
+    if (res_mode != RES_NONE && ((res.cs & 7) || (res.coff & 7) || res.f32)) return false;
+    if ((double)n * in.h * in.w * in.cs * 2.0 >= (double)H8_OOB || (double)n * out.h * out.w * out.cs * 2.0 >= (double)H8_OOB) return false;
+    if (res_mode != RES_NONE && (double)n * out.h * out.w * res.cs * 2.0 >= (double)H8_OOB) return false;
+    HaloPlan pl;
+    if (!plan_halo(out.h, out.w, 1, &pl) || pl.eff < 0.6 || pl.maxpix > H8_MAXPIX) return false;
+    // one workgroup per CU walking its XCD's items in rounds of 32: the launch has to fill the chip, in nearly whole rounds
+    const long tiles8 = ((long)n * pl.NS * pl.TPS + 7) / 8, items_xcd = tiles8 * (out.c / 128);
+    if (items_xcd < H8_SLOTS) return false;
+    const long rounds = (items_xcd + H8_SLOTS - 1) / H8_SLOTS;
+    return (double)items_xcd / (double)(rounds * H8_SLOTS) >= 0.8;
+}
+
+template <typename E, int MODE>
+static hipError_t h8_launch(const H8Dev& d, int act, dim3 grid, hipStream_t st) {
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute((const void*)conv_h8_kernel<E, ACT_NONE, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)conv_h8_kernel<E, ACT_SILU, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)conv_h8_kernel<E, ACT_RELU, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_done = true;
+    }
+    if (act == ACT_SILU) hipLaunchKernelGGL((conv_h8_kernel<E, ACT_SILU, MODE>), grid, dim3(H8_THR), H8_LDS, st, d);
+    else if (act == ACT_RELU) hipLaunchKernelGGL((conv_h8_kernel<E, ACT_RELU, MODE>), grid, dim3(H8_THR), H8_LDS, st, d);
+    else hipLaunchKernelGGL((conv_h8_kernel<E, ACT_NONE, MODE>), grid, dim3(H8_THR), H8_LDS, st, d);
+    return hipGetLastError();
+}
+
+hipError_t launch_conv_halo8(const ConvArgs& a, hipStream_t st) {
+    HaloPlan pl;
+    if (!halo8_applicable(a.kh, a.kw, a.stride, a.pad, a.n, a.in, a.out, a.res, a.res_mode) || !plan_halo(a.out.h, a.out.w, 1, &pl))
+        return hipErrorNotSupported;
+    H8Dev d;
+    d.in = (const uint16_t*)a.in.p; d.wgt = (const uint16_t*)a.wgt; d.bias = a.bias; d.out = (uint16_t*)a.out.p;
+    d.res = (const uint16_t*)a.res.p;
+    d.in_cs = a.in.cs; d.in_coff = a.in.coff; d.cin = a.in.c; d.H = a.in.h; d.W = a.in.w;
+    d.out_cs = a.out.cs; d.out_coff = a.out.coff; d.cout = a.out.c;
+    d.res_cs = a.res.cs; d.res_coff = a.res.coff; d.res_mode = a.res_mode;
+    d.nchunk = (a.in.c + 31) / 32;
+    d.in_bytes = (uint32_t)((size_t)a.n * a.in.h * a.in.w * a.in.cs * 2);
+    d.wgt_bytes = (uint32_t)((size_t)(a.out.c / 64) * d.nchunk * H8_SLAB);
+    d.out_bytes = (uint32_t)((size_t)a.n * a.out.h * a.out.w * a.out.cs * 2);
+    d.res_bytes = a.res_mode != RES_NONE ? (uint32_t)((size_t)a.n * a.out.h * a.out.w * a.res.cs * 2) : 0u;
+    d.SW = pl.SW; d.NS = pl.NS; d.TPS = pl.TPS; d.WW = pl.WW;
+    d.mg_ww = pl.mg_ww; d.mg_sw = pl.mg_sw;
+    d.ntiles = a.n * pl.NS * pl.TPS;
+    d.tiles8 = (d.ntiles + 7) / 8;
+    d.ncb = a.out.c / 128;
+    const int items_xcd = d.tiles8 * d.ncb;
+    const int slots = items_xcd < H8_SLOTS ? items_xcd : H8_SLOTS;
+    dim3 grid(8 * slots);
+    const int forced = h8_mode();
+    const bool pingpong = forced == 3 || (forced != 2 && d.nchunk >= 12);
+    if (a.prec == PREC_FP16) return pingpong ? h8_launch<Fp16, 1>(d, a.act, grid, st) : h8_launch<Fp16, 2>(d, a.act, grid, st);
+    return pingpong ? h8_launch<Bf16, 1>(d, a.act, grid, st) : h8_launch<Bf16, 2>(d, a.act, grid, st);
+}
+
+}  // namespace adas

@@ -315,6 +315,8 @@ const char* conv_kernel_name(const ConvArgs& a, int prec, int kernel) {
         snprintf(buf, sizeof(buf), a.out.c <= 32 ? "conv_halo_rw_kernel<%d,%s,bn32>" : "conv_halo_rw_kernel<%d,%s>", (a.in.c + 31) / 32, actn);
     } else if (kernel == CONV_HALO && halo_s2p_applicable(a.kh, a.kw, a.stride, a.pad, a.res_mode, a.n, a.in, a.out)) {
         snprintf(buf, sizeof(buf), "conv_s2p_kernel<%s>", actn);
+    } else if (kernel == CONV_HALO && halo8_applicable(a.kh, a.kw, a.stride, a.pad, a.n, a.in, a.out, a.res, a.res_mode)) {
+        snprintf(buf, sizeof(buf), "conv_h8_kernel<%s>", actn);
     } else if (kernel == CONV_HALO) {
         snprintf(buf, sizeof(buf), "conv_halo_kernel<%d,%s,s%d>", a.out.c <= 16 ? 16 : (a.out.c <= 32 ? 32 : 64), actn, a.stride);
     } else if (kernel == CONV_FC) {
@@ -413,6 +415,10 @@ hipError_t launch_conv(const ConvArgs& a, int prec, hipStream_t st) {
         }
         if (halo_s2p_applicable(a.kh, a.kw, a.stride, a.pad, a.res_mode, a.n, a.in, a.out)) {
             hipError_t e = launch_conv_halo_s2p(a, st);
+            if (e != hipErrorNotSupported) return e;
+        }
+        if (halo8_applicable(a.kh, a.kw, a.stride, a.pad, a.n, a.in, a.out, a.res, a.res_mode)) {
+            hipError_t e = launch_conv_halo8(a, st);
             if (e != hipErrorNotSupported) return e;
         }
         return launch_conv_halo(a, st);

@@ -408,6 +408,8 @@ int adas_engine_layer_kernel(const adas_engine* e, int layer, int batch, char* n
         a.in = make_view(e, o.in_buf[0], o.in_coff[0], o.in_c[0]);
         a.out = make_view(e, o.out_buf, o.out_coff, o.out_c);
         a.n = batch; a.kh = o.kh; a.kw = o.kw; a.stride = o.stride; a.pad = o.pad; a.act = o.act; a.res_mode = o.res_mode;
+        if (o.res_mode != RES_NONE) a.res = make_view(e, o.res_buf, o.res_coff, o.out_c);
+        else { a.res = a.out; a.res.p = nullptr; }
         a.k = op.k; a.kpad = op.kpad; a.m = batch * a.out.h * a.out.w; a.max_n = e->max_batch; a.prec = e->prec;
         snprintf(name, cap, "%s%s", conv_kernel_name(a, e->prec, op.kernel), op.fuse_pool >= 0 ? "+pool" : "");
     } else if (o.type == OP_DETECT_V8 && op.det_src[0] >= 0) {

@@ -45,6 +45,16 @@ hipError_t launch_conv_halo_rw(const ConvArgs& a, hipStream_t st);
 // conv_halo_s2.hip: stride-2 3x3 for Cout % 128 == 0 (parity-plane LDS window, 8 waves, same weight packing)
 bool halo_s2p_applicable(int kh, int kw, int stride, int pad, int res_mode, int n, const TView& in, const TView& out);
 hipError_t launch_conv_halo_s2p(const ConvArgs& a, hipStream_t st);
+// conv_halo.hip's tile plan (strip-linear tiles of halo_bm(S) output pixels), shared with conv_halo8.hip
+struct HaloPlan {
+    int SW, NS, TPS, WW, maxpix;   // strip width, strips per row, tiles per strip, window width, window pixels
+    double eff;                    // useful fraction of the tiles' pixels
+    uint32_t mg_ww, mg_sw;         // n / WW == (n * mg_ww) >> 20, n / SW == (n * mg_sw) >> 20 for every n the kernels divide
+};
+bool plan_halo(int Ho, int Wo, int S, HaloPlan* out);
+// conv_halo8.hip: stride-1 3x3 for Cout % 128 == 0, Cin % 32 == 0: persistent, LDS-DMA fed, counted waits (same weight packing)
+bool halo8_applicable(int kh, int kw, int stride, int pad, int n, const TView& in, const TView& out, const TView& res, int res_mode);
+hipError_t launch_conv_halo8(const ConvArgs& a, hipStream_t st);
 // returns hipSuccess or the launch error.  prec: PREC_*.
 hipError_t launch_conv(const ConvArgs& a, int prec, hipStream_t st);
 const char* conv_tile_name(const ConvArgs& a, int prec);
