@@ -306,47 +306,54 @@ __global__ __launch_bounds__(H8_THR, 1) void conv_h8_kernel(H8Dev a) {
         // ---------------- epilogue: lane holds channels kg*4..+3 of pixel lrow of every (i, j) tile (bias already in)
         float4 biasn[4];
         load_bias(nxt.cb, biasn);
-        // value of (pixel j, channel tile i) after residual / activation; q: the lane's 4 residual channels of that tile
-        auto finish = [&](int i, int j, uint2 q, float v[4]) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = acc[i][j][e];
-            if (has_res) {
-                const float rv[4] = {E::lo(q.x), E::hi(q.x), E::lo(q.y), E::hi(q.y)};
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = a.res_mode == RES_BEFORE_ACT ? h8_act<ACT>(v[e] + rv[e]) : h8_act<ACT>(v[e]) + rv[e];
-            } else {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = h8_act<ACT>(v[e]);
-            }
-        };
         H8P(2)
         h8_wait_vm<0>();   // the stream's pieces retire before the stores join the queue: the counted waits of the next item then
                            // never depend on how stores and loads retire relative to each other
+        // RM: residual mode as a compile-time constant (one uniform branch per item instead of selects per element)
+        auto write_out = [&](auto rm_c) {
+            constexpr int RM = decltype(rm_c)::value;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const uint32_t oo = po[j] == H8_OOB ? H8_OOB : (po[j] * (uint32_t)a.out_cs + (uint32_t)a.out_coff) * 2u + ch0;
+            for (int j = 0; j < 4; ++j) {
+                const uint32_t oo = po[j] == H8_OOB ? H8_OOB : (po[j] * (uint32_t)a.out_cs + (uint32_t)a.out_coff) * 2u + ch0;
 #pragma unroll
-            for (int i = 0; i < 4; i += 2) {
-                uint2 qx = make_uint2(0u, 0u), qy = qx;
-                if (has_res) {
-                    // v_permlane16_swap is its own inverse: the exchange that forms the 16-byte stores hands a lane its two
-                    // 4-channel groups of the 16 bytes it loaded in that layout
-                    const qu32x4 w = rraw[j][i >> 1];
-                    const auto r0 = __builtin_amdgcn_permlane16_swap(w[0], w[2], false, false);
-                    const auto r1 = __builtin_amdgcn_permlane16_swap(w[1], w[3], false, false);
-                    qx = make_uint2(r0[0], r1[0]);
-                    qy = make_uint2(r0[1], r1[1]);
+                for (int i = 0; i < 4; i += 2) {
+                    float vx[4], vy[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        vx[e] = acc[i][j][e];
+                        vy[e] = acc[i + 1][j][e];
+                    }
+                    if (RM != RES_NONE) {
+                        // v_permlane16_swap is its own inverse: the exchange that forms the 16-byte stores hands a lane its two
+                        // 4-channel groups of the 16 bytes it loaded in that layout
+                        const qu32x4 w = rraw[j][i >> 1];
+                        const auto r0 = __builtin_amdgcn_permlane16_swap(w[0], w[2], false, false);
+                        const auto r1 = __builtin_amdgcn_permlane16_swap(w[1], w[3], false, false);
+                        const float rx[4] = {E::lo(r0[0]), E::hi(r0[0]), E::lo(r1[0]), E::hi(r1[0])};
+                        const float ry[4] = {E::lo(r0[1]), E::hi(r0[1]), E::lo(r1[1]), E::hi(r1[1])};
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            vx[e] = RM == RES_BEFORE_ACT ? h8_act<ACT>(vx[e] + rx[e]) : h8_act<ACT>(vx[e]) + rx[e];
+                            vy[e] = RM == RES_BEFORE_ACT ? h8_act<ACT>(vy[e] + ry[e]) : h8_act<ACT>(vy[e]) + ry[e];
+                        }
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            vx[e] = h8_act<ACT>(vx[e]);
+                            vy[e] = h8_act<ACT>(vy[e]);
+                        }
+                    }
+                    const uint32_t x0 = E::pack2(vx[0], vx[1]), x1 = E::pack2(vx[2], vx[3]);
+                    const uint32_t y0 = E::pack2(vy[0], vy[1]), y1 = E::pack2(vy[2], vy[3]);
+                    const auto s0 = __builtin_amdgcn_permlane16_swap(x0, y0, false, false);
+                    const auto s1 = __builtin_amdgcn_permlane16_swap(x1, y1, false, false);
+                    __builtin_amdgcn_raw_buffer_store_b128(qu32x4{s0[0], s1[0], s0[1], s1[1]}, rout, oo + i * 32, 0, 0);
                 }
-                float vx[4], vy[4];
-                finish(i, j, qx, vx);
-                finish(i + 1, j, qy, vy);
-                const uint32_t x0 = E::pack2(vx[0], vx[1]), x1 = E::pack2(vx[2], vx[3]);
-                const uint32_t y0 = E::pack2(vy[0], vy[1]), y1 = E::pack2(vy[2], vy[3]);
-                const auto s0 = __builtin_amdgcn_permlane16_swap(x0, y0, false, false);
-                const auto s1 = __builtin_amdgcn_permlane16_swap(x1, y1, false, false);
-                __builtin_amdgcn_raw_buffer_store_b128(qu32x4{s0[0], s1[0], s0[1], s1[1]}, rout, oo + i * 32, 0, 0);
             }
-        }
+        };
+        if (a.res_mode == RES_NONE) write_out(std::integral_constant<int, RES_NONE>{});
+        else if (a.res_mode == RES_BEFORE_ACT) write_out(std::integral_constant<int, RES_BEFORE_ACT>{});
+        else write_out(std::integral_constant<int, RES_AFTER_ACT>{});
 
         H8P(3)
 #ifdef ADAS_H8_PROF
