@@ -229,6 +229,7 @@ __global__ __launch_bounds__(H8_THR, 1) void conv_h8_kernel(H8Dev a) {
         const uint32_t ch0 = (uint32_t)(cur.cb * 256) + ch_lane;
         const bool has_res = a.res_mode != RES_NONE;
         qu32x4 rraw[4][2];   // residual, fetched under the last row of taps of the last chunk
+        float4 biasn[4];     // the next item's bias, fetched there too
 
         qf32x4 acc[4][4];   // starts at the bias
 #pragma unroll
@@ -249,9 +250,10 @@ __global__ __launch_bounds__(H8_THR, 1) void conv_h8_kernel(H8Dev a) {
             auto tap = [&](auto kk_c) {
                 constexpr int kk = decltype(kk_c)::value;
                 // ---------------- read segment: fragments of tap kk, DMA pieces, counted wait
+                if (lastc && kk == 6) load_bias(nxt.cb, biasn);
                 if (lastc && kk == 6 && has_res) {
-                    // 16-byte residual loads in the layout of the epilogue's stores.  They sit in the in-order queue between the
-                    // pieces of taps 5 and 6: the waits of taps 6-8 allow 8 more outstanding operations
+                    // 16-byte residual loads in the layout of the epilogue's stores.  These (8) and the bias loads (4) sit in the
+                    // in-order queue between the pieces of taps 5 and 6: the waits of taps 6-8 allow that many more operations
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         const uint32_t ro = po[j] == H8_OOB ? H8_OOB : (po[j] * (uint32_t)a.res_cs + (uint32_t)a.res_coff) * 2u + ch0;
@@ -274,7 +276,8 @@ __global__ __launch_bounds__(H8_THR, 1) void conv_h8_kernel(H8Dev a) {
                 constexpr bool sync_here = MODE != 2 || kk % 3 == 2;
                 // an item starts drained (the epilogue's vmcnt(0)): its first taps need no wait
                 if (sync_here && (c > 0 || kk >= 3)) {
-                    if (lastc && kk >= 6 && has_res) h8_wait_vm<h8_allow(MODE, kk) + 8>();
+                    if (lastc && kk >= 6 && has_res) h8_wait_vm<h8_allow(MODE, kk) + 12>();
+                    else if (lastc && kk >= 6) h8_wait_vm<h8_allow(MODE, kk) + 4>();
                     else h8_wait_vm<h8_allow(MODE, kk)>();
                 }
                 if (MODE == 1) {
@@ -304,8 +307,6 @@ __global__ __launch_bounds__(H8_THR, 1) void conv_h8_kernel(H8Dev a) {
 
         H8P(1)
         // ---------------- epilogue: lane holds channels kg*4..+3 of pixel lrow of every (i, j) tile (bias already in)
-        float4 biasn[4];
-        load_bias(nxt.cb, biasn);
         H8P(2)
         h8_wait_vm<0>();   // the stream's pieces retire before the stores join the queue: the counted waits of the next item then
                            // never depend on how stores and loads retire relative to each other
