@@ -147,19 +147,26 @@ __global__ __launch_bounds__(H8_THR, 1) void conv_h8_kernel(H8Dev a) {
         it.y_first = (int)(((uint32_t)it.p0 * a.mg_sw) >> 20);
         return it;
     };
-    // source byte offsets of this lane's 16 bytes in each of the wave's window pieces (chunk 0); H8_OOB -> the DMA writes zeros
-    auto win_offsets = [&](const Item& it, uint32_t* g) {
+    // source byte offset of this lane's 16 bytes in the wave's window piece i (chunk 0); H8_OOB -> the DMA writes zeros
+    auto win_offset = [&](const Item& it, int i) {
         const int y_lastp = (int)(((uint32_t)(it.p0 + H8_BM - 1) * a.mg_sw) >> 20);
         const int npix = (y_lastp - it.y_first + 3) * a.WW;
-        const int wy0 = it.y_first - 1, wx0 = it.sx0 - 1;
-#pragma unroll
-        for (int i = 0; i < H8_NWP; ++i) {
-            const int pix = (wave + 8 * i) * 16 + (lane >> 2);
-            const int wy = (int)(((uint32_t)pix * a.mg_ww) >> 20), wx = pix - wy * a.WW;
-            const int iy = wy0 + wy, ix = wx0 + wx;
-            const bool ok = pix < npix && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
-            g[i] = ok ? ((uint32_t)((it.img * a.H + iy) * a.W + ix) * (uint32_t)a.in_cs + (uint32_t)a.in_coff) * 2u + wpiece : H8_OOB;
-        }
+        const int pix = (wave + 8 * i) * 16 + (lane >> 2);
+        const int wy = (int)(((uint32_t)pix * a.mg_ww) >> 20), wx = pix - wy * a.WW;
+        const int iy = it.y_first - 1 + wy, ix = it.sx0 - 1 + wx;
+        const bool ok = pix < npix && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+        return ok ? ((uint32_t)((it.img * a.H + iy) * a.W + ix) * (uint32_t)a.in_cs + (uint32_t)a.in_coff) * 2u + wpiece : H8_OOB;
+    };
+    // window pixel of this lane's output pixel j at tap (0, 0), and from it the byte offset (within a window buffer) of the
+    // lane's 16 bytes at tap t
+    auto tap00 = [&](const Item& it, int j) {
+        const int p = it.p0 + (grp * 4 + j) * 16 + lrow;
+        const int y = (int)(((uint32_t)p * a.mg_sw) >> 20), xs = p - y * a.SW;
+        return (y - it.y_first) * a.WW + xs;
+    };
+    auto tap_offset = [&](int ap, int t) {
+        const int pw = ap + (t / 3) * a.WW + (t % 3);
+        return (uint32_t)(pw * 64 + ((kg ^ ((pw >> 1) & 2)) << 4));
     };
     // scalar byte offset of this wave's 16 rows of (channel block cb, half hb, chunk 0, tap 0)
     auto wgt_base = [&](int cb) { return (uint32_t)(((2 * cb + hb) * a.nchunk) * H8_SLAB + grp * 1024); };
@@ -171,7 +178,15 @@ __global__ __launch_bounds__(H8_THR, 1) void conv_h8_kernel(H8Dev a) {
     int k = slot;
     Item cur = decode(k);
     uint32_t gcur[H8_NWP], gnxt[H8_NWP];
-    win_offsets(cur, gcur);
+#pragma unroll
+    for (int i = 0; i < H8_NWP; ++i) gcur[i] = win_offset(cur, i);
+    uint32_t xoff[4][9];   // tap offsets of the item being computed; re-written tap by tap for the next item during the last chunk
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int ap = tap00(cur, j);
+#pragma unroll
+        for (int t = 0; t < 9; ++t) xoff[j][t] = tap_offset(ap, t);
+    }
     uint32_t wcur = wgt_base(cur.cb);
     int par = 0;
     float4 bias4[4];
@@ -197,27 +212,9 @@ __global__ __launch_bounds__(H8_THR, 1) void conv_h8_kernel(H8Dev a) {
         H8P(5)
         const int kn = k + nslot;
         const bool has_next = kn < nitem;
-        const Item nxt = decode(has_next ? kn : k);
-        win_offsets(nxt, gnxt);
-        if (!has_next) {
-#pragma unroll
-            for (int i = 0; i < H8_NWP; ++i) gnxt[i] = H8_OOB;
-        }
-        const uint32_t wnxt_item = wgt_base(nxt.cb);   // no next item: re-reads this item's weights into slots nobody reads
-
-        // byte offset (within a window buffer) of this lane's 16 bytes of output pixel j at each tap
-        uint32_t xoff[4][9];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int p = cur.p0 + (grp * 4 + j) * 16 + lrow;
-            const int y = (int)(((uint32_t)p * a.mg_sw) >> 20), xs = p - y * a.SW;
-            const int ap = (y - cur.y_first) * a.WW + xs;
-#pragma unroll
-            for (int t = 0; t < 9; ++t) {
-                const int pw = ap + (t / 3) * a.WW + (t % 3);
-                xoff[j][t] = (uint32_t)(pw * 64 + ((kg ^ ((pw >> 1) & 2)) << 4));
-            }
-        }
+        Item nxt = cur;           // decoded at the start of the last chunk, with everything else the next item needs
+        uint32_t wnxt_item = 0;
+        int apn[4] = {0, 0, 0, 0};
 
         uint32_t po[4];   // pixel index of the lane's output pixel j (H8_OOB outside the image: loads return 0, stores are dropped)
 #pragma unroll
@@ -240,6 +237,12 @@ __global__ __launch_bounds__(H8_THR, 1) void conv_h8_kernel(H8Dev a) {
         H8P(0)
         auto chunk = [&](auto last_c, const int c) {
             constexpr bool lastc = decltype(last_c)::value;
+            if (lastc) {
+                nxt = decode(has_next ? kn : k);
+                wnxt_item = wgt_base(nxt.cb);   // no next item: re-reads this item's weights into slots nobody reads
+#pragma unroll
+                for (int j = 0; j < 4; ++j) apn[j] = tap00(nxt, j);
+            }
             if (!lastc) {
 #pragma unroll
                 for (int i = 0; i < H8_NWP; ++i) gcur[i] += 64u;   // the next chunk of the same window (H8_OOB + 64 * chunks stays out of range)
@@ -273,6 +276,13 @@ __global__ __launch_bounds__(H8_THR, 1) void conv_h8_kernel(H8Dev a) {
                 }
                 if (kk >= 1 && kk <= H8_NWP)
                     __builtin_amdgcn_raw_ptr_buffer_load_lds(rin, (lds_vp)(lds8 + winw + (wave + 8 * (kk - 1)) * 1024), 16, lastc ? gnxt[kk - 1] : gcur[kk - 1], 0, 0, 0);
+                if (lastc) {
+                    // the next item's addresses, computed where this item no longer needs the registers: tap kk's offsets once its
+                    // fragment reads are issued, window piece kk one tap before it is issued
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) xoff[j][kk] = tap_offset(apn[j], kk);
+                    if (kk < H8_NWP) gnxt[kk] = has_next ? win_offset(nxt, kk) : H8_OOB;
+                }
                 constexpr bool sync_here = MODE != 2 || kk % 3 == 2;
                 // an item starts drained (the epilogue's vmcnt(0)): its first taps need no wait
                 if (sync_here && (c > 0 || kk >= 3)) {
