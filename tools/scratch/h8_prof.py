@@ -25,18 +25,18 @@ e = CE.HipEngine(path, "fp16", a.batch)
 xin = np.random.default_rng(0).uniform(0, 1, (a.batch, 3, H * a.s, W * a.s)).astype(np.float32)
 buf = L.DeviceBuffer.from_array(xin)
 lib = C.CDLL(L.LIB_PATH)
-out = (C.c_ulonglong * 16)()
+out = (C.c_ulonglong * 32)()
 e.profile(buf.ptr, a.batch, 2)
 lib.adas_debug_h8_prof(out, 1)
 rows = e.profile(buf.ptr, a.batch, 5)
 lib.adas_debug_h8_prof(out, 0)
 ms = [r[3] for r in rows if r[0] == "test"][0]
-names = ["item setup (decode, offsets, acc init)", "chunk loop", "epilogue: loads + address math", "epilogue: drain + compute + stores", "-", "loop top"]
+names = ["item setup", "first chunk", "epilogue: address math", "epilogue: drain + compute + stores", "last chunk: tap 8", "loop top", "middle chunks (all)", None] + ["last chunk: tap %d" % t for t in range(8)]
 print(f"layer {ms*1e3:.1f} us")
 for g in (0, 1):
-    n = out[7 + 8 * g]
-    tot = sum(out[i + 8 * g] for i in range(6))
+    n = out[7 + 16 * g]
+    tot = sum(out[i + 16 * g] for i in range(16) if i != 7)
     print(f" wave group {g}: {n} items; mean cycles per item:")
     for i, nm in enumerate(names):
-        print(f"  {nm:40s} {out[i + 8 * g]/max(n,1):9.0f}  {100*out[i + 8 * g]/max(tot,1):5.1f}%")
+        if nm: print(f"  {nm:40s} {out[i + 16 * g]/max(n,1):9.0f}  {100*out[i + 16 * g]/max(tot,1):5.1f}%")
     print(f"  {'total':40s} {tot/max(n,1):9.0f}")

@@ -44,7 +44,8 @@ struct H8Dev {
     int nchunk;               // 32-channel chunks of the packed weights
     int SW, NS, TPS, WW;      // strip width, strips per row, tiles per strip, window width (conv_halo.hip's plan)
     uint32_t mg_ww, mg_sw;
-    int ntiles, tiles8, ncb;  // tiles, ceil(tiles / 8) (one contiguous range per XCD), 128-channel blocks
+    uint32_t mg_img, mg_tps, mg_upt;  // ceil(2^32 / d) for d = NS * TPS, TPS, ncb / cpw: unit -> tile -> (image, strip) by multiply-high
+    int ntiles, tiles8, ncb, cpw;  // tiles, ceil(tiles / 8) (one contiguous range per XCD), 128-channel blocks
 };
 
 constexpr int H8_THR = 512;
@@ -88,7 +89,7 @@ __host__ __device__ constexpr int h8_allow(int mode, int k) {
 }
 
 #ifdef ADAS_H8_PROF   // scratch instrumentation (tools/scratch/h8_prof.py): shader cycles of waves 0 and 4 per item phase
-__device__ unsigned long long g_h8_prof[256][16];
+__device__ unsigned long long g_h8_prof[256][32];
 #define H8P(i)                                      \
     if (lane == 0 && grp == 0) {                    \
         const unsigned long long t__ = clock64();   \
@@ -110,12 +111,15 @@ __global__ __launch_bounds__(H8_THR, 1) void conv_h8_kernel(H8Dev a) {
     const int lrow = lane & 15, kg = lane >> 4;
     const int hb = wave >> 2, grp = wave & 3;   // 64-channel half (= wave group), pixel quarter
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, nslot = gridDim.x >> 3;
-    // items of this XCD: tiles [xcd * tiles8, ...) x ncb channel blocks, channel block fastest (the blocks of a tile run on
-    // neighbouring CUs of one XCD at the same time: its window comes from HBM once)
+    // Work list: XCD x owns the contiguous tile range [x * tiles8, ...).  A unit = one tile x `cpw` consecutive 128-channel blocks
+    // (the host picks cpw, a divisor of ncb, so that the units fill the chip); workgroup `slot` takes units slot, slot + nslot, ...
+    // and computes a unit's channel blocks back to back (an "item" = one tile x one block): the tile's window is re-read by the
+    // CU that just read it, its addresses are computed once per unit.  Units of one tile sit in neighbouring slots.
     int tiles_here = a.ntiles - xcd * a.tiles8;
     tiles_here = tiles_here < 0 ? 0 : (tiles_here > a.tiles8 ? a.tiles8 : tiles_here);
-    const int nitem = tiles_here * a.ncb;
-    if (slot >= nitem) return;
+    const int upt = a.ncb / a.cpw;            // units per tile
+    const int units_here = tiles_here * upt;
+    if (slot >= units_here) return;
 
     __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc((void*)a.in, 0, a.in_bytes, 0x00020000);
     __amdgpu_buffer_rsrc_t rwg = __builtin_amdgcn_make_buffer_rsrc((void*)a.wgt, 0, a.wgt_bytes, 0x00020000);
@@ -131,42 +135,50 @@ __global__ __launch_bounds__(H8_THR, 1) void conv_h8_kernel(H8Dev a) {
     const uint32_t wrd = (uint32_t)(H8_WR + hb * 4096 + lrow * 64 + ((kg ^ gsw[(lrow >> 2) & 3]) << 4));
     // epilogue: after the 16-lane row exchange a lane owns 8 consecutive channels: tile i + (kg & 1), channels (kg >> 1) * 8 ..
     const uint32_t ch_lane = (uint32_t)((hb * 64 + (kg & 1) * 16 + (kg >> 1) * 8) * 2);
+    const bool has_res = a.res_mode != RES_NONE;
 
-    struct Item {
-        int img, sx0, p0, y_first, cb;
+    struct Tile {
+        int img, sx0, p0, y_first;
     };
-    auto decode = [&](int k) {
-        Item it;
-        int tile = xcd * a.tiles8 + k / a.ncb;
-        it.cb = k % a.ncb;
-        it.img = tile / per_img;
-        tile -= it.img * per_img;
-        const int strip = tile / a.TPS, t = tile - strip * a.TPS;
-        it.sx0 = strip * a.SW;
-        it.p0 = t * H8_BM;
-        it.y_first = (int)(((uint32_t)it.p0 * a.mg_sw) >> 20);
-        return it;
+    auto decode = [&](int u) {   // u: unit index within the XCD's range.  n / d = umulhi(n, ceil(2^32 / d)) for n * d < 2^32
+        Tile t;
+        int tile = xcd * a.tiles8 + (upt == 1 ? u : (int)__umulhi((uint32_t)u, a.mg_upt));
+        t.img = per_img == 1 ? tile : (int)__umulhi((uint32_t)tile, a.mg_img);
+        tile -= t.img * per_img;
+        const int strip = a.TPS == 1 ? tile : (int)__umulhi((uint32_t)tile, a.mg_tps);
+        t.sx0 = strip * a.SW;
+        t.p0 = (tile - strip * a.TPS) * H8_BM;
+        t.y_first = (int)(((uint32_t)t.p0 * a.mg_sw) >> 20);
+        return t;
     };
     // source byte offset of this lane's 16 bytes in the wave's window piece i (chunk 0); H8_OOB -> the DMA writes zeros
-    auto win_offset = [&](const Item& it, int i) {
-        const int y_lastp = (int)(((uint32_t)(it.p0 + H8_BM - 1) * a.mg_sw) >> 20);
-        const int npix = (y_lastp - it.y_first + 3) * a.WW;
+    auto win_offset = [&](const Tile& t, int i) {
+        const int y_lastp = (int)(((uint32_t)(t.p0 + H8_BM - 1) * a.mg_sw) >> 20);
+        const int npix = (y_lastp - t.y_first + 3) * a.WW;
         const int pix = (wave + 8 * i) * 16 + (lane >> 2);
         const int wy = (int)(((uint32_t)pix * a.mg_ww) >> 20), wx = pix - wy * a.WW;
-        const int iy = it.y_first - 1 + wy, ix = it.sx0 - 1 + wx;
+        const int iy = t.y_first - 1 + wy, ix = t.sx0 - 1 + wx;
         const bool ok = pix < npix && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
-        return ok ? ((uint32_t)((it.img * a.H + iy) * a.W + ix) * (uint32_t)a.in_cs + (uint32_t)a.in_coff) * 2u + wpiece : H8_OOB;
+        const uint32_t off = ((uint32_t)((t.img * a.H + iy) * a.W + ix) * (uint32_t)a.in_cs + (uint32_t)a.in_coff) * 2u + wpiece;
+        const uint32_t m = 0u - (uint32_t)ok;   // select by mask: a branch here would split the MFMA block this is scheduled into
+        return (off & m) | (H8_OOB & ~m);
     };
-    // window pixel of this lane's output pixel j at tap (0, 0), and from it the byte offset (within a window buffer) of the
-    // lane's 16 bytes at tap t
-    auto tap00 = [&](const Item& it, int j) {
-        const int p = it.p0 + (grp * 4 + j) * 16 + lrow;
+    // (window pixel of this lane's output pixel j at tap (0, 0)) * 64 + kg * 16, and from it the byte offset within a window
+    // buffer of the lane's 16 bytes at tap t: pixel pw = that + tap shift, 16-byte position kg ^ (((pw >> 2) & 1) << 1)
+    auto tap00 = [&](const Tile& t, int j) {
+        const int p = t.p0 + (grp * 4 + j) * 16 + lrow;
         const int y = (int)(((uint32_t)p * a.mg_sw) >> 20), xs = p - y * a.SW;
-        return (y - it.y_first) * a.WW + xs;
+        return (uint32_t)((((y - t.y_first) * a.WW + xs) << 6) | (kg << 4));
     };
-    auto tap_offset = [&](int ap, int t) {
-        const int pw = ap + (t / 3) * a.WW + (t % 3);
-        return (uint32_t)(pw * 64 + ((kg ^ ((pw >> 1) & 2)) << 4));
+    auto tap_offset = [&](uint32_t ap64, int t) {
+        const uint32_t v = ap64 + (uint32_t)(((t / 3) * a.WW + (t % 3)) << 6);
+        return v ^ ((v >> 3) & 0x20u);
+    };
+    // pixel index of the lane's output pixel j (H8_OOB outside the image: loads return 0, stores are dropped)
+    auto out_pixel = [&](const Tile& t, int j) {
+        const int p = t.p0 + (grp * 4 + j) * 16 + lrow;
+        const int y = (int)(((uint32_t)p * a.mg_sw) >> 20), x = t.sx0 + (p - y * a.SW);
+        return (y < a.H && x < a.W) ? (uint32_t)((t.img * a.H + y) * a.W + x) : H8_OOB;
     };
     // scalar byte offset of this wave's 16 rows of (channel block cb, half hb, chunk 0, tap 0)
     auto wgt_base = [&](int cb) { return (uint32_t)(((2 * cb + hb) * a.nchunk) * H8_SLAB + grp * 1024); };
@@ -175,22 +187,25 @@ __global__ __launch_bounds__(H8_THR, 1) void conv_h8_kernel(H8Dev a) {
         for (int i = 0; i < 4; ++i) b[i] = *reinterpret_cast<const float4*>(a.bias + cb * 128 + hb * 64 + i * 16 + kg * 4);
     };
 
-    int k = slot;
-    Item cur = decode(k);
-    uint32_t gcur[H8_NWP], gnxt[H8_NWP];
+    auto first_cb = [&](int u) { return upt == 1 ? 0 : (u - (int)__umulhi((uint32_t)u, a.mg_upt) * upt) * a.cpw; };
+    int ti = slot, cb = first_cb(slot), cbi = 0;   // unit, channel block, its index within the unit
+    Tile cur = decode(ti);
+    uint32_t gcur[H8_NWP], gnxt[H8_NWP];   // window piece sources: the chunk being fetched / chunk 0 of the next item
+    uint32_t xoff[4][9];                   // tap offsets of the item being computed; re-written tap by tap during its last chunk
+    uint32_t po[4];
 #pragma unroll
     for (int i = 0; i < H8_NWP; ++i) gcur[i] = win_offset(cur, i);
-    uint32_t xoff[4][9];   // tap offsets of the item being computed; re-written tap by tap for the next item during the last chunk
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        const int ap = tap00(cur, j);
+        const uint32_t ap64 = tap00(cur, j);
 #pragma unroll
-        for (int t = 0; t < 9; ++t) xoff[j][t] = tap_offset(ap, t);
+        for (int t = 0; t < 9; ++t) xoff[j][t] = tap_offset(ap64, t);
+        po[j] = out_pixel(cur, j);
     }
-    uint32_t wcur = wgt_base(cur.cb);
+    uint32_t wcur = wgt_base(cb);
     int par = 0;
-    float4 bias4[4];
-    load_bias(cur.cb, bias4);
+    float4 biasn[4];   // bias of the item about to start
+    load_bias(cb, biasn);
 
     // ---- prologue: window of chunk 0 into buffer 0, weights of taps 0 .. LOOK-1
 #pragma unroll
@@ -199,51 +214,40 @@ __global__ __launch_bounds__(H8_THR, 1) void conv_h8_kernel(H8Dev a) {
 #pragma unroll
     for (int t = 0; t < LOOK; ++t)
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rwg, (lds_vp)(lds8 + H8_WR + t * H8_TAP + wave * 1024), 16, wlane, wcur + t * 4096, 0, 0);
+    qf32x4 acc[4][4];   // starts at the bias
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = qf32x4{biasn[i].x, biasn[i].y, biasn[i].z, biasn[i].w};
     h8_wait_vm<0>();
     __builtin_amdgcn_s_barrier();
     if (MODE == 1 && hb) __builtin_amdgcn_s_barrier();   // group 1 runs one segment behind group 0
 
 #ifdef ADAS_H8_PROF
     unsigned long long tprev__ = clock64();
-    unsigned long long pacc__[6] = {0, 0, 0, 0, 0, 0};
+    unsigned long long pacc__[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     int nit__ = 0;
 #endif
     for (;;) {
         H8P(5)
-        const int kn = k + nslot;
-        const bool has_next = kn < nitem;
-        Item nxt = cur;           // decoded at the start of the last chunk, with everything else the next item needs
-        uint32_t wnxt_item = 0;
-        int apn[4] = {0, 0, 0, 0};
-
-        uint32_t po[4];   // pixel index of the lane's output pixel j (H8_OOB outside the image: loads return 0, stores are dropped)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int p = cur.p0 + (grp * 4 + j) * 16 + lrow;
-            const int y = (int)(((uint32_t)p * a.mg_sw) >> 20), x = cur.sx0 + (p - y * a.SW);
-            po[j] = (y < a.H && x < a.W) ? (uint32_t)((cur.img * a.H + y) * a.W + x) : H8_OOB;
-        }
-        const uint32_t ch0 = (uint32_t)(cur.cb * 256) + ch_lane;
-        const bool has_res = a.res_mode != RES_NONE;
+        const bool newtile = cbi + 1 == a.cpw;   // the item after this one starts another unit
+        const bool has_next = !newtile || ti + nslot < units_here;
+        const int cbn = newtile ? first_cb(has_next ? ti + nslot : ti) : cb + 1;
+        const uint32_t ch0 = (uint32_t)(cb * 256) + ch_lane;
+        Tile nxt = cur;   // decoded at the start of the last chunk, with everything else the next item needs
+        uint32_t wnxt_item = 0, apn[4] = {0, 0, 0, 0};
         qu32x4 rraw[4][2];   // residual, fetched under the last row of taps of the last chunk
-        float4 biasn[4];     // the next item's bias, fetched there too
-
-        qf32x4 acc[4][4];   // starts at the bias
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) acc[i][j] = qf32x4{bias4[i].x, bias4[i].y, bias4[i].z, bias4[i].w};
-
         H8P(0)
+
         auto chunk = [&](auto last_c, const int c) {
             constexpr bool lastc = decltype(last_c)::value;
             if (lastc) {
-                nxt = decode(has_next ? kn : k);
-                wnxt_item = wgt_base(nxt.cb);   // no next item: re-reads this item's weights into slots nobody reads
+                if (newtile && has_next) nxt = decode(ti + nslot);
+                if (!has_next) nxt.y_first = a.H + 4;   // no next item: every window row is outside the image, all pieces zero-fill
+                wnxt_item = wgt_base(cbn);   // no next item: re-reads weights into slots nobody reads
 #pragma unroll
                 for (int j = 0; j < 4; ++j) apn[j] = tap00(nxt, j);
-            }
-            if (!lastc) {
+            } else {
 #pragma unroll
                 for (int i = 0; i < H8_NWP; ++i) gcur[i] += 64u;   // the next chunk of the same window (H8_OOB + 64 * chunks stays out of range)
             }
@@ -253,7 +257,7 @@ __global__ __launch_bounds__(H8_THR, 1) void conv_h8_kernel(H8Dev a) {
             auto tap = [&](auto kk_c) {
                 constexpr int kk = decltype(kk_c)::value;
                 // ---------------- read segment: fragments of tap kk, DMA pieces, counted wait
-                if (lastc && kk == 6) load_bias(nxt.cb, biasn);
+                if (lastc && kk == 6) load_bias(cbn, biasn);
                 if (lastc && kk == 6 && has_res) {
                     // 16-byte residual loads in the layout of the epilogue's stores.  These (8) and the bias loads (4) sit in the
                     // in-order queue between the pieces of taps 5 and 6: the waits of taps 6-8 allow that many more operations
@@ -274,15 +278,8 @@ __global__ __launch_bounds__(H8_THR, 1) void conv_h8_kernel(H8Dev a) {
                     const uint32_t src = (kk + LOOK < 9 ? wthis : wnext) + (uint32_t)kt * 4096u;
                     __builtin_amdgcn_raw_ptr_buffer_load_lds(rwg, (lds_vp)(lds8 + H8_WR + kt * H8_TAP + wave * 1024), 16, wlane, src, 0, 0);
                 }
-                if (kk >= 1 && kk <= H8_NWP)
+                if constexpr (kk >= 1 && kk <= H8_NWP)
                     __builtin_amdgcn_raw_ptr_buffer_load_lds(rin, (lds_vp)(lds8 + winw + (wave + 8 * (kk - 1)) * 1024), 16, lastc ? gnxt[kk - 1] : gcur[kk - 1], 0, 0, 0);
-                if (lastc) {
-                    // the next item's addresses, computed where this item no longer needs the registers: tap kk's offsets once its
-                    // fragment reads are issued, window piece kk one tap before it is issued
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) xoff[j][kk] = tap_offset(apn[j], kk);
-                    if (kk < H8_NWP) gnxt[kk] = has_next ? win_offset(nxt, kk) : H8_OOB;
-                }
                 constexpr bool sync_here = MODE != 2 || kk % 3 == 2;
                 // an item starts drained (the epilogue's vmcnt(0)): its first taps need no wait
                 if (sync_here && (c > 0 || kk >= 3)) {
@@ -297,29 +294,51 @@ __global__ __launch_bounds__(H8_THR, 1) void conv_h8_kernel(H8Dev a) {
                 }
                 // ---------------- MFMA segment
                 __builtin_amdgcn_s_setprio(1);
+                if (lastc) {
+                    // The next item's addresses, computed where this item no longer needs the registers (tap kk's offsets once its
+                    // fragment reads are issued; window piece kk one tap before it is issued) and placed between the MFMAs: a wave
+                    // issues one 16-cycle MFMA every ~4 issue slots, the address arithmetic rides in the other three
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) xoff[j][kk] = tap_offset(apn[j], kk);
+                    if constexpr (kk < H8_NWP) gnxt[kk] = win_offset(nxt, kk);
+                }
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
 #pragma unroll
                     for (int j = 0; j < 4; ++j) acc[i][j] = E::mfma(wf[i], xf[j], acc[i][j]);
+                if (lastc) {
+#pragma unroll
+                    for (int g = 0; g < 16; ++g) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // one MFMA
+                        __builtin_amdgcn_sched_group_barrier(0x006, 3, 0);   // up to three VALU / SALU
+                    }
+                }
                 __builtin_amdgcn_s_setprio(0);
                 if (sync_here) {
                     __builtin_amdgcn_sched_barrier(0);
                     __builtin_amdgcn_s_barrier();
                     __builtin_amdgcn_sched_barrier(0);
                 }
+#ifdef ADAS_H8_PROF
+                if (lastc && kk < 8) { H8P(8 + kk) }
+#endif
             };
             tap(std::integral_constant<int, 0>{}); tap(std::integral_constant<int, 1>{}); tap(std::integral_constant<int, 2>{});
             tap(std::integral_constant<int, 3>{}); tap(std::integral_constant<int, 4>{}); tap(std::integral_constant<int, 5>{});
             tap(std::integral_constant<int, 6>{}); tap(std::integral_constant<int, 7>{}); tap(std::integral_constant<int, 8>{});
+#ifdef ADAS_H8_PROF
+            if (lastc) { H8P(4) } else if (c == 0) { H8P(1) } else { H8P(6) }
+#endif
         };
         for (int c = 0; c + 1 < a.nchunk; ++c) chunk(std::false_type{}, c);
         chunk(std::true_type{}, a.nchunk - 1);
 
-        H8P(1)
         // ---------------- epilogue: lane holds channels kg*4..+3 of pixel lrow of every (i, j) tile (bias already in)
         H8P(2)
-        h8_wait_vm<0>();   // the stream's pieces retire before the stores join the queue: the counted waits of the next item then
-                           // never depend on how stores and loads retire relative to each other
+        // The stream's pieces, the residual and the bias retire before the stores join the queue: the counted waits of the next item
+        // then never depend on how stores and loads retire relative to each other.  (The builtin form, so that hipcc's scoreboard
+        // knows the residual / bias registers are complete.)
+        __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0), expcnt / lgkmcnt untouched
         // RM: residual mode as a compile-time constant (one uniform branch per item instead of selects per element)
         auto write_out = [&](auto rm_c) {
             constexpr int RM = decltype(rm_c)::value;
@@ -359,6 +378,9 @@ __global__ __launch_bounds__(H8_THR, 1) void conv_h8_kernel(H8Dev a) {
                     const auto s0 = __builtin_amdgcn_permlane16_swap(x0, y0, false, false);
                     const auto s1 = __builtin_amdgcn_permlane16_swap(x1, y1, false, false);
                     __builtin_amdgcn_raw_buffer_store_b128(qu32x4{s0[0], s1[0], s0[1], s1[1]}, rout, oo + i * 32, 0, 0);
+                    // the next item's accumulators start at its bias
+                    acc[i][j] = qf32x4{biasn[i].x, biasn[i].y, biasn[i].z, biasn[i].w};
+                    acc[i + 1][j] = qf32x4{biasn[i + 1].x, biasn[i + 1].y, biasn[i + 1].z, biasn[i + 1].w};
                 }
             }
         };
@@ -371,12 +393,16 @@ __global__ __launch_bounds__(H8_THR, 1) void conv_h8_kernel(H8Dev a) {
         ++nit__;
 #endif
         if (!has_next) break;
-        k = kn;
-        cur = nxt;
+        if (newtile) {
+            ti += nslot;
+            cur = nxt;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) po[j] = out_pixel(cur, j);
+        }
+        cb = cbn;
+        cbi = newtile ? 0 : cbi + 1;
 #pragma unroll
         for (int i = 0; i < H8_NWP; ++i) gcur[i] = gnxt[i];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) bias4[i] = biasn[i];
         wcur = wnxt_item;
         par = (par + a.nchunk) & 1;
     }
@@ -384,18 +410,19 @@ __global__ __launch_bounds__(H8_THR, 1) void conv_h8_kernel(H8Dev a) {
 #ifdef ADAS_H8_PROF
     if (lane == 0 && grp == 0) {
         unsigned long long* b__ = g_h8_prof[blockIdx.x & 255];
-        for (int i__ = 0; i__ < 6; ++i__) atomicAdd(&b__[i__ + 8 * hb], pacc__[i__]);
-        atomicAdd(&b__[7 + 8 * hb], (unsigned long long)nit__);
+        for (int i__ = 0; i__ < 16; ++i__)
+            if (i__ != 7) atomicAdd(&b__[i__ + 16 * hb], pacc__[i__]);
+        atomicAdd(&b__[7 + 16 * hb], (unsigned long long)nit__);
     }
 #endif
 }
 
 #ifdef ADAS_H8_PROF
 extern "C" int adas_debug_h8_prof(unsigned long long* out16, int reset) {
-    static unsigned long long h[256][16];
-    if (out16) {
+    static unsigned long long h[256][32];
+    if (out16) {   // 32 values: 16 per wave group
         if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_h8_prof), sizeof(h)) != hipSuccess) return -1;
-        for (int i = 0; i < 16; ++i) {
+        for (int i = 0; i < 32; ++i) {
             out16[i] = 0;
             for (int b = 0; b < 256; ++b) out16[i] += h[b][i];
         }
@@ -418,6 +445,17 @@ static int h8_mode() {   // ADAS_HALO8: 0 off, 1 on (default: synchronisation va
     return v;
 }
 
+// channel blocks a workgroup computes back to back on one tile: the largest divisor of ncb that still leaves every CU of an XCD
+// at least one unit and wastes under a fifth of the last round (0: none does)
+static int h8_blocks_per_unit(long tiles8, int ncb) {
+    for (int cpw = ncb; cpw >= 1; --cpw) {
+        if (ncb % cpw) continue;
+        const long units8 = tiles8 * (ncb / cpw), rounds = (units8 + H8_SLOTS - 1) / H8_SLOTS;
+        if (units8 >= H8_SLOTS && (double)units8 / (double)(rounds * H8_SLOTS) >= 0.8) return cpw;
+    }
+    return 0;
+}
+
 bool halo8_applicable(int kh, int kw, int stride, int pad, int n, const TView& in, const TView& out, const TView& res, int res_mode) {
     if (!h8_mode()) return false;
     if (kh != 3 || kw != 3 || stride != 1 || pad != 1) return false;
@@ -430,10 +468,9 @@ bool halo8_applicable(int kh, int kw, int stride, int pad, int n, const TView& i
     HaloPlan pl;
     if (!plan_halo(out.h, out.w, 1, &pl) || pl.eff < 0.6 || pl.maxpix > H8_MAXPIX) return false;
     // one workgroup per CU walking its XCD's items in rounds of 32: the launch has to fill the chip, in nearly whole rounds
-    const long tiles8 = ((long)n * pl.NS * pl.TPS + 7) / 8, items_xcd = tiles8 * (out.c / 128);
-    if (items_xcd < H8_SLOTS) return false;
-    const long rounds = (items_xcd + H8_SLOTS - 1) / H8_SLOTS;
-    return (double)items_xcd / (double)(rounds * H8_SLOTS) >= 0.8;
+    const long ntiles = (long)n * pl.NS * pl.TPS, tiles8 = (ntiles + 7) / 8;
+    if (ntiles * (out.c / 128) * pl.NS * pl.TPS >= (1L << 32)) return false;
+    return h8_blocks_per_unit(tiles8, out.c / 128) > 0;
 }
 
 template <typename E, int MODE>
@@ -468,11 +505,18 @@ hipError_t launch_conv_halo8(const ConvArgs& a, hipStream_t st) {
     d.res_bytes = a.res_mode != RES_NONE ? (uint32_t)((size_t)a.n * a.out.h * a.out.w * a.res.cs * 2) : 0u;
     d.SW = pl.SW; d.NS = pl.NS; d.TPS = pl.TPS; d.WW = pl.WW;
     d.mg_ww = pl.mg_ww; d.mg_sw = pl.mg_sw;
+    d.mg_img = (uint32_t)(((1ull << 32) + (uint64_t)(pl.NS * pl.TPS) - 1) / (uint64_t)(pl.NS * pl.TPS));   // unused when the divisor is 1
+    d.mg_tps = (uint32_t)(((1ull << 32) + (uint64_t)pl.TPS - 1) / (uint64_t)pl.TPS);
+
     d.ntiles = a.n * pl.NS * pl.TPS;
     d.tiles8 = (d.ntiles + 7) / 8;
     d.ncb = a.out.c / 128;
-    const int items_xcd = d.tiles8 * d.ncb;
-    const int slots = items_xcd < H8_SLOTS ? items_xcd : H8_SLOTS;
+    d.cpw = h8_blocks_per_unit(d.tiles8, d.ncb);
+    if (d.cpw <= 0) return hipErrorNotSupported;
+    const int upt = d.ncb / d.cpw;
+    d.mg_upt = (uint32_t)(((1ull << 32) + (uint64_t)upt - 1) / (uint64_t)upt);
+    const int units8 = d.tiles8 * upt;
+    const int slots = units8 < H8_SLOTS ? units8 : H8_SLOTS;
     dim3 grid(8 * slots);
     const int forced = h8_mode();
     const bool pingpong = forced == 3 || (forced != 2 && d.nchunk >= 12);
