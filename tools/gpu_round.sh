@@ -14,7 +14,7 @@ tail -5 $out/pytest_gpu.log
 for C in FETCH_SIZE WRITE_SIZE; do
   ( timeout 600 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $out/pmc_$C -o p -- python bench.py --no-cpu-baseline --no-extras --no-overlap --steps 5 --warmup 2 > /dev/null 2> $out/pmc_$C.err )
 done
-python tools/traffic_summary.py $out "conv_halo_kernel<adas::Fp16, 64, 2, 1>" "conv_halo_kernel<64,RELU,s1>" 64 fp16 $commit > $out/traffic.json
+python tools/traffic_summary.py $out "conv_h8_kernel<adas::Fp16, 2" "conv_h8_kernel<RELU>" 64 fp16 $commit > $out/traffic.json   # both sync variants
 cat $out/traffic.json
 [ -s $out/traffic.json ] && grep -q hbm_bytes_per_launch $out/traffic.json && cp $out/traffic.json profiles/traffic.json   # bench.py reads it
 ( timeout 600 python bench.py > $out/bench.json 2> $out/bench.err; echo "bench exit $?" >> $out/bench.err )
