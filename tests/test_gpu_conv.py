@@ -207,7 +207,7 @@ def test_conv3x3_s2_halo_shapes(CE, hw):
         assert rel < 1e-2, (hw, cin, cout, rel, mx)
 
 
-@pytest.mark.parametrize("case", [(80, 400, 64, 64, M.ACT_RELU, M.RES_BEFORE_ACT), (80, 80, 64, 80, M.ACT_SILU, M.RES_NONE),
+@pytest.mark.parametrize("case", [(80, 400, 64, 64, M.ACT_RELU, M.RES_BEFORE_ACT), (80, 80, 64, 128, M.ACT_SILU, M.RES_NONE),
                                   (160, 160, 32, 64, M.ACT_SILU, M.RES_NONE), (46, 74, 48, 64, M.ACT_SILU, M.RES_AFTER_ACT),
                                   (80, 80, 16, 128, M.ACT_NONE, M.RES_NONE), (80, 80, 32, 32, M.ACT_SILU, M.RES_AFTER_ACT),
                                   (160, 160, 16, 32, M.ACT_SILU, M.RES_NONE), (46, 74, 64, 24, M.ACT_RELU, M.RES_BEFORE_ACT)], ids=str)
@@ -315,3 +315,18 @@ def test_conv3x3_s1_dma_fed_kernel_is_deterministic(CE, case):
         again = e.fetch_activation("test", batch)
         assert np.array_equal(first, again), (case, it, float(np.abs(first - again).max()))
     e.close(); os.remove(path)
+
+
+@pytest.mark.parametrize("case", [
+    # H, W, cin, cout, stride, act, res_mode: YOLOv8n's class branch (64 / 128 / 256 -> 80 -> 80), a residual, 96 and 72 channels, stride 2
+    (80, 80, 64, 80, 1, M.ACT_SILU, M.RES_NONE), (40, 40, 128, 80, 1, M.ACT_SILU, M.RES_NONE), (20, 20, 256, 80, 1, M.ACT_SILU, M.RES_NONE),
+    (80, 80, 80, 80, 1, M.ACT_SILU, M.RES_AFTER_ACT), (23, 37, 64, 96, 1, M.ACT_RELU, M.RES_NONE), (40, 40, 96, 72, 1, M.ACT_NONE, M.RES_NONE),
+    (46, 74, 64, 80, 2, M.ACT_SILU, M.RES_NONE),
+], ids=str)
+@pytest.mark.parametrize("prec,tol", [("bf16", 1e-2), ("fp16", 1.5e-3)])
+def test_conv3x3_48_wide_blocks(CE, case, prec, tol):
+    """65..96 output channels run as two 48-channel blocks (three 16-channel MFMA tiles per wave: the odd tile takes the 8-byte
+    store / residual path) instead of two 64-channel blocks with a mostly-padded second block."""
+    H, W, cin, cout, s, act, res_mode = case
+    rel, mx = run_case(CE, H, W, cin, cout, 3, s, act, res_mode, prec, batch=4, expect_kernel="conv_halo_kernel<48")
+    assert rel < tol, (case, prec, rel, mx)

@@ -1,3 +1,3 @@
 cd $GRAFT_REPO_ROOT
-timeout 1500 python -m pytest tests -m gpu -q -x 2>&1 | tail -3
-for m in 1 1 0; do echo "mode $m: $(ADAS_HALO8=$m timeout 300 python bench.py --no-cpu-baseline --no-extras 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'], d['stages']['lane_net_ms'], d['roofline']['kernel'], d['roofline']['achieved'])")"; done
+timeout 900 python -m pytest tests/test_gpu_conv.py -q 2>&1 | tail -3
+timeout 300 python tools/profile_layers.py yolov8n --batch 64 --precision fp16 --top 70 2>/dev/null | grep -E "ms/step|model.22"

@@ -273,6 +273,8 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(HaloDev a) {
                     rq[j][i] = make_uint2(s0[0], s1[0]);
                     rq[j][i + 1] = make_uint2(s0[1], s1[1]);
                 }
+                if (TN & 1)   // the unpaired last channel tile (BN = 48): 8-byte load
+                    rq[j][TN - 1] = *reinterpret_cast<const uint2*>(a.res + mpix[j] * a.res_cs + a.res_coff + n0 + kg * 4 + (TN - 1) * 16);
             } else {
 #pragma unroll
                 for (int i = 0; i < TN; ++i)
@@ -319,6 +321,15 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(HaloDev a) {
                     if (full_n || c + 8 <= a.cout) *reinterpret_cast<hu32x4*>(op) = hu32x4{s0[0], s1[0], s0[1], s1[1]};
                     else if (c + 4 <= a.cout) *reinterpret_cast<uint2*>(op) = make_uint2(s0[0], s1[0]);
                 }
+            }
+            if (TN & 1) {   // the unpaired last channel tile: 8-byte store
+                float v[4];
+                finish(TN - 1, j, v);
+                uint2 q;
+                q.x = E::pack2(v[0], v[1]);
+                q.y = E::pack2(v[2], v[3]);
+                if (pok[j] && (full_n || n0 + (TN - 1) * 16 + kg * 4 < a.cout))
+                    *reinterpret_cast<uint2*>((uint16_t*)a.out + mpix[j] * a.out_cs + a.out_coff + n0 + kg * 4 + (TN - 1) * 16) = q;
             }
         }
     } else {
@@ -375,8 +386,8 @@ static bool magic_ok(int d, int nmax, uint32_t* magic) {
 }
 
 // Ho x Wo: OUTPUT extent; S: stride (1 or 2); pad = 1, 3x3.
-static bool plan_halo_uncached(int Ho, int Wo, int S, HaloPlan* best) {
-    const int BM = halo_bm(S), MAXPIX = halo_maxpix(S);
+static bool plan_halo_uncached(int Ho, int Wo, int S, int maxpix_cap, HaloPlan* best) {
+    const int BM = halo_bm(S), MAXPIX = maxpix_cap > 0 ? maxpix_cap : halo_maxpix(S);
     // strip widths: powers of two, the whole row, and the row cut into 2 / 3 / 4 equal strips (40x200 maps: 100-wide strips fill
     // 97.7 % of their tiles' pixels, 32-wide ones 89.3 %)
     int cand[9] = {16, 32, 64, 128, 256, Wo, (Wo + 1) / 2, (Wo + 2) / 3, (Wo + 3) / 4};
@@ -403,15 +414,15 @@ static bool plan_halo_uncached(int Ho, int Wo, int S, HaloPlan* best) {
 }
 
 // plans are pure functions of (Ho, Wo, S): memoised so eager launches do not redo the exhaustive checks
-bool plan_halo(int Ho, int Wo, int S, HaloPlan* out) {
+bool plan_halo(int Ho, int Wo, int S, HaloPlan* out, int maxpix_cap) {
     static std::mutex mu;
-    static std::map<std::tuple<int, int, int>, std::pair<bool, HaloPlan>> cache;
+    static std::map<std::tuple<int, int, int, int>, std::pair<bool, HaloPlan>> cache;
     std::lock_guard<std::mutex> lk(mu);
-    auto key = std::make_tuple(Ho, Wo, S);
+    auto key = std::make_tuple(Ho, Wo, S, maxpix_cap);
     auto it = cache.find(key);
     if (it == cache.end()) {
         HaloPlan p{};
-        bool ok = plan_halo_uncached(Ho, Wo, S, &p);
+        bool ok = plan_halo_uncached(Ho, Wo, S, maxpix_cap, &p);
         it = cache.emplace(key, std::make_pair(ok, p)).first;
     }
     *out = it->second.second;
@@ -435,10 +446,12 @@ static hipError_t launch_bn(const HaloDev& d, int act, dim3 grid, size_t lds, hi
 template <typename E>
 static hipError_t launch_e(const HaloDev& d, int act, int stride, int bn, dim3 grid, size_t lds, hipStream_t st) {
     if (stride == 2) {
+        if (bn == 48) return launch_bn<E, 48, 2>(d, act, grid, lds, st);
         if (bn == 64) return launch_bn<E, 64, 2>(d, act, grid, lds, st);
         if (bn == 32) return launch_bn<E, 32, 2>(d, act, grid, lds, st);
         return launch_bn<E, 16, 2>(d, act, grid, lds, st);
     }
+    if (bn == 48) return launch_bn<E, 48, 1>(d, act, grid, lds, st);
     if (bn == 64) return launch_bn<E, 64, 1>(d, act, grid, lds, st);
     if (bn == 32) return launch_bn<E, 32, 1>(d, act, grid, lds, st);
     return launch_bn<E, 16, 1>(d, act, grid, lds, st);
@@ -506,7 +519,7 @@ hipError_t launch_conv_halo(const ConvArgs& a, hipStream_t st) {
     d.out_f32 = a.out.f32;
     d.mg_ww = pl.mg_ww;
     d.mg_sw = pl.mg_sw;
-    const int bn = a.out.c <= 16 ? 16 : (a.out.c <= 32 ? 32 : 64);
+    const int bn = halo_bn(a.out.c);
     d.ntiles = a.n * pl.NS * pl.TPS;
     { static int xm = -1; if (xm < 0) { const char* e = getenv("ADAS_HALO_XMAP"); xm = e ? atoi(e) : 1; } d.xmap = xm; }
     d.tiles8 = (d.ntiles + 7) / 8;

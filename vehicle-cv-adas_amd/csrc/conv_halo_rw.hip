@@ -357,7 +357,7 @@ bool halo_rw_applicable(int kh, int kw, int stride, int pad, int n, const TView&
     if (stride != 1 || kh != 3 || kw != 3 || pad != 1) return false;
     if (in.f32 || out.f32 || out.h != in.h || out.w != in.w) return false;
     if ((in.c & 7) || (in.cs & 7) || (in.coff & 7) || (out.c & 3) || (out.cs & 3) || (out.coff & 3)) return false;
-    if (in.c < 16 || in.c > 64 || out.c <= 16) return false;  // cout <= 16 (BN = 16 packing) stays on conv_halo
+    if (in.c < 16 || in.c > 64 || out.c <= 16 || halo_bn(out.c) == 48) return false;  // BN = 16 / 48 packings stay on conv_halo
     if ((long)in.h * in.w * in.cs >= (1L << 30)) return false;
     RwPlan pl;
     const int nch = (in.c + 31) / 32;

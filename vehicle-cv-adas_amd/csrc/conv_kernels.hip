@@ -318,7 +318,7 @@ const char* conv_kernel_name(const ConvArgs& a, int prec, int kernel) {
     } else if (kernel == CONV_HALO && halo8_applicable(a.kh, a.kw, a.stride, a.pad, a.n, a.in, a.out, a.res, a.res_mode)) {
         snprintf(buf, sizeof(buf), "conv_h8_kernel<%s>", actn);
     } else if (kernel == CONV_HALO) {
-        snprintf(buf, sizeof(buf), "conv_halo_kernel<%d,%s,s%d>", a.out.c <= 16 ? 16 : (a.out.c <= 32 ? 32 : 64), actn, a.stride);
+        snprintf(buf, sizeof(buf), "conv_halo_kernel<%d,%s,s%d>", halo_bn(a.out.c), actn, a.stride);
     } else if (kernel == CONV_FC) {
         snprintf(buf, sizeof(buf), "fc_kernel");
     } else if (kernel == CONV_PW) {

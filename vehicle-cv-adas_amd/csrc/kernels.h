@@ -51,7 +51,7 @@ struct HaloPlan {
     double eff;                    // useful fraction of the tiles' pixels
     uint32_t mg_ww, mg_sw;         // n / WW == (n * mg_ww) >> 20, n / SW == (n * mg_sw) >> 20 for every n the kernels divide
 };
-bool plan_halo(int Ho, int Wo, int S, HaloPlan* out);
+bool plan_halo(int Ho, int Wo, int S, HaloPlan* out, int maxpix_cap = 0);   // maxpix_cap: window pixel budget (0: the kernel's default)
 // conv_halo8.hip: stride-1 3x3 for Cout % 128 == 0, Cin % 32 == 0: persistent, LDS-DMA fed, counted waits (same weight packing)
 bool halo8_applicable(int kh, int kw, int stride, int pad, int n, const TView& in, const TView& out, const TView& res, int res_mode);
 hipError_t launch_conv_halo8(const ConvArgs& a, hipStream_t st);
@@ -93,7 +93,9 @@ hipError_t launch_conv_stem(const float* nchw, int n, int c_true, int H, int W, 
                             const float* bias, const TView& conv_out, bool pool, const TView& pool_out, bool packed_in, int prec, hipStream_t st);
 // CONV_HALO packing: slab order [cout tile of halo_bn(cout)][32-channel chunk][tap][n within tile][32] -- the 9*BN*64 B a
 // workgroup stages per chunk are one contiguous run (every wave-level staging load reads 1 KB of consecutive bytes).
-inline int halo_bn(int cout) { return cout <= 16 ? 16 : (cout <= 32 ? 32 : 64); }
+// 65..96 output channels (YOLOv8n's class branch: 80) run as two 48-wide blocks: as two 64-wide blocks the second is mostly padding
+// (an 80-wide single block was tried: 80 accumulators + 12 weight staging slots spill 54-94 VGPRs at two workgroups per CU).
+inline int halo_bn(int cout) { return cout <= 16 ? 16 : (cout <= 32 ? 32 : ((cout > 64 && cout <= 96) ? 48 : 64)); }
 hipError_t launch_pack_weights_halo(const float* src, void* dst, int cout, int cout_pad, int cin, int cin_pad, int prec, hipStream_t st);
 // Linear-layer packing (CONV_FC): src [cout][cin] fp32 -> bf16 MFMA-fragment order [cout_pad/16][kpad/32][64][8]
 hipError_t launch_pack_weights_fc(const float* src, void* dst, int cout, int cout_pad, int cin, int kpad, int prec, hipStream_t st);
