@@ -330,3 +330,45 @@ def test_conv3x3_48_wide_blocks(CE, case, prec, tol):
     H, W, cin, cout, s, act, res_mode = case
     rel, mx = run_case(CE, H, W, cin, cout, 3, s, act, res_mode, prec, batch=4, expect_kernel="conv_halo_kernel<48")
     assert rel < tol, (case, prec, rel, mx)
+
+
+def _c2f_case(CE, H, W, c2, n, shortcut, prec, batch=3, seed=0):
+    """input(3) -> 1x1 expand -> C2f(c2, n) built by models._c2f (channel slices of one concat buffer) -> fp32 tap; torch reference."""
+    ws = M.SynthWeights(seed, gain=1.0)
+    g = M.Graph("unit", 3, H, W, ws)
+    x, c3 = g.input()
+    a = g.conv(x, c2, 1, 1, "expand", act=M.ACT_SILU, true_cin=c3)
+    y = M._c2f(g, a, c2, n, shortcut, "blk")
+    z = g.conv(y, 8, 1, 1, "tap", act=M.ACT_NONE, f32_out=True)
+    g.output(z, 0, [1, z.h * z.w * 8], "o")
+    path = os.path.join(tempfile.gettempdir(), f"unit_c2f_{H}_{W}_{c2}_{n}_{int(shortcut)}.hipm")
+    g.save(path)
+    e = CE.HipEngine(path, prec, batch)
+    xin = np.random.default_rng(seed).uniform(0, 1, (batch, 3, H, W)).astype(np.float32)
+    e.engine_inference(xin)
+    got = e.fetch_activation("blk.cv2.conv", batch)
+    names = [e.layer_kernel(e.layer_index(f"blk.m.{i}.cv1.conv"), batch) for i in range(n)]
+    e.close(); os.remove(path)
+    Wt = {k_: torch.from_numpy(v) for k_, v in ws.store.items()}
+    cv = lambda t, nm, k: F.silu(F.conv2d(t, Wt[nm + ".weight"], Wt[nm + ".bias"], padding=k // 2))
+    with torch.no_grad():
+        t = cv(torch.from_numpy(xin), "expand", 1)
+        ys = list(cv(t, "blk.cv1.conv", 1).chunk(2, 1))
+        for i in range(n):
+            b = cv(cv(ys[-1], f"blk.m.{i}.cv1.conv", 3), f"blk.m.{i}.cv2.conv", 3)
+            ys.append(ys[-1] + b if shortcut else b)
+        want = cv(torch.cat(ys, 1), "blk.cv2.conv", 1).numpy()
+    rel = float(np.linalg.norm(got - want) / (np.linalg.norm(want) + 1e-30))
+    return rel, names
+
+
+@pytest.mark.parametrize("case", [(160, 160, 32, 1, True), (80, 80, 64, 2, True), (80, 80, 64, 1, False), (23, 37, 32, 2, True),
+                                  (16, 16, 64, 1, True), (50, 70, 64, 2, False)], ids=str)
+@pytest.mark.parametrize("prec,tol", [("bf16", 2e-2), ("fp16", 2.5e-3)])
+def test_c2f_bottleneck_pairs_fused(CE, case, prec, tol):
+    """The 3x3 -> 3x3 Bottlenecks of a C2f block on 16 / 32 channels run as one launch each (conv_pair.hip): the intermediate stays
+    in LDS, the shortcut comes from the staged window; inputs and outputs are channel slices of the block's concat buffer."""
+    H, W, c2, n, shortcut = case
+    rel, names = _c2f_case(CE, H, W, c2, n, shortcut, prec)
+    assert all("conv_pair_kernel" in k for k in names), names
+    assert rel < tol, (case, prec, rel)

@@ -23,6 +23,7 @@ UNITS = [
     ("conv_halo_rw.hip", []),
     ("conv_halo_s2.hip", []),
     ("conv_halo8.hip", []),
+    ("conv_pair.hip", []),
     ("conv_fc.hip", []),
     ("conv_pw.hip", []),
     ("conv_stem.hip", []),

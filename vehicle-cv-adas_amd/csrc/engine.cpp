@@ -187,6 +187,36 @@ int adas_engine_create(const char* model_path, int precision, int max_batch, ada
             }
         }
     }
+    // ---- 3x3 -> 3x3 pair fusion (conv_pair.hip): conv A's output feeds only conv B (the Bottleneck of YOLOv8's C2f blocks)
+    std::vector<int> pair_of(e->ops.size(), -1);   // B -> A
+    for (size_t ai = 0; ai + 1 < e->ops.size(); ++ai) {
+        const FileOp& qa = fo[ai];
+        if (qa.type != OP_CONV || e->ops[ai].skip || e->ops[ai].kernel == CONV_STEM || pair_of[ai] >= 0) continue;
+        int bi = -1, readers = 0;
+        for (size_t j = 0; j < fo.size(); ++j) {
+            if (j == ai) continue;
+            bool reads = false;
+            for (uint32_t t = 0; t < fo[j].n_in && t < 8; ++t) reads = reads || fo[j].in_buf[t] == qa.out_buf;
+            reads = reads || (fo[j].res_mode != RES_NONE && fo[j].res_buf == qa.out_buf);
+            if (reads) { ++readers; bi = (int)j; }
+        }
+        bool is_out = false;
+        for (auto& q : fout) is_out = is_out || q.buf == qa.out_buf;
+        if (readers != 1 || is_out || bi <= (int)ai) continue;
+        const FileOp& qb = fo[bi];
+        if (qb.type != OP_CONV || e->ops[bi].skip || qb.n_in != 1 || qb.in_buf[0] != qa.out_buf || qb.in_coff[0] != qa.out_coff || qb.in_c[0] != qa.out_c) continue;
+        bool clean = true;   // nothing between A and B writes A's input or B's output region's buffer in a way the fusion would reorder
+        for (int j = (int)ai + 1; j < bi && clean; ++j) clean = fo[j].out_buf != qa.in_buf[0] && fo[j].out_buf != qb.out_buf;
+        if (!clean) continue;
+        TView x = make_view(e, qa.in_buf[0], qa.in_coff[0], qa.in_c[0]), t = make_view(e, qa.out_buf, qa.out_coff, qa.out_c);
+        TView y = make_view(e, qb.out_buf, qb.out_coff, qb.out_c);
+        TView r2 = qb.res_mode != RES_NONE ? make_view(e, qb.res_buf, qb.res_coff, qb.out_c) : y;
+        if (!pair_applicable(precision, qa.kh, qa.kw, qa.stride, qa.pad, qa.act, qa.res_mode, x, t, qb.kh, qb.kw, qb.stride, qb.pad, qb.act, qb.res_mode, y, r2))
+            continue;
+        e->ops[ai].pair_b = bi;
+        e->ops[bi].skip = true;
+        pair_of[bi] = (int)ai;
+    }
     for (auto& op : e->ops) {
         const FileOp& o = op.f;
         if (o.type == OP_CONV && op.kernel == CONV_STEM) {
@@ -222,6 +252,8 @@ int adas_engine_create(const char* model_path, int precision, int max_batch, ada
             op.kpad = pl.kpad;
             op.cin_pad = pl.cin_pad;
             op.cout_pad = (cout + 127) / 128 * 128;
+            const size_t self = (size_t)(&op - &e->ops[0]);
+            if (op.pair_b >= 0 || pair_of[self] >= 0) op.kernel = CONV_PAIR;   // fragment packing (fits the plan's allocation: <= 18 KB)
             op.w_off = packed_total;
             packed_total += ((size_t)op.cout_pad * op.kpad * esz + 255) & ~(size_t)255;
             op.b_off = packed_total;
@@ -316,7 +348,8 @@ int adas_engine_create(const char* model_path, int precision, int max_batch, ada
                 if (hipMemcpy(base + op.b_off, b.data(), (size_t)op.cout_pad * 4, hipMemcpyHostToDevice) != hipSuccess) { rc = ADAS_ERR_HIP; break; }
                 continue;
             }
-            hipError_t pe = (op.kernel == CONV_FC || op.kernel == CONV_PW)
+            hipError_t pe = op.kernel == CONV_PAIR ? launch_pack_weights_pair(d_stage, base + op.w_off, o.out_c, precision, 0)
+                            : (op.kernel == CONV_FC || op.kernel == CONV_PW)
                                 ? launch_pack_weights_fc(d_stage, base + op.w_off, o.out_c, op.cout_pad, o.in_c[0], op.kpad, precision, 0)
                                 : op.kernel == CONV_HALO
                                 ? launch_pack_weights_halo(d_stage, base + op.w_off, o.out_c, op.cout_pad, o.in_c[0], op.cin_pad, precision, 0)
@@ -399,7 +432,11 @@ int adas_engine_layer_kernel(const adas_engine* e, int layer, int batch, char* n
     const FileOp& o = op.f;
     static const char* kOther[] = {"input_nchw_kernel", "", "maxpool_kernel", "upsample2_kernel", "detect_v8_kernel", "detect_v5_kernel",
                                    "layernorm_kernel"};
-    if (op.skip) {
+    if (op.skip && op.kernel == CONV_PAIR) {
+        snprintf(name, cap, "(fused into the pair launch)");
+    } else if (o.type == OP_CONV && op.pair_b >= 0) {
+        snprintf(name, cap, "conv_pair_kernel<%d>", (int)o.out_c);
+    } else if (op.skip) {
         snprintf(name, cap, o.type == OP_CONV && o.kh == 1 && op.kernel == CONV_PW ? "(fused into the Detect launch)" : "(fused into the stem launch)");
     } else if (o.type == OP_CONV && op.kernel == CONV_STEM && op.fuse_conv2 >= 0) {
         snprintf(name, cap, "conv_stem_kernel<%d,1,SILU>+conv3x3s2", (int)o.kh);
@@ -463,6 +500,13 @@ int engine_run_op(adas_engine* e, int i, const float* d_in, int batch, hipStream
             err = launch_input_nchw(d_in, make_view(e, o.out_buf, 0, 8), batch, e->hdr.in_c, e->prec, st);
             break;
         case OP_CONV: {
+            if (op.pair_b >= 0) {   // this conv and the one behind it, one launch
+                const EngOp& b = e->ops[op.pair_b];
+                err = launch_conv_pair(make_view(e, o.in_buf[0], o.in_coff[0], o.in_c[0]), make_view(e, b.f.out_buf, b.f.out_coff, b.f.out_c),
+                                       wb + op.w_off, (const float*)(wb + op.b_off), wb + b.w_off, (const float*)(wb + b.b_off), batch,
+                                       b.f.res_mode != RES_NONE, e->prec, st);
+                break;
+            }
             ConvArgs a;
             a.in = make_view(e, o.in_buf[0], o.in_coff[0], o.in_c[0]);
             a.out = make_view(e, o.out_buf, o.out_coff, o.out_c);
@@ -623,6 +667,9 @@ int adas_engine_fetch_activation(adas_engine* e, int layer, int batch, float* h_
     ADAS_REQUIRE(!(e->ops[layer].skip && o.type == OP_INPUT) &&
                      !(e->ops[layer].kernel == CONV_STEM && (e->ops[layer].fuse_pool >= 0 || e->ops[layer].fuse_conv2 >= 0)), ADAS_ERR_INVALID,
                  "layer %d (%s) is fused into the stem launch and has no materialised activation (ADAS_NO_STEM=1 keeps it)", layer,
+                 e->ops[layer].name.c_str());
+    ADAS_REQUIRE(e->ops[layer].pair_b < 0, ADAS_ERR_INVALID,
+                 "layer %d (%s) is the first conv of a fused 3x3 pair: its activation stays in LDS (ADAS_NO_PAIR_FUSE=1 keeps it)", layer,
                  e->ops[layer].name.c_str());
     TView v = make_view(e, o.out_buf, o.out_coff, o.out_c);
     if (o.type == OP_INPUT) v.c = 8;

@@ -31,7 +31,8 @@ struct ConvArgs {
 
 // Which kernel runs a conv and how its weights are packed.  Decided once at load time from static
 // shapes and re-derived identically at launch time.
-enum { CONV_GATHER = 0, CONV_HALO = 1, CONV_FC = 2, CONV_STEM = 3, CONV_PW = 4, CONV_STEM2 = 5 /* second conv of a fused YOLO stem */ };
+enum { CONV_GATHER = 0, CONV_HALO = 1, CONV_FC = 2, CONV_STEM = 3, CONV_PW = 4, CONV_STEM2 = 5 /* second conv of a fused YOLO stem */,
+       CONV_PAIR = 6 /* either conv of a fused 3x3 -> 3x3 pair (conv_pair.hip) */ };
 struct ConvPlan {
     int kernel;   // CONV_*
     int cin_pad;  // channels per tap in the packed weights (halo: padded to 32 so the tail is zero)
@@ -55,6 +56,12 @@ bool plan_halo(int Ho, int Wo, int S, HaloPlan* out, int maxpix_cap = 0);   // m
 // conv_halo8.hip: stride-1 3x3 for Cout % 128 == 0, Cin % 32 == 0: persistent, LDS-DMA fed, counted waits (same weight packing)
 bool halo8_applicable(int kh, int kw, int stride, int pad, int n, const TView& in, const TView& out, const TView& res, int res_mode);
 hipError_t launch_conv_halo8(const ConvArgs& a, hipStream_t st);
+// conv_pair.hip: conv A (x -> t) and conv B (t -> y [+ x]) in one launch, t never written: 3x3 s1 SiLU on 16 or 32 channels
+bool pair_applicable(int prec, int kh, int kw, int stride, int pad, int act, int res_mode, const TView& x, const TView& t, int kh2, int kw2,
+                     int stride2, int pad2, int act2, int res_mode2, const TView& y, const TView& res2);
+hipError_t launch_pack_weights_pair(const float* src, void* dst, int c, int prec, hipStream_t st);   // src fp32 [c][9][c]
+hipError_t launch_conv_pair(const TView& x, const TView& y, const void* w1, const float* b1, const void* w2, const float* b2, int n, bool has_res,
+                            int prec, hipStream_t st);
 // returns hipSuccess or the launch error.  prec: PREC_*.
 hipError_t launch_conv(const ConvArgs& a, int prec, hipStream_t st);
 const char* conv_tile_name(const ConvArgs& a, int prec);
