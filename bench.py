@@ -434,7 +434,7 @@ def main():
     n_launches = 0
     for eng, dptr in ((pipe.det, d_det[0].ptr), (pipe.lane, d_lane[0].ptr)):
         eng.profile(dptr, S, iters=3)            # the device idled while the stats were fetched: let the clocks come back first
-        stem_label = None
+        stem_label = pair_label = None
         for li, (name, fl, kind, ms) in enumerate(eng.profile(dptr, S, iters=10)):
             all_ms += ms
             label = eng.layer_kernel(li, S)
@@ -446,10 +446,14 @@ def main():
                 launches = 1
                 if label.startswith("(fused into the stem") and stem_label:
                     label, launches = stem_label, 0   # the stem launch does this layer's work: its FLOPs belong to that launch
+                elif label.startswith("(fused into the pair") and pair_label:
+                    label, launches = pair_label, 0   # second conv of a 3x3 -> 3x3 pair: computed by the first conv's launch
                 elif label.startswith("(fused into"):
                     continue                          # fused into a neighbouring conv launch that reports the FLOPs itself
                 elif label.startswith("conv_stem_kernel"):
                     stem_label = label
+                elif label.startswith("conv_pair_kernel"):
+                    pair_label = label
                 conv_ms += ms
                 conv_flops += fl * S
                 k = by_kernel.setdefault(label, [0.0, 0.0, 0])

@@ -1,3 +1,2 @@
 cd $GRAFT_REPO_ROOT
-timeout 900 python -m pytest tests/test_gpu_conv.py -q -k "c2f" 2>&1 | tail -12
-timeout 300 python tools/profile_layers.py yolov8n --batch 64 --precision fp16 --top 70 2>/dev/null | grep -E "ms/step|model.2\.|model.4\.|model.15\."
+for sn in 0 1 0 1; do echo "== snake $sn"; ADAS_SNAKE=$sn timeout 300 python tools/profile_layers.py ufldv2_res18 --batch 64 --precision fp16 --top 30 2>/dev/null | grep -E "ms/step|layer1|layer2\.[01]\.conv[12] .*k3s1"; done
