@@ -1,2 +1,3 @@
 cd $GRAFT_REPO_ROOT
-for sn in 0 1 0 1; do echo "== snake $sn"; ADAS_SNAKE=$sn timeout 300 python tools/profile_layers.py ufldv2_res18 --batch 64 --precision fp16 --top 30 2>/dev/null | grep -E "ms/step|layer1|layer2\.[01]\.conv[12] .*k3s1"; done
+timeout 900 python -m pytest tests/test_gpu_frontend.py tests/test_gpu_pipeline.py tests/test_gpu_configs.py -q 2>&1 | tail -3
+for m in 1 1; do echo "run: $(timeout 300 python bench.py --no-cpu-baseline --no-extras 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'], d['stages'])")"; done

@@ -77,6 +77,49 @@ __device__ __forceinline__ void resize_px(const uint8_t* __restrict__ src, const
     }
 }
 
+// Row-wise form of resize_px for the streaming kernels below: a workgroup owns a few output rows of one frame, the column taps and
+// coefficients (identical for every row) are tabulated once per workgroup in LDS, the row taps are workgroup-uniform.  Same
+// arithmetic as resize_px, value for value (lin_coef is evaluated with the same arguments): the outputs are bit-identical; what
+// goes away is two integer divisions (one 64-bit) and two double-precision coordinate evaluations per pixel.
+struct ColTap {
+    short x0, x1, a0, a1;   // source columns, 11-bit coefficients (<= 2048)
+};
+constexpr int PRE_ROWS = 8;       // output rows per workgroup
+constexpr int PRE_MAXW = 8192;    // widest resized row the (dynamic LDS) table holds: 64 KB
+
+__device__ __forceinline__ void col_table(ColTap* tab, const ResizeGeom& g, int first, int count) {
+    for (int t = threadIdx.x; t < count; t += blockDim.x) {
+        int x0, x1, a0, a1;
+        lin_coef(first + t, g.scale_x, g.sw, &x0, &x1, &a0, &a1, true);
+        tab[t] = ColTap{(short)x0, (short)x1, (short)a0, (short)a1};
+    }
+}
+// resized pixel of row taps (r0, r1, b0, b1) and column entry c; identity resizes are handled by the caller
+__device__ __forceinline__ void resize_row_px(const uint8_t* __restrict__ r0, const uint8_t* __restrict__ r1, int b0, int b1, const ColTap c,
+                                              int sw, int out[3]) {
+    const int x0 = c.x0, x1 = c.x1, a0 = c.a0, a1 = c.a1;
+    if (x1 == x0 + 1 && x0 * 3 + 8 <= sw * 3) {
+        unsigned long long w0, w1;
+        __builtin_memcpy(&w0, r0 + x0 * 3, 8);
+        __builtin_memcpy(&w1, r1 + x0 * 3, 8);
+#pragma unroll
+        for (int ch = 0; ch < 3; ++ch) {
+            const int h0 = (int)((w0 >> (8 * ch)) & 0xff) * a0 + (int)((w0 >> (8 * (3 + ch))) & 0xff) * a1;
+            const int h1 = (int)((w1 >> (8 * ch)) & 0xff) * a0 + (int)((w1 >> (8 * (3 + ch))) & 0xff) * a1;
+            const int v = (((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1 >> 4)) >> 16) + 2) >> 2;
+            out[ch] = v < 0 ? 0 : (v > 255 ? 255 : v);
+        }
+        return;
+    }
+#pragma unroll
+    for (int ch = 0; ch < 3; ++ch) {
+        const int h0 = r0[x0 * 3 + ch] * a0 + r0[x1 * 3 + ch] * a1;
+        const int h1 = r1[x0 * 3 + ch] * a0 + r1[x1 * 3 + ch] * a1;
+        const int v = (((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1 >> 4)) >> 16) + 2) >> 2;
+        out[ch] = v < 0 ? 0 : (v > 255 ? 255 : v);
+    }
+}
+
 // PACK: write the frame as the fused first layer stages it anyway -- (c0, c1, c2, 0) bf16 pixels, 8 B each, NHWC -- instead of
 // three fp32 planes: the same round-to-nearest-even conversion conv_stem.hip applies to the fp32 seam tensor, so the network sees
 // identical values while the tensor between pre-processing and stem shrinks from 12 to 8 bytes per pixel.
@@ -95,30 +138,48 @@ struct YoloPreDev {
 template <int PACK>   // 0: fp32 NCHW planes; 1: packed bf16 pixels; 2: packed fp16 pixels
 __global__ void preprocess_yolo_kernel(YoloPreDev d) {
     const size_t plane = (size_t)d.dh * d.dw;
-    const size_t total = (size_t)d.n * plane;
     // a u8 value has 256 images under the normalisation: tabulate them once per workgroup with the reference's arithmetic
     // (blobFromImage: float32(v) * (1/255.0) evaluated in double) instead of redoing the double-precision step per pixel
     __shared__ float lut[256];
+    extern __shared__ ColTap tab[];   // [resized width]
     for (int t = threadIdx.x; t < 256; t += blockDim.x) lut[t] = (float)((double)t * (1.0 / 255.0));
+    const bool identity = d.g.rh == d.g.sh && d.g.rw == d.g.sw;   // cv2.resize with dsize == ssize copies
+    if (!identity) col_table(tab, d.g, 0, d.g.rw);
     __syncthreads();
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-        const int b = (int)(i / plane);
-        const int p = (int)(i - (size_t)b * plane);
-        const int y = p / d.dw, x = p - y * d.dw;
-        int v[3] = {114, 114, 114};  // canvas (utils.py:54)
-        const int ry = y - d.padh, rx = x - d.padw;
-        if (ry >= 0 && ry < d.g.rh && rx >= 0 && rx < d.g.rw) resize_px(d.src + (size_t)b * d.g.sh * d.g.sw * 3, d.g, ry, rx, v);
-        // swapRB: plane 0 = R = source channel 2
-        const float c0 = lut[v[2]], c1 = lut[v[1]], c2 = lut[v[0]];
-        if (PACK == 2) {
-            reinterpret_cast<uint2*>(d.dst)[i] = make_uint2(adas::Fp16::pack2(c0, c1), adas::Fp16::pack2(c2, 0.f));
-        } else if (PACK == 1) {
-            reinterpret_cast<uint2*>(d.dst)[i] = make_uint2(pre_pack2(c0, c1), pre_pack2(c2, 0.f));
-        } else {
-            float* o = d.dst + (size_t)b * 3 * plane + p;
-            o[0] = c0;
-            o[plane] = c1;
-            o[2 * plane] = c2;
+    const int rows_per_img = (d.dh + PRE_ROWS - 1) / PRE_ROWS;
+    const int b = blockIdx.x / rows_per_img, yb = (blockIdx.x - b * rows_per_img) * PRE_ROWS;
+    const uint8_t* src = d.src + (size_t)b * d.g.sh * d.g.sw * 3;
+    for (int yy = 0; yy < PRE_ROWS && yb + yy < d.dh; ++yy) {
+        const int y = yb + yy, ry = y - d.padh;
+        const bool row_in = ry >= 0 && ry < d.g.rh;
+        int y0 = 0, y1 = 0, b0 = 0, b1 = 0;
+        if (row_in && !identity) lin_coef(ry, d.g.scale_y, d.g.sh, &y0, &y1, &b0, &b1, false);
+        const uint8_t* r0 = src + (size_t)y0 * d.g.sw * 3;
+        const uint8_t* r1 = src + (size_t)y1 * d.g.sw * 3;
+        for (int x = threadIdx.x; x < d.dw; x += blockDim.x) {
+            int v[3] = {114, 114, 114};  // canvas (utils.py:54)
+            const int rx = x - d.padw;
+            if (row_in && rx >= 0 && rx < d.g.rw) {
+                if (identity) {
+                    const uint8_t* q = src + ((size_t)ry * d.g.sw + rx) * 3;
+                    v[0] = q[0]; v[1] = q[1]; v[2] = q[2];
+                } else {
+                    resize_row_px(r0, r1, b0, b1, tab[rx], d.g.sw, v);
+                }
+            }
+            // swapRB: plane 0 = R = source channel 2
+            const float c0 = lut[v[2]], c1 = lut[v[1]], c2 = lut[v[0]];
+            const size_t p = (size_t)y * d.dw + x, i = (size_t)b * plane + p;
+            if (PACK == 2) {
+                reinterpret_cast<uint2*>(d.dst)[i] = make_uint2(adas::Fp16::pack2(c0, c1), adas::Fp16::pack2(c2, 0.f));
+            } else if (PACK == 1) {
+                reinterpret_cast<uint2*>(d.dst)[i] = make_uint2(pre_pack2(c0, c1), pre_pack2(c2, 0.f));
+            } else {
+                float* o = d.dst + (size_t)b * 3 * plane + p;
+                o[0] = c0;
+                o[plane] = c1;
+                o[2 * plane] = c2;
+            }
         }
     }
 }
@@ -157,34 +218,49 @@ struct UfldPreDev {
 template <int PACK>
 __global__ void preprocess_ufld_kernel(UfldPreDev d) {
     const size_t plane = (size_t)d.ih * d.iw;
-    const size_t total = (size_t)d.n * plane;
     const double mean[3] = {0.485, 0.456, 0.406}, stdv[3] = {0.229, 0.224, 0.225};
     // 256 possible u8 values per channel: the reference's float32 / float64 normalisation is tabulated once per workgroup
     // (three double-precision divisions per pixel otherwise: the kernel was ALU-bound at 1.9 TB/s)
     __shared__ float lut[3][256];
+    extern __shared__ ColTap tab[];   // [input width]
     for (int t = threadIdx.x; t < 768; t += blockDim.x) {
         const int c = t >> 8, u = t & 255;
         const float q = (float)u / 255.0f;                                 // float32 array / Python float stays float32
         lut[c][u] = (float)(((double)q - mean[c]) / stdv[c]);             // - list, / list promote to float64
     }
+    const bool identity = d.g.rh == d.g.sh && d.g.rw == d.g.sw;
+    if (!identity) col_table(tab, d.g, 0, d.iw);
     __syncthreads();
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-        const int b = (int)(i / plane);
-        const int p = (int)(i - (size_t)b * plane);
-        const int y = p / d.iw, x = p - y * d.iw;
-        int v[3];
-        resize_px(d.src + (size_t)b * d.g.sh * d.g.sw * 3, d.g, d.row0 + y, x, v);
-        float cv[3];
+    const int rows_per_img = (d.ih + PRE_ROWS - 1) / PRE_ROWS;
+    const int b = blockIdx.x / rows_per_img, yb = (blockIdx.x - b * rows_per_img) * PRE_ROWS;
+    const uint8_t* src = d.src + (size_t)b * d.g.sh * d.g.sw * 3;
+    for (int yy = 0; yy < PRE_ROWS && yb + yy < d.ih; ++yy) {
+        const int y = yb + yy, ry = d.row0 + y;
+        int y0 = 0, y1 = 0, b0 = 0, b1 = 0;
+        if (!identity) lin_coef(ry, d.g.scale_y, d.g.sh, &y0, &y1, &b0, &b1, false);
+        const uint8_t* r0 = src + (size_t)y0 * d.g.sw * 3;
+        const uint8_t* r1 = src + (size_t)y1 * d.g.sw * 3;
+        for (int x = threadIdx.x; x < d.iw; x += blockDim.x) {
+            int v[3];
+            if (identity) {
+                const uint8_t* q = src + ((size_t)ry * d.g.sw + x) * 3;
+                v[0] = q[0]; v[1] = q[1]; v[2] = q[2];
+            } else {
+                resize_row_px(r0, r1, b0, b1, tab[x], d.g.sw, v);
+            }
+            float cv[3];
 #pragma unroll
-        for (int c = 0; c < 3; ++c) cv[c] = lut[c][v[2 - c]];  // RGB plane c = BGR source channel 2-c
-        if (PACK == 2) {
-            reinterpret_cast<uint2*>(d.dst)[i] = make_uint2(adas::Fp16::pack2(cv[0], cv[1]), adas::Fp16::pack2(cv[2], 0.f));
-        } else if (PACK == 1) {
-            reinterpret_cast<uint2*>(d.dst)[i] = make_uint2(pre_pack2(cv[0], cv[1]), pre_pack2(cv[2], 0.f));
-        } else {
-            float* o = d.dst + (size_t)b * 3 * plane + p;
+            for (int c = 0; c < 3; ++c) cv[c] = lut[c][v[2 - c]];  // RGB plane c = BGR source channel 2-c
+            const size_t p = (size_t)y * d.iw + x, i = (size_t)b * plane + p;
+            if (PACK == 2) {
+                reinterpret_cast<uint2*>(d.dst)[i] = make_uint2(adas::Fp16::pack2(cv[0], cv[1]), adas::Fp16::pack2(cv[2], 0.f));
+            } else if (PACK == 1) {
+                reinterpret_cast<uint2*>(d.dst)[i] = make_uint2(pre_pack2(cv[0], cv[1]), pre_pack2(cv[2], 0.f));
+            } else {
+                float* o = d.dst + (size_t)b * 3 * plane + p;
 #pragma unroll
-            for (int c = 0; c < 3; ++c) o[(size_t)c * plane] = cv[c];
+                for (int c = 0; c < 3; ++c) o[(size_t)c * plane] = cv[c];
+            }
         }
     }
 }
@@ -218,9 +294,14 @@ static int preprocess_yolo_impl(const uint8_t* d_frames_bgr, int n, int src_h, i
     d.g.scale_y = 1.0 / ((double)newh / (double)src_h);
     d.g.scale_x = 1.0 / ((double)neww / (double)src_w);
     if (pack == 3) hipLaunchKernelGGL(preprocess_effdet_kernel, dim3(grid_for((size_t)n * dst_h * dst_w)), dim3(256), 0, (hipStream_t)stream, d);
-    else if (pack == 2) hipLaunchKernelGGL(preprocess_yolo_kernel<2>, dim3(grid_for((size_t)n * dst_h * dst_w)), dim3(256), 0, (hipStream_t)stream, d);
-    else if (pack == 1) hipLaunchKernelGGL(preprocess_yolo_kernel<1>, dim3(grid_for((size_t)n * dst_h * dst_w)), dim3(256), 0, (hipStream_t)stream, d);
-    else hipLaunchKernelGGL(preprocess_yolo_kernel<0>, dim3(grid_for((size_t)n * dst_h * dst_w)), dim3(256), 0, (hipStream_t)stream, d);
+    else {
+        ADAS_REQUIRE(neww <= PRE_MAXW && src_w < 32768 && src_h < 32768, ADAS_ERR_INVALID, "adas_preprocess_yolo: resized width %d exceeds %d", neww, PRE_MAXW);
+        const dim3 grid((unsigned)(n * ((dst_h + PRE_ROWS - 1) / PRE_ROWS)));
+        const size_t tab_bytes = (size_t)neww * sizeof(ColTap);
+        if (pack == 2) hipLaunchKernelGGL(preprocess_yolo_kernel<2>, grid, dim3(256), tab_bytes, (hipStream_t)stream, d);
+        else if (pack == 1) hipLaunchKernelGGL(preprocess_yolo_kernel<1>, grid, dim3(256), tab_bytes, (hipStream_t)stream, d);
+        else hipLaunchKernelGGL(preprocess_yolo_kernel<0>, grid, dim3(256), tab_bytes, (hipStream_t)stream, d);
+    }
     ADAS_HIP_TRY(hipGetLastError());
     return ADAS_OK;
 }
@@ -255,9 +336,12 @@ static int preprocess_ufld_impl(const uint8_t* d_frames_bgr, int n, int src_h, i
     d.g.sh = src_h; d.g.sw = src_w; d.g.rh = rh; d.g.rw = in_w;
     d.g.scale_y = 1.0 / ((double)rh / (double)src_h);
     d.g.scale_x = 1.0 / ((double)in_w / (double)src_w);
-    if (pack == 2) hipLaunchKernelGGL(preprocess_ufld_kernel<2>, dim3(grid_for((size_t)n * in_h * in_w)), dim3(256), 0, (hipStream_t)stream, d);
-    else if (pack == 1) hipLaunchKernelGGL(preprocess_ufld_kernel<1>, dim3(grid_for((size_t)n * in_h * in_w)), dim3(256), 0, (hipStream_t)stream, d);
-    else hipLaunchKernelGGL(preprocess_ufld_kernel<0>, dim3(grid_for((size_t)n * in_h * in_w)), dim3(256), 0, (hipStream_t)stream, d);
+    ADAS_REQUIRE(in_w <= PRE_MAXW && src_w < 32768 && src_h < 32768, ADAS_ERR_INVALID, "adas_preprocess_ufld: input width %d exceeds %d", in_w, PRE_MAXW);
+    const dim3 grid((unsigned)(n * ((in_h + PRE_ROWS - 1) / PRE_ROWS)));
+    const size_t tab_bytes = (size_t)in_w * sizeof(ColTap);
+    if (pack == 2) hipLaunchKernelGGL(preprocess_ufld_kernel<2>, grid, dim3(256), tab_bytes, (hipStream_t)stream, d);
+    else if (pack == 1) hipLaunchKernelGGL(preprocess_ufld_kernel<1>, grid, dim3(256), tab_bytes, (hipStream_t)stream, d);
+    else hipLaunchKernelGGL(preprocess_ufld_kernel<0>, grid, dim3(256), tab_bytes, (hipStream_t)stream, d);
     ADAS_HIP_TRY(hipGetLastError());
     return ADAS_OK;
 }
