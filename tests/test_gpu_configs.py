@@ -78,6 +78,28 @@ def test_ufldv2_culane_full_geometry_vs_oracle(backbone, prec):
     e.close()
 
 
+@pytest.mark.parametrize("prec", ["fp16", "bf16"])
+def test_ufldv2_culane_at_the_bench_batch_vs_oracle(prec):
+    """The kernels the 64-stream bench selects are chosen by batch (persistent / LDS-DMA fed 3x3 kernels need a chip full of tiles:
+    conv_halo8, conv_halo_rw, conv_halo_s2): the same C3 network at batch 64, three distinct frames tiled over the batch.  Frames
+    0-2 against the oracle; every copy of a frame has to come out bit-identical to the first (different workgroups, same arithmetic)."""
+    path, W, g = netutil.model("ufldv2_res18")
+    x3 = netutil.lane_frames(3, 320, 1600, seed=11)
+    x = np.ascontiguousarray(np.concatenate([x3] * 22, 0)[:64])
+    want = nets.ufldv2_forward(x3, W, "18")
+    e = CE.HipEngine(path, precision=prec, max_batch=64)
+    kernels = {e.layer_kernel(i, 64) for i in range(e.stats()["num_layers"])}
+    assert any("conv_h8_kernel" in k for k in kernels) and any("conv_halo_rw_kernel" in k for k in kernels), kernels
+    got = e.engine_inference(x)
+    tag = "ufldv2-r18 batch 64 %s " % prec
+    for o, w in zip(got, want):
+        err, rel = report(tag + "output", o[:3], w)
+        assert rel <= REL_TOL[prec]
+        for k in range(3, 64):
+            assert np.array_equal(o[k], o[k % 3]), (k, float(np.abs(o[k] - o[k % 3]).max()))
+    e.close()
+
+
 @pytest.mark.parametrize("scale,prec", [("s", "fp32"), ("s", "fp16"), ("l", "fp32"), ("l", "fp16")])
 def test_yolov8_s_and_l_640_vs_oracle(scale, prec):
     """BASELINE configs C4 / C5: YOLOv8s and YOLOv8l at 640x640 (head layout yoloDetector.py:110-133)."""
