@@ -203,3 +203,25 @@ def test_wider_yolo_scales_vs_oracle(CE, name, scale):
         else:
             assert rel_l2(got, want) <= 6e-2
         e.close()
+
+
+@pytest.mark.parametrize("prec", ["fp16", "bf16"])
+def test_sppf_pools_fused_launch_equals_three_launches(CE, prec, monkeypatch):
+    """SPPF's three chained 5x5 max-pools run as one launch (8-channel slab of a frame's map in LDS, row then column maxima).
+    Max-pooling is exact, so every pooled slice and the block output have to equal the three-launch path bit for bit."""
+    path, W, g = netutil.model("yolov8n")
+    x = netutil.coco_like_frames(3)
+    outs = {}
+    for fused in (True, False):
+        if fused:
+            monkeypatch.delenv("ADAS_NO_POOL_FUSE", raising=False)
+        else:
+            monkeypatch.setenv("ADAS_NO_POOL_FUSE", "1")
+        e = CE.HipEngine(path, precision=prec, max_batch=3)
+        names = [e.layer_kernel(e.layer_index("model.9.m%d" % i), 3) for i in range(3)]
+        assert (("sppf_pool3_kernel" in names[0]) and all("fused into the SPPF" in n for n in names[1:])) == fused, names
+        e.engine_inference(x)
+        outs[fused] = [e.fetch_activation("model.9.m%d" % i, 3) for i in range(3)] + [e.fetch_activation("model.9.cv2.conv", 3)]
+        e.close()
+    for a, b in zip(outs[True], outs[False]):
+        assert a.shape == b.shape and np.array_equal(a, b)

@@ -1,4 +1,3 @@
 cd $GRAFT_REPO_ROOT
-mkdir -p gpurun_out/presets
-timeout 600 python bench.py --preset c4 --no-cpu-baseline > gpurun_out/presets/c4.json 2> gpurun_out/presets/c4.err; tail -c 300 gpurun_out/presets/c4.err
-timeout 600 python bench.py --preset c5 --no-cpu-baseline > gpurun_out/presets/c5.json 2> gpurun_out/presets/c5.err; tail -c 300 gpurun_out/presets/c5.err
+timeout 900 python -m pytest tests/test_gpu_nets.py -q 2>&1 | tail -4
+timeout 300 python tools/profile_layers.py yolov8n --batch 64 --precision fp16 --top 80 2>/dev/null | grep -E "ms/step|model.9\."

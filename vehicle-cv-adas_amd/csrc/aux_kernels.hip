@@ -198,6 +198,74 @@ hipError_t launch_maxpool(TView in, TView out, int n, int k, int s, int p, int p
     return hipGetLastError();
 }
 
+// SPPF (ultralytics SPPF, YOLOv5 / v8 model.9): three chained 5x5 stride-1 pad-2 max-pools whose outputs are concatenated.  One
+// workgroup holds an 8-channel slab of one frame's map in LDS and produces all three (row maximum, then column maximum, per pool:
+// out-of-image taps are skipped, which is max-pooling's -inf padding); three launches of 25 loads per output become one of one.
+// Maximum is exact, so the values are the separate launches' values.
+struct Pool3Dev {
+    const void* in;
+    void* out[3];
+    int in_cs, in_coff, out_cs[3], out_coff[3];
+    int c, H, W, n;
+};
+template <typename E>
+__global__ __launch_bounds__(256) void sppf_pool3_kernel(Pool3Dev d) {
+    extern __shared__ __attribute__((aligned(16))) uint4 pl[];   // [2][H * W]: current map, row maxima
+    const int c8n = d.c >> 3, b = blockIdx.x / c8n, c8 = blockIdx.x - b * c8n;
+    const int HW = d.H * d.W;
+    uint4* cur = pl;
+    uint4* row = pl + HW;
+    const uint16_t* ip = (const uint16_t*)d.in + (size_t)b * HW * d.in_cs + d.in_coff + c8 * 8;
+    for (int p = threadIdx.x; p < HW; p += blockDim.x) cur[p] = *reinterpret_cast<const uint4*>(ip + (size_t)p * d.in_cs);
+    __syncthreads();
+    auto vmax = [](uint4 a, uint4 b) { return uint4{E::max2(a.x, b.x), E::max2(a.y, b.y), E::max2(a.z, b.z), E::max2(a.w, b.w)}; };
+    for (int k = 0; k < 3; ++k) {
+        for (int p = threadIdx.x; p < HW; p += blockDim.x) {
+            const int y = p / d.W, x = p - y * d.W;
+            uint4 m = cur[p];
+#pragma unroll
+            for (int dx = -2; dx <= 2; ++dx)
+                if (dx != 0 && (unsigned)(x + dx) < (unsigned)d.W) m = vmax(m, cur[p + dx]);
+            row[p] = m;
+        }
+        __syncthreads();
+        uint16_t* op = (uint16_t*)d.out[k] + (size_t)b * HW * d.out_cs[k] + d.out_coff[k] + c8 * 8;
+        for (int p = threadIdx.x; p < HW; p += blockDim.x) {
+            const int y = p / d.W;
+            uint4 m = row[p];
+#pragma unroll
+            for (int dy = -2; dy <= 2; ++dy)
+                if (dy != 0 && (unsigned)(y + dy) < (unsigned)d.H) m = vmax(m, row[p + dy * d.W]);
+            *reinterpret_cast<uint4*>(op + (size_t)p * d.out_cs[k]) = m;
+            cur[p] = m;   // the next pool's input (cur is only read by the row pass, which has finished)
+        }
+        __syncthreads();
+    }
+}
+bool sppf_pool3_applicable(int prec, const TView& in, const TView out[3]) {
+    if (!prec_is16(prec) || in.f32 || (in.c & 7) || ((in.cs | in.coff) & 7)) return false;
+    for (int k = 0; k < 3; ++k)
+        if (out[k].f32 || out[k].c != in.c || out[k].h != in.h || out[k].w != in.w || ((out[k].cs | out[k].coff) & 7)) return false;
+    return (size_t)in.h * in.w * 32 <= 96 * 1024;   // two 16-byte planes of the map in LDS
+}
+hipError_t launch_sppf_pool3(const TView& in, const TView out[3], int n, int prec, hipStream_t st_) {
+    if (!sppf_pool3_applicable(prec, in, out)) return hipErrorNotSupported;
+    Pool3Dev d;
+    d.in = in.p; d.in_cs = in.cs; d.in_coff = in.coff; d.c = in.c; d.H = in.h; d.W = in.w; d.n = n;
+    for (int k = 0; k < 3; ++k) { d.out[k] = out[k].p; d.out_cs[k] = out[k].cs; d.out_coff[k] = out[k].coff; }
+    const size_t lds = (size_t)in.h * in.w * 32;
+    const dim3 grid((unsigned)(n * (in.c >> 3)));
+    ADAS_DISPATCH_E16(prec == PREC_FP16, E, {
+        static bool attr_done = false;
+        if (!attr_done) {
+            (void)hipFuncSetAttribute((const void*)sppf_pool3_kernel<E>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+            attr_done = true;
+        }
+        hipLaunchKernelGGL((sppf_pool3_kernel<E>), grid, dim3(256), lds, st_, d);
+    });
+    return hipGetLastError();
+}
+
 template <typename T>
 __global__ void upsample2_kernel(PoolDev d) {
     const int c8n = d.c >> 3;

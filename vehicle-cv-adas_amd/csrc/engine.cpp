@@ -187,6 +187,25 @@ int adas_engine_create(const char* model_path, int precision, int max_batch, ada
             }
         }
     }
+    // ---- SPPF: three chained 5x5 s1 p2 max-pools (each reading the previous one's output) run as one launch
+    {
+        const char* env = getenv("ADAS_NO_POOL_FUSE");
+        const bool enabled = !(env && env[0] == '1');
+        for (size_t i = 0; enabled && i + 2 < fo.size(); ++i) {
+            const FileOp &p0 = fo[i], &p1 = fo[i + 1], &p2 = fo[i + 2];
+            auto is5 = [](const FileOp& q) { return q.type == OP_MAXPOOL && q.kh == 5 && q.stride == 1 && q.pad == 2 && q.n_in == 1; };
+            auto feeds = [](const FileOp& a, const FileOp& b) { return b.in_buf[0] == a.out_buf && b.in_coff[0] == a.out_coff && b.in_c[0] == a.out_c; };
+            if (!is5(p0) || !is5(p1) || !is5(p2) || !feeds(p0, p1) || !feeds(p1, p2) || e->ops[i].skip) continue;
+            TView in = make_view(e, p0.in_buf[0], p0.in_coff[0], p0.in_c[0]);
+            TView outs[3] = {make_view(e, p0.out_buf, p0.out_coff, p0.out_c), make_view(e, p1.out_buf, p1.out_coff, p1.out_c),
+                             make_view(e, p2.out_buf, p2.out_coff, p2.out_c)};
+            if (!sppf_pool3_applicable(precision, in, outs)) continue;
+            e->ops[i].pool3[0] = (int)i + 1;
+            e->ops[i].pool3[1] = (int)i + 2;
+            e->ops[i + 1].skip = e->ops[i + 2].skip = true;
+            i += 2;
+        }
+    }
     // ---- 3x3 -> 3x3 pair fusion (conv_pair.hip): conv A's output feeds only conv B (the Bottleneck of YOLOv8's C2f blocks)
     std::vector<int> pair_of(e->ops.size(), -1);   // B -> A
     for (size_t ai = 0; ai + 1 < e->ops.size(); ++ai) {
@@ -432,7 +451,11 @@ int adas_engine_layer_kernel(const adas_engine* e, int layer, int batch, char* n
     const FileOp& o = op.f;
     static const char* kOther[] = {"input_nchw_kernel", "", "maxpool_kernel", "upsample2_kernel", "detect_v8_kernel", "detect_v5_kernel",
                                    "layernorm_kernel"};
-    if (op.skip && op.kernel == CONV_PAIR) {
+    if (op.skip && o.type == OP_MAXPOOL && o.kh == 5) {
+        snprintf(name, cap, "(fused into the SPPF pool launch)");
+    } else if (o.type == OP_MAXPOOL && op.pool3[0] >= 0) {
+        snprintf(name, cap, "sppf_pool3_kernel");
+    } else if (op.skip && op.kernel == CONV_PAIR) {
         snprintf(name, cap, "(fused into the pair launch)");
     } else if (o.type == OP_CONV && op.pair_b >= 0) {
         snprintf(name, cap, "conv_pair_kernel<%d>", (int)o.out_c);
@@ -520,6 +543,13 @@ int engine_run_op(adas_engine* e, int i, const float* d_in, int batch, hipStream
             break;
         }
         case OP_MAXPOOL:
+            if (op.pool3[0] >= 0) {
+                const FileOp &q1 = e->ops[op.pool3[0]].f, &q2 = e->ops[op.pool3[1]].f;
+                const TView outs[3] = {make_view(e, o.out_buf, o.out_coff, o.out_c), make_view(e, q1.out_buf, q1.out_coff, q1.out_c),
+                                       make_view(e, q2.out_buf, q2.out_coff, q2.out_c)};
+                err = launch_sppf_pool3(make_view(e, o.in_buf[0], o.in_coff[0], o.in_c[0]), outs, batch, e->prec, st);
+                break;
+            }
             err = launch_maxpool(make_view(e, o.in_buf[0], o.in_coff[0], o.in_c[0]), make_view(e, o.out_buf, o.out_coff, o.out_c), batch,
                                  o.kh, o.stride, o.pad, e->prec, st);
             break;

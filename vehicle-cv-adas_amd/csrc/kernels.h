@@ -70,6 +70,9 @@ const char* conv_kernel_name(const ConvArgs& a, int prec, int kernel);
 hipError_t launch_input_nchw(const float* nchw, TView out, int n, int c_true, int prec, hipStream_t st);
 hipError_t launch_maxpool(TView in, TView out, int n, int k, int s, int p, int prec, hipStream_t st);
 hipError_t launch_upsample2(TView in, TView out, int n, int prec, hipStream_t st);
+// three chained 5x5 s1 p2 max-pools (SPPF) in one launch: out[0] = pool(in), out[1] = pool(out[0]), out[2] = pool(out[1])
+bool sppf_pool3_applicable(int prec, const TView& in, const TView out[3]);
+hipError_t launch_sppf_pool3(const TView& in, const TView out[3], int n, int prec, hipStream_t st);
 // YOLOv8 Detect decode: ins = {box0, cls0, box1, cls1, box2, cls2} fp32 logits NHWC; out fp32 [n][4+nc][A]
 hipError_t launch_detect_v8(const TView* ins, float* out, int n, int nc, int A, const int strides[3], hipStream_t st);
 hipError_t launch_detect_v8_fused(const TView* hidden, const void* const* wfrag, const float* const* bias, float* out, int n, int nc, int A,
