@@ -225,3 +225,25 @@ def test_sppf_pools_fused_launch_equals_three_launches(CE, prec, monkeypatch):
         e.close()
     for a, b in zip(outs[True], outs[False]):
         assert a.shape == b.shape and np.array_equal(a, b)
+
+
+@pytest.mark.parametrize("prec", ["fp16", "bf16"])
+def test_neck_upsample_folded_into_its_consumer(CE, prec, monkeypatch):
+    """Upsample -> Concat -> C2f.cv1 (YOLO necks): the 1x1 conv reads the upsampled channels from the half-resolution tensor at
+    (y / 2, x / 2) and the upsample launch is dropped.  Same values in, same arithmetic: outputs equal the unfolded path bit for bit."""
+    path, W, g = netutil.model("yolov8n")
+    x = netutil.coco_like_frames(3)
+    outs = {}
+    for folded in (True, False):
+        if folded:
+            monkeypatch.delenv("ADAS_NO_UPSAMPLE_FOLD", raising=False)
+        else:
+            monkeypatch.setenv("ADAS_NO_UPSAMPLE_FOLD", "1")
+        e = CE.HipEngine(path, precision=prec, max_batch=3)
+        names = [e.layer_kernel(e.layer_index(n), 3) for n in ("model.10", "model.13")]
+        assert all(("folded into" in n) == folded for n in names), names
+        head = e.engine_inference(x)[0]
+        outs[folded] = [e.fetch_activation(n, 3) for n in ("model.12.cv1.conv", "model.15.cv1.conv", "model.15.cv2.conv")] + [head]
+        e.close()
+    for a, b in zip(outs[True], outs[False]):
+        assert a.shape == b.shape and np.array_equal(a, b)

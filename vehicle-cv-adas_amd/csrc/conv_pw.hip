@@ -29,6 +29,8 @@ struct PwDev {
     int NT;                 // feature tiles (cout_pad16 / 16)
     int NTL;                // feature tiles one workgroup owns (blockIdx.y selects the range; NT when the weights fit LDS whole)
     int mtiles;
+    const uint16_t* up;     // half-resolution source of the first up_ks K steps (nearest-neighbour 2x upsample folded in), or null
+    int up_cs, up_coff, up_ks, up_W, up_HW;
 };
 
 template <typename E, int KS, bool TAIL>
@@ -66,8 +68,18 @@ __global__ __launch_bounds__(512) void conv_pw_kernel(PwDev a) {
         }
         const uint16_t* ip = a.in + ipix * a.in_cs + a.in_coff + kg * 8;
         pu32x4 xb[KS];
+        if (a.up) {   // workgroup-uniform: the first up_ks K steps come from the half-resolution tensor (stride 1 only)
+            const int mm = ok ? m : 0;
+            const int n = mm / a.HW, rem = mm - n * a.HW;
+            const int oy = rem / a.W, ox = rem - oy * a.W;
+            const uint16_t* up = a.up + ((size_t)n * a.up_HW + (size_t)(oy >> 1) * a.up_W + (ox >> 1)) * a.up_cs + a.up_coff + kg * 8;
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) xb[ks] = __builtin_nontemporal_load(reinterpret_cast<const pu32x4*>(ip + ks * 32));
+            for (int ks = 0; ks < KS; ++ks)
+                xb[ks] = ks < a.up_ks ? *reinterpret_cast<const pu32x4*>(up + ks * 32) : __builtin_nontemporal_load(reinterpret_cast<const pu32x4*>(ip + ks * 32));
+        } else {
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) xb[ks] = __builtin_nontemporal_load(reinterpret_cast<const pu32x4*>(ip + ks * 32));
+        }
         if (tail_zero) xb[KS - 1] = pu32x4{0u, 0u, 0u, 0u};
 
         const size_t obase = (size_t)(ok ? m : 0) * a.out_cs + a.out_coff + kg * 4 + nt0 * 16;
@@ -157,6 +169,11 @@ hipError_t launch_conv_pw(const ConvArgs& a, hipStream_t st) {
     d.out_cs = a.out.cs; d.out_coff = a.out.coff; d.cout = a.out.c; d.out_f32 = a.out.f32;
     d.M = a.m; d.stride = a.stride; d.Wo = a.out.w; d.HoWo = a.out.h * a.out.w; d.W = a.in.w; d.HW = a.in.h * a.in.w;
     d.act = a.act;
+    d.up = nullptr; d.up_cs = d.up_coff = d.up_ks = d.up_W = d.up_HW = 0;
+    if (a.up_c > 0) {
+        if (a.stride != 1 || (a.up_c & 31) || a.up.c != a.up_c || 2 * a.up.h != a.in.h || 2 * a.up.w != a.in.w || a.up.f32 || ((a.up.cs | a.up.coff) & 7)) return hipErrorInvalidValue;
+        d.up = (const uint16_t*)a.up.p; d.up_cs = a.up.cs; d.up_coff = a.up.coff; d.up_ks = a.up_c / 32; d.up_W = a.up.w; d.up_HW = a.up.h * a.up.w;
+    }
     const int ks = (a.in.c + 31) / 32;
     d.NT = (a.out.c + 15) / 16;
     d.mtiles = (a.m + 15) / 16;

@@ -187,6 +187,40 @@ int adas_engine_create(const char* model_path, int precision, int max_batch, ada
             }
         }
     }
+    // ---- nearest 2x upsample folded into its consumer: the upsample writes the leading channels of a concat buffer that exactly one
+    // 1x1 conv reads (YOLO necks: Upsample -> Concat -> C2f.cv1); that conv then fetches those channels from the half-resolution
+    // tensor itself and the upsample launch (and its 4x larger copy of the tensor) disappears
+    {
+        const char* env = getenv("ADAS_NO_UPSAMPLE_FOLD");
+        const bool enabled = prec_is16(precision) && !(env && env[0] == '1');
+        for (size_t ui = 0; enabled && ui < fo.size(); ++ui) {
+            const FileOp& u = fo[ui];
+            if (u.type != OP_UPSAMPLE2 || e->ops[ui].skip || u.out_coff != 0 || (u.out_c & 31)) continue;
+            int reader = -1, nread = 0;
+            for (size_t j = 0; j < fo.size(); ++j) {
+                if (j == ui) continue;
+                // readers of the upsampled channel range (another slice of the same concat buffer may have its own readers)
+                auto overlaps = [&](uint32_t buf, uint32_t coff, uint32_t c) { return buf == u.out_buf && coff < u.out_coff + u.out_c && coff + c > u.out_coff; };
+                bool r = fo[j].res_mode != RES_NONE && overlaps(fo[j].res_buf, fo[j].res_coff, fo[j].out_c);
+                for (uint32_t t = 0; t < fo[j].n_in && t < 8; ++t) r = r || overlaps(fo[j].in_buf[t], fo[j].in_coff[t], fo[j].in_c[t]);
+                if (r) { ++nread; reader = (int)j; }
+            }
+            bool is_out = false;
+            for (auto& q : fout) is_out = is_out || q.buf == u.out_buf;
+            if (nread != 1 || is_out || reader <= (int)ui) continue;
+            const FileOp& c = fo[reader];
+            if (c.type != OP_CONV || c.kh != 1 || c.kw != 1 || c.stride != 1 || c.pad != 0 || c.res_mode != RES_NONE || c.n_in != 1 || c.in_coff[0] != 0 ||
+                c.in_c[0] <= u.out_c || e->ops[reader].skip)
+                continue;
+            TView cin = make_view(e, c.in_buf[0], c.in_coff[0], c.in_c[0]), cout = make_view(e, c.out_buf, c.out_coff, c.out_c);
+            if (!pw_applicable(precision, 1, 1, 1, 0, RES_NONE, cin, cout)) continue;
+            bool clean = true;   // the low-resolution source is not rewritten between the upsample and the conv
+            for (int j = (int)ui + 1; j < reader && clean; ++j) clean = fo[j].out_buf != u.in_buf[0];
+            if (!clean) continue;
+            e->ops[reader].up_src = (int)ui;
+            e->ops[ui].skip = true;
+        }
+    }
     // ---- SPPF: three chained 5x5 s1 p2 max-pools (each reading the previous one's output) run as one launch
     {
         const char* env = getenv("ADAS_NO_POOL_FUSE");
@@ -451,7 +485,9 @@ int adas_engine_layer_kernel(const adas_engine* e, int layer, int batch, char* n
     const FileOp& o = op.f;
     static const char* kOther[] = {"input_nchw_kernel", "", "maxpool_kernel", "upsample2_kernel", "detect_v8_kernel", "detect_v5_kernel",
                                    "layernorm_kernel"};
-    if (op.skip && o.type == OP_MAXPOOL && o.kh == 5) {
+    if (op.skip && o.type == OP_UPSAMPLE2) {
+        snprintf(name, cap, "(folded into the consumer's loads)");
+    } else if (op.skip && o.type == OP_MAXPOOL && o.kh == 5) {
         snprintf(name, cap, "(fused into the SPPF pool launch)");
     } else if (o.type == OP_MAXPOOL && op.pool3[0] >= 0) {
         snprintf(name, cap, "sppf_pool3_kernel");
@@ -539,6 +575,11 @@ int engine_run_op(adas_engine* e, int i, const float* d_in, int batch, hipStream
             a.bias = (const float*)(wb + op.b_off);
             a.n = batch; a.kh = o.kh; a.kw = o.kw; a.stride = o.stride; a.pad = o.pad; a.act = o.act; a.res_mode = o.res_mode;
             a.k = op.k; a.kpad = op.kpad; a.m = batch * a.out.h * a.out.w; a.max_n = e->max_batch; a.prec = e->prec;
+            if (op.up_src >= 0) {
+                const FileOp& u = e->ops[op.up_src].f;
+                a.up = make_view(e, u.in_buf[0], u.in_coff[0], u.in_c[0]);
+                a.up_c = (int)u.out_c;
+            }
             err = launch_conv(a, e->prec, st);
             break;
         }
@@ -697,6 +738,9 @@ int adas_engine_fetch_activation(adas_engine* e, int layer, int batch, float* h_
     ADAS_REQUIRE(!(e->ops[layer].skip && o.type == OP_INPUT) &&
                      !(e->ops[layer].kernel == CONV_STEM && (e->ops[layer].fuse_pool >= 0 || e->ops[layer].fuse_conv2 >= 0)), ADAS_ERR_INVALID,
                  "layer %d (%s) is fused into the stem launch and has no materialised activation (ADAS_NO_STEM=1 keeps it)", layer,
+                 e->ops[layer].name.c_str());
+    ADAS_REQUIRE(!(e->ops[layer].skip && o.type == OP_UPSAMPLE2), ADAS_ERR_INVALID,
+                 "layer %d (%s) is folded into its consumer's loads and has no materialised activation (ADAS_NO_UPSAMPLE_FOLD=1 keeps it)", layer,
                  e->ops[layer].name.c_str());
     ADAS_REQUIRE(e->ops[layer].pair_b < 0, ADAS_ERR_INVALID,
                  "layer %d (%s) is the first conv of a fused 3x3 pair: its activation stays in LDS (ADAS_NO_PAIR_FUSE=1 keeps it)", layer,

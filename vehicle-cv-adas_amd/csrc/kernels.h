@@ -27,6 +27,10 @@ struct ConvArgs {
     int k, kpad, m;     // K = kh*kw*cin ; padded to 32 ; M = n*ho*wo
     int max_n;          // the engine's max_batch (static: decides the FC weight packing)
     int prec;           // PREC_*: the 16-bit kernels pick their operand type (bf16 | fp16) from it
+    // 1x1 convs over a concat whose FIRST up_c channels are a 2x nearest-neighbour upsample of `up`: conv_pw.hip reads those
+    // channels from the half-resolution tensor at (y / 2, x / 2) and the upsample launch is dropped (up_c = 0: none)
+    TView up{};
+    int up_c = 0;
 };
 
 // Which kernel runs a conv and how its weights are packed.  Decided once at load time from static
@@ -62,6 +66,7 @@ bool pair_applicable(int prec, int kh, int kw, int stride, int pad, int act, int
 hipError_t launch_pack_weights_pair(const float* src, void* dst, int c, int prec, hipStream_t st);   // src fp32 [c][9][c]
 hipError_t launch_conv_pair(const TView& x, const TView& y, const void* w1, const float* b1, const void* w2, const float* b2, int n, bool has_res,
                             int prec, hipStream_t st);
+bool pw_applicable(int prec, int kh, int kw, int stride, int pad, int res_mode, const TView& in, const TView& out);  // conv_pw.hip
 // returns hipSuccess or the launch error.  prec: PREC_*.
 hipError_t launch_conv(const ConvArgs& a, int prec, hipStream_t st);
 const char* conv_tile_name(const ConvArgs& a, int prec);
