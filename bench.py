@@ -438,7 +438,7 @@ def main():
         for li, (name, fl, kind, ms) in enumerate(eng.profile(dptr, S, iters=10)):
             all_ms += ms
             label = eng.layer_kernel(li, S)
-            if not label.startswith("(fused"):
+            if not label.startswith("("):   # "(fused into ...)" / "(folded into ...)": no launch of its own
                 n_launches += 1
             if kind == 1:   # OP_CONV
                 if label.startswith("(fused into the Detect"):
