@@ -54,7 +54,7 @@ constexpr int STEM_WW = 72;  // window row pitch in pixels (even: 16 B aligned f
 // PACKED: the input is the (c0, c1, c2, 0) bf16 NHWC tensor adas_preprocess_*_packed writes (8 B per pixel, one load per window
 // pixel) instead of the fp32 NCHW seam tensor (three loads + a conversion); same values either way.
 template <typename E, int KH, int NT, int ACT, bool POOL, bool CONV2 = false, bool PACKED = false>
-__global__ __launch_bounds__(256, 2) void conv_stem_kernel(StemDev a) {
+__global__ __launch_bounds__(256, CONV2 ? 3 : 2) void conv_stem_kernel(StemDev a) {
     typedef typename E::vec8 svec8;
     constexpr bool TILE2 = POOL || CONV2;
     constexpr int CTH = CONV2 ? 17 : (POOL ? 9 : 8), CTW = TILE2 ? 33 : 32;  // conv tile (POOL: 4x16 pooled + halo)
@@ -361,7 +361,7 @@ hipError_t launch_conv_stem2(const float* nchw, int n, int c_true, int H, int W,
     d.ntiles = n * d.tiles_x * d.tiles_y;
     d.wfrag2 = (const uint16_t*)wfrag2; d.bias2 = bias2;
     if ((size_t)c_true * H * W * 4 >= (1ull << 31)) return hipErrorInvalidValue;
-    const int grid = d.ntiles < 1024 ? d.ntiles : 1024;
+    const int grid = d.ntiles < 768 ? d.ntiles : 768;   // persistent: three workgroups per CU (launch bounds), one generation
     if (kh != 3 && kh != 6) return hipErrorInvalidValue;
     ADAS_DISPATCH_E16(prec == PREC_FP16, E, {
         if (kh == 3 && packed_in) hipLaunchKernelGGL((conv_stem_kernel<E, 3, 1, ACT_SILU, false, true, true>), dim3(grid), dim3(256), 0, st, d);
