@@ -128,6 +128,26 @@ def test_yolov8_s_and_l_640_vs_oracle(scale, prec):
     e.close()
 
 
+def test_yolov8s_at_a_batch_that_selects_the_persistent_kernels():
+    """YOLOv8s at batch 48: its 128- / 256-channel 3x3 layers then bring enough tiles for the batch-selected kernels (conv_halo8 on the
+    40x40x128 Bottlenecks), the class branch runs the 48-wide blocks, C2f pairs / folded upsamples / one-launch SPPF pools are
+    all in the graph.  Two distinct frames tiled over the batch: frames 0-1 against the oracle, copies bit-identical."""
+    path, W, g = netutil.model("yolov8s")
+    x2 = netutil.coco_like_frames(2, seed=5)
+    x = np.ascontiguousarray(np.concatenate([x2] * 24, 0))
+    want = nets.yolov8_forward(x2, W, "s")
+    e = CE.HipEngine(path, precision="fp16", max_batch=48)
+    kernels = {e.layer_kernel(i, 48) for i in range(e.stats()["num_layers"])}
+    print(sorted(kernels))
+    assert any("conv_h8_kernel" in k for k in kernels), kernels
+    got = e.engine_inference(x)[0]
+    err, rel = report("yolov8s batch 48 fp16 head", got[:2], want)
+    assert rel <= REL_TOL["fp16"]
+    for k in range(2, 48):
+        assert np.array_equal(got[k], got[k % 2]), k
+    e.close()
+
+
 def test_yolov8n_non_square_input_vs_oracle():
     """A 384x640 export (yoloDetector.py:96-102 letterboxes to whatever the engine reports): the graph builder takes (H, W)."""
     path, W, g = netutil.model("yolov8n", imgsz=(384, 640))
