@@ -1,7 +1,7 @@
 // conv_halo8.hip -- stride-1 3x3 convolution for Cout % 128 == 0: a persistent, LDS-DMA fed, two-wave-group form of the halo kernel.
 //
 // conv_halo.hip stages every 32-channel chunk through registers and synchronises twice per chunk with nothing in flight across
-// the barriers; it tops out at ~0.9-1.0 PFLOP/s ("what bounds conv_halo").  This kernel keeps the tiling (strip-linear
+// the barriers; it tops out at ~0.9-1.0 PFLOP/s.  This kernel keeps the tiling (strip-linear
 // 256-pixel tiles, 64-byte swizzled window pixels, swizzled 64-byte weight rows, the same CONV_HALO weight packing) and changes
 // the synchronisation structure:
 //   * one 8-wave workgroup per CU owns 256 pixels x 128 output channels (waves 0-3 / 4-7 = the two 64-channel halves, each wave
@@ -13,8 +13,12 @@
 //     x 64 B); at tap T every wave issues its 1 KiB of the weights of tap T+4 and, on taps 1-5 of a chunk, 1 KiB of the next
 //     chunk's (or the next item's first) window.  Waits are COUNTED (`s_waitcnt vmcnt(N)`, N = the pieces issued in the last
 //     three taps): nothing ever drains the queue inside the stream;
-//   * the two wave groups run one barrier apart (group 1 takes one extra barrier up front): while one group issues the 8 fragment
-//     reads + DMA pieces of a tap, the other group's 16 MFMAs of the previous tap occupy the matrix pipe of the same SIMDs.
+//   * MODE 1: the two wave groups run one barrier apart (group 1 takes one extra barrier up front): while one group issues the 8
+//     fragment reads + DMA pieces of a tap, the other group's 16 MFMAs of the previous tap occupy the matrix pipe of the same SIMDs;
+//     MODE 2: one barrier per tap row, weights six taps ahead, all waves free-running in between (layers with few chunks per item);
+//   * an item's epilogue costs 2-4 k cycles with nothing to hide it under, so everything else that belongs to an item boundary is
+//     moved off it: the residual and the next item's bias are fetched under the last tap row (counted waits widened by their 12
+//     queue slots), the next item's tap / window offsets are computed between the last chunk's MFMAs.
 // Ordering rules the schedule relies on (cdna_hip_programming.md, "256^2 8-phase template"): a DMA piece is visible to a reader
 // that has passed a barrier which every issuing wave reached after its counted wait; with the groups one barrier apart that is
 // "wait at the end of tap T's read segment, read in tap T+1's".  A buffer is re-filled no earlier than the read segment two taps
