@@ -437,7 +437,7 @@ def main():
         stem_label = pair_label = None
         for li, (name, fl, kind, ms) in enumerate(eng.profile(dptr, S, iters=10)):
             all_ms += ms
-            label = eng.layer_kernel(li, S)
+            label = eng.layer_kernel(li, S).replace("+shortcut", "")   # same kernel with the block's projection folded in
             if not label.startswith("("):   # "(fused into ...)" / "(folded into ...)": no launch of its own
                 n_launches += 1
             if kind == 1:   # OP_CONV

@@ -372,3 +372,45 @@ def test_c2f_bottleneck_pairs_fused(CE, case, prec, tol):
     rel, names = _c2f_case(CE, H, W, c2, n, shortcut, prec)
     assert all("conv_pair_kernel" in k for k in names), names
     assert rel < tol, (case, prec, rel)
+
+
+@pytest.mark.parametrize("case", [
+    # H, W (block output), Cp (block input channels), C, batch: ResNet layer2.0 / layer3.0 / layer4.0 shapes, odd input extents
+    (40, 200, 64, 128, 8), (20, 100, 128, 256, 16), (10, 50, 256, 512, 32), (23, 37, 64, 128, 119),
+], ids=str)
+@pytest.mark.parametrize("prec,tol", [("bf16", 1e-2), ("fp16", 2e-3)])
+def test_projection_shortcut_folded_into_conv2(CE, case, prec, tol):
+    """ResNet layerN.0: out = relu(conv3x3(t) + conv1x1_s2(x)).  At batches where conv_halo8 takes conv2 the projection runs inside its
+    launch (extra K steps on x[2y, 2x] before the 3x3 stream) and the projection conv's own launch is dropped; checked against
+    torch, and against the unfolded path's kernel names at a batch too small for the persistent kernel."""
+    H, W, cp, c, batch = case
+    ws = M.SynthWeights(1, gain=1.0)
+    Hin, Win = 2 * H - (H % 2), 2 * W - (W % 2)      # odd block outputs come from odd inputs: (in + 1) // 2
+    g = M.Graph("unit", 3, Hin, Win, ws)
+    x0, c3 = g.input()
+    x = g.conv(x0, cp, 1, 1, "expand", act=M.ACT_RELU, true_cin=c3)
+    t = g.conv(x, c, 3, 2, "conv1", act=M.ACT_RELU)
+    d = g.conv(x, c, 1, 2, "down", act=M.ACT_NONE, pad=0)
+    y = g.conv(t, c, 3, 1, "conv2", act=M.ACT_RELU, res=d, res_mode=M.RES_BEFORE_ACT)
+    z = g.conv(y, 8, 1, 1, "tap", act=M.ACT_NONE, f32_out=True)
+    g.output(z, 0, [1, z.h * z.w * 8], "o")
+    assert (y.h, y.w) == (H, W)
+    path = os.path.join(tempfile.gettempdir(), f"unit_ds_{H}_{W}_{cp}_{c}.hipm")
+    g.save(path)
+    e = CE.HipEngine(path, prec, batch)
+    xin = np.random.default_rng(2).uniform(0, 1, (batch, 3, Hin, Win)).astype(np.float32)
+    e.engine_inference(xin)
+    got = e.fetch_activation("conv2", batch)
+    names = (e.layer_kernel(e.layer_index("down"), batch), e.layer_kernel(e.layer_index("conv2"), batch))
+    small = (e.layer_kernel(e.layer_index("down"), 1), e.layer_kernel(e.layer_index("conv2"), 1))
+    e.close(); os.remove(path)
+    assert "shortcut of" in names[0] and "conv_h8_kernel" in names[1] and "+shortcut" in names[1], names
+    assert "conv_pw_kernel" in small[0] and "+shortcut" not in small[1], small
+    Wt = {k_: torch.from_numpy(v) for k_, v in ws.store.items()}
+    with torch.no_grad():
+        xt = F.relu(F.conv2d(torch.from_numpy(xin), Wt["expand.weight"], Wt["expand.bias"]))
+        tt = F.relu(F.conv2d(xt, Wt["conv1.weight"], Wt["conv1.bias"], stride=2, padding=1))
+        dt = F.conv2d(xt, Wt["down.weight"], Wt["down.bias"], stride=2)
+        want = F.relu(F.conv2d(tt, Wt["conv2.weight"], Wt["conv2.bias"], padding=1) + dt).numpy()
+    rel = float(np.linalg.norm(got - want) / (np.linalg.norm(want) + 1e-30))
+    assert rel < tol, (case, prec, rel)

@@ -91,6 +91,7 @@ def test_pipeline_step_from_camera_frames(tmp_path):
         pa.step_frames(dc.ptr, (720, 1280), 0.6); pa.sync()
         L.check(L.lib().adas_preprocess_yolo(dc.ptr, S, 720, 1280, dt.ptr, 640, 640, 1, None))
         L.check(L.lib().adas_preprocess_ufld(dc.ptr, S, 720, 1280, lt.ptr, 320, 1600, C.c_double(0.6), None))
+        L.check(L.lib().adas_synchronize())   # the stand-alone kernels ran on the null stream; the pipeline's streams are non-blocking
         pb.step(dt.ptr, lt.ptr); pb.sync()
         for s in range(S):
             a, b = PP.YoloPost.fetch(pa.post, s), PP.YoloPost.fetch(pb.post, s)

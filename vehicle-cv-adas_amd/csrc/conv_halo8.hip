@@ -50,6 +50,13 @@ struct H8Dev {
     uint32_t mg_ww, mg_sw;
     uint32_t mg_img, mg_tps, mg_upt;  // ceil(2^32 / d) for d = NS * TPS, TPS, ncb / cpw: unit -> tile -> (image, strip) by multiply-high
     int ntiles, tiles8, ncb, cpw;  // tiles, ceil(tiles / 8) (one contiguous range per XCD), 128-channel blocks
+    // projection shortcut folded in (ResNet layerN.0: out = relu(conv3x3(t) + W_ds x[2y, 2x] + biases)): the 1x1 stride-2 conv is
+    // ndc extra 32-channel K steps accumulated before the 3x3 stream starts (ndc = 0: none)
+    const uint16_t* ds_in;    // x: [n][2H][2W][ds_cs]
+    const uint16_t* ds_w;     // [cout / 64][ndc][64 rows][32]
+    const float* ds_bias;
+    uint32_t ds_bytes;
+    int ds_cs, ds_coff, ds_H, ds_W, ndc;
 };
 
 constexpr int H8_THR = 512;
@@ -188,7 +195,13 @@ __global__ __launch_bounds__(H8_THR, 1) void conv_h8_kernel(H8Dev a) {
     auto wgt_base = [&](int cb) { return (uint32_t)(((2 * cb + hb) * a.nchunk) * H8_SLAB + grp * 1024); };
     auto load_bias = [&](int cb, float4* b) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) b[i] = *reinterpret_cast<const float4*>(a.bias + cb * 128 + hb * 64 + i * 16 + kg * 4);
+        for (int i = 0; i < 4; ++i) {
+            b[i] = *reinterpret_cast<const float4*>(a.bias + cb * 128 + hb * 64 + i * 16 + kg * 4);
+            if (a.ndc > 0) {
+                const float4 d = *reinterpret_cast<const float4*>(a.ds_bias + cb * 128 + hb * 64 + i * 16 + kg * 4);
+                b[i].x += d.x; b[i].y += d.y; b[i].z += d.z; b[i].w += d.w;
+            }
+        }
     };
 
     auto first_cb = [&](int u) { return upt == 1 ? 0 : (u - (int)__umulhi((uint32_t)u, a.mg_upt) * upt) * a.cpw; };
@@ -242,6 +255,58 @@ __global__ __launch_bounds__(H8_THR, 1) void conv_h8_kernel(H8Dev a) {
         uint32_t wnxt_item = 0, apn[4] = {0, 0, 0, 0};
         qu32x4 rraw[4][2];   // residual, fetched under the last row of taps of the last chunk
         H8P(0)
+
+        if (a.ndc > 0) {
+            // ---- projection shortcut: ndc K steps of x[2y, 2x] (no halo: the tile's own 256 pixels, 16 KB per step) against
+            // [128 x 32] weight tiles, staged in the window buffer the first chunk does not use, both wave groups in lockstep
+            // (group 0 waits one barrier for group 1, the stagger is re-established afterwards)
+            if (MODE == 1 && !hb) __builtin_amdgcn_s_barrier();
+            __amdgpu_buffer_rsrc_t rds = __builtin_amdgcn_make_buffer_rsrc((void*)a.ds_in, 0, a.ds_bytes, 0x00020000);
+            __amdgpu_buffer_rsrc_t rdw = __builtin_amdgcn_make_buffer_rsrc((void*)a.ds_w, 0, (uint32_t)(a.cout / 64) * (uint32_t)a.ndc * 4096u, 0x00020000);
+            // two x tiles (2 x 16 KB) in the free window buffer, two weight tiles in the ring slots the stream fills last
+            // (LOOK, LOOK + 1): step d + 1 is in flight while step d is multiplied
+            const uint32_t xbuf = (uint32_t)(((par + 1) & 1) * H8_WIN), wbuf = (uint32_t)(H8_WR + LOOK * H8_TAP);
+            uint32_t xo[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const int q = (wave * 2 + t) * 16 + (lane >> 2);          // tile pixel of this lane's 16 bytes
+                const int p = cur.p0 + q;
+                const int y = (int)(((uint32_t)p * a.mg_sw) >> 20), x = cur.sx0 + (p - y * a.SW);
+                const bool ok = y < a.H && x < a.W;
+                const uint32_t off = ((uint32_t)((cur.img * a.ds_H + 2 * y) * a.ds_W + 2 * x) * (uint32_t)a.ds_cs + (uint32_t)a.ds_coff) * 2u +
+                                     ((uint32_t)((lane & 3) ^ (((q >> 2) & 1) << 1)) << 4);
+                xo[t] = ok ? off : H8_OOB;
+            }
+            const uint32_t dwb = (uint32_t)((2 * cb + hb) * a.ndc) * 4096u + (uint32_t)grp * 1024u;
+            auto issue = [&](int d) {
+                const uint32_t sel = (uint32_t)(d & 1);
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rds, (lds_vp)(lds8 + xbuf + sel * 16384u + (wave * 2 + t) * 1024), 16, xo[t] + (uint32_t)d * 64u, 0, 0, 0);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rdw, (lds_vp)(lds8 + wbuf + sel * H8_TAP + wave * 1024), 16, wlane, dwb + (uint32_t)d * 4096u, 0, 0);
+            };
+            issue(0);
+            for (int d = 0; d < a.ndc; ++d) {
+                __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): step d has landed (nothing else is in flight here)
+                __builtin_amdgcn_s_barrier();         // ... for every wave, and every wave is past step d - 1's reads
+                if (d + 1 < a.ndc) issue(d + 1);      // into the buffers step d - 1 used
+                const uint32_t sel = (uint32_t)(d & 1);
+                hvec8 wf[4], xf[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) wf[i] = *reinterpret_cast<const hvec8*>(lds8 + wbuf + sel * H8_TAP + (wrd - H8_WR) + i * 1024);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int q = (grp * 4 + j) * 16 + lrow;
+                    xf[j] = *reinterpret_cast<const hvec8*>(lds8 + xbuf + sel * 16384u + q * 64 + ((kg ^ (((q >> 2) & 1) << 1)) << 4));
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[i][j] = E::mfma(wf[i], xf[j], acc[i][j]);
+            }
+            __builtin_amdgcn_s_barrier();   // the last step's tiles are read before the stream re-uses their slots
+            if (MODE == 1 && hb) __builtin_amdgcn_s_barrier();
+        }
 
         auto chunk = [&](auto last_c, const int c) {
             constexpr bool lastc = decltype(last_c)::value;
@@ -477,6 +542,48 @@ bool halo8_applicable(int kh, int kw, int stride, int pad, int n, const TView& i
     return h8_blocks_per_unit(tiles8, out.c / 128) > 0;
 }
 
+static bool h8_ds_enabled() {
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("ADAS_NO_DS_FUSE");
+        v = (e && e[0] == '1') ? 0 : 1;
+    }
+    return v == 1;
+}
+
+bool halo8_ds_applicable(int kh, int kw, int stride, int pad, int n, const TView& in, const TView& out, const TView& x) {
+    if (!h8_ds_enabled()) return false;
+    TView none = out;
+    none.p = nullptr;
+    if (!halo8_applicable(kh, kw, stride, pad, n, in, out, none, RES_NONE)) return false;
+    if (x.f32 || (x.c & 31) || x.c < 32 || x.c > 512 || ((x.cs | x.coff) & 7)) return false;
+    if ((x.h + 1) / 2 != out.h || (x.w + 1) / 2 != out.w) return false;   // 1x1, stride 2, pad 0
+    return (double)n * x.h * x.w * x.cs * 2.0 < (double)H8_OOB;
+}
+
+// fp32 [cout][cin] -> 16-bit [cout / 64][cin / 32][64 rows][32]: the per-step weight tiles of the projection pre-pass
+template <typename T>
+__global__ void pack_weights_ds_kernel(const float* __restrict__ src, T* __restrict__ dst, int cout, int cin) {
+    const int total = cout * cin;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const int c = i & 31;
+        int r = i >> 5;
+        const int row = r & 63; r >>= 6;
+        const int nd = cin >> 5;
+        const int d = r % nd, tile = r / nd;
+        const float v = src[(size_t)(tile * 64 + row) * cin + d * 32 + c];
+        if constexpr (sizeof(T) == sizeof(f16s) && !std::is_same<T, uint16_t>::value) dst[i].v = Fp16::from_f32(v);
+        else dst[i] = Bf16::from_f32(v);
+    }
+}
+hipError_t launch_pack_weights_ds(const float* src, void* dst, int cout, int cin, int prec, hipStream_t st) {
+    if ((cout & 63) || (cin & 31)) return hipErrorInvalidValue;
+    const int blocks = (cout * cin + 255) / 256;
+    if (prec == PREC_FP16) hipLaunchKernelGGL(pack_weights_ds_kernel<f16s>, dim3(blocks), dim3(256), 0, st, src, (f16s*)dst, cout, cin);
+    else hipLaunchKernelGGL(pack_weights_ds_kernel<uint16_t>, dim3(blocks), dim3(256), 0, st, src, (uint16_t*)dst, cout, cin);
+    return hipGetLastError();
+}
+
 template <typename E, int MODE>
 static hipError_t h8_launch(const H8Dev& d, int act, dim3 grid, hipStream_t st) {
     static bool attr_done = false;
@@ -515,6 +622,13 @@ hipError_t launch_conv_halo8(const ConvArgs& a, hipStream_t st) {
     d.ntiles = a.n * pl.NS * pl.TPS;
     d.tiles8 = (d.ntiles + 7) / 8;
     d.ncb = a.out.c / 128;
+    d.ds_in = nullptr; d.ds_w = nullptr; d.ds_bias = nullptr; d.ds_bytes = 0; d.ds_cs = d.ds_coff = d.ds_H = d.ds_W = d.ndc = 0;
+    if (a.ds_w) {
+        d.ds_in = (const uint16_t*)a.ds_in.p; d.ds_w = (const uint16_t*)a.ds_w; d.ds_bias = a.ds_bias;
+        d.ds_bytes = (uint32_t)((size_t)a.n * a.ds_in.h * a.ds_in.w * a.ds_in.cs * 2);
+        d.ds_cs = a.ds_in.cs; d.ds_coff = a.ds_in.coff; d.ds_H = a.ds_in.h; d.ds_W = a.ds_in.w; d.ndc = a.ds_in.c / 32;
+        d.res_mode = RES_NONE;   // the shortcut arrives through the MFMAs
+    }
     d.cpw = h8_blocks_per_unit(d.tiles8, d.ncb);
     if (d.cpw <= 0) return hipErrorNotSupported;
     const int upt = d.ncb / d.cpw;

@@ -28,6 +28,16 @@ static TView make_view(const adas_engine* e, int buf, int coff, int c) {
     return v;
 }
 
+// does conv `ci` (with a projection shortcut link) take its shortcut into its own launch at this batch?
+static bool ds_folded(const adas_engine* e, int ci, int batch) {
+    const EngOp& c = e->ops[ci];
+    if (c.ds_src < 0 || c.kernel != CONV_HALO) return false;
+    const FileOp& o = c.f;
+    const FileOp& d = e->ops[c.ds_src].f;
+    return halo8_ds_applicable(o.kh, o.kw, o.stride, o.pad, batch, make_view(e, o.in_buf[0], o.in_coff[0], o.in_c[0]),
+                               make_view(e, o.out_buf, o.out_coff, o.out_c), make_view(e, d.in_buf[0], d.in_coff[0], d.in_c[0]));
+}
+
 static int free_engine(adas_engine* e) {
     if (!e) return ADAS_OK;
     for (auto& b : e->bufs)
@@ -187,6 +197,33 @@ int adas_engine_create(const char* model_path, int precision, int max_batch, ada
             }
         }
     }
+    // ---- projection shortcut folded into the conv that adds it (ResNet layerN.0: conv2 + downsample): decided per launch, because
+    // the kernel that can do it (conv_halo8.hip) is chosen by batch
+    for (size_t ci = 0; ci < fo.size(); ++ci) {
+        const FileOp& c = fo[ci];
+        if (c.type != OP_CONV || c.kh != 3 || c.kw != 3 || c.stride != 1 || c.pad != 1 || c.res_mode != RES_BEFORE_ACT || !prec_is16(precision)) continue;
+        int di = -1;
+        for (int j = (int)ci - 1; j >= 0 && di < 0; --j)
+            if (fo[j].type == OP_CONV && fo[j].out_buf == c.res_buf && fo[j].out_coff == c.res_coff && fo[j].out_c == c.out_c) di = j;
+        if (di < 0) continue;
+        const FileOp& d = fo[di];
+        if (d.kh != 1 || d.kw != 1 || d.stride != 2 || d.pad != 0 || d.act != ACT_NONE || d.res_mode != RES_NONE || d.n_in != 1 || (d.in_c[0] & 31) ||
+            (d.out_c & 63) || e->ops[di].skip)
+            continue;
+        int nread = 0;
+        for (size_t j = 0; j < fo.size(); ++j) {
+            bool r = fo[j].res_mode != RES_NONE && fo[j].res_buf == d.out_buf;
+            for (uint32_t t = 0; t < fo[j].n_in && t < 8; ++t) r = r || fo[j].in_buf[t] == d.out_buf;
+            nread += r ? 1 : 0;
+        }
+        bool is_out = false;
+        for (auto& q : fout) is_out = is_out || q.buf == d.out_buf;
+        bool clean = true;   // x is not rewritten between the projection and the conv
+        for (int j = di + 1; j < (int)ci && clean; ++j) clean = fo[j].out_buf != d.in_buf[0];
+        if (nread != 1 || is_out || !clean) continue;
+        e->ops[ci].ds_src = di;
+        e->ops[di].ds_user = (int)ci;
+    }
     // ---- nearest 2x upsample folded into its consumer: the upsample writes the leading channels of a concat buffer that exactly one
     // 1x1 conv reads (YOLO necks: Upsample -> Concat -> C2f.cv1); that conv then fetches those channels from the half-resolution
     // tensor itself and the upsample launch (and its 4x larger copy of the tensor) disappears
@@ -307,6 +344,10 @@ int adas_engine_create(const char* model_path, int precision, int max_batch, ada
             op.cout_pad = (cout + 127) / 128 * 128;
             const size_t self = (size_t)(&op - &e->ops[0]);
             if (op.pair_b >= 0 || pair_of[self] >= 0) op.kernel = CONV_PAIR;   // fragment packing (fits the plan's allocation: <= 18 KB)
+            if (op.ds_user >= 0) {   // second copy of the projection weights, as per-step tiles
+                op.ds_w_off = packed_total;
+                packed_total += ((size_t)cout * cin * esz + 255) & ~(size_t)255;
+            }
             op.w_off = packed_total;
             packed_total += ((size_t)op.cout_pad * op.kpad * esz + 255) & ~(size_t)255;
             op.b_off = packed_total;
@@ -407,6 +448,7 @@ int adas_engine_create(const char* model_path, int precision, int max_batch, ada
                                 : op.kernel == CONV_HALO
                                 ? launch_pack_weights_halo(d_stage, base + op.w_off, o.out_c, op.cout_pad, o.in_c[0], op.cin_pad, precision, 0)
                                 : launch_pack_weights(d_stage, base + op.w_off, o.out_c, op.cout_pad, o.kh * o.kw, o.in_c[0], op.cin_pad, op.kpad, precision, 0);
+            if (pe == hipSuccess && op.ds_user >= 0) pe = launch_pack_weights_ds(d_stage, base + op.ds_w_off, o.out_c, o.in_c[0], precision, 0);
             if (pe != hipSuccess) { rc = ADAS_ERR_HIP; break; }
             if (hipDeviceSynchronize() != hipSuccess) { rc = ADAS_ERR_HIP; break; }
             std::vector<float> b(op.cout_pad, 0.f);
@@ -485,7 +527,9 @@ int adas_engine_layer_kernel(const adas_engine* e, int layer, int batch, char* n
     const FileOp& o = op.f;
     static const char* kOther[] = {"input_nchw_kernel", "", "maxpool_kernel", "upsample2_kernel", "detect_v8_kernel", "detect_v5_kernel",
                                    "layernorm_kernel"};
-    if (op.skip && o.type == OP_UPSAMPLE2) {
+    if (o.type == OP_CONV && op.ds_user >= 0 && ds_folded(e, op.ds_user, batch)) {
+        snprintf(name, cap, "(fused into the conv it is the shortcut of)");
+    } else if (op.skip && o.type == OP_UPSAMPLE2) {
         snprintf(name, cap, "(folded into the consumer's loads)");
     } else if (op.skip && o.type == OP_MAXPOOL && o.kh == 5) {
         snprintf(name, cap, "(fused into the SPPF pool launch)");
@@ -507,7 +551,8 @@ int adas_engine_layer_kernel(const adas_engine* e, int layer, int batch, char* n
         if (o.res_mode != RES_NONE) a.res = make_view(e, o.res_buf, o.res_coff, o.out_c);
         else { a.res = a.out; a.res.p = nullptr; }
         a.k = op.k; a.kpad = op.kpad; a.m = batch * a.out.h * a.out.w; a.max_n = e->max_batch; a.prec = e->prec;
-        snprintf(name, cap, "%s%s", conv_kernel_name(a, e->prec, op.kernel), op.fuse_pool >= 0 ? "+pool" : "");
+        snprintf(name, cap, "%s%s%s", conv_kernel_name(a, e->prec, op.kernel), op.fuse_pool >= 0 ? "+pool" : "",
+                 (op.ds_src >= 0 && ds_folded(e, layer, batch)) ? "+shortcut" : "");
     } else if (o.type == OP_DETECT_V8 && op.det_src[0] >= 0) {
         snprintf(name, cap, "detect_v8_fused_kernel");
     } else {
@@ -527,6 +572,7 @@ int adas_engine_layer_info(const adas_engine* e, int layer, char* name, int cap,
 
 // ------------------------------------------------------------------------------------- execution
 namespace adas {
+
 int engine_run_op(adas_engine* e, int i, const float* d_in, int batch, hipStream_t st, bool packed_in) {
     EngOp& op = e->ops[i];
     const FileOp& o = op.f;
@@ -559,6 +605,7 @@ int engine_run_op(adas_engine* e, int i, const float* d_in, int batch, hipStream
             err = launch_input_nchw(d_in, make_view(e, o.out_buf, 0, 8), batch, e->hdr.in_c, e->prec, st);
             break;
         case OP_CONV: {
+            if (op.ds_user >= 0 && ds_folded(e, op.ds_user, batch)) break;   // computed inside the conv it is the shortcut of
             if (op.pair_b >= 0) {   // this conv and the one behind it, one launch
                 const EngOp& b = e->ops[op.pair_b];
                 err = launch_conv_pair(make_view(e, o.in_buf[0], o.in_coff[0], o.in_c[0]), make_view(e, b.f.out_buf, b.f.out_coff, b.f.out_c),
@@ -575,6 +622,12 @@ int engine_run_op(adas_engine* e, int i, const float* d_in, int batch, hipStream
             a.bias = (const float*)(wb + op.b_off);
             a.n = batch; a.kh = o.kh; a.kw = o.kw; a.stride = o.stride; a.pad = o.pad; a.act = o.act; a.res_mode = o.res_mode;
             a.k = op.k; a.kpad = op.kpad; a.m = batch * a.out.h * a.out.w; a.max_n = e->max_batch; a.prec = e->prec;
+            if (op.ds_src >= 0 && ds_folded(e, i, batch)) {
+                const EngOp& dsop = e->ops[op.ds_src];
+                a.ds_in = make_view(e, dsop.f.in_buf[0], dsop.f.in_coff[0], dsop.f.in_c[0]);
+                a.ds_w = wb + dsop.ds_w_off;
+                a.ds_bias = (const float*)(wb + dsop.b_off);
+            }
             if (op.up_src >= 0) {
                 const FileOp& u = e->ops[op.up_src].f;
                 a.up = make_view(e, u.in_buf[0], u.in_coff[0], u.in_c[0]);
@@ -738,6 +791,9 @@ int adas_engine_fetch_activation(adas_engine* e, int layer, int batch, float* h_
     ADAS_REQUIRE(!(e->ops[layer].skip && o.type == OP_INPUT) &&
                      !(e->ops[layer].kernel == CONV_STEM && (e->ops[layer].fuse_pool >= 0 || e->ops[layer].fuse_conv2 >= 0)), ADAS_ERR_INVALID,
                  "layer %d (%s) is fused into the stem launch and has no materialised activation (ADAS_NO_STEM=1 keeps it)", layer,
+                 e->ops[layer].name.c_str());
+    ADAS_REQUIRE(!(e->ops[layer].ds_user >= 0 && ds_folded(e, e->ops[layer].ds_user, batch)), ADAS_ERR_INVALID,
+                 "layer %d (%s) is a projection shortcut computed inside the conv that adds it at this batch (ADAS_NO_DS_FUSE=1 keeps it)", layer,
                  e->ops[layer].name.c_str());
     ADAS_REQUIRE(!(e->ops[layer].skip && o.type == OP_UPSAMPLE2), ADAS_ERR_INVALID,
                  "layer %d (%s) is folded into its consumer's loads and has no materialised activation (ADAS_NO_UPSAMPLE_FOLD=1 keeps it)", layer,

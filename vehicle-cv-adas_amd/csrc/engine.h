@@ -56,6 +56,10 @@ struct EngOp {
     bool skip = false;       // fused into a neighbouring launch (input conversion / stem max-pool)
     int fuse_pool = -1;      // CONV_STEM: index of the max-pool op folded into this conv, or -1
     int fuse_conv2 = -1;     // CONV_STEM: index of the 3x3 s2 16->32 conv folded into this launch (YOLO stems), or -1
+    int ds_src = -1;         // 3x3 conv whose residual is a 1x1 stride-2 projection: index of that projection conv (folded into this launch
+                             // at batches where conv_halo8 takes the layer), or -1
+    int ds_user = -1;        // the projection conv's side of the same link
+    size_t ds_w_off = 0;     // projection weights re-packed as per-step tiles for the fold
     int up_src = -1;         // OP_CONV (1x1): index of the upsample op folded into this conv's activation loads, or -1
     int pool3[2] = {-1, -1}; // OP_MAXPOOL: the two pools chained behind this one, folded into its launch (SPPF), or -1
     int pair_b = -1;         // CONV_PAIR: index of the second conv of the pair this op launches (its own output is never written), or -1

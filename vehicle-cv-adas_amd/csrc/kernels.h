@@ -31,6 +31,11 @@ struct ConvArgs {
     // channels from the half-resolution tensor at (y / 2, x / 2) and the upsample launch is dropped (up_c = 0: none)
     TView up{};
     int up_c = 0;
+    // conv_halo8.hip: the residual of this 3x3 conv is a 1x1 stride-2 projection of ds_in (ResNet layerN.0 shortcut); when ds_w is set
+    // the projection is accumulated inside this launch (weights [cout / 64][ds_in.c / 32][64][32], bias ds_bias) and `res` is ignored
+    TView ds_in{};
+    const void* ds_w = nullptr;
+    const float* ds_bias = nullptr;
 };
 
 // Which kernel runs a conv and how its weights are packed.  Decided once at load time from static
@@ -59,6 +64,9 @@ struct HaloPlan {
 bool plan_halo(int Ho, int Wo, int S, HaloPlan* out, int maxpix_cap = 0);   // maxpix_cap: window pixel budget (0: the kernel's default)
 // conv_halo8.hip: stride-1 3x3 for Cout % 128 == 0, Cin % 32 == 0: persistent, LDS-DMA fed, counted waits (same weight packing)
 bool halo8_applicable(int kh, int kw, int stride, int pad, int n, const TView& in, const TView& out, const TView& res, int res_mode);
+// the same conv with its projection shortcut (1x1 stride 2 on `x`, no activation) folded in
+bool halo8_ds_applicable(int kh, int kw, int stride, int pad, int n, const TView& in, const TView& out, const TView& x);
+hipError_t launch_pack_weights_ds(const float* src, void* dst, int cout, int cin, int prec, hipStream_t st);   // src fp32 [cout][cin]
 hipError_t launch_conv_halo8(const ConvArgs& a, hipStream_t st);
 // conv_pair.hip: conv A (x -> t) and conv B (t -> y [+ x]) in one launch, t never written: 3x3 s1 SiLU on 16 or 32 channels
 bool pair_applicable(int prec, int kh, int kw, int stride, int pad, int act, int res_mode, const TView& x, const TView& t, int kh2, int kw2,
