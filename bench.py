@@ -435,14 +435,19 @@ def main():
     for eng, dptr in ((pipe.det, d_det[0].ptr), (pipe.lane, d_lane[0].ptr)):
         eng.profile(dptr, S, iters=3)            # the device idled while the stats were fetched: let the clocks come back first
         stem_label = pair_label = None
+        pending_shortcut = 0.0
         for li, (name, fl, kind, ms) in enumerate(eng.profile(dptr, S, iters=10)):
             all_ms += ms
-            label = eng.layer_kernel(li, S).replace("+shortcut", "")   # same kernel with the block's projection folded in
+            raw_label = eng.layer_kernel(li, S)
+            label = raw_label.replace("+shortcut", "")   # same kernel with the block's projection folded in
             if not label.startswith("("):   # "(fused into ...)" / "(folded into ...)": no launch of its own
                 n_launches += 1
             if kind == 1:   # OP_CONV
                 if label.startswith("(fused into the Detect"):
                     continue            # runs inside the Detect launch (not a conv kernel): its FLOPs are left out of the conv totals
+                if label.startswith("(fused into the conv it is the shortcut of"):
+                    pending_shortcut += fl * S      # a 1x1 projection computed by the "+shortcut" launch behind it
+                    continue
                 launches = 1
                 if label.startswith("(fused into the stem") and stem_label:
                     label, launches = stem_label, 0   # the stem launch does this layer's work: its FLOPs belong to that launch
@@ -454,10 +459,13 @@ def main():
                     stem_label = label
                 elif label.startswith("conv_pair_kernel"):
                     pair_label = label
+                extra = 0.0
+                if raw_label.endswith("+shortcut"):
+                    extra, pending_shortcut = pending_shortcut, 0.0
                 conv_ms += ms
-                conv_flops += fl * S
+                conv_flops += fl * S + extra
                 k = by_kernel.setdefault(label, [0.0, 0.0, 0])
-                k[0] += ms; k[1] += fl * S; k[2] += launches
+                k[0] += ms; k[1] += fl * S + extra; k[2] += launches
     achieved_all = conv_flops / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
     dom_name, (dom_ms, dom_fl, dom_n) = max(by_kernel.items(), key=lambda kv: kv[1][0])
     achieved = dom_fl / (dom_ms * 1e-3) / 1e12 if dom_ms > 0 else 0.0

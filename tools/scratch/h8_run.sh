@@ -1,2 +1,3 @@
 cd $GRAFT_REPO_ROOT
-echo "== default, with sync"; timeout 600 python tools/scratch/flaky_pipe.py 100 2>&1 | tail -4
+timeout 600 python bench.py --no-cpu-baseline --no-extras > gpurun_out/b1.json 2>/dev/null; python -c "
+import json; d=json.load(open('gpurun_out/b1.json')); r=d['roofline']; print(d['value'], r['kernel'], r['achieved'], r['frac'], r['gflop_per_launch'], r['avg_launch_us'], r['all_conv_frac'])"
