@@ -1,3 +1,4 @@
 cd $GRAFT_REPO_ROOT
-timeout 600 python bench.py --no-cpu-baseline --no-extras > gpurun_out/b1.json 2>/dev/null; python -c "
-import json; d=json.load(open('gpurun_out/b1.json')); r=d['roofline']; print(d['value'], r['kernel'], r['achieved'], r['frac'], r['gflop_per_launch'], r['avg_launch_us'], r['all_conv_frac'])"
+timeout 900 python -m pytest tests/test_gpu_conv.py -q -k "projection_shortcut or dma_fed" 2>&1 | tail -2
+timeout 600 python -m pytest tests/test_gpu_configs.py -q -k "bench_batch" 2>&1 | tail -1
+for m in 0 0; do timeout 300 python tools/profile_layers.py ufldv2_res18 --batch 64 --precision fp16 --top 30 2>/dev/null | grep -E "ms/step|layer[234]\.0\.conv2"; done

@@ -264,7 +264,7 @@ __global__ __launch_bounds__(H8_THR, 1) void conv_h8_kernel(H8Dev a) {
             __amdgpu_buffer_rsrc_t rds = __builtin_amdgcn_make_buffer_rsrc((void*)a.ds_in, 0, a.ds_bytes, 0x00020000);
             __amdgpu_buffer_rsrc_t rdw = __builtin_amdgcn_make_buffer_rsrc((void*)a.ds_w, 0, (uint32_t)(a.cout / 64) * (uint32_t)a.ndc * 4096u, 0x00020000);
             // two x tiles (2 x 16 KB) in the free window buffer, two weight tiles in the ring slots the stream fills last
-            // (LOOK, LOOK + 1): step d + 1 is in flight while step d is multiplied
+            // (LOOK, LOOK + 1): two steps are fetched per round trip
             const uint32_t xbuf = (uint32_t)(((par + 1) & 1) * H8_WIN), wbuf = (uint32_t)(H8_WR + LOOK * H8_TAP);
             uint32_t xo[2];
 #pragma unroll
@@ -285,24 +285,31 @@ __global__ __launch_bounds__(H8_THR, 1) void conv_h8_kernel(H8Dev a) {
                     __builtin_amdgcn_raw_ptr_buffer_load_lds(rds, (lds_vp)(lds8 + xbuf + sel * 16384u + (wave * 2 + t) * 1024), 16, xo[t] + (uint32_t)d * 64u, 0, 0, 0);
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rdw, (lds_vp)(lds8 + wbuf + sel * H8_TAP + wave * 1024), 16, wlane, dwb + (uint32_t)d * 4096u, 0, 0);
             };
-            issue(0);
-            for (int d = 0; d < a.ndc; ++d) {
-                __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): step d has landed (nothing else is in flight here)
-                __builtin_amdgcn_s_barrier();         // ... for every wave, and every wave is past step d - 1's reads
-                if (d + 1 < a.ndc) issue(d + 1);      // into the buffers step d - 1 used
-                const uint32_t sel = (uint32_t)(d & 1);
-                hvec8 wf[4], xf[4];
+            // two steps per round trip: the gather of x[2y, 2x] (16 cache lines per 1 KiB piece) is latency, not bandwidth
+            for (int d = 0; d < a.ndc; d += 2) {
+                const bool two = d + 1 < a.ndc;
+                issue(d);
+                if (two) issue(d + 1);
+                __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): both steps have landed (nothing else is in flight here)
+                __builtin_amdgcn_s_barrier();         // ... for every wave
 #pragma unroll
-                for (int i = 0; i < 4; ++i) wf[i] = *reinterpret_cast<const hvec8*>(lds8 + wbuf + sel * H8_TAP + (wrd - H8_WR) + i * 1024);
+                for (int h = 0; h < 2; ++h) {
+                    if (h == 1 && !two) break;
+                    const uint32_t sel = (uint32_t)h;   // issue() places step d + h in buffer (d + h) & 1 == h (d is even)
+                    hvec8 wf[4], xf[4];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int q = (grp * 4 + j) * 16 + lrow;
-                    xf[j] = *reinterpret_cast<const hvec8*>(lds8 + xbuf + sel * 16384u + q * 64 + ((kg ^ (((q >> 2) & 1) << 1)) << 4));
+                    for (int i = 0; i < 4; ++i) wf[i] = *reinterpret_cast<const hvec8*>(lds8 + wbuf + sel * H8_TAP + (wrd - H8_WR) + i * 1024);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int q = (grp * 4 + j) * 16 + lrow;
+                        xf[j] = *reinterpret_cast<const hvec8*>(lds8 + xbuf + sel * 16384u + q * 64 + ((kg ^ (((q >> 2) & 1) << 1)) << 4));
+                    }
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) acc[i][j] = E::mfma(wf[i], xf[j], acc[i][j]);
                 }
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) acc[i][j] = E::mfma(wf[i], xf[j], acc[i][j]);
+                if (d + 2 < a.ndc) __builtin_amdgcn_s_barrier();   // both tiles are read before the next round overwrites them
             }
             __builtin_amdgcn_s_barrier();   // the last step's tiles are read before the stream re-uses their slots
             if (MODE == 1 && hb) __builtin_amdgcn_s_barrier();
