@@ -568,6 +568,9 @@ bool halo8_ds_applicable(int kh, int kw, int stride, int pad, int n, const TView
     return (double)n * x.h * x.w * x.cs * 2.0 < (double)H8_OOB;
 }
 
+__device__ __forceinline__ void h8_store(uint16_t* p, float v) { *p = Bf16::from_f32(v); }
+__device__ __forceinline__ void h8_store(f16s* p, float v) { p->v = Fp16::from_f32(v); }
+
 // fp32 [cout][cin] -> 16-bit [cout / 64][cin / 32][64 rows][32]: the per-step weight tiles of the projection pre-pass
 template <typename T>
 __global__ void pack_weights_ds_kernel(const float* __restrict__ src, T* __restrict__ dst, int cout, int cin) {
@@ -579,8 +582,7 @@ __global__ void pack_weights_ds_kernel(const float* __restrict__ src, T* __restr
         const int nd = cin >> 5;
         const int d = r % nd, tile = r / nd;
         const float v = src[(size_t)(tile * 64 + row) * cin + d * 32 + c];
-        if constexpr (sizeof(T) == sizeof(f16s) && !std::is_same<T, uint16_t>::value) dst[i].v = Fp16::from_f32(v);
-        else dst[i] = Bf16::from_f32(v);
+        h8_store(dst + i, v);
     }
 }
 hipError_t launch_pack_weights_ds(const float* src, void* dst, int cout, int cin, int prec, hipStream_t st) {
