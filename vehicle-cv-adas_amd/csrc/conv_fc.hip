@@ -190,7 +190,9 @@ static hipError_t fc_launch_rows(const FcDev& d, int cout, hipStream_t st) {
     if (tm == 1) return fc_launch<E, 4, 1, 1, 4>(d, st);
     if (tm == 2) return fc_launch<E, 4, 2, 1, 4>(d, st);
     // 33..64 rows: 3.9 TB/s on cls.3.  Splitting K over the waves of a workgroup (more resident waves, partial sums through LDS)
-    // was measured and does not help (see fc_wide_ks): the launch is not short of bytes in flight.
+    // was measured and does not help (see fc_wide_ks): the launch is not short of bytes in flight.  Deeper rings or narrower
+    // workgroups neither: <4,4,1,U=4> 111 us, U=5 114 us (276-280 VGPRs: one wave per SIMD), <2,4,1,U=4> 125 us, <2,4,1,U=6> 116 us
+    // against 94 us for <4,4,1,3>.
     const int ks = fc_wide_ks();
     if (ks == 4) return fc_launch<E, 4, 4, 4, 3>(d, st);
     if (ks == 2) return fc_launch<E, 4, 4, 2, 3>(d, st);
