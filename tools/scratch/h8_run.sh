@@ -1,2 +1,2 @@
 cd $GRAFT_REPO_ROOT
-for u in 3 4 5 24 26 3; do echo "U=$u: $(ADAS_FC_U=$u timeout 300 python tools/profile_layers.py ufldv2_res18 --batch 64 --precision fp16 --top 30 2>/dev/null | grep -E "cls.3" | cut -c1-60)"; done
+for nh in 0 1; do echo "== NO_HALO=$nh"; ADAS_NO_HALO=$nh timeout 300 python tools/profile_layers.py yolov8n --batch 64 --precision fp16 --top 80 2>/dev/null | grep -E "ms/step|model\.(6|8|12|18|21)\.m\.0\.cv1|model.22.cv2.2|model.22.cv2.1.1"; done
