@@ -1,4 +1,2 @@
 cd $GRAFT_REPO_ROOT
-cp vehicle-cv-adas_amd/libadas_hip.so /tmp/lib_keep.so
-for v in base noprio look5 base noprio look5; do cp vehicle-cv-adas_amd/_ab/lib_$v.so vehicle-cv-adas_amd/libadas_hip.so; echo "== $v $(timeout 300 python tools/profile_layers.py ufldv2_res18 --batch 64 --precision fp16 --top 30 2>/dev/null | grep -E "layer[234]\.[01]\.conv[12] .*k3s1" | awk '{s+=$1} END {print "sum9", s}')"; done
-cp /tmp/lib_keep.so vehicle-cv-adas_amd/libadas_hip.so
+for m in 0 1 2 0 1 2; do echo "prio mode $m: $(ADAS_STREAM_PRIO=$m timeout 300 python bench.py --no-cpu-baseline --no-extras 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'])")"; done
