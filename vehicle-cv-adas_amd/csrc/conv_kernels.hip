@@ -408,6 +408,12 @@ ConvPlan plan_conv(int prec, int kh, int kw, int stride, int pad, int max_n, int
 hipError_t launch_conv(const ConvArgs& a, int prec, hipStream_t st) {
     ConvPlan pl = plan_conv(prec, a.kh, a.kw, a.stride, a.pad, a.max_n, a.res_mode, a.in, a.out);
     if (pl.kpad != a.kpad) return hipErrorInvalidValue;  // weights were packed for a different plan
+    if (a.up_c > 0 && pl.kernel != CONV_PW) return hipErrorInvalidValue;   // only conv_pw fetches the folded upsample's channels
+    if (a.ds_w) {   // the engine dropped the projection's launch: only conv_halo8 computes it inside this conv
+        if (pl.kernel != CONV_HALO) return hipErrorInvalidValue;
+        hipError_t e = launch_conv_halo8(a, st);
+        return e == hipErrorNotSupported ? hipErrorInvalidValue : e;
+    }
     if (pl.kernel == CONV_HALO) {
         if (halo_rw_applicable(a.kh, a.kw, a.stride, a.pad, a.n, a.in, a.out)) {
             hipError_t e = launch_conv_halo_rw(a, st);

@@ -34,8 +34,13 @@ static bool ds_folded(const adas_engine* e, int ci, int batch) {
     if (c.ds_src < 0 || c.kernel != CONV_HALO) return false;
     const FileOp& o = c.f;
     const FileOp& d = e->ops[c.ds_src].f;
-    return halo8_ds_applicable(o.kh, o.kw, o.stride, o.pad, batch, make_view(e, o.in_buf[0], o.in_coff[0], o.in_c[0]),
-                               make_view(e, o.out_buf, o.out_coff, o.out_c), make_view(e, d.in_buf[0], d.in_coff[0], d.in_c[0]));
+    // exactly launch_conv's order of choice: halo_rw and the stride-2 kernel come before conv_halo8 and know nothing of ds_w, and
+    // conv_halo8 is asked with the conv's real residual view (the projection's output buffer)
+    const TView in = make_view(e, o.in_buf[0], o.in_coff[0], o.in_c[0]), out = make_view(e, o.out_buf, o.out_coff, o.out_c);
+    if (halo_rw_applicable(o.kh, o.kw, o.stride, o.pad, batch, in, out)) return false;
+    if (halo_s2p_applicable(o.kh, o.kw, o.stride, o.pad, o.res_mode, batch, in, out)) return false;
+    if (!halo8_applicable(o.kh, o.kw, o.stride, o.pad, batch, in, out, make_view(e, o.res_buf, o.res_coff, o.out_c), o.res_mode)) return false;
+    return halo8_ds_applicable(o.kh, o.kw, o.stride, o.pad, batch, in, out, make_view(e, d.in_buf[0], d.in_coff[0], d.in_c[0]));
 }
 
 static int free_engine(adas_engine* e) {
@@ -149,6 +154,15 @@ int adas_engine_create(const char* model_path, int precision, int max_batch, ada
         op.w_off = op.b_off = 0;
         e->ops.push_back(op);
     }
+    // The fusion passes below count the readers of a tensor by buffer index.  A buffer that is re-viewed through an alias
+    // (Graph.alias: the same bytes under another shape) has readers those counts would miss, so such buffers stay out of every fusion.
+    auto aliased = [&](int64_t buf) {
+        if (buf < 0 || buf >= (int64_t)e->bufs.size()) return false;
+        if (e->bufs[buf].alias_of >= 0) return true;
+        for (auto& b : e->bufs)
+            if (b.alias_of == (int)buf) return true;
+        return false;
+    };
     // ---- first-layer fusion (conv_stem.hip): input conversion + stride-2 conv (+ the ResNet stem's max-pool) in one launch
     {
         const char* env = getenv("ADAS_NO_STEM");
@@ -163,7 +177,8 @@ int adas_engine_create(const char* model_path, int precision, int max_batch, ada
                 if ((int)q.buf == buf) return true;
             return false;
         };
-        if (enabled && e->ops.size() >= 2 && fo[0].type == OP_INPUT && fo[1].type == OP_CONV && fo[1].in_buf[0] == fo[0].out_buf) {
+        if (enabled && e->ops.size() >= 2 && fo[0].type == OP_INPUT && fo[1].type == OP_CONV && fo[1].in_buf[0] == fo[0].out_buf &&
+            !aliased(fo[0].out_buf) && !aliased(fo[1].out_buf)) {
             bool only = true;
             for (size_t i = 2; i < fo.size(); ++i) only = only && !reads_buf(fo[i], fo[0].out_buf);
             bool pool = e->ops.size() >= 3 && fo[2].type == OP_MAXPOOL && fo[2].kh == 3 && fo[2].stride == 2 && fo[2].pad == 1 &&
@@ -220,7 +235,7 @@ int adas_engine_create(const char* model_path, int precision, int max_batch, ada
         for (auto& q : fout) is_out = is_out || q.buf == d.out_buf;
         bool clean = true;   // x is not rewritten between the projection and the conv
         for (int j = di + 1; j < (int)ci && clean; ++j) clean = fo[j].out_buf != d.in_buf[0];
-        if (nread != 1 || is_out || !clean) continue;
+        if (nread != 1 || is_out || !clean || aliased(d.out_buf)) continue;
         e->ops[ci].ds_src = di;
         e->ops[di].ds_user = (int)ci;
     }
@@ -244,13 +259,14 @@ int adas_engine_create(const char* model_path, int precision, int max_batch, ada
             }
             bool is_out = false;
             for (auto& q : fout) is_out = is_out || q.buf == u.out_buf;
-            if (nread != 1 || is_out || reader <= (int)ui) continue;
+            if (nread != 1 || is_out || reader <= (int)ui || aliased(u.out_buf)) continue;
             const FileOp& c = fo[reader];
             if (c.type != OP_CONV || c.kh != 1 || c.kw != 1 || c.stride != 1 || c.pad != 0 || c.res_mode != RES_NONE || c.n_in != 1 || c.in_coff[0] != 0 ||
                 c.in_c[0] <= u.out_c || e->ops[reader].skip)
                 continue;
             TView cin = make_view(e, c.in_buf[0], c.in_coff[0], c.in_c[0]), cout = make_view(e, c.out_buf, c.out_coff, c.out_c);
-            if (!pw_applicable(precision, 1, 1, 1, 0, RES_NONE, cin, cout)) continue;
+            // only conv_pw reads ConvArgs::up: fold when the reader is PLANNED onto it (ADAS_NO_PW=1 plans it elsewhere)
+            if (plan_conv(precision, 1, 1, 1, 0, max_batch, RES_NONE, cin, cout).kernel != CONV_PW) continue;
             bool clean = true;   // the low-resolution source is not rewritten between the upsample and the conv
             for (int j = (int)ui + 1; j < reader && clean; ++j) clean = fo[j].out_buf != u.in_buf[0];
             if (!clean) continue;
@@ -292,7 +308,7 @@ int adas_engine_create(const char* model_path, int precision, int max_batch, ada
         }
         bool is_out = false;
         for (auto& q : fout) is_out = is_out || q.buf == qa.out_buf;
-        if (readers != 1 || is_out || bi <= (int)ai) continue;
+        if (readers != 1 || is_out || bi <= (int)ai || aliased(qa.out_buf)) continue;
         const FileOp& qb = fo[bi];
         if (qb.type != OP_CONV || e->ops[bi].skip || qb.n_in != 1 || qb.in_buf[0] != qa.out_buf || qb.in_coff[0] != qa.out_coff || qb.in_c[0] != qa.out_c) continue;
         bool clean = true;   // nothing between A and B writes A's input or B's output region's buffer in a way the fusion would reorder
@@ -301,6 +317,8 @@ int adas_engine_create(const char* model_path, int precision, int max_batch, ada
         TView x = make_view(e, qa.in_buf[0], qa.in_coff[0], qa.in_c[0]), t = make_view(e, qa.out_buf, qa.out_coff, qa.out_c);
         TView y = make_view(e, qb.out_buf, qb.out_coff, qb.out_c);
         TView r2 = qb.res_mode != RES_NONE ? make_view(e, qb.res_buf, qb.res_coff, qb.out_c) : y;
+        // the pair writes y while other workgroups still read x halos: y must not overlap x (same memory, intersecting channel ranges)
+        if (y.p == x.p && y.coff < x.coff + x.c && x.coff < y.coff + y.c) continue;
         if (!pair_applicable(precision, qa.kh, qa.kw, qa.stride, qa.pad, qa.act, qa.res_mode, x, t, qb.kh, qb.kw, qb.stride, qb.pad, qb.act, qb.res_mode, y, r2))
             continue;
         e->ops[ai].pair_b = bi;
@@ -390,6 +408,7 @@ int adas_engine_create(const char* model_path, int precision, int max_batch, ada
                     ok = ok && !(r.res_mode != RES_NONE && r.res_buf == q.out_buf);
                 }
                 for (auto& out : fout) ok = ok && out.buf != q.out_buf;
+                ok = ok && !aliased(q.out_buf);
             }
             for (int l = 1; l < 3 && ok; ++l)  // one hidden width per branch
                 ok = e->ops[src[2 * l]].f.in_c[0] == e->ops[src[0]].f.in_c[0] && e->ops[src[2 * l + 1]].f.in_c[0] == e->ops[src[1]].f.in_c[0];

@@ -85,7 +85,8 @@ struct ColTap {
     short x0, x1, a0, a1;   // source columns, 11-bit coefficients (<= 2048)
 };
 constexpr int PRE_ROWS = 8;       // output rows per workgroup
-constexpr int PRE_MAXW = 8192;    // widest resized row the (dynamic LDS) table holds: 64 KB
+constexpr int PRE_MAXW = 7680;    // widest resized row the (dynamic LDS) table holds: 60 KB + the kernels' <= 3 KB of static LDS stay under
+                                  // the 64 KB a launch gets without hipFuncSetAttribute(MaxDynamicSharedMemorySize)
 
 __device__ __forceinline__ void col_table(ColTap* tab, const ResizeGeom& g, int first, int count) {
     for (int t = threadIdx.x; t < count; t += blockDim.x) {
