@@ -81,35 +81,37 @@ def lane_frames(n, seed, h=320, w=1600):
 
 
 class SynthDetector:
-    """Seeded synthetic detector with a calibratable Detect class bias.
+    """Seeded synthetic detector with a calibratable Detect class branch.
 
     Random weights give 0 or thousands of boxes per frame; a trained detector gives tens.  The Detect cls biases (one value for all
     classes and levels) are therefore set from the frames' own logits: "conf > box_score" <=> "an anchor's best class logit (without
-    bias) > t", so t fixes how many anchors of each frame become candidates.  The last cls conv is scaled by `sharpen` first so that
-    the surviving scores spread over (0.4, 1) the way a trained head's do -- otherwise every score sits just above 0.4 and ByteTrack
-    (new tracks need >= 0.6, byteTracker.py:43,162) never starts a track."""
+    bias) > t", so t fixes how many anchors of each frame become candidates.  The last cls conv is scaled by `sharpen` so that the
+    surviving scores spread over (0.4, 1) the way a trained head's do -- otherwise every score sits just above 0.4 and ByteTrack
+    (new tracks need >= 0.6, byteTracker.py:43,162) never starts a track.  `sharpen=None` derives the factor from the measured
+    spread of the best logits (SPREAD standard deviations of it become SPREAD logit units), so the workload does not depend on the
+    synthetic weights' gain."""
+    SPREAD = 2.0      # the top anchors of a frame (~1.5 sigma over the threshold) reach conf ~0.9
 
-    def __init__(self, M, CE, name, workdir, tag, sharpen=8.0, batch=16):
+    def __init__(self, M, CE, name, workdir, tag, sharpen=None, batch=16):
         self.M, self.CE, self.name, self.workdir, self.tag, self.batch = M, CE, name, workdir, tag, batch
         ws = M.SynthWeights(0, gain=M.synth_gain(name))
-        M.build(name, wsrc=ws)                      # populates ws.store
-        for i in range(3):
-            ws.store[f"model.22.cv3.{i}.2.weight"] = ws.store[f"model.22.cv3.{i}.2.weight"] * np.float32(sharpen)
+        g = M.build(name, wsrc=ws)                      # populates ws.store
         self.ws = ws
-        g = M.build(name, wsrc=ws)
+        self.sharpen = sharpen
+        self.head = "model.23.one2one_cv3" if name.startswith("yolov10") else "model.22.cv3"
         self._uncal = os.path.join(workdir, f"{name}_{tag}_uncal.hipm")
         g.save(self._uncal)
         self._eng = CE.HipEngine(self._uncal, "fp32", batch)
 
     def best_logits(self, seam):
-        """seam: (n,3,H,W) fp32 -> (n, A) every anchor's best class logit without its bias, ascending per frame."""
+        """seam: (n,3,H,W) fp32 -> (n, A) every anchor's best class logit without its bias (un-sharpened), ascending per frame."""
         out = []
         for f0 in range(0, len(seam), self.batch):
             chunk = seam[f0:f0 + self.batch]
             self._eng.engine_inference(chunk)
             per_level = []
             for i in range(3):
-                lname = f"model.22.cv3.{i}.2"
+                lname = f"{self.head}.{i}.2"
                 z = self._eng.fetch_activation(lname, len(chunk))
                 b = self.ws.store[lname + ".bias"]
                 per_level.append((z - b.reshape(1, -1, 1, 1)).max(axis=1).reshape(len(chunk), -1))
@@ -118,12 +120,20 @@ class SynthDetector:
         best.sort(axis=1)
         return best
 
+    def fix_sharpen(self, best):
+        """Choose the cls scale from the first batch of best logits (once)."""
+        if self.sharpen is None:
+            self.sharpen = float(self.SPREAD / max(float(best.std()), 1e-12))
+        return self.sharpen
+
     @staticmethod
     def threshold(best, target_per_frame, capacity=None):
         """t such that the MEDIAN frame has ~target anchors over it and (capacity given) no frame more than 0.8 * capacity."""
         A = best.shape[1]
-        k_med = min(A - 1, max(1, int(round(target_per_frame))))
-        t = float(np.median(best[:, A - k_med]))
+        k_med = min(A - 2, max(1, int(round(target_per_frame))))
+        # midway between the k-th and (k+1)-th best logit of each frame: the threshold never sits ON an anchor's logit (a score of
+        # exactly box_score would be decided by the last rounding bit of whichever precision runs)
+        t = float(np.median(0.5 * (best[:, A - k_med] + best[:, A - k_med - 1])))
         if capacity is not None:
             k_cap = min(A - 1, max(1, int(0.8 * capacity)))
             t = max(t, float(best[:, A - k_cap].max()))
@@ -134,26 +144,29 @@ class SynthDetector:
         return (best > t).sum(axis=1)
 
     def finish(self, t):
-        """-> (path of the calibrated container, its weights, Graph)."""
+        """t: threshold on the UN-sharpened best logits -> (path of the calibrated container, its weights, Graph)."""
         M = self.M
         self._eng.close()
         os.remove(self._uncal)
+        sh = np.float32(self.sharpen if self.sharpen is not None else 1.0)
         ws2 = M.SynthWeights(0, gain=M.synth_gain(self.name))
         ws2.store.update(self.ws.store)
         for i in range(3):
-            lname = f"model.22.cv3.{i}.2"
-            ws2.store[lname + ".bias"] = np.full_like(self.ws.store[lname + ".bias"], math.log(0.4 / 0.6) - t)
+            lname = f"{self.head}.{i}.2"
+            ws2.store[lname + ".weight"] = self.ws.store[lname + ".weight"] * sh
+            ws2.store[lname + ".bias"] = np.full_like(self.ws.store[lname + ".bias"], math.log(0.4 / 0.6) - float(sh) * t)
         g2 = M.build(self.name, wsrc=ws2)
         path = os.path.join(self.workdir, f"{self.name}_{self.tag}.hipm")
         g2.save(path)
         return path, dict(ws2.store), g2
 
 
-def build_detector(M, CE, name, frames, workdir, tag, target_per_frame=30.0, sharpen=8.0, capacity=None):
+def build_detector(M, CE, name, frames, workdir, tag, target_per_frame=30.0, sharpen=None, capacity=None):
     """Calibrated synthetic detector for the given seam frames (see SynthDetector): the median frame gets ~target candidates and,
     with `capacity`, no frame more than 0.8 * capacity."""
     sd = SynthDetector(M, CE, name, workdir, tag, sharpen, batch=min(len(frames), 16))
     best = sd.best_logits(frames)
+    sd.fix_sharpen(best)
     return sd.finish(SynthDetector.threshold(best, target_per_frame, capacity))
 
 
@@ -191,20 +204,27 @@ def measure_parity(det_eng, lane_eng, det_name, lane_name, Wd, Wl, dframes, lfra
                          "the 16-bit modes are bounded by rel-L2 (fp16 8e-3, bf16 6e-2)"}
 
 
-def cpu_baseline(det_name, lane_name, Wd, Wl, dframes, lframes, lb, budget_s=20.0):
-    """The oracle (torch-CPU fp32 nets + NumPy post-processing + NumPy/SciPy ByteTrack) timed on host cores."""
+def cpu_baseline(det_name, lane_name, Wd, Wl, dframes, lframes, lb, budget_s=20.0, cams=None):
+    """The oracle (NumPy pre-processing + torch-CPU fp32 nets + NumPy post-processing + NumPy/SciPy ByteTrack) timed on host cores.
+    With `cams` (u8 camera frames) both legs start at the camera frame, like the GPU step; without, at the engine seam."""
     import torch
-    from oracle import nets, yolo_post, ufld_decode, bytetrack
+    from oracle import nets, yolo_post, ufld_decode, bytetrack, preprocess
     cfg = ufld_decode.ModelConfig("culane")
     trk = bytetrack.BYTETracker()
     scale = det_name[-1]
     bb = lane_name.split("res")[-1]
+    det_fwd = (lambda x: nets.yolov10_forward(x, Wd, det_name[len("yolov10"):])) if det_name.startswith("yolov10") else (lambda x: nets.yolov8_forward(x, Wd, scale))
 
     def one(i):
-        y = nets.yolov8_forward(dframes[i:i + 1], Wd, scale)[0]
+        if cams is not None:
+            xd = preprocess.yolo_prepare_input(cams[i], (640, 640))
+            xl = preprocess.ufld_prepare_input(cams[i], (320, 1600), 0.6)
+        else:
+            xd, xl = dframes[i:i + 1], lframes[i:i + 1]
+        y = det_fwd(xd)[0]
         r = yolo_post.detect_post(y, lb, "yolov8", 0.4, 0.45)
         trk.update(r["xyxy_int"], r["conf"], r["class_id"])
-        o = nets.ufldv2_forward(lframes[i:i + 1], Wl, bb)
+        o = nets.ufldv2_forward(xl, Wl, bb)
         ufld_decode.process_output(o, cfg, 1280, 720)
     one(0)  # warm-up (oneDNN primitive creation)
     t0 = time.perf_counter()
@@ -216,9 +236,77 @@ def cpu_baseline(det_name, lane_name, Wd, Wl, dframes, lframes, lb, budget_s=20.
             break
     dt = time.perf_counter() - t0
     return dict(value=round(n / dt, 3), unit="frames/s", cores=int(torch.get_num_threads()), kind="port",
-                sample=f"{n} frames of the same synthetic workload from the engine seam on (pre-processing not timed on the CPU side), "
-                       f"batch 1, torch-CPU fp32 nets + NumPy post-proc/ByteTrack "
-                       f"(oracle/), {dt:.1f} s")
+                sample=f"{n} frames of the same synthetic workload "
+                       + ("from the u8 camera frame on (NumPy letterbox/resize/normalise restatement included, like the GPU step), "
+                          if cams is not None else "from the engine seam on (pre-processing not timed on the CPU side), ")
+                       + f"batch 1, torch-CPU fp32 nets + NumPy post-proc/ByteTrack (oracle/), {dt:.1f} s")
+
+
+def measure_e2e(L, make_pipe, det_name, lane_name, Wd, Wl, d_cam, h_cam, S, hold, precision, n_streams_cmp=8):
+    """End-to-end parity of the TIMED mode: a fresh pipeline (fresh trackers) replays the timed frame sets -- set 0, set 1, set 0
+    again, each held `hold` steps -- and after every step the first `n_streams_cmp` streams are compared with the fp32 oracle chain
+    (oracle.preprocess -> nets -> yolo_post -> bytetrack, ufld_decode): candidate anchor sets, NMS survivors, track ids and states,
+    lane points (tests/chain_parity.py; north_star: "bit-exact NMS survivor indices / ByteTrack ID assignment")."""
+    import chain_parity as CP
+    import gpu_api
+    PP = importlib.import_module("adas_amd.postproc")
+    pp = make_pipe(precision)
+    chain = CP.OracleChain(det_name, Wd, lane_name, Wl)
+    streams = list(range(min(S, n_streams_cmp)))
+    sets = list(range(len(d_cam))) + [0]
+    steps = len(sets) * hold
+    t0 = time.perf_counter()
+    st = CP.run_device_chain(pp, lambda s: PP.YoloPost.fetch(pp.post, s), lambda s: gpu_api.track_snapshot(*pp.tracker.fetch(s)),
+                             [d_cam[i] for i in sets], [h_cam[i] for i in sets], chain, steps, hold, streams)
+    pp.close()
+    out = st.summary()
+    out.update({"mode": precision, "streams_compared": len(streams), "steps": steps, "frame_hold": hold,
+                "against": "the whole fp32 oracle chain on the timed frames (oracle outputs cached per distinct frame)",
+                "seconds": round(time.perf_counter() - t0, 1), "mismatches": st.mismatch_log[:4]})
+    return out
+
+
+def measure_post_hbm(L, pipe, gd, gl, S, layer_ms, precision):
+    """Achieved HBM rate of the memory-bound post-processing kernels (north_star: "rocprof reports achieved HBM GB/s on the
+    memory-bound post-proc"): algorithmic bytes of one launch over S frames / its duration by hipEvents on the launch stream."""
+    import ctypes as C
+    esz = 4 if precision == "fp32" else 2
+    out = []
+
+    def row(kernel, nbytes, ms, what):
+        if ms and ms > 0:
+            out.append({"kernel": kernel, "bytes": int(nbytes), "us": round(ms * 1e3, 2), "tb_s": round(nbytes / (ms * 1e-3) / 1e12, 3),
+                        "frac_of_8tbs": round(nbytes / (ms * 1e-3) / (PEAK_HBM_GBS * 1e9), 4), "what": what})
+    try:
+        meta = gd.meta
+        A, nc = meta["anchors"], meta["nc"]
+        head_bytes = S * (4 + nc) * A * 4
+        ms2 = (C.c_float * 2)()
+        L.check(L.lib().adas_yolo_post_profile(pipe.post.h, pipe.det.output_device_ptr(0), S, 20, ms2))
+        row("yolo_scan_v8", head_bytes + S * A * 8, float(ms2[0]), "head tensor read once + per-anchor best (conf, class) written")
+        out.append({"kernel": "yolo_post_kernel", "us": round(float(ms2[1]) * 1e3, 2), "bound": "latency",
+                    "what": "compaction + inverse letterbox + sequential fp64 NMS + RectInfo, one workgroup per frame"})
+        for name, (ms, label) in layer_ms.items():
+            if label == "detect_v8_fused_kernel":
+                det_ops = {o["name"]: o for o in gd.ops}
+                hid = sum(o["ins"][0].h * o["ins"][0].w * o["ins"][0].c for nm, o in det_ops.items() if nm.endswith(".2") and ".cv" in nm)
+                row(label, S * (hid * esz + (4 + nc) * A * 4), ms, "hidden activations of both Detect branches in, fp32 (4+nc, A) head out")
+            if label == "fc_kernel" and name == "cls.3":
+                o = [q for q in gl.ops if q["name"] == "cls.3"][0]
+                cin, cout = o["ins"][0].c, o["out"].c
+                groups = (S + 63) // 64
+                row(label + "(cls.3)", groups * cout * cin * esz + S * (cin * esz + cout * 4), ms, "weights streamed once per <=64-row group + rows in + fp32 logits out")
+        lane_out = sum(int(np.prod(sh[2][1:])) for sh in gl.outs)
+        ptrs = [pipe.lane.output_device_ptr(i) for i in range(4)]
+        pipe.decode.run_device(ptrs, [lane_out] * 4, S, None)
+        with L.StreamTimer(None) as tm:
+            for _ in range(20):
+                pipe.decode.run_device(ptrs, [lane_out] * 4, S, None)
+        row("ufld_decode_kernel", S * lane_out * 4, tm.ms / 20.0, "the four head views read once")
+        tm.close()
+    except Exception as ex:
+        out.append({"error": repr(ex)})
+    return out
 
 
 PRESETS = {   # BASELINE.json configs
@@ -274,6 +362,8 @@ def main():
                     "in HBM) instead of at the u8 camera frames")
     ap.add_argument("--candidates", type=float, default=100.0, help="anchors over box_score on the median generated frame (the detector's class "
                     "bias is calibrated to it); frames outside [8, 0.7 * capacity] are not used")
+    ap.add_argument("--repeats", type=int, default=5, help="repeats of the --steps loop after the headline one (min / median / max reported)")
+    ap.add_argument("--latency-steps", type=int, default=40, help="individually synchronised steps for the p50 / p99 step latency")
     ap.add_argument("--pool", type=int, default=2, help="distinct frame sets cycled through")
     ap.add_argument("--hold", type=int, default=4, help="consecutive steps each frame set is shown for (a scene that changes "
                     "every HOLD frames: gives ByteTrack confirmed, lost and re-found tracks to maintain)")
@@ -334,6 +424,7 @@ def main():
             dc.free(); dt_.free(); lt_.free()
             return a, b
         cams, dseam, lseam, bests = [], [], [], []
+        cams_all, counts_all = [], []               # the first S*P frames as drawn (no selection): the `unfiltered` leg
         t_cal, need, drawn = None, S * P, 0
         per_draw = max(S, 32)                       # enough frames for the median that sets the threshold
         for batch_i in range(8):
@@ -342,7 +433,11 @@ def main():
             a, b = seam_of(cam)
             best = sd.best_logits(a)
             if t_cal is None:
+                sd.fix_sharpen(best)
                 t_cal = SynthDetector.threshold(best, TARGET)
+            if sum(len(c) for c in cams_all) < need:
+                cams_all.append(cam)
+                counts_all.append(SynthDetector.counts(best, t_cal))
             ok = np.nonzero((SynthDetector.counts(best, t_cal) >= LO) & (SynthDetector.counts(best, t_cal) <= HI))[0]
             cams.append(cam[ok]); dseam.append(a[ok]); lseam.append(b[ok]); bests.append(best[ok])
             if sum(len(c) for c in cams) >= need:
@@ -358,7 +453,9 @@ def main():
     else:
         dpool = [det_frames(S, 1000 * rank + 10 + p) for p in range(P)]
         lpool = [lane_frames(S, 1000 * rank + 50 + p) for p in range(P)]
-        t_cal = SynthDetector.threshold(sd.best_logits(np.concatenate(dpool)), TARGET, CAP)
+        best0 = sd.best_logits(np.concatenate(dpool))
+        sd.fix_sharpen(best0)
+        t_cal = SynthDetector.threshold(best0, TARGET, CAP)
     det_path, Wd, gd = sd.finish(t_cal)
     wl = M.SynthWeights(1, gain=M.RELU_RES_GAIN)
     gl = M.build(args.lane, wsrc=wl)
@@ -399,7 +496,24 @@ def main():
     elapsed = timed_loop(stepper(pipe), args.steps, args.warmup, full_sync(pipe), barrier)
     local_elapsed = elapsed
     elapsed = SH.max_over_ranks(elapsed, dist, stat_dev)        # RCCL: clock + stats only, no data-path collective
-    per_rank = SH.gather_stats({"frames": float(args.steps * S), "seconds": local_elapsed}, ("frames", "seconds"), dist, stat_dev)
+    # ---- after the headline: the same loop REPEATS more times (box-to-box and run-to-run spread of `value`), then the step latency
+    # distribution (every step synchronised: p50 / p99 of launch-to-completion, SURVEY 8e's per-rank statistics)
+    rep_fps = []
+    for _ in range(max(0, args.repeats)):
+        t_r = timed_loop(stepper(pipe), args.steps, 1, full_sync(pipe), barrier)
+        rep_fps.append(args.steps * S / t_r)
+    lat = []
+    sync_ = full_sync(pipe)
+    one_ = stepper(pipe)
+    for i in range(max(8, args.latency_steps)):
+        t0 = time.perf_counter()
+        one_(i)
+        sync_()
+        lat.append((time.perf_counter() - t0) * 1e3)
+    lat = np.sort(np.asarray(lat[2:]))
+    p50, p99 = float(np.percentile(lat, 50)), float(np.percentile(lat, 99))
+    per_rank = SH.gather_stats({"frames": float(args.steps * S), "seconds": local_elapsed, "p50_ms": p50, "p99_ms": p99},
+                               ("frames", "seconds", "p50_ms", "p99_ms"), dist, stat_dev)
     if dist is not None:
         dist.barrier()
 
@@ -431,6 +545,7 @@ def main():
     # grouped by the kernel instantiation each conv layer resolves to; the dominant kernel = most device time.
     conv_ms, conv_flops, all_ms = 0.0, 0.0, 0.0
     by_kernel = {}
+    layer_ms = {}
     n_launches = 0
     for eng, dptr in ((pipe.det, d_det[0].ptr), (pipe.lane, d_lane[0].ptr)):
         eng.profile(dptr, S, iters=3)            # the device idled while the stats were fetched: let the clocks come back first
@@ -439,6 +554,7 @@ def main():
         for li, (name, fl, kind, ms) in enumerate(eng.profile(dptr, S, iters=10)):
             all_ms += ms
             raw_label = eng.layer_kernel(li, S)
+            layer_ms[name] = (ms, raw_label)
             label = raw_label.replace("+shortcut", "")   # same kernel with the block's projection folded in
             if not label.startswith("("):   # "(fused into ...)" / "(folded into ...)": no launch of its own
                 n_launches += 1
@@ -500,8 +616,44 @@ def main():
 
     extras = rank == 0 and world == 1 and not args.no_extras
     parity = None
+    post_hbm = unfiltered = None
     if extras:
         parity = measure_parity(pipe.det, pipe.lane, args.det, args.lane, Wd, Wl, dpool[0], lpool[0], args.precision)
+        post_hbm = measure_post_hbm(L, pipe, gd, gl, S, layer_ms, args.precision)
+    if extras and from_frames:
+        try:
+            parity["e2e"] = measure_e2e(L, make_pipe, args.det, args.lane, Wd, Wl, d_cam, h_cam, S, H, args.precision)
+        except Exception as ex:   # the leg is a measurement, not the gate (tests/test_gpu_chain.py is): report what happened
+            parity["e2e"] = {"error": repr(ex)}
+        # ---- the same step on the frames AS DRAWN (no selection by candidate count) with a 1024-candidate arena: what the selection
+        # and the 512-candidate wave-NMS limit are worth.  Frames over 1024 candidates are truncated there and counted.
+        try:
+            cams_u = np.concatenate(cams_all)[:S * P]
+            cnt_u = np.concatenate(counts_all)[:S * P]
+            d_u = [L.DeviceBuffer.from_array(np.ascontiguousarray(cams_u[p_ * S:(p_ + 1) * S])) for p_ in range(len(cams_u) // S)]
+            pu = PL.AdasPipeline(det_path, lane_path, n_streams=S, precision=args.precision, src_hw=(720, 1280), use_graph=not args.no_graph,
+                                 max_candidates=1024, overlap=not args.no_overlap)
+
+            def step_u(i):
+                pu.step_frames(d_u[(i // H) % len(d_u)].ptr, (720, 1280), 0.6)
+            t_u = timed_loop(step_u, args.steps, args.warmup, full_sync(pu), barrier)
+            n_over_u = 0
+            for k in range(len(d_u)):
+                pu.step_frames(d_u[k].ptr, (720, 1280), 0.6)
+                pu.sync()
+                n_over_u += sum(1 for s_ in range(S) if PP.YoloPost.fetch(pu.post, s_).get("overflow"))
+            unfiltered = {"value": round(args.steps * S / t_u, 2), "unit": "frames/s", "ms_per_step": round(t_u / args.steps * 1e3, 4),
+                          "candidate_capacity": 1024, "frames": int(len(d_u) * S), "frames_over_capacity_truncated": int(n_over_u),
+                          "candidates_median": int(np.median(cnt_u)), "candidates_max": int(cnt_u.max()),
+                          "candidates_p90": int(np.percentile(cnt_u, 90)),
+                          "what": "the generated frames as drawn (no selection by candidate count); block-wide NMS above 512 candidates is in "
+                                  "this timed path; a frame over 1024 candidates is truncated (counted here), so this line is context, "
+                                  "not `value`"}
+            pu.close()
+            for b in d_u:
+                b.free()
+        except Exception as ex:
+            unfiltered = {"error": repr(ex)}
 
     # ---- the same step fed from pinned HOST frames: double-buffered async H2D on a copy stream inside the timed loop
     # (demo.py:261-270 hands the path a host frame).  `value` stays the HBM-resident rate; this is the PCIe-inclusive one.
@@ -584,12 +736,20 @@ def main():
         "parity": parity,
         "modes": modes,
         "host_ingest": host_ingest,
-        "per_rank": [{"frames": r["frames"], "seconds": round(r["seconds"], 5)} for r in per_rank],
+        "repeats": ({"n": len(rep_fps), "fps_min": round(min(rep_fps), 1), "fps_median": round(float(np.median(rep_fps)), 1),
+                     "fps_max": round(max(rep_fps), 1), "what": "the --steps loop again after the headline one, same process (rank 0)"}
+                    if rep_fps else None),
+        "step_latency_ms": {"p50": round(p50, 4), "p99": round(p99, 4), "steps": int(len(lat)),
+                            "what": "one step launched and synchronised at a time (rank 0): graph launch + device time"},
+        "post_hbm": post_hbm,
+        "unfiltered": unfiltered,
+        "per_rank": [{"frames": r["frames"], "seconds": round(r["seconds"], 5), "p50_ms": round(r["p50_ms"], 4), "p99_ms": round(r["p99_ms"], 4)}
+                     for r in per_rank],
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import yolo_post
         lb = yolo_post.letterbox_params((720, 1280), (640, 640))
-        result["cpu_baseline"] = cpu_baseline(args.det, args.lane, Wd, Wl, dpool[0], lpool[0], lb)
+        result["cpu_baseline"] = cpu_baseline(args.det, args.lane, Wd, Wl, dpool[0], lpool[0], lb, cams=h_cam[0] if from_frames else None)
     else:
         result["cpu_baseline"] = None
     if rank == 0:

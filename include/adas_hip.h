@@ -45,6 +45,15 @@ int adas_synchronize(void);
 /* Page-locked host memory for frames that adas_pipeline_step_frames_host uploads asynchronously. */
 int adas_host_alloc(void** h_ptr, size_t bytes);
 int adas_host_free(void* h_ptr);
+/* A pair of timing events for measuring a stretch of work ON THE STREAM IT IS LAUNCHED ON (bench.py's roofline / post_hbm legs:
+ * no reference counterpart; the reference times with time.time() around synchronous calls, demo.py:262-281).
+ * start/stop record on `stream`; elapsed_ms waits for the stop event. */
+typedef struct adas_timer adas_timer;
+int adas_timer_create(adas_timer** out);
+int adas_timer_destroy(adas_timer* t);
+int adas_timer_start(adas_timer* t, void* stream);
+int adas_timer_stop(adas_timer* t, void* stream);
+int adas_timer_elapsed_ms(adas_timer* t, float* ms);
 
 /* ===================================================================================
  * Engine: replaces EngineBase / OnnxEngine / TensorRTEngine (coreEngine.py:7-39,120-186)
@@ -155,6 +164,10 @@ int adas_yolo_post_destroy(adas_yolo_post* h);
 int adas_yolo_post_set_input_size(adas_yolo_post* h, int in_h, int in_w);
 /* d_head: batch head tensors back to back in the reference layout, fp32, in HBM. Asynchronous. */
 int adas_yolo_post_run(adas_yolo_post* h, const float* d_head, int batch, void* stream);
+/* The same two launches `iters` times on the null stream with events between them: ms[0] = the head scan (per-anchor best class,
+ * HBM-bound: the whole head tensor is read once), ms[1] = candidate compaction + inverse letterbox + NMS + RectInfo (latency-bound),
+ * averaged per run.  Measurement only (bench.py `post_hbm`). */
+int adas_yolo_post_profile(adas_yolo_post* h, const float* d_head, int batch, int iters, float ms[2]);
 
 typedef struct {
     int32_t n_found;       /* anchors over threshold (may exceed capacity) */

@@ -27,15 +27,29 @@ def _t(W, name):
     return torch.from_numpy(np.ascontiguousarray(W[name]))
 
 
+# None | "fp16" | "bf16": storage-rounding emulation of the 16-bit engine modes on the CPU (weights and every conv output rounded
+# to the storage type, fp32 accumulate; head logits (act=None) stay fp32 like the engine's f32 head buffers).  A study / expectation
+# tool for tests and tools/ (how much of a 16-bit deviation is storage rounding): the parity reference is always EMULATE = None.
+EMULATE = None
+
+
+def _round(t):
+    if EMULATE == "fp16":
+        return t.half().float()
+    if EMULATE == "bf16":
+        return t.bfloat16().float()
+    return t
+
+
 def _conv(x, W, name, s=1, p=None, act="silu"):
-    w = _t(W, name + ".weight")
+    w = _round(_t(W, name + ".weight"))
     b = _t(W, name + ".bias")
     k = w.shape[-1]
     y = F.conv2d(x, w, b, stride=s, padding=(k // 2 if p is None else p))
     if act == "silu":
-        y = F.silu(y)
+        y = _round(F.silu(y))
     elif act == "relu":
-        y = F.relu(y)
+        y = _round(F.relu(y))
     return y
 
 

@@ -1,0 +1,174 @@
+"""End-to-end parity bookkeeping: the fused device step against the whole fp32 oracle chain, frame by frame.
+
+TEST INFRASTRUCTURE (imports oracle/): used by tests/test_gpu_chain.py and by bench.py's `parity.e2e` leg (after the timed region).
+The contract (BASELINE.json north_star): "bit-exact for NMS survivor indices / ByteTrack ID assignment" -- what the reference
+produces per frame at yoloDetector.py:126-139 (candidates: best class prob > box_score), :141-157 (fast_soft_nms survivors) and
+byteTracker.py:62-185 (track ids / states), and the lane points of ultrafastLaneDetectorV2.py:115-160.
+
+The oracle side is CACHED per distinct frame (a held frame is the same input on every step it is shown): the cache holds the
+checker's own outputs, never the device's.
+"""
+import numpy as np
+
+from oracle import nets, preprocess, yolo_post, ufld_decode, bytetrack
+
+
+class OracleChain:
+    """fp32 oracle of one ADAS pipeline: u8 BGR frame -> (detections, lanes); trackers are per stream."""
+
+    def __init__(self, det_name, Wd, lane_name, Wl, src_hw=(720, 1280), det_hw=(640, 640), lane_hw=(320, 1600), crop_ratio=0.6,
+                 box_score=0.4, nms_iou=0.45, emulate=None):
+        self.det_name, self.Wd, self.lane_name, self.Wl = det_name, Wd, lane_name, Wl
+        self.src_hw, self.det_hw, self.lane_hw, self.crop = src_hw, det_hw, lane_hw, crop_ratio
+        self.box_score, self.nms_iou = box_score, nms_iou
+        self.lb = yolo_post.letterbox_params(src_hw, det_hw)
+        self.cfg = ufld_decode.ModelConfig("culane")
+        self.trackers = {}                     # stream id -> its own BYTETracker (fresh state)
+        self.emulate = emulate          # None: the parity reference.  "fp16"/"bf16": CPU storage-rounding emulation (studies only)
+        self._det_cache, self._lane_cache = {}, {}
+
+    def _forward(self, fn, *a, **k):
+        nets.EMULATE = self.emulate
+        try:
+            return fn(*a, **k)
+        finally:
+            nets.EMULATE = None
+
+    def detections(self, frame, key=None):
+        """-> oracle.yolo_post.detect_post() dict of this frame (cached under `key`)."""
+        if key is not None and key in self._det_cache:
+            return self._det_cache[key]
+        x = preprocess.yolo_prepare_input(frame, self.det_hw)
+        if self.det_name.startswith("yolov10"):
+            head = self._forward(nets.yolov10_forward, x, self.Wd, self.det_name[len("yolov10"):])[0]
+        else:
+            head = self._forward(nets.yolov8_forward, x, self.Wd, self.det_name[-1])[0]
+        r = yolo_post.detect_post(head, self.lb, "yolov8", self.box_score, self.nms_iou)
+        if key is not None:
+            self._det_cache[key] = r
+        return r
+
+    def lanes(self, frame, key=None):
+        if self.lane_name is None:
+            return None
+        if key is not None and key in self._lane_cache:
+            return self._lane_cache[key]
+        x = preprocess.ufld_prepare_input(frame, self.lane_hw, self.crop)
+        outs = self._forward(nets.ufldv2_forward, x, self.Wl, self.lane_name.split("res")[-1])
+        r = ufld_decode.process_output(outs, self.cfg, self.src_hw[1], self.src_hw[0])
+        if key is not None:
+            self._lane_cache[key] = r
+        return r
+
+    def track(self, stream, det):
+        trk = self.trackers.setdefault(stream, bytetrack.BYTETracker())
+        return trk.update(det["xyxy_int"], det["conf"], det["class_id"])
+
+
+def survivor_anchors(det):
+    """Anchor index of every NMS survivor, in keep order (robust to the candidate list's indexing)."""
+    keep = np.asarray(det["keep"], np.int64)
+    return np.asarray(det["cand_anchor"], np.int64)[keep] if keep.size else np.zeros(0, np.int64)
+
+
+def track_ids(snap):
+    return ([(t["track_id"], t["state"], t["is_activated"], t["class_id"]) for t in snap["tracked"]],
+            [(t["track_id"], t["state"], t["class_id"]) for t in snap["lost"]], snap["count"])
+
+
+class ChainStats:
+    """Counts, over compared frames, how often the device's discrete decisions equal the oracle's."""
+
+    FIELDS = ("frames", "identical_candidate_sets", "identical_keep_indices", "identical_survivors", "identical_track_ids",
+              "lanes_identical_status", "lanes_within_1px")
+
+    def __init__(self):
+        self.n = dict.fromkeys(self.FIELDS, 0)
+        self.n_cand = self.n_cand_sym_diff = self.n_surv = self.n_surv_sym_diff = 0
+        self.max_conf_diff = self.max_box_diff = 0.0
+        self.max_lane_px = 0
+        self.first_track_divergence = None
+        self.mismatch_log = []
+
+    def add_detections(self, got, want, ctx=None):
+        self.n["frames"] += 1
+        ga, wa = np.asarray(got["cand_anchor"], np.int64), np.asarray(want["cand_anchor"], np.int64)
+        same_c = ga.shape == wa.shape and np.array_equal(ga, wa) and np.array_equal(got["cand_cls"], want["cand_cls"])
+        self.n["identical_candidate_sets"] += int(same_c)
+        self.n_cand += len(wa)
+        self.n_cand_sym_diff += len(np.setxor1d(ga, wa))
+        same_k = np.array_equal(np.asarray(got["keep"], np.int64), np.asarray(want["keep"], np.int64))
+        self.n["identical_keep_indices"] += int(same_c and same_k)
+        gs, ws = survivor_anchors(got), survivor_anchors(want)
+        same_s = gs.shape == ws.shape and np.array_equal(gs, ws) and np.array_equal(got["class_id"], want["class_id"])
+        self.n["identical_survivors"] += int(same_s)
+        self.n_surv += len(ws)
+        self.n_surv_sym_diff += len(np.setxor1d(gs, ws))
+        if same_s and len(ws):
+            self.max_conf_diff = max(self.max_conf_diff, float(np.abs(np.asarray(got["conf"]) - want["conf"]).max()))
+            self.max_box_diff = max(self.max_box_diff, float(np.abs(np.asarray(got["xywh"]) - want["xywh"]).max()))
+        if not same_s and len(self.mismatch_log) < 8:
+            self.mismatch_log.append({"ctx": ctx, "only_device": np.setdiff1d(gs, ws).tolist()[:6], "only_oracle": np.setdiff1d(ws, gs).tolist()[:6]})
+        return same_c, same_s
+
+    def add_tracks(self, got_snap, want_snap, ctx=None):
+        same = track_ids(got_snap) == track_ids(want_snap)
+        self.n["identical_track_ids"] += int(same)
+        if not same and self.first_track_divergence is None:
+            self.first_track_divergence = ctx
+        return same
+
+    def add_lanes(self, got, want):
+        (gl, gs), (wl, ws) = got, want
+        same_status = [bool(s) for s in gs] == [bool(s) for s in ws]
+        self.n["lanes_identical_status"] += int(same_status)
+        ok = same_status
+        if ok:
+            for a, b in zip(gl, wl):
+                a = np.asarray(a, np.int64).reshape(-1, 2); b = np.asarray(b, np.int64).reshape(-1, 2)
+                if a.shape != b.shape:
+                    ok = False
+                    break
+                d = int(np.abs(a - b).max(initial=0))
+                self.max_lane_px = max(self.max_lane_px, d)
+                ok = ok and d <= 1
+        self.n["lanes_within_1px"] += int(ok)
+        return ok
+
+    def summary(self):
+        f = max(1, self.n["frames"])
+        out = dict(self.n)
+        out.update({
+            "frac_identical_candidate_sets": round(self.n["identical_candidate_sets"] / f, 4),
+            "frac_identical_survivors": round(self.n["identical_survivors"] / f, 4),
+            "frac_identical_track_ids": round(self.n["identical_track_ids"] / f, 4),
+            "candidates_compared": self.n_cand, "candidate_anchors_differing": self.n_cand_sym_diff,
+            "survivors_compared": self.n_surv, "survivor_anchors_differing": self.n_surv_sym_diff,
+            "max_conf_diff_on_identical_frames": float("%.3e" % self.max_conf_diff),
+            "max_box_diff_px_on_identical_frames": float("%.3e" % self.max_box_diff),
+            "max_lane_point_diff_px": self.max_lane_px, "first_track_divergence": self.first_track_divergence,
+        })
+        return out
+
+
+def run_device_chain(pipe, fetch_post, fetch_tracks, d_frame_sets, h_frame_sets, chain, steps, hold, streams, src_hw=(720, 1280), crop=0.6,
+                     lanes=True):
+    """Drive `pipe` (an AdasPipeline with FRESH tracker state) for `steps` steps over the frame sets (each held `hold` steps) and
+    compare streams `streams` with the oracle chain after every step.  fetch_post(s) -> detections dict, fetch_tracks(s) ->
+    snapshot dict (tests/gpu_api.track_snapshot form)."""
+    st = ChainStats()
+    for k in range(steps):
+        i = (k // hold) % len(d_frame_sets)
+        pipe.step_frames(d_frame_sets[i].ptr, src_hw, crop)
+        pipe.sync()
+        for s in streams:
+            frame = h_frame_sets[i][s]
+            want = chain.detections(frame, key=(i, s))
+            got = fetch_post(s)
+            if got.get("overflow"):
+                raise RuntimeError("stream %d step %d: candidate arena overflow in the parity leg" % (s, k))
+            st.add_detections(got, want, ctx=[k, s])
+            st.add_tracks(fetch_tracks(s), chain.track(s, want), ctx=[k, s])
+            if lanes and pipe.decode is not None:
+                st.add_lanes(pipe.decode.fetch(s), chain.lanes(frame, key=(i, s)))
+    return st

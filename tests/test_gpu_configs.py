@@ -8,8 +8,9 @@
 The lane-network oracle is pinned to the reference's own parsingNet modules (tests/test_oracle_golden.py, ufld_net.npz).
 Tolerances (BASELINE.json north_star: "within 1e-3 on conv activations"):
   fp32 mode   max|diff| <= 1e-3 on every tapped activation and output (relative to the tensor's range where it exceeds 1)
-  fp16 mode   the precision the reference ships (demo.py:18-29): rel-L2 bounds below, measured values printed
-  bf16 mode   rel-L2 <= 6e-2 (8 significant bits)
+  fp16 mode   the precision the reference ships (demo.py:18-29): rel-L2 <= 3e-3 on activations and outputs; calibrated detector
+              heads: max-abs <= 8e-3 on class probabilities, <= 0.1 px on boxes (measured values printed)
+  bf16 mode   rel-L2 <= 3e-2 (8 significant bits)
 """
 import importlib
 
@@ -29,12 +30,21 @@ PP = importlib.import_module("adas_amd.postproc")
 PL = importlib.import_module("adas_amd.pipeline")
 M = importlib.import_module("adas_amd.models")
 
-# Whole-network rel-L2 bounds of the 16-bit modes.  One fp16 layer leaves ~6e-4 (tools/layer_drift.py: model.1 6.1e-4 vs bf16
-# 5.0e-3, the 8x of three more mantissa bits); what is bounded here is that error after the network's own amplification: the seeded
-# random-weight nets grow a perturbation ~1.1x per layer (YOLOv8n: 6e-4 -> 1.6e-2 over 33 convs on these frames; the ResNet lane
-# nets stay at 9e-4), a property of the synthetic weights, not of the kernels.
-REL_TOL = {"fp16": 8e-3, "bf16": 6e-2}
-REL_TOL_V8N = {"fp16": 2.5e-2, "bf16": 6e-2}
+# Whole-network bounds of the 16-bit modes.  One fp16 layer leaves ~6e-4 rel-L2 (tools/layer_drift.py; bf16 5e-3: three mantissa
+# bits fewer); the seeded synthetic nets are built just below their critical gain (models.py SILU_GAIN), so that error keeps its
+# relative size through the depth instead of growing ~1.1x per layer (round 2).  Bounds: rel-L2 on tapped activations and outputs,
+# and -- for the detectors, on a CALIBRATED head (bench.build_detector: ~100 anchors over box_score, scores spread to ~0.9, i.e.
+# probabilities where the sigmoid is steepest) -- max-abs on class probabilities and on boxes in input pixels.
+REL_TOL = {"fp16": 3e-3, "bf16": 3e-2}
+CLS_TOL = {"fp16": 8e-3, "bf16": 8e-2}      # max |prob - prob_oracle| over all (class, anchor) of the calibrated head
+BOX_TOL = {"fp16": 0.1, "bf16": 1.0}        # max |xywh - xywh_oracle| in input pixels (DFL expectation x stride)
+
+
+def calibrated(tmp_path, name, x, tag):
+    """(path, weights) of `name` with its class branch calibrated on frames x (see bench.SynthDetector)."""
+    import bench
+    path, W, g = bench.build_detector(M, CE, name, x, str(tmp_path), tag, target_per_frame=100.0)
+    return path, W
 
 
 def rel_l2(a, b):
@@ -100,19 +110,21 @@ def test_ufldv2_culane_at_the_bench_batch_vs_oracle(prec):
     e.close()
 
 
-@pytest.mark.parametrize("scale,prec", [("s", "fp32"), ("s", "fp16"), ("l", "fp32"), ("l", "fp16")])
-def test_yolov8_s_and_l_640_vs_oracle(scale, prec):
-    """BASELINE configs C4 / C5: YOLOv8s and YOLOv8l at 640x640 (head layout yoloDetector.py:110-133)."""
-    path, W, g = netutil.model("yolov8" + scale)
-    x = netutil.coco_like_frames(1, seed=11)
+@pytest.mark.parametrize("scale,prec", [("s", "fp32"), ("s", "fp16"), ("l", "fp32"), ("l", "fp16"), ("n", "fp16"), ("n", "bf16")])
+def test_yolov8_640_vs_oracle(tmp_path, scale, prec):
+    """BASELINE configs C2 / C4 / C5: YOLOv8n / s / l at 640x640 (head layout yoloDetector.py:110-133), calibrated class branch."""
+    x = netutil.coco_like_frames(2, seed=11)
+    path, W = calibrated(tmp_path, "yolov8" + scale, x, "cfg_%s_%s" % (scale, prec))
     taps = {}
     want = nets.yolov8_forward(x, W, scale, taps=taps)
-    e = CE.HipEngine(path, precision=prec, max_batch=1)
+    e = CE.HipEngine(path, precision=prec, max_batch=2)
     got = e.engine_inference(x)[0]
-    assert got.shape == want.shape == (1, 84, 8400)
+    assert got.shape == want.shape == (2, 84, 8400)
+    n_over = int((want[:, 4:].max(axis=1) > 0.4).sum())
+    assert n_over >= 50, n_over             # the calibrated head really has scores around the decision threshold
     tag = "yolov8%s %s " % (scale, prec)
     for lname, key in (("model.15.cv2.conv", "p3"), ("model.18.cv2.conv", "p4"), ("model.21.cv2.conv", "p5")):
-        a = e.fetch_activation(lname, 1)
+        a = e.fetch_activation(lname, 2)
         ref = taps[key].numpy()
         err, rel = report(tag + key, a, ref)
         if prec == "fp32":
@@ -120,11 +132,14 @@ def test_yolov8_s_and_l_640_vs_oracle(scale, prec):
         else:
             assert rel <= REL_TOL[prec], lname
     errh, relh = report(tag + "head", got, want)
+    ecls = float(np.abs(got[:, 4:] - want[:, 4:]).max())
+    ebox = float(np.abs(got[:, :4] - want[:, :4]).max())
+    print("%s max|prob diff| %.3e  max|box diff| %.3e px  (%d anchors over 0.4)" % (tag, ecls, ebox, n_over))
     if prec == "fp32":
-        assert relh <= 1e-4
-        assert np.abs(got[:, :4] - want[:, :4]).max() <= 1e-3 * max(1.0, float(np.abs(want[:, :4]).max()))
+        assert relh <= 1e-4 and ecls <= 1e-3
+        assert ebox <= 1e-3 * max(1.0, float(np.abs(want[:, :4]).max()))
     else:
-        assert relh <= REL_TOL[prec]
+        assert ecls <= CLS_TOL[prec] and ebox <= BOX_TOL[prec]
     e.close()
 
 
@@ -142,7 +157,7 @@ def test_yolov8s_at_a_batch_that_selects_the_persistent_kernels():
     assert any("conv_h8_kernel" in k for k in kernels), kernels
     got = e.engine_inference(x)[0]
     err, rel = report("yolov8s batch 48 fp16 head", got[:2], want)
-    assert rel <= REL_TOL["fp16"]
+    assert rel <= REL_TOL["fp16"] and np.abs(got[:2, :4] - want[:, :4]).max() <= BOX_TOL["fp16"]
     for k in range(2, 48):
         assert np.array_equal(got[k], got[k % 2]), k
     e.close()
@@ -163,19 +178,10 @@ def test_yolov8n_non_square_input_vs_oracle():
     e.close()
 
 
-@pytest.mark.parametrize("prec,tol", [("fp16", 3e-3), ("bf16", 6e-2)])
-def test_yolov8n_and_ufld_small_16bit_modes(prec, tol):
-    """The two 16-bit precisions through the same kernels (elem16.h): whole-network rel-L2 against the fp32 oracle."""
-    path, W, g = netutil.model("yolov8n")
-    x = netutil.coco_like_frames(2)
-    taps = {}
-    want = nets.yolov8_forward(x, W, "n", taps=taps)
-    e = CE.HipEngine(path, precision=prec, max_batch=2)
-    got = e.engine_inference(x)[0]
-    _, rp3 = report("yolov8n %s p3" % prec, e.fetch_activation("model.15.cv2.conv", 2), taps["p3"].numpy())
-    _, rh = report("yolov8n %s head" % prec, got, want)
-    assert rp3 <= REL_TOL_V8N[prec] and rh <= REL_TOL_V8N[prec]
-    e.close()
+@pytest.mark.parametrize("prec", ["fp16", "bf16"])
+def test_ufld_small_16bit_modes(prec):
+    """The two 16-bit precisions through the same kernels (elem16.h): whole-network rel-L2 against the fp32 oracle (lane net at a
+    reduced geometry; the detectors' 16-bit bounds are in test_yolov8_640_vs_oracle)."""
     kw = dict(in_h=160, in_w=800, num_grid_row=100, num_cls_row=36, num_grid_col=50, num_cls_col=41)
     lpath, LW, lg = netutil.model("ufldv2_res18", **kw)
     lx = netutil.lane_frames(2, 160, 800)
@@ -183,7 +189,7 @@ def test_yolov8n_and_ufld_small_16bit_modes(prec, tol):
     le = CE.HipEngine(lpath, precision=prec, max_batch=2)
     for o, w, nm in zip(le.engine_inference(lx), lwant, ("loc_row", "loc_col", "exist_row", "exist_col")):
         _, r = report("ufldv2-small %s %s" % (prec, nm), o, w)
-        assert r <= tol
+        assert r <= REL_TOL[prec]
     le.close()
 
 

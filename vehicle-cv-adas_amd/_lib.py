@@ -91,6 +91,11 @@ _SIGS = {
     "adas_synchronize": (C.c_int, []),
     "adas_host_alloc": (C.c_int, [C.POINTER(_P), C.c_size_t]),
     "adas_host_free": (C.c_int, [_P]),
+    "adas_timer_create": (C.c_int, [C.POINTER(_P)]),
+    "adas_timer_destroy": (C.c_int, [_P]),
+    "adas_timer_start": (C.c_int, [_P, _P]),
+    "adas_timer_stop": (C.c_int, [_P, _P]),
+    "adas_timer_elapsed_ms": (C.c_int, [_P, C.POINTER(C.c_float)]),
     "adas_engine_create": (C.c_int, [C.c_char_p, C.c_int, C.c_int, C.POINTER(_P)]),
     "adas_engine_destroy": (C.c_int, [_P]),
     "adas_engine_input_shape": (C.c_int, [_P, C.POINTER(C.c_int64)]),
@@ -120,6 +125,7 @@ _SIGS = {
     "adas_yolo_post_destroy": (C.c_int, [_P]),
     "adas_yolo_post_set_input_size": (C.c_int, [_P, C.c_int, C.c_int]),
     "adas_yolo_post_run": (C.c_int, [_P, _P, C.c_int, _P]),
+    "adas_yolo_post_profile": (C.c_int, [_P, _P, C.c_int, C.c_int, C.POINTER(C.c_float)]),
     "adas_yolo_post_fetch": (C.c_int, [_P, C.c_int, C.POINTER(YoloCounts)] + [_P] * 9),
     "adas_yolo_post_device_views": (C.c_int, [_P] + [C.POINTER(_P)] * 4),
     "adas_yolo_post_capacity": (C.c_int, [_P, C.POINTER(C.c_int)]),
@@ -230,6 +236,37 @@ class DeviceBuffer:
             self.free()
         except Exception:
             pass
+
+
+class StreamTimer:
+    """hipEvents around work launched on `stream` (adas_timer_*): `with StreamTimer() as t: ...launches...; t.ms`."""
+
+    def __init__(self, stream=None):
+        self.stream = stream
+        h = C.c_void_p()
+        check(lib().adas_timer_create(C.byref(h)))
+        self.h = h.value
+
+    def __enter__(self):
+        check(lib().adas_timer_start(self.h, self.stream))
+        return self
+
+    def __exit__(self, *exc):
+        check(lib().adas_timer_stop(self.h, self.stream))
+        return False
+
+    @property
+    def ms(self):
+        v = C.c_float()
+        check(lib().adas_timer_elapsed_ms(self.h, C.byref(v)))
+        return float(v.value)
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().adas_timer_destroy(self.h)
+            self.h = None
+
+    __del__ = close
 
 
 class PinnedBuffer:

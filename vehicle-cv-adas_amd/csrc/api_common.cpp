@@ -70,3 +70,43 @@ int adas_synchronize(void) {
     return ADAS_OK;
 }
 }
+
+struct adas_timer {
+    hipEvent_t a = nullptr, b = nullptr;
+};
+extern "C" {
+int adas_timer_create(adas_timer** out) {
+    ADAS_REQUIRE(out, ADAS_ERR_INVALID, "adas_timer_create: null out pointer");
+    ADAS_REQUIRE(adas_device_count() > 0, ADAS_ERR_NO_DEVICE, "no HIP device visible; this library has no CPU fallback");
+    adas_timer* t = new adas_timer();
+    if (hipEventCreate(&t->a) != hipSuccess || hipEventCreate(&t->b) != hipSuccess) {
+        adas_timer_destroy(t);
+        return adas::hip_fail(hipGetLastError(), "hipEventCreate", __FILE__, __LINE__);
+    }
+    *out = t;
+    return ADAS_OK;
+}
+int adas_timer_destroy(adas_timer* t) {
+    if (!t) return ADAS_OK;
+    if (t->a) (void)hipEventDestroy(t->a);
+    if (t->b) (void)hipEventDestroy(t->b);
+    delete t;
+    return ADAS_OK;
+}
+int adas_timer_start(adas_timer* t, void* stream) {
+    ADAS_REQUIRE(t, ADAS_ERR_INVALID, "null timer");
+    ADAS_HIP_TRY(hipEventRecord(t->a, (hipStream_t)stream));
+    return ADAS_OK;
+}
+int adas_timer_stop(adas_timer* t, void* stream) {
+    ADAS_REQUIRE(t, ADAS_ERR_INVALID, "null timer");
+    ADAS_HIP_TRY(hipEventRecord(t->b, (hipStream_t)stream));
+    return ADAS_OK;
+}
+int adas_timer_elapsed_ms(adas_timer* t, float* ms) {
+    ADAS_REQUIRE(t && ms, ADAS_ERR_INVALID, "null argument");
+    ADAS_HIP_TRY(hipEventSynchronize(t->b));
+    ADAS_HIP_TRY(hipEventElapsedTime(ms, t->a, t->b));
+    return ADAS_OK;
+}
+}

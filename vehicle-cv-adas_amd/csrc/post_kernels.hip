@@ -473,6 +473,38 @@ int adas_yolo_post_run(adas_yolo_post* h, const float* d_head, int batch, void* 
     return ADAS_OK;
 }
 
+int adas_yolo_post_profile(adas_yolo_post* h, const float* d_head, int batch, int iters, float ms[2]) {
+    ADAS_REQUIRE(h && d_head && ms && batch > 0 && batch <= h->max_batch && iters > 0, ADAS_ERR_INVALID, "adas_yolo_post_profile: bad argument");
+    ADAS_REQUIRE(h->p.layout != ADAS_HEAD_V5_LITE || h->dev.cfg.in_h > 0, ADAS_ERR_INVALID, "v5-lite head: call adas_yolo_post_set_input_size first");
+    hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
+    for (auto& e : ev) ADAS_HIP_TRY(hipEventCreate(&e));
+    YoloPostDev d = h->dev;
+    d.head = d_head;
+    h->last = 0;
+    const int A = h->p.num_anchors, nc = h->p.num_classes;
+    const size_t lds = YoloLds::bytes(h->p.max_candidates, 256);
+    ms[0] = ms[1] = 0.f;
+    int rc = ADAS_OK;
+    for (int it = 0; it < iters && rc == ADAS_OK; ++it) {
+        (void)hipEventRecord(ev[0], 0);
+        if (h->p.layout == ADAS_HEAD_V8) hipLaunchKernelGGL(yolo_scan_v8, dim3(((A + 3) / 4 + 63) / 64, batch), dim3(256), 0, 0, d_head, A, nc, d.best_conf, d.best_cls);
+        else hipLaunchKernelGGL(yolo_scan_v5, dim3(512, batch), dim3(256), 0, 0, d_head, A, nc, d.best_conf, d.best_cls);
+        (void)hipEventRecord(ev[1], 0);
+        hipLaunchKernelGGL(yolo_post_kernel, dim3(batch), dim3(256), lds, 0, d);
+        (void)hipEventRecord(ev[2], 0);
+        hipError_t e = hipEventSynchronize(ev[2]);
+        if (e == hipSuccess) e = hipGetLastError();
+        float a = 0.f, b = 0.f;
+        if (e == hipSuccess) e = hipEventElapsedTime(&a, ev[0], ev[1]);
+        if (e == hipSuccess) e = hipEventElapsedTime(&b, ev[1], ev[2]);
+        if (e != hipSuccess) rc = hip_fail(e, "adas_yolo_post_profile", __FILE__, __LINE__);
+        ms[0] += a / (float)iters;
+        ms[1] += b / (float)iters;
+    }
+    for (auto& e : ev) (void)hipEventDestroy(e);
+    return rc;
+}
+
 int adas_yolo_post_fetch(adas_yolo_post* h, int frame, adas_yolo_counts* counts, int32_t* cand_anchor, double* cand_xywh,
                          double* cand_conf, int32_t* cand_cls, int32_t* keep, double* det_xywh, double* det_conf,
                          int32_t* det_cls, int32_t* det_xyxy_int) {
