@@ -242,7 +242,7 @@ def cpu_baseline(det_name, lane_name, Wd, Wl, dframes, lframes, lb, budget_s=20.
                        + f"batch 1, torch-CPU fp32 nets + NumPy post-proc/ByteTrack (oracle/), {dt:.1f} s")
 
 
-def measure_e2e(L, make_pipe, det_name, lane_name, Wd, Wl, d_cam, h_cam, S, hold, precision, n_streams_cmp=8):
+def measure_e2e(L, make_pipe, det_name, lane_name, Wd, Wl, d_cam, h_cam, S, hold, precision, n_streams_cmp=8, micro_batch=1):
     """End-to-end parity of the TIMED mode: a fresh pipeline (fresh trackers) replays the timed frame sets -- set 0, set 1, set 0
     again, each held `hold` steps -- and after every step the first `n_streams_cmp` streams are compared with the fp32 oracle chain
     (oracle.preprocess -> nets -> yolo_post -> bytetrack, ufld_decode): candidate anchor sets, NMS survivors, track ids and states,
@@ -257,7 +257,8 @@ def measure_e2e(L, make_pipe, det_name, lane_name, Wd, Wl, d_cam, h_cam, S, hold
     steps = len(sets) * hold
     t0 = time.perf_counter()
     st = CP.run_device_chain(pp, lambda s: PP.YoloPost.fetch(pp.post, s), lambda s: gpu_api.track_snapshot(*pp.tracker.fetch(s)),
-                             [d_cam[i] for i in sets], [h_cam[i] for i in sets], chain, steps, hold, streams)
+                             [d_cam[i] for i in sets], [h_cam[i] for i in sets], chain, steps, hold, streams, micro_batch=micro_batch,
+                             n_streams=S)
     pp.close()
     out = st.summary()
     out.update({"mode": precision, "streams_compared": len(streams), "steps": steps, "frame_hold": hold,
@@ -311,8 +312,11 @@ def measure_post_hbm(L, pipe, gd, gl, S, layer_ms, precision):
 
 PRESETS = {   # BASELINE.json configs
     "north-star": dict(det="yolov8n", lane="ufldv2_res18", streams=64),   # configs[1] + configs[2] + NMS + ByteTrack (the metric's combo)
-    "c4": dict(det="yolov8s", lane="ufldv2_res18", streams=16),           # configs[3]: YOLOv8s + UFLDv2 + ByteTrack, 1280x720 stream
-    "c5": dict(det="yolov8l", lane="ufldv2_res18", streams=1),            # configs[4]: one 1280x720 stream per GPU, YOLOv8l
+    # configs[3]: YOLOv8s + UFLDv2 + ByteTrack on 1280x720 streams; configs[4]: one 1280x720 stream per GPU, YOLOv8l.  Few streams per
+    # GPU cannot fill 256 CUs one frame at a time: these presets run temporal micro-batches; `--micro-batch 1` is
+    # the frame-at-a-time latency mode, reported beside the throughput line as `frame_at_a_time`.
+    "c4": dict(det="yolov8s", lane="ufldv2_res18", streams=16, micro_batch=4),
+    "c5": dict(det="yolov8l", lane="ufldv2_res18", streams=1, micro_batch=16),
 }
 
 
@@ -350,7 +354,9 @@ def main():
     ap.add_argument("--steps", type=int, default=40)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--preset", default="north-star", choices=sorted(PRESETS))
-    ap.add_argument("--streams", type=int, default=None, help="independent video streams (frames per step) per GPU")
+    ap.add_argument("--streams", type=int, default=None, help="independent video streams per GPU")
+    ap.add_argument("--micro-batch", type=int, default=None, help="consecutive frames of every stream per step (temporal micro-batching; "
+                    "1 = the reference's frame-at-a-time calling pattern)")
     ap.add_argument("--det", default=None)
     ap.add_argument("--lane", default=None)
     ap.add_argument("--precision", default="fp16", choices=["fp16", "bf16", "fp32"])
@@ -372,6 +378,7 @@ def main():
     args.det = args.det or pre["det"]
     args.lane = args.lane or pre["lane"]
     args.streams = args.streams or pre["streams"]
+    args.micro_batch = args.micro_batch or pre.get("micro_batch", 1)
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         raise SystemExit(relaunch_multi_gpu(args))
@@ -398,7 +405,8 @@ def main():
     L.check(L.lib().adas_set_device(local_rank))
     import ctypes as C
 
-    S, P = args.streams, args.pool
+    NSTREAMS, B = args.streams, max(1, args.micro_batch)   # independent streams; consecutive frames of each per step (temporal micro-batch)
+    S, P = NSTREAMS * B, args.pool                         # S = frames per step on this GPU (frame b of stream s at index b * NSTREAMS + s)
     CAP = 512                                   # candidates per frame the post-processor holds (wave-NMS limit)
     workdir = os.environ.get("ADAS_MODEL_DIR") or tempfile.mkdtemp(prefix=f"adas_bench_r{rank}_")
     from_frames = not args.from_seam
@@ -464,8 +472,8 @@ def main():
     t_build = time.time() - t_build
 
     def make_pipe(precision):
-        return PL.AdasPipeline(det_path, lane_path, n_streams=S, precision=precision, src_hw=(720, 1280),
-                               use_graph=not args.no_graph, max_candidates=CAP, overlap=not args.no_overlap)
+        return PL.AdasPipeline(det_path, lane_path, n_streams=NSTREAMS, precision=precision, src_hw=(720, 1280),
+                               use_graph=not args.no_graph, max_candidates=CAP, overlap=not args.no_overlap, micro_batch=B)
 
     pipe = make_pipe(args.precision)
     d_det = [L.DeviceBuffer.from_array(a) for a in dpool]
@@ -537,7 +545,7 @@ def main():
     n_cand = [len(d["cand_conf"]) for d in dets]
     n_keep = float(np.mean([len(d["keep"]) for d in dets]))
     n_hi = float(np.mean([int((d["conf"] >= 0.6).sum()) for d in dets]))
-    hdrs = [pipe.tracker.fetch(s)[0] for s in range(min(S, 8))]
+    hdrs = [pipe.tracker.fetch(s)[0] for s in range(min(NSTREAMS, 8))]
     n_trk = float(np.mean([h.n_tracked for h in hdrs]))
     n_lost = float(np.mean([h.n_lost for h in hdrs]))
 
@@ -601,7 +609,7 @@ def main():
     # second eager pass with section events for a per-stage breakdown
     stage = None
     try:
-        d = L.PipelineDesc(pipe.det.handle, pipe.lane.handle, pipe.post.h, pipe.decode.h, pipe.tracker.h, S, 0)
+        d = L.PipelineDesc(pipe.det.handle, pipe.lane.handle, pipe.post.h, pipe.decode.h, pipe.tracker.h, NSTREAMS, 0, None, B if B > 1 else 0, 0)
         h = C.c_void_p()
         L.check(L.lib().adas_pipeline_create(C.byref(d), C.byref(h)))
         for _ in range(2):
@@ -622,7 +630,7 @@ def main():
         post_hbm = measure_post_hbm(L, pipe, gd, gl, S, layer_ms, args.precision)
     if extras and from_frames:
         try:
-            parity["e2e"] = measure_e2e(L, make_pipe, args.det, args.lane, Wd, Wl, d_cam, h_cam, S, H, args.precision)
+            parity["e2e"] = measure_e2e(L, make_pipe, args.det, args.lane, Wd, Wl, d_cam, h_cam, NSTREAMS, H, args.precision, micro_batch=B)
         except Exception as ex:   # the leg is a measurement, not the gate (tests/test_gpu_chain.py is): report what happened
             parity["e2e"] = {"error": repr(ex)}
         # ---- the same step on the frames AS DRAWN (no selection by candidate count) with a 1024-candidate arena: what the selection
@@ -631,8 +639,8 @@ def main():
             cams_u = np.concatenate(cams_all)[:S * P]
             cnt_u = np.concatenate(counts_all)[:S * P]
             d_u = [L.DeviceBuffer.from_array(np.ascontiguousarray(cams_u[p_ * S:(p_ + 1) * S])) for p_ in range(len(cams_u) // S)]
-            pu = PL.AdasPipeline(det_path, lane_path, n_streams=S, precision=args.precision, src_hw=(720, 1280), use_graph=not args.no_graph,
-                                 max_candidates=1024, overlap=not args.no_overlap)
+            pu = PL.AdasPipeline(det_path, lane_path, n_streams=NSTREAMS, precision=args.precision, src_hw=(720, 1280), use_graph=not args.no_graph,
+                                 max_candidates=1024, overlap=not args.no_overlap, micro_batch=B)
 
             def step_u(i):
                 pu.step_frames(d_u[(i // H) % len(d_u)].ptr, (720, 1280), 0.6)
@@ -674,6 +682,22 @@ def main():
         for b in pinned:
             b.free()
 
+    # ---- presets that micro-batch: the same streams one frame at a time (the reference's calling pattern, latency mode)
+    frame_at_a_time = None
+    if extras and from_frames and B > 1:
+        try:
+            p1 = PL.AdasPipeline(det_path, lane_path, n_streams=NSTREAMS, precision=args.precision, src_hw=(720, 1280),
+                                 use_graph=not args.no_graph, max_candidates=CAP, overlap=not args.no_overlap)
+
+            def step1(i):
+                p1.step_frames(d_cam[(i // H) % P].ptr, (720, 1280), 0.6)     # the first NSTREAMS frames of the set: frame 0 of each stream
+            t1 = timed_loop(step1, args.steps, args.warmup, full_sync(p1), barrier)
+            frame_at_a_time = {"value": round(args.steps * NSTREAMS / t1, 2), "unit": "frames/s", "ms_per_step": round(t1 / args.steps * 1e3, 4),
+                               "frames_per_step": NSTREAMS, "what": "micro_batch = 1: one frame of each stream per step (per-frame latency mode)"}
+            p1.close()
+        except Exception as ex:
+            frame_at_a_time = {"error": repr(ex)}
+
     frames = args.steps * S * world
     fps = frames / elapsed
     flops_frame = pipe.flops_per_frame()
@@ -707,8 +731,10 @@ def main():
         "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
         "config": {"workload": f"{args.det} 640x640 + {args.lane} (CULane) 1600x320 + decode/NMS + ByteTrack, "
-                               f"{S} independent 1280x720-source streams per GPU (one frame of each per step)",
-                   "preset": args.preset, "streams_per_gpu": S, "frames_per_step": S * world, "gflop_per_frame": round(flops_frame / 1e9, 2),
+                               f"{NSTREAMS} independent 1280x720-source streams per GPU ("
+                               + ("one frame of each per step)" if B == 1 else f"{B} consecutive frames of each per step: temporal micro-batching, "
+                                  "nets on all frames at once, tracker consumes them in order)"),
+                   "preset": args.preset, "streams_per_gpu": NSTREAMS, "micro_batch": B, "frames_per_step": S * world, "gflop_per_frame": round(flops_frame / 1e9, 2),
                    "hip_graph": not args.no_graph, "candidates_per_frame": round(float(np.mean(n_cand)), 1), "candidates_median": int(np.median(n_cand)),
                    "candidates_max_over_timed_frames": max_found, "candidate_capacity": CAP, "frames_at_candidate_capacity": n_over,
                    "detections_per_frame": round(n_keep, 1), "detections_over_0.6": round(n_hi, 1),
@@ -742,6 +768,7 @@ def main():
         "step_latency_ms": {"p50": round(p50, 4), "p99": round(p99, 4), "steps": int(len(lat)),
                             "what": "one step launched and synchronised at a time (rank 0): graph launch + device time"},
         "post_hbm": post_hbm,
+        "frame_at_a_time": frame_at_a_time,
         "unfiltered": unfiltered,
         "per_rank": [{"frames": r["frames"], "seconds": round(r["seconds"], 5), "p50_ms": round(r["p50_ms"], 4), "p99_ms": round(r["p99_ms"], 4)}
                      for r in per_rank],

@@ -364,10 +364,18 @@ typedef struct {
     int32_t use_graph;          /* bit0: capture the step in a hipGraph (the lane branch is then forked onto a second
                                  * stream so the two nets overlap); bit1: keep both nets on one stream */
     adas_lane_geometry* geometry; /* may be NULL; with lane: area polygon / bird view / curvature right behind the decode */
+    int32_t micro_batch;        /* 0 / 1: one frame of every stream per step.  B > 1: temporal micro-batching -- a step takes B
+                                 * CONSECUTIVE frames of every stream (frame b of stream s at index b * n_streams + s of the input),
+                                 * the pre-processing / networks / decode / NMS run on all n_streams * B frames at once (no
+                                 * cross-frame dependency there) and the tracker then consumes each stream's B frames in order
+                                 * (B update launches).  Engines, post and decode handles need max_batch >= n_streams * B; results of
+                                 * frame b of stream s are fetched at frame index b * n_streams + s, tracker state per stream.
+                                 * Throughput mode for few streams per GPU (adds B - 1 frames of latency). */
+    int32_t reserved;
 } adas_pipeline_desc;
 int adas_pipeline_create(const adas_pipeline_desc* d, adas_pipeline** out);
 int adas_pipeline_destroy(adas_pipeline* p);
-/* One step = one frame of every stream.  Asynchronous; adas_pipeline_sync() waits for it. */
+/* One step = one frame of every stream (micro_batch frames with temporal micro-batching).  Asynchronous; adas_pipeline_sync() waits. */
 int adas_pipeline_step(adas_pipeline* p, const float* d_det_input_nchw, const float* d_lane_input_nchw);
 /* The same step from camera frames: n_streams BGR u8 frames (src_h x src_w x 3, back to back) in HBM; each branch runs its
  * pre-processing (adas_preprocess_yolo / adas_preprocess_ufld with lane_crop_ratio = ModelConfig.crop_ratio) into seam

@@ -79,12 +79,14 @@ def track_ids(snap):
 class ChainStats:
     """Counts, over compared frames, how often the device's discrete decisions equal the oracle's."""
 
-    FIELDS = ("frames", "identical_candidate_sets", "identical_keep_indices", "identical_survivors", "identical_track_ids",
-              "lanes_identical_status", "lanes_within_1px")
+    FIELDS = ("frames", "identical_candidate_sets", "identical_keep_indices", "identical_survivor_sets", "identical_survivors",
+              "identical_track_ids", "lanes_identical_status", "lanes_within_1px")
 
     def __init__(self):
         self.n = dict.fromkeys(self.FIELDS, 0)
         self.n_cand = self.n_cand_sym_diff = self.n_surv = self.n_surv_sym_diff = 0
+        self.n_lane_pts = self.n_lane_pts_off = 0
+        self.n_track_checks = 0
         self.max_conf_diff = self.max_box_diff = 0.0
         self.max_lane_px = 0
         self.first_track_divergence = None
@@ -100,6 +102,13 @@ class ChainStats:
         same_k = np.array_equal(np.asarray(got["keep"], np.int64), np.asarray(want["keep"], np.int64))
         self.n["identical_keep_indices"] += int(same_c and same_k)
         gs, ws = survivor_anchors(got), survivor_anchors(want)
+        # the same survivors with the same classes, as a SET (the keep order is the NMS's score order: two survivors whose scores
+        # differ by less than the 16-bit error may swap places) ...
+        gset = sorted(zip(gs.tolist(), np.asarray(got["class_id"]).tolist()))
+        wset = sorted(zip(ws.tolist(), np.asarray(want["class_id"]).tolist()))
+        same_set = gset == wset
+        self.n["identical_survivor_sets"] += int(same_set)
+        # ... and in the same ORDER (what RectInfo consumers and the tracker's id assignment see)
         same_s = gs.shape == ws.shape and np.array_equal(gs, ws) and np.array_equal(got["class_id"], want["class_id"])
         self.n["identical_survivors"] += int(same_s)
         self.n_surv += len(ws)
@@ -107,18 +116,21 @@ class ChainStats:
         if same_s and len(ws):
             self.max_conf_diff = max(self.max_conf_diff, float(np.abs(np.asarray(got["conf"]) - want["conf"]).max()))
             self.max_box_diff = max(self.max_box_diff, float(np.abs(np.asarray(got["xywh"]) - want["xywh"]).max()))
-        if not same_s and len(self.mismatch_log) < 8:
+        if not same_set and len(self.mismatch_log) < 8:
             self.mismatch_log.append({"ctx": ctx, "only_device": np.setdiff1d(gs, ws).tolist()[:6], "only_oracle": np.setdiff1d(ws, gs).tolist()[:6]})
         return same_c, same_s
 
     def add_tracks(self, got_snap, want_snap, ctx=None):
         same = track_ids(got_snap) == track_ids(want_snap)
+        self.n_track_checks += 1
         self.n["identical_track_ids"] += int(same)
         if not same and self.first_track_divergence is None:
             self.first_track_divergence = ctx
         return same
 
     def add_lanes(self, got, want):
+        """Per frame: detected flags identical, every lane point within 1 px.  Per point: how many are further off (a row/column
+        whose two best grid cells are closer than the 16-bit error picks the other cell: an arg-max decision, tens of pixels)."""
         (gl, gs), (wl, ws) = got, want
         same_status = [bool(s) for s in gs] == [bool(s) for s in ws]
         self.n["lanes_identical_status"] += int(same_status)
@@ -126,12 +138,15 @@ class ChainStats:
         if ok:
             for a, b in zip(gl, wl):
                 a = np.asarray(a, np.int64).reshape(-1, 2); b = np.asarray(b, np.int64).reshape(-1, 2)
+                self.n_lane_pts += len(b)
                 if a.shape != b.shape:
                     ok = False
-                    break
-                d = int(np.abs(a - b).max(initial=0))
-                self.max_lane_px = max(self.max_lane_px, d)
-                ok = ok and d <= 1
+                    self.n_lane_pts_off += abs(len(a) - len(b))
+                    continue
+                d = np.abs(a - b).max(axis=1) if len(b) else np.zeros(0, np.int64)
+                self.max_lane_px = max(self.max_lane_px, int(d.max(initial=0)))
+                self.n_lane_pts_off += int((d > 1).sum())
+                ok = ok and int(d.max(initial=0)) <= 1
         self.n["lanes_within_1px"] += int(ok)
         return ok
 
@@ -140,35 +155,46 @@ class ChainStats:
         out = dict(self.n)
         out.update({
             "frac_identical_candidate_sets": round(self.n["identical_candidate_sets"] / f, 4),
-            "frac_identical_survivors": round(self.n["identical_survivors"] / f, 4),
-            "frac_identical_track_ids": round(self.n["identical_track_ids"] / f, 4),
+            "frac_identical_survivor_sets": round(self.n["identical_survivor_sets"] / f, 4),
+            "frac_identical_survivors_in_order": round(self.n["identical_survivors"] / f, 4),
+            "track_states_compared": self.n_track_checks,
+            "frac_identical_track_ids": round(self.n["identical_track_ids"] / max(1, self.n_track_checks), 4),
             "candidates_compared": self.n_cand, "candidate_anchors_differing": self.n_cand_sym_diff,
             "survivors_compared": self.n_surv, "survivor_anchors_differing": self.n_surv_sym_diff,
             "max_conf_diff_on_identical_frames": float("%.3e" % self.max_conf_diff),
             "max_box_diff_px_on_identical_frames": float("%.3e" % self.max_box_diff),
+            "lane_points_compared": self.n_lane_pts, "lane_points_off_by_more_than_1px": self.n_lane_pts_off,
             "max_lane_point_diff_px": self.max_lane_px, "first_track_divergence": self.first_track_divergence,
         })
         return out
 
 
 def run_device_chain(pipe, fetch_post, fetch_tracks, d_frame_sets, h_frame_sets, chain, steps, hold, streams, src_hw=(720, 1280), crop=0.6,
-                     lanes=True):
+                     lanes=True, micro_batch=1, n_streams=None):
     """Drive `pipe` (an AdasPipeline with FRESH tracker state) for `steps` steps over the frame sets (each held `hold` steps) and
-    compare streams `streams` with the oracle chain after every step.  fetch_post(s) -> detections dict, fetch_tracks(s) ->
-    snapshot dict (tests/gpu_api.track_snapshot form)."""
+    compare streams `streams` with the oracle chain after every step.  fetch_post(f) -> detections dict of frame index f,
+    fetch_tracks(s) -> snapshot dict (tests/gpu_api.track_snapshot form).  micro_batch B > 1: a frame set holds B consecutive
+    frames of each of the n_streams streams (frame b of stream s at index b * n_streams + s); the oracle tracker of a stream
+    consumes them in order and is compared after the last one."""
     st = ChainStats()
+    B = max(1, int(micro_batch))
+    NS = n_streams if n_streams is not None else (len(h_frame_sets[0]) // B)
     for k in range(steps):
         i = (k // hold) % len(d_frame_sets)
         pipe.step_frames(d_frame_sets[i].ptr, src_hw, crop)
         pipe.sync()
         for s in streams:
-            frame = h_frame_sets[i][s]
-            want = chain.detections(frame, key=(i, s))
-            got = fetch_post(s)
-            if got.get("overflow"):
-                raise RuntimeError("stream %d step %d: candidate arena overflow in the parity leg" % (s, k))
-            st.add_detections(got, want, ctx=[k, s])
-            st.add_tracks(fetch_tracks(s), chain.track(s, want), ctx=[k, s])
-            if lanes and pipe.decode is not None:
-                st.add_lanes(pipe.decode.fetch(s), chain.lanes(frame, key=(i, s)))
+            want_trk = None
+            for b in range(B):
+                f = b * NS + s
+                frame = h_frame_sets[i][f]
+                want = chain.detections(frame, key=(i, f))
+                got = fetch_post(f)
+                if got.get("overflow"):
+                    raise RuntimeError("frame %d step %d: candidate arena overflow in the parity leg" % (f, k))
+                st.add_detections(got, want, ctx=[k, s, b])
+                want_trk = chain.track(s, want)
+                if lanes and pipe.decode is not None:
+                    st.add_lanes(pipe.decode.fetch(f), chain.lanes(frame, key=(i, f)))
+            st.add_tracks(fetch_tracks(s), want_trk, ctx=[k, s])
     return st

@@ -414,3 +414,39 @@ def test_projection_shortcut_folded_into_conv2(CE, case, prec, tol):
         want = F.relu(F.conv2d(tt, Wt["conv2.weight"], Wt["conv2.bias"], padding=1) + dt).numpy()
     rel = float(np.linalg.norm(got - want) / (np.linalg.norm(want) + 1e-30))
     assert rel < tol, (case, prec, rel)
+
+
+@pytest.mark.parametrize("k,cin,cout", [(3, 64, 64), (3, 128, 128), (1, 64, 64), (3, 32, 32)], ids=str)
+def test_fp16_stores_saturate_instead_of_overflowing(CE, k, cin, cout):
+    """Fp16 kernels run with MODE.FP16_OVFL set (elem16.h Fp16::enter): an activation past the half range is stored as +-65504, not
+    as inf (which the next layer would turn into NaN).  A conv whose true outputs reach ~1e5..1e6 must come back finite, equal to
+    65504 where the oracle exceeds it and equal to the rounded oracle elsewhere."""
+    H, W, batch = 40, 40, 2
+    rng = np.random.default_rng(3)
+    w_exp = np.zeros((cin, 3, 1, 1), np.float32); w_exp[:, :, 0, 0] = rng.uniform(50.0, 300.0, (cin, 3))
+    w_test = rng.uniform(0.0, 2.0, (cout, cin, k, k)).astype(np.float32)
+    w_test[: cout // 2] *= 1e-3                                      # half of the channels stay in range
+    d = {"expand.weight": w_exp, "expand.bias": np.zeros(cin, np.float32), "test.weight": w_test, "test.bias": np.zeros(cout, np.float32),
+         "tap.weight": np.full((8, cout, 1, 1), 1e-6, np.float32), "tap.bias": np.zeros(8, np.float32)}
+    g = M.Graph("sat", 3, H, W, M.DictWeights(d))
+    x, c3 = g.input()
+    a = g.conv(x, cin, 1, 1, "expand", act=M.ACT_NONE, true_cin=c3)
+    y = g.conv(a, cout, k, 1, "test", act=M.ACT_NONE)
+    z = g.conv(y, 8, 1, 1, "tap", act=M.ACT_NONE, f32_out=True)
+    g.output(z, 0, [1, z.h * z.w * 8], "o")
+    path = os.path.join(tempfile.gettempdir(), f"sat_{k}_{cin}_{cout}.hipm")
+    g.save(path)
+    e = CE.HipEngine(path, "fp16", batch)
+    xin = rng.uniform(0.2, 1, (batch, 3, H, W)).astype(np.float32)
+    out = e.engine_inference(xin)[0]
+    got = e.fetch_activation("test", batch)
+    e.close(); os.remove(path)
+    with torch.no_grad():
+        a_ = F.conv2d(torch.from_numpy(xin), torch.from_numpy(w_exp)).half().float()
+        want = F.conv2d(a_, torch.from_numpy(w_test).half().float(), padding=k // 2).numpy()
+    assert np.isfinite(got).all() and np.isfinite(out).all()
+    over = want > 70000.0
+    assert over.mean() > 0.2 and (want < 60000.0).mean() > 0.2          # the case really straddles the half range
+    assert (got[over] == 65504.0).all()
+    inr = want < 60000.0
+    assert np.abs(got[inr] - want[inr]).max() <= 2e-3 * np.abs(want[inr]).max()

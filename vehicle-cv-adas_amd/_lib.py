@@ -72,7 +72,8 @@ class TrackHeader(C.Structure):
 
 class PipelineDesc(C.Structure):
     _fields_ = [("detector", C.c_void_p), ("lane", C.c_void_p), ("post", C.c_void_p), ("decode", C.c_void_p),
-                ("tracker", C.c_void_p), ("n_streams", C.c_int32), ("use_graph", C.c_int32), ("geometry", C.c_void_p)]
+                ("tracker", C.c_void_p), ("n_streams", C.c_int32), ("use_graph", C.c_int32), ("geometry", C.c_void_p),
+                ("micro_batch", C.c_int32), ("reserved", C.c_int32)]
 
 
 TRACK_DTYPE = np.dtype([("tlwh", "f8", 4), ("score", "f8"), ("track_id", "i4"), ("state", "i4"), ("is_activated", "i4"),

@@ -33,6 +33,7 @@ struct FcDev {
 
 template <typename E, int TN, int TM, int KS, int U>
 __global__ __launch_bounds__(64 * KS) void fc_kernel(FcDev a) {
+    E::enter();
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lrow = lane & 15, kg = lane >> 4;
     const int n0 = blockIdx.x * (TN * 16);

@@ -100,6 +100,7 @@ __device__ unsigned long long g_halo_prof[256][16];
 
 template <typename E, int BN, int ACT, int S>   // E: element tag (elem16.h)
 __global__ __launch_bounds__(256, 2) void conv_halo_kernel(HaloDev a) {
+    E::enter();
     typedef typename E::vec8 hvec8;
     constexpr int TAPS = 9;
     constexpr int HALO_BM = halo_bm(S);

@@ -113,6 +113,7 @@ __device__ unsigned long long g_h8_prof[256][32];
 
 template <typename E, int ACT, int MODE>
 __global__ __launch_bounds__(H8_THR, 1) void conv_h8_kernel(H8Dev a) {
+    E::enter();
     typedef typename E::vec8 hvec8;
     constexpr int LOOK = h8_look(MODE);
     extern __shared__ __attribute__((aligned(16))) uint8_t lds8[];

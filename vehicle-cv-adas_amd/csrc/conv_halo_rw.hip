@@ -58,6 +58,7 @@ template <typename E, int NCH, int ACT, bool HAS_RES, int BN = 64>  // NCH = 32-
                                                        // the CONV_HALO packing of the layer: halo_bn(cout)); HAS_RES is a template flag because a runtime branch
                                           // around the residual loads makes hipcc drain vmcnt(0) at the join -- and with it the window prefetch
 __global__ __launch_bounds__(RW_THR, RW_NW / 4) void conv_halo_rw_kernel(RwDev a) {
+    E::enter();
     typedef typename E::vec8 rvec8;
     constexpr int TAPS = 9, TM = RW_BM / 16 / RW_NW, TN = BN / 16;
     constexpr int WROWS = TAPS * BN;                  // weight rows of 64 B per plane (576 at BN = 64)

@@ -57,6 +57,7 @@ constexpr int S2_NW = (2 * S2_WROWS * 4) / S2_THR;        // weight slots per th
 
 template <typename E, int ACT>
 __global__ __launch_bounds__(S2_THR, 1) void conv_s2p_kernel(S2Dev a) {
+    E::enter();
     typedef typename E::vec8 vec8;
     constexpr int TAPS = 9, TM = 4, TN = 4;
     extern __shared__ __attribute__((aligned(16))) uint16_t lds[];

@@ -134,6 +134,7 @@ struct ConvDev {
 // T = activation/weight element (uint16_t = bf16 bits, or float); OutT = output element; ResT = residual element
 template <typename T, typename OutT, int BM, int BN, int WM, int WN>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvDev a) {
+    if constexpr (sizeof(OutT) == 2 && !__is_same(OutT, uint16_t)) Fp16::enter();   // half stores saturate (elem16.h)
     constexpr int PADE = 16 / (int)sizeof(T);
     constexpr int LDK = 32 + PADE;
     constexpr int TM = BM / WM / 16, TN = BN / WN / 16;

@@ -51,6 +51,7 @@ __device__ __forceinline__ int pair_pos(int p, int c) {
 
 template <typename E, int C>
 __global__ __launch_bounds__(256, C == 16 ? 6 : 3) void conv_pair_kernel(PairDev a) {
+    E::enter();
     typedef typename E::vec8 vec8;
     constexpr int NT = C / 16;               // 16-channel output tiles
     constexpr int NK = C == 16 ? 5 : 9;      // K steps of 32

@@ -35,6 +35,7 @@ struct PwDev {
 
 template <typename E, int KS, bool TAIL>
 __global__ __launch_bounds__(512) void conv_pw_kernel(PwDev a) {
+    E::enter();
     extern __shared__ __attribute__((aligned(16))) uint16_t wl[];  // [NTL][KS][64][8]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lrow = lane & 15, kg = lane >> 4;

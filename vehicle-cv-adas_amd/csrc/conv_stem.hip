@@ -55,6 +55,7 @@ constexpr int STEM_WW = 72;  // window row pitch in pixels (even: 16 B aligned f
 // pixel) instead of the fp32 NCHW seam tensor (three loads + a conversion); same values either way.
 template <typename E, int KH, int NT, int ACT, bool POOL, bool CONV2 = false, bool PACKED = false>
 __global__ __launch_bounds__(256, CONV2 ? 3 : 2) void conv_stem_kernel(StemDev a) {
+    E::enter();
     typedef typename E::vec8 svec8;
     constexpr bool TILE2 = POOL || CONV2;
     constexpr int CTH = CONV2 ? 17 : (POOL ? 9 : 8), CTW = TILE2 ? 33 : 32;  // conv tile (POOL: 4x16 pooled + halo)

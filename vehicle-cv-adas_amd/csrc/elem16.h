@@ -33,6 +33,7 @@ struct Bf16 {
     static __device__ __forceinline__ e_f32x4 mfma(e_u32x4 a, e_u32x4 b, e_f32x4 c) {
         return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(vec8, a), __builtin_bit_cast(vec8, b), c, 0, 0, 0);
     }
+    static __device__ __forceinline__ void enter() {}   // bf16 has fp32's exponent range: nothing to saturate
     static __device__ __forceinline__ uint32_t pack2(float a, float b) {  // v_cvt_pk_bf16_f32, round to nearest even
         return __builtin_bit_cast(uint32_t, __builtin_convertvector(e_f32x2{a, b}, e_bf16x2));
     }
@@ -61,18 +62,20 @@ struct Fp16 {
     static __device__ __forceinline__ e_f32x4 mfma(e_u32x4 a, e_u32x4 b, e_f32x4 c) {
         return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(vec8, a), __builtin_bit_cast(vec8, b), c, 0, 0, 0);
     }
-    // v_cvt_f16_f32 does not saturate: a value past the half range would become inf and the next layer NaN.  Stores clamp to the
-    // largest finite half (one v_med3_f32 per element; in-range values are untouched, so results are bit-identical below 65504).
-    static __device__ __forceinline__ float sat(float v) { return __builtin_amdgcn_fmed3f(v, -65504.0f, 65504.0f); }
+    // v_cvt_f16_f32 does not saturate by default: a value past the half range would become inf and the next layer NaN.  Every
+    // kernel that stores halves calls enter() first: MODE.FP16_OVFL = 1 makes an overflowed half result clamp to +-65504 (true
+    // infinities, e.g. max-pool padding, stay infinite) -- one scalar instruction per wave instead of a v_med3 per stored element
+    // (the per-element clamp measured -2 % end to end); results below 65504 are bit-identical.
+    static __device__ __forceinline__ void enter() { __builtin_amdgcn_s_setreg((unsigned short)(1 | (23 << 6) | (0 << 11)), 1u); }
     static __device__ __forceinline__ uint32_t pack2(float a, float b) {  // two v_cvt_f16_f32 (round to nearest even) + v_pack_b32_f16
-        return __builtin_bit_cast(uint32_t, __builtin_convertvector(e_f32x2{sat(a), sat(b)}, e_f16x2));
+        return __builtin_bit_cast(uint32_t, __builtin_convertvector(e_f32x2{a, b}, e_f16x2));
     }
     static __device__ __forceinline__ float lo(uint32_t u) { return (float)__builtin_bit_cast(e_f16x2, u)[0]; }
     static __device__ __forceinline__ float hi(uint32_t u) { return (float)__builtin_bit_cast(e_f16x2, u)[1]; }
     static __device__ __forceinline__ float to_f32(uint16_t h) { return (float)__builtin_bit_cast(_Float16, h); }
-    static __device__ __forceinline__ uint16_t from_f32(float f) { return __builtin_bit_cast(uint16_t, (_Float16)sat(f)); }
-    static __device__ __forceinline__ uint32_t max2(uint32_t a, uint32_t b) {   // max-pool: -inf padding must stay -inf (no clamp)
-        return __builtin_bit_cast(uint32_t, __builtin_convertvector(e_f32x2{fmaxf(lo(a), lo(b)), fmaxf(hi(a), hi(b))}, e_f16x2));
+    static __device__ __forceinline__ uint16_t from_f32(float f) { return __builtin_bit_cast(uint16_t, (_Float16)f); }
+    static __device__ __forceinline__ uint32_t max2(uint32_t a, uint32_t b) {
+        return pack2(fmaxf(lo(a), lo(b)), fmaxf(hi(a), hi(b)));
     }
     static inline uint16_t host_from_f32(float f) { return __builtin_bit_cast(uint16_t, (_Float16)f); }
 };

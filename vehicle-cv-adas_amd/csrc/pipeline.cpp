@@ -57,7 +57,9 @@ using namespace adas;
 // latency-bound detector layers and the MFMA-bound lane layers share the chip (independent work:
 // demo.py:261-281 runs them back to back only because the reference is single-threaded Python).
 static int record_step(adas_pipeline* p, const float* d_det, const float* d_lane, bool events) {
-    const int S = p->d.n_streams;
+    const int NS = p->d.n_streams;                                   // streams (tracker instances)
+    const int B = p->d.micro_batch > 1 ? p->d.micro_batch : 1;       // consecutive frames of each stream in this step
+    const int S = NS * B;                                            // frames through pre-processing, nets, decode and NMS
     hipStream_t st = p->st;
     const bool fork = !events && p->d.detector && p->d.lane && !(p->d.use_graph & 2);
     hipStream_t sl = fork ? p->st_lane : st;
@@ -120,8 +122,12 @@ static int record_step(adas_pipeline* p, const float* d_det, const float* d_lane
         int cap = 0;
         rc = adas_yolo_post_capacity(p->d.post, &cap);
         if (rc) return rc;
-        rc = adas_bytetrack_update_device(p->d.tracker, xy, sc, cl, cn, cap, 4, 2, S, st);
-        if (rc) return rc;
+        // frame b of stream s sits at frame index b * NS + s: update launch b reads rows [b * NS, b * NS + NS), in temporal order
+        for (int b = 0; b < B; ++b) {
+            const size_t f0 = (size_t)b * NS;
+            rc = adas_bytetrack_update_device(p->d.tracker, xy + f0 * cap * 4, sc + f0 * cap, cl + f0 * cap, cn + f0 * 4, cap, 4, 2, NS, st);
+            if (rc) return rc;
+        }
     }
     if (fork) {
         ADAS_HIP_TRY(hipEventRecord(p->ev_join, sl));
@@ -173,8 +179,10 @@ int adas_pipeline_create(const adas_pipeline_desc* d, adas_pipeline** out) {
                          (long long)od[2], (long long)od[3], (long long)want[i][1], (long long)want[i][2], (long long)want[i][3]);
         }
     }
-    ADAS_REQUIRE(!d->detector || d->n_streams <= d->detector->max_batch, ADAS_ERR_INVALID, "n_streams exceeds detector max_batch");
-    ADAS_REQUIRE(!d->lane || d->n_streams <= d->lane->max_batch, ADAS_ERR_INVALID, "n_streams exceeds lane max_batch");
+    const int frames_per_step = d->n_streams * (d->micro_batch > 1 ? d->micro_batch : 1);
+    ADAS_REQUIRE(d->micro_batch >= 0 && d->micro_batch <= 64, ADAS_ERR_INVALID, "micro_batch must be in [0, 64]");
+    ADAS_REQUIRE(!d->detector || frames_per_step <= d->detector->max_batch, ADAS_ERR_INVALID, "n_streams x micro_batch exceeds detector max_batch");
+    ADAS_REQUIRE(!d->lane || frames_per_step <= d->lane->max_batch, ADAS_ERR_INVALID, "n_streams x micro_batch exceeds lane max_batch");
     adas_pipeline* p = new adas_pipeline();
     p->d = *d;
     if (hipStreamCreateWithFlags(&p->st, hipStreamNonBlocking) != hipSuccess) {
@@ -274,7 +282,7 @@ int adas_pipeline_step(adas_pipeline* p, const float* d_det, const float* d_lane
 int adas_pipeline_step_frames(adas_pipeline* p, const uint8_t* d_frames_bgr, int src_h, int src_w, double lane_crop_ratio) {
     ADAS_REQUIRE(p && d_frames_bgr && src_h > 0 && src_w > 0, ADAS_ERR_INVALID, "adas_pipeline_step_frames: bad argument");
     ADAS_REQUIRE(!p->d.lane || (lane_crop_ratio > 0.0 && lane_crop_ratio <= 1.0), ADAS_ERR_INVALID, "lane crop ratio must be in (0, 1]");
-    const size_t S = p->d.n_streams;
+    const size_t S = (size_t)p->d.n_streams * (p->d.micro_batch > 1 ? p->d.micro_batch : 1);
     if (!p->det_in && !p->lane_in) {
         const char* env = getenv("ADAS_NO_PACKED_SEAM");
         p->packed = !(env && env[0] == '1') && (!p->d.detector || adas_engine_accepts_packed_input(p->d.detector)) &&
@@ -303,7 +311,7 @@ int adas_pipeline_step_frames(adas_pipeline* p, const uint8_t* d_frames_bgr, int
 
 int adas_pipeline_step_frames_host(adas_pipeline* p, const uint8_t* h_frames_bgr, int src_h, int src_w, double lane_crop_ratio) {
     ADAS_REQUIRE(p && h_frames_bgr && src_h > 0 && src_w > 0, ADAS_ERR_INVALID, "adas_pipeline_step_frames_host: bad argument");
-    const size_t bytes = (size_t)p->d.n_streams * src_h * src_w * 3;
+    const size_t bytes = (size_t)p->d.n_streams * (p->d.micro_batch > 1 ? p->d.micro_batch : 1) * src_h * src_w * 3;
     if (!p->st_copy) {
         ADAS_HIP_TRY(hipStreamCreateWithFlags(&p->st_copy, hipStreamNonBlocking));
         for (int k = 0; k < 2; ++k) {

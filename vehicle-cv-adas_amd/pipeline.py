@@ -19,9 +19,15 @@ CULANE = dict(grid_row=200, cls_row=72, grid_col=100, cls_col=81,
 class AdasPipeline:
     def __init__(self, det_model=None, lane_model=None, n_streams=1, precision=None, src_hw=(720, 1280),
                  box_score=0.4, nms_iou=0.45, head_layout=L.HEAD_V8, num_classes=None, use_graph=True,
-                 max_candidates=512, track=True, lane_cfg=None, nms_mode=L.NMS_REFERENCE, overlap=True, geometry=None):
-        """geometry: None, or dict(bird_wh=(w, h), M=3x3, adjust_lanes=True) to run the lane-geometry kernel behind the decode."""
+                 max_candidates=512, track=True, lane_cfg=None, nms_mode=L.NMS_REFERENCE, overlap=True, geometry=None, micro_batch=1):
+        """geometry: None, or dict(bird_wh=(w, h), M=3x3, adjust_lanes=True) to run the lane-geometry kernel behind the decode.
+        micro_batch B > 1: temporal micro-batching (adas_pipeline_desc.micro_batch) -- a step takes B consecutive frames of every
+        stream, frame b of stream s at index b * n_streams + s of the input and of every per-frame fetch; the tracker consumes
+        them in order.  Throughput mode for few streams per GPU."""
         self.S = n_streams
+        self.B = max(1, int(micro_batch))
+        n_tracks = n_streams
+        n_streams = n_streams * self.B          # frames per step through the engines / post / decode handles
         self.det = self.lane = self.post = self.decode = self.tracker = self.geometry = None
         if det_model:
             self.det = HipEngine(det_model, precision, n_streams)
@@ -36,7 +42,7 @@ class AdasPipeline:
             lb = letterbox(src_hw, ishape[2:])
             self.post = YoloPost(head_layout, A, num_classes, box_score, nms_iou, lb, nms_mode, max_candidates, n_streams)
             if track:
-                self.tracker = DeviceTracker(n_streams, max_dets=max_candidates)
+                self.tracker = DeviceTracker(n_tracks, max_dets=max_candidates)
         if lane_model:
             self.lane = HipEngine(lane_model, precision, n_streams)
             cfg = dict(CULANE)
@@ -53,8 +59,8 @@ class AdasPipeline:
                 self.geometry = LaneGeometry(src_hw[0], geometry["bird_wh"], geometry["M"], geometry.get("adjust_lanes", True), n_streams)
         d = L.PipelineDesc(self.det.handle if self.det else None, self.lane.handle if self.lane else None,
                            self.post.h if self.post else None, self.decode.h if self.decode else None,
-                           self.tracker.h if self.tracker else None, n_streams, (1 if use_graph else 0) | (0 if overlap else 2),
-                           self.geometry.h if self.geometry else None)
+                           self.tracker.h if self.tracker else None, n_tracks, (1 if use_graph else 0) | (0 if overlap else 2),
+                           self.geometry.h if self.geometry else None, self.B if self.B > 1 else 0, 0)
         h = C.c_void_p()
         L.check(L.lib().adas_pipeline_create(C.byref(d), C.byref(h)))
         self.h = h.value
