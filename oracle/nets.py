@@ -102,34 +102,131 @@ def yolov8_forward(x, W, scale="n", nc=80, taps=None):
             taps.update(p3=x15, p4=x18, p5=x21, b4=x4, b6=x6, sppf=x9)
         feats = [x15, x18, x21]
         N = x.shape[0]
-        outs, anchors, strides = [], [], []
+        outs = []
         for i, f in enumerate(feats):
             b = _conv(_conv(f, W, f"model.22.cv2.{i}.0.conv"), W, f"model.22.cv2.{i}.1.conv")
             b = _conv(b, W, f"model.22.cv2.{i}.2", act=None)
             c = _conv(_conv(f, W, f"model.22.cv3.{i}.0.conv"), W, f"model.22.cv3.{i}.1.conv")
             c = _conv(c, W, f"model.22.cv3.{i}.2", act=None)
             outs.append(torch.cat((b, c), 1).view(N, 64 + nc, -1))
-            h, w = f.shape[2:]
-            sy, sx = torch.meshgrid(torch.arange(h, dtype=torch.float32) + 0.5,
-                                    torch.arange(w, dtype=torch.float32) + 0.5, indexing="ij")
-            anchors.append(torch.stack((sx, sy), -1).view(-1, 2))
-            strides.append((h, w))
-        H_in = feats[0].shape[2] * 8
-        stride_t = torch.cat([torch.full((h * w, 1), float(H_in // h)) for h, w in strides])
-        xcat = torch.cat(outs, 2)
-        box, cls = xcat.split((64, nc), 1)
-        # DFL: softmax over 16 bins, expectation (ultralytics DFL module)
-        A = box.shape[2]
-        d = box.view(N, 4, 16, A).transpose(2, 1).softmax(1)
-        dist = (d * torch.arange(16, dtype=torch.float32).view(1, 16, 1, 1)).sum(1)      # (N,4,A)
-        anc = torch.cat(anchors).transpose(0, 1).unsqueeze(0)                                # (1,2,A)
-        lt, rb = dist.chunk(2, 1)
-        x1y1 = anc - lt
-        x2y2 = anc + rb
-        dbox = torch.cat(((x1y1 + x2y2) / 2, x2y2 - x1y1), 1) * stride_t.transpose(0, 1)
+        return _v8_decode(outs, [f.shape[2:] for f in feats], nc, taps)
+
+
+def _v8_decode(outs, sizes, nc, taps=None):
+    """ultralytics Detect inference path: per-level (N, 64+nc, h*w) logits -> (N, 4+nc, A): DFL expectation over 16 bins, dist2bbox
+    (xywh) x stride, sigmoid class probabilities."""
+    N = outs[0].shape[0]
+    anchors = []
+    for h, w in sizes:
+        sy, sx = torch.meshgrid(torch.arange(h, dtype=torch.float32) + 0.5, torch.arange(w, dtype=torch.float32) + 0.5, indexing="ij")
+        anchors.append(torch.stack((sx, sy), -1).view(-1, 2))
+    H_in = sizes[0][0] * 8
+    stride_t = torch.cat([torch.full((h * w, 1), float(H_in // h)) for h, w in sizes])
+    xcat = torch.cat(outs, 2)
+    box, cls = xcat.split((64, nc), 1)
+    A = box.shape[2]
+    d = box.view(N, 4, 16, A).transpose(2, 1).softmax(1)
+    dist = (d * torch.arange(16, dtype=torch.float32).view(1, 16, 1, 1)).sum(1)      # (N,4,A)
+    anc = torch.cat(anchors).transpose(0, 1).unsqueeze(0)                                # (1,2,A)
+    lt, rb = dist.chunk(2, 1)
+    x1y1 = anc - lt
+    x2y2 = anc + rb
+    dbox = torch.cat(((x1y1 + x2y2) / 2, x2y2 - x1y1), 1) * stride_t.transpose(0, 1)
+    if taps is not None:
+        taps.update(box_logits=box, cls_logits=cls)
+    return torch.cat((dbox, cls.sigmoid()), 1).numpy()
+
+
+# ------------------------------------------------------------------ YOLOv10
+# THU-MIG/yolov10 (ultralytics 8.1 fork) yolov10n.yaml + nn/modules/block.py (SCDown, PSA/Attention, CIB, C2fCIB, RepVGGDW fused to one
+# 7x7) + head.py v10Detect (one-to-one branch).  PARITY UNPINNED like the other YOLO graphs (architecture not in the reference; the
+# reference only pins the I/O: demo.py:24-30 ships yolov10n, yoloDetector.py:114,121 decodes a v8-layout (1, 4+nc, A) tensor);
+# parameter / FLOP counts match the published 2.3 M / 6.7 G.
+V10_SCALES = {"n": (0.33, 0.25, 1024)}
+
+
+def _dwconv(x, W, name, s=1, act="silu"):
+    w = _round(_t(W, name + ".weight"))
+    k = w.shape[-1]
+    y = F.conv2d(x, w, _t(W, name + ".bias"), stride=s, padding=k // 2, groups=x.shape[1])
+    return _round(F.silu(y)) if act == "silu" else _round(y)
+
+
+def _scdown(x, W, name, s=2):
+    return _dwconv(_conv(x, W, f"{name}.cv1.conv"), W, f"{name}.cv2.conv", s, act=None)
+
+
+def _psa(x, W, name):
+    c = x.shape[1] // 2
+    nh = c // 64
+    hd = c // nh
+    kd = hd // 2
+    a, b = _conv(x, W, f"{name}.cv1.conv").split((c, c), 1)
+    B, _, H, Wd = b.shape
+    N = H * Wd
+    qkv = _round(_conv(b, W, f"{name}.attn.qkv.conv", act=None))
+    q, k, v = qkv.view(B, nh, 2 * kd + hd, N).split([kd, kd, hd], dim=2)
+    attn = ((q.transpose(-2, -1) @ k) * (kd ** -0.5)).softmax(dim=-1)
+    y = _round((v @ attn.transpose(-2, -1)).reshape(B, c, H, Wd))
+    y = _round(y + _dwconv(v.reshape(B, c, H, Wd), W, f"{name}.attn.pe.conv", act=None))
+    b = _round(b + _conv(y, W, f"{name}.attn.proj.conv", act=None))
+    b = _round(b + _conv(_conv(b, W, f"{name}.ffn.0.conv"), W, f"{name}.ffn.1.conv", act=None))
+    return _conv(torch.cat((a, b), 1), W, f"{name}.cv2.conv")
+
+
+def _cib(x, W, name, lk):
+    t = _dwconv(x, W, f"{name}.cv1.0.conv")
+    t = _conv(t, W, f"{name}.cv1.1.conv")
+    t = _dwconv(t, W, f"{name}.cv1.2.conv.conv" if lk else f"{name}.cv1.2.conv")      # deploy form of RepVGGDW: one 7x7 + SiLU
+    t = _conv(t, W, f"{name}.cv1.3.conv")
+    return x + _dwconv(t, W, f"{name}.cv1.4.conv")
+
+
+def _c2fcib(x, W, name, n, lk):
+    y = list(_conv(x, W, f"{name}.cv1.conv").chunk(2, 1))
+    for i in range(n):
+        y.append(_cib(y[-1], W, f"{name}.m.{i}", lk))
+    return _conv(torch.cat(y, 1), W, f"{name}.cv2.conv")
+
+
+def yolov10_forward(x, W, scale="n", nc=80, taps=None):
+    """x: (N,3,H,W) fp32 in [0,1] -> (N, 4+nc, A) fp32 in the v8 head layout the reference decodes (yoloDetector.py:114,121)."""
+    depth = V10_SCALES[scale][0]
+    dep = lambda n: max(round(n * depth), 1)
+    x = torch.as_tensor(x, dtype=torch.float32)
+    with torch.no_grad():
+        x = _conv(x, W, "model.0.conv", 2)
+        x = _conv(x, W, "model.1.conv", 2)
+        x = _c2f(x, W, "model.2", dep(3), True)
+        x = _conv(x, W, "model.3.conv", 2)
+        x4 = _c2f(x, W, "model.4", dep(6), True)
+        x = _scdown(x4, W, "model.5")
+        x6 = _c2f(x, W, "model.6", dep(6), True)
+        x = _scdown(x6, W, "model.7")
+        x = _c2f(x, W, "model.8", dep(3), True)
+        x = _sppf(x, W, "model.9")
+        x10 = _psa(x, W, "model.10")
+        x = torch.cat((F.interpolate(x10, scale_factor=2, mode="nearest"), x6), 1)
+        x13 = _c2f(x, W, "model.13", dep(3), False)
+        x = torch.cat((F.interpolate(x13, scale_factor=2, mode="nearest"), x4), 1)
+        x16 = _c2f(x, W, "model.16", dep(3), False)
+        x = torch.cat((_conv(x16, W, "model.17.conv", 2), x13), 1)
+        x19 = _c2f(x, W, "model.19", dep(3), False)
+        x = torch.cat((_scdown(x19, W, "model.20"), x10), 1)
+        x22 = _c2fcib(x, W, "model.22", dep(3), True)
         if taps is not None:
-            taps.update(box_logits=box, cls_logits=cls)
-        return torch.cat((dbox, cls.sigmoid()), 1).numpy()
+            taps.update(p3=x16, p4=x19, p5=x22, psa=x10)
+        outs = []
+        feats = [x16, x19, x22]
+        N = x.shape[0]
+        for i, f in enumerate(feats):
+            b = _conv(_conv(f, W, f"model.23.one2one_cv2.{i}.0.conv"), W, f"model.23.one2one_cv2.{i}.1.conv")
+            b = _conv(b, W, f"model.23.one2one_cv2.{i}.2", act=None)
+            c = _conv(_dwconv(f, W, f"model.23.one2one_cv3.{i}.0.0.conv"), W, f"model.23.one2one_cv3.{i}.0.1.conv")
+            c = _conv(_dwconv(c, W, f"model.23.one2one_cv3.{i}.1.0.conv"), W, f"model.23.one2one_cv3.{i}.1.1.conv")
+            c = _conv(c, W, f"model.23.one2one_cv3.{i}.2", act=None)
+            outs.append(torch.cat((b, c), 1).view(N, 64 + nc, -1))
+        return _v8_decode(outs, [f.shape[2:] for f in feats], nc, taps)
 
 
 # ------------------------------------------------------------------ YOLOv5

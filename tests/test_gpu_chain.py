@@ -67,14 +67,16 @@ def _assert_exact(o):
 
 
 def _assert_16bit(o):
-    """Bounds on how MANY discrete decisions differ (measured values are printed by _run_chain).  First GPU measurement of the
-    north-star pipeline in fp16 (round 3): 8 of 4,640 candidate anchors, 30 of 432 survivor anchors (one frame, held), all track ids
-    identical, 2 of 32 frames with a lane point on another grid cell."""
+    """Bounds on how MANY discrete decisions differ (measured values are printed by _run_chain).  A half-precision network leaves
+    ~1e-3 of the anchor-to-anchor logit spread as error (tools/scratch/snr_cpu.py), so of 8400 anchors with ~100 over the threshold
+    about 0.4-1 per frame sits closer to it than that and is decided differently; one such anchor changes the NMS outcome of its
+    neighbourhood (one or two survivors).  Measured (round 3, MI355X): north-star pipeline 8 of 4,640 candidate anchors and 95.8 % of
+    frames with identical survivor sets over 96 frames; YOLOv8s 0.6 % / 4.1 % and YOLOv8l 2.6 % / 10 % of candidate / survivor
+    anchors over 384 / 192 frames (bench.py parity.e2e).  The bounds below leave room for the small samples of these tests."""
     n = o["frames"]
     assert o["survivors_compared"] >= 2 * n
-    assert o["candidate_anchors_differing"] <= 0.03 * o["candidates_compared"], o
-    assert o["survivor_anchors_differing"] <= 0.12 * o["survivors_compared"], o
-    assert o["identical_survivor_sets"] >= 0.5 * n, o
+    assert o["candidate_anchors_differing"] <= 0.04 * o["candidates_compared"], o
+    assert o["survivor_anchors_differing"] <= 4 * n and o["survivor_anchors_differing"] <= 0.5 * o["survivors_compared"], o
     assert o["lanes_identical_status"] == n, o
     assert o["lane_points_off_by_more_than_1px"] <= 0.02 * max(1, o["lane_points_compared"]), o
     assert o["max_conf_diff_on_identical_frames"] <= 2e-2 and o["max_box_diff_px_on_identical_frames"] <= 0.5, o
@@ -84,6 +86,7 @@ def test_step_frames_fp16_matches_oracle_chain(tmp_path):
     """The north-star pipeline (YOLOv8n + UFLDv2-R18) in the benchmarked precision: 4 streams x 8 steps, three frame sets."""
     o = _run_chain(tmp_path, "yolov8n", "fp16", S=4, steps=8, hold=2, n_sets=3)
     _assert_16bit(o)
+    assert o["identical_survivor_sets"] >= 0.5 * o["frames"], o
 
 
 def test_step_frames_more_than_two_streams_fp32_no_graph(tmp_path):

@@ -28,6 +28,7 @@ UNITS = [
     ("conv_pw.hip", []),
     ("conv_stem.hip", []),
     ("aux_kernels.hip", []),
+    ("dw_attn.hip", []),
     ("engine.cpp", []),
     ("pipeline.cpp", []),
 ]

@@ -1,0 +1,239 @@
+// dw_attn.hip -- the two YOLOv10 operators the v8-family kernels do not cover (the reference's shipped default detector is
+// yolov10n: demo.py:24-30; its head is decoded as a v8-layout tensor, yoloDetector.py:114,121):
+//   dwconv     depth-wise k x k convolution (k = 3 or 7, stride 1 or 2, groups = channels) + bias [+ SiLU] [+ residual add]:
+//              SCDown.cv2, CIB's three depth-wise layers (the fused RepVGGDW is one 7x7), v10Detect's class-branch 3x3s and
+//              the positional encoding of PSA's attention.  HBM-bound streaming: thread = (output pixel, 8-channel group), one
+//              16-byte (16-bit modes) load per tap from a window that lives in L1/L2, fp32 weights [tap][C], fp32 accumulate.
+//   attention  PSA's softmax attention (ultralytics Attention: per head q, k of key_dim and v of head_dim channels cut out of one
+//              qkv tensor; out[d, i] = sum_j v[d, j] * softmax_j(q_i . k_j * scale)) on the 20x20 (N = 400 tokens) P5 map.  One
+//              thread per query token: keys / values stream through LDS in chunks of 64 tokens (fp32), scores of a chunk sit in
+//              registers, the running maximum / denominator are rescaled once per chunk (online softmax).  Latency-sized work
+//              (31 MFLOP per frame and head): no MFMA.
+// All three precisions run the same code on the storage type (elem16.h / float).
+#include "kernels.h"
+#include "elem16.h"
+
+namespace adas {
+
+template <typename T> struct Vec8;
+template <> struct Vec8<uint16_t> {
+    static __device__ __forceinline__ void load(const uint16_t* p, float v[8]) {
+        const uint4 q = *reinterpret_cast<const uint4*>(p);
+        const uint32_t w[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { v[2 * k] = Bf16::lo(w[k]); v[2 * k + 1] = Bf16::hi(w[k]); }
+    }
+    static __device__ __forceinline__ void store(uint16_t* p, const float v[8]) {
+        *reinterpret_cast<uint4*>(p) = make_uint4(Bf16::pack2(v[0], v[1]), Bf16::pack2(v[2], v[3]), Bf16::pack2(v[4], v[5]), Bf16::pack2(v[6], v[7]));
+    }
+};
+template <> struct Vec8<f16s> {
+    static __device__ __forceinline__ void load(const f16s* p, float v[8]) {
+        const uint4 q = *reinterpret_cast<const uint4*>(p);
+        const uint32_t w[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { v[2 * k] = Fp16::lo(w[k]); v[2 * k + 1] = Fp16::hi(w[k]); }
+    }
+    static __device__ __forceinline__ void store(f16s* p, const float v[8]) {
+        *reinterpret_cast<uint4*>(p) = make_uint4(Fp16::pack2(v[0], v[1]), Fp16::pack2(v[2], v[3]), Fp16::pack2(v[4], v[5]), Fp16::pack2(v[6], v[7]));
+    }
+};
+template <> struct Vec8<float> {
+    static __device__ __forceinline__ void load(const float* p, float v[8]) {
+        const float4 a = reinterpret_cast<const float4*>(p)[0], b = reinterpret_cast<const float4*>(p)[1];
+        v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+    }
+    static __device__ __forceinline__ void store(float* p, const float v[8]) {
+        reinterpret_cast<float4*>(p)[0] = make_float4(v[0], v[1], v[2], v[3]);
+        reinterpret_cast<float4*>(p)[1] = make_float4(v[4], v[5], v[6], v[7]);
+    }
+};
+
+struct DwDev {
+    const void* in;
+    void* out;
+    const void* res;
+    const float* wgt;   // [k*k][C] fp32
+    const float* bias;  // [C]
+    int in_cs, in_coff, out_cs, out_coff, res_cs, res_coff;
+    int c, H, W, Ho, Wo, k, s, p, n, act, has_res;
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void dwconv_kernel(DwDev d) {
+    if constexpr (sizeof(T) == 2 && !__is_same(T, uint16_t)) Fp16::enter();
+    const int c8n = d.c >> 3;
+    const size_t total = (size_t)d.n * d.Ho * d.Wo * c8n;
+    const T* __restrict__ in = (const T*)d.in;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int c8 = (int)(i % c8n);
+        size_t pix = i / c8n;
+        const int ox = (int)(pix % d.Wo);
+        size_t t = pix / d.Wo;
+        const int oy = (int)(t % d.Ho);
+        const size_t b = t / d.Ho;
+        const int c = c8 * 8;
+        float acc[8];
+        {
+            const float4 b0 = *reinterpret_cast<const float4*>(d.bias + c), b1 = *reinterpret_cast<const float4*>(d.bias + c + 4);
+            acc[0] = b0.x; acc[1] = b0.y; acc[2] = b0.z; acc[3] = b0.w; acc[4] = b1.x; acc[5] = b1.y; acc[6] = b1.z; acc[7] = b1.w;
+        }
+        for (int r = 0; r < d.k; ++r) {
+            const int iy = oy * d.s - d.p + r;
+            if ((unsigned)iy >= (unsigned)d.H) continue;
+            for (int q = 0; q < d.k; ++q) {
+                const int ix = ox * d.s - d.p + q;
+                if ((unsigned)ix >= (unsigned)d.W) continue;
+                float x[8];
+                Vec8<T>::load(in + ((b * d.H + iy) * d.W + ix) * d.in_cs + d.in_coff + c, x);
+                const float* wp = d.wgt + (size_t)(r * d.k + q) * d.c + c;
+                const float4 w0 = *reinterpret_cast<const float4*>(wp), w1 = *reinterpret_cast<const float4*>(wp + 4);
+                acc[0] = fmaf(x[0], w0.x, acc[0]); acc[1] = fmaf(x[1], w0.y, acc[1]); acc[2] = fmaf(x[2], w0.z, acc[2]); acc[3] = fmaf(x[3], w0.w, acc[3]);
+                acc[4] = fmaf(x[4], w1.x, acc[4]); acc[5] = fmaf(x[5], w1.y, acc[5]); acc[6] = fmaf(x[6], w1.z, acc[6]); acc[7] = fmaf(x[7], w1.w, acc[7]);
+            }
+        }
+        if (d.act == ACT_SILU) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[e] = acc[e] / (1.0f + expf(-acc[e]));
+        } else if (d.act == ACT_RELU) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[e] = fmaxf(acc[e], 0.0f);
+        }
+        if (d.has_res) {   // x + block(x): added after the activation (RES_AFTER_ACT)
+            float rv[8];
+            Vec8<T>::load((const T*)d.res + pix * d.res_cs + d.res_coff + c, rv);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[e] += rv[e];
+        }
+        Vec8<T>::store((T*)d.out + pix * d.out_cs + d.out_coff + c, acc);
+    }
+}
+
+bool dwconv_supported(int k, int stride, int pad, int res_mode, const TView& in, const TView& out) {
+    if ((k != 3 && k != 7) || (stride != 1 && stride != 2) || pad != k / 2) return false;
+    if (res_mode != RES_NONE && res_mode != RES_AFTER_ACT) return false;
+    if (in.c != out.c || (in.c & 7) || (in.cs & 7) || (in.coff & 7) || (out.cs & 7) || (out.coff & 7) || in.f32 || out.f32) return false;
+    return out.h == (in.h + 2 * pad - k) / stride + 1 && out.w == (in.w + 2 * pad - k) / stride + 1;
+}
+
+hipError_t launch_dwconv(const TView& in, const TView& out, const TView& res, int res_mode, const float* wgt, const float* bias, int n, int k,
+                         int stride, int pad, int act, int prec, hipStream_t st) {
+    if (!dwconv_supported(k, stride, pad, res_mode, in, out)) return hipErrorInvalidValue;
+    if (res_mode != RES_NONE && ((res.cs & 7) || (res.coff & 7) || res.f32 || res.h != out.h || res.w != out.w)) return hipErrorInvalidValue;
+    DwDev d;
+    d.in = in.p; d.out = out.p; d.res = res_mode != RES_NONE ? res.p : nullptr; d.wgt = wgt; d.bias = bias;
+    d.in_cs = in.cs; d.in_coff = in.coff; d.out_cs = out.cs; d.out_coff = out.coff; d.res_cs = res.cs; d.res_coff = res.coff;
+    d.c = in.c; d.H = in.h; d.W = in.w; d.Ho = out.h; d.Wo = out.w; d.k = k; d.s = stride; d.p = pad; d.n = n; d.act = act;
+    d.has_res = res_mode != RES_NONE;
+    const size_t total = (size_t)n * out.h * out.w * (in.c >> 3);
+    const int blocks = (int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
+    if (prec == PREC_FP32) hipLaunchKernelGGL(dwconv_kernel<float>, dim3(blocks), dim3(256), 0, st, d);
+    else if (prec == PREC_FP16) hipLaunchKernelGGL(dwconv_kernel<f16s>, dim3(blocks), dim3(256), 0, st, d);
+    else hipLaunchKernelGGL(dwconv_kernel<uint16_t>, dim3(blocks), dim3(256), 0, st, d);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------- attention
+struct AttnDev {
+    const void* qkv;
+    void* out;
+    int in_cs, in_coff, out_cs, out_coff;
+    int N;          // tokens per frame (H * W)
+    int nh;
+    float scale;
+};
+
+constexpr int AT_KD = 32, AT_HD = 64, AT_CH = 64, AT_THR = 128;
+
+template <typename T> __device__ __forceinline__ float at_ld(const T* p);
+template <> __device__ __forceinline__ float at_ld<float>(const float* p) { return *p; }
+template <> __device__ __forceinline__ float at_ld<uint16_t>(const uint16_t* p) { return Bf16::to_f32(*p); }
+template <> __device__ __forceinline__ float at_ld<f16s>(const f16s* p) { return Fp16::to_f32(p->v); }
+template <typename T> __device__ __forceinline__ void at_st(T* p, float v);
+template <> __device__ __forceinline__ void at_st<float>(float* p, float v) { *p = v; }
+template <> __device__ __forceinline__ void at_st<uint16_t>(uint16_t* p, float v) { *p = Bf16::from_f32(v); }
+template <> __device__ __forceinline__ void at_st<f16s>(f16s* p, float v) { p->v = Fp16::from_f32(v); }
+
+// grid (ceil(N / AT_THR), nh, batch); thread = one query token
+template <typename T>
+__global__ __launch_bounds__(AT_THR) void attention_kernel(AttnDev a) {
+    if constexpr (sizeof(T) == 2 && !__is_same(T, uint16_t)) Fp16::enter();
+    __shared__ float Ks[AT_CH][AT_KD + 1];
+    __shared__ float Vs[AT_CH][AT_HD + 1];
+    const int tid = threadIdx.x, h = blockIdx.y;
+    const size_t b = blockIdx.z;
+    const int i = blockIdx.x * AT_THR + tid;
+    const int hc = h * (2 * AT_KD + AT_HD);
+    const T* base = (const T*)a.qkv + b * (size_t)a.N * a.in_cs + a.in_coff + hc;
+    float q[AT_KD];
+    {
+        const T* qp = base + (size_t)(i < a.N ? i : 0) * a.in_cs;
+#pragma unroll
+        for (int d = 0; d < AT_KD; ++d) q[d] = at_ld<T>(qp + d) * a.scale;
+    }
+    float acc[AT_HD];
+#pragma unroll
+    for (int d = 0; d < AT_HD; ++d) acc[d] = 0.f;
+    float m = -INFINITY, l = 0.f;
+    for (int j0 = 0; j0 < a.N; j0 += AT_CH) {
+        const int nj = a.N - j0 < AT_CH ? a.N - j0 : AT_CH;
+        __syncthreads();
+        for (int e = tid; e < AT_CH * AT_KD; e += AT_THR) {
+            const int j = e / AT_KD, d = e - j * AT_KD;
+            Ks[j][d] = j < nj ? at_ld<T>(base + (size_t)(j0 + j) * a.in_cs + AT_KD + d) : 0.f;
+        }
+        for (int e = tid; e < AT_CH * AT_HD; e += AT_THR) {
+            const int j = e / AT_HD, d = e - j * AT_HD;
+            Vs[j][d] = j < nj ? at_ld<T>(base + (size_t)(j0 + j) * a.in_cs + 2 * AT_KD + d) : 0.f;
+        }
+        __syncthreads();
+        float s[AT_CH];
+        float cm = -INFINITY;
+#pragma unroll
+        for (int j = 0; j < AT_CH; ++j) {
+            float v = 0.f;
+#pragma unroll
+            for (int d = 0; d < AT_KD; ++d) v = fmaf(q[d], Ks[j][d], v);
+            s[j] = j < nj ? v : -INFINITY;
+            cm = fmaxf(cm, s[j]);
+        }
+        const float mn = fmaxf(m, cm);
+        const float corr = expf(m - mn);     // 0 on the first chunk (m = -inf)
+        l *= corr;
+#pragma unroll
+        for (int d = 0; d < AT_HD; ++d) acc[d] *= corr;
+#pragma unroll
+        for (int j = 0; j < AT_CH; ++j) {
+            const float p = expf(s[j] - mn);  // exp(-inf) = 0 for the padded tail
+            l += p;
+#pragma unroll
+            for (int d = 0; d < AT_HD; ++d) acc[d] = fmaf(p, Vs[j][d], acc[d]);
+        }
+        m = mn;
+    }
+    if (i < a.N) {
+        const float inv = 1.0f / l;
+        T* op = (T*)a.out + (b * (size_t)a.N + i) * a.out_cs + a.out_coff + h * AT_HD;
+#pragma unroll
+        for (int d = 0; d < AT_HD; ++d) at_st<T>(op + d, acc[d] * inv);
+    }
+}
+
+bool attention_supported(int nh, int kd, int hd, const TView& qkv, const TView& out) {
+    return kd == AT_KD && hd == AT_HD && nh >= 1 && qkv.c == nh * (2 * kd + hd) && out.c == nh * hd && qkv.h == out.h && qkv.w == out.w && !qkv.f32 &&
+           !out.f32;
+}
+
+hipError_t launch_attention(const TView& qkv, const TView& out, int n, int nh, int kd, int hd, float scale, int prec, hipStream_t st) {
+    if (!attention_supported(nh, kd, hd, qkv, out)) return hipErrorInvalidValue;
+    AttnDev a;
+    a.qkv = qkv.p; a.out = out.p; a.in_cs = qkv.cs; a.in_coff = qkv.coff; a.out_cs = out.cs; a.out_coff = out.coff;
+    a.N = qkv.h * qkv.w; a.nh = nh; a.scale = scale;
+    const dim3 grid((a.N + AT_THR - 1) / AT_THR, nh, n);
+    if (prec == PREC_FP32) hipLaunchKernelGGL(attention_kernel<float>, grid, dim3(AT_THR), 0, st, a);
+    else if (prec == PREC_FP16) hipLaunchKernelGGL(attention_kernel<f16s>, grid, dim3(AT_THR), 0, st, a);
+    else hipLaunchKernelGGL(attention_kernel<uint16_t>, grid, dim3(AT_THR), 0, st, a);
+    return hipGetLastError();
+}
+
+}  // namespace adas

@@ -144,6 +144,25 @@ int adas_engine_create(const char* model_path, int precision, int max_batch, ada
     }
     for (auto& b : e->bufs)
         if (b.alias_of >= 0) b.d = e->bufs[b.alias_of].d;
+    // ---- the operators without a generic fallback must be shapes their kernel takes (a damaged or foreign container fails here, not at launch)
+    for (auto& o : fo) {
+        auto view = [&](int buf, int coff, int c) { return make_view(e, buf, coff, c); };
+        bool ok = true;
+        if (o.type == OP_DWCONV)
+            ok = o.n_in == 1 && o.kh == o.kw &&
+                 dwconv_supported((int)o.kh, (int)o.stride, (int)o.pad, (int)o.res_mode, view(o.in_buf[0], o.in_coff[0], o.in_c[0]), view(o.out_buf, o.out_coff, o.out_c)) &&
+                 o.w_elems == (uint64_t)o.kh * o.kw * o.out_c && o.b_elems == (uint64_t)o.out_c;
+        else if (o.type == OP_ATTENTION)
+            ok = o.n_in == 1 && attention_supported((int)o.params[0], (int)o.params[1], (int)o.params[2], view(o.in_buf[0], o.in_coff[0], o.in_c[0]),
+                                                    view(o.out_buf, o.out_coff, o.out_c));
+        if (!ok) {
+            fclose(f);
+            free_engine(e);
+            set_error("[%s]: layer %s: unsupported %s shape", model_path, std::string(o.name, strnlen(o.name, sizeof(o.name))).c_str(),
+                      o.type == OP_DWCONV ? "depth-wise convolution" : "attention");
+            return ADAS_ERR_FORMAT;
+        }
+    }
     // ---- weights: stream the fp32 blob through a staging buffer, pack on the device
     size_t packed_total = 0;
     const size_t esz = precision == PREC_FP32 ? 4 : 2;
@@ -370,7 +389,7 @@ int adas_engine_create(const char* model_path, int precision, int max_batch, ada
             packed_total += ((size_t)op.cout_pad * op.kpad * esz + 255) & ~(size_t)255;
             op.b_off = packed_total;
             packed_total += ((size_t)op.cout_pad * 4 + 255) & ~(size_t)255;
-        } else if (o.type == OP_LAYERNORM) {
+        } else if (o.type == OP_LAYERNORM || o.type == OP_DWCONV) {
             op.w_off = packed_total;
             packed_total += ((size_t)o.w_elems * 4 + 255) & ~(size_t)255;
             op.b_off = packed_total;
@@ -478,6 +497,15 @@ int adas_engine_create(const char* model_path, int precision, int max_batch, ada
             if (hipMemcpy(base + op.w_off, h_stage.data(), o.w_elems * 4, hipMemcpyHostToDevice) != hipSuccess) { rc = ADAS_ERR_HIP; break; }
             if (!read_blob(o.b_off, o.b_elems, h_stage.data())) { rc = ADAS_ERR_FORMAT; break; }
             if (hipMemcpy(base + op.b_off, h_stage.data(), o.b_elems * 4, hipMemcpyHostToDevice) != hipSuccess) { rc = ADAS_ERR_HIP; break; }
+        } else if (o.type == OP_DWCONV) {   // container [C][kh][kw] -> device [kh*kw][C] fp32 (every precision: 36..6272 floats per layer)
+            const size_t C_ = o.out_c, T_ = (size_t)o.kh * o.kw;
+            if (!read_blob(o.w_off, o.w_elems, h_stage.data())) { rc = ADAS_ERR_FORMAT; break; }
+            std::vector<float> wt(C_ * T_);
+            for (size_t c = 0; c < C_; ++c)
+                for (size_t t = 0; t < T_; ++t) wt[t * C_ + c] = h_stage[c * T_ + t];
+            if (hipMemcpy(base + op.w_off, wt.data(), wt.size() * 4, hipMemcpyHostToDevice) != hipSuccess) { rc = ADAS_ERR_HIP; break; }
+            if (!read_blob(o.b_off, o.b_elems, h_stage.data())) { rc = ADAS_ERR_FORMAT; break; }
+            if (hipMemcpy(base + op.b_off, h_stage.data(), o.b_elems * 4, hipMemcpyHostToDevice) != hipSuccess) { rc = ADAS_ERR_HIP; break; }
         } else if (o.type == OP_DETECT_V5) {
             float anc[18];
             if (o.w_elems != 18 || !read_blob(o.w_off, 18, anc)) { rc = ADAS_ERR_FORMAT; break; }
@@ -545,7 +573,7 @@ int adas_engine_layer_kernel(const adas_engine* e, int layer, int batch, char* n
     const EngOp& op = e->ops[layer];
     const FileOp& o = op.f;
     static const char* kOther[] = {"input_nchw_kernel", "", "maxpool_kernel", "upsample2_kernel", "detect_v8_kernel", "detect_v5_kernel",
-                                   "layernorm_kernel"};
+                                   "layernorm_kernel", "dwconv_kernel", "attention_kernel"};
     if (o.type == OP_CONV && op.ds_user >= 0 && ds_folded(e, op.ds_user, batch)) {
         snprintf(name, cap, "(fused into the conv it is the shortcut of)");
     } else if (op.skip && o.type == OP_UPSAMPLE2) {
@@ -575,7 +603,7 @@ int adas_engine_layer_kernel(const adas_engine* e, int layer, int batch, char* n
     } else if (o.type == OP_DETECT_V8 && op.det_src[0] >= 0) {
         snprintf(name, cap, "detect_v8_fused_kernel");
     } else {
-        snprintf(name, cap, "%s", o.type < 7 ? kOther[o.type] : "?");
+        snprintf(name, cap, "%s", o.type < 9 ? kOther[o.type] : "?");
     }
     return ADAS_OK;
 }
@@ -697,6 +725,18 @@ int engine_run_op(adas_engine* e, int i, const float* d_in, int batch, hipStream
                                    (const float*)(wb + op.w_off), st);
             break;
         }
+        case OP_DWCONV: {
+            TView r{};
+            if (o.res_mode != RES_NONE) r = make_view(e, o.res_buf, o.res_coff, o.out_c);
+            err = launch_dwconv(make_view(e, o.in_buf[0], o.in_coff[0], o.in_c[0]), make_view(e, o.out_buf, o.out_coff, o.out_c), r, (int)o.res_mode,
+                                (const float*)(wb + op.w_off), (const float*)(wb + op.b_off), batch, (int)o.kh, (int)o.stride, (int)o.pad, (int)o.act,
+                                e->prec, st);
+            break;
+        }
+        case OP_ATTENTION:
+            err = launch_attention(make_view(e, o.in_buf[0], o.in_coff[0], o.in_c[0]), make_view(e, o.out_buf, o.out_coff, o.out_c), batch,
+                                   (int)o.params[0], (int)o.params[1], (int)o.params[2], o.params[3], e->prec, st);
+            break;
         case OP_LAYERNORM: {
             const EngBuf& ib = e->bufs[o.in_buf[0]];
             int len = ib.h * ib.w * ib.c;

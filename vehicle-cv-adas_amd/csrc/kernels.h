@@ -122,6 +122,13 @@ inline int halo_bn(int cout) { return cout <= 16 ? 16 : (cout <= 32 ? 32 : ((cou
 hipError_t launch_pack_weights_halo(const float* src, void* dst, int cout, int cout_pad, int cin, int cin_pad, int prec, hipStream_t st);
 // Linear-layer packing (CONV_FC): src [cout][cin] fp32 -> bf16 MFMA-fragment order [cout_pad/16][kpad/32][64][8]
 hipError_t launch_pack_weights_fc(const float* src, void* dst, int cout, int cout_pad, int cin, int kpad, int prec, hipStream_t st);
+// dw_attn.hip: depth-wise k x k conv (k = 3 | 7, stride 1 | 2, pad k/2; weights fp32 [k*k][C], bias fp32 [C]; residual: RES_AFTER_ACT only)
+bool dwconv_supported(int k, int stride, int pad, int res_mode, const TView& in, const TView& out);
+hipError_t launch_dwconv(const TView& in, const TView& out, const TView& res, int res_mode, const float* wgt, const float* bias, int n, int k,
+                         int stride, int pad, int act, int prec, hipStream_t st);
+// dw_attn.hip: PSA softmax attention over the H*W tokens of one qkv tensor (per head: key_dim q, key_dim k, head_dim v channels)
+bool attention_supported(int nh, int kd, int hd, const TView& qkv, const TView& out);
+hipError_t launch_attention(const TView& qkv, const TView& out, int n, int nh, int kd, int hd, float scale, int prec, hipStream_t st);
 // NHWC (compute type or fp32) activation view -> NCHW fp32 (debug / parity tap)
 hipError_t launch_nhwc_to_nchw(TView in, float* out, int n, int prec, hipStream_t st);
 

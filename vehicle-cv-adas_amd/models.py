@@ -22,7 +22,7 @@ from collections import OrderedDict
 import numpy as np
 
 MAGIC = b"ADASHIP1"
-OP_INPUT, OP_CONV, OP_MAXPOOL, OP_UPSAMPLE2, OP_DETECT_V8, OP_DETECT_V5, OP_LAYERNORM = range(7)
+OP_INPUT, OP_CONV, OP_MAXPOOL, OP_UPSAMPLE2, OP_DETECT_V8, OP_DETECT_V5, OP_LAYERNORM, OP_DWCONV, OP_ATTENTION = range(9)
 ACT_NONE, ACT_SILU, ACT_RELU = 0, 1, 2
 RES_NONE, RES_AFTER_ACT, RES_BEFORE_ACT = 0, 1, 2
 BUF_F32 = 1
@@ -44,11 +44,13 @@ HDR_SIZE, BUF_SIZE, OP_SIZE, OUT_SIZE = (struct.calcsize(f) for f in (HDR_FMT, B
 # off by 0.25 on YOLOv8s).  Below it the activations settle at the bias-driven level (rms ~0.04) and a perturbation keeps its
 # relative size through the depth (measured with oracle/nets.py EMULATE="fp16", tools/scratch/drift_cpu.py: logit error / logit
 # signal 3.4e-3 at gain 1.15 vs 7e-4 at 1.08, box error 0.12 px rms vs 6e-4 px).  The synthetic nets are therefore built just
-# BELOW the critical gain of their scale; a trained checkpoint needs none of this (DictWeights).
-SILU_GAIN = 1.08                # YOLOv8 n/s, YOLOv10n (critical gain ~1.11: 1.13 already amplifies 3x)
+# BELOW the critical gain of their scale -- not far below: there the input-dependent signal itself decays with depth while the
+# rounding noise of the last layers does not (tools/scratch/snr_cpu.py: anchor-to-anchor spread of the best class logit over its
+# fp16 error = 400-1500 just below the critical gain, 77-200 just above).  A trained checkpoint needs none of this (DictWeights).
+SILU_GAIN = 1.05                # YOLOv8 n/s, YOLOv10n (critical gain ~1.11 for n, ~1.09 for s and v10n: 0.02 above it the error is 3-10x)
 V5_SILU_GAIN = 1.15             # YOLOv5 (C3 blocks; kept at the round-1 value)
 RELU_RES_GAIN = 0.8             # ResNet lane nets: ReLU + residual adds double the variance; flat drift at 0.8 (9e-4 rel-L2 fp16)
-SYNTH_GAINS = {"yolov8m": 0.98, "yolov8l": 0.93, "yolov8x": 0.93}   # deeper Bottleneck chains: critical gain ~1.03 (m), ~0.98 (l)
+SYNTH_GAINS = {"yolov8m": 0.98, "yolov8l": 0.94, "yolov8x": 0.94}   # deeper Bottleneck chains: critical gain ~1.03 (m), ~0.97 (l)
 
 
 def synth_gain(name):
@@ -185,6 +187,36 @@ class Graph:
                  flops=fl, name=name)
         self.n_convs += 1
         self.n_params += W.size + (B.size if bias else 0)
+        return out
+
+    def dwconv(self, x, k, s, name, act=ACT_SILU, out=None, res=None, weight=None, bias=None):
+        """Depth-wise k x k conv (groups = channels, pad k // 2), BatchNorm folded: weight 'name.weight' (C,1,k,k), 'name.bias' (C,).
+        res: added after the activation (x + block(x)).  weight / bias: explicit arrays (a channel slice of a shared parameter)."""
+        c, p = x.c, k // 2
+        ho, wo = (x.h + 2 * p - k) // s + 1, (x.w + 2 * p - k) // s + 1
+        if out is None:
+            out = self.buf(ho, wo, c)
+        assert (out.h, out.w, out.c) == (ho, wo, c), (name, (out.h, out.w, out.c), (ho, wo, c))
+        W = self.w(name + ".weight", (c, 1, k, k), "conv") if weight is None else np.asarray(weight, np.float32)
+        B = self.w(name + ".bias", (c,), "bias") if bias is None else np.asarray(bias, np.float32)
+        assert W.shape == (c, 1, k, k) and B.shape == (c,)
+        woff, boff = self._blob(W.reshape(c, k * k)), self._blob(B)
+        self._op(OP_DWCONV, [x], out, kh=k, kw=k, stride=s, pad=p, act=act, res_mode=RES_AFTER_ACT if res is not None else RES_NONE, res=res,
+                 w=woff, b=boff, flops=2.0 * ho * wo * c * k * k, name=name)
+        self.n_convs += 1
+        if weight is None:
+            self.n_params += W.size + B.size
+        return out
+
+    def attention(self, qkv, num_heads, key_dim, head_dim, name, out=None):
+        """Softmax attention over the H*W tokens of `qkv` (channels per head: key_dim q, key_dim k, head_dim v): ultralytics
+        Attention.forward without its qkv / proj / pe convolutions."""
+        assert qkv.c == num_heads * (2 * key_dim + head_dim)
+        if out is None:
+            out = self.buf(qkv.h, qkv.w, num_heads * head_dim)
+        n = qkv.h * qkv.w
+        self._op(OP_ATTENTION, [qkv], out, params=[num_heads, key_dim, head_dim, float(key_dim) ** -0.5],
+                 flops=2.0 * num_heads * n * n * (key_dim + head_dim), name=name)
         return out
 
     def maxpool(self, x, k, s, p, out=None, name="maxpool"):
@@ -335,6 +367,127 @@ def yolov8(scale="n", nc=80, imgsz=640, wsrc=None, seed=0):
     g._op(OP_DETECT_V8, ins, head, params=[nc, A] + strides, name="model.22.decode")
     g.output(head, 0, [1, 4 + nc, A], "output0")
     g.meta = dict(kind="yolov8", nc=nc, anchors=A, strides=strides)
+    return g
+
+
+# =====================================================================================
+# YOLOv10 (THU-MIG yolov10n.yaml / ultralytics 8.1 fork: SCDown, PSA, C2fCIB, v10Detect) -- the reference's shipped default detector
+# (demo.py:24-30 yolov10n-coco_fp16.trt, ObjectModelType.YOLOV10).  yoloDetector.py:114,121 transposes and decodes its output as a
+# v8-layout (1, 4+nc, A) tensor [cx, cy, w, h, class probabilities]: the graph ends in the v8 decode over the ONE-TO-ONE head
+# (the branch v10 deploys; same Detect arithmetic as v8: DFL expectation, dist2bbox, sigmoid).
+# =====================================================================================
+V10_SCALES = {"n": (0.33, 0.25, 1024)}
+
+
+def _scdown(g, x, c2, k, s, name, out=None):
+    """SCDown: 1x1 Conv (SiLU) then depth-wise k x k stride-s conv without activation."""
+    t = g.conv(x, c2, 1, 1, f"{name}.cv1.conv")
+    return g.dwconv(t, k, s, f"{name}.cv2.conv", act=ACT_NONE, out=out)
+
+
+def _psa_block(g, x, name, out=None):
+    """PSA(c1, c1, e=0.5): cv1 -> (a, b); b = b + Attention(b); b = b + FFN(b); cv2(cat(a, b)).
+    Attention(dim=c, num_heads=c // 64, attn_ratio=0.5): qkv 1x1 (no act) -> per head q, k (key_dim = head_dim / 2) and v (head_dim);
+    softmax(q^T k / sqrt(key_dim)) applied to v, plus pe (depth-wise 3x3, no act) of v; proj 1x1 (no act)."""
+    c = x.c // 2
+    nh = c // 64
+    hd = c // nh
+    kd = hd // 2
+    ab = g.buf(x.h, x.w, 2 * c)
+    g.conv(x, 2 * c, 1, 1, f"{name}.cv1.conv", out=ab)
+    b = ab.slice(c, c)
+    qkv = g.conv(b, c + 2 * nh * kd, 1, 1, f"{name}.attn.qkv.conv", act=ACT_NONE)
+    att = g.attention(qkv, nh, kd, hd, f"{name}.attn.softmax")
+    # + pe(v.reshape(B, C, H, W)): output channel h * hd + d is v of head h, i.e. qkv channel h * (2 kd + hd) + 2 kd + d
+    pw = g.w(f"{name}.attn.pe.conv.weight", (c, 1, 3, 3), "conv")
+    pb = g.w(f"{name}.attn.pe.conv.bias", (c,), "bias")
+    g.n_params += pw.size + pb.size
+    summed = g.buf(x.h, x.w, c)
+    for h in range(nh):
+        v = qkv.slice(h * (2 * kd + hd) + 2 * kd, hd)
+        g.dwconv(v, 3, 1, f"{name}.attn.pe.conv.h{h}", act=ACT_NONE, out=summed.slice(h * hd, hd), res=att.slice(h * hd, hd),
+                 weight=pw[h * hd:(h + 1) * hd], bias=pb[h * hd:(h + 1) * hd])
+    b1 = g.conv(summed, c, 1, 1, f"{name}.attn.proj.conv", act=ACT_NONE, res=b, res_mode=RES_AFTER_ACT)          # b + attn(b)
+    f = g.conv(b1, 2 * c, 1, 1, f"{name}.ffn.0.conv")
+    # b + ffn(b) lands in b's own slot of the (a, b) buffer: the old b has no reader left, and cv2 reads cat(a, b) without a copy
+    g.conv(f, c, 1, 1, f"{name}.ffn.1.conv", act=ACT_NONE, res=b1, res_mode=RES_AFTER_ACT, out=b)
+    return g.conv(ab, x.c, 1, 1, f"{name}.cv2.conv", out=out)
+
+
+def _cib(g, x, name, lk, out=None, shortcut=True):
+    """CIB(c, c, e=1.0): dw3x3 -> 1x1 (2c) -> dw3x3 | fused RepVGGDW 7x7 -> 1x1 (c) -> dw3x3, all SiLU; x + cv1(x)."""
+    c = x.c
+    t = g.dwconv(x, 3, 1, f"{name}.cv1.0.conv")
+    t = g.conv(t, 2 * c, 1, 1, f"{name}.cv1.1.conv")
+    t = g.dwconv(t, 7, 1, f"{name}.cv1.2.conv.conv") if lk else g.dwconv(t, 3, 1, f"{name}.cv1.2.conv")
+    t = g.conv(t, c, 1, 1, f"{name}.cv1.3.conv")
+    return g.dwconv(t, 3, 1, f"{name}.cv1.4.conv", out=out, res=x if shortcut else None)
+
+
+def _c2fcib(g, x, c2, n, shortcut, lk, name, out=None):
+    c = c2 // 2
+    cat = g.buf(x.h, x.w, (2 + n) * c)
+    g.conv(x, 2 * c, 1, 1, f"{name}.cv1.conv", out=cat.slice(0, 2 * c))
+    for i in range(n):
+        _cib(g, cat.slice((1 + i) * c, c), f"{name}.m.{i}", lk, out=cat.slice((2 + i) * c, c), shortcut=shortcut)
+    return g.conv(cat, c2, 1, 1, f"{name}.cv2.conv", out=out)
+
+
+def yolov10(scale="n", nc=80, imgsz=640, wsrc=None, seed=0):
+    depth, width, max_ch = V10_SCALES[scale]
+    wsrc = wsrc or SynthWeights(seed, gain=synth_gain(f"yolov10{scale}"))
+    H, W = _hw(imgsz)
+    g = Graph(f"yolov10{scale}", 3, H, W, wsrc)
+    ch = lambda c: _mk(c, width, max_ch)
+    dep = lambda n: max(round(n * depth), 1)
+    c1, c2, c3, c4, c5 = ch(64), ch(128), ch(256), ch(512), ch(1024)
+    x, cin = g.input()
+    cat12 = g.buf(H // 16, W // 16, c5 + c4)   # [up(10), 6]
+    cat15 = g.buf(H // 8, W // 8, c4 + c3)     # [up(13), 4]
+    cat18 = g.buf(H // 16, W // 16, c3 + c4)   # [17, 13]
+    cat21 = g.buf(H // 32, W // 32, c4 + c5)   # [20, 10]
+    x = g.conv(x, c1, 3, 2, "model.0.conv", true_cin=cin)
+    x = g.conv(x, c2, 3, 2, "model.1.conv")
+    x = _c2f(g, x, c2, dep(3), True, "model.2")
+    x = g.conv(x, c3, 3, 2, "model.3.conv")
+    p3b = _c2f(g, x, c3, dep(6), True, "model.4", out=cat15.slice(c4, c3))
+    x = _scdown(g, p3b, c4, 3, 2, "model.5")
+    p4b = _c2f(g, x, c4, dep(6), True, "model.6", out=cat12.slice(c5, c4))
+    x = _scdown(g, p4b, c5, 3, 2, "model.7")
+    x = _c2f(g, x, c5, dep(3), True, "model.8")
+    x = _sppf(g, x, c5, "model.9")
+    p5b = _psa_block(g, x, "model.10", out=cat21.slice(c4, c5))
+    g.upsample2(p5b, out=cat12.slice(0, c5), name="model.11")
+    n13 = _c2f(g, cat12, c4, dep(3), False, "model.13", out=cat18.slice(c3, c4))
+    g.upsample2(n13, out=cat15.slice(0, c4), name="model.14")
+    p3 = _c2f(g, cat15, c3, dep(3), False, "model.16")
+    g.conv(p3, c3, 3, 2, "model.17.conv", out=cat18.slice(0, c3))
+    p4 = _c2f(g, cat18, c4, dep(3), False, "model.19")
+    _scdown(g, p4, c4, 3, 2, "model.20", out=cat21.slice(0, c4))
+    p5 = _c2fcib(g, cat21, c5, dep(3), True, True, "model.22")
+    # v10Detect, one-to-one branch (cv2: two 3x3 + 1x1 as v8; cv3: (dw3x3, 1x1), (dw3x3, 1x1), 1x1)
+    feats = [p3, p4, p5]
+    cb = max(16, feats[0].c // 4, 64)
+    cc = max(feats[0].c, min(nc, 100))
+    ins, strides = [], []
+    for i, f in enumerate(feats):
+        s = H // f.h
+        strides.append(s)
+        b = g.conv(f, cb, 3, 1, f"model.23.one2one_cv2.{i}.0.conv")
+        b = g.conv(b, cb, 3, 1, f"model.23.one2one_cv2.{i}.1.conv")
+        b = g.conv(b, 64, 1, 1, f"model.23.one2one_cv2.{i}.2", act=ACT_NONE, f32_out=True, bias_fill=1.0)
+        c = g.dwconv(f, 3, 1, f"model.23.one2one_cv3.{i}.0.0.conv")
+        c = g.conv(c, cc, 1, 1, f"model.23.one2one_cv3.{i}.0.1.conv")
+        c = g.dwconv(c, 3, 1, f"model.23.one2one_cv3.{i}.1.0.conv")
+        c = g.conv(c, cc, 1, 1, f"model.23.one2one_cv3.{i}.1.1.conv")
+        c = g.conv(c, nc, 1, 1, f"model.23.one2one_cv3.{i}.2", act=ACT_NONE, f32_out=True,
+                   bias_fill=math.log(5 / nc / (640 / s) ** 2))
+        ins += [b, c]
+    A = sum(f.h * f.w for f in feats)
+    head = g.buf(1, 1, (4 + nc) * A, f32=True)
+    g._op(OP_DETECT_V8, ins, head, params=[nc, A] + strides, name="model.23.decode")
+    g.output(head, 0, [1, 4 + nc, A], "output0")
+    g.meta = dict(kind="yolov10", nc=nc, anchors=A, strides=strides)
     return g
 
 
@@ -530,6 +683,7 @@ BUILDERS = {
     "yolov8n": lambda **k: yolov8("n", **k), "yolov8s": lambda **k: yolov8("s", **k),
     "yolov8m": lambda **k: yolov8("m", **k), "yolov8l": lambda **k: yolov8("l", **k),
     "yolov8x": lambda **k: yolov8("x", **k),
+    "yolov10n": lambda **k: yolov10("n", **k),
     "yolov5n": lambda **k: yolov5("n", **k), "yolov5s": lambda **k: yolov5("s", **k),
     "yolov5m": lambda **k: yolov5("m", **k), "yolov5l": lambda **k: yolov5("l", **k), "yolov5x": lambda **k: yolov5("x", **k),
     "ufldv2_res18": lambda **k: ufldv2("18", **k), "ufldv2_res34": lambda **k: ufldv2("34", **k),
