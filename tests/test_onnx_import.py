@@ -239,3 +239,48 @@ def test_fp16_export_and_input_size_checks(tmp_path):
         r.write_bytes(OW.model(nodes, inits, [("images", bad)], [("output0", [1, 84, 8400])]))
         with pytest.raises(ValueError):
             OI.detect_arch(OI.read_onnx(str(r)))
+
+
+def test_yolov10n_names_depthwise_and_unfused_repvggdw(tmp_path):
+    """The reference's shipped default (demo.py:24-30) exported with the v8-layout head it decodes (yoloDetector.py:114,121):
+    recognised by its PSA / one-to-one-head parameter names (or its depth-wise convolutions), weights taken by name, and an
+    un-fused RepVGGDW (7x7 + 3x3 branches, each with its own BatchNorm) re-parameterised to the single 7x7 the graph runs."""
+    W, g = synth("yolov10n")
+    rng = np.random.default_rng(1)
+    inits, nodes, want = [], [], dict(W)
+    rep = "model.22.m.0.cv1.2"
+    for i, base in enumerate(k[:-7] for k in list(W) if k.endswith(".weight")):
+        w, b = W[base + ".weight"], W[base + ".bias"]
+        grp = [OW.attr_int("group", w.shape[0])] if w.shape[1] == 1 and w.shape[0] > 1 else []
+        if base == rep + ".conv.conv":
+            # split the fused 7x7 into the two un-fused branches with BatchNorms: 7x7 part + 3x3 part
+            c = w.shape[0]
+            w3 = (rng.standard_normal((c, 1, 3, 3)) * 0.1).astype(np.float32)
+            stats = {}
+            for br in ("conv", "conv1"):
+                gmm, bt, mu, var = (rng.uniform(0.5, 1.5, c).astype(np.float32), rng.normal(0, .1, c).astype(np.float32),
+                                    rng.normal(0, .1, c).astype(np.float32), rng.uniform(0.5, 1.5, c).astype(np.float32))
+                stats[br] = (gmm, bt, mu, var)
+                for suf, a in ((".weight", gmm), (".bias", bt), (".running_mean", mu), (".running_var", var)):
+                    inits.append(OW.tensor("%s.%s.bn%s" % (rep, br, suf), a))
+            w7 = (rng.standard_normal((c, 1, 7, 7)) * 0.1).astype(np.float32)
+            inits.append(OW.tensor(rep + ".conv.conv.weight", w7))
+            inits.append(OW.tensor(rep + ".conv1.conv.weight", w3))
+            f7 = OI.fold_bn(w7, None, *stats["conv"], 1e-3)
+            f3 = OI.fold_bn(w3, None, *stats["conv1"], 1e-3)
+            want[base + ".weight"] = (f7[0] + np.pad(f3[0], ((0, 0), (0, 0), (2, 2), (2, 2)))).astype(np.float32)
+            want[base + ".bias"] = (f7[1] + f3[1]).astype(np.float32)
+            nodes.append(OW.node("Conv", ["t%d" % i, rep + ".conv.conv.weight"], ["t%da" % i], "Conv_%da" % i, [OW.attr_ints("kernel_shape", [7, 7])] + grp))
+            nodes.append(OW.node("Conv", ["t%d" % i, rep + ".conv1.conv.weight"], ["t%db" % i], "Conv_%db" % i, [OW.attr_ints("kernel_shape", [3, 3])] + grp))
+            continue
+        inits.append(OW.tensor(base + ".weight", w)); inits.append(OW.tensor(base + ".bias", b))
+        nodes.append(OW.node("Conv", ["t%d" % i, base + ".weight", base + ".bias"], ["t%d" % (i + 1)], "Conv_%d" % i,
+                             [OW.attr_ints("kernel_shape", list(w.shape[2:]))] + grp))
+    p = tmp_path / "yolov10n.onnx"
+    p.write_bytes(OW.model(nodes, inits, [("images", [1, 3, 640, 640])], [("output0", [1, 84, 8400])]))
+    m = OI.read_onnx(str(p))
+    assert OI.detect_arch(m) == ("yolov10n", dict(nc=80, imgsz=(640, 640)))
+    out, g2 = OI.convert(str(p), str(tmp_path / "v10.hipm"))
+    assert g2.name == "yolov10n" and abs(g2.flops / 1e9 - 6.76) < 0.02 and abs(g2.n_params / 1e6 - 2.30) < 0.01
+    ref = M.build("yolov10n", wsrc=M.DictWeights(want))
+    assert g2.tobytes() == ref.tobytes()

@@ -296,6 +296,15 @@ def detect_arch(m):
                 raise ValueError("YOLOv8 width not supported: " + found)
             if H % 32 or W % 32:
                 raise ValueError("YOLO input size must be multiples of 32: " + found)
+            # YOLOv10 (the reference's shipped default, demo.py:24-30) exported with the v8-layout head the reference decodes
+            # (yoloDetector.py:114,121): same stem and output shape as YOLOv8; told apart by its PSA / one-to-one-head parameters
+            # or, when the exporter dropped the names, by its depth-wise convolutions (SCDown, CIB: v8 has none)
+            is_v10 = any(".attn.qkv." in k or ".one2one_cv" in k for k in m.initializers) or \
+                any(nd["op"] == "Conv" and nd["attrs"].get("group", 1) > 1 for nd in m.nodes)
+            if is_v10:
+                if scale != "n":
+                    raise ValueError("YOLOv10 scale %r is not built (yolov10n is): %s" % (scale, found))
+                return "yolov10n", dict(nc=o[1] - 4, imgsz=(H, W))
             return "yolov8" + scale, dict(nc=o[1] - 4, imgsz=(H, W))
         if c0[2] == 6 and o[1] > o[2]:                      # (1, A, 5+nc): YOLOv5 v6.x
             scale = {16: "n", 32: "s", 48: "m", 64: "l", 80: "x"}.get(c0[0])
@@ -344,7 +353,19 @@ class OnnxWeights:
         w = self.init.get(base + ".weight")
         if w is None:
             return None
-        w = np.asarray(w, np.float32)
+        if base.endswith(".conv.conv") and base[:-len(".conv.conv")] + ".conv1.conv.weight" in self.init:
+            # an UN-fused RepVGGDW (YOLOv10 CIB with lk=True: 7x7 + 3x3 depth-wise branches, each Conv+BN): re-parameterise to the one
+            # 7x7 the deploy form runs (RepVGGDW.fuse: the 3x3 kernel zero-padded to 7x7 and added, biases added)
+            stem = base[:-len(".conv.conv")]
+            w7, b7 = self._named_conv_plain(stem + ".conv.conv")
+            w3, b3 = self._named_conv_plain(stem + ".conv1.conv")
+            b7 = np.zeros(w7.shape[0], np.float32) if b7 is None else b7
+            b3 = np.zeros(w3.shape[0], np.float32) if b3 is None else b3
+            return (w7 + np.pad(w3, ((0, 0), (0, 0), (2, 2), (2, 2)))).astype(np.float32), (b7 + b3).astype(np.float32)
+        return self._named_conv_plain(base)
+
+    def _named_conv_plain(self, base):
+        w = np.asarray(self.init[base + ".weight"], np.float32)
         b = self.init.get(base + ".bias")
         b = None if b is None else np.asarray(b, np.float32)
         stem = base[:-len(".conv")] if base.endswith(".conv") else None
