@@ -28,7 +28,7 @@ kern = {r[0]: e.layer_kernel(i, a.batch) for i, r in enumerate(rows)}
 for name, fl, kind, ms in rows:
     o = ops.get(name)
     desc = ""
-    if o is not None and o["type"] == 1:
+    if o is not None and o["type"] in (1, 7):
         v = o["ins"][0]; ov = o["out"]
         desc = f"{v.h}x{v.w}x{v.c}->{ov.c} k{o['kh']}s{o['stride']}"
     desc = f"{desc:28s} {kern[name]}"
