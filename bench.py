@@ -128,16 +128,26 @@ class SynthDetector:
 
     @staticmethod
     def threshold(best, target_per_frame, capacity=None):
-        """t such that the MEDIAN frame has ~target anchors over it and (capacity given) no frame more than 0.8 * capacity."""
+        """t such that the MEDIAN frame has ~target anchors over it and (capacity given) no frame more than 0.8 * capacity.
+
+        The threshold is placed in the WIDEST GAP of the calibration frames' best-logit values between the thresholds that would give
+        the median frame 1.25x and 0.8x the target count.  Random weights give whole uniform image regions near-identical logits
+        (clumps whose members differ by ~1e-7): a threshold at a quantile can land inside such a clump, and then even the fp32 engine
+        and the fp32 oracle (1e-6 apart) decide those anchors differently.  A trained detector's scores have no such clumps at its
+        operating threshold; the gap rule gives the synthetic one the same property on its calibration frames."""
         A = best.shape[1]
-        k_med = min(A - 2, max(1, int(round(target_per_frame))))
-        # midway between the k-th and (k+1)-th best logit of each frame: the threshold never sits ON an anchor's logit (a score of
-        # exactly box_score would be decided by the last rounding bit of whichever precision runs)
-        t = float(np.median(0.5 * (best[:, A - k_med] + best[:, A - k_med - 1])))
+        k = min(A - 2, max(1, int(round(target_per_frame))))
+        k_lo, k_hi = min(A - 2, max(k + 1, int(round(1.25 * k)))), max(1, int(round(0.8 * k)))
+        t_lo, t_hi = float(np.median(best[:, A - k_lo])), float(np.median(best[:, A - k_hi]))
         if capacity is not None:
             k_cap = min(A - 1, max(1, int(0.8 * capacity)))
-            t = max(t, float(best[:, A - k_cap].max()))
-        return t
+            t_cap = float(best[:, A - k_cap].max())
+            t_lo, t_hi = max(t_lo, t_cap), max(t_hi, t_cap + abs(t_cap) * 1e-3 + 1e-6)
+        vals = np.unique(best[(best >= t_lo) & (best <= t_hi)])
+        if len(vals) >= 2:
+            i = int(np.argmax(np.diff(vals)))
+            return float(0.5 * (float(vals[i]) + float(vals[i + 1])))
+        return float(0.5 * (t_lo + t_hi))
 
     @staticmethod
     def counts(best, t):

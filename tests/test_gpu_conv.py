@@ -450,3 +450,38 @@ def test_fp16_stores_saturate_instead_of_overflowing(CE, k, cin, cout):
     assert (got[over] == 65504.0).all()
     inr = want < 60000.0
     assert np.abs(got[inr] - want[inr]).max() <= 2e-3 * np.abs(want[inr]).max()
+
+
+@pytest.mark.parametrize("case", [(768, 256, 40, 40, 2), (1024, 512, 20, 20, 2), (1280, 512, 20, 20, 16), (2048, 512, 40, 40, 8),
+                                  (1152, 576, 23, 37, 3), (768, 80, 20, 20, 2)], ids=str)
+@pytest.mark.parametrize("prec,tol", [("fp16", 2e-3), ("bf16", 1e-2)])
+def test_wide_pointwise_conv_gemm_kernel(CE, case, prec, tol):
+    """conv_pwg.hip: 1x1 convs with Cin > 512 (the C2f / SPPF output convs of YOLOv8 s/m/l/x) as a K-looped MFMA GEMM, 128- and
+    64-pixel tiles, ragged pixel and channel tails, with SiLU."""
+    cin, cout, H, W, batch = case
+    rel, mx = run_case(CE, H, W, cin, cout, 1, 1, M.ACT_SILU, M.RES_NONE, prec, batch=batch, expect_kernel="conv_pwg_kernel")
+    assert rel < tol, (case, prec, rel, mx)
+
+
+def test_wide_pointwise_conv_with_residual(CE):
+    rel, mx = run_case(CE, 20, 20, 1024, 1024, 1, 1, M.ACT_SILU, M.RES_AFTER_ACT, "fp16", batch=2, expect_kernel="conv_pwg_kernel")
+    assert rel < 2e-3, (rel, mx)
+
+
+@pytest.mark.parametrize("name,batch", [("yolov8s", 1), ("yolov8s", 64), ("yolov8m", 16), ("yolov8l", 1), ("yolov8l", 16), ("yolov8x", 4), ("yolov10n", 64)])
+def test_no_generic_fallback_kernel_in_16bit_modes(CE, name, batch):
+    """Every conv of the YOLOv8 s / m / l / x graphs (and YOLOv10n's plain convs) resolves to a specialised kernel in the 16-bit
+    modes: conv_igemm_kernel (the generic implicit GEMM) is the fp32 parity path and the shapes nothing else takes.  The only
+    exception allowed: 1x1 convs WITH a residual (PSA's proj / ffn.1 in YOLOv10n, Cin 128 / 256)."""
+    import netutil
+    path, W, g = netutil.model(name)
+    e = CE.HipEngine(path, "fp16", batch)
+    ops = {o["name"]: o for o in g.ops}
+    bad = []
+    for i in range(e.stats()["num_layers"]):
+        k = e.layer_kernel(i, batch)
+        nm = e.layer_info(i)[0]
+        if "conv_igemm" in k and not (ops[nm]["kh"] == 1 and ops[nm]["res"] is not None):
+            bad.append((nm, k))
+    e.close()
+    assert not bad, bad

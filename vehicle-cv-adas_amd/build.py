@@ -26,6 +26,7 @@ UNITS = [
     ("conv_pair.hip", []),
     ("conv_fc.hip", []),
     ("conv_pw.hip", []),
+    ("conv_pwg.hip", []),
     ("conv_stem.hip", []),
     ("aux_kernels.hip", []),
     ("dw_attn.hip", []),

@@ -326,6 +326,8 @@ const char* conv_kernel_name(const ConvArgs& a, int prec, int kernel) {
         snprintf(buf, sizeof(buf), "conv_pw_kernel<%d>", (a.in.c + 31) / 32);
     } else if (kernel == CONV_STEM) {
         snprintf(buf, sizeof(buf), "conv_stem_kernel<%d,%d,%s>", a.kh, (a.out.c + 15) / 16, actn);
+    } else if (kernel == CONV_GATHER && pwg_applicable(prec, a.kh, a.kw, a.stride, a.pad, a.in, a.out, a.res, a.res_mode)) {
+        snprintf(buf, sizeof(buf), "%s", pwg_kernel_name(a.m, a.out.c));
     } else {
         Tile t = pick_tile(a, prec);
         const bool of32 = a.out.f32 || prec == PREC_FP32;
@@ -432,6 +434,10 @@ hipError_t launch_conv(const ConvArgs& a, int prec, hipStream_t st) {
     }
     if (pl.kernel == CONV_PW) return launch_conv_pw(a, st);
     if (pl.kernel == CONV_FC) return a.res_mode == RES_NONE ? launch_fc(a, st) : hipErrorInvalidValue;
+    if (pwg_applicable(prec, a.kh, a.kw, a.stride, a.pad, a.in, a.out, a.res, a.res_mode)) {   // wide 1x1: same packing, K-looped GEMM kernel
+        hipError_t e = launch_conv_pwg(a, st);
+        if (e != hipErrorNotSupported) return e;
+    }
     ConvDev d;
     d.in = a.in.p; d.wgt = a.wgt; d.bias = a.bias; d.out = a.out.p; d.res = a.res.p;
     d.in_cs = a.in.cs; d.in_coff = a.in.coff; d.cin = a.in.c; d.H = a.in.h; d.W = a.in.w;

@@ -75,6 +75,10 @@ hipError_t launch_pack_weights_pair(const float* src, void* dst, int c, int prec
 hipError_t launch_conv_pair(const TView& x, const TView& y, const void* w1, const float* b1, const void* w2, const float* b2, int n, bool has_res,
                             int prec, hipStream_t st);
 bool pw_applicable(int prec, int kh, int kw, int stride, int pad, int res_mode, const TView& in, const TView& out);  // conv_pw.hip
+// conv_pwg.hip: 1x1 stride-1 convs conv_pw does not take (Cin > 512), a K-looped MFMA GEMM on the generic [cout_pad][K] weight packing
+bool pwg_applicable(int prec, int kh, int kw, int stride, int pad, const TView& in, const TView& out, const TView& res, int res_mode);
+hipError_t launch_conv_pwg(const ConvArgs& a, hipStream_t st);
+const char* pwg_kernel_name(int m, int cout);
 // returns hipSuccess or the launch error.  prec: PREC_*.
 hipError_t launch_conv(const ConvArgs& a, int prec, hipStream_t st);
 const char* conv_tile_name(const ConvArgs& a, int prec);
