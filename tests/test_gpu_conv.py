@@ -453,11 +453,12 @@ def test_fp16_stores_saturate_instead_of_overflowing(CE, k, cin, cout):
 
 
 @pytest.mark.parametrize("case", [(768, 256, 40, 40, 2), (1024, 512, 20, 20, 2), (1280, 512, 20, 20, 16), (2048, 512, 40, 40, 8),
-                                  (1152, 576, 23, 37, 3), (768, 80, 20, 20, 2)], ids=str)
+                                  (1152, 576, 23, 37, 3), (768, 80, 20, 20, 2), (400, 320, 40, 40, 2), (160, 160, 80, 80, 2), (328, 64, 20, 20, 2)], ids=str)
 @pytest.mark.parametrize("prec,tol", [("fp16", 2e-3), ("bf16", 1e-2)])
 def test_wide_pointwise_conv_gemm_kernel(CE, case, prec, tol):
-    """conv_pwg.hip: 1x1 convs with Cin > 512 (the C2f / SPPF output convs of YOLOv8 s/m/l/x) as a K-looped MFMA GEMM, 128- and
-    64-pixel tiles, ragged pixel and channel tails, with SiLU."""
+    """conv_pwg.hip: 1x1 convs with Cin > 512 (the C2f / SPPF output convs of YOLOv8 s/m/l/x) and the K-step counts conv_pw is not
+    instantiated for (YOLOv8x 160 / 400 channels; a Cin that is no multiple of 32) as a K-looped MFMA GEMM: 128- and 64-pixel tiles,
+    ragged pixel, channel and K tails, with SiLU."""
     cin, cout, H, W, batch = case
     rel, mx = run_case(CE, H, W, cin, cout, 1, 1, M.ACT_SILU, M.RES_NONE, prec, batch=batch, expect_kernel="conv_pwg_kernel")
     assert rel < tol, (case, prec, rel, mx)

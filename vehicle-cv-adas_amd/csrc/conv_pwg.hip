@@ -1,5 +1,5 @@
-// conv_pwg.hip -- pointwise (1x1, stride 1) convolution as a K-looped MFMA GEMM: the wide 1x1 layers conv_pw.hip does not take
-// (Cin > 512: its weights-resident-in-LDS design stops there).  These are the C2f / SPPF output convs over concats of the s / m / l / x
+// conv_pwg.hip -- pointwise (1x1, stride 1) convolution as a K-looped MFMA GEMM: the 1x1 layers conv_pw.hip does not take
+// (Cin > 512: its weights-resident-in-LDS design stops there; and the K-step counts it is not instantiated for, e.g. YOLOv8x's 160 / 400).  These are the C2f / SPPF output convs over concats of the s / m / l / x
 // scales (YOLOv8s 768 / 1024, YOLOv8l 1024 .. 2048, YOLOv8x up to 2560 input channels): arithmetic intensity
 // 2*Cin*Cout / (2*(Cin+Cout)) > 300 FLOP/B -- MFMA-bound GEMMs, not streaming layers.
 //
@@ -26,7 +26,7 @@ struct PwgDev {
     const float* bias;
     uint16_t* out;
     const uint16_t* res;
-    int in_cs, in_coff, K;
+    int in_cs, in_coff, K, KP;   // K = Cin (any multiple of 8), KP = weight row pitch (K rounded up to 32)
     int out_cs, out_coff, cout;
     int res_cs, res_coff, res_mode;
     int act, M;
@@ -57,14 +57,25 @@ __global__ __launch_bounds__(256, 2) void conv_pwg_kernel(PwgDev a) {
         aok[i] = m < a.M;
         ap[i] = a.in + (size_t)(aok[i] ? m : 0) * a.in_cs + a.in_coff + kc * 8;
     }
-    const uint16_t* bp = a.wgt + (size_t)(n0 + r0) * a.K + kc * 8;   // weight rows are padded to a multiple of 128: always in range
+    const uint16_t* bp = a.wgt + (size_t)(n0 + r0) * a.KP + kc * 8;   // weight rows are padded to a multiple of 128: always in range
 
     gu32x4 ra[A_IT], rb[B_IT];
+    // the last K step of a Cin that is not a multiple of 64: chunks past Cin are fetched from the step's first chunk (in range) and
+    // zeroed by a select -- no branch around the loads (hipcc would wait vmcnt(0) at the join)
     auto gload = [&](int k0) {
+        const bool kin = k0 + kc * 8 < a.K;
+        const int ko = kin ? k0 : k0 - kc * 8;
+        const gu32x4 zero{0u, 0u, 0u, 0u};
 #pragma unroll
-        for (int i = 0; i < A_IT; ++i) ra[i] = *reinterpret_cast<const gu32x4*>(ap[i] + k0);   // rows past M re-read pixel 0: never stored
+        for (int i = 0; i < A_IT; ++i) {   // rows past M re-read pixel 0: never stored
+            const gu32x4 v = *reinterpret_cast<const gu32x4*>(ap[i] + ko);
+            ra[i] = kin ? v : zero;
+        }
 #pragma unroll
-        for (int i = 0; i < B_IT; ++i) rb[i] = *reinterpret_cast<const gu32x4*>(bp + (size_t)(32 * i) * a.K + k0);
+        for (int i = 0; i < B_IT; ++i) {
+            const gu32x4 v = *reinterpret_cast<const gu32x4*>(bp + (size_t)(32 * i) * a.KP + ko);
+            rb[i] = kin ? v : zero;
+        }
     };
     auto lstore = [&](int buf) {
 #pragma unroll
@@ -80,7 +91,7 @@ __global__ __launch_bounds__(256, 2) void conv_pwg_kernel(PwgDev a) {
         for (int j = 0; j < TM; ++j) acc[i][j] = gf32x4{0.f, 0.f, 0.f, 0.f};
 
     const int lrow = lane & 15, kg = lane >> 4;
-    const int KT = a.K / PWG_KS;
+    const int KT = (a.K + PWG_KS - 1) / PWG_KS;
     gload(0);
     lstore(0);
     __syncthreads();
@@ -147,7 +158,7 @@ bool pwg_applicable(int prec, int kh, int kw, int stride, int pad, const TView& 
     if (!pwg_enabled() || !prec_is16(prec) || in.f32 || out.f32) return false;
     if (kh != 1 || kw != 1 || stride != 1 || pad != 0) return false;
     if (in.h == 1 && in.w == 1) return false;   // Linear layers: conv_fc.hip
-    if ((in.c % PWG_KS) || in.c < 2 * PWG_KS || (in.cs & 7) || (in.coff & 7) || (out.c & 3) || (out.cs & 3) || (out.coff & 3)) return false;
+    if ((in.c & 7) || in.c < 2 * PWG_KS || (in.cs & 7) || (in.coff & 7) || (out.c & 3) || (out.cs & 3) || (out.coff & 3)) return false;
     if (res_mode != RES_NONE && (res.f32 || (res.cs & 3) || (res.coff & 3))) return false;
     return true;
 }
@@ -160,10 +171,10 @@ static int pwg_bm(int m, int cout) {
 const char* pwg_kernel_name(int m, int cout) { return pwg_bm(m, cout) == 128 ? "conv_pwg_kernel<128>" : "conv_pwg_kernel<64>"; }
 
 hipError_t launch_conv_pwg(const ConvArgs& a, hipStream_t st) {
-    if (!pwg_applicable(a.prec, a.kh, a.kw, a.stride, a.pad, a.in, a.out, a.res, a.res_mode) || a.kpad != a.in.c) return hipErrorNotSupported;
+    if (!pwg_applicable(a.prec, a.kh, a.kw, a.stride, a.pad, a.in, a.out, a.res, a.res_mode) || a.kpad < a.in.c) return hipErrorNotSupported;
     PwgDev d;
     d.in = (const uint16_t*)a.in.p; d.wgt = (const uint16_t*)a.wgt; d.bias = a.bias; d.out = (uint16_t*)a.out.p; d.res = (const uint16_t*)a.res.p;
-    d.in_cs = a.in.cs; d.in_coff = a.in.coff; d.K = a.in.c;
+    d.in_cs = a.in.cs; d.in_coff = a.in.coff; d.K = a.in.c; d.KP = a.kpad;
     d.out_cs = a.out.cs; d.out_coff = a.out.coff; d.cout = a.out.c;
     d.res_cs = a.res.cs; d.res_coff = a.res.coff; d.res_mode = a.res_mode;
     d.act = a.act; d.M = a.m;
