@@ -67,6 +67,10 @@ def cam_frames(n, seed, h=720, w=1280):
             x0, y0 = rng.integers(0, w - 20), rng.integers(0, h - 20)
             x1, y1 = min(w, x0 + rng.integers(20, 400)), min(h, y0 + rng.integers(20, 300))
             img[y0:y1, x0:x1] = rng.integers(0, 255, 3)
+        # sensor noise over everything, the filled rectangles included: a perfectly uniform region gives every anchor inside it the SAME
+        # score and box distances, i.e. exact ties in the NMS (order of equal scores, IoU of equal neighbours sitting on the threshold)
+        # that no camera frame has and that any rounding -- fp16 or a different fp32 summation order -- resolves differently
+        img = np.clip(img + rng.integers(-6, 7, img.shape), 0, 255)
         out[i] = img.astype(np.uint8)
     return out
 

@@ -132,7 +132,7 @@ bool pw_applicable(int prec, int kh, int kw, int stride, int pad, int res_mode, 
     if ((in.c & 7) || (in.cs & 7) || (in.coff & 7) || (out.c & 3) || (out.cs & 3) || (out.coff & 3)) return false;
     const int ks = (in.c + 31) / 32, nt = (out.c + 15) / 16;
     if (ks > 16) return false;
-    if (!(ks <= 4 || ks == 6 || ks == 8 || ks == 12 || ks == 16)) return false;
+    if (!(ks <= 6 || ks == 8 || ks == 10 || ks == 12 || ks == 16)) return false;   // instantiated K-step counts (5 / 10: YOLOv8x's 160 / 320 channels)
     return pw_tiles_per_wg(nt, ks) > 0;
 }
 
@@ -155,6 +155,8 @@ static hipError_t pw_launch_ks(const PwDev& d, int ks, bool tail, dim3 grid, siz
         case 2: return pw_launch<E, 2>(d, tail, grid, lds, st);
         case 3: return pw_launch<E, 3>(d, tail, grid, lds, st);
         case 4: return pw_launch<E, 4>(d, tail, grid, lds, st);
+        case 5: return pw_launch<E, 5>(d, tail, grid, lds, st);
+        case 10: return pw_launch<E, 10>(d, tail, grid, lds, st);
         case 6: return pw_launch<E, 6>(d, tail, grid, lds, st);
         case 8: return pw_launch<E, 8>(d, tail, grid, lds, st);
         case 12: return pw_launch<E, 12>(d, tail, grid, lds, st);

@@ -303,7 +303,8 @@ bool stem_applicable(int prec, int in_c_true, int kh, int kw, int stride, int pa
     if (!prec_is16(prec) || in_c_true > 3 || stride != 2 || res_mode != RES_NONE) return false;
     if (!(kh == 3 || kh == 6 || kh == 7) || kw != kh) return false;  // kw <= 8 pixel slots per K step
     if (pad > kh / 2) return false;
-    if (out.f32 || !(out.c == 16 || out.c == 32 || out.c == 64)) return false;
+    if (out.f32 || !(out.c == 16 || out.c == 32 || out.c == 48 || out.c == 64 || out.c == 80)) return false;   // n, s, m, l, x stems
+    if (pool && out.c != 64) return false;
     const TView& o = pool ? pool_out : out;
     if ((o.cs & 7) || (o.coff & 7) || o.f32) return false;
     if (pool && (kh != 7 || out.c != 64 || act != ACT_RELU)) return false;  // the ResNet stem is the only pooled instance
@@ -391,8 +392,8 @@ static hipError_t stem_launch_shape(const StemDev& d, int kh, int nt, bool pool,
     if (pool) return stem_launch_act<E, 7, 4, true>(d, act, packed_in, st);
 #define STEM_CASE(KH_, NT_) \
     if (kh == KH_ && nt == NT_) return stem_launch_act<E, KH_, NT_, false>(d, act, packed_in, st);
-    STEM_CASE(3, 1) STEM_CASE(3, 2) STEM_CASE(3, 4)
-    STEM_CASE(6, 1) STEM_CASE(6, 2) STEM_CASE(6, 4)
+    STEM_CASE(3, 1) STEM_CASE(3, 2) STEM_CASE(3, 3) STEM_CASE(3, 4) STEM_CASE(3, 5)
+    STEM_CASE(6, 1) STEM_CASE(6, 2) STEM_CASE(6, 3) STEM_CASE(6, 4) STEM_CASE(6, 5)
     STEM_CASE(7, 4)
 #undef STEM_CASE
     return hipErrorInvalidValue;

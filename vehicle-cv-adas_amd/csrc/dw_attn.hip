@@ -12,6 +12,7 @@
 // All three precisions run the same code on the storage type (elem16.h / float).
 #include "kernels.h"
 #include "elem16.h"
+#include <stdlib.h>
 
 namespace adas {
 
@@ -219,6 +220,115 @@ __global__ __launch_bounds__(AT_THR) void attention_kernel(AttnDev a) {
     }
 }
 
+// ---- 16-bit modes: the same attention on the matrix cores (flash-attention form).  A wave owns 16 queries, a workgroup (4 waves) 64;
+// keys / values stream through LDS in chunks of 128 tokens.  S = K Q^T as 8 MFMAs per chunk with K as the A operand (one 32-deep step:
+// key_dim = 32), so a lane ends up with 4 consecutive KEYS of one query per 16-key tile -- which is, two tiles at a time, exactly the
+// B-operand fragment of the second product out^T = V^T P (8 k-elements per lane: the sum over keys does not care about their order, so
+// "k index e" is defined as tile 2u row 4g+e / tile 2u+1 row 4g+e-4 and V^T is read from LDS in that order): no lane exchange between
+// the two GEMMs.  Softmax statistics per query live in the 4 lanes that share its column (two xor-shuffles), online over chunks.
+constexpr int FA_CH = 128, FA_KP = AT_KD + 8, FA_VP = FA_CH + 16;   // LDS pitches in elements: K rows 80 B, V^T rows 288 B
+
+template <typename E>
+__global__ __launch_bounds__(256) void attention_mfma_kernel(AttnDev a) {
+    E::enter();
+    __shared__ __attribute__((aligned(16))) uint16_t Ks[FA_CH][FA_KP];
+    __shared__ __attribute__((aligned(16))) uint16_t Vt[AT_HD][FA_VP];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = blockIdx.y;
+    const int lrow = lane & 15, g = lane >> 4;
+    const size_t b = blockIdx.z;
+    const int hc = h * (2 * AT_KD + AT_HD);
+    const uint16_t* base = (const uint16_t*)a.qkv + b * (size_t)a.N * a.in_cs + a.in_coff + hc;
+    const int qi = blockIdx.x * 64 + wave * 16 + lrow;          // this lane's query (B-operand column)
+    const e_u32x4 qf = *reinterpret_cast<const e_u32x4*>(base + (size_t)(qi < a.N ? qi : 0) * a.in_cs + g * 8);
+    e_f32x4 acc[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) acc[dt] = e_f32x4{0.f, 0.f, 0.f, 0.f};
+    float m = -INFINITY, l = 0.f;
+    for (int j0 = 0; j0 < a.N; j0 += FA_CH) {
+        const int nj = a.N - j0 < FA_CH ? a.N - j0 : FA_CH;
+        __syncthreads();
+        // K chunk: 128 keys x 32 channels = 512 16-byte pieces; V chunk transposed: 128 keys x 64 channels = 1024 pieces, 8 b16 stores each
+        for (int e = tid; e < FA_CH * 4; e += 256) {
+            const int j = e >> 2, c8 = e & 3;
+            e_u32x4 v{0u, 0u, 0u, 0u};
+            if (j < nj) v = *reinterpret_cast<const e_u32x4*>(base + (size_t)(j0 + j) * a.in_cs + AT_KD + c8 * 8);
+            *reinterpret_cast<e_u32x4*>(&Ks[j][c8 * 8]) = v;
+        }
+        for (int e = tid; e < FA_CH * 8; e += 256) {
+            const int j = e >> 3, c8 = e & 7;
+            e_u32x4 v{0u, 0u, 0u, 0u};
+            if (j < nj) v = *reinterpret_cast<const e_u32x4*>(base + (size_t)(j0 + j) * a.in_cs + 2 * AT_KD + c8 * 8);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                Vt[c8 * 8 + 2 * q][j] = (uint16_t)(v[q] & 0xffffu);
+                Vt[c8 * 8 + 2 * q + 1][j] = (uint16_t)(v[q] >> 16);
+            }
+        }
+        __syncthreads();
+        // S tile: keys (t * 16 + 4g + r) x query lrow
+        e_f32x4 sc[FA_CH / 16];
+        float cm = -INFINITY;
+#pragma unroll
+        for (int t = 0; t < FA_CH / 16; ++t) {
+            const e_u32x4 kf = *reinterpret_cast<const e_u32x4*>(&Ks[t * 16 + lrow][g * 8]);
+            sc[t] = E::mfma(kf, qf, e_f32x4{0.f, 0.f, 0.f, 0.f});
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const bool valid = t * 16 + g * 4 + r < nj;
+                sc[t][r] = valid ? sc[t][r] * a.scale : -INFINITY;
+                cm = fmaxf(cm, sc[t][r]);
+            }
+        }
+        cm = fmaxf(cm, __shfl_xor(cm, 16));
+        cm = fmaxf(cm, __shfl_xor(cm, 32));
+        const float mn = fmaxf(m, cm);
+        const float corr = __expf(m - mn);
+        float ls = 0.f;
+        uint32_t pk[FA_CH / 16][2];
+#pragma unroll
+        for (int t = 0; t < FA_CH / 16; ++t) {
+            float p[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                p[r] = __expf(sc[t][r] - mn);
+                ls += p[r];
+            }
+            pk[t][0] = E::pack2(p[0], p[1]);
+            pk[t][1] = E::pack2(p[2], p[3]);
+        }
+        ls += __shfl_xor(ls, 16);
+        ls += __shfl_xor(ls, 32);
+        l = l * corr + ls;
+        m = mn;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[dt][r] *= corr;
+        }
+#pragma unroll
+        for (int u = 0; u < FA_CH / 32; ++u) {
+            const e_u32x4 pf{pk[2 * u][0], pk[2 * u][1], pk[2 * u + 1][0], pk[2 * u + 1][1]};
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                const uint16_t* vr = &Vt[dt * 16 + lrow][u * 32 + g * 4];
+                const uint2 v0 = *reinterpret_cast<const uint2*>(vr), v1 = *reinterpret_cast<const uint2*>(vr + 16);
+                acc[dt] = E::mfma(e_u32x4{v0.x, v0.y, v1.x, v1.y}, pf, acc[dt]);
+            }
+        }
+    }
+    if (qi < a.N) {
+        const float inv = 1.0f / l;
+        uint16_t* op = (uint16_t*)a.out + (b * (size_t)a.N + qi) * a.out_cs + a.out_coff + h * AT_HD + g * 4;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+            uint2 q;
+            q.x = E::pack2(acc[dt][0] * inv, acc[dt][1] * inv);
+            q.y = E::pack2(acc[dt][2] * inv, acc[dt][3] * inv);
+            *reinterpret_cast<uint2*>(op + dt * 16) = q;
+        }
+    }
+}
+
 bool attention_supported(int nh, int kd, int hd, const TView& qkv, const TView& out) {
     return kd == AT_KD && hd == AT_HD && nh >= 1 && qkv.c == nh * (2 * kd + hd) && out.c == nh * hd && qkv.h == out.h && qkv.w == out.w && !qkv.f32 &&
            !out.f32;
@@ -230,8 +340,18 @@ hipError_t launch_attention(const TView& qkv, const TView& out, int n, int nh, i
     a.qkv = qkv.p; a.out = out.p; a.in_cs = qkv.cs; a.in_coff = qkv.coff; a.out_cs = out.cs; a.out_coff = out.coff;
     a.N = qkv.h * qkv.w; a.nh = nh; a.scale = scale;
     const dim3 grid((a.N + AT_THR - 1) / AT_THR, nh, n);
+    static int mfma = -1;
+    if (mfma < 0) {
+        const char* e = getenv("ADAS_NO_ATTN_MFMA");
+        mfma = (e && e[0] == '1') ? 0 : 1;
+    }
+    const bool aligned = !((qkv.cs | qkv.coff) & 7) && !((out.cs | out.coff) & 3);
     if (prec == PREC_FP32) hipLaunchKernelGGL(attention_kernel<float>, grid, dim3(AT_THR), 0, st, a);
-    else if (prec == PREC_FP16) hipLaunchKernelGGL(attention_kernel<f16s>, grid, dim3(AT_THR), 0, st, a);
+    else if (mfma && aligned) {
+        const dim3 g2((a.N + 63) / 64, nh, n);
+        if (prec == PREC_FP16) hipLaunchKernelGGL(attention_mfma_kernel<Fp16>, g2, dim3(256), 0, st, a);
+        else hipLaunchKernelGGL(attention_mfma_kernel<Bf16>, g2, dim3(256), 0, st, a);
+    } else if (prec == PREC_FP16) hipLaunchKernelGGL(attention_kernel<f16s>, grid, dim3(AT_THR), 0, st, a);
     else hipLaunchKernelGGL(attention_kernel<uint16_t>, grid, dim3(AT_THR), 0, st, a);
     return hipGetLastError();
 }
