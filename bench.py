@@ -92,9 +92,8 @@ class SynthDetector:
     bias) > t", so t fixes how many anchors of each frame become candidates.  The last cls conv is scaled by `sharpen` so that the
     surviving scores spread over (0.4, 1) the way a trained head's do -- otherwise every score sits just above 0.4 and ByteTrack
     (new tracks need >= 0.6, byteTracker.py:43,162) never starts a track.  `sharpen=None` derives the factor from the measured
-    spread of the best logits (SPREAD standard deviations of it become SPREAD logit units), so the workload does not depend on the
-    synthetic weights' gain."""
-    SPREAD = 2.0      # the top anchors of a frame (~1.5 sigma over the threshold) reach conf ~0.9
+    logits (fix_sharpen), so the workload does not depend on the synthetic weights' gain."""
+    TOP_CONF = 0.999   # score of the strongest anchor of the calibration frames
 
     def __init__(self, M, CE, name, workdir, tag, sharpen=None, batch=16):
         self.M, self.CE, self.name, self.workdir, self.tag, self.batch = M, CE, name, workdir, tag, batch
@@ -124,10 +123,15 @@ class SynthDetector:
         best.sort(axis=1)
         return best
 
-    def fix_sharpen(self, best):
-        """Choose the cls scale from the first batch of best logits (once)."""
+    def fix_sharpen(self, best, t):
+        """Choose the cls scale from the calibration frames' best logits and their threshold t (once): the strongest anchor maps to
+        TOP_CONF.  The best-logit distribution of a random-weight net is heavy-tailed (the strongest anchors sit ~8 sigma over the
+        threshold, the median candidate at 1-10 % of that): scaling by the standard deviation would push the top anchors into the
+        sigmoid's saturation, where fp32 scores differ in their last bit only and the NMS order among them is decided by rounding."""
         if self.sharpen is None:
-            self.sharpen = float(self.SPREAD / max(float(best.std()), 1e-12))
+            top = float(best.max())
+            span = math.log(self.TOP_CONF / (1.0 - self.TOP_CONF)) - math.log(0.4 / 0.6)
+            self.sharpen = float(span / max(top - t, 1e-12))
         return self.sharpen
 
     @staticmethod
@@ -180,8 +184,9 @@ def build_detector(M, CE, name, frames, workdir, tag, target_per_frame=30.0, sha
     with `capacity`, no frame more than 0.8 * capacity."""
     sd = SynthDetector(M, CE, name, workdir, tag, sharpen, batch=min(len(frames), 16))
     best = sd.best_logits(frames)
-    sd.fix_sharpen(best)
-    return sd.finish(SynthDetector.threshold(best, target_per_frame, capacity))
+    t = SynthDetector.threshold(best, target_per_frame, capacity)
+    sd.fix_sharpen(best, t)
+    return sd.finish(t)
 
 
 def measure_parity(det_eng, lane_eng, det_name, lane_name, Wd, Wl, dframes, lframes, precision):
@@ -217,7 +222,7 @@ def measure_parity(det_eng, lane_eng, det_name, lane_name, Wd, Wl, dframes, lfra
             "lane_rel_l2_outputs": float("%.3e" % rel(lflat_g, lflat_w)), "lane_max_abs_outputs": float("%.3e" % np.abs(lflat_g - lflat_w).max()),
             "lane_max_ref_outputs": round(float(np.abs(lflat_w).max()), 2),
             "tolerance": "north_star: 1e-3 on conv activations; fp32 mode meets it absolutely (tests/test_gpu_nets.py, test_gpu_configs.py); "
-                         "16-bit modes: rel-L2 <= 3e-3 (fp16) / 3e-2 (bf16) on activations, calibrated heads max-abs <= 8e-3 on class "
+                         "16-bit modes: rel-L2 <= 5e-3 (fp16) / 4e-2 (bf16) on activations, calibrated heads max-abs <= 8e-3 on class "
                          "probabilities and <= 0.1 px on boxes in fp16 (tests/test_gpu_configs.py)"}
 
 
@@ -282,6 +287,65 @@ def measure_e2e(L, make_pipe, det_name, lane_name, Wd, Wl, d_cam, h_cam, S, hold
                 "against": "the whole fp32 oracle chain on the timed frames (oracle outputs cached per distinct frame)",
                 "seconds": round(time.perf_counter() - t0, 1), "mismatches": st.mismatch_log[:4]})
     return out
+
+
+def measure_traffic_pmc(dom_label, args):
+    """HBM bytes per launch of the dominant kernel FROM THIS RUN: PMC counters need rocprofv3 around a process, so two short child
+    runs of this same script (same preset / precision / streams, nets on one stream, 3 steps, no extras) are wrapped in
+    `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` (separate passes: FETCH_SIZE takes 3 of the 4 TCC counter slots) with
+    --kernel-trace only, and the per-dispatch averages of the named kernel are combined as MI355X_MICROARCH.md prescribes for gfx950
+    (FETCH_SIZE x2 for 16 B/lane reads, WRITE_SIZE as reported; both in KiB).  -> (bytes or None, source dict)."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    etag = "Fp16" if args.precision == "fp16" else "Bf16"
+    acts = {"RELU": 2, "SILU": 1, "NONE": 0}
+    pat = None
+    for kname in ("conv_h8_kernel", "conv_halo_rw_kernel", "conv_s2p_kernel"):
+        if dom_label.startswith(kname + "<"):
+            inner = dom_label[len(kname) + 1:-1].split(",")
+            if kname == "conv_h8_kernel":
+                pat = f"{kname}<adas::{etag}, {acts.get(inner[0], 2)}"
+            elif kname == "conv_s2p_kernel":
+                pat = f"{kname}<adas::{etag}, {acts.get(inner[0], 2)}"
+            else:
+                pat = f"{kname}<adas::{etag}, {inner[0]}, {acts.get(inner[1], 2)}"
+    if dom_label.startswith("conv_halo_kernel<"):
+        bn, act, st = dom_label[len("conv_halo_kernel<"):-1].split(",")
+        pat = f"conv_halo_kernel<adas::{etag}, {bn}, {acts.get(act, 1)}, {st[1:]}"
+    if pat is None or args.precision == "fp32" or not os.path.exists(exe):
+        return None, None
+    tot = {}
+    t0 = time.perf_counter()
+    try:
+        for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+            d = tempfile.mkdtemp(prefix="adas_pmc_")
+            cmd = [exe, "--pmc", ctr, "--kernel-trace", "--output-format", "csv", "-d", d, "-o", "p", "--", sys.executable, os.path.abspath(__file__),
+                   "--preset", args.preset, "--precision", args.precision, "--streams", str(args.streams), "--micro-batch", str(args.micro_batch),
+                   "--det", args.det, "--lane", args.lane, "--no-cpu-baseline", "--no-extras", "--no-overlap", "--steps", "3", "--warmup", "1",
+                   "--repeats", "0", "--latency-steps", "8"]
+            env = dict(os.environ, TMPDIR="/tmp", ADAS_BENCH_NO_PMC="1")
+            subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=300, check=False)
+            v, n = 0.0, 0
+            for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+                for r in csv.DictReader(open(f)):
+                    if pat in r.get("Kernel_Name", "") and r.get("Counter_Name") == ctr:
+                        v += float(r["Counter_Value"]); n += 1
+            shutil.rmtree(d, ignore_errors=True)
+            if n == 0:
+                return None, {"error": f"no {ctr} samples for kernel pattern {pat!r}"}
+            tot[ctr] = (v / n, n)
+    except Exception as ex:
+        return None, {"error": repr(ex)}
+    hbm = 2.0 * tot["FETCH_SIZE"][0] * 1024 + tot["WRITE_SIZE"][0] * 1024
+    return int(round(hbm)), {"collected": "in this run", "fetch_kib_raw": round(tot["FETCH_SIZE"][0], 1), "write_kib_raw": round(tot["WRITE_SIZE"][0], 1),
+                             "dispatches_sampled": [tot["FETCH_SIZE"][1], tot["WRITE_SIZE"][1]], "kernel_pattern": pat,
+                             "seconds": round(time.perf_counter() - t0, 1),
+                             "method": "two child runs of bench.py (--no-overlap --steps 3 --no-extras) under rocprofv3 --pmc FETCH_SIZE / "
+                                       "--pmc WRITE_SIZE (+ --kernel-trace), per-dispatch average of the dominant kernel; "
+                                       "FETCH_SIZE x2 (gfx950 16 B/lane correction), WRITE_SIZE as reported, KiB -> bytes"}
 
 
 def measure_post_hbm(L, pipe, gd, gl, S, layer_ms, precision):
@@ -459,8 +523,8 @@ def main():
             a, b = seam_of(cam)
             best = sd.best_logits(a)
             if t_cal is None:
-                sd.fix_sharpen(best)
                 t_cal = SynthDetector.threshold(best, TARGET)
+                sd.fix_sharpen(best, t_cal)
             if sum(len(c) for c in cams_all) < need:
                 cams_all.append(cam)
                 counts_all.append(SynthDetector.counts(best, t_cal))
@@ -480,8 +544,8 @@ def main():
         dpool = [det_frames(S, 1000 * rank + 10 + p) for p in range(P)]
         lpool = [lane_frames(S, 1000 * rank + 50 + p) for p in range(P)]
         best0 = sd.best_logits(np.concatenate(dpool))
-        sd.fix_sharpen(best0)
         t_cal = SynthDetector.threshold(best0, TARGET, CAP)
+        sd.fix_sharpen(best0, t_cal)
     det_path, Wd, gd = sd.finish(t_cal)
     wl = M.SynthWeights(1, gain=M.RELU_RES_GAIN)
     gl = M.build(args.lane, wsrc=wl)
@@ -613,8 +677,10 @@ def main():
     achieved = dom_fl / (dom_ms * 1e-3) / 1e12 if dom_ms > 0 else 0.0
     top = sorted(by_kernel.items(), key=lambda kv: -kv[1][0])[:6]
     traffic, traffic_src = None, None
-    tpath = os.path.join(ROOT, "profiles", "traffic.json")       # HBM bytes per launch from rocprofv3 --pmc passes (tools/gpu_round.sh)
-    if os.path.exists(tpath):
+    if rank == 0 and world == 1 and not args.no_extras and os.environ.get("ADAS_BENCH_NO_PMC") != "1":
+        traffic, traffic_src = measure_traffic_pmc(dom_name, args)
+    tpath = os.path.join(ROOT, "profiles", "traffic.json")       # fallback: the figure tools/gpu_round.sh collected at a stated commit
+    if traffic is None and os.path.exists(tpath):
         try:
             tj = json.load(open(tpath))
             if tj.get("kernel") == dom_name and tj.get("streams") == S and tj.get("precision", "bf16") == args.precision:

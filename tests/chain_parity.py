@@ -76,16 +76,45 @@ def track_ids(snap):
             [(t["track_id"], t["state"], t["class_id"]) for t in snap["lost"]], snap["count"])
 
 
+def _iou_xywh(a, b):
+    """IoU matrix of boxes (x, y, w, h) [top-left + size], plain geometry (a matching criterion, not the reference's "+1" NMS IoU)."""
+    a = np.asarray(a, np.float64).reshape(-1, 4); b = np.asarray(b, np.float64).reshape(-1, 4)
+    ax2, ay2, bx2, by2 = a[:, 0] + a[:, 2], a[:, 1] + a[:, 3], b[:, 0] + b[:, 2], b[:, 1] + b[:, 3]
+    iw = np.clip(np.minimum(ax2[:, None], bx2[None]) - np.maximum(a[:, 0][:, None], b[:, 0][None]), 0, None)
+    ih = np.clip(np.minimum(ay2[:, None], by2[None]) - np.maximum(a[:, 1][:, None], b[:, 1][None]), 0, None)
+    inter = iw * ih
+    return inter / np.maximum((a[:, 2] * a[:, 3])[:, None] + (b[:, 2] * b[:, 3])[None] - inter, 1e-30)
+
+
+def unmatched_survivors(got, want, iou_min=0.9, conf_tol=2e-2):
+    """Number of survivors on either side without a one-to-one partner of the same class, IoU >= iou_min and |conf diff| <= conf_tol:
+    0 means the two detection lists describe the same objects (possibly through different, tied neighbouring anchors)."""
+    ng, nw = len(got["keep"]), len(want["keep"])
+    if ng == 0 or nw == 0:
+        return ng + nw
+    iou = _iou_xywh(got["xywh"], want["xywh"])
+    ok = (iou >= iou_min) & (np.asarray(got["class_id"])[:, None] == np.asarray(want["class_id"])[None]) & \
+         (np.abs(np.asarray(got["conf"])[:, None] - np.asarray(want["conf"])[None]) <= conf_tol)
+    used, n_match = set(), 0
+    for i in np.argsort(-np.asarray(got["conf"])):
+        cand = [j for j in np.argsort(-iou[i]) if ok[i, j] and j not in used]
+        if cand:
+            used.add(cand[0]); n_match += 1
+    return (ng - n_match) + (nw - n_match)
+
+
 class ChainStats:
     """Counts, over compared frames, how often the device's discrete decisions equal the oracle's."""
 
     FIELDS = ("frames", "identical_candidate_sets", "identical_keep_indices", "identical_survivor_sets", "identical_survivors",
+              "equivalent_survivor_sets",
               "identical_track_ids", "lanes_identical_status", "lanes_within_1px")
 
     def __init__(self):
         self.n = dict.fromkeys(self.FIELDS, 0)
         self.n_cand = self.n_cand_sym_diff = self.n_surv = self.n_surv_sym_diff = 0
         self.n_lane_pts = self.n_lane_pts_off = 0
+        self.n_surv_unmatched = 0
         self.n_track_checks = 0
         self.max_conf_diff = self.max_box_diff = 0.0
         self.max_lane_px = 0
@@ -113,6 +142,12 @@ class ChainStats:
         self.n["identical_survivors"] += int(same_s)
         self.n_surv += len(ws)
         self.n_surv_sym_diff += len(np.setxor1d(gs, ws))
+        # the same OBJECTS: every survivor has a one-to-one partner of the same class with IoU >= 0.9 and conf within 2e-2 (two
+        # neighbouring anchors of one object whose scores tie within the 16-bit error swap roles in the NMS: another anchor id, the
+        # same detection)
+        um = 0 if same_s else unmatched_survivors(got, want)
+        self.n_surv_unmatched += um
+        self.n["equivalent_survivor_sets"] += int(um == 0)
         if same_s and len(ws):
             self.max_conf_diff = max(self.max_conf_diff, float(np.abs(np.asarray(got["conf"]) - want["conf"]).max()))
             self.max_box_diff = max(self.max_box_diff, float(np.abs(np.asarray(got["xywh"]) - want["xywh"]).max()))
@@ -157,6 +192,8 @@ class ChainStats:
             "frac_identical_candidate_sets": round(self.n["identical_candidate_sets"] / f, 4),
             "frac_identical_survivor_sets": round(self.n["identical_survivor_sets"] / f, 4),
             "frac_identical_survivors_in_order": round(self.n["identical_survivors"] / f, 4),
+            "frac_equivalent_survivor_sets": round(self.n["equivalent_survivor_sets"] / f, 4),
+            "survivors_without_equivalent_partner": self.n_surv_unmatched,
             "track_states_compared": self.n_track_checks,
             "frac_identical_track_ids": round(self.n["identical_track_ids"] / max(1, self.n_track_checks), 4),
             "candidates_compared": self.n_cand, "candidate_anchors_differing": self.n_cand_sym_diff,

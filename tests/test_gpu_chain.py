@@ -68,7 +68,7 @@ def _assert_exact(o):
 
 def _assert_16bit(o):
     """Bounds on how MANY discrete decisions differ (measured values are printed by _run_chain).  A half-precision network leaves
-    ~1e-3 of the anchor-to-anchor logit spread as error (tools/scratch/snr_cpu.py), so of 8400 anchors with ~100 over the threshold
+    ~1e-3 of the anchor-to-anchor logit spread as error (tools/synth_snr.py), so of 8400 anchors with ~100 over the threshold
     about 0.4-1 per frame sits closer to it than that and is decided differently; one such anchor changes the NMS outcome of its
     neighbourhood (one or two survivors).  Measured (round 3, MI355X): north-star pipeline 8 of 4,640 candidate anchors and 95.8 % of
     frames with identical survivor sets over 96 frames; YOLOv8s 0.6 % / 4.1 % and YOLOv8l 2.6 % / 10 % of candidate / survivor

@@ -106,7 +106,7 @@ def test_yolov10n_640_vs_oracle(tmp_path, prec):
     e = CE.HipEngine(path, precision=prec, max_batch=2)
     assert e.get_engine_output_shape()[0] == [[1, 84, 8400]]
     got = e.engine_inference(x)[0]
-    rtol = {"fp16": 3e-3, "bf16": 3e-2}
+    rtol = {"fp16": 5e-3, "bf16": 4e-2}
     for lname, key in (("model.10.cv2.conv", "psa"), ("model.16.cv2.conv", "p3"), ("model.19.cv2.conv", "p4"), ("model.22.cv2.conv", "p5")):
         a = e.fetch_activation(lname, 2)
         ref = taps[key].numpy()

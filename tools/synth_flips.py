@@ -2,7 +2,7 @@
 oracle chain on bench-like frames, by synthetic gain and sharpen."""
 import sys, os, math
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import bench, netutil, chain_parity as CP
 from oracle import nets, preprocess
@@ -24,9 +24,9 @@ def study(scale, gain, sharpen, nframes=12, steps_per=3, target=100):
         best.append((z - b).max(0))
     best = np.sort(np.stack(best), 1)
     sig = float(best.std())
-    sh = sharpen / sig if sharpen < 0 else sharpen
-    sh = abs(sh)
-    t = float(np.median(best[:, -target])) * sh
+    t0 = bench.SynthDetector.threshold(best, target)
+    sh = (math.log(0.999 / 0.001) - math.log(0.4 / 0.6)) / (float(best.max()) - t0) if sharpen < 0 else sharpen
+    t = t0 * sh
     for i in range(3):
         W[f"model.22.cv3.{i}.2.weight"] = W[f"model.22.cv3.{i}.2.weight"] * np.float32(sh)
         W[f"model.22.cv3.{i}.2.bias"] = np.full_like(W[f"model.22.cv3.{i}.2.bias"], math.log(0.4 / 0.6) - t)
@@ -41,8 +41,8 @@ def study(scale, gain, sharpen, nframes=12, steps_per=3, target=100):
             st.add_detections(got, want, ctx=[k, s]); ncand.append(len(want["cand_anchor"]))
             st.add_tracks(emu.track(s, got), ref.track(s, want), ctx=[k, s])
     o = st.summary()
-    print("v8%s gain %.2f sharpen %.1f (logit sigma %.3f): cand/frame med %d max %d | identical cand %.2f surv %.2f ids %.2f | cand diff %d/%d surv diff %d/%d conf %.1e box %.1e" % (
-        scale, gain, sh, sig, np.median(ncand), max(ncand), o["frac_identical_candidate_sets"], o["frac_identical_survivors"], o["frac_identical_track_ids"],
+    print("v8%s gain %.2f sharpen %.1f (logit sigma %.3f): cand/frame med %d max %d | identical cand %.2f surv %.2f (equivalent %.2f) ids %.2f | cand diff %d/%d surv diff %d/%d conf %.1e box %.1e" % (
+        scale, gain, sh, sig, np.median(ncand), max(ncand), o["frac_identical_candidate_sets"], o["frac_identical_survivor_sets"], o["frac_equivalent_survivor_sets"], o["frac_identical_track_ids"],
         o["candidate_anchors_differing"], o["candidates_compared"], o["survivor_anchors_differing"], o["survivors_compared"], o["max_conf_diff_on_identical_frames"], o["max_box_diff_px_on_identical_frames"]), flush=True)
 
 if __name__ == "__main__":

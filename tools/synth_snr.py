@@ -1,7 +1,7 @@
 """CPU study: anchor-to-anchor signal of the best class logit vs its fp16-emulation error, by synthetic gain."""
 import sys, os
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 from oracle import nets
 import netutil, bench
