@@ -93,7 +93,8 @@ class SynthDetector:
     surviving scores spread over (0.4, 1) the way a trained head's do -- otherwise every score sits just above 0.4 and ByteTrack
     (new tracks need >= 0.6, byteTracker.py:43,162) never starts a track.  `sharpen=None` derives the factor from the measured
     logits (fix_sharpen), so the workload does not depend on the synthetic weights' gain."""
-    TOP_CONF = 0.999   # score of the strongest anchor of the calibration frames
+    MED_TOP_CONF = 0.9     # score of the median calibration frame's strongest anchor
+    MAX_TOP_LOGIT = 12.0   # ... but no calibration frame's strongest anchor beyond this logit (1 - 6e-6: still resolved in fp32)
 
     def __init__(self, M, CE, name, workdir, tag, sharpen=None, batch=16):
         self.M, self.CE, self.name, self.workdir, self.tag, self.batch = M, CE, name, workdir, tag, batch
@@ -124,14 +125,18 @@ class SynthDetector:
         return best
 
     def fix_sharpen(self, best, t):
-        """Choose the cls scale from the calibration frames' best logits and their threshold t (once): the strongest anchor maps to
-        TOP_CONF.  The best-logit distribution of a random-weight net is heavy-tailed (the strongest anchors sit ~8 sigma over the
-        threshold, the median candidate at 1-10 % of that): scaling by the standard deviation would push the top anchors into the
-        sigmoid's saturation, where fp32 scores differ in their last bit only and the NMS order among them is decided by rounding."""
+        """Choose the cls scale from the calibration frames' best logits and their threshold t (once): the MEDIAN frame's strongest
+        anchor maps to MED_TOP_CONF (so that most frames carry detections over ByteTrack's 0.6), capped so that the strongest anchor
+        of all calibration frames stays at a logit of MAX_TOP_LOGIT.  The best-logit distribution of a random-weight net is
+        heavy-tailed, within a frame (the strongest anchors sit ~8 sigma over the threshold, the median candidate at 1-10 % of
+        that) and across frames (per-frame maxima differ 20x): scaling by the standard deviation pushes the top anchors deep into
+        the sigmoid's saturation, where fp32 scores differ in their last bit only and the NMS order among them is decided by rounding."""
         if self.sharpen is None:
-            top = float(best.max())
-            span = math.log(self.TOP_CONF / (1.0 - self.TOP_CONF)) - math.log(0.4 / 0.6)
-            self.sharpen = float(span / max(top - t, 1e-12))
+            fmax = best[:, -1]                                    # per-frame strongest anchor (rows are sorted ascending)
+            span = math.log(self.MED_TOP_CONF / (1.0 - self.MED_TOP_CONF)) - math.log(0.4 / 0.6)
+            s_med = span / max(float(np.median(fmax)) - t, 1e-12)
+            s_cap = (self.MAX_TOP_LOGIT - math.log(0.4 / 0.6)) / max(float(fmax.max()) - t, 1e-12)
+            self.sharpen = float(min(s_med, s_cap))
         return self.sharpen
 
     @staticmethod
@@ -222,7 +227,7 @@ def measure_parity(det_eng, lane_eng, det_name, lane_name, Wd, Wl, dframes, lfra
             "lane_rel_l2_outputs": float("%.3e" % rel(lflat_g, lflat_w)), "lane_max_abs_outputs": float("%.3e" % np.abs(lflat_g - lflat_w).max()),
             "lane_max_ref_outputs": round(float(np.abs(lflat_w).max()), 2),
             "tolerance": "north_star: 1e-3 on conv activations; fp32 mode meets it absolutely (tests/test_gpu_nets.py, test_gpu_configs.py); "
-                         "16-bit modes: rel-L2 <= 5e-3 (fp16) / 4e-2 (bf16) on activations, calibrated heads max-abs <= 8e-3 on class "
+                         "16-bit modes: rel-L2 <= 5e-3 (fp16) / 4e-2 (bf16) on activations, calibrated heads max-abs <= 1.5e-2 on class "
                          "probabilities and <= 0.1 px on boxes in fp16 (tests/test_gpu_configs.py)"}
 
 

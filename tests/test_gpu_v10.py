@@ -124,7 +124,7 @@ def test_yolov10n_640_vs_oracle(tmp_path, prec):
     if prec == "fp32":
         assert ecls <= 1e-3 and ebox <= 1e-3 * max(1.0, float(np.abs(want[:, :4]).max()))
     else:
-        assert ecls <= {"fp16": 8e-3, "bf16": 8e-2}[prec] and ebox <= {"fp16": 0.1, "bf16": 1.0}[prec]
+        assert ecls <= {"fp16": 1.5e-2, "bf16": 1e-1}[prec] and ebox <= {"fp16": 0.1, "bf16": 1.0}[prec]
     e.close()
 
 
