@@ -185,7 +185,7 @@ def test_ufld_v1_vs_oracle(CE, name, prec, G, K):
 def test_wider_yolo_scales_vs_oracle(CE, name, scale):
     """The m/x width and depth multiples (README model table: yolov5n/s/m/l/x, yolov8n/s/m/l/x) at 256x256: channel counts
     that are not powers of two (48, 80, 96, 160, 320, ...) through the same kernels.  Tolerances: relative L2 of the head
-    tensor <= 2e-4 in fp32 and <= 6e-2 in bf16.  No absolute bound on the class probabilities here: with random weights the
+    tensor <= 2e-4 in fp32 and <= 8e-2 in bf16.  No absolute bound on the class probabilities here: with random weights the
     logits of these 2-4x deeper nets grow to thousands, so a 1e-6 relative summation-order difference against oneDNN moves
     a near-zero logit by 1e-2 and its sigmoid visibly (the n-scale tests keep the absolute 1e-3 bound)."""
     path, W, g = netutil.model(name, imgsz=256)
@@ -201,7 +201,7 @@ def test_wider_yolo_scales_vs_oracle(CE, name, scale):
         if prec == "fp32":
             assert rel_l2(got, want) <= 2e-4
         else:
-            assert rel_l2(got, want) <= 6e-2
+            assert rel_l2(got, want) <= 8e-2
         e.close()
 
 

@@ -1,32 +1,36 @@
 #!/bin/bash
-# usage (on the GPU box, via gpurun): tools/gpu_round.sh <tag>
-# runs the gpu tests, the default bench, and a rocprofv3 --kernel-trace --stats pass of the same bench command;
+# usage (on the GPU box, via gpurun): tools/gpu_round.sh <tag> <commit>
+# the whole GPU suite, the default bench (its roofline.traffic comes from its own rocprofv3 --pmc child runs), rocprofv3
+# --kernel-trace --stats passes of the same bench command (overlapped and one-stream), the preset benches, per-layer tables;
 # everything lands under gpurun_out/<tag>/
-tag=${1:-r02}
+tag=${1:-r03}
 commit=${2:-unknown}     # the caller passes `git rev-parse --short HEAD` (the GPU box has no .git)
 out=$GRAFT_REPO_ROOT/gpurun_out/$tag
 mkdir -p $out
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
+echo "commit $commit" > $out/commit.txt
 ( timeout 1500 python -m pytest tests -m gpu -q > $out/pytest_gpu.log 2>&1; echo "pytest exit $?" >> $out/pytest_gpu.log )
 tail -5 $out/pytest_gpu.log
-# HBM traffic of the dominant kernel: two PMC passes (FETCH_SIZE costs 3 of 4 TCC slots)
-for C in FETCH_SIZE WRITE_SIZE; do
-  ( timeout 600 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $out/pmc_$C -o p -- python bench.py --no-cpu-baseline --no-extras --no-overlap --steps 5 --warmup 2 > /dev/null 2> $out/pmc_$C.err )
-done
-python tools/traffic_summary.py $out "conv_h8_kernel<adas::Fp16, 2" "conv_h8_kernel<RELU>" 64 fp16 $commit > $out/traffic.json   # both sync variants
-cat $out/traffic.json
-[ -s $out/traffic.json ] && grep -q hbm_bytes_per_launch $out/traffic.json && cp $out/traffic.json profiles/traffic.json   # bench.py reads it
-( timeout 600 python bench.py > $out/bench.json 2> $out/bench.err; echo "bench exit $?" >> $out/bench.err )
-cat $out/bench.json
+( timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $out/smoke.log 2>&1; echo "smoke exit $?" >> $out/smoke.log ); tail -2 $out/smoke.log
+( timeout 900 python bench.py > $out/bench.json 2> $out/bench.err; echo "bench exit $?" >> $out/bench.err )
+cat $out/bench.json | cut -c1-600
 ( timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof -o bench -- python bench.py --no-cpu-baseline --no-extras > $out/bench_prof.json 2> $out/bench_prof.err )
 f=$(find $out/prof -name '*kernel_stats.csv' | head -1)
-[ -n "$f" ] && cp $f $out/kernel_stats.csv && head -25 $f
-# drop the bulky per-dispatch trace, keep the stats
-find $out/prof -name '*kernel_trace.csv' -size +8M -delete
+[ -n "$f" ] && cp $f $out/kernel_stats.csv && head -12 $f
 # the same bench with both nets on one stream: per-kernel durations comparable with bench.py's own hipEvent pass
 ( timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof_noov -o bench -- python bench.py --no-cpu-baseline --no-extras --no-overlap > $out/bench_noov.json 2> $out/bench_noov.err )
 f=$(find $out/prof_noov -name '*kernel_stats.csv' | head -1)
 [ -n "$f" ] && cp $f $out/kernel_stats_no_overlap.csv
-find $out/prof_noov -name '*kernel_trace.csv' -size +8M -delete
-find $out -name '*kernel_trace.csv' -size +8M -delete
+find $out -name '*kernel_trace.csv' -delete
+find $out -name '*agent_info.csv' -delete
+for p in c4 c5 v10; do
+  ( timeout 900 python bench.py --preset $p --no-cpu-baseline > $out/bench_$p.json 2> $out/bench_$p.err; echo "bench exit $?" >> $out/bench_$p.err )
+  tail -1 $out/bench_$p.err
+done
+python tools/profile_layers.py yolov8n --batch 64 --precision fp16 --top 100 > $out/layers_yolov8n_b64_fp16.txt 2>&1
+python tools/profile_layers.py ufldv2_res18 --batch 64 --precision fp16 --top 100 > $out/layers_ufldv2_res18_b64_fp16.txt 2>&1
+python tools/profile_layers.py yolov10n --batch 64 --precision fp16 --top 120 > $out/layers_yolov10n_b64_fp16.txt 2>&1
+python tools/layer_drift.py yolov8n fp16 > $out/layer_drift_yolov8n.txt 2>&1
+python tools/layer_drift.py yolov8s fp16 > $out/layer_drift_yolov8s.txt 2>&1
+tail -3 $out/layer_drift_yolov8n.txt
