@@ -14,6 +14,7 @@
 // ((b0*(S0>>4))>>16 + (b1*(S1>>4))>>16 + 2)>>2).  Parity with a real cv2 build is UNPINNED; identity-size
 // resizes are exact by construction.  HBM-bound streaming kernels: one thread per output pixel.
 #include "common.h"
+#include <stdlib.h>
 #include "elem16.h"
 #include <math.h>
 
@@ -84,7 +85,17 @@ __device__ __forceinline__ void resize_px(const uint8_t* __restrict__ src, const
 struct ColTap {
     short x0, x1, a0, a1;   // source columns, 11-bit coefficients (<= 2048)
 };
-constexpr int PRE_ROWS = 8;       // output rows per workgroup
+// output rows per workgroup: every workgroup tabulates the column taps (double-precision coordinates) and the normalisation LUT
+// (double divisions) before its first pixel, so the rows it owns amortise that; ADAS_PRE_ROWS overrides (A/B measurements)
+static int pre_rows() {
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("ADAS_PRE_ROWS");
+        v = e ? atoi(e) : 8;
+        if (v < 1 || v > 1024) v = 8;
+    }
+    return v;
+}
 constexpr int PRE_MAXW = 7680;    // widest resized row the (dynamic LDS) table holds: 60 KB + the kernels' <= 3 KB of static LDS stay under
                                   // the 64 KB a launch gets without hipFuncSetAttribute(MaxDynamicSharedMemorySize)
 
@@ -135,6 +146,7 @@ struct YoloPreDev {
     float* dst;
     ResizeGeom g;
     int n, dh, dw, padh, padw;
+    int rows;   // output rows per workgroup
 };
 template <int PACK>   // 0: fp32 NCHW planes; 1: packed bf16 pixels; 2: packed fp16 pixels
 __global__ void preprocess_yolo_kernel(YoloPreDev d) {
@@ -147,6 +159,7 @@ __global__ void preprocess_yolo_kernel(YoloPreDev d) {
     const bool identity = d.g.rh == d.g.sh && d.g.rw == d.g.sw;   // cv2.resize with dsize == ssize copies
     if (!identity) col_table(tab, d.g, 0, d.g.rw);
     __syncthreads();
+    const int PRE_ROWS = d.rows;
     const int rows_per_img = (d.dh + PRE_ROWS - 1) / PRE_ROWS;
     const int b = blockIdx.x / rows_per_img, yb = (blockIdx.x - b * rows_per_img) * PRE_ROWS;
     const uint8_t* src = d.src + (size_t)b * d.g.sh * d.g.sw * 3;
@@ -215,6 +228,7 @@ struct UfldPreDev {
     float* dst;
     ResizeGeom g;
     int n, ih, iw, row0;
+    int rows;   // output rows per workgroup
 };
 template <int PACK>
 __global__ void preprocess_ufld_kernel(UfldPreDev d) {
@@ -232,6 +246,7 @@ __global__ void preprocess_ufld_kernel(UfldPreDev d) {
     const bool identity = d.g.rh == d.g.sh && d.g.rw == d.g.sw;
     if (!identity) col_table(tab, d.g, 0, d.iw);
     __syncthreads();
+    const int PRE_ROWS = d.rows;
     const int rows_per_img = (d.ih + PRE_ROWS - 1) / PRE_ROWS;
     const int b = blockIdx.x / rows_per_img, yb = (blockIdx.x - b * rows_per_img) * PRE_ROWS;
     const uint8_t* src = d.src + (size_t)b * d.g.sh * d.g.sw * 3;
@@ -283,6 +298,7 @@ static int preprocess_yolo_impl(const uint8_t* d_frames_bgr, int n, int src_h, i
     int rc = adas_letterbox_params(src_h, src_w, dst_h, dst_w, keep_ratio, &lb);
     if (rc) return rc;
     YoloPreDev d;
+    d.rows = 0;
     d.src = d_frames_bgr; d.dst = d_out_nchw; d.n = n; d.dh = dst_h; d.dw = dst_w; d.padh = lb.pad_h; d.padw = lb.pad_w;
     // resized extent = Scaler._new_shape (utils.py:43-52): recover it from the ratios' definition
     int newh = dst_h, neww = dst_w;
@@ -297,7 +313,8 @@ static int preprocess_yolo_impl(const uint8_t* d_frames_bgr, int n, int src_h, i
     if (pack == 3) hipLaunchKernelGGL(preprocess_effdet_kernel, dim3(grid_for((size_t)n * dst_h * dst_w)), dim3(256), 0, (hipStream_t)stream, d);
     else {
         ADAS_REQUIRE(neww <= PRE_MAXW && src_w < 32768 && src_h < 32768, ADAS_ERR_INVALID, "adas_preprocess_yolo: resized width %d exceeds %d", neww, PRE_MAXW);
-        const dim3 grid((unsigned)(n * ((dst_h + PRE_ROWS - 1) / PRE_ROWS)));
+        d.rows = pre_rows();
+        const dim3 grid((unsigned)(n * ((dst_h + d.rows - 1) / d.rows)));
         const size_t tab_bytes = (size_t)neww * sizeof(ColTap);
         if (pack == 2) hipLaunchKernelGGL(preprocess_yolo_kernel<2>, grid, dim3(256), tab_bytes, (hipStream_t)stream, d);
         else if (pack == 1) hipLaunchKernelGGL(preprocess_yolo_kernel<1>, grid, dim3(256), tab_bytes, (hipStream_t)stream, d);
@@ -338,7 +355,8 @@ static int preprocess_ufld_impl(const uint8_t* d_frames_bgr, int n, int src_h, i
     d.g.scale_y = 1.0 / ((double)rh / (double)src_h);
     d.g.scale_x = 1.0 / ((double)in_w / (double)src_w);
     ADAS_REQUIRE(in_w <= PRE_MAXW && src_w < 32768 && src_h < 32768, ADAS_ERR_INVALID, "adas_preprocess_ufld: input width %d exceeds %d", in_w, PRE_MAXW);
-    const dim3 grid((unsigned)(n * ((in_h + PRE_ROWS - 1) / PRE_ROWS)));
+    d.rows = pre_rows();
+    const dim3 grid((unsigned)(n * ((in_h + d.rows - 1) / d.rows)));
     const size_t tab_bytes = (size_t)in_w * sizeof(ColTap);
     if (pack == 2) hipLaunchKernelGGL(preprocess_ufld_kernel<2>, grid, dim3(256), tab_bytes, (hipStream_t)stream, d);
     else if (pack == 1) hipLaunchKernelGGL(preprocess_ufld_kernel<1>, grid, dim3(256), tab_bytes, (hipStream_t)stream, d);
