@@ -86,19 +86,20 @@ struct ColTap {
     short x0, x1, a0, a1;   // source columns, 11-bit coefficients (<= 2048)
 };
 // output rows per workgroup: every workgroup tabulates the column taps (double-precision coordinates) and the normalisation LUT
-// (double divisions) before its first pixel, so the rows it owns amortise that; ADAS_PRE_ROWS overrides (A/B measurements)
-static int pre_rows() {
-    static int v = -1;
-    if (v < 0) {
+// (double divisions) before its first pixel, but fewer, larger workgroups cost more than they save -- measured at 64 frames
+// (tools/bench_pre.py, bit-identical outputs): detector 107-111 us at 3-4 rows, 120 at 8, 165 at 32, 549 at 160; lane 154-155 us at
+// 3-16 rows except 8 (162), 210 at 32.  ADAS_PRE_ROWS overrides both (A/B measurements).
+static int pre_rows(int dflt) {
+    static int v = -2;
+    if (v == -2) {
         const char* e = getenv("ADAS_PRE_ROWS");
-        v = e ? atoi(e) : 8;
-        if (v < 1 || v > 1024) v = 8;
+        v = e ? atoi(e) : -1;
+        if (v < 1 || v > 1024) v = -1;
     }
-    return v;
+    return v > 0 ? v : dflt;
 }
 constexpr int PRE_MAXW = 7680;    // widest resized row the (dynamic LDS) table holds: 60 KB + the kernels' <= 3 KB of static LDS stay under
                                   // the 64 KB a launch gets without hipFuncSetAttribute(MaxDynamicSharedMemorySize)
-
 __device__ __forceinline__ void col_table(ColTap* tab, const ResizeGeom& g, int first, int count) {
     for (int t = threadIdx.x; t < count; t += blockDim.x) {
         int x0, x1, a0, a1;
@@ -313,7 +314,7 @@ static int preprocess_yolo_impl(const uint8_t* d_frames_bgr, int n, int src_h, i
     if (pack == 3) hipLaunchKernelGGL(preprocess_effdet_kernel, dim3(grid_for((size_t)n * dst_h * dst_w)), dim3(256), 0, (hipStream_t)stream, d);
     else {
         ADAS_REQUIRE(neww <= PRE_MAXW && src_w < 32768 && src_h < 32768, ADAS_ERR_INVALID, "adas_preprocess_yolo: resized width %d exceeds %d", neww, PRE_MAXW);
-        d.rows = pre_rows();
+        d.rows = pre_rows(4);
         const dim3 grid((unsigned)(n * ((dst_h + d.rows - 1) / d.rows)));
         const size_t tab_bytes = (size_t)neww * sizeof(ColTap);
         if (pack == 2) hipLaunchKernelGGL(preprocess_yolo_kernel<2>, grid, dim3(256), tab_bytes, (hipStream_t)stream, d);
@@ -355,7 +356,7 @@ static int preprocess_ufld_impl(const uint8_t* d_frames_bgr, int n, int src_h, i
     d.g.scale_y = 1.0 / ((double)rh / (double)src_h);
     d.g.scale_x = 1.0 / ((double)in_w / (double)src_w);
     ADAS_REQUIRE(in_w <= PRE_MAXW && src_w < 32768 && src_h < 32768, ADAS_ERR_INVALID, "adas_preprocess_ufld: input width %d exceeds %d", in_w, PRE_MAXW);
-    d.rows = pre_rows();
+    d.rows = pre_rows(12);
     const dim3 grid((unsigned)(n * ((in_h + d.rows - 1) / d.rows)));
     const size_t tab_bytes = (size_t)in_w * sizeof(ColTap);
     if (pack == 2) hipLaunchKernelGGL(preprocess_ufld_kernel<2>, grid, dim3(256), tab_bytes, (hipStream_t)stream, d);
