@@ -1,0 +1,117 @@
+"""CPU interpreter of a models.Graph (the op list a `.hipm` container serialises), in torch fp32.
+
+TEST INFRASTRUCTURE: lets the GPU-less suite check that the graph BUILDERS (models.py: views, concat-by-offset, residual links,
+weight layouts, op parameters) describe the same network as the oracle's forward functions -- the engine executes exactly this
+op list, so a wiring mistake in a builder is caught here without a GPU.  It interprets the ops' documented semantics
+(csrc/engine.h op types, kernels.h ConvArgs); it shares no code with the HIP kernels and is not a fallback for them."""
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+import importlib
+from conftest import load_pkg
+
+load_pkg()
+M = importlib.import_module("adas_amd.models")
+
+
+def _act(y, act):
+    if act == M.ACT_SILU:
+        return F.silu(y)
+    if act == M.ACT_RELU:
+        return F.relu(y)
+    return y
+
+
+def run(g, x):
+    """g: models.Graph; x: (N, 3, H, W) float32 -> list of output arrays in g.outs order (batch first)."""
+    x = torch.as_tensor(x, dtype=torch.float32)
+    N = x.shape[0]
+    blob = np.frombuffer(bytes(g.blob), np.float32)
+    bufs = [torch.zeros(N, c, h, w) for (h, w, c, fl) in g.bufs]
+    for bi, (h, w, c, fl) in enumerate(g.bufs):          # aliases share storage: re-view the target's memory (NHWC order)
+        if fl & M.BUF_ALIAS:
+            bufs[bi] = None
+    alias_of = {bi: fl >> 8 for bi, (h, w, c, fl) in enumerate(g.bufs) if fl & M.BUF_ALIAS}
+
+    def read(v):
+        if v.buf in alias_of:                             # same bytes as the target buffer, NHWC flat order, other shape
+            t = bufs[alias_of[v.buf]]
+            flat = t.permute(0, 2, 3, 1).reshape(N, -1)
+            h, w, c, _ = g.bufs[v.buf]
+            full = flat.reshape(N, h, w, c).permute(0, 3, 1, 2)
+            return full[:, v.coff:v.coff + v.c]
+        return bufs[v.buf][:, v.coff:v.coff + v.c]
+
+    def write(v, y):
+        assert v.buf not in alias_of
+        bufs[v.buf][:, v.coff:v.coff + v.c] = y
+
+    def wb(op):
+        (wo, wn), (bo, bn) = op["w"], op["b"]
+        return blob[wo // 4: wo // 4 + wn], blob[bo // 4: bo // 4 + bn]
+
+    with torch.no_grad():
+        for op in g.ops:
+            t, ins, out = op["type"], op["ins"], op["out"]
+            if t == M.OP_INPUT:
+                y = torch.zeros(N, 8, g.in_h, g.in_w)
+                y[:, :g.in_c] = x
+                write(out, y)
+            elif t == M.OP_CONV:
+                w, b = wb(op)
+                k, cin, cout = op["kh"], ins[0].c, out.c
+                W = torch.from_numpy(w.copy()).reshape(cout, k, k, cin).permute(0, 3, 1, 2) if not (k == 1 and w.size == cout * cin) \
+                    else torch.from_numpy(w.copy()).reshape(cout, cin, 1, 1)
+                y = F.conv2d(read(ins[0]), W, torch.from_numpy(b.copy()), stride=op["stride"], padding=op["pad"])
+                if op["res_mode"] == M.RES_BEFORE_ACT:
+                    y = _act(y + read(op["res"]), op["act"])
+                elif op["res_mode"] == M.RES_AFTER_ACT:
+                    y = _act(y, op["act"]) + read(op["res"])
+                else:
+                    y = _act(y, op["act"])
+                write(out, y)
+            elif t == M.OP_DWCONV:
+                w, b = wb(op)
+                k, c = op["kh"], out.c
+                y = F.conv2d(read(ins[0]), torch.from_numpy(w.copy()).reshape(c, 1, k, k), torch.from_numpy(b.copy()), stride=op["stride"],
+                             padding=op["pad"], groups=c)
+                y = _act(y, op["act"])
+                if op["res_mode"] != M.RES_NONE:
+                    y = y + read(op["res"])
+                write(out, y)
+            elif t == M.OP_MAXPOOL:
+                write(out, F.max_pool2d(read(ins[0]), op["kh"], op["stride"], op["pad"]))
+            elif t == M.OP_UPSAMPLE2:
+                write(out, F.interpolate(read(ins[0]), scale_factor=2, mode="nearest"))
+            elif t == M.OP_ATTENTION:
+                nh, kd, hd, scale = int(op["params"][0]), int(op["params"][1]), int(op["params"][2]), float(op["params"][3])
+                q_k_v = read(ins[0])
+                B, _, H, W_ = q_k_v.shape
+                q, k_, v = q_k_v.reshape(B, nh, 2 * kd + hd, H * W_).split([kd, kd, hd], dim=2)
+                attn = ((q.transpose(-2, -1) @ k_) * scale).softmax(dim=-1)
+                write(out, (v @ attn.transpose(-2, -1)).reshape(B, nh * hd, H, W_))
+            elif t == M.OP_LAYERNORM:
+                w, b = wb(op)
+                flat = read(ins[0]).permute(0, 2, 3, 1).reshape(N, -1)          # the engine normalises the NHWC-flat vector
+                y = F.layer_norm(flat, (flat.shape[1],), torch.from_numpy(w.copy()), torch.from_numpy(b.copy()), float(op["params"][0]))
+                write(out, y.reshape(N, 1, 1, -1).permute(0, 3, 1, 2))
+            elif t == M.OP_DETECT_V8:
+                nc, A = int(op["params"][0]), int(op["params"][1])
+                strides = [int(s) for s in op["params"][2:5]]
+                levels = [torch.cat((read(ins[2 * i]), read(ins[2 * i + 1])), 1).reshape(N, 64 + nc, -1) for i in range(3)]
+                from oracle import nets
+                y = torch.from_numpy(nets._v8_decode(levels, [(ins[2 * i].h, ins[2 * i].w) for i in range(3)], nc))
+                bufs[out.buf] = y.reshape(N, -1, 1, 1)
+            elif t == M.OP_DETECT_V5:
+                raise NotImplementedError("v5 Detect decode is covered by the GPU tests")
+            else:
+                raise ValueError(t)
+    outs = []
+    for buf, off, dims, name in g.outs:
+        if buf in alias_of:
+            raise NotImplementedError
+        flat = bufs[buf].permute(0, 2, 3, 1).reshape(N, -1)
+        n = int(np.prod(dims[1:]))
+        outs.append(flat[:, off:off + n].reshape([N] + list(dims[1:])).numpy())
+    return outs

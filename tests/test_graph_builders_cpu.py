@@ -1,0 +1,52 @@
+"""CPU: the graph builders (models.py) against the oracle's forward functions, through a torch interpreter of the op list
+(tests/graph_interp.py) -- the engine executes exactly this op list, so views / concat offsets / residual links / weight layouts /
+op parameters of every builder are checked here without a GPU.  Reduced input sizes keep the CPU suite short."""
+import importlib
+
+import numpy as np
+import pytest
+
+import graph_interp
+import netutil
+from conftest import load_pkg
+from oracle import nets
+
+load_pkg()
+M = importlib.import_module("adas_amd.models")
+
+
+def _build(name, **kw):
+    ws = M.SynthWeights(0, gain=M.synth_gain(name))
+    g = M.build(name, wsrc=ws, **kw)
+    return g, dict(ws.store)
+
+
+@pytest.mark.parametrize("name,fwd,scale", [("yolov8n", "yolov8_forward", "n"), ("yolov8s", "yolov8_forward", "s"), ("yolov10n", "yolov10_forward", "n")])
+def test_yolo_graph_equals_oracle(name, fwd, scale):
+    g, W = _build(name, imgsz=(96, 128))
+    x = netutil.coco_like_frames(2, 96, 128, seed=3)
+    got = graph_interp.run(g, x)[0]
+    want = getattr(nets, fwd)(x, W, scale)
+    assert got.shape == want.shape
+    np.testing.assert_allclose(got[:, 4:], want[:, 4:], rtol=0, atol=2e-6)      # class probabilities
+    np.testing.assert_allclose(got[:, :4], want[:, :4], rtol=0, atol=2e-4)      # boxes in pixels
+
+
+def test_yolov10n_published_size():
+    g, _ = _build("yolov10n")
+    assert abs(g.n_params / 1e6 - 2.30) < 0.01 and abs(g.flops / 1e9 - 6.76) < 0.02     # THU-MIG: 2.3 M parameters, 6.7 GFLOPs
+    kinds = [o["type"] for o in g.ops]
+    assert kinds.count(M.OP_ATTENTION) == 1 and kinds.count(M.OP_DWCONV) == 3 + 3 + 2 + 3 * 2      # SCDown x3, CIB 3, attention pe 2 (one per head), head 6
+    assert [tuple(d) for _, _, d, _ in g.outs] == [(1, 84, 8400)]
+
+
+@pytest.mark.parametrize("name,kw,okw", [("ufldv2_res18", dict(in_h=64, in_w=160, num_grid_row=20, num_cls_row=8, num_grid_col=10, num_cls_col=9), {}),
+                                          ("ufldv2_tusimple_res18", dict(in_h=64, in_w=160, num_grid_row=20, num_cls_row=8, num_grid_col=10, num_cls_col=9), dict(fc_norm=False))])
+def test_ufldv2_graph_equals_oracle(name, kw, okw):
+    g, W = _build(name, **kw)
+    x = netutil.lane_frames(2, 64, 160, seed=5)
+    want = nets.ufldv2_forward(x, W, "18", 20, 8, 10, 9, **okw)
+    got = graph_interp.run(g, x)       # Tusimple: the FC reads the pool output through an alias (torch .view), no LayerNorm
+    for a, b in zip(got, want):
+        assert a.shape == b.shape
+        np.testing.assert_allclose(a, b, rtol=0, atol=5e-5)
