@@ -67,7 +67,8 @@ struct HaloDev {
 
 constexpr int HALO_CK = 32;
 __host__ __device__ constexpr int halo_bm(int S) { return S == 1 ? 256 : 128; }
-__host__ __device__ constexpr int halo_maxpix(int S) { return S == 1 ? 640 : 704; }  // window pixels (2 workgroups per CU)
+// window pixels: 2 workgroups per CU at the default tile; the 128-pixel stride-1 tiles of small layers (round 3) keep 384 (3 per CU)
+__host__ __device__ constexpr int halo_maxpix(int S, int BM = 0) { return S == 1 ? ((BM == 128) ? 384 : 640) : 704; }
 constexpr int HALO_PIX = HALO_CK;       // elements per LDS window pixel (64 B, chunk-swizzled)
 constexpr int HALO_WPIX = HALO_CK;      // weight rows are unpadded (64 B) and XOR-swizzled instead: their
                                         // fragment reads always start at a 16-aligned row, so chunk kg of row r is
@@ -98,13 +99,18 @@ __device__ unsigned long long g_halo_prof[256][16];
 #define HPROF_FLUSH
 #endif
 
-template <typename E, int BN, int ACT, int S>   // E: element tag (elem16.h)
-__global__ __launch_bounds__(256, 2) void conv_halo_kernel(HaloDev a) {
+// BM: output pixels per tile.  halo_bm(S) by default; stride-1 layers whose 256-pixel tiling gives the chip fewer than 320 workgroups
+// (20x20 maps at 64 frames, everything at batch 1) run 128-pixel tiles instead: half the work per workgroup, twice the workgroups --
+// their duration is one workgroup's latency chain, and a second / third resident workgroup hides it.  Measured (round 3): YOLOv8l +
+// UFLDv2 one frame at a time 364 -> 453 frames/s; at 64 frames the 20x20 layers gain 1-8 us each, the 40x40 ones (448 workgroups)
+// would lose 2 us each and stay on 256-pixel tiles; end to end at 64 frames within the +-1 % run-to-run noise.
+template <typename E, int BN, int ACT, int S, int BM = halo_bm(S)>   // E: element tag (elem16.h)
+__global__ __launch_bounds__(256, (S == 1 && BM == 128) ? 3 : 2) void conv_halo_kernel(HaloDev a) {
     E::enter();
     typedef typename E::vec8 hvec8;
     constexpr int TAPS = 9;
-    constexpr int HALO_BM = halo_bm(S);
-    constexpr int HALO_NA = halo_maxpix(S) * 4 / 256;
+    constexpr int HALO_BM = BM;
+    constexpr int HALO_NA = halo_maxpix(S, BM) * 4 / 256;
     constexpr int TM = HALO_BM / 64, TN = BN / 16;
     constexpr int NW = (TAPS * BN * 4 + 255) / 256;  // weight chunk loads per thread per channel chunk
     constexpr int WROWS = TAPS * BN;
@@ -387,8 +393,8 @@ static bool magic_ok(int d, int nmax, uint32_t* magic) {
 }
 
 // Ho x Wo: OUTPUT extent; S: stride (1 or 2); pad = 1, 3x3.
-static bool plan_halo_uncached(int Ho, int Wo, int S, int maxpix_cap, HaloPlan* best) {
-    const int BM = halo_bm(S), MAXPIX = maxpix_cap > 0 ? maxpix_cap : halo_maxpix(S);
+static bool plan_halo_uncached(int Ho, int Wo, int S, int maxpix_cap, int bm, HaloPlan* best) {
+    const int BM = bm > 0 ? bm : halo_bm(S), MAXPIX = maxpix_cap > 0 ? maxpix_cap : halo_maxpix(S, BM);
     // strip widths: powers of two, the whole row, and the row cut into 2 / 3 / 4 equal strips (40x200 maps: 100-wide strips fill
     // 97.7 % of their tiles' pixels, 32-wide ones 89.3 %)
     int cand[9] = {16, 32, 64, 128, 256, Wo, (Wo + 1) / 2, (Wo + 2) / 3, (Wo + 3) / 4};
@@ -415,37 +421,43 @@ static bool plan_halo_uncached(int Ho, int Wo, int S, int maxpix_cap, HaloPlan* 
 }
 
 // plans are pure functions of (Ho, Wo, S): memoised so eager launches do not redo the exhaustive checks
-bool plan_halo(int Ho, int Wo, int S, HaloPlan* out, int maxpix_cap) {
+bool plan_halo(int Ho, int Wo, int S, HaloPlan* out, int maxpix_cap, int bm) {
     static std::mutex mu;
-    static std::map<std::tuple<int, int, int, int>, std::pair<bool, HaloPlan>> cache;
+    static std::map<std::tuple<int, int, int, int, int>, std::pair<bool, HaloPlan>> cache;
     std::lock_guard<std::mutex> lk(mu);
-    auto key = std::make_tuple(Ho, Wo, S, maxpix_cap);
+    auto key = std::make_tuple(Ho, Wo, S, maxpix_cap, bm);
     auto it = cache.find(key);
     if (it == cache.end()) {
         HaloPlan p{};
-        bool ok = plan_halo_uncached(Ho, Wo, S, maxpix_cap, &p);
+        bool ok = plan_halo_uncached(Ho, Wo, S, maxpix_cap, bm, &p);
         it = cache.emplace(key, std::make_pair(ok, p)).first;
     }
     *out = it->second.second;
     return it->second.first;
 }
 
-template <typename E, int BN, int S>
+template <typename E, int BN, int S, int BM = halo_bm(S)>
 static hipError_t launch_bn(const HaloDev& d, int act, dim3 grid, size_t lds, hipStream_t st) {
     static bool attr_done = false;
     if (!attr_done) {
-        (void)hipFuncSetAttribute((const void*)conv_halo_kernel<E, BN, ACT_NONE, S>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute((const void*)conv_halo_kernel<E, BN, ACT_SILU, S>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute((const void*)conv_halo_kernel<E, BN, ACT_RELU, S>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)conv_halo_kernel<E, BN, ACT_NONE, S, BM>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)conv_halo_kernel<E, BN, ACT_SILU, S, BM>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)conv_halo_kernel<E, BN, ACT_RELU, S, BM>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_done = true;
     }
-    if (act == ACT_SILU) hipLaunchKernelGGL((conv_halo_kernel<E, BN, ACT_SILU, S>), grid, dim3(256), lds, st, d);
-    else if (act == ACT_RELU) hipLaunchKernelGGL((conv_halo_kernel<E, BN, ACT_RELU, S>), grid, dim3(256), lds, st, d);
-    else hipLaunchKernelGGL((conv_halo_kernel<E, BN, ACT_NONE, S>), grid, dim3(256), lds, st, d);
+    if (act == ACT_SILU) hipLaunchKernelGGL((conv_halo_kernel<E, BN, ACT_SILU, S, BM>), grid, dim3(256), lds, st, d);
+    else if (act == ACT_RELU) hipLaunchKernelGGL((conv_halo_kernel<E, BN, ACT_RELU, S, BM>), grid, dim3(256), lds, st, d);
+    else hipLaunchKernelGGL((conv_halo_kernel<E, BN, ACT_NONE, S, BM>), grid, dim3(256), lds, st, d);
     return hipGetLastError();
 }
 template <typename E>
-static hipError_t launch_e(const HaloDev& d, int act, int stride, int bn, dim3 grid, size_t lds, hipStream_t st) {
+static hipError_t launch_e(const HaloDev& d, int act, int stride, int bn, int bm, dim3 grid, size_t lds, hipStream_t st) {
+    if (stride == 1 && bm == 128) {
+        if (bn == 48) return launch_bn<E, 48, 1, 128>(d, act, grid, lds, st);
+        if (bn == 64) return launch_bn<E, 64, 1, 128>(d, act, grid, lds, st);
+        if (bn == 32) return launch_bn<E, 32, 1, 128>(d, act, grid, lds, st);
+        return launch_bn<E, 16, 1, 128>(d, act, grid, lds, st);
+    }
     if (stride == 2) {
         if (bn == 48) return launch_bn<E, 48, 2>(d, act, grid, lds, st);
         if (bn == 64) return launch_bn<E, 64, 2>(d, act, grid, lds, st);
@@ -505,9 +517,31 @@ bool halo_applicable(int kh, int kw, int stride, int pad, const TView& in, const
     return plan_halo(out.h, out.w, stride, &pl) && pl.eff >= 0.6;
 }
 
+// 128-pixel tiles for stride-1 layers whose 256-pixel tiling would leave the chip under three workgroups per CU
+// ADAS_HALO_BM128 = workgroup-count threshold below which a stride-1 layer takes 128-pixel tiles (0: never)
+static int halo_small_tiles() {
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("ADAS_HALO_BM128");
+        v = e ? atoi(e) : 320;
+        if (v < 0) v = 0;
+    }
+    return v;
+}
+int halo_tile_pixels(const ConvArgs& a) {
+    if (a.stride != 1 || !halo_small_tiles()) return halo_bm(a.stride);
+    HaloPlan p256, p128;
+    if (!plan_halo(a.out.h, a.out.w, 1, &p256) || !plan_halo(a.out.h, a.out.w, 1, &p128, 0, 128) || p128.eff < 0.6) return 256;
+    const int bn = halo_bn(a.out.c);
+    const long wgs = (long)a.n * p256.NS * p256.TPS * ((a.out.c + bn - 1) / bn);
+    return wgs < halo_small_tiles() ? 128 : 256;
+}
+
 hipError_t launch_conv_halo(const ConvArgs& a, hipStream_t st) {
     HaloPlan pl;
-    if (!halo_applicable(a.kh, a.kw, a.stride, a.pad, a.in, a.out) || !plan_halo(a.out.h, a.out.w, a.stride, &pl)) return hipErrorNotSupported;
+    if (!halo_applicable(a.kh, a.kw, a.stride, a.pad, a.in, a.out)) return hipErrorNotSupported;
+    const int bm = halo_tile_pixels(a);
+    if (!plan_halo(a.out.h, a.out.w, a.stride, &pl, 0, bm == halo_bm(a.stride) ? 0 : bm)) return hipErrorNotSupported;
     HaloDev d;
     d.in = (const uint16_t*)a.in.p; d.wgt = (const uint16_t*)a.wgt; d.bias = a.bias; d.out = a.out.p;
     d.res = (const uint16_t*)a.res.p;
@@ -528,8 +562,8 @@ hipError_t launch_conv_halo(const ConvArgs& a, hipStream_t st) {
     d.cbg = halo_cb_group(d.ncb, (size_t)d.cin_pad * 9 * bn * 2);
     dim3 grid(8 * d.tiles8 * d.cbg * ((d.ncb + d.cbg - 1) / d.cbg));
     size_t lds = ((size_t)pl.maxpix * HALO_PIX + (size_t)9 * bn * HALO_WPIX) * 2;
-    if (a.prec == PREC_FP16) return launch_e<Fp16>(d, a.act, a.stride, bn, grid, lds, st);
-    return launch_e<Bf16>(d, a.act, a.stride, bn, grid, lds, st);
+    if (a.prec == PREC_FP16) return launch_e<Fp16>(d, a.act, a.stride, bn, bm, grid, lds, st);
+    return launch_e<Bf16>(d, a.act, a.stride, bn, bm, grid, lds, st);
 }
 
 }  // namespace adas

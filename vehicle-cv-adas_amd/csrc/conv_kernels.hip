@@ -319,7 +319,8 @@ const char* conv_kernel_name(const ConvArgs& a, int prec, int kernel) {
     } else if (kernel == CONV_HALO && halo8_applicable(a.kh, a.kw, a.stride, a.pad, a.n, a.in, a.out, a.res, a.res_mode)) {
         snprintf(buf, sizeof(buf), "conv_h8_kernel<%s>", actn);
     } else if (kernel == CONV_HALO) {
-        snprintf(buf, sizeof(buf), "conv_halo_kernel<%d,%s,s%d>", halo_bn(a.out.c), actn, a.stride);
+        snprintf(buf, sizeof(buf), a.stride == 1 && halo_tile_pixels(a) == 128 ? "conv_halo_kernel<%d,%s,s%d,bm128>" : "conv_halo_kernel<%d,%s,s%d>",
+                 halo_bn(a.out.c), actn, a.stride);
     } else if (kernel == CONV_FC) {
         snprintf(buf, sizeof(buf), "fc_kernel");
     } else if (kernel == CONV_PW) {

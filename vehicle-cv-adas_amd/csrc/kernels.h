@@ -61,7 +61,9 @@ struct HaloPlan {
     double eff;                    // useful fraction of the tiles' pixels
     uint32_t mg_ww, mg_sw;         // n / WW == (n * mg_ww) >> 20, n / SW == (n * mg_sw) >> 20 for every n the kernels divide
 };
-bool plan_halo(int Ho, int Wo, int S, HaloPlan* out, int maxpix_cap = 0);   // maxpix_cap: window pixel budget (0: the kernel's default)
+// maxpix_cap: window pixel budget (0: the kernel's default); bm: output pixels per tile (0: halo_bm(S) = 256 at stride 1, 128 at stride 2)
+bool plan_halo(int Ho, int Wo, int S, HaloPlan* out, int maxpix_cap = 0, int bm = 0);
+int halo_tile_pixels(const ConvArgs& a);   // conv_halo.hip: the tile size launch_conv_halo picks for this launch (128 on small stride-1 layers)
 // conv_halo8.hip: stride-1 3x3 for Cout % 128 == 0, Cin % 32 == 0: persistent, LDS-DMA fed, counted waits (same weight packing)
 bool halo8_applicable(int kh, int kw, int stride, int pad, int n, const TView& in, const TView& out, const TView& res, int res_mode);
 // the same conv with its projection shortcut (1x1 stride 2 on `x`, no activation) folded in
