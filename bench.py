@@ -332,7 +332,7 @@ def measure_traffic_pmc(dom_label, args):
                    "--det", args.det, "--lane", args.lane, "--no-cpu-baseline", "--no-extras", "--no-overlap", "--steps", "3", "--warmup", "1",
                    "--repeats", "0", "--latency-steps", "8"]
             env = dict(os.environ, TMPDIR="/tmp", ADAS_BENCH_NO_PMC="1")
-            subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=300, check=False)
+            subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=150, check=False)
             v, n = 0.0, 0
             for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
                 for r in csv.DictReader(open(f)):

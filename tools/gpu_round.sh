@@ -24,6 +24,8 @@ f=$(find $out/prof_noov -name '*kernel_stats.csv' | head -1)
 [ -n "$f" ] && cp $f $out/kernel_stats_no_overlap.csv
 find $out -name '*kernel_trace.csv' -delete
 find $out -name '*agent_info.csv' -delete
+( timeout 600 python bench.py --preset c5 --micro-batch 48 --no-cpu-baseline --no-extras > $out/bench_c5_b48.json 2> /dev/null )
+( timeout 600 python bench.py --preset c5 --micro-batch 1 --no-cpu-baseline --no-extras > $out/bench_c5_b1.json 2> /dev/null )
 for p in c4 c5 v10; do
   ( timeout 900 python bench.py --preset $p --no-cpu-baseline > $out/bench_$p.json 2> $out/bench_$p.err; echo "bench exit $?" >> $out/bench_$p.err )
   tail -1 $out/bench_$p.err
