@@ -70,9 +70,9 @@ def _assert_16bit(o):
     """Bounds on how MANY discrete decisions differ (measured values are printed by _run_chain).  A half-precision network leaves
     ~1e-3 of the anchor-to-anchor logit spread as error (tools/synth_snr.py), so of 8400 anchors with ~100 over the threshold
     about 0.4-1 per frame sits closer to it than that and is decided differently; one such anchor changes the NMS outcome of its
-    neighbourhood (one or two survivors).  Measured (round 3, MI355X): north-star pipeline 8 of 4,640 candidate anchors and 95.8 % of
-    frames with identical survivor sets over 96 frames; YOLOv8s 0.6 % / 4.1 % and YOLOv8l 2.6 % / 10 % of candidate / survivor
-    anchors over 384 / 192 frames (bench.py parity.e2e).  The bounds below leave room for the small samples of these tests."""
+    neighbourhood (one or two survivors).  Measured (round 3, MI355X, bench.py parity.e2e): north-star pipeline 8 of 9,336 candidate
+    anchors, 91.7 % of 96 frames with identical survivor sets, 100 % identical track ids; YOLOv8s 0.4 % / 3.6 % and YOLOv8l 2.3 % / 10 %
+    of candidate / survivor anchors over 384 / 192 frames.  The bounds below leave room for the small samples of these tests."""
     n = o["frames"]
     assert o["survivors_compared"] >= 2 * n
     assert o["candidate_anchors_differing"] <= 0.04 * o["candidates_compared"], o
