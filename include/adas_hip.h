@@ -344,6 +344,12 @@ int adas_bytetrack_update_host(adas_bytetrack* h, int stream_index, const double
 int adas_bytetrack_update_device(adas_bytetrack* h, const double* d_xyxy, const double* d_scores,
                                  const int32_t* d_cls, const int32_t* d_counts, int det_stride, int count_stride,
                                  int count_index, int n_streams, void* stream);
+/* The same for n_frames CONSECUTIVE frames of every stream in one launch (temporal micro-batching, adas_pipeline_desc.micro_batch):
+ * frame f of stream s reads detection slab f * n_streams + s; the updates of a stream run in temporal order inside its workgroup,
+ * exactly as n_frames calls of adas_bytetrack_update_device would (BYTETracker.update once per frame, byteTracker.py:62). */
+int adas_bytetrack_update_device_frames(adas_bytetrack* h, const double* d_xyxy, const double* d_scores,
+                                        const int32_t* d_cls, const int32_t* d_counts, int det_stride, int count_stride,
+                                        int count_index, int n_streams, int n_frames, void* stream);
 /* Synchronises; tracks[0..n_tracked) are tracked_stracks, then n_lost lost_stracks, list order kept. */
 int adas_bytetrack_fetch(adas_bytetrack* h, int stream_index, adas_track_header* hdr, adas_track* tracks,
                          int max_tracks);

@@ -82,14 +82,16 @@ def yolov8_forward(x, W, scale="n", nc=80, taps=None):
     with torch.no_grad():
         x = _conv(x, W, "model.0.conv", 2)
         x = _conv(x, W, "model.1.conv", 2)
-        x = _c2f(x, W, "model.2", dep(3), True)
-        x = _conv(x, W, "model.3.conv", 2)
+        x2 = _c2f(x, W, "model.2", dep(3), True)
+        x = _conv(x2, W, "model.3.conv", 2)
         x4 = _c2f(x, W, "model.4", dep(6), True)
         x = _conv(x4, W, "model.5.conv", 2)
         x6 = _c2f(x, W, "model.6", dep(6), True)
         x = _conv(x6, W, "model.7.conv", 2)
         x = _c2f(x, W, "model.8", dep(3), True)
         x9 = _sppf(x, W, "model.9")
+        if taps is not None:
+            taps.update(c2f2=x2)
         x = torch.cat((F.interpolate(x9, scale_factor=2, mode="nearest"), x6), 1)
         x12 = _c2f(x, W, "model.12", dep(3), False)
         x = torch.cat((F.interpolate(x12, scale_factor=2, mode="nearest"), x4), 1)

@@ -247,3 +247,28 @@ def test_neck_upsample_folded_into_its_consumer(CE, prec, monkeypatch):
         e.close()
     for a, b in zip(outs[True], outs[False]):
         assert a.shape == b.shape and np.array_equal(a, b)
+
+
+@pytest.mark.parametrize("imgsz", [(640, 640), (352, 608)], ids=str)
+@pytest.mark.parametrize("prec,tol", [("fp16", 2e-3), ("bf16", 1.5e-2)])
+def test_whole_c2f_block_fused_launch(CE, imgsz, prec, tol):
+    """conv_c2f.hip: YOLOv8n's model.2 (cv1 1x1 -> split -> 3x3 Bottleneck pair + shortcut -> cv2 1x1 over the concat) runs as ONE launch
+    in the 16-bit modes, the 48-channel concat never written; its output against the oracle's model.2 output, on whole and on ragged
+    16 x 16 tiles (88 x 152 map), and the whole head after it."""
+    path, W, g = netutil.model("yolov8n", imgsz=imgsz)
+    x = netutil.coco_like_frames(2, imgsz[0], imgsz[1], seed=9)
+    taps = {}
+    want = nets.yolov8_forward(x, W, "n", taps=taps)
+    e = CE.HipEngine(path, precision=prec, max_batch=2)
+    names = {nm: e.layer_kernel(e.layer_index(nm), 2) for nm in ("model.2.cv1.conv", "model.2.m.0.cv1.conv", "model.2.m.0.cv2.conv", "model.2.cv2.conv")}
+    assert names["model.2.cv1.conv"] == "conv_c2f16_kernel" and all("fused into the C2f" in names[k] for k in list(names)[1:]), names
+    got = e.engine_inference(x)[0]
+    a = e.fetch_activation("model.2.cv2.conv", 2)
+    ref = taps["c2f2"].numpy()
+    assert a.shape == ref.shape
+    print(prec, imgsz, "model.2 out rel_l2 %.3e max|diff| %.3e max|ref| %.2f" % (rel_l2(a, ref), np.abs(a - ref).max(), np.abs(ref).max()))
+    assert rel_l2(a, ref) <= tol
+    assert rel_l2(got, want) <= 5 * tol
+    with pytest.raises(Exception):
+        e.fetch_activation("model.2.cv1.conv", 2)       # stays in LDS
+    e.close()

@@ -156,6 +156,7 @@ _SIGS = {
     "adas_bytetrack_reset": (C.c_int, [_P, C.c_int]),
     "adas_bytetrack_update_host": (C.c_int, [_P, C.c_int, _P, _P, _P, C.c_int]),
     "adas_bytetrack_update_device": (C.c_int, [_P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
+    "adas_bytetrack_update_device_frames": (C.c_int, [_P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
     "adas_bytetrack_fetch": (C.c_int, [_P, C.c_int, C.POINTER(TrackHeader), _P, C.c_int]),
     "adas_pipeline_create": (C.c_int, [C.POINTER(PipelineDesc), C.POINTER(_P)]),
     "adas_pipeline_destroy": (C.c_int, [_P]),

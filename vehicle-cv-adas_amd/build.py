@@ -24,6 +24,7 @@ UNITS = [
     ("conv_halo_s2.hip", []),
     ("conv_halo8.hip", []),
     ("conv_pair.hip", []),
+    ("conv_c2f.hip", []),
     ("conv_fc.hip", []),
     ("conv_pw.hip", []),
     ("conv_pwg.hip", []),

@@ -43,6 +43,19 @@ static bool ds_folded(const adas_engine* e, int ci, int batch) {
     return halo8_ds_applicable(o.kh, o.kw, o.stride, o.pad, batch, in, out, make_view(e, d.in_buf[0], d.in_coff[0], d.in_c[0]));
 }
 
+// is op `i` one of the three convs a fused C2f launch computes besides its cv1?
+static bool in_c2f(const adas_engine* e, int i) {
+    for (auto& q : e->ops)
+        if (q.c2f[0] == i || q.c2f[1] == i || q.c2f[2] == i) return true;
+    return false;
+}
+
+static bool is_c2f_tail(const adas_engine* e, int i) {   // the block's cv2: its output IS materialised
+    for (auto& q : e->ops)
+        if (q.c2f[2] == i) return true;
+    return false;
+}
+
 static int free_engine(adas_engine* e) {
     if (!e) return ADAS_OK;
     for (auto& b : e->bufs)
@@ -344,6 +357,43 @@ int adas_engine_create(const char* model_path, int precision, int max_batch, ada
         e->ops[bi].skip = true;
         pair_of[bi] = (int)ai;
     }
+    // ---- whole-C2f fusion (conv_c2f.hip): cv1 1x1 -> [split] -> fused 3x3 pair with shortcut -> cv2 1x1 over the concat, when the concat
+    // buffer has no other reader: one launch, the concat is never written (YOLOv8n / YOLOv10n model.2)
+    std::vector<int> c2f_role(e->ops.size(), 0);   // 1: cv1 (launches the block), 2: cv2
+    for (size_t ai = 0; ai < e->ops.size(); ++ai) {
+        const int bi = e->ops[ai].pair_b;
+        if (bi < 0) continue;
+        const FileOp &qa = fo[ai], &qb = fo[bi];
+        const int cat = qa.in_buf[0];
+        if (qa.in_c[0] != 16 || qb.out_buf != cat || qb.out_coff != qa.in_coff[0] + 16 || qb.res_mode != RES_AFTER_ACT || qa.in_coff[0] < 16 || aliased(cat)) continue;
+        int c1 = -1, c2 = -1, readers = 0;
+        for (size_t j = 0; j < fo.size(); ++j) {
+            const FileOp& q = fo[j];
+            bool reads = q.res_mode != RES_NONE && q.res_buf == cat;
+            for (uint32_t t = 0; t < q.n_in && t < 8; ++t) reads = reads || q.in_buf[t] == cat;
+            if (reads) ++readers;
+            if (q.type != OP_CONV || q.kh != 1 || q.kw != 1 || q.stride != 1 || q.pad != 0 || q.act != ACT_SILU || q.res_mode != RES_NONE || q.n_in != 1 ||
+                e->ops[j].skip)
+                continue;
+            if ((int)j < (int)ai && q.out_buf == cat && q.out_coff == qa.in_coff[0] - 16 && q.out_c == 32 && q.in_c[0] == 32 && e->ops[j].up_src < 0) c1 = (int)j;
+            if ((int)j > bi && q.in_buf[0] == cat && q.in_coff[0] == qa.in_coff[0] - 16 && q.in_c[0] == 48 && q.out_c == 32) c2 = (int)j;
+        }
+        bool is_out = false;
+        for (auto& q : fout) is_out = is_out || (int)q.buf == cat;
+        if (c1 < 0 || c2 < 0 || readers != 3 || is_out) continue;   // readers: conv A, conv B's shortcut, cv2
+        bool sole_writers = true;   // nothing else writes into the concat buffer
+        for (size_t j = 0; j < fo.size(); ++j) sole_writers = sole_writers && !(fo[j].out_buf == cat && (int)j != c1 && (int)j != bi);
+        if (!sole_writers) continue;
+        const FileOp &q1 = fo[c1], &q2 = fo[c2];
+        if (!c2f16_applicable(precision, make_view(e, q1.in_buf[0], q1.in_coff[0], q1.in_c[0]), make_view(e, q1.out_buf, q1.out_coff, q1.out_c),
+                              make_view(e, qa.in_buf[0], qa.in_coff[0], qa.in_c[0]), make_view(e, qb.out_buf, qb.out_coff, qb.out_c),
+                              make_view(e, q2.in_buf[0], q2.in_coff[0], q2.in_c[0]), make_view(e, q2.out_buf, q2.out_coff, q2.out_c)))
+            continue;
+        e->ops[c1].c2f[0] = (int)ai; e->ops[c1].c2f[1] = bi; e->ops[c1].c2f[2] = c2;
+        e->ops[ai].skip = true;   // (conv B is skipped already: the pair launch is replaced as a whole)
+        e->ops[c2].skip = true;
+        c2f_role[c1] = 1; c2f_role[c2] = 2;
+    }
     for (auto& op : e->ops) {
         const FileOp& o = op.f;
         if (o.type == OP_CONV && op.kernel == CONV_STEM) {
@@ -381,6 +431,7 @@ int adas_engine_create(const char* model_path, int precision, int max_batch, ada
             op.cout_pad = (cout + 127) / 128 * 128;
             const size_t self = (size_t)(&op - &e->ops[0]);
             if (op.pair_b >= 0 || pair_of[self] >= 0) op.kernel = CONV_PAIR;   // fragment packing (fits the plan's allocation: <= 18 KB)
+            if (c2f_role[self]) op.kernel = CONV_C2F_PW;                        // 1x1 fragments: 2 / 4 KB, inside the plan's 8 / 16 KB
             if (op.ds_user >= 0) {   // second copy of the projection weights, as per-step tiles
                 op.ds_w_off = packed_total;
                 packed_total += ((size_t)cout * cin * esz + 255) & ~(size_t)255;
@@ -480,7 +531,8 @@ int adas_engine_create(const char* model_path, int precision, int max_batch, ada
                 if (hipMemcpy(base + op.b_off, b.data(), (size_t)op.cout_pad * 4, hipMemcpyHostToDevice) != hipSuccess) { rc = ADAS_ERR_HIP; break; }
                 continue;
             }
-            hipError_t pe = op.kernel == CONV_PAIR ? launch_pack_weights_pair(d_stage, base + op.w_off, o.out_c, precision, 0)
+            hipError_t pe = op.kernel == CONV_C2F_PW ? launch_pack_weights_c2f_pw(d_stage, base + op.w_off, o.out_c, o.in_c[0], precision, 0)
+                            : op.kernel == CONV_PAIR ? launch_pack_weights_pair(d_stage, base + op.w_off, o.out_c, precision, 0)
                             : (op.kernel == CONV_FC || op.kernel == CONV_PW)
                                 ? launch_pack_weights_fc(d_stage, base + op.w_off, o.out_c, op.cout_pad, o.in_c[0], op.kpad, precision, 0)
                                 : op.kernel == CONV_HALO
@@ -582,6 +634,10 @@ int adas_engine_layer_kernel(const adas_engine* e, int layer, int batch, char* n
         snprintf(name, cap, "(fused into the SPPF pool launch)");
     } else if (o.type == OP_MAXPOOL && op.pool3[0] >= 0) {
         snprintf(name, cap, "sppf_pool3_kernel");
+    } else if (o.type == OP_CONV && op.c2f[0] >= 0) {
+        snprintf(name, cap, "conv_c2f16_kernel");
+    } else if (op.skip && o.type == OP_CONV && in_c2f(e, layer)) {
+        snprintf(name, cap, "(fused into the C2f launch)");
     } else if (op.skip && op.kernel == CONV_PAIR) {
         snprintf(name, cap, "(fused into the pair launch)");
     } else if (o.type == OP_CONV && op.pair_b >= 0) {
@@ -653,6 +709,13 @@ int engine_run_op(adas_engine* e, int i, const float* d_in, int batch, hipStream
             break;
         case OP_CONV: {
             if (op.ds_user >= 0 && ds_folded(e, op.ds_user, batch)) break;   // computed inside the conv it is the shortcut of
+            if (op.c2f[0] >= 0) {   // this 1x1 conv, the Bottleneck pair behind it and the block's closing 1x1 conv: one launch
+                const EngOp &ca = e->ops[op.c2f[0]], &cb = e->ops[op.c2f[1]], &c2 = e->ops[op.c2f[2]];
+                err = launch_conv_c2f16(make_view(e, o.in_buf[0], o.in_coff[0], o.in_c[0]), make_view(e, c2.f.out_buf, c2.f.out_coff, c2.f.out_c),
+                                        wb + op.w_off, (const float*)(wb + op.b_off), wb + ca.w_off, (const float*)(wb + ca.b_off), wb + cb.w_off,
+                                        (const float*)(wb + cb.b_off), wb + c2.w_off, (const float*)(wb + c2.b_off), batch, e->prec, st);
+                break;
+            }
             if (op.pair_b >= 0) {   // this conv and the one behind it, one launch
                 const EngOp& b = e->ops[op.pair_b];
                 err = launch_conv_pair(make_view(e, o.in_buf[0], o.in_coff[0], o.in_c[0]), make_view(e, b.f.out_buf, b.f.out_coff, b.f.out_c),
@@ -857,6 +920,12 @@ int adas_engine_fetch_activation(adas_engine* e, int layer, int batch, float* h_
     ADAS_REQUIRE(!(e->ops[layer].skip && o.type == OP_UPSAMPLE2), ADAS_ERR_INVALID,
                  "layer %d (%s) is folded into its consumer's loads and has no materialised activation (ADAS_NO_UPSAMPLE_FOLD=1 keeps it)", layer,
                  e->ops[layer].name.c_str());
+    {   // a fused C2f launch materialises only its cv2 output: cv1 and the Bottleneck's two convs stay in LDS
+        const bool c2f_hidden = e->ops[layer].c2f[0] >= 0 || (in_c2f(e, layer) && !is_c2f_tail(e, layer));
+        ADAS_REQUIRE(!c2f_hidden, ADAS_ERR_INVALID,
+                     "layer %d (%s) is computed inside a fused C2f launch: its activation stays in LDS (ADAS_NO_C2F_FUSE=1 keeps it)", layer,
+                     e->ops[layer].name.c_str());
+    }
     ADAS_REQUIRE(e->ops[layer].pair_b < 0, ADAS_ERR_INVALID,
                  "layer %d (%s) is the first conv of a fused 3x3 pair: its activation stays in LDS (ADAS_NO_PAIR_FUSE=1 keeps it)", layer,
                  e->ops[layer].name.c_str());

@@ -41,7 +41,8 @@ struct ConvArgs {
 // Which kernel runs a conv and how its weights are packed.  Decided once at load time from static
 // shapes and re-derived identically at launch time.
 enum { CONV_GATHER = 0, CONV_HALO = 1, CONV_FC = 2, CONV_STEM = 3, CONV_PW = 4, CONV_STEM2 = 5 /* second conv of a fused YOLO stem */,
-       CONV_PAIR = 6 /* either conv of a fused 3x3 -> 3x3 pair (conv_pair.hip) */ };
+       CONV_PAIR = 6 /* either conv of a fused 3x3 -> 3x3 pair (conv_pair.hip) */,
+       CONV_C2F_PW = 7 /* the 1x1 convs of a fused C2f block (conv_c2f.hip): MFMA-fragment packing */ };
 struct ConvPlan {
     int kernel;   // CONV_*
     int cin_pad;  // channels per tap in the packed weights (halo: padded to 32 so the tail is zero)
@@ -76,6 +77,13 @@ bool pair_applicable(int prec, int kh, int kw, int stride, int pad, int act, int
 hipError_t launch_pack_weights_pair(const float* src, void* dst, int c, int prec, hipStream_t st);   // src fp32 [c][9][c]
 hipError_t launch_conv_pair(const TView& x, const TView& y, const void* w1, const float* b1, const void* w2, const float* b2, int n, bool has_res,
                             int prec, hipStream_t st);
+// conv_c2f.hip: a whole C2f(32, 32, n = 1, shortcut) block (YOLOv8n / YOLOv10n model.2) in one launch: cv1 1x1 -> split -> 3x3 pair + shortcut ->
+// cv2 1x1 over the 48-channel concat, which is never written.  cat01 / y1 / y2 / cat: the concat buffer's slices the separate ops use.
+bool c2f16_applicable(int prec, const TView& x, const TView& cat01, const TView& y1, const TView& y2, const TView& cat, const TView& out);
+hipError_t launch_pack_weights_c2f_pw(const float* src, void* dst, int cout, int cin, int prec, hipStream_t st);   // 1x1 weights as MFMA fragments
+size_t c2f_pw_weight_bytes(int cout, int cin);
+hipError_t launch_conv_c2f16(const TView& x, const TView& out, const void* w_cv1, const float* b_cv1, const void* w_a, const float* b_a, const void* w_b,
+                             const float* b_b, const void* w_cv2, const float* b_cv2, int n, int prec, hipStream_t st);
 bool pw_applicable(int prec, int kh, int kw, int stride, int pad, int res_mode, const TView& in, const TView& out);  // conv_pw.hip
 // conv_pwg.hip: 1x1 stride-1 convs conv_pw does not take (Cin > 512), a K-looped MFMA GEMM on the generic [cout_pad][K] weight packing
 bool pwg_applicable(int prec, int kh, int kw, int stride, int pad, const TView& in, const TView& out, const TView& res, int res_mode);

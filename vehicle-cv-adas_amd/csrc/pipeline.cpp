@@ -122,12 +122,10 @@ static int record_step(adas_pipeline* p, const float* d_det, const float* d_lane
         int cap = 0;
         rc = adas_yolo_post_capacity(p->d.post, &cap);
         if (rc) return rc;
-        // frame b of stream s sits at frame index b * NS + s: update launch b reads rows [b * NS, b * NS + NS), in temporal order
-        for (int b = 0; b < B; ++b) {
-            const size_t f0 = (size_t)b * NS;
-            rc = adas_bytetrack_update_device(p->d.tracker, xy + f0 * cap * 4, sc + f0 * cap, cl + f0 * cap, cn + f0 * 4, cap, 4, 2, NS, st);
-            if (rc) return rc;
-        }
+        // frame b of stream s sits at frame index b * NS + s: one launch, every stream's workgroup runs its B updates in temporal order
+        rc = B > 1 ? adas_bytetrack_update_device_frames(p->d.tracker, xy, sc, cl, cn, cap, 4, 2, NS, B, st)
+                   : adas_bytetrack_update_device(p->d.tracker, xy, sc, cl, cn, cap, 4, 2, NS, st);
+        if (rc) return rc;
     }
     if (fork) {
         ADAS_HIP_TRY(hipEventRecord(p->ev_join, sl));

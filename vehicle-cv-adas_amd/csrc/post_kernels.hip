@@ -242,6 +242,8 @@ struct BtDev {
     const int* cls;
     const int* counts;
     int det_stride, count_stride, count_index, first_stream;
+    int n_frames = 1, frame_slabs = 0;   // temporal micro-batch: this launch consumes n_frames consecutive frames of every stream, frame f of
+                                         // the stream in block b at detection slab f * frame_slabs + b
 };
 
 __host__ __device__ inline size_t bt_align(size_t x) { return (x + 63) & ~(size_t)63; }
@@ -264,14 +266,17 @@ __global__ __launch_bounds__(256) void bytetrack_update_kernel(BtDev d) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int s = d.first_stream + blockIdx.x;
     BtStream S = bt_view(d.base + (size_t)s * d.stream_bytes, d.P.MT, d.P.MD);
-    const int q = blockIdx.x;  // detection slab index
-    BtDet det;
-    det.tlbr = d.xyxy + (size_t)q * d.det_stride * 4;
-    det.score = d.score + (size_t)q * d.det_stride;
-    det.cls = d.cls + (size_t)q * d.det_stride;
-    det.nd = d.counts[(size_t)q * d.count_stride + d.count_index];
     Ctx c{(int)threadIdx.x, (int)blockDim.x};
-    bytetrack_update(c, d.P, S, det, smem);
+    for (int f = 0; f < d.n_frames; ++f) {   // one update per frame, in temporal order (BYTETracker.update is called once per frame)
+        const int q = f * d.frame_slabs + (int)blockIdx.x;  // detection slab index
+        BtDet det;
+        det.tlbr = d.xyxy + (size_t)q * d.det_stride * 4;
+        det.score = d.score + (size_t)q * d.det_stride;
+        det.cls = d.cls + (size_t)q * d.det_stride;
+        det.nd = d.counts[(size_t)q * d.count_stride + d.count_index];
+        bytetrack_update(c, d.P, S, det, smem);
+        __syncthreads();   // the next frame's update starts from the track table and LDS this one leaves behind
+    }
 }
 
 __global__ __launch_bounds__(256) void bytetrack_reset_kernel(BtDev d) {
@@ -936,6 +941,22 @@ int adas_bytetrack_update_device(adas_bytetrack* h, const double* d_xyxy, const 
     BtDev d = h->dev;
     d.xyxy = d_xyxy; d.score = d_scores; d.cls = d_cls; d.counts = d_counts;
     d.det_stride = det_stride; d.count_stride = count_stride; d.count_index = count_index; d.first_stream = 0;
+    size_t lds = BtLds::bytes(h->p.max_tracks, h->p.max_dets, 256);
+    hipLaunchKernelGGL(bytetrack_update_kernel, dim3(n_streams), dim3(256), lds, st, d);
+    ADAS_HIP_TRY(hipGetLastError());
+    return ADAS_OK;
+}
+int adas_bytetrack_update_device_frames(adas_bytetrack* h, const double* d_xyxy, const double* d_scores, const int32_t* d_cls,
+                                        const int32_t* d_counts, int det_stride, int count_stride, int count_index, int n_streams, int n_frames,
+                                        void* stream) {
+    ADAS_REQUIRE(h && d_xyxy && d_scores && d_cls && d_counts && n_streams > 0 && n_streams <= h->n_streams && n_frames > 0, ADAS_ERR_INVALID,
+                 "adas_bytetrack_update_device_frames: bad argument");
+    hipStream_t st = (hipStream_t)stream;
+    h->last = st;
+    BtDev d = h->dev;
+    d.xyxy = d_xyxy; d.score = d_scores; d.cls = d_cls; d.counts = d_counts;
+    d.det_stride = det_stride; d.count_stride = count_stride; d.count_index = count_index; d.first_stream = 0;
+    d.n_frames = n_frames; d.frame_slabs = n_streams;
     size_t lds = BtLds::bytes(h->p.max_tracks, h->p.max_dets, 256);
     hipLaunchKernelGGL(bytetrack_update_kernel, dim3(n_streams), dim3(256), lds, st, d);
     ADAS_HIP_TRY(hipGetLastError());
