@@ -370,7 +370,8 @@ def test_c2f_bottleneck_pairs_fused(CE, case, prec, tol):
     in LDS, the shortcut comes from the staged window; inputs and outputs are channel slices of the block's concat buffer."""
     H, W, c2, n, shortcut = case
     rel, names = _c2f_case(CE, H, W, c2, n, shortcut, prec)
-    assert all("conv_pair_kernel" in k for k in names), names
+    # a C2f(32, 32, n = 1, shortcut) block is taken as a whole by conv_c2f.hip (round 3): its pair is then part of that launch
+    assert all("conv_pair_kernel" in k or "fused into the C2f launch" in k for k in names), names
     assert rel < tol, (case, prec, rel)
 
 
