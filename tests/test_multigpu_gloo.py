@@ -34,8 +34,9 @@ def _worker(rank, world, port, q):
     dist = sh.init_process_group(env, backend="gloo")
     mine = sh.streams_of_rank(9, env)
     elapsed = sh.max_over_ranks(1.0 + rank, dist)                       # rank 1 is the slow one
-    stats = sh.gather_stats({"frames": 40.0 * len(mine), "seconds": 1.0 + rank, "streams": float(len(mine))},
-                            ("frames", "seconds", "streams"), dist)
+    # the per-rank record bench.py gathers: {frames, seconds, p50, p99} (+ the stream count for this test)
+    stats = sh.gather_stats({"frames": 40.0 * len(mine), "seconds": 1.0 + rank, "streams": float(len(mine)), "p50_ms": 5.0 + rank, "p99_ms": 5.5 + rank},
+                            ("frames", "seconds", "streams", "p50_ms", "p99_ms"), dist)
     dist.barrier()
     q.put((rank, mine, elapsed, stats))
     dist.destroy_process_group()
@@ -54,5 +55,6 @@ def test_two_rank_gloo_stats_gather():
     assert s0 == [0, 2, 4, 6, 8] and s1 == [1, 3, 5, 7]
     assert e0 == e1 == 2.0                                                # max over ranks, identical everywhere
     assert st0 == st1 and [d["streams"] for d in st0] == [5.0, 4.0]
+    assert [d["p50_ms"] for d in st0] == [5.0, 6.0] and [d["p99_ms"] for d in st0] == [5.5, 6.5]
     agg = SH.aggregate_throughput(st0)
     assert agg["frames"] == 360.0 and agg["seconds"] == 2.0 and agg["fps"] == 180.0
