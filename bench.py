@@ -200,11 +200,10 @@ def measure_parity(det_eng, lane_eng, det_name, lane_name, Wd, Wl, dframes, lfra
     from oracle import nets
     n = min(2, len(dframes), det_eng.max_batch)
     taps = {}
-    v10 = det_name.startswith("yolov10")
-    want = (nets.yolov10_forward(dframes[:n], Wd, det_name[len("yolov10"):], taps=taps) if v10 else
-            nets.yolov8_forward(dframes[:n], Wd, det_name[-1], taps=taps))
+    want = nets.detector_forward(det_name, dframes[:n], Wd, taps=taps)
     got = det_eng.engine_inference(dframes[:n])[0]
-    p3 = det_eng.fetch_activation("model.16.cv2.conv" if v10 else "model.15.cv2.conv", n)
+    p3_layer = {"yolov10": "model.16.cv2.conv", "yolov9t": "model.15.cv4.conv"}.get(det_name[:7], "model.15.cv2.conv")
+    p3 = det_eng.fetch_activation(p3_layer, n)
     rp3 = taps["p3"].numpy()
 
     def rel(a, b):
@@ -240,7 +239,7 @@ def cpu_baseline(det_name, lane_name, Wd, Wl, dframes, lframes, lb, budget_s=20.
     trk = bytetrack.BYTETracker()
     scale = det_name[-1]
     bb = lane_name.split("res")[-1]
-    det_fwd = (lambda x: nets.yolov10_forward(x, Wd, det_name[len("yolov10"):])) if det_name.startswith("yolov10") else (lambda x: nets.yolov8_forward(x, Wd, scale))
+    det_fwd = lambda x: nets.detector_forward(det_name, x, Wd)
 
     def one(i):
         if cams is not None:
@@ -399,6 +398,7 @@ def measure_post_hbm(L, pipe, gd, gl, S, layer_ms, precision):
 PRESETS = {   # BASELINE.json configs
     "north-star": dict(det="yolov8n", lane="ufldv2_res18", streams=64),   # configs[1] + configs[2] + NMS + ByteTrack (the metric's combo)
     "v10": dict(det="yolov10n", lane="ufldv2_res18", streams=64),         # the reference's shipped default detector (demo.py:24-30)
+    "v9": dict(det="yolov9t", lane="ufldv2_res18", streams=64),           # YOLOv9 (README.md:57), GELAN-t
     # configs[3]: YOLOv8s + UFLDv2 + ByteTrack on 1280x720 streams; configs[4]: one 1280x720 stream per GPU, YOLOv8l.  Few streams per
     # GPU cannot fill 256 CUs one frame at a time: these presets run temporal micro-batches; `--micro-batch 1` is
     # the frame-at-a-time latency mode, reported beside the throughput line as `frame_at_a_time`.

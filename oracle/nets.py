@@ -231,6 +231,88 @@ def yolov10_forward(x, W, scale="n", nc=80, taps=None):
         return _v8_decode(outs, [f.shape[2:] for f in feats], nc, taps)
 
 
+# ------------------------------------------------------------------ YOLOv9t
+# GELAN-t (ultralytics yolov9t.yaml: "917 layers, 2128720 parameters, 8.5 GFLOPs" un-fused; this deploy form with RepConv
+# re-parameterised to one 3x3 counts 2.09 M / 8.2 G): ELAN1, AConv, RepNCSPELAN4 (RepCSP of RepBottlenecks), SPPELAN, v8 Detect.
+# PARITY UNPINNED like the other YOLO graphs (README.md:57 lists YOLOv9; yoloDetector.py:114,121 pins the head layout only).
+def _repcsp(x, W, name, n):
+    y = _conv(x, W, f"{name}.cv1.conv")
+    for i in range(n):
+        y = _round(y + _conv(_conv(y, W, f"{name}.m.{i}.cv1.conv"), W, f"{name}.m.{i}.cv2.conv"))
+    return _conv(torch.cat((y, _conv(x, W, f"{name}.cv2.conv")), 1), W, f"{name}.cv3.conv")
+
+
+def _repncspelan4(x, W, name, n):
+    y = list(_conv(x, W, f"{name}.cv1.conv").chunk(2, 1))
+    y.append(_conv(_repcsp(y[-1], W, f"{name}.cv2.0", n), W, f"{name}.cv2.1.conv"))
+    y.append(_conv(_repcsp(y[-1], W, f"{name}.cv3.0", n), W, f"{name}.cv3.1.conv"))
+    return _conv(torch.cat(y, 1), W, f"{name}.cv4.conv")
+
+
+def _elan1(x, W, name):
+    y = list(_conv(x, W, f"{name}.cv1.conv").chunk(2, 1))
+    y.append(_conv(y[-1], W, f"{name}.cv2.conv"))
+    y.append(_conv(y[-1], W, f"{name}.cv3.conv"))
+    return _conv(torch.cat(y, 1), W, f"{name}.cv4.conv")
+
+
+def _aconv(x, W, name):
+    return _conv(_round(F.avg_pool2d(x, 2, 1, 0, False, True)), W, f"{name}.cv1.conv", 2)
+
+
+def _sppelan(x, W, name):
+    y = [_conv(x, W, f"{name}.cv1.conv")]
+    for _ in range(3):
+        y.append(F.max_pool2d(y[-1], 5, 1, 2))
+    return _conv(torch.cat(y, 1), W, f"{name}.cv5.conv")
+
+
+def yolov9t_forward(x, W, nc=80, taps=None):
+    x = torch.as_tensor(x, dtype=torch.float32)
+    with torch.no_grad():
+        x = _conv(x, W, "model.0.conv", 2)
+        x = _conv(x, W, "model.1.conv", 2)
+        x = _elan1(x, W, "model.2")
+        x = _aconv(x, W, "model.3")
+        x4 = _repncspelan4(x, W, "model.4", 3)
+        x = _aconv(x4, W, "model.5")
+        x6 = _repncspelan4(x, W, "model.6", 3)
+        x = _aconv(x6, W, "model.7")
+        x = _repncspelan4(x, W, "model.8", 3)
+        x9 = _sppelan(x, W, "model.9")
+        x = torch.cat((F.interpolate(x9, scale_factor=2, mode="nearest"), x6), 1)
+        x12 = _repncspelan4(x, W, "model.12", 3)
+        x = torch.cat((F.interpolate(x12, scale_factor=2, mode="nearest"), x4), 1)
+        x15 = _repncspelan4(x, W, "model.15", 3)
+        x = torch.cat((_aconv(x15, W, "model.16"), x12), 1)
+        x18 = _repncspelan4(x, W, "model.18", 3)
+        x = torch.cat((_aconv(x18, W, "model.19"), x9), 1)
+        x21 = _repncspelan4(x, W, "model.21", 3)
+        if taps is not None:
+            taps.update(p3=x15, p4=x18, p5=x21, sppelan=x9)
+        feats = [x15, x18, x21]
+        N = x.shape[0]
+        outs = []
+        for i, f in enumerate(feats):
+            b = _conv(_conv(f, W, f"model.22.cv2.{i}.0.conv"), W, f"model.22.cv2.{i}.1.conv")
+            b = _conv(b, W, f"model.22.cv2.{i}.2", act=None)
+            c = _conv(_conv(f, W, f"model.22.cv3.{i}.0.conv"), W, f"model.22.cv3.{i}.1.conv")
+            c = _conv(c, W, f"model.22.cv3.{i}.2", act=None)
+            outs.append(torch.cat((b, c), 1).view(N, 64 + nc, -1))
+        return _v8_decode(outs, [f.shape[2:] for f in feats], nc, taps)
+
+
+def detector_forward(name, x, W, nc=80, taps=None):
+    """Forward of the (4+nc, A)-head detector graph `name` ("yolov8n" .. "yolov8x", "yolov10n", "yolov9t")."""
+    if name.startswith("yolov10"):
+        return yolov10_forward(x, W, name[len("yolov10"):], nc, taps)
+    if name.startswith("yolov9"):
+        return yolov9t_forward(x, W, nc, taps)
+    if name.startswith("yolov8"):
+        return yolov8_forward(x, W, name[-1], nc, taps)
+    raise ValueError(name)
+
+
 # ------------------------------------------------------------------ YOLOv5
 V5_SCALES = {"n": (0.33, 0.25), "s": (0.33, 0.50), "m": (0.67, 0.75), "l": (1.0, 1.0), "x": (1.33, 1.25)}
 V5_ANCHORS = [[10, 13, 16, 30, 33, 23], [30, 61, 62, 45, 59, 119], [116, 90, 156, 198, 373, 326]]

@@ -39,10 +39,7 @@ class OracleChain:
         if key is not None and key in self._det_cache:
             return self._det_cache[key]
         x = preprocess.yolo_prepare_input(frame, self.det_hw)
-        if self.det_name.startswith("yolov10"):
-            head = self._forward(nets.yolov10_forward, x, self.Wd, self.det_name[len("yolov10"):])[0]
-        else:
-            head = self._forward(nets.yolov8_forward, x, self.Wd, self.det_name[-1])[0]
+        head = self._forward(nets.detector_forward, self.det_name, x, self.Wd)[0]
         r = yolo_post.detect_post(head, self.lb, "yolov8", self.box_score, self.nms_iou)
         if key is not None:
             self._det_cache[key] = r

@@ -82,6 +82,8 @@ def run(g, x):
                 write(out, y)
             elif t == M.OP_MAXPOOL:
                 write(out, F.max_pool2d(read(ins[0]), op["kh"], op["stride"], op["pad"]))
+            elif t == M.OP_AVGPOOL:
+                write(out, F.avg_pool2d(read(ins[0]), op["kh"], op["stride"], op["pad"], False, True))
             elif t == M.OP_UPSAMPLE2:
                 write(out, F.interpolate(read(ins[0]), scale_factor=2, mode="nearest"))
             elif t == M.OP_ATTENTION:

@@ -21,12 +21,13 @@ def _build(name, **kw):
     return g, dict(ws.store)
 
 
-@pytest.mark.parametrize("name,fwd,scale", [("yolov8n", "yolov8_forward", "n"), ("yolov8s", "yolov8_forward", "s"), ("yolov10n", "yolov10_forward", "n")])
+@pytest.mark.parametrize("name,fwd,scale", [("yolov8n", "yolov8_forward", "n"), ("yolov8s", "yolov8_forward", "s"), ("yolov10n", "yolov10_forward", "n"),
+                                            ("yolov9t", "yolov9t_forward", None)])
 def test_yolo_graph_equals_oracle(name, fwd, scale):
     g, W = _build(name, imgsz=(96, 128))
     x = netutil.coco_like_frames(2, 96, 128, seed=3)
     got = graph_interp.run(g, x)[0]
-    want = getattr(nets, fwd)(x, W, scale)
+    want = getattr(nets, fwd)(x, W, scale) if scale else getattr(nets, fwd)(x, W)
     assert got.shape == want.shape
     np.testing.assert_allclose(got[:, 4:], want[:, 4:], rtol=0, atol=2e-6)      # class probabilities
     np.testing.assert_allclose(got[:, :4], want[:, :4], rtol=0, atol=2e-4)      # boxes in pixels
@@ -50,3 +51,20 @@ def test_ufldv2_graph_equals_oracle(name, kw, okw):
     for a, b in zip(got, want):
         assert a.shape == b.shape
         np.testing.assert_allclose(a, b, rtol=0, atol=5e-5)
+
+
+def test_yolov9t_size_matches_upstream_yaml():
+    """ultralytics yolov9t.yaml: "917 layers, 2128720 parameters, 8.5 GFLOPs" for the UN-fused model (RepConv = 3x3 + 1x1 branches, every
+    Conv followed by a BatchNorm); the deploy form built here folds both away: minus the 42 RepConv 1x1 branches and the BatchNorm
+    affine pairs, plus one bias per conv."""
+    g, W = _build("yolov9t")
+    rep1x1 = sum(W[k].shape[0] * W[k].shape[1] for k in W if ".m." in k and k.endswith(".cv1.conv.weight"))     # the fused-away 1x1 branches
+    n_bias = sum(v.size for k, v in W.items() if k.endswith(".bias"))
+    convs_with_bn = [k for k in W if k.endswith(".conv.weight")]
+    bn_affine = sum(2 * W[k].shape[0] for k in convs_with_bn)
+    rep_bn = sum(2 * 2 * W[k].shape[0] for k in W if ".m." in k and k.endswith(".cv1.conv.weight"))             # RepConv's two extra branch BNs
+    head_bias = sum(W[k].size for k in W if k.endswith(".2.bias"))                                             # the Detect heads' plain Conv2d biases
+    unfused = g.n_params - n_bias + head_bias + rep1x1 + bn_affine + rep_bn
+    assert abs(unfused - 2128720) / 2128720 < 0.01, unfused
+    assert abs(g.flops / 1e9 - 8.23) < 0.05
+    assert [tuple(d) for _, _, d, _ in g.outs] == [(1, 84, 8400)]

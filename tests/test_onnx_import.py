@@ -284,3 +284,22 @@ def test_yolov10n_names_depthwise_and_unfused_repvggdw(tmp_path):
     assert g2.name == "yolov10n" and abs(g2.flops / 1e9 - 6.76) < 0.02 and abs(g2.n_params / 1e6 - 2.30) < 0.01
     ref = M.build("yolov10n", wsrc=M.DictWeights(want))
     assert g2.tobytes() == ref.tobytes()
+
+
+def test_yolov9t_recognised_by_average_pool_or_names(tmp_path):
+    """YOLOv9t (GELAN-t) shares YOLOv8n's stem width and (1, 84, 8400) head: told apart by its AConv average-pool nodes or its
+    RepNCSPELAN4 parameter names; weights by name; RepConv is expected in its fused (deploy) form, as ultralytics exports it."""
+    W, g = synth("yolov9t")
+    inits, nodes = [], []
+    for i, base in enumerate(k[:-7] for k in list(W) if k.endswith(".weight")):
+        w, b = W[base + ".weight"], W[base + ".bias"]
+        inits.append(OW.tensor(base + ".weight", w)); inits.append(OW.tensor(base + ".bias", b))
+        nodes.append(OW.node("Conv", ["t%d" % i, base + ".weight", base + ".bias"], ["t%d" % (i + 1)], "Conv_%d" % i,
+                             [OW.attr_ints("kernel_shape", list(w.shape[2:]))]))
+    nodes.insert(3, OW.node("AveragePool", ["t3"], ["t3p"], "AveragePool_0", [OW.attr_ints("kernel_shape", [2, 2])]))
+    p = tmp_path / "yolov9t.onnx"
+    p.write_bytes(OW.model(nodes, inits, [("images", [1, 3, 640, 640])], [("output0", [1, 84, 8400])]))
+    m = OI.read_onnx(str(p))
+    assert OI.detect_arch(m) == ("yolov9t", dict(nc=80, imgsz=(640, 640)))
+    out, g2 = OI.convert(str(p), str(tmp_path / "v9.hipm"))
+    assert g2.name == "yolov9t" and g2.tobytes() == M.build("yolov9t", wsrc=M.DictWeights(W)).tobytes()

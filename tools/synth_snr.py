@@ -14,7 +14,7 @@ def run(fam, scale, gain, x):
     M.build(name, wsrc=ws)
     W = dict(ws.store)
     head = "model.23.one2one_cv3" if fam == "yolov10" else "model.22.cv3"
-    fwd = nets.yolov10_forward if fam == "yolov10" else nets.yolov8_forward
+    fwd = (lambda x_, W_, sc, taps=None: nets.detector_forward(name, x_, W_, taps=taps))
     bias = np.concatenate([np.repeat(W[f"{head}.{i}.2.bias"][:, None], n, 1) for i, n in enumerate((6400, 1600, 400))], 1)
     res = {}
     for emu in (None, "fp16"):

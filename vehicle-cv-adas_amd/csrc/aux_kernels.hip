@@ -198,6 +198,47 @@ hipError_t launch_maxpool(TView in, TView out, int n, int k, int s, int p, int p
     return hipGetLastError();
 }
 
+// F.avg_pool2d(x, k, s, p, ceil_mode=False, count_include_pad=True): YOLOv9's AConv / ADown (2x2, stride 1, no padding).  thread = (output
+// pixel, 8 channels); the sum runs over the window in row-major order in fp32 and is divided by k*k (padding counts as zeros).
+template <typename T>
+__global__ void avgpool_kernel(PoolDev d) {
+    const int c8n = d.c >> 3;
+    const size_t total = (size_t)d.n * d.Ho * d.Wo * c8n;
+    const float inv = 1.0f / (float)(d.k * d.k);
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int c8 = (int)(i % c8n);
+        const size_t pix = i / c8n;
+        const int ox = (int)(pix % d.Wo);
+        const size_t t = pix / d.Wo;
+        const int oy = (int)(t % d.Ho);
+        const size_t b = t / d.Ho;
+        float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        for (int r = 0; r < d.k; ++r) {
+            const int iy = oy * d.s - d.p + r;
+            if ((unsigned)iy >= (unsigned)d.H) continue;
+            for (int q = 0; q < d.k; ++q) {
+                const int ix = ox * d.s - d.p + q;
+                if ((unsigned)ix >= (unsigned)d.W) continue;
+                const T* ip = (const T*)d.in + ((b * d.H + iy) * d.W + ix) * d.in_cs + d.in_coff + c8 * 8;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) acc[e] += ld<T>(ip + e);
+            }
+        }
+        T* op = (T*)d.out + pix * d.out_cs + d.out_coff + c8 * 8;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) st<T>(op + e, acc[e] * inv);
+    }
+}
+hipError_t launch_avgpool(TView in, TView out, int n, int k, int s, int p, int prec, hipStream_t st_) {
+    if (in.c != out.c || (in.c & 7) || ((in.cs | in.coff | out.cs | out.coff) & 7) || k < 1 || k > 7) return hipErrorInvalidValue;
+    if (out.h != (in.h + 2 * p - k) / s + 1 || out.w != (in.w + 2 * p - k) / s + 1) return hipErrorInvalidValue;
+    PoolDev d{in.p, out.p, in.cs, in.coff, out.cs, out.coff, in.c, in.h, in.w, out.h, out.w, k, s, p, n};
+    const size_t total = (size_t)n * out.h * out.w * (in.c >> 3);
+    const int blocks = (int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
+    ADAS_DISPATCH_STORAGE(prec, T, hipLaunchKernelGGL(avgpool_kernel<T>, dim3(blocks), dim3(256), 0, st_, d));
+    return hipGetLastError();
+}
+
 // SPPF (ultralytics SPPF, YOLOv5 / v8 model.9): three chained 5x5 stride-1 pad-2 max-pools whose outputs are concatenated.  One
 // workgroup holds an 8-channel slab of one frame's map in LDS and produces all three (row maximum, then column maximum, per pool:
 // out-of-image taps are skipped, which is max-pooling's -inf padding); three launches of 25 loads per output become one of one.

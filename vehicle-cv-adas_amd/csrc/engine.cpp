@@ -625,7 +625,7 @@ int adas_engine_layer_kernel(const adas_engine* e, int layer, int batch, char* n
     const EngOp& op = e->ops[layer];
     const FileOp& o = op.f;
     static const char* kOther[] = {"input_nchw_kernel", "", "maxpool_kernel", "upsample2_kernel", "detect_v8_kernel", "detect_v5_kernel",
-                                   "layernorm_kernel", "dwconv_kernel", "attention_kernel"};
+                                   "layernorm_kernel", "dwconv_kernel", "attention_kernel", "avgpool_kernel"};
     if (o.type == OP_CONV && op.ds_user >= 0 && ds_folded(e, op.ds_user, batch)) {
         snprintf(name, cap, "(fused into the conv it is the shortcut of)");
     } else if (op.skip && o.type == OP_UPSAMPLE2) {
@@ -659,7 +659,7 @@ int adas_engine_layer_kernel(const adas_engine* e, int layer, int batch, char* n
     } else if (o.type == OP_DETECT_V8 && op.det_src[0] >= 0) {
         snprintf(name, cap, "detect_v8_fused_kernel");
     } else {
-        snprintf(name, cap, "%s", o.type < 9 ? kOther[o.type] : "?");
+        snprintf(name, cap, "%s", o.type < 10 ? kOther[o.type] : "?");
     }
     return ADAS_OK;
 }
@@ -756,6 +756,10 @@ int engine_run_op(adas_engine* e, int i, const float* d_in, int batch, hipStream
             }
             err = launch_maxpool(make_view(e, o.in_buf[0], o.in_coff[0], o.in_c[0]), make_view(e, o.out_buf, o.out_coff, o.out_c), batch,
                                  o.kh, o.stride, o.pad, e->prec, st);
+            break;
+        case OP_AVGPOOL:
+            err = launch_avgpool(make_view(e, o.in_buf[0], o.in_coff[0], o.in_c[0]), make_view(e, o.out_buf, o.out_coff, o.out_c), batch, o.kh, o.stride,
+                                 o.pad, e->prec, st);
             break;
         case OP_UPSAMPLE2:
             err = launch_upsample2(make_view(e, o.in_buf[0], o.in_coff[0], o.in_c[0]), make_view(e, o.out_buf, o.out_coff, o.out_c), batch,

@@ -96,6 +96,7 @@ const char* conv_kernel_name(const ConvArgs& a, int prec, int kernel);
 
 hipError_t launch_input_nchw(const float* nchw, TView out, int n, int c_true, int prec, hipStream_t st);
 hipError_t launch_maxpool(TView in, TView out, int n, int k, int s, int p, int prec, hipStream_t st);
+hipError_t launch_avgpool(TView in, TView out, int n, int k, int s, int p, int prec, hipStream_t st);   // count_include_pad average (YOLOv9 AConv)
 hipError_t launch_upsample2(TView in, TView out, int n, int prec, hipStream_t st);
 // three chained 5x5 s1 p2 max-pools (SPPF) in one launch: out[0] = pool(in), out[1] = pool(out[0]), out[2] = pool(out[1])
 bool sppf_pool3_applicable(int prec, const TView& in, const TView out[3]);

@@ -305,6 +305,13 @@ def detect_arch(m):
                 if scale != "n":
                     raise ValueError("YOLOv10 scale %r is not built (yolov10n is): %s" % (scale, found))
                 return "yolov10n", dict(nc=o[1] - 4, imgsz=(H, W))
+            # YOLOv9 (GELAN): the same stem width and head as YOLOv8n; its AConv / ADown down-sampling average-pools first (v8 / v10
+            # graphs have no AveragePool node), its blocks are RepNCSPELAN4 (parameter names model.N.cv2.0.cv1.conv ...)
+            is_v9 = any(nd["op"] == "AveragePool" for nd in m.nodes) or any(".cv2.0.m.0.cv1." in k for k in m.initializers)
+            if is_v9:
+                if scale != "n":
+                    raise ValueError("YOLOv9 with a %d-channel stem is not built (yolov9t is): %s" % (c0[0], found))
+                return "yolov9t", dict(nc=o[1] - 4, imgsz=(H, W))
             return "yolov8" + scale, dict(nc=o[1] - 4, imgsz=(H, W))
         if c0[2] == 6 and o[1] > o[2]:                      # (1, A, 5+nc): YOLOv5 v6.x
             scale = {16: "n", 32: "s", 48: "m", 64: "l", 80: "x"}.get(c0[0])
