@@ -95,6 +95,7 @@ class SynthDetector:
     logits (fix_sharpen), so the workload does not depend on the synthetic weights' gain."""
     MED_TOP_CONF = 0.9     # score of the median calibration frame's strongest anchor
     MAX_TOP_LOGIT = 12.0   # ... but no calibration frame's strongest anchor beyond this logit (1 - 6e-6: still resolved in fp32)
+    OBJ_LOGIT = 6.0        # v5-layout heads: constant objectness sigmoid(6) = 0.9975
 
     def __init__(self, M, CE, name, workdir, tag, sharpen=None, batch=16):
         self.M, self.CE, self.name, self.workdir, self.tag, self.batch = M, CE, name, workdir, tag, batch
@@ -103,6 +104,11 @@ class SynthDetector:
         self.ws = ws
         self.sharpen = sharpen
         self.head = "model.23.one2one_cv3" if name.startswith("yolov10") else "model.22.cv3"
+        # v5-layout heads (YOLOv5 Detect / YOLOv7 IDetect: one 1x1 per level, per anchor [x, y, w, h, obj, nc classes]): the class rows
+        # are calibrated like the v8 cls branch; the objectness rows are made constant (weights 0, bias OBJ_LOGIT), so that
+        # conf = obj * cls > box_score is again a threshold on the best class logit
+        self.v5 = {"yolov5": "model.24.m", "yolov7": "model.77.m"}.get(name[:6])
+        self.no = g.outs[0][2][2] if self.v5 else None
         self._uncal = os.path.join(workdir, f"{name}_{tag}_uncal.hipm")
         g.save(self._uncal)
         self._eng = CE.HipEngine(self._uncal, "fp32", batch)
@@ -115,10 +121,14 @@ class SynthDetector:
             self._eng.engine_inference(chunk)
             per_level = []
             for i in range(3):
-                lname = f"{self.head}.{i}.2"
+                lname = f"{self.v5}.{i}" if self.v5 else f"{self.head}.{i}.2"
                 z = self._eng.fetch_activation(lname, len(chunk))
-                b = self.ws.store[lname + ".bias"]
-                per_level.append((z - b.reshape(1, -1, 1, 1)).max(axis=1).reshape(len(chunk), -1))
+                z = z - self.ws.store[lname + ".bias"].reshape(1, -1, 1, 1)
+                if self.v5:
+                    z = z.reshape(len(chunk), 3, self.no, -1)[:, :, 5:]            # (n, anchor, class, cell)
+                    per_level.append(z.max(axis=2).reshape(len(chunk), -1))
+                else:
+                    per_level.append(z.max(axis=1).reshape(len(chunk), -1))
             out.append(np.concatenate(per_level, axis=1))
         best = np.concatenate(out, axis=0)
         best.sort(axis=1)
@@ -175,6 +185,17 @@ class SynthDetector:
         ws2 = M.SynthWeights(0, gain=M.synth_gain(self.name))
         ws2.store.update(self.ws.store)
         for i in range(3):
+            if self.v5:
+                lname = f"{self.v5}.{i}"
+                w = self.ws.store[lname + ".weight"].copy().reshape(3, self.no, -1)
+                b = self.ws.store[lname + ".bias"].copy().reshape(3, self.no)
+                obj = 1.0 / (1.0 + math.exp(-self.OBJ_LOGIT))
+                w[:, 4], b[:, 4] = 0.0, self.OBJ_LOGIT
+                w[:, 5:] *= sh
+                b[:, 5:] = math.log((0.4 / obj) / (1.0 - 0.4 / obj)) - float(sh) * t
+                ws2.store[lname + ".weight"] = w.reshape(self.ws.store[lname + ".weight"].shape)
+                ws2.store[lname + ".bias"] = b.reshape(-1)
+                continue
             lname = f"{self.head}.{i}.2"
             ws2.store[lname + ".weight"] = self.ws.store[lname + ".weight"] * sh
             ws2.store[lname + ".bias"] = np.full_like(self.ws.store[lname + ".bias"], math.log(0.4 / 0.6) - float(sh) * t)
@@ -202,7 +223,9 @@ def measure_parity(det_eng, lane_eng, det_name, lane_name, Wd, Wl, dframes, lfra
     taps = {}
     want = nets.detector_forward(det_name, dframes[:n], Wd, taps=taps)
     got = det_eng.engine_inference(dframes[:n])[0]
-    p3_layer = {"yolov10": "model.16.cv2.conv", "yolov9t": "model.15.cv4.conv"}.get(det_name[:7], "model.15.cv2.conv")
+    p3_layer = {"yolov10": "model.16.cv2.conv", "yolov9t": "model.15.cv4.conv", "yolov7-": "model.74.conv"}.get(det_name[:7], "model.15.cv2.conv")
+    v5 = nets.head_layout(det_name) == "yolov5"      # (A, 5+nc): boxes first along the LAST axis
+    sl_cls, sl_box = ((Ellipsis, slice(4, None)), (Ellipsis, slice(0, 4))) if v5 else ((slice(None), slice(4, None)), (slice(None), slice(0, 4)))
     p3 = det_eng.fetch_activation(p3_layer, n)
     rp3 = taps["p3"].numpy()
 
@@ -219,8 +242,8 @@ def measure_parity(det_eng, lane_eng, det_name, lane_name, Wd, Wl, dframes, lfra
     return {"mode": precision, "against": "oracle/nets.py torch-CPU fp32 on the timed models and frames (2 frames per net)",
             "det_rel_l2_p3": float("%.3e" % rel(p3, rp3)), "det_max_abs_p3": float("%.3e" % np.abs(p3 - rp3).max()),
             "det_max_ref_p3": round(float(np.abs(rp3).max()), 2),
-            "det_rel_l2_head": float("%.3e" % rel(got, want)), "det_max_abs_cls": float("%.3e" % np.abs(got[:, 4:] - want[:, 4:]).max()),
-            "det_max_abs_box_px": float("%.3e" % np.abs(got[:, :4] - want[:, :4]).max()),
+            "det_rel_l2_head": float("%.3e" % rel(got, want)), "det_max_abs_cls": float("%.3e" % np.abs(got[sl_cls] - want[sl_cls]).max()),
+            "det_max_abs_box_px": float("%.3e" % np.abs(got[sl_box] - want[sl_box]).max()),
             "lane_rel_l2_layer4": float("%.3e" % rel(l4, r4)), "lane_max_abs_layer4": float("%.3e" % np.abs(l4 - r4).max()),
             "lane_max_ref_layer4": round(float(np.abs(r4).max()), 2),
             "lane_rel_l2_outputs": float("%.3e" % rel(lflat_g, lflat_w)), "lane_max_abs_outputs": float("%.3e" % np.abs(lflat_g - lflat_w).max()),
@@ -248,7 +271,7 @@ def cpu_baseline(det_name, lane_name, Wd, Wl, dframes, lframes, lb, budget_s=20.
         else:
             xd, xl = dframes[i:i + 1], lframes[i:i + 1]
         y = det_fwd(xd)[0]
-        r = yolo_post.detect_post(y, lb, "yolov8", 0.4, 0.45)
+        r = yolo_post.detect_post(y, lb, nets.head_layout(det_name), 0.4, 0.45)
         trk.update(r["xyxy_int"], r["conf"], r["class_id"])
         o = nets.ufldv2_forward(xl, Wl, bb)
         ufld_decode.process_output(o, cfg, 1280, 720)
@@ -366,10 +389,11 @@ def measure_post_hbm(L, pipe, gd, gl, S, layer_ms, precision):
     try:
         meta = gd.meta
         A, nc = meta["anchors"], meta["nc"]
-        head_bytes = S * (4 + nc) * A * 4
+        v5 = meta["kind"] in ("yolov5", "yolov7")
+        head_bytes = S * ((5 if v5 else 4) + nc) * A * 4
         ms2 = (C.c_float * 2)()
         L.check(L.lib().adas_yolo_post_profile(pipe.post.h, pipe.det.output_device_ptr(0), S, 20, ms2))
-        row("yolo_scan_v8", head_bytes + S * A * 8, float(ms2[0]), "head tensor read once + per-anchor best (conf, class) written")
+        row("yolo_scan_v5" if v5 else "yolo_scan_v8", head_bytes + S * A * 8, float(ms2[0]), "head tensor read once + per-anchor best (conf, class) written")
         out.append({"kernel": "yolo_post_kernel", "us": round(float(ms2[1]) * 1e3, 2), "bound": "latency",
                     "what": "compaction + inverse letterbox + sequential fp64 NMS + RectInfo, one workgroup per frame"})
         for name, (ms, label) in layer_ms.items():
@@ -399,6 +423,7 @@ PRESETS = {   # BASELINE.json configs
     "north-star": dict(det="yolov8n", lane="ufldv2_res18", streams=64),   # configs[1] + configs[2] + NMS + ByteTrack (the metric's combo)
     "v10": dict(det="yolov10n", lane="ufldv2_res18", streams=64),         # the reference's shipped default detector (demo.py:24-30)
     "v9": dict(det="yolov9t", lane="ufldv2_res18", streams=64),           # YOLOv9 (README.md:57), GELAN-t
+    "v7": dict(det="yolov7-tiny", lane="ufldv2_res18", streams=64),       # YOLOv7 (README.md:55), v5-layout head, LeakyReLU
     # configs[3]: YOLOv8s + UFLDv2 + ByteTrack on 1280x720 streams; configs[4]: one 1280x720 stream per GPU, YOLOv8l.  Few streams per
     # GPU cannot fill 256 CUs one frame at a time: these presets run temporal micro-batches; `--micro-batch 1` is
     # the frame-at-a-time latency mode, reported beside the throughput line as `frame_at_a_time`.
@@ -558,8 +583,10 @@ def main():
     Wl = wl.store
     t_build = time.time() - t_build
 
+    HEAD = L.HEAD_V5 if args.det.startswith(("yolov5", "yolov7")) else L.HEAD_V8        # yoloDetector.py:110-124
+
     def make_pipe(precision):
-        return PL.AdasPipeline(det_path, lane_path, n_streams=NSTREAMS, precision=precision, src_hw=(720, 1280),
+        return PL.AdasPipeline(det_path, lane_path, n_streams=NSTREAMS, precision=precision, src_hw=(720, 1280), head_layout=HEAD,
                                use_graph=not args.no_graph, max_candidates=CAP, overlap=not args.no_overlap, micro_batch=B)
 
     pipe = make_pipe(args.precision)
@@ -732,7 +759,7 @@ def main():
             cams_u = np.concatenate(cams_all)[:S * P]
             cnt_u = np.concatenate(counts_all)[:S * P]
             d_u = [L.DeviceBuffer.from_array(np.ascontiguousarray(cams_u[p_ * S:(p_ + 1) * S])) for p_ in range(len(cams_u) // S)]
-            pu = PL.AdasPipeline(det_path, lane_path, n_streams=NSTREAMS, precision=args.precision, src_hw=(720, 1280), use_graph=not args.no_graph,
+            pu = PL.AdasPipeline(det_path, lane_path, n_streams=NSTREAMS, precision=args.precision, src_hw=(720, 1280), head_layout=HEAD, use_graph=not args.no_graph,
                                  max_candidates=1024, overlap=not args.no_overlap, micro_batch=B)
 
             def step_u(i):
@@ -779,7 +806,7 @@ def main():
     frame_at_a_time = None
     if extras and from_frames and B > 1:
         try:
-            p1 = PL.AdasPipeline(det_path, lane_path, n_streams=NSTREAMS, precision=args.precision, src_hw=(720, 1280),
+            p1 = PL.AdasPipeline(det_path, lane_path, n_streams=NSTREAMS, precision=args.precision, src_hw=(720, 1280), head_layout=HEAD,
                                  use_graph=not args.no_graph, max_candidates=CAP, overlap=not args.no_overlap)
 
             def step1(i):

@@ -50,6 +50,8 @@ def _conv(x, W, name, s=1, p=None, act="silu"):
         y = _round(F.silu(y))
     elif act == "relu":
         y = _round(F.relu(y))
+    elif act == "leaky":
+        y = _round(F.leaky_relu(y, 0.1))
     return y
 
 
@@ -302,8 +304,18 @@ def yolov9t_forward(x, W, nc=80, taps=None):
         return _v8_decode(outs, [f.shape[2:] for f in feats], nc, taps)
 
 
+def head_layout(name):
+    """"yolov5" (A, 5+nc) or "yolov8" (4+nc, A): the `model_type` argument of oracle.yolo_post.detect_post for graph `name`."""
+    return "yolov5" if name.startswith(("yolov5", "yolov7")) else "yolov8"
+
+
 def detector_forward(name, x, W, nc=80, taps=None):
-    """Forward of the (4+nc, A)-head detector graph `name` ("yolov8n" .. "yolov8x", "yolov10n", "yolov9t")."""
+    """Forward of the detector graph `name`: (4+nc, A) heads ("yolov8n" .. "yolov8x", "yolov10n", "yolov9t") or the v5 layout
+    (A, 5+nc) ("yolov7-tiny", "yolov5n" .. "yolov5x"; no taps for YOLOv5)."""
+    if name.startswith("yolov7"):
+        return yolov7_tiny_forward(x, W, nc, taps)
+    if name.startswith("yolov5"):
+        return yolov5_forward(x, W, name[-1], nc)
     if name.startswith("yolov10"):
         return yolov10_forward(x, W, name[len("yolov10"):], nc, taps)
     if name.startswith("yolov9"):
@@ -351,20 +363,71 @@ def yolov5_forward(x, W, scale="n", nc=80):
         x20 = _c3(x, W, "model.20", dep(3), False)
         x = torch.cat((_conv(x20, W, "model.21.conv", 2), x10), 1)
         x23 = _c3(x, W, "model.23", dep(3), False)
-        no, z = nc + 5, []
-        H_in = x17.shape[2] * 8
-        for i, f in enumerate((x17, x20, x23)):
-            y = _conv(f, W, f"model.24.m.{i}", act=None)
-            bs, _, ny, nx = y.shape
-            y = y.view(bs, 3, no, ny, nx).permute(0, 1, 3, 4, 2).contiguous().sigmoid()
-            stride = float(H_in // ny)
-            yv, xv = torch.meshgrid(torch.arange(ny, dtype=torch.float32), torch.arange(nx, dtype=torch.float32), indexing="ij")
-            grid = torch.stack((xv, yv), 2).view(1, 1, ny, nx, 2)
-            ag = torch.tensor(V5_ANCHORS[i], dtype=torch.float32).view(1, 3, 1, 1, 2)
-            xy = (y[..., 0:2] * 2 - 0.5 + grid) * stride
-            wh = (y[..., 2:4] * 2) ** 2 * ag
-            z.append(torch.cat((xy, wh, y[..., 4:]), -1).view(bs, -1, no))
-        return torch.cat(z, 1).numpy()
+        return _v5_decode((x17, x20, x23), W, "model.24.m.{}", nc, V5_ANCHORS, x17.shape[2] * 8)
+
+
+def _v5_decode(feats, W, name_fmt, nc, anchors, H_in):
+    """yolov5 models/yolo.py Detect.forward (inference branch): per level a 1x1 conv, sigmoid, then the grid / anchor decode."""
+    no, z = nc + 5, []
+    for i, f in enumerate(feats):
+        y = _conv(f, W, name_fmt.format(i), act=None)
+        bs, _, ny, nx = y.shape
+        y = y.view(bs, 3, no, ny, nx).permute(0, 1, 3, 4, 2).contiguous().sigmoid()
+        stride = float(H_in // ny)
+        yv, xv = torch.meshgrid(torch.arange(ny, dtype=torch.float32), torch.arange(nx, dtype=torch.float32), indexing="ij")
+        grid = torch.stack((xv, yv), 2).view(1, 1, ny, nx, 2)
+        ag = torch.tensor(anchors[i], dtype=torch.float32).view(1, 3, 1, 1, 2)
+        xy = (y[..., 0:2] * 2 - 0.5 + grid) * stride
+        wh = (y[..., 2:4] * 2) ** 2 * ag
+        z.append(torch.cat((xy, wh, y[..., 4:]), -1).view(bs, -1, no))
+    return torch.cat(z, 1).numpy()
+
+
+# ------------------------------------------------------------------ YOLOv7-tiny
+# WongKinYiu/yolov7 cfg/deploy/yolov7-tiny.yaml restated as its row table [from, module, args]; every Conv is conv + folded BN +
+# LeakyReLU(0.1), MP = MaxPool2d(2, 2), SP(k) = MaxPool2d(k, 1, k // 2); the reference decodes the exported head as the v5 layout
+# (yoloDetector.py:110-124).  Interpreted row by row exactly like upstream's parse_model / forward_once: y[i] = module(y[from]).
+def _v7_elan(c, cout):
+    return [(-1, "Conv", (c, 1, 1)), (-2, "Conv", (c, 1, 1)), (-1, "Conv", (c, 3, 1)), (-1, "Conv", (c, 3, 1)),
+            ((-1, -2, -3, -4), "Concat", ()), (-1, "Conv", (cout, 1, 1))]
+
+
+V7_TINY_ROWS = (
+    [(-1, "Conv", (32, 3, 2)), (-1, "Conv", (64, 3, 2))] + _v7_elan(32, 64) +                                   # 0-7
+    [(-1, "MP", ())] + _v7_elan(64, 128) + [(-1, "MP", ())] + _v7_elan(128, 256) + [(-1, "MP", ())] + _v7_elan(256, 512) +   # 8-28
+    [(-1, "Conv", (256, 1, 1)), (-2, "Conv", (256, 1, 1)), (-1, "SP", (5,)), (-2, "SP", (9,)), (-3, "SP", (13,)),
+     ((-1, -2, -3, -4), "Concat", ()), (-1, "Conv", (256, 1, 1)), ((-1, -7), "Concat", ()), (-1, "Conv", (256, 1, 1))] +      # 29-37
+    [(-1, "Conv", (128, 1, 1)), (-1, "Up", ()), (21, "Conv", (128, 1, 1)), ((-1, -2), "Concat", ())] + _v7_elan(64, 128) +   # 38-47
+    [(-1, "Conv", (64, 1, 1)), (-1, "Up", ()), (14, "Conv", (64, 1, 1)), ((-1, -2), "Concat", ())] + _v7_elan(32, 64) +      # 48-57
+    [(-1, "Conv", (128, 3, 2)), ((-1, 47), "Concat", ())] + _v7_elan(64, 128) +                                               # 58-65
+    [(-1, "Conv", (256, 3, 2)), ((-1, 37), "Concat", ())] + _v7_elan(128, 256) +                                              # 66-73
+    [(57, "Conv", (128, 3, 1)), (65, "Conv", (256, 3, 1)), (73, "Conv", (512, 3, 1))])                                        # 74-76
+V7_TINY_ANCHORS = [[10, 13, 16, 30, 33, 23], [30, 61, 62, 45, 59, 119], [116, 90, 156, 198, 373, 326]]
+
+
+def yolov7_tiny_forward(x, W, nc=80, taps=None):
+    x = torch.as_tensor(x, dtype=torch.float32)
+    H_in = x.shape[2]
+    y = []
+    with torch.no_grad():
+        for i, (frm, mod, args) in enumerate(V7_TINY_ROWS):
+            src = [x if not y else y[i + f if f < 0 else f] for f in (frm if isinstance(frm, tuple) else (frm,))]
+            if mod == "Conv":
+                c, k, s = args
+                o = _conv(src[0], W, f"model.{i}.conv", s, act="leaky")
+                assert o.shape[1] == c, (i, o.shape)
+            elif mod == "MP":
+                o = F.max_pool2d(src[0], 2, 2)
+            elif mod == "SP":
+                o = F.max_pool2d(src[0], args[0], 1, args[0] // 2)
+            elif mod == "Up":
+                o = F.interpolate(src[0], scale_factor=2, mode="nearest")
+            else:
+                o = torch.cat(src, 1)
+            y.append(o)
+        if taps is not None:
+            taps.update(p3=y[74], p4=y[75], p5=y[76], sppcspc=y[37])
+        return _v5_decode(y[74:77], W, "model.77.m.{}", nc, V7_TINY_ANCHORS, H_in)
 
 
 # ------------------------------------------------------------------ UFLDv2

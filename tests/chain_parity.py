@@ -40,7 +40,7 @@ class OracleChain:
             return self._det_cache[key]
         x = preprocess.yolo_prepare_input(frame, self.det_hw)
         head = self._forward(nets.detector_forward, self.det_name, x, self.Wd)[0]
-        r = yolo_post.detect_post(head, self.lb, "yolov8", self.box_score, self.nms_iou)
+        r = yolo_post.detect_post(head, self.lb, nets.head_layout(self.det_name), self.box_score, self.nms_iou)
         if key is not None:
             self._det_cache[key] = r
         return r

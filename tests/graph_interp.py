@@ -20,6 +20,8 @@ def _act(y, act):
         return F.silu(y)
     if act == M.ACT_RELU:
         return F.relu(y)
+    if act == M.ACT_LEAKY:
+        return F.leaky_relu(y, 0.1)
     return y
 
 
@@ -106,7 +108,19 @@ def run(g, x):
                 y = torch.from_numpy(nets._v8_decode(levels, [(ins[2 * i].h, ins[2 * i].w) for i in range(3)], nc))
                 bufs[out.buf] = y.reshape(N, -1, 1, 1)
             elif t == M.OP_DETECT_V5:
-                raise NotImplementedError("v5 Detect decode is covered by the GPU tests")
+                nc, A = int(op["params"][0]), int(op["params"][1])          # engine.h: level l = (3 * (5 + nc), h, w) raw logits, anchor a's
+                no = nc + 5                                                  # 5 + nc channels contiguous; rows ordered (level, a, y, x)
+                (wo, wn) = op["w"]
+                anc = torch.from_numpy(blob[wo // 4: wo // 4 + wn].copy()).reshape(3, 3, 2)
+                rows = []
+                for l in range(3):
+                    s_ = float(op["params"][2 + l])
+                    p = read(ins[l]).reshape(N, 3, no, ins[l].h, ins[l].w).permute(0, 1, 3, 4, 2).sigmoid()
+                    gy, gx = torch.meshgrid(torch.arange(ins[l].h, dtype=torch.float32), torch.arange(ins[l].w, dtype=torch.float32), indexing="ij")
+                    xy = (p[..., 0:2] * 2 - 0.5 + torch.stack((gx, gy), -1)) * s_
+                    wh = (p[..., 2:4] * 2) ** 2 * anc[l].reshape(1, 3, 1, 1, 2)
+                    rows.append(torch.cat((xy, wh, p[..., 4:]), -1).reshape(N, -1, no))
+                bufs[out.buf] = torch.cat(rows, 1).reshape(N, A * no, 1, 1)
             else:
                 raise ValueError(t)
     outs = []

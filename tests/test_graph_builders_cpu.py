@@ -33,6 +33,26 @@ def test_yolo_graph_equals_oracle(name, fwd, scale):
     np.testing.assert_allclose(got[:, :4], want[:, :4], rtol=0, atol=2e-4)      # boxes in pixels
 
 
+def test_yolov7_tiny_graph_equals_oracle():
+    """The explicit builder (models.yolov7_tiny) against the oracle's row-table interpretation of yolov7-tiny.yaml, v5-layout decode included."""
+    g, W = _build("yolov7-tiny", imgsz=(96, 128))
+    x = netutil.coco_like_frames(2, 96, 128, seed=3)
+    got = graph_interp.run(g, x)[0]
+    want = nets.yolov7_tiny_forward(x, W)
+    assert got.shape == want.shape == (2, 3 * (12 * 16 + 6 * 8 + 3 * 4), 85)
+    np.testing.assert_allclose(got[..., 4:], want[..., 4:], rtol=0, atol=2e-6)
+    np.testing.assert_allclose(got[..., :4], want[..., :4], rtol=1e-5, atol=2e-4)      # wh = (2 sigmoid)^2 * anchor reaches 1e3 px
+
+
+def test_yolov7_tiny_published_size():
+    """WongKinYiu/yolov7 README: YOLOv7-tiny 6.2 M parameters, 13.8 GFLOPs; the fused model summary reads "6219709 parameters"."""
+    g, _ = _build("yolov7-tiny")
+    assert g.n_params == 6219709
+    assert abs(g.flops / 1e9 - 13.7) < 0.1
+    assert [tuple(d) for _, _, d, _ in g.outs] == [(1, 25200, 85)]
+    assert all(o["act"] == M.ACT_LEAKY for o in g.ops if o["type"] == M.OP_CONV and not o["name"].startswith("model.77"))
+
+
 def test_yolov10n_published_size():
     g, _ = _build("yolov10n")
     assert abs(g.n_params / 1e6 - 2.30) < 0.01 and abs(g.flops / 1e9 - 6.76) < 0.02     # THU-MIG: 2.3 M parameters, 6.7 GFLOPs

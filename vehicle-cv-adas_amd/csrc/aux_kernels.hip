@@ -1,6 +1,6 @@
 // aux_kernels.hip -- the non-GEMM ops of the detector / lane graphs, all HBM-bound streaming kernels:
 //   input_nchw   NCHW fp32 (the coreEngine.py seam layout) -> NHWC compute type, channels padded to 8
-//   maxpool      k x k / stride s over a channel-sliced NHWC view (ResNet stem 3x3 s2, SPPF 5x5 s1)
+//   maxpool      k x k / stride s over a channel-sliced NHWC view (ResNet stem 3x3 s2, SPPF 5x5 s1, YOLOv7 MP 2x2 s2 / SP 5, 9, 13)
 //   upsample2    nearest x2, written straight into the consumer's concat slice
 //   detect_v8    DFL softmax-expectation + dist2bbox + sigmoid -> (N, 4+nc, A)   (yoloDetector.py:110-122 layout)
 //   detect_v5    sigmoid + grid/anchor decode -> (N, A, 5+nc)                    (yoloDetector.py:23,111)
@@ -187,11 +187,12 @@ hipError_t launch_maxpool(TView in, TView out, int n, int k, int s, int p, int p
     PoolDev d{in.p, out.p, in.cs, in.coff, out.cs, out.coff, in.c, in.h, in.w, out.h, out.w, k, s, p, n};
     size_t total = (size_t)n * out.h * out.w * (in.c >> 3);
     int blocks = (int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
-    if (prec == PREC_FP32 || (k != 5 && k != 3)) {
+    if (prec == PREC_FP32 || (k != 5 && k != 3 && k != 2)) {
         ADAS_DISPATCH_STORAGE(prec, T, hipLaunchKernelGGL(maxpool_kernel<T>, dim3(blocks), dim3(256), 0, st_, d));
     } else {
         ADAS_DISPATCH_E16(prec == PREC_FP16, E, {
             if (k == 5) hipLaunchKernelGGL((maxpool16_kernel<E, 5>), dim3(blocks), dim3(256), 0, st_, d);
+            else if (k == 2) hipLaunchKernelGGL((maxpool16_kernel<E, 2>), dim3(blocks), dim3(256), 0, st_, d);   // YOLOv7's MP
             else hipLaunchKernelGGL((maxpool16_kernel<E, 3>), dim3(blocks), dim3(256), 0, st_, d);
         });
     }

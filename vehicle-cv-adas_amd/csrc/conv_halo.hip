@@ -44,6 +44,7 @@ template <int ACT>
 __device__ __forceinline__ float h_act(float v) {
     if (ACT == ACT_SILU) return v * __frcp_rn(1.0f + __expf(-v));
     if (ACT == ACT_RELU) return fmaxf(v, 0.0f);
+    if (ACT == ACT_LEAKY) return fmaxf(v, 0.1f * v);
     return v;
 }
 
@@ -443,10 +444,12 @@ static hipError_t launch_bn(const HaloDev& d, int act, dim3 grid, size_t lds, hi
         (void)hipFuncSetAttribute((const void*)conv_halo_kernel<E, BN, ACT_NONE, S, BM>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute((const void*)conv_halo_kernel<E, BN, ACT_SILU, S, BM>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute((const void*)conv_halo_kernel<E, BN, ACT_RELU, S, BM>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)conv_halo_kernel<E, BN, ACT_LEAKY, S, BM>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_done = true;
     }
     if (act == ACT_SILU) hipLaunchKernelGGL((conv_halo_kernel<E, BN, ACT_SILU, S, BM>), grid, dim3(256), lds, st, d);
     else if (act == ACT_RELU) hipLaunchKernelGGL((conv_halo_kernel<E, BN, ACT_RELU, S, BM>), grid, dim3(256), lds, st, d);
+    else if (act == ACT_LEAKY) hipLaunchKernelGGL((conv_halo_kernel<E, BN, ACT_LEAKY, S, BM>), grid, dim3(256), lds, st, d);
     else hipLaunchKernelGGL((conv_halo_kernel<E, BN, ACT_NONE, S, BM>), grid, dim3(256), lds, st, d);
     return hipGetLastError();
 }

@@ -101,6 +101,9 @@ __global__ __launch_bounds__(512) void conv_pw_kernel(PwDev a) {
             } else if (a.act == ACT_RELU) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+            } else if (a.act == ACT_LEAKY) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.1f * v[r]);
             }
             if (a.out_f32) {
                 *reinterpret_cast<float4*>((float*)a.out + obase + nt * 16) = make_float4(v[0], v[1], v[2], v[3]);

@@ -7,7 +7,7 @@ namespace adas {
 
 enum { PREC_BF16 = 0, PREC_FP32 = 1, PREC_FP16 = 2 };  // == ADAS_PREC_* (include/adas_hip.h)
 inline bool prec_is16(int prec) { return prec != PREC_FP32; }   // bf16 and fp16 share every 16-bit kernel (elem16.h)
-enum { ACT_NONE = 0, ACT_SILU = 1, ACT_RELU = 2 };
+enum { ACT_NONE = 0, ACT_SILU = 1, ACT_RELU = 2, ACT_LEAKY = 3 /* LeakyReLU(0.1): YOLOv7 (conv_halo, conv_pw, conv_pwg, conv_igemm) */ };
 enum { RES_NONE = 0, RES_AFTER_ACT = 1, RES_BEFORE_ACT = 2 };
 
 // One NHWC tensor view: channel slice [coff, coff+c) of a buffer whose pixel stride is `cs` elements.

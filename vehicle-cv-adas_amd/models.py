@@ -23,7 +23,7 @@ import numpy as np
 
 MAGIC = b"ADASHIP1"
 OP_INPUT, OP_CONV, OP_MAXPOOL, OP_UPSAMPLE2, OP_DETECT_V8, OP_DETECT_V5, OP_LAYERNORM, OP_DWCONV, OP_ATTENTION, OP_AVGPOOL = range(10)
-ACT_NONE, ACT_SILU, ACT_RELU = 0, 1, 2
+ACT_NONE, ACT_SILU, ACT_RELU, ACT_LEAKY = 0, 1, 2, 3      # ACT_LEAKY: LeakyReLU(0.1) (YOLOv7)
 RES_NONE, RES_AFTER_ACT, RES_BEFORE_ACT = 0, 1, 2
 BUF_F32 = 1
 BUF_ALIAS = 2      # flags bit 1: this buffer is another view of buffer (flags >> 8) - same bytes, different (h, w, c)
@@ -54,7 +54,8 @@ SILU_GAIN = 1.10                # YOLOv8 n/s: AT the critical gain (n ~1.11, s ~
 V5_SILU_GAIN = 1.15             # YOLOv5 (C3 blocks; kept at the round-1 value: its deeper scales are chaotic there, bf16 head rel-L2 6e-2,
                                 # and no better at 1.0)
 RELU_RES_GAIN = 0.8             # ResNet lane nets: ReLU + residual adds double the variance; flat drift at 0.8 (9e-4 rel-L2 fp16)
-SYNTH_GAINS = {"yolov9t": 1.12,                                       # critical between 1.16 and 1.22 (activations explode there)
+SYNTH_GAINS = {"yolov7-tiny": 1.0,                                    # LeakyReLU: piecewise linear, no chaos (fp16 rel-L2 1.3e-3 at any gain); 1.0 keeps rms ~0.4
+               "yolov9t": 1.12,                                       # critical between 1.16 and 1.22 (activations explode there)
                "yolov10n": 1.05,                                      # critical ~1.09 (1.08 already drifts: fp16 rel-L2 1.9e-3 at P5, boxes 0.3 px)
                "yolov8m": 0.99, "yolov8l": 0.96, "yolov8x": 0.98}     # deeper Bottleneck chains: critical gain ~1.03 (m), ~0.97 (l), ~1.0 (x)
 
@@ -605,6 +606,108 @@ def yolov9t(nc=80, imgsz=640, wsrc=None, seed=0):
 
 
 # =====================================================================================
+# YOLOv7-tiny (WongKinYiu/yolov7 cfg/deploy/yolov7-tiny.yaml; README.md:55 lists YOLOv7; yoloDetector.py:110-124 decodes its head as the
+# v5 layout (1, A, 5+nc)).  78 rows, every Conv with LeakyReLU(0.1): ELAN-tiny blocks (two 1x1 branches, two chained 3x3, concat of the
+# four, 1x1), MP = 2x2 stride-2 max-pool, an SPPCSPC-tiny (5 / 9 / 13 max-pools), PAN neck, IDetect (its ImplicitA / ImplicitM fold
+# into the 1x1 at deploy: the v5 Detect arithmetic with the tiny yaml's anchors).  Weight names: `model.<row>.conv` as upstream.
+# =====================================================================================
+V7_TINY_ANCHORS = [[10, 13, 16, 30, 33, 23], [30, 61, 62, 45, 59, 119], [116, 90, 156, 198, 373, 326]]
+
+
+def yolov7_tiny(nc=80, imgsz=640, wsrc=None, seed=0):
+    wsrc = wsrc or SynthWeights(seed, gain=synth_gain("yolov7-tiny"))
+    H, W = _hw(imgsz)
+    g = Graph("yolov7-tiny", 3, H, W, wsrc)
+    x, cin = g.input()
+    row = [0]
+
+    def cv(src, c, k, s, out=None, true_cin=None):
+        y = g.conv(src, c, k, s, f"model.{row[0]}.conv", act=ACT_LEAKY, out=out, true_cin=true_cin)
+        row[0] += 1
+        return y
+
+    def elan(src, c, cout, out=None):
+        """rows r .. r+5: 1x1 (a), 1x1 on the same input (b), 3x3 on b (c), 3x3 on c (d), Concat [d, c, b, a], 1x1."""
+        cat = g.buf(src.h, src.w, 4 * c)
+        cv(src, c, 1, 1, out=cat.slice(3 * c, c))
+        b = cv(src, c, 1, 1, out=cat.slice(2 * c, c))
+        cc = cv(b, c, 3, 1, out=cat.slice(c, c))
+        cv(cc, c, 3, 1, out=cat.slice(0, c))
+        row[0] += 1                                        # the Concat row
+        return cv(cat, cout, 1, 1, out=out)
+
+    def mp(src):
+        y = g.maxpool(src, 2, 2, 0, name=f"model.{row[0]}")
+        row[0] += 1
+        return y
+
+    cat59 = g.buf(H // 16, W // 16, 256)                   # row 59: Concat [row 58, row 47]
+    cat67 = g.buf(H // 32, W // 32, 512)                   # row 67: Concat [row 66, row 37]
+    x = cv(x, 32, 3, 2, true_cin=cin)                      # 0
+    x = cv(x, 64, 3, 2)                                    # 1
+    x = elan(x, 32, 64)                                    # 2-7
+    x = mp(x)                                              # 8
+    p3b = elan(x, 64, 128)                                 # 9-14
+    x = mp(p3b)                                            # 15
+    p4b = elan(x, 128, 256)                                # 16-21
+    x = mp(p4b)                                            # 22
+    x = elan(x, 256, 512)                                  # 23-28
+    # SPPCSPC-tiny, rows 29-37: bypass = row 29, pooled branch on row 30
+    catb = g.buf(x.h, x.w, 512)                            # row 36: Concat [row 35, row 29]
+    cats = g.buf(x.h, x.w, 1024)                           # row 34: Concat [SP13, SP9, SP5, row 30]
+    cv(x, 256, 1, 1, out=catb.slice(256, 256))             # 29
+    r30 = cv(x, 256, 1, 1, out=cats.slice(768, 256))       # 30
+    for k, off in ((5, 512), (9, 256), (13, 0)):           # 31, 32, 33: SP(k) = MaxPool2d(k, 1, k // 2), each on row 30
+        g.maxpool(r30, k, 1, k // 2, out=cats.slice(off, 256), name=f"model.{row[0]}")
+        row[0] += 1
+    row[0] += 1                                            # 34 Concat
+    cv(cats, 256, 1, 1, out=catb.slice(0, 256))            # 35
+    row[0] += 1                                            # 36 Concat
+    p5 = cv(catb, 256, 1, 1, out=cat67.slice(256, 256))    # 37
+    # top-down
+    cat41 = g.buf(H // 16, W // 16, 256)                   # row 41: Concat [row 40, row 39]
+    t = cv(p5, 128, 1, 1)                                  # 38
+    g.upsample2(t, out=cat41.slice(128, 128), name=f"model.{row[0]}"); row[0] += 1      # 39
+    cv(p4b, 128, 1, 1, out=cat41.slice(0, 128))            # 40 (route backbone P4 = row 21)
+    row[0] += 1                                            # 41
+    n47 = elan(cat41, 64, 128, out=cat59.slice(128, 128))  # 42-47
+    cat51 = g.buf(H // 8, W // 8, 128)                     # row 51: Concat [row 50, row 49]
+    t = cv(n47, 64, 1, 1)                                  # 48
+    g.upsample2(t, out=cat51.slice(64, 64), name=f"model.{row[0]}"); row[0] += 1        # 49
+    cv(p3b, 64, 1, 1, out=cat51.slice(0, 64))              # 50 (route backbone P3 = row 14)
+    row[0] += 1                                            # 51
+    n57 = elan(cat51, 32, 64)                              # 52-57
+    # bottom-up
+    cv(n57, 128, 3, 2, out=cat59.slice(0, 128))            # 58
+    row[0] += 1                                            # 59
+    n65 = elan(cat59, 64, 128)                             # 60-65
+    cv(n65, 256, 3, 2, out=cat67.slice(0, 256))            # 66
+    row[0] += 1                                            # 67
+    n73 = elan(cat67, 128, 256)                            # 68-73
+    assert row[0] == 74, row[0]
+    feats = [cv(n57, 128, 3, 1), cv(n65, 256, 3, 1), cv(n73, 512, 3, 1)]      # 74, 75, 76
+    no = nc + 5
+    ins, strides = [], []
+    for i, f in enumerate(feats):                          # 77: IDetect, deploy form (implicit layers folded into the 1x1)
+        s_ = H // f.h
+        strides.append(s_)
+        bias = np.zeros((3, no), np.float32)
+        bias[:, 4] = math.log(8 / (640 / s_) ** 2)
+        bias[:, 5:] = math.log(0.6 / (nc - 0.999999))
+        name = f"model.77.m.{i}"
+        if isinstance(wsrc, SynthWeights) and name + ".bias" not in wsrc.store:
+            wsrc.store[name + ".bias"] = bias.reshape(-1) + 0.01 * wsrc.rng.standard_normal(3 * no).astype(np.float32)
+        ins.append(g.conv(f, 3 * no, 1, 1, name, act=ACT_NONE, f32_out=True))
+    A = 3 * sum(f.h * f.w for f in feats)
+    head = g.buf(1, 1, A * no, f32=True)
+    g._op(OP_DETECT_V5, ins, head, params=[nc, A] + strides, name="model.77.decode")
+    g.ops[-1]["w"] = g._blob(np.asarray([a for lvl in V7_TINY_ANCHORS for a in lvl], np.float32))
+    g.output(head, 0, [1, A, no], "output0")
+    g.meta = dict(kind="yolov7", nc=nc, anchors=A, strides=strides)
+    return g
+
+
+# =====================================================================================
 # YOLOv5 v6.2
 # =====================================================================================
 V5_SCALES = {"n": (0.33, 0.25), "s": (0.33, 0.50), "m": (0.67, 0.75), "l": (1.0, 1.0), "x": (1.33, 1.25)}
@@ -668,7 +771,7 @@ def yolov5(scale="n", nc=80, imgsz=640, wsrc=None, seed=0):
         bias[:, 4] = math.log(8 / (640 / s) ** 2)
         bias[:, 5:] = math.log(0.6 / (nc - 0.999999))
         name = f"model.24.m.{i}"
-        if isinstance(wsrc, SynthWeights):
+        if isinstance(wsrc, SynthWeights) and name + ".bias" not in wsrc.store:
             wsrc.store[name + ".bias"] = bias.reshape(-1) + 0.01 * wsrc.rng.standard_normal(3 * no).astype(np.float32)
         ins.append(g.conv(f, 3 * no, 1, 1, name, act=ACT_NONE, f32_out=True))
     A = 3 * sum(f.h * f.w for f in feats)
@@ -798,6 +901,7 @@ BUILDERS = {
     "yolov8x": lambda **k: yolov8("x", **k),
     "yolov10n": lambda **k: yolov10("n", **k),
     "yolov9t": lambda **k: yolov9t(**k),
+    "yolov7-tiny": lambda **k: yolov7_tiny(**k),
     "yolov5n": lambda **k: yolov5("n", **k), "yolov5s": lambda **k: yolov5("s", **k),
     "yolov5m": lambda **k: yolov5("m", **k), "yolov5l": lambda **k: yolov5("l", **k), "yolov5x": lambda **k: yolov5("x", **k),
     "ufldv2_res18": lambda **k: ufldv2("18", **k), "ufldv2_res34": lambda **k: ufldv2("34", **k),
