@@ -303,3 +303,26 @@ def test_yolov9t_recognised_by_average_pool_or_names(tmp_path):
     assert OI.detect_arch(m) == ("yolov9t", dict(nc=80, imgsz=(640, 640)))
     out, g2 = OI.convert(str(p), str(tmp_path / "v9.hipm"))
     assert g2.name == "yolov9t" and g2.tobytes() == M.build("yolov9t", wsrc=M.DictWeights(W)).tobytes()
+
+
+def test_yolov7_tiny_recognised_by_stem_and_v5_layout(tmp_path):
+    """YOLOv7-tiny: (1, 25200, 85) head like YOLOv5 but a 3x3 32-channel stem and 58 convolutions (LeakyRelu nodes between them);
+    weights by their upstream names (model.<row>.conv, model.77.m.<level>)."""
+    W, g = synth("yolov7-tiny")
+    inits, nodes = [], []
+    for i, base in enumerate(k[:-7] for k in list(W) if k.endswith(".weight")):
+        w, b = W[base + ".weight"], W[base + ".bias"]
+        inits.append(OW.tensor(base + ".weight", w)); inits.append(OW.tensor(base + ".bias", b))
+        nodes.append(OW.node("Conv", ["t%d" % i, base + ".weight", base + ".bias"], ["c%d" % i], "Conv_%d" % i,
+                             [OW.attr_ints("kernel_shape", list(w.shape[2:]))]))
+        nodes.append(OW.node("LeakyRelu", ["c%d" % i], ["t%d" % (i + 1)], "LeakyRelu_%d" % i, [OW.attr_float("alpha", 0.1)]))
+    p = tmp_path / "yolov7-tiny.onnx"
+    p.write_bytes(OW.model(nodes, inits, [("images", [1, 3, 640, 640])], [("output", [1, 25200, 85])]))
+    m = OI.read_onnx(str(p))
+    assert OI.detect_arch(m) == ("yolov7-tiny", dict(nc=80, imgsz=(640, 640)))
+    out, g2 = OI.convert(str(p), str(tmp_path / "v7.hipm"))
+    assert g2.name == "yolov7-tiny" and g2.tobytes() == M.build("yolov7-tiny", wsrc=M.DictWeights(W)).tobytes()
+    q = tmp_path / "yolov7.onnx"                             # another YOLOv7 scale: refused by name, not mis-built
+    q.write_bytes(OW.model(nodes[:40], inits, [("images", [1, 3, 640, 640])], [("output", [1, 25200, 85])]))
+    with pytest.raises(ValueError, match="yolov7-tiny"):
+        OI.detect_arch(OI.read_onnx(str(q)))

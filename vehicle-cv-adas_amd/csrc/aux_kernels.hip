@@ -633,6 +633,166 @@ hipError_t launch_detect_v5(const TView* ins, float* out, int n, int nc, int A, 
     return hipGetLastError();
 }
 
+// ------------------------------------------------------------------------------------- Detect (v5 layout), fused with its 1x1 convs
+// model.24.m.l (YOLOv5) / model.77.m.l (YOLOv7 IDetect, deploy form) produce 3 * (5 + nc) raw logits per cell that feed nothing but the
+// decode: as separate launches the fp32 logits are written once and read once (2 x 4 * A * (5 + nc) bytes per frame, 1.1 GB per 64-frame
+// step at 640x640) around a Cout = 255 GEMM that fits no 16-channel-tiled kernel.  Here a workgroup owns 128 consecutive cells of one
+// anchor of one level of one frame: the anchor's 5 + nc weight rows (zero-padded to 16-row MFMA A tiles, streamed through LDS in
+// 256-channel K chunks) times the cells' activations (B fragments straight from HBM), then sigmoid + grid / anchor decode in the
+// accumulators, staged through LDS so that every wave writes its 32 rows of the (A, 5 + nc) output as one contiguous run.
+#define ADAS_DET5_NT 6     // 16-row tiles per anchor: 5 + nc <= 96
+#define ADAS_DET5_KC 8     // K steps (of 32 channels) per LDS weight chunk
+struct Det5Dev {
+    const uint16_t* x[3];   // level inputs (16-bit NHWC views)
+    int x_cs[3], x_coff[3], cin[3];
+    const uint16_t* w[3];   // [anchor][k step][tile][lane][8] MFMA A fragments (launch_pack_weights_det5)
+    const float* bias[3];   // [3 * (5 + nc)]
+    int hw[3], nx[3], stride[3], row_off[3], blk_off[3];
+    const float* anchors;   // [3 levels][3 anchors][2]
+    float* out;
+    int nc, A, n;
+};
+
+template <typename E>
+__global__ __launch_bounds__(256) void detect_v5_fused_kernel(Det5Dev d) {
+    extern __shared__ __attribute__((aligned(16))) uint16_t wl[];      // weight chunk, then the output staging
+    E::enter();
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lrow = lane & 15, kg = lane >> 4;
+    const int b = blockIdx.y, no = d.nc + 5, NT = (no + 15) >> 4;
+    const int lvl = (int)blockIdx.x >= d.blk_off[2] ? 2 : ((int)blockIdx.x >= d.blk_off[1] ? 1 : 0);
+    const int hw = d.hw[lvl], nblk = (hw + 127) >> 7;
+    const int rel = blockIdx.x - d.blk_off[lvl], a = rel / nblk, p0 = (rel - a * nblk) * 128 + wave * 32;
+    const int KS = d.cin[lvl] >> 5;
+    const uint16_t* wsrc = d.w[lvl] + (size_t)a * KS * NT * 512;
+
+    const uint16_t* ip[2];
+    bool ok[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const int p = p0 + t * 16 + lrow;
+        ok[t] = p < hw;
+        ip[t] = d.x[lvl] + ((size_t)b * hw + (ok[t] ? p : 0)) * d.x_cs[lvl] + d.x_coff[lvl] + kg * 8;
+    }
+    df32x4 acc[2][ADAS_DET5_NT];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int nt = 0; nt < ADAS_DET5_NT; ++nt) acc[t][nt] = df32x4{0.f, 0.f, 0.f, 0.f};
+
+    for (int ks0 = 0; ks0 < KS; ks0 += ADAS_DET5_KC) {
+        const int kc = min(ADAS_DET5_KC, KS - ks0);
+        du32x4 xb[2][ADAS_DET5_KC];                         // the chunk's activations: in flight while the weights are staged
+#pragma unroll
+        for (int k = 0; k < ADAS_DET5_KC; ++k)
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                xb[t][k] = du32x4{0u, 0u, 0u, 0u};
+                if (k < kc && ok[t]) xb[t][k] = *reinterpret_cast<const du32x4*>(ip[t] + (ks0 + k) * 32);
+            }
+        __syncthreads();
+        const du32x4* src = reinterpret_cast<const du32x4*>(wsrc + (size_t)ks0 * NT * 512);
+        for (int i = tid; i < kc * NT * 64; i += 256) reinterpret_cast<du32x4*>(wl)[i] = src[i];
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < ADAS_DET5_KC; ++k) {
+            if (k < kc) {
+#pragma unroll
+                for (int nt = 0; nt < ADAS_DET5_NT; ++nt) {
+                    if (nt < NT) {
+                        const du32x4 wf = *reinterpret_cast<const du32x4*>(wl + ((size_t)(k * NT + nt) * 64 + lane) * 8);
+                        acc[0][nt] = E::mfma(wf, xb[0][k], acc[0][nt]);
+                        acc[1][nt] = E::mfma(wf, xb[1][k], acc[1][nt]);
+                    }
+                }
+            }
+        }
+    }
+    __syncthreads();
+    // ---- sigmoid + decode (yolov5 models/yolo.py Detect.forward, inference branch) into this wave's staging rows [32][no]
+    float* stage = reinterpret_cast<float*>(wl) + (size_t)wave * 32 * no;
+    const float sl = (float)d.stride[lvl];
+    const float aw = d.anchors[lvl * 6 + a * 2], ah = d.anchors[lvl * 6 + a * 2 + 1];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const int p = p0 + t * 16 + lrow;
+        const float gx = (float)(p % d.nx[lvl]), gy = (float)(p / d.nx[lvl]);
+#pragma unroll
+        for (int nt = 0; nt < ADAS_DET5_NT; ++nt) {
+            if (nt < NT) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int c = nt * 16 + kg * 4 + r;
+                    if (c < no) {
+                        const float sg = 1.0f / (1.0f + expf(-(acc[t][nt][r] + d.bias[lvl][a * no + c])));
+                        float o = sg;
+                        if (c == 0) o = (sg * 2.0f - 0.5f + gx) * sl;
+                        else if (c == 1) o = (sg * 2.0f - 0.5f + gy) * sl;
+                        else if (c < 4) { const float q = sg * 2.0f; o = q * q * (c == 2 ? aw : ah); }
+                        stage[(t * 16 + lrow) * no + c] = o;
+                    }
+                }
+            }
+        }
+    }
+    __syncthreads();
+    const int rows = min(32, hw - p0);
+    if (rows > 0) {
+        float* dst = d.out + ((size_t)b * d.A + d.row_off[lvl] + (size_t)a * hw + p0) * no;
+        for (int i = lane; i < rows * no; i += 64) dst[i] = stage[i];
+    }
+}
+
+// fp32 [3 * no][cin] (1x1 conv) -> per anchor MFMA A fragments [a][k step][tile][lane][8]: row = a * no + 16 * tile + (lane & 15) (zero
+// for rows past the anchor's no), K = 32 ks + 8 (lane >> 4) + e
+template <typename T>
+__global__ void pack_weights_det5_kernel(const float* __restrict__ src, T* __restrict__ dst, int no, int cin, int nt_n, int total) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int nks = cin >> 5;
+    const int e = idx & 7, lane = (idx >> 3) & 63, f = idx >> 9;
+    const int nt = f % nt_n, ks = (f / nt_n) % nks, a = f / (nt_n * nks);
+    const int c = nt * 16 + (lane & 15), k = ks * 32 + (lane >> 4) * 8 + e;
+    const float v = c < no ? src[(size_t)(a * no + c) * cin + k] : 0.0f;
+    st(dst + idx, v);
+}
+size_t det5_weight_bytes(int no, int cin) { return (size_t)3 * ((no + 15) / 16) * (cin / 32) * 512 * 2; }
+bool det5_applicable(int prec, int nc, const TView& in, const TView& logits) {
+    static int off = -1;
+    if (off < 0) { const char* e = getenv("ADAS_NO_DETECT_FUSE"); off = (e && e[0] == '1') ? 1 : 0; }
+    if (off || !prec_is16(prec) || nc + 5 > 16 * ADAS_DET5_NT) return false;
+    if (in.f32 || !logits.f32 || logits.c != 3 * (nc + 5) || logits.coff) return false;
+    return (in.c & 31) == 0 && ((in.cs | in.coff) & 7) == 0 && in.h == logits.h && in.w == logits.w;
+}
+hipError_t launch_pack_weights_det5(const float* src, void* dst, int no, int cin, int prec, hipStream_t st) {
+    const int nt_n = (no + 15) / 16, total = 3 * nt_n * (cin / 32) * 512;
+    if (prec == PREC_FP16) hipLaunchKernelGGL(pack_weights_det5_kernel<f16s>, dim3((total + 255) / 256), dim3(256), 0, st, src, (f16s*)dst, no, cin, nt_n, total);
+    else hipLaunchKernelGGL(pack_weights_det5_kernel<uint16_t>, dim3((total + 255) / 256), dim3(256), 0, st, src, (uint16_t*)dst, no, cin, nt_n, total);
+    return hipGetLastError();
+}
+// hidden[l]: input of the level's 1x1 conv; wfrag / bias: its det5-packed weights and its 3 * (5 + nc) biases
+hipError_t launch_detect_v5_fused(const TView* hidden, const void* const* wfrag, const float* const* bias, float* out, int n, int nc, int A,
+                                  const int strides[3], const float* d_anchors, int prec, hipStream_t st_) {
+    Det5Dev d;
+    int off = 0, blocks = 0;
+    const int no = nc + 5, NT = (no + 15) / 16;
+    if (NT > ADAS_DET5_NT) return hipErrorInvalidValue;
+    for (int l = 0; l < 3; ++l) {
+        const TView& h = hidden[l];
+        if (h.f32 || (h.c & 31) || ((h.cs | h.coff) & 7)) return hipErrorInvalidValue;
+        d.x[l] = (const uint16_t*)h.p; d.x_cs[l] = h.cs; d.x_coff[l] = h.coff; d.cin[l] = h.c;
+        d.w[l] = (const uint16_t*)wfrag[l]; d.bias[l] = bias[l];
+        d.hw[l] = h.h * h.w; d.nx[l] = h.w; d.stride[l] = strides[l]; d.row_off[l] = off; d.blk_off[l] = blocks;
+        off += 3 * d.hw[l];
+        blocks += 3 * ((d.hw[l] + 127) / 128);
+    }
+    if (off != A) return hipErrorInvalidValue;
+    d.anchors = d_anchors; d.out = out; d.nc = nc; d.A = A; d.n = n;
+    const size_t lw = (size_t)ADAS_DET5_KC * NT * 1024, ls = (size_t)4 * 32 * no * 4;
+    const size_t lds = lw > ls ? lw : ls;
+    ADAS_DISPATCH_E16(prec == PREC_FP16, E, hipLaunchKernelGGL(detect_v5_fused_kernel<E>, dim3(blocks, n), dim3(256), lds, st_, d));
+    return hipGetLastError();
+}
+
 // ------------------------------------------------------------------------------------- LayerNorm
 template <typename T>
 __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ in, T* __restrict__ out,

@@ -87,6 +87,7 @@ template <int ACT>
 __device__ __forceinline__ float h8_act(float v) {
     if (ACT == ACT_SILU) return v * __frcp_rn(1.0f + __expf(-v));
     if (ACT == ACT_RELU) return fmaxf(v, 0.0f);
+    if (ACT == ACT_LEAKY) return fmaxf(v, 0.1f * v);
     return v;
 }
 
@@ -601,10 +602,12 @@ static hipError_t h8_launch(const H8Dev& d, int act, dim3 grid, hipStream_t st) 
         (void)hipFuncSetAttribute((const void*)conv_h8_kernel<E, ACT_NONE, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute((const void*)conv_h8_kernel<E, ACT_SILU, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute((const void*)conv_h8_kernel<E, ACT_RELU, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)conv_h8_kernel<E, ACT_LEAKY, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_done = true;
     }
     if (act == ACT_SILU) hipLaunchKernelGGL((conv_h8_kernel<E, ACT_SILU, MODE>), grid, dim3(H8_THR), H8_LDS, st, d);
     else if (act == ACT_RELU) hipLaunchKernelGGL((conv_h8_kernel<E, ACT_RELU, MODE>), grid, dim3(H8_THR), H8_LDS, st, d);
+    else if (act == ACT_LEAKY) hipLaunchKernelGGL((conv_h8_kernel<E, ACT_LEAKY, MODE>), grid, dim3(H8_THR), H8_LDS, st, d);
     else hipLaunchKernelGGL((conv_h8_kernel<E, ACT_NONE, MODE>), grid, dim3(H8_THR), H8_LDS, st, d);
     return hipGetLastError();
 }

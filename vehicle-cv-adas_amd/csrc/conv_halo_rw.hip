@@ -28,6 +28,7 @@ template <int ACT>
 __device__ __forceinline__ float r_act(float v) {
     if (ACT == ACT_SILU) return v * __frcp_rn(1.0f + __expf(-v));
     if (ACT == ACT_RELU) return fmaxf(v, 0.0f);
+    if (ACT == ACT_LEAKY) return fmaxf(v, 0.1f * v);
     return v;
 }
 
@@ -376,10 +377,12 @@ static hipError_t rw_launch(const RwDev& d, int act, int grid, size_t lds, hipSt
         (void)hipFuncSetAttribute((const void*)conv_halo_rw_kernel<E, NCH, ACT_NONE, HAS_RES, BN>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute((const void*)conv_halo_rw_kernel<E, NCH, ACT_SILU, HAS_RES, BN>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute((const void*)conv_halo_rw_kernel<E, NCH, ACT_RELU, HAS_RES, BN>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)conv_halo_rw_kernel<E, NCH, ACT_LEAKY, HAS_RES, BN>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_done = true;
     }
     if (act == ACT_SILU) hipLaunchKernelGGL((conv_halo_rw_kernel<E, NCH, ACT_SILU, HAS_RES, BN>), dim3(grid), dim3(RW_THR), lds, st, d);
     else if (act == ACT_RELU) hipLaunchKernelGGL((conv_halo_rw_kernel<E, NCH, ACT_RELU, HAS_RES, BN>), dim3(grid), dim3(RW_THR), lds, st, d);
+    else if (act == ACT_LEAKY) hipLaunchKernelGGL((conv_halo_rw_kernel<E, NCH, ACT_LEAKY, HAS_RES, BN>), dim3(grid), dim3(RW_THR), lds, st, d);
     else hipLaunchKernelGGL((conv_halo_rw_kernel<E, NCH, ACT_NONE, HAS_RES, BN>), dim3(grid), dim3(RW_THR), lds, st, d);
     return hipGetLastError();
 }

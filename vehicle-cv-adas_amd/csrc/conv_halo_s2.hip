@@ -30,6 +30,7 @@ template <int ACT>
 __device__ __forceinline__ float s2_act(float v) {
     if (ACT == ACT_SILU) return v * __frcp_rn(1.0f + __expf(-v));
     if (ACT == ACT_RELU) return fmaxf(v, 0.0f);
+    if (ACT == ACT_LEAKY) return fmaxf(v, 0.1f * v);
     return v;
 }
 
@@ -309,14 +310,15 @@ hipError_t launch_conv_halo_s2p(const ConvArgs& a, hipStream_t st) {
     static bool attr_done = false;
     if (!attr_done) {
 #define S2_ATTR(E_, A_) (void)hipFuncSetAttribute((const void*)conv_s2p_kernel<E_, A_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)
-        S2_ATTR(Bf16, ACT_NONE); S2_ATTR(Bf16, ACT_SILU); S2_ATTR(Bf16, ACT_RELU);
-        S2_ATTR(Fp16, ACT_NONE); S2_ATTR(Fp16, ACT_SILU); S2_ATTR(Fp16, ACT_RELU);
+        S2_ATTR(Bf16, ACT_NONE); S2_ATTR(Bf16, ACT_SILU); S2_ATTR(Bf16, ACT_RELU); S2_ATTR(Bf16, ACT_LEAKY);
+        S2_ATTR(Fp16, ACT_NONE); S2_ATTR(Fp16, ACT_SILU); S2_ATTR(Fp16, ACT_RELU); S2_ATTR(Fp16, ACT_LEAKY);
 #undef S2_ATTR
         attr_done = true;
     }
     ADAS_DISPATCH_E16(a.prec == PREC_FP16, E, {
         if (a.act == ACT_SILU) hipLaunchKernelGGL((conv_s2p_kernel<E, ACT_SILU>), grid, dim3(S2_THR), lds, st, d);
         else if (a.act == ACT_RELU) hipLaunchKernelGGL((conv_s2p_kernel<E, ACT_RELU>), grid, dim3(S2_THR), lds, st, d);
+        else if (a.act == ACT_LEAKY) hipLaunchKernelGGL((conv_s2p_kernel<E, ACT_LEAKY>), grid, dim3(S2_THR), lds, st, d);
         else hipLaunchKernelGGL((conv_s2p_kernel<E, ACT_NONE>), grid, dim3(S2_THR), lds, st, d);
     });
     return hipGetLastError();

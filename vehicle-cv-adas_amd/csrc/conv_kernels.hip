@@ -313,12 +313,11 @@ const char* conv_tile_name(const ConvArgs& a, int prec) {
 const char* conv_kernel_name(const ConvArgs& a, int prec, int kernel) {
     static thread_local char buf[96];
     const char* actn = a.act == ACT_SILU ? "SILU" : (a.act == ACT_RELU ? "RELU" : (a.act == ACT_LEAKY ? "LEAKY" : "NONE"));
-    const bool leaky = a.act == ACT_LEAKY;   // only conv_halo / conv_pw / conv_pwg / conv_igemm instantiate LeakyReLU
-    if (kernel == CONV_HALO && !leaky && halo_rw_applicable(a.kh, a.kw, a.stride, a.pad, a.n, a.in, a.out)) {
+    if (kernel == CONV_HALO && halo_rw_applicable(a.kh, a.kw, a.stride, a.pad, a.n, a.in, a.out)) {
         snprintf(buf, sizeof(buf), a.out.c <= 32 ? "conv_halo_rw_kernel<%d,%s,bn32>" : "conv_halo_rw_kernel<%d,%s>", (a.in.c + 31) / 32, actn);
-    } else if (kernel == CONV_HALO && !leaky && halo_s2p_applicable(a.kh, a.kw, a.stride, a.pad, a.res_mode, a.n, a.in, a.out)) {
+    } else if (kernel == CONV_HALO && halo_s2p_applicable(a.kh, a.kw, a.stride, a.pad, a.res_mode, a.n, a.in, a.out)) {
         snprintf(buf, sizeof(buf), "conv_s2p_kernel<%s>", actn);
-    } else if (kernel == CONV_HALO && !leaky && halo8_applicable(a.kh, a.kw, a.stride, a.pad, a.n, a.in, a.out, a.res, a.res_mode)) {
+    } else if (kernel == CONV_HALO && halo8_applicable(a.kh, a.kw, a.stride, a.pad, a.n, a.in, a.out, a.res, a.res_mode)) {
         snprintf(buf, sizeof(buf), "conv_h8_kernel<%s>", actn);
     } else if (kernel == CONV_HALO) {
         snprintf(buf, sizeof(buf), a.stride == 1 && halo_tile_pixels(a) == 128 ? "conv_halo_kernel<%d,%s,s%d,bm128>" : "conv_halo_kernel<%d,%s,s%d>",
@@ -421,7 +420,6 @@ hipError_t launch_conv(const ConvArgs& a, int prec, hipStream_t st) {
         return e == hipErrorNotSupported ? hipErrorInvalidValue : e;
     }
     if (pl.kernel == CONV_HALO) {
-        if (a.act == ACT_LEAKY) return launch_conv_halo(a, st);   // LeakyReLU: instantiated in conv_halo only
         if (halo_rw_applicable(a.kh, a.kw, a.stride, a.pad, a.n, a.in, a.out)) {
             hipError_t e = launch_conv_halo_rw(a, st);
             if (e != hipErrorNotSupported) return e;  // e.g. a residual view that is not 16-byte aligned: same packing, other kernel

@@ -27,6 +27,7 @@ template <int ACT>
 __device__ __forceinline__ float s_act(float v) {
     if (ACT == ACT_SILU) return v * __frcp_rn(1.0f + __expf(-v));
     if (ACT == ACT_RELU) return fmaxf(v, 0.0f);
+    if (ACT == ACT_LEAKY) return fmaxf(v, 0.1f * v);
     return v;
 }
 
@@ -308,7 +309,7 @@ bool stem_applicable(int prec, int in_c_true, int kh, int kw, int stride, int pa
     const TView& o = pool ? pool_out : out;
     if ((o.cs & 7) || (o.coff & 7) || o.f32) return false;
     if (pool && (kh != 7 || out.c != 64 || act != ACT_RELU)) return false;  // the ResNet stem is the only pooled instance
-    if (!pool && !(act == ACT_SILU || act == ACT_RELU)) return false;
+    if (!pool && !(act == ACT_SILU || act == ACT_RELU || (act == ACT_LEAKY && kh == 3))) return false;
     return true;
 }
 
@@ -377,6 +378,13 @@ hipError_t launch_conv_stem2(const float* nchw, int n, int c_true, int H, int W,
 template <typename E, int KH, int NT, bool POOL>
 static hipError_t stem_launch_act(const StemDev& d, int act, bool packed_in, hipStream_t st) {
     const int grid = d.ntiles < 1024 ? d.ntiles : 1024;
+    if constexpr (KH == 3 && !POOL) {      // LeakyReLU(0.1): the 3x3 stems only (YOLOv7)
+        if (act == ACT_LEAKY) {
+            if (packed_in) hipLaunchKernelGGL((conv_stem_kernel<E, KH, NT, ACT_LEAKY, POOL, false, true>), dim3(grid), dim3(256), 0, st, d);
+            else hipLaunchKernelGGL((conv_stem_kernel<E, KH, NT, ACT_LEAKY, POOL, false, false>), dim3(grid), dim3(256), 0, st, d);
+            return hipGetLastError();
+        }
+    }
     if (packed_in) {
         if (act == ACT_RELU) hipLaunchKernelGGL((conv_stem_kernel<E, KH, NT, ACT_RELU, POOL, false, true>), dim3(grid), dim3(256), 0, st, d);
         else hipLaunchKernelGGL((conv_stem_kernel<E, KH, NT, ACT_SILU, POOL, false, true>), dim3(grid), dim3(256), 0, st, d);

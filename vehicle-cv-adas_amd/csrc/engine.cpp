@@ -359,6 +359,38 @@ int adas_engine_create(const char* model_path, int precision, int max_batch, ada
     }
     // ---- whole-C2f fusion (conv_c2f.hip): cv1 1x1 -> [split] -> fused 3x3 pair with shortcut -> cv2 1x1 over the concat, when the concat
     // buffer has no other reader: one launch, the concat is never written (YOLOv8n / YOLOv10n model.2)
+    // ---- v5-layout Detect fusion (aux_kernels.hip detect_v5_fused_kernel): the per-level 1x1 convs feed only the decode; decided before
+    // the weight layout because the fused launch wants per-anchor MFMA fragments (CONV_DET5)
+    std::vector<int> det5_of(e->ops.size(), -1);    // conv -> its OP_DETECT_V5
+    for (size_t di = 0; di < fo.size(); ++di) {
+        const FileOp& dq = fo[di];
+        if (dq.type != OP_DETECT_V5 || dq.n_in != 3) continue;
+        int src[3];
+        bool ok = true;
+        for (int k = 0; k < 3 && ok; ++k) {
+            src[k] = -1;
+            for (size_t j = 0; j < di; ++j)
+                if (fo[j].type == OP_CONV && fo[j].out_buf == dq.in_buf[k] && fo[j].out_coff == dq.in_coff[k] && fo[j].out_c == dq.in_c[k]) src[k] = (int)j;
+            ok = src[k] >= 0;
+            if (!ok) break;
+            const FileOp& q = fo[src[k]];
+            ok = q.kh == 1 && q.kw == 1 && q.stride == 1 && q.pad == 0 && q.act == ACT_NONE && q.res_mode == RES_NONE && q.n_in == 1 && !e->ops[src[k]].skip &&
+                 det5_applicable(precision, (int)dq.params[0], make_view(e, q.in_buf[0], q.in_coff[0], q.in_c[0]), make_view(e, q.out_buf, q.out_coff, q.out_c));
+            for (size_t j = 0; j < fo.size() && ok; ++j) {  // nobody else reads the logits
+                if (j == di) continue;
+                for (uint32_t t = 0; t < fo[j].n_in && t < 8; ++t) ok = ok && fo[j].in_buf[t] != q.out_buf;
+                ok = ok && !(fo[j].res_mode != RES_NONE && fo[j].res_buf == q.out_buf);
+            }
+            for (auto& out : fout) ok = ok && out.buf != q.out_buf;
+            ok = ok && !aliased(q.out_buf);
+        }
+        if (!ok) continue;
+        for (int k = 0; k < 3; ++k) {
+            e->ops[di].det_src[k] = src[k];
+            e->ops[src[k]].skip = true;
+            det5_of[src[k]] = (int)di;
+        }
+    }
     std::vector<int> c2f_role(e->ops.size(), 0);   // 1: cv1 (launches the block), 2: cv2
     for (size_t ai = 0; ai < e->ops.size(); ++ai) {
         const int bi = e->ops[ai].pair_b;
@@ -432,6 +464,14 @@ int adas_engine_create(const char* model_path, int precision, int max_batch, ada
             const size_t self = (size_t)(&op - &e->ops[0]);
             if (op.pair_b >= 0 || pair_of[self] >= 0) op.kernel = CONV_PAIR;   // fragment packing (fits the plan's allocation: <= 18 KB)
             if (c2f_role[self]) op.kernel = CONV_C2F_PW;                        // 1x1 fragments: 2 / 4 KB, inside the plan's 8 / 16 KB
+            if (det5_of[self] >= 0) {                                           // per-anchor fragments: 3 x 96 rows, more than the plan's 256
+                op.kernel = CONV_DET5;
+                op.w_off = packed_total;
+                packed_total += (det5_weight_bytes(cout / 3, cin) + 255) & ~(size_t)255;
+                op.b_off = packed_total;
+                packed_total += ((size_t)op.cout_pad * 4 + 255) & ~(size_t)255;
+                continue;
+            }
             if (op.ds_user >= 0) {   // second copy of the projection weights, as per-step tiles
                 op.ds_w_off = packed_total;
                 packed_total += ((size_t)cout * cin * esz + 255) & ~(size_t)255;
@@ -531,7 +571,8 @@ int adas_engine_create(const char* model_path, int precision, int max_batch, ada
                 if (hipMemcpy(base + op.b_off, b.data(), (size_t)op.cout_pad * 4, hipMemcpyHostToDevice) != hipSuccess) { rc = ADAS_ERR_HIP; break; }
                 continue;
             }
-            hipError_t pe = op.kernel == CONV_C2F_PW ? launch_pack_weights_c2f_pw(d_stage, base + op.w_off, o.out_c, o.in_c[0], precision, 0)
+            hipError_t pe = op.kernel == CONV_DET5 ? launch_pack_weights_det5(d_stage, base + op.w_off, o.out_c / 3, o.in_c[0], precision, 0)
+                            : op.kernel == CONV_C2F_PW ? launch_pack_weights_c2f_pw(d_stage, base + op.w_off, o.out_c, o.in_c[0], precision, 0)
                             : op.kernel == CONV_PAIR ? launch_pack_weights_pair(d_stage, base + op.w_off, o.out_c, precision, 0)
                             : (op.kernel == CONV_FC || op.kernel == CONV_PW)
                                 ? launch_pack_weights_fc(d_stage, base + op.w_off, o.out_c, op.cout_pad, o.in_c[0], op.kpad, precision, 0)
@@ -643,7 +684,7 @@ int adas_engine_layer_kernel(const adas_engine* e, int layer, int batch, char* n
     } else if (o.type == OP_CONV && op.pair_b >= 0) {
         snprintf(name, cap, "conv_pair_kernel<%d>", (int)o.out_c);
     } else if (op.skip) {
-        snprintf(name, cap, o.type == OP_CONV && o.kh == 1 && op.kernel == CONV_PW ? "(fused into the Detect launch)" : "(fused into the stem launch)");
+        snprintf(name, cap, o.type == OP_CONV && o.kh == 1 && (op.kernel == CONV_PW || op.kernel == CONV_DET5) ? "(fused into the Detect launch)" : "(fused into the stem launch)");
     } else if (o.type == OP_CONV && op.kernel == CONV_STEM && op.fuse_conv2 >= 0) {
         snprintf(name, cap, "conv_stem_kernel<%d,1,SILU>+conv3x3s2", (int)o.kh);
     } else if (o.type == OP_CONV) {
@@ -658,6 +699,8 @@ int adas_engine_layer_kernel(const adas_engine* e, int layer, int batch, char* n
                  (op.ds_src >= 0 && ds_folded(e, layer, batch)) ? "+shortcut" : "");
     } else if (o.type == OP_DETECT_V8 && op.det_src[0] >= 0) {
         snprintf(name, cap, "detect_v8_fused_kernel");
+    } else if (o.type == OP_DETECT_V5 && op.det_src[0] >= 0) {
+        snprintf(name, cap, "detect_v5_fused_kernel");
     } else {
         snprintf(name, cap, "%s", o.type < 10 ? kOther[o.type] : "?");
     }
@@ -786,8 +829,21 @@ int engine_run_op(adas_engine* e, int i, const float* d_in, int batch, hipStream
         }
         case OP_DETECT_V5: {
             TView ins[3];
-            for (int k = 0; k < 3; ++k) ins[k] = make_view(e, o.in_buf[k], o.in_coff[k], o.in_c[k]);
             int strides[3] = {(int)o.params[2], (int)o.params[3], (int)o.params[4]};
+            if (op.det_src[0] >= 0) {  // decode + the three 1x1 convs in front of it
+                const void* wf[3];
+                const float* bs[3];
+                for (int k = 0; k < 3; ++k) {
+                    const EngOp& c = e->ops[op.det_src[k]];
+                    ins[k] = make_view(e, c.f.in_buf[0], c.f.in_coff[0], c.f.in_c[0]);
+                    wf[k] = wb + c.w_off;
+                    bs[k] = (const float*)(wb + c.b_off);
+                }
+                err = launch_detect_v5_fused(ins, wf, bs, (float*)e->bufs[o.out_buf].d, batch, (int)o.params[0], (int)o.params[1], strides,
+                                             (const float*)(wb + op.w_off), e->prec, st);
+                break;
+            }
+            for (int k = 0; k < 3; ++k) ins[k] = make_view(e, o.in_buf[k], o.in_coff[k], o.in_c[k]);
             err = launch_detect_v5(ins, (float*)e->bufs[o.out_buf].d, batch, (int)o.params[0], (int)o.params[1], strides,
                                    (const float*)(wb + op.w_off), st);
             break;
@@ -911,7 +967,7 @@ int adas_engine_profile(adas_engine* e, const float* d_input, int batch, int ite
 int adas_engine_fetch_activation(adas_engine* e, int layer, int batch, float* h_out, int64_t dims[4]) {
     ADAS_REQUIRE(e && layer >= 0 && layer < (int)e->ops.size() && batch > 0 && batch <= e->max_batch, ADAS_ERR_INVALID, "bad layer/batch");
     const FileOp& o = e->ops[layer].f;
-    ADAS_REQUIRE(!(e->ops[layer].skip && o.type == OP_CONV && e->ops[layer].kernel == CONV_PW), ADAS_ERR_INVALID,
+    ADAS_REQUIRE(!(e->ops[layer].skip && o.type == OP_CONV && (e->ops[layer].kernel == CONV_PW || e->ops[layer].kernel == CONV_DET5)), ADAS_ERR_INVALID,
                  "layer %d (%s) is fused into the Detect launch and has no materialised activation (ADAS_NO_DETECT_FUSE=1 keeps it)", layer,
                  e->ops[layer].name.c_str());
     ADAS_REQUIRE(!(e->ops[layer].skip && o.type == OP_INPUT) &&

@@ -65,7 +65,8 @@ struct EngOp {
     int pool3[2] = {-1, -1}; // OP_MAXPOOL: the two pools chained behind this one, folded into its launch (SPPF), or -1
     int pair_b = -1;         // CONV_PAIR: index of the second conv of the pair this op launches (its own output is never written), or -1
     int c2f[3] = {-1, -1, -1};   // cv1 of a fused C2f block (conv_c2f.hip): indices of the Bottleneck's conv A, conv B and of cv2 (all skipped), or -1
-    int det_src[6] = {-1, -1, -1, -1, -1, -1};  // OP_DETECT_V8: the six 1x1 convs (cv2.i.2, cv3.i.2) folded into the decode launch, or -1
+    int det_src[6] = {-1, -1, -1, -1, -1, -1};  // OP_DETECT_V8: the six 1x1 convs (cv2.i.2, cv3.i.2) folded into the decode launch, or -1;
+                                                // OP_DETECT_V5: the three per-level 1x1 convs (det_src[0..2])
 };
 struct EngOut {
     uint32_t buf, offset, ndim, dims[4];

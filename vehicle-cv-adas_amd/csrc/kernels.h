@@ -42,7 +42,8 @@ struct ConvArgs {
 // shapes and re-derived identically at launch time.
 enum { CONV_GATHER = 0, CONV_HALO = 1, CONV_FC = 2, CONV_STEM = 3, CONV_PW = 4, CONV_STEM2 = 5 /* second conv of a fused YOLO stem */,
        CONV_PAIR = 6 /* either conv of a fused 3x3 -> 3x3 pair (conv_pair.hip) */,
-       CONV_C2F_PW = 7 /* the 1x1 convs of a fused C2f block (conv_c2f.hip): MFMA-fragment packing */ };
+       CONV_C2F_PW = 7 /* the 1x1 convs of a fused C2f block (conv_c2f.hip): MFMA-fragment packing */,
+       CONV_DET5 = 8 /* the per-level 1x1 of a v5-layout Detect folded into the decode launch (aux_kernels.hip): per-anchor fragments */ };
 struct ConvPlan {
     int kernel;   // CONV_*
     int cin_pad;  // channels per tap in the packed weights (halo: padded to 32 so the tail is zero)
@@ -106,6 +107,11 @@ hipError_t launch_detect_v8(const TView* ins, float* out, int n, int nc, int A, 
 hipError_t launch_detect_v8_fused(const TView* hidden, const void* const* wfrag, const float* const* bias, float* out, int n, int nc, int A,
                                   const int strides[3], int prec, hipStream_t st);
 // YOLOv5 Detect decode: ins = 3 fp32 maps [n][ny][nx][3*(5+nc)]; out fp32 [n][A][5+nc]; anchors[18] device
+bool det5_applicable(int prec, int nc, const TView& in, const TView& logits);
+size_t det5_weight_bytes(int no, int cin);
+hipError_t launch_pack_weights_det5(const float* src, void* dst, int no, int cin, int prec, hipStream_t st);   // src fp32 [3 * no][cin]
+hipError_t launch_detect_v5_fused(const TView* hidden, const void* const* wfrag, const float* const* bias, float* out, int n, int nc, int A,
+                                  const int strides[3], const float* d_anchors, int prec, hipStream_t st);
 hipError_t launch_detect_v5(const TView* ins, float* out, int n, int nc, int A, const int strides[3],
                             const float* d_anchors, hipStream_t st);
 // LayerNorm over the flat per-frame vector (len elements, fp32 in) -> compute type out

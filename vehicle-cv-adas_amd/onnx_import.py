@@ -313,6 +313,13 @@ def detect_arch(m):
                     raise ValueError("YOLOv9 with a %d-channel stem is not built (yolov9t is): %s" % (c0[0], found))
                 return "yolov9t", dict(nc=o[1] - 4, imgsz=(H, W))
             return "yolov8" + scale, dict(nc=o[1] - 4, imgsz=(H, W))
+        if c0[2] == 3 and o[1] > o[2]:                      # (1, A, 5+nc) behind a 3x3 stem: YOLOv7 (v5-layout head, yoloDetector.py:110-124)
+            if H % 32 or W % 32:
+                raise ValueError("YOLO input size must be multiples of 32: " + found)
+            n_plain = sum(1 for w_, _ in convs if w_.shape[1] * w_.shape[2] > 0)
+            if c0[0] != 32 or n_plain != 58:                # yolov7-tiny: 32-channel stem, 55 Conv modules + the 3 IDetect 1x1s
+                raise ValueError("YOLOv7 variant not built (yolov7-tiny, 58 convs behind a 32-channel stem, is): " + found)
+            return "yolov7-tiny", dict(nc=o[2] - 5, imgsz=(H, W))
         if c0[2] == 6 and o[1] > o[2]:                      # (1, A, 5+nc): YOLOv5 v6.x
             scale = {16: "n", 32: "s", 48: "m", 64: "l", 80: "x"}.get(c0[0])
             if scale is None:
