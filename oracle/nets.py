@@ -310,7 +310,7 @@ def head_layout(name):
 
 
 def detector_forward(name, x, W, nc=80, taps=None):
-    """Forward of the detector graph `name`: (4+nc, A) heads ("yolov8n" .. "yolov8x", "yolov10n", "yolov9t") or the v5 layout
+    """Forward of the detector graph `name`: (4+nc, A) heads ("yolov8n" .. "yolov8x", "yolov10n", "yolov9t", "yolov9s") or the v5 layout
     (A, 5+nc) ("yolov7-tiny", "yolov5n" .. "yolov5x"; no taps for YOLOv5)."""
     if name.startswith("yolov7"):
         return yolov7_tiny_forward(x, W, nc, taps)

@@ -22,7 +22,7 @@ def _build(name, **kw):
 
 
 @pytest.mark.parametrize("name,fwd,scale", [("yolov8n", "yolov8_forward", "n"), ("yolov8s", "yolov8_forward", "s"), ("yolov10n", "yolov10_forward", "n"),
-                                            ("yolov9t", "yolov9t_forward", None)])
+                                            ("yolov9t", "yolov9t_forward", None), ("yolov9s", "yolov9t_forward", None)])
 def test_yolo_graph_equals_oracle(name, fwd, scale):
     g, W = _build(name, imgsz=(96, 128))
     x = netutil.coco_like_frames(2, 96, 128, seed=3)
@@ -71,6 +71,16 @@ def test_ufldv2_graph_equals_oracle(name, kw, okw):
     for a, b in zip(got, want):
         assert a.shape == b.shape
         np.testing.assert_allclose(a, b, rtol=0, atol=5e-5)
+
+
+def test_yolov9s_size_matches_upstream_yaml():
+    """ultralytics yolov9s.yaml: "917 layers, 7318368 parameters" un-fused (the yolov9t graph with doubled widths); same reconstruction as below."""
+    g, W = _build("yolov9s")
+    rep = [k for k in W if ".m." in k and k.endswith(".cv1.conv.weight")]
+    unfused = (g.n_params - sum(v.size for k, v in W.items() if k.endswith(".bias")) + sum(W[k].size for k in W if k.endswith(".2.bias")) +
+               sum(W[k].shape[0] * W[k].shape[1] for k in rep) + sum(2 * W[k].shape[0] for k in W if k.endswith(".conv.weight")) + sum(4 * W[k].shape[0] for k in rep))
+    assert abs(unfused - 7318368) / 7318368 < 0.005, unfused
+    assert abs(g.flops / 1e9 - 26.9) < 0.1 and [tuple(d) for _, _, d, _ in g.outs] == [(1, 84, 8400)]
 
 
 def test_yolov9t_size_matches_upstream_yaml():

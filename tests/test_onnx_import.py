@@ -286,10 +286,11 @@ def test_yolov10n_names_depthwise_and_unfused_repvggdw(tmp_path):
     assert g2.tobytes() == ref.tobytes()
 
 
-def test_yolov9t_recognised_by_average_pool_or_names(tmp_path):
-    """YOLOv9t (GELAN-t) shares YOLOv8n's stem width and (1, 84, 8400) head: told apart by its AConv average-pool nodes or its
+@pytest.mark.parametrize("name", ["yolov9t", "yolov9s"])
+def test_yolov9t_recognised_by_average_pool_or_names(tmp_path, name):
+    """YOLOv9t / s (GELAN) share YOLOv8n / s's stem width and (1, 84, 8400) head: told apart by their AConv average-pool nodes or
     RepNCSPELAN4 parameter names; weights by name; RepConv is expected in its fused (deploy) form, as ultralytics exports it."""
-    W, g = synth("yolov9t")
+    W, g = synth(name)
     inits, nodes = [], []
     for i, base in enumerate(k[:-7] for k in list(W) if k.endswith(".weight")):
         w, b = W[base + ".weight"], W[base + ".bias"]
@@ -297,12 +298,12 @@ def test_yolov9t_recognised_by_average_pool_or_names(tmp_path):
         nodes.append(OW.node("Conv", ["t%d" % i, base + ".weight", base + ".bias"], ["t%d" % (i + 1)], "Conv_%d" % i,
                              [OW.attr_ints("kernel_shape", list(w.shape[2:]))]))
     nodes.insert(3, OW.node("AveragePool", ["t3"], ["t3p"], "AveragePool_0", [OW.attr_ints("kernel_shape", [2, 2])]))
-    p = tmp_path / "yolov9t.onnx"
+    p = tmp_path / (name + ".onnx")
     p.write_bytes(OW.model(nodes, inits, [("images", [1, 3, 640, 640])], [("output0", [1, 84, 8400])]))
     m = OI.read_onnx(str(p))
-    assert OI.detect_arch(m) == ("yolov9t", dict(nc=80, imgsz=(640, 640)))
+    assert OI.detect_arch(m) == (name, dict(nc=80, imgsz=(640, 640)))
     out, g2 = OI.convert(str(p), str(tmp_path / "v9.hipm"))
-    assert g2.name == "yolov9t" and g2.tobytes() == M.build("yolov9t", wsrc=M.DictWeights(W)).tobytes()
+    assert g2.name == name and g2.tobytes() == M.build(name, wsrc=M.DictWeights(W)).tobytes()
 
 
 def test_yolov7_tiny_recognised_by_stem_and_v5_layout(tmp_path):

@@ -324,6 +324,23 @@ int adas_engine_create(const char* model_path, int precision, int max_batch, ada
             e->ops[i + 1].skip = e->ops[i + 2].skip = true;
             i += 2;
         }
+        // SPP (YOLOv7's SPPCSPC, YOLOv3/v4): 5x5, 9x9 and 13x13 stride-1 max-pools of ONE tensor.  Stride-1 max-pools with -inf padding
+        // compose exactly (a 9x9 window clipped to the image = the 5x5 max of 5x5 maxima), so the three are the SPPF chain's three
+        // outputs and take the same launch -- bit-identical, and the 81 / 169 sequential loads per output of the generic kernel go away
+        for (size_t i = 0; enabled && i + 2 < fo.size(); ++i) {
+            const FileOp &p0 = fo[i], &p1 = fo[i + 1], &p2 = fo[i + 2];
+            auto isk = [](const FileOp& q, uint32_t k) { return q.type == OP_MAXPOOL && q.kh == k && q.stride == 1 && q.pad == k / 2 && q.n_in == 1; };
+            auto same_in = [](const FileOp& a, const FileOp& b) { return a.in_buf[0] == b.in_buf[0] && a.in_coff[0] == b.in_coff[0] && a.in_c[0] == b.in_c[0]; };
+            if (!isk(p0, 5) || !isk(p1, 9) || !isk(p2, 13) || !same_in(p0, p1) || !same_in(p0, p2) || e->ops[i].skip || e->ops[i + 1].skip || e->ops[i + 2].skip) continue;
+            TView in = make_view(e, p0.in_buf[0], p0.in_coff[0], p0.in_c[0]);
+            TView outs[3] = {make_view(e, p0.out_buf, p0.out_coff, p0.out_c), make_view(e, p1.out_buf, p1.out_coff, p1.out_c),
+                             make_view(e, p2.out_buf, p2.out_coff, p2.out_c)};
+            if (!sppf_pool3_applicable(precision, in, outs)) continue;
+            e->ops[i].pool3[0] = (int)i + 1;
+            e->ops[i].pool3[1] = (int)i + 2;
+            e->ops[i + 1].skip = e->ops[i + 2].skip = true;
+            i += 2;
+        }
     }
     // ---- 3x3 -> 3x3 pair fusion (conv_pair.hip): conv A's output feeds only conv B (the Bottleneck of YOLOv8's C2f blocks)
     std::vector<int> pair_of(e->ops.size(), -1);   // B -> A
@@ -671,7 +688,7 @@ int adas_engine_layer_kernel(const adas_engine* e, int layer, int batch, char* n
         snprintf(name, cap, "(fused into the conv it is the shortcut of)");
     } else if (op.skip && o.type == OP_UPSAMPLE2) {
         snprintf(name, cap, "(folded into the consumer's loads)");
-    } else if (op.skip && o.type == OP_MAXPOOL && o.kh == 5) {
+    } else if (op.skip && o.type == OP_MAXPOOL && (o.kh == 5 || o.kh == 9 || o.kh == 13)) {
         snprintf(name, cap, "(fused into the SPPF pool launch)");
     } else if (o.type == OP_MAXPOOL && op.pool3[0] >= 0) {
         snprintf(name, cap, "sppf_pool3_kernel");

@@ -54,7 +54,8 @@ SILU_GAIN = 1.10                # YOLOv8 n/s: AT the critical gain (n ~1.11, s ~
 V5_SILU_GAIN = 1.15             # YOLOv5 (C3 blocks; kept at the round-1 value: its deeper scales are chaotic there, bf16 head rel-L2 6e-2,
                                 # and no better at 1.0)
 RELU_RES_GAIN = 0.8             # ResNet lane nets: ReLU + residual adds double the variance; flat drift at 0.8 (9e-4 rel-L2 fp16)
-SYNTH_GAINS = {"yolov7-tiny": 1.0,                                    # LeakyReLU: piecewise linear, no chaos (fp16 rel-L2 1.3e-3 at any gain); 1.0 keeps rms ~0.4
+SYNTH_GAINS = {"yolov9s": 1.06,                                       # 1.12 (yolov9t's) has a runaway mode on small inputs (96x128: rms 1e5 at P5)
+               "yolov7-tiny": 1.0,                                    # LeakyReLU: piecewise linear, no chaos (fp16 rel-L2 1.3e-3 at any gain); 1.0 keeps rms ~0.4
                "yolov9t": 1.12,                                       # critical between 1.16 and 1.22 (activations explode there)
                "yolov10n": 1.05,                                      # critical ~1.09 (1.08 already drifts: fp16 rel-L2 1.9e-3 at P5, boxes 0.3 px)
                "yolov8m": 0.99, "yolov8l": 0.96, "yolov8x": 0.98}     # deeper Bottleneck chains: critical gain ~1.03 (m), ~0.97 (l), ~1.0 (x)
@@ -556,33 +557,37 @@ def _sppelan(g, x, c2, c3, name, out=None):
     return g.conv(cat, c2, 1, 1, f"{name}.cv5.conv", out=out)
 
 
-def yolov9t(nc=80, imgsz=640, wsrc=None, seed=0):
-    wsrc = wsrc or SynthWeights(seed, gain=synth_gain("yolov9t"))
+def yolov9t(nc=80, imgsz=640, wsrc=None, seed=0, scale="t"):
+    """ultralytics cfg/models/v9/yolov9t.yaml / yolov9s.yaml: the s graph is the t graph with every width doubled (same modules, same
+    repeats) -- `scale` "t" | "s"."""
+    m = {"t": 1, "s": 2}[scale]
+    name = "yolov9" + scale
+    wsrc = wsrc or SynthWeights(seed, gain=synth_gain(name))
     H, W = _hw(imgsz)
-    g = Graph("yolov9t", 3, H, W, wsrc)
+    g = Graph(name, 3, H, W, wsrc)
     x, cin = g.input()
-    cat11 = g.buf(H // 16, W // 16, 128 + 96)    # [up(9), 6]
-    cat14 = g.buf(H // 8, W // 8, 96 + 64)       # [up(12), 4]
-    cat17 = g.buf(H // 16, W // 16, 48 + 96)     # [16, 12]
-    cat20 = g.buf(H // 32, W // 32, 64 + 128)    # [19, 9]
-    x = g.conv(x, 16, 3, 2, "model.0.conv", true_cin=cin)
-    x = g.conv(x, 32, 3, 2, "model.1.conv")
-    x = _elan1(g, x, 32, 32, 16, "model.2")
-    x = _aconv(g, x, 64, "model.3")
-    p3b = _repncspelan4(g, x, 64, 64, 32, 3, "model.4", out=cat14.slice(96, 64))
-    x = _aconv(g, p3b, 96, "model.5")
-    p4b = _repncspelan4(g, x, 96, 96, 48, 3, "model.6", out=cat11.slice(128, 96))
-    x = _aconv(g, p4b, 128, "model.7")
-    x = _repncspelan4(g, x, 128, 128, 64, 3, "model.8")
-    p5b = _sppelan(g, x, 128, 64, "model.9", out=cat20.slice(64, 128))
-    g.upsample2(p5b, out=cat11.slice(0, 128), name="model.10")
-    n12 = _repncspelan4(g, cat11, 96, 96, 48, 3, "model.12", out=cat17.slice(48, 96))
-    g.upsample2(n12, out=cat14.slice(0, 96), name="model.13")
-    p3 = _repncspelan4(g, cat14, 64, 64, 32, 3, "model.15")
-    _aconv(g, p3, 48, "model.16", out=cat17.slice(0, 48))
-    p4 = _repncspelan4(g, cat17, 96, 96, 48, 3, "model.18")
-    _aconv(g, p4, 64, "model.19", out=cat20.slice(0, 64))
-    p5 = _repncspelan4(g, cat20, 128, 128, 64, 3, "model.21")
+    cat11 = g.buf(H // 16, W // 16, m * (128 + 96))    # [up(9), 6]
+    cat14 = g.buf(H // 8, W // 8, m * (96 + 64))       # [up(12), 4]
+    cat17 = g.buf(H // 16, W // 16, m * (48 + 96))     # [16, 12]
+    cat20 = g.buf(H // 32, W // 32, m * (64 + 128))    # [19, 9]
+    x = g.conv(x, 16 * m, 3, 2, "model.0.conv", true_cin=cin)
+    x = g.conv(x, 32 * m, 3, 2, "model.1.conv")
+    x = _elan1(g, x, 32 * m, 32 * m, 16 * m, "model.2")
+    x = _aconv(g, x, 64 * m, "model.3")
+    p3b = _repncspelan4(g, x, 64 * m, 64 * m, 32 * m, 3, "model.4", out=cat14.slice(96 * m, 64 * m))
+    x = _aconv(g, p3b, 96 * m, "model.5")
+    p4b = _repncspelan4(g, x, 96 * m, 96 * m, 48 * m, 3, "model.6", out=cat11.slice(128 * m, 96 * m))
+    x = _aconv(g, p4b, 128 * m, "model.7")
+    x = _repncspelan4(g, x, 128 * m, 128 * m, 64 * m, 3, "model.8")
+    p5b = _sppelan(g, x, 128 * m, 64 * m, "model.9", out=cat20.slice(64 * m, 128 * m))
+    g.upsample2(p5b, out=cat11.slice(0, 128 * m), name="model.10")
+    n12 = _repncspelan4(g, cat11, 96 * m, 96 * m, 48 * m, 3, "model.12", out=cat17.slice(48 * m, 96 * m))
+    g.upsample2(n12, out=cat14.slice(0, 96 * m), name="model.13")
+    p3 = _repncspelan4(g, cat14, 64 * m, 64 * m, 32 * m, 3, "model.15")
+    _aconv(g, p3, 48 * m, "model.16", out=cat17.slice(0, 48 * m))
+    p4 = _repncspelan4(g, cat17, 96 * m, 96 * m, 48 * m, 3, "model.18")
+    _aconv(g, p4, 64 * m, "model.19", out=cat20.slice(0, 64 * m))
+    p5 = _repncspelan4(g, cat20, 128 * m, 128 * m, 64 * m, 3, "model.21")
     feats = [p3, p4, p5]
     cb = max(16, feats[0].c // 4, 64)
     cc = max(feats[0].c, min(nc, 100))
@@ -901,6 +906,7 @@ BUILDERS = {
     "yolov8x": lambda **k: yolov8("x", **k),
     "yolov10n": lambda **k: yolov10("n", **k),
     "yolov9t": lambda **k: yolov9t(**k),
+    "yolov9s": lambda **k: yolov9t(scale="s", **k),
     "yolov7-tiny": lambda **k: yolov7_tiny(**k),
     "yolov5n": lambda **k: yolov5("n", **k), "yolov5s": lambda **k: yolov5("s", **k),
     "yolov5m": lambda **k: yolov5("m", **k), "yolov5l": lambda **k: yolov5("l", **k), "yolov5x": lambda **k: yolov5("x", **k),

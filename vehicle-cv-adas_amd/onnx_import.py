@@ -309,9 +309,9 @@ def detect_arch(m):
             # graphs have no AveragePool node), its blocks are RepNCSPELAN4 (parameter names model.N.cv2.0.cv1.conv ...)
             is_v9 = any(nd["op"] == "AveragePool" for nd in m.nodes) or any(".cv2.0.m.0.cv1." in k for k in m.initializers)
             if is_v9:
-                if scale != "n":
-                    raise ValueError("YOLOv9 with a %d-channel stem is not built (yolov9t is): %s" % (c0[0], found))
-                return "yolov9t", dict(nc=o[1] - 4, imgsz=(H, W))
+                if scale not in ("n", "s"):
+                    raise ValueError("YOLOv9 with a %d-channel stem is not built (yolov9t and yolov9s are): %s" % (c0[0], found))
+                return "yolov9" + ("t" if scale == "n" else "s"), dict(nc=o[1] - 4, imgsz=(H, W))
             return "yolov8" + scale, dict(nc=o[1] - 4, imgsz=(H, W))
         if c0[2] == 3 and o[1] > o[2]:                      # (1, A, 5+nc) behind a 3x3 stem: YOLOv7 (v5-layout head, yoloDetector.py:110-124)
             if H % 32 or W % 32:
