@@ -223,7 +223,7 @@ def measure_parity(det_eng, lane_eng, det_name, lane_name, Wd, Wl, dframes, lfra
     taps = {}
     want = nets.detector_forward(det_name, dframes[:n], Wd, taps=taps)
     got = det_eng.engine_inference(dframes[:n])[0]
-    p3_layer = {"yolov10": "model.16.cv2.conv", "yolov9t": "model.15.cv4.conv", "yolov9s": "model.15.cv4.conv", "yolov7-": "model.74.conv"}.get(det_name[:7], "model.15.cv2.conv")
+    p3_layer = {"yolov1": "model.16.cv2.conv", "yolov9": "model.15.cv4.conv", "yolov7": "model.74.conv"}.get(det_name[:6], "model.15.cv2.conv")
     v5 = nets.head_layout(det_name) == "yolov5"      # (A, 5+nc): boxes first along the LAST axis
     sl_cls, sl_box = ((Ellipsis, slice(4, None)), (Ellipsis, slice(0, 4))) if v5 else ((slice(None), slice(4, None)), (slice(None), slice(0, 4)))
     p3 = det_eng.fetch_activation(p3_layer, n)

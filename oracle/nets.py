@@ -146,7 +146,7 @@ def _v8_decode(outs, sizes, nc, taps=None):
 # 7x7) + head.py v10Detect (one-to-one branch).  PARITY UNPINNED like the other YOLO graphs (architecture not in the reference; the
 # reference only pins the I/O: demo.py:24-30 ships yolov10n, yoloDetector.py:114,121 decodes a v8-layout (1, 4+nc, A) tensor);
 # parameter / FLOP counts match the published 2.3 M / 6.7 G.
-V10_SCALES = {"n": (0.33, 0.25, 1024)}
+V10_SCALES = {"n": (0.33, 0.25, 1024), "s": (0.33, 0.50, 1024)}      # yolov10s.yaml differs from n in row 8 (C2fCIB with the 7x7 branch)
 
 
 def _dwconv(x, W, name, s=1, act="silu"):
@@ -207,7 +207,7 @@ def yolov10_forward(x, W, scale="n", nc=80, taps=None):
         x = _scdown(x4, W, "model.5")
         x6 = _c2f(x, W, "model.6", dep(6), True)
         x = _scdown(x6, W, "model.7")
-        x = _c2f(x, W, "model.8", dep(3), True)
+        x = _c2f(x, W, "model.8", dep(3), True) if scale == "n" else _c2fcib(x, W, "model.8", dep(3), True)
         x = _sppf(x, W, "model.9")
         x10 = _psa(x, W, "model.10")
         x = torch.cat((F.interpolate(x10, scale_factor=2, mode="nearest"), x6), 1)
@@ -304,13 +304,56 @@ def yolov9t_forward(x, W, nc=80, taps=None):
         return _v8_decode(outs, [f.shape[2:] for f in feats], nc, taps)
 
 
+def _adown(x, W, name):
+    """ultralytics nn/modules/block.py ADown.forward."""
+    x = _round(F.avg_pool2d(x, 2, 1, 0, False, True))
+    x1, x2 = x.chunk(2, 1)
+    return torch.cat((_conv(x1, W, f"{name}.cv1.conv", 2), _conv(F.max_pool2d(x2, 3, 2, 1), W, f"{name}.cv2.conv")), 1)
+
+
+def yolov9c_forward(x, W, nc=80, taps=None):
+    """ultralytics cfg/models/v9/yolov9c.yaml row by row (RepConv in its fused deploy form)."""
+    x = torch.as_tensor(x, dtype=torch.float32)
+    with torch.no_grad():
+        x = _conv(x, W, "model.0.conv", 2)
+        x = _conv(x, W, "model.1.conv", 2)
+        x = _repncspelan4(x, W, "model.2", 1)
+        x = _adown(x, W, "model.3")
+        x4 = _repncspelan4(x, W, "model.4", 1)
+        x = _adown(x4, W, "model.5")
+        x6 = _repncspelan4(x, W, "model.6", 1)
+        x = _adown(x6, W, "model.7")
+        x = _repncspelan4(x, W, "model.8", 1)
+        x9 = _sppelan(x, W, "model.9")
+        x = torch.cat((F.interpolate(x9, scale_factor=2, mode="nearest"), x6), 1)
+        x12 = _repncspelan4(x, W, "model.12", 1)
+        x = torch.cat((F.interpolate(x12, scale_factor=2, mode="nearest"), x4), 1)
+        x15 = _repncspelan4(x, W, "model.15", 1)
+        x = torch.cat((_adown(x15, W, "model.16"), x12), 1)
+        x18 = _repncspelan4(x, W, "model.18", 1)
+        x = torch.cat((_adown(x18, W, "model.19"), x9), 1)
+        x21 = _repncspelan4(x, W, "model.21", 1)
+        if taps is not None:
+            taps.update(p3=x15, p4=x18, p5=x21, sppelan=x9)
+        feats = [x15, x18, x21]
+        N = x.shape[0]
+        outs = []
+        for i, f in enumerate(feats):
+            b = _conv(_conv(f, W, f"model.22.cv2.{i}.0.conv"), W, f"model.22.cv2.{i}.1.conv")
+            b = _conv(b, W, f"model.22.cv2.{i}.2", act=None)
+            c = _conv(_conv(f, W, f"model.22.cv3.{i}.0.conv"), W, f"model.22.cv3.{i}.1.conv")
+            c = _conv(c, W, f"model.22.cv3.{i}.2", act=None)
+            outs.append(torch.cat((b, c), 1).view(N, 64 + nc, -1))
+        return _v8_decode(outs, [f.shape[2:] for f in feats], nc, taps)
+
+
 def head_layout(name):
     """"yolov5" (A, 5+nc) or "yolov8" (4+nc, A): the `model_type` argument of oracle.yolo_post.detect_post for graph `name`."""
     return "yolov5" if name.startswith(("yolov5", "yolov7")) else "yolov8"
 
 
 def detector_forward(name, x, W, nc=80, taps=None):
-    """Forward of the detector graph `name`: (4+nc, A) heads ("yolov8n" .. "yolov8x", "yolov10n", "yolov9t", "yolov9s") or the v5 layout
+    """Forward of the detector graph `name`: (4+nc, A) heads ("yolov8n" .. "yolov8x", "yolov10n", "yolov10s", "yolov9t", "yolov9s", "yolov9c") or the v5 layout
     (A, 5+nc) ("yolov7-tiny", "yolov5n" .. "yolov5x"; no taps for YOLOv5)."""
     if name.startswith("yolov7"):
         return yolov7_tiny_forward(x, W, nc, taps)
@@ -318,6 +361,8 @@ def detector_forward(name, x, W, nc=80, taps=None):
         return yolov5_forward(x, W, name[-1], nc)
     if name.startswith("yolov10"):
         return yolov10_forward(x, W, name[len("yolov10"):], nc, taps)
+    if name == "yolov9c":
+        return yolov9c_forward(x, W, nc, taps)
     if name.startswith("yolov9"):
         return yolov9t_forward(x, W, nc, taps)
     if name.startswith("yolov8"):

@@ -128,6 +128,32 @@ def test_yolov10n_640_vs_oracle(tmp_path, prec):
     e.close()
 
 
+@pytest.mark.parametrize("prec", ["fp32", "fp16"])
+def test_yolov10s_vs_oracle(prec):
+    """YOLOv10s (7.2 M parameters; the n yaml at width 0.5 with a C2fCIB + 7x7 depth-wise branch in backbone row 8, 4-head PSA attention on
+    512 channels): 384x640 input, 2 frames, tapped activations and the head."""
+    path, W, g = netutil.model("yolov10s", imgsz=(384, 640))
+    x = netutil.coco_like_frames(2, 384, 640, seed=12)
+    taps = {}
+    want = nets.yolov10_forward(x, W, "s", taps=taps)
+    e = CE.HipEngine(path, precision=prec, max_batch=2)
+    got = e.engine_inference(x)[0]
+    for lname, key in (("model.10.cv2.conv", "psa"), ("model.16.cv2.conv", "p3"), ("model.22.cv2.conv", "p5")):
+        a = e.fetch_activation(lname, 2)
+        ref = taps[key].numpy()
+        err, rel = float(np.abs(a - ref).max()), rel_l2(a, ref)
+        print("yolov10s %s %-4s max|diff| %.3e  rel_l2 %.3e  max|ref| %.2f" % (prec, key, err, rel, np.abs(ref).max()))
+        assert (err <= 1e-3 * max(1.0, float(np.abs(ref).max()))) if prec == "fp32" else (rel <= 5e-3), lname
+    ecls, ebox = float(np.abs(got[:, 4:] - want[:, 4:]).max()), float(np.abs(got[:, :4] - want[:, :4]).max())
+    print("yolov10s %s head: max|prob diff| %.3e  max|box diff| %.3e px" % (prec, ecls, ebox))
+    assert got.shape == want.shape == (2, 84, 5040)
+    if prec == "fp32":
+        assert ecls <= 1e-3 and ebox <= 1e-3 * max(1.0, float(np.abs(want[:, :4]).max()))
+    else:
+        assert ecls <= 2e-2 and ebox <= 0.25
+    e.close()
+
+
 def _frames(n, seed):
     import bench
     return bench.cam_frames(n, seed)

@@ -88,23 +88,25 @@ def test_yolov9t_640_vs_oracle(tmp_path, prec):
     e.close()
 
 
+@pytest.mark.parametrize("name", ["yolov9s", "yolov9c"])
 @pytest.mark.parametrize("prec", ["fp32", "fp16"])
-def test_yolov9s_vs_oracle(prec):
-    """YOLOv9s = the t graph with doubled widths (7.2 M parameters): 384x640 input, 2 frames, tapped activations and the head."""
-    path, W, g = netutil.model("yolov9s", imgsz=(384, 640))
+def test_yolov9s_c_vs_oracle(prec, name):
+    """YOLOv9s = the t graph with doubled widths (7.2 M parameters); YOLOv9c = GELAN-c with ADown (25.4 M): 384x640 input, 2 frames,
+    tapped activations and the head."""
+    path, W, g = netutil.model(name, imgsz=(384, 640))
     x = netutil.coco_like_frames(2, 384, 640, seed=12)
     taps = {}
-    want = nets.yolov9t_forward(x, W, taps=taps)
+    want = nets.detector_forward(name, x, W, taps=taps)
     e = CE.HipEngine(path, precision=prec, max_batch=2)
     got = e.engine_inference(x)[0]
     for lname, key in (("model.9.cv5.conv", "sppelan"), ("model.15.cv4.conv", "p3"), ("model.21.cv4.conv", "p5")):
         a = e.fetch_activation(lname, 2)
         ref = taps[key].numpy()
         err, rel = float(np.abs(a - ref).max()), rel_l2(a, ref)
-        print("yolov9s %s %-7s max|diff| %.3e  rel_l2 %.3e  max|ref| %.2f" % (prec, key, err, rel, np.abs(ref).max()))
+        print(name + " %s %-7s max|diff| %.3e  rel_l2 %.3e  max|ref| %.2f" % (prec, key, err, rel, np.abs(ref).max()))
         assert (err <= 1e-3 * max(1.0, float(np.abs(ref).max()))) if prec == "fp32" else (rel <= 5e-3), lname
     ecls, ebox = float(np.abs(got[:, 4:] - want[:, 4:]).max()), float(np.abs(got[:, :4] - want[:, :4]).max())
-    print("yolov9s %s head: max|prob diff| %.3e  max|box diff| %.3e px" % (prec, ecls, ebox))
+    print(name + " %s head: max|prob diff| %.3e  max|box diff| %.3e px" % (prec, ecls, ebox))
     assert got.shape == want.shape == (2, 84, 5040)
     if prec == "fp32":
         assert ecls <= 1e-3 and ebox <= 1e-3 * max(1.0, float(np.abs(want[:, :4]).max()))

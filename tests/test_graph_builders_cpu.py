@@ -21,8 +21,8 @@ def _build(name, **kw):
     return g, dict(ws.store)
 
 
-@pytest.mark.parametrize("name,fwd,scale", [("yolov8n", "yolov8_forward", "n"), ("yolov8s", "yolov8_forward", "s"), ("yolov10n", "yolov10_forward", "n"),
-                                            ("yolov9t", "yolov9t_forward", None), ("yolov9s", "yolov9t_forward", None)])
+@pytest.mark.parametrize("name,fwd,scale", [("yolov8n", "yolov8_forward", "n"), ("yolov8s", "yolov8_forward", "s"), ("yolov10n", "yolov10_forward", "n"), ("yolov10s", "yolov10_forward", "s"),
+                                            ("yolov9t", "yolov9t_forward", None), ("yolov9s", "yolov9t_forward", None), ("yolov9c", "yolov9c_forward", None)])
 def test_yolo_graph_equals_oracle(name, fwd, scale):
     g, W = _build(name, imgsz=(96, 128))
     x = netutil.coco_like_frames(2, 96, 128, seed=3)
@@ -73,14 +73,23 @@ def test_ufldv2_graph_equals_oracle(name, kw, okw):
         np.testing.assert_allclose(a, b, rtol=0, atol=5e-5)
 
 
-def test_yolov9s_size_matches_upstream_yaml():
-    """ultralytics yolov9s.yaml: "917 layers, 7318368 parameters" un-fused (the yolov9t graph with doubled widths); same reconstruction as below."""
-    g, W = _build("yolov9s")
+def test_yolov10s_published_size():
+    g, _ = _build("yolov10s")
+    assert abs(g.n_params / 1e6 - 7.25) < 0.05 and abs(g.flops / 1e9 - 21.7) < 0.15      # THU-MIG: YOLOv10-S 7.2 M parameters, 21.6 GFLOPs
+    kinds = [o["type"] for o in g.ops]
+    assert kinds.count(M.OP_ATTENTION) == 1 and [tuple(d) for _, _, d, _ in g.outs] == [(1, 84, 8400)]
+
+
+@pytest.mark.parametrize("name,unfused_params,gflop", [("yolov9s", 7318368, 26.9), ("yolov9c", 25590912, 102.7)])
+def test_yolov9s_c_size_matches_upstream_yaml(name, unfused_params, gflop):
+    """ultralytics model summaries of the UN-fused graphs: yolov9s "917 layers, 7318368 parameters" (the yolov9t graph with doubled widths),
+    yolov9c "618 layers, 25590912 parameters" (ADown, one RepBottleneck per RepCSP); same reconstruction as for yolov9t below."""
+    g, W = _build(name)
     rep = [k for k in W if ".m." in k and k.endswith(".cv1.conv.weight")]
     unfused = (g.n_params - sum(v.size for k, v in W.items() if k.endswith(".bias")) + sum(W[k].size for k in W if k.endswith(".2.bias")) +
                sum(W[k].shape[0] * W[k].shape[1] for k in rep) + sum(2 * W[k].shape[0] for k in W if k.endswith(".conv.weight")) + sum(4 * W[k].shape[0] for k in rep))
-    assert abs(unfused - 7318368) / 7318368 < 0.005, unfused
-    assert abs(g.flops / 1e9 - 26.9) < 0.1 and [tuple(d) for _, _, d, _ in g.outs] == [(1, 84, 8400)]
+    assert abs(unfused - unfused_params) / unfused_params < 0.005, unfused
+    assert abs(g.flops / 1e9 - gflop) < 0.1 and [tuple(d) for _, _, d, _ in g.outs] == [(1, 84, 8400)]
 
 
 def test_yolov9t_size_matches_upstream_yaml():

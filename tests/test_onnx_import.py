@@ -286,7 +286,7 @@ def test_yolov10n_names_depthwise_and_unfused_repvggdw(tmp_path):
     assert g2.tobytes() == ref.tobytes()
 
 
-@pytest.mark.parametrize("name", ["yolov9t", "yolov9s"])
+@pytest.mark.parametrize("name", ["yolov9t", "yolov9s", "yolov9c"])
 def test_yolov9t_recognised_by_average_pool_or_names(tmp_path, name):
     """YOLOv9t / s (GELAN) share YOLOv8n / s's stem width and (1, 84, 8400) head: told apart by their AConv average-pool nodes or
     RepNCSPELAN4 parameter names; weights by name; RepConv is expected in its fused (deploy) form, as ultralytics exports it."""

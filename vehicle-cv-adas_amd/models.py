@@ -54,9 +54,11 @@ SILU_GAIN = 1.10                # YOLOv8 n/s: AT the critical gain (n ~1.11, s ~
 V5_SILU_GAIN = 1.15             # YOLOv5 (C3 blocks; kept at the round-1 value: its deeper scales are chaotic there, bf16 head rel-L2 6e-2,
                                 # and no better at 1.0)
 RELU_RES_GAIN = 0.8             # ResNet lane nets: ReLU + residual adds double the variance; flat drift at 0.8 (9e-4 rel-L2 fp16)
-SYNTH_GAINS = {"yolov9s": 1.06,                                       # 1.12 (yolov9t's) has a runaway mode on small inputs (96x128: rms 1e5 at P5)
+SYNTH_GAINS = {"yolov9c": 1.06,
+               "yolov9s": 1.06,                                       # 1.12 (yolov9t's) has a runaway mode on small inputs (96x128: rms 1e5 at P5)
                "yolov7-tiny": 1.0,                                    # LeakyReLU: piecewise linear, no chaos (fp16 rel-L2 1.3e-3 at any gain); 1.0 keeps rms ~0.4
                "yolov9t": 1.12,                                       # critical between 1.16 and 1.22 (activations explode there)
+               "yolov10s": 1.0,
                "yolov10n": 1.05,                                      # critical ~1.09 (1.08 already drifts: fp16 rel-L2 1.9e-3 at P5, boxes 0.3 px)
                "yolov8m": 0.99, "yolov8l": 0.96, "yolov8x": 0.98}     # deeper Bottleneck chains: critical gain ~1.03 (m), ~0.97 (l), ~1.0 (x)
 
@@ -394,7 +396,7 @@ def yolov8(scale="n", nc=80, imgsz=640, wsrc=None, seed=0):
 # v8-layout (1, 4+nc, A) tensor [cx, cy, w, h, class probabilities]: the graph ends in the v8 decode over the ONE-TO-ONE head
 # (the branch v10 deploys; same Detect arithmetic as v8: DFL expectation, dist2bbox, sigmoid).
 # =====================================================================================
-V10_SCALES = {"n": (0.33, 0.25, 1024)}
+V10_SCALES = {"n": (0.33, 0.25, 1024), "s": (0.33, 0.50, 1024)}      # yolov10s.yaml: row 8 is a C2fCIB(lk) instead of n's C2f
 
 
 def _scdown(g, x, c2, k, s, name, out=None):
@@ -472,7 +474,7 @@ def yolov10(scale="n", nc=80, imgsz=640, wsrc=None, seed=0):
     x = _scdown(g, p3b, c4, 3, 2, "model.5")
     p4b = _c2f(g, x, c4, dep(6), True, "model.6", out=cat12.slice(c5, c4))
     x = _scdown(g, p4b, c5, 3, 2, "model.7")
-    x = _c2f(g, x, c5, dep(3), True, "model.8")
+    x = _c2f(g, x, c5, dep(3), True, "model.8") if scale == "n" else _c2fcib(g, x, c5, dep(3), True, True, "model.8")
     x = _sppf(g, x, c5, "model.9")
     p5b = _psa_block(g, x, "model.10", out=cat21.slice(c4, c5))
     g.upsample2(p5b, out=cat12.slice(0, c5), name="model.11")
@@ -557,6 +559,29 @@ def _sppelan(g, x, c2, c3, name, out=None):
     return g.conv(cat, c2, 1, 1, f"{name}.cv5.conv", out=out)
 
 
+def _v9_detect(g, feats, nc, H, name):
+    """The v8 Detect head of the YOLOv9 graphs (model.22)."""
+    cb = max(16, feats[0].c // 4, 64)
+    cc = max(feats[0].c, min(nc, 100))
+    ins, strides = [], []
+    for i, f in enumerate(feats):
+        s = H // f.h
+        strides.append(s)
+        b = g.conv(f, cb, 3, 1, f"model.22.cv2.{i}.0.conv")
+        b = g.conv(b, cb, 3, 1, f"model.22.cv2.{i}.1.conv")
+        b = g.conv(b, 64, 1, 1, f"model.22.cv2.{i}.2", act=ACT_NONE, f32_out=True, bias_fill=1.0)
+        c = g.conv(f, cc, 3, 1, f"model.22.cv3.{i}.0.conv")
+        c = g.conv(c, cc, 3, 1, f"model.22.cv3.{i}.1.conv")
+        c = g.conv(c, nc, 1, 1, f"model.22.cv3.{i}.2", act=ACT_NONE, f32_out=True, bias_fill=math.log(5 / nc / (640 / s) ** 2))
+        ins += [b, c]
+    A = sum(f.h * f.w for f in feats)
+    head = g.buf(1, 1, (4 + nc) * A, f32=True)
+    g._op(OP_DETECT_V8, ins, head, params=[nc, A] + strides, name="model.22.decode")
+    g.output(head, 0, [1, 4 + nc, A], "output0")
+    g.meta = dict(kind="yolov9", nc=nc, anchors=A, strides=strides)
+    return g
+
+
 def yolov9t(nc=80, imgsz=640, wsrc=None, seed=0, scale="t"):
     """ultralytics cfg/models/v9/yolov9t.yaml / yolov9s.yaml: the s graph is the t graph with every width doubled (same modules, same
     repeats) -- `scale` "t" | "s"."""
@@ -588,26 +613,51 @@ def yolov9t(nc=80, imgsz=640, wsrc=None, seed=0, scale="t"):
     p4 = _repncspelan4(g, cat17, 96 * m, 96 * m, 48 * m, 3, "model.18")
     _aconv(g, p4, 64 * m, "model.19", out=cat20.slice(0, 64 * m))
     p5 = _repncspelan4(g, cat20, 128 * m, 128 * m, 64 * m, 3, "model.21")
-    feats = [p3, p4, p5]
-    cb = max(16, feats[0].c // 4, 64)
-    cc = max(feats[0].c, min(nc, 100))
-    ins, strides = [], []
-    for i, f in enumerate(feats):
-        s = H // f.h
-        strides.append(s)
-        b = g.conv(f, cb, 3, 1, f"model.22.cv2.{i}.0.conv")
-        b = g.conv(b, cb, 3, 1, f"model.22.cv2.{i}.1.conv")
-        b = g.conv(b, 64, 1, 1, f"model.22.cv2.{i}.2", act=ACT_NONE, f32_out=True, bias_fill=1.0)
-        c = g.conv(f, cc, 3, 1, f"model.22.cv3.{i}.0.conv")
-        c = g.conv(c, cc, 3, 1, f"model.22.cv3.{i}.1.conv")
-        c = g.conv(c, nc, 1, 1, f"model.22.cv3.{i}.2", act=ACT_NONE, f32_out=True, bias_fill=math.log(5 / nc / (640 / s) ** 2))
-        ins += [b, c]
-    A = sum(f.h * f.w for f in feats)
-    head = g.buf(1, 1, (4 + nc) * A, f32=True)
-    g._op(OP_DETECT_V8, ins, head, params=[nc, A] + strides, name="model.22.decode")
-    g.output(head, 0, [1, 4 + nc, A], "output0")
-    g.meta = dict(kind="yolov9", nc=nc, anchors=A, strides=strides)
-    return g
+    return _v9_detect(g, [p3, p4, p5], nc, H, name)
+
+
+def _adown(g, x, c2, name, out=None):
+    """ADown(c1, c2): 2x2 s1 average pool, then channel halves -> (3x3 s2 conv | 3x3 s2 p1 max-pool + 1x1 conv), concatenated."""
+    c = c2 // 2
+    if out is None:
+        out = g.buf(x.h // 2, x.w // 2, c2)
+    t = g.avgpool(x, 2, 1, 0, name=f"{name}.pool")
+    g.conv(t.slice(0, x.c // 2), c, 3, 2, f"{name}.cv1.conv", out=out.slice(0, c))
+    mp = g.maxpool(t.slice(x.c // 2, x.c // 2), 3, 2, 1, name=f"{name}.mp")
+    g.conv(mp, c, 1, 1, f"{name}.cv2.conv", out=out.slice(c, c))
+    return out
+
+
+def yolov9c(nc=80, imgsz=640, wsrc=None, seed=0):
+    """ultralytics cfg/models/v9/yolov9c.yaml (GELAN-c, 25.3 M parameters / 102 GFLOPs fused): RepNCSPELAN4 with one RepBottleneck per
+    RepCSP, ADown down-sampling, SPPELAN, v8 Detect."""
+    wsrc = wsrc or SynthWeights(seed, gain=synth_gain("yolov9c"))
+    H, W = _hw(imgsz)
+    g = Graph("yolov9c", 3, H, W, wsrc)
+    x, cin = g.input()
+    cat11 = g.buf(H // 16, W // 16, 512 + 512)    # [up(9), 6]
+    cat14 = g.buf(H // 8, W // 8, 512 + 512)      # [up(12), 4]
+    cat17 = g.buf(H // 16, W // 16, 256 + 512)    # [16, 12]
+    cat20 = g.buf(H // 32, W // 32, 512 + 512)    # [19, 9]
+    x = g.conv(x, 64, 3, 2, "model.0.conv", true_cin=cin)
+    x = g.conv(x, 128, 3, 2, "model.1.conv")
+    x = _repncspelan4(g, x, 256, 128, 64, 1, "model.2")
+    x = _adown(g, x, 256, "model.3")
+    p3b = _repncspelan4(g, x, 512, 256, 128, 1, "model.4", out=cat14.slice(512, 512))
+    x = _adown(g, p3b, 512, "model.5")
+    p4b = _repncspelan4(g, x, 512, 512, 256, 1, "model.6", out=cat11.slice(512, 512))
+    x = _adown(g, p4b, 512, "model.7")
+    x = _repncspelan4(g, x, 512, 512, 256, 1, "model.8")
+    p5b = _sppelan(g, x, 512, 256, "model.9", out=cat20.slice(512, 512))
+    g.upsample2(p5b, out=cat11.slice(0, 512), name="model.10")
+    n12 = _repncspelan4(g, cat11, 512, 512, 256, 1, "model.12", out=cat17.slice(256, 512))
+    g.upsample2(n12, out=cat14.slice(0, 512), name="model.13")
+    p3 = _repncspelan4(g, cat14, 256, 256, 128, 1, "model.15")
+    _adown(g, p3, 256, "model.16", out=cat17.slice(0, 256))
+    p4 = _repncspelan4(g, cat17, 512, 512, 256, 1, "model.18")
+    _adown(g, p4, 512, "model.19", out=cat20.slice(0, 512))
+    p5 = _repncspelan4(g, cat20, 512, 512, 256, 1, "model.21")
+    return _v9_detect(g, [p3, p4, p5], nc, H, "yolov9c")
 
 
 # =====================================================================================
@@ -905,8 +955,10 @@ BUILDERS = {
     "yolov8m": lambda **k: yolov8("m", **k), "yolov8l": lambda **k: yolov8("l", **k),
     "yolov8x": lambda **k: yolov8("x", **k),
     "yolov10n": lambda **k: yolov10("n", **k),
+    "yolov10s": lambda **k: yolov10("s", **k),
     "yolov9t": lambda **k: yolov9t(**k),
     "yolov9s": lambda **k: yolov9t(scale="s", **k),
+    "yolov9c": lambda **k: yolov9c(**k),
     "yolov7-tiny": lambda **k: yolov7_tiny(**k),
     "yolov5n": lambda **k: yolov5("n", **k), "yolov5s": lambda **k: yolov5("s", **k),
     "yolov5m": lambda **k: yolov5("m", **k), "yolov5l": lambda **k: yolov5("l", **k), "yolov5x": lambda **k: yolov5("x", **k),

@@ -302,16 +302,17 @@ def detect_arch(m):
             is_v10 = any(".attn.qkv." in k or ".one2one_cv" in k for k in m.initializers) or \
                 any(nd["op"] == "Conv" and nd["attrs"].get("group", 1) > 1 for nd in m.nodes)
             if is_v10:
-                if scale != "n":
-                    raise ValueError("YOLOv10 scale %r is not built (yolov10n is): %s" % (scale, found))
-                return "yolov10n", dict(nc=o[1] - 4, imgsz=(H, W))
+                if scale not in ("n", "s"):
+                    raise ValueError("YOLOv10 scale %r is not built (yolov10n and yolov10s are): %s" % (scale, found))
+                return "yolov10" + scale, dict(nc=o[1] - 4, imgsz=(H, W))
             # YOLOv9 (GELAN): the same stem width and head as YOLOv8n; its AConv / ADown down-sampling average-pools first (v8 / v10
             # graphs have no AveragePool node), its blocks are RepNCSPELAN4 (parameter names model.N.cv2.0.cv1.conv ...)
             is_v9 = any(nd["op"] == "AveragePool" for nd in m.nodes) or any(".cv2.0.m.0.cv1." in k for k in m.initializers)
             if is_v9:
-                if scale not in ("n", "s"):
-                    raise ValueError("YOLOv9 with a %d-channel stem is not built (yolov9t and yolov9s are): %s" % (c0[0], found))
-                return "yolov9" + ("t" if scale == "n" else "s"), dict(nc=o[1] - 4, imgsz=(H, W))
+                v9 = {"n": "t", "s": "s", "l": "c"}.get(scale)      # stem widths 16 / 32 / 64
+                if v9 is None:
+                    raise ValueError("YOLOv9 with a %d-channel stem is not built (yolov9t, yolov9s and yolov9c are): %s" % (c0[0], found))
+                return "yolov9" + v9, dict(nc=o[1] - 4, imgsz=(H, W))
             return "yolov8" + scale, dict(nc=o[1] - 4, imgsz=(H, W))
         if c0[2] == 3 and o[1] > o[2]:                      # (1, A, 5+nc) behind a 3x3 stem: YOLOv7 (v5-layout head, yoloDetector.py:110-124)
             if H % 32 or W % 32:
