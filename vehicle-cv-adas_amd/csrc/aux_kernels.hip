@@ -474,8 +474,8 @@ __global__ __launch_bounds__(256) void detect_v8_fused_kernel(DetFuseDev d) {
     uint16_t* wbox = wl;                                  // [4][KSb][512]
     uint16_t* wcls = wl + (size_t)4 * KSb * 512;          // [NTc][KSc][512]
     float* bias = reinterpret_cast<float*>(wcls + (size_t)NTc * KSc * 512);  // [64 + NTc*16]
-    for (int i = tid; i < 4 * KSb * 64; i += 256) *reinterpret_cast<du32x4*>(wbox + (size_t)i * 8) = *reinterpret_cast<const du32x4*>(d.wb[lvl] + (size_t)i * 8);
-    for (int i = tid; i < NTc * KSc * 64; i += 256) *reinterpret_cast<du32x4*>(wcls + (size_t)i * 8) = *reinterpret_cast<const du32x4*>(d.wc[lvl] + (size_t)i * 8);
+    stage_lds16<256, 4>(wbox, d.wb[lvl], 4 * KSb * 64, tid);
+    stage_lds16<256, 8>(wcls, d.wc[lvl], NTc * KSc * 64, tid);
     for (int i = tid; i < 64 + NTc * 16; i += 256) bias[i] = i < 64 ? d.bb[lvl][i] : d.bc[lvl][i - 64];
     __syncthreads();
 
@@ -652,11 +652,11 @@ struct Det5Dev {
     int hw[3], nx[3], stride[3], row_off[3], blk_off[3];
     const float* anchors;   // [3 levels][3 anchors][2]
     float* out;
-    int nc, A, n;
+    int nc, A, n, lds_bias_off;   // lds_bias_off: in floats
 };
 
 template <typename E>
-__global__ __launch_bounds__(256) void detect_v5_fused_kernel(Det5Dev d) {
+__global__ __launch_bounds__(256, 3) void detect_v5_fused_kernel(Det5Dev d) {
     extern __shared__ __attribute__((aligned(16))) uint16_t wl[];      // weight chunk, then the output staging
     E::enter();
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lrow = lane & 15, kg = lane >> 4;
@@ -666,6 +666,8 @@ __global__ __launch_bounds__(256) void detect_v5_fused_kernel(Det5Dev d) {
     const int rel = blockIdx.x - d.blk_off[lvl], a = rel / nblk, p0 = (rel - a * nblk) * 128 + wave * 32;
     const int KS = d.cin[lvl] >> 5;
     const uint16_t* wsrc = d.w[lvl] + (size_t)a * KS * NT * 512;
+    float* bl = reinterpret_cast<float*>(wl) + d.lds_bias_off;     // the anchor's 5 + nc biases, behind the weight / staging region
+    if (tid < no) bl[tid] = d.bias[lvl][a * no + tid];              // (visible after the K loop's barriers)
 
     const uint16_t* ip[2];
     bool ok[2];
@@ -692,8 +694,8 @@ __global__ __launch_bounds__(256) void detect_v5_fused_kernel(Det5Dev d) {
                 if (k < kc && ok[t]) xb[t][k] = *reinterpret_cast<const du32x4*>(ip[t] + (ks0 + k) * 32);
             }
         __syncthreads();
-        const du32x4* src = reinterpret_cast<const du32x4*>(wsrc + (size_t)ks0 * NT * 512);
-        for (int i = tid; i < kc * NT * 64; i += 256) reinterpret_cast<du32x4*>(wl)[i] = src[i];
+        const uint16_t* src = wsrc + (size_t)ks0 * NT * 512;
+        stage_lds16<256, 6>(wl, src, kc * NT * 64, tid);
         __syncthreads();
 #pragma unroll
         for (int k = 0; k < ADAS_DET5_KC; ++k) {
@@ -725,7 +727,7 @@ __global__ __launch_bounds__(256) void detect_v5_fused_kernel(Det5Dev d) {
                 for (int r = 0; r < 4; ++r) {
                     const int c = nt * 16 + kg * 4 + r;
                     if (c < no) {
-                        const float sg = __frcp_rn(1.0f + __expf(-(acc[t][nt][r] + d.bias[lvl][a * no + c])));
+                        const float sg = __frcp_rn(1.0f + __expf(-(acc[t][nt][r] + bl[c])));
                         float o = sg;
                         if (c == 0) o = (sg * 2.0f - 0.5f + gx) * sl;
                         else if (c == 1) o = (sg * 2.0f - 0.5f + gy) * sl;
@@ -740,7 +742,20 @@ __global__ __launch_bounds__(256) void detect_v5_fused_kernel(Det5Dev d) {
     const int rows = min(32, hw - p0);
     if (rows > 0) {
         float* dst = d.out + ((size_t)b * d.A + d.row_off[lvl] + (size_t)a * hw + p0) * no;
-        for (int i = lane; i < rows * no; i += 64) dst[i] = stage[i];
+        const int nel = rows * no;
+        for (int i0 = 0; i0 < nel; i0 += 64 * 8) {           // eight LDS reads in flight, then eight coalesced 256-byte stores
+            float tmp[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int i = i0 + j * 64 + lane;
+                tmp[j] = stage[i < nel ? i : 0];
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int i = i0 + j * 64 + lane;
+                if (i < nel) dst[i] = tmp[j];
+            }
+        }
     }
 }
 
@@ -790,7 +805,9 @@ hipError_t launch_detect_v5_fused(const TView* hidden, const void* const* wfrag,
     if (off != A) return hipErrorInvalidValue;
     d.anchors = d_anchors; d.out = out; d.nc = nc; d.A = A; d.n = n;
     const size_t lw = (size_t)ADAS_DET5_KC * NT * 1024, ls = (size_t)4 * 32 * no * 4;
-    const size_t lds = lw > ls ? lw : ls;
+    const size_t region = ((lw > ls ? lw : ls) + 15) & ~(size_t)15;
+    d.lds_bias_off = (int)(region / 4);
+    const size_t lds = region + (size_t)no * 4;
     ADAS_DISPATCH_E16(prec == PREC_FP16, E, hipLaunchKernelGGL(detect_v5_fused_kernel<E>, dim3(blocks, n), dim3(256), lds, st_, d));
     return hipGetLastError();
 }

@@ -44,11 +44,11 @@ __global__ __launch_bounds__(512) void conv_pw_kernel(PwDev a) {
     const int nt0 = blockIdx.y * a.NTL;
     const int ntl = a.NT - nt0 < a.NTL ? a.NT - nt0 : a.NTL;
     float* bl = reinterpret_cast<float*>(wl + (size_t)a.NTL * KS * 512);  // [NTL*16] bias, behind the weights
-    {   // weights: contiguous copy, 16 B per thread per trip; bias too (a global bias load inside the feature-tile loop
+    {   // weights: contiguous copy, eight 16-byte loads in flight per thread (elem16.h stage_lds16); bias too (a global bias load inside the feature-tile loop
         // costs one exposed L2 round trip per tile: hipcc waits vmcnt(0) right behind it)
         const int n16 = ntl * KS * 64;
         const uint16_t* wsrc = a.wfrag + (size_t)nt0 * KS * 512;
-        for (int i = tid; i < n16; i += 512) *reinterpret_cast<pu32x4*>(wl + (size_t)i * 8) = *reinterpret_cast<const pu32x4*>(wsrc + (size_t)i * 8);
+        stage_lds16<512, 8>(wl, wsrc, n16, tid);
         for (int i = tid; i < ntl * 16; i += 512) bl[i] = a.bias[nt0 * 16 + i];   // bias is padded to a multiple of 128 entries
     }
     __syncthreads();

@@ -78,7 +78,7 @@ __global__ __launch_bounds__(256, CONV2 ? 3 : 2) void conv_stem_kernel(StemDev a
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lrow = lane & 15, kg = lane >> 4;
-    for (int i = tid; i < NT * KH * 64; i += 256) *reinterpret_cast<su32x4*>(wl + i * 8) = *reinterpret_cast<const su32x4*>(a.wfrag + (size_t)i * 8);
+    stage_lds16<256, (NT * KH * 64 + 255) / 256 < 8 ? (NT * KH * 64 + 255) / 256 : 8>(wl, a.wfrag, NT * KH * 64, tid);
     if (CONV2)
         for (int i = tid; i < 2 * 5 * 64; i += 256) *reinterpret_cast<su32x4*>(w2l + i * 8) = *reinterpret_cast<const su32x4*>(a.wfrag2 + (size_t)i * 8);
 

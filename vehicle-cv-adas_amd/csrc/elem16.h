@@ -92,4 +92,29 @@ struct Fp16 {
         }                                  \
     } while (0)
 
+
+// Contiguous global -> LDS copy of n16 16-byte words by THREADS threads with U loads in flight per thread.  The obvious
+// `for (i = tid; i < n; i += THREADS) lds[i] = src[i];` compiles to load / s_waitcnt vmcnt(0) / ds_write per trip (hipcc neither unrolls
+// nor pipelines a 16-byte copy loop with a runtime trip count): one exposed L2 round trip per 16 bytes per thread, 24 of them in front of
+// the first MFMA of a 384 -> 256 pointwise conv.
+template <int THREADS, int U = 8>
+__device__ __forceinline__ void stage_lds16(void* lds_dst, const void* src, int n16, int tid) {
+    typedef __attribute__((ext_vector_type(4))) uint32_t sl_u32x4;
+    const sl_u32x4* s = reinterpret_cast<const sl_u32x4*>(src);
+    sl_u32x4* d = reinterpret_cast<sl_u32x4*>(lds_dst);
+    for (int i0 = 0; i0 < n16; i0 += THREADS * U) {
+        sl_u32x4 t[U];
+#pragma unroll
+        for (int j = 0; j < U; ++j) {
+            const int i = i0 + j * THREADS + tid;
+            t[j] = s[i < n16 ? i : 0];
+        }
+#pragma unroll
+        for (int j = 0; j < U; ++j) {
+            const int i = i0 + j * THREADS + tid;
+            if (i < n16) d[i] = t[j];
+        }
+    }
+}
+
 }  // namespace adas
