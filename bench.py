@@ -109,9 +109,13 @@ class SynthDetector:
         # conf = obj * cls > box_score is again a threshold on the best class logit
         self.v5 = {"yolov5": "model.24.m", "yolov7": "model.77.m"}.get(name[:6])
         self.no = g.outs[0][2][2] if self.v5 else None
+        self.v6 = name.startswith("yolov6")      # EffiDeHead: separate class predictors, objectness 1: conf = class probability, as for v8
         self._uncal = os.path.join(workdir, f"{name}_{tag}_uncal.hipm")
         g.save(self._uncal)
         self._eng = CE.HipEngine(self._uncal, "fp32", batch)
+
+    def _cls_layer(self, i):
+        return f"{self.v5}.{i}" if self.v5 else (f"detect.cls_preds.{i}" if self.v6 else f"{self.head}.{i}.2")
 
     def best_logits(self, seam):
         """seam: (n,3,H,W) fp32 -> (n, A) every anchor's best class logit without its bias (un-sharpened), ascending per frame."""
@@ -121,7 +125,7 @@ class SynthDetector:
             self._eng.engine_inference(chunk)
             per_level = []
             for i in range(3):
-                lname = f"{self.v5}.{i}" if self.v5 else f"{self.head}.{i}.2"
+                lname = self._cls_layer(i)
                 z = self._eng.fetch_activation(lname, len(chunk))
                 z = z - self.ws.store[lname + ".bias"].reshape(1, -1, 1, 1)
                 if self.v5:
@@ -196,7 +200,7 @@ class SynthDetector:
                 ws2.store[lname + ".weight"] = w.reshape(self.ws.store[lname + ".weight"].shape)
                 ws2.store[lname + ".bias"] = b.reshape(-1)
                 continue
-            lname = f"{self.head}.{i}.2"
+            lname = self._cls_layer(i)
             ws2.store[lname + ".weight"] = self.ws.store[lname + ".weight"] * sh
             ws2.store[lname + ".bias"] = np.full_like(self.ws.store[lname + ".bias"], math.log(0.4 / 0.6) - float(sh) * t)
         g2 = M.build(self.name, wsrc=ws2)
@@ -223,7 +227,8 @@ def measure_parity(det_eng, lane_eng, det_name, lane_name, Wd, Wl, dframes, lfra
     taps = {}
     want = nets.detector_forward(det_name, dframes[:n], Wd, taps=taps)
     got = det_eng.engine_inference(dframes[:n])[0]
-    p3_layer = {"yolov1": "model.16.cv2.conv", "yolov9": "model.15.cv4.conv", "yolov7": "model.74.conv"}.get(det_name[:6], "model.15.cv2.conv")
+    p3_layer = {"yolov1": "model.16.cv2.conv", "yolov9": "model.15.cv4.conv", "yolov7": "model.74.conv",
+                "yolov6": "neck.Rep_p3.block.2.rbr_reparam"}.get(det_name[:6], "model.15.cv2.conv")
     v5 = nets.head_layout(det_name) == "yolov5"      # (A, 5+nc): boxes first along the LAST axis
     sl_cls, sl_box = ((Ellipsis, slice(4, None)), (Ellipsis, slice(0, 4))) if v5 else ((slice(None), slice(4, None)), (slice(None), slice(0, 4)))
     p3 = det_eng.fetch_activation(p3_layer, n)
@@ -389,7 +394,7 @@ def measure_post_hbm(L, pipe, gd, gl, S, layer_ms, precision):
     try:
         meta = gd.meta
         A, nc = meta["anchors"], meta["nc"]
-        v5 = meta["kind"] in ("yolov5", "yolov7")
+        v5 = meta["kind"] in ("yolov5", "yolov6", "yolov7")
         head_bytes = S * ((5 if v5 else 4) + nc) * A * 4
         ms2 = (C.c_float * 2)()
         L.check(L.lib().adas_yolo_post_profile(pipe.post.h, pipe.det.output_device_ptr(0), S, 20, ms2))
@@ -424,6 +429,7 @@ PRESETS = {   # BASELINE.json configs
     "v10": dict(det="yolov10n", lane="ufldv2_res18", streams=64),         # the reference's shipped default detector (demo.py:24-30)
     "v9": dict(det="yolov9t", lane="ufldv2_res18", streams=64),           # YOLOv9 (README.md:57), GELAN-t
     "v7": dict(det="yolov7-tiny", lane="ufldv2_res18", streams=64),       # YOLOv7 (README.md:55), v5-layout head, LeakyReLU
+    "v6": dict(det="yolov6n", lane="ufldv2_res18", streams=64),           # YOLOv6 (README.md:54), RepVGG-deploy, anchor-free, v5-layout rows
     # configs[3]: YOLOv8s + UFLDv2 + ByteTrack on 1280x720 streams; configs[4]: one 1280x720 stream per GPU, YOLOv8l.  Few streams per
     # GPU cannot fill 256 CUs one frame at a time: these presets run temporal micro-batches; `--micro-batch 1` is
     # the frame-at-a-time latency mode, reported beside the throughput line as `frame_at_a_time`.
@@ -583,7 +589,7 @@ def main():
     Wl = wl.store
     t_build = time.time() - t_build
 
-    HEAD = L.HEAD_V5 if args.det.startswith(("yolov5", "yolov7")) else L.HEAD_V8        # yoloDetector.py:110-124
+    HEAD = L.HEAD_V5 if args.det.startswith(("yolov5", "yolov6", "yolov7")) else L.HEAD_V8        # yoloDetector.py:110-124
 
     def make_pipe(precision):
         return PL.AdasPipeline(det_path, lane_path, n_streams=NSTREAMS, precision=precision, src_hw=(720, 1280), head_layout=HEAD,

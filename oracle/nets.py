@@ -347,16 +347,97 @@ def yolov9c_forward(x, W, nc=80, taps=None):
         return _v8_decode(outs, [f.shape[2:] for f in feats], nc, taps)
 
 
+# ------------------------------------------------------------------ YOLOv6 v3.0 n / s
+# meituan/YOLOv6: yolov6/models/efficientrep.py (EfficientRep), reppan.py (RepBiFPANNeck), effidehead.py (Detect.forward, eval),
+# layers/common.py (RepVGGBlock deploy = 3x3 conv + ReLU, ConvBNReLU, SimCSPSPPF, BiFusion, Transpose), configs/yolov6n.py / yolov6s.py
+# (depth 0.33, width 0.25 / 0.50, num_repeats [1, 6, 12, 18, 6] + [12, 12, 12, 12], fuse_P2, cspsppf, use_dfl False).
+V6_SCALES = {"n": (0.33, 0.25), "s": (0.33, 0.50)}
+
+
+def _v6_rep(x, W, name, s=1):
+    return _conv(x, W, name + ".rbr_reparam", s, act="relu")
+
+
+def _v6_cbr(x, W, name, s=1):
+    return _conv(x, W, name + ".block.conv", s, act="relu")
+
+
+def _v6_repblock(x, W, name, n):
+    x = _v6_rep(x, W, name + ".conv1")
+    for i in range(n - 1):
+        x = _v6_rep(x, W, f"{name}.block.{i}")
+    return x
+
+
+def _v6_simcspsppf(x, W, name):
+    x1 = _v6_cbr(_v6_cbr(_v6_cbr(x, W, name + ".cv1"), W, name + ".cv3"), W, name + ".cv4")
+    y0 = _v6_cbr(x, W, name + ".cv2")
+    y1 = F.max_pool2d(x1, 5, 1, 2)
+    y2 = F.max_pool2d(y1, 5, 1, 2)
+    y3 = _v6_cbr(_v6_cbr(torch.cat((x1, y1, y2, F.max_pool2d(y2, 5, 1, 2)), 1), W, name + ".cv5"), W, name + ".cv6")
+    return _v6_cbr(torch.cat((y0, y3), 1), W, name + ".cv7")
+
+
+def _v6_bifusion(xs, W, name):
+    wt = _round(_t(W, name + ".upsample.upsample_transpose.weight"))
+    x0 = _round(F.conv_transpose2d(xs[0], wt, _t(W, name + ".upsample.upsample_transpose.bias"), stride=2))
+    x1 = _v6_cbr(xs[1], W, name + ".cv1")
+    x2 = _v6_cbr(_v6_cbr(xs[2], W, name + ".cv2"), W, name + ".downsample", 2)
+    return _v6_cbr(torch.cat((x0, x1, x2), 1), W, name + ".cv3")
+
+
+def yolov6_forward(x, W, scale="n", nc=80, taps=None):
+    """x: (N,3,H,W) fp32 in [0,1] -> (N, A, 5+nc): [cx, cy, w, h] in input pixels, objectness 1, class probabilities."""
+    depth = V6_SCALES[scale][0]
+    rn = lambda n: max(round(n * depth), 1) if n > 1 else n
+    nb, nk = [rn(n) for n in (1, 6, 12, 18, 6)], rn(12)
+    x = torch.as_tensor(x, dtype=torch.float32)
+    H_in = x.shape[2]
+    with torch.no_grad():
+        x = _v6_rep(x, W, "backbone.stem", 2)
+        outs = []
+        for i in range(1, 5):
+            x = _v6_repblock(_v6_rep(x, W, f"backbone.ERBlock_{i + 1}.0", 2), W, f"backbone.ERBlock_{i + 1}.1", nb[i])
+            outs.append(x)
+        x3, x2, x1, _ = outs
+        x0 = _v6_simcspsppf(x, W, "backbone.ERBlock_5.2")
+        fpn_out0 = _v6_cbr(x0, W, "neck.reduce_layer0")
+        f_out0 = _v6_repblock(_v6_bifusion([fpn_out0, x1, x2], W, "neck.Bifusion0"), W, "neck.Rep_p4", nk)
+        fpn_out1 = _v6_cbr(f_out0, W, "neck.reduce_layer1")
+        pan_out2 = _v6_repblock(_v6_bifusion([fpn_out1, x2, x3], W, "neck.Bifusion1"), W, "neck.Rep_p3", nk)
+        pan_out1 = _v6_repblock(torch.cat((_v6_cbr(pan_out2, W, "neck.downsample2", 2), fpn_out1), 1), W, "neck.Rep_n3", nk)
+        pan_out0 = _v6_repblock(torch.cat((_v6_cbr(pan_out1, W, "neck.downsample1", 2), fpn_out0), 1), W, "neck.Rep_n4", nk)
+        if taps is not None:
+            taps.update(p3=pan_out2, p4=pan_out1, p5=pan_out0, sppf=x0)
+        cls_l, reg_l, pts, strd = [], [], [], []
+        for i, f in enumerate((pan_out2, pan_out1, pan_out0)):
+            b, _, h, w = f.shape
+            st = _conv(f, W, f"detect.stems.{i}.conv")
+            cls_l.append(torch.sigmoid(_conv(_conv(st, W, f"detect.cls_convs.{i}.conv"), W, f"detect.cls_preds.{i}", act=None)).reshape(b, nc, h * w))
+            reg_l.append(_conv(_conv(st, W, f"detect.reg_convs.{i}.conv"), W, f"detect.reg_preds.{i}", act=None).reshape(b, 4, h * w))
+            sy, sx = torch.meshgrid(torch.arange(h, dtype=torch.float32) + 0.5, torch.arange(w, dtype=torch.float32) + 0.5, indexing="ij")
+            pts.append(torch.stack((sx, sy), -1).reshape(-1, 2))
+            strd.append(torch.full((h * w, 1), float(H_in // h)))
+        cls_score = torch.cat(cls_l, -1).permute(0, 2, 1)
+        dist = torch.cat(reg_l, -1).permute(0, 2, 1)
+        anchor_points, stride_tensor = torch.cat(pts), torch.cat(strd)
+        x1y1, x2y2 = anchor_points - dist[..., :2], anchor_points + dist[..., 2:]
+        boxes = torch.cat(((x1y1 + x2y2) / 2, x2y2 - x1y1), -1) * stride_tensor
+        return torch.cat((boxes, torch.ones(boxes.shape[0], boxes.shape[1], 1), cls_score), -1).numpy()
+
+
 def head_layout(name):
     """"yolov5" (A, 5+nc) or "yolov8" (4+nc, A): the `model_type` argument of oracle.yolo_post.detect_post for graph `name`."""
-    return "yolov5" if name.startswith(("yolov5", "yolov7")) else "yolov8"
+    return "yolov5" if name.startswith(("yolov5", "yolov6", "yolov7")) else "yolov8"
 
 
 def detector_forward(name, x, W, nc=80, taps=None):
     """Forward of the detector graph `name`: (4+nc, A) heads ("yolov8n" .. "yolov8x", "yolov10n", "yolov10s", "yolov9t", "yolov9s", "yolov9c") or the v5 layout
-    (A, 5+nc) ("yolov7-tiny", "yolov5n" .. "yolov5x"; no taps for YOLOv5)."""
+    (A, 5+nc) ("yolov7-tiny", "yolov6n", "yolov6s", "yolov5n" .. "yolov5x"; no taps for YOLOv5)."""
     if name.startswith("yolov7"):
         return yolov7_tiny_forward(x, W, nc, taps)
+    if name.startswith("yolov6"):
+        return yolov6_forward(x, W, name[-1], nc, taps)
     if name.startswith("yolov5"):
         return yolov5_forward(x, W, name[-1], nc)
     if name.startswith("yolov10"):

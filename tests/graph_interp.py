@@ -88,6 +88,22 @@ def run(g, x):
                 write(out, F.avg_pool2d(read(ins[0]), op["kh"], op["stride"], op["pad"], False, True))
             elif t == M.OP_UPSAMPLE2:
                 write(out, F.interpolate(read(ins[0]), scale_factor=2, mode="nearest"))
+            elif t == M.OP_DEPTH2SPACE:                                          # channel blocks ordered (dy, dx), C channels each
+                v = read(ins[0])
+                B, c4, h, w_ = v.shape
+                write(out, v.reshape(B, 2, 2, c4 // 4, h, w_).permute(0, 3, 4, 1, 5, 2).reshape(B, c4 // 4, 2 * h, 2 * w_))
+            elif t == M.OP_DETECT_V6:                                            # engine.h: inputs (reg, cls) per level, rows (level, y, x)
+                nc, A = int(op["params"][0]), int(op["params"][1])
+                rows = []
+                for l in range(3):
+                    s_ = float(op["params"][2 + l])
+                    r, c = read(ins[2 * l]), read(ins[2 * l + 1])
+                    h, w_ = ins[2 * l].h, ins[2 * l].w
+                    gy, gx = torch.meshgrid(torch.arange(h, dtype=torch.float32) + 0.5, torch.arange(w_, dtype=torch.float32) + 0.5, indexing="ij")
+                    x1, y1, x2, y2 = gx - r[:, 0], gy - r[:, 1], gx + r[:, 2], gy + r[:, 3]
+                    box = torch.stack(((x1 + x2) / 2, (y1 + y2) / 2, x2 - x1, y2 - y1), 1) * s_
+                    rows.append(torch.cat((box, torch.ones(N, 1, h, w_), c.sigmoid()), 1).reshape(N, 5 + nc, h * w_).permute(0, 2, 1))
+                bufs[out.buf] = torch.cat(rows, 1).reshape(N, A * (5 + nc), 1, 1)
             elif t == M.OP_ATTENTION:
                 nh, kd, hd, scale = int(op["params"][0]), int(op["params"][1]), int(op["params"][2]), float(op["params"][3])
                 q_k_v = read(ins[0])

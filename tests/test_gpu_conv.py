@@ -473,7 +473,7 @@ def test_wide_pointwise_conv_with_residual(CE):
 
 
 @pytest.mark.parametrize("name,batch", [("yolov8s", 1), ("yolov8s", 64), ("yolov8m", 16), ("yolov8l", 1), ("yolov8l", 16), ("yolov8x", 4), ("yolov10n", 64), ("yolov10s", 16), ("yolov9t", 64), ("yolov9s", 16), ("yolov9c", 8),
-                                        ("yolov7-tiny", 64)])
+                                        ("yolov7-tiny", 64), ("yolov6n", 64), ("yolov6s", 16)])
 def test_no_generic_fallback_kernel_in_16bit_modes(CE, name, batch):
     """Every conv of the YOLOv8 s / m / l / x graphs (and YOLOv10n's plain convs) resolves to a specialised kernel in the 16-bit
     modes: conv_igemm_kernel (the generic implicit GEMM) is the fp32 parity path and the shapes nothing else takes.  The only

@@ -44,6 +44,29 @@ def test_yolov7_tiny_graph_equals_oracle():
     np.testing.assert_allclose(got[..., :4], want[..., :4], rtol=1e-5, atol=2e-4)      # wh = (2 sigmoid)^2 * anchor reaches 1e3 px
 
 
+@pytest.mark.parametrize("name", ["yolov6n", "yolov6s"])
+def test_yolov6_graph_equals_oracle(name):
+    """models.yolov6 (ConvTranspose2d as 1x1 conv + depth-to-space, concat by channel offset, anchor-free decode op) against the oracle's
+    module-by-module forward with F.conv_transpose2d."""
+    g, W = _build(name, imgsz=(96, 128))
+    x = netutil.coco_like_frames(2, 96, 128, seed=3)
+    got = graph_interp.run(g, x)[0]
+    want = nets.yolov6_forward(x, W, name[-1])
+    assert got.shape == want.shape == (2, 12 * 16 + 6 * 8 + 3 * 4, 85)
+    np.testing.assert_allclose(got[..., 4:], want[..., 4:], rtol=0, atol=2e-6)
+    np.testing.assert_allclose(got[..., :4], want[..., :4], rtol=1e-5, atol=2e-4)
+    assert np.all(got[..., 4] == 1.0)                                        # EffiDeHead writes objectness 1
+
+
+def test_yolov6_published_size():
+    """meituan/YOLOv6 v3.0 model table: YOLOv6-N 4.7 M parameters / 11.4 GFLOPs, YOLOv6-S 18.5 M / 45.3 G (deploy form)."""
+    for name, p, f in (("yolov6n", 4.65, 11.3), ("yolov6s", 18.54, 45.0)):
+        g, _ = _build(name)
+        assert abs(g.n_params / 1e6 - p) < 0.01 and abs(g.flops / 1e9 - f) < 0.05, (name, g.n_params, g.flops)
+        kinds = [o["type"] for o in g.ops]
+        assert kinds.count(M.OP_DEPTH2SPACE) == 2 and kinds.count(M.OP_DETECT_V6) == 1 and [tuple(d) for _, _, d, _ in g.outs] == [(1, 8400, 85)]
+
+
 def test_yolov7_tiny_published_size():
     """WongKinYiu/yolov7 README: YOLOv7-tiny 6.2 M parameters, 13.8 GFLOPs; the fused model summary reads "6219709 parameters"."""
     g, _ = _build("yolov7-tiny")

@@ -327,3 +327,22 @@ def test_yolov7_tiny_recognised_by_stem_and_v5_layout(tmp_path):
     q.write_bytes(OW.model(nodes[:40], inits, [("images", [1, 3, 640, 640])], [("output", [1, 25200, 85])]))
     with pytest.raises(ValueError, match="yolov7-tiny"):
         OI.detect_arch(OI.read_onnx(str(q)))
+
+
+def test_yolov6n_weights_by_execution_order(tmp_path):
+    """YOLOv6 v3.0 deploy export: anonymous initializers (the exporter drops upstream's module paths), 69 Conv + 2 ConvTranspose nodes in
+    execution order, ConvTranspose weights in (Cin, Cout, 2, 2) layout; recognised by its transposed convs and (1, 8400, 85) output."""
+    W, g = synth("yolov6n")
+    inits, nodes = [], []
+    for i, base in enumerate(k[:-7] for k in list(W) if k.endswith(".weight")):
+        w, b = W[base + ".weight"], W[base + ".bias"]
+        wn, bn = "onnx::Conv_%d" % (900 + 2 * i), "onnx::Conv_%d" % (901 + 2 * i)
+        inits.append(OW.tensor(wn, w)); inits.append(OW.tensor(bn, b))
+        op = "ConvTranspose" if "upsample_transpose" in base else "Conv"
+        nodes.append(OW.node(op, ["t%d" % i, wn, bn], ["t%d" % (i + 1)], "%s_%d" % (op, i), [OW.attr_ints("kernel_shape", list(w.shape[2:]))]))
+    p = tmp_path / "yolov6n.onnx"
+    p.write_bytes(OW.model(nodes, inits, [("images", [1, 3, 640, 640])], [("outputs", [1, 8400, 85])]))
+    m = OI.read_onnx(str(p))
+    assert OI.detect_arch(m) == ("yolov6n", dict(nc=80, imgsz=(640, 640)))
+    out, g2 = OI.convert(str(p), str(tmp_path / "v6.hipm"))
+    assert g2.name == "yolov6n" and g2.tobytes() == M.build("yolov6n", wsrc=M.DictWeights(W)).tobytes()

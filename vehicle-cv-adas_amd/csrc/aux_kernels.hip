@@ -340,6 +340,45 @@ hipError_t launch_upsample2(TView in, TView out, int n, int prec, hipStream_t st
     return hipGetLastError();
 }
 
+// depth-to-space, block 2: out[2y + dy][2x + dx][c] = in[y][x][(2 dy + dx) * C + c].  With a 1x1 conv to 4 C channels in front (rows
+// ordered (dy, dx, c)) this is ConvTranspose2d(kernel 2, stride 2): YOLOv6's BiFusion up-sampling (yolov6/layers/common.py Transpose).
+template <typename T>
+__global__ void depth2space_kernel(PoolDev d) {
+    const int c8n = d.c >> 3;      // d.c: OUTPUT channels C
+    size_t total = (size_t)d.n * d.Ho * d.Wo * c8n;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        int c8 = (int)(i % c8n);
+        size_t pix = i / c8n;
+        int ox = (int)(pix % d.Wo);
+        size_t t = pix / d.Wo;
+        int oy = (int)(t % d.Ho), b = (int)(t / d.Ho);
+        const int q = ((oy & 1) << 1) | (ox & 1);
+        const T* ip = (const T*)d.in + ((size_t)(b * d.H + (oy >> 1)) * d.W + (ox >> 1)) * d.in_cs + d.in_coff + q * d.c + c8 * 8;
+        T* op = (T*)d.out + pix * d.out_cs + d.out_coff + c8 * 8;
+        if (sizeof(T) == 2) {
+            *reinterpret_cast<uint4*>(op) = *reinterpret_cast<const uint4*>(ip);
+        } else {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) op[k] = ip[k];
+        }
+    }
+}
+bool depth2space_supported(const TView& in, const TView& out) {
+    return in.c == 4 * out.c && (out.c & 7) == 0 && ((in.cs | in.coff | out.cs | out.coff) & 7) == 0 && out.h == 2 * in.h && out.w == 2 * in.w &&
+           !in.f32 && !out.f32;
+}
+hipError_t launch_depth2space(TView in, TView out, int n, int prec, hipStream_t st_) {
+    if (!depth2space_supported(in, out)) return hipErrorInvalidValue;
+    PoolDev d{in.p, out.p, in.cs, in.coff, out.cs, out.coff, out.c, in.h, in.w, out.h, out.w, 0, 0, 0, n};
+    size_t total = (size_t)n * out.h * out.w * (out.c >> 3);
+    int blocks = (int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
+    if (prec == PREC_FP32)
+        hipLaunchKernelGGL(depth2space_kernel<float>, dim3(blocks), dim3(256), 0, st_, d);
+    else
+        hipLaunchKernelGGL(depth2space_kernel<uint16_t>, dim3(blocks), dim3(256), 0, st_, d);
+    return hipGetLastError();
+}
+
 // ------------------------------------------------------------------------------------- Detect (v8)
 struct DetV8Dev {
     const float* box[3];
@@ -809,6 +848,59 @@ hipError_t launch_detect_v5_fused(const TView* hidden, const void* const* wfrag,
     d.lds_bias_off = (int)(region / 4);
     const size_t lds = region + (size_t)no * 4;
     ADAS_DISPATCH_E16(prec == PREC_FP16, E, hipLaunchKernelGGL(detect_v5_fused_kernel<E>, dim3(blocks, n), dim3(256), lds, st_, d));
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------- Detect (v6: anchor-free, v5 output layout)
+// YOLOv6 EffiDeHead.forward, inference branch without DFL (yolov6/models/effidehead.py, yolov6/assigners/anchor_generator.py,
+// yolov6/utils/general.py dist2bbox 'xywh'): per level raw (l, t, r, b) distances in grid units and class logits ->
+// row = [cx, cy, w, h] * stride with anchor point (x + 0.5, y + 0.5), objectness 1, sigmoid(class logits): (A, 5 + nc), A = sum of cells.
+struct DetV6Dev {
+    const float* reg[3];
+    const float* cls[3];
+    int reg_cs[3], cls_cs[3], hw[3], nx[3], stride[3], row_off[3];
+    float* out;
+    int nc, A, n;
+};
+__global__ void detect_v6_kernel(DetV6Dev d) {
+    const int no = d.nc + 5;
+    const int b = blockIdx.y;
+    const size_t per_frame = (size_t)d.A * no;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < per_frame; i += (size_t)gridDim.x * blockDim.x) {
+        const int row = (int)(i / no), c = (int)(i - (size_t)row * no);
+        const int l = (row >= d.row_off[2]) ? 2 : (row >= d.row_off[1] ? 1 : 0);
+        const int p = row - d.row_off[l];
+        const size_t pix = (size_t)b * d.hw[l] + p;
+        float o;
+        if (c < 4) {
+            const float* r = d.reg[l] + pix * d.reg_cs[l];
+            const float ax = (float)(p % d.nx[l]) + 0.5f, ay = (float)(p / d.nx[l]) + 0.5f;
+            const float x1 = ax - r[0], y1 = ay - r[1], x2 = ax + r[2], y2 = ay + r[3];
+            const float s = (float)d.stride[l];
+            o = (c == 0 ? (x1 + x2) / 2 : c == 1 ? (y1 + y2) / 2 : c == 2 ? x2 - x1 : y2 - y1) * s;
+        } else if (c == 4) {
+            o = 1.0f;
+        } else {
+            o = 1.0f / (1.0f + expf(-d.cls[l][pix * d.cls_cs[l] + (c - 5)]));
+        }
+        d.out[(size_t)b * per_frame + i] = o;
+    }
+}
+// ins[2l] = reg_preds.l (4 fp32 channels), ins[2l + 1] = cls_preds.l (nc fp32 channels)
+hipError_t launch_detect_v6(const TView* ins, float* out, int n, int nc, int A, const int strides[3], hipStream_t st_) {
+    DetV6Dev d;
+    int off = 0;
+    for (int l = 0; l < 3; ++l) {
+        const TView& r = ins[2 * l];
+        const TView& c = ins[2 * l + 1];
+        if (!r.f32 || !c.f32 || r.c != 4 || c.c != nc || r.coff || c.coff || r.h != c.h || r.w != c.w) return hipErrorInvalidValue;
+        d.reg[l] = (const float*)r.p; d.cls[l] = (const float*)c.p; d.reg_cs[l] = r.cs; d.cls_cs[l] = c.cs;
+        d.hw[l] = r.h * r.w; d.nx[l] = r.w; d.stride[l] = strides[l]; d.row_off[l] = off;
+        off += d.hw[l];
+    }
+    if (off != A) return hipErrorInvalidValue;
+    d.out = out; d.nc = nc; d.A = A; d.n = n;
+    hipLaunchKernelGGL(detect_v6_kernel, dim3(1024, n), dim3(256), 0, st_, d);
     return hipGetLastError();
 }
 

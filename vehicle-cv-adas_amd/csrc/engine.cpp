@@ -168,11 +168,15 @@ int adas_engine_create(const char* model_path, int precision, int max_batch, ada
         else if (o.type == OP_ATTENTION)
             ok = o.n_in == 1 && attention_supported((int)o.params[0], (int)o.params[1], (int)o.params[2], view(o.in_buf[0], o.in_coff[0], o.in_c[0]),
                                                     view(o.out_buf, o.out_coff, o.out_c));
+        else if (o.type == OP_DEPTH2SPACE)
+            ok = o.n_in == 1 && depth2space_supported(view(o.in_buf[0], o.in_coff[0], o.in_c[0]), view(o.out_buf, o.out_coff, o.out_c));
+        else if (o.type == OP_DETECT_V6)
+            ok = o.n_in == 6;
         if (!ok) {
             fclose(f);
             free_engine(e);
             set_error("[%s]: layer %s: unsupported %s shape", model_path, std::string(o.name, strnlen(o.name, sizeof(o.name))).c_str(),
-                      o.type == OP_DWCONV ? "depth-wise convolution" : "attention");
+                      o.type == OP_DWCONV ? "depth-wise convolution" : o.type == OP_ATTENTION ? "attention" : o.type == OP_DEPTH2SPACE ? "depth-to-space" : "Detect");
             return ADAS_ERR_FORMAT;
         }
     }
@@ -683,7 +687,7 @@ int adas_engine_layer_kernel(const adas_engine* e, int layer, int batch, char* n
     const EngOp& op = e->ops[layer];
     const FileOp& o = op.f;
     static const char* kOther[] = {"input_nchw_kernel", "", "maxpool_kernel", "upsample2_kernel", "detect_v8_kernel", "detect_v5_kernel",
-                                   "layernorm_kernel", "dwconv_kernel", "attention_kernel", "avgpool_kernel"};
+                                   "layernorm_kernel", "dwconv_kernel", "attention_kernel", "avgpool_kernel", "depth2space_kernel", "detect_v6_kernel"};
     if (o.type == OP_CONV && op.ds_user >= 0 && ds_folded(e, op.ds_user, batch)) {
         snprintf(name, cap, "(fused into the conv it is the shortcut of)");
     } else if (op.skip && o.type == OP_UPSAMPLE2) {
@@ -719,7 +723,7 @@ int adas_engine_layer_kernel(const adas_engine* e, int layer, int batch, char* n
     } else if (o.type == OP_DETECT_V5 && op.det_src[0] >= 0) {
         snprintf(name, cap, "detect_v5_fused_kernel");
     } else {
-        snprintf(name, cap, "%s", o.type < 10 ? kOther[o.type] : "?");
+        snprintf(name, cap, "%s", o.type < 12 ? kOther[o.type] : "?");
     }
     return ADAS_OK;
 }
@@ -821,6 +825,16 @@ int engine_run_op(adas_engine* e, int i, const float* d_in, int batch, hipStream
             err = launch_avgpool(make_view(e, o.in_buf[0], o.in_coff[0], o.in_c[0]), make_view(e, o.out_buf, o.out_coff, o.out_c), batch, o.kh, o.stride,
                                  o.pad, e->prec, st);
             break;
+        case OP_DEPTH2SPACE:
+            err = launch_depth2space(make_view(e, o.in_buf[0], o.in_coff[0], o.in_c[0]), make_view(e, o.out_buf, o.out_coff, o.out_c), batch, e->prec, st);
+            break;
+        case OP_DETECT_V6: {
+            TView ins[6];
+            for (int k = 0; k < 6; ++k) ins[k] = make_view(e, o.in_buf[k], o.in_coff[k], o.in_c[k]);
+            int strides[3] = {(int)o.params[2], (int)o.params[3], (int)o.params[4]};
+            err = launch_detect_v6(ins, (float*)e->bufs[o.out_buf].d, batch, (int)o.params[0], (int)o.params[1], strides, st);
+            break;
+        }
         case OP_UPSAMPLE2:
             err = launch_upsample2(make_view(e, o.in_buf[0], o.in_coff[0], o.in_c[0]), make_view(e, o.out_buf, o.out_coff, o.out_c), batch,
                                    e->prec, st);

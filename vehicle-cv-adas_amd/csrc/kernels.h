@@ -99,6 +99,9 @@ hipError_t launch_input_nchw(const float* nchw, TView out, int n, int c_true, in
 hipError_t launch_maxpool(TView in, TView out, int n, int k, int s, int p, int prec, hipStream_t st);
 hipError_t launch_avgpool(TView in, TView out, int n, int k, int s, int p, int prec, hipStream_t st);   // count_include_pad average (YOLOv9 AConv)
 hipError_t launch_upsample2(TView in, TView out, int n, int prec, hipStream_t st);
+bool depth2space_supported(const TView& in, const TView& out);
+hipError_t launch_depth2space(TView in, TView out, int n, int prec, hipStream_t st);   // block 2: ConvTranspose2d(k 2, s 2) behind a 1x1 conv (YOLOv6)
+hipError_t launch_detect_v6(const TView* ins, float* out, int n, int nc, int A, const int strides[3], hipStream_t st);
 // three chained 5x5 s1 p2 max-pools (SPPF) in one launch: out[0] = pool(in), out[1] = pool(out[0]), out[2] = pool(out[1])
 bool sppf_pool3_applicable(int prec, const TView& in, const TView out[3]);
 hipError_t launch_sppf_pool3(const TView& in, const TView out[3], int n, int prec, hipStream_t st);

@@ -22,7 +22,8 @@ from collections import OrderedDict
 import numpy as np
 
 MAGIC = b"ADASHIP1"
-OP_INPUT, OP_CONV, OP_MAXPOOL, OP_UPSAMPLE2, OP_DETECT_V8, OP_DETECT_V5, OP_LAYERNORM, OP_DWCONV, OP_ATTENTION, OP_AVGPOOL = range(10)
+(OP_INPUT, OP_CONV, OP_MAXPOOL, OP_UPSAMPLE2, OP_DETECT_V8, OP_DETECT_V5, OP_LAYERNORM, OP_DWCONV, OP_ATTENTION, OP_AVGPOOL, OP_DEPTH2SPACE,
+ OP_DETECT_V6) = range(12)
 ACT_NONE, ACT_SILU, ACT_RELU, ACT_LEAKY = 0, 1, 2, 3      # ACT_LEAKY: LeakyReLU(0.1) (YOLOv7)
 RES_NONE, RES_AFTER_ACT, RES_BEFORE_ACT = 0, 1, 2
 BUF_F32 = 1
@@ -54,7 +55,8 @@ SILU_GAIN = 1.10                # YOLOv8 n/s: AT the critical gain (n ~1.11, s ~
 V5_SILU_GAIN = 1.15             # YOLOv5 (C3 blocks; kept at the round-1 value: its deeper scales are chaotic there, bf16 head rel-L2 6e-2,
                                 # and no better at 1.0)
 RELU_RES_GAIN = 0.8             # ResNet lane nets: ReLU + residual adds double the variance; flat drift at 0.8 (9e-4 rel-L2 fp16)
-SYNTH_GAINS = {"yolov9c": 1.06,
+SYNTH_GAINS = {"yolov6n": 0.95, "yolov6s": 0.95,                      # plain ReLU 3x3 stacks (no residuals): He gain 1 holds the variance; 0.95 decays gently
+               "yolov9c": 1.06,
                "yolov9s": 1.06,                                       # 1.12 (yolov9t's) has a runaway mode on small inputs (96x128: rms 1e5 at P5)
                "yolov7-tiny": 1.0,                                    # LeakyReLU: piecewise linear, no chaos (fp16 rel-L2 1.3e-3 at any gain); 1.0 keeps rms ~0.4
                "yolov9t": 1.12,                                       # critical between 1.16 and 1.22 (activations explode there)
@@ -172,8 +174,9 @@ class Graph:
         return View(v.buf, 0, 8, v.h, v.w), self.in_c
 
     def conv(self, x, cout, k, s, name, act=ACT_SILU, out=None, res=None, res_mode=RES_NONE, true_cin=None, bias=True,
-             wname=None, bname=None, pad=None, f32_out=False, bias_fill=None, wkind="conv"):
-        """x: View (its .c may be zero-padded beyond true_cin).  Weight 'name.weight' is OIHW with I=true_cin."""
+             wname=None, bname=None, pad=None, f32_out=False, bias_fill=None, wkind="conv", weight=None, bias_arr=None):
+        """x: View (its .c may be zero-padded beyond true_cin).  Weight 'name.weight' is OIHW with I=true_cin.
+        weight / bias_arr: explicit arrays (a re-arranged parameter the caller owns and counts, e.g. deconv2x2)."""
         cin_true = true_cin if true_cin is not None else x.c
         p = (k // 2) if pad is None else pad
         ho = (x.h + 2 * p - k) // s + 1
@@ -182,9 +185,12 @@ class Graph:
             out = self.buf(ho, wo, cout, f32=f32_out)
         assert (out.h, out.w, out.c) == (ho, wo, cout), (name, (out.h, out.w, out.c), (ho, wo, cout))
         wshape = (cout, cin_true, k, k) if wkind == "conv" else (cout, cin_true)
-        W = self.w(wname or name + ".weight", wshape, wkind)
+        W = self.w(wname or name + ".weight", wshape, wkind) if weight is None else np.asarray(weight, np.float32).reshape(wshape)
         W4 = W.reshape(cout, cin_true, k, k)
-        B = self.w(bname or name + ".bias", (cout,), "bias", fill=bias_fill) if bias else np.zeros(cout, np.float32)
+        if bias_arr is not None:
+            B = np.asarray(bias_arr, np.float32).reshape(cout)
+        else:
+            B = self.w(bname or name + ".bias", (cout,), "bias", fill=bias_fill) if bias else np.zeros(cout, np.float32)
         if k == 1 and cin_true == x.c:
             ohwi = W4.reshape(cout, cin_true)                     # 1x1 / linear: OIHW == OHWI
         else:
@@ -196,7 +202,23 @@ class Graph:
         self._op(OP_CONV, [x], out, kh=k, kw=k, stride=s, pad=p, act=act, res_mode=res_mode, res=res, w=woff, b=boff,
                  flops=fl, name=name)
         self.n_convs += 1
-        self.n_params += W.size + (B.size if bias else 0)
+        if weight is None:
+            self.n_params += W.size + (B.size if bias else 0)
+        return out
+
+    def deconv2x2(self, x, cout, name, out=None):
+        """nn.ConvTranspose2d(cin, cout, kernel_size=2, stride=2, bias=True) (YOLOv6 Transpose): weight 'name.weight' in torch's (cin, cout, 2, 2)
+        layout.  out[2y + dy, 2x + dx] = W[:, :, dy, dx]^T x[y, x] + b: a 1x1 conv to 4 * cout channels (rows ordered (dy, dx, cout): MFMA work,
+        conv_pw) followed by a depth-to-space move."""
+        cin = x.c
+        Wt = self.w(name + ".weight", (cin, cout, 2, 2), "conv")
+        B = self.w(name + ".bias", (cout,), "bias")
+        t = self.conv(x, 4 * cout, 1, 1, name, act=ACT_NONE, weight=Wt.transpose(2, 3, 1, 0).reshape(4 * cout, cin, 1, 1), bias_arr=np.tile(B, 4))
+        self.n_params += Wt.size + B.size
+        if out is None:
+            out = self.buf(2 * x.h, 2 * x.w, cout)
+        assert (out.h, out.w, out.c) == (2 * x.h, 2 * x.w, cout)
+        self._op(OP_DEPTH2SPACE, [t], out, name=name + ".d2s")
         return out
 
     def dwconv(self, x, k, s, name, act=ACT_SILU, out=None, res=None, weight=None, bias=None):
@@ -661,6 +683,106 @@ def yolov9c(nc=80, imgsz=640, wsrc=None, seed=0):
 
 
 # =====================================================================================
+# YOLOv6 v3.0 n / s (meituan/YOLOv6 configs/yolov6n.py, yolov6s.py; README.md:54 lists YOLOv6; yoloDetector.py:110-124 decodes its
+# (1, A, 5+nc) head like v5's: probs = det[5:] * det[4], and EffiDeHead writes objectness 1).  Deploy form: every RepVGGBlock is one 3x3
+# conv + ReLU.  EfficientRep backbone (stem, four ERBlocks = stride-2 RepVGGBlock + RepBlock, SimCSPSPPF), RepBiFPANNeck (BiFusion:
+# ConvTranspose2d 2x2 up-sampling of the deeper map + 1x1 of the same-scale map + stride-2 3x3 of the shallower one, concatenated),
+# EffiDeHead without DFL (1x1 stem, 3x3 cls / reg convs with SiLU, 1x1 predictors; anchor-free distances).  Weight names follow upstream's
+# module paths; the deploy convs carry `.rbr_reparam` / `.block.conv`.
+# Sizes: n 4.65 M parameters / 11.3 GFLOPs, s 18.54 M / 45.0 G (upstream tables: 4.7 M / 11.4 G, 18.5 M / 45.3 G).
+# =====================================================================================
+V6_SCALES = {"n": (0.33, 0.25), "s": (0.33, 0.50)}
+
+
+def yolov6(scale="n", nc=80, imgsz=640, wsrc=None, seed=0):
+    depth, width = V6_SCALES[scale]
+    name = "yolov6" + scale
+    wsrc = wsrc or SynthWeights(seed, gain=synth_gain(name))
+    H, W = _hw(imgsz)
+    g = Graph(name, 3, H, W, wsrc)
+    x, cin = g.input()
+    rep_n = lambda n: max(round(n * depth), 1) if n > 1 else n
+    ch = [int(c * width) for c in (64, 128, 256, 512, 1024, 256, 128, 128, 256, 256, 512)]
+    nb = [rep_n(n) for n in (1, 6, 12, 18, 6)]
+    nn_ = rep_n(12)
+
+    def rep(src, c, s, nm, out=None, true_cin=None):        # RepVGGBlock, deploy form
+        return g.conv(src, c, 3, s, nm + ".rbr_reparam", act=ACT_RELU, out=out, true_cin=true_cin)
+
+    def cbr(src, c, k, s, nm, out=None):                     # ConvBNReLU
+        return g.conv(src, c, k, s, nm + ".block.conv", act=ACT_RELU, out=out)
+
+    def repblock(src, c, n, nm, out=None):                   # RepBlock: conv1 + (n - 1) blocks
+        y = rep(src, c, 1, nm + ".conv1", out=out if n == 1 else None)
+        for i in range(n - 1):
+            y = rep(y, c, 1, f"{nm}.block.{i}", out=out if i == n - 2 else None)
+        return y
+
+    # ---- EfficientRep
+    x = rep(x, ch[0], 2, "backbone.stem", true_cin=cin)
+    feats = []
+    for i in range(1, 5):
+        x = rep(x, ch[i], 2, f"backbone.ERBlock_{i + 1}.0")
+        x = repblock(x, ch[i], nb[i], f"backbone.ERBlock_{i + 1}.1")
+        feats.append(x)
+    x3, x2, x1, x = feats                                     # P2 (stride 4), P3, P4, P5 before the SPP
+    c_ = ch[4] // 2                                           # SimCSPSPPF(c5, c5, 5, e=0.5)
+    sp = "backbone.ERBlock_5.2"
+    cat2 = g.buf(x.h, x.w, 2 * c_)                            # cv7 input: cat(y0 = cv2(x), y3)
+    cat4 = g.buf(x.h, x.w, 4 * c_)                            # cv5 input: cat(x1, m(x1), m(m(x1)), m(m(m(x1))))
+    t = cbr(x, c_, 1, 1, sp + ".cv1")
+    t = cbr(t, c_, 3, 1, sp + ".cv3")
+    cbr(t, c_, 1, 1, sp + ".cv4", out=cat4.slice(0, c_))
+    cbr(x, c_, 1, 1, sp + ".cv2", out=cat2.slice(0, c_))
+    for i in range(3):
+        g.maxpool(cat4.slice(i * c_, c_), 5, 1, 2, out=cat4.slice((i + 1) * c_, c_), name=f"{sp}.m{i}")
+    t = cbr(cat4, c_, 1, 1, sp + ".cv5")
+    cbr(t, c_, 3, 1, sp + ".cv6", out=cat2.slice(c_, c_))
+    x0 = cbr(cat2, ch[4], 1, 1, sp + ".cv7")
+
+    # ---- RepBiFPANNeck
+    def bifusion(deep, same, shallow, c, nm):
+        """BiFusion.forward: cv3(cat(upsample(x[0]), cv1(x[1]), downsample(cv2(x[2]))))."""
+        cat = g.buf(same.h, same.w, 3 * c)
+        g.deconv2x2(deep, c, nm + ".upsample.upsample_transpose", out=cat.slice(0, c))
+        cbr(same, c, 1, 1, nm + ".cv1", out=cat.slice(c, c))
+        t_ = cbr(shallow, c, 1, 1, nm + ".cv2")
+        cbr(t_, c, 3, 2, nm + ".downsample", out=cat.slice(2 * c, c))
+        return cbr(cat, c, 1, 1, nm + ".cv3")
+
+    catn3 = g.buf(H // 16, W // 16, ch[7] + ch[6])            # cat(downsample2(pan_out2), fpn_out1)
+    catn4 = g.buf(H // 32, W // 32, ch[9] + ch[5])            # cat(downsample1(pan_out1), fpn_out0)
+    fpn0 = cbr(x0, ch[5], 1, 1, "neck.reduce_layer0", out=catn4.slice(ch[9], ch[5]))
+    f0 = repblock(bifusion(fpn0, x1, x2, ch[5], "neck.Bifusion0"), ch[5], nn_, "neck.Rep_p4")
+    fpn1 = cbr(f0, ch[6], 1, 1, "neck.reduce_layer1", out=catn3.slice(ch[7], ch[6]))
+    pan2 = repblock(bifusion(fpn1, x2, x3, ch[6], "neck.Bifusion1"), ch[6], nn_, "neck.Rep_p3")
+    cbr(pan2, ch[7], 3, 2, "neck.downsample2", out=catn3.slice(0, ch[7]))
+    pan1 = repblock(catn3, ch[8], nn_, "neck.Rep_n3")
+    cbr(pan1, ch[9], 3, 2, "neck.downsample1", out=catn4.slice(0, ch[9]))
+    pan0 = repblock(catn4, ch[10], nn_, "neck.Rep_n4")
+
+    # ---- EffiDeHead (inference, use_dfl = False)
+    ins, strides = [], []
+    levels = [pan2, pan1, pan0]
+    for i, f in enumerate(levels):
+        s_ = H // f.h
+        strides.append(s_)
+        st = g.conv(f, f.c, 1, 1, f"detect.stems.{i}.conv")                     # (layers in upstream's execution order: onnx_import
+        cf = g.conv(st, f.c, 3, 1, f"detect.cls_convs.{i}.conv")               #  maps YOLOv6 weights by position)
+        cl = g.conv(cf, nc, 1, 1, f"detect.cls_preds.{i}", act=ACT_NONE, f32_out=True, bias_fill=-math.log((1 - 0.01) / 0.01))
+        rf = g.conv(st, f.c, 3, 1, f"detect.reg_convs.{i}.conv")
+        rg = g.conv(rf, 4, 1, 1, f"detect.reg_preds.{i}", act=ACT_NONE, f32_out=True, bias_fill=1.0)
+        ins += [rg, cl]
+    A = sum(f.h * f.w for f in levels)
+    no = nc + 5
+    head = g.buf(1, 1, A * no, f32=True)
+    g._op(OP_DETECT_V6, ins, head, params=[nc, A] + strides, name="detect.decode")
+    g.output(head, 0, [1, A, no], "outputs")
+    g.meta = dict(kind="yolov6", nc=nc, anchors=A, strides=strides)
+    return g
+
+
+# =====================================================================================
 # YOLOv7-tiny (WongKinYiu/yolov7 cfg/deploy/yolov7-tiny.yaml; README.md:55 lists YOLOv7; yoloDetector.py:110-124 decodes its head as the
 # v5 layout (1, A, 5+nc)).  78 rows, every Conv with LeakyReLU(0.1): ELAN-tiny blocks (two 1x1 branches, two chained 3x3, concat of the
 # four, 1x1), MP = 2x2 stride-2 max-pool, an SPPCSPC-tiny (5 / 9 / 13 max-pools), PAN neck, IDetect (its ImplicitA / ImplicitM fold
@@ -960,6 +1082,8 @@ BUILDERS = {
     "yolov9s": lambda **k: yolov9t(scale="s", **k),
     "yolov9c": lambda **k: yolov9c(**k),
     "yolov7-tiny": lambda **k: yolov7_tiny(**k),
+    "yolov6n": lambda **k: yolov6("n", **k),
+    "yolov6s": lambda **k: yolov6("s", **k),
     "yolov5n": lambda **k: yolov5("n", **k), "yolov5s": lambda **k: yolov5("s", **k),
     "yolov5m": lambda **k: yolov5("m", **k), "yolov5l": lambda **k: yolov5("l", **k), "yolov5x": lambda **k: yolov5("x", **k),
     "ufldv2_res18": lambda **k: ufldv2("18", **k), "ufldv2_res34": lambda **k: ufldv2("34", **k),

@@ -234,12 +234,12 @@ def read_onnx(path):
 
 # ------------------------------------------------------------------------------------- architecture detection
 def _convs_in_order(m):
-    """[(weight fp32 OIHW, bias fp32 | None)] per Conv node in graph (= PyTorch execution) order, BatchNormalization
-    nodes that consume a Conv output folded in."""
+    """[(weight fp32 OIHW, bias fp32 | None)] per Conv / ConvTranspose node (the latter's weight in its own (Cin, Cout, kH, kW) layout) in
+    graph (= PyTorch execution) order, BatchNormalization nodes that consume a Conv output folded in."""
     by_out = {}
     convs = []
     for nd in m.nodes:
-        if nd["op"] == "Conv" and len(nd["inputs"]) >= 2 and nd["inputs"][1] in m.initializers:
+        if nd["op"] in ("Conv", "ConvTranspose") and len(nd["inputs"]) >= 2 and nd["inputs"][1] in m.initializers:
             w = np.asarray(m.initializers[nd["inputs"][1]], np.float32)
             b = np.asarray(m.initializers[nd["inputs"][2]], np.float32) if len(nd["inputs"]) > 2 and nd["inputs"][2] in m.initializers else None
             rec = [w, b, nd]
@@ -314,6 +314,15 @@ def detect_arch(m):
                     raise ValueError("YOLOv9 with a %d-channel stem is not built (yolov9t, yolov9s and yolov9c are): %s" % (c0[0], found))
                 return "yolov9" + v9, dict(nc=o[1] - 4, imgsz=(H, W))
             return "yolov8" + scale, dict(nc=o[1] - 4, imgsz=(H, W))
+        if c0[2] == 3 and o[1] > o[2] and any(nd["op"] == "ConvTranspose" for nd in m.nodes):
+            # (1, A, 5+nc) with A = one row per cell, transposed-conv up-sampling in the neck: YOLOv6 v3.0 (RepBiFPANNeck); deploy export
+            # (RepVGG blocks fused).  Told apart by width: 16-channel stem = n, 32 = s; the conv count pins the depth (0.33).
+            if H % 32 or W % 32:
+                raise ValueError("YOLO input size must be multiples of 32: " + found)
+            scale = {16: "n", 32: "s"}.get(c0[0])
+            if scale is None or len(convs) != 71 or o[1] != (H // 8) * (W // 8) + (H // 16) * (W // 16) + (H // 32) * (W // 32):
+                raise ValueError("YOLOv6 variant not built (v3.0 yolov6n / yolov6s deploy exports, 69 Conv + 2 ConvTranspose nodes, are): " + found)
+            return "yolov6" + scale, dict(nc=o[2] - 5, imgsz=(H, W))
         if c0[2] == 3 and o[1] > o[2]:                      # (1, A, 5+nc) behind a 3x3 stem: YOLOv7 (v5-layout head, yoloDetector.py:110-124)
             if H % 32 or W % 32:
                 raise ValueError("YOLO input size must be multiples of 32: " + found)
@@ -410,11 +419,25 @@ class OnnxWeights:
             return None
         return np.ascontiguousarray(lin[order])
 
+    def _v6_by_order(self, name):
+        """YOLOv6: upstream module paths differ between releases and exporters drop them; the k-th parameterised layer the builder asks for
+        (models.yolov6 requests them in upstream forward order) is the k-th Conv / ConvTranspose node of the export."""
+        base = name.rsplit(".", 1)[0]
+        if not hasattr(self, "_v6_idx"):
+            self._v6_idx = {}
+        idx = self._v6_idx.setdefault(base, len(self._v6_idx))
+        if idx >= len(self.convs):
+            return None
+        w, b = self.convs[idx]
+        return w if name.endswith(".weight") else (b if b is not None else np.zeros(w.shape[1] if w.ndim == 4 and ".upsample_transpose" in base else w.shape[0], np.float32))
+
     def __call__(self, name, shape, kind, fill=None):
         if name in self.store:
             return self.store[name]
         arr = None
-        if kind in ("conv", "bias") and (name.endswith(".weight") or name.endswith(".bias")):
+        if self.arch.startswith("yolov6") and name not in self.init:
+            arr = self._v6_by_order(name)
+        if arr is None and kind in ("conv", "bias") and (name.endswith(".weight") or name.endswith(".bias")):
             base = name.rsplit(".", 1)[0]
             pair = self._named_conv(base) if kind in ("conv", "bias") and base + ".weight" in self.init else None
             if pair is None and self.arch.startswith("ufld"):
