@@ -862,20 +862,22 @@ struct DetV6Dev {
     float* out;
     int nc, A, n;
 };
-__global__ void detect_v6_kernel(DetV6Dev d) {
+__global__ __launch_bounds__(256) void detect_v6_kernel(DetV6Dev d) {   // workgroup = 32 consecutive rows of one frame (contiguous in and out)
     const int no = d.nc + 5;
-    const int b = blockIdx.y;
-    const size_t per_frame = (size_t)d.A * no;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < per_frame; i += (size_t)gridDim.x * blockDim.x) {
-        const int row = (int)(i / no), c = (int)(i - (size_t)row * no);
+    const int b = blockIdx.y, row0 = blockIdx.x * 32;
+    const int nel = min(32, d.A - row0) * no;
+    float* out = d.out + ((size_t)b * d.A + row0) * no;
+    for (int e = threadIdx.x; e < nel; e += 256) {
+        const int r = e / no, c = e - r * no;               // 32-bit, e < 32 * no (a 64-bit division per element tripled the launch time)
+        const int row = row0 + r;
         const int l = (row >= d.row_off[2]) ? 2 : (row >= d.row_off[1] ? 1 : 0);
         const int p = row - d.row_off[l];
         const size_t pix = (size_t)b * d.hw[l] + p;
         float o;
         if (c < 4) {
-            const float* r = d.reg[l] + pix * d.reg_cs[l];
+            const float4 rg = *reinterpret_cast<const float4*>(d.reg[l] + pix * d.reg_cs[l]);
             const float ax = (float)(p % d.nx[l]) + 0.5f, ay = (float)(p / d.nx[l]) + 0.5f;
-            const float x1 = ax - r[0], y1 = ay - r[1], x2 = ax + r[2], y2 = ay + r[3];
+            const float x1 = ax - rg.x, y1 = ay - rg.y, x2 = ax + rg.z, y2 = ay + rg.w;
             const float s = (float)d.stride[l];
             o = (c == 0 ? (x1 + x2) / 2 : c == 1 ? (y1 + y2) / 2 : c == 2 ? x2 - x1 : y2 - y1) * s;
         } else if (c == 4) {
@@ -883,7 +885,7 @@ __global__ void detect_v6_kernel(DetV6Dev d) {
         } else {
             o = 1.0f / (1.0f + expf(-d.cls[l][pix * d.cls_cs[l] + (c - 5)]));
         }
-        d.out[(size_t)b * per_frame + i] = o;
+        out[e] = o;
     }
 }
 // ins[2l] = reg_preds.l (4 fp32 channels), ins[2l + 1] = cls_preds.l (nc fp32 channels)
@@ -900,7 +902,8 @@ hipError_t launch_detect_v6(const TView* ins, float* out, int n, int nc, int A, 
     }
     if (off != A) return hipErrorInvalidValue;
     d.out = out; d.nc = nc; d.A = A; d.n = n;
-    hipLaunchKernelGGL(detect_v6_kernel, dim3(1024, n), dim3(256), 0, st_, d);
+    if (((ins[0].cs | ins[2].cs | ins[4].cs) & 3) != 0) return hipErrorInvalidValue;   // float4 loads of the (l, t, r, b) distances
+    hipLaunchKernelGGL(detect_v6_kernel, dim3((A + 31) / 32, n), dim3(256), 0, st_, d);
     return hipGetLastError();
 }
 

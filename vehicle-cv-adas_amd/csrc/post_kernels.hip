@@ -86,7 +86,8 @@ __global__ __launch_bounds__(256) void yolo_scan_v8(const float* __restrict__ he
     }
 }
 
-// scan, v5-family layout [A][5+nc]: one wave per row, conf = cls * obj rounded in fp32.
+// scan, v5-family layout [A][5+nc]: 16 lanes per row, four rows per wave pass (a wave per row left 12 dependent load -> 6-step reduce
+// round trips per wave: 1.5 TB/s on the 8.57 MB head); conf = cls * obj rounded in fp32, first maximum wins (np.argmax).
 __global__ __launch_bounds__(256) void yolo_scan_v5(const float* __restrict__ head, int A, int nc,
                                                     float* __restrict__ best_conf, int* __restrict__ best_cls) {
     const int frame = blockIdx.y;
@@ -94,30 +95,32 @@ __global__ __launch_bounds__(256) void yolo_scan_v5(const float* __restrict__ he
     head += (size_t)frame * (size_t)A * no;
     best_conf += (size_t)frame * A;
     best_cls += (size_t)frame * A;
-    const int lane = threadIdx.x & 63;
+    const int lane = threadIdx.x & 63, sub = lane & 15, q = lane >> 4;
     const int wave = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int nwaves = gridDim.x * 4;
-    for (int a = wave; a < A; a += nwaves) {
-        const float* row = head + (size_t)a * no;
+    for (int a0 = wave * 4; a0 < A; a0 += nwaves * 4) {
+        const int a = a0 + q;
+        const bool ok = a < A;
+        const float* row = head + (size_t)(ok ? a : 0) * no;
         const float obj = row[4];
         float bv = 0.f;
         int bi = 0x7fffffff;
-        for (int c = lane; c < nc; c += 64) {
+        for (int c = sub; c < nc; c += 16) {
             float p = row[5 + c] * obj;
             if (bi == 0x7fffffff || p > bv) {
                 bv = p;
                 bi = c;
             }
         }
-        for (int off = 32; off > 0; off >>= 1) {
-            float ov = __shfl_down(bv, off, 64);
-            int oi = __shfl_down(bi, off, 64);
+        for (int off = 8; off > 0; off >>= 1) {
+            float ov = __shfl_down(bv, off, 16);
+            int oi = __shfl_down(bi, off, 16);
             if (oi != 0x7fffffff && (bi == 0x7fffffff || ov > bv || (ov == bv && oi < bi))) {
                 bv = ov;
                 bi = oi;
             }
         }
-        if (lane == 0) {
+        if (sub == 0 && ok) {
             best_conf[a] = bv;
             best_cls[a] = bi == 0x7fffffff ? 0 : bi;
         }
