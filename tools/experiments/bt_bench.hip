@@ -1,8 +1,8 @@
 // bt_bench.hip -- standalone latency harness for the device ByteTrack update (track_core.h).
 // Scratch tool: synthetic random-walk boxes, S streams, F frames; prints average kernel time of the last frames and a
 // checksum of every frame's output messages so two builds of track_core.h can be compared for identical results.
-//   hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -I vehicle-cv-adas_amd/csrc tools/scratch/bt_bench.hip -o tools/scratch/bt_bench
-//   tools/scratch/bt_bench [streams=16] [objects=60] [frames=120] [MT=256] [MD=256]
+//   hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -I vehicle-cv-adas_amd/csrc tools/experiments/bt_bench.hip -o tools/experiments/bt_bench
+//   tools/experiments/bt_bench [streams=16] [objects=60] [frames=120] [MT=256] [MD=256]
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <stdlib.h>

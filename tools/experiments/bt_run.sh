@@ -1,5 +1,5 @@
 cd $GRAFT_REPO_ROOT
-B=tools/scratch/_bin
+B=tools/experiments/_bin
 for cfg in "16 60 120 256 512" "64 20 120 256 512" "16 150 100 256 512" "4 400 60 512 512" "2 600 40 1024 1024"; do
   for v in bt_old bt_new bt_new2; do timeout 120 $B/$v $cfg; done
 done

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """scratch: per-phase cycle breakdown of conv_halo_kernel (needs a build with ADAS_CFLAGS=-DADAS_H8_PROF).
-   python tools/scratch/halo_prof.py --hw 80 400 --cin 64 --cout 64 --batch 64"""
+   python tools/experiments/halo_prof.py --hw 80 400 --cin 64 --cout 64 --batch 64"""
 import argparse, ctypes as C, importlib, os, sys, tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))

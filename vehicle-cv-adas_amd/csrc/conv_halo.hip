@@ -76,7 +76,7 @@ constexpr int HALO_WPIX = HALO_CK;      // weight rows are unpadded (64 B) and X
                                         // stored at position kg ^ g[(r>>2)&3], g = {0,2,3,1} -> all 4 lane groups
                                         // of ds_read_b128 hit 16 distinct 16-byte slots
 
-#ifdef ADAS_HALO_PROF  // scratch instrumentation (tools/scratch/halo_prof.py): per-phase shader cycles of wave 0, accumulated in
+#ifdef ADAS_HALO_PROF  // scratch instrumentation (tools/experiments/halo_prof.py): per-phase shader cycles of wave 0, accumulated in
 // registers and flushed once per workgroup into one of 256 counter banks (so the atomics do not serialise the chip)
 __device__ unsigned long long g_halo_prof[256][16];
 #define HPROF(i)                                    \
@@ -492,7 +492,7 @@ static bool halo_s2_enabled() {
 }
 
 // cout blocks of a tile that run back to back on one XCD: the largest divisor of ncb whose weight slabs together stay
-// within half of the XCD's 4 MiB L2 (every tile re-reads them).  Measured at 64 frames (tools/scratch/cbg_sweep.sh):
+// within half of the XCD's 4 MiB L2 (every tile re-reads them).  Measured at 64 frames (tools/experiments/cbg_sweep.sh):
 // 256->256 20x100 188 -> 168 us, its stride-2 sibling 330 -> 300 us, 128->128 194 -> 190 us, 512->512 neutral at 2 or 8
 // and 11 % slower with a non-divisor (the padded last group skews the dispatch order).  ADAS_HALO_CBG overrides.
 static int halo_cb_group(int ncb, size_t slab_bytes) {

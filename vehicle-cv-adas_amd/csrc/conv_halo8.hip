@@ -100,7 +100,7 @@ __host__ __device__ constexpr int h8_allow(int mode, int k) {
                      : h8_issued(k) + h8_issued((k + 8) % 9) + h8_issued((k + 7) % 9);
 }
 
-#ifdef ADAS_H8_PROF   // scratch instrumentation (tools/scratch/h8_prof.py): shader cycles of waves 0 and 4 per item phase
+#ifdef ADAS_H8_PROF   // scratch instrumentation (tools/experiments/h8_prof.py): shader cycles of waves 0 and 4 per item phase
 __device__ unsigned long long g_h8_prof[256][32];
 #define H8P(i)                                      \
     if (lane == 0 && grp == 0) {                    \

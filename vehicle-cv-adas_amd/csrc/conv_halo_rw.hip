@@ -1,7 +1,7 @@
 // conv_halo_rw.hip -- stride-1 3x3 convolution for SHORT K (Cin <= 64): persistent workgroups with the weights
 // resident in LDS.
 //
-// Phase profile of conv_halo at Cin = 64 (tools/scratch/halo_prof.py, 80x400x64->64, 64 frames): only ~1/4 of a
+// Phase profile of conv_halo at Cin = 64 (tools/experiments/halo_prof.py, 80x400x64->64, 64 frames): only ~1/4 of a
 // workgroup's cycles are the tap loop; the rest is per-tile fixed cost -- 64 % of the bytes it stages are the 73 KB
 // of weights, identical for every one of the 8000 tiles.  Here a workgroup
 //   * loads the 9 x 64 x Cin weight slab of its output-channel tile ONCE and keeps it in LDS (<= 73.7 KB),

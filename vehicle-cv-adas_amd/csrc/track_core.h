@@ -578,7 +578,7 @@ struct BtLds {
 
 enum { N_ERR = 0 };
 
-// phase timers for tools/scratch/bt_bench.hip (scratch builds only)
+// phase timers for tools/experiments/bt_bench.hip (scratch builds only)
 #if defined(ADAS_BT_PROF) && defined(__HIP_DEVICE_COMPILE__)
 #define BT_MARK_INIT unsigned long long bt_t0_ = wall_clock64()
 #define BT_MARK(i)                                      \
