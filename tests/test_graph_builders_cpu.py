@@ -33,6 +33,20 @@ def test_yolo_graph_equals_oracle(name, fwd, scale):
     np.testing.assert_allclose(got[:, :4], want[:, :4], rtol=0, atol=2e-4)      # boxes in pixels
 
 
+@pytest.mark.parametrize("scale", ["n", "s"])
+def test_yolov5_graph_equals_oracle(scale):
+    """YOLOv5 v6.2 (C3 with cv1 | cv2 as one stacked 1x1 conv, SPPF, anchor-based Detect) against the oracle's module-by-module forward."""
+    ws = M.SynthWeights(0, gain=1.0)          # below the chaotic regime of the v5 test gain (1.15 amplifies fp32 summation-order noise 1e3 x)
+    g = M.build("yolov5" + scale, wsrc=ws, imgsz=(96, 128))
+    W = dict(ws.store)
+    x = netutil.coco_like_frames(2, 96, 128, seed=3)
+    got = graph_interp.run(g, x)[0]
+    want = nets.yolov5_forward(x, W, scale)
+    assert got.shape == want.shape == (2, 3 * (12 * 16 + 6 * 8 + 3 * 4), 85)
+    np.testing.assert_allclose(got[..., 4:], want[..., 4:], rtol=0, atol=5e-6)
+    np.testing.assert_allclose(got[..., :4], want[..., :4], rtol=2e-5, atol=5e-4)
+
+
 def test_yolov7_tiny_graph_equals_oracle():
     """The explicit builder (models.yolov7_tiny) against the oracle's row-table interpretation of yolov7-tiny.yaml, v5-layout decode included."""
     g, W = _build("yolov7-tiny", imgsz=(96, 128))
