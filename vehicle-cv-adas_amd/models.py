@@ -206,15 +206,18 @@ class Graph:
             self.n_params += W.size + (B.size if bias else 0)
         return out
 
-    def conv_siblings(self, x, specs, k, s, out, act=ACT_SILU):
+    def conv_siblings(self, x, specs, k, s, out, act=ACT_SILU, draw=None):
         """Convs that read the SAME tensor with the same kernel / stride / activation and write ADJACENT channel slices of one buffer
         (C3 / RepCSP cv1 | cv2, ELAN's two 1x1 branches) as ONE conv with the weight matrices stacked: the input is read once and a launch
         goes away; every output channel keeps its own arithmetic (same K order), so the values are those of the separate convs.
         specs: [(cout, name)] in the channel order of `out` (a view of sum(cout) channels).  Weights keep their own names."""
         couts = [c for c, _ in specs]
         assert out.c == sum(couts)
-        Ws = [self.w(n + ".weight", (c, x.c, k, k), "conv") for c, n in specs]
-        Bs = [self.w(n + ".bias", (c,), "bias") for c, n in specs]
+        Ws, Bs = [None] * len(specs), [None] * len(specs)
+        for i in (draw if draw is not None else range(len(specs))):      # parameter request order = the module order of the separate convs
+            c, n = specs[i]                                               # (a seeded SynthWeights source draws in request order)
+            Ws[i] = self.w(n + ".weight", (c, x.c, k, k), "conv")
+            Bs[i] = self.w(n + ".bias", (c,), "bias")
         name = specs[0][1] + "".join("+" + n.rsplit(".", 2)[-2] + "." + n.rsplit(".", 1)[-1] if n.count(".") >= 2 else "+" + n for _, n in specs[1:])
         assert len(name) < 48, name
         self.conv(x, out.c, k, s, name, act=act, out=out, weight=np.concatenate(Ws, 0), bias_arr=np.concatenate(Bs, 0))
@@ -563,7 +566,7 @@ def _repcsp(g, x, c2, n, name, out=None):
     c_ = c2 // 2
     T = g.buf(x.h, x.w, 3 * c_)                      # [m(cv1 x) | cv2 x | cv1 x], as in _c3
     cat = T.slice(0, 2 * c_)
-    _, y = g.conv_siblings(x, [(c_, f"{name}.cv2.conv"), (c_, f"{name}.cv1.conv")], 1, 1, out=T.slice(c_, 2 * c_))
+    _, y = g.conv_siblings(x, [(c_, f"{name}.cv2.conv"), (c_, f"{name}.cv1.conv")], 1, 1, out=T.slice(c_, 2 * c_), draw=(1, 0))
     for i in range(n):
         t = g.conv(y, c_, 3, 1, f"{name}.m.{i}.cv1.conv")                       # RepConv in deploy form: one fused 3x3 + SiLU
         y = g.conv(t, c_, 3, 1, f"{name}.m.{i}.cv2.conv", out=cat.slice(0, c_) if i == n - 1 else None, res=y, res_mode=RES_AFTER_ACT)
@@ -826,7 +829,7 @@ def yolov7_tiny(nc=80, imgsz=640, wsrc=None, seed=0):
     def elan(src, c, cout, out=None):
         """rows r .. r+5: 1x1 (a), 1x1 on the same input (b), 3x3 on b (c), 3x3 on c (d), Concat [d, c, b, a], 1x1."""
         cat = g.buf(src.h, src.w, 4 * c)
-        b, _ = g.conv_siblings(src, [(c, f"model.{row[0] + 1}.conv"), (c, f"model.{row[0]}.conv")], 1, 1, out=cat.slice(2 * c, 2 * c), act=ACT_LEAKY)
+        b, _ = g.conv_siblings(src, [(c, f"model.{row[0] + 1}.conv"), (c, f"model.{row[0]}.conv")], 1, 1, out=cat.slice(2 * c, 2 * c), act=ACT_LEAKY, draw=(1, 0))
         row[0] += 2                                        # rows r (a -> slot 3) and r + 1 (b -> slot 2): one launch
         cc = cv(b, c, 3, 1, out=cat.slice(c, c))
         cv(cc, c, 3, 1, out=cat.slice(0, c))
@@ -915,7 +918,7 @@ def _c3(g, x, c2, n, shortcut, name, out=None):
     c_ = c2 // 2
     T = g.buf(x.h, x.w, 3 * c_)                      # [m(cv1 x) | cv2 x | cv1 x]: cv3 reads the first two slots, cv1 + cv2 are one launch
     cat = T.slice(0, 2 * c_)
-    _, y = g.conv_siblings(x, [(c_, f"{name}.cv2.conv"), (c_, f"{name}.cv1.conv")], 1, 1, out=T.slice(c_, 2 * c_))
+    _, y = g.conv_siblings(x, [(c_, f"{name}.cv2.conv"), (c_, f"{name}.cv1.conv")], 1, 1, out=T.slice(c_, 2 * c_), draw=(1, 0))
     for i in range(n):
         t = g.conv(y, c_, 1, 1, f"{name}.m.{i}.cv1.conv")
         last = (i == n - 1)
