@@ -347,7 +347,7 @@ def measure_traffic_pmc(dom_label, args):
     if dom_label.startswith("conv_halo_kernel<"):
         bn, act, st = dom_label[len("conv_halo_kernel<"):-1].split(",")
         pat = f"conv_halo_kernel<adas::{etag}, {bn}, {acts.get(act, 1)}, {st[1:]}"
-    if pat is None or args.precision == "fp32" or not os.path.exists(exe):
+    if pat is None or args.precision in ("fp32", "fp16x3") or not os.path.exists(exe):
         return None, None
     tot = {}
     t0 = time.perf_counter()
@@ -384,7 +384,7 @@ def measure_post_hbm(L, pipe, gd, gl, S, layer_ms, precision):
     """Achieved HBM rate of the memory-bound post-processing kernels (north_star: "rocprof reports achieved HBM GB/s on the
     memory-bound post-proc"): algorithmic bytes of one launch over S frames / its duration by hipEvents on the launch stream."""
     import ctypes as C
-    esz = 4 if precision == "fp32" else 2
+    esz = 4 if precision in ("fp32", "fp16x3") else 2
     out = []
 
     def row(kernel, nbytes, ms, what):
@@ -477,7 +477,7 @@ def main():
                     "1 = the reference's frame-at-a-time calling pattern)")
     ap.add_argument("--det", default=None)
     ap.add_argument("--lane", default=None)
-    ap.add_argument("--precision", default="fp16", choices=["fp16", "bf16", "fp32"])
+    ap.add_argument("--precision", default="fp16", choices=["fp16", "bf16", "fp32", "fp16x3"])
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-overlap", action="store_true", help="keep detector and lane nets on one HIP stream")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -834,7 +834,7 @@ def main():
     modes = None
     if extras:
         modes = {args.precision: {"value": round(fps, 2), "ms_per_step": round(elapsed / args.steps * 1e3, 4)}}
-        for other in ("fp16", "bf16", "fp32"):
+        for other in ("fp16", "bf16", "fp16x3", "fp32"):
             if other == args.precision:
                 continue
             try:
@@ -847,6 +847,15 @@ def main():
                 if other == "fp32":
                     modes[other]["parity"] = "max|diff| <= 1e-3 on tapped activations and outputs vs the fp32 oracle (tests/test_gpu_configs.py)"
                 po.close()
+                if other == "fp16x3" and from_frames:
+                    # the split precision is the mode that has to meet the north-star parity gate AT SPEED: its own end-to-end check
+                    # against the fp32 oracle chain on the timed frames (every field should read 100 %)
+                    e2 = measure_e2e(L, make_pipe, args.det, args.lane, Wd, Wl, d_cam, h_cam, NSTREAMS, H, other, micro_batch=B)
+                    modes[other]["what"] = ("(hi, lo) half pairs, three f16 MFMAs per product, fp32 accumulate (csrc/conv_x3.hip): the fp32 mode's "
+                                            "decisions on the 16-bit matrix cores")
+                    modes[other]["e2e"] = {k_: e2.get(k_) for k_ in (
+                        "frames", "identical_candidate_sets", "identical_survivor_sets", "identical_survivors", "identical_track_ids",
+                        "track_states_compared", "lanes_within_1px", "max_conf_diff_on_identical_frames", "max_lane_point_diff_px")}
             except Exception as ex:
                 modes[other] = {"error": str(ex)}
     os.remove(lane_path)

@@ -64,6 +64,10 @@ typedef struct adas_engine adas_engine;
 #define ADAS_PREC_FP32 1 /* fp32 storage + fp32 MFMA (parity precision, 1e-3 vs the fp32 oracle) */
 #define ADAS_PREC_FP16 2 /* IEEE half storage + f16 MFMA (bf16's rate, 11 significant bits), fp32 accumulate: the precision the
                           * reference ships (demo.py:18-29 *_fp16.trt; coreEngine.py:168 fp16 engine_dtype) */
+#define ADAS_PREC_FP16X3 3 /* split precision: every activation and weight is a pair of halves (hi, lo * 2^11) = 22 significant
+                            * bits, every product three f16 MFMAs (hi*hi + 2^-11 (hi*lo + lo*hi)), fp32 accumulate: f32-class results
+                            * (the discrete decisions of the fp32 oracle chain) at a third of the 16-bit MFMA rate instead of
+                            * the f32 MFMA's sixteenth */
 
 /* OnnxEngine.__init__(path) / TensorRTEngine.__init__(path) (coreEngine.py:122-126,161-170).
  * `max_batch` frames per call are planned in HBM (the reference is fixed at 1). */

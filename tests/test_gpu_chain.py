@@ -89,23 +89,35 @@ def test_step_frames_fp16_matches_oracle_chain(tmp_path):
     assert o["identical_survivor_sets"] >= 0.5 * o["frames"], o
 
 
-def test_step_frames_more_than_two_streams_fp32_no_graph(tmp_path):
-    """Eager launches (use_graph=False: the section-event path of record_step) and 6 streams: exact against the oracle chain."""
-    o = _run_chain(tmp_path, "yolov8n", "fp32", S=6, steps=4, hold=2, n_sets=2, use_graph=False)
+@pytest.mark.parametrize("prec", ["fp32", "fp16x3"])
+def test_step_frames_more_than_two_streams_exact_no_graph(tmp_path, prec):
+    """Eager launches (use_graph=False: the section-event path of record_step) and 6 streams: exact against the oracle chain, in the
+    fp32 mode and in the split precision (three f16 MFMAs per product, csrc/conv_x3.hip)."""
+    o = _run_chain(tmp_path, "yolov8n", prec, S=6, steps=4, hold=2, n_sets=2, use_graph=False)
     _assert_exact(o)
 
 
-@pytest.mark.parametrize("det,prec", [("yolov8s", "fp32"), ("yolov8s", "fp16"), ("yolov8l", "fp32"), ("yolov8l", "fp16")])
+def test_step_frames_split_precision_matches_oracle_chain_exactly(tmp_path):
+    """The north-star pipeline in the split precision (fp16x3), hipGraph replay, on the frames the fp16 test above runs: every
+    discrete decision of the fp32 oracle chain (candidates, survivors, track ids and states, lane cells) -- the north-star parity
+    gate on the 16-bit matrix cores."""
+    o = _run_chain(tmp_path, "yolov8n", "fp16x3", S=4, steps=8, hold=2, n_sets=3)
+    _assert_exact(o)
+
+
+@pytest.mark.parametrize("det,prec", [("yolov8s", "fp32"), ("yolov8s", "fp16"), ("yolov8l", "fp32"), ("yolov8l", "fp16"),
+                                      ("yolov8s", "fp16x3"), ("yolov8l", "fp16x3")])
 def test_c4_c5_pipelines_match_oracle_chain(tmp_path, det, prec):
     """BASELINE configs[3] / configs[4]: YOLOv8s / YOLOv8l + UFLDv2-R18 + ByteTrack on 1280x720 frames, 2 streams x 6 steps."""
     o = _run_chain(tmp_path, det, prec, S=2, steps=6, hold=2, n_sets=2, seed=410)
-    if prec == "fp32":
+    if prec in ("fp32", "fp16x3"):
         _assert_exact(o)
     else:
         _assert_16bit(o)
 
 
-def test_micro_batched_step_matches_oracle_chain_fp32(tmp_path):
+@pytest.mark.parametrize("prec", ["fp32", "fp16x3"])
+def test_micro_batched_step_matches_oracle_chain_exactly(tmp_path, prec):
     """Temporal micro-batching (adas_pipeline_desc.micro_batch): 2 streams x 3 consecutive frames per step through the nets at once,
     tracker updates in temporal order -- exact against the oracle chain consuming the same frames one at a time."""
     import bench
@@ -115,7 +127,7 @@ def test_micro_batched_step_matches_oracle_chain_fp32(tmp_path):
     seam0 = np.concatenate([preprocess.yolo_prepare_input(f, (640, 640)) for p in pool for f in p])
     det_path, Wd, gd = bench.build_detector(M, CE, "yolov8n", seam0, str(tmp_path), "mb", target_per_frame=100.0, capacity=1024)
     lane_path, Wl, gl = netutil.model("ufldv2_res18")
-    pipe = PL.AdasPipeline(det_path, lane_path, n_streams=NS, precision="fp32", src_hw=(720, 1280), use_graph=True, max_candidates=1024, micro_batch=B)
+    pipe = PL.AdasPipeline(det_path, lane_path, n_streams=NS, precision=prec, src_hw=(720, 1280), use_graph=True, max_candidates=1024, micro_batch=B)
     d_pool = [L.DeviceBuffer.from_array(p) for p in pool]
     chain = CP.OracleChain("yolov8n", Wd, "ufldv2_res18", Wl)
     st = CP.run_device_chain(pipe, lambda f: PP.YoloPost.fetch(pipe.post, f), lambda s: gpu_api.track_snapshot(*pipe.tracker.fetch(s)),

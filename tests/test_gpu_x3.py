@@ -1,0 +1,191 @@
+"""GPU: the split precision (ADAS_PREC_FP16X3, "fp16x3"): every value a (hi, lo) pair of halves, every product three f16 MFMAs with
+fp32 accumulation (csrc/elem16.h, conv_x3.hip).  Its contract is the fp32 parity mode's: f32-class layer results, every discrete
+decision of the fp32 oracle chain reproduced (BASELINE.json north_star: "bit-exact for NMS survivor indices / ByteTrack ID
+assignment", yoloDetector.py:126-157, byteTracker.py:62-185) -- on the 16-bit matrix cores instead of the 1/16-rate f32 MFMA.
+
+Layer tests bound the error against torch fp32 at 20x below anything a half-precision layer can reach (fp16: ~6e-4 rel-L2) and print
+it next to the fp32 mode's error on the same case; network tests use the fp32 mode's bounds of tests/test_gpu_configs.py.
+"""
+import importlib
+
+import numpy as np
+import pytest
+
+import netutil
+from conftest import load_pkg
+from oracle import nets
+
+import test_gpu_conv as TC
+import test_gpu_configs as TG
+
+pytestmark = pytest.mark.gpu
+load_pkg()
+M = importlib.import_module("adas_amd.models")
+CE = importlib.import_module("adas_amd.coreEngine")
+
+X3_REL = 3e-6      # rel-L2 of one tested layer behind a 1x1 expand layer (measured values are printed)
+
+
+@pytest.mark.parametrize("case", [(64, 64, 3, 1, M.ACT_RELU, M.RES_BEFORE_ACT), (64, 128, 3, 2, M.ACT_RELU, M.RES_NONE),
+                                  (16, 16, 3, 1, M.ACT_SILU, M.RES_AFTER_ACT), (48, 32, 1, 1, M.ACT_SILU, M.RES_NONE),
+                                  (64, 128, 1, 2, M.ACT_NONE, M.RES_NONE), (256, 64, 3, 1, M.ACT_SILU, M.RES_NONE),
+                                  (24, 40, 3, 1, M.ACT_LEAKY, M.RES_NONE), (128, 128, 3, 1, M.ACT_RELU, M.RES_BEFORE_ACT),
+                                  (8, 64, 7, 2, M.ACT_RELU, M.RES_NONE)], ids=str)
+def test_conv_layers_f32_class(case):
+    cin, cout, k, s, act, rm = case
+    info = {}
+    rel, mx = TC.run_case(CE, 40, 56, cin, cout, k, s, act, rm, "fp16x3", info=info)
+    rel32, mx32 = TC.run_case(CE, 40, 56, cin, cout, k, s, act, rm, "fp32")
+    print("x3 %s: rel %.2e max %.2e  (fp32 mode: rel %.2e max %.2e)  %s" % (case, rel, mx, rel32, mx32, info.get("kernel")))
+    assert "x3" in info["kernel"], info
+    assert rel < X3_REL and mx < 1e-4, (case, rel, mx)
+
+
+@pytest.mark.parametrize("hw", [(80, 400), (23, 37), (7, 300), (20, 20)], ids=lambda s: f"{s[0]}x{s[1]}")
+def test_conv3x3_shapes(hw):
+    H, W = hw
+    for cin, cout, act, rm in ((64, 64, M.ACT_RELU, M.RES_BEFORE_ACT), (32, 16, M.ACT_SILU, M.RES_NONE), (80, 80, M.ACT_SILU, M.RES_NONE)):
+        rel, mx = TC.run_case(CE, H, W, cin, cout, 3, 1, act, rm, "fp16x3")
+        assert rel < X3_REL, (hw, cin, cout, rel, mx)
+
+
+@pytest.mark.parametrize("case", [(1, 4000, 2048, M.ACT_RELU, False), (64, 2048, 1000, M.ACT_NONE, True), (3, 512, 91224, M.ACT_NONE, True),
+                                  (130, 256, 264, M.ACT_NONE, True)], ids=str)
+def test_linear_layers_f32_class(case):
+    batch, cin, cout, act, f32_out = case
+    rel = TC.run_fc_case(CE, batch, cin, cout, act, f32_out, prec="fp16x3")
+    rel = rel[0] if isinstance(rel, tuple) else rel
+    print("x3 linear %s: rel %.2e" % (case, rel))
+    assert rel < X3_REL, (case, rel)
+
+
+def test_tiny_and_huge_magnitudes_survive_the_split():
+    """lo is scaled by 2^11 and hi is zeroed below the half normal range (the value moves into lo, keeping 11 bits): values from the
+    half normal range up to 3e4 keep 22 bits, and whatever lies below it is off by at most 2^-14 * 2^-11 relative to NOTHING larger
+    than itself -- an absolute floor of ~3e-8 * 2^-11.  A conv on inputs ~1e-2 with weights ~1e-1, on O(1) and on O(300) inputs comes
+    out with f32-class relative error; on inputs ~1e-4 with weights ~1e-3 (every value below the half normal range) the error is
+    bounded absolutely."""
+    import os, tempfile
+    import torch
+    import torch.nn.functional as F
+    for in_scale, w_scale in ((1e-2, 1e-1), (1.0, 1.0), (300.0, 0.5), (1e-4, 1e-3)):
+        ws = M.SynthWeights(5, gain=1.0)
+        g = M.Graph("mag", 3, 24, 40, ws)
+        x, c3 = g.input()
+        a = g.conv(x, 32, 1, 1, "expand", act=M.ACT_NONE, true_cin=c3)
+        y = g.conv(a, 32, 3, 1, "test", act=M.ACT_NONE)
+        for nm in list(ws.store):                      # weights and biases of both layers
+            if nm.startswith(("expand.", "test.")):
+                ws.store[nm] = ws.store[nm] * np.float32(w_scale if nm.endswith("weight") else w_scale * in_scale)
+        # (the first graph only drew the seeded arrays: the container is built from the scaled ones)
+        g2 = M.Graph("mag", 3, 24, 40, M.DictWeights(dict(ws.store)))
+        x, c3 = g2.input()
+        a = g2.conv(x, 32, 1, 1, "expand", act=M.ACT_NONE, true_cin=c3)
+        y = g2.conv(a, 32, 3, 1, "test", act=M.ACT_NONE)
+        z = g2.conv(y, 8, 1, 1, "tap", act=M.ACT_NONE, f32_out=True)
+        g2.output(z, 0, [1, z.h * z.w * 8], "o")
+        path = os.path.join(tempfile.gettempdir(), "x3_mag.hipm")
+        g2.save(path)
+        e = CE.HipEngine(path, "fp16x3", 2)
+        xin = (np.random.default_rng(1).uniform(-1, 1, (2, 3, 24, 40)) * in_scale).astype(np.float32)
+        e.engine_inference(xin)
+        got = e.fetch_activation("test", 2)
+        e.close(); os.remove(path)
+        Wt = {k_: torch.from_numpy(v).double() for k_, v in ws.store.items() if k_.startswith(("expand.", "test."))}
+        with torch.no_grad():
+            t = torch.from_numpy(xin).double()
+            want = F.conv2d(F.conv2d(t, Wt["expand.weight"], Wt["expand.bias"]), Wt["test.weight"], Wt["test.bias"], padding=1).numpy()
+        rel = float(np.linalg.norm(got - want) / np.linalg.norm(want))
+        mx = float(np.abs(got - want).max())
+        print("x3 magnitudes in %.0e w %.0e: rel %.2e  max|diff| %.2e  max|ref| %.2e" % (in_scale, w_scale, rel, mx, np.abs(want).max()))
+        if in_scale * w_scale > 1e-6:
+            assert rel < X3_REL, (in_scale, w_scale, rel)
+        else:
+            assert mx < 1e-9, (in_scale, w_scale, mx)
+
+
+@pytest.mark.parametrize("backbone", ["18", "34"])
+def test_ufldv2_culane_full_geometry_vs_oracle(backbone):
+    """C3 at full geometry (stem 7x7 s2, 3x3 s2 max-pool, residual stages, 1x1 pool conv, LayerNorm, both Linear layers): the fp32
+    mode's bound (max|diff| <= 1e-3) and rel-L2 <= 1e-5."""
+    path, W, g = netutil.model("ufldv2_res" + backbone)
+    x = netutil.lane_frames(2, 320, 1600, seed=7)
+    taps = {}
+    want = nets.ufldv2_forward(x, W, backbone, taps=taps)
+    e = CE.HipEngine(path, precision="fp16x3", max_batch=2)
+    got = e.engine_inference(x)
+    last = "model.layer4.%d.conv2" % (1 if backbone == "18" else 2)
+    a = e.fetch_activation(last, 2)
+    ref = taps["layer4"].numpy()
+    err4, rel4 = TG.report("ufldv2-r%s fp16x3 layer4" % backbone, a, ref)
+    assert err4 <= 1e-3 * max(1.0, float(np.abs(ref).max())) and rel4 <= 1e-5
+    for o, w in zip(got, want):
+        err, rel = TG.report("ufldv2-r%s fp16x3 output" % backbone, o, w)
+        assert err <= 1e-3 * max(1.0, float(np.abs(w).max())) and rel <= 1e-5
+    e.close()
+
+
+@pytest.mark.parametrize("scale", ["n", "s"])
+def test_yolov8_640_vs_oracle(tmp_path, scale):
+    """C2 / C4 detectors with a calibrated class branch: the fp32 mode's bounds."""
+    x = netutil.coco_like_frames(2, seed=11)
+    path, W = TG.calibrated(tmp_path, "yolov8" + scale, x, "x3_%s" % scale)
+    taps = {}
+    want = nets.yolov8_forward(x, W, scale, taps=taps)
+    e = CE.HipEngine(path, precision="fp16x3", max_batch=2)
+    got = e.engine_inference(x)[0]
+    for lname, key in (("model.15.cv2.conv", "p3"), ("model.18.cv2.conv", "p4"), ("model.21.cv2.conv", "p5")):
+        a = e.fetch_activation(lname, 2)
+        ref = taps[key].numpy()
+        err, rel = TG.report("yolov8%s fp16x3 %s" % (scale, key), a, ref)
+        assert err <= 1e-3 * max(1.0, float(np.abs(ref).max())) and rel <= 1e-5, lname
+    errh, relh = TG.report("yolov8%s fp16x3 head" % scale, got, want)
+    ecls = float(np.abs(got[:, 4:] - want[:, 4:]).max())
+    ebox = float(np.abs(got[:, :4] - want[:, :4]).max())
+    print("yolov8%s fp16x3 max|prob diff| %.3e  max|box diff| %.3e px" % (scale, ecls, ebox))
+    assert relh <= 1e-4 and ecls <= 1e-4 and ebox <= 1e-3 * max(1.0, float(np.abs(want[:, :4]).max()))
+    e.close()
+
+
+def test_yolov10n_vs_oracle():
+    """Depth-wise convs and PSA attention in the split storage (fp32 arithmetic on the joined values)."""
+    path, W, g = netutil.model("yolov10n")
+    x = netutil.coco_like_frames(2, seed=4)
+    want = nets.detector_forward("yolov10n", x, W)[0]
+    e = CE.HipEngine(path, precision="fp16x3", max_batch=2)
+    got = e.engine_inference(x)[0]
+    err, rel = TG.report("yolov10n fp16x3 head", got, want)
+    assert rel <= 1e-4 and np.abs(got[:, 4:] - want[:, 4:]).max() <= 1e-3
+    e.close()
+
+
+@pytest.mark.parametrize("case", [(64, 64, M.ACT_RELU, M.RES_BEFORE_ACT, 32), (128, 128, M.ACT_RELU, M.RES_BEFORE_ACT, 64), (32, 64, M.ACT_SILU, M.RES_NONE, 32),
+                                  (256, 64, M.ACT_NONE, M.RES_NONE, 32), (64, 128, M.ACT_LEAKY, M.RES_AFTER_ACT, 64)], ids=str)
+def test_halo8_x3_kernel_layers(case):
+    """The persistent LDS-DMA kernel of the split precision (conv_halo8_x3.hip: half-chunk stream, main / cross accumulators) at batches
+    that fill the chip, ragged 40x56 maps (strip tiles wrap rows, window rows outside the image zero-filled by the DMA)."""
+    cin, cout, act, rm, batch = case
+    info = {}
+    rel, mx = TC.run_case(CE, 40, 56, cin, cout, 3, 1, act, rm, "fp16x3", batch=batch, info=info)
+    print("h8x3 %s: rel %.2e max %.2e  %s" % (case, rel, mx, info.get("kernel")))
+    assert "conv_h8x3_kernel" in info["kernel"], info
+    assert rel < X3_REL and mx < 1e-4, (case, rel, mx)
+
+
+def test_ufldv2_culane_at_the_bench_batch_vs_oracle():
+    """The C3 network at batch 64 (the bench's batch): the 3x3 stride-1 layers run on conv_h8x3_kernel.  Three distinct frames tiled
+    over the batch: frames 0-2 against the oracle, every copy bit-identical to the first (different workgroups, same arithmetic)."""
+    path, W, g = netutil.model("ufldv2_res18")
+    x3 = netutil.lane_frames(3, 320, 1600, seed=11)
+    x = np.ascontiguousarray(np.concatenate([x3] * 22, 0)[:64])
+    want = nets.ufldv2_forward(x3, W, "18")
+    e = CE.HipEngine(path, precision="fp16x3", max_batch=64)
+    kernels = [e.layer_kernel(i, 64) for i in range(e.stats()["num_layers"])]
+    assert sum("conv_h8x3_kernel" in k for k in kernels) >= 13, kernels
+    got = e.engine_inference(x)
+    for o, w in zip(got, want):
+        err, rel = TG.report("ufldv2-r18 batch 64 fp16x3 output", o[:3], w)
+        assert rel <= 1e-5 and err <= 1e-3 * max(1.0, float(np.abs(w).max()))
+        for k in range(3, 64):
+            assert np.array_equal(o[k], o[k % 3]), (k, float(np.abs(o[k] - o[k % 3]).max()))
+    e.close()

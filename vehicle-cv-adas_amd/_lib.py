@@ -14,8 +14,9 @@ LIB_PATH = os.path.join(HERE, "libadas_hip.so")
 UFLD_MAX_POINTS = 128
 HEAD_V8, HEAD_V5, HEAD_V5_LITE = 0, 1, 2
 NMS_REFERENCE, NMS_GREEDY = 0, 1
-PREC_BF16, PREC_FP32, PREC_FP16 = 0, 1, 2
-PRECISIONS = {"bf16": PREC_BF16, "fp32": PREC_FP32, "fp16": PREC_FP16}
+PREC_BF16, PREC_FP32, PREC_FP16, PREC_FP16X3 = 0, 1, 2, 3
+# "fp16x3": split precision -- (hi, lo) half pairs, three f16 MFMAs per product, fp32 accumulate: the fp32 mode's results at speed
+PRECISIONS = {"bf16": PREC_BF16, "fp32": PREC_FP32, "fp16": PREC_FP16, "fp16x3": PREC_FP16X3}
 
 
 class AdasError(RuntimeError):

@@ -19,10 +19,12 @@ UNITS = [
     ("post_kernels.hip", ["-ffp-contract=off"]),
     ("pre_kernels.hip", ["-ffp-contract=off"]),
     ("conv_kernels.hip", []),
+    ("conv_x3.hip", []),
     ("conv_halo.hip", []),
     ("conv_halo_rw.hip", []),
     ("conv_halo_s2.hip", []),
     ("conv_halo8.hip", []),
+    ("conv_halo8_x3.hip", []),
     ("conv_pair.hip", []),
     ("conv_c2f.hip", []),
     ("conv_fc.hip", []),
@@ -49,7 +51,7 @@ def build(force=False, verbose=True):
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     os.makedirs(OBJ, exist_ok=True)
     hdr_t = max(os.path.getmtime(h) for h in _deps())
-    objs, rebuilt = [], False
+    objs, todo = [], []
     for src, extra in UNITS:
         sp = os.path.join(CSRC, src)
         if not os.path.exists(sp):
@@ -57,11 +59,18 @@ def build(force=False, verbose=True):
         op = os.path.join(OBJ, os.path.splitext(src)[0] + ".o")
         objs.append(op)
         if force or not os.path.exists(op) or os.path.getmtime(op) < max(os.path.getmtime(sp), hdr_t):
-            cmd = [hipcc, *COMMON, *extra, "-c", sp, "-o", op]
+            todo.append([hipcc, *COMMON, *extra, "-c", sp, "-o", op])
+    rebuilt = bool(todo)
+    if todo:   # the units are independent: compile them side by side (ADAS_BUILD_JOBS, default = min(8, cores))
+        from concurrent.futures import ThreadPoolExecutor
+        jobs = max(1, int(os.environ.get("ADAS_BUILD_JOBS", min(8, os.cpu_count() or 1))))
+
+        def run(cmd):
             if verbose:
                 print(" ".join(cmd), flush=True)
             subprocess.check_call(cmd)
-            rebuilt = True
+        with ThreadPoolExecutor(jobs) as ex:
+            list(ex.map(run, todo))
     if rebuilt or not os.path.exists(OUT):
         cmd = [hipcc, "-shared", "-fPIC", f"--offload-arch={ARCH}", *objs, "-o", OUT]
         if verbose:

@@ -25,12 +25,18 @@ template <typename T> __device__ __forceinline__ void st(T* p, float v);
 template <> __device__ __forceinline__ void st<float>(float* p, float v) { *p = v; }
 template <> __device__ __forceinline__ void st<uint16_t>(uint16_t* p, float v) { *p = a_f2bf(v); }
 template <> __device__ __forceinline__ void st<f16s>(f16s* p, float v) { p->v = Fp16::from_f32(v); }
+// split precision (elem16.h x3s): a channel slot of the G8 layout; the group follows from the address
+template <> __device__ __forceinline__ float ld<x3s>(const x3s* p) { return x3_ld(p); }
+template <> __device__ __forceinline__ void st<x3s>(x3s* p, float v) { x3_st(p, v); }
 
 // launch `KERNEL<T>` with T = the storage type of an engine precision
 #define ADAS_DISPATCH_STORAGE(prec, T, ...) \
     do {                                    \
         if ((prec) == PREC_FP32) {          \
             using T = float;                \
+            __VA_ARGS__;                    \
+        } else if ((prec) == PREC_X3) {     \
+            using T = x3s;                  \
             __VA_ARGS__;                    \
         } else if ((prec) == PREC_FP16) {   \
             using T = f16s;                 \
@@ -55,11 +61,28 @@ __global__ void input_nchw_kernel(const float* __restrict__ src, T* __restrict__
         }
     }
 }
+// split precision: the pixel's 8 channel slots are one G8 group -- 16 bytes of hi + 16 bytes of lo, two stores
+__global__ void input_nchw_x3_kernel(const float* __restrict__ src, x3s* __restrict__ dst, int n, int c_true, int hw, int cs) {
+    Fp16::enter();
+    size_t total = (size_t)n * hw;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        size_t b = i / hw, p = i - b * hw;
+        float v[8];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) v[c] = (c < c_true) ? src[(b * c_true + c) * hw + p] : 0.0f;
+        x3_store8(dst + i * cs, v);
+    }
+}
 hipError_t launch_input_nchw(const float* nchw, TView out, int n, int c_true, int prec, hipStream_t st_) {
     int hw = out.h * out.w;
     size_t total = (size_t)n * hw;
     int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
     if (out.c != 8 || out.coff != 0 || c_true > 8) return hipErrorInvalidValue;
+    if (prec == PREC_X3) {
+        if (out.cs & 7) return hipErrorInvalidValue;
+        hipLaunchKernelGGL(input_nchw_x3_kernel, dim3(blocks), dim3(256), 0, st_, nchw, (x3s*)out.p, n, c_true, hw, out.cs);
+        return hipGetLastError();
+    }
     ADAS_DISPATCH_STORAGE(prec, T, hipLaunchKernelGGL(input_nchw_kernel<T>, dim3(blocks), dim3(256), 0, st_, nchw, (T*)out.p, n, c_true, hw, out.cs));
     return hipGetLastError();
 }
@@ -109,6 +132,13 @@ __device__ __forceinline__ void put8(float* op, const float m[8]) {
 #pragma unroll
     for (int q = 0; q < 8; ++q) op[q] = m[q];
 }
+__device__ __forceinline__ void max8(float m[8], const x3s* ip) {   // the maximum of the joined values (hi alone can tie)
+    float v[8];
+    x3_load8(ip, v);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) m[q] = fmaxf(m[q], v[q]);
+}
+__device__ __forceinline__ void put8(x3s* op, const float m[8]) { x3_store8(op, m); }
 template <typename T>
 __global__ void maxpool_kernel(PoolDev d) {
     const int c8n = d.c >> 3;
@@ -182,12 +212,67 @@ __global__ void maxpool16_kernel(PoolDev d) {
     }
 }
 
+// split precision, compile-time window: like maxpool16_kernel every tap's group (16 B hi + 16 B lo) is loaded unconditionally from a
+// clamped address and out-of-image taps are masked afterwards, so the K*K load pairs of a thread are in flight together; the maximum is
+// taken on the joined values.  K = 5 (SPPF, 100 registers of loads) stays on the generic kernel.
+template <int K>
+__global__ void maxpool_x3_kernel(PoolDev d) {
+    Fp16::enter();
+    const int c8n = d.c >> 3;
+    size_t total = (size_t)d.n * d.Ho * d.Wo * c8n;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        int c8 = (int)(i % c8n);
+        size_t pix = i / c8n;
+        int ox = (int)(pix % d.Wo);
+        size_t t = pix / d.Wo;
+        int oy = (int)(t % d.Ho), b = (int)(t / d.Ho);
+        const x3s* base = (const x3s*)d.in + (size_t)b * d.H * d.W * d.in_cs + d.in_coff + c8 * 8;
+        uint4 vh[K * K], vl[K * K];
+#pragma unroll
+        for (int r = 0; r < K; ++r) {
+            const int iy = oy * d.s - d.p + r, iyc = iy < 0 ? 0 : (iy >= d.H ? d.H - 1 : iy);
+#pragma unroll
+            for (int q = 0; q < K; ++q) {
+                const int ix = ox * d.s - d.p + q, ixc = ix < 0 ? 0 : (ix >= d.W ? d.W - 1 : ix);
+                const uint4* g = reinterpret_cast<const uint4*>(base + ((size_t)iyc * d.W + ixc) * d.in_cs);
+                vh[r * K + q] = g[0];
+                vl[r * K + q] = g[1];
+            }
+        }
+        float m[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) m[q] = -3.0e38f;
+#pragma unroll
+        for (int r = 0; r < K; ++r) {
+            const int iy = oy * d.s - d.p + r;
+#pragma unroll
+            for (int q = 0; q < K; ++q) {
+                const int ix = ox * d.s - d.p + q;
+                const bool in = (unsigned)iy < (unsigned)d.H && (unsigned)ix < (unsigned)d.W;
+                const uint32_t hw[4] = {vh[r * K + q].x, vh[r * K + q].y, vh[r * K + q].z, vh[r * K + q].w};
+                const uint32_t lw[4] = {vl[r * K + q].x, vl[r * K + q].y, vl[r * K + q].z, vl[r * K + q].w};
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const e_f16x2 hh = __builtin_bit_cast(e_f16x2, hw[k]), ll = __builtin_bit_cast(e_f16x2, lw[k]);
+                    const float v0 = x3_join(hh[0], ll[0]), v1 = x3_join(hh[1], ll[1]);
+                    m[2 * k] = fmaxf(m[2 * k], in ? v0 : -3.0e38f);
+                    m[2 * k + 1] = fmaxf(m[2 * k + 1], in ? v1 : -3.0e38f);
+                }
+            }
+        }
+        x3_store8((x3s*)d.out + pix * d.out_cs + d.out_coff + c8 * 8, m);
+    }
+}
+
 hipError_t launch_maxpool(TView in, TView out, int n, int k, int s, int p, int prec, hipStream_t st_) {
     if (in.c != out.c || (in.c & 7) || ((in.cs | in.coff | out.cs | out.coff) & 7)) return hipErrorInvalidValue;
     PoolDev d{in.p, out.p, in.cs, in.coff, out.cs, out.coff, in.c, in.h, in.w, out.h, out.w, k, s, p, n};
     size_t total = (size_t)n * out.h * out.w * (in.c >> 3);
     int blocks = (int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
-    if (prec == PREC_FP32 || (k != 5 && k != 3 && k != 2)) {
+    if (prec == PREC_X3 && (k == 3 || k == 2)) {
+        if (k == 3) hipLaunchKernelGGL((maxpool_x3_kernel<3>), dim3(blocks), dim3(256), 0, st_, d);
+        else hipLaunchKernelGGL((maxpool_x3_kernel<2>), dim3(blocks), dim3(256), 0, st_, d);
+    } else if (!prec_is16(prec) || (k != 5 && k != 3 && k != 2)) {
         ADAS_DISPATCH_STORAGE(prec, T, hipLaunchKernelGGL(maxpool_kernel<T>, dim3(blocks), dim3(256), 0, st_, d));
     } else {
         ADAS_DISPATCH_E16(prec == PREC_FP16, E, {
@@ -322,9 +407,10 @@ __global__ void upsample2_kernel(PoolDev d) {
         T* op = (T*)d.out + pix * d.out_cs + d.out_coff + c8 * 8;
         if (sizeof(T) == 2) {  // 8 bf16 = one 16-byte move (views are 8-channel aligned)
             *reinterpret_cast<uint4*>(op) = *reinterpret_cast<const uint4*>(ip);
-        } else {
-#pragma unroll
-            for (int q = 0; q < 8; ++q) op[q] = ip[q];
+        } else {               // 8 four-byte slots (fp32, or one G8 group of the split precision): two 16-byte moves
+            const uint4 q0 = reinterpret_cast<const uint4*>(ip)[0], q1 = reinterpret_cast<const uint4*>(ip)[1];
+            reinterpret_cast<uint4*>(op)[0] = q0;
+            reinterpret_cast<uint4*>(op)[1] = q1;
         }
     }
 }
@@ -333,7 +419,7 @@ hipError_t launch_upsample2(TView in, TView out, int n, int prec, hipStream_t st
     PoolDev d{in.p, out.p, in.cs, in.coff, out.cs, out.coff, in.c, in.h, in.w, out.h, out.w, 0, 0, 0, n};
     size_t total = (size_t)n * out.h * out.w * (in.c >> 3);
     int blocks = (int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
-    if (prec == PREC_FP32)
+    if (!prec_is16(prec))   // fp32, or the split precision: a G8 group of 8 channels is 32 bytes moved as a whole
         hipLaunchKernelGGL(upsample2_kernel<float>, dim3(blocks), dim3(256), 0, st_, d);
     else
         hipLaunchKernelGGL(upsample2_kernel<uint16_t>, dim3(blocks), dim3(256), 0, st_, d);
@@ -358,8 +444,9 @@ __global__ void depth2space_kernel(PoolDev d) {
         if (sizeof(T) == 2) {
             *reinterpret_cast<uint4*>(op) = *reinterpret_cast<const uint4*>(ip);
         } else {
-#pragma unroll
-            for (int k = 0; k < 8; ++k) op[k] = ip[k];
+            const uint4 q0 = reinterpret_cast<const uint4*>(ip)[0], q1 = reinterpret_cast<const uint4*>(ip)[1];
+            reinterpret_cast<uint4*>(op)[0] = q0;
+            reinterpret_cast<uint4*>(op)[1] = q1;
         }
     }
 }
@@ -372,7 +459,7 @@ hipError_t launch_depth2space(TView in, TView out, int n, int prec, hipStream_t 
     PoolDev d{in.p, out.p, in.cs, in.coff, out.cs, out.coff, out.c, in.h, in.w, out.h, out.w, 0, 0, 0, n};
     size_t total = (size_t)n * out.h * out.w * (out.c >> 3);
     int blocks = (int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
-    if (prec == PREC_FP32)
+    if (!prec_is16(prec))   // (the split precision's 32-byte groups move as wholes)
         hipLaunchKernelGGL(depth2space_kernel<float>, dim3(blocks), dim3(256), 0, st_, d);
     else
         hipLaunchKernelGGL(depth2space_kernel<uint16_t>, dim3(blocks), dim3(256), 0, st_, d);

@@ -1,0 +1,481 @@
+// conv_halo8_x3.hip -- the stride-1 3x3 convolution of the split precision (ADAS_PREC_FP16X3) on conv_halo8.hip's structure: one
+// persistent 8-wave workgroup per CU, window and per-tap weight tiles fed by LDS-DMA, counted waits, never draining inside the stream.
+//
+// conv_x3.hip (the generic kernel) gathers every input pixel once per tap from L2: at three MFMAs per product it is L2-bound at
+// ~500 TFLOP/s of MFMA work (measured: 150-207 TFLOP/s of conv work on the UFLD layers).  Here the split operands run through the
+// halo stream as HALF-CHUNKS: a 32-channel chunk of the G8 activation tensor (128 B per pixel: four groups of [16 B hi | 16 B lo])
+// is streamed as an H chunk (the four hi pieces) followed by an L chunk (the four lo pieces), each through the same 64-byte window
+// pixels, swizzle and double buffering as the 16-bit kernel -- the DMA's per-lane source address picks hi or lo.
+//   item      256 pixels x 64 output channels; wave group hb owns 32 of them as four 16-row MFMA tiles:
+//             rows 0-31 = MAIN (w_hi), rows 32-63 = CROSS (H chunk: w_lo * 2^11; L chunk: w_hi)
+//   H chunk   main += w_hi a_hi (8 MFMAs per wave and tap), cross += w_lo a_hi (8)
+//   L chunk   cross += w_hi a_lo (8); the main rows of its weight tiles are never read
+//   epilogue  out = act(main + 2^-11 cross [+ residual]) -> split -> G8 store (8 B hi + 8 B lo per lane and 16-channel tile)
+// = the three-MFMA product of elem16.h with no operand re-fetch.  Weight slabs [64-row block][half-chunk][tap][64 rows][32] are packed at
+// load time (launch_pack_weights_h8x3); an eligible conv keeps both this packing and the generic one, the launch picks by batch.
+#include "kernels.h"
+#include "elem16.h"
+#include <stdlib.h>
+#include <string.h>
+#include <type_traits>
+
+namespace adas {
+
+typedef __attribute__((ext_vector_type(4))) float yf32x4;
+typedef __attribute__((ext_vector_type(4))) uint32_t yu32x4;
+typedef __attribute__((ext_vector_type(2))) uint32_t yu32x2;
+typedef __attribute__((address_space(3))) void* ylds_vp;
+
+struct H8XDev {
+    const void* in;
+    const void* wgt;
+    const float* bias;
+    void* out;
+    const void* res;
+    uint32_t in_bytes, wgt_bytes, out_bytes, res_bytes;
+    int in_cs, in_coff, cin, H, W;
+    int out_cs, out_coff, cout;
+    int res_cs, res_coff, res_mode;
+    int nck;                  // half-chunks: 2 * (cin / 32), order H0 L0 H1 L1 ...
+    int SW, NS, TPS, WW;      // strip width, strips per row, tiles per strip, window width (conv_halo.hip's plan)
+    uint32_t mg_ww, mg_sw;
+    uint32_t mg_img, mg_tps, mg_upt;
+    int ntiles, tiles8, ncb, cpw;  // tiles, ceil(tiles / 8), 64-channel blocks, blocks per unit
+};
+
+constexpr int X8_THR = 512;
+constexpr int X8_BM = 256;
+constexpr int X8_MAXPIX = 640;
+constexpr int X8_WIN = X8_MAXPIX * 64;          // bytes of one window buffer (one half-chunk: 32 halves per pixel)
+constexpr int X8_TAP = 2 * 64 * 64;             // bytes of one tap's weights (two 64-row blocks)
+constexpr int X8_WR = 2 * X8_WIN;               // byte offset of the weight ring
+constexpr int X8_LDS = X8_WR + 9 * X8_TAP;      // 155,648 B
+constexpr int X8_NWP = X8_MAXPIX / 16 / 8;      // window pieces per wave (5)
+constexpr int X8_SLAB = 9 * 64 * 64;            // bytes of one (64-row block, half-chunk) weight slab
+constexpr uint32_t X8_OOB = 0xF0000000u;
+constexpr int X8_SLOTS = 32;
+
+__host__ __device__ constexpr int x8_look(int mode) { return mode == 2 ? 6 : 4; }
+
+template <int N>
+__device__ __forceinline__ void x8_wait_vm() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+template <int ACT>
+__device__ __forceinline__ float x8_act(float v) {
+    if (ACT == ACT_SILU) return v / (1.0f + expf(-v));   // the parity modes use the exact forms (conv_x3.hip x3_act)
+    if (ACT == ACT_RELU) return fmaxf(v, 0.0f);
+    if (ACT == ACT_LEAKY) return fmaxf(v, 0.1f * v);
+    return v;
+}
+
+__host__ __device__ constexpr int x8_issued(int k) { return 1 + ((k >= 1 && k <= X8_NWP) ? 1 : 0); }
+__host__ __device__ constexpr int x8_allow(int mode, int k) {
+    return mode == 2 ? x8_issued(k) + x8_issued(k - 1) + x8_issued(k - 2)
+                     : x8_issued(k) + x8_issued((k + 8) % 9) + x8_issued((k + 7) % 9);
+}
+// loads queued under the last tap row of an item besides the stream's pieces: the next item's bias (2 float4) and, with a residual,
+// 16 eight-byte loads (4 pixel tiles x 2 channel tiles x {hi, lo})
+constexpr int X8_NBIAS = 2, X8_NRES = 16;
+
+template <int ACT, int MODE>
+__global__ __launch_bounds__(X8_THR, 1) void conv_h8x3_kernel(H8XDev a) {
+    Fp16::enter();
+    typedef Fp16::vec8 hvec8;
+    constexpr int LOOK = x8_look(MODE);
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds8[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lrow = lane & 15, kg = lane >> 4;
+    const int hb = wave >> 2, grp = wave & 3;   // 32-channel half of the item (= wave group), pixel quarter
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, nslot = gridDim.x >> 3;
+    int tiles_here = a.ntiles - xcd * a.tiles8;
+    tiles_here = tiles_here < 0 ? 0 : (tiles_here > a.tiles8 ? a.tiles8 : tiles_here);
+    const int upt = a.ncb / a.cpw;            // units per tile
+    const int units_here = tiles_here * upt;
+    if (slot >= units_here) return;
+
+    __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc((void*)a.in, 0, a.in_bytes, 0x00020000);
+    __amdgpu_buffer_rsrc_t rwg = __builtin_amdgcn_make_buffer_rsrc((void*)a.wgt, 0, a.wgt_bytes, 0x00020000);
+    __amdgpu_buffer_rsrc_t rout = __builtin_amdgcn_make_buffer_rsrc((void*)a.out, 0, a.out_bytes, 0x00020000);
+    __amdgpu_buffer_rsrc_t rres = __builtin_amdgcn_make_buffer_rsrc((void*)(a.res_mode != RES_NONE ? a.res : a.out), 0,
+                                                                    a.res_mode != RES_NONE ? a.res_bytes : 0u, 0x00020000);
+    const int per_img = a.NS * a.TPS;
+    const int gsw[4] = {0, 2, 3, 1};
+    const uint32_t wlane = (uint32_t)((lane >> 2) * 64 + (((lane & 3) ^ gsw[(lane >> 4) & 3]) << 4));
+    // window: LDS position (lane & 3) of pixel (lane >> 2) holds K group (lane & 3) ^ swizzle; in the G8 tensor that group's hi
+    // halves sit at group * 32 bytes (its lo halves 16 bytes behind)
+    const uint32_t wpiece = (uint32_t)((lane & 3) ^ (((lane >> 4) & 1) << 1)) << 5;
+    const uint32_t wrd = (uint32_t)(X8_WR + hb * 4096 + lrow * 64 + ((kg ^ gsw[(lrow >> 2) & 3]) << 4));
+    // epilogue: lane owns channels kg*4 .. +3 of 16-channel tile i of the wave group's 32: G8 byte offset of their hi halves within
+    // the pixel's 64-channel run (lo halves 16 bytes behind): group (hb*32 + i*16 + kg*4) / 8, element (kg & 1) * 4
+    const uint32_t ch_lane = (uint32_t)((hb * 4 + (kg >> 1)) * 32 + (kg & 1) * 8);
+    const bool has_res = a.res_mode != RES_NONE;
+
+    struct Tile {
+        int img, sx0, p0, y_first;
+    };
+    auto decode = [&](int u) {
+        Tile t;
+        int tile = xcd * a.tiles8 + (upt == 1 ? u : (int)__umulhi((uint32_t)u, a.mg_upt));
+        t.img = per_img == 1 ? tile : (int)__umulhi((uint32_t)tile, a.mg_img);
+        tile -= t.img * per_img;
+        const int strip = a.TPS == 1 ? tile : (int)__umulhi((uint32_t)tile, a.mg_tps);
+        t.sx0 = strip * a.SW;
+        t.p0 = (tile - strip * a.TPS) * X8_BM;
+        t.y_first = (int)(((uint32_t)t.p0 * a.mg_sw) >> 20);
+        return t;
+    };
+    // source byte offset of this lane's 16 bytes in the wave's window piece i (half-chunk 0 = hi of channels 0-31)
+    auto win_offset = [&](const Tile& t, int i) {
+        const int y_lastp = (int)(((uint32_t)(t.p0 + X8_BM - 1) * a.mg_sw) >> 20);
+        const int npix = (y_lastp - t.y_first + 3) * a.WW;
+        const int pix = (wave + 8 * i) * 16 + (lane >> 2);
+        const int wy = (int)(((uint32_t)pix * a.mg_ww) >> 20), wx = pix - wy * a.WW;
+        const int iy = t.y_first - 1 + wy, ix = t.sx0 - 1 + wx;
+        const bool ok = pix < npix && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+        const uint32_t off = ((uint32_t)((t.img * a.H + iy) * a.W + ix) * (uint32_t)a.in_cs + (uint32_t)a.in_coff) * 4u + wpiece;
+        const uint32_t m = 0u - (uint32_t)ok;
+        return (off & m) | (X8_OOB & ~m);
+    };
+    auto tap00 = [&](const Tile& t, int j) {
+        const int p = t.p0 + (grp * 4 + j) * 16 + lrow;
+        const int y = (int)(((uint32_t)p * a.mg_sw) >> 20), xs = p - y * a.SW;
+        return (uint32_t)((((y - t.y_first) * a.WW + xs) << 6) | (kg << 4));
+    };
+    auto tap_offset = [&](uint32_t ap64, int t) {
+        const uint32_t v = ap64 + (uint32_t)(((t / 3) * a.WW + (t % 3)) << 6);
+        return v ^ ((v >> 3) & 0x20u);
+    };
+    auto out_pixel = [&](const Tile& t, int j) {
+        const int p = t.p0 + (grp * 4 + j) * 16 + lrow;
+        const int y = (int)(((uint32_t)p * a.mg_sw) >> 20), x = t.sx0 + (p - y * a.SW);
+        return (y < a.H && x < a.W) ? (uint32_t)((t.img * a.H + y) * a.W + x) : X8_OOB;
+    };
+    // scalar byte offset of this wave's 16 rows of (64-channel block cb, half hb, half-chunk 0, tap 0)
+    auto wgt_base = [&](int cb) { return (uint32_t)(((2 * cb + hb) * a.nck) * X8_SLAB + grp * 1024); };
+    auto load_bias = [&](int cb, float4* b) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) b[i] = *reinterpret_cast<const float4*>(a.bias + cb * 64 + hb * 32 + i * 16 + kg * 4);
+    };
+
+    auto first_cb = [&](int u) { return upt == 1 ? 0 : (u - (int)__umulhi((uint32_t)u, a.mg_upt) * upt) * a.cpw; };
+    int ti = slot, cb = first_cb(slot), cbi = 0;
+    Tile cur = decode(ti);
+    uint32_t gcur[X8_NWP], gnxt[X8_NWP];
+    uint32_t xoff[4][9];
+    uint32_t po[4];
+#pragma unroll
+    for (int i = 0; i < X8_NWP; ++i) gcur[i] = win_offset(cur, i);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const uint32_t ap64 = tap00(cur, j);
+#pragma unroll
+        for (int t = 0; t < 9; ++t) xoff[j][t] = tap_offset(ap64, t);
+        po[j] = out_pixel(cur, j);
+    }
+    uint32_t wcur = wgt_base(cb);
+    int par = 0;
+    float4 biasn[2];
+    load_bias(cb, biasn);
+
+    // ---- prologue: window of half-chunk 0 into buffer 0, weights of taps 0 .. LOOK-1
+#pragma unroll
+    for (int i = 0; i < X8_NWP; ++i)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rin, (ylds_vp)(lds8 + (wave + 8 * i) * 1024), 16, gcur[i], 0, 0, 0);
+#pragma unroll
+    for (int t = 0; t < LOOK; ++t)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rwg, (ylds_vp)(lds8 + X8_WR + t * X8_TAP + wave * 1024), 16, wlane, wcur + t * 4096, 0, 0);
+    yf32x4 acc[4][4];   // [0..1]: main, starts at the bias; [2..3]: cross, starts at zero
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            acc[i][j] = yf32x4{biasn[i].x, biasn[i].y, biasn[i].z, biasn[i].w};
+            acc[i + 2][j] = yf32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    }
+    x8_wait_vm<0>();
+    __builtin_amdgcn_s_barrier();
+    if (MODE == 1 && hb) __builtin_amdgcn_s_barrier();   // group 1 runs one segment behind group 0
+
+    for (;;) {
+        const bool newtile = cbi + 1 == a.cpw;
+        const bool has_next = !newtile || ti + nslot < units_here;
+        const int cbn = newtile ? first_cb(has_next ? ti + nslot : ti) : cb + 1;
+        const uint32_t ch0 = (uint32_t)(cb * 256) + ch_lane;   // 64 channels = 256 bytes of G8 storage
+        Tile nxt = cur;
+        uint32_t wnxt_item = 0, apn[4] = {0, 0, 0, 0};
+        yu32x2 rraw[4][2][2];   // residual [pixel tile][channel tile][hi | lo], fetched under the last row of taps of the last half-chunk
+
+        auto chunk = [&](auto last_c, auto lo_c, const int c) {
+            constexpr bool lastc = decltype(last_c)::value;
+            constexpr bool islo = decltype(lo_c)::value;   // L half-chunk: only the cross tiles (i = 2, 3) accumulate
+            if (lastc) {
+                if (newtile && has_next) nxt = decode(ti + nslot);
+                if (!has_next) nxt.y_first = a.H + 4;
+                wnxt_item = wgt_base(cbn);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) apn[j] = tap00(nxt, j);
+            } else {
+                // the half-chunk fetched during this one: after an H chunk its own lo pieces (16 bytes on), after an L chunk the hi
+                // pieces of the next 32 channels (a group is 32 bytes, a chunk 128)
+#pragma unroll
+                for (int i = 0; i < X8_NWP; ++i) gcur[i] += islo ? 112u : 16u;
+            }
+            const uint32_t wthis = wcur + (uint32_t)c * X8_SLAB;
+            const uint32_t wnext = lastc ? wnxt_item : wthis + X8_SLAB;
+            const uint32_t winr = (uint32_t)(((par + c) & 1) * X8_WIN), winw = X8_WIN - winr;
+            auto tap = [&](auto kk_c) {
+                constexpr int kk = decltype(kk_c)::value;
+                if (lastc && kk == 6) load_bias(cbn, biasn);
+                if (lastc && kk == 6 && has_res) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const uint32_t ro = po[j] == X8_OOB ? X8_OOB : (po[j] * (uint32_t)a.res_cs + (uint32_t)a.res_coff) * 4u + ch0;
+#pragma unroll
+                        for (int i = 0; i < 2; ++i) {
+                            rraw[j][i][0] = __builtin_amdgcn_raw_buffer_load_b64(rres, ro + i * 64, 0, 0);
+                            rraw[j][i][1] = __builtin_amdgcn_raw_buffer_load_b64(rres, ro + i * 64 + 16, 0, 0);
+                        }
+                    }
+                }
+                hvec8 wf[4], xf[4];
+#pragma unroll
+                for (int i = islo ? 2 : 0; i < 4; ++i) wf[i] = *reinterpret_cast<const hvec8*>(lds8 + wrd + kk * X8_TAP + i * 1024);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) xf[j] = *reinterpret_cast<const hvec8*>(lds8 + xoff[j][kk] + winr);
+                {
+                    constexpr int kt = (kk + LOOK) % 9;
+                    const uint32_t src = (kk + LOOK < 9 ? wthis : wnext) + (uint32_t)kt * 4096u;
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rwg, (ylds_vp)(lds8 + X8_WR + kt * X8_TAP + wave * 1024), 16, wlane, src, 0, 0);
+                }
+                if constexpr (kk >= 1 && kk <= X8_NWP)
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rin, (ylds_vp)(lds8 + winw + (wave + 8 * (kk - 1)) * 1024), 16, lastc ? gnxt[kk - 1] : gcur[kk - 1], 0, 0, 0);
+                constexpr bool sync_here = MODE != 2 || kk % 3 == 2;
+                if (sync_here && (c > 0 || kk >= 3)) {
+                    if (lastc && kk >= 6 && has_res) x8_wait_vm<x8_allow(MODE, kk) + X8_NBIAS + X8_NRES>();
+                    else if (lastc && kk >= 6) x8_wait_vm<x8_allow(MODE, kk) + X8_NBIAS>();
+                    else x8_wait_vm<x8_allow(MODE, kk)>();
+                }
+                if (MODE == 1) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    __builtin_amdgcn_s_barrier();
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                __builtin_amdgcn_s_setprio(1);
+                if (lastc) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) xoff[j][kk] = tap_offset(apn[j], kk);
+                    if constexpr (kk < X8_NWP) gnxt[kk] = win_offset(nxt, kk);
+                }
+#pragma unroll
+                for (int i = islo ? 2 : 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[i][j] = Fp16::mfma(wf[i], xf[j], acc[i][j]);
+                if (lastc) {
+#pragma unroll
+                    for (int g = 0; g < (islo ? 8 : 16); ++g) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // one MFMA
+                        __builtin_amdgcn_sched_group_barrier(0x006, 6, 0);   // address arithmetic of the next item in its shadow
+                    }
+                }
+                __builtin_amdgcn_s_setprio(0);
+                if (sync_here) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    __builtin_amdgcn_s_barrier();
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            };
+            tap(std::integral_constant<int, 0>{}); tap(std::integral_constant<int, 1>{}); tap(std::integral_constant<int, 2>{});
+            tap(std::integral_constant<int, 3>{}); tap(std::integral_constant<int, 4>{}); tap(std::integral_constant<int, 5>{});
+            tap(std::integral_constant<int, 6>{}); tap(std::integral_constant<int, 7>{}); tap(std::integral_constant<int, 8>{});
+        };
+        for (int c = 0; c + 1 < a.nck; ++c) {
+            if (c & 1) chunk(std::false_type{}, std::true_type{}, c);
+            else chunk(std::false_type{}, std::false_type{}, c);
+        }
+        chunk(std::true_type{}, std::true_type{}, a.nck - 1);   // nck is even: the last half-chunk is an L chunk
+
+        // ---------------- epilogue: lane holds channels kg*4..+3 of pixel lrow of every (i, j) tile
+        __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
+        auto write_out = [&](auto rm_c) {
+            constexpr int RM = decltype(rm_c)::value;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const uint32_t oo = po[j] == X8_OOB ? X8_OOB : (po[j] * (uint32_t)a.out_cs + (uint32_t)a.out_coff) * 4u + ch0;
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    float v[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = acc[i][j][e] + acc[i + 2][j][e] * kX3Down;
+                    if (RM != RES_NONE) {
+                        const e_f16x2 h0 = __builtin_bit_cast(e_f16x2, rraw[j][i][0][0]), h1 = __builtin_bit_cast(e_f16x2, rraw[j][i][0][1]);
+                        const e_f16x2 l0 = __builtin_bit_cast(e_f16x2, rraw[j][i][1][0]), l1 = __builtin_bit_cast(e_f16x2, rraw[j][i][1][1]);
+                        const float r[4] = {x3_join(h0[0], l0[0]), x3_join(h0[1], l0[1]), x3_join(h1[0], l1[0]), x3_join(h1[1], l1[1])};
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = RM == RES_BEFORE_ACT ? x8_act<ACT>(v[e] + r[e]) : x8_act<ACT>(v[e]) + r[e];
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = x8_act<ACT>(v[e]);
+                    }
+                    e_f16x2 h0, h1, l0, l1;
+                    _Float16 h, l;
+                    x3_split(v[0], h, l); h0[0] = h; l0[0] = l;
+                    x3_split(v[1], h, l); h0[1] = h; l0[1] = l;
+                    x3_split(v[2], h, l); h1[0] = h; l1[0] = l;
+                    x3_split(v[3], h, l); h1[1] = h; l1[1] = l;
+                    __builtin_amdgcn_raw_buffer_store_b64(yu32x2{__builtin_bit_cast(uint32_t, h0), __builtin_bit_cast(uint32_t, h1)}, rout, oo + i * 64, 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b64(yu32x2{__builtin_bit_cast(uint32_t, l0), __builtin_bit_cast(uint32_t, l1)}, rout, oo + i * 64 + 16, 0, 0);
+                    acc[i][j] = yf32x4{biasn[i].x, biasn[i].y, biasn[i].z, biasn[i].w};
+                    acc[i + 2][j] = yf32x4{0.f, 0.f, 0.f, 0.f};
+                }
+            }
+        };
+        if (a.res_mode == RES_NONE) write_out(std::integral_constant<int, RES_NONE>{});
+        else if (a.res_mode == RES_BEFORE_ACT) write_out(std::integral_constant<int, RES_BEFORE_ACT>{});
+        else write_out(std::integral_constant<int, RES_AFTER_ACT>{});
+
+        if (!has_next) break;
+        if (newtile) {
+            ti += nslot;
+            cur = nxt;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) po[j] = out_pixel(cur, j);
+        }
+        cb = cbn;
+        cbi = newtile ? 0 : cbi + 1;
+#pragma unroll
+        for (int i = 0; i < X8_NWP; ++i) gcur[i] = gnxt[i];
+        wcur = wnxt_item;
+        par = (par + a.nck) & 1;
+    }
+    if (MODE == 1 && !hb) __builtin_amdgcn_s_barrier();   // pairs with group 1's extra barrier
+}
+
+// -------------------------------------------------------------------------------------
+static int x8_mode() {   // ADAS_HALO8_X3: 0 off, 1 on (default: synchronisation variant picked per layer), 2 / 3 force variant 2 / 1
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("ADAS_HALO8_X3");
+        v = e ? atoi(e) : 1;
+    }
+    return v;
+}
+
+static int x8_blocks_per_unit(long tiles8, int ncb) {
+    for (int cpw = ncb; cpw >= 1; --cpw) {
+        if (ncb % cpw) continue;
+        const long units8 = tiles8 * (ncb / cpw), rounds = (units8 + X8_SLOTS - 1) / X8_SLOTS;
+        if (units8 >= X8_SLOTS && (double)units8 / (double)(rounds * X8_SLOTS) >= 0.8) return cpw;
+    }
+    return 0;
+}
+
+// static part (shapes): decides at load time whether a conv also gets the half-chunk weight packing
+bool halo8_x3_shape_ok(int kh, int kw, int stride, int pad, const TView& in, const TView& out) {
+    if (!x8_mode()) return false;
+    if (kh != 3 || kw != 3 || stride != 1 || pad != 1) return false;
+    if (in.f32 || out.f32 || out.h != in.h || out.w != in.w) return false;
+    if ((out.c & 63) || (in.c & 31) || in.c < 32) return false;
+    if ((in.cs & 7) || (in.coff & 7) || (out.cs & 7) || (out.coff & 7)) return false;
+    HaloPlan pl;
+    return plan_halo(out.h, out.w, 1, &pl) && pl.eff >= 0.6 && pl.maxpix <= X8_MAXPIX;
+}
+size_t halo8_x3_weight_bytes(int cout, int cin) { return (size_t)(cout / 32) * (size_t)(2 * (cin / 32)) * X8_SLAB; }
+
+bool halo8_x3_applicable(int kh, int kw, int stride, int pad, int n, const TView& in, const TView& out, const TView& res, int res_mode) {
+    if (!halo8_x3_shape_ok(kh, kw, stride, pad, in, out)) return false;
+    if (res_mode != RES_NONE && ((res.cs & 7) || (res.coff & 7) || res.f32)) return false;
+    if ((double)n * in.h * in.w * in.cs * 4.0 >= (double)X8_OOB || (double)n * out.h * out.w * out.cs * 4.0 >= (double)X8_OOB) return false;
+    if (res_mode != RES_NONE && (double)n * out.h * out.w * res.cs * 4.0 >= (double)X8_OOB) return false;
+    if ((double)halo8_x3_weight_bytes(out.c, in.c) >= (double)X8_OOB) return false;
+    HaloPlan pl;
+    if (!plan_halo(out.h, out.w, 1, &pl)) return false;
+    const long ntiles = (long)n * pl.NS * pl.TPS, tiles8 = (ntiles + 7) / 8;
+    if (ntiles * (out.c / 64) * pl.NS * pl.TPS >= (1L << 32)) return false;
+    return x8_blocks_per_unit(tiles8, out.c / 64) > 0;
+}
+
+// fp32 [cout][9][cin] -> halves [cout / 32][2 * cin / 32][9][64 rows][32]: block b = output channels 32 b .. 32 b + 31;
+// rows 0-31 main, rows 32-63 cross.  H half-chunk (even): main = hi(w), cross = lo(w); L half-chunk (odd): main = 0, cross = hi(w).
+__global__ void pack_weights_h8x3_kernel(const float* __restrict__ src, uint16_t* __restrict__ dst, int cout, int cin, size_t total) {
+    const int nck = 2 * (cin >> 5);
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int k = (int)(i & 31);
+        size_t r = i >> 5;
+        const int row = (int)(r & 63); r >>= 6;
+        const int tap = (int)(r % 9); r /= 9;
+        const int ck = (int)(r % nck);
+        const size_t blk = r / nck;
+        const size_t co = blk * 32 + (row & 31);
+        const int ci = (ck >> 1) * 32 + k;
+        const float w = src[(co * 9 + tap) * cin + ci];
+        _Float16 h, l;
+        x3_split(w, h, l);
+        const bool cross = row >= 32, lo_chunk = (ck & 1) != 0;
+        const _Float16 v = lo_chunk ? (cross ? h : (_Float16)0.0f) : (cross ? l : h);
+        dst[i] = __builtin_bit_cast(uint16_t, v);
+    }
+}
+hipError_t launch_pack_weights_h8x3(const float* src, void* dst, int cout, int cin, hipStream_t st) {
+    if ((cout & 63) || (cin & 31)) return hipErrorInvalidValue;
+    const size_t total = halo8_x3_weight_bytes(cout, cin) / 2;
+    const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+    hipLaunchKernelGGL(pack_weights_h8x3_kernel, dim3(blocks), dim3(256), 0, st, src, (uint16_t*)dst, cout, cin, total);
+    return hipGetLastError();
+}
+
+template <int MODE>
+static hipError_t x8_launch(const H8XDev& d, int act, dim3 grid, hipStream_t st) {
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute((const void*)conv_h8x3_kernel<ACT_NONE, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)conv_h8x3_kernel<ACT_SILU, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)conv_h8x3_kernel<ACT_RELU, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)conv_h8x3_kernel<ACT_LEAKY, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_done = true;
+    }
+    if (act == ACT_SILU) hipLaunchKernelGGL((conv_h8x3_kernel<ACT_SILU, MODE>), grid, dim3(X8_THR), X8_LDS, st, d);
+    else if (act == ACT_RELU) hipLaunchKernelGGL((conv_h8x3_kernel<ACT_RELU, MODE>), grid, dim3(X8_THR), X8_LDS, st, d);
+    else if (act == ACT_LEAKY) hipLaunchKernelGGL((conv_h8x3_kernel<ACT_LEAKY, MODE>), grid, dim3(X8_THR), X8_LDS, st, d);
+    else hipLaunchKernelGGL((conv_h8x3_kernel<ACT_NONE, MODE>), grid, dim3(X8_THR), X8_LDS, st, d);
+    return hipGetLastError();
+}
+
+hipError_t launch_conv_halo8_x3(const ConvArgs& a, hipStream_t st) {
+    HaloPlan pl;
+    if (!a.wgt_h8x3 || !halo8_x3_applicable(a.kh, a.kw, a.stride, a.pad, a.n, a.in, a.out, a.res, a.res_mode) || !plan_halo(a.out.h, a.out.w, 1, &pl))
+        return hipErrorNotSupported;
+    H8XDev d;
+    d.in = a.in.p; d.wgt = a.wgt_h8x3; d.bias = a.bias; d.out = a.out.p; d.res = a.res.p;
+    d.in_cs = a.in.cs; d.in_coff = a.in.coff; d.cin = a.in.c; d.H = a.in.h; d.W = a.in.w;
+    d.out_cs = a.out.cs; d.out_coff = a.out.coff; d.cout = a.out.c;
+    d.res_cs = a.res.cs; d.res_coff = a.res.coff; d.res_mode = a.res_mode;
+    d.nck = 2 * (a.in.c / 32);
+    d.in_bytes = (uint32_t)((size_t)a.n * a.in.h * a.in.w * a.in.cs * 4);
+    d.wgt_bytes = (uint32_t)halo8_x3_weight_bytes(a.out.c, a.in.c);
+    d.out_bytes = (uint32_t)((size_t)a.n * a.out.h * a.out.w * a.out.cs * 4);
+    d.res_bytes = a.res_mode != RES_NONE ? (uint32_t)((size_t)a.n * a.out.h * a.out.w * a.res.cs * 4) : 0u;
+    d.SW = pl.SW; d.NS = pl.NS; d.TPS = pl.TPS; d.WW = pl.WW;
+    d.mg_ww = pl.mg_ww; d.mg_sw = pl.mg_sw;
+    d.mg_img = (uint32_t)(((1ull << 32) + (uint64_t)(pl.NS * pl.TPS) - 1) / (uint64_t)(pl.NS * pl.TPS));
+    d.mg_tps = (uint32_t)(((1ull << 32) + (uint64_t)pl.TPS - 1) / (uint64_t)pl.TPS);
+    d.ntiles = a.n * pl.NS * pl.TPS;
+    d.tiles8 = (d.ntiles + 7) / 8;
+    d.ncb = a.out.c / 64;
+    d.cpw = x8_blocks_per_unit(d.tiles8, d.ncb);
+    if (d.cpw <= 0) return hipErrorNotSupported;
+    const int upt = d.ncb / d.cpw;
+    d.mg_upt = (uint32_t)(((1ull << 32) + (uint64_t)upt - 1) / (uint64_t)upt);
+    const int units8 = d.tiles8 * upt;
+    const int slots = units8 < X8_SLOTS ? units8 : X8_SLOTS;
+    dim3 grid(8 * slots);
+    const int forced = x8_mode();
+    const bool pingpong = forced == 3 || (forced != 2 && d.nck >= 24);
+    return pingpong ? x8_launch<1>(d, a.act, grid, st) : x8_launch<2>(d, a.act, grid, st);
+}
+
+}  // namespace adas

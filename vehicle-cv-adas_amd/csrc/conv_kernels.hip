@@ -312,6 +312,13 @@ const char* conv_tile_name(const ConvArgs& a, int prec) {
 // Name of the kernel instantiation a conv launch resolves to (as rocprofv3 --kernel-trace prints it, minus namespaces).
 const char* conv_kernel_name(const ConvArgs& a, int prec, int kernel) {
     static thread_local char buf[96];
+    if (prec == PREC_X3) {
+        if (a.wgt_h8x3 && halo8_x3_applicable(a.kh, a.kw, a.stride, a.pad, a.n, a.in, a.out, a.res, a.res_mode)) {
+            snprintf(buf, sizeof(buf), "conv_h8x3_kernel<%s>", a.act == ACT_SILU ? "SILU" : (a.act == ACT_RELU ? "RELU" : (a.act == ACT_LEAKY ? "LEAKY" : "NONE")));
+            return buf;
+        }
+        return conv_x3_kernel_name(a);
+    }
     const char* actn = a.act == ACT_SILU ? "SILU" : (a.act == ACT_RELU ? "RELU" : (a.act == ACT_LEAKY ? "LEAKY" : "NONE"));
     if (kernel == CONV_HALO && halo_rw_applicable(a.kh, a.kw, a.stride, a.pad, a.n, a.in, a.out)) {
         snprintf(buf, sizeof(buf), a.out.c <= 32 ? "conv_halo_rw_kernel<%d,%s,bn32>" : "conv_halo_rw_kernel<%d,%s>", (a.in.c + 31) / 32, actn);
@@ -393,6 +400,12 @@ static bool fc_enabled() {
 
 ConvPlan plan_conv(int prec, int kh, int kw, int stride, int pad, int max_n, int res_mode, const TView& in, const TView& out) {
     ConvPlan p;
+    if (prec == PREC_X3) {   // split precision: one generic kernel (conv_x3.hip), K = (tap, channel) in G8 groups
+        p.kernel = CONV_GATHER;
+        p.cin_pad = in.c;
+        p.kpad = (kh * kw * p.cin_pad + 31) / 32 * 32;
+        return p;
+    }
     if (fc_enabled() && fc_applicable(prec, kh, kw, stride, max_n, in, out)) {
         p.kernel = CONV_FC;
         p.cin_pad = in.c;
@@ -413,6 +426,14 @@ ConvPlan plan_conv(int prec, int kh, int kw, int stride, int pad, int max_n, int
 hipError_t launch_conv(const ConvArgs& a, int prec, hipStream_t st) {
     ConvPlan pl = plan_conv(prec, a.kh, a.kw, a.stride, a.pad, a.max_n, a.res_mode, a.in, a.out);
     if (pl.kpad != a.kpad) return hipErrorInvalidValue;  // weights were packed for a different plan
+    if (prec == PREC_X3) {
+        if (a.up_c > 0 || a.ds_w) return hipErrorInvalidValue;
+        if (a.wgt_h8x3 && halo8_x3_applicable(a.kh, a.kw, a.stride, a.pad, a.n, a.in, a.out, a.res, a.res_mode)) {
+            hipError_t e = launch_conv_halo8_x3(a, st);
+            if (e != hipErrorNotSupported) return e;
+        }
+        return launch_conv_x3(a, st);
+    }
     if (a.up_c > 0 && pl.kernel != CONV_PW) return hipErrorInvalidValue;   // only conv_pw fetches the folded upsample's channels
     if (a.ds_w) {   // the engine dropped the projection's launch: only conv_halo8 computes it inside this conv
         if (pl.kernel != CONV_HALO) return hipErrorInvalidValue;
@@ -501,6 +522,7 @@ hipError_t launch_pack_weights_halo(const float* src, void* dst, int cout, int c
 
 hipError_t launch_pack_weights(const float* src, void* dst, int cout, int cout_pad, int taps, int cin, int cin_pad, int kpad, int prec,
                                hipStream_t st) {
+    if (prec == PREC_X3) return launch_pack_weights_x3(src, dst, cout, cout_pad, taps, cin, cin_pad, kpad, st);
     size_t total = (size_t)cout_pad * kpad;
     int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
     if (prec == PREC_FP32)

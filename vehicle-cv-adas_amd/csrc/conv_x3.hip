@@ -1,0 +1,308 @@
+// conv_x3.hip -- the convolution of the split precision (ADAS_PREC_FP16X3): f32-class results on the 16-bit matrix cores.
+//
+//   out[m][co] = act( bias[co] + sum_k a[m][k] * w[co][k] ) (+ residual),   a = a_hi + 2^-11 a_lo,  w = w_hi + 2^-11 w_lo  (elem16.h)
+//   sum a*w = sum a_hi*w_hi  +  2^-11 ( sum a_hi*w_lo + sum a_lo*w_hi )      [the a_lo*w_lo term is 2^-22 of a product: dropped]
+//
+// Three v_mfma_f32_16x16x32_f16 per (fragment pair, 32-deep K step) into TWO fp32 accumulator sets -- `main` (hi*hi) and `cross`
+// (hi*lo + lo*hi, both carrying the same 2^11 scale) -- combined once in the epilogue.  Products of two halves are exact in fp32, so
+// what is lost against an f32 convolution is the 2^-22 representation of the operands and the dropped lo*lo term: the parity mode's
+// error class at 3/16 of its MFMA cost (the f32-input MFMA runs at 1/16 of the 16-bit rate: ADAS_PREC_FP32).
+//
+// This file: the GENERIC kernel (any kernel size / stride / channel count multiple of 8), the implicit-GEMM structure of
+// conv_kernels.hip with both halves of every operand staged -- per 32-deep K step a workgroup (4 waves) gathers the BM x 32
+// activation slab and the BN x 32 weight slab, each as a hi and a lo plane, into padded LDS rows; a wave's K step is 12 fragment
+// reads for 24 MFMAs.  Storage is the G8 layout of elem16.h (a K chunk of 8 channels = 16 bytes of hi + 16 bytes of lo, adjacent),
+// for activations and for the packed weights alike.
+#include "kernels.h"
+#include "elem16.h"
+#include <stdlib.h>
+
+namespace adas {
+
+typedef __attribute__((ext_vector_type(4))) float xf32x4;
+
+struct X3Dev {
+    const void* in;
+    const void* wgt;
+    const float* bias;
+    void* out;
+    const void* res;
+    int in_cs, in_coff, cin, H, W;
+    int out_cs, out_coff, cout, Ho, Wo;
+    int res_cs, res_coff, res_mode;
+    int kh, kw, stride, pad, act;
+    int nq, kpad, M;
+};
+
+#define ADAS_X3_MAX_Q 1152   // K / 8 chunks (conv_kernels.hip ADAS_MAX_Q)
+
+__device__ __forceinline__ float x3_act(float v, int act) {
+    if (act == ACT_SILU) return v / (1.0f + expf(-v));
+    if (act == ACT_RELU) return fmaxf(v, 0.0f);
+    if (act == ACT_LEAKY) return fmaxf(v, 0.1f * v);
+    return v;
+}
+
+template <int BM, int BN, int WM, int WN, bool OUT_F32>
+__global__ __launch_bounds__(256) void conv_x3_igemm_kernel(X3Dev a) {
+    Fp16::enter();
+    constexpr int LDK = 40;   // 32 halves + 8 of padding: 80-byte rows, conflict-free ds_read_b128
+    constexpr int TM = BM / WM / 16, TN = BN / WN / 16;
+    constexpr int A_IT = (BM * 4 + 255) / 256, B_IT = (BN * 4 + 255) / 256;
+    static_assert(WM * WN == 4 && TM >= 1 && TN >= 1, "tile");
+    __shared__ __attribute__((aligned(16))) uint16_t Ah[2][BM][LDK], Al[2][BM][LDK];
+    __shared__ __attribute__((aligned(16))) uint16_t Bh[2][BN][LDK], Bl[2][BN][LDK];
+    __shared__ uint16_t ktab[ADAS_X3_MAX_Q];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+    const x3s* __restrict__ in = (const x3s*)a.in;
+    const x3s* __restrict__ wgt = (const x3s*)a.wgt;
+
+    // K chunk table: q -> (r, s, c8), 3 + 3 + 10 bits
+    const int cin8 = a.cin >> 3;
+    for (int q = tid; q < a.nq; q += 256) {
+        int tap = q / cin8, c8 = q - tap * cin8;
+        int r = tap / a.kw, s = tap - r * a.kw;
+        ktab[q] = (uint16_t)((r << 13) | (s << 10) | c8);
+    }
+    const int kc = tid & 3;
+    int iy0[A_IT], ix0[A_IT], pb[A_IT];
+#pragma unroll
+    for (int i = 0; i < A_IT; ++i) {
+        int row = (tid >> 2) + 64 * i;
+        int m = m0 + row;
+        bool ok = (row < BM) && (m < a.M);
+        int mm = ok ? m : 0;
+        int hw = a.Ho * a.Wo;
+        int n = mm / hw, rem = mm - n * hw;
+        int oy = rem / a.Wo, ox = rem - oy * a.Wo;
+        iy0[i] = oy * a.stride - a.pad;
+        ix0[i] = ox * a.stride - a.pad;
+        pb[i] = ok ? n * a.H * a.W : -1;
+    }
+    __syncthreads();
+
+    const int KT = a.kpad >> 5;
+    e_u32x4 rah[A_IT], ral[A_IT], rbh[B_IT], rbl[B_IT];
+    const e_u32x4 zero4 = {0u, 0u, 0u, 0u};
+
+    auto gload = [&](int ks) {
+        const int q = ks * 4 + kc;
+        int r = 0, s = 0, c8 = 0;
+        const bool qok = q < a.nq;
+        if (qok) {
+            int e = ktab[q];
+            r = e >> 13;
+            s = (e >> 10) & 7;
+            c8 = e & 1023;
+        }
+#pragma unroll
+        for (int i = 0; i < A_IT; ++i) {
+            int iy = iy0[i] + r, ix = ix0[i] + s;
+            bool ok = qok && pb[i] >= 0 && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+            // always-valid address + select (a branch around the load would serialise the A_IT loads on vmcnt(0))
+            const size_t pix = ok ? (size_t)(pb[i] + iy * a.W + ix) : 0;
+            const e_u32x4* g = reinterpret_cast<const e_u32x4*>(in + (pix * a.in_cs + a.in_coff + c8 * 8));
+            const e_u32x4 h = g[0], l = g[1];
+            rah[i] = ok ? h : zero4;
+            ral[i] = ok ? l : zero4;
+        }
+#pragma unroll
+        for (int i = 0; i < B_IT; ++i) {
+            int row = (tid >> 2) + 64 * i;
+            if (row < BN) {
+                const e_u32x4* g = reinterpret_cast<const e_u32x4*>(wgt + ((size_t)(n0 + row) * a.kpad + ks * 32 + kc * 8));
+                rbh[i] = g[0];
+                rbl[i] = g[1];
+            }
+        }
+    };
+    auto lstore = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < A_IT; ++i) {
+            int row = (tid >> 2) + 64 * i;
+            if (row < BM) {
+                *reinterpret_cast<e_u32x4*>(&Ah[buf][row][kc * 8]) = rah[i];
+                *reinterpret_cast<e_u32x4*>(&Al[buf][row][kc * 8]) = ral[i];
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < B_IT; ++i) {
+            int row = (tid >> 2) + 64 * i;
+            if (row < BN) {
+                *reinterpret_cast<e_u32x4*>(&Bh[buf][row][kc * 8]) = rbh[i];
+                *reinterpret_cast<e_u32x4*>(&Bl[buf][row][kc * 8]) = rbl[i];
+            }
+        }
+    };
+
+    xf32x4 accm[TN][TM], accx[TN][TM];
+#pragma unroll
+    for (int i = 0; i < TN; ++i)
+#pragma unroll
+        for (int j = 0; j < TM; ++j) accm[i][j] = accx[i][j] = xf32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int lrow = lane & 15, kg = lane >> 4;
+    gload(0);
+    lstore(0);
+    __syncthreads();
+    for (int ks = 0; ks < KT; ++ks) {
+        const int buf = ks & 1;
+        if (ks + 1 < KT) gload(ks + 1);
+        e_u32x4 wh[TN], wl[TN], xh[TM], xl[TM];
+#pragma unroll
+        for (int i = 0; i < TN; ++i) {
+            wh[i] = *reinterpret_cast<const e_u32x4*>(&Bh[buf][(wn * TN + i) * 16 + lrow][kg * 8]);
+            wl[i] = *reinterpret_cast<const e_u32x4*>(&Bl[buf][(wn * TN + i) * 16 + lrow][kg * 8]);
+        }
+#pragma unroll
+        for (int j = 0; j < TM; ++j) {
+            xh[j] = *reinterpret_cast<const e_u32x4*>(&Ah[buf][(wm * TM + j) * 16 + lrow][kg * 8]);
+            xl[j] = *reinterpret_cast<const e_u32x4*>(&Al[buf][(wm * TM + j) * 16 + lrow][kg * 8]);
+        }
+        // three passes over the tile grid: the two MFMAs into one cross accumulator are TM * TN instructions apart (no dependent stall)
+#pragma unroll
+        for (int i = 0; i < TN; ++i)
+#pragma unroll
+            for (int j = 0; j < TM; ++j) accm[i][j] = Fp16::mfma(wh[i], xh[j], accm[i][j]);
+#pragma unroll
+        for (int i = 0; i < TN; ++i)
+#pragma unroll
+            for (int j = 0; j < TM; ++j) accx[i][j] = Fp16::mfma(wl[i], xh[j], accx[i][j]);
+#pragma unroll
+        for (int i = 0; i < TN; ++i)
+#pragma unroll
+            for (int j = 0; j < TM; ++j) accx[i][j] = Fp16::mfma(wh[i], xl[j], accx[i][j]);
+        if (ks + 1 < KT) lstore(buf ^ 1);
+        __syncthreads();
+    }
+
+    // ---- fused epilogue: lane holds channels c..c+3 of pixel m
+    const bool vec_ok = ((a.cout & 3) == 0) && ((a.out_cs & 3) == 0) && ((a.out_coff & 3) == 0);
+#pragma unroll
+    for (int j = 0; j < TM; ++j) {
+        const int m = m0 + (wm * TM + j) * 16 + lrow;
+        if (m >= a.M) continue;
+#pragma unroll
+        for (int i = 0; i < TN; ++i) {
+            const int c = n0 + (wn * TN + i) * 16 + kg * 4;
+            if (c >= a.cout) continue;
+            float v[4];
+            const float4 b = *reinterpret_cast<const float4*>(a.bias + c);   // bias is padded to 128
+            const float bb[4] = {b.x, b.y, b.z, b.w};
+#pragma unroll
+            for (int t = 0; t < 4; ++t) v[t] = (accm[i][j][t] + accx[i][j][t] * kX3Down) + bb[t];
+            if (a.res_mode != RES_NONE) {
+                float rv[4];
+                x3_load4((const x3s*)a.res + ((size_t)m * a.res_cs + a.res_coff + c), rv);
+                if (a.res_mode == RES_BEFORE_ACT) {
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) v[t] = x3_act(v[t] + rv[t], a.act);
+                } else {
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) v[t] = x3_act(v[t], a.act) + rv[t];
+                }
+            } else {
+#pragma unroll
+                for (int t = 0; t < 4; ++t) v[t] = x3_act(v[t], a.act);
+            }
+            const size_t o = (size_t)m * a.out_cs + a.out_coff + c;
+            if (OUT_F32) {
+                float* op = (float*)a.out + o;
+                if (vec_ok && c + 3 < a.cout) {
+                    *reinterpret_cast<float4*>(op) = make_float4(v[0], v[1], v[2], v[3]);
+                } else {
+#pragma unroll
+                    for (int t = 0; t < 4; ++t)
+                        if (c + t < a.cout) op[t] = v[t];
+                }
+            } else {
+                x3s* op = (x3s*)a.out + o;
+                if (vec_ok && c + 3 < a.cout) {
+                    x3_store4(op, v);
+                } else {
+#pragma unroll
+                    for (int t = 0; t < 4; ++t)
+                        if (c + t < a.cout) x3_st(op + t, v[t]);
+                }
+            }
+        }
+    }
+}
+
+struct X3Tile {
+    int bm, bn;
+};
+static X3Tile x3_pick_tile(const ConvArgs& a) {
+    const int bn = a.out.c <= 16 ? 16 : (a.out.c <= 32 ? 32 : 64);
+    const long tiles128 = (long)((a.m + 127) / 128) * ((a.out.c + bn - 1) / bn);
+    return X3Tile{(tiles128 >= 512 && a.m > 64) ? 128 : 64, bn};
+}
+
+const char* conv_x3_kernel_name(const ConvArgs& a) {
+    static thread_local char buf[64];
+    const X3Tile t = x3_pick_tile(a);
+    snprintf(buf, sizeof(buf), "conv_x3_igemm_kernel<%d,%d%s>", t.bm, t.bn, a.out.f32 ? ",f32" : "");
+    return buf;
+}
+
+template <bool OUT_F32>
+static hipError_t launch_x3_typed(const X3Dev& d, X3Tile t, hipStream_t st) {
+    dim3 grid((d.M + t.bm - 1) / t.bm, (d.cout + t.bn - 1) / t.bn);
+#define LAUNCH(BM_, BN_, WM_, WN_)                                                                           \
+    if (t.bm == BM_ && t.bn == BN_) {                                                                         \
+        hipLaunchKernelGGL((conv_x3_igemm_kernel<BM_, BN_, WM_, WN_, OUT_F32>), grid, dim3(256), 0, st, d);   \
+        return hipGetLastError();                                                                             \
+    }
+    LAUNCH(128, 64, 2, 2)
+    LAUNCH(128, 32, 4, 1)
+    LAUNCH(128, 16, 4, 1)
+    LAUNCH(64, 64, 2, 2)
+    LAUNCH(64, 32, 2, 2)
+    LAUNCH(64, 16, 4, 1)
+#undef LAUNCH
+    return hipErrorInvalidValue;
+}
+
+hipError_t launch_conv_x3(const ConvArgs& a, hipStream_t st) {
+    X3Dev d;
+    d.in = a.in.p; d.wgt = a.wgt; d.bias = a.bias; d.out = a.out.p; d.res = a.res.p;
+    d.in_cs = a.in.cs; d.in_coff = a.in.coff; d.cin = a.in.c; d.H = a.in.h; d.W = a.in.w;
+    d.out_cs = a.out.cs; d.out_coff = a.out.coff; d.cout = a.out.c; d.Ho = a.out.h; d.Wo = a.out.w;
+    d.res_cs = a.res.cs; d.res_coff = a.res.coff; d.res_mode = a.res_mode;
+    d.kh = a.kh; d.kw = a.kw; d.stride = a.stride; d.pad = a.pad; d.act = a.act;
+    d.nq = a.k / 8; d.kpad = a.kpad; d.M = a.m;
+    if (d.nq > ADAS_X3_MAX_Q || (a.in.c & 7) || (a.in.cs & 7) || (a.in.coff & 7) || a.in.c > 8184 || a.kh > 7 || a.kw > 7) return hipErrorInvalidValue;
+    if (a.in.f32) return hipErrorInvalidValue;                       // conv inputs are always in the compute type
+    if (!a.out.f32 && ((a.out.cs | a.out.coff) & 7)) return hipErrorInvalidValue;   // G8 groups: 8-channel aligned views
+    if (a.res_mode != RES_NONE && (a.res.f32 || ((a.res.cs | a.res.coff) & 7))) return hipErrorInvalidValue;
+    const X3Tile t = x3_pick_tile(a);
+    return a.out.f32 ? launch_x3_typed<true>(d, t, st) : launch_x3_typed<false>(d, t, st);
+}
+
+// fp32 [cout][taps][cin] -> G8 [cout_pad][kpad / 8][hi 8 | lo 8], element (row, tap * cin_pad + c), zero padded
+__global__ void pack_weights_x3_kernel(const float* __restrict__ src, uint16_t* __restrict__ dst, int cout, int taps, int cin, int cin_pad, int kpad,
+                                       size_t total) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t row = i / kpad;
+        const int col = (int)(i - row * kpad);
+        const int tap = col / cin_pad, c = col - tap * cin_pad;
+        const float v = (row < (size_t)cout && tap < taps && c < cin) ? src[(row * taps + tap) * cin + c] : 0.0f;
+        _Float16 h, l;
+        x3_split(v, h, l);
+        const size_t g = (i >> 3) * 16 + (i & 7);
+        dst[g] = __builtin_bit_cast(uint16_t, h);
+        dst[g + 8] = __builtin_bit_cast(uint16_t, l);
+    }
+}
+hipError_t launch_pack_weights_x3(const float* src, void* dst, int cout, int cout_pad, int taps, int cin, int cin_pad, int kpad, hipStream_t st) {
+    if (kpad & 7) return hipErrorInvalidValue;
+    const size_t total = (size_t)cout_pad * kpad;
+    const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+    hipLaunchKernelGGL(pack_weights_x3_kernel, dim3(blocks), dim3(256), 0, st, src, (uint16_t*)dst, cout, taps, cin, cin_pad, kpad, total);
+    return hipGetLastError();
+}
+
+}  // namespace adas

@@ -50,6 +50,11 @@ template <> struct Vec8<float> {
     }
 };
 
+template <> struct Vec8<x3s> {   // split precision: one G8 group (elem16.h)
+    static __device__ __forceinline__ void load(const x3s* p, float v[8]) { x3_load8(p, v); }
+    static __device__ __forceinline__ void store(x3s* p, const float v[8]) { x3_store8(p, v); }
+};
+
 struct DwDev {
     const void* in;
     void* out;
@@ -129,6 +134,7 @@ hipError_t launch_dwconv(const TView& in, const TView& out, const TView& res, in
     const size_t total = (size_t)n * out.h * out.w * (in.c >> 3);
     const int blocks = (int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
     if (prec == PREC_FP32) hipLaunchKernelGGL(dwconv_kernel<float>, dim3(blocks), dim3(256), 0, st, d);
+    else if (prec == PREC_X3) hipLaunchKernelGGL(dwconv_kernel<x3s>, dim3(blocks), dim3(256), 0, st, d);
     else if (prec == PREC_FP16) hipLaunchKernelGGL(dwconv_kernel<f16s>, dim3(blocks), dim3(256), 0, st, d);
     else hipLaunchKernelGGL(dwconv_kernel<uint16_t>, dim3(blocks), dim3(256), 0, st, d);
     return hipGetLastError();
@@ -154,6 +160,8 @@ template <typename T> __device__ __forceinline__ void at_st(T* p, float v);
 template <> __device__ __forceinline__ void at_st<float>(float* p, float v) { *p = v; }
 template <> __device__ __forceinline__ void at_st<uint16_t>(uint16_t* p, float v) { *p = Bf16::from_f32(v); }
 template <> __device__ __forceinline__ void at_st<f16s>(f16s* p, float v) { p->v = Fp16::from_f32(v); }
+template <> __device__ __forceinline__ float at_ld<x3s>(const x3s* p) { return x3_ld(p); }
+template <> __device__ __forceinline__ void at_st<x3s>(x3s* p, float v) { x3_st(p, v); }
 
 // grid (ceil(N / AT_THR), nh, batch); thread = one query token
 template <typename T>
@@ -347,6 +355,7 @@ hipError_t launch_attention(const TView& qkv, const TView& out, int n, int nh, i
     }
     const bool aligned = !((qkv.cs | qkv.coff) & 7) && !((out.cs | out.coff) & 3);
     if (prec == PREC_FP32) hipLaunchKernelGGL(attention_kernel<float>, grid, dim3(AT_THR), 0, st, a);
+    else if (prec == PREC_X3) hipLaunchKernelGGL(attention_kernel<x3s>, grid, dim3(AT_THR), 0, st, a);   // fp32 arithmetic on the joined values
     else if (mfma && aligned) {
         const dim3 g2((a.N + 63) / 64, nh, n);
         if (prec == PREC_FP16) hipLaunchKernelGGL(attention_mfma_kernel<Fp16>, g2, dim3(256), 0, st, a);

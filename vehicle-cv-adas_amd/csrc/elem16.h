@@ -80,6 +80,93 @@ struct Fp16 {
     static inline uint16_t host_from_f32(float f) { return __builtin_bit_cast(uint16_t, (_Float16)f); }
 };
 
+// ---- split precision (ADAS_PREC_FP16X3, kernels.h PREC_X3) ------------------------------------------------------------------
+// A value x (f32) is carried as two halves: hi = half(x) and lo = half((x - hi) * 2^11), i.e. x = hi + lo * 2^-11 to 22 significant
+// bits (x - hi is exact in f32; the scale keeps lo a NORMAL half whatever the magnitude of x).  A product of two such values is
+//     a * w = a_hi * w_hi + 2^-11 (a_hi * w_lo + a_lo * w_hi) + O(2^-22),
+// three f16 MFMAs into two fp32 accumulator sets (main, cross) that the epilogue combines: main + cross * 2^-11.
+// Storage ("G8"): NHWC with 4 bytes per channel; every aligned group of 8 channels is 32 bytes = [8 hi halves][8 lo halves], so a
+// lane's MFMA fragment (8 consecutive channels of one pixel) is one 16-byte load for hi and one for lo.  `x3s*` addresses channel
+// SLOTS of 4 bytes (pointer arithmetic like float*); buffers are 256-byte aligned and pixel strides / view offsets multiples of 8
+// channels, so the group a slot belongs to follows from its address.
+struct x3s {
+    uint32_t slot;
+};
+constexpr float kX3Up = 2048.0f, kX3Down = 1.0f / 2048.0f;
+
+__host__ __device__ __forceinline__ void x3_split(float x, _Float16& h, _Float16& l) {
+    _Float16 hh = (_Float16)x;
+    if (!(x >= 6.103515625e-05f || x <= -6.103515625e-05f)) hh = (_Float16)0.0f;   // no subnormal hi: the value moves into lo
+    h = hh;
+    l = (_Float16)((x - (float)hh) * kX3Up);
+}
+__host__ __device__ __forceinline__ float x3_join(_Float16 h, _Float16 l) { return (float)h + (float)l * kX3Down; }
+
+#if defined(__HIPCC__)
+// one slot (any channel): the group's base is the address rounded down to 32 bytes
+__device__ __forceinline__ float x3_ld(const x3s* p) {
+    const uintptr_t a = reinterpret_cast<uintptr_t>(p);
+    const _Float16* g = reinterpret_cast<const _Float16*>(a & ~(uintptr_t)31);
+    const int w = (int)((a & 31) >> 2);
+    return x3_join(g[w], g[8 + w]);
+}
+__device__ __forceinline__ void x3_st(x3s* p, float v) {
+    const uintptr_t a = reinterpret_cast<uintptr_t>(p);
+    _Float16* g = reinterpret_cast<_Float16*>(a & ~(uintptr_t)31);
+    const int w = (int)((a & 31) >> 2);
+    _Float16 h, l;
+    x3_split(v, h, l);
+    g[w] = h;
+    g[8 + w] = l;
+}
+// 4 consecutive channels starting at a multiple of 4 (the conv epilogues' lane ownership): 8 bytes of hi + 8 bytes of lo
+__device__ __forceinline__ void x3_load4(const x3s* p, float v[4]) {
+    const uintptr_t a = reinterpret_cast<uintptr_t>(p);
+    const unsigned char* g = reinterpret_cast<const unsigned char*>(a & ~(uintptr_t)31) + ((a & 31) >> 1);
+    const uint2 h = *reinterpret_cast<const uint2*>(g), l = *reinterpret_cast<const uint2*>(g + 16);
+    const e_f16x2 h0 = __builtin_bit_cast(e_f16x2, h.x), h1 = __builtin_bit_cast(e_f16x2, h.y);
+    const e_f16x2 l0 = __builtin_bit_cast(e_f16x2, l.x), l1 = __builtin_bit_cast(e_f16x2, l.y);
+    v[0] = x3_join(h0[0], l0[0]); v[1] = x3_join(h0[1], l0[1]); v[2] = x3_join(h1[0], l1[0]); v[3] = x3_join(h1[1], l1[1]);
+}
+__device__ __forceinline__ void x3_store4(x3s* p, const float v[4]) {
+    const uintptr_t a = reinterpret_cast<uintptr_t>(p);
+    unsigned char* g = reinterpret_cast<unsigned char*>(a & ~(uintptr_t)31) + ((a & 31) >> 1);
+    e_f16x2 h0, h1, l0, l1;
+    _Float16 h, l;
+    x3_split(v[0], h, l); h0[0] = h; l0[0] = l;
+    x3_split(v[1], h, l); h0[1] = h; l0[1] = l;
+    x3_split(v[2], h, l); h1[0] = h; l1[0] = l;
+    x3_split(v[3], h, l); h1[1] = h; l1[1] = l;
+    *reinterpret_cast<uint2*>(g) = make_uint2(__builtin_bit_cast(uint32_t, h0), __builtin_bit_cast(uint32_t, h1));
+    *reinterpret_cast<uint2*>(g + 16) = make_uint2(__builtin_bit_cast(uint32_t, l0), __builtin_bit_cast(uint32_t, l1));
+}
+// a whole group (p: 8-channel aligned slot)
+__device__ __forceinline__ void x3_load8(const x3s* p, float v[8]) {
+    const uint4 h = reinterpret_cast<const uint4*>(p)[0], l = reinterpret_cast<const uint4*>(p)[1];
+    const uint32_t hw[4] = {h.x, h.y, h.z, h.w}, lw[4] = {l.x, l.y, l.z, l.w};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const e_f16x2 hh = __builtin_bit_cast(e_f16x2, hw[k]), ll = __builtin_bit_cast(e_f16x2, lw[k]);
+        v[2 * k] = x3_join(hh[0], ll[0]);
+        v[2 * k + 1] = x3_join(hh[1], ll[1]);
+    }
+}
+__device__ __forceinline__ void x3_store8(x3s* p, const float v[8]) {
+    uint32_t hw[4], lw[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        e_f16x2 hh, ll;
+        _Float16 h, l;
+        x3_split(v[2 * k], h, l); hh[0] = h; ll[0] = l;
+        x3_split(v[2 * k + 1], h, l); hh[1] = h; ll[1] = l;
+        hw[k] = __builtin_bit_cast(uint32_t, hh);
+        lw[k] = __builtin_bit_cast(uint32_t, ll);
+    }
+    reinterpret_cast<uint4*>(p)[0] = make_uint4(hw[0], hw[1], hw[2], hw[3]);
+    reinterpret_cast<uint4*>(p)[1] = make_uint4(lw[0], lw[1], lw[2], lw[3]);
+}
+#endif
+
 // Run `fn(tag)` with the element tag of a 16-bit engine precision (PREC_FP16 -> Fp16, otherwise Bf16).
 #define ADAS_DISPATCH_E16(is_half, E, ...) \
     do {                                   \

@@ -13,7 +13,7 @@
 
 using namespace adas;
 
-static size_t elem_size(const adas_engine* e, const EngBuf& b) { return (b.f32 || e->prec == PREC_FP32) ? 4 : 2; }
+static size_t elem_size(const adas_engine* e, const EngBuf& b) { return b.f32 ? 4 : (size_t)prec_esize(e->prec); }   // split precision: a (hi, lo) pair
 
 static TView make_view(const adas_engine* e, int buf, int coff, int c) {
     const EngBuf& b = e->bufs[buf];
@@ -72,8 +72,8 @@ extern "C" {
 
 int adas_engine_create(const char* model_path, int precision, int max_batch, adas_engine** out) {
     ADAS_REQUIRE(model_path && out && max_batch > 0, ADAS_ERR_INVALID, "adas_engine_create: bad argument");
-    ADAS_REQUIRE(precision == ADAS_PREC_BF16 || precision == ADAS_PREC_FP32 || precision == ADAS_PREC_FP16, ADAS_ERR_INVALID, "unknown precision %d",
-                 precision);
+    ADAS_REQUIRE(precision == ADAS_PREC_BF16 || precision == ADAS_PREC_FP32 || precision == ADAS_PREC_FP16 || precision == ADAS_PREC_FP16X3,
+                 ADAS_ERR_INVALID, "unknown precision %d", precision);
     FILE* f = fopen(model_path, "rb");
     if (!f) {  // coreEngine.py:12-13
         set_error("The model path [%s] can't not found! (%s)", model_path, strerror(errno));
@@ -144,6 +144,14 @@ int adas_engine_create(const char* model_path, int precision, int max_batch, ada
             return ADAS_ERR_FORMAT;
         }
     }
+    if (precision == PREC_X3)   // the G8 layout groups 8 channels: every 16-bit tensor of the graph must be a whole number of groups
+        for (size_t bi = 0; bi < e->bufs.size(); ++bi)
+            if (!e->bufs[bi].f32 && (e->bufs[bi].c & 7)) {
+                fclose(f);
+                free_engine(e);
+                set_error("[%s]: buffer %zu has %d channels: the split precision (fp16x3) needs multiples of 8", model_path, bi, e->bufs[bi].c);
+                return ADAS_ERR_FORMAT;
+            }
     for (auto& b : e->bufs) {
         if (b.alias_of >= 0) continue;
         size_t bytes = (size_t)max_batch * b.h * b.w * b.c * elem_size(e, b);
@@ -182,7 +190,7 @@ int adas_engine_create(const char* model_path, int precision, int max_batch, ada
     }
     // ---- weights: stream the fp32 blob through a staging buffer, pack on the device
     size_t packed_total = 0;
-    const size_t esz = precision == PREC_FP32 ? 4 : 2;
+    const size_t esz = (size_t)prec_esize(precision);
     for (auto& o : fo) {
         EngOp op;
         op.f = o;
@@ -493,6 +501,12 @@ int adas_engine_create(const char* model_path, int precision, int max_batch, ada
                 packed_total += ((size_t)op.cout_pad * 4 + 255) & ~(size_t)255;
                 continue;
             }
+            if (precision == PREC_X3 && halo8_x3_shape_ok(o.kh, o.kw, o.stride, o.pad, make_view(e, o.in_buf[0], o.in_coff[0], o.in_c[0]),
+                                                          make_view(e, o.out_buf, o.out_coff, o.out_c))) {
+                op.has_x3h8 = true;   // the batch decides at launch which of the two packings runs
+                op.x3h8_w_off = packed_total;
+                packed_total += (halo8_x3_weight_bytes(cout, cin) + 255) & ~(size_t)255;
+            }
             if (op.ds_user >= 0) {   // second copy of the projection weights, as per-step tiles
                 op.ds_w_off = packed_total;
                 packed_total += ((size_t)cout * cin * esz + 255) & ~(size_t)255;
@@ -600,6 +614,7 @@ int adas_engine_create(const char* model_path, int precision, int max_batch, ada
                                 : op.kernel == CONV_HALO
                                 ? launch_pack_weights_halo(d_stage, base + op.w_off, o.out_c, op.cout_pad, o.in_c[0], op.cin_pad, precision, 0)
                                 : launch_pack_weights(d_stage, base + op.w_off, o.out_c, op.cout_pad, o.kh * o.kw, o.in_c[0], op.cin_pad, op.kpad, precision, 0);
+            if (pe == hipSuccess && op.has_x3h8) pe = launch_pack_weights_h8x3(d_stage, base + op.x3h8_w_off, o.out_c, o.in_c[0], 0);
             if (pe == hipSuccess && op.ds_user >= 0) pe = launch_pack_weights_ds(d_stage, base + op.ds_w_off, o.out_c, o.in_c[0], precision, 0);
             if (pe != hipSuccess) { rc = ADAS_ERR_HIP; break; }
             if (hipDeviceSynchronize() != hipSuccess) { rc = ADAS_ERR_HIP; break; }
@@ -716,6 +731,7 @@ int adas_engine_layer_kernel(const adas_engine* e, int layer, int batch, char* n
         if (o.res_mode != RES_NONE) a.res = make_view(e, o.res_buf, o.res_coff, o.out_c);
         else { a.res = a.out; a.res.p = nullptr; }
         a.k = op.k; a.kpad = op.kpad; a.m = batch * a.out.h * a.out.w; a.max_n = e->max_batch; a.prec = e->prec;
+        if (op.has_x3h8) a.wgt_h8x3 = (const unsigned char*)e->d_weights + op.x3h8_w_off;
         snprintf(name, cap, "%s%s%s", conv_kernel_name(a, e->prec, op.kernel), op.fuse_pool >= 0 ? "+pool" : "",
                  (op.ds_src >= 0 && ds_folded(e, layer, batch)) ? "+shortcut" : "");
     } else if (o.type == OP_DETECT_V8 && op.det_src[0] >= 0) {
@@ -796,6 +812,7 @@ int engine_run_op(adas_engine* e, int i, const float* d_in, int batch, hipStream
             a.bias = (const float*)(wb + op.b_off);
             a.n = batch; a.kh = o.kh; a.kw = o.kw; a.stride = o.stride; a.pad = o.pad; a.act = o.act; a.res_mode = o.res_mode;
             a.k = op.k; a.kpad = op.kpad; a.m = batch * a.out.h * a.out.w; a.max_n = e->max_batch; a.prec = e->prec;
+            if (op.has_x3h8) a.wgt_h8x3 = wb + op.x3h8_w_off;
             if (op.ds_src >= 0 && ds_folded(e, i, batch)) {
                 const EngOp& dsop = e->ops[op.ds_src];
                 a.ds_in = make_view(e, dsop.f.in_buf[0], dsop.f.in_coff[0], dsop.f.in_c[0]);

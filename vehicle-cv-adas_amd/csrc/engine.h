@@ -62,6 +62,8 @@ struct EngOp {
                              // at batches where conv_halo8 takes the layer), or -1
     int ds_user = -1;        // the projection conv's side of the same link
     size_t ds_w_off = 0;     // projection weights re-packed as per-step tiles for the fold
+    size_t x3h8_w_off = 0;   // split precision: second packing of a 3x3 s1 conv for conv_halo8_x3.hip (has_x3h8)
+    bool has_x3h8 = false;
     int up_src = -1;         // OP_CONV (1x1): index of the upsample op folded into this conv's activation loads, or -1
     int pool3[2] = {-1, -1}; // OP_MAXPOOL: the two pools chained behind this one, folded into its launch (SPPF), or -1
     int pair_b = -1;         // CONV_PAIR: index of the second conv of the pair this op launches (its own output is never written), or -1

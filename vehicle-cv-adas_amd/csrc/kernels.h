@@ -5,8 +5,10 @@
 
 namespace adas {
 
-enum { PREC_BF16 = 0, PREC_FP32 = 1, PREC_FP16 = 2 };  // == ADAS_PREC_* (include/adas_hip.h)
-inline bool prec_is16(int prec) { return prec != PREC_FP32; }   // bf16 and fp16 share every 16-bit kernel (elem16.h)
+enum { PREC_BF16 = 0, PREC_FP32 = 1, PREC_FP16 = 2, PREC_X3 = 3 };  // == ADAS_PREC_* (include/adas_hip.h)
+inline bool prec_is16(int prec) { return prec == PREC_BF16 || prec == PREC_FP16; }   // bf16 and fp16 share every 16-bit kernel (elem16.h)
+// bytes per activation / weight element: the split precision stores a (hi, lo) pair of halves per element (elem16.h, x3s)
+inline int prec_esize(int prec) { return prec_is16(prec) ? 2 : 4; }
 enum { ACT_NONE = 0, ACT_SILU = 1, ACT_RELU = 2, ACT_LEAKY = 3 /* LeakyReLU(0.1): YOLOv7 (conv_halo, conv_pw, conv_pwg, conv_igemm) */ };
 enum { RES_NONE = 0, RES_AFTER_ACT = 1, RES_BEFORE_ACT = 2 };
 
@@ -36,6 +38,8 @@ struct ConvArgs {
     TView ds_in{};
     const void* ds_w = nullptr;
     const float* ds_bias = nullptr;
+    // split precision: the same weights in conv_halo8_x3.hip's half-chunk slab packing (nullptr: the layer's shape does not take it)
+    const void* wgt_h8x3 = nullptr;
 };
 
 // Which kernel runs a conv and how its weights are packed.  Decided once at load time from static
@@ -90,6 +94,16 @@ bool pw_applicable(int prec, int kh, int kw, int stride, int pad, int res_mode, 
 bool pwg_applicable(int prec, int kh, int kw, int stride, int pad, const TView& in, const TView& out, const TView& res, int res_mode);
 hipError_t launch_conv_pwg(const ConvArgs& a, hipStream_t st);
 const char* pwg_kernel_name(int m, int cout);
+// conv_x3.hip: the split precision's convolution (any kernel size / stride, channel counts multiples of 8) and its G8 weight packing
+hipError_t launch_conv_x3(const ConvArgs& a, hipStream_t st);
+const char* conv_x3_kernel_name(const ConvArgs& a);
+hipError_t launch_pack_weights_x3(const float* src, void* dst, int cout, int cout_pad, int taps, int cin, int cin_pad, int kpad, hipStream_t st);
+// conv_halo8_x3.hip: stride-1 3x3, Cout % 64 == 0, Cin % 32 == 0, in the split precision: persistent, LDS-DMA fed, half-chunk stream
+bool halo8_x3_shape_ok(int kh, int kw, int stride, int pad, const TView& in, const TView& out);   // static: gets the second weight packing
+bool halo8_x3_applicable(int kh, int kw, int stride, int pad, int n, const TView& in, const TView& out, const TView& res, int res_mode);
+size_t halo8_x3_weight_bytes(int cout, int cin);
+hipError_t launch_pack_weights_h8x3(const float* src, void* dst, int cout, int cin, hipStream_t st);   // src fp32 [cout][9][cin]
+hipError_t launch_conv_halo8_x3(const ConvArgs& a, hipStream_t st);
 // returns hipSuccess or the launch error.  prec: PREC_*.
 hipError_t launch_conv(const ConvArgs& a, int prec, hipStream_t st);
 const char* conv_tile_name(const ConvArgs& a, int prec);
