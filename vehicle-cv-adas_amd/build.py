@@ -31,6 +31,7 @@ UNITS = [
     ("conv_pw.hip", []),
     ("conv_pwg.hip", []),
     ("conv_stem.hip", []),
+    ("conv_stem_x3.hip", []),
     ("aux_kernels.hip", []),
     ("dw_attn.hip", []),
     ("engine.cpp", []),

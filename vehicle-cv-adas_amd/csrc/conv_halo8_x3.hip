@@ -237,8 +237,9 @@ __global__ __launch_bounds__(X8_THR, 1) void conv_h8x3_kernel(H8XDev a) {
                         const uint32_t ro = po[j] == X8_OOB ? X8_OOB : (po[j] * (uint32_t)a.res_cs + (uint32_t)a.res_coff) * 4u + ch0;
 #pragma unroll
                         for (int i = 0; i < 2; ++i) {
-                            rraw[j][i][0] = __builtin_amdgcn_raw_buffer_load_b64(rres, ro + i * 64, 0, 0);
-                            rraw[j][i][1] = __builtin_amdgcn_raw_buffer_load_b64(rres, ro + i * 64 + 16, 0, 0);
+                            const uint32_t ri = (cb * 64 + hb * 32 + i * 16 + kg * 4 < a.cout) ? ro + i * 64 : X8_OOB;
+                            rraw[j][i][0] = __builtin_bit_cast(yu32x2, __builtin_amdgcn_raw_buffer_load_b64(rres, ri, 0, 0));
+                            rraw[j][i][1] = __builtin_bit_cast(yu32x2, __builtin_amdgcn_raw_buffer_load_b64(rres, ri + 16, 0, 0));
                         }
                     }
                 }
@@ -308,12 +309,18 @@ __global__ __launch_bounds__(X8_THR, 1) void conv_h8x3_kernel(H8XDev a) {
                 const uint32_t oo = po[j] == X8_OOB ? X8_OOB : (po[j] * (uint32_t)a.out_cs + (uint32_t)a.out_coff) * 4u + ch0;
 #pragma unroll
                 for (int i = 0; i < 2; ++i) {
+                    // channels past cout (the padded tail of the last 64-channel block) are computed on zero weights and not stored
+                    const uint32_t oi = (cb * 64 + hb * 32 + i * 16 + kg * 4 < a.cout) ? oo + i * 64 : X8_OOB;
                     float v[4];
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] = acc[i][j][e] + acc[i + 2][j][e] * kX3Down;
                     if (RM != RES_NONE) {
-                        const e_f16x2 h0 = __builtin_bit_cast(e_f16x2, rraw[j][i][0][0]), h1 = __builtin_bit_cast(e_f16x2, rraw[j][i][0][1]);
-                        const e_f16x2 l0 = __builtin_bit_cast(e_f16x2, rraw[j][i][1][0]), l1 = __builtin_bit_cast(e_f16x2, rraw[j][i][1][1]);
+                        // (words copied to scalars first: hipcc's __builtin_bit_cast applied directly to a vector ELEMENT reads element 0)
+                        const uint32_t wh0 = rraw[j][i][0].x, wh1 = rraw[j][i][0].y, wl0 = rraw[j][i][1].x, wl1 = rraw[j][i][1].y;
+                        const e_f16x2 h0 = __builtin_bit_cast(e_f16x2, wh0);
+                        const e_f16x2 h1 = __builtin_bit_cast(e_f16x2, wh1);
+                        const e_f16x2 l0 = __builtin_bit_cast(e_f16x2, wl0);
+                        const e_f16x2 l1 = __builtin_bit_cast(e_f16x2, wl1);
                         const float r[4] = {x3_join(h0[0], l0[0]), x3_join(h0[1], l0[1]), x3_join(h1[0], l1[0]), x3_join(h1[1], l1[1])};
 #pragma unroll
                         for (int e = 0; e < 4; ++e) v[e] = RM == RES_BEFORE_ACT ? x8_act<ACT>(v[e] + r[e]) : x8_act<ACT>(v[e]) + r[e];
@@ -327,8 +334,8 @@ __global__ __launch_bounds__(X8_THR, 1) void conv_h8x3_kernel(H8XDev a) {
                     x3_split(v[1], h, l); h0[1] = h; l0[1] = l;
                     x3_split(v[2], h, l); h1[0] = h; l1[0] = l;
                     x3_split(v[3], h, l); h1[1] = h; l1[1] = l;
-                    __builtin_amdgcn_raw_buffer_store_b64(yu32x2{__builtin_bit_cast(uint32_t, h0), __builtin_bit_cast(uint32_t, h1)}, rout, oo + i * 64, 0, 0);
-                    __builtin_amdgcn_raw_buffer_store_b64(yu32x2{__builtin_bit_cast(uint32_t, l0), __builtin_bit_cast(uint32_t, l1)}, rout, oo + i * 64 + 16, 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b64(yu32x2{__builtin_bit_cast(uint32_t, h0), __builtin_bit_cast(uint32_t, h1)}, rout, oi, 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b64(yu32x2{__builtin_bit_cast(uint32_t, l0), __builtin_bit_cast(uint32_t, l1)}, rout, oi + 16, 0, 0);
                     acc[i][j] = yf32x4{biasn[i].x, biasn[i].y, biasn[i].z, biasn[i].w};
                     acc[i + 2][j] = yf32x4{0.f, 0.f, 0.f, 0.f};
                 }
@@ -374,17 +381,23 @@ static int x8_blocks_per_unit(long tiles8, int ncb) {
     return 0;
 }
 
-// static part (shapes): decides at load time whether a conv also gets the half-chunk weight packing
+// static part (shapes): decides at load time whether a conv also gets the half-chunk weight packing.  Channel counts need not be whole
+// blocks: Cout is padded to 64-channel items (zero weight rows, stores masked) and Cin to 32-channel chunks (zero weight columns; the
+// window then reads past the view's channels into the neighbouring finite values, which the zero weights cancel).  The padding is MFMA
+// work: layers that would spend more than half of it on zeros stay on the generic kernel.
+static int x8_cin_pad(int cin) { return (cin + 31) / 32 * 32; }
+static int x8_cout_pad(int cout) { return (cout + 63) / 64 * 64; }
 bool halo8_x3_shape_ok(int kh, int kw, int stride, int pad, const TView& in, const TView& out) {
     if (!x8_mode()) return false;
     if (kh != 3 || kw != 3 || stride != 1 || pad != 1) return false;
     if (in.f32 || out.f32 || out.h != in.h || out.w != in.w) return false;
-    if ((out.c & 63) || (in.c & 31) || in.c < 32) return false;
+    if ((out.c & 7) || (in.c & 7) || in.c < 16) return false;
     if ((in.cs & 7) || (in.coff & 7) || (out.cs & 7) || (out.coff & 7)) return false;
+    if ((double)in.c * out.c < 0.5 * (double)x8_cin_pad(in.c) * x8_cout_pad(out.c)) return false;
     HaloPlan pl;
     return plan_halo(out.h, out.w, 1, &pl) && pl.eff >= 0.6 && pl.maxpix <= X8_MAXPIX;
 }
-size_t halo8_x3_weight_bytes(int cout, int cin) { return (size_t)(cout / 32) * (size_t)(2 * (cin / 32)) * X8_SLAB; }
+size_t halo8_x3_weight_bytes(int cout, int cin) { return (size_t)(x8_cout_pad(cout) / 32) * (size_t)(2 * (x8_cin_pad(cin) / 32)) * X8_SLAB; }
 
 bool halo8_x3_applicable(int kh, int kw, int stride, int pad, int n, const TView& in, const TView& out, const TView& res, int res_mode) {
     if (!halo8_x3_shape_ok(kh, kw, stride, pad, in, out)) return false;
@@ -395,14 +408,14 @@ bool halo8_x3_applicable(int kh, int kw, int stride, int pad, int n, const TView
     HaloPlan pl;
     if (!plan_halo(out.h, out.w, 1, &pl)) return false;
     const long ntiles = (long)n * pl.NS * pl.TPS, tiles8 = (ntiles + 7) / 8;
-    if (ntiles * (out.c / 64) * pl.NS * pl.TPS >= (1L << 32)) return false;
-    return x8_blocks_per_unit(tiles8, out.c / 64) > 0;
+    if (ntiles * (x8_cout_pad(out.c) / 64) * pl.NS * pl.TPS >= (1L << 32)) return false;
+    return x8_blocks_per_unit(tiles8, x8_cout_pad(out.c) / 64) > 0;
 }
 
-// fp32 [cout][9][cin] -> halves [cout / 32][2 * cin / 32][9][64 rows][32]: block b = output channels 32 b .. 32 b + 31;
+// fp32 [cout][9][cin] -> halves [cout_pad / 32][2 * cin_pad / 32][9][64 rows][32]: block b = output channels 32 b .. 32 b + 31;
 // rows 0-31 main, rows 32-63 cross.  H half-chunk (even): main = hi(w), cross = lo(w); L half-chunk (odd): main = 0, cross = hi(w).
-__global__ void pack_weights_h8x3_kernel(const float* __restrict__ src, uint16_t* __restrict__ dst, int cout, int cin, size_t total) {
-    const int nck = 2 * (cin >> 5);
+// Rows past cout and columns past cin are zero.
+__global__ void pack_weights_h8x3_kernel(const float* __restrict__ src, uint16_t* __restrict__ dst, int cout, int cin, int nck, size_t total) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
         const int k = (int)(i & 31);
         size_t r = i >> 5;
@@ -412,7 +425,7 @@ __global__ void pack_weights_h8x3_kernel(const float* __restrict__ src, uint16_t
         const size_t blk = r / nck;
         const size_t co = blk * 32 + (row & 31);
         const int ci = (ck >> 1) * 32 + k;
-        const float w = src[(co * 9 + tap) * cin + ci];
+        const float w = (co < (size_t)cout && ci < cin) ? src[(co * 9 + tap) * cin + ci] : 0.0f;
         _Float16 h, l;
         x3_split(w, h, l);
         const bool cross = row >= 32, lo_chunk = (ck & 1) != 0;
@@ -421,10 +434,10 @@ __global__ void pack_weights_h8x3_kernel(const float* __restrict__ src, uint16_t
     }
 }
 hipError_t launch_pack_weights_h8x3(const float* src, void* dst, int cout, int cin, hipStream_t st) {
-    if ((cout & 63) || (cin & 31)) return hipErrorInvalidValue;
+    if ((cout & 7) || (cin & 7)) return hipErrorInvalidValue;
     const size_t total = halo8_x3_weight_bytes(cout, cin) / 2;
     const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
-    hipLaunchKernelGGL(pack_weights_h8x3_kernel, dim3(blocks), dim3(256), 0, st, src, (uint16_t*)dst, cout, cin, total);
+    hipLaunchKernelGGL(pack_weights_h8x3_kernel, dim3(blocks), dim3(256), 0, st, src, (uint16_t*)dst, cout, cin, 2 * (x8_cin_pad(cin) / 32), total);
     return hipGetLastError();
 }
 
@@ -454,7 +467,7 @@ hipError_t launch_conv_halo8_x3(const ConvArgs& a, hipStream_t st) {
     d.in_cs = a.in.cs; d.in_coff = a.in.coff; d.cin = a.in.c; d.H = a.in.h; d.W = a.in.w;
     d.out_cs = a.out.cs; d.out_coff = a.out.coff; d.cout = a.out.c;
     d.res_cs = a.res.cs; d.res_coff = a.res.coff; d.res_mode = a.res_mode;
-    d.nck = 2 * (a.in.c / 32);
+    d.nck = 2 * (x8_cin_pad(a.in.c) / 32);
     d.in_bytes = (uint32_t)((size_t)a.n * a.in.h * a.in.w * a.in.cs * 4);
     d.wgt_bytes = (uint32_t)halo8_x3_weight_bytes(a.out.c, a.in.c);
     d.out_bytes = (uint32_t)((size_t)a.n * a.out.h * a.out.w * a.out.cs * 4);
@@ -465,7 +478,7 @@ hipError_t launch_conv_halo8_x3(const ConvArgs& a, hipStream_t st) {
     d.mg_tps = (uint32_t)(((1ull << 32) + (uint64_t)pl.TPS - 1) / (uint64_t)pl.TPS);
     d.ntiles = a.n * pl.NS * pl.TPS;
     d.tiles8 = (d.ntiles + 7) / 8;
-    d.ncb = a.out.c / 64;
+    d.ncb = x8_cout_pad(a.out.c) / 64;
     d.cpw = x8_blocks_per_unit(d.tiles8, d.ncb);
     if (d.cpw <= 0) return hipErrorNotSupported;
     const int upt = d.ncb / d.cpw;

@@ -312,6 +312,10 @@ const char* conv_tile_name(const ConvArgs& a, int prec) {
 // Name of the kernel instantiation a conv launch resolves to (as rocprofv3 --kernel-trace prints it, minus namespaces).
 const char* conv_kernel_name(const ConvArgs& a, int prec, int kernel) {
     static thread_local char buf[96];
+    if (prec == PREC_X3 && kernel == CONV_STEM) {
+        snprintf(buf, sizeof(buf), "conv_stem_x3_kernel<%d,%d,%s>", a.kh, (a.out.c + 15) / 16, a.act == ACT_SILU ? "SILU" : (a.act == ACT_RELU ? "RELU" : "LEAKY"));
+        return buf;
+    }
     if (prec == PREC_X3) {
         if (a.wgt_h8x3 && halo8_x3_applicable(a.kh, a.kw, a.stride, a.pad, a.n, a.in, a.out, a.res, a.res_mode)) {
             snprintf(buf, sizeof(buf), "conv_h8x3_kernel<%s>", a.act == ACT_SILU ? "SILU" : (a.act == ACT_RELU ? "RELU" : (a.act == ACT_LEAKY ? "LEAKY" : "NONE")));

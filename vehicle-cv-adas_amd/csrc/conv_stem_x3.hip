@@ -1,0 +1,257 @@
+// conv_stem_x3.hip -- the first layer of each network in the split precision (ADAS_PREC_FP16X3): engine-seam tensor (NCHW fp32,
+// coreEngine.py:150-157) -> stride-2 conv (7x7 ResNet stem, backbone.py:50-52; 3x3 / 6x6 YOLO stems) + bias + ReLU / SiLU -> G8 NHWC.
+//
+// The generic split-precision path spends two launches here (NCHW -> 8-channel G8 conversion, then an implicit GEMM whose K is padded
+// from 147 to 392 because Cin = 3 is stored as 8: 2.7 + 1.2 ms per 64 UFLD frames, measured).  This kernel is conv_stem.hip's scheme
+// with both halves of every operand: the fp32 planes are read once, split, and kept as two zero-padded (c0, c1, c2, 0) windows in LDS
+// (hi and lo); with 4-channel pixels one 16x16x32 B fragment is 8 consecutive window pixels of one tap row, so a KH-row kernel is KH
+// K-steps of three MFMAs per tile pair (main += w_hi x_hi; cross += w_lo x_hi + w_hi x_lo).  Weights sit in LDS in fragment order
+// (hi array, lo array) for the whole persistent workgroup; the next tile's window is fetched into registers under the current tile's
+// MFMAs.  The ResNet max-pool stays a separate launch (maxpool_x3_kernel) in this precision.
+#include "kernels.h"
+#include "elem16.h"
+#include <string.h>
+
+namespace adas {
+
+typedef __attribute__((ext_vector_type(4))) float zf32x4;
+typedef __attribute__((ext_vector_type(2))) uint32_t zu32x2;
+
+struct StemX3Dev {
+    const float* in;        // [N][C][H][W] fp32
+    const uint16_t* wfrag;  // [2 (hi | lo)][NT][KH][64 lanes][8] halves, fragment order
+    const float* bias;
+    x3s* out;               // NHWC G8 view
+    int out_cs, out_coff, cout;
+    int N, C, H, W;
+    int Ho, Wo;
+    int pad;
+    int tiles_x, tiles_y, ntiles;
+};
+
+constexpr int SX3_WW = 72;  // window row pitch in pixels
+
+__host__ __device__ constexpr int sx3_cth(int kh) { return kh == 7 ? 6 : 8; }   // conv tile rows (7x7: 6, so that two workgroups share a CU's LDS)
+__host__ __device__ constexpr int sx3_lds_bytes(int kh, int nt) {
+    return (2 * nt * kh * 512 + 2 * (2 * (sx3_cth(kh) - 1) + kh) * SX3_WW * 4) * 2;
+}
+
+template <int ACT>
+__device__ __forceinline__ float sx3_act(float v) {
+    if (ACT == ACT_SILU) return v / (1.0f + expf(-v));
+    if (ACT == ACT_RELU) return fmaxf(v, 0.0f);
+    if (ACT == ACT_LEAKY) return fmaxf(v, 0.1f * v);
+    return v;
+}
+
+template <int KH, int NT, int ACT>
+__global__ __launch_bounds__(256, 2) void conv_stem_x3_kernel(StemX3Dev a) {
+    Fp16::enter();
+    constexpr int CTH = sx3_cth(KH), CTW = 32;
+    constexpr int NPIX = CTH * CTW;
+    constexpr int NMT = NPIX / 16, MT = NMT / 4;
+    static_assert(NMT % 4 == 0, "M tiles over 4 waves");
+    constexpr int WW = SX3_WW, WH = 2 * (CTH - 1) + KH;
+    constexpr int NQ = (WH * WW + 255) / 256;
+    constexpr int WFR = NT * KH * 512;   // halves per weight array
+    extern __shared__ __attribute__((aligned(16))) uint16_t sx3_lds[];
+    uint16_t* wlh = sx3_lds;
+    uint16_t* wll = wlh + WFR;
+    uint16_t* winh = wll + WFR;
+    uint16_t* winl = winh + WH * WW * 4;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lrow = lane & 15, kg = lane >> 4;
+    stage_lds16<256, 8>(wlh, a.wfrag, 2 * NT * KH * 64, tid);   // both arrays, contiguous
+
+    int boff[MT];
+#pragma unroll
+    for (int j = 0; j < MT; ++j) {
+        const int p = (wave * MT + j) * 16 + lrow;
+        const int cy = p / CTW, cx = p - cy * CTW;
+        boff[j] = ((2 * cy) * WW + 2 * cx + 2 * kg) * 4;
+    }
+    const int per_img = a.tiles_x * a.tiles_y;
+    const int plane = a.H * a.W;
+
+    uint32_t px[NQ][3];
+    auto fetch = [&](int tile) {
+        const bool live = tile < a.ntiles;
+        const int tl = live ? tile : 0;
+        const int img = tl / per_img;
+        const int t2 = tl - img * per_img;
+        const int ty = t2 / a.tiles_x, tx = t2 - ty * a.tiles_x;
+        const int iy0 = 2 * (ty * CTH) - a.pad, ix0 = 2 * (tx * CTW) - a.pad;
+        const void* in_img = (const void*)(a.in + (size_t)img * a.C * plane);
+        __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)in_img, 0, a.C * plane * 4, 0x00020000);
+#pragma unroll
+        for (int i = 0; i < NQ; ++i) {
+            const int q = tid + 256 * i;
+            const int wy = q / WW, wx = q - wy * WW;
+            const int iy = iy0 + wy, ix = ix0 + wx;
+            const bool ok = live && q < WH * WW && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+            const uint32_t off = (uint32_t)((iy * a.W + ix) * 4);
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const uint32_t oc = (ok && c < a.C) ? off + (uint32_t)(c * plane * 4) : 0x80000000u;
+                px[i][c] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rsrc, oc, 0, 0);
+            }
+        }
+    };
+
+    const int gstride = gridDim.x;
+    auto step = [&](const int tile) {
+        const int img = tile / per_img;
+        const int t2 = tile - img * per_img;
+        const int ty = t2 / a.tiles_x, tx = t2 - ty * a.tiles_x;
+        const int cy0 = ty * CTH, cx0 = tx * CTW;
+
+        __syncthreads();  // previous tile's readers of the windows are done (first trip: the weights are in LDS)
+#pragma unroll
+        for (int i = 0; i < NQ; ++i) {
+            const int q = tid + 256 * i;
+            if (q < WH * WW) {
+                _Float16 h[3], l[3];
+#pragma unroll
+                for (int c = 0; c < 3; ++c) x3_split(__uint_as_float(px[i][c]), h[c], l[c]);
+                zu32x2 vh, vl;
+                vh.x = __builtin_bit_cast(uint32_t, e_f16x2{h[0], h[1]});
+                vh.y = __builtin_bit_cast(uint32_t, e_f16x2{h[2], (_Float16)0.0f});
+                vl.x = __builtin_bit_cast(uint32_t, e_f16x2{l[0], l[1]});
+                vl.y = __builtin_bit_cast(uint32_t, e_f16x2{l[2], (_Float16)0.0f});
+                *reinterpret_cast<zu32x2*>(winh + q * 4) = vh;
+                *reinterpret_cast<zu32x2*>(winl + q * 4) = vl;
+            }
+        }
+        __syncthreads();
+        fetch(tile + gstride);  // in flight under this tile's MFMAs
+
+        zf32x4 accm[MT][NT], accx[MT][NT];
+#pragma unroll
+        for (int j = 0; j < MT; ++j)
+#pragma unroll
+            for (int i = 0; i < NT; ++i) accm[j][i] = accx[j][i] = zf32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int r = 0; r < KH; ++r) {
+            e_u32x4 wh[NT], wl[NT], xh[MT], xl[MT];
+#pragma unroll
+            for (int i = 0; i < NT; ++i) {
+                wh[i] = *reinterpret_cast<const e_u32x4*>(wlh + ((i * KH + r) * 64 + lane) * 8);
+                wl[i] = *reinterpret_cast<const e_u32x4*>(wll + ((i * KH + r) * 64 + lane) * 8);
+            }
+#pragma unroll
+            for (int j = 0; j < MT; ++j) {
+                xh[j] = *reinterpret_cast<const e_u32x4*>(winh + boff[j] + r * WW * 4);
+                xl[j] = *reinterpret_cast<const e_u32x4*>(winl + boff[j] + r * WW * 4);
+            }
+#pragma unroll
+            for (int j = 0; j < MT; ++j)
+#pragma unroll
+                for (int i = 0; i < NT; ++i) accm[j][i] = Fp16::mfma(wh[i], xh[j], accm[j][i]);
+#pragma unroll
+            for (int j = 0; j < MT; ++j)
+#pragma unroll
+                for (int i = 0; i < NT; ++i) accx[j][i] = Fp16::mfma(wl[i], xh[j], accx[j][i]);
+#pragma unroll
+            for (int j = 0; j < MT; ++j)
+#pragma unroll
+                for (int i = 0; i < NT; ++i) accx[j][i] = Fp16::mfma(wh[i], xl[j], accx[j][i]);
+        }
+
+        // ---- epilogue: lane holds channels i*16 + kg*4 .. +3 of conv pixel (cy, cx) of the tile
+        float4 bias4[NT];
+#pragma unroll
+        for (int i = 0; i < NT; ++i) bias4[i] = *reinterpret_cast<const float4*>(a.bias + i * 16 + kg * 4);
+#pragma unroll
+        for (int j = 0; j < MT; ++j) {
+            const int p = (wave * MT + j) * 16 + lrow;
+            const int cy = p / CTW, cx = p - cy * CTW;
+            const int oy = cy0 + cy, ox = cx0 + cx;
+            if (oy >= a.Ho || ox >= a.Wo) continue;
+            x3s* op = a.out + ((size_t)(img * a.Ho + oy) * a.Wo + ox) * a.out_cs + a.out_coff + kg * 4;
+#pragma unroll
+            for (int i = 0; i < NT; ++i) {
+                if (i * 16 + kg * 4 >= a.cout) continue;
+                const float v[4] = {sx3_act<ACT>(accm[j][i][0] + accx[j][i][0] * kX3Down + bias4[i].x),
+                                    sx3_act<ACT>(accm[j][i][1] + accx[j][i][1] * kX3Down + bias4[i].y),
+                                    sx3_act<ACT>(accm[j][i][2] + accx[j][i][2] * kX3Down + bias4[i].z),
+                                    sx3_act<ACT>(accm[j][i][3] + accx[j][i][3] * kX3Down + bias4[i].w)};
+                x3_store4(op + i * 16, v);
+            }
+        }
+    };
+    int tile = blockIdx.x;
+    if (tile >= a.ntiles) return;
+    fetch(tile);
+    for (; tile < a.ntiles; tile += gstride) step(tile);
+}
+
+// -------------------------------------------------------------------------------------
+bool stem_x3_applicable(int in_c_true, int kh, int kw, int stride, int pad, int act, int res_mode, const TView& out) {
+    if (in_c_true > 3 || stride != 2 || res_mode != RES_NONE) return false;
+    if (!(kh == 3 || kh == 6 || kh == 7) || kw != kh || pad > kh / 2) return false;
+    if (out.f32 || (out.cs & 7) || (out.coff & 7)) return false;
+    if (kh == 7) return out.c == 64 && act == ACT_RELU;
+    return (out.c == 16 || out.c == 32 || out.c == 48 || out.c == 64 || out.c == 80) && (act == ACT_SILU || act == ACT_RELU || act == ACT_LEAKY);
+}
+
+size_t stem_x3_weight_bytes(int kh, int cout) { return 2 * stem_weight_bytes(kh, cout); }
+
+// host-side packing: w = [cout][kh][kw][cs] fp32 (OHWI) -> fragment order, hi array then lo array (stem_pack_weights' order)
+void stem_x3_pack_weights(const float* w, int cout, int kh, int kw, int cs, int c_true, uint16_t* dst) {
+    const int NT = (cout + 15) / 16;
+    const size_t arr = (size_t)NT * kh * 64 * 8;
+    for (int nt = 0; nt < NT; ++nt)
+        for (int r = 0; r < kh; ++r)
+            for (int lane = 0; lane < 64; ++lane)
+                for (int e = 0; e < 8; ++e) {
+                    const int co = nt * 16 + (lane & 15), kg = lane >> 4;
+                    const int s = 2 * kg + e / 4, ch = e & 3;
+                    float v = 0.f;
+                    if (co < cout && s < kw && ch < c_true) v = w[(((size_t)co * kh + r) * kw + s) * cs + ch];
+                    _Float16 h, l;
+                    x3_split(v, h, l);
+                    const size_t at = ((size_t)(nt * kh + r) * 64 + lane) * 8 + e;
+                    dst[at] = __builtin_bit_cast(uint16_t, h);
+                    dst[arr + at] = __builtin_bit_cast(uint16_t, l);
+                }
+}
+
+template <int KH, int NT>
+static hipError_t sx3_launch(const StemX3Dev& d, int act, hipStream_t st) {
+    constexpr int lds = sx3_lds_bytes(KH, NT);
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute((const void*)conv_stem_x3_kernel<KH, NT, ACT_RELU>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)conv_stem_x3_kernel<KH, NT, ACT_SILU>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)conv_stem_x3_kernel<KH, NT, ACT_LEAKY>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_done = true;
+    }
+    const int grid = d.ntiles < 512 ? d.ntiles : 512;   // persistent: two workgroups per CU
+    if (act == ACT_RELU) hipLaunchKernelGGL((conv_stem_x3_kernel<KH, NT, ACT_RELU>), dim3(grid), dim3(256), lds, st, d);
+    else if (act == ACT_LEAKY) hipLaunchKernelGGL((conv_stem_x3_kernel<KH, NT, ACT_LEAKY>), dim3(grid), dim3(256), lds, st, d);
+    else hipLaunchKernelGGL((conv_stem_x3_kernel<KH, NT, ACT_SILU>), dim3(grid), dim3(256), lds, st, d);
+    return hipGetLastError();
+}
+
+hipError_t launch_conv_stem_x3(const float* nchw, int n, int c_true, int H, int W, int kh, int pad, int act, const void* wfrag, const float* bias,
+                               const TView& out, hipStream_t st) {
+    StemX3Dev d;
+    d.in = nchw; d.wfrag = (const uint16_t*)wfrag; d.bias = bias;
+    d.out = (x3s*)out.p; d.out_cs = out.cs; d.out_coff = out.coff; d.cout = out.c;
+    d.N = n; d.C = c_true; d.H = H; d.W = W; d.Ho = out.h; d.Wo = out.w;
+    d.pad = pad;
+    d.tiles_x = (d.Wo + 31) / 32; d.tiles_y = (d.Ho + sx3_cth(kh) - 1) / sx3_cth(kh);
+    d.ntiles = n * d.tiles_x * d.tiles_y;
+    if ((size_t)c_true * H * W * 4 >= (1ull << 31)) return hipErrorInvalidValue;
+    const int nt = (out.c + 15) / 16;
+#define SX3_CASE(KH_, NT_) \
+    if (kh == KH_ && nt == NT_) return sx3_launch<KH_, NT_>(d, act, st);
+    SX3_CASE(3, 1) SX3_CASE(3, 2) SX3_CASE(3, 3) SX3_CASE(3, 4) SX3_CASE(3, 5)
+    SX3_CASE(6, 1) SX3_CASE(6, 2) SX3_CASE(6, 3) SX3_CASE(6, 4) SX3_CASE(6, 5)
+    SX3_CASE(7, 4)
+#undef SX3_CASE
+    return hipErrorInvalidValue;
+}
+
+}  // namespace adas

@@ -221,7 +221,17 @@ int adas_engine_create(const char* model_path, int precision, int max_batch, ada
                 if ((int)q.buf == buf) return true;
             return false;
         };
-        if (enabled && e->ops.size() >= 2 && fo[0].type == OP_INPUT && fo[1].type == OP_CONV && fo[1].in_buf[0] == fo[0].out_buf &&
+        if (enabled && precision == PREC_X3 && e->ops.size() >= 2 && fo[0].type == OP_INPUT && fo[1].type == OP_CONV && fo[1].in_buf[0] == fo[0].out_buf &&
+            !aliased(fo[0].out_buf) && !aliased(fo[1].out_buf)) {
+            // split precision: input conversion + first conv in one launch (conv_stem_x3.hip); the max-pool / second conv stay separate
+            bool only = true;
+            for (size_t i = 2; i < fo.size(); ++i) only = only && !reads_buf(fo[i], fo[0].out_buf);
+            if (only && stem_x3_applicable(hd.in_c, fo[1].kh, fo[1].kw, fo[1].stride, fo[1].pad, fo[1].act, fo[1].res_mode,
+                                           make_view(e, fo[1].out_buf, fo[1].out_coff, fo[1].out_c))) {
+                e->ops[0].skip = true;
+                e->ops[1].kernel = CONV_STEM;
+            }
+        } else if (enabled && e->ops.size() >= 2 && fo[0].type == OP_INPUT && fo[1].type == OP_CONV && fo[1].in_buf[0] == fo[0].out_buf &&
             !aliased(fo[0].out_buf) && !aliased(fo[1].out_buf)) {
             bool only = true;
             for (size_t i = 2; i < fo.size(); ++i) only = only && !reads_buf(fo[i], fo[0].out_buf);
@@ -463,7 +473,7 @@ int adas_engine_create(const char* model_path, int precision, int max_batch, ada
             op.cin_pad = 4;
             op.cout_pad = (o.out_c + 127) / 128 * 128;
             op.w_off = packed_total;
-            packed_total += (stem_weight_bytes(o.kh, o.out_c) + 255) & ~(size_t)255;
+            packed_total += ((precision == PREC_X3 ? stem_x3_weight_bytes(o.kh, o.out_c) : stem_weight_bytes(o.kh, o.out_c)) + 255) & ~(size_t)255;
             op.b_off = packed_total;
             packed_total += ((size_t)op.cout_pad * 4 + 255) & ~(size_t)255;
         } else if (o.type == OP_CONV && op.kernel == CONV_STEM2) {
@@ -597,8 +607,11 @@ int adas_engine_create(const char* model_path, int precision, int max_batch, ada
             if (!read_blob(o.w_off, o.w_elems, h_stage.data()) || o.w_elems != (uint64_t)o.out_c * op.k) { rc = ADAS_ERR_FORMAT; break; }
             if (hipMemcpy(d_stage, h_stage.data(), o.w_elems * 4, hipMemcpyHostToDevice) != hipSuccess) { rc = ADAS_ERR_HIP; break; }
             if (op.kernel == CONV_STEM || op.kernel == CONV_STEM2) {
-                std::vector<uint16_t> frag((op.kernel == CONV_STEM2 ? stem2_weight_bytes() : stem_weight_bytes(o.kh, o.out_c)) / 2);
+                std::vector<uint16_t> frag((op.kernel == CONV_STEM2 ? stem2_weight_bytes()
+                                            : precision == PREC_X3   ? stem_x3_weight_bytes(o.kh, o.out_c)
+                                                                     : stem_weight_bytes(o.kh, o.out_c)) / 2);
                 if (op.kernel == CONV_STEM2) stem2_pack_weights(h_stage.data(), frag.data(), precision);
+                else if (precision == PREC_X3) stem_x3_pack_weights(h_stage.data(), o.out_c, o.kh, o.kw, o.in_c[0], hd.in_c, frag.data());
                 else stem_pack_weights(h_stage.data(), o.out_c, o.kh, o.kw, o.in_c[0], hd.in_c, frag.data(), precision);
                 if (hipMemcpy(base + op.w_off, frag.data(), frag.size() * 2, hipMemcpyHostToDevice) != hipSuccess) { rc = ADAS_ERR_HIP; break; }
                 std::vector<float> b(op.cout_pad, 0.f);
@@ -769,7 +782,9 @@ int engine_run_op(adas_engine* e, int i, const float* d_in, int batch, hipStream
             const FileOp& po = e->ops[op.fuse_pool].f;
             pv = make_view(e, po.out_buf, po.out_coff, po.out_c);
         }
-        if (op.fuse_conv2 >= 0) {
+        if (e->prec == PREC_X3) {
+            err = launch_conv_stem_x3(d_in, batch, e->hdr.in_c, e->hdr.in_h, e->hdr.in_w, o.kh, o.pad, o.act, wb + op.w_off, (const float*)(wb + op.b_off), cv, st);
+        } else if (op.fuse_conv2 >= 0) {
             const EngOp& c2 = e->ops[op.fuse_conv2];
             err = launch_conv_stem2(d_in, batch, e->hdr.in_c, e->hdr.in_h, e->hdr.in_w, o.kh, o.pad, wb + op.w_off, (const float*)(wb + op.b_off), cv,
                                     wb + c2.w_off, (const float*)(wb + c2.b_off), make_view(e, c2.f.out_buf, c2.f.out_coff, c2.f.out_c), packed_in, e->prec, st);
@@ -950,7 +965,8 @@ int adas_engine_precision(const adas_engine* e) { return e ? e->prec : -1; }
 int adas_engine_model_io_half(const adas_engine* e) { return e ? (int)((e->hdr.in_cpad >> 16) & 1u) : 0; }
 
 int adas_engine_accepts_packed_input(const adas_engine* e) {
-    return (e && e->ops.size() >= 2 && e->ops[0].skip && e->ops[1].kernel == CONV_STEM) ? 1 : 0;
+    // (the split precision's stem reads the fp32 seam tensor: a 16-bit packed pixel could not carry its 22 bits)
+    return (e && e->prec != PREC_X3 && e->ops.size() >= 2 && e->ops[0].skip && e->ops[1].kernel == CONV_STEM) ? 1 : 0;
 }
 
 int adas_engine_infer_device_packed(adas_engine* e, const uint16_t* d_input_nhwc4, int batch, void* stream) {

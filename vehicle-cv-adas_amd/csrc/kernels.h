@@ -150,6 +150,12 @@ bool stem2_applicable(int prec, int kh, int pad, int act, const TView& stem_out,
 hipError_t launch_conv_stem2(const float* nchw, int n, int c_true, int H, int W, int kh, int pad, const void* wfrag, const float* bias,
                              const TView& stem_out, const void* wfrag2, const float* bias2, const TView& out2, bool packed_in, int prec, hipStream_t st);
 void stem_pack_weights(const float* w_ohwi, int cout, int kh, int kw, int cs, int c_true, uint16_t* dst_host, int prec);
+// conv_stem_x3.hip: the first layer in the split precision (NCHW fp32 -> stride-2 conv + act -> G8 NHWC; no pool / second-conv fusion)
+bool stem_x3_applicable(int in_c_true, int kh, int kw, int stride, int pad, int act, int res_mode, const TView& out);
+size_t stem_x3_weight_bytes(int kh, int cout);
+void stem_x3_pack_weights(const float* w_ohwi, int cout, int kh, int kw, int cs, int c_true, uint16_t* dst_host);   // hi array, then lo array
+hipError_t launch_conv_stem_x3(const float* nchw, int n, int c_true, int H, int W, int kh, int pad, int act, const void* wfrag, const float* bias,
+                               const TView& out, hipStream_t st);
 hipError_t launch_conv_stem(const float* nchw, int n, int c_true, int H, int W, int kh, int pad, int act, const void* wfrag,
                             const float* bias, const TView& conv_out, bool pool, const TView& pool_out, bool packed_in, int prec, hipStream_t st);
 // CONV_HALO packing: slab order [cout tile of halo_bn(cout)][32-channel chunk][tap][n within tile][32] -- the 9*BN*64 B a
