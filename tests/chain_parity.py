@@ -105,7 +105,7 @@ class ChainStats:
 
     FIELDS = ("frames", "identical_candidate_sets", "identical_keep_indices", "identical_survivor_sets", "identical_survivors",
               "equivalent_survivor_sets",
-              "identical_track_ids", "lanes_identical_status", "lanes_within_1px")
+              "identical_track_ids", "equivalent_tracks", "lanes_identical_status", "lanes_within_1px")
 
     def __init__(self):
         self.n = dict.fromkeys(self.FIELDS, 0)
@@ -116,6 +116,7 @@ class ChainStats:
         self.max_conf_diff = self.max_box_diff = 0.0
         self.max_lane_px = 0
         self.first_track_divergence = None
+        self.idmaps = {}                # stream -> {device track id: oracle track id} (equivalent_tracks)
         self.mismatch_log = []
 
     def add_detections(self, got, want, ctx=None):
@@ -158,7 +159,35 @@ class ChainStats:
         self.n["identical_track_ids"] += int(same)
         if not same and self.first_track_divergence is None:
             self.first_track_divergence = ctx
+        # the same TRACKS under a consistent renaming of ids: ByteTrack numbers new tracks in detection order, so two detections whose
+        # confidences tie within the 16-bit error and swap places in the list swap their (future) ids -- every later snapshot of that
+        # stream then "differs" although each track follows the same object with the same state.  Tracks are paired by state, class and
+        # box (within 2 px); the pairing must be one-to-one and must agree with every earlier snapshot of the stream.
+        stream = ctx[1] if ctx is not None and len(ctx) > 1 else 0
+        self.n["equivalent_tracks"] += int(same or self._tracks_equivalent(got_snap, want_snap, stream))
         return same
+
+    def _tracks_equivalent(self, got, want, stream):
+        idmap = self.idmaps.setdefault(stream, {})
+        for key in ("tracked", "lost"):
+            g, w = list(got[key]), list(want[key])
+            if len(g) != len(w):
+                return False
+            used = set()
+            for t in g:
+                best, bd = None, 2.0
+                for j, u in enumerate(w):
+                    if j in used or u["state"] != t["state"] or u["class_id"] != t["class_id"] or bool(u.get("is_activated", True)) != bool(t.get("is_activated", True)):
+                        continue
+                    d = float(np.abs(np.asarray(t["tlwh"], np.float64) - np.asarray(u["tlwh"], np.float64)).max())
+                    if d <= bd:
+                        best, bd = j, d
+                if best is None:
+                    return False
+                used.add(best)
+                if idmap.setdefault(t["track_id"], w[best]["track_id"]) != w[best]["track_id"]:
+                    return False
+        return len(set(idmap.values())) == len(idmap)
 
     def add_lanes(self, got, want):
         """Per frame: detected flags identical, every lane point within 1 px.  Per point: how many are further off (a row/column
@@ -193,6 +222,7 @@ class ChainStats:
             "survivors_without_equivalent_partner": self.n_surv_unmatched,
             "track_states_compared": self.n_track_checks,
             "frac_identical_track_ids": round(self.n["identical_track_ids"] / max(1, self.n_track_checks), 4),
+            "frac_equivalent_tracks": round(self.n["equivalent_tracks"] / max(1, self.n_track_checks), 4),
             "candidates_compared": self.n_cand, "candidate_anchors_differing": self.n_cand_sym_diff,
             "survivors_compared": self.n_surv, "survivor_anchors_differing": self.n_surv_sym_diff,
             "max_conf_diff_on_identical_frames": float("%.3e" % self.max_conf_diff),
@@ -231,4 +261,21 @@ def run_device_chain(pipe, fetch_post, fetch_tracks, d_frame_sets, h_frame_sets,
                 if lanes and pipe.decode is not None:
                     st.add_lanes(pipe.decode.fetch(f), chain.lanes(frame, key=(i, f)))
             st.add_tracks(fetch_tracks(s), want_trk, ctx=[k, s])
+    return st
+
+
+def run_oracle_vs_oracle(chain_a, chain_b, h_frame_sets, steps, hold, streams, lanes=True):
+    """The same bookkeeping with chain_a in the device's place: how many discrete decisions differ between two ORACLE chains on the frame
+    schedule run_device_chain uses (e.g. OracleChain(emulate="fp16") against the fp32 chain: what storage rounding alone costs, the
+    yardstick a 16-bit device run is held against)."""
+    st = ChainStats()
+    for k in range(steps):
+        i = (k // hold) % len(h_frame_sets)
+        for s in streams:
+            frame = h_frame_sets[i][s]
+            got, want = chain_a.detections(frame, key=(i, s)), chain_b.detections(frame, key=(i, s))
+            st.add_detections(got, want, ctx=[k, s, 0])
+            st.add_tracks(chain_a.track(s, got), chain_b.track(s, want), ctx=[k, s])
+            if lanes and chain_a.lane_name is not None:
+                st.add_lanes(chain_a.lanes(frame, key=(i, s)), chain_b.lanes(frame, key=(i, s)))
     return st

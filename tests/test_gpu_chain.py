@@ -31,7 +31,7 @@ PL = importlib.import_module("adas_amd.pipeline")
 M = importlib.import_module("adas_amd.models")
 
 
-def _run_chain(tmp_path, det, prec, S, steps, hold, n_sets, use_graph=True, target=100.0, cap=1024, seed=300):
+def _run_chain(tmp_path, det, prec, S, steps, hold, n_sets, use_graph=True, target=100.0, cap=1024, seed=300, emulate=None):
     import bench
     from oracle import preprocess
     pool = [bench.cam_frames(S, seed + i) for i in range(n_sets)]
@@ -47,8 +47,17 @@ def _run_chain(tmp_path, det, prec, S, steps, hold, n_sets, use_graph=True, targ
     for b in d_pool:
         b.free()
     out = st.summary()
+    if emulate:     # the same schedule through the CPU oracle with storage rounded to `emulate`: the yardstick of _assert_16bit
+        ref2 = CP.OracleChain(det, Wd, "ufldv2_res18", Wl)
+        ref2._det_cache, ref2._lane_cache = chain._det_cache, chain._lane_cache
+        out["emulated"] = CP.run_oracle_vs_oracle(CP.OracleChain(det, Wd, "ufldv2_res18", Wl, emulate=emulate), ref2, pool, steps, hold,
+                                                  list(range(S))).summary()
+        print("%s storage-rounding emulation (%s) vs fp32 chain: %s" % (det, emulate, {k: out["emulated"][k] for k in (
+            "identical_candidate_sets", "identical_survivors", "equivalent_survivor_sets", "identical_track_ids", "equivalent_tracks",
+            "lanes_within_1px", "candidate_anchors_differing", "survivor_anchors_differing", "lane_points_off_by_more_than_1px")}))
     print("%s %s S=%d steps=%d graph=%s: %s" % (det, prec, S, steps, use_graph, {k: out[k] for k in (
-        "frames", "identical_candidate_sets", "identical_survivor_sets", "identical_survivors", "identical_track_ids", "lanes_within_1px",
+        "frames", "identical_candidate_sets", "identical_survivor_sets", "identical_survivors", "equivalent_survivor_sets", "identical_track_ids",
+        "equivalent_tracks", "track_states_compared", "lanes_within_1px",
         "lane_points_compared", "lane_points_off_by_more_than_1px", "candidates_compared",
         "candidate_anchors_differing", "survivors_compared", "survivor_anchors_differing", "max_conf_diff_on_identical_frames",
         "max_box_diff_px_on_identical_frames", "max_lane_point_diff_px", "first_track_divergence")}))
@@ -66,17 +75,36 @@ def _assert_exact(o):
     assert o["max_conf_diff_on_identical_frames"] <= 1e-4 and o["max_box_diff_px_on_identical_frames"] <= 1e-2
 
 
-def _assert_16bit(o):
+def _assert_16bit(o, strict=True):
     """Bounds on how MANY discrete decisions differ (measured values are printed by _run_chain).  A half-precision network leaves
     ~1e-3 of the anchor-to-anchor logit spread as error (tools/synth_snr.py), so of 8400 anchors with ~100 over the threshold
     about 0.4-1 per frame sits closer to it than that and is decided differently; one such anchor changes the NMS outcome of its
-    neighbourhood (one or two survivors).  Measured (round 3, MI355X, bench.py parity.e2e): north-star pipeline 8 of 9,336 candidate
-    anchors, 91.7 % of 96 frames with identical survivor sets, 100 % identical track ids; YOLOv8s 0.4 % / 3.6 % and YOLOv8l 2.3 % / 10 %
-    of candidate / survivor anchors over 384 / 192 frames.  The bounds below leave room for the small samples of these tests."""
+    neighbourhood (one or two survivors).  What the tracker and every consumer see has to hold up regardless: `strict` (the
+    north-star YOLOv8n and the YOLOv8s pipelines) requires >= 75 % of the compared track snapshots EQUIVALENT (same tracks under a
+    consistent id renaming) and >= 90 % of the frames with EQUIVALENT survivor lists (one-to-one partners of the same class,
+    IoU >= 0.9, confidence within 2e-2); where the run carries the storage-rounding emulation of the same schedule (`emulated`), the
+    device is held to IT: no more lost decisions than half storage alone costs.  The seeded
+    YOLOv8l net does not meet that in fp16 (profiles/r04/layer_drift_yolov8l.txt: flat 3-9e-4 per layer, no kernel stands out; its
+    class signal across anchors is ~1 % of the logit magnitude and the calibration stretches the rounding noise with it): it is held to
+    the storage-rounding yardstick alone (`emulated` below) -- and to exactness in fp16x3."""
     n = o["frames"]
     assert o["survivors_compared"] >= 2 * n
     assert o["candidate_anchors_differing"] <= 0.04 * o["candidates_compared"], o
-    assert o["survivor_anchors_differing"] <= 4 * n and o["survivor_anchors_differing"] <= 0.5 * o["survivors_compared"], o
+    assert o["survivor_anchors_differing"] <= 4 * n, o
+    if strict:
+        # the same tracks (state, class, box) under a consistent renaming of ids -- ByteTrack numbers new tracks in detection order, and
+        # two detections tied within the 16-bit error swap list places (chain_parity.ChainStats.add_tracks).  Measured on this file's
+        # samples: 26 of 32 (YOLOv8n), 12 of 12 (YOLOv8s); the CPU emulation that only rounds storage to half loses as many (below)
+        assert o["equivalent_tracks"] >= 0.75 * o["track_states_compared"] > 0, o
+        assert o["equivalent_survivor_sets"] >= 0.9 * n, o
+    e = o.get("emulated")
+    if e is not None:
+        # kernel error or 16-bit rounding?  The device may lose no more decisions than the storage-rounding emulation does (+ a
+        # small-sample allowance): what fp16 costs here is the format's, not the kernels'
+        for k, slack in (("equivalent_tracks", 3), ("equivalent_survivor_sets", 3), ("identical_survivors", 4), ("lanes_within_1px", 4)):
+            assert o[k] >= e[k] - slack, (k, o[k], e[k])
+        for k, slack in (("candidate_anchors_differing", 6), ("survivor_anchors_differing", 6), ("lane_points_off_by_more_than_1px", 6)):
+            assert o[k] <= 2 * e[k] + slack, (k, o[k], e[k])
     assert o["lanes_identical_status"] == n, o
     assert o["lane_points_off_by_more_than_1px"] <= 0.02 * max(1, o["lane_points_compared"]), o
     assert o["max_conf_diff_on_identical_frames"] <= 2e-2 and o["max_box_diff_px_on_identical_frames"] <= 0.5, o
@@ -84,9 +112,9 @@ def _assert_16bit(o):
 
 def test_step_frames_fp16_matches_oracle_chain(tmp_path):
     """The north-star pipeline (YOLOv8n + UFLDv2-R18) in the benchmarked precision: 4 streams x 8 steps, three frame sets."""
-    o = _run_chain(tmp_path, "yolov8n", "fp16", S=4, steps=8, hold=2, n_sets=3)
+    o = _run_chain(tmp_path, "yolov8n", "fp16", S=4, steps=8, hold=2, n_sets=3, emulate="fp16")
     _assert_16bit(o)
-    assert o["identical_survivor_sets"] >= 0.5 * o["frames"], o
+    assert o["identical_survivor_sets"] >= 0.75 * o["frames"], o
 
 
 @pytest.mark.parametrize("prec", ["fp32", "fp16x3"])
@@ -109,11 +137,11 @@ def test_step_frames_split_precision_matches_oracle_chain_exactly(tmp_path):
                                       ("yolov8s", "fp16x3"), ("yolov8l", "fp16x3")])
 def test_c4_c5_pipelines_match_oracle_chain(tmp_path, det, prec):
     """BASELINE configs[3] / configs[4]: YOLOv8s / YOLOv8l + UFLDv2-R18 + ByteTrack on 1280x720 frames, 2 streams x 6 steps."""
-    o = _run_chain(tmp_path, det, prec, S=2, steps=6, hold=2, n_sets=2, seed=410)
+    o = _run_chain(tmp_path, det, prec, S=2, steps=6, hold=2, n_sets=2, seed=410, emulate="fp16" if prec == "fp16" else None)
     if prec in ("fp32", "fp16x3"):
         _assert_exact(o)
     else:
-        _assert_16bit(o)
+        _assert_16bit(o, strict=det != "yolov8l")
 
 
 @pytest.mark.parametrize("prec", ["fp32", "fp16x3"])

@@ -1,0 +1,13 @@
+#!/bin/bash
+out=$GRAFT_REPO_ROOT/gpurun_out/r04e
+mkdir -p $out
+cd $GRAFT_REPO_ROOT
+export TMPDIR=/tmp
+( timeout 900 python -m pytest tests/test_gpu_x3.py -q -s > $out/pytest_x3.log 2>&1; echo "exit $?" >> $out/pytest_x3.log ); tail -3 $out/pytest_x3.log
+( timeout 900 python -m pytest tests/test_gpu_chain.py -q -s -k "x3 or split" > $out/pytest_chain_x3.log 2>&1; echo "exit $?" >> $out/pytest_chain_x3.log ); tail -3 $out/pytest_chain_x3.log
+python tools/profile_layers.py ufldv2_res18 --batch 64 --precision fp16x3 --top 40 > $out/layers_ufld_x3.txt 2>&1
+python tools/profile_layers.py yolov8n --batch 64 --precision fp16x3 --top 80 > $out/layers_v8n_x3.txt 2>&1
+head -6 $out/layers_ufld_x3.txt | cut -c1-140; head -3 $out/layers_v8n_x3.txt | cut -c1-140
+( timeout 600 python bench.py --precision fp16x3 --no-cpu-baseline --no-extras --steps 20 --repeats 2 > $out/bench_x3.json 2> $out/bench_x3.err; echo "exit $?" >> $out/bench_x3.err )
+cut -c1-300 $out/bench_x3.json; tail -2 $out/bench_x3.err
+( timeout 1500 python -m pytest tests -m gpu -q -x > $out/pytest_gpu.log 2>&1; echo "pytest exit $?" >> $out/pytest_gpu.log ); tail -5 $out/pytest_gpu.log

@@ -7,10 +7,11 @@
 // (hi and lo); with 4-channel pixels one 16x16x32 B fragment is 8 consecutive window pixels of one tap row, so a KH-row kernel is KH
 // K-steps of three MFMAs per tile pair (main += w_hi x_hi; cross += w_lo x_hi + w_hi x_lo).  Weights sit in LDS in fragment order
 // (hi array, lo array) for the whole persistent workgroup; the next tile's window is fetched into registers under the current tile's
-// MFMAs.  The ResNet max-pool stays a separate launch (maxpool_x3_kernel) in this precision.
+// MFMAs.  The ResNet stem takes its 3x3 s2 max-pool into the launch (conv_stem_pool_x3_kernel below).
 #include "kernels.h"
 #include "elem16.h"
 #include <string.h>
+#include <type_traits>
 
 namespace adas {
 
@@ -184,6 +185,221 @@ __global__ __launch_bounds__(256, 2) void conv_stem_x3_kernel(StemX3Dev a) {
     if (tile >= a.ntiles) return;
     fetch(tile);
     for (; tile < a.ntiles; tile += gstride) step(tile);
+}
+
+// ---- the ResNet stem with its 3x3 s2 p1 max-pool (backbone.py:50-53) in one launch: 7x7 s2 conv + ReLU on the 9 x 33 conv pixels a
+// 4 x 16 tile of pooled pixels needs (incl. the pool halo), kept in LDS as fp32 (conv pixels outside the image = -inf: the pool's
+// padding), pooled, split and stored -- the 64-channel conv output (32.8 MB per 1600x320 frame in the split storage, written and read
+// back by a separate pool launch: 0.57 ms per 64 frames at the HBM roofline, measured) never exists.  8 waves, one workgroup per CU:
+// 19 M tiles dealt round-robin (tile t -> wave t % 8: every SIMD gets 4-5 tiles); weights 56 KB + max(two windows 26 KB, conv tile
+// 79 KB) of LDS.
+struct StemPoolX3Dev {
+    const float* in;
+    const uint16_t* wfrag;
+    const float* bias;
+    x3s* out;               // pooled NHWC G8 view
+    int out_cs, out_coff;
+    int N, C, H, W;
+    int Ho, Wo, Hp, Wp;     // conv / pooled extents
+    int pad;
+    int tiles_x, tiles_y, ntiles;
+};
+constexpr int SP3_CTH = 9, SP3_CTW = 33, SP3_NPIX = SP3_CTH * SP3_CTW, SP3_NMT = (SP3_NPIX + 15) / 16;   // 297 conv pixels, 19 M tiles
+constexpr int SP3_WH = 2 * (SP3_CTH - 1) + 7, SP3_CP = 68;                                               // window rows; conv-tile pitch (floats)
+constexpr int SP3_WFR = 4 * 7 * 512;
+constexpr int SP3_LDS = 2 * SP3_WFR * 2 + (SP3_NPIX * SP3_CP * 4 > 2 * SP3_WH * SX3_WW * 8 ? SP3_NPIX * SP3_CP * 4 : 2 * SP3_WH * SX3_WW * 8);
+
+__global__ __launch_bounds__(512, 1) void conv_stem_pool_x3_kernel(StemPoolX3Dev a) {
+    Fp16::enter();
+    constexpr int KH = 7, NT = 4, WW = SX3_WW, WH = SP3_WH, CTW = SP3_CTW, NPIX = SP3_NPIX, CP = SP3_CP;
+    constexpr int NQ = (WH * WW + 511) / 512;
+    extern __shared__ __attribute__((aligned(16))) uint16_t sx3_lds[];
+    uint16_t* wlh = sx3_lds;
+    uint16_t* wll = wlh + SP3_WFR;
+    uint16_t* winh = wll + SP3_WFR;            // windows and conv tile share one region (never live together)
+    uint16_t* winl = winh + WH * WW * 4;
+    float* ctile = reinterpret_cast<float*>(winh);
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lrow = lane & 15, kg = lane >> 4;
+    stage_lds16<512, 8>(wlh, a.wfrag, 2 * NT * KH * 64, tid);
+
+    // this wave's M tiles: wave, wave + 8, wave + 16 (the third only for waves 0-2)
+    int boff[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        const int p = (wave + 8 * j) * 16 + lrow;
+        const int pc = p < NPIX ? p : NPIX - 1;
+        const int cy = pc / CTW, cx = pc - cy * CTW;
+        boff[j] = ((2 * cy) * WW + 2 * cx + 2 * kg) * 4;
+    }
+    const bool three = wave + 16 < SP3_NMT;
+    const int per_img = a.tiles_x * a.tiles_y;
+    const int plane = a.H * a.W;
+
+    uint32_t px[NQ][3];
+    auto fetch = [&](int tile) {
+        const bool live = tile < a.ntiles;
+        const int tl = live ? tile : 0;
+        const int img = tl / per_img;
+        const int t2 = tl - img * per_img;
+        const int ty = t2 / a.tiles_x, tx = t2 - ty * a.tiles_x;
+        const int cy0 = 2 * (ty * 4) - 1, cx0 = 2 * (tx * 16) - 1;
+        const int iy0 = 2 * cy0 - a.pad, ix0 = 2 * cx0 - a.pad;
+        const void* in_img = (const void*)(a.in + (size_t)img * a.C * plane);
+        __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)in_img, 0, a.C * plane * 4, 0x00020000);
+#pragma unroll
+        for (int i = 0; i < NQ; ++i) {
+            const int q = tid + 512 * i;
+            const int wy = q / WW, wx = q - wy * WW;
+            const int iy = iy0 + wy, ix = ix0 + wx;
+            const bool ok = live && q < WH * WW && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+            const uint32_t off = (uint32_t)((iy * a.W + ix) * 4);
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const uint32_t oc = (ok && c < a.C) ? off + (uint32_t)(c * plane * 4) : 0x80000000u;
+                px[i][c] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rsrc, oc, 0, 0);
+            }
+        }
+    };
+
+    const int gstride = gridDim.x;
+    auto step = [&](const int tile) {
+        const int img = tile / per_img;
+        const int t2 = tile - img * per_img;
+        const int ty = t2 / a.tiles_x, tx = t2 - ty * a.tiles_x;
+        const int cy0 = 2 * (ty * 4) - 1, cx0 = 2 * (tx * 16) - 1;
+
+        __syncthreads();  // the previous tile's pool is done reading the shared region
+#pragma unroll
+        for (int i = 0; i < NQ; ++i) {
+            const int q = tid + 512 * i;
+            if (q < WH * WW) {
+                _Float16 h[3], l[3];
+#pragma unroll
+                for (int c = 0; c < 3; ++c) x3_split(__uint_as_float(px[i][c]), h[c], l[c]);
+                zu32x2 vh, vl;
+                vh.x = __builtin_bit_cast(uint32_t, e_f16x2{h[0], h[1]});
+                vh.y = __builtin_bit_cast(uint32_t, e_f16x2{h[2], (_Float16)0.0f});
+                vl.x = __builtin_bit_cast(uint32_t, e_f16x2{l[0], l[1]});
+                vl.y = __builtin_bit_cast(uint32_t, e_f16x2{l[2], (_Float16)0.0f});
+                *reinterpret_cast<zu32x2*>(winh + q * 4) = vh;
+                *reinterpret_cast<zu32x2*>(winl + q * 4) = vl;
+            }
+        }
+        __syncthreads();
+        fetch(tile + gstride);
+
+        zf32x4 accm[3][NT], accx[3][NT];
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+#pragma unroll
+            for (int i = 0; i < NT; ++i) accm[j][i] = accx[j][i] = zf32x4{0.f, 0.f, 0.f, 0.f};
+        auto mma = [&](auto mt_c) {
+            constexpr int MT = decltype(mt_c)::value;
+#pragma unroll
+            for (int r = 0; r < KH; ++r) {
+                e_u32x4 wh[NT], wl[NT], xh[MT], xl[MT];
+#pragma unroll
+                for (int i = 0; i < NT; ++i) {
+                    wh[i] = *reinterpret_cast<const e_u32x4*>(wlh + ((i * KH + r) * 64 + lane) * 8);
+                    wl[i] = *reinterpret_cast<const e_u32x4*>(wll + ((i * KH + r) * 64 + lane) * 8);
+                }
+#pragma unroll
+                for (int j = 0; j < MT; ++j) {
+                    xh[j] = *reinterpret_cast<const e_u32x4*>(winh + boff[j] + r * WW * 4);
+                    xl[j] = *reinterpret_cast<const e_u32x4*>(winl + boff[j] + r * WW * 4);
+                }
+#pragma unroll
+                for (int j = 0; j < MT; ++j)
+#pragma unroll
+                    for (int i = 0; i < NT; ++i) accm[j][i] = Fp16::mfma(wh[i], xh[j], accm[j][i]);
+#pragma unroll
+                for (int j = 0; j < MT; ++j)
+#pragma unroll
+                    for (int i = 0; i < NT; ++i) accx[j][i] = Fp16::mfma(wl[i], xh[j], accx[j][i]);
+#pragma unroll
+                for (int j = 0; j < MT; ++j)
+#pragma unroll
+                    for (int i = 0; i < NT; ++i) accx[j][i] = Fp16::mfma(wh[i], xl[j], accx[j][i]);
+            }
+        };
+        if (three) mma(std::integral_constant<int, 3>{});
+        else mma(std::integral_constant<int, 2>{});
+
+        float4 bias4[NT];
+#pragma unroll
+        for (int i = 0; i < NT; ++i) bias4[i] = *reinterpret_cast<const float4*>(a.bias + i * 16 + kg * 4);
+        __syncthreads();  // every wave is done reading the windows: the conv tile may overwrite them
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const int p = (wave + 8 * j) * 16 + lrow;
+            if (p >= NPIX || (j == 2 && !three)) continue;
+            const int cy = p / CTW, cx = p - cy * CTW;
+            const int gy = cy0 + cy, gx = cx0 + cx;
+            const bool valid = (unsigned)gy < (unsigned)a.Ho && (unsigned)gx < (unsigned)a.Wo;   // else: the pool's padding
+#pragma unroll
+            for (int i = 0; i < NT; ++i) {
+                float4 v;
+                v.x = valid ? fmaxf(accm[j][i][0] + accx[j][i][0] * kX3Down + bias4[i].x, 0.0f) : -3.0e38f;
+                v.y = valid ? fmaxf(accm[j][i][1] + accx[j][i][1] * kX3Down + bias4[i].y, 0.0f) : -3.0e38f;
+                v.z = valid ? fmaxf(accm[j][i][2] + accx[j][i][2] * kX3Down + bias4[i].z, 0.0f) : -3.0e38f;
+                v.w = valid ? fmaxf(accm[j][i][3] + accx[j][i][3] * kX3Down + bias4[i].w, 0.0f) : -3.0e38f;
+                *reinterpret_cast<float4*>(ctile + p * CP + i * 16 + kg * 4) = v;
+            }
+        }
+        __syncthreads();
+        {   // pool: thread = (pooled pixel, 8-channel group): 64 x 8 = 512
+            const int pp = tid >> 3, cg = tid & 7;
+            const int py = pp >> 4, pxx = pp & 15;
+            const int gpy = ty * 4 + py, gpx = tx * 16 + pxx;
+            if (gpy < a.Hp && gpx < a.Wp) {
+                float m[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) m[e] = -3.0e38f;
+#pragma unroll
+                for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+                    for (int dx = 0; dx < 3; ++dx) {
+                        const float* cp = ctile + ((2 * py + dy) * CTW + 2 * pxx + dx) * CP + cg * 8;
+                        const float4 v0 = *reinterpret_cast<const float4*>(cp), v1 = *reinterpret_cast<const float4*>(cp + 4);
+                        m[0] = fmaxf(m[0], v0.x); m[1] = fmaxf(m[1], v0.y); m[2] = fmaxf(m[2], v0.z); m[3] = fmaxf(m[3], v0.w);
+                        m[4] = fmaxf(m[4], v1.x); m[5] = fmaxf(m[5], v1.y); m[6] = fmaxf(m[6], v1.z); m[7] = fmaxf(m[7], v1.w);
+                    }
+                x3_store8(a.out + ((size_t)(img * a.Hp + gpy) * a.Wp + gpx) * a.out_cs + a.out_coff + cg * 8, m);
+            }
+        }
+    };
+    int tile = blockIdx.x;
+    if (tile >= a.ntiles) return;
+    fetch(tile);
+    for (; tile < a.ntiles; tile += gstride) step(tile);
+}
+
+bool stem_pool_x3_applicable(int in_c_true, int kh, int kw, int stride, int pad, int act, int res_mode, const TView& conv_out, const TView& pool_out) {
+    if (in_c_true > 3 || stride != 2 || res_mode != RES_NONE || kh != 7 || kw != 7 || pad > 3 || act != ACT_RELU) return false;
+    if (conv_out.c != 64 || pool_out.c != 64 || pool_out.f32 || (pool_out.cs & 7) || (pool_out.coff & 7)) return false;
+    return pool_out.h == (conv_out.h + 2 - 3) / 2 + 1 && pool_out.w == (conv_out.w + 2 - 3) / 2 + 1;
+}
+
+hipError_t launch_conv_stem_pool_x3(const float* nchw, int n, int c_true, int H, int W, int pad, const void* wfrag, const float* bias,
+                                    const TView& conv_out, const TView& pool_out, hipStream_t st) {
+    StemPoolX3Dev d;
+    d.in = nchw; d.wfrag = (const uint16_t*)wfrag; d.bias = bias;
+    d.out = (x3s*)pool_out.p; d.out_cs = pool_out.cs; d.out_coff = pool_out.coff;
+    d.N = n; d.C = c_true; d.H = H; d.W = W; d.Ho = conv_out.h; d.Wo = conv_out.w; d.Hp = pool_out.h; d.Wp = pool_out.w;
+    d.pad = pad;
+    d.tiles_x = (d.Wp + 15) / 16; d.tiles_y = (d.Hp + 3) / 4;
+    d.ntiles = n * d.tiles_x * d.tiles_y;
+    if ((size_t)c_true * H * W * 4 >= (1ull << 31)) return hipErrorInvalidValue;
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute((const void*)conv_stem_pool_x3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_done = true;
+    }
+    const int grid = d.ntiles < 256 ? d.ntiles : 256;   // persistent: one workgroup per CU
+    hipLaunchKernelGGL(conv_stem_pool_x3_kernel, dim3(grid), dim3(512), SP3_LDS, st, d);
+    return hipGetLastError();
 }
 
 // -------------------------------------------------------------------------------------

@@ -230,6 +230,18 @@ int adas_engine_create(const char* model_path, int precision, int max_batch, ada
                                            make_view(e, fo[1].out_buf, fo[1].out_coff, fo[1].out_c))) {
                 e->ops[0].skip = true;
                 e->ops[1].kernel = CONV_STEM;
+                // the ResNet stem's max-pool joins the launch when nothing else reads the conv output
+                bool pool = e->ops.size() >= 3 && fo[2].type == OP_MAXPOOL && fo[2].kh == 3 && fo[2].stride == 2 && fo[2].pad == 1 &&
+                            fo[2].in_buf[0] == fo[1].out_buf && fo[2].in_coff[0] == fo[1].out_coff && fo[2].in_c[0] == fo[1].out_c &&
+                            !is_output(fo[1].out_buf) && !aliased(fo[2].out_buf);
+                for (size_t i = 3; i < fo.size() && pool; ++i) pool = !reads_buf(fo[i], fo[1].out_buf);
+                const char* envp = getenv("ADAS_NO_STEM_POOL_X3");
+                if (pool && !(envp && envp[0] == '1') &&
+                    stem_pool_x3_applicable(hd.in_c, fo[1].kh, fo[1].kw, fo[1].stride, fo[1].pad, fo[1].act, fo[1].res_mode,
+                                            make_view(e, fo[1].out_buf, fo[1].out_coff, fo[1].out_c), make_view(e, fo[2].out_buf, fo[2].out_coff, fo[2].out_c))) {
+                    e->ops[1].fuse_pool = 2;
+                    e->ops[2].skip = true;
+                }
             }
         } else if (enabled && e->ops.size() >= 2 && fo[0].type == OP_INPUT && fo[1].type == OP_CONV && fo[1].in_buf[0] == fo[0].out_buf &&
             !aliased(fo[0].out_buf) && !aliased(fo[1].out_buf)) {
@@ -782,7 +794,9 @@ int engine_run_op(adas_engine* e, int i, const float* d_in, int batch, hipStream
             const FileOp& po = e->ops[op.fuse_pool].f;
             pv = make_view(e, po.out_buf, po.out_coff, po.out_c);
         }
-        if (e->prec == PREC_X3) {
+        if (e->prec == PREC_X3 && op.fuse_pool >= 0) {
+            err = launch_conv_stem_pool_x3(d_in, batch, e->hdr.in_c, e->hdr.in_h, e->hdr.in_w, o.pad, wb + op.w_off, (const float*)(wb + op.b_off), cv, pv, st);
+        } else if (e->prec == PREC_X3) {
             err = launch_conv_stem_x3(d_in, batch, e->hdr.in_c, e->hdr.in_h, e->hdr.in_w, o.kh, o.pad, o.act, wb + op.w_off, (const float*)(wb + op.b_off), cv, st);
         } else if (op.fuse_conv2 >= 0) {
             const EngOp& c2 = e->ops[op.fuse_conv2];

@@ -156,6 +156,10 @@ size_t stem_x3_weight_bytes(int kh, int cout);
 void stem_x3_pack_weights(const float* w_ohwi, int cout, int kh, int kw, int cs, int c_true, uint16_t* dst_host);   // hi array, then lo array
 hipError_t launch_conv_stem_x3(const float* nchw, int n, int c_true, int H, int W, int kh, int pad, int act, const void* wfrag, const float* bias,
                                const TView& out, hipStream_t st);
+// the ResNet stem (7x7 s2 + ReLU, 64 channels) with its 3x3 s2 p1 max-pool in one launch; same weight packing
+bool stem_pool_x3_applicable(int in_c_true, int kh, int kw, int stride, int pad, int act, int res_mode, const TView& conv_out, const TView& pool_out);
+hipError_t launch_conv_stem_pool_x3(const float* nchw, int n, int c_true, int H, int W, int pad, const void* wfrag, const float* bias,
+                                    const TView& conv_out, const TView& pool_out, hipStream_t st);
 hipError_t launch_conv_stem(const float* nchw, int n, int c_true, int H, int W, int kh, int pad, int act, const void* wfrag,
                             const float* bias, const TView& conv_out, bool pool, const TView& pool_out, bool packed_in, int prec, hipStream_t st);
 // CONV_HALO packing: slab order [cout tile of halo_bn(cout)][32-channel chunk][tap][n within tile][32] -- the 9*BN*64 B a
