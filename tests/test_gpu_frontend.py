@@ -156,14 +156,25 @@ def test_bytetracker_dropin_with_label_strings():
     lab_id = {"car": 0, "truck": 1, "bus": 2}
     trk = D.BYTETracker()
     ora = bytetrack.BYTETracker()
+    crop_of = {}
     for fidx in range(40):
         pos += vel + rng.normal(0, 1, (n, 2))
         keep = rng.uniform(size=n) > 0.12
         boxes = np.concatenate([pos, pos + size], 1).astype(np.int64)[keep]
         scores = rng.uniform(0.3, 0.95, n)[keep]
         labs = [l for l, k in zip(labels, keep) if k]
-        msgs = trk.update(boxes.tolist(), scores.tolist(), labs, None)
+        frame = rng.integers(0, 255, (720, 1280, 3)).astype(np.uint8)
+        msgs = trk.update(boxes.tolist(), scores.tolist(), labs, frame)
         want = ora.update(boxes, scores, np.array([lab_id[l] for l in labs]))
+        for m in msgs:
+            # strack.py:131-143 / byteTracker.py:161-168: a track carries ONE crop, taken from the frame it was activated on at its
+            # box of that frame (tlwh truncated to int, clipped to the frame); on that frame the box is the detection's
+            assert isinstance(m["crops"], list) and len(m["crops"]) == 1 and m["crops"][0].dtype == np.uint8
+            if m["start_frame_number"] == m["curr_frame_number"] == fidx + 1:
+                x, y, w, h = (int(np.floor(v + 1e-9)) for v in m["tlwh"])
+                ref = frame[max(0, y):min(720, y + h), max(0, x):min(1280, x + w), :]
+                crop_of[m["track_id"]] = ref.copy()
+            assert np.array_equal(m["crops"][0], crop_of[m["track_id"]]), (fidx, m["track_id"])
         assert [m["track_id"] for m in msgs] == [t["track_id"] for t in want["tracked"]], fidx
         for m, t in zip(msgs, want["tracked"]):
             assert m["is_activated"] == t["is_activated"] and m["state"] == t["state"] and m["score"] == t["score"]

@@ -106,6 +106,21 @@ def test_yolo_post_overflow_is_loud(G):
     assert got["overflow"] and got["rc"] == -5 and got["n_found"] > 128
 
 
+@pytest.mark.parametrize("n_hot,cap", [(3000, 4096), (5000, 8400)])
+def test_yolo_post_unbounded_candidates_spill_to_hbm(G, n_hot, cap):
+    """The reference appends candidates without limit (yoloDetector.py:126-133).  An arena larger than LDS holds (> 2048 candidates, up
+    to one per anchor) works out of a per-frame HBM workspace: thousands of anchors over the threshold, bit-exact against the oracle
+    (candidates, the bug-compatible sequential NMS over all of them, RectInfo fields), in both NMS modes."""
+    head = synth.synth_v8_head(9, n_hot, n_hot // 4)
+    lbp = yolo_post.letterbox_params((720, 1280), (640, 640))
+    for mode in (0, 1):
+        want = yolo_post.detect_post(head, lbp, "yolov8", 0.3, 0.45, "reference" if mode == 0 else "greedy")
+        assert len(want["cand_conf"]) > 2048
+        got = G.yolo_post(head, 0, lbp, 0.3, 0.45, mode, cap=cap)
+        assert got["rc"] == 0 and not got["overflow"] and got["n_found"] == len(want["cand_conf"])
+        pc.check_yolo(got, want)
+
+
 def test_nms_kats(G):
     lbp = yolo_post.letterbox_params((640, 640), (640, 640))
     kats = [([(0, 0, 10, 10), (100, 100, 10, 10), (200, 200, 10, 10)], [.5, .9, .7], [1, 2]),

@@ -647,7 +647,8 @@ hipError_t launch_conv_halo8(const ConvArgs& a, hipStream_t st) {
     const int upt = d.ncb / d.cpw;
     d.mg_upt = (uint32_t)(((1ull << 32) + (uint64_t)upt - 1) / (uint64_t)upt);
     const int units8 = d.tiles8 * upt;
-    const int slots = units8 < H8_SLOTS ? units8 : H8_SLOTS;
+    const int cap_slots = persist_slots(0);
+    const int slots = units8 < cap_slots ? units8 : cap_slots;
     dim3 grid(8 * slots);
     const int forced = h8_mode();
     const bool pingpong = forced == 3 || (forced != 2 && d.nchunk >= 12);

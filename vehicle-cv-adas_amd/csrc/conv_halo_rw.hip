@@ -406,7 +406,7 @@ hipError_t launch_conv_halo_rw(const ConvArgs& a, hipStream_t st) {
     const int bn = a.out.c <= 32 ? 32 : RW_BN;  // == halo_bn(cout): the packing the weights were given
     d.NT = (a.out.c + bn - 1) / bn;
     d.mg_ww = pl.mg_ww; d.mg_sw = pl.mg_sw;
-    int grid = 256 * per_cu / d.NT * d.NT;  // one (or two, see plan_rw) workgroups per CU, a multiple of the channel tiles
+    int grid = 8 * persist_slots(1) * per_cu / d.NT * d.NT;  // one (or two, see plan_rw) workgroups per CU, a multiple of the channel tiles
     const size_t lds = ((size_t)nch * 9 * bn * 32 + (size_t)2 * nch * pl.maxpix * 32) * 2;
     const bool res = a.res_mode != RES_NONE;
     if (res && (((a.res.cs | a.res.coff) & 7) != 0)) return hipErrorNotSupported;  // halo_rw_applicable() keeps such layers on conv_halo

@@ -289,6 +289,21 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvDev a) {
 struct Tile {
     int bm, bn;
 };
+int persist_slots(int which) {
+    // which: 0 conv_halo8, 1 conv_halo_rw, 2 conv_stem.  ADAS_PERSIST_SLOTS sets all three, ADAS_PERSIST_SLOTS_H8 / _RW / _STEM one
+    static int v[3] = {-1, -1, -1};
+    if (v[0] < 0) {
+        const char* all = getenv("ADAS_PERSIST_SLOTS");
+        const char* names[3] = {"ADAS_PERSIST_SLOTS_H8", "ADAS_PERSIST_SLOTS_RW", "ADAS_PERSIST_SLOTS_STEM"};
+        for (int i = 2; i >= 0; --i) {
+            const char* e = getenv(names[i]);
+            int x = e ? atoi(e) : (all ? atoi(all) : 32);
+            v[i] = (x < 4 || x > 32) ? 32 : x;
+        }
+    }
+    return v[which < 0 || which > 2 ? 0 : which];
+}
+
 static Tile pick_tile(const ConvArgs& a, int prec) {
     int bn;
     if (a.out.c <= 16) bn = 16;

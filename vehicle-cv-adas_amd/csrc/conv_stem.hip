@@ -377,7 +377,8 @@ hipError_t launch_conv_stem2(const float* nchw, int n, int c_true, int H, int W,
 
 template <typename E, int KH, int NT, bool POOL>
 static hipError_t stem_launch_act(const StemDev& d, int act, bool packed_in, hipStream_t st) {
-    const int grid = d.ntiles < 1024 ? d.ntiles : 1024;
+    const int cap_grid = 32 * persist_slots(2);   // 1024 at the default: two generations of two workgroups per CU
+    const int grid = d.ntiles < cap_grid ? d.ntiles : cap_grid;
     if constexpr (KH == 3 && !POOL) {      // LeakyReLU(0.1): the 3x3 stems only (YOLOv7)
         if (act == ACT_LEAKY) {
             if (packed_in) hipLaunchKernelGGL((conv_stem_kernel<E, KH, NT, ACT_LEAKY, POOL, false, true>), dim3(grid), dim3(256), 0, st, d);

@@ -12,6 +12,11 @@ inline int prec_esize(int prec) { return prec_is16(prec) ? 2 : 4; }
 enum { ACT_NONE = 0, ACT_SILU = 1, ACT_RELU = 2, ACT_LEAKY = 3 /* LeakyReLU(0.1): YOLOv7 (conv_halo, conv_pw, conv_pwg, conv_igemm) */ };
 enum { RES_NONE = 0, RES_AFTER_ACT = 1, RES_BEFORE_ACT = 2 };
 
+// Workgroups per XCD the PERSISTENT kernels (conv_halo8, conv_halo_rw, conv_stem: one resident workgroup set walking a work list) launch:
+// 32 = every CU (default).  ADAS_PERSIST_SLOTS=<n> leaves (32 - n) CUs of every XCD to whatever else is in flight (the other
+// network's kernels on the pipeline's second stream) -- an experiment knob, read once.
+int persist_slots(int which);   // 0 conv_halo8, 1 conv_halo_rw, 2 conv_stem
+
 // One NHWC tensor view: channel slice [coff, coff+c) of a buffer whose pixel stride is `cs` elements.
 struct TView {
     void* p;

@@ -144,11 +144,18 @@ struct YoloPostDev {
     int* det_cls;
     int* det_xyxy_i;
     double* det_xyxy_d;
+    unsigned char* spill;   // candidate capacities past the LDS arena (> 2048): the frame's working set lives here (HBM), else nullptr
+    size_t spill_stride;
 };
 
+// SPILL: the NMS working set (YoloLds: coordinates, scores, areas, order, reduction scratch) of a frame is carved out of a per-frame
+// HBM workspace instead of LDS.  The reference appends candidates without limit (yoloDetector.py:126-133); a post-processor created
+// with max_candidates above what LDS holds keeps that semantics at HBM latency (same code, same arithmetic, same results).
+template <bool SPILL>
 __global__ __launch_bounds__(256) void yolo_post_kernel(YoloPostDev d) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_lds[];
     const int b = blockIdx.x;
+    unsigned char* smem = SPILL ? d.spill + (size_t)b * d.spill_stride : smem_lds;
     const size_t cap = d.cfg.cap;
     YoloPostFrame f;
     f.head = d.head + b * d.head_stride;
@@ -387,7 +394,8 @@ int adas_yolo_post_create(const adas_yolo_post_params* p, int max_batch, adas_yo
     ADAS_REQUIRE(p->nms_mode == ADAS_NMS_REFERENCE || p->nms_mode == ADAS_NMS_GREEDY, ADAS_ERR_INVALID, "unknown nms mode %d", p->nms_mode);
     ADAS_REQUIRE(p->num_anchors > 0 && p->num_classes > 0, ADAS_ERR_INVALID, "bad head geometry");
     ADAS_REQUIRE(p->box_score >= 0.0, ADAS_ERR_INVALID, "box_score must be >= 0");
-    ADAS_REQUIRE(p->max_candidates >= 16 && p->max_candidates <= 2048, ADAS_ERR_INVALID, "max_candidates must be in [16, 2048]");
+    ADAS_REQUIRE(p->max_candidates >= 16 && p->max_candidates <= (p->num_anchors > 2048 ? p->num_anchors : 2048), ADAS_ERR_INVALID,
+                 "max_candidates must be in [16, max(2048, num_anchors)]");
     ADAS_REQUIRE(adas_device_count() > 0, ADAS_ERR_NO_DEVICE, "no HIP device visible; this library has no CPU fallback");
     adas_yolo_post* h = new (std::nothrow) adas_yolo_post();
     ADAS_REQUIRE(h, ADAS_ERR_INVALID, "out of host memory");
@@ -395,7 +403,9 @@ int adas_yolo_post_create(const adas_yolo_post_params* p, int max_batch, adas_yo
     h->max_batch = max_batch;
     h->last = 0;
     const size_t B = max_batch, A = p->num_anchors, cap = p->max_candidates;
-    size_t bytes = B * (A * 8 + 16 + cap * (4 + 32 + 8 + 4 + 4 + 32 + 8 + 4 + 16 + 32)) + 16 * 256;
+    const bool spill = p->max_candidates > 2048;                       // past the LDS arena: per-frame HBM workspace
+    const size_t spill_stride = spill ? ((YoloLds::bytes(p->max_candidates, 256) + 255) & ~(size_t)255) : 0;
+    size_t bytes = B * (A * 8 + 16 + cap * (4 + 32 + 8 + 4 + 4 + 32 + 8 + 4 + 16 + 32)) + 16 * 256 + B * spill_stride + 256;
     if (hipMalloc(&h->arena, bytes) != hipSuccess) {
         delete h;
         return hip_fail(hipGetLastError(), "hipMalloc(yolo_post arena)", __FILE__, __LINE__);
@@ -420,8 +430,10 @@ int adas_yolo_post_create(const adas_yolo_post_params* p, int max_batch, adas_yo
     d.det_cls = carve<int>(q, B * cap);
     d.det_xyxy_i = carve<int>(q, B * cap * 4);
     d.det_xyxy_d = carve<double>(q, B * cap * 4);
-    size_t lds = YoloLds::bytes(p->max_candidates, 256);
-    if (hipFuncSetAttribute((const void*)yolo_post_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+    d.spill = spill ? carve<unsigned char>(q, B * spill_stride) : nullptr;
+    d.spill_stride = spill_stride;
+    size_t lds = spill ? 0 : YoloLds::bytes(p->max_candidates, 256);
+    if (!spill && hipFuncSetAttribute((const void*)yolo_post_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
         hipFree(h->arena);
         delete h;
         return hip_fail(hipGetLastError(), "hipFuncSetAttribute(yolo_post_kernel)", __FILE__, __LINE__);
@@ -475,8 +487,12 @@ int adas_yolo_post_run(adas_yolo_post* h, const float* d_head, int batch, void* 
         dim3 grid(512, batch);
         hipLaunchKernelGGL(yolo_scan_v5, grid, dim3(256), 0, st, d_head, A, nc, d.best_conf, d.best_cls);
     }
-    size_t lds = YoloLds::bytes(h->p.max_candidates, 256);
-    hipLaunchKernelGGL(yolo_post_kernel, dim3(batch), dim3(256), lds, st, d);
+    if (d.spill) {
+        hipLaunchKernelGGL(yolo_post_kernel<true>, dim3(batch), dim3(256), 0, st, d);
+    } else {
+        size_t lds = YoloLds::bytes(h->p.max_candidates, 256);
+        hipLaunchKernelGGL(yolo_post_kernel<false>, dim3(batch), dim3(256), lds, st, d);
+    }
     ADAS_HIP_TRY(hipGetLastError());
     return ADAS_OK;
 }
@@ -490,7 +506,7 @@ int adas_yolo_post_profile(adas_yolo_post* h, const float* d_head, int batch, in
     d.head = d_head;
     h->last = 0;
     const int A = h->p.num_anchors, nc = h->p.num_classes;
-    const size_t lds = YoloLds::bytes(h->p.max_candidates, 256);
+    const size_t lds = d.spill ? 0 : YoloLds::bytes(h->p.max_candidates, 256);
     ms[0] = ms[1] = 0.f;
     int rc = ADAS_OK;
     for (int it = 0; it < iters && rc == ADAS_OK; ++it) {
@@ -498,7 +514,8 @@ int adas_yolo_post_profile(adas_yolo_post* h, const float* d_head, int batch, in
         if (h->p.layout == ADAS_HEAD_V8) hipLaunchKernelGGL(yolo_scan_v8, dim3(((A + 3) / 4 + 63) / 64, batch), dim3(256), 0, 0, d_head, A, nc, d.best_conf, d.best_cls);
         else hipLaunchKernelGGL(yolo_scan_v5, dim3(512, batch), dim3(256), 0, 0, d_head, A, nc, d.best_conf, d.best_cls);
         (void)hipEventRecord(ev[1], 0);
-        hipLaunchKernelGGL(yolo_post_kernel, dim3(batch), dim3(256), lds, 0, d);
+        if (d.spill) hipLaunchKernelGGL(yolo_post_kernel<true>, dim3(batch), dim3(256), 0, 0, d);
+        else hipLaunchKernelGGL(yolo_post_kernel<false>, dim3(batch), dim3(256), lds, 0, d);
         (void)hipEventRecord(ev[2], 0);
         hipError_t e = hipEventSynchronize(ev[2]);
         if (e == hipSuccess) e = hipGetLastError();

@@ -130,7 +130,7 @@ class _FrameStage:
 
 
 # =====================================================================================
-MAX_CANDIDATE_LIMIT = 2048     # adas_yolo_post_create's upper bound (post_kernels.hip)
+MAX_LDS_CANDIDATES = 2048      # candidate arenas up to this size live in LDS; larger ones (up to one per anchor) in HBM (post_kernels.hip)
 
 
 class YoloDetector(_Defaults):
@@ -204,24 +204,18 @@ class YoloDetector(_Defaults):
         post = self._post_for((h, w))
         post.run_device(self.engine.output_device_ptr(0), 1, None)
         r = post.fetch(0)
-        # The reference's candidate lists are unbounded (yoloDetector.py:120-133); the device arena is not.  A frame with more
-        # anchors over box_score than the arena holds is re-run with a larger arena (the head tensor is still in HBM); past the
-        # library's limit the frame is reported with its first `max_candidates` anchors and a warning -- never an exception
-        # in the middle of a video loop.
-        while r["overflow"] and self.max_candidates < MAX_CANDIDATE_LIMIT:
-            self.max_candidates = min(MAX_CANDIDATE_LIMIT, max(2 * self.max_candidates, int(r["n_found"])))
+        # The reference's candidate lists are unbounded (yoloDetector.py:120-133).  A frame with more anchors over box_score than the
+        # arena holds is re-run with a larger arena (the head tensor is still in HBM): up to one slot per anchor, at which point nothing
+        # can overflow -- arenas past MAX_LDS_CANDIDATES work out of an HBM workspace (slower, same results).
+        limit = int(post.params.num_anchors)
+        while r["overflow"] and self.max_candidates < limit:
+            self.max_candidates = min(limit, max(2 * self.max_candidates, int(r["n_found"])))
             self._post_key = None
             post = self._post_for((h, w))
             post.run_device(self.engine.output_device_ptr(0), 1, None)
             r = post.fetch(0)
         if r["overflow"]:
-            msg = "YoloDetector: %d anchors over box_score exceed the %d-candidate arena; NMS ran on the first %d" % (
-                r["n_found"], self.max_candidates, self.max_candidates)
-            if self.logger:
-                self.logger.warning(msg)
-            else:
-                import warnings
-                warnings.warn(msg, RuntimeWarning)
+            raise RuntimeError("YoloDetector: %d anchors over box_score with a %d-candidate arena of %d anchors" % (r["n_found"], self.max_candidates, limit))
         elif r["rc"] != 0:
             L.check(r["rc"])
         self._last = r
@@ -657,6 +651,7 @@ class BYTETracker:
         self._dev = DeviceTracker(1, track_thresh, track_buffer, match_thresh, frame_rate, max_tracks, max_dets)
         self._tracked: List[Dict[str, Any]] = []
         self._lost: List[Dict[str, Any]] = []
+        self._crops: Dict[int, list] = {}      # track id -> [crop]: strack.py:46,131-143 (filled once, when the track is activated)
 
     def _cls_index(self, c):
         if isinstance(c, (int, np.integer)):
@@ -675,7 +670,7 @@ class BYTETracker:
                         "state": int(r["state"]), "score": float(r["score"]), "start_frame_number": int(r["start_frame"]),
                         "curr_frame_number": int(r["frame_id"]),
                         "time_since_update": int(self.frame_id - r["frame_id"]), "location": str((np.inf, np.inf)),
-                        "crops": None, "class_id": self._cls_value(int(r["class_id"])),
+                        "crops": self._crops.get(int(r["track_id"]), []), "class_id": self._cls_value(int(r["class_id"])),
                         "tlwh": [float(v) for v in r["tlwh"]]})
         return out
 
@@ -686,6 +681,20 @@ class BYTETracker:
         c = np.asarray([self._cls_index(x) for x in class_ids], np.int32)
         self._dev.update_host(0, b, s, c)
         hdr, tracked, lost = self._dev.fetch(0)
+        if frame is not None:
+            # byteTracker.py:161-168: a NEW track (unmatched detection over det_thresh) is activated and takes one crop of the frame at
+            # its box (strack.py:131-143: tlwh truncated to int, clipped to the frame, copied); older tracks keep theirs
+            fr = np.asarray(frame)
+            for r in tracked:
+                tid = int(r["track_id"])
+                if int(r["start_frame"]) == self.frame_id and tid not in self._crops:
+                    tx1, ty1, tw, th = (int(np.floor(float(v) + 1e-9)) for v in r["tlwh"])
+                    x1, y1 = max(0, tx1), max(0, ty1)
+                    x2, y2 = min(fr.shape[1], tx1 + tw), min(fr.shape[0], ty1 + th)
+                    self._crops[tid] = [fr[y1:y2, x1:x2, :].copy()]
+        live = {int(r["track_id"]) for r in tracked} | {int(r["track_id"]) for r in lost}
+        for tid in [t for t in self._crops if t not in live]:
+            del self._crops[tid]                       # removed tracks: their crops go with them
         self._tracked = self._messages(tracked, hdr.id_count)
         self._lost = self._messages(lost, hdr.id_count)
         return self._tracked
@@ -701,6 +710,7 @@ class BYTETracker:
     def reset(self):
         self.frame_id = 0
         self._tracked, self._lost = [], []
+        self._crops = {}
         self._dev.reset(0)
 
     def close(self):
