@@ -1,0 +1,228 @@
+"""models.Graph -> ONNX file, in the node vocabulary the exporters of the reference's models emit (ultralytics / torch.onnx.export):
+Conv (+ Sigmoid, Mul = SiLU | Relu | LeakyRelu) [+ Add], grouped Conv, MaxPool, AveragePool, Resize(nearest, x2), Slice / Split, Concat,
+and the Detect tail (Concat -> Reshape -> Concat -> Split -> DFL softmax-expectation conv -> dist2bbox arithmetic -> Sigmoid -> Concat for the
+v8 layout; Reshape -> Transpose -> Sigmoid -> grid / anchor arithmetic for the v5 layout).
+
+TEST INFRASTRUCTURE: lets the suite write ONNX files of graphs that models.py does NOT hand-build (other widths / depths, ad-hoc
+topologies) and check that vehicle-cv-adas_amd/onnx_lower.py maps them back onto the engine's op list.  Shares no code with the lowering."""
+import importlib
+
+import numpy as np
+
+import onnx_writer as OW
+from conftest import load_pkg
+
+load_pkg()
+M = importlib.import_module("adas_amd.models")
+
+
+def _i64(name, vals):
+    return OW.tensor(name, np.asarray(vals, np.int64))
+
+
+class Emitter:
+    def __init__(self, g, use_split=True):
+        self.g = g
+        self.blob = np.frombuffer(bytes(g.blob), np.float32)
+        self.nodes, self.inits = [], []
+        self.segs = {}          # buffer -> list of (coff, c, tensor name), latest writer wins
+        self.n = 0
+        self.use_split = use_split
+        self.split_cache = {}
+
+    def name(self, base):
+        self.n += 1
+        return "%s_%d" % (base, self.n)
+
+    def node(self, op, ins, outs, attrs=(), name=None):
+        self.nodes.append(OW.node(op, ins, outs, name or self.name("/" + op), attrs))
+
+    def wrote(self, view, tensor):
+        segs = [s for s in self.segs.get(view.buf, []) if s[0] + s[1] <= view.coff or s[0] >= view.coff + view.c]
+        segs.append((view.coff, view.c, tensor))
+        self.segs[view.buf] = sorted(segs)
+
+    def slice_of(self, tensor, total_c, off, c):
+        if off == 0 and c == total_c:
+            return tensor
+        if self.use_split and total_c == 2 * c and off in (0, c):          # x.chunk(2, 1): one Split node, both halves
+            key = (tensor, c)
+            if key not in self.split_cache:
+                a, b = self.name(tensor + "_s0"), self.name(tensor + "_s1")
+                sp = self.name("split")
+                self.inits.append(_i64(sp, [c, c]))
+                self.node("Split", [tensor, sp], [a, b], [OW.attr_int("axis", 1)])
+                self.split_cache[key] = (a, b)
+            return self.split_cache[key][0 if off == 0 else 1]
+        if (tensor, off, c) in self.split_cache:
+            return self.split_cache[(tensor, off, c)]
+        out = self.name(tensor + "_sl")
+        self.split_cache[(tensor, off, c)] = out
+        st, en, ax = self.name("starts"), self.name("ends"), self.name("axes")
+        self.inits += [_i64(st, [off]), _i64(en, [off + c]), _i64(ax, [1])]
+        self.node("Slice", [tensor, st, en, ax], [out])
+        return out
+
+    def read(self, view):
+        """ONNX tensor holding the channels [coff, coff + c) of the view's buffer: a produced tensor, a slice of one, or a Concat."""
+        parts, pos, end = [], view.coff, view.coff + view.c
+        for off, c, t in self.segs.get(view.buf, []):
+            if off + c <= pos or off >= end:
+                continue
+            assert off <= pos, ("hole in buffer %d at channel %d" % (view.buf, pos))
+            lo, hi = pos - off, min(end, off + c) - off
+            parts.append(self.slice_of(t, c, lo, hi - lo))
+            pos = off + hi
+        assert pos == end and parts, (view.buf, view.coff, view.c, self.segs.get(view.buf))
+        if len(parts) == 1:
+            return parts[0]
+        out = self.name("cat")
+        self.node("Concat", parts, [out], [OW.attr_int("axis", 1)])
+        return out
+
+    def act(self, x, a):
+        if a == M.ACT_SILU:
+            s, o = self.name("sig"), self.name("silu")
+            self.node("Sigmoid", [x], [s])
+            self.node("Mul", [x, s], [o])
+            return o
+        if a == M.ACT_RELU:
+            o = self.name("relu")
+            self.node("Relu", [x], [o])
+            return o
+        if a == M.ACT_LEAKY:
+            o = self.name("lrelu")
+            self.node("LeakyRelu", [x], [o], [OW.attr_float("alpha", 0.1)])
+            return o
+        return x
+
+    def emit(self, path, out_name="output0"):
+        g = self.g
+        first_conv = True
+        outputs = []
+        for op in g.ops:
+            t, ins, out = op["type"], op["ins"], op["out"]
+            (wo, wn), (bo, bn) = op["w"], op["b"]
+            w, b = self.blob[wo // 4: wo // 4 + wn], self.blob[bo // 4: bo // 4 + bn]
+            if t == M.OP_INPUT:
+                self.wrote(M.View(out.buf, 0, 8, out.h, out.w), "images")
+            elif t == M.OP_CONV:
+                k, cout, cin_buf = op["kh"], out.c, ins[0].c
+                if first_conv:
+                    cin = g.in_c
+                    W = w.reshape(cout, k, k, cin_buf)[..., :cin].transpose(0, 3, 1, 2)
+                    x = "images"
+                    first_conv = False
+                else:
+                    cin = cin_buf
+                    W = w.reshape(cout, cin, 1, 1) if (k == 1 and w.size == cout * cin) else w.reshape(cout, k, k, cin).transpose(0, 3, 1, 2)
+                    x = self.read(ins[0])
+                base = op["name"]
+                self.inits += [OW.tensor(base + ".weight", np.ascontiguousarray(W, np.float32)), OW.tensor(base + ".bias", np.ascontiguousarray(b, np.float32))]
+                y = self.name(base + "_out")
+                p = op["pad"]
+                self.node("Conv", [x, base + ".weight", base + ".bias"], [y],
+                          [OW.attr_ints("kernel_shape", [k, k]), OW.attr_ints("strides", [op["stride"]] * 2), OW.attr_ints("pads", [p] * 4),
+                           OW.attr_ints("dilations", [1, 1]), OW.attr_int("group", 1)], name="/" + base + "/Conv")
+                if op["res_mode"] == M.RES_BEFORE_ACT:
+                    s_ = self.name("add")
+                    self.node("Add", [y, self.read(op["res"])], [s_])
+                    y = self.act(s_, op["act"])
+                else:
+                    y = self.act(y, op["act"])
+                    if op["res_mode"] == M.RES_AFTER_ACT:
+                        s_ = self.name("add")
+                        self.node("Add", [self.read(op["res"]), y], [s_])
+                        y = s_
+                self.wrote(out, y)
+            elif t == M.OP_DWCONV:
+                k, c = op["kh"], out.c
+                base = op["name"]
+                self.inits += [OW.tensor(base + ".weight", np.ascontiguousarray(w.reshape(c, 1, k, k), np.float32)), OW.tensor(base + ".bias", np.ascontiguousarray(b, np.float32))]
+                y = self.name(base + "_out")
+                self.node("Conv", [self.read(ins[0]), base + ".weight", base + ".bias"], [y],
+                          [OW.attr_ints("kernel_shape", [k, k]), OW.attr_ints("strides", [op["stride"]] * 2), OW.attr_ints("pads", [op["pad"]] * 4),
+                           OW.attr_ints("dilations", [1, 1]), OW.attr_int("group", c)])
+                y = self.act(y, op["act"])
+                if op["res_mode"] != M.RES_NONE:
+                    s_ = self.name("add")
+                    self.node("Add", [self.read(op["res"]), y], [s_])
+                    y = s_
+                self.wrote(out, y)
+            elif t in (M.OP_MAXPOOL, M.OP_AVGPOOL):
+                y = self.name("pool")
+                attrs = [OW.attr_ints("kernel_shape", [op["kh"]] * 2), OW.attr_ints("strides", [op["stride"]] * 2), OW.attr_ints("pads", [op["pad"]] * 4)]
+                if t == M.OP_AVGPOOL:
+                    attrs.append(OW.attr_int("count_include_pad", 1))
+                self.node("MaxPool" if t == M.OP_MAXPOOL else "AveragePool", [self.read(ins[0])], [y], attrs)
+                self.wrote(out, y)
+            elif t == M.OP_UPSAMPLE2:
+                y, sc = self.name("up"), self.name("scales")
+                self.inits.append(OW.tensor(sc, np.asarray([1, 1, 2, 2], np.float32)))
+                self.node("Resize", [self.read(ins[0]), "", sc], [y], [OW.attr_str("mode", "nearest")])
+                self.wrote(out, y)
+            elif t == M.OP_DETECT_V8:
+                nc, A = int(op["params"][0]), int(op["params"][1])
+                lv = []
+                for i in range(3):
+                    c_, r_ = self.name("dcat"), self.name("dresh")
+                    self.node("Concat", [self.read(ins[2 * i]), self.read(ins[2 * i + 1])], [c_], [OW.attr_int("axis", 1)])
+                    shp = self.name("shape")
+                    self.inits.append(_i64(shp, [1, 64 + nc, -1]))
+                    self.node("Reshape", [c_, shp], [r_])
+                    lv.append(r_)
+                allc = self.name("dall")
+                self.node("Concat", lv, [allc], [OW.attr_int("axis", 2)])
+                # the rest of the tail (DFL expectation, dist2bbox, sigmoid) as the exporter writes it; the lowering recognises the head
+                # by its front (three Concat -> Reshape pairs feeding one axis-2 Concat) and replaces everything behind it
+                bx, cl, sp = self.name("box"), self.name("cls"), self.name("split")
+                self.inits.append(_i64(sp, [64, nc]))
+                self.node("Split", [allc, sp], [bx, cl], [OW.attr_int("axis", 1)])
+                s1, r1, t1, sm, dfl, r2 = (self.name(n) for n in ("shape", "r", "t", "sm", "dfl", "r"))
+                self.inits += [_i64(s1, [1, 4, 16, A]), OW.tensor("dfl.conv.weight", np.arange(16, dtype=np.float32).reshape(1, 16, 1, 1))]
+                self.node("Reshape", [bx, s1], [r1])
+                self.node("Transpose", [r1], [t1], [OW.attr_ints("perm", [0, 2, 1, 3])])
+                self.node("Softmax", [t1], [sm], [OW.attr_int("axis", 1)])
+                self.node("Conv", [sm, "dfl.conv.weight"], [dfl], [OW.attr_ints("kernel_shape", [1, 1])])
+                s2 = self.name("shape")
+                self.inits.append(_i64(s2, [1, 4, A]))
+                self.node("Reshape", [dfl, s2], [r2])
+                sg = self.name("clsp")
+                self.node("Sigmoid", [cl], [sg])
+                self.node("Concat", [r2, sg], [out_name], [OW.attr_int("axis", 1)])
+                outputs.append((out_name, [1, 4 + nc, A]))
+            elif t == M.OP_DETECT_V5:
+                nc, A = int(op["params"][0]), int(op["params"][1])
+                no = nc + 5
+                anc = self.blob[wo // 4: wo // 4 + wn].reshape(3, 3, 2)
+                rows = []
+                for l in range(3):
+                    h, w_ = ins[l].h, ins[l].w
+                    s5, r5, t5, sg = (self.name(n) for n in ("shape", "r5", "t5", "sig"))
+                    self.inits.append(_i64(s5, [1, 3, no, h, w_]))
+                    self.node("Reshape", [self.read(ins[l]), s5], [r5])
+                    self.node("Transpose", [r5], [t5], [OW.attr_ints("perm", [0, 1, 3, 4, 2])])
+                    self.node("Sigmoid", [t5], [sg])
+                    # wh branch: (2 p)^2 * anchor_grid -- the constant the lowering reads the anchors from
+                    ag, two, m2, pw, wh = (self.name(n) for n in ("anchor_grid", "two", "m2", "pow", "wh"))
+                    self.inits += [OW.tensor(ag, np.ascontiguousarray(np.broadcast_to(anc[l].reshape(1, 3, 1, 1, 2), (1, 3, h, w_, 2)), np.float32)),
+                                   OW.tensor(two, np.asarray([2.0], np.float32))]
+                    self.node("Mul", [sg, two], [m2])
+                    self.node("Pow", [m2, two], [pw])
+                    self.node("Mul", [pw, ag], [wh])
+                    s3, r3 = self.name("shape"), self.name("rows")
+                    self.inits.append(_i64(s3, [1, -1, no]))
+                    self.node("Reshape", [wh, s3], [r3])
+                    rows.append(r3)
+                self.node("Concat", rows, [out_name], [OW.attr_int("axis", 1)])
+                outputs.append((out_name, [1, A, no]))
+            else:
+                raise NotImplementedError("emitter: op type %d (%s)" % (t, op["name"]))
+        assert outputs, "graph has no Detect op (the emitter writes detector graphs)"
+        data = OW.model(self.nodes, self.inits, [("images", [1, g.in_c, g.in_h, g.in_w])], outputs)
+        open(path, "wb").write(data)
+        return path
+
+
+def emit(g, path, use_split=True):
+    return Emitter(g, use_split).emit(path)

@@ -50,6 +50,10 @@ def attr_float(name, f):
     return _ld(1, name.encode()) + _varint((2 << 3) | 5) + struct.pack("<f", f) + _vi(20, 1)
 
 
+def attr_str(name, text):
+    return _ld(1, name.encode()) + _ld(4, text.encode()) + _vi(20, 3)
+
+
 def node(op, inputs, outputs, name="", attrs=()):
     out = b"".join(_ld(1, i.encode()) for i in inputs) + b"".join(_ld(2, o.encode()) for o in outputs)
     out += _ld(3, name.encode()) + _ld(4, op.encode()) + b"".join(_ld(5, a) for a in attrs)

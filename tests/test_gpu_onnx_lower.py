@@ -1,0 +1,62 @@
+"""GPU: an ONNX file of a graph models.py does not hand-build goes straight into HipEngine (coreEngine.py:159-186: the reference hands any
+ONNX file to its engine): the generic lowering (onnx_lower.py) turns it into the engine's op list, the engine's load-time passes fuse it
+like a hand-built graph, and the outputs match the torch interpreter of the ORIGINAL op list (tests/graph_interp.py) within the
+precisions' usual bounds."""
+import importlib
+
+import numpy as np
+import pytest
+
+import graph_interp
+import onnx_emit
+from conftest import load_pkg
+
+pytestmark = pytest.mark.gpu
+load_pkg()
+M = importlib.import_module("adas_amd.models")
+CE = importlib.import_module("adas_amd.coreEngine")
+
+
+def _custom_v8(tag, depth, width, **kw):
+    M.V8_SCALES[tag] = (depth, width, 1024)
+    try:
+        return M.yolov8(tag, **kw)
+    finally:
+        del M.V8_SCALES[tag]
+
+
+@pytest.mark.parametrize("prec,tol", [("fp32", 1e-5), ("fp16x3", 1e-5), ("fp16", 5e-3), ("bf16", 4e-2)])
+def test_custom_scale_yolov8_onnx_runs_through_hipengine(tmp_path, prec, tol):
+    g = _custom_v8("q", 0.67, 0.375, imgsz=(128, 160), nc=80)          # width 0.375: 24-channel stem -- no builder, no detect_arch entry
+    path = str(tmp_path / "yolov8q.onnx")
+    onnx_emit.emit(g, path)
+    x = np.random.default_rng(1).uniform(0, 1, (2, 3, 128, 160)).astype(np.float32)
+    want = graph_interp.run(g, x)[0]
+    e = CE.OnnxEngine(path, precision=prec, max_batch=2)               # the reference's call: OnnxEngine("model.onnx")
+    assert e.get_engine_input_shape() == [1, 3, 128, 160] and e.get_engine_output_shape()[0] == [[1, 84, want.shape[2]]]
+    got = np.array(e.engine_inference(x)[0], copy=True)
+    kernels = [e.layer_kernel(i, 2) for i in range(e.stats()["num_layers"])]
+    e.close()
+    rel = float(np.linalg.norm(got - want) / np.linalg.norm(want))
+    print("lowered yolov8(custom) %s: rel %.2e  max|prob diff| %.2e" % (prec, rel, float(np.abs(got[:, 4:] - want[:, 4:]).max())))
+    assert rel <= tol
+    if prec == "fp16":      # the engine's fusion passes see a lowered graph like a hand-built one
+        assert any("detect_v8_fused_kernel" in k for k in kernels) and any("conv_stem_kernel" in k for k in kernels), kernels
+
+
+def test_v5_layout_onnx_runs_through_hipengine(tmp_path):
+    g = M.build("yolov7-tiny", imgsz=(96, 128), nc=11)
+    path = str(tmp_path / "v7_generic.onnx")
+    onnx_emit.emit(g, path)
+    OL = importlib.import_module("adas_amd.onnx_lower")
+    OI = importlib.import_module("adas_amd.onnx_import")
+    g2 = OL.lower(OI.read_onnx(path), "v7g")                           # the generic path (convert() would pick the hand-built builder)
+    hipm = str(tmp_path / "v7_generic.hipm")
+    g2.save(hipm)
+    x = np.random.default_rng(2).uniform(0, 1, (2, 3, 96, 128)).astype(np.float32)
+    want = graph_interp.run(g, x)[0]
+    e = CE.HipEngine(hipm, precision="fp32", max_batch=2)
+    got = np.array(e.engine_inference(x)[0], copy=True)
+    e.close()
+    assert got.shape == want.shape
+    assert float(np.abs(got - want).max()) <= 1e-3 * max(1.0, float(np.abs(want).max()))

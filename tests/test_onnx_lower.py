@@ -1,0 +1,129 @@
+"""CPU: the ONNX graph lowering (vehicle-cv-adas_amd/onnx_lower.py): detector graphs that models.py does NOT hand-build are written as ONNX
+files in the exporters' node vocabulary (tests/onnx_emit.py), lowered back onto the engine's op list and run through the torch interpreter
+of that op list (tests/graph_interp.py) next to the original graph: same outputs, no extra copies where producers can write into the
+concat buffers.  The reference loads ANY ONNX file through ONNXRuntime (coreEngine.py:159-186); this is the counterpart for graphs outside
+the hand-built set."""
+import importlib
+import os
+
+import numpy as np
+import pytest
+
+import graph_interp
+import onnx_emit
+import onnx_writer as OW
+from conftest import load_pkg
+
+load_pkg()
+M = importlib.import_module("adas_amd.models")
+OI = importlib.import_module("adas_amd.onnx_import")
+OL = importlib.import_module("adas_amd.onnx_lower")
+
+
+def _roundtrip(g, path, use_split=True, n=2, via_convert=False):
+    onnx_emit.emit(g, str(path), use_split)
+    if via_convert:
+        hipm, g2 = OI.convert(str(path), str(path) + ".hipm")
+        assert os.path.getsize(hipm) > 0
+    else:
+        g2 = OL.lower(OI.read_onnx(str(path)), "t")
+    x = np.random.default_rng(0).uniform(0, 1, (n, 3, g.in_h, g.in_w)).astype(np.float32)
+    a, b = graph_interp.run(g, x), graph_interp.run(g2, x)
+    assert len(a) == len(b) == 1 and a[0].shape == b[0].shape
+    return g2, float(np.abs(a[0] - b[0]).max())
+
+
+def _custom_v8(tag, depth, width, **kw):
+    M.V8_SCALES[tag] = (depth, width, 1024)
+    try:
+        return M.yolov8(tag, **kw)
+    finally:
+        del M.V8_SCALES[tag]
+
+
+@pytest.mark.parametrize("use_split", [True, False], ids=["Split", "Slice"])
+def test_yolov8_custom_scale_not_in_models(tmp_path, use_split):
+    """A YOLOv8 at width 0.375 / depth 0.67 (24-channel stem, two Bottlenecks per C2f): no builder has it, detect_arch rejects it, the
+    lowering maps it op for op -- same op count, same buffer count (every Concat input is written in place), identical outputs."""
+    g = _custom_v8("q", 0.67, 0.375, imgsz=(64, 96), nc=12)
+    with pytest.raises(ValueError):
+        onnx_emit.emit(g, str(tmp_path / "q0.onnx"), use_split)
+        OI.detect_arch(OI.read_onnx(str(tmp_path / "q0.onnx")))
+    g2, err = _roundtrip(g, tmp_path / "q.onnx", use_split, via_convert=True)
+    assert err == 0.0
+    assert len(g2.ops) == len(g.ops) and len(g2.bufs) == len(g.bufs)
+    assert g2.meta["kind"] == "yolov8" and g2.meta["nc"] == 12
+    assert g2.outs[0][2] == g.outs[0][2]
+
+
+def test_v5_layout_head_and_leaky_relu(tmp_path):
+    """YOLOv7-tiny's op vocabulary (LeakyReLU, SPP max-pools of one tensor, IDetect in deploy form) through the GENERIC path: the anchors
+    come out of the graph's anchor_grid constants."""
+    g = M.build("yolov7-tiny", imgsz=64, nc=7)
+    g2, err = _roundtrip(g, tmp_path / "v7.onnx")
+    assert err == 0.0 and g2.meta["kind"] == "yolov5" and len(g2.ops) == len(g.ops)
+    d0 = [o for o in g.ops if o["type"] == M.OP_DETECT_V5][0]
+    d1 = [o for o in g2.ops if o["type"] == M.OP_DETECT_V5][0]
+    blob0, blob1 = np.frombuffer(bytes(g.blob), np.float32), np.frombuffer(bytes(g2.blob), np.float32)
+    assert np.array_equal(blob0[d0["w"][0] // 4: d0["w"][0] // 4 + 18], blob1[d1["w"][0] // 4: d1["w"][0] // 4 + 18])
+
+
+def test_gelan_style_graph_with_average_pools(tmp_path):
+    """YOLOv9t's vocabulary (AConv average pools, RepNCSPELAN4 with nested splits and concats): tensors that sit in two concats are
+    copied into the second one (a 1x1 max-pool), everything else is written in place."""
+    g = M.build("yolov9t", imgsz=64, nc=5)
+    g2, err = _roundtrip(g, tmp_path / "v9.onnx")
+    assert err == 0.0
+    copies = [o for o in g2.ops if o["type"] == M.OP_MAXPOOL and o["kh"] == 1]
+    assert len(g2.ops) - len(g.ops) == len(copies) <= 16
+
+
+def test_adhoc_graph_residuals_both_orders_and_depthwise(tmp_path):
+    """A graph no family has: ResNet-style pre-activation residual (Conv -> Add -> ReLU), Bottleneck-style post-activation residual,
+    a depth-wise 3x3, nested concats, and a v8 Detect head on three ad-hoc pyramid levels."""
+    ws = M.SynthWeights(3, gain=1.0)
+    g = M.Graph("adhoc", 3, 64, 64, ws)
+    x, cin = g.input()
+    x = g.conv(x, 16, 3, 2, "stem", act=M.ACT_RELU, true_cin=cin)
+    t = g.conv(x, 16, 3, 1, "b0.conv1", act=M.ACT_RELU)
+    x = g.conv(t, 16, 3, 1, "b0.conv2", act=M.ACT_RELU, res=x, res_mode=M.RES_BEFORE_ACT)
+    cat = g.buf(16, 16, 48)
+    p3 = g.conv(x, 32, 3, 2, "down1", out=cat.slice(0, 32))
+    g.dwconv(p3.slice(0, 16), 3, 1, "dw", act=M.ACT_SILU, out=cat.slice(32, 16), res=p3.slice(16, 16))
+    p3 = g.conv(cat, 32, 1, 1, "mix", act=M.ACT_LEAKY)
+    p4 = g.conv(p3, 64, 3, 2, "down2")
+    t = g.conv(p4, 64, 3, 1, "b1.cv1")
+    p4 = g.conv(t, 64, 3, 1, "b1.cv2", res=p4, res_mode=M.RES_AFTER_ACT)
+    p5 = g.maxpool(p4, 2, 2, 0, name="mp")
+    ins, strides, nc = [], [], 9
+    for i, f in enumerate((p3, p4, p5)):
+        b = g.conv(f, 64, 1, 1, "head.cv2.%d" % i, act=M.ACT_NONE, f32_out=True)
+        c = g.conv(f, nc, 1, 1, "head.cv3.%d" % i, act=M.ACT_NONE, f32_out=True)
+        ins += [b, c]
+        strides.append(64 // f.h)
+    A = sum(f.h * f.w for f in (p3, p4, p5))
+    head = g.buf(1, 1, (4 + nc) * A, f32=True)
+    g._op(M.OP_DETECT_V8, ins, head, params=[nc, A] + strides, name="decode")
+    g.output(head, 0, [1, 4 + nc, A], "output0")
+    g2, err = _roundtrip(g, tmp_path / "adhoc.onnx", via_convert=True)
+    assert err == 0.0 and len(g2.ops) == len(g.ops)
+    kinds = [(o["type"], o["act"], o["res_mode"]) for o in g2.ops]
+    assert (M.OP_CONV, M.ACT_RELU, M.RES_BEFORE_ACT) in kinds and (M.OP_CONV, M.ACT_SILU, M.RES_AFTER_ACT) in kinds
+    assert any(o["type"] == M.OP_DWCONV and o["res_mode"] == M.RES_AFTER_ACT for o in g2.ops)
+
+
+def test_unsupported_nodes_fail_loudly_naming_the_node(tmp_path):
+    """Softmax attention (YOLOv10's PSA) and stand-alone arithmetic have no counterpart: the error names the node and the op."""
+    w = np.zeros((8, 3, 3, 3), np.float32)
+    nodes = [OW.node("Conv", ["images", "w"], ["c"], "/c", [OW.attr_ints("kernel_shape", [3, 3]), OW.attr_ints("pads", [1, 1, 1, 1])]),
+             OW.node("Softmax", ["c"], ["s"], "/attn/Softmax", [OW.attr_int("axis", 1)]),
+             OW.node("Conv", ["s", "w2"], ["o1"], "/h1", [OW.attr_ints("kernel_shape", [1, 1])]),
+             OW.node("Concat", ["o1", "o1"], ["cc"], "/cat", [OW.attr_int("axis", 1)]),
+             OW.node("Reshape", ["cc", "shp"], ["r"], "/r")]
+    inits = [OW.tensor("w", w), OW.tensor("w2", np.zeros((64, 8, 1, 1), np.float32)), OW.tensor("shp", np.asarray([1, 128, -1], np.int64))]
+    p = tmp_path / "bad.onnx"
+    open(p, "wb").write(OW.model(nodes, inits, [("images", [1, 3, 32, 32])], [("r", [1, 128, 1024])]))
+    with pytest.raises(ValueError, match="Detect head|Softmax"):
+        OL.lower(OI.read_onnx(str(p)))
+    with pytest.raises(ValueError, match="neither a hand-built architecture"):
+        OI.convert(str(p))

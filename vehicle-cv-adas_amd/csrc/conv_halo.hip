@@ -421,6 +421,23 @@ static bool plan_halo_uncached(int Ho, int Wo, int S, int maxpix_cap, int bm, Ha
     return found;
 }
 
+// one strip width, as given (experiments: ADAS_H8_SW): the same bookkeeping as a candidate of plan_halo_uncached
+bool plan_halo_sw(int Ho, int Wo, int S, int SW, int maxpix_cap, HaloPlan* out) {
+    const int BM = halo_bm(S), MAXPIX = maxpix_cap > 0 ? maxpix_cap : halo_maxpix(S, BM);
+    if (SW < 8) return false;
+    int rows = (BM + SW - 1) / SW + ((BM % SW) ? 1 : 0);
+    int WW = (SW - 1) * S + 3;
+    int maxpix = ((rows - 1) * S + 3) * WW;
+    if (maxpix > MAXPIX) return false;
+    int NS = (Wo + SW - 1) / SW;
+    int TPS = (Ho * SW + BM - 1) / BM;
+    double eff = (double)Ho * Wo / ((double)NS * TPS * BM);
+    uint32_t mw, ms;
+    if (!magic_ok(WW, MAXPIX + 64, &mw) || !magic_ok(SW, TPS * BM + BM, &ms)) return false;
+    *out = HaloPlan{SW, NS, TPS, WW, maxpix, eff, mw, ms};
+    return true;
+}
+
 // plans are pure functions of (Ho, Wo, S): memoised so eager launches do not redo the exhaustive checks
 bool plan_halo(int Ho, int Wo, int S, HaloPlan* out, int maxpix_cap, int bm) {
     static std::mutex mu;

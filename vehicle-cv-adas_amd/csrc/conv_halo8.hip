@@ -616,6 +616,12 @@ hipError_t launch_conv_halo8(const ConvArgs& a, hipStream_t st) {
     HaloPlan pl;
     if (!halo8_applicable(a.kh, a.kw, a.stride, a.pad, a.n, a.in, a.out, a.res, a.res_mode) || !plan_halo(a.out.h, a.out.w, 1, &pl))
         return hipErrorNotSupported;
+    {   // ADAS_H8_SW=<strip width>: narrower strips = squarer tiles = less halo per window (and more padded pixels): an experiment knob
+        static int sw = -1;
+        if (sw < 0) { const char* e = getenv("ADAS_H8_SW"); sw = e ? atoi(e) : 0; }
+        HaloPlan alt;
+        if (sw > 0 && plan_halo_sw(a.out.h, a.out.w, 1, sw, H8_MAXPIX, &alt) && alt.eff >= 0.6) pl = alt;
+    }
     H8Dev d;
     d.in = (const uint16_t*)a.in.p; d.wgt = (const uint16_t*)a.wgt; d.bias = a.bias; d.out = (uint16_t*)a.out.p;
     d.res = (const uint16_t*)a.res.p;

@@ -74,6 +74,7 @@ struct HaloPlan {
 };
 // maxpix_cap: window pixel budget (0: the kernel's default); bm: output pixels per tile (0: halo_bm(S) = 256 at stride 1, 128 at stride 2)
 bool plan_halo(int Ho, int Wo, int S, HaloPlan* out, int maxpix_cap = 0, int bm = 0);
+bool plan_halo_sw(int Ho, int Wo, int S, int SW, int maxpix_cap, HaloPlan* out);   // one given strip width (experiments)
 int halo_tile_pixels(const ConvArgs& a);   // conv_halo.hip: the tile size launch_conv_halo picks for this launch (128 on small stride-1 layers)
 // conv_halo8.hip: stride-1 3x3 for Cout % 128 == 0, Cin % 32 == 0: persistent, LDS-DMA fed, counted waits (same weight packing)
 bool halo8_applicable(int kh, int kw, int stride, int pad, int n, const TView& in, const TView& out, const TView& res, int res_mode);

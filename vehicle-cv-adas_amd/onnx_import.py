@@ -32,7 +32,7 @@ except ImportError:  # executed as a script
 
 # Revision of this importer + the container it writes: part of the name of HipEngine's converted-model cache
 # (coreEngine.HipEngine._resolve_container), so containers written by an older importer are not reused.
-IMPORTER_VERSION = 2
+IMPORTER_VERSION = 3
 
 
 # ------------------------------------------------------------------------------------- protobuf wire format
@@ -469,8 +469,20 @@ def convert(onnx_path, hipm_path=None, io_half=None):
     weights stay fp32 in the container (the engine converts them to its compute type at load: `precision="fp16"` rounds them to
     half exactly as the converted file would hold them) and only the I/O contract changes."""
     m = read_onnx(onnx_path)
-    arch, kw = detect_arch(m)
-    g = M.build(arch, wsrc=OnnxWeights(m, arch), **kw)
+    try:
+        arch, kw = detect_arch(m)
+        g = M.build(arch, wsrc=OnnxWeights(m, arch), **kw)
+    except (ValueError, KeyError, AssertionError) as e_arch:
+        # not one of the hand-built architectures (or a variant of one whose tensors do not fit its builder): lower the node list itself
+        # onto the engine's op list (onnx_lower.py) -- another width / depth of a supported family, an ad-hoc CSP graph
+        try:
+            from . import onnx_lower as OL
+        except ImportError:
+            import onnx_lower as OL
+        try:
+            g = OL.lower(m, name=os.path.splitext(os.path.basename(onnx_path))[0][:60])
+        except OL.LowerError as e_low:
+            raise ValueError("[%s] is neither a hand-built architecture (%s) nor a graph the generic lowering takes (%s)" % (onnx_path, e_arch, e_low))
     # an fp16 export (onnxQuantization.py:11-41 / ultralytics half=True) declares float16 graph inputs: the reference then feeds and
     # receives float16 arrays (coreEngine.py:168); recorded in the container so HipEngine can report the same engine_dtype
     g.io_half = (bool(m.inputs) and m.elem_types.get(m.inputs[0][0]) == 10) if io_half is None else bool(io_half)

@@ -1,0 +1,521 @@
+"""ONNX graph -> engine op list: load detector graphs `models.py` does not hand-build (coreEngine.py:159-186 hands ANY
+ONNX file to ONNXRuntime).
+
+`onnx_import.detect_arch` recognises the architectures with a hand-written builder and pours the file's weights into them.  Everything
+else -- another width or depth of a supported family (YOLOv8 at a custom scale, YOLOv7 / v5-layout variants, GELAN-style stacks), an
+ad-hoc CSP network -- goes through this module: the node list is walked once and mapped onto the op list the engine already executes,
+
+    Conv [+ Sigmoid, Mul | Relu | LeakyRelu(0.1)] [+ Add]      -> OP_CONV with a fused activation and residual (either order)
+    Conv with group == channels                                 -> OP_DWCONV
+    MaxPool / AveragePool(count_include_pad) / Resize(nearest x2) / ConvTranspose(k 2, s 2)
+    Concat(axis 1) / Split(axis 1) / Slice(axis 1)              -> no op at all: producers write channel slices of one buffer, consumers read views
+    the Detect tail                                             -> OP_DETECT_V8 (three Concat[box, cls] -> Reshape pairs feeding one axis-2 Concat;
+                                                                   everything behind it -- DFL, dist2bbox, sigmoid -- is the op) or
+                                                                   OP_DETECT_V5 (three 1x1 convs of 3 (5 + nc) channels reshaped to (1, 3, no, h, w);
+                                                                   anchors read from the graph's anchor_grid constants)
+
+and the engine's own load-time passes (stem, pair / C2f / Detect fusion, folded upsamples, conv_halo8 / conv_h8x3 selection) then see
+the same op list a hand-written builder would have produced.  Anything outside this vocabulary raises ValueError naming the node --
+softmax attention (YOLOv10's PSA) and stand-alone element-wise arithmetic among them; those graphs need a builder.
+
+Buffer planning: a Concat's output is ONE buffer and each input tensor is assigned the channel slice it occupies, so its producer writes
+there directly (a tensor that is already placed elsewhere, or a graph input, is copied in by a 1x1 max-pool).  Split / Slice outputs are
+views of their source; consecutive slices of one tensor that re-appear in order inside a Concat (C2f: cv1's two halves) place the whole
+source tensor.  Concats may nest."""
+import numpy as np
+
+try:
+    from . import models as M
+except ImportError:  # executed top-level
+    import models as M
+
+
+class LowerError(ValueError):
+    pass
+
+
+def _const(m, name):
+    return m.initializers.get(name)
+
+
+def _ints(m, nd, attr, inp):
+    """An integer list given as attribute `attr` (older opsets) or as constant input number `inp` (newer)."""
+    if attr in nd["attrs"] and nd["attrs"][attr] is not None:
+        v = nd["attrs"][attr]
+        return [int(x) for x in (v if isinstance(v, (list, tuple)) else [v])]
+    if inp is not None and len(nd["inputs"]) > inp and nd["inputs"][inp]:
+        c = _const(m, nd["inputs"][inp])
+        if c is None:
+            raise LowerError("node %s (%s): input %d must be a constant" % (nd["name"], nd["op"], inp))
+        return [int(x) for x in np.asarray(c).reshape(-1)]
+    return None
+
+
+class _Lowering:
+    def __init__(self, m, name):
+        self.m = m
+        self.nodes = m.nodes
+        self.name = name
+        if len(m.inputs) != 1 or len(m.inputs[0][1]) != 4:
+            raise LowerError("expected one NCHW graph input, found %s" % (m.inputs,))
+        self.in_name, ishape = m.inputs[0]
+        if any((not isinstance(d, int)) or d <= 0 for d in ishape[1:]):
+            raise LowerError("dynamic input size %s (export with fixed H and W)" % (ishape,))
+        self.in_c, self.in_h, self.in_w = ishape[1], ishape[2], ishape[3]
+        if self.in_c > 8:
+            raise LowerError("input has %d channels (the engine's input layer takes up to 8)" % self.in_c)
+        self.shape = {self.in_name: (self.in_c, self.in_h, self.in_w)}      # activation tensors: (C, H, W)
+        self.producer = {}
+        self.consumers = {}
+        for i, nd in enumerate(self.nodes):
+            for o in nd["outputs"]:
+                self.producer[o] = i
+            for t in nd["inputs"]:
+                if t and t not in m.initializers:
+                    self.consumers.setdefault(t, []).append(i)
+        self.graph_outs = [n for n, _ in m.outputs]
+
+    # ------------------------------------------------------------------ pass 1a: macro ops
+    def _single_consumer(self, t, op=None):
+        c = self.consumers.get(t, [])
+        if len(c) != 1 or t in self.graph_outs:
+            return None
+        nd = self.nodes[c[0]]
+        return c[0] if (op is None or nd["op"] == op) else None
+
+    def _absorb_act(self, t, used):
+        """(act, output tensor) of the activation nodes that consume conv output t, marking them used."""
+        cons = [i for i in self.consumers.get(t, [])]
+        if t not in self.graph_outs and len(cons) == 2:
+            a, b = (self.nodes[i] for i in cons)
+            for s, mnode, si, mi in ((a, b, cons[0], cons[1]), (b, a, cons[1], cons[0])):
+                if s["op"] == "Sigmoid" and mnode["op"] == "Mul" and sorted(mnode["inputs"]) == sorted([t, s["outputs"][0]]) and \
+                        self.consumers.get(s["outputs"][0], []) == [mi]:
+                    used.update((si, mi))
+                    return M.ACT_SILU, mnode["outputs"][0]
+        i = self._single_consumer(t)
+        if i is not None:
+            nd = self.nodes[i]
+            if nd["op"] == "Relu":
+                used.add(i)
+                return M.ACT_RELU, nd["outputs"][0]
+            if nd["op"] == "LeakyRelu" and abs(float(nd["attrs"].get("alpha", 0.01)) - 0.1) < 1e-6:
+                used.add(i)
+                return M.ACT_LEAKY, nd["outputs"][0]
+            if nd["op"] == "HardSwish" or nd["op"] == "Clip":
+                raise LowerError("node %s: activation %s has no kernel" % (nd["name"], nd["op"]))
+        return M.ACT_NONE, t
+
+    def _macro_ops(self):
+        """[(kind, node index, dict)] in graph order; activation / residual nodes absorbed into their convolution."""
+        used, ops = set(), []
+        for i, nd in enumerate(self.nodes):
+            if i in used:
+                continue
+            op = nd["op"]
+            if op in ("Conv", "ConvTranspose"):
+                w = _const(self.m, nd["inputs"][1]) if len(nd["inputs"]) > 1 else None
+                if w is None:
+                    raise LowerError("node %s: convolution weights must be an initializer" % nd["name"])
+                rec = dict(x=nd["inputs"][0], w=np.asarray(w, np.float32),
+                           b=np.asarray(_const(self.m, nd["inputs"][2]), np.float32) if len(nd["inputs"]) > 2 and nd["inputs"][2] else None,
+                           name=self._layer_name(nd), res=None, res_mode=M.RES_NONE)
+                t = nd["outputs"][0]
+                if op == "ConvTranspose":
+                    rec.update(act=M.ACT_NONE, out=t)
+                    ops.append(("deconv", i, rec))
+                    continue
+                # Conv -> Add(residual) -> act  (ResNet)   |   Conv -> act -> Add(residual)  (Bottleneck shortcut)
+                j = self._single_consumer(t, "Add")
+                if j is not None and self._is_act_input(self.nodes[j]["outputs"][0]):
+                    other = [x for x in self.nodes[j]["inputs"] if x != t]
+                    if len(other) == 1 and other[0] not in self.m.initializers:
+                        used.add(j)
+                        act, out = self._absorb_act(self.nodes[j]["outputs"][0], used)
+                        rec.update(act=act, out=out, res=other[0], res_mode=M.RES_BEFORE_ACT)
+                        ops.append(("conv", i, rec))
+                        continue
+                act, out = self._absorb_act(t, used)
+                j = self._single_consumer(out, "Add")
+                if j is not None:
+                    other = [x for x in self.nodes[j]["inputs"] if x != out]
+                    if len(other) == 1 and other[0] not in self.m.initializers and self._defined_before(other[0], i):
+                        used.add(j)
+                        rec.update(res=other[0], res_mode=M.RES_AFTER_ACT)
+                        out = self.nodes[j]["outputs"][0]
+                rec.update(act=act, out=out)
+                ops.append(("conv", i, rec))
+            elif op in ("MaxPool", "AveragePool", "Resize", "Upsample", "Concat", "Split", "Slice", "Identity"):
+                ops.append((op.lower(), i, {}))
+            else:
+                ops.append(("other", i, {}))
+        return ops
+
+    def _is_act_input(self, t):
+        c = self.consumers.get(t, [])
+        return len(c) == 1 and self.nodes[c[0]]["op"] in ("Relu", "LeakyRelu") or \
+            (len(c) == 2 and {self.nodes[k]["op"] for k in c} == {"Sigmoid", "Mul"})
+
+    def _defined_before(self, t, node_idx):
+        while t in self.producer and self.nodes[self.producer[t]]["op"] in ("Slice", "Split", "Identity"):   # views: what matters is their source
+            t = self.nodes[self.producer[t]]["inputs"][0]
+        return t == self.in_name or self.producer.get(t, 1 << 30) < node_idx
+
+    def _layer_name(self, nd):
+        w = nd["inputs"][1] if len(nd["inputs"]) > 1 else ""
+        base = w[:-len(".weight")] if w.endswith(".weight") else (nd["name"].strip("/").replace("/", ".") or w)
+        return base[-47:] if base else "conv%d" % self.producer[nd["outputs"][0]]
+
+    # ------------------------------------------------------------------ lowering proper
+    def run(self):
+        m = self.m
+        ops = self._macro_ops()
+        # ---- the Detect tail: found first, so that everything behind its front is skipped
+        tail = self._find_tail(ops)
+        # the network body = the ancestors of the Detect inputs (the tail's own nodes, and whatever only feeds them, are the Detect op)
+        made_by = {}
+        for kind, i, rec in ops:
+            if kind in ("conv", "deconv"):
+                made_by[rec["out"]] = (kind, i, rec)
+            else:
+                for o in self.nodes[i]["outputs"]:
+                    made_by[o] = (kind, i, rec)
+        need, todo = set(), list(tail["f32_tensors"])
+        while todo:
+            t = todo.pop()
+            if t == self.in_name or t not in made_by:
+                if t != self.in_name:
+                    raise LowerError("tensor %r feeding the Detect head has no producer among the supported nodes" % t)
+                continue
+            kind, i, rec = made_by[t]
+            if i in need:
+                continue
+            need.add(i)
+            srcs = [rec["x"]] + ([rec["res"]] if rec.get("res") is not None else []) if kind in ("conv", "deconv") else \
+                [x for x in self.nodes[i]["inputs"] if x and x not in m.initializers]
+            todo += srcs
+        body = [o for o in ops if o[1] in need]
+        # ---- pass 1b: shapes, aliases (Split / Slice views), concat placement
+        alias = {}                                   # tensor -> (source tensor, channel offset)
+        place = {}                                   # tensor -> (concat output tensor, channel offset)
+        copies = []                                  # (concat tensor, offset, source tensor, src offset, channels)
+        root_of = lambda t: self._root(t, alias)
+
+        for kind, i, rec in body:
+            nd = self.nodes[i]
+            if kind == "conv":
+                c, h, w_ = self._shape(rec["x"])
+                W = rec["w"]
+                group = int(nd["attrs"].get("group", 1))
+                k = W.shape[2]
+                if W.shape[2] != W.shape[3]:
+                    raise LowerError("node %s: %dx%d kernel (square kernels only)" % (nd["name"], W.shape[2], W.shape[3]))
+                st = _ints(m, nd, "strides", None) or [1, 1]
+                pd = _ints(m, nd, "pads", None) or [0, 0, 0, 0]
+                dl = _ints(m, nd, "dilations", None) or [1, 1]
+                if st[0] != st[1] or len(set(pd)) != 1 or dl != [1, 1]:
+                    raise LowerError("node %s: strides %s pads %s dilations %s (symmetric, undilated convolutions only)" % (nd["name"], st, pd, dl))
+                if group not in (1, c) or (group == c and (W.shape[0] != c or c == 1)):
+                    if group != 1:
+                        raise LowerError("node %s: group %d of %d channels (plain and depth-wise convolutions only)" % (nd["name"], group, c))
+                if group == 1 and W.shape[1] != c:
+                    raise LowerError("node %s: weight expects %d input channels, tensor has %d" % (nd["name"], W.shape[1], c))
+                rec.update(k=k, s=st[0], p=pd[0], dw=(group == c and group > 1))
+                ho, wo = (h + 2 * pd[0] - k) // st[0] + 1, (w_ + 2 * pd[0] - k) // st[0] + 1
+                self.shape[rec["out"]] = (W.shape[0], ho, wo)
+                if rec["res"] is not None and self._shape(rec["res"]) != self.shape[rec["out"]]:
+                    raise LowerError("node %s: residual shape %s != output shape %s" % (nd["name"], self._shape(rec["res"]), self.shape[rec["out"]]))
+            elif kind == "deconv":
+                c, h, w_ = self._shape(rec["x"])
+                W = rec["w"]
+                st = _ints(m, nd, "strides", None) or [1, 1]
+                if tuple(W.shape[2:]) != (2, 2) or st != [2, 2] or W.shape[0] != c or int(nd["attrs"].get("group", 1)) != 1:
+                    raise LowerError("node %s: only ConvTranspose2d(kernel 2, stride 2) is built" % nd["name"])
+                self.shape[rec["out"]] = (W.shape[1], 2 * h, 2 * w_)
+            elif kind in ("maxpool", "averagepool"):
+                c, h, w_ = self._shape(nd["inputs"][0])
+                ks = _ints(m, nd, "kernel_shape", None)
+                st = _ints(m, nd, "strides", None) or [1, 1]
+                pd = _ints(m, nd, "pads", None) or [0, 0, 0, 0]
+                if ks[0] != ks[1] or st[0] != st[1] or len(set(pd)) != 1 or int(nd["attrs"].get("ceil_mode", 0)):
+                    raise LowerError("node %s: pooling %s / %s / %s" % (nd["name"], ks, st, pd))
+                if kind == "averagepool" and pd[0] and not int(nd["attrs"].get("count_include_pad", 0)):
+                    raise LowerError("node %s: AveragePool with padding needs count_include_pad=1" % nd["name"])
+                self.shape[nd["outputs"][0]] = (c, (h + 2 * pd[0] - ks[0]) // st[0] + 1, (w_ + 2 * pd[0] - ks[0]) // st[0] + 1)
+            elif kind in ("resize", "upsample"):
+                c, h, w_ = self._shape(nd["inputs"][0])
+                mode = nd["attrs"].get("mode", b"nearest")
+                mode = mode.decode() if isinstance(mode, (bytes, bytearray)) else str(mode)
+                sc = None
+                for idx in (2, 1):
+                    if len(nd["inputs"]) > idx and nd["inputs"][idx] and _const(m, nd["inputs"][idx]) is not None and np.asarray(_const(m, nd["inputs"][idx])).size == 4:
+                        sc = [float(x) for x in np.asarray(_const(m, nd["inputs"][idx])).reshape(-1)]
+                        break
+                if sc is None and len(nd["inputs"]) > 3 and nd["inputs"][3] and _const(m, nd["inputs"][3]) is not None:
+                    sz = [int(x) for x in np.asarray(_const(m, nd["inputs"][3])).reshape(-1)]
+                    sc = [1.0, 1.0, sz[2] / h, sz[3] / w_]
+                if mode != "nearest" or sc is None or sc[:2] != [1.0, 1.0] or sc[2:] != [2.0, 2.0]:
+                    raise LowerError("node %s: only nearest-neighbour x2 up-sampling is built (mode %s, scales %s)" % (nd["name"], mode, sc))
+                self.shape[nd["outputs"][0]] = (c, 2 * h, 2 * w_)
+            elif kind == "identity":
+                self.shape[nd["outputs"][0]] = self._shape(nd["inputs"][0])
+                alias[nd["outputs"][0]] = (nd["inputs"][0], 0)
+            elif kind == "split":
+                c, h, w_ = self._shape(nd["inputs"][0])
+                axis = int(nd["attrs"].get("axis", 0))
+                parts = _ints(m, nd, "split", 1) or [c // len(nd["outputs"])] * len(nd["outputs"])
+                if axis != 1 or sum(parts) != c:
+                    raise LowerError("node %s: Split along axis %d / %s of %d channels" % (nd["name"], axis, parts, c))
+                off = 0
+                for o, pc in zip(nd["outputs"], parts):
+                    self.shape[o] = (pc, h, w_)
+                    alias[o] = (nd["inputs"][0], off)
+                    off += pc
+            elif kind == "slice":
+                c, h, w_ = self._shape(nd["inputs"][0])
+                starts, ends = _ints(m, nd, "starts", 1), _ints(m, nd, "ends", 2)
+                axes = _ints(m, nd, "axes", 3) or [0]
+                steps = _ints(m, nd, "steps", 4) or [1]
+                if axes != [1] or steps != [1] or len(starts) != 1:
+                    raise LowerError("node %s: Slice on axes %s steps %s (channel slices only)" % (nd["name"], axes, steps))
+                s0 = starts[0] + c if starts[0] < 0 else starts[0]
+                e0 = min(c, ends[0] + c if ends[0] < 0 else ends[0])
+                self.shape[nd["outputs"][0]] = (e0 - s0, h, w_)
+                alias[nd["outputs"][0]] = (nd["inputs"][0], s0)
+            elif kind == "concat":
+                if int(nd["attrs"].get("axis", 0)) != 1:
+                    raise LowerError("node %s: Concat along axis %s in the network body" % (nd["name"], nd["attrs"].get("axis")))
+                shp = [self._shape(t) for t in nd["inputs"]]
+                if len({s[1:] for s in shp}) != 1:
+                    raise LowerError("node %s: Concat of different spatial sizes %s" % (nd["name"], shp))
+                self.shape[nd["outputs"][0]] = (sum(s[0] for s in shp), shp[0][1], shp[0][2])
+            else:
+                raise LowerError("node %s: op %s has no counterpart in the engine (stand-alone element-wise arithmetic and attention need a "
+                                 "hand-written builder)" % (nd["name"] or "#%d" % i, nd["op"]))
+
+        # concat placement, in graph order
+        for kind, i, rec in body:
+            if kind != "concat":
+                continue
+            nd = self.nodes[i]
+            out, off = nd["outputs"][0], 0
+            k = 0
+            ins = nd["inputs"]
+            while k < len(ins):
+                r, ro = root_of(ins[k])
+                c = self.shape[ins[k]][0]
+                # a run of consecutive slices of one source tensor that covers it from channel 0 in order places the whole source
+                run_c, k2 = c, k + 1
+                if ro == 0:
+                    while k2 < len(ins) and run_c < self.shape[r][0]:
+                        r2, ro2 = root_of(ins[k2])
+                        if r2 != r or ro2 != run_c:
+                            break
+                        run_c += self.shape[ins[k2]][0]
+                        k2 += 1
+                whole = ro == 0 and run_c == self.shape[r][0]
+                if whole and r not in place and r != self.in_name and r not in self.graph_outs:
+                    place[r] = (out, off)
+                    off += run_c
+                    k = k2
+                else:
+                    copies.append((out, off, r, ro, c))
+                    off += c
+                    k += 1
+        self.alias, self.place = alias, place
+
+        # ---- pass 2: emission
+        g = M.Graph(self.name, self.in_c, self.in_h, self.in_w, M.DictWeights({}))
+        x_in, _ = g.input()
+        self.g, self.bufs = g, {}
+        self.bufs[self.in_name] = x_in.buf
+        f32 = set(tail["f32_tensors"])
+        self.f32 = f32
+        first = True
+        copy_at = {}
+        for cp in copies:
+            copy_at.setdefault(self.producer.get(cp[0]), []).append(cp)
+        for kind, i, rec in body:
+            nd = self.nodes[i]
+            if kind == "conv":
+                xin = self._view(rec["x"])
+                out = self._view(rec["out"], make=True)
+                res = self._view(rec["res"]) if rec["res"] is not None else None
+                if rec["dw"]:
+                    if rec["res_mode"] == M.RES_BEFORE_ACT:
+                        raise LowerError("node %s: depth-wise convolution with a pre-activation residual" % nd["name"])
+                    b = rec["b"] if rec["b"] is not None else np.zeros(rec["w"].shape[0], np.float32)
+                    g.dwconv(xin, rec["k"], rec["s"], rec["name"], act=rec["act"], out=out, res=res, weight=rec["w"].reshape(-1, 1, rec["k"], rec["k"]), bias=b)
+                    if rec["p"] != rec["k"] // 2:
+                        raise LowerError("node %s: depth-wise padding %d (k // 2 only)" % (nd["name"], rec["p"]))
+                else:
+                    true_cin = self.in_c if rec["x"] == self.in_name else None
+                    b = rec["b"] if rec["b"] is not None else np.zeros(rec["w"].shape[0], np.float32)
+                    g.conv(xin, rec["w"].shape[0], rec["k"], rec["s"], rec["name"], act=rec["act"], out=out, res=res, res_mode=rec["res_mode"],
+                           true_cin=true_cin, pad=rec["p"], weight=rec["w"], bias_arr=b)
+                g.n_params += rec["w"].size + (rec["b"].size if rec["b"] is not None else 0)
+                first = False
+            elif kind == "deconv":
+                xin, out = self._view(rec["x"]), self._view(rec["out"], make=True)
+                W, b = rec["w"], rec["b"] if rec["b"] is not None else np.zeros(rec["w"].shape[1], np.float32)
+                g.w = M.DictWeights({rec["name"] + ".weight": W, rec["name"] + ".bias": b})
+                g.deconv2x2(xin, W.shape[1], rec["name"], out=out)
+            elif kind in ("maxpool", "averagepool"):
+                ks = _ints(m, nd, "kernel_shape", None)[0]
+                st = (_ints(m, nd, "strides", None) or [1, 1])[0]
+                pd = (_ints(m, nd, "pads", None) or [0, 0, 0, 0])[0]
+                xin, out = self._view(nd["inputs"][0]), self._view(nd["outputs"][0], make=True)
+                (g.maxpool if kind == "maxpool" else g.avgpool)(xin, ks, st, pd, out=out, name=(nd["name"].strip("/").replace("/", ".") or kind)[-47:])
+            elif kind in ("resize", "upsample"):
+                g.upsample2(self._view(nd["inputs"][0]), out=self._view(nd["outputs"][0], make=True), name=(nd["name"].strip("/").replace("/", ".") or "upsample")[-47:])
+            elif kind == "concat":
+                self._view(nd["outputs"][0], make=True)
+                for (ct, off, r, ro, c) in copy_at.get(i, []):
+                    src = self._view(r).slice(ro, c)
+                    dst = self._view(ct).slice(off, c)
+                    g.maxpool(src, 1, 1, 0, out=dst, name=("copy.%s" % r)[-47:])           # a 1x1 max-pool moves the channels
+        # ---- the Detect op
+        self._emit_tail(tail)
+        g.w = M.DictWeights({})
+        return g
+
+    # ------------------------------------------------------------------ helpers
+    def _shape(self, t):
+        if t not in self.shape:
+            raise LowerError("tensor %r is used before any supported node defines it" % t)
+        return self.shape[t]
+
+    @staticmethod
+    def _root(t, alias):
+        off = 0
+        while t in alias:
+            t, o = alias[t]
+            off += o
+        return t, off
+
+    def _physical(self, t):
+        """(tensor that owns a buffer, channel offset inside it) of tensor t, through aliases and concat placements."""
+        off = 0
+        while True:
+            if t in self.alias:
+                t, o = self.alias[t]
+                off += o
+            elif t in self.place:
+                t, o = self.place[t]
+                off += o
+            else:
+                return t, off
+
+    def _view(self, t, make=False):
+        owner, off = self._physical(t)
+        c, h, w_ = self._shape(t)
+        if owner not in self.bufs:
+            if not make and owner != t:
+                pass
+            oc, oh, ow = self._shape(owner)
+            self.bufs[owner] = self.g.buf(oh, ow, oc, f32=owner in self.f32).buf
+        return M.View(self.bufs[owner], off, c, h, w_)
+
+    # ------------------------------------------------------------------ Detect tails
+    def _find_tail(self, ops):
+        m = self.m
+        if len(self.graph_outs) != 1:
+            raise LowerError("expected one graph output, found %s" % (self.graph_outs,))
+        oshape = m.outputs[0][1]
+        by_node = {i: (kind, rec) for kind, i, rec in ops}
+        conv_out = {rec["out"]: (i, rec) for kind, i, rec in ops if kind == "conv"}
+        # v8 layout: axis-2 Concat of three Reshape(Concat[box conv, cls conv])
+        for i, nd in enumerate(self.nodes):
+            if nd["op"] != "Concat" or int(nd["attrs"].get("axis", 0)) != 2 or len(nd["inputs"]) != 3:
+                continue
+            levels = []
+            for t in nd["inputs"]:
+                r = self.nodes[self.producer[t]] if t in self.producer else None
+                if r is None or r["op"] != "Reshape":
+                    break
+                c = self.nodes[self.producer[r["inputs"][0]]] if r["inputs"][0] in self.producer else None
+                if c is None or c["op"] != "Concat" or int(c["attrs"].get("axis", 0)) != 1 or len(c["inputs"]) != 2 or \
+                        not all(x in conv_out and conv_out[x][1]["act"] == M.ACT_NONE and conv_out[x][1]["res"] is None for x in c["inputs"]):
+                    break
+                levels.append((self.producer[r["inputs"][0]], c["inputs"][0], c["inputs"][1]))
+            if len(levels) != 3:
+                continue
+            box_c = conv_out[levels[0][1]][1]["w"].shape[0]
+            nc = conv_out[levels[0][2]][1]["w"].shape[0]
+            if box_c != 64 or len(oshape) != 3 or oshape[1] != 4 + nc:
+                raise LowerError("Detect head with %d box channels / %d classes and output %s: only the reg_max = 16 v8 layout (1, 4 + nc, A) is built" % (box_c, nc, oshape))
+            return dict(kind="v8", levels=[(b, c) for _, b, c in levels], nc=nc, out_name=self.graph_outs[0],
+                        f32_tensors=[t for _, b, c in levels for t in (b, c)])
+        # v5 layout: three 1x1 convs of 3 * no channels, each reshaped to (1, 3, no, h, w)
+        if len(oshape) == 3:
+            no = oshape[2]
+            levels = []
+            for kind, i, rec in ops:
+                if kind != "conv" or rec["act"] != M.ACT_NONE or rec["res"] is not None or rec["w"].shape[0] != 3 * no or rec["w"].shape[2] != 1:
+                    continue
+                j = self._single_consumer(rec["out"], "Reshape")
+                if j is None:
+                    continue
+                tgt = _ints(m, self.nodes[j], "shape", 1)
+                if tgt is None or len(tgt) != 5 or tgt[1] != 3 or tgt[2] != no:
+                    continue
+                levels.append((j, rec["out"], self._anchors_behind(j)))
+            if len(levels) == 3:
+                return dict(kind="v5", levels=[(t, a) for _, t, a in levels], nc=no - 5, out_name=self.graph_outs[0],
+                            f32_tensors=[t for _, t, _ in levels])
+        raise LowerError("no Detect head recognised (output %s): the v8 layout needs three Concat[box, cls] -> Reshape pairs feeding an axis-2 Concat, "
+                         "the v5 layout three 1x1 convolutions of 3 (5 + nc) channels reshaped to (1, 3, 5 + nc, h, w)" % (oshape,))
+
+    def _anchors_behind(self, node_idx):
+        """The (3, 2) anchor sizes (pixels) of one v5-layout level: the constant of shape (1, 3, ., ., 2) that does not vary over the cells
+        (anchor_grid; the other such constant is the cell grid) among the constants consumed downstream of the level's Reshape."""
+        seen, todo = set(), [self.nodes[node_idx]["outputs"][0]]
+        while todo:
+            t = todo.pop()
+            for j in self.consumers.get(t, []):
+                nd = self.nodes[j]
+                if nd["op"] == "Concat" and int(nd["attrs"].get("axis", 0)) == 1 and len(nd["inputs"]) == 3 and nd["outputs"][0] in self.graph_outs:
+                    continue
+                for x in nd["inputs"]:
+                    c = _const(self.m, x)
+                    if c is not None and np.asarray(c).ndim == 5 and np.asarray(c).shape[1] == 3 and np.asarray(c).shape[4] == 2:
+                        a = np.asarray(c, np.float32)
+                        flat = a.reshape(3, -1, 2)
+                        if np.all(flat == flat[:, :1]) and float(np.abs(flat).max()) > 0:
+                            return flat[:, 0].copy()
+                for o in nd["outputs"]:
+                    if o not in seen:
+                        seen.add(o)
+                        todo.append(o)
+        raise LowerError("v5-layout Detect level: no anchor_grid constant of shape (1, 3, h, w, 2) found behind the head")
+
+    def _emit_tail(self, tail):
+        g = self.g
+        nc = tail["nc"]
+        if tail["kind"] == "v8":
+            ins, strides = [], []
+            for b, c in tail["levels"]:
+                vb, vc = self._view(b), self._view(c)
+                ins += [vb, vc]
+                strides.append(self.in_h // vb.h)
+            A = sum(ins[2 * k].h * ins[2 * k].w for k in range(3))
+            head = g.buf(1, 1, (4 + nc) * A, f32=True)
+            g._op(M.OP_DETECT_V8, ins, head, params=[nc, A] + strides, name="detect.decode")
+            g.output(head, 0, [1, 4 + nc, A], tail["out_name"])
+            g.meta = dict(kind="yolov8", nc=nc, anchors=A, strides=strides)
+        else:
+            lv = [(self._view(t), a) for t, a in tail["levels"]]          # graph order = the order of the rows in the output
+            ins = [v for v, _ in lv]
+            strides = [self.in_h // v.h for v in ins]
+            A = 3 * sum(v.h * v.w for v in ins)
+            no = nc + 5
+            head = g.buf(1, 1, A * no, f32=True)
+            anc = np.stack([a for _, a in lv]).astype(np.float32)          # (3 levels, 3 anchors, 2) in pixels
+            g._op(M.OP_DETECT_V5, ins, head, w=g._blob(anc), params=[nc, A] + strides, name="detect.decode")
+            g.output(head, 0, [1, A, no], tail["out_name"])
+            g.meta = dict(kind="yolov5", nc=nc, anchors=A, strides=strides)
+
+
+def lower(m, name="onnx_graph"):
+    """OnnxModel (onnx_import.read_onnx) -> models.Graph.  Raises LowerError (a ValueError) naming the first node it cannot map."""
+    return _Lowering(m, name).run()
