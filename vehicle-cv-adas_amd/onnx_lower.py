@@ -409,6 +409,8 @@ class _Lowering:
     def _view(self, t, make=False):
         owner, off = self._physical(t)
         c, h, w_ = self._shape(t)
+        if t == self.in_name:
+            return M.View(self.bufs[t], 0, 8, h, w_)       # the engine's input layer: channels zero-padded to 8 (conv(..., true_cin))
         if owner not in self.bufs:
             if not make and owner != t:
                 pass
