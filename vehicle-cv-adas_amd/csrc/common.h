@@ -14,6 +14,16 @@ unsigned long long config_generation();
 void bump_config_generation();
 }  // namespace adas
 
+// frames a post-processing handle was created for (post_kernels.hip): adas_pipeline_create checks them against n_streams x micro_batch
+struct adas_yolo_post;
+struct adas_ufld_decode;
+struct adas_lane_geometry;
+namespace adas {
+int handle_max_batch(const ::adas_yolo_post* h);
+int handle_max_batch(const ::adas_ufld_decode* h);
+int handle_max_batch(const ::adas_lane_geometry* h);
+}  // namespace adas
+
 #define ADAS_HIP_TRY(expr)                                                      \
     do {                                                                        \
         hipError_t e__ = (expr);                                                \

@@ -449,6 +449,7 @@ int adas_engine_create(const char* model_path, int precision, int max_batch, ada
         const FileOp &qa = fo[ai], &qb = fo[bi];
         const int cat = qa.in_buf[0];
         if (qa.in_c[0] != 16 || qb.out_buf != cat || qb.out_coff != qa.in_coff[0] + 16 || qb.res_mode != RES_AFTER_ACT || qa.in_coff[0] < 16 || aliased(cat)) continue;
+        if (qb.res_buf != cat || qb.res_coff != qa.in_coff[0]) continue;   // conv B's shortcut must be the y1 slice conv A reads (the fused kernel adds THAT)
         int c1 = -1, c2 = -1, readers = 0;
         for (size_t j = 0; j < fo.size(); ++j) {
             const FileOp& q = fo[j];
@@ -468,6 +469,21 @@ int adas_engine_create(const char* model_path, int precision, int max_batch, ada
         for (size_t j = 0; j < fo.size(); ++j) sole_writers = sole_writers && !(fo[j].out_buf == cat && (int)j != c1 && (int)j != bi);
         if (!sole_writers) continue;
         const FileOp &q1 = fo[c1], &q2 = fo[c2];
+        {   // the fused launch runs cv2 at cv1's position: nothing between cv1 and cv2 other than conv A / conv B may touch cv2's output buffer or
+            // rewrite the block input, and cv2's output must not overlap the input whose halos other workgroups are still reading
+            bool safe = true;
+            for (int j = c1 + 1; j < c2 && safe; ++j) {
+                if (j == (int)ai || j == bi) continue;
+                const FileOp& q = fo[j];
+                bool touches = q.out_buf == q2.out_buf || q.out_buf == q1.in_buf[0] || (q.res_mode != RES_NONE && q.res_buf == q2.out_buf);
+                for (uint32_t t = 0; t < q.n_in && t < 8; ++t) touches = touches || q.in_buf[t] == q2.out_buf;
+                safe = !touches;
+            }
+            if (q2.out_buf == q1.in_buf[0] && q2.out_coff < q1.in_coff[0] + q1.in_c[0] && q1.in_coff[0] < q2.out_coff + q2.out_c) safe = false;
+            if (!safe) continue;
+            const EngBuf& xb = e->bufs[q1.in_buf[0]];   // conv_c2f.hip addresses the input with 31-bit byte offsets: decided here, at max_batch
+            if ((double)max_batch * xb.h * xb.w * xb.c * 2.0 >= 2147483648.0) continue;
+        }
         if (!c2f16_applicable(precision, make_view(e, q1.in_buf[0], q1.in_coff[0], q1.in_c[0]), make_view(e, q1.out_buf, q1.out_coff, q1.out_c),
                               make_view(e, qa.in_buf[0], qa.in_coff[0], qa.in_c[0]), make_view(e, qb.out_buf, qb.out_coff, qb.out_c),
                               make_view(e, q2.in_buf[0], q2.in_coff[0], q2.in_c[0]), make_view(e, q2.out_buf, q2.out_coff, q2.out_c)))

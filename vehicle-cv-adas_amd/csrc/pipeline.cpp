@@ -181,6 +181,13 @@ int adas_pipeline_create(const adas_pipeline_desc* d, adas_pipeline** out) {
     ADAS_REQUIRE(d->micro_batch >= 0 && d->micro_batch <= 64, ADAS_ERR_INVALID, "micro_batch must be in [0, 64]");
     ADAS_REQUIRE(!d->detector || frames_per_step <= d->detector->max_batch, ADAS_ERR_INVALID, "n_streams x micro_batch exceeds detector max_batch");
     ADAS_REQUIRE(!d->lane || frames_per_step <= d->lane->max_batch, ADAS_ERR_INVALID, "n_streams x micro_batch exceeds lane max_batch");
+    // the post-processing handles index per-frame arenas: too small a handle must fail here, not inside the first (captured) step
+    ADAS_REQUIRE(!d->post || frames_per_step <= adas::handle_max_batch(d->post), ADAS_ERR_INVALID,
+                 "n_streams x micro_batch = %d exceeds the yolo_post handle's max_batch %d", frames_per_step, adas::handle_max_batch(d->post));
+    ADAS_REQUIRE(!d->decode || frames_per_step <= adas::handle_max_batch(d->decode), ADAS_ERR_INVALID,
+                 "n_streams x micro_batch = %d exceeds the ufld_decode handle's max_batch %d", frames_per_step, adas::handle_max_batch(d->decode));
+    ADAS_REQUIRE(!d->geometry || frames_per_step <= adas::handle_max_batch(d->geometry), ADAS_ERR_INVALID,
+                 "n_streams x micro_batch = %d exceeds the lane_geometry handle's max_batch %d", frames_per_step, adas::handle_max_batch(d->geometry));
     adas_pipeline* p = new adas_pipeline();
     p->d = *d;
     if (hipStreamCreateWithFlags(&p->st, hipStreamNonBlocking) != hipSuccess) {

@@ -358,6 +358,12 @@ struct adas_bytetrack {
     hipStream_t last;
 };
 
+namespace adas {
+int handle_max_batch(const ::adas_yolo_post* h) { return h ? h->max_batch : 0; }
+int handle_max_batch(const ::adas_ufld_decode* h) { return h ? h->max_batch : 0; }
+int handle_max_batch(const ::adas_lane_geometry* h) { return h ? h->max_batch : 0; }
+}  // namespace adas
+
 template <class T>
 static T* carve(unsigned char*& p, size_t n) {
     T* r = (T*)p;

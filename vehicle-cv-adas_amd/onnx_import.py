@@ -425,18 +425,35 @@ class OnnxWeights:
         base = name.rsplit(".", 1)[0]
         if not hasattr(self, "_v6_idx"):
             self._v6_idx = {}
-        idx = self._v6_idx.setdefault(base, len(self._v6_idx))
+        idx = self._v6_idx.setdefault(base, len(self._v6_idx))      # advanced on EVERY parametrised layer, named in the file or not
         if idx >= len(self.convs):
             return None
         w, b = self.convs[idx]
         return w if name.endswith(".weight") else (b if b is not None else np.zeros(w.shape[1] if w.ndim == 4 and ".upsample_transpose" in base else w.shape[0], np.float32))
 
+    def _v6_lookup(self, name, shape):
+        """YOLOv6: the positional tensor of this request, cross-checked against the named one when the export kept names.  A file that
+        names only SOME of its layers would let the position fall behind the true layer: refused."""
+        pos = self._v6_by_order(name)
+        named = self.init.get(name)
+        if named is None:
+            if not hasattr(self, "_v6_seen_named"):
+                self._v6_seen_named = False
+            if self._v6_seen_named and name.endswith(".weight"):
+                raise ValueError("YOLOv6 export names only part of its layers (%r is missing): cannot map weights by position safely" % name)
+            return pos
+        if name.endswith(".weight"):
+            self._v6_seen_named = True
+        if pos is not None and name.endswith(".weight") and pos.size != np.asarray(named).size:
+            raise ValueError("YOLOv6 export: tensor %r (%d values) does not sit at its layer's position in the graph (%d values there)" % (name, np.asarray(named).size, pos.size))
+        return None     # the named path below takes it
+
     def __call__(self, name, shape, kind, fill=None):
         if name in self.store:
             return self.store[name]
         arr = None
-        if self.arch.startswith("yolov6") and name not in self.init:
-            arr = self._v6_by_order(name)
+        if self.arch.startswith("yolov6"):
+            arr = self._v6_lookup(name, shape)
         if arr is None and kind in ("conv", "bias") and (name.endswith(".weight") or name.endswith(".bias")):
             base = name.rsplit(".", 1)[0]
             pair = self._named_conv(base) if kind in ("conv", "bias") and base + ".weight" in self.init else None
