@@ -552,9 +552,22 @@ int halo_tile_pixels(const ConvArgs& a) {
     if (a.stride != 1 || !halo_small_tiles()) return halo_bm(a.stride);
     HaloPlan p256, p128;
     if (!plan_halo(a.out.h, a.out.w, 1, &p256) || !plan_halo(a.out.h, a.out.w, 1, &p128, 0, 128) || p128.eff < 0.6) return 256;
-    const int bn = halo_bn(a.out.c);
+    const int bn = a.halo_bn > 0 ? a.halo_bn : halo_bn(a.out.c);
     const long wgs = (long)a.n * p256.NS * p256.TPS * ((a.out.c + bn - 1) / bn);
     return wgs < halo_small_tiles() ? 128 : 256;
+}
+
+int plan_halo_bn(int max_n, int stride, const TView& in, const TView& out) {
+    static int on = -1;
+    if (on < 0) { const char* e = getenv("ADAS_NO_HALO_NARROW"); on = (e && e[0] == '1') ? 0 : 1; }
+    if (!on || !halo_applicable(3, 3, stride, 1, in, out)) return 0;
+    const int bn0 = halo_bn(out.c);
+    HaloPlan p;
+    if (!(stride == 1 ? plan_halo(out.h, out.w, 1, &p, 0, 128) : plan_halo(out.h, out.w, 2, &p))) return 0;
+    const long tiles = (long)max_n * p.NS * p.TPS;
+    int bn = bn0;
+    while (bn > 16 && tiles * ((out.c + bn - 1) / bn) < 256) bn = bn == 48 ? 32 : bn / 2;   // a workgroup per CU at least, if the layer has them
+    return bn == bn0 ? 0 : bn;
 }
 
 hipError_t launch_conv_halo(const ConvArgs& a, hipStream_t st) {
@@ -574,7 +587,7 @@ hipError_t launch_conv_halo(const ConvArgs& a, hipStream_t st) {
     d.out_f32 = a.out.f32;
     d.mg_ww = pl.mg_ww;
     d.mg_sw = pl.mg_sw;
-    const int bn = halo_bn(a.out.c);
+    const int bn = a.halo_bn > 0 ? a.halo_bn : halo_bn(a.out.c);
     d.ntiles = a.n * pl.NS * pl.TPS;
     { static int xm = -1; if (xm < 0) { const char* e = getenv("ADAS_HALO_XMAP"); xm = e ? atoi(e) : 1; } d.xmap = xm; }
     d.tiles8 = (d.ntiles + 7) / 8;

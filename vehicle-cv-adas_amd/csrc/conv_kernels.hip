@@ -339,7 +339,9 @@ const char* conv_kernel_name(const ConvArgs& a, int prec, int kernel) {
         return conv_x3_kernel_name(a);
     }
     const char* actn = a.act == ACT_SILU ? "SILU" : (a.act == ACT_RELU ? "RELU" : (a.act == ACT_LEAKY ? "LEAKY" : "NONE"));
-    if (kernel == CONV_HALO && halo_rw_applicable(a.kh, a.kw, a.stride, a.pad, a.n, a.in, a.out)) {
+    if (kernel == CONV_HALO && a.halo_bn > 0 && a.halo_bn != halo_bn(a.out.c)) {
+        snprintf(buf, sizeof(buf), a.stride == 1 && halo_tile_pixels(a) == 128 ? "conv_halo_kernel<%d,%s,s%d,bm128>" : "conv_halo_kernel<%d,%s,s%d>", a.halo_bn, actn, a.stride);
+    } else if (kernel == CONV_HALO && halo_rw_applicable(a.kh, a.kw, a.stride, a.pad, a.n, a.in, a.out)) {
         snprintf(buf, sizeof(buf), a.out.c <= 32 ? "conv_halo_rw_kernel<%d,%s,bn32>" : "conv_halo_rw_kernel<%d,%s>", (a.in.c + 31) / 32, actn);
     } else if (kernel == CONV_HALO && halo_s2p_applicable(a.kh, a.kw, a.stride, a.pad, a.res_mode, a.n, a.in, a.out)) {
         snprintf(buf, sizeof(buf), "conv_s2p_kernel<%s>", actn);
@@ -459,6 +461,7 @@ hipError_t launch_conv(const ConvArgs& a, int prec, hipStream_t st) {
         hipError_t e = launch_conv_halo8(a, st);
         return e == hipErrorNotSupported ? hipErrorInvalidValue : e;
     }
+    if (pl.kernel == CONV_HALO && a.halo_bn > 0 && a.halo_bn != halo_bn(a.out.c)) return launch_conv_halo(a, st);   // packed for narrower blocks
     if (pl.kernel == CONV_HALO) {
         if (halo_rw_applicable(a.kh, a.kw, a.stride, a.pad, a.n, a.in, a.out)) {
             hipError_t e = launch_conv_halo_rw(a, st);
@@ -529,13 +532,14 @@ __global__ void pack_weights_halo_kernel(const float* __restrict__ src, T* __res
         stf(dst + i, v);
     }
 }
-hipError_t launch_pack_weights_halo(const float* src, void* dst, int cout, int cout_pad, int cin, int cin_pad, int prec, hipStream_t st) {
+hipError_t launch_pack_weights_halo(const float* src, void* dst, int cout, int cout_pad, int cin, int cin_pad, int prec, hipStream_t st, int bn) {
+    if (bn <= 0) bn = halo_bn(cout);
     const size_t total = (size_t)cout_pad * 9 * cin_pad;
     const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
     if (prec == PREC_FP16)
-        hipLaunchKernelGGL(pack_weights_halo_kernel<f16s>, dim3(blocks), dim3(256), 0, st, src, (f16s*)dst, cout, cin, cin_pad, halo_bn(cout), total);
+        hipLaunchKernelGGL(pack_weights_halo_kernel<f16s>, dim3(blocks), dim3(256), 0, st, src, (f16s*)dst, cout, cin, cin_pad, bn, total);
     else
-        hipLaunchKernelGGL(pack_weights_halo_kernel<uint16_t>, dim3(blocks), dim3(256), 0, st, src, (uint16_t*)dst, cout, cin, cin_pad, halo_bn(cout), total);
+        hipLaunchKernelGGL(pack_weights_halo_kernel<uint16_t>, dim3(blocks), dim3(256), 0, st, src, (uint16_t*)dst, cout, cin, cin_pad, bn, total);
     return hipGetLastError();
 }
 

@@ -14,6 +14,7 @@
 #include "kernels.h"
 #include "elem16.h"
 #include <stdlib.h>
+#include <type_traits>
 
 namespace adas {
 
@@ -32,7 +33,7 @@ struct PwgDev {
     int act, M;
 };
 
-constexpr int PWG_BN = 128, PWG_KS = 64, PWG_LDK = PWG_KS + 8;   // LDS row pitch in elements (144 B)
+constexpr int PWG_BN = 128, PWG_KS = 64, PWG_LDK = PWG_KS + 8, PWG_D = 3;   // LDS row pitch in elements (144 B)
 
 template <typename E, int BM>
 __global__ __launch_bounds__(256, 2) void conv_pwg_kernel(PwgDev a) {
@@ -59,29 +60,37 @@ __global__ __launch_bounds__(256, 2) void conv_pwg_kernel(PwgDev a) {
     }
     const uint16_t* bp = a.wgt + (size_t)(n0 + r0) * a.KP + kc * 8;   // weight rows are padded to a multiple of 128: always in range
 
-    gu32x4 ra[A_IT], rb[B_IT];
-    // the last K step of a Cin that is not a multiple of 64: chunks past Cin are fetched from the step's first chunk (in range) and
-    // zeroed by a select -- no branch around the loads (hipcc would wait vmcnt(0) at the join)
-    auto gload = [&](int k0) {
-        const bool kin = k0 + kc * 8 < a.K;
-        const int ko = kin ? k0 : k0 - kc * 8;
+    // PWG_D register stages: the loads of K steps k+1 .. k+PWG_D are in flight under the MFMAs of step k.  One stage (round 3) left a
+    // layer whose tiles do not fill the chip -- K = 1280 .. 2048 at 40x40 / 20x20, one frame -- bound by one memory round trip per step
+    // (48 us for 32 steps); the loop is unrolled by PWG_D so that every stage is a fixed set of registers.
+    gu32x4 ra[PWG_D][A_IT], rb[PWG_D][B_IT];
+    // the last K step of a Cin that is not a multiple of 64: chunks past Cin are fetched from the step's first chunk (in range) and zeroed
+    // by a select at the LDS store (no branch around the loads -- hipcc would wait vmcnt(0) at the join -- and no arithmetic on the loaded
+    // registers before the store either: a select next to the load is a use, and a use ends the prefetch)
+    // Branch-free on purpose: a conditional load or store splits the loop body into basic blocks and hipcc's wait-count insertion then
+    // falls back to vmcnt(0) at every LDS store (measured: no prefetch at all).  So every step loads (a step past K re-reads step 0, in
+    // range), every step stores (a step past K stores zeros, which the MFMAs add as zeros), and K is walked in whole rounds of PWG_D.
+    auto gload = [&](auto st_c, int k0) {
+        constexpr int st = decltype(st_c)::value;
+        const int kq = k0 < a.K ? k0 : 0;
+        const int ko = (kq + kc * 8 < a.K) ? kq : kq - kc * 8;
+#pragma unroll
+        for (int i = 0; i < A_IT; ++i) ra[st][i] = *reinterpret_cast<const gu32x4*>(ap[i] + ko);   // rows past M re-read pixel 0: never stored
+#pragma unroll
+        for (int i = 0; i < B_IT; ++i) rb[st][i] = *reinterpret_cast<const gu32x4*>(bp + (size_t)(32 * i) * a.KP + ko);
+        // keep the stages' loads in ISSUE order: hipcc's scheduler moves independent loads next to their first use, which put the stage
+        // needed first LAST in the queue
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    auto lstore = [&](auto st_c, int buf, int k0) {
+        constexpr int st = decltype(st_c)::value;
+        const bool kin = k0 + kc * 8 < a.K;    // chunks past Cin (the tail of the last step, every chunk of a step past K): zeros
         const gu32x4 zero{0u, 0u, 0u, 0u};
 #pragma unroll
-        for (int i = 0; i < A_IT; ++i) {   // rows past M re-read pixel 0: never stored
-            const gu32x4 v = *reinterpret_cast<const gu32x4*>(ap[i] + ko);
-            ra[i] = kin ? v : zero;
-        }
+        for (int i = 0; i < A_IT; ++i) *reinterpret_cast<gu32x4*>(&As[buf][r0 + 32 * i][kc * 8]) = kin ? ra[st][i] : zero;
 #pragma unroll
-        for (int i = 0; i < B_IT; ++i) {
-            const gu32x4 v = *reinterpret_cast<const gu32x4*>(bp + (size_t)(32 * i) * a.KP + ko);
-            rb[i] = kin ? v : zero;
-        }
-    };
-    auto lstore = [&](int buf) {
-#pragma unroll
-        for (int i = 0; i < A_IT; ++i) *reinterpret_cast<gu32x4*>(&As[buf][r0 + 32 * i][kc * 8]) = ra[i];
-#pragma unroll
-        for (int i = 0; i < B_IT; ++i) *reinterpret_cast<gu32x4*>(&Bs[buf][r0 + 32 * i][kc * 8]) = rb[i];
+        for (int i = 0; i < B_IT; ++i) *reinterpret_cast<gu32x4*>(&Bs[buf][r0 + 32 * i][kc * 8]) = kin ? rb[st][i] : zero;
+        __builtin_amdgcn_sched_barrier(0);
     };
 
     gf32x4 acc[TN][TM];
@@ -92,12 +101,18 @@ __global__ __launch_bounds__(256, 2) void conv_pwg_kernel(PwgDev a) {
 
     const int lrow = lane & 15, kg = lane >> 4;
     const int KT = (a.K + PWG_KS - 1) / PWG_KS;
-    gload(0);
-    lstore(0);
+    const int KR = (KT + PWG_D - 1) / PWG_D * PWG_D;   // steps walked: whole rounds (the surplus steps multiply zeros)
+    // K step s lives in register stage s % PWG_D; step 0 goes to LDS now, steps 1 .. PWG_D stay in flight
+    gload(std::integral_constant<int, 0>{}, 0);
+    gload(std::integral_constant<int, 1>{}, PWG_KS);
+    gload(std::integral_constant<int, 2>{}, 2 * PWG_KS);
+    lstore(std::integral_constant<int, 0>{}, 0, 0);
+    gload(std::integral_constant<int, 0>{}, 3 * PWG_KS);
     __syncthreads();
-    for (int ks = 0; ks < KT; ++ks) {
+    auto step = [&](auto u_c, int ks) {   // u = ks % PWG_D
+        constexpr int u = decltype(u_c)::value;
+        constexpr int nxt = (u + 1) % PWG_D;            // the stage that holds step ks + 1
         const int buf = ks & 1;
-        if (ks + 1 < KT) gload((ks + 1) * PWG_KS);
 #pragma unroll
         for (int h = 0; h < 2; ++h) {   // the two 32-deep MFMA steps of this 64-deep K step
             gu32x4 wf[TN], xf[TM];
@@ -110,8 +125,14 @@ __global__ __launch_bounds__(256, 2) void conv_pwg_kernel(PwgDev a) {
 #pragma unroll
                 for (int j = 0; j < TM; ++j) acc[i][j] = E::mfma(wf[i], xf[j], acc[i][j]);
         }
-        if (ks + 1 < KT) lstore(buf ^ 1);
+        lstore(std::integral_constant<int, nxt>{}, buf ^ 1, (ks + 1) * PWG_KS);              // waits for step ks + 1's loads only
+        gload(std::integral_constant<int, nxt>{}, (ks + 1 + PWG_D) * PWG_KS);                // its stage is free again
         __syncthreads();
+    };
+    for (int ks0 = 0; ks0 < KR; ks0 += PWG_D) {
+        step(std::integral_constant<int, 0>{}, ks0);
+        step(std::integral_constant<int, 1>{}, ks0 + 1);
+        step(std::integral_constant<int, 2>{}, ks0 + 2);
     }
 
     // ---- epilogue: the weights are the MFMA A operand, so a lane holds channels c .. c+3 of pixel m

@@ -31,7 +31,7 @@ static TView make_view(const adas_engine* e, int buf, int coff, int c) {
 // does conv `ci` (with a projection shortcut link) take its shortcut into its own launch at this batch?
 static bool ds_folded(const adas_engine* e, int ci, int batch) {
     const EngOp& c = e->ops[ci];
-    if (c.ds_src < 0 || c.kernel != CONV_HALO) return false;
+    if (c.ds_src < 0 || c.kernel != CONV_HALO || c.halo_bn > 0) return false;   // (a narrow-block packing runs on conv_halo only)
     const FileOp& o = c.f;
     const FileOp& d = e->ops[c.ds_src].f;
     // exactly launch_conv's order of choice: halo_rw and the stride-2 kernel come before conv_halo8 and know nothing of ds_w, and
@@ -525,6 +525,8 @@ int adas_engine_create(const char* model_path, int precision, int max_batch, ada
                 return ADAS_ERR_FORMAT;
             }
             op.kernel = pl.kernel;
+            if (pl.kernel == CONV_HALO)   // few tiles at this engine's max_batch: narrower channel blocks (fixes the packing: decided here)
+                op.halo_bn = plan_halo_bn(max_batch, (int)o.stride, make_view(e, o.in_buf[0], o.in_coff[0], o.in_c[0]), make_view(e, o.out_buf, o.out_coff, o.out_c));
             op.kpad = pl.kpad;
             op.cin_pad = pl.cin_pad;
             op.cout_pad = (cout + 127) / 128 * 128;
@@ -653,7 +655,7 @@ int adas_engine_create(const char* model_path, int precision, int max_batch, ada
                             : (op.kernel == CONV_FC || op.kernel == CONV_PW)
                                 ? launch_pack_weights_fc(d_stage, base + op.w_off, o.out_c, op.cout_pad, o.in_c[0], op.kpad, precision, 0)
                                 : op.kernel == CONV_HALO
-                                ? launch_pack_weights_halo(d_stage, base + op.w_off, o.out_c, op.cout_pad, o.in_c[0], op.cin_pad, precision, 0)
+                                ? launch_pack_weights_halo(d_stage, base + op.w_off, o.out_c, op.cout_pad, o.in_c[0], op.cin_pad, precision, 0, op.halo_bn)
                                 : launch_pack_weights(d_stage, base + op.w_off, o.out_c, op.cout_pad, o.kh * o.kw, o.in_c[0], op.cin_pad, op.kpad, precision, 0);
             if (pe == hipSuccess && op.has_x3h8) pe = launch_pack_weights_h8x3(d_stage, base + op.x3h8_w_off, o.out_c, o.in_c[0], 0);
             if (pe == hipSuccess && op.ds_user >= 0) pe = launch_pack_weights_ds(d_stage, base + op.ds_w_off, o.out_c, o.in_c[0], precision, 0);
@@ -773,6 +775,7 @@ int adas_engine_layer_kernel(const adas_engine* e, int layer, int batch, char* n
         else { a.res = a.out; a.res.p = nullptr; }
         a.k = op.k; a.kpad = op.kpad; a.m = batch * a.out.h * a.out.w; a.max_n = e->max_batch; a.prec = e->prec;
         if (op.has_x3h8) a.wgt_h8x3 = (const unsigned char*)e->d_weights + op.x3h8_w_off;
+        a.halo_bn = op.halo_bn;
         snprintf(name, cap, "%s%s%s", conv_kernel_name(a, e->prec, op.kernel), op.fuse_pool >= 0 ? "+pool" : "",
                  (op.ds_src >= 0 && ds_folded(e, layer, batch)) ? "+shortcut" : "");
     } else if (o.type == OP_DETECT_V8 && op.det_src[0] >= 0) {
@@ -858,6 +861,7 @@ int engine_run_op(adas_engine* e, int i, const float* d_in, int batch, hipStream
             a.n = batch; a.kh = o.kh; a.kw = o.kw; a.stride = o.stride; a.pad = o.pad; a.act = o.act; a.res_mode = o.res_mode;
             a.k = op.k; a.kpad = op.kpad; a.m = batch * a.out.h * a.out.w; a.max_n = e->max_batch; a.prec = e->prec;
             if (op.has_x3h8) a.wgt_h8x3 = wb + op.x3h8_w_off;
+            a.halo_bn = op.halo_bn;
             if (op.ds_src >= 0 && ds_folded(e, i, batch)) {
                 const EngOp& dsop = e->ops[op.ds_src];
                 a.ds_in = make_view(e, dsop.f.in_buf[0], dsop.f.in_coff[0], dsop.f.in_c[0]);

@@ -64,6 +64,7 @@ struct EngOp {
     size_t ds_w_off = 0;     // projection weights re-packed as per-step tiles for the fold
     size_t x3h8_w_off = 0;   // split precision: second packing of a 3x3 s1 conv for conv_halo8_x3.hip (has_x3h8)
     bool has_x3h8 = false;
+    int halo_bn = 0;         // CONV_HALO: output channels per workgroup the weights are packed for (0: halo_bn(cout)); plan_halo_bn
     int up_src = -1;         // OP_CONV (1x1): index of the upsample op folded into this conv's activation loads, or -1
     int pool3[2] = {-1, -1}; // OP_MAXPOOL: the two pools chained behind this one, folded into its launch (SPPF), or -1
     int pair_b = -1;         // CONV_PAIR: index of the second conv of the pair this op launches (its own output is never written), or -1

@@ -43,6 +43,7 @@ struct ConvArgs {
     TView ds_in{};
     const void* ds_w = nullptr;
     const float* ds_bias = nullptr;
+    int halo_bn = 0;    // conv_halo: output channels per workgroup the weights were packed for (0: halo_bn(cout); see plan_halo_bn)
     // split precision: the same weights in conv_halo8_x3.hip's half-chunk slab packing (nullptr: the layer's shape does not take it)
     const void* wgt_h8x3 = nullptr;
 };
@@ -173,7 +174,11 @@ hipError_t launch_conv_stem(const float* nchw, int n, int c_true, int H, int W, 
 // 65..96 output channels (YOLOv8n's class branch: 80) run as two 48-wide blocks: as two 64-wide blocks the second is mostly padding
 // (an 80-wide single block was tried: 80 accumulators + 12 weight staging slots spill 54-94 VGPRs at two workgroups per CU).
 inline int halo_bn(int cout) { return cout <= 16 ? 16 : (cout <= 32 ? 32 : ((cout > 64 && cout <= 96) ? 48 : 64)); }
-hipError_t launch_pack_weights_halo(const float* src, void* dst, int cout, int cout_pad, int cin, int cin_pad, int prec, hipStream_t st);
+// Output channels per conv_halo workgroup for a layer whose tiles do not fill the chip at the engine's max_batch (one frame at a time:
+// 40x40x256 -> 256 is 13 tiles x 4 blocks = 52 workgroups, each an 8-chunk latency chain): narrower blocks = more, shorter workgroups.
+// 0 = halo_bn(cout).  Decided at load (it fixes the weight packing); a layer with a non-default block runs on conv_halo only.
+int plan_halo_bn(int max_n, int stride, const TView& in, const TView& out);
+hipError_t launch_pack_weights_halo(const float* src, void* dst, int cout, int cout_pad, int cin, int cin_pad, int prec, hipStream_t st, int bn = 0);
 // Linear-layer packing (CONV_FC): src [cout][cin] fp32 -> bf16 MFMA-fragment order [cout_pad/16][kpad/32][64][8]
 hipError_t launch_pack_weights_fc(const float* src, void* dst, int cout, int cout_pad, int cin, int kpad, int prec, hipStream_t st);
 // dw_attn.hip: depth-wise k x k conv (k = 3 | 7, stride 1 | 2, pad k/2; weights fp32 [k*k][C], bias fp32 [C]; residual: RES_AFTER_ACT only)
