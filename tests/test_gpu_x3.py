@@ -41,6 +41,20 @@ def test_conv_layers_f32_class(case):
     assert rel < X3_REL and mx < 1e-4, (case, rel, mx)
 
 
+@pytest.mark.parametrize("case", [(32, 32, 1, M.ACT_SILU), (40, 80, 1, M.ACT_SILU), (96, 64, 1, M.ACT_SILU), (192, 64, 1, M.ACT_SILU),
+                                  (128, 256, 2, M.ACT_NONE), (160, 160, 1, M.ACT_LEAKY), (384, 128, 1, M.ACT_SILU), (512, 256, 1, M.ACT_SILU),
+                                  (256, 512, 2, M.ACT_NONE)], ids=str)
+def test_pointwise_layers_on_the_streaming_kernel(case):
+    """conv_pw_x3.hip: weights resident in LDS as hi | lo fragment blocks, activations straight from the G8 tensor; K steps 1..16, the
+    ragged last step (40 channels), stride 2 (the ResNet projections) and the layers whose weights are cut into ranges."""
+    cin, cout, s, act = case
+    info = {}
+    rel, mx = TC.run_case(CE, 40, 56, cin, cout, 1, s, act, M.RES_NONE, "fp16x3", info=info, batch=3)
+    print("x3 pointwise %s: rel %.2e max %.2e  %s" % (case, rel, mx, info.get("kernel")))
+    assert "conv_pwx3_kernel" in info["kernel"], info
+    assert rel < X3_REL and mx < 1e-4, (case, rel, mx)
+
+
 @pytest.mark.parametrize("hw", [(80, 400), (23, 37), (7, 300), (20, 20)], ids=lambda s: f"{s[0]}x{s[1]}")
 def test_conv3x3_shapes(hw):
     H, W = hw
@@ -50,7 +64,7 @@ def test_conv3x3_shapes(hw):
 
 
 @pytest.mark.parametrize("case", [(1, 4000, 2048, M.ACT_RELU, False), (64, 2048, 1000, M.ACT_NONE, True), (3, 512, 91224, M.ACT_NONE, True),
-                                  (130, 256, 264, M.ACT_NONE, True)], ids=str)
+                                  (130, 256, 264, M.ACT_NONE, True), (40, 512, 9000, M.ACT_NONE, True), (20, 256, 8200, M.ACT_RELU, False)], ids=str)
 def test_linear_layers_f32_class(case):
     batch, cin, cout, act, f32_out = case
     rel = TC.run_fc_case(CE, batch, cin, cout, act, f32_out, prec="fp16x3")

@@ -25,6 +25,7 @@ UNITS = [
     ("conv_halo_s2.hip", []),
     ("conv_halo8.hip", []),
     ("conv_halo8_x3.hip", []),
+    ("conv_pw_x3.hip", []),
     ("conv_pair.hip", []),
     ("conv_c2f.hip", []),
     ("conv_fc.hip", []),

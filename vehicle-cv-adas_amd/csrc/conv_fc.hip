@@ -74,14 +74,19 @@ __global__ __launch_bounds__(64 * KS) void fc_kernel(FcDev a) {
     };
     if (n >= U) {
 #pragma unroll
-        for (int u = 0; u < U; ++u) load(u, u);
+        for (int u = 0; u < U; ++u) {
+            load(u, u);
+            __builtin_amdgcn_sched_barrier(0);  // keep the ring stages in issue order: the counted waits below
+        }                                       // can then leave U-1 stages in flight (hipcc interleaves them otherwise)
         const int main_steps = ((n - U) / U) * U;  // steps whose ring slot is refilled unconditionally
         int s = 0;
         for (; s < main_steps; s += U) {
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 mma(u);
+                __builtin_amdgcn_sched_barrier(0);
                 load(u, s + u + U);
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
 #pragma unroll
@@ -233,6 +238,7 @@ __global__ void pack_weights_fc_kernel(const float* __restrict__ src, uint16_t* 
 }
 
 hipError_t launch_pack_weights_fc(const float* src, void* dst, int cout, int cout_pad, int cin, int kpad, int prec, hipStream_t st) {
+    if (prec == PREC_X3) return launch_pack_weights_fcx3(src, dst, cout, cout_pad, cin, kpad, st);
     size_t total = (size_t)cout_pad * kpad;
     int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
     ADAS_DISPATCH_E16(prec == PREC_FP16, E,

@@ -331,6 +331,11 @@ const char* conv_kernel_name(const ConvArgs& a, int prec, int kernel) {
         snprintf(buf, sizeof(buf), "conv_stem_x3_kernel<%d,%d,%s>", a.kh, (a.out.c + 15) / 16, a.act == ACT_SILU ? "SILU" : (a.act == ACT_RELU ? "RELU" : "LEAKY"));
         return buf;
     }
+    if (prec == PREC_X3 && kernel == CONV_FC) return "fc_x3_kernel";
+    if (prec == PREC_X3 && kernel == CONV_PW) {
+        snprintf(buf, sizeof(buf), "conv_pwx3_kernel<%d>", (a.in.c + 31) / 32);
+        return buf;
+    }
     if (prec == PREC_X3) {
         if (a.wgt_h8x3 && halo8_x3_applicable(a.kh, a.kw, a.stride, a.pad, a.n, a.in, a.out, a.res, a.res_mode)) {
             snprintf(buf, sizeof(buf), "conv_h8x3_kernel<%s>", a.act == ACT_SILU ? "SILU" : (a.act == ACT_RELU ? "RELU" : (a.act == ACT_LEAKY ? "LEAKY" : "NONE")));
@@ -421,8 +426,10 @@ static bool fc_enabled() {
 
 ConvPlan plan_conv(int prec, int kh, int kw, int stride, int pad, int max_n, int res_mode, const TView& in, const TView& out) {
     ConvPlan p;
-    if (prec == PREC_X3) {   // split precision: one generic kernel (conv_x3.hip), K = (tap, channel) in G8 groups
-        p.kernel = CONV_GATHER;
+    if (prec == PREC_X3) {   // split precision: the two streaming kernels (conv_pw_x3.hip), else the generic one (conv_x3.hip), K = (tap, channel) in G8 groups
+        p.kernel = (fc_enabled() && fc_x3_applicable(kh, kw, stride, in, out))                    ? CONV_FC
+                   : (pw_enabled() && pw_x3_applicable(kh, kw, stride, pad, res_mode, in, out)) ? CONV_PW
+                                                                                                : CONV_GATHER;
         p.cin_pad = in.c;
         p.kpad = (kh * kw * p.cin_pad + 31) / 32 * 32;
         return p;
@@ -448,7 +455,9 @@ hipError_t launch_conv(const ConvArgs& a, int prec, hipStream_t st) {
     ConvPlan pl = plan_conv(prec, a.kh, a.kw, a.stride, a.pad, a.max_n, a.res_mode, a.in, a.out);
     if (pl.kpad != a.kpad) return hipErrorInvalidValue;  // weights were packed for a different plan
     if (prec == PREC_X3) {
-        if (a.up_c > 0 || a.ds_w) return hipErrorInvalidValue;
+        if ((a.up_c > 0 && pl.kernel != CONV_PW) || a.ds_w) return hipErrorInvalidValue;
+        if (pl.kernel == CONV_FC) return launch_fc_x3(a, st);
+        if (pl.kernel == CONV_PW) return launch_conv_pw_x3(a, st);
         if (a.wgt_h8x3 && halo8_x3_applicable(a.kh, a.kw, a.stride, a.pad, a.n, a.in, a.out, a.res, a.res_mode)) {
             hipError_t e = launch_conv_halo8_x3(a, st);
             if (e != hipErrorNotSupported) return e;

@@ -310,7 +310,7 @@ int adas_engine_create(const char* model_path, int precision, int max_batch, ada
     // tensor itself and the upsample launch (and its 4x larger copy of the tensor) disappears
     {
         const char* env = getenv("ADAS_NO_UPSAMPLE_FOLD");
-        const bool enabled = prec_is16(precision) && !(env && env[0] == '1');
+        const bool enabled = (prec_is16(precision) || precision == PREC_X3) && !(env && env[0] == '1');
         for (size_t ui = 0; enabled && ui < fo.size(); ++ui) {
             const FileOp& u = fo[ui];
             if (u.type != OP_UPSAMPLE2 || e->ops[ui].skip || u.out_coff != 0 || (u.out_c & 31)) continue;

@@ -180,6 +180,12 @@ inline int halo_bn(int cout) { return cout <= 16 ? 16 : (cout <= 32 ? 32 : ((cou
 int plan_halo_bn(int max_n, int stride, const TView& in, const TView& out);
 hipError_t launch_pack_weights_halo(const float* src, void* dst, int cout, int cout_pad, int cin, int cin_pad, int prec, hipStream_t st, int bn = 0);
 // Linear-layer packing (CONV_FC): src [cout][cin] fp32 -> bf16 MFMA-fragment order [cout_pad/16][kpad/32][64][8]
+// conv_pw_x3.hip: the split precision's pointwise conv and Linear kernels (fragment-ordered hi | lo weight blocks)
+bool pw_x3_applicable(int kh, int kw, int stride, int pad, int res_mode, const TView& in, const TView& out);
+hipError_t launch_conv_pw_x3(const ConvArgs& a, hipStream_t st);
+bool fc_x3_applicable(int kh, int kw, int stride, const TView& in, const TView& out);
+hipError_t launch_fc_x3(const ConvArgs& a, hipStream_t st);
+hipError_t launch_pack_weights_fcx3(const float* src, void* dst, int cout, int cout_pad, int cin, int kpad, hipStream_t st);
 hipError_t launch_pack_weights_fc(const float* src, void* dst, int cout, int cout_pad, int cin, int kpad, int prec, hipStream_t st);
 // dw_attn.hip: depth-wise k x k conv (k = 3 | 7, stride 1 | 2, pad k/2; weights fp32 [k*k][C], bias fp32 [C]; residual: RES_AFTER_ACT only)
 bool dwconv_supported(int k, int stride, int pad, int res_mode, const TView& in, const TView& out);
