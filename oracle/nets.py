@@ -426,6 +426,98 @@ def yolov6_forward(x, W, scale="n", nc=80, taps=None):
         return torch.cat((boxes, torch.ones(boxes.shape[0], boxes.shape[1], 1), cls_score), -1).numpy()
 
 
+# ------------------------------------------------------------------ EfficientDet-D0
+# PARITY UNPINNED (the reference ships no EfficientDet weights or graph; it loads an exported efficientdet-d0 .onnx through
+# onnxruntime, ObjectDetector/efficientdetDetector.py:18-44).  Restates the published architecture: EfficientNet-B0 (arXiv:1905.11946
+# table 1: MBConv with squeeze-and-excitation 0.25, swish), BiFPN with fast normalised fusion (arXiv:1911.09070 section 3.3, eq. 3,
+# D0: 64 channels x 3 cells) and the shared separable-conv class / box heads (section 4: 3 layers at D0, 9 anchors), BatchNorm folded.
+EFFNET_B0 = [(1, 3, 1, 16, 1), (6, 3, 2, 24, 2), (6, 5, 2, 40, 2), (6, 3, 2, 80, 3), (6, 5, 1, 112, 3), (6, 5, 2, 192, 4), (6, 3, 1, 320, 1)]
+
+
+def _fusion(W, name):
+    w = np.maximum(np.asarray(W[name], np.float32), np.float32(0))
+    return (w / (w.sum(dtype=np.float32) + np.float32(1e-4))).astype(np.float32)
+
+
+def _se(x, W, name):
+    m = x.mean((2, 3), keepdim=True)
+    h = F.silu(F.conv2d(m, _t(W, name + ".reduce.weight"), _t(W, name + ".reduce.bias")))
+    return _round(x * torch.sigmoid(F.conv2d(h, _t(W, name + ".expand.weight"), _t(W, name + ".expand.bias"))))
+
+
+def _mbconv(x, W, name, e, k, s, cout):
+    cin = x.shape[1]
+    t = _conv(x, W, name + ".expand") if e != 1 else x
+    t = _dwconv(t, W, name + ".dw", s)
+    t = _se(t, W, name + ".se")
+    t = _conv(t, W, name + ".project", act=None)
+    return _round(t + x) if (s == 1 and cin == cout) else _round(t)
+
+
+def _sepconv(x, W, name, act=None, dw_name=None):
+    w = _round(_t(W, (dw_name or name) + ".dw.weight"))
+    t = _round(F.conv2d(x, w, None, padding=1, groups=x.shape[1]))
+    y = _conv(t, W, name + ".pw", act=act)
+    return y if act is None and name.endswith(".header") else _round(y)
+
+
+def efficientdet_forward(x, W, nc=90, fpn_cells=3, head_layers=3, taps=None):
+    """-> (regression (N, A, 4) rows (level, y, x, anchor) as (dy, dx, dh, dw), class logits (N, A, nc))."""
+    tap = (lambda k, v: taps.__setitem__(k, v.numpy().copy())) if taps is not None else (lambda k, v: None)
+    t = _conv(x, W, "stem", s=2)
+    feats, bi = [], 0
+    for si, (e, k, s, c, n) in enumerate(EFFNET_B0):
+        for r in range(n):
+            t = _mbconv(t, W, f"blocks.{bi}", e, k, s if r == 0 else 1, c)
+            bi += 1
+        if si in (2, 4, 6):
+            feats.append(t)
+    c3, c4, c5 = feats
+    tap("c3", c3); tap("c4", c4); tap("c5", c5)
+    up = lambda v: F.interpolate(v, scale_factor=2, mode="nearest")
+    down = lambda v: F.max_pool2d(v, 3, 2, 1)
+    p = None
+    for cell in range(fpn_cells):
+        nm = f"bifpn.{cell}"
+        if cell == 0:
+            p3 = _conv(c3, W, nm + ".p3_down", act=None); p4 = _conv(c4, W, nm + ".p4_down", act=None); p5 = _conv(c5, W, nm + ".p5_down", act=None)
+            p3, p4, p5 = _round(p3), _round(p4), _round(p5)
+            p6 = down(_round(_conv(c5, W, nm + ".p5_to_p6", act=None)))
+            p7 = down(p6)
+            p4b, p5b = _round(_conv(c4, W, nm + ".p4_down_2", act=None)), _round(_conv(c5, W, nm + ".p5_down_2", act=None))
+        else:
+            p3, p4, p5, p6, p7 = p
+            p4b, p5b = p4, p5
+
+        def fuse(tag, ins):
+            w = _fusion(W, f"{nm}.{tag}")
+            acc = 0
+            for wi, v in zip(w, ins):
+                acc = acc + float(wi) * v
+            return _round(F.silu(acc))
+
+        p6u = _sepconv(fuse("p6_w1", [p6, up(p7)]), W, nm + ".conv6_up")
+        p5u = _sepconv(fuse("p5_w1", [p5, up(p6u)]), W, nm + ".conv5_up")
+        p4u = _sepconv(fuse("p4_w1", [p4, up(p5u)]), W, nm + ".conv4_up")
+        p3o = _sepconv(fuse("p3_w1", [p3, up(p4u)]), W, nm + ".conv3_up")
+        p4o = _sepconv(fuse("p4_w2", [p4b, p4u, down(p3o)]), W, nm + ".conv4_down")
+        p5o = _sepconv(fuse("p5_w2", [p5b, p5u, down(p4o)]), W, nm + ".conv5_down")
+        p6o = _sepconv(fuse("p6_w2", [p6, p6u, down(p5o)]), W, nm + ".conv6_down")
+        p7o = _sepconv(fuse("p7_w2", [p7, down(p6o)]), W, nm + ".conv7_down")
+        p = (p3o, p4o, p5o, p6o, p7o)
+        for lv, v in enumerate(p):
+            tap(f"bifpn{cell}.p{lv + 3}", v)
+    regs, clss = [], []
+    for lv, f in enumerate(p):
+        for branch, dst, per in (("regressor", regs, 4), ("classifier", clss, nc)):
+            t = f
+            for i in range(head_layers):
+                t = _sepconv(t, W, f"{branch}.l{lv}.{i}", act="silu", dw_name=f"{branch}.conv_list.{i}")
+            o = _sepconv(t, W, f"{branch}.l{lv}.header", dw_name=f"{branch}.header")
+            dst.append(o.permute(0, 2, 3, 1).reshape(o.shape[0], -1, per))
+    return torch.cat(regs, 1), torch.cat(clss, 1)
+
+
 def head_layout(name):
     """"yolov5" (A, 5+nc) or "yolov8" (4+nc, A): the `model_type` argument of oracle.yolo_post.detect_post for graph `name`."""
     return "yolov5" if name.startswith(("yolov5", "yolov6", "yolov7")) else "yolov8"

@@ -88,6 +88,23 @@ def run(g, x):
                 write(out, F.avg_pool2d(read(ins[0]), op["kh"], op["stride"], op["pad"], False, True))
             elif t == M.OP_UPSAMPLE2:
                 write(out, F.interpolate(read(ins[0]), scale_factor=2, mode="nearest"))
+            elif t == M.OP_SE_GATE:                                              # engine.h: w = [W1 | b1], b = [W2 | b2], params[0] = squeeze width
+                w, b = wb(op)
+                c, cr = ins[0].c, int(op["params"][0])
+                m = read(ins[0]).mean((2, 3))
+                hdn = F.silu(m @ torch.from_numpy(w[:cr * c].copy()).reshape(cr, c).T + torch.from_numpy(w[cr * c:].copy()))
+                gate = torch.sigmoid(hdn @ torch.from_numpy(b[:c * cr].copy()).reshape(c, cr).T + torch.from_numpy(b[c * cr:].copy()))
+                write(out, gate.reshape(N, c, 1, 1))
+            elif t == M.OP_SCALE:
+                write(out, read(ins[0]) * read(ins[1]))
+            elif t == M.OP_WSUM:
+                acc = 0
+                for v, wgt in zip(ins, op["params"]):
+                    a = read(v)
+                    if a.shape[2] * 2 == out.h:
+                        a = F.interpolate(a, scale_factor=2, mode="nearest")
+                    acc = acc + float(wgt) * a
+                write(out, _act(acc, op["act"]))
             elif t == M.OP_DEPTH2SPACE:                                          # channel blocks ordered (dy, dx), C channels each
                 v = read(ins[0])
                 B, c4, h, w_ = v.shape

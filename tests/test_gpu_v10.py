@@ -159,18 +159,19 @@ def _frames(n, seed):
     return bench.cam_frames(n, seed)
 
 
-def test_yolov10_detector_dropin_and_pipeline_chain(tmp_path):
+@pytest.mark.parametrize("prec", ["fp32", "fp16x3"])
+def test_yolov10_detector_dropin_and_pipeline_chain(tmp_path, prec):
     """demo.py's default configuration (ObjectModelType.YOLOV10, box_score 0.4, box_nms_iou 0.5): YoloDetector frame -> RectInfo
-    against the oracle's post-processing of the engine's own head, then the fused step (YOLOv10n + UFLDv2-R18 + ByteTrack, fp32)
-    against the whole oracle chain."""
+    against the oracle's post-processing of the engine's own head, then the fused step (YOLOv10n + UFLDv2-R18 + ByteTrack) against
+    the whole oracle chain -- in both parity modes (fp32 on the f32 MFMA, fp16x3 on the 16-bit one)."""
     import bench
     cams = _frames(4, 77)
     seam = np.concatenate([preprocess.yolo_prepare_input(f, (640, 640)) for f in cams])
     path, W, g = bench.build_detector(M, CE, "yolov10n", seam, str(tmp_path), "v10d", target_per_frame=80.0, capacity=1024)
     lab = tmp_path / "coco_label.txt"
     lab.write_text("\n".join(f"class{i}" for i in range(80)))
-    det = D.YoloDetector(model_path=path, model_type=D.ObjectModelType.YOLOV10, classes_path=str(lab), box_score=0.4, box_nms_iou=0.5, precision="fp32")
-    eng = CE.OnnxEngine(path, precision="fp32")
+    det = D.YoloDetector(model_path=path, model_type=D.ObjectModelType.YOLOV10, classes_path=str(lab), box_score=0.4, box_nms_iou=0.5, precision=prec)
+    eng = CE.OnnxEngine(path, precision=prec)
     lb = yolo_post.letterbox_params((720, 1280), (640, 640))
     n_total = 0
     for f in cams[:2]:
@@ -185,7 +186,7 @@ def test_yolov10_detector_dropin_and_pipeline_chain(tmp_path):
     lane_path, Wl, gl = netutil.model("ufldv2_res18")
     S = 2
     pool = [cams[:2], cams[2:]]
-    pipe = PL.AdasPipeline(path, lane_path, n_streams=S, precision="fp32", src_hw=(720, 1280), use_graph=True, max_candidates=1024)
+    pipe = PL.AdasPipeline(path, lane_path, n_streams=S, precision=prec, src_hw=(720, 1280), use_graph=True, max_candidates=1024)
     d_pool = [L.DeviceBuffer.from_array(np.ascontiguousarray(p)) for p in pool]
     chain = CP.OracleChain("yolov10n", W, "ufldv2_res18", Wl)
     st = CP.run_device_chain(pipe, lambda s: PP.YoloPost.fetch(pipe.post, s), lambda s: gpu_api.track_snapshot(*pipe.tracker.fetch(s)),
@@ -194,7 +195,7 @@ def test_yolov10_detector_dropin_and_pipeline_chain(tmp_path):
     for b in d_pool:
         b.free()
     o = st.summary()
-    print("yolov10n pipeline fp32:", o)
+    print("yolov10n pipeline %s:" % prec, o)
     n = o["frames"]
     assert o["identical_candidate_sets"] == n and o["identical_survivors"] == n and o["identical_track_ids"] == o["track_states_compared"]
     assert o["lanes_within_1px"] == n and o["survivors_compared"] >= n

@@ -144,3 +144,19 @@ def test_yolov9t_size_matches_upstream_yaml():
     assert abs(unfused - 2128720) / 2128720 < 0.01, unfused
     assert abs(g.flops / 1e9 - 8.23) < 0.05
     assert [tuple(d) for _, _, d, _ in g.outs] == [(1, 84, 8400)]
+
+
+def test_efficientdet_d0_graph_equals_oracle():
+    """EfficientDet-D0 (models.efficientdet: EfficientNet-B0 MBConv + squeeze-and-excitation, three BiFPN cells with fast normalised
+    fusion, shared separable-conv heads) against the oracle's module-by-module forward: the ten raw head tensors, rows (y, x, anchor)."""
+    g, W = _build("efficientdet-d0", imgsz=(128, 256))
+    assert len(g.outs) == 10 and abs(M.build("efficientdet-d0").flops / 2 - 2.5e9) < 0.1e9      # the paper's 2.5 B multiply-adds at 512 x 512
+    x = (netutil.coco_like_frames(2, 128, 256, seed=3) - 0.45) / 0.225
+    outs = graph_interp.run(g, x)
+    reg, cls = nets.efficientdet_forward(__import__("torch").from_numpy(x), W)
+    got_reg = np.concatenate([o.reshape(2, -1, 4) for o in outs[0::2]], 1)
+    got_cls = np.concatenate([o.reshape(2, -1, 90) for o in outs[1::2]], 1)
+    n_anchors = 9 * sum((128 >> l) * (256 >> l) for l in range(3, 8))
+    assert got_reg.shape == tuple(reg.shape) == (2, n_anchors, 4) and got_cls.shape == tuple(cls.shape) == (2, n_anchors, 90)
+    np.testing.assert_allclose(got_reg, reg.numpy(), rtol=0, atol=2e-5)
+    np.testing.assert_allclose(got_cls, cls.numpy(), rtol=0, atol=2e-5)

@@ -35,6 +35,7 @@ UNITS = [
     ("conv_stem_x3.hip", []),
     ("aux_kernels.hip", []),
     ("dw_attn.hip", []),
+    ("fuse_ops.hip", []),
     ("engine.cpp", []),
     ("pipeline.cpp", []),
 ]

@@ -1,6 +1,6 @@
 // dw_attn.hip -- the two YOLOv10 operators the v8-family kernels do not cover (the reference's shipped default detector is
 // yolov10n: demo.py:24-30; its head is decoded as a v8-layout tensor, yoloDetector.py:114,121):
-//   dwconv     depth-wise k x k convolution (k = 3 or 7, stride 1 or 2, groups = channels) + bias [+ SiLU] [+ residual add]:
+//   dwconv     depth-wise k x k convolution (k = 3, 5 or 7, stride 1 or 2, groups = channels) + bias [+ SiLU] [+ residual add]:
 //              SCDown.cv2, CIB's three depth-wise layers (the fused RepVGGDW is one 7x7), v10Detect's class-branch 3x3s and
 //              the positional encoding of PSA's attention.  HBM-bound streaming: thread = (output pixel, 8-channel group), one
 //              16-byte (16-bit modes) load per tap from a window that lives in L1/L2, fp32 weights [tap][C], fp32 accumulate.
@@ -15,45 +15,6 @@
 #include <stdlib.h>
 
 namespace adas {
-
-template <typename T> struct Vec8;
-template <> struct Vec8<uint16_t> {
-    static __device__ __forceinline__ void load(const uint16_t* p, float v[8]) {
-        const uint4 q = *reinterpret_cast<const uint4*>(p);
-        const uint32_t w[4] = {q.x, q.y, q.z, q.w};
-#pragma unroll
-        for (int k = 0; k < 4; ++k) { v[2 * k] = Bf16::lo(w[k]); v[2 * k + 1] = Bf16::hi(w[k]); }
-    }
-    static __device__ __forceinline__ void store(uint16_t* p, const float v[8]) {
-        *reinterpret_cast<uint4*>(p) = make_uint4(Bf16::pack2(v[0], v[1]), Bf16::pack2(v[2], v[3]), Bf16::pack2(v[4], v[5]), Bf16::pack2(v[6], v[7]));
-    }
-};
-template <> struct Vec8<f16s> {
-    static __device__ __forceinline__ void load(const f16s* p, float v[8]) {
-        const uint4 q = *reinterpret_cast<const uint4*>(p);
-        const uint32_t w[4] = {q.x, q.y, q.z, q.w};
-#pragma unroll
-        for (int k = 0; k < 4; ++k) { v[2 * k] = Fp16::lo(w[k]); v[2 * k + 1] = Fp16::hi(w[k]); }
-    }
-    static __device__ __forceinline__ void store(f16s* p, const float v[8]) {
-        *reinterpret_cast<uint4*>(p) = make_uint4(Fp16::pack2(v[0], v[1]), Fp16::pack2(v[2], v[3]), Fp16::pack2(v[4], v[5]), Fp16::pack2(v[6], v[7]));
-    }
-};
-template <> struct Vec8<float> {
-    static __device__ __forceinline__ void load(const float* p, float v[8]) {
-        const float4 a = reinterpret_cast<const float4*>(p)[0], b = reinterpret_cast<const float4*>(p)[1];
-        v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
-    }
-    static __device__ __forceinline__ void store(float* p, const float v[8]) {
-        reinterpret_cast<float4*>(p)[0] = make_float4(v[0], v[1], v[2], v[3]);
-        reinterpret_cast<float4*>(p)[1] = make_float4(v[4], v[5], v[6], v[7]);
-    }
-};
-
-template <> struct Vec8<x3s> {   // split precision: one G8 group (elem16.h)
-    static __device__ __forceinline__ void load(const x3s* p, float v[8]) { x3_load8(p, v); }
-    static __device__ __forceinline__ void store(x3s* p, const float v[8]) { x3_store8(p, v); }
-};
 
 struct DwDev {
     const void* in;
@@ -116,7 +77,7 @@ __global__ __launch_bounds__(256) void dwconv_kernel(DwDev d) {
 }
 
 bool dwconv_supported(int k, int stride, int pad, int res_mode, const TView& in, const TView& out) {
-    if ((k != 3 && k != 7) || (stride != 1 && stride != 2) || pad != k / 2) return false;
+    if ((k != 3 && k != 5 && k != 7) || (stride != 1 && stride != 2) || pad != k / 2) return false;
     if (res_mode != RES_NONE && res_mode != RES_AFTER_ACT) return false;
     if (in.c != out.c || (in.c & 7) || (in.cs & 7) || (in.coff & 7) || (out.cs & 7) || (out.coff & 7) || in.f32 || out.f32) return false;
     return out.h == (in.h + 2 * pad - k) / stride + 1 && out.w == (in.w + 2 * pad - k) / stride + 1;

@@ -167,6 +167,49 @@ __device__ __forceinline__ void x3_store8(x3s* p, const float v[8]) {
 }
 #endif
 
+#if defined(__HIPCC__)
+// 8 consecutive channels of one pixel as fp32, on any storage type (bf16 `uint16_t`, fp16 `f16s`, `float`, split `x3s`): the
+// element-wise / depth-wise kernels run the same code in every precision
+template <typename T> struct Vec8;
+template <> struct Vec8<uint16_t> {
+    static __device__ __forceinline__ void load(const uint16_t* p, float v[8]) {
+        const uint4 q = *reinterpret_cast<const uint4*>(p);
+        const uint32_t w[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { v[2 * k] = Bf16::lo(w[k]); v[2 * k + 1] = Bf16::hi(w[k]); }
+    }
+    static __device__ __forceinline__ void store(uint16_t* p, const float v[8]) {
+        *reinterpret_cast<uint4*>(p) = make_uint4(Bf16::pack2(v[0], v[1]), Bf16::pack2(v[2], v[3]), Bf16::pack2(v[4], v[5]), Bf16::pack2(v[6], v[7]));
+    }
+};
+template <> struct Vec8<f16s> {
+    static __device__ __forceinline__ void load(const f16s* p, float v[8]) {
+        const uint4 q = *reinterpret_cast<const uint4*>(p);
+        const uint32_t w[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { v[2 * k] = Fp16::lo(w[k]); v[2 * k + 1] = Fp16::hi(w[k]); }
+    }
+    static __device__ __forceinline__ void store(f16s* p, const float v[8]) {
+        *reinterpret_cast<uint4*>(p) = make_uint4(Fp16::pack2(v[0], v[1]), Fp16::pack2(v[2], v[3]), Fp16::pack2(v[4], v[5]), Fp16::pack2(v[6], v[7]));
+    }
+};
+template <> struct Vec8<float> {
+    static __device__ __forceinline__ void load(const float* p, float v[8]) {
+        const float4 a = reinterpret_cast<const float4*>(p)[0], b = reinterpret_cast<const float4*>(p)[1];
+        v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+    }
+    static __device__ __forceinline__ void store(float* p, const float v[8]) {
+        reinterpret_cast<float4*>(p)[0] = make_float4(v[0], v[1], v[2], v[3]);
+        reinterpret_cast<float4*>(p)[1] = make_float4(v[4], v[5], v[6], v[7]);
+    }
+};
+
+template <> struct Vec8<x3s> {   // split precision: one G8 group (elem16.h)
+    static __device__ __forceinline__ void load(const x3s* p, float v[8]) { x3_load8(p, v); }
+    static __device__ __forceinline__ void store(x3s* p, const float v[8]) { x3_store8(p, v); }
+};
+#endif
+
 // Run `fn(tag)` with the element tag of a 16-bit engine precision (PREC_FP16 -> Fp16, otherwise Bf16).
 #define ADAS_DISPATCH_E16(is_half, E, ...) \
     do {                                   \

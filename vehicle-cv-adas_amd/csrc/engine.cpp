@@ -180,11 +180,21 @@ int adas_engine_create(const char* model_path, int precision, int max_batch, ada
             ok = o.n_in == 1 && depth2space_supported(view(o.in_buf[0], o.in_coff[0], o.in_c[0]), view(o.out_buf, o.out_coff, o.out_c));
         else if (o.type == OP_DETECT_V6)
             ok = o.n_in == 6;
+        else if (o.type == OP_SE_GATE)
+            ok = o.n_in == 1 && se_gate_supported(view(o.in_buf[0], o.in_coff[0], o.in_c[0]), view(o.out_buf, o.out_coff, o.out_c), (int)o.params[0], o.w_elems, o.b_elems);
+        else if (o.type == OP_SCALE)
+            ok = o.n_in == 2 && scale_supported(view(o.in_buf[0], o.in_coff[0], o.in_c[0]), view(o.in_buf[1], o.in_coff[1], o.in_c[1]), view(o.out_buf, o.out_coff, o.out_c));
+        else if (o.type == OP_WSUM) {
+            TView ins[3];
+            for (uint32_t k = 0; k < o.n_in && k < 3; ++k) ins[k] = view(o.in_buf[k], o.in_coff[k], o.in_c[k]);
+            ok = o.n_in <= 3 && wsum_supported((int)o.n_in, ins, view(o.out_buf, o.out_coff, o.out_c));
+        }
         if (!ok) {
             fclose(f);
             free_engine(e);
             set_error("[%s]: layer %s: unsupported %s shape", model_path, std::string(o.name, strnlen(o.name, sizeof(o.name))).c_str(),
-                      o.type == OP_DWCONV ? "depth-wise convolution" : o.type == OP_ATTENTION ? "attention" : o.type == OP_DEPTH2SPACE ? "depth-to-space" : "Detect");
+                      o.type == OP_DWCONV ? "depth-wise convolution" : o.type == OP_ATTENTION ? "attention" : o.type == OP_DEPTH2SPACE ? "depth-to-space"
+                      : o.type == OP_SE_GATE ? "squeeze-and-excitation" : o.type == OP_SCALE ? "channel scale" : o.type == OP_WSUM ? "weighted sum" : "Detect");
             return ADAS_ERR_FORMAT;
         }
     }
@@ -555,7 +565,7 @@ int adas_engine_create(const char* model_path, int precision, int max_batch, ada
             packed_total += ((size_t)op.cout_pad * op.kpad * esz + 255) & ~(size_t)255;
             op.b_off = packed_total;
             packed_total += ((size_t)op.cout_pad * 4 + 255) & ~(size_t)255;
-        } else if (o.type == OP_LAYERNORM || o.type == OP_DWCONV) {
+        } else if (o.type == OP_LAYERNORM || o.type == OP_DWCONV || o.type == OP_SE_GATE) {
             op.w_off = packed_total;
             packed_total += ((size_t)o.w_elems * 4 + 255) & ~(size_t)255;
             op.b_off = packed_total;
@@ -617,7 +627,10 @@ int adas_engine_create(const char* model_path, int precision, int max_batch, ada
     }
     (void)hipMemset(e->d_weights, 0, packed_total + 256);
     size_t max_w = 0;
-    for (auto& o : fo) max_w = o.w_elems > max_w ? (size_t)o.w_elems : max_w;
+    for (auto& o : fo) {
+        max_w = o.w_elems > max_w ? (size_t)o.w_elems : max_w;
+        max_w = o.b_elems > max_w ? (size_t)o.b_elems : max_w;   // layernorm / squeeze-and-excitation stage their second blob too
+    }
     float* d_stage = nullptr;
     std::vector<float> h_stage(max_w ? max_w : 1);
     if (hipMalloc((void**)&d_stage, max_w * 4 + 256) != hipSuccess) {
@@ -664,7 +677,7 @@ int adas_engine_create(const char* model_path, int precision, int max_batch, ada
             std::vector<float> b(op.cout_pad, 0.f);
             if (!read_blob(o.b_off, o.b_elems, b.data())) { rc = ADAS_ERR_FORMAT; break; }
             if (hipMemcpy(base + op.b_off, b.data(), (size_t)op.cout_pad * 4, hipMemcpyHostToDevice) != hipSuccess) { rc = ADAS_ERR_HIP; break; }
-        } else if (o.type == OP_LAYERNORM) {
+        } else if (o.type == OP_LAYERNORM || o.type == OP_SE_GATE) {
             if (!read_blob(o.w_off, o.w_elems, h_stage.data())) { rc = ADAS_ERR_FORMAT; break; }
             if (hipMemcpy(base + op.w_off, h_stage.data(), o.w_elems * 4, hipMemcpyHostToDevice) != hipSuccess) { rc = ADAS_ERR_HIP; break; }
             if (!read_blob(o.b_off, o.b_elems, h_stage.data())) { rc = ADAS_ERR_FORMAT; break; }
@@ -745,7 +758,8 @@ int adas_engine_layer_kernel(const adas_engine* e, int layer, int batch, char* n
     const EngOp& op = e->ops[layer];
     const FileOp& o = op.f;
     static const char* kOther[] = {"input_nchw_kernel", "", "maxpool_kernel", "upsample2_kernel", "detect_v8_kernel", "detect_v5_kernel",
-                                   "layernorm_kernel", "dwconv_kernel", "attention_kernel", "avgpool_kernel", "depth2space_kernel", "detect_v6_kernel"};
+                                   "layernorm_kernel", "dwconv_kernel", "attention_kernel", "avgpool_kernel", "depth2space_kernel", "detect_v6_kernel",
+                                   "se_gate_kernel", "scale_kernel", "wsum_kernel"};
     if (o.type == OP_CONV && op.ds_user >= 0 && ds_folded(e, op.ds_user, batch)) {
         snprintf(name, cap, "(fused into the conv it is the shortcut of)");
     } else if (op.skip && o.type == OP_UPSAMPLE2) {
@@ -783,7 +797,7 @@ int adas_engine_layer_kernel(const adas_engine* e, int layer, int batch, char* n
     } else if (o.type == OP_DETECT_V5 && op.det_src[0] >= 0) {
         snprintf(name, cap, "detect_v5_fused_kernel");
     } else {
-        snprintf(name, cap, "%s", o.type < 12 ? kOther[o.type] : "?");
+        snprintf(name, cap, "%s", o.type < 15 ? kOther[o.type] : "?");
     }
     return ADAS_OK;
 }
@@ -951,6 +965,23 @@ int engine_run_op(adas_engine* e, int i, const float* d_in, int batch, hipStream
             err = launch_dwconv(make_view(e, o.in_buf[0], o.in_coff[0], o.in_c[0]), make_view(e, o.out_buf, o.out_coff, o.out_c), r, (int)o.res_mode,
                                 (const float*)(wb + op.w_off), (const float*)(wb + op.b_off), batch, (int)o.kh, (int)o.stride, (int)o.pad, (int)o.act,
                                 e->prec, st);
+            break;
+        }
+        case OP_SE_GATE: {
+            const float* w1 = (const float*)(wb + op.w_off);
+            const float* w2 = (const float*)(wb + op.b_off);
+            err = launch_se_gate(make_view(e, o.in_buf[0], o.in_coff[0], o.in_c[0]), make_view(e, o.out_buf, o.out_coff, o.out_c), w1, w2, (int)o.params[0], batch,
+                                 e->prec, st);
+            break;
+        }
+        case OP_SCALE:
+            err = launch_scale(make_view(e, o.in_buf[0], o.in_coff[0], o.in_c[0]), make_view(e, o.in_buf[1], o.in_coff[1], o.in_c[1]),
+                               make_view(e, o.out_buf, o.out_coff, o.out_c), batch, e->prec, st);
+            break;
+        case OP_WSUM: {
+            TView ins[3];
+            for (uint32_t k = 0; k < o.n_in && k < 3; ++k) ins[k] = make_view(e, o.in_buf[k], o.in_coff[k], o.in_c[k]);
+            err = launch_wsum((int)o.n_in, ins, o.params, make_view(e, o.out_buf, o.out_coff, o.out_c), batch, (int)o.act, e->prec, st);
             break;
         }
         case OP_ATTENTION:

@@ -1,0 +1,215 @@
+// fuse_ops.hip -- the element-wise operators of the EfficientDet graph (the reference's fourth detector family:
+// ObjectDetector/efficientdetDetector.py:18-111 loads an exported EfficientDet-D0; EfficientNet MBConv blocks carry a
+// squeeze-and-excitation gate, BiFPN nodes are weighted sums of 2-3 maps at one resolution):
+//   se_gate   gate[n][c] = sigmoid(W2 silu(W1 mean_hw(x[n]) + b1) + b2)           (OP_SE_GATE; fp32 arithmetic in every precision)
+//   scale     out[n][p][c] = x[n][p][c] * gate[n][c]                                (OP_SCALE)
+//   wsum      out = act(w0 a + w1 b [+ w2 c]), an input of half the output's resolution is read at (y / 2, x / 2)
+//             (nearest 2x upsample folded into the loads)                            (OP_WSUM: BiFPN fast normalised fusion, the
+//             weights are constants at inference: relu(w_i) / (sum_j relu(w_j) + 1e-4))
+// All HBM-bound streaming: thread = (pixel, 8-channel group), 16-byte loads (16-bit modes), fp32 arithmetic, one pass.
+// se_gate is one workgroup per frame with a fixed summation order (stripes of pixels, then stripes in index order): results do not
+// depend on scheduling, graph replay = eager bit for bit.
+#include "kernels.h"
+#include "elem16.h"
+
+namespace adas {
+
+struct SeDev {
+    const void* in;
+    float* gate;         // [n][gate_cs] (+ gate_coff) fp32
+    const float* w1;     // [cr][c] then b1[cr]
+    const float* w2;     // [c][cr] then b2[c]
+    int in_cs, in_coff, gate_cs, gate_coff;
+    int c, cr, HW, S;    // S: pixel stripes (1024 / (c / 8))
+};
+
+template <typename T>
+__global__ __launch_bounds__(1024) void se_gate_kernel(SeDev d) {
+    if constexpr (sizeof(T) == 2 && !__is_same(T, uint16_t)) Fp16::enter();
+    extern __shared__ float sm[];
+    float* part = sm;                 // [S][c]
+    float* mean = sm + d.S * d.c;     // [c]
+    float* hid = mean + d.c;          // [cr]
+    const int n = blockIdx.x, t = threadIdx.x, G = d.c >> 3;
+    const int g = t % G, s = t / G;
+    if (s < d.S) {
+        float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        const T* base = (const T*)d.in + (size_t)n * d.HW * d.in_cs + d.in_coff + g * 8;
+        for (int p = s; p < d.HW; p += d.S) {
+            float x[8];
+            Vec8<T>::load(base + (size_t)p * d.in_cs, x);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[e] += x[e];
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) part[s * d.c + g * 8 + e] = acc[e];
+    }
+    __syncthreads();
+    for (int ch = t; ch < d.c; ch += 1024) {
+        float m = 0.f;
+        for (int q = 0; q < d.S; ++q) m += part[q * d.c + ch];
+        mean[ch] = m / (float)d.HW;
+    }
+    __syncthreads();
+    const int lane = t & 63, wave = t >> 6;
+    for (int j = wave; j < d.cr; j += 16) {
+        float a = 0.f;
+        for (int ch = lane; ch < d.c; ch += 64) a = fmaf(d.w1[(size_t)j * d.c + ch], mean[ch], a);
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) a += __shfl_xor(a, o);
+        if (lane == 0) {
+            const float v = a + d.w1[(size_t)d.cr * d.c + j];
+            hid[j] = v / (1.0f + expf(-v));
+        }
+    }
+    __syncthreads();
+    for (int ch = t; ch < d.c; ch += 1024) {
+        float v = d.w2[(size_t)d.c * d.cr + ch];
+        for (int j = 0; j < d.cr; ++j) v = fmaf(d.w2[(size_t)ch * d.cr + j], hid[j], v);
+        d.gate[(size_t)n * d.gate_cs + d.gate_coff + ch] = 1.0f / (1.0f + expf(-v));
+    }
+}
+
+bool se_gate_supported(const TView& in, const TView& gate, int cr, uint64_t w_elems, uint64_t b_elems) {
+    if (in.f32 || !gate.f32 || gate.h != 1 || gate.w != 1 || gate.c != in.c) return false;
+    if ((in.c & 7) || (in.cs & 7) || (in.coff & 7) || in.c > 8192 || cr < 1 || cr > 2048) return false;
+    return w_elems == (uint64_t)cr * in.c + cr && b_elems == (uint64_t)in.c * cr + in.c;
+}
+
+hipError_t launch_se_gate(const TView& in, const TView& gate, const float* w1, const float* w2, int cr, int n, int prec, hipStream_t st) {
+    SeDev d;
+    d.in = in.p; d.gate = (float*)gate.p; d.w1 = w1; d.w2 = w2;
+    d.in_cs = in.cs; d.in_coff = in.coff; d.gate_cs = gate.cs; d.gate_coff = gate.coff;
+    d.c = in.c; d.cr = cr; d.HW = in.h * in.w;
+    const int G = in.c >> 3;
+    d.S = 1024 / G;
+    if (d.S < 1) return hipErrorInvalidValue;
+    if (d.S > d.HW) d.S = d.HW;
+    const size_t lds = ((size_t)d.S * d.c + d.c + cr) * 4;
+    if (prec == PREC_FP32) hipLaunchKernelGGL(se_gate_kernel<float>, dim3(n), dim3(1024), lds, st, d);
+    else if (prec == PREC_X3) hipLaunchKernelGGL(se_gate_kernel<x3s>, dim3(n), dim3(1024), lds, st, d);
+    else if (prec == PREC_FP16) hipLaunchKernelGGL(se_gate_kernel<f16s>, dim3(n), dim3(1024), lds, st, d);
+    else hipLaunchKernelGGL(se_gate_kernel<uint16_t>, dim3(n), dim3(1024), lds, st, d);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------- scale
+struct ScDev {
+    const void* in;
+    const float* gate;
+    void* out;
+    int in_cs, in_coff, out_cs, out_coff, gate_cs, gate_coff;
+    int c, HW, n;
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void scale_kernel(ScDev d) {
+    if constexpr (sizeof(T) == 2 && !__is_same(T, uint16_t)) Fp16::enter();
+    const int G = d.c >> 3;
+    const size_t total = (size_t)d.n * d.HW * G;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int g = (int)(i % G);
+        const size_t pix = i / G;
+        const size_t b = pix / d.HW;
+        float x[8];
+        Vec8<T>::load((const T*)d.in + pix * d.in_cs + d.in_coff + g * 8, x);
+        const float* gp = d.gate + b * d.gate_cs + d.gate_coff + g * 8;
+        const float4 g0 = *reinterpret_cast<const float4*>(gp), g1 = *reinterpret_cast<const float4*>(gp + 4);
+        x[0] *= g0.x; x[1] *= g0.y; x[2] *= g0.z; x[3] *= g0.w; x[4] *= g1.x; x[5] *= g1.y; x[6] *= g1.z; x[7] *= g1.w;
+        Vec8<T>::store((T*)d.out + pix * d.out_cs + d.out_coff + g * 8, x);
+    }
+}
+
+bool scale_supported(const TView& in, const TView& gate, const TView& out) {
+    if (in.f32 || out.f32 || !gate.f32 || gate.h != 1 || gate.w != 1 || gate.c != in.c || out.c != in.c || out.h != in.h || out.w != in.w) return false;
+    return !((in.c & 7) || (in.cs & 7) || (in.coff & 7) || (out.cs & 7) || (out.coff & 7) || (gate.cs & 3) || (gate.coff & 3));
+}
+
+hipError_t launch_scale(const TView& in, const TView& gate, const TView& out, int n, int prec, hipStream_t st) {
+    if (!scale_supported(in, gate, out)) return hipErrorInvalidValue;
+    ScDev d;
+    d.in = in.p; d.gate = (const float*)gate.p; d.out = out.p;
+    d.in_cs = in.cs; d.in_coff = in.coff; d.out_cs = out.cs; d.out_coff = out.coff; d.gate_cs = gate.cs; d.gate_coff = gate.coff;
+    d.c = in.c; d.HW = in.h * in.w; d.n = n;
+    const size_t total = (size_t)n * d.HW * (in.c >> 3);
+    const int blocks = (int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
+    if (prec == PREC_FP32) hipLaunchKernelGGL(scale_kernel<float>, dim3(blocks), dim3(256), 0, st, d);
+    else if (prec == PREC_X3) hipLaunchKernelGGL(scale_kernel<x3s>, dim3(blocks), dim3(256), 0, st, d);
+    else if (prec == PREC_FP16) hipLaunchKernelGGL(scale_kernel<f16s>, dim3(blocks), dim3(256), 0, st, d);
+    else hipLaunchKernelGGL(scale_kernel<uint16_t>, dim3(blocks), dim3(256), 0, st, d);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------- weighted sum
+struct WsDev {
+    const void* in[3];
+    void* out;
+    int cs[3], coff[3], half[3];   // half: the input has half the output's resolution
+    float w[3];
+    int out_cs, out_coff;
+    int n_in, c, H, W, n, act;
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void wsum_kernel(WsDev d) {
+    if constexpr (sizeof(T) == 2 && !__is_same(T, uint16_t)) Fp16::enter();
+    const int G = d.c >> 3;
+    const size_t total = (size_t)d.n * d.H * d.W * G;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int g = (int)(i % G);
+        const size_t pix = i / G;
+        const int x = (int)(pix % d.W);
+        const size_t t = pix / d.W;
+        const int y = (int)(t % d.H);
+        const size_t b = t / d.H;
+        float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            if (k >= d.n_in) break;
+            const size_t sp = d.half[k] ? ((b * (d.H >> 1) + (y >> 1)) * (d.W >> 1) + (x >> 1)) : pix;
+            float v[8];
+            Vec8<T>::load((const T*)d.in[k] + sp * d.cs[k] + d.coff[k] + g * 8, v);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[e] = fmaf(d.w[k], v[e], acc[e]);
+        }
+        if (d.act == ACT_SILU) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[e] = acc[e] / (1.0f + expf(-acc[e]));
+        } else if (d.act == ACT_RELU) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[e] = fmaxf(acc[e], 0.0f);
+        }
+        Vec8<T>::store((T*)d.out + pix * d.out_cs + d.out_coff + g * 8, acc);
+    }
+}
+
+bool wsum_supported(int n_in, const TView* ins, const TView& out) {
+    if (n_in < 2 || n_in > 3 || out.f32 || (out.c & 7) || (out.cs & 7) || (out.coff & 7)) return false;
+    for (int k = 0; k < n_in; ++k) {
+        const TView& v = ins[k];
+        if (v.f32 || v.c != out.c || (v.cs & 7) || (v.coff & 7)) return false;
+        const bool same = v.h == out.h && v.w == out.w, half = v.h * 2 == out.h && v.w * 2 == out.w;
+        if (!same && !half) return false;
+    }
+    return true;
+}
+
+hipError_t launch_wsum(int n_in, const TView* ins, const float* w, const TView& out, int n, int act, int prec, hipStream_t st) {
+    if (!wsum_supported(n_in, ins, out)) return hipErrorInvalidValue;
+    WsDev d;
+    for (int k = 0; k < 3; ++k) {
+        const TView& v = ins[k < n_in ? k : 0];
+        d.in[k] = v.p; d.cs[k] = v.cs; d.coff[k] = v.coff; d.half[k] = v.h != out.h; d.w[k] = k < n_in ? w[k] : 0.0f;
+    }
+    d.out = out.p; d.out_cs = out.cs; d.out_coff = out.coff;
+    d.n_in = n_in; d.c = out.c; d.H = out.h; d.W = out.w; d.n = n; d.act = act;
+    const size_t total = (size_t)n * out.h * out.w * (out.c >> 3);
+    const int blocks = (int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
+    if (prec == PREC_FP32) hipLaunchKernelGGL(wsum_kernel<float>, dim3(blocks), dim3(256), 0, st, d);
+    else if (prec == PREC_X3) hipLaunchKernelGGL(wsum_kernel<x3s>, dim3(blocks), dim3(256), 0, st, d);
+    else if (prec == PREC_FP16) hipLaunchKernelGGL(wsum_kernel<f16s>, dim3(blocks), dim3(256), 0, st, d);
+    else hipLaunchKernelGGL(wsum_kernel<uint16_t>, dim3(blocks), dim3(256), 0, st, d);
+    return hipGetLastError();
+}
+
+}  // namespace adas

@@ -188,6 +188,13 @@ hipError_t launch_fc_x3(const ConvArgs& a, hipStream_t st);
 hipError_t launch_pack_weights_fcx3(const float* src, void* dst, int cout, int cout_pad, int cin, int kpad, hipStream_t st);
 hipError_t launch_pack_weights_fc(const float* src, void* dst, int cout, int cout_pad, int cin, int kpad, int prec, hipStream_t st);
 // dw_attn.hip: depth-wise k x k conv (k = 3 | 7, stride 1 | 2, pad k/2; weights fp32 [k*k][C], bias fp32 [C]; residual: RES_AFTER_ACT only)
+// fuse_ops.hip: EfficientDet's element-wise operators (squeeze-and-excitation gate, channel scale, BiFPN weighted sum)
+bool se_gate_supported(const TView& in, const TView& gate, int cr, uint64_t w_elems, uint64_t b_elems);
+hipError_t launch_se_gate(const TView& in, const TView& gate, const float* w1, const float* w2, int cr, int n, int prec, hipStream_t st);
+bool scale_supported(const TView& in, const TView& gate, const TView& out);
+hipError_t launch_scale(const TView& in, const TView& gate, const TView& out, int n, int prec, hipStream_t st);
+bool wsum_supported(int n_in, const TView* ins, const TView& out);
+hipError_t launch_wsum(int n_in, const TView* ins, const float* w, const TView& out, int n, int act, int prec, hipStream_t st);
 bool dwconv_supported(int k, int stride, int pad, int res_mode, const TView& in, const TView& out);
 hipError_t launch_dwconv(const TView& in, const TView& out, const TView& res, int res_mode, const float* wgt, const float* bias, int n, int k,
                          int stride, int pad, int act, int prec, hipStream_t st);

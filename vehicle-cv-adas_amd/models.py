@@ -23,7 +23,7 @@ import numpy as np
 
 MAGIC = b"ADASHIP1"
 (OP_INPUT, OP_CONV, OP_MAXPOOL, OP_UPSAMPLE2, OP_DETECT_V8, OP_DETECT_V5, OP_LAYERNORM, OP_DWCONV, OP_ATTENTION, OP_AVGPOOL, OP_DEPTH2SPACE,
- OP_DETECT_V6) = range(12)
+ OP_DETECT_V6, OP_SE_GATE, OP_SCALE, OP_WSUM) = range(15)
 ACT_NONE, ACT_SILU, ACT_RELU, ACT_LEAKY = 0, 1, 2, 3      # ACT_LEAKY: LeakyReLU(0.1) (YOLOv7)
 RES_NONE, RES_AFTER_ACT, RES_BEFORE_ACT = 0, 1, 2
 BUF_F32 = 1
@@ -62,6 +62,7 @@ SYNTH_GAINS = {"yolov6n": 0.95, "yolov6s": 0.95,                      # plain Re
                "yolov9t": 1.12,                                       # critical between 1.16 and 1.22 (activations explode there)
                "yolov10s": 1.0,
                "yolov10n": 1.05,                                      # critical ~1.09 (1.08 already drifts: fp16 rel-L2 1.9e-3 at P5, boxes 0.3 px)
+               "efficientdet-d0": 1.05,                               # = EFFDET_GAIN
                "yolov8m": 0.99, "yolov8l": 0.96, "yolov8x": 0.98}     # deeper Bottleneck chains: critical gain ~1.03 (m), ~0.97 (l), ~1.0 (x)
 
 
@@ -298,6 +299,36 @@ class Graph:
             out = self.buf(x.h * 2, x.w * 2, x.c)
         assert (out.h, out.w, out.c) == (x.h * 2, x.w * 2, x.c)
         self._op(OP_UPSAMPLE2, [x], out, name=name)
+        return out
+
+    def se(self, x, cr, name, out=None):
+        """Squeeze-and-excitation (EfficientNet MBConv): x * sigmoid(W2 silu(W1 mean_hw(x) + b1) + b2), squeeze width cr.  Parameters
+        'name.reduce.{weight,bias}' (cr, C, 1, 1) and 'name.expand.{weight,bias}' (C, cr, 1, 1).  Two launches: the gate (one fp32 value
+        per frame and channel, fp32 arithmetic in every precision) and the channel scale."""
+        c = x.c
+        W1, b1 = self.w(name + ".reduce.weight", (cr, c, 1, 1), "conv"), self.w(name + ".reduce.bias", (cr,), "bias")
+        W2, b2 = self.w(name + ".expand.weight", (c, cr, 1, 1), "conv"), self.w(name + ".expand.bias", (c,), "bias")
+        gate = self.buf(1, 1, c, f32=True)
+        self._op(OP_SE_GATE, [x], gate, w=self._blob(np.concatenate([W1.ravel(), b1])), b=self._blob(np.concatenate([W2.ravel(), b2])),
+                 params=[cr], flops=x.h * x.w * c + 4.0 * c * cr, name=name + ".gate")
+        if out is None:
+            out = self.buf(x.h, x.w, c)
+        assert (out.h, out.w, out.c) == (x.h, x.w, c)
+        self._op(OP_SCALE, [x, gate], out, flops=float(x.h * x.w * c), name=name + ".scale")
+        self.n_params += W1.size + b1.size + W2.size + b2.size
+        return out
+
+    def wsum(self, ins, weights, name, act=ACT_SILU, out=None):
+        """act(sum_i weights[i] * ins[i]) over 2-3 maps of one width; an input of half the output's resolution is read through a nearest
+        2x upsample (BiFPN top-down nodes).  The output resolution is that of the largest input."""
+        assert 2 <= len(ins) <= 3 and len(weights) == len(ins)
+        h, w, c = max(v.h for v in ins), max(v.w for v in ins), ins[0].c
+        for v in ins:
+            assert v.c == c and ((v.h, v.w) == (h, w) or (2 * v.h, 2 * v.w) == (h, w)), (name, (v.h, v.w, v.c), (h, w, c))
+        if out is None:
+            out = self.buf(h, w, c)
+        assert (out.h, out.w, out.c) == (h, w, c)
+        self._op(OP_WSUM, list(ins), out, act=act, params=[float(np.float32(x)) for x in weights], flops=2.0 * len(ins) * h * w * c, name=name)
         return out
 
     def output(self, view, offset, dims, name):
@@ -1095,7 +1126,106 @@ TUSIMPLE = dict(in_h=320, in_w=800, num_grid_row=100, num_cls_row=56, num_grid_c
 # -> 187,260.
 CURVELANES = dict(in_h=800, in_w=1600, num_grid_row=200, num_cls_row=72, num_grid_col=100, num_cls_col=41, num_lanes=10, fc_norm=True)
 
+# =====================================================================================
+# EfficientDet-D0  (Tan, Pang, Le: "EfficientDet", arXiv:1911.09070; the reference's EfficientdetDetector loads an exported
+# efficientdet-d0 graph: ObjectDetector/efficientdetDetector.py:18-44, demo default 'models/efficientdet-d0-coco_fp32.onnx' :119)
+# =====================================================================================
+# EfficientNet-B0 stages (Tan & Le, arXiv:1905.11946 table 1): (expand ratio, kernel, stride, out channels, repeats); SE ratio 0.25
+# of the block's INPUT channels; swish everywhere; identity skip when stride 1 and in == out.
+EFFNET_B0 = [(1, 3, 1, 16, 1), (6, 3, 2, 24, 2), (6, 5, 2, 40, 2), (6, 3, 2, 80, 3), (6, 5, 1, 112, 3), (6, 5, 2, 192, 4), (6, 3, 1, 320, 1)]
+EFFDET_D0 = dict(imgsz=512, fpn_c=64, fpn_cells=3, head_layers=3, num_anchors=9)
+EFFDET_GAIN = 1.05    # synthetic weights: critical gain between 1.07 and 1.1 (activations explode through the linear project / BiFPN convs);
+                      # 1.05 keeps rms 0.06-0.5 through the depth and class logits with std ~0.7 (a trained checkpoint needs none of this)
+
+
+def fusion_weights(p):
+    """BiFPN fast normalised fusion (EfficientDet eq. 3) at inference: relu(p_i) / (sum_j relu(p_j) + 1e-4), float32."""
+    w = np.maximum(np.asarray(p, np.float32), np.float32(0))
+    return (w / (w.sum(dtype=np.float32) + np.float32(1e-4))).astype(np.float32)
+
+
+def _mbconv(g, x, name, expand, k, s, cout):
+    cin = x.c
+    t = x
+    if expand != 1:
+        t = g.conv(t, cin * expand, 1, 1, name + ".expand")
+    t = g.dwconv(t, k, s, name + ".dw")
+    t = g.se(t, max(1, int(cin * 0.25)), name + ".se")
+    skip = x if (s == 1 and cin == cout) else None
+    return g.conv(t, cout, 1, 1, name + ".project", act=ACT_NONE, res=skip, res_mode=RES_AFTER_ACT if skip is not None else RES_NONE)
+
+
+def _sepconv(g, x, cout, name, act=ACT_NONE, f32_out=False, dw_name=None, bias_fill=None):
+    """SeparableConvBlock: depth-wise 3x3 (no bias) -> point-wise 1x1 (bias; the BatchNorm behind it folded in) [-> swish]."""
+    c = x.c
+    dw = g.w((dw_name or name) + ".dw.weight", (c, 1, 3, 3), "conv")
+    t = g.dwconv(x, 3, 1, name + ".dw", act=ACT_NONE, weight=dw, bias=np.zeros(c, np.float32))
+    return g.conv(t, cout, 1, 1, name + ".pw", act=act, f32_out=f32_out, bias_fill=bias_fill)
+
+
+def efficientdet(nc=90, imgsz=512, wsrc=None, seed=0, fpn_c=64, fpn_cells=3, head_layers=3, num_anchors=9, cls_bias=-3.0):
+    """EfficientDet-D0 up to its two raw head tensors per pyramid level: box regression (dy, dx, dh, dw) x 9 anchors and class logits
+    nc x 9 anchors, rows ordered (y, x, anchor) -- what the exported graph feeds its in-graph anchor decode + NMS
+    (postproc.EffdetTail).  Symmetric k // 2 padding (the PyTorch-native variant of the architecture).  cls_bias: the classifier
+    header's bias (trained nets start it at -log(99); a seeded net needs it for a sparse score field)."""
+    H, W = _hw(imgsz)
+    assert H % 128 == 0 and W % 128 == 0, "EfficientDet needs inputs divisible by 128 (five pyramid levels, 2x resampling)"
+    ws = wsrc or SynthWeights(seed, gain=EFFDET_GAIN)
+    g = Graph("efficientdet-d0", 3, H, W, ws)
+    x, c3 = g.input()
+    t = g.conv(x, 32, 3, 2, "stem", true_cin=c3)
+    feats, bi = [], 0
+    for si, (e, k, s, c, n) in enumerate(EFFNET_B0):
+        for r in range(n):
+            t = _mbconv(g, t, f"blocks.{bi}", e, k, s if r == 0 else 1, c)
+            bi += 1
+        if si in (2, 4, 6):
+            feats.append(t)
+    c3f, c4f, c5f = feats
+    # ---- BiFPN
+    p = None
+    for cell in range(fpn_cells):
+        nm = f"bifpn.{cell}"
+        if cell == 0:
+            p3 = g.conv(c3f, fpn_c, 1, 1, nm + ".p3_down", act=ACT_NONE)
+            p4 = g.conv(c4f, fpn_c, 1, 1, nm + ".p4_down", act=ACT_NONE)
+            p5 = g.conv(c5f, fpn_c, 1, 1, nm + ".p5_down", act=ACT_NONE)
+            p6 = g.maxpool(g.conv(c5f, fpn_c, 1, 1, nm + ".p5_to_p6", act=ACT_NONE), 3, 2, 1, name=nm + ".p6_pool")
+            p7 = g.maxpool(p6, 3, 2, 1, name=nm + ".p7_pool")
+            p4b = g.conv(c4f, fpn_c, 1, 1, nm + ".p4_down_2", act=ACT_NONE)   # the bottom-up path of the first cell re-projects P4 / P5
+            p5b = g.conv(c5f, fpn_c, 1, 1, nm + ".p5_down_2", act=ACT_NONE)
+        else:
+            p3, p4, p5, p6, p7 = p
+            p4b, p5b = p4, p5
+
+        def fw(tag, n):
+            return fusion_weights(ws(f"{nm}.{tag}", (n,), "ln_w"))
+
+        p6u = _sepconv(g, g.wsum([p6, p7], fw("p6_w1", 2), nm + ".p6_td"), fpn_c, nm + ".conv6_up")
+        p5u = _sepconv(g, g.wsum([p5, p6u], fw("p5_w1", 2), nm + ".p5_td"), fpn_c, nm + ".conv5_up")
+        p4u = _sepconv(g, g.wsum([p4, p5u], fw("p4_w1", 2), nm + ".p4_td"), fpn_c, nm + ".conv4_up")
+        p3o = _sepconv(g, g.wsum([p3, p4u], fw("p3_w1", 2), nm + ".p3_td"), fpn_c, nm + ".conv3_up")
+        p4o = _sepconv(g, g.wsum([p4b, p4u, g.maxpool(p3o, 3, 2, 1, name=nm + ".p3_ds")], fw("p4_w2", 3), nm + ".p4_bu"), fpn_c, nm + ".conv4_down")
+        p5o = _sepconv(g, g.wsum([p5b, p5u, g.maxpool(p4o, 3, 2, 1, name=nm + ".p4_ds")], fw("p5_w2", 3), nm + ".p5_bu"), fpn_c, nm + ".conv5_down")
+        p6o = _sepconv(g, g.wsum([p6, p6u, g.maxpool(p5o, 3, 2, 1, name=nm + ".p5_ds")], fw("p6_w2", 3), nm + ".p6_bu"), fpn_c, nm + ".conv6_down")
+        p7o = _sepconv(g, g.wsum([p7, g.maxpool(p6o, 3, 2, 1, name=nm + ".p6_ds")], fw("p7_w2", 2), nm + ".p7_bu"), fpn_c, nm + ".conv7_down")
+        p = (p3o, p4o, p5o, p6o, p7o)
+    # ---- heads: the depth-wise / point-wise convs of a layer are shared by the five levels, the BatchNorm behind them is not (folded:
+    # point-wise parameters per level); the header has no BatchNorm
+    for lv, f in enumerate(p):
+        for branch, cout in (("regressor", num_anchors * 4), ("classifier", num_anchors * nc)):
+            t = f
+            for i in range(head_layers):
+                t = _sepconv(g, t, fpn_c, f"{branch}.l{lv}.{i}", act=ACT_SILU, dw_name=f"{branch}.conv_list.{i}")
+            o = _sepconv(g, t, cout, f"{branch}.l{lv}.header", f32_out=True, dw_name=f"{branch}.header",
+                         bias_fill=cls_bias if branch == "classifier" else None)
+            per = 4 if branch == "regressor" else nc
+            g.output(o, 0, [1, o.h * o.w * num_anchors, per], ("regression" if branch == "regressor" else "classification") + f".l{lv}")
+    return g
+
+
 BUILDERS = {
+    "efficientdet-d0": lambda **k: efficientdet(**k),
     "yolov8n": lambda **k: yolov8("n", **k), "yolov8s": lambda **k: yolov8("s", **k),
     "yolov8m": lambda **k: yolov8("m", **k), "yolov8l": lambda **k: yolov8("l", **k),
     "yolov8x": lambda **k: yolov8("x", **k),
