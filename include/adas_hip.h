@@ -217,6 +217,32 @@ int adas_effdet_post_run(adas_effdet_post* h, const float* d_boxes, const int32_
 /* Synchronises.  xywh [k][4] float32 (RectInfo x, y, width, height), conf [k], class_id [k], xyxy_int [k][4]; returns k in *n_keep. */
 int adas_effdet_post_fetch(adas_effdet_post* h, int frame, int32_t* n_keep, float* xywh, float* conf, int32_t* class_id,
                            int32_t* xyxy_int);
+/* The in-graph tail of the exported EfficientDet-D0 the reference loads (efficientdetDetector.py:38 OnnxEngine(model_path); its three
+ * outputs are read at :68-70): anchor decode, score threshold and per-class NMS over the network's raw head tensors (per pyramid
+ * level l = 0..4, stride 8 << l: box regression [batch][cells_l * 9][4] as (dy, dx, dh, dw) and class logits
+ * [batch][cells_l * 9][num_classes], rows ordered (y, x, anchor) -- the ten outputs of the "efficientdet-d0" engine graph).  The
+ * reference holds no such graph or weights: the steps restate the published post-processing of the architecture (csrc/post_core.h
+ * effdet_tail_frame).  Output per frame: boxes (n, 4) xyxy float32 in input pixels, class ids, confidences, by descending
+ * confidence -- what adas_effdet_post_run consumes. */
+typedef struct adas_effdet_tail adas_effdet_tail;
+typedef struct {
+    int32_t in_h, in_w;          /* network input (multiples of 128) */
+    int32_t num_classes;         /* 90 for the COCO export */
+    int32_t max_candidates;      /* anchors over score_thr per frame, <= 3072 (more: ADAS_ERR_CAPACITY at fetch) */
+    int32_t max_det;             /* survivors per frame */
+    int32_t reserved;
+    double score_thr, iou_thr;   /* score > score_thr is a candidate; IoU > iou_thr suppresses within a class */
+    double anchor_scale;         /* 4.0 */
+} adas_effdet_tail_params;
+int adas_effdet_tail_create(const adas_effdet_tail_params* p, int max_batch, adas_effdet_tail** out);
+int adas_effdet_tail_destroy(adas_effdet_tail* h);
+int adas_effdet_tail_run(adas_effdet_tail* h, const float* const* d_reg /* [5] */, const float* const* d_cls /* [5] */, int batch, void* stream);
+/* Synchronises.  boxes_xyxy [n][4], class_id [n], conf [n]; n_candidates (optional) = anchors over the threshold. */
+int adas_effdet_tail_fetch(adas_effdet_tail* h, int frame, int32_t* n_det, float* boxes_xyxy, int32_t* class_id, float* conf,
+                           int32_t* n_candidates);
+/* Device-resident results: boxes [max_batch][max_det][4], ids / confs [max_batch][max_det], counts [max_batch][2] (survivors, candidates). */
+int adas_effdet_tail_device_views(adas_effdet_tail* h, const float** d_boxes, const int32_t** d_ids, const float** d_confs,
+                                  const int32_t** d_counts);
 /* EfficientdetDetector.__prepare_input (efficientdetDetector.py:57-65): Scaler.process_image letterbox (canvas 114), then
  * (pixel / 255 - mean) / std per BGR channel -- NO channel swap -- with mean (0.406, 0.456, 0.485), std (0.225, 0.224, 0.229),
  * evaluated in double and cast to float32; NCHW. */

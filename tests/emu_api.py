@@ -86,6 +86,16 @@ def effdet(boxes, ids, confs, lb, box_score, cap=256):
     return dict(xywh=xywh[:k], conf=conf[:k], class_id=cls[:k].astype(np.int64), xyxy_int=xi[:k].astype(np.int64))
 
 
+def effdet_tail(reg, cls, in_hw, score_thr=0.05, iou_thr=0.5, max_det=100, cap=2048, anchor_scale=4.0):
+    import ctypes as C
+    reg = np.ascontiguousarray(reg, np.float32).reshape(-1, 4); cls = np.ascontiguousarray(cls, np.float32)
+    cnt = np.zeros(2, np.int32); boxes = np.zeros((max_det, 4), np.float32); ids = np.zeros(max_det, np.int32); confs = np.zeros(max_det, np.float32)
+    lib().emu_effdet_tail(_p(reg), _p(cls), int(in_hw[0]), int(in_hw[1]), int(cls.shape[1]), cap, max_det, C.c_double(score_thr), C.c_double(iou_thr),
+                          C.c_double(anchor_scale), _p(cnt), _p(boxes), _p(ids), _p(confs))
+    k = int(cnt[0])
+    return dict(boxes=boxes[:k], class_id=ids[:k].astype(np.int64), conf=confs[:k], n_candidates=int(cnt[1]))
+
+
 def ufld1(head, cfg, input_wh, src_wh):
     out = np.ascontiguousarray(head, np.float32)
     cnt = np.zeros(4, np.int32); det = np.zeros(4, np.int32); pts = np.zeros((4, 128, 2), np.int32)

@@ -62,6 +62,24 @@ int emu_effdet(const float* boxes, const int* ids, const float* confs, int n, in
     return 0;
 }
 
+// level l tensors of ONE frame, contiguous: reg_all = [A][4], cls_all = [A][nc], rows (level, y, x, anchor)
+int emu_effdet_tail(const float* reg_all, const float* cls_all, int in_h, int in_w, int nc, int cap, int max_det, double score_thr, double iou_thr,
+                    double anchor_scale, int* count, float* boxes, int* ids, float* confs) {
+    EffdetTailCfg cfg{in_h, in_w, nc, cap, max_det, score_thr, iou_thr, anchor_scale};
+    EffdetTailFrame f;
+    size_t row = 0;
+    for (int l = 0; l < 5; ++l) {
+        f.reg[l] = reg_all + row * 4;
+        f.cls[l] = cls_all + row * nc;
+        row += (size_t)(in_h >> (3 + l)) * (size_t)(in_w >> (3 + l)) * 9;
+    }
+    f.count = count; f.boxes = boxes; f.ids = ids; f.confs = confs;
+    std::vector<unsigned char> lds(effdet_tail_lds_bytes(cap, 1) + 64);
+    Ctx c{0, 1};
+    effdet_tail_frame(c, cfg, f, lds.data());
+    return 0;
+}
+
 int emu_ufld1(const float* out, int G, int K, int cfg_w, int cfg_h, int in_w, int in_h, int src_w, int src_h,
               const double* row_anchor, int* lane_cnt, int* lane_det, int* lane_pts) {
     Ufld1Cfg cfg{G, K, 4, cfg_w, cfg_h, in_w, in_h, src_w, src_h, row_anchor};

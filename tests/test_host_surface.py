@@ -27,6 +27,7 @@ def test_ctypes_structs_match_the_header_layout(tmp_path):
     (an ABI drift between the two would otherwise only show up as garbage on a GPU box)."""
     import ctypes as C, subprocess
     pairs = [("adas_yolo_post_params", L.YoloPostParams), ("adas_yolo_counts", L.YoloCounts), ("adas_ufld_params", L.UfldParams), ("adas_effdet_post_params", L.EffdetPostParams),
+             ("adas_effdet_tail_params", L.EffdetTailParams),
              ("adas_ufld1_params", L.Ufld1Params), ("adas_lane_geometry_params", L.LaneGeometryParams),
              ("adas_lane_geometry_result", L.LaneGeometryResult), ("adas_bytetrack_params", L.BytetrackParams),
              ("adas_track_header", L.TrackHeader), ("adas_pipeline_desc", L.PipelineDesc)]

@@ -227,3 +227,58 @@ def test_lane_geometry_reference_goldens():
     assert got["offset"] == pytest.approx(cv["offset"], rel=1e-7)
     empty = emu_api.lane_geometry([[], [], [], []], [False] * 4, 720, (1280, 720), np.eye(3), True)
     assert empty["direction"] is None and not empty["area_status"] and len(empty["area_points"]) == 0
+
+
+def _effdet_heads(seed, in_hw, nc=90, bias=-8.0, spread=1.0, n_obj=12):
+    """Synthetic raw head tensors of one frame: background logits around `bias`, a few object blobs (neighbouring anchors of one class
+    with correlated regressions, so the NMS has overlapping same-class boxes to suppress and overlapping other-class boxes to keep)."""
+    rng = np.random.default_rng(seed)
+    A = 9 * sum((in_hw[0] >> l) * (in_hw[1] >> l) for l in range(3, 8))
+    cls = (bias + spread * rng.standard_normal((A, nc))).astype(np.float32)
+    reg = (0.3 * rng.standard_normal((A, 4))).astype(np.float32)
+    for _ in range(n_obj):
+        a0 = int(rng.integers(0, A - 40)); c = int(rng.integers(0, nc))
+        idx = a0 + rng.choice(40, 12, replace=False)
+        cls[idx, c] = rng.uniform(-1.0, 3.0, 12).astype(np.float32)
+        cls[idx[:3], (c + 1) % nc] = rng.uniform(0.0, 3.0, 3).astype(np.float32)
+        reg[idx] = (0.05 * rng.standard_normal((12, 4))).astype(np.float32)
+    return reg, cls
+
+
+@pytest.mark.parametrize("seed,in_hw,thr,iou,max_det", [(0, (128, 128), 0.05, 0.5, 100), (1, (256, 384), 0.2, 0.5, 100), (2, (128, 256), 0.05, 0.3, 7),
+                                                        (3, (512, 512), 0.3, 0.5, 100), (4, (128, 128), 0.999, 0.5, 100)])
+def test_effdet_tail(seed, in_hw, thr, iou, max_det):
+    """The in-graph tail of EfficientDet (csrc/post_core.h effdet_tail_frame, host build) against the numpy restatement: candidates,
+    order, decoded + clipped boxes, per-class suppression, the max_det cut -- bit for bit."""
+    from oracle import effdet_tail
+    reg, cls = _effdet_heads(seed, in_hw)
+    want = effdet_tail.tail(reg, cls, in_hw, thr, iou, max_det)
+    got = emu_api.effdet_tail(reg, cls, in_hw, thr, iou, max_det, cap=3072)
+    assert got["n_candidates"] == want["n_candidates"] <= 3072
+    if thr < 0.9:
+        assert len(want["conf"]) >= min(max_det, 5) and want["n_candidates"] > len(want["conf"])      # the NMS has something to do
+    else:
+        assert want["n_candidates"] == 0 and len(got["conf"]) == 0
+    np.testing.assert_array_equal(got["class_id"], want["class_id"])
+    np.testing.assert_array_equal(got["conf"], want["conf"])
+    np.testing.assert_array_equal(got["boxes"], want["boxes"])
+
+
+def test_effdet_anchor_table():
+    """oracle.effdet_tail.anchors: counts, order and the D0 geometry the paper states (anchor side 4 x stride x 2^(k/3), three aspect ratios)."""
+    from oracle import effdet_tail
+    a = effdet_tail.anchors(512, 512)
+    assert a.shape == (49104, 4)                                  # 9 * (64^2 + 32^2 + 16^2 + 8^2 + 4^2)
+    np.testing.assert_allclose(a[0], [4 - 16, 4 - 16, 4 + 16, 4 + 16])                 # level 3, cell (0, 0), scale 1, ratio (1, 1): side 32
+    np.testing.assert_allclose(a[1], [4 - 0.7 * 16, 4 - 1.4 * 16, 4 + 0.7 * 16, 4 + 1.4 * 16], rtol=1e-6)
+    np.testing.assert_allclose(a[9], [4 - 16, 12 - 16, 4 + 16, 12 + 16])               # next cell along x
+    last = a[-1]                                                  # level 7, last cell, scale 2^(2/3), ratio (0.7, 1.4)
+    side = 4 * 128 * 2 ** (2 / 3)
+    np.testing.assert_allclose(last, [448 - 1.4 * side / 2, 448 - 0.7 * side / 2, 448 + 1.4 * side / 2, 448 + 0.7 * side / 2], rtol=1e-6)
+
+
+def test_effdet_tail_overflow_is_reported():
+    """More anchors over the score threshold than max_candidates: the count is reported (the C-ABI turns it into ADAS_ERR_CAPACITY), nothing is kept."""
+    reg, cls = _effdet_heads(5, (128, 128), bias=0.0)
+    got = emu_api.effdet_tail(reg, cls, (128, 128), 0.05, 0.5, 100, cap=64)
+    assert got["n_candidates"] > 64 and len(got["conf"]) == 0

@@ -40,6 +40,11 @@ class EffdetPostParams(C.Structure):
                 ("max_boxes", C.c_int32), ("reserved", C.c_int32)]
 
 
+class EffdetTailParams(C.Structure):
+    _fields_ = [("in_h", C.c_int32), ("in_w", C.c_int32), ("num_classes", C.c_int32), ("max_candidates", C.c_int32), ("max_det", C.c_int32),
+                ("reserved", C.c_int32), ("score_thr", C.c_double), ("iou_thr", C.c_double), ("anchor_scale", C.c_double)]
+
+
 class UfldParams(C.Structure):
     _fields_ = [("grid_row", C.c_int32), ("cls_row", C.c_int32), ("grid_col", C.c_int32), ("cls_col", C.c_int32),
                 ("img_w", C.c_int32), ("img_h", C.c_int32), ("local_width", C.c_int32), ("num_lanes", C.c_int32),
@@ -136,6 +141,11 @@ _SIGS = {
     "adas_effdet_post_destroy": (C.c_int, [_P]),
     "adas_effdet_post_run": (C.c_int, [_P, _P, _P, _P, _P, C.c_int, _P]),
     "adas_effdet_post_fetch": (C.c_int, [_P, C.c_int, C.POINTER(C.c_int32), _P, _P, _P, _P]),
+    "adas_effdet_tail_create": (C.c_int, [C.POINTER(EffdetTailParams), C.c_int, C.POINTER(_P)]),
+    "adas_effdet_tail_destroy": (C.c_int, [_P]),
+    "adas_effdet_tail_run": (C.c_int, [_P, _P, _P, C.c_int, _P]),
+    "adas_effdet_tail_fetch": (C.c_int, [_P, C.c_int, C.POINTER(C.c_int32), _P, _P, _P, C.POINTER(C.c_int32)]),
+    "adas_effdet_tail_device_views": (C.c_int, [_P, C.POINTER(_P), C.POINTER(_P), C.POINTER(_P), C.POINTER(_P)]),
     "adas_preprocess_effdet": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, _P, C.c_int, C.c_int, C.c_int, _P]),
     "adas_ufld_decode_create": (C.c_int, [C.POINTER(UfldParams), C.c_int, C.POINTER(_P)]),
     "adas_ufld_decode_destroy": (C.c_int, [_P]),

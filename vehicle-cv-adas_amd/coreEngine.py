@@ -220,6 +220,75 @@ class HipEngine(EngineBase):
             pass
 
 
+class EfficientdetEngine(EngineBase):
+    """The exported EfficientDet-D0 graph the reference hands OnnxEngine (efficientdetDetector.py:38): network + in-graph anchor decode and
+    NMS, three outputs -- boxes (n, 4) xyxy float32 in input pixels, class ids (n), confidences (n), by descending confidence
+    (:68-70).  Here: the "efficientdet-d0" engine graph (models.efficientdet: ten raw head tensors, device-resident) followed by the
+    device tail (postproc.EffdetTail).  engine_inference takes the reference's (1, 3, H, W) tensor; a batch returns per-frame lists."""
+
+    OUTPUT_NAMES = ["boxes", "class_ids", "scores"]
+
+    def __init__(self, model_path, precision=None, max_batch=1, score_thr=0.05, iou_thr=0.5, max_det=100, max_candidates=2048):
+        EngineBase.__init__(self, model_path)
+        try:
+            from .postproc import EffdetTail
+        except ImportError:
+            from postproc import EffdetTail
+        self.net = HipEngine(model_path, precision, max_batch)
+        shapes, names = self.net.get_engine_output_shape()
+        want = [("regression.l%d" % (i // 2)) if i % 2 == 0 else ("classification.l%d" % (i // 2)) for i in range(10)]
+        if names != want:
+            self.net.close()
+            raise Exception("%s is not an EfficientDet head graph (outputs %s)" % (model_path, names))
+        self.num_classes = int(shapes[1][2])
+        shp = self.net.get_engine_input_shape()
+        self.tail = EffdetTail(shp[2:], self.num_classes, score_thr, iou_thr, max_det, max_candidates, max_batch)
+        self.max_det, self.max_batch = int(max_det), int(max_batch)
+        self.precision = self.net.precision
+        self.providers, self.framework_type, self.engine_dtype = self.net.providers, self.net.framework_type, self.net.engine_dtype
+        self._x = None
+
+    def get_engine_input_shape(self):
+        return self.net.get_engine_input_shape()
+
+    def get_engine_output_shape(self):
+        return [[-1, 4], [-1], [-1]], list(self.OUTPUT_NAMES)
+
+    def engine_inference(self, input_tensor):
+        x = np.ascontiguousarray(input_tensor, dtype=np.float32)
+        shp = self.net.get_engine_input_shape()
+        if x.ndim != 4 or list(x.shape[1:]) != shp[1:] or x.shape[0] > self.max_batch:
+            raise Exception("input tensor shape %s does not match the engine input %s (max batch %d)" % (list(x.shape), shp, self.max_batch))
+        batch = x.shape[0]
+        if self._x is None:
+            self._x = L.DeviceBuffer(self.max_batch * int(np.prod(shp[1:])) * 4)
+        self._x.upload(x)
+        self.net.infer_device(self._x.ptr, batch)
+        self.tail.run([self.net.output_device_ptr(2 * l) for l in range(5)], [self.net.output_device_ptr(2 * l + 1) for l in range(5)], batch)
+        res = [self.tail.fetch(b) for b in range(batch)]
+        self.last_candidates = [r["n_candidates"] for r in res]
+        if batch == 1:
+            r = res[0]
+            return [r["boxes"], r["class_id"], r["conf"]]
+        return [[r["boxes"] for r in res], [r["class_id"] for r in res], [r["conf"] for r in res]]
+
+    def close(self):
+        for k in ("tail", "net"):
+            o = getattr(self, k, None)
+            if o is not None:
+                o.close()
+                setattr(self, k, None)
+        if getattr(self, "_x", None) is not None:
+            self._x.free()
+            self._x = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 # Names the reference's detector modules import (yoloDetector.py:12,16; ultrafastLaneDetectorV2.py:7,13)
 OnnxEngine = HipEngine
 TensorRTEngine = HipEngine

@@ -899,4 +899,176 @@ ADAS_DEV void effdet_post_frame(const Ctx& c, const EffdetCfg& cfg, const Effdet
     }
 }
 
+// ===========================================================================
+// EfficientDet in-graph tail: what the exported efficientdet-d0 graph does behind its two head tensors before it hands
+// (boxes, class ids, confidences) to EfficientdetDetector.__process_output (efficientdetDetector.py:67-70).  The reference ships
+// no such graph (it loads an .onnx through onnxruntime): this restates the published post-processing of the architecture
+// (arXiv:1911.09070 section 4 / the public PyTorch implementation's Anchors, BBoxTransform, ClipBoxes and batched NMS):
+//   anchors   pyramid levels 3..7 (strides 8..128), per cell 3 octave scales 2^(k/3) x 3 aspect ratios (1,1), (1.4,0.7), (0.7,1.4),
+//             side = anchor_scale * stride * scale; centre (stride / 2 + i * stride); rows ordered (level, y, x, scale, ratio)
+//   score     sigmoid of the largest class logit (first index on ties), kept when > score_thr
+//   box       (dy, dx, dh, dw) against the anchor: centre = d * size + centre_a, size = exp(d) * size_a; xyxy; clipped to
+//             [0, W - 1] x [0, H - 1]
+//   NMS       greedy by descending score (ties: anchor order), a box suppresses later boxes of the SAME class with IoU > iou_thr;
+//             at most max_det survivors
+// Arithmetic: anchors and results are float32 values, every expression in between is evaluated in double (the convention of this
+// file: decisions do not depend on the host's or the device's float32 libm).
+// ===========================================================================
+struct EffdetTailCfg {
+    int in_h, in_w, nc, cap, max_det;
+    double score_thr, iou_thr, anchor_scale;
+};
+struct EffdetTailFrame {
+    const float* reg[5];   // level l: [cells_l * 9][4]
+    const float* cls[5];   // level l: [cells_l * 9][nc]
+    int* count;            // [2]: survivors, candidates (candidates > cap: overflow, nothing else is written)
+    float* boxes;          // [max_det][4] x1, y1, x2, y2 in input pixels
+    int* ids;              // [max_det]
+    float* confs;          // [max_det]
+};
+struct EffdetTailLds {     // carved from one LDS block of effdet_tail_lds_bytes(cap, nthr)
+    float* score;          // [cap] by candidate (anchor order)
+    int* anchor;           // [cap]
+    int* cid;              // [cap]
+    int* order;            // [cap] candidate index by rank
+    float* box;            // [cap][4] by rank
+    int* supp;             // [cap] by rank
+    int* scan;             // [nthr + 1]
+};
+ADAS_HD size_t effdet_tail_lds_bytes(int cap, int nthr) { return (size_t)cap * (4 + 4 + 4 + 4 + 16 + 4) + ((size_t)nthr + 2) * 4; }
+ADAS_DEV EffdetTailLds effdet_tail_carve(void* lds, int cap) {
+    EffdetTailLds L;
+    unsigned char* q = (unsigned char*)lds;
+    L.box = (float*)q; q += (size_t)cap * 16;
+    L.score = (float*)q; q += (size_t)cap * 4;
+    L.anchor = (int*)q; q += (size_t)cap * 4;
+    L.cid = (int*)q; q += (size_t)cap * 4;
+    L.order = (int*)q; q += (size_t)cap * 4;
+    L.supp = (int*)q; q += (size_t)cap * 4;
+    L.scan = (int*)q;
+    return L;
+}
+// anchor a (global row index) -> level, cell, shape; returns the float32 anchor (y1, x1, y2, x2)
+ADAS_DEV void effdet_anchor(const EffdetTailCfg& cfg, int a, int& level, int& row, float out[4]) {
+    int base = 0;
+    level = 0;
+    for (int l = 0; l < 5; ++l) {
+        const int n = (cfg.in_h >> (3 + l)) * (cfg.in_w >> (3 + l)) * 9;
+        if (a < base + n || l == 4) { level = l; break; }
+        base += n;
+    }
+    row = a - base;
+    const int stride = 8 << level, wl = cfg.in_w >> (3 + level);
+    const int k = row % 9, cell = row / 9;
+    const int y = cell / wl, x = cell - y * wl;
+    const double scales[3] = {1.0, 1.2599210498948732, 1.5874010519681994};   // 2^(0/3), 2^(1/3), 2^(2/3)
+    const double rx[3] = {1.0, 1.4, 0.7}, ry[3] = {1.0, 0.7, 1.4};
+    const double side = cfg.anchor_scale * (double)stride * scales[k / 3];
+    const double ax2 = side * rx[k % 3] / 2.0, ay2 = side * ry[k % 3] / 2.0;
+    const double cy = (double)stride / 2.0 + (double)y * (double)stride, cx = (double)stride / 2.0 + (double)x * (double)stride;
+    out[0] = (float)(cy - ay2); out[1] = (float)(cx - ax2); out[2] = (float)(cy + ay2); out[3] = (float)(cx + ax2);
+}
+ADAS_DEV void effdet_tail_frame(const Ctx& c, const EffdetTailCfg& cfg, const EffdetTailFrame& f, void* lds) {
+    EffdetTailLds L = effdet_tail_carve(lds, cfg.cap);
+    int total = 0;
+    for (int l = 0; l < 5; ++l) total += (cfg.in_h >> (3 + l)) * (cfg.in_w >> (3 + l)) * 9;
+    // ---- candidates in anchor order: chunks of nthr anchors, block-wide exclusive scan of the keep flags
+    int n_cand = 0;
+    for (int a0 = 0; a0 < total; a0 += c.nthr) {
+        const int a = a0 + c.tid;
+        int keep = 0, best_c = 0;
+        float sc = 0.f;
+        if (a < total) {
+            int base = 0, level = 0;
+            for (int l = 0; l < 5; ++l) {
+                const int n = (cfg.in_h >> (3 + l)) * (cfg.in_w >> (3 + l)) * 9;
+                if (a < base + n || l == 4) { level = l; break; }
+                base += n;
+            }
+            const float* p = f.cls[level] + (size_t)(a - base) * cfg.nc;
+            float best = p[0];
+            for (int k = 1; k < cfg.nc; ++k) {
+                const float v = p[k];
+                if (v > best) { best = v; best_c = k; }
+            }
+            sc = (float)(1.0 / (1.0 + exp(-(double)best)));
+            keep = ((double)sc > cfg.score_thr) ? 1 : 0;
+        }
+        L.scan[c.tid + 1] = keep;
+        c.sync();
+        if (c.tid == 0) {
+            L.scan[0] = 0;
+            for (int i = 0; i < c.nthr; ++i) L.scan[i + 1] += L.scan[i];
+        }
+        c.sync();
+        const int pos = n_cand + L.scan[c.tid];
+        if (keep && pos < cfg.cap) {
+            L.score[pos] = sc; L.anchor[pos] = a; L.cid[pos] = best_c;
+        }
+        n_cand += L.scan[c.nthr];
+        c.sync();
+    }
+    if (c.tid == 0) f.count[1] = n_cand;
+    if (n_cand > cfg.cap) {   // overflow: the caller reports ADAS_ERR_CAPACITY
+        if (c.tid == 0) f.count[0] = 0;
+        return;
+    }
+    // ---- rank by (score descending, anchor ascending): candidates are already in anchor order
+    ADAS_PAR_FOR(c, i, 0, n_cand) {
+        const float si = L.score[i];
+        int r = 0;
+        for (int j = 0; j < n_cand; ++j) {
+            const float sj = L.score[j];
+            r += (sj > si || (sj == si && j < i)) ? 1 : 0;
+        }
+        L.order[r] = i;
+    }
+    c.sync();
+    // ---- decode + clip, by rank
+    ADAS_PAR_FOR(c, r, 0, n_cand) {
+        const int i = L.order[r];
+        int level, row;
+        float an[4];
+        effdet_anchor(cfg, L.anchor[i], level, row, an);
+        const float* d = f.reg[level] + (size_t)row * 4;
+        const double ya = ((double)an[0] + (double)an[2]) / 2.0, xa = ((double)an[1] + (double)an[3]) / 2.0;
+        const double ha = (double)an[2] - (double)an[0], wa = (double)an[3] - (double)an[1];
+        const double w = exp((double)d[3]) * wa, h = exp((double)d[2]) * ha;
+        const double yc = (double)d[0] * ha + ya, xc = (double)d[1] * wa + xa;
+        double x1 = xc - w / 2.0, y1 = yc - h / 2.0, x2 = xc + w / 2.0, y2 = yc + h / 2.0;
+        x1 = x1 < 0.0 ? 0.0 : x1; y1 = y1 < 0.0 ? 0.0 : y1;
+        const double xm = (double)(cfg.in_w - 1), ym = (double)(cfg.in_h - 1);
+        x2 = x2 > xm ? xm : x2; y2 = y2 > ym ? ym : y2;
+        L.box[r * 4 + 0] = (float)x1; L.box[r * 4 + 1] = (float)y1; L.box[r * 4 + 2] = (float)x2; L.box[r * 4 + 3] = (float)y2;
+        L.supp[r] = 0;
+    }
+    c.sync();
+    // ---- greedy per-class NMS in rank order
+    int kept = 0;
+    for (int r = 0; r < n_cand && kept < cfg.max_det; ++r) {
+        if (L.supp[r]) continue;   // uniform: every thread reads the same LDS word after the sync below
+        const int i = L.order[r];
+        if (c.tid == 0) {
+            f.boxes[kept * 4 + 0] = L.box[r * 4 + 0]; f.boxes[kept * 4 + 1] = L.box[r * 4 + 1];
+            f.boxes[kept * 4 + 2] = L.box[r * 4 + 2]; f.boxes[kept * 4 + 3] = L.box[r * 4 + 3];
+            f.ids[kept] = L.cid[i];
+            f.confs[kept] = L.score[i];
+        }
+        ++kept;
+        const double ax1 = L.box[r * 4 + 0], ay1 = L.box[r * 4 + 1], ax2 = L.box[r * 4 + 2], ay2 = L.box[r * 4 + 3];
+        const double aarea = (ax2 - ax1) * (ay2 - ay1);
+        const int ci = L.cid[i];
+        ADAS_PAR_FOR(c, q, r + 1, n_cand) {
+            if (L.supp[q] || L.cid[L.order[q]] != ci) continue;
+            const double bx1 = L.box[q * 4 + 0], by1 = L.box[q * 4 + 1], bx2 = L.box[q * 4 + 2], by2 = L.box[q * 4 + 3];
+            const double iw = (ax2 < bx2 ? ax2 : bx2) - (ax1 > bx1 ? ax1 : bx1), ih = (ay2 < by2 ? ay2 : by2) - (ay1 > by1 ? ay1 : by1);
+            const double inter = (iw > 0.0 ? iw : 0.0) * (ih > 0.0 ? ih : 0.0);
+            const double uni = aarea + (bx2 - bx1) * (by2 - by1) - inter;
+            if (inter / uni > cfg.iou_thr) L.supp[q] = 1;
+        }
+        c.sync();
+    }
+    if (c.tid == 0) f.count[0] = kept;
+}
+
 }  // namespace adas

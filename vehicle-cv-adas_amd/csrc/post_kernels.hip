@@ -343,6 +343,35 @@ struct adas_effdet_post {
     void* arena;
     hipStream_t last;
 };
+struct EffdetTailDev {
+    EffdetTailCfg cfg;
+    const float* reg[5];
+    const float* cls[5];
+    size_t rows[5];        // cells_l * 9: frame stride of level l in rows
+    int* count;            // [B][2]
+    float* boxes;          // [B][max_det][4]
+    int* ids;              // [B][max_det]
+    float* confs;          // [B][max_det]
+};
+__global__ __launch_bounds__(1024) void effdet_tail_kernel(EffdetTailDev d) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const size_t b = blockIdx.x, md = d.cfg.max_det;
+    EffdetTailFrame f;
+    for (int l = 0; l < 5; ++l) {
+        f.reg[l] = d.reg[l] + b * d.rows[l] * 4;
+        f.cls[l] = d.cls[l] + b * d.rows[l] * d.cfg.nc;
+    }
+    f.count = d.count + b * 2; f.boxes = d.boxes + b * md * 4; f.ids = d.ids + b * md; f.confs = d.confs + b * md;
+    Ctx c{(int)threadIdx.x, (int)blockDim.x};
+    effdet_tail_frame(c, d.cfg, f, smem);
+}
+struct adas_effdet_tail {
+    adas_effdet_tail_params p;
+    int max_batch;
+    EffdetTailDev dev;
+    void* arena;
+    hipStream_t last;
+};
 struct adas_lane_geometry {
     int max_batch;
     LaneGeomDev dev;
@@ -654,6 +683,86 @@ int adas_effdet_post_fetch(adas_effdet_post* h, int frame, int32_t* n_keep, floa
         if (class_id) ADAS_HIP_TRY(hipMemcpy(class_id, d.cls + b * cap, (size_t)k * 4, hipMemcpyDeviceToHost));
         if (xyxy_int) ADAS_HIP_TRY(hipMemcpy(xyxy_int, d.xyxy_i + b * cap * 4, (size_t)k * 16, hipMemcpyDeviceToHost));
     }
+    return ADAS_OK;
+}
+
+int adas_effdet_tail_create(const adas_effdet_tail_params* p, int max_batch, adas_effdet_tail** out) {
+    ADAS_REQUIRE(p && out && max_batch > 0, ADAS_ERR_INVALID, "adas_effdet_tail_create: bad argument");
+    ADAS_REQUIRE(p->in_h >= 128 && p->in_w >= 128 && p->in_h % 128 == 0 && p->in_w % 128 == 0, ADAS_ERR_INVALID,
+                 "the input size must be a multiple of 128 (five pyramid levels)");
+    ADAS_REQUIRE(p->num_classes >= 1 && p->num_classes <= 4096, ADAS_ERR_INVALID, "num_classes must be in [1, 4096]");
+    ADAS_REQUIRE(p->max_candidates >= 1 && p->max_candidates <= 3072 && p->max_det >= 1 && p->max_det <= p->max_candidates, ADAS_ERR_INVALID,
+                 "max_candidates must be in [1, 3072] and max_det in [1, max_candidates]");
+    ADAS_REQUIRE(p->score_thr >= 0 && p->score_thr < 1 && p->iou_thr > 0 && p->iou_thr <= 1 && p->anchor_scale > 0, ADAS_ERR_INVALID, "bad thresholds");
+    ADAS_REQUIRE(adas_device_count() > 0, ADAS_ERR_NO_DEVICE, "no HIP device visible; this library has no CPU fallback");
+    adas_effdet_tail* h = new (std::nothrow) adas_effdet_tail();
+    ADAS_REQUIRE(h, ADAS_ERR_INVALID, "out of host memory");
+    h->p = *p;
+    h->max_batch = max_batch;
+    h->last = 0;
+    const size_t B = max_batch, md = p->max_det;
+    const size_t bytes = B * (md * (16 + 4 + 4) + 8) + 8 * 256;
+    if (hipMalloc(&h->arena, bytes) != hipSuccess) {
+        delete h;
+        return hip_fail(hipGetLastError(), "hipMalloc(effdet tail arena)", __FILE__, __LINE__);
+    }
+    hipMemset(h->arena, 0, bytes);
+    unsigned char* q = (unsigned char*)h->arena;
+    EffdetTailDev& d = h->dev;
+    d.cfg = EffdetTailCfg{p->in_h, p->in_w, p->num_classes, p->max_candidates, p->max_det, p->score_thr, p->iou_thr, p->anchor_scale};
+    for (int l = 0; l < 5; ++l) d.rows[l] = (size_t)(p->in_h >> (3 + l)) * (size_t)(p->in_w >> (3 + l)) * 9;
+    d.count = carve<int>(q, B * 2);
+    d.boxes = carve<float>(q, B * md * 4);
+    d.ids = carve<int>(q, B * md);
+    d.confs = carve<float>(q, B * md);
+    (void)hipFuncSetAttribute((const void*)effdet_tail_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    *out = h;
+    return ADAS_OK;
+}
+int adas_effdet_tail_destroy(adas_effdet_tail* h) {
+    if (!h) return ADAS_OK;
+    hipFree(h->arena);
+    delete h;
+    return ADAS_OK;
+}
+int adas_effdet_tail_run(adas_effdet_tail* h, const float* const* d_reg, const float* const* d_cls, int batch, void* stream) {
+    ADAS_REQUIRE(h && d_reg && d_cls && batch > 0 && batch <= h->max_batch, ADAS_ERR_INVALID, "adas_effdet_tail_run: bad argument");
+    EffdetTailDev d = h->dev;
+    for (int l = 0; l < 5; ++l) {
+        ADAS_REQUIRE(d_reg[l] && d_cls[l], ADAS_ERR_INVALID, "adas_effdet_tail_run: level %d tensor is null", l);
+        d.reg[l] = d_reg[l]; d.cls[l] = d_cls[l];
+    }
+    hipStream_t st = (hipStream_t)stream;
+    h->last = st;
+    const size_t lds = effdet_tail_lds_bytes(h->p.max_candidates, 1024);
+    hipLaunchKernelGGL(effdet_tail_kernel, dim3(batch), dim3(1024), lds, st, d);
+    ADAS_HIP_TRY(hipGetLastError());
+    return ADAS_OK;
+}
+int adas_effdet_tail_fetch(adas_effdet_tail* h, int frame, int32_t* n_det, float* boxes_xyxy, int32_t* class_id, float* conf, int32_t* n_candidates) {
+    ADAS_REQUIRE(h && n_det && frame >= 0 && frame < h->max_batch, ADAS_ERR_INVALID, "adas_effdet_tail_fetch: bad argument");
+    ADAS_HIP_TRY(hipStreamSynchronize(h->last));
+    const EffdetTailDev& d = h->dev;
+    const size_t md = h->p.max_det, b = frame;
+    int cnt[2] = {0, 0};
+    ADAS_HIP_TRY(hipMemcpy(cnt, d.count + b * 2, 8, hipMemcpyDeviceToHost));
+    if (n_candidates) *n_candidates = cnt[1];
+    ADAS_REQUIRE(cnt[1] <= h->p.max_candidates, ADAS_ERR_CAPACITY, "frame %d: %d anchors over score_thr, max_candidates is %d", frame, cnt[1],
+                 h->p.max_candidates);
+    *n_det = cnt[0];
+    if (cnt[0] > 0) {
+        if (boxes_xyxy) ADAS_HIP_TRY(hipMemcpy(boxes_xyxy, d.boxes + b * md * 4, (size_t)cnt[0] * 16, hipMemcpyDeviceToHost));
+        if (class_id) ADAS_HIP_TRY(hipMemcpy(class_id, d.ids + b * md, (size_t)cnt[0] * 4, hipMemcpyDeviceToHost));
+        if (conf) ADAS_HIP_TRY(hipMemcpy(conf, d.confs + b * md, (size_t)cnt[0] * 4, hipMemcpyDeviceToHost));
+    }
+    return ADAS_OK;
+}
+int adas_effdet_tail_device_views(adas_effdet_tail* h, const float** d_boxes, const int32_t** d_ids, const float** d_confs, const int32_t** d_counts) {
+    ADAS_REQUIRE(h, ADAS_ERR_INVALID, "adas_effdet_tail_device_views: bad argument");
+    if (d_boxes) *d_boxes = h->dev.boxes;
+    if (d_ids) *d_ids = h->dev.ids;
+    if (d_confs) *d_confs = h->dev.confs;
+    if (d_counts) *d_counts = h->dev.count;
     return ADAS_OK;
 }
 

@@ -26,7 +26,7 @@ from typing import Any, Dict, List, Tuple
 import numpy as np
 
 from . import _lib as L
-from .coreEngine import OnnxEngine, TensorRTEngine
+from .coreEngine import OnnxEngine, TensorRTEngine, EfficientdetEngine
 from .postproc import YoloPost, EffdetPost, UfldDecode, Ufld1Decode, LaneGeometry, DeviceTracker, letterbox
 
 
@@ -245,10 +245,11 @@ class YoloDetector(_Defaults):
 class EfficientdetDetector(_Defaults):
     """efficientdetDetector.py:18-111.  The exported EfficientDet graph carries its own decode + NMS; around it the reference does
     letterbox + BGR mean/std normalisation (:57-65) and inverse letterbox + score filter + label lookup (:67-85).  Both run on the
-    device here (adas_preprocess_effdet, adas_effdet_post_*).  HipEngine builds YOLO / UFLD graphs only (depth-wise convs, BiFPN and
-    the in-graph NMS of EfficientDet have no kernels): pass `engine=` -- any object with the EngineBase surface
-    (get_engine_input_shape / get_engine_output_shape / engine_inference / engine_dtype) -- or a model path HipEngine can load;
-    an EfficientDet .onnx fails loudly in onnx_import.detect_arch."""
+    device here (adas_preprocess_effdet, adas_effdet_post_*).  The graph itself is coreEngine.EfficientdetEngine: the EfficientDet-D0
+    network (models.efficientdet: EfficientNet-B0 MBConv + squeeze-and-excitation, BiFPN, separable-conv heads) and the in-graph tail
+    (anchor decode + per-class NMS, adas_effdet_tail_*) on the device -- `model_path` is an "efficientdet-d0" .hipm container; or pass
+    `engine=`, any object with the EngineBase surface (get_engine_input_shape / get_engine_output_shape / engine_inference /
+    engine_dtype).  An EfficientDet .onnx with its NMS baked in is not importable (onnx_import fails loudly)."""
     _defaults = {
         "model_path": './models/efficientdet-d0-coco_fp32.onnx',
         "model_type": ObjectModelType.EfficientDet,
@@ -265,7 +266,7 @@ class EfficientdetDetector(_Defaults):
         assert os.path.isfile(classes_path), Exception("%s is not exist." % classes_path)
         with open(classes_path) as f:
             self.class_names = [c.strip() for c in f.readlines()]
-        self.engine = engine if engine is not None else OnnxEngine(os.path.expanduser(self.model_path))
+        self.engine = engine if engine is not None else EfficientdetEngine(os.path.expanduser(self.model_path), precision=getattr(self, "precision", None))
         self.input_shapes = self.engine.get_engine_input_shape()                 # core.py:73-82
         self.input_types = self.engine.engine_dtype
         self.channes, self.input_height, self.input_width = self.input_shapes[1:]

@@ -83,6 +83,40 @@ class YoloPost:
     __del__ = close
 
 
+class EffdetTail:
+    """The in-graph tail of the exported EfficientDet-D0 (adas_effdet_tail_*): anchor decode + score threshold + per-class NMS over the ten
+    raw head tensors of the "efficientdet-d0" engine graph -> (boxes xyxy float32, class ids, confidences) per frame, the three arrays
+    EfficientdetDetector.__process_output reads (efficientdetDetector.py:68-70)."""
+
+    def __init__(self, in_hw, num_classes=90, score_thr=0.05, iou_thr=0.5, max_det=100, max_candidates=2048, max_batch=1, anchor_scale=4.0):
+        p = L.EffdetTailParams(int(in_hw[0]), int(in_hw[1]), int(num_classes), int(max_candidates), int(max_det), 0, float(score_thr), float(iou_thr),
+                               float(anchor_scale))
+        self.max_det, self.max_batch = int(max_det), int(max_batch)
+        h = C.c_void_p()
+        L.check(L.lib().adas_effdet_tail_create(C.byref(p), max_batch, C.byref(h)))
+        self.h = h.value
+
+    def run(self, reg_ptrs, cls_ptrs, batch, stream=None):
+        """reg_ptrs / cls_ptrs: five device pointers each (pyramid levels 3..7), [batch][cells * 9][4 | num_classes] float32."""
+        reg = (C.c_void_p * 5)(*[int(p) for p in reg_ptrs])
+        cls = (C.c_void_p * 5)(*[int(p) for p in cls_ptrs])
+        L.check(L.lib().adas_effdet_tail_run(self.h, reg, cls, int(batch), stream))
+
+    def fetch(self, frame=0):
+        n, nc = C.c_int32(), C.c_int32()
+        boxes = np.zeros((self.max_det, 4), np.float32); ids = np.zeros(self.max_det, np.int32); conf = np.zeros(self.max_det, np.float32)
+        L.check(L.lib().adas_effdet_tail_fetch(self.h, frame, C.byref(n), L.ptr(boxes), L.ptr(ids), L.ptr(conf), C.byref(nc)))
+        k = n.value
+        return dict(boxes=boxes[:k].copy(), class_id=ids[:k].astype(np.int64), conf=conf[:k].copy(), n_candidates=nc.value)
+
+    def close(self):
+        if getattr(self, "h", None):
+            L.lib().adas_effdet_tail_destroy(self.h)
+            self.h = None
+
+    __del__ = close
+
+
 class EffdetPost:
     """EfficientdetDetector.__process_output on the device (adas_effdet_post_*): inverse letterbox in float32 + `conf < box_score`
     filter over the exported graph's (boxes, ids, confs) outputs."""
