@@ -403,14 +403,20 @@ def measure_post_hbm(L, pipe, gd, gl, S, layer_ms, precision):
         head_bytes = S * ((5 if v5 else 4) + nc) * A * 4
         ms2 = (C.c_float * 2)()
         L.check(L.lib().adas_yolo_post_profile(pipe.post.h, pipe.det.output_device_ptr(0), S, 20, ms2))
-        row("yolo_scan_v5" if v5 else "yolo_scan_v8", head_bytes + S * A * 8, float(ms2[0]), "head tensor read once + per-anchor best (conf, class) written")
+        sink = bool(L.lib().adas_pipeline_detect_sink(pipe.h))
+        row("yolo_scan_v5" if v5 else "yolo_scan_v8", head_bytes + S * A * 8, float(ms2[0]),
+            "head tensor read once + per-anchor best (conf, class) written" +
+            (" -- stand-alone API only: this pipeline's steps take the per-anchor maxima from detect_v8_fused's registers (no scan launch, no class rows)" if sink else ""))
         out.append({"kernel": "yolo_post_kernel", "us": round(float(ms2[1]) * 1e3, 2), "bound": "latency",
                     "what": "compaction + inverse letterbox + sequential fp64 NMS + RectInfo, one workgroup per frame"})
         for name, (ms, label) in layer_ms.items():
             if label == "detect_v8_fused_kernel":
                 det_ops = {o["name"]: o for o in gd.ops}
                 hid = sum(o["ins"][0].h * o["ins"][0].w * o["ins"][0].c for nm, o in det_ops.items() if nm.endswith(".2") and ".cv" in nm)
-                row(label, S * (hid * esz + (4 + nc) * A * 4), ms, "hidden activations of both Detect branches in, fp32 (4+nc, A) head out")
+                row(label, S * (hid * esz + (4 + nc) * A * 4), ms, "hidden activations of both Detect branches in, fp32 (4+nc, A) head out (eager per-layer pass: whole head)")
+                if sink:
+                    out.append({"kernel": label + " (in the step)", "bytes": int(S * (hid * esz + 4 * A * 4 + A * 8)),
+                                "what": "pipeline steps: hidden activations in, the four box rows + per-anchor (best probability, class) out; timed inside stages.det_net_ms"})
             if label == "fc_kernel" and name == "cls.3":
                 o = [q for q in gl.ops if q["name"] == "cls.3"][0]
                 cin, cout = o["ins"][0].c, o["out"].c

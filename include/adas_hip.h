@@ -99,6 +99,13 @@ int adas_engine_stats(const adas_engine* e, double* flops_per_frame, double* wei
 /* Per-layer device timing of the last adas_engine_profile() call (hipEvents on the engine stream). */
 int adas_engine_profile(adas_engine* e, const float* d_input_nchw, int batch, int iters, float* ms_per_layer,
                         int max_layers, int* num_layers);
+/* Pipeline-internal fast path of a v8-layout detector whose Detect head runs as the fused kernel (16-bit precisions): while a sink is
+ * set, inference writes per anchor the best class probability and its first arg-max class ([batch][num_anchors] each) plus the four
+ * box rows of the head, and NOT the head's class rows -- exactly what adas_yolo_post_run derives from them (yoloDetector.py:120-127).
+ * Pass the arrays of adas_yolo_post_scan_views and run adas_yolo_post_run_prescanned afterwards; pass NULL, NULL to restore the full
+ * head.  adas_pipeline_* does this around its own detector launches; engine_inference callers never see it. */
+int adas_engine_detect_sink_supported(const adas_engine* e);
+int adas_engine_set_detect_sink(adas_engine* e, float* d_best_conf, int32_t* d_best_cls);
 int adas_engine_layer_info(const adas_engine* e, int layer, char* name, int name_cap, double* flops, int* kind);
 /* Which kernel instantiation layer `layer` launches at `batch` frames (matches the rocprofv3 kernel name). */
 int adas_engine_layer_kernel(const adas_engine* e, int layer, int batch, char* name, int name_cap);
@@ -171,6 +178,10 @@ int adas_yolo_post_run(adas_yolo_post* h, const float* d_head, int batch, void* 
 /* The same two launches `iters` times on the null stream with events between them: ms[0] = the head scan (per-anchor best class,
  * HBM-bound: the whole head tensor is read once), ms[1] = candidate compaction + inverse letterbox + NMS + RectInfo (latency-bound),
  * averaged per run.  Measurement only (bench.py `post_hbm`). */
+/* The post-processing without its class scan: per-anchor (best probability, class) were written into the arrays of
+ * adas_yolo_post_scan_views by the producer of the head (adas_engine_set_detect_sink); d_head supplies the box rows. */
+int adas_yolo_post_scan_views(adas_yolo_post* h, float** d_best_conf, int32_t** d_best_cls);
+int adas_yolo_post_run_prescanned(adas_yolo_post* h, const float* d_head, int batch, void* stream);
 int adas_yolo_post_profile(adas_yolo_post* h, const float* d_head, int batch, int iters, float ms[2]);
 
 typedef struct {
@@ -410,6 +421,8 @@ typedef struct {
     int32_t reserved;
 } adas_pipeline_desc;
 int adas_pipeline_create(const adas_pipeline_desc* d, adas_pipeline** out);
+/* 1 when the steps feed the post-processing's per-anchor scan arrays from the fused Detect kernel (adas_engine_set_detect_sink). */
+int adas_pipeline_detect_sink(const adas_pipeline* p);
 int adas_pipeline_destroy(adas_pipeline* p);
 /* One step = one frame of every stream (micro_batch frames with temporal micro-batching).  Asynchronous; adas_pipeline_sync() waits. */
 int adas_pipeline_step(adas_pipeline* p, const float* d_det_input_nchw, const float* d_lane_input_nchw);

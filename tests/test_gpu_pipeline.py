@@ -33,6 +33,9 @@ def test_pipeline_equals_components(tmp_path, use_graph, overlap):
     pipe = PL.AdasPipeline(det_path, lane_path, n_streams=S, precision="bf16", src_hw=(720, 1280), use_graph=use_graph,
                            max_candidates=512, lane_cfg=LANE_CFG, overlap=overlap, geometry=dict(bird_wh=(1280, 720), M=Mh))
     geo = PP.LaneGeometry(720, (1280, 720), Mh, True, S)
+    # the step feeds the post-processing's per-anchor (best probability, class) arrays from the fused Detect kernel's registers and never
+    # writes the head's class rows; the component path below writes the whole head and scans it: same candidates, bit for bit
+    assert L.lib().adas_pipeline_detect_sink(pipe.h) == 1
     d_det = [L.DeviceBuffer.from_array(f) for f in frames]
     d_lane = [L.DeviceBuffer.from_array(f) for f in lanes_in]
 
@@ -198,3 +201,38 @@ def test_changed_crop_ratio_or_config_recaptures_the_graph(tmp_path):
         seen.append(pg.decode.fetch(0))
     assert seen[0] == seen[2]
     pg.close(); pe.close(); dc.free()
+
+
+def test_detect_sink_off_gives_the_same_step(tmp_path, monkeypatch):
+    """ADAS_NO_DETECT_SINK=1 (full head + class scan inside the step) against the default (per-anchor maxima straight from the Detect
+    kernel): identical candidates, survivors and tracks; a detector engine keeps returning the whole head to engine_inference callers."""
+    import bench
+    S = 2
+    cam = [bench.cam_frames(S, 90 + i) for i in range(2)]
+    seam = np.concatenate([importlib.import_module("oracle.preprocess").yolo_prepare_input(f, (640, 640)) for f in cam[0]])
+    det_path, _, _ = bench.build_detector(M, CE, "yolov8n", seam, str(tmp_path), "sink", target_per_frame=60.0)
+    lane_path, _, _ = netutil.model("ufldv2_res18")
+    pa = PL.AdasPipeline(det_path, lane_path, n_streams=S, precision="fp16", src_hw=(720, 1280), use_graph=True)
+    monkeypatch.setenv("ADAS_NO_DETECT_SINK", "1")
+    pb = PL.AdasPipeline(det_path, lane_path, n_streams=S, precision="fp16", src_hw=(720, 1280), use_graph=True)
+    monkeypatch.delenv("ADAS_NO_DETECT_SINK")
+    assert L.lib().adas_pipeline_detect_sink(pa.h) == 1 and L.lib().adas_pipeline_detect_sink(pb.h) == 0
+    n = 0
+    for k in (0, 1, 1, 0):
+        dc = L.DeviceBuffer.from_array(cam[k])
+        pa.step_frames(dc.ptr, (720, 1280), 0.6); pa.sync()
+        pb.step_frames(dc.ptr, (720, 1280), 0.6); pb.sync()
+        for s in range(S):
+            a, b = PP.YoloPost.fetch(pa.post, s), PP.YoloPost.fetch(pb.post, s)
+            for key in ("cand_anchor", "cand_conf", "cand_cls", "cand_xywh", "keep", "xywh", "conf", "class_id", "xyxy_int"):
+                np.testing.assert_array_equal(a[key], b[key], err_msg=key)
+            n += len(a["cand_anchor"])
+            pc.check_track_frame(gpu_api.track_snapshot(*pa.tracker.fetch(s)), gpu_api.track_snapshot(*pb.tracker.fetch(s)), ctx=(k, s))
+        dc.free()
+    assert n > 50
+    # the engine inside the sink pipeline still hands the whole head to a host caller (the sink is set only around the step's launches)
+    x = seam[:S].astype(np.float32)
+    ha, hb = pa.det.engine_inference(x)[0], pb.det.engine_inference(x)[0]
+    np.testing.assert_array_equal(ha, hb)
+    assert float(np.abs(ha[:, 4:]).max()) > 0.0
+    pa.close(); pb.close()

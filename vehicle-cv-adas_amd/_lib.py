@@ -135,6 +135,11 @@ _SIGS = {
     "adas_yolo_post_profile": (C.c_int, [_P, _P, C.c_int, C.c_int, C.POINTER(C.c_float)]),
     "adas_yolo_post_fetch": (C.c_int, [_P, C.c_int, C.POINTER(YoloCounts)] + [_P] * 9),
     "adas_yolo_post_device_views": (C.c_int, [_P] + [C.POINTER(_P)] * 4),
+    "adas_yolo_post_scan_views": (C.c_int, [_P, C.POINTER(_P), C.POINTER(_P)]),
+    "adas_yolo_post_run_prescanned": (C.c_int, [_P, _P, C.c_int, _P]),
+    "adas_engine_detect_sink_supported": (C.c_int, [_P]),
+    "adas_engine_set_detect_sink": (C.c_int, [_P, _P, _P]),
+    "adas_pipeline_detect_sink": (C.c_int, [_P]),
     "adas_yolo_post_capacity": (C.c_int, [_P, C.POINTER(C.c_int)]),
     "adas_yolo_post_head_shape": (C.c_int, [_P, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "adas_effdet_post_create": (C.c_int, [C.POINTER(EffdetPostParams), C.c_int, C.POINTER(_P)]),

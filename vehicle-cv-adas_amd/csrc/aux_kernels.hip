@@ -581,11 +581,17 @@ struct DetFuseDev {
     int hw[3], w[3], stride[3], a_off[3];
     float* out;
     int nc, A, n;
+    float* sink_conf;       // SINK: per-anchor best class probability / first arg-max class ([n][A] each), written instead of the class rows
+    int* sink_cls;
 };
 
 __device__ __forceinline__ float detf_quad(float v, int m) { return __shfl_xor(v, m, 64); }
 
-template <typename E>
+// SINK (pipeline steps): the consumer is the post-processing, which reads the four box rows of candidate anchors and, per anchor, the
+// best class probability and its first arg-max (yoloDetector.py:120-127) -- what yolo_scan_v8 derives from the 80 class rows.  The
+// probabilities are in this kernel's registers: the per-anchor maximum is taken here (same float values, same first-maximum rule) and the
+// class rows (181 MB per 64 frames, written here and read back by the scan) never exist.
+template <typename E, bool SINK>
 __global__ __launch_bounds__(256) void detect_v8_fused_kernel(DetFuseDev d) {
     extern __shared__ __attribute__((aligned(16))) uint16_t wl[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lrow = lane & 15, kg = lane >> 4;
@@ -662,6 +668,8 @@ __global__ __launch_bounds__(256) void detect_v8_fused_kernel(DetFuseDev d) {
             xc[ks] = du32x4{0u, 0u, 0u, 0u};
             if (ks < KSc && ok && ks * 32 + kg * 8 < d.cc) xc[ks] = *reinterpret_cast<const du32x4*>(ip + ks * 32);
         }
+        float bv = 0.f;
+        int bi = -1;
         for (int nt = 0; nt < NTc; ++nt) {
             df32x4 acc = df32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -674,7 +682,34 @@ __global__ __launch_bounds__(256) void detect_v8_fused_kernel(DetFuseDev d) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int c = nt * 16 + kg * 4 + r;
-                if (ok && c < d.nc) out[(size_t)(4 + c) * d.A + p] = 1.0f / (1.0f + expf(-(acc[r] + bias[64 + c])));
+                if (SINK) {
+                    if (c < d.nc) {
+                        const float v = 1.0f / (1.0f + expf(-(acc[r] + bias[64 + c])));
+                        if (bi < 0 || v > bv) {   // classes ascend within a lane: strict > keeps the first maximum
+                            bv = v;
+                            bi = c;
+                        }
+                    }
+                } else if (ok && c < d.nc) {
+                    out[(size_t)(4 + c) * d.A + p] = 1.0f / (1.0f + expf(-(acc[r] + bias[64 + c])));
+                }
+            }
+        }
+        if (SINK) {
+            // the four lanes of a pixel (kg = 0..3) hold interleaved class quads: larger value wins, equal values -> smaller class
+#pragma unroll
+            for (int m = 16; m <= 32; m <<= 1) {
+                const float ov = __shfl_xor(bv, m, 64);
+                const int oi = __shfl_xor(bi, m, 64);
+                if (oi >= 0 && (bi < 0 || ov > bv || (ov == bv && oi < bi))) {
+                    bv = ov;
+                    bi = oi;
+                }
+            }
+            if (ok && kg == 0) {
+                const size_t o = (size_t)b * d.A + d.a_off[lvl] + p;
+                d.sink_conf[o] = bv;
+                d.sink_cls[o] = bi < 0 ? 0 : bi;
             }
         }
     }
@@ -682,7 +717,7 @@ __global__ __launch_bounds__(256) void detect_v8_fused_kernel(DetFuseDev d) {
 
 // hidden[2l] / hidden[2l+1]: inputs of cv2.l.2 / cv3.l.2; wfrag/bias: their packed (CONV_PW order) weights and biases
 hipError_t launch_detect_v8_fused(const TView* hidden, const void* const* wfrag, const float* const* bias, float* out, int n, int nc, int A,
-                                  const int strides[3], int prec, hipStream_t st_) {
+                                  const int strides[3], int prec, hipStream_t st_, float* sink_conf, int* sink_cls) {
     DetFuseDev d;
     int off = 0, blocks = 0;
     d.cb = hidden[0].c; d.cc = hidden[1].c;
@@ -701,16 +736,22 @@ hipError_t launch_detect_v8_fused(const TView* hidden, const void* const* wfrag,
     }
     if (off != A || (d.cc + 31) / 32 > ADAS_DETF_MAXKS) return hipErrorInvalidValue;
     d.out = out; d.nc = nc; d.A = A; d.n = n;
+    d.sink_conf = sink_conf; d.sink_cls = sink_cls;
     const int KSb = (d.cb + 31) / 32, KSc = (d.cc + 31) / 32, NTc = (nc + 15) / 16;
     const size_t lds = ((size_t)4 * KSb + (size_t)NTc * KSc) * 1024 + (64 + (size_t)NTc * 16) * 4;
     static bool attr_done = false;
     if (!attr_done) {
-        (void)hipFuncSetAttribute((const void*)detect_v8_fused_kernel<Bf16>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-        (void)hipFuncSetAttribute((const void*)detect_v8_fused_kernel<Fp16>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+        (void)hipFuncSetAttribute((const void*)detect_v8_fused_kernel<Bf16, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+        (void)hipFuncSetAttribute((const void*)detect_v8_fused_kernel<Fp16, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+        (void)hipFuncSetAttribute((const void*)detect_v8_fused_kernel<Bf16, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+        (void)hipFuncSetAttribute((const void*)detect_v8_fused_kernel<Fp16, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
         attr_done = true;
     }
     if (lds > 150 * 1024) return hipErrorNotSupported;
-    ADAS_DISPATCH_E16(prec == PREC_FP16, E, hipLaunchKernelGGL(detect_v8_fused_kernel<E>, dim3(blocks, n), dim3(256), lds, st_, d));
+    if (sink_conf && sink_cls)
+        ADAS_DISPATCH_E16(prec == PREC_FP16, E, hipLaunchKernelGGL((detect_v8_fused_kernel<E, true>), dim3(blocks, n), dim3(256), lds, st_, d));
+    else
+        ADAS_DISPATCH_E16(prec == PREC_FP16, E, hipLaunchKernelGGL((detect_v8_fused_kernel<E, false>), dim3(blocks, n), dim3(256), lds, st_, d));
     return hipGetLastError();
 }
 

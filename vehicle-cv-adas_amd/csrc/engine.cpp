@@ -801,6 +801,20 @@ int adas_engine_layer_kernel(const adas_engine* e, int layer, int batch, char* n
     }
     return ADAS_OK;
 }
+int adas_engine_detect_sink_supported(const adas_engine* e) {
+    if (!e) return 0;
+    for (auto& op : e->ops)
+        if (op.f.type == OP_DETECT_V8 && op.det_src[0] >= 0) return 1;
+    return 0;
+}
+int adas_engine_set_detect_sink(adas_engine* e, float* d_best_conf, int32_t* d_best_cls) {
+    ADAS_REQUIRE(e && ((d_best_conf == nullptr) == (d_best_cls == nullptr)), ADAS_ERR_INVALID, "adas_engine_set_detect_sink: bad argument");
+    ADAS_REQUIRE(!d_best_conf || adas_engine_detect_sink_supported(e), ADAS_ERR_INVALID,
+                 "this engine's Detect is not the fused v8 kernel (16-bit precisions, six 1x1 head convs folded): it has no per-anchor sink");
+    e->sink_conf = d_best_conf;
+    e->sink_cls = d_best_cls;
+    return ADAS_OK;
+}
 int adas_engine_layer_info(const adas_engine* e, int layer, char* name, int cap, double* flops, int* kind) {
     ADAS_REQUIRE(e && layer >= 0 && layer < (int)e->ops.size(), ADAS_ERR_INVALID, "bad layer index");
     if (name && cap > 0) snprintf(name, cap, "%s", e->ops[layer].name.c_str());
@@ -931,7 +945,7 @@ int engine_run_op(adas_engine* e, int i, const float* d_in, int batch, hipStream
                     wf[k] = wb + c.w_off;
                     bs[k] = (const float*)(wb + c.b_off);
                 }
-                err = launch_detect_v8_fused(ins, wf, bs, (float*)e->bufs[o.out_buf].d, batch, (int)o.params[0], (int)o.params[1], strides, e->prec, st);
+                err = launch_detect_v8_fused(ins, wf, bs, (float*)e->bufs[o.out_buf].d, batch, (int)o.params[0], (int)o.params[1], strides, e->prec, st, e->sink_conf, e->sink_cls);
                 break;
             }
             for (int k = 0; k < 6; ++k) ins[k] = make_view(e, o.in_buf[k], o.in_coff[k], o.in_c[k]);

@@ -98,4 +98,6 @@ struct adas_engine {
     size_t weight_bytes = 0, act_bytes = 0;
     std::vector<hipEvent_t> events;
     hipStream_t last = 0;
+    float* sink_conf = nullptr;   // adas_engine_set_detect_sink: the fused v8 Detect writes per-anchor (best probability, class) here
+    int* sink_cls = nullptr;      // instead of the head's class rows (pipeline steps)
 };

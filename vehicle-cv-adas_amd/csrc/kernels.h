@@ -129,7 +129,7 @@ hipError_t launch_sppf_pool3(const TView& in, const TView out[3], int n, int pre
 // YOLOv8 Detect decode: ins = {box0, cls0, box1, cls1, box2, cls2} fp32 logits NHWC; out fp32 [n][4+nc][A]
 hipError_t launch_detect_v8(const TView* ins, float* out, int n, int nc, int A, const int strides[3], hipStream_t st);
 hipError_t launch_detect_v8_fused(const TView* hidden, const void* const* wfrag, const float* const* bias, float* out, int n, int nc, int A,
-                                  const int strides[3], int prec, hipStream_t st);
+                                  const int strides[3], int prec, hipStream_t st, float* sink_conf = nullptr, int* sink_cls = nullptr);
 // YOLOv5 Detect decode: ins = 3 fp32 maps [n][ny][nx][3*(5+nc)]; out fp32 [n][A][5+nc]; anchors[18] device
 bool det5_applicable(int prec, int nc, const TView& in, const TView& logits);
 size_t det5_weight_bytes(int no, int cin);

@@ -2,6 +2,7 @@
 // n_streams independent video streams, optionally replayed from a hipGraph.
 // Mirrors what demo.py:261-281 drives per frame, minus UI; nothing returns to the host per step.
 #include "engine.h"
+#include <stdlib.h>
 
 struct adas_yolo_post;
 struct adas_ufld_decode;
@@ -32,6 +33,7 @@ struct adas_pipeline {
     unsigned long long graphs_gen = 0;       // config generation the cached captures were recorded under
     hipEvent_t ev[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     bool timed = false;
+    bool sink = false;   // the detector's fused v8 Detect feeds the post-processing's scan arrays directly (decided at create)
     // step_frames: u8 camera frames in, the engine-seam tensors live here
     float* det_in = nullptr;
     float* lane_in = nullptr;
@@ -89,10 +91,22 @@ static int record_step(adas_pipeline* p, const float* d_det, const float* d_lane
     }
     const bool packed_now = p->fsrc.frames && p->packed;
     if (p->d.detector) {
+        // fused v8 Detect: per-anchor (best probability, class) come straight out of its registers into the post-processing's scan arrays;
+        // the head's class rows are not written and the scan launch goes away (ADAS_NO_DETECT_SINK=1: the full head + scan)
+        float* sc_conf = nullptr;
+        int32_t* sc_cls = nullptr;
+        if (p->sink) {
+            rc = adas_yolo_post_scan_views(p->d.post, &sc_conf, &sc_cls);
+            if (rc) return rc;
+            rc = adas_engine_set_detect_sink(p->d.detector, sc_conf, sc_cls);
+            if (rc) return rc;
+        }
         rc = packed_now ? adas_engine_infer_device_packed(p->d.detector, (const uint16_t*)d_det, S, st) : adas_engine_infer_device(p->d.detector, d_det, S, st);
+        if (p->sink) (void)adas_engine_set_detect_sink(p->d.detector, nullptr, nullptr);   // launches are enqueued (or captured) with the sink baked in
         if (rc) return rc;
         if (events) ADAS_HIP_TRY(hipEventRecord(p->ev[1], st));
-        rc = adas_yolo_post_run(p->d.post, adas_engine_output_device(p->d.detector, 0), S, st);
+        rc = p->sink ? adas_yolo_post_run_prescanned(p->d.post, adas_engine_output_device(p->d.detector, 0), S, st)
+                     : adas_yolo_post_run(p->d.post, adas_engine_output_device(p->d.detector, 0), S, st);
         if (rc) return rc;
     } else if (events) ADAS_HIP_TRY(hipEventRecord(p->ev[1], st));
     if (events) ADAS_HIP_TRY(hipEventRecord(p->ev[2], st));
@@ -208,9 +222,16 @@ int adas_pipeline_create(const adas_pipeline_desc* d, adas_pipeline** out) {
         adas_pipeline_destroy(p);
         return hip_fail(hipGetLastError(), "hipEventCreate", __FILE__, __LINE__);
     }
+    if (d->detector && d->post) {
+        int32_t layout = -1;
+        const char* env = getenv("ADAS_NO_DETECT_SINK");
+        (void)adas_yolo_post_head_shape(d->post, &layout, nullptr, nullptr);
+        p->sink = layout == ADAS_HEAD_V8 && adas_engine_detect_sink_supported(d->detector) && !(env && env[0] == '1');
+    }
     *out = p;
     return ADAS_OK;
 }
+int adas_pipeline_detect_sink(const adas_pipeline* p) { return p && p->sink ? 1 : 0; }
 
 int adas_pipeline_destroy(adas_pipeline* p) {
     if (!p) return ADAS_OK;

@@ -506,6 +506,29 @@ int adas_yolo_post_set_input_size(adas_yolo_post* h, int in_h, int in_w) {
     return ADAS_OK;
 }
 
+int adas_yolo_post_scan_views(adas_yolo_post* h, float** d_best_conf, int32_t** d_best_cls) {
+    ADAS_REQUIRE(h && d_best_conf && d_best_cls, ADAS_ERR_INVALID, "adas_yolo_post_scan_views: bad argument");
+    *d_best_conf = h->dev.best_conf;
+    *d_best_cls = h->dev.best_cls;
+    return ADAS_OK;
+}
+int adas_yolo_post_run_prescanned(adas_yolo_post* h, const float* d_head, int batch, void* stream) {
+    ADAS_REQUIRE(h && d_head && batch > 0 && batch <= h->max_batch, ADAS_ERR_INVALID, "adas_yolo_post_run_prescanned: bad argument (batch %d, max %d)", batch,
+                 h ? h->max_batch : 0);
+    ADAS_REQUIRE(h->p.layout == ADAS_HEAD_V8, ADAS_ERR_INVALID, "adas_yolo_post_run_prescanned: v8-layout heads only");
+    hipStream_t st = (hipStream_t)stream;
+    h->last = st;
+    YoloPostDev d = h->dev;
+    d.head = d_head;
+    if (d.spill) {
+        hipLaunchKernelGGL(yolo_post_kernel<true>, dim3(batch), dim3(256), 0, st, d);
+    } else {
+        size_t lds = YoloLds::bytes(h->p.max_candidates, 256);
+        hipLaunchKernelGGL(yolo_post_kernel<false>, dim3(batch), dim3(256), lds, st, d);
+    }
+    ADAS_HIP_TRY(hipGetLastError());
+    return ADAS_OK;
+}
 int adas_yolo_post_run(adas_yolo_post* h, const float* d_head, int batch, void* stream) {
     ADAS_REQUIRE(h && d_head && batch > 0 && batch <= h->max_batch, ADAS_ERR_INVALID, "adas_yolo_post_run: bad argument (batch %d, max %d)", batch, h ? h->max_batch : 0);
     ADAS_REQUIRE(h->p.layout != ADAS_HEAD_V5_LITE || h->dev.cfg.in_h > 0, ADAS_ERR_INVALID,
