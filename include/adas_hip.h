@@ -391,6 +391,12 @@ int adas_bytetrack_update_device(adas_bytetrack* h, const double* d_xyxy, const 
 int adas_bytetrack_update_device_frames(adas_bytetrack* h, const double* d_xyxy, const double* d_scores,
                                         const int32_t* d_cls, const int32_t* d_counts, int det_stride, int count_stride,
                                         int count_index, int n_streams, int n_frames, void* stream);
+/* Sizes the per-frame message store of adas_bytetrack_update_device_frames ahead of time (needed before such a launch is captured into
+ * a hipGraph: adas_pipeline_create does it for micro-batched pipelines; eager launches size it on demand). */
+int adas_bytetrack_reserve_frames(adas_bytetrack* h, int n_frames, int n_streams);
+/* The message of frame `frame` (0 .. n_frames - 1) of the LAST adas_bytetrack_update_device_frames launch: what BYTETracker.update returned
+ * for that frame (byteTracker.py:185) -- the live state (adas_bytetrack_fetch) only holds the last frame's.  Same layout as fetch. */
+int adas_bytetrack_fetch_frame(adas_bytetrack* h, int stream_index, int frame, adas_track_header* hdr, adas_track* tracks, int max_tracks);
 /* Synchronises; tracks[0..n_tracked) are tracked_stracks, then n_lost lost_stracks, list order kept. */
 int adas_bytetrack_fetch(adas_bytetrack* h, int stream_index, adas_track_header* hdr, adas_track* tracks,
                          int max_tracks);

@@ -234,12 +234,13 @@ class ChainStats:
 
 
 def run_device_chain(pipe, fetch_post, fetch_tracks, d_frame_sets, h_frame_sets, chain, steps, hold, streams, src_hw=(720, 1280), crop=0.6,
-                     lanes=True, micro_batch=1, n_streams=None):
+                     lanes=True, micro_batch=1, n_streams=None, fetch_tracks_frame=None):
     """Drive `pipe` (an AdasPipeline with FRESH tracker state) for `steps` steps over the frame sets (each held `hold` steps) and
     compare streams `streams` with the oracle chain after every step.  fetch_post(f) -> detections dict of frame index f,
     fetch_tracks(s) -> snapshot dict (tests/gpu_api.track_snapshot form).  micro_batch B > 1: a frame set holds B consecutive
     frames of each of the n_streams streams (frame b of stream s at index b * n_streams + s); the oracle tracker of a stream
-    consumes them in order and is compared after the last one."""
+    consumes them in order and is compared after the last one -- and, with fetch_tracks_frame(s, b) (the per-frame message store of the
+    micro-batched tracker launch), after every frame."""
     st = ChainStats()
     B = max(1, int(micro_batch))
     NS = n_streams if n_streams is not None else (len(h_frame_sets[0]) // B)
@@ -258,6 +259,8 @@ def run_device_chain(pipe, fetch_post, fetch_tracks, d_frame_sets, h_frame_sets,
                     raise RuntimeError("frame %d step %d: candidate arena overflow in the parity leg" % (f, k))
                 st.add_detections(got, want, ctx=[k, s, b])
                 want_trk = chain.track(s, want)
+                if fetch_tracks_frame is not None:
+                    st.add_tracks(fetch_tracks_frame(s, b), want_trk, ctx=[k, s, b])
                 if lanes and pipe.decode is not None:
                     st.add_lanes(pipe.decode.fetch(f), chain.lanes(frame, key=(i, f)))
             st.add_tracks(fetch_tracks(s), want_trk, ctx=[k, s])

@@ -147,7 +147,8 @@ def test_c4_c5_pipelines_match_oracle_chain(tmp_path, det, prec):
 @pytest.mark.parametrize("prec", ["fp32", "fp16x3"])
 def test_micro_batched_step_matches_oracle_chain_exactly(tmp_path, prec):
     """Temporal micro-batching (adas_pipeline_desc.micro_batch): 2 streams x 3 consecutive frames per step through the nets at once,
-    tracker updates in temporal order -- exact against the oracle chain consuming the same frames one at a time."""
+    tracker updates in temporal order -- exact against the oracle chain consuming the same frames one at a time, the tracker message of
+    EVERY frame included (adas_bytetrack_fetch_frame)."""
     import bench
     from oracle import preprocess
     NS, B, steps = 2, 3, 3
@@ -159,11 +160,13 @@ def test_micro_batched_step_matches_oracle_chain_exactly(tmp_path, prec):
     d_pool = [L.DeviceBuffer.from_array(p) for p in pool]
     chain = CP.OracleChain("yolov8n", Wd, "ufldv2_res18", Wl)
     st = CP.run_device_chain(pipe, lambda f: PP.YoloPost.fetch(pipe.post, f), lambda s: gpu_api.track_snapshot(*pipe.tracker.fetch(s)),
-                             d_pool, pool, chain, steps, 1, list(range(NS)), micro_batch=B, n_streams=NS)
+                             d_pool, pool, chain, steps, 1, list(range(NS)), micro_batch=B, n_streams=NS,
+                             fetch_tracks_frame=lambda s, b: gpu_api.track_snapshot(*pipe.tracker.fetch_frame(s, b)))
     pipe.close()
     for b in d_pool:
         b.free()
     o = st.summary()
     print("micro-batch:", o)
-    assert o["frames"] == NS * B * steps and o["track_states_compared"] == NS * steps
+    # tracker messages: one per frame (what BYTETracker.update returns every frame, kept by the micro-batched launch) + the live state
+    assert o["frames"] == NS * B * steps and o["track_states_compared"] == NS * steps * (B + 1)
     _assert_exact(o)

@@ -174,6 +174,8 @@ _SIGS = {
     "adas_bytetrack_update_device": (C.c_int, [_P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
     "adas_bytetrack_update_device_frames": (C.c_int, [_P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
     "adas_bytetrack_fetch": (C.c_int, [_P, C.c_int, C.POINTER(TrackHeader), _P, C.c_int]),
+    "adas_bytetrack_reserve_frames": (C.c_int, [_P, C.c_int, C.c_int]),
+    "adas_bytetrack_fetch_frame": (C.c_int, [_P, C.c_int, C.c_int, C.POINTER(TrackHeader), _P, C.c_int]),
     "adas_pipeline_create": (C.c_int, [C.POINTER(PipelineDesc), C.POINTER(_P)]),
     "adas_pipeline_destroy": (C.c_int, [_P]),
     "adas_pipeline_step": (C.c_int, [_P, _P, _P]),

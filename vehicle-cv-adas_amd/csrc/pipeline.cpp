@@ -222,6 +222,13 @@ int adas_pipeline_create(const adas_pipeline_desc* d, adas_pipeline** out) {
         adas_pipeline_destroy(p);
         return hip_fail(hipGetLastError(), "hipEventCreate", __FILE__, __LINE__);
     }
+    if (d->tracker && d->detector && d->micro_batch > 1) {   // every frame's tracker message stays fetchable (adas_bytetrack_fetch_frame)
+        int rc = adas_bytetrack_reserve_frames(d->tracker, d->micro_batch, d->n_streams);
+        if (rc) {
+            adas_pipeline_destroy(p);
+            return rc;
+        }
+    }
     if (d->detector && d->post) {
         int32_t layout = -1;
         const char* env = getenv("ADAS_NO_DETECT_SINK");

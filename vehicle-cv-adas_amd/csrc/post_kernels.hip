@@ -254,9 +254,12 @@ struct BtDev {
     int det_stride, count_stride, count_index, first_stream;
     int n_frames = 1, frame_slabs = 0;   // temporal micro-batch: this launch consumes n_frames consecutive frames of every stream, frame f of
                                          // the stream in block b at detection slab f * frame_slabs + b
+    unsigned char* snap = nullptr;       // micro-batch: [frame][stream] copies of (header, out list) after each frame's update -- the message
+    size_t snap_bytes = 0;               // BYTETracker.update returns every frame (byteTracker.py:185); the live state only holds the last one
 };
 
 __host__ __device__ inline size_t bt_align(size_t x) { return (x + 63) & ~(size_t)63; }
+__host__ __device__ inline size_t bt_snap_bytes(int MT) { return bt_align(sizeof(BtHeader)) + bt_align((size_t)2 * MT * sizeof(BtOut)); }
 __host__ __device__ inline size_t bt_stream_bytes(int MT, int MD) {
     return bt_align(sizeof(BtHeader)) + bt_align((size_t)MT * sizeof(BtTrack)) + bt_align((size_t)MT * MD * 8) +
            bt_align((size_t)2 * MT * sizeof(BtOut)) + 2 * bt_align((size_t)MT * 4);
@@ -286,6 +289,17 @@ __global__ __launch_bounds__(256) void bytetrack_update_kernel(BtDev d) {
         det.nd = d.counts[(size_t)q * d.count_stride + d.count_index];
         bytetrack_update(c, d.P, S, det, smem);
         __syncthreads();   // the next frame's update starts from the track table and LDS this one leaves behind
+        if (d.snap) {      // this frame's message: header + tracked / lost lists, 8-byte words
+            unsigned char* q = d.snap + ((size_t)f * d.frame_slabs + blockIdx.x) * d.snap_bytes;
+            const unsigned long long* sh = (const unsigned long long*)S.hdr;
+            const unsigned long long* so = (const unsigned long long*)S.out;
+            unsigned long long* dh = (unsigned long long*)q;
+            unsigned long long* dout = (unsigned long long*)(q + bt_align(sizeof(BtHeader)));
+            const int nw = (S.hdr->n_tracked + S.hdr->n_lost) * (int)(sizeof(BtOut) / 8);
+            for (int i = threadIdx.x; i < (int)(sizeof(BtHeader) / 8); i += blockDim.x) dh[i] = sh[i];
+            for (int i = threadIdx.x; i < nw; i += blockDim.x) dout[i] = so[i];
+            __syncthreads();
+        }
     }
 }
 
@@ -385,6 +399,8 @@ struct adas_bytetrack {
     void* arena;
     double* h_stage_d;  // device staging for update_host
     hipStream_t last;
+    void* snap = nullptr;      // per-frame snapshots of the last update_device_frames launch ([n_frames][n_streams], grown on demand)
+    int snap_frames = 0, snap_streams = 0;
 };
 
 namespace adas {
@@ -1050,6 +1066,7 @@ int adas_bytetrack_create(const adas_bytetrack_params* p, int n_streams, adas_by
 }
 int adas_bytetrack_destroy(adas_bytetrack* h) {
     if (!h) return ADAS_OK;
+    if (h->snap) (void)hipFree(h->snap);
     hipFree(h->arena);
     delete h;
     return ADAS_OK;
@@ -1104,6 +1121,17 @@ int adas_bytetrack_update_device(adas_bytetrack* h, const double* d_xyxy, const 
     ADAS_HIP_TRY(hipGetLastError());
     return ADAS_OK;
 }
+int adas_bytetrack_reserve_frames(adas_bytetrack* h, int n_frames, int n_streams) {
+    ADAS_REQUIRE(h && n_frames >= 1 && n_streams >= 1 && n_streams <= h->n_streams, ADAS_ERR_INVALID, "adas_bytetrack_reserve_frames: bad argument");
+    if (n_frames <= h->snap_frames && n_streams == h->snap_streams) return ADAS_OK;
+    ADAS_HIP_TRY(hipStreamSynchronize(h->last));
+    if (h->snap) (void)hipFree(h->snap);
+    h->snap = nullptr; h->snap_frames = h->snap_streams = 0;
+    ADAS_HIP_TRY(hipMalloc(&h->snap, bt_snap_bytes(h->p.max_tracks) * (size_t)n_frames * (size_t)n_streams));
+    ADAS_HIP_TRY(hipMemset(h->snap, 0, bt_snap_bytes(h->p.max_tracks) * (size_t)n_frames * (size_t)n_streams));
+    h->snap_frames = n_frames; h->snap_streams = n_streams;
+    return ADAS_OK;
+}
 int adas_bytetrack_update_device_frames(adas_bytetrack* h, const double* d_xyxy, const double* d_scores, const int32_t* d_cls,
                                         const int32_t* d_counts, int det_stride, int count_stride, int count_index, int n_streams, int n_frames,
                                         void* stream) {
@@ -1115,9 +1143,35 @@ int adas_bytetrack_update_device_frames(adas_bytetrack* h, const double* d_xyxy,
     d.xyxy = d_xyxy; d.score = d_scores; d.cls = d_cls; d.counts = d_counts;
     d.det_stride = det_stride; d.count_stride = count_stride; d.count_index = count_index; d.first_stream = 0;
     d.n_frames = n_frames; d.frame_slabs = n_streams;
+    if (n_frames > 1) {   // keep every frame's message fetchable (adas_bytetrack_fetch_frame)
+        if (n_frames > h->snap_frames || n_streams != h->snap_streams) {   // (re)allocation: never inside a stream capture (adas_pipeline_create reserves)
+            hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+            (void)hipStreamIsCapturing(st, &cs);
+            ADAS_REQUIRE(cs == hipStreamCaptureStatusNone, ADAS_ERR_INVALID,
+                         "call adas_bytetrack_reserve_frames(%d frames, %d streams) before capturing a micro-batched step", n_frames, n_streams);
+            int rc = adas_bytetrack_reserve_frames(h, n_frames, n_streams);
+            if (rc) return rc;
+        }
+        d.snap = (unsigned char*)h->snap; d.snap_bytes = bt_snap_bytes(h->p.max_tracks);
+    }
     size_t lds = BtLds::bytes(h->p.max_tracks, h->p.max_dets, 256);
     hipLaunchKernelGGL(bytetrack_update_kernel, dim3(n_streams), dim3(256), lds, st, d);
     ADAS_HIP_TRY(hipGetLastError());
+    return ADAS_OK;
+}
+int adas_bytetrack_fetch_frame(adas_bytetrack* h, int stream_index, int frame, adas_track_header* hdr, adas_track* tracks, int max_tracks) {
+    ADAS_REQUIRE(h && hdr && stream_index >= 0 && stream_index < h->n_streams, ADAS_ERR_INVALID, "adas_bytetrack_fetch_frame: bad argument");
+    ADAS_REQUIRE(h->snap && frame >= 0 && frame < h->snap_frames && stream_index < h->snap_streams, ADAS_ERR_INVALID,
+                 "adas_bytetrack_fetch_frame: frame %d of stream %d is not part of the last adas_bytetrack_update_device_frames launch (%d frames x %d streams)",
+                 frame, stream_index, h->snap_frames, h->snap_streams);
+    ADAS_HIP_TRY(hipStreamSynchronize(h->last));
+    const unsigned char* q = (const unsigned char*)h->snap + ((size_t)frame * h->snap_streams + stream_index) * bt_snap_bytes(h->p.max_tracks);
+    ADAS_HIP_TRY(hipMemcpy(hdr, q, sizeof(BtHeader), hipMemcpyDeviceToHost));
+    const int n = hdr->n_tracked + hdr->n_lost;
+    if (tracks && n > 0) {
+        ADAS_REQUIRE(n <= max_tracks, ADAS_ERR_CAPACITY, "fetch buffer holds %d tracks, need %d", max_tracks, n);
+        ADAS_HIP_TRY(hipMemcpy(tracks, q + bt_align(sizeof(BtHeader)), (size_t)n * sizeof(BtOut), hipMemcpyDeviceToHost));
+    }
     return ADAS_OK;
 }
 int adas_bytetrack_fetch(adas_bytetrack* h, int stream_index, adas_track_header* hdr, adas_track* tracks, int max_tracks) {

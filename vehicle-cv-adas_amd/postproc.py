@@ -319,6 +319,13 @@ class DeviceTracker:
         L.check(L.lib().adas_bytetrack_fetch(self.h, stream, C.byref(hdr), L.ptr(recs), len(recs)))
         return hdr, recs[:hdr.n_tracked], recs[hdr.n_tracked:hdr.n_tracked + hdr.n_lost]
 
+    def fetch_frame(self, stream, frame):
+        """The tracker message of frame `frame` of the last micro-batched step (what BYTETracker.update returned for that frame)."""
+        hdr = L.TrackHeader()
+        recs = np.zeros(2 * self.max_tracks, L.TRACK_DTYPE)
+        L.check(L.lib().adas_bytetrack_fetch_frame(self.h, stream, frame, C.byref(hdr), L.ptr(recs), len(recs)))
+        return hdr, recs[:hdr.n_tracked], recs[hdr.n_tracked:hdr.n_tracked + hdr.n_lost]
+
     def close(self):
         if getattr(self, "h", None):
             L.lib().adas_bytetrack_destroy(self.h)
