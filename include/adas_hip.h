@@ -105,6 +105,9 @@ int adas_engine_profile(adas_engine* e, const float* d_input_nchw, int batch, in
  * Pass the arrays of adas_yolo_post_scan_views and run adas_yolo_post_run_prescanned afterwards; pass NULL, NULL to restore the full
  * head.  adas_pipeline_* does this around its own detector launches; engine_inference callers never see it. */
 int adas_engine_detect_sink_supported(const adas_engine* e);
+/* Layout (ADAS_HEAD_V8 | ADAS_HEAD_V5), anchor and class count of the head the sink describes: the arrays handed to
+ * adas_engine_set_detect_sink hold [max_batch][num_anchors] entries. */
+int adas_engine_detect_sink_shape(const adas_engine* e, int32_t* layout, int32_t* num_anchors, int32_t* num_classes);
 int adas_engine_set_detect_sink(adas_engine* e, float* d_best_conf, int32_t* d_best_cls);
 int adas_engine_layer_info(const adas_engine* e, int layer, char* name, int name_cap, double* flops, int* kind);
 /* Which kernel instantiation layer `layer` launches at `batch` frames (matches the rocprofv3 kernel name). */

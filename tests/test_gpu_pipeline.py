@@ -203,18 +203,20 @@ def test_changed_crop_ratio_or_config_recaptures_the_graph(tmp_path):
     pg.close(); pe.close(); dc.free()
 
 
-def test_detect_sink_off_gives_the_same_step(tmp_path, monkeypatch):
+@pytest.mark.parametrize("det_name", ["yolov8n", "yolov7-tiny"])
+def test_detect_sink_off_gives_the_same_step(tmp_path, monkeypatch, det_name):
     """ADAS_NO_DETECT_SINK=1 (full head + class scan inside the step) against the default (per-anchor maxima straight from the Detect
     kernel): identical candidates, survivors and tracks; a detector engine keeps returning the whole head to engine_inference callers."""
     import bench
     S = 2
     cam = [bench.cam_frames(S, 90 + i) for i in range(2)]
     seam = np.concatenate([importlib.import_module("oracle.preprocess").yolo_prepare_input(f, (640, 640)) for f in cam[0]])
-    det_path, _, _ = bench.build_detector(M, CE, "yolov8n", seam, str(tmp_path), "sink", target_per_frame=60.0)
+    det_path, _, _ = bench.build_detector(M, CE, det_name, seam, str(tmp_path), "sink", target_per_frame=60.0)   # v8 layout / v5 layout
     lane_path, _, _ = netutil.model("ufldv2_res18")
-    pa = PL.AdasPipeline(det_path, lane_path, n_streams=S, precision="fp16", src_hw=(720, 1280), use_graph=True)
+    kw = dict(n_streams=S, precision="fp16", src_hw=(720, 1280), use_graph=True, head_layout=L.HEAD_V8 if det_name == "yolov8n" else L.HEAD_V5)
+    pa = PL.AdasPipeline(det_path, lane_path, **kw)
     monkeypatch.setenv("ADAS_NO_DETECT_SINK", "1")
-    pb = PL.AdasPipeline(det_path, lane_path, n_streams=S, precision="fp16", src_hw=(720, 1280), use_graph=True)
+    pb = PL.AdasPipeline(det_path, lane_path, **kw)
     monkeypatch.delenv("ADAS_NO_DETECT_SINK")
     assert L.lib().adas_pipeline_detect_sink(pa.h) == 1 and L.lib().adas_pipeline_detect_sink(pb.h) == 0
     n = 0
@@ -234,5 +236,17 @@ def test_detect_sink_off_gives_the_same_step(tmp_path, monkeypatch):
     x = seam[:S].astype(np.float32)
     ha, hb = pa.det.engine_inference(x)[0], pb.det.engine_inference(x)[0]
     np.testing.assert_array_equal(ha, hb)
-    assert float(np.abs(ha[:, 4:]).max()) > 0.0
+    assert float(np.abs(ha[:, 4:] if det_name == "yolov8n" else ha[..., 5:]).max()) > 0.0
     pa.close(); pb.close()
+
+
+def test_detect_sink_needs_a_post_processor_of_the_same_head(tmp_path):
+    """A v5-layout detector behind a post-processor created for the v8 reading of its (1, 25200, 85) head (legal: the shapes are
+    consistent) must not get the sink: the engine would write 25,200 entries per frame into scan arrays sized for 85 anchors."""
+    det_path = M.build("yolov7-tiny").save(str(tmp_path / "v7.hipm"))
+    p = PL.AdasPipeline(det_path, None, n_streams=2, precision="fp16", src_hw=(720, 1280), use_graph=False)     # head_layout defaults to v8
+    assert L.lib().adas_pipeline_detect_sink(p.h) == 0
+    p.close()
+    p = PL.AdasPipeline(det_path, None, n_streams=2, precision="fp16", src_hw=(720, 1280), use_graph=False, head_layout=L.HEAD_V5)
+    assert L.lib().adas_pipeline_detect_sink(p.h) == 1
+    p.close()

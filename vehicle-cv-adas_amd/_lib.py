@@ -138,6 +138,7 @@ _SIGS = {
     "adas_yolo_post_scan_views": (C.c_int, [_P, C.POINTER(_P), C.POINTER(_P)]),
     "adas_yolo_post_run_prescanned": (C.c_int, [_P, _P, C.c_int, _P]),
     "adas_engine_detect_sink_supported": (C.c_int, [_P]),
+    "adas_engine_detect_sink_shape": (C.c_int, [_P, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "adas_engine_set_detect_sink": (C.c_int, [_P, _P, _P]),
     "adas_pipeline_detect_sink": (C.c_int, [_P]),
     "adas_yolo_post_capacity": (C.c_int, [_P, C.POINTER(C.c_int)]),

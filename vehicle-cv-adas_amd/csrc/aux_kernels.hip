@@ -820,9 +820,14 @@ struct Det5Dev {
     const float* anchors;   // [3 levels][3 anchors][2]
     float* out;
     int nc, A, n, lds_bias_off;   // lds_bias_off: in floats
+    float* sink_conf;       // SINK: per-row best class confidence (class x objectness, fp32) / first arg-max class, [n][A] each
+    int* sink_cls;
 };
 
-template <typename E>
+// SINK (pipeline steps): per row the post-processing reads the box and, from the scan, max_k(cls_k * obj) with its first arg-max
+// (yoloDetector.py:123-127).  The decoded row sits in this wave's LDS staging area: the pair is taken there (same fp32 products, same
+// first-maximum rule as yolo_scan_v5) and only the five leading values of the row go to HBM -- no class values written, no scan launch.
+template <typename E, bool SINK>
 __global__ __launch_bounds__(256, 3) void detect_v5_fused_kernel(Det5Dev d) {
     extern __shared__ __attribute__((aligned(16))) uint16_t wl[];      // weight chunk, then the output staging
     E::enter();
@@ -907,7 +912,31 @@ __global__ __launch_bounds__(256, 3) void detect_v5_fused_kernel(Det5Dev d) {
     }
     __syncthreads();
     const int rows = min(32, hw - p0);
-    if (rows > 0) {
+    if (SINK) {
+        if (rows > 0) {
+            const size_t row0 = (size_t)b * d.A + d.row_off[lvl] + (size_t)a * hw + p0;
+            if (lane < rows) {
+                const float* r = stage + lane * no;
+                const float obj = r[4];
+                float bv = 0.f;
+                int bi = -1;
+                for (int c = 0; c < d.nc; ++c) {
+                    const float pr = r[5 + c] * obj;
+                    if (bi < 0 || pr > bv) {
+                        bv = pr;
+                        bi = c;
+                    }
+                }
+                d.sink_conf[row0 + lane] = bv;
+                d.sink_cls[row0 + lane] = bi < 0 ? 0 : bi;
+            }
+            float* dst = d.out + row0 * no;
+            for (int i = lane; i < rows * 5; i += 64) {
+                const int rr = i / 5, cc = i - rr * 5;
+                dst[(size_t)rr * no + cc] = stage[rr * no + cc];
+            }
+        }
+    } else if (rows > 0) {
         float* dst = d.out + ((size_t)b * d.A + d.row_off[lvl] + (size_t)a * hw + p0) * no;
         const int nel = rows * no;
         for (int i0 = 0; i0 < nel; i0 += 64 * 8) {           // eight LDS reads in flight, then eight coalesced 256-byte stores
@@ -955,7 +984,7 @@ hipError_t launch_pack_weights_det5(const float* src, void* dst, int no, int cin
 }
 // hidden[l]: input of the level's 1x1 conv; wfrag / bias: its det5-packed weights and its 3 * (5 + nc) biases
 hipError_t launch_detect_v5_fused(const TView* hidden, const void* const* wfrag, const float* const* bias, float* out, int n, int nc, int A,
-                                  const int strides[3], const float* d_anchors, int prec, hipStream_t st_) {
+                                  const int strides[3], const float* d_anchors, int prec, hipStream_t st_, float* sink_conf, int* sink_cls) {
     Det5Dev d;
     int off = 0, blocks = 0;
     const int no = nc + 5, NT = (no + 15) / 16;
@@ -975,7 +1004,11 @@ hipError_t launch_detect_v5_fused(const TView* hidden, const void* const* wfrag,
     const size_t region = ((lw > ls ? lw : ls) + 15) & ~(size_t)15;
     d.lds_bias_off = (int)(region / 4);
     const size_t lds = region + (size_t)no * 4;
-    ADAS_DISPATCH_E16(prec == PREC_FP16, E, hipLaunchKernelGGL(detect_v5_fused_kernel<E>, dim3(blocks, n), dim3(256), lds, st_, d));
+    d.sink_conf = sink_conf; d.sink_cls = sink_cls;
+    if (sink_conf && sink_cls)
+        ADAS_DISPATCH_E16(prec == PREC_FP16, E, hipLaunchKernelGGL((detect_v5_fused_kernel<E, true>), dim3(blocks, n), dim3(256), lds, st_, d));
+    else
+        ADAS_DISPATCH_E16(prec == PREC_FP16, E, hipLaunchKernelGGL((detect_v5_fused_kernel<E, false>), dim3(blocks, n), dim3(256), lds, st_, d));
     return hipGetLastError();
 }
 

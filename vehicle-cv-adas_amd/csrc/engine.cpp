@@ -804,13 +804,25 @@ int adas_engine_layer_kernel(const adas_engine* e, int layer, int batch, char* n
 int adas_engine_detect_sink_supported(const adas_engine* e) {
     if (!e) return 0;
     for (auto& op : e->ops)
-        if (op.f.type == OP_DETECT_V8 && op.det_src[0] >= 0) return 1;
+        if ((op.f.type == OP_DETECT_V8 || op.f.type == OP_DETECT_V5) && op.det_src[0] >= 0) return 1;
     return 0;
+}
+int adas_engine_detect_sink_shape(const adas_engine* e, int32_t* layout, int32_t* num_anchors, int32_t* num_classes) {
+    ADAS_REQUIRE(e, ADAS_ERR_INVALID, "adas_engine_detect_sink_shape: null engine");
+    for (auto& op : e->ops)
+        if ((op.f.type == OP_DETECT_V8 || op.f.type == OP_DETECT_V5) && op.det_src[0] >= 0) {
+            if (layout) *layout = op.f.type == OP_DETECT_V8 ? ADAS_HEAD_V8 : ADAS_HEAD_V5;
+            if (num_classes) *num_classes = (int32_t)op.f.params[0];
+            if (num_anchors) *num_anchors = (int32_t)op.f.params[1];
+            return ADAS_OK;
+        }
+    set_error("this engine has no fused Detect kernel");
+    return ADAS_ERR_INVALID;
 }
 int adas_engine_set_detect_sink(adas_engine* e, float* d_best_conf, int32_t* d_best_cls) {
     ADAS_REQUIRE(e && ((d_best_conf == nullptr) == (d_best_cls == nullptr)), ADAS_ERR_INVALID, "adas_engine_set_detect_sink: bad argument");
     ADAS_REQUIRE(!d_best_conf || adas_engine_detect_sink_supported(e), ADAS_ERR_INVALID,
-                 "this engine's Detect is not the fused v8 kernel (16-bit precisions, six 1x1 head convs folded): it has no per-anchor sink");
+                 "this engine's Detect is not one of the fused kernels (16-bit precisions, the head's last 1x1 convs folded in): it has no per-anchor sink");
     e->sink_conf = d_best_conf;
     e->sink_cls = d_best_cls;
     return ADAS_OK;
@@ -965,7 +977,7 @@ int engine_run_op(adas_engine* e, int i, const float* d_in, int batch, hipStream
                     bs[k] = (const float*)(wb + c.b_off);
                 }
                 err = launch_detect_v5_fused(ins, wf, bs, (float*)e->bufs[o.out_buf].d, batch, (int)o.params[0], (int)o.params[1], strides,
-                                             (const float*)(wb + op.w_off), e->prec, st);
+                                             (const float*)(wb + op.w_off), e->prec, st, e->sink_conf, e->sink_cls);
                 break;
             }
             for (int k = 0; k < 3; ++k) ins[k] = make_view(e, o.in_buf[k], o.in_coff[k], o.in_c[k]);

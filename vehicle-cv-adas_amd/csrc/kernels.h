@@ -135,7 +135,7 @@ bool det5_applicable(int prec, int nc, const TView& in, const TView& logits);
 size_t det5_weight_bytes(int no, int cin);
 hipError_t launch_pack_weights_det5(const float* src, void* dst, int no, int cin, int prec, hipStream_t st);   // src fp32 [3 * no][cin]
 hipError_t launch_detect_v5_fused(const TView* hidden, const void* const* wfrag, const float* const* bias, float* out, int n, int nc, int A,
-                                  const int strides[3], const float* d_anchors, int prec, hipStream_t st);
+                                  const int strides[3], const float* d_anchors, int prec, hipStream_t st, float* sink_conf = nullptr, int* sink_cls = nullptr);
 hipError_t launch_detect_v5(const TView* ins, float* out, int n, int nc, int A, const int strides[3],
                             const float* d_anchors, hipStream_t st);
 // LayerNorm over the flat per-frame vector (len elements, fp32 in) -> compute type out

@@ -230,10 +230,13 @@ int adas_pipeline_create(const adas_pipeline_desc* d, adas_pipeline** out) {
         }
     }
     if (d->detector && d->post) {
-        int32_t layout = -1;
+        // only when the post-processing was created for exactly the head the engine's fused Detect describes (its scan arrays hold
+        // [max_batch][num_anchors] entries of that layout)
+        int32_t layout = -1, pa = 0, pn = 0, el = -2, ea = 0, en = 0;
         const char* env = getenv("ADAS_NO_DETECT_SINK");
-        (void)adas_yolo_post_head_shape(d->post, &layout, nullptr, nullptr);
-        p->sink = layout == ADAS_HEAD_V8 && adas_engine_detect_sink_supported(d->detector) && !(env && env[0] == '1');
+        (void)adas_yolo_post_head_shape(d->post, &layout, &pa, &pn);
+        p->sink = adas_engine_detect_sink_supported(d->detector) && adas_engine_detect_sink_shape(d->detector, &el, &ea, &en) == ADAS_OK &&
+                  el == layout && ea == pa && en == pn && !(env && env[0] == '1');
     }
     *out = p;
     return ADAS_OK;

@@ -531,7 +531,7 @@ int adas_yolo_post_scan_views(adas_yolo_post* h, float** d_best_conf, int32_t** 
 int adas_yolo_post_run_prescanned(adas_yolo_post* h, const float* d_head, int batch, void* stream) {
     ADAS_REQUIRE(h && d_head && batch > 0 && batch <= h->max_batch, ADAS_ERR_INVALID, "adas_yolo_post_run_prescanned: bad argument (batch %d, max %d)", batch,
                  h ? h->max_batch : 0);
-    ADAS_REQUIRE(h->p.layout == ADAS_HEAD_V8, ADAS_ERR_INVALID, "adas_yolo_post_run_prescanned: v8-layout heads only");
+    ADAS_REQUIRE(h->p.layout == ADAS_HEAD_V8 || h->p.layout == ADAS_HEAD_V5, ADAS_ERR_INVALID, "adas_yolo_post_run_prescanned: v8- and v5-layout heads only");
     hipStream_t st = (hipStream_t)stream;
     h->last = st;
     YoloPostDev d = h->dev;
