@@ -920,6 +920,13 @@ def main():
         from oracle import yolo_post
         lb = yolo_post.letterbox_params((720, 1280), (640, 640))
         result["cpu_baseline"] = cpu_baseline(args.det, args.lane, Wd, Wl, dpool[0], lpool[0], lb, cams=h_cam[0] if from_frames else None)
+        # the REFERENCE's own post-processing legs (its Python, timed where /root/reference exists: tools/ref_postproc_timing.py): a
+        # committed measurement, quoted beside the live port number -- never read from the reference tree at run time
+        ref_txt = os.path.join(ROOT, "profiles", "r04", "reference_postproc_cpu.txt")
+        if os.path.isfile(ref_txt):
+            lines = [l.strip() for l in open(ref_txt).read().splitlines() if l.strip()]
+            result["cpu_baseline"]["reference_postproc_legs"] = {"file": "profiles/r04/reference_postproc_cpu.txt",
+                                                                 "summary": next((l for l in lines if l.startswith("sum:")), None)}
     else:
         result["cpu_baseline"] = None
     # ---- the keys a reader of the line's TAIL must see come last (a driver that keeps the last few KB of stdout keeps these): stage
