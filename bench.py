@@ -916,6 +916,10 @@ def main():
         "per_rank": [{"frames": r["frames"], "seconds": round(r["seconds"], 5), "p50_ms": round(r["p50_ms"], 4), "p99_ms": round(r["p99_ms"], 4)}
                      for r in per_rank],
     }
+    if args.precision == "fp16x3":   # split precision: three f16 MFMAs per multiply-add of the algorithmic count
+        result["roofline"]["mfma_products_per_mac"] = 3
+        result["roofline"]["mfma_issue_frac"] = round(3.0 * achieved / PEAK_BF16_TFLOPS, 5)
+        result["roofline"]["peak_note"] += "; fp16x3 issues 3 MFMAs per algorithmic multiply-add: `frac` counts algorithmic FLOPs, `mfma_issue_frac` the MFMA work"
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import yolo_post
         lb = yolo_post.letterbox_params((720, 1280), (640, 640))

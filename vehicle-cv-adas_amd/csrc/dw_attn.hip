@@ -23,37 +23,62 @@ struct DwDev {
     const float* wgt;   // [k*k][C] fp32
     const float* bias;  // [C]
     int in_cs, in_coff, out_cs, out_coff, res_cs, res_coff;
-    int c, H, W, Ho, Wo, k, s, p, n, act, has_res;
+    int c, H, W, Ho, Wo, k, s, p, n, act, has_res, small;
 };
 
-template <typename T>
+template <typename T, int K>
 __global__ __launch_bounds__(256) void dwconv_kernel(DwDev d) {
     if constexpr (sizeof(T) == 2 && !__is_same(T, uint16_t)) Fp16::enter();
     const int c8n = d.c >> 3;
     const size_t total = (size_t)d.n * d.Ho * d.Wo * c8n;
     const T* __restrict__ in = (const T*)d.in;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-        const int c8 = (int)(i % c8n);
-        size_t pix = i / c8n;
-        const int ox = (int)(pix % d.Wo);
-        size_t t = pix / d.Wo;
-        const int oy = (int)(t % d.Ho);
-        const size_t b = t / d.Ho;
+    // XCD-aware traversal: workgroup b runs on XCD b % 8 (each XCD has its own L2).  A k x k window shares its rows with the outputs one
+    // row up and down, i.e. with workgroups ~one image row of threads away -- under a plain grid-stride loop those sit on OTHER XCDs and
+    // every input row is fetched into three (k = 3) L2s.  Here each XCD owns one contiguous eighth of the index space and its workgroups
+    // stride inside it: vertical neighbours share an L2 (measured on EfficientNet-B0's depth-wise layers: DESIGN 9.7).
+    const unsigned xcd = blockIdx.x & 7u, slot = blockIdx.x >> 3, per_xcd = gridDim.x >> 3;
+    const size_t chunk = (total + 7) / 8, lo = (size_t)xcd * chunk, hi = lo + chunk < total ? lo + chunk : total;
+    for (size_t i = lo + (size_t)slot * blockDim.x + threadIdx.x; i < hi; i += (size_t)per_xcd * blockDim.x) {
+        int c8, ox, oy;
+        size_t pix, b;
+        if (d.small) {   // the whole index space fits 32 bits: 32-bit divisions (a 64-bit one costs ~10x; uniform branch)
+            const unsigned iu = (unsigned)i, pu = iu / (unsigned)c8n, tu = pu / (unsigned)d.Wo;
+            c8 = (int)(iu - pu * (unsigned)c8n);
+            ox = (int)(pu - tu * (unsigned)d.Wo);
+            const unsigned bu = tu / (unsigned)d.Ho;
+            oy = (int)(tu - bu * (unsigned)d.Ho);
+            pix = pu; b = bu;
+        } else {
+            c8 = (int)(i % c8n);
+            pix = i / c8n;
+            ox = (int)(pix % d.Wo);
+            const size_t t = pix / d.Wo;
+            oy = (int)(t % d.Ho);
+            b = t / d.Ho;
+        }
         const int c = c8 * 8;
         float acc[8];
         {
             const float4 b0 = *reinterpret_cast<const float4*>(d.bias + c), b1 = *reinterpret_cast<const float4*>(d.bias + c + 4);
             acc[0] = b0.x; acc[1] = b0.y; acc[2] = b0.z; acc[3] = b0.w; acc[4] = b1.x; acc[5] = b1.y; acc[6] = b1.z; acc[7] = b1.w;
         }
-        for (int r = 0; r < d.k; ++r) {
-            const int iy = oy * d.s - d.p + r;
+        // K is a compile-time constant (3 / 5 / 7): both tap loops unroll, the row's address arithmetic is hoisted and the K * K
+        // input loads of an output are independent of each other (same taps in the same (r, q) order: identical sums)
+        const int iy0 = oy * d.s - d.p, ix0 = ox * d.s - d.p;
+        const T* base = in + (b * d.H * d.W) * (size_t)d.in_cs + d.in_coff + c;
+        const float* wbase = d.wgt + c;
+#pragma unroll
+        for (int r = 0; r < K; ++r) {
+            const int iy = iy0 + r;
             if ((unsigned)iy >= (unsigned)d.H) continue;
-            for (int q = 0; q < d.k; ++q) {
-                const int ix = ox * d.s - d.p + q;
+            const T* rowp = base + (size_t)iy * d.W * d.in_cs;
+#pragma unroll
+            for (int q = 0; q < K; ++q) {
+                const int ix = ix0 + q;
                 if ((unsigned)ix >= (unsigned)d.W) continue;
                 float x[8];
-                Vec8<T>::load(in + ((b * d.H + iy) * d.W + ix) * d.in_cs + d.in_coff + c, x);
-                const float* wp = d.wgt + (size_t)(r * d.k + q) * d.c + c;
+                Vec8<T>::load(rowp + (size_t)ix * d.in_cs, x);
+                const float* wp = wbase + (size_t)(r * K + q) * d.c;
                 const float4 w0 = *reinterpret_cast<const float4*>(wp), w1 = *reinterpret_cast<const float4*>(wp + 4);
                 acc[0] = fmaf(x[0], w0.x, acc[0]); acc[1] = fmaf(x[1], w0.y, acc[1]); acc[2] = fmaf(x[2], w0.z, acc[2]); acc[3] = fmaf(x[3], w0.w, acc[3]);
                 acc[4] = fmaf(x[4], w1.x, acc[4]); acc[5] = fmaf(x[5], w1.y, acc[5]); acc[6] = fmaf(x[6], w1.z, acc[6]); acc[7] = fmaf(x[7], w1.w, acc[7]);
@@ -76,6 +101,87 @@ __global__ __launch_bounds__(256) void dwconv_kernel(DwDev d) {
     }
 }
 
+// Strip form: a thread owns P consecutive outputs of one row and one 8-channel group.  The plain kernel above issues, per output, K*K
+// 16-byte activation loads and 2*K*K 16-byte weight loads through the 64 B/clk L1 -- 27 KB per wave at K = 3, which bounds
+// EfficientNet's 128x128x144 layer at ~240 us where HBM needs 120 (measured 386; unrolling, 32-bit index arithmetic and an XCD-aware
+// traversal changed nothing: round 4).  Here one tap ROW of weights (K x 8 fp32) sits in registers while the strip's
+// (P - 1) * S + K input columns stream past it: per output K * ((P-1)S + K) / P activation loads and 2K*K / P weight loads (K = 3,
+// S = 1, P = 4: 4.5 + 4.5 instead of 9 + 18).  Every output still accumulates its taps in (row, column) order with fmaf: results are
+// bit-identical to the plain kernel's.
+template <typename T, int K, int S, int P>
+__global__ __launch_bounds__(256) void dwconv_strip_kernel(DwDev d) {
+    if constexpr (sizeof(T) == 2 && !__is_same(T, uint16_t)) Fp16::enter();
+    constexpr int NC = (P - 1) * S + K;   // input columns a strip touches
+    const unsigned c8n = (unsigned)(d.c >> 3), strips = (unsigned)((d.Wo + P - 1) / P);
+    const unsigned total = (unsigned)d.n * (unsigned)d.Ho * strips * c8n;   // host guarantees < 2^31
+    const T* __restrict__ in = (const T*)d.in;
+    for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const unsigned u = i / c8n, c8 = i - u * c8n;
+        const unsigned v = u / strips, sx = u - v * strips;
+        const unsigned b = v / (unsigned)d.Ho, oy = v - b * (unsigned)d.Ho;
+        const int c = (int)c8 * 8, ox0 = (int)sx * P;
+        float acc[P][8];
+        {
+            const float4 b0 = *reinterpret_cast<const float4*>(d.bias + c), b1 = *reinterpret_cast<const float4*>(d.bias + c + 4);
+#pragma unroll
+            for (int t = 0; t < P; ++t) {
+                acc[t][0] = b0.x; acc[t][1] = b0.y; acc[t][2] = b0.z; acc[t][3] = b0.w;
+                acc[t][4] = b1.x; acc[t][5] = b1.y; acc[t][6] = b1.z; acc[t][7] = b1.w;
+            }
+        }
+        const int iy0 = (int)oy * S - d.p, ix0 = ox0 * S - d.p;
+        const T* base = in + ((size_t)b * d.H * d.W) * (size_t)d.in_cs + d.in_coff + c;
+#pragma unroll
+        for (int r = 0; r < K; ++r) {
+            const int iy = iy0 + r;
+            if ((unsigned)iy >= (unsigned)d.H) continue;
+            float w[K][8];
+#pragma unroll
+            for (int q = 0; q < K; ++q) {
+                const float* wp = d.wgt + (size_t)(r * K + q) * d.c + c;
+                const float4 w0 = *reinterpret_cast<const float4*>(wp), w1 = *reinterpret_cast<const float4*>(wp + 4);
+                w[q][0] = w0.x; w[q][1] = w0.y; w[q][2] = w0.z; w[q][3] = w0.w; w[q][4] = w1.x; w[q][5] = w1.y; w[q][6] = w1.z; w[q][7] = w1.w;
+            }
+            const T* rowp = base + (size_t)iy * d.W * d.in_cs;
+#pragma unroll
+            for (int j = 0; j < NC; ++j) {
+                const int ix = ix0 + j;
+                if ((unsigned)ix >= (unsigned)d.W) continue;
+                float x[8];
+                Vec8<T>::load(rowp + (size_t)ix * d.in_cs, x);
+#pragma unroll
+                for (int t = 0; t < P; ++t) {
+                    const int q = j - t * S;            // compile-time after unrolling: the tap this column is for output t
+                    if (q >= 0 && q < K) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) acc[t][e] = fmaf(x[e], w[q][e], acc[t][e]);
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < P; ++t) {
+            const int ox = ox0 + t;
+            if (ox >= d.Wo) break;
+            if (d.act == ACT_SILU) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) acc[t][e] = acc[t][e] / (1.0f + expf(-acc[t][e]));
+            } else if (d.act == ACT_RELU) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) acc[t][e] = fmaxf(acc[t][e], 0.0f);
+            }
+            const size_t pix = ((size_t)b * d.Ho + oy) * d.Wo + ox;
+            if (d.has_res) {
+                float rv[8];
+                Vec8<T>::load((const T*)d.res + pix * d.res_cs + d.res_coff + c, rv);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) acc[t][e] += rv[e];
+            }
+            Vec8<T>::store((T*)d.out + pix * d.out_cs + d.out_coff + c, acc[t]);
+        }
+    }
+}
+
 bool dwconv_supported(int k, int stride, int pad, int res_mode, const TView& in, const TView& out) {
     if ((k != 3 && k != 5 && k != 7) || (stride != 1 && stride != 2) || pad != k / 2) return false;
     if (res_mode != RES_NONE && res_mode != RES_AFTER_ACT) return false;
@@ -93,11 +199,48 @@ hipError_t launch_dwconv(const TView& in, const TView& out, const TView& res, in
     d.c = in.c; d.H = in.h; d.W = in.w; d.Ho = out.h; d.Wo = out.w; d.k = k; d.s = stride; d.p = pad; d.n = n; d.act = act;
     d.has_res = res_mode != RES_NONE;
     const size_t total = (size_t)n * out.h * out.w * (in.c >> 3);
-    const int blocks = (int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
-    if (prec == PREC_FP32) hipLaunchKernelGGL(dwconv_kernel<float>, dim3(blocks), dim3(256), 0, st, d);
-    else if (prec == PREC_X3) hipLaunchKernelGGL(dwconv_kernel<x3s>, dim3(blocks), dim3(256), 0, st, d);
-    else if (prec == PREC_FP16) hipLaunchKernelGGL(dwconv_kernel<f16s>, dim3(blocks), dim3(256), 0, st, d);
-    else hipLaunchKernelGGL(dwconv_kernel<uint16_t>, dim3(blocks), dim3(256), 0, st, d);
+    d.small = total < ((size_t)1 << 31) ? 1 : 0;
+    {   // strip form (4 outputs per thread) whenever a row has at least one whole strip and the index space fits 32 bits
+        static int use_strip = -1;
+        if (use_strip < 0) {
+            const char* e = getenv("ADAS_NO_DW_STRIP");
+            use_strip = (e && e[0] == '1') ? 0 : 1;
+        }
+        const size_t items = (size_t)n * out.h * ((out.w + 3) / 4) * (in.c >> 3);
+        if (use_strip && out.w >= 4 && items < ((size_t)1 << 31)) {
+            const int sb = (int)((items + 255) / 256 < 16384 ? (items + 255) / 256 : 16384);
+#define ADAS_DWS(T, K_, S_) hipLaunchKernelGGL((dwconv_strip_kernel<T, K_, S_, 4>), dim3(sb), dim3(256), 0, st, d)
+#define ADAS_DWS_K(T)                                                   \
+    do {                                                                \
+        if (k == 3 && stride == 1) ADAS_DWS(T, 3, 1);                   \
+        else if (k == 3) ADAS_DWS(T, 3, 2);                             \
+        else if (k == 5 && stride == 1) ADAS_DWS(T, 5, 1);              \
+        else if (k == 5) ADAS_DWS(T, 5, 2);                             \
+        else if (stride == 1) ADAS_DWS(T, 7, 1);                        \
+        else ADAS_DWS(T, 7, 2);                                         \
+    } while (0)
+            if (prec == PREC_FP32) ADAS_DWS_K(float);
+            else if (prec == PREC_X3) ADAS_DWS_K(x3s);
+            else if (prec == PREC_FP16) ADAS_DWS_K(f16s);
+            else ADAS_DWS_K(uint16_t);
+#undef ADAS_DWS_K
+#undef ADAS_DWS
+            return hipGetLastError();
+        }
+    }
+    int blocks = (int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
+    blocks = (blocks + 7) & ~7;   // a whole number of workgroups per XCD
+#define ADAS_DW_LAUNCH(T)                                                                                     \
+    do {                                                                                                      \
+        if (k == 3) hipLaunchKernelGGL((dwconv_kernel<T, 3>), dim3(blocks), dim3(256), 0, st, d);             \
+        else if (k == 5) hipLaunchKernelGGL((dwconv_kernel<T, 5>), dim3(blocks), dim3(256), 0, st, d);        \
+        else hipLaunchKernelGGL((dwconv_kernel<T, 7>), dim3(blocks), dim3(256), 0, st, d);                    \
+    } while (0)
+    if (prec == PREC_FP32) ADAS_DW_LAUNCH(float);
+    else if (prec == PREC_X3) ADAS_DW_LAUNCH(x3s);
+    else if (prec == PREC_FP16) ADAS_DW_LAUNCH(f16s);
+    else ADAS_DW_LAUNCH(uint16_t);
+#undef ADAS_DW_LAUNCH
     return hipGetLastError();
 }
 
