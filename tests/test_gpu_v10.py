@@ -62,6 +62,33 @@ def test_depthwise_conv_kernel(k, s, c, act, res, prec, tol):
     assert rel_l2(got, want) <= tol, (rel_l2(got, want), float(np.abs(got - want).max()))
 
 
+@pytest.mark.parametrize("k,s,c", [(3, 1, 64), (3, 2, 144), (5, 1, 240), (5, 2, 96), (7, 1, 256)], ids=str)
+@pytest.mark.parametrize("prec", ["fp32", "fp16", "fp16x3"])
+def test_depthwise_strip_form_is_bit_identical_to_the_plain_kernel(tmp_path, monkeypatch, k, s, c, prec):
+    """dwconv_strip_kernel (4 outputs per thread, a tap row of weights in registers) accumulates every output's taps in the plain kernel's
+    (row, column) order: the same bits, on widths that are not a multiple of the strip (37) and at the image borders."""
+    H, W, batch = 23, 37, 3
+    ws = M.SynthWeights(5, gain=1.0)
+    g = M.Graph("dwstrip", 3, H, W, ws)
+    x, c3 = g.input()
+    a = g.conv(x, c, 1, 1, "expand", act=M.ACT_SILU, true_cin=c3)
+    y = g.dwconv(a, k, s, "test", act=M.ACT_SILU, res=a if s == 1 else None)
+    z = g.conv(y, 8, 1, 1, "tap", act=M.ACT_NONE, f32_out=True)
+    g.output(z, 0, [1, z.h * z.w * 8], "o")
+    path = str(tmp_path / "dwstrip.hipm")
+    g.save(path)
+    e = CE.HipEngine(path, prec, batch)
+    xin = np.random.default_rng(0).uniform(0, 1, (batch, 3, H, W)).astype(np.float32)
+    e.engine_inference(xin)
+    strip = e.fetch_activation("test", batch).copy()
+    monkeypatch.setenv("ADAS_NO_DW_STRIP", "1")
+    e.engine_inference(xin)
+    plain = e.fetch_activation("test", batch).copy()
+    e.close()
+    assert np.abs(strip).max() > 1e-3
+    np.testing.assert_array_equal(strip, plain)
+
+
 @pytest.mark.parametrize("hw,nh", [((20, 20), 2), ((12, 20), 2), ((9, 7), 1), ((20, 20), 4)], ids=str)
 @pytest.mark.parametrize("prec,tol", [("fp32", 1e-5), ("fp16", 3e-3), ("bf16", 2e-2)])
 def test_attention_kernel(hw, nh, prec, tol):

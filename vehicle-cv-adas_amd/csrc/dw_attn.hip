@@ -201,11 +201,8 @@ hipError_t launch_dwconv(const TView& in, const TView& out, const TView& res, in
     const size_t total = (size_t)n * out.h * out.w * (in.c >> 3);
     d.small = total < ((size_t)1 << 31) ? 1 : 0;
     {   // strip form (4 outputs per thread) whenever a row has at least one whole strip and the index space fits 32 bits
-        static int use_strip = -1;
-        if (use_strip < 0) {
-            const char* e = getenv("ADAS_NO_DW_STRIP");
-            use_strip = (e && e[0] == '1') ? 0 : 1;
-        }
+        const char* e = getenv("ADAS_NO_DW_STRIP");     // read per launch (tests hold the two forms against each other in one process)
+        const int use_strip = (e && e[0] == '1') ? 0 : 1;
         const size_t items = (size_t)n * out.h * ((out.w + 3) / 4) * (in.c >> 3);
         if (use_strip && out.w >= 4 && items < ((size_t)1 << 31)) {
             const int sb = (int)((items + 255) / 256 < 16384 ? (items + 255) / 256 : 16384);
