@@ -25,8 +25,9 @@ def _act(y, act):
     return y
 
 
-def run(g, x):
-    """g: models.Graph; x: (N, 3, H, W) float32 -> list of output arrays in g.outs order (batch first)."""
+def run(g, x, taps=None):
+    """g: models.Graph; x: (N, 3, H, W) float32 -> list of output arrays in g.outs order (batch first).  taps: dict filled with every op's
+    output view (NCHW numpy) by op name, as it stands right after the op ran."""
     x = torch.as_tensor(x, dtype=torch.float32)
     N = x.shape[0]
     blob = np.frombuffer(bytes(g.blob), np.float32)
@@ -136,6 +137,7 @@ def run(g, x):
             elif t == M.OP_DETECT_V8:
                 nc, A = int(op["params"][0]), int(op["params"][1])
                 strides = [int(s) for s in op["params"][2:5]]
+                assert strides == [ins[0].h * 8 // ins[2 * i].h for i in range(3)], ("the oracle's v8 decode takes the first level as stride 8", strides)
                 levels = [torch.cat((read(ins[2 * i]), read(ins[2 * i + 1])), 1).reshape(N, 64 + nc, -1) for i in range(3)]
                 from oracle import nets
                 y = torch.from_numpy(nets._v8_decode(levels, [(ins[2 * i].h, ins[2 * i].w) for i in range(3)], nc))
@@ -156,6 +158,8 @@ def run(g, x):
                 bufs[out.buf] = torch.cat(rows, 1).reshape(N, A * no, 1, 1)
             else:
                 raise ValueError(t)
+            if taps is not None and t not in (M.OP_INPUT, M.OP_DETECT_V8, M.OP_DETECT_V5, M.OP_DETECT_V6) and out.buf not in alias_of:
+                taps[op["name"]] = bufs[out.buf][:, out.coff:out.coff + out.c].numpy().copy()
     outs = []
     for buf, off, dims, name in g.outs:
         if buf in alias_of:

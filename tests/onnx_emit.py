@@ -156,6 +156,37 @@ class Emitter:
                     attrs.append(OW.attr_int("count_include_pad", 1))
                 self.node("MaxPool" if t == M.OP_MAXPOOL else "AveragePool", [self.read(ins[0])], [y], attrs)
                 self.wrote(out, y)
+            elif t == M.OP_WSUM:
+                # BiFPN / CBFuse style node as exporters write it: [Resize(nearest, x2)] -> Mul(constant) per input, a chain of Adds, activation
+                terms = []
+                for v, wgt in zip(ins, op["params"]):
+                    a = self.read(v)
+                    if v.h * 2 == out.h:
+                        u, sc = self.name("up"), self.name("scales")
+                        self.inits.append(OW.tensor(sc, np.asarray([1, 1, 2, 2], np.float32)))
+                        self.node("Resize", [a, "", sc], [u], [OW.attr_str("mode", "nearest")])
+                        a = u
+                    if float(np.float32(wgt)) != 1.0:
+                        cw, mu = self.name("fw"), self.name("scaled")
+                        self.inits.append(OW.tensor(cw, np.asarray(np.float32(wgt)).reshape(())))
+                        self.node("Mul", [a, cw], [mu])
+                        a = mu
+                    terms.append(a)
+                acc = terms[0]
+                for a in terms[1:]:
+                    nx = self.name("sum")
+                    self.node("Add", [acc, a], [nx])
+                    acc = nx
+                if op["act"] == M.ACT_SILU:
+                    sg, y = self.name("sig"), self.name("act")
+                    self.node("Sigmoid", [acc], [sg])
+                    self.node("Mul", [acc, sg], [y])
+                    acc = y
+                elif op["act"] == M.ACT_RELU:
+                    y = self.name("act")
+                    self.node("Relu", [acc], [y])
+                    acc = y
+                self.wrote(out, acc)
             elif t == M.OP_UPSAMPLE2:
                 y, sc = self.name("up"), self.name("scales")
                 self.inits.append(OW.tensor(sc, np.asarray([1, 1, 2, 2], np.float32)))

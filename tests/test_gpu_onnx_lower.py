@@ -60,3 +60,22 @@ def test_v5_layout_onnx_runs_through_hipengine(tmp_path):
     e.close()
     assert got.shape == want.shape
     assert float(np.abs(got - want).max()) <= 1e-3 * max(1.0, float(np.abs(want).max()))
+
+
+@pytest.mark.parametrize("prec,tol", [("fp32", 1e-5), ("fp16x3", 1e-5), ("fp16", 5e-3)])
+def test_bifpn_style_sums_onnx_runs_through_hipengine(tmp_path, prec, tol):
+    """A graph with stand-alone sums of feature maps (weighted, up-sampled terms, swish / ReLU behind them: BiFPN / CBFuse style) as an
+    exporter writes it -> OnnxEngine: the sums run as wsum_kernel launches with the up-sampling folded into their loads."""
+    from test_onnx_lower import fuse_graph
+    g = fuse_graph(128)
+    path = str(tmp_path / "fuse.onnx")
+    onnx_emit.emit(g, path)
+    x = np.random.default_rng(3).uniform(0, 1, (2, 3, 128, 128)).astype(np.float32)
+    want = graph_interp.run(g, x)[0]
+    e = CE.OnnxEngine(path, precision=prec, max_batch=2)
+    got = np.array(e.engine_inference(x)[0], copy=True)
+    kernels = [e.layer_kernel(i, 2) for i in range(e.stats()["num_layers"])]
+    e.close()
+    rel = float(np.linalg.norm(got - want) / np.linalg.norm(want))
+    print("lowered sums graph %s: rel %.2e" % (prec, rel))
+    assert rel <= tol and kernels.count("wsum_kernel") == 4 and "upsample2_kernel" not in kernels

@@ -82,9 +82,10 @@ def test_adhoc_graph_residuals_both_orders_and_depthwise(tmp_path):
     """A graph no family has: ResNet-style pre-activation residual (Conv -> Add -> ReLU), Bottleneck-style post-activation residual,
     a depth-wise 3x3, nested concats, and a v8 Detect head on three ad-hoc pyramid levels."""
     ws = M.SynthWeights(3, gain=1.0)
-    g = M.Graph("adhoc", 3, 64, 64, ws)
+    g = M.Graph("adhoc", 3, 128, 128, ws)
     x, cin = g.input()
     x = g.conv(x, 16, 3, 2, "stem", act=M.ACT_RELU, true_cin=cin)
+    x = g.maxpool(x, 2, 2, 0, name="stem.pool")                                                # pyramid levels at stride 8 / 16 / 32
     t = g.conv(x, 16, 3, 1, "b0.conv1", act=M.ACT_RELU)
     x = g.conv(t, 16, 3, 1, "b0.conv2", act=M.ACT_RELU, res=x, res_mode=M.RES_BEFORE_ACT)
     cat = g.buf(16, 16, 48)
@@ -100,7 +101,7 @@ def test_adhoc_graph_residuals_both_orders_and_depthwise(tmp_path):
         b = g.conv(f, 64, 1, 1, "head.cv2.%d" % i, act=M.ACT_NONE, f32_out=True)
         c = g.conv(f, nc, 1, 1, "head.cv3.%d" % i, act=M.ACT_NONE, f32_out=True)
         ins += [b, c]
-        strides.append(64 // f.h)
+        strides.append(128 // f.h)
     A = sum(f.h * f.w for f in (p3, p4, p5))
     head = g.buf(1, 1, (4 + nc) * A, f32=True)
     g._op(M.OP_DETECT_V8, ins, head, params=[nc, A] + strides, name="decode")
@@ -110,6 +111,47 @@ def test_adhoc_graph_residuals_both_orders_and_depthwise(tmp_path):
     kinds = [(o["type"], o["act"], o["res_mode"]) for o in g2.ops]
     assert (M.OP_CONV, M.ACT_RELU, M.RES_BEFORE_ACT) in kinds and (M.OP_CONV, M.ACT_SILU, M.RES_AFTER_ACT) in kinds
     assert any(o["type"] == M.OP_DWCONV and o["res_mode"] == M.RES_AFTER_ACT for o in g2.ops)
+
+
+def test_standalone_sums_become_weighted_sum_ops(tmp_path):
+    """BiFPN / CBFuse style nodes -- a sum of 2-3 feature maps, terms scaled by constants, a nearest x2 Resize in front of a term, swish or
+    ReLU behind the sum -- written the way exporters write them (Resize, Mul by a scalar, a chain of Adds, Sigmoid * Mul) come back as ONE
+    weighted-sum op each (the up-sampling folded into its loads), next to convolution residuals, which stay inside their convolutions."""
+    g = fuse_graph()
+    g2, err = _roundtrip(g, tmp_path / "fuse.onnx", via_convert=True)
+    assert err == 0.0 and len(g2.ops) == len(g.ops)
+    sums = [o for o in g2.ops if o["type"] == M.OP_WSUM]
+    assert [len(o["ins"]) for o in sums] == [2, 2, 3, 2] and [o["act"] for o in sums] == [M.ACT_SILU, M.ACT_NONE, M.ACT_SILU, M.ACT_RELU]
+    assert [o["ins"][1].h * 2 == o["out"].h for o in sums] == [True, True, False, False]              # folded up-sampling where the graph had a Resize
+    np.testing.assert_allclose(sums[2]["params"][:3], M.fusion_weights([0.9, 1.1, 0.4]), rtol=0, atol=0)
+    assert not any(o["type"] == M.OP_UPSAMPLE2 for o in g2.ops)
+    assert any(o["type"] == M.OP_CONV and o["res_mode"] == M.RES_AFTER_ACT for o in g2.ops)
+
+
+def fuse_graph(hw=128):
+    ws = M.SynthWeights(4, gain=1.0)
+    g = M.Graph("fuse", 3, hw, hw, ws)
+    x, cin = g.input()
+    x = g.conv(x, 16, 3, 2, "stem", true_cin=cin)
+    x = g.conv(x, 16, 3, 2, "c2")
+    p3 = g.conv(x, 32, 3, 2, "p3")                                                             # stride 8 / 16 / 32 pyramid
+    p4 = g.conv(p3, 32, 3, 2, "p4")
+    p5 = g.conv(p4, 32, 3, 2, "p5")
+    t = g.conv(p4, 32, 3, 1, "blk.cv1")
+    p4 = g.conv(t, 32, 3, 1, "blk.cv2", res=p4, res_mode=M.RES_AFTER_ACT)                     # a residual: stays in the conv
+    td4 = g.conv(g.wsum([p4, p5], M.fusion_weights([1.3, 0.6]), "td4.fuse"), 32, 3, 1, "td4.conv")          # weighted, upsampled term, swish
+    td3 = g.wsum([p3, td4], [1.0, 1.0], "td3.sum", act=M.ACT_NONE)                                           # plain sum, upsampled term
+    bu4 = g.conv(g.wsum([p4, td4, g.maxpool(td3, 3, 2, 1, name="ds")], M.fusion_weights([0.9, 1.1, 0.4]), "bu4.fuse"), 32, 3, 1, "bu4.conv")
+    s5 = g.wsum([p5, g.maxpool(bu4, 3, 2, 1, name="ds2")], [1.0, 0.5], "s5.sum", act=M.ACT_RELU)              # ReLU behind the sum
+    ins, strides, nc = [], [], 7
+    for i, f in enumerate((td3, bu4, s5)):
+        ins += [g.conv(f, 64, 1, 1, "head.cv2.%d" % i, act=M.ACT_NONE, f32_out=True), g.conv(f, nc, 1, 1, "head.cv3.%d" % i, act=M.ACT_NONE, f32_out=True)]
+        strides.append(hw // f.h)
+    A = sum(f.h * f.w for f in (td3, bu4, s5))
+    head = g.buf(1, 1, (4 + nc) * A, f32=True)
+    g._op(M.OP_DETECT_V8, ins, head, params=[nc, A] + strides, name="decode")
+    g.output(head, 0, [1, 4 + nc, A], "output0")
+    return g
 
 
 def test_unsupported_nodes_fail_loudly_naming_the_node(tmp_path):

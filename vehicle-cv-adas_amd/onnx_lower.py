@@ -145,11 +145,140 @@ class _Lowering:
                         out = self.nodes[j]["outputs"][0]
                 rec.update(act=act, out=out)
                 ops.append(("conv", i, rec))
+            elif op == "Add" and self._is_free_sum(nd):
+                # a stand-alone sum of feature maps (BiFPN fusion node, CBFuse, an identity shortcut around a block): the chain of Adds,
+                # the constant scale in front of a term (Mul by a scalar initializer), a nearest x2 Resize that only this sum reads and the
+                # activation behind it collapse into ONE weighted-sum op
+                terms = self._sum_terms(nd["outputs"][0], used, i)
+                if terms is None or not 2 <= len(terms) <= 3:
+                    ops.append(("other", i, {}))
+                    continue
+                act, out = self._absorb_act(nd["outputs"][0], used)
+                ops.append(("wsum", i, dict(terms=terms, act=act, out=out, name=(nd["name"].strip("/").replace("/", ".") or "sum%d" % i)[-47:])))
+            elif op in ("Mul", "Resize", "Upsample") and self._feeds_only_free_sum(nd):
+                continue          # folded into the weighted sum that consumes it (emitted there)
             elif op in ("MaxPool", "AveragePool", "Resize", "Upsample", "Concat", "Split", "Slice", "Identity"):
                 ops.append((op.lower(), i, {}))
             else:
                 ops.append(("other", i, {}))
         return ops
+
+    # ---- stand-alone sums
+    def _is_free_sum(self, nd):
+        """An Add of two non-constant tensors that is the END of its chain (its output does not feed another Add of the same kind through a
+        single-consumer link) and is not a convolution's residual (those are absorbed before this node is reached)."""
+        if len(nd["inputs"]) != 2 or any(x in self.m.initializers for x in nd["inputs"]):
+            return False
+        j = self._single_consumer(nd["outputs"][0], "Add")
+        if j is not None and not any(x in self.m.initializers for x in self.nodes[j]["inputs"]):
+            return False          # an inner link of a longer chain: handled from the chain's last Add
+        return True
+
+    def _term(self, t, used):
+        """(source tensor, weight, upsampled) of one term: through Mul(x, scalar constant) and a nearest x2 Resize read by nobody else."""
+        wgt, up = 1.0, False
+        for _ in range(3):
+            i = self.producer.get(t)
+            if i is None or len(self.consumers.get(t, [])) != 1 or t in self.graph_outs:
+                break
+            nd = self.nodes[i]
+            if nd["op"] == "Mul":
+                cs = [x for x in nd["inputs"] if x in self.m.initializers and np.asarray(self.m.initializers[x]).size == 1]
+                xs = [x for x in nd["inputs"] if x not in self.m.initializers]
+                if len(cs) != 1 or len(xs) != 1:
+                    break
+                wgt *= float(np.asarray(self.m.initializers[cs[0]], np.float32).reshape(-1)[0])
+                used.add(i)
+                t = xs[0]
+            elif nd["op"] in ("Resize", "Upsample") and not up:
+                used.add(i)
+                up = True
+                t = nd["inputs"][0]
+            else:
+                break
+        return t, wgt, up
+
+    def _sum_terms(self, t, used, last):
+        """Terms of the Add chain ending in tensor t, left to right; inner Adds are marked used."""
+        nd = self.nodes[self.producer[t]]
+        terms = []
+        for x in nd["inputs"]:
+            i = self.producer.get(x)
+            if i is not None and self.nodes[i]["op"] == "Add" and len(self.consumers.get(x, [])) == 1 and x not in self.graph_outs and \
+                    not any(y in self.m.initializers for y in self.nodes[i]["inputs"]) and i not in used:
+                inner = self._sum_terms(x, used, last)
+                if inner is None:
+                    return None
+                used.add(i)
+                terms += inner
+            else:
+                terms.append(self._term(x, used))
+        return terms
+
+    def _feeds_only_free_sum(self, nd):
+        """Mul-by-constant / Resize nodes in front of a stand-alone sum are visited BEFORE the Add (graph order): decide here, without the
+        `used` set, whether the sum will swallow them."""
+        if nd["op"] == "Mul":     # only a scale by a scalar constant is a term's weight (x * sigmoid(x), x * gate are not)
+            cs = [x for x in nd["inputs"] if x in self.m.initializers and np.asarray(self.m.initializers[x]).size == 1]
+            if len(cs) != 1 or len(nd["inputs"]) != 2:
+                return False
+        t = nd["outputs"][0]
+        for _ in range(3):
+            c = self.consumers.get(t, [])
+            if len(c) != 1 or t in self.graph_outs:
+                return False
+            nx = self.nodes[c[0]]
+            if nx["op"] == "Add":
+                if any(x in self.m.initializers for x in nx["inputs"]):
+                    return False
+                # walk to the end of the chain and ask whether THAT add is a free sum whose term count fits
+                end = nx
+                while True:
+                    j = self._single_consumer(end["outputs"][0], "Add")
+                    if j is None or any(x in self.m.initializers for x in self.nodes[j]["inputs"]):
+                        break
+                    end = self.nodes[j]
+                if not self._is_free_sum(end):
+                    return False
+                n_terms = self._count_terms(end["outputs"][0])
+                return 2 <= n_terms <= 3 and self._is_sum_not_residual(end)
+            if nx["op"] == "Mul" and nd["op"] != "Mul":
+                cs = [x for x in nx["inputs"] if x in self.m.initializers and np.asarray(self.m.initializers[x]).size == 1]
+                if len(cs) != 1:
+                    return False
+                t = nx["outputs"][0]
+                continue
+            return False
+        return False
+
+    def _count_terms(self, t):
+        nd = self.nodes[self.producer[t]]
+        n = 0
+        for x in nd["inputs"]:
+            i = self.producer.get(x)
+            if i is not None and self.nodes[i]["op"] == "Add" and len(self.consumers.get(x, [])) == 1 and x not in self.graph_outs and \
+                    not any(y in self.m.initializers for y in self.nodes[i]["inputs"]):
+                n += self._count_terms(x)
+            else:
+                n += 1
+        return n
+
+    def _is_sum_not_residual(self, end):
+        """False when the chain's last Add is one a convolution absorbs as its residual (Conv -> Add, Conv -> act -> Add)."""
+        for x in end["inputs"]:
+            i = self.producer.get(x)
+            if i is None:
+                continue
+            src = self.nodes[i]
+            if src["op"] == "Conv" and len(self.consumers.get(x, [])) == 1:
+                return False
+            if src["op"] in ("Relu", "LeakyRelu", "Mul") and len(self.consumers.get(x, [])) == 1:
+                # activation of a convolution?  (Mul = x * sigmoid(x))
+                y = src["inputs"][0]
+                k = self.producer.get(y)
+                if k is not None and self.nodes[k]["op"] == "Conv":
+                    return False
+        return True
 
     def _is_act_input(self, t):
         c = self.consumers.get(t, [])
@@ -175,7 +304,7 @@ class _Lowering:
         # the network body = the ancestors of the Detect inputs (the tail's own nodes, and whatever only feeds them, are the Detect op)
         made_by = {}
         for kind, i, rec in ops:
-            if kind in ("conv", "deconv"):
+            if kind in ("conv", "deconv", "wsum"):
                 made_by[rec["out"]] = (kind, i, rec)
             else:
                 for o in self.nodes[i]["outputs"]:
@@ -192,7 +321,7 @@ class _Lowering:
                 continue
             need.add(i)
             srcs = [rec["x"]] + ([rec["res"]] if rec.get("res") is not None else []) if kind in ("conv", "deconv") else \
-                [x for x in self.nodes[i]["inputs"] if x and x not in m.initializers]
+                [t_ for t_, _, _ in rec["terms"]] if kind == "wsum" else [x for x in self.nodes[i]["inputs"] if x and x not in m.initializers]
             todo += srcs
         body = [o for o in ops if o[1] in need]
         # ---- pass 1b: shapes, aliases (Split / Slice views), concat placement
@@ -232,6 +361,14 @@ class _Lowering:
                 if tuple(W.shape[2:]) != (2, 2) or st != [2, 2] or W.shape[0] != c or int(nd["attrs"].get("group", 1)) != 1:
                     raise LowerError("node %s: only ConvTranspose2d(kernel 2, stride 2) is built" % nd["name"])
                 self.shape[rec["out"]] = (W.shape[1], 2 * h, 2 * w_)
+            elif kind == "wsum":
+                shp = []
+                for t_, _, up in rec["terms"]:
+                    c, h, w_ = self._shape(t_)
+                    shp.append((c, 2 * h, 2 * w_) if up else (c, h, w_))
+                if len(set(shp)) != 1 or shp[0][0] % 8:
+                    raise LowerError("node %s: sum of maps of shapes %s (one shape, channels a multiple of 8)" % (nd["name"], shp))
+                self.shape[rec["out"]] = shp[0]
             elif kind in ("maxpool", "averagepool"):
                 c, h, w_ = self._shape(nd["inputs"][0])
                 ks = _ints(m, nd, "kernel_shape", None)
@@ -290,8 +427,8 @@ class _Lowering:
                     raise LowerError("node %s: Concat of different spatial sizes %s" % (nd["name"], shp))
                 self.shape[nd["outputs"][0]] = (sum(s[0] for s in shp), shp[0][1], shp[0][2])
             else:
-                raise LowerError("node %s: op %s has no counterpart in the engine (stand-alone element-wise arithmetic and attention need a "
-                                 "hand-written builder)" % (nd["name"] or "#%d" % i, nd["op"]))
+                raise LowerError("node %s: op %s has no counterpart in the engine (attention and element-wise arithmetic other than sums of 2-3 "
+                                 "feature maps need a hand-written builder)" % (nd["name"] or "#%d" % i, nd["op"]))
 
         # concat placement, in graph order
         for kind, i, rec in body:
@@ -355,6 +492,9 @@ class _Lowering:
                            true_cin=true_cin, pad=rec["p"], weight=rec["w"], bias_arr=b)
                 g.n_params += rec["w"].size + (rec["b"].size if rec["b"] is not None else 0)
                 first = False
+            elif kind == "wsum":
+                views = [self._view(t_) for t_, _, _ in rec["terms"]]
+                g.wsum(views, [w_ for _, w_, _ in rec["terms"]], rec["name"], act=rec["act"], out=self._view(rec["out"], make=True))
             elif kind == "deconv":
                 xin, out = self._view(rec["x"]), self._view(rec["out"], make=True)
                 W, b = rec["w"], rec["b"] if rec["b"] is not None else np.zeros(rec["w"].shape[1], np.float32)
