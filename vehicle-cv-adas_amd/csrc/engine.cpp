@@ -996,8 +996,11 @@ int engine_run_op(adas_engine* e, int i, const float* d_in, int batch, hipStream
         case OP_SE_GATE: {
             const float* w1 = (const float*)(wb + op.w_off);
             const float* w2 = (const float*)(wb + op.b_off);
+            TView scratch{};
+            const bool has_scratch = o.res_buf >= 0 && o.res_buf < (int32_t)e->bufs.size();   // res_buf: the per-frame scratch of the two-launch form
+            if (has_scratch) scratch = make_view(e, o.res_buf, 0, e->bufs[o.res_buf].c);
             err = launch_se_gate(make_view(e, o.in_buf[0], o.in_coff[0], o.in_c[0]), make_view(e, o.out_buf, o.out_coff, o.out_c), w1, w2, (int)o.params[0], batch,
-                                 e->prec, st);
+                                 e->prec, st, has_scratch ? &scratch : nullptr);
             break;
         }
         case OP_SCALE:

@@ -21,7 +21,39 @@ struct SeDev {
     const float* w2;     // [c][cr] then b2[c]
     int in_cs, in_coff, gate_cs, gate_coff;
     int c, cr, HW, S;    // S: pixel stripes (1024 / (c / 8))
+    float* part;         // two-launch form: [n][P][c] partial channel sums written by se_partial_kernel (null: this kernel sums the frame itself)
+    int P;
 };
+
+// Partial channel sums of pixel range p of frame b (grid = n * P workgroups): one workgroup per frame leaves 64 of 256 CUs busy on a
+// 64-frame batch and reads 4 MB through one CU's L1 on the large maps; P ranges per frame fill the chip.  Fixed order: stripes of a
+// range are reduced in index order here, ranges in index order by the gate kernel.
+template <typename T>
+__global__ __launch_bounds__(256) void se_partial_kernel(SeDev d) {
+    if constexpr (sizeof(T) == 2 && !__is_same(T, uint16_t)) Fp16::enter();
+    extern __shared__ float sm[];   // [S][c]
+    const int b = blockIdx.x / d.P, p = blockIdx.x - b * d.P, t = threadIdx.x, G = d.c >> 3;
+    const int S = d.S, g = t % G, s = t / G;
+    const int lo = (int)((long)d.HW * p / d.P), hi = (int)((long)d.HW * (p + 1) / d.P);
+    if (s < S) {
+        float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        const T* base = (const T*)d.in + (size_t)b * d.HW * d.in_cs + d.in_coff + g * 8;
+        for (int q = lo + s; q < hi; q += S) {
+            float x[8];
+            Vec8<T>::load(base + (size_t)q * d.in_cs, x);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[e] += x[e];
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) sm[s * d.c + g * 8 + e] = acc[e];
+    }
+    __syncthreads();
+    for (int ch = t; ch < d.c; ch += 256) {
+        float m = 0.f;
+        for (int q = 0; q < S; ++q) m += sm[q * d.c + ch];
+        d.part[((size_t)b * d.P + p) * d.c + ch] = m;
+    }
+}
 
 template <typename T>
 __global__ __launch_bounds__(1024) void se_gate_kernel(SeDev d) {
@@ -32,23 +64,31 @@ __global__ __launch_bounds__(1024) void se_gate_kernel(SeDev d) {
     float* hid = mean + d.c;          // [cr]
     const int n = blockIdx.x, t = threadIdx.x, G = d.c >> 3;
     const int g = t % G, s = t / G;
-    if (s < d.S) {
-        float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        const T* base = (const T*)d.in + (size_t)n * d.HW * d.in_cs + d.in_coff + g * 8;
-        for (int p = s; p < d.HW; p += d.S) {
-            float x[8];
-            Vec8<T>::load(base + (size_t)p * d.in_cs, x);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) acc[e] += x[e];
+    if (d.part) {   // two-launch form: the ranges' partial sums, in range order
+        for (int ch = t; ch < d.c; ch += 1024) {
+            float m = 0.f;
+            for (int q = 0; q < d.P; ++q) m += d.part[((size_t)n * d.P + q) * d.c + ch];
+            mean[ch] = m / (float)d.HW;
         }
+    } else {
+        if (s < d.S) {
+            float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            const T* base = (const T*)d.in + (size_t)n * d.HW * d.in_cs + d.in_coff + g * 8;
+            for (int p = s; p < d.HW; p += d.S) {
+                float x[8];
+                Vec8<T>::load(base + (size_t)p * d.in_cs, x);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) part[s * d.c + g * 8 + e] = acc[e];
-    }
-    __syncthreads();
-    for (int ch = t; ch < d.c; ch += 1024) {
-        float m = 0.f;
-        for (int q = 0; q < d.S; ++q) m += part[q * d.c + ch];
-        mean[ch] = m / (float)d.HW;
+                for (int e = 0; e < 8; ++e) acc[e] += x[e];
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) part[s * d.c + g * 8 + e] = acc[e];
+        }
+        __syncthreads();
+        for (int ch = t; ch < d.c; ch += 1024) {
+            float m = 0.f;
+            for (int q = 0; q < d.S; ++q) m += part[q * d.c + ch];
+            mean[ch] = m / (float)d.HW;
+        }
     }
     __syncthreads();
     const int lane = t & 63, wave = t >> 6;
@@ -76,12 +116,26 @@ bool se_gate_supported(const TView& in, const TView& gate, int cr, uint64_t w_el
     return w_elems == (uint64_t)cr * in.c + cr && b_elems == (uint64_t)in.c * cr + in.c;
 }
 
-hipError_t launch_se_gate(const TView& in, const TView& gate, const float* w1, const float* w2, int cr, int n, int prec, hipStream_t st) {
+hipError_t launch_se_gate(const TView& in, const TView& gate, const float* w1, const float* w2, int cr, int n, int prec, hipStream_t st, const TView* scratch) {
     SeDev d;
+    d.part = nullptr; d.P = 0;
     d.in = in.p; d.gate = (float*)gate.p; d.w1 = w1; d.w2 = w2;
     d.in_cs = in.cs; d.in_coff = in.coff; d.gate_cs = gate.cs; d.gate_coff = gate.coff;
     d.c = in.c; d.cr = cr; d.HW = in.h * in.w;
     const int G = in.c >> 3;
+    if (scratch && scratch->p && scratch->f32 && G <= 256 && scratch->c >= in.c && scratch->c % in.c == 0 && d.HW >= 4 * (scratch->c / in.c)) {
+        // two launches: P pixel ranges per frame (P = scratch channels / C), then the gate from the ranges' sums
+        d.part = (float*)scratch->p; d.P = scratch->c / in.c;
+        SeDev a = d;
+        a.S = 256 / G;
+        const size_t la = (size_t)a.S * d.c * 4;
+        if (prec == PREC_FP32) hipLaunchKernelGGL(se_partial_kernel<float>, dim3(n * d.P), dim3(256), la, st, a);
+        else if (prec == PREC_X3) hipLaunchKernelGGL(se_partial_kernel<x3s>, dim3(n * d.P), dim3(256), la, st, a);
+        else if (prec == PREC_FP16) hipLaunchKernelGGL(se_partial_kernel<f16s>, dim3(n * d.P), dim3(256), la, st, a);
+        else hipLaunchKernelGGL(se_partial_kernel<uint16_t>, dim3(n * d.P), dim3(256), la, st, a);
+        // the scratch buffer is laid out per frame by the engine ([frame][P * C]): frame stride = scratch->cs
+        if (scratch->cs != scratch->c) return hipErrorInvalidValue;
+    }
     d.S = 1024 / G;
     if (d.S < 1) return hipErrorInvalidValue;
     if (d.S > d.HW) d.S = d.HW;

@@ -190,7 +190,8 @@ hipError_t launch_pack_weights_fc(const float* src, void* dst, int cout, int cou
 // dw_attn.hip: depth-wise k x k conv (k = 3 | 7, stride 1 | 2, pad k/2; weights fp32 [k*k][C], bias fp32 [C]; residual: RES_AFTER_ACT only)
 // fuse_ops.hip: EfficientDet's element-wise operators (squeeze-and-excitation gate, channel scale, BiFPN weighted sum)
 bool se_gate_supported(const TView& in, const TView& gate, int cr, uint64_t w_elems, uint64_t b_elems);
-hipError_t launch_se_gate(const TView& in, const TView& gate, const float* w1, const float* w2, int cr, int n, int prec, hipStream_t st);
+hipError_t launch_se_gate(const TView& in, const TView& gate, const float* w1, const float* w2, int cr, int n, int prec, hipStream_t st,
+                          const TView* scratch = nullptr);   // scratch: fp32 1x1x(P*C) per frame -> P pixel ranges summed by their own launch
 bool scale_supported(const TView& in, const TView& gate, const TView& out);
 hipError_t launch_scale(const TView& in, const TView& gate, const TView& out, int n, int prec, hipStream_t st);
 bool wsum_supported(int n_in, const TView* ins, const TView& out);

@@ -309,8 +309,12 @@ class Graph:
         W1, b1 = self.w(name + ".reduce.weight", (cr, c, 1, 1), "conv"), self.w(name + ".reduce.bias", (cr,), "bias")
         W2, b2 = self.w(name + ".expand.weight", (c, cr, 1, 1), "conv"), self.w(name + ".expand.bias", (c,), "bias")
         gate = self.buf(1, 1, c, f32=True)
+        # maps of >= 1024 pixels: 16 pixel ranges per frame are summed by their own launch into this scratch (res slot of the op), so
+        # that a batch fills the chip; the gate kernel then adds the ranges in order (results do not depend on the split being used:
+        # the sums are the same stripes in another grouping -- fp32, ~1e-7 apart)
+        scratch = self.buf(1, 1, 16 * c, f32=True) if x.h * x.w >= 1024 and c <= 2048 else None
         self._op(OP_SE_GATE, [x], gate, w=self._blob(np.concatenate([W1.ravel(), b1])), b=self._blob(np.concatenate([W2.ravel(), b2])),
-                 params=[cr], flops=x.h * x.w * c + 4.0 * c * cr, name=name + ".gate")
+                 res=scratch, params=[cr], flops=x.h * x.w * c + 4.0 * c * cr, name=name + ".gate")
         if out is None:
             out = self.buf(x.h, x.w, c)
         assert (out.h, out.w, out.c) == (x.h, x.w, c)
