@@ -156,6 +156,27 @@ class Emitter:
                     attrs.append(OW.attr_int("count_include_pad", 1))
                 self.node("MaxPool" if t == M.OP_MAXPOOL else "AveragePool", [self.read(ins[0])], [y], attrs)
                 self.wrote(out, y)
+            elif t == M.OP_SE_GATE:
+                # squeeze-and-excitation as torch exports it: GlobalAveragePool -> Conv -> Sigmoid * Mul (swish) -> Conv -> Sigmoid;  the
+                # gate tensor (N, C, 1, 1) multiplies x in the OP_SCALE that follows
+                c, cr = ins[0].c, int(op["params"][0])
+                w_, b_ = self.blob[wo // 4: wo // 4 + wn], self.blob[bo // 4: bo // 4 + bn]
+                base = op["name"][:-len(".gate")] if op["name"].endswith(".gate") else op["name"]
+                n1, n2 = base + ".reduce", base + ".expand"
+                self.inits += [OW.tensor(n1 + ".weight", w_[:cr * c].reshape(cr, c, 1, 1)), OW.tensor(n1 + ".bias", w_[cr * c:]),
+                               OW.tensor(n2 + ".weight", b_[:c * cr].reshape(c, cr, 1, 1)), OW.tensor(n2 + ".bias", b_[c * cr:])]
+                gp, r1, sg, a1, e1, gate = (self.name(n) for n in ("gap", "se_r", "se_sig", "se_a", "se_e", "se_gate"))
+                self.node("GlobalAveragePool", [self.read(ins[0])], [gp])
+                self.node("Conv", [gp, n1 + ".weight", n1 + ".bias"], [r1], [OW.attr_ints("kernel_shape", [1, 1])])
+                self.node("Sigmoid", [r1], [sg])
+                self.node("Mul", [r1, sg], [a1])
+                self.node("Conv", [a1, n2 + ".weight", n2 + ".bias"], [e1], [OW.attr_ints("kernel_shape", [1, 1])])
+                self.node("Sigmoid", [e1], [gate])
+                self.wrote(out, gate)
+            elif t == M.OP_SCALE:
+                y = self.name("se_out")
+                self.node("Mul", [self.read(ins[0]), self.read(ins[1])], [y])
+                self.wrote(out, y)
             elif t == M.OP_WSUM:
                 # BiFPN / CBFuse style node as exporters write it: [Resize(nearest, x2)] -> Mul(constant) per input, a chain of Adds, activation
                 terms = []
@@ -249,6 +270,24 @@ class Emitter:
                 outputs.append((out_name, [1, A, no]))
             else:
                 raise NotImplementedError("emitter: op type %d (%s)" % (t, op["name"]))
+        if not outputs and g.outs and all(nm.startswith(("regression.l", "classification.l")) for _, _, _, nm in g.outs):
+            # head-only export of an anchor-based detector (EfficientDet without decode / NMS): per level conv -> Transpose(NHWC) -> Reshape
+            # (1, -1, k), levels concatenated along axis 1: two outputs
+            cols = {"regression": [], "classification": []}
+            per = {}
+            for buf, off, dims, nm in g.outs:
+                kind = nm.split(".")[0]
+                h_, w_, c_, _ = g.bufs[buf]
+                t = self.read(M.View(buf, 0, c_, h_, w_))
+                tr, rs, shp = self.name("nhwc"), self.name("rows"), self.name("shape")
+                self.node("Transpose", [t], [tr], [OW.attr_ints("perm", [0, 2, 3, 1])])
+                self.inits.append(_i64(shp, [1, -1, int(dims[2])]))
+                self.node("Reshape", [tr, shp], [rs])
+                cols[kind].append(rs)
+                per[kind] = (int(dims[2]), per.get(kind, (0, 0))[1] + int(dims[1]))
+            for kind in ("regression", "classification"):
+                self.node("Concat", cols[kind], [kind], [OW.attr_int("axis", 1)])
+                outputs.append((kind, [1, per[kind][1], per[kind][0]]))
         assert outputs, "graph has no Detect op (the emitter writes detector graphs)"
         data = OW.model(self.nodes, self.inits, [("images", [1, g.in_c, g.in_h, g.in_w])], outputs)
         open(path, "wb").write(data)

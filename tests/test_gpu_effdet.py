@@ -190,3 +190,26 @@ def test_efficientdet_detector_end_to_end(tmp_path, prec):
     print("efficientdet detector %s: %d candidates, %d boxes over %.2f on 5 frames" % (prec, n_cand, n_total, thr))
     assert n_cand >= 1000 and n_total >= 50
     raw.close(); det.close()
+
+
+def test_efficientdet_from_a_head_only_onnx_file(tmp_path):
+    """EfficientdetDetector(model_path="...onnx"): a head-only export (two outputs: box regression and class logits over all levels) goes
+    through the generic ONNX lowering (squeeze-and-excitation, BiFPN sums, separable heads recognised node by node) and gives the
+    detections of the container-built graph, bit for bit."""
+    import onnx_emit
+    path, W, g = netutil.model("efficientdet-d0")
+    onnx_path = str(tmp_path / "efficientdet-d0_heads.onnx")
+    onnx_emit.emit(g, onnx_path)
+    lab = tmp_path / "coco90.txt"
+    lab.write_text("\n".join("c%d" % i for i in range(90)))
+    da = D.EfficientdetDetector(model_path=path, classes_path=str(lab), box_score=0.08, precision="fp16")
+    db = D.EfficientdetDetector(model_path=onnx_path, classes_path=str(lab), box_score=0.08, precision="fp16")
+    n = 0
+    for f in _frames(3, 77):
+        da.DetectFrame(f); db.DetectFrame(f)
+        assert len(da.object_info) == len(db.object_info)
+        for a, b in zip(da.object_info, db.object_info):
+            assert (a.x, a.y, a.width, a.height, a.conf, a.label) == (b.x, b.y, b.width, b.height, b.conf, b.label)
+        n += len(da.object_info)
+    assert n >= 50
+    da.close(); db.close()

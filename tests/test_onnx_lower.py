@@ -128,6 +128,56 @@ def test_standalone_sums_become_weighted_sum_ops(tmp_path):
     assert any(o["type"] == M.OP_CONV and o["res_mode"] == M.RES_AFTER_ACT for o in g2.ops)
 
 
+def test_mbconv_blocks_with_squeeze_and_excitation(tmp_path):
+    """EfficientNet-style inverted-residual blocks (1x1 expand, depth-wise 3x3 / 5x5, swish squeeze-and-excitation, linear 1x1 project with
+    an identity skip) as torch exports them -- GlobalAveragePool -> Conv -> Sigmoid * Mul -> Conv -> Sigmoid -> Mul(x, gate) -- come back as
+    the gate + scale operator pair; the skip stays inside the project convolution."""
+    ws = M.SynthWeights(6, gain=1.0)
+    g = M.Graph("mb", 3, 128, 128, ws)
+    x, cin = g.input()
+    x = g.conv(x, 16, 3, 2, "stem", true_cin=cin)
+    x = M._mbconv(g, x, "blocks.0", 1, 3, 1, 16)           # expand ratio 1, skip
+    x = M._mbconv(g, x, "blocks.1", 6, 3, 2, 24)
+    p3 = M._mbconv(g, x, "blocks.2", 6, 5, 2, 40)           # stride 8
+    t = M._mbconv(g, p3, "blocks.3", 6, 5, 1, 40)           # skip
+    p4 = M._mbconv(g, t, "blocks.4", 6, 3, 2, 80)
+    p5 = M._mbconv(g, p4, "blocks.5", 6, 5, 2, 112)
+    ins, strides, nc = [], [], 8
+    for i, f in enumerate((t, p4, p5)):
+        ins += [g.conv(f, 64, 1, 1, "head.cv2.%d" % i, act=M.ACT_NONE, f32_out=True), g.conv(f, nc, 1, 1, "head.cv3.%d" % i, act=M.ACT_NONE, f32_out=True)]
+        strides.append(128 // f.h)
+    A = sum(f.h * f.w for f in (t, p4, p5))
+    head = g.buf(1, 1, (4 + nc) * A, f32=True)
+    g._op(M.OP_DETECT_V8, ins, head, params=[nc, A] + strides, name="decode")
+    g.output(head, 0, [1, 4 + nc, A], "output0")
+    g2, err = _roundtrip(g, tmp_path / "mb.onnx", via_convert=True)
+    assert err == 0.0 and len(g2.ops) == len(g.ops)
+    assert sum(o["type"] == M.OP_SE_GATE for o in g2.ops) == 6 and sum(o["type"] == M.OP_SCALE for o in g2.ops) == 6
+    assert [int(o["params"][0]) for o in g2.ops if o["type"] == M.OP_SE_GATE] == [4, 4, 6, 10, 10, 20]       # squeeze widths = 0.25 x block input
+    assert sum(o["type"] == M.OP_CONV and o["res_mode"] == M.RES_AFTER_ACT for o in g2.ops) == 2
+
+
+def test_efficientdet_d0_head_only_export_round_trip(tmp_path):
+    """The whole EfficientDet-D0 graph (253 operators: MBConv + squeeze-and-excitation, three BiFPN cells, shared separable heads) written as a
+    head-only ONNX export -- two outputs, box regression (1, A, 4) and class logits (1, A, 90) as axis-1 Concats of per-level
+    Reshape(Transpose(conv)) -- and lowered back: the same op list, the ten per-level outputs EfficientdetEngine feeds to the device tail."""
+    ws = M.SynthWeights(0, gain=M.synth_gain("efficientdet-d0"))
+    g = M.build("efficientdet-d0", wsrc=ws, imgsz=(128, 128))
+    path = str(tmp_path / "effdet_heads.onnx")
+    onnx_emit.emit(g, path)
+    m = OI.read_onnx(path)
+    assert [o for o, _ in m.outputs] == ["regression", "classification"] and m.outputs[0][1] == [1, 9 * (256 + 64 + 16 + 4 + 1), 4]
+    hipm, g2 = OI.convert(path, path + ".hipm")
+    assert [nm for _, _, _, nm in g2.outs] == [nm for _, _, _, nm in g.outs] and len(g2.ops) == len(g.ops)
+    x = np.random.default_rng(0).uniform(-1, 1, (2, 3, 128, 128)).astype(np.float32)
+    a, b = graph_interp.run(g, x), graph_interp.run(g2, x)
+    assert len(a) == len(b) == 10
+    for u, v in zip(a, b):
+        np.testing.assert_array_equal(u, v)
+    kinds = [o["type"] for o in g2.ops]
+    assert kinds.count(M.OP_SE_GATE) == 16 and kinds.count(M.OP_WSUM) == 24 and kinds.count(M.OP_UPSAMPLE2) == 0
+
+
 def fuse_graph(hw=128):
     ws = M.SynthWeights(4, gain=1.0)
     g = M.Graph("fuse", 3, hw, hw, ws)

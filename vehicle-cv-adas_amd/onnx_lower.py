@@ -145,6 +145,9 @@ class _Lowering:
                         out = self.nodes[j]["outputs"][0]
                 rec.update(act=act, out=out)
                 ops.append(("conv", i, rec))
+            elif op == "GlobalAveragePool":
+                rec = self._match_se(i, used)
+                ops.append(("se", i, rec) if rec is not None else ("other", i, {}))
             elif op == "Add" and self._is_free_sum(nd):
                 # a stand-alone sum of feature maps (BiFPN fusion node, CBFuse, an identity shortcut around a block): the chain of Adds,
                 # the constant scale in front of a term (Mul by a scalar initializer), a nearest x2 Resize that only this sum reads and the
@@ -162,6 +165,47 @@ class _Lowering:
             else:
                 ops.append(("other", i, {}))
         return ops
+
+    # ---- squeeze-and-excitation
+    def _match_se(self, i, used):
+        """GlobalAveragePool(x) -> Conv 1x1 -> swish -> Conv 1x1 -> Sigmoid -> Mul(x, .): one gate + scale pair (OP_SE_GATE, OP_SCALE).  Returns
+        None when the nodes behind the pool are anything else (the pool is then reported as unsupported)."""
+        nd = self.nodes[i]
+        x, t = nd["inputs"][0], nd["outputs"][0]
+        j1 = self._single_consumer(t, "Conv")
+        if j1 is None:
+            return None
+        c1 = self.nodes[j1]
+        w1 = _const(self.m, c1["inputs"][1]) if len(c1["inputs"]) > 1 else None
+        b1 = _const(self.m, c1["inputs"][2]) if len(c1["inputs"]) > 2 and c1["inputs"][2] else None
+        if w1 is None or np.asarray(w1).ndim != 4 or tuple(np.asarray(w1).shape[2:]) != (1, 1):
+            return None
+        tmp = set()
+        act, a = self._absorb_act(c1["outputs"][0], tmp)
+        if act != M.ACT_SILU:
+            return None
+        j2 = self._single_consumer(a, "Conv")
+        if j2 is None:
+            return None
+        c2 = self.nodes[j2]
+        w2 = _const(self.m, c2["inputs"][1]) if len(c2["inputs"]) > 1 else None
+        b2 = _const(self.m, c2["inputs"][2]) if len(c2["inputs"]) > 2 and c2["inputs"][2] else None
+        if w2 is None or tuple(np.asarray(w2).shape[2:]) != (1, 1) or np.asarray(w2).shape[:2] != np.asarray(w1).shape[1::-1]:
+            return None
+        j3 = self._single_consumer(c2["outputs"][0], "Sigmoid")
+        if j3 is None:
+            return None
+        j4 = self._single_consumer(self.nodes[j3]["outputs"][0], "Mul")
+        if j4 is None or sorted(self.nodes[j4]["inputs"]) != sorted([x, self.nodes[j3]["outputs"][0]]):
+            return None
+        used.update(tmp)
+        used.update((j1, j2, j3, j4))
+        w1, w2 = np.asarray(w1, np.float32), np.asarray(w2, np.float32)
+        name = self._layer_name(c1)
+        name = name[:-len(".reduce")] if name.endswith(".reduce") else name
+        return dict(x=x, out=self.nodes[j4]["outputs"][0], name=name[-40:], w1=w1, w2=w2,
+                    b1=np.asarray(b1, np.float32) if b1 is not None else np.zeros(w1.shape[0], np.float32),
+                    b2=np.asarray(b2, np.float32) if b2 is not None else np.zeros(w2.shape[0], np.float32))
 
     # ---- stand-alone sums
     def _is_free_sum(self, nd):
@@ -304,7 +348,7 @@ class _Lowering:
         # the network body = the ancestors of the Detect inputs (the tail's own nodes, and whatever only feeds them, are the Detect op)
         made_by = {}
         for kind, i, rec in ops:
-            if kind in ("conv", "deconv", "wsum"):
+            if kind in ("conv", "deconv", "wsum", "se"):
                 made_by[rec["out"]] = (kind, i, rec)
             else:
                 for o in self.nodes[i]["outputs"]:
@@ -321,7 +365,8 @@ class _Lowering:
                 continue
             need.add(i)
             srcs = [rec["x"]] + ([rec["res"]] if rec.get("res") is not None else []) if kind in ("conv", "deconv") else \
-                [t_ for t_, _, _ in rec["terms"]] if kind == "wsum" else [x for x in self.nodes[i]["inputs"] if x and x not in m.initializers]
+                [t_ for t_, _, _ in rec["terms"]] if kind == "wsum" else [rec["x"]] if kind == "se" else \
+                [x for x in self.nodes[i]["inputs"] if x and x not in m.initializers]
             todo += srcs
         body = [o for o in ops if o[1] in need]
         # ---- pass 1b: shapes, aliases (Split / Slice views), concat placement
@@ -361,6 +406,11 @@ class _Lowering:
                 if tuple(W.shape[2:]) != (2, 2) or st != [2, 2] or W.shape[0] != c or int(nd["attrs"].get("group", 1)) != 1:
                     raise LowerError("node %s: only ConvTranspose2d(kernel 2, stride 2) is built" % nd["name"])
                 self.shape[rec["out"]] = (W.shape[1], 2 * h, 2 * w_)
+            elif kind == "se":
+                c, h, w_ = self._shape(rec["x"])
+                if c % 8 or rec["w1"].shape[1] != c:
+                    raise LowerError("node %s: squeeze-and-excitation over %d channels (weights for %d; multiples of 8 only)" % (nd["name"], c, rec["w1"].shape[1]))
+                self.shape[rec["out"]] = (c, h, w_)
             elif kind == "wsum":
                 shp = []
                 for t_, _, up in rec["terms"]:
@@ -428,7 +478,7 @@ class _Lowering:
                 self.shape[nd["outputs"][0]] = (sum(s[0] for s in shp), shp[0][1], shp[0][2])
             else:
                 raise LowerError("node %s: op %s has no counterpart in the engine (attention and element-wise arithmetic other than sums of 2-3 "
-                                 "feature maps need a hand-written builder)" % (nd["name"] or "#%d" % i, nd["op"]))
+                                 "feature maps and swish squeeze-and-excitation gates need a hand-written builder)" % (nd["name"] or "#%d" % i, nd["op"]))
 
         # concat placement, in graph order
         for kind, i, rec in body:
@@ -492,6 +542,10 @@ class _Lowering:
                            true_cin=true_cin, pad=rec["p"], weight=rec["w"], bias_arr=b)
                 g.n_params += rec["w"].size + (rec["b"].size if rec["b"] is not None else 0)
                 first = False
+            elif kind == "se":
+                n_ = rec["name"]
+                g.w = M.DictWeights({n_ + ".reduce.weight": rec["w1"], n_ + ".reduce.bias": rec["b1"], n_ + ".expand.weight": rec["w2"], n_ + ".expand.bias": rec["b2"]})
+                g.se(self._view(rec["x"]), rec["w1"].shape[0], n_, out=self._view(rec["out"], make=True))
             elif kind == "wsum":
                 views = [self._view(t_) for t_, _, _ in rec["terms"]]
                 g.wsum(views, [w_ for _, w_, _ in rec["terms"]], rec["name"], act=rec["act"], out=self._view(rec["out"], make=True))
@@ -561,8 +615,10 @@ class _Lowering:
     # ------------------------------------------------------------------ Detect tails
     def _find_tail(self, ops):
         m = self.m
+        if len(self.graph_outs) == 2:
+            return self._find_raw_heads(ops)
         if len(self.graph_outs) != 1:
-            raise LowerError("expected one graph output, found %s" % (self.graph_outs,))
+            raise LowerError("expected one graph output (a YOLO head) or two (box regression and class logits of an anchor-based head), found %s" % (self.graph_outs,))
         oshape = m.outputs[0][1]
         by_node = {i: (kind, rec) for kind, i, rec in ops}
         conv_out = {rec["out"]: (i, rec) for kind, i, rec in ops if kind == "conv"}
@@ -608,6 +664,41 @@ class _Lowering:
         raise LowerError("no Detect head recognised (output %s): the v8 layout needs three Concat[box, cls] -> Reshape pairs feeding an axis-2 Concat, "
                          "the v5 layout three 1x1 convolutions of 3 (5 + nc) channels reshaped to (1, 3, 5 + nc, h, w)" % (oshape,))
 
+    def _find_raw_heads(self, ops):
+        """A head-only export of an anchor-based detector (EfficientDet without its in-graph decode / NMS): two outputs, each the axis-1
+        Concat over the pyramid levels of Reshape(Transpose(conv, NCHW -> NHWC), (1, -1, k)) -- box regression (k = 4) and class LOGITS
+        (k = classes).  The convolutions' fp32 outputs ARE those tensors level by level (NHWC rows ordered (y, x, anchor)): the engine graph
+        gets one output per level and tensor, named like the hand-built EfficientDet graph's (regression.l<i>, classification.l<i>), which
+        coreEngine.EfficientdetEngine hands to the device tail."""
+        conv_out = {rec["out"]: rec for kind, i, rec in ops if kind == "conv"}
+        found = {}
+        for oname, oshape in self.m.outputs:
+            nd = self.nodes[self.producer[oname]] if oname in self.producer else None
+            if nd is not None and nd["op"] == "Sigmoid":
+                raise LowerError("output %s: class probabilities (a Sigmoid behind the head): export the logits, the device tail applies it" % oname)
+            if nd is None or nd["op"] != "Concat" or int(nd["attrs"].get("axis", 0)) != 1 or len(oshape) != 3:
+                raise LowerError("output %s %s: expected Concat(axis 1) of per-level Reshape(Transpose(conv)) tensors" % (oname, oshape))
+            k, levels = int(oshape[2]), []
+            for t in nd["inputs"]:
+                r = self.nodes[self.producer[t]] if t in self.producer else None
+                tr = self.nodes[self.producer[r["inputs"][0]]] if r is not None and r["op"] == "Reshape" and r["inputs"][0] in self.producer else None
+                if tr is None or tr["op"] != "Transpose" or _ints(self.m, tr, "perm", None) != [0, 2, 3, 1] or tr["inputs"][0] not in conv_out:
+                    raise LowerError("output %s: level tensor %r is not Reshape(Transpose(conv, perm 0 2 3 1))" % (oname, t))
+                rec = conv_out[tr["inputs"][0]]
+                if rec["act"] != M.ACT_NONE or rec["res"] is not None or rec["w"].shape[0] % k:
+                    raise LowerError("output %s: head convolution %s (%d channels) does not end in rows of %d values" % (oname, rec["name"], rec["w"].shape[0], k))
+                levels.append((tr["inputs"][0], rec["w"].shape[0] // k))
+            found[k] = (oname, levels)
+        if 4 not in found or len(found) != 2:
+            raise LowerError("outputs %s: one must carry 4 box values per anchor, the other the class logits" % ([o for o, _ in self.m.outputs],))
+        reg = found[4]
+        cls = found[[k for k in found if k != 4][0]] if len([k for k in found if k != 4]) == 1 else None
+        if cls is None or len(reg[1]) != len(cls[1]) or any(a != b for (_, a), (_, b) in zip(reg[1], cls[1])):
+            raise LowerError("box and class heads disagree on levels / anchors per cell")
+        nc = [k for k in found if k != 4][0]
+        return dict(kind="raw", reg=[t for t, _ in reg[1]], cls=[t for t, _ in cls[1]], anchors=reg[1][0][1], nc=nc,
+                    f32_tensors=[t for t, _ in reg[1]] + [t for t, _ in cls[1]])
+
     def _anchors_behind(self, node_idx):
         """The (3, 2) anchor sizes (pixels) of one v5-layout level: the constant of shape (1, 3, ., ., 2) that does not vary over the cells
         (anchor_grid; the other such constant is the cell grid) among the constants consumed downstream of the level's Reshape."""
@@ -634,6 +725,12 @@ class _Lowering:
     def _emit_tail(self, tail):
         g = self.g
         nc = tail["nc"]
+        if tail["kind"] == "raw":
+            for lv, (r, c) in enumerate(zip(tail["reg"], tail["cls"])):
+                vr, vc = self._view(r), self._view(c)
+                g.output(vr, 0, [1, vr.h * vr.w * tail["anchors"], 4], "regression.l%d" % lv)
+                g.output(vc, 0, [1, vc.h * vc.w * tail["anchors"], nc], "classification.l%d" % lv)
+            return
         if tail["kind"] == "v8":
             ins, strides = [], []
             for b, c in tail["levels"]:
