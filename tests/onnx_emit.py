@@ -38,8 +38,19 @@ class Emitter:
         self.nodes.append(OW.node(op, ins, outs, name or self.name("/" + op), attrs))
 
     def wrote(self, view, tensor):
-        segs = [s for s in self.segs.get(view.buf, []) if s[0] + s[1] <= view.coff or s[0] >= view.coff + view.c]
-        segs.append((view.coff, view.c, tensor))
+        """Segments are (buffer channel offset, channels, tensor, offset inside the tensor, the tensor's channel count): a later write over PART
+        of an earlier tensor's range (PSA: b + ffn(b) lands in b's slot of the (a, b) buffer) keeps the rest of that tensor readable."""
+        lo, hi = view.coff, view.coff + view.c
+        segs = []
+        for off, c, t, toff, tc in self.segs.get(view.buf, []):
+            if off + c <= lo or off >= hi:
+                segs.append((off, c, t, toff, tc))
+                continue
+            if off < lo:
+                segs.append((off, lo - off, t, toff, tc))
+            if off + c > hi:
+                segs.append((hi, off + c - hi, t, toff + (hi - off), tc))
+        segs.append((view.coff, view.c, tensor, 0, view.c))
         self.segs[view.buf] = sorted(segs)
 
     def slice_of(self, tensor, total_c, off, c):
@@ -66,12 +77,12 @@ class Emitter:
     def read(self, view):
         """ONNX tensor holding the channels [coff, coff + c) of the view's buffer: a produced tensor, a slice of one, or a Concat."""
         parts, pos, end = [], view.coff, view.coff + view.c
-        for off, c, t in self.segs.get(view.buf, []):
+        for off, c, t, toff, tc in self.segs.get(view.buf, []):
             if off + c <= pos or off >= end:
                 continue
             assert off <= pos, ("hole in buffer %d at channel %d" % (view.buf, pos))
             lo, hi = pos - off, min(end, off + c) - off
-            parts.append(self.slice_of(t, c, lo, hi - lo))
+            parts.append(self.slice_of(t, tc, toff + lo, hi - lo))
             pos = off + hi
         assert pos == end and parts, (view.buf, view.coff, view.c, self.segs.get(view.buf))
         if len(parts) == 1:
@@ -135,6 +146,44 @@ class Emitter:
                         self.node("Add", [self.read(op["res"]), y], [s_])
                         y = s_
                 self.wrote(out, y)
+            elif t == M.OP_ATTENTION:
+                # ultralytics Attention.forward as torch.onnx exports it: qkv -> Reshape (B, heads, 2 kd + hd, N) -> Split -> q^T k * scale ->
+                # Softmax -> v attn^T -> Reshape (B, C, H, W), plus pe = depth-wise conv of v.reshape(B, C, H, W), Add.  The engine graph holds
+                # the pe conv as one depth-wise op per head (each adds its slice of the attention output): they are gathered here and
+                # written as the ONE grouped convolution the exporter emits.
+                nh, kd, hd, scale = int(op["params"][0]), int(op["params"][1]), int(op["params"][2]), float(op["params"][3])
+                H_, W_ = ins[0].h, ins[0].w
+                N_, C_ = H_ * W_, nh * hd
+                qkv = self.read(ins[0])
+                heads = [o2 for o2 in g.ops if o2["type"] == M.OP_DWCONV and o2["ins"][0].buf == ins[0].buf and o2["res"] is not None and o2["res"].buf == out.buf]
+                assert len(heads) == nh and all(o2["act"] == M.ACT_NONE and o2["kh"] == heads[0]["kh"] for o2 in heads), "attention without its per-head pe convs"
+                heads.sort(key=lambda o2: o2["res"].coff)
+                names = {n: self.name(n) for n in ("r", "q", "k", "v", "qt", "s", "sc", "a", "at", "o", "o4", "v4", "pe", "y", "shp", "shp4", "spl", "scale")}
+                self.inits += [_i64(names["shp"], [1, nh, 2 * kd + hd, N_]), _i64(names["shp4"], [1, C_, H_, W_]), _i64(names["spl"], [kd, kd, hd]),
+                               OW.tensor(names["scale"], np.asarray(np.float32(scale)).reshape(()))]
+                self.node("Reshape", [qkv, names["shp"]], [names["r"]])
+                self.node("Split", [names["r"], names["spl"]], [names["q"], names["k"], names["v"]], [OW.attr_int("axis", 2)])
+                self.node("Transpose", [names["q"]], [names["qt"]], [OW.attr_ints("perm", [0, 1, 3, 2])])
+                self.node("MatMul", [names["qt"], names["k"]], [names["s"]])
+                self.node("Mul", [names["s"], names["scale"]], [names["sc"]])
+                self.node("Softmax", [names["sc"]], [names["a"]], [OW.attr_int("axis", -1)])
+                self.node("Transpose", [names["a"]], [names["at"]], [OW.attr_ints("perm", [0, 1, 3, 2])])
+                self.node("MatMul", [names["v"], names["at"]], [names["o"]])
+                self.node("Reshape", [names["o"], names["shp4"]], [names["o4"]])
+                self.node("Reshape", [names["v"], names["shp4"]], [names["v4"]])
+                kpe = heads[0]["kh"]
+                pw = np.concatenate([self.blob[o2["w"][0] // 4: o2["w"][0] // 4 + o2["w"][1]].reshape(hd, 1, kpe, kpe) for o2 in heads])
+                pb = np.concatenate([self.blob[o2["b"][0] // 4: o2["b"][0] // 4 + o2["b"][1]] for o2 in heads])
+                base = heads[0]["name"].rsplit(".h", 1)[0]
+                self.inits += [OW.tensor(base + ".weight", np.ascontiguousarray(pw, np.float32)), OW.tensor(base + ".bias", np.ascontiguousarray(pb, np.float32))]
+                self.node("Conv", [names["v4"], base + ".weight", base + ".bias"], [names["pe"]],
+                          [OW.attr_ints("kernel_shape", [kpe, kpe]), OW.attr_ints("pads", [kpe // 2] * 4), OW.attr_int("group", C_)])
+                self.node("Add", [names["o4"], names["pe"]], [names["y"]])
+                summed = heads[0]["out"]
+                self.wrote(M.View(summed.buf, summed.coff - heads[0]["res"].coff, C_, H_, W_), names["y"])
+                self.pe_done = getattr(self, "pe_done", set()) | {id(o2) for o2 in heads}
+            elif t == M.OP_DWCONV and id(op) in getattr(self, "pe_done", set()):
+                pass      # written with its attention op
             elif t == M.OP_DWCONV:
                 k, c = op["kh"], out.c
                 base = op["name"]

@@ -79,3 +79,21 @@ def test_bifpn_style_sums_onnx_runs_through_hipengine(tmp_path, prec, tol):
     rel = float(np.linalg.norm(got - want) / np.linalg.norm(want))
     print("lowered sums graph %s: rel %.2e" % (prec, rel))
     assert rel <= tol and kernels.count("wsum_kernel") == 4 and "upsample2_kernel" not in kernels
+
+
+@pytest.mark.parametrize("prec,tol", [("fp32", 1e-5), ("fp16x3", 1e-5), ("fp16", 5e-3)])
+def test_custom_scale_yolov10_onnx_with_attention_runs_through_hipengine(tmp_path, prec, tol):
+    """OnnxEngine on a YOLOv10 of a scale outside models.py (3-head PSA): the lowered attention runs on attention_mfma_kernel / attention_kernel."""
+    from test_onnx_lower import custom_v10
+    g = custom_v10(imgsz=(128, 160), nc=80)
+    path = str(tmp_path / "yolov10q.onnx")
+    onnx_emit.emit(g, path)
+    x = np.random.default_rng(4).uniform(0, 1, (2, 3, 128, 160)).astype(np.float32)
+    want = graph_interp.run(g, x)[0]
+    e = CE.OnnxEngine(path, precision=prec, max_batch=2)
+    got = np.array(e.engine_inference(x)[0], copy=True)
+    kernels = [e.layer_kernel(i, 2) for i in range(e.stats()["num_layers"])]
+    e.close()
+    rel = float(np.linalg.norm(got - want) / np.linalg.norm(want))
+    print("lowered yolov10(custom) %s: rel %.2e" % (prec, rel))
+    assert rel <= tol and any("attention" in k for k in kernels)

@@ -128,6 +128,26 @@ def test_standalone_sums_become_weighted_sum_ops(tmp_path):
     assert any(o["type"] == M.OP_CONV and o["res_mode"] == M.RES_AFTER_ACT for o in g2.ops)
 
 
+def custom_v10(tag="q", depth=0.67, width=0.375, **kw):
+    M.V10_SCALES[tag] = (depth, width, 1024)
+    try:
+        return M.yolov10(tag, **kw)
+    finally:
+        del M.V10_SCALES[tag]
+
+
+def test_yolov10_custom_scale_with_psa_attention(tmp_path):
+    """A YOLOv10 of a scale models.py does not build (width 0.375: a 3-head PSA) as ultralytics exports it: the softmax attention
+    (Reshape -> Split -> q^T k * scale -> Softmax -> v attn^T -> Reshape, + the depth-wise `pe` conv of v, Add) comes back as one attention op
+    and one depth-wise conv per head; SCDown / CIB depth-wise convs, the RepVGGDW 7x7 and the one-to-one v8-layout head like any other graph."""
+    g = custom_v10(imgsz=(128, 160), nc=80)
+    g2, err = _roundtrip(g, tmp_path / "v10q.onnx", via_convert=True)
+    att = [o for o in g2.ops if o["type"] == M.OP_ATTENTION]
+    assert err == 0.0 and len(att) == 1 and [int(v) for v in att[0]["params"][:3]] == [3, 32, 64]
+    assert len(g2.ops) <= len(g.ops) + 1            # the builder writes b + ffn(b) into b's slot of the (a, b) buffer; the lowering keeps one copy
+    assert sum(o["type"] == M.OP_DWCONV and o["res"] is not None and o["res"].buf == att[0]["out"].buf for o in g2.ops) == 3
+
+
 def test_mbconv_blocks_with_squeeze_and_excitation(tmp_path):
     """EfficientNet-style inverted-residual blocks (1x1 expand, depth-wise 3x3 / 5x5, swish squeeze-and-excitation, linear 1x1 project with
     an identity skip) as torch exports them -- GlobalAveragePool -> Conv -> Sigmoid * Mul -> Conv -> Sigmoid -> Mul(x, gate) -- come back as
@@ -205,7 +225,8 @@ def fuse_graph(hw=128):
 
 
 def test_unsupported_nodes_fail_loudly_naming_the_node(tmp_path):
-    """Softmax attention (YOLOv10's PSA) and stand-alone arithmetic have no counterpart: the error names the node and the op."""
+    """Nodes outside the recognised patterns (a bare Softmax that is not ultralytics-style attention) have no counterpart: the error names
+    the node and the op."""
     w = np.zeros((8, 3, 3, 3), np.float32)
     nodes = [OW.node("Conv", ["images", "w"], ["c"], "/c", [OW.attr_ints("kernel_shape", [3, 3]), OW.attr_ints("pads", [1, 1, 1, 1])]),
              OW.node("Softmax", ["c"], ["s"], "/attn/Softmax", [OW.attr_int("axis", 1)]),

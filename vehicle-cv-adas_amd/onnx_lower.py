@@ -145,6 +145,9 @@ class _Lowering:
                         out = self.nodes[j]["outputs"][0]
                 rec.update(act=act, out=out)
                 ops.append(("conv", i, rec))
+            elif op == "Reshape" and self._looks_like_attention(nd):
+                rec = self._match_attention(i, used)
+                ops.append(("attn", i, rec) if rec is not None else ("other", i, {}))
             elif op == "GlobalAveragePool":
                 rec = self._match_se(i, used)
                 ops.append(("se", i, rec) if rec is not None else ("other", i, {}))
@@ -165,6 +168,78 @@ class _Lowering:
             else:
                 ops.append(("other", i, {}))
         return ops
+
+    # ---- softmax attention (ultralytics Attention: YOLOv10 PSA)
+    def _looks_like_attention(self, nd):
+        j = self._single_consumer(nd["outputs"][0], "Split")
+        return j is not None and len(self.nodes[j]["outputs"]) == 3 and int(self.nodes[j]["attrs"].get("axis", 0)) == 2
+
+    def _match_attention(self, i, used):
+        """qkv -> Reshape (B, heads, 2 kd + hd, N) -> Split(q, k, v) -> Softmax((q^T k) * scale) -> v attn^T -> Reshape (B, C, H, W), plus the
+        depth-wise `pe` convolution of v.reshape(B, C, H, W), Add: one OP_ATTENTION and one depth-wise conv per head (each adds its slice of
+        the attention output).  None when the nodes do not form exactly this pattern."""
+        m, nd = self.m, self.nodes[i]
+        one = lambda t, op: self._single_consumer(t, op)
+        shp = _ints(m, nd, "shape", 1)
+        js = one(nd["outputs"][0], "Split")
+        sp = self.nodes[js]
+        parts = _ints(m, sp, "split", 1)
+        if shp is None or len(shp) != 4 or parts is None or len(parts) != 3 or parts[0] != parts[1] or sum(parts) != shp[2]:
+            return None
+        nh, kd, hd = int(shp[1]), int(parts[0]), int(parts[2])
+        q, k, v = sp["outputs"]
+        jt = one(q, "Transpose")
+        if jt is None or _ints(m, self.nodes[jt], "perm", None) != [0, 1, 3, 2]:
+            return None
+        jm = one(self.nodes[jt]["outputs"][0], "MatMul")
+        if jm is None or self.nodes[jm]["inputs"] != [self.nodes[jt]["outputs"][0], k] or self.consumers.get(k, []) != [jm]:
+            return None
+        t, chain, scale = self.nodes[jm]["outputs"][0], [jt, jm], 1.0
+        jx = one(t, "Mul")
+        if jx is not None:
+            cs = [x for x in self.nodes[jx]["inputs"] if x in m.initializers and np.asarray(m.initializers[x]).size == 1]
+            if len(cs) != 1:
+                return None
+            scale = float(np.asarray(m.initializers[cs[0]], np.float32).reshape(-1)[0])
+            chain.append(jx)
+            t = self.nodes[jx]["outputs"][0]
+        jsm = one(t, "Softmax")
+        if jsm is None or int(self.nodes[jsm]["attrs"].get("axis", -1)) not in (-1, 3):
+            return None
+        jt2 = one(self.nodes[jsm]["outputs"][0], "Transpose")
+        if jt2 is None or _ints(m, self.nodes[jt2], "perm", None) != [0, 1, 3, 2]:
+            return None
+        jm2 = one(self.nodes[jt2]["outputs"][0], "MatMul")
+        if jm2 is None or self.nodes[jm2]["inputs"] != [v, self.nodes[jt2]["outputs"][0]]:
+            return None
+        jr = one(self.nodes[jm2]["outputs"][0], "Reshape")
+        vc = [c for c in self.consumers.get(v, []) if c != jm2]
+        if jr is None or len(vc) != 1 or self.nodes[vc[0]]["op"] != "Reshape":
+            return None
+        jc = one(self.nodes[vc[0]]["outputs"][0], "Conv")
+        if jc is None:
+            return None
+        pe = self.nodes[jc]
+        pw = _const(m, pe["inputs"][1]) if len(pe["inputs"]) > 1 else None
+        pb = _const(m, pe["inputs"][2]) if len(pe["inputs"]) > 2 and pe["inputs"][2] else None
+        C = nh * hd
+        if pw is None or int(pe["attrs"].get("group", 1)) != C or tuple(np.asarray(pw).shape[:2]) != (C, 1) or np.asarray(pw).shape[2] != np.asarray(pw).shape[3]:
+            return None
+        kpe = int(np.asarray(pw).shape[2])
+        if (_ints(m, pe, "pads", None) or [0] * 4) != [kpe // 2] * 4 or (_ints(m, pe, "strides", None) or [1, 1]) != [1, 1]:
+            return None
+        ja = one(pe["outputs"][0], "Add")
+        o4 = self.nodes[jr]["outputs"][0]
+        if ja is None or sorted(self.nodes[ja]["inputs"]) != sorted([o4, pe["outputs"][0]]) or self.consumers.get(o4, []) != [ja]:
+            return None
+        if abs(scale - float(kd) ** -0.5) > 1e-6 * max(1.0, abs(scale)):
+            raise LowerError("node %s: attention scale %g is not key_dim ** -0.5 = %g" % (nd["name"], scale, float(kd) ** -0.5))
+        used.update(chain + [js, jsm, jt2, jm2, jr, vc[0], jc, ja])
+        src = self.nodes[self.producer[nd["inputs"][0]]] if nd["inputs"][0] in self.producer else None
+        base = self._layer_name(src) if src is not None and src["op"] == "Conv" else "attn%d" % i
+        base = base.rsplit(".qkv", 1)[0] if ".qkv" in base else base
+        return dict(x=nd["inputs"][0], out=self.nodes[ja]["outputs"][0], nh=nh, kd=kd, hd=hd, N=int(shp[3]), name=base[-30:],
+                    pw=np.asarray(pw, np.float32), pb=np.asarray(pb, np.float32) if pb is not None else np.zeros(C, np.float32))
 
     # ---- squeeze-and-excitation
     def _match_se(self, i, used):
@@ -348,7 +423,7 @@ class _Lowering:
         # the network body = the ancestors of the Detect inputs (the tail's own nodes, and whatever only feeds them, are the Detect op)
         made_by = {}
         for kind, i, rec in ops:
-            if kind in ("conv", "deconv", "wsum", "se"):
+            if kind in ("conv", "deconv", "wsum", "se", "attn"):
                 made_by[rec["out"]] = (kind, i, rec)
             else:
                 for o in self.nodes[i]["outputs"]:
@@ -365,7 +440,7 @@ class _Lowering:
                 continue
             need.add(i)
             srcs = [rec["x"]] + ([rec["res"]] if rec.get("res") is not None else []) if kind in ("conv", "deconv") else \
-                [t_ for t_, _, _ in rec["terms"]] if kind == "wsum" else [rec["x"]] if kind == "se" else \
+                [t_ for t_, _, _ in rec["terms"]] if kind == "wsum" else [rec["x"]] if kind in ("se", "attn") else \
                 [x for x in self.nodes[i]["inputs"] if x and x not in m.initializers]
             todo += srcs
         body = [o for o in ops if o[1] in need]
@@ -406,6 +481,12 @@ class _Lowering:
                 if tuple(W.shape[2:]) != (2, 2) or st != [2, 2] or W.shape[0] != c or int(nd["attrs"].get("group", 1)) != 1:
                     raise LowerError("node %s: only ConvTranspose2d(kernel 2, stride 2) is built" % nd["name"])
                 self.shape[rec["out"]] = (W.shape[1], 2 * h, 2 * w_)
+            elif kind == "attn":
+                c, h, w_ = self._shape(rec["x"])
+                if c != rec["nh"] * (2 * rec["kd"] + rec["hd"]) or h * w_ != rec["N"]:
+                    raise LowerError("node %s: attention over a %s tensor with %d heads of %d + %d + %d channels and %d tokens" % (
+                        nd["name"], (c, h, w_), rec["nh"], rec["kd"], rec["kd"], rec["hd"], rec["N"]))
+                self.shape[rec["out"]] = (rec["nh"] * rec["hd"], h, w_)
             elif kind == "se":
                 c, h, w_ = self._shape(rec["x"])
                 if c % 8 or rec["w1"].shape[1] != c:
@@ -477,8 +558,8 @@ class _Lowering:
                     raise LowerError("node %s: Concat of different spatial sizes %s" % (nd["name"], shp))
                 self.shape[nd["outputs"][0]] = (sum(s[0] for s in shp), shp[0][1], shp[0][2])
             else:
-                raise LowerError("node %s: op %s has no counterpart in the engine (attention and element-wise arithmetic other than sums of 2-3 "
-                                 "feature maps and swish squeeze-and-excitation gates need a hand-written builder)" % (nd["name"] or "#%d" % i, nd["op"]))
+                raise LowerError("node %s: op %s has no counterpart in the engine (element-wise arithmetic other than sums of 2-3 feature maps, swish "
+                                 "squeeze-and-excitation gates and ultralytics-style softmax attention needs a hand-written builder)" % (nd["name"] or "#%d" % i, nd["op"]))
 
         # concat placement, in graph order
         for kind, i, rec in body:
@@ -542,6 +623,17 @@ class _Lowering:
                            true_cin=true_cin, pad=rec["p"], weight=rec["w"], bias_arr=b)
                 g.n_params += rec["w"].size + (rec["b"].size if rec["b"] is not None else 0)
                 first = False
+            elif kind == "attn":
+                nh, kd, hd = rec["nh"], rec["kd"], rec["hd"]
+                qkv = self._view(rec["x"])
+                att = g.attention(qkv, nh, kd, hd, rec["name"] + ".softmax")
+                summed = self._view(rec["out"], make=True)
+                kpe = rec["pw"].shape[2]
+                for h_ in range(nh):     # pe(v) per head, adding that head's slice of the attention output (models._psa_block)
+                    v_ = qkv.slice(h_ * (2 * kd + hd) + 2 * kd, hd)
+                    g.dwconv(v_, kpe, 1, "%s.pe.conv.h%d" % (rec["name"], h_), act=M.ACT_NONE, out=summed.slice(h_ * hd, hd), res=att.slice(h_ * hd, hd),
+                             weight=rec["pw"][h_ * hd:(h_ + 1) * hd], bias=rec["pb"][h_ * hd:(h_ + 1) * hd])
+                g.n_params += rec["pw"].size + rec["pb"].size
             elif kind == "se":
                 n_ = rec["name"]
                 g.w = M.DictWeights({n_ + ".reduce.weight": rec["w1"], n_ + ".reduce.bias": rec["b1"], n_ + ".expand.weight": rec["w2"], n_ + ".expand.bias": rec["b2"]})
