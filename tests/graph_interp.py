@@ -98,6 +98,10 @@ def run(g, x, taps=None):
                 write(out, gate.reshape(N, c, 1, 1))
             elif t == M.OP_SCALE:
                 write(out, read(ins[0]) * read(ins[1]))
+            elif t == M.OP_SHUFFLE:
+                v, gr = read(ins[0]), int(op["params"][0])
+                B, C_, H_, W_ = v.shape
+                write(out, v.reshape(B, gr, C_ // gr, H_, W_).transpose(1, 2).reshape(B, C_, H_, W_))
             elif t == M.OP_WSUM:
                 acc = 0
                 for v, wgt in zip(ins, op["params"]):

@@ -205,6 +205,14 @@ class Emitter:
                     attrs.append(OW.attr_int("count_include_pad", 1))
                 self.node("MaxPool" if t == M.OP_MAXPOOL else "AveragePool", [self.read(ins[0])], [y], attrs)
                 self.wrote(out, y)
+            elif t == M.OP_SHUFFLE:
+                gr, c_ = int(op["params"][0]), ins[0].c
+                s1, s2, r1, t1, y = self.name("shape"), self.name("shape"), self.name("sh_r"), self.name("sh_t"), self.name("shuffled")
+                self.inits += [_i64(s1, [1, gr, c_ // gr, ins[0].h, ins[0].w]), _i64(s2, [1, c_, ins[0].h, ins[0].w])]
+                self.node("Reshape", [self.read(ins[0]), s1], [r1])
+                self.node("Transpose", [r1], [t1], [OW.attr_ints("perm", [0, 2, 1, 3, 4])])
+                self.node("Reshape", [t1, s2], [y])
+                self.wrote(out, y)
             elif t == M.OP_SE_GATE:
                 # squeeze-and-excitation as torch exports it: GlobalAveragePool -> Conv -> Sigmoid * Mul (swish) -> Conv -> Sigmoid;  the
                 # gate tensor (N, C, 1, 1) multiplies x in the OP_SCALE that follows

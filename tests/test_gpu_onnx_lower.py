@@ -97,3 +97,21 @@ def test_custom_scale_yolov10_onnx_with_attention_runs_through_hipengine(tmp_pat
     rel = float(np.linalg.norm(got - want) / np.linalg.norm(want))
     print("lowered yolov10(custom) %s: rel %.2e" % (prec, rel))
     assert rel <= tol and any("attention" in k for k in kernels)
+
+
+@pytest.mark.parametrize("prec,tol", [("fp32", 1e-5), ("fp16x3", 1e-5), ("fp16", 5e-3), ("bf16", 4e-2)])
+def test_shufflenet_onnx_runs_through_hipengine(tmp_path, prec, tol):
+    """ShuffleNetV2 units (YOLOv5-lite style backbone) through OnnxEngine: the channel shuffle runs as shuffle_kernel in every storage type."""
+    from test_onnx_lower import shufflenet_graph
+    g = shufflenet_graph(128)
+    path = str(tmp_path / "shuffle.onnx")
+    onnx_emit.emit(g, path)
+    x = np.random.default_rng(5).uniform(0, 1, (2, 3, 128, 128)).astype(np.float32)
+    want = graph_interp.run(g, x)[0]
+    e = CE.OnnxEngine(path, precision=prec, max_batch=2)
+    got = np.array(e.engine_inference(x)[0], copy=True)
+    kernels = [e.layer_kernel(i, 2) for i in range(e.stats()["num_layers"])]
+    e.close()
+    rel = float(np.linalg.norm(got - want) / np.linalg.norm(want))
+    print("lowered shufflenet %s: rel %.2e" % (prec, rel))
+    assert rel <= tol and kernels.count("shuffle_kernel") == 8

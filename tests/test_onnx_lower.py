@@ -128,6 +128,56 @@ def test_standalone_sums_become_weighted_sum_ops(tmp_path):
     assert any(o["type"] == M.OP_CONV and o["res_mode"] == M.RES_AFTER_ACT for o in g2.ops)
 
 
+def shufflenet_graph(hw=128):
+    """ShuffleNetV2 units (the YOLOv5-lite backbones of the reference's model table): stride-1 units (chunk, right branch 1x1 -> depth-wise 3x3
+    -> 1x1, concat, channel shuffle) and stride-2 units (both branches down-sample), ReLU, a max-pooled stem, v8-layout head."""
+    ws = M.SynthWeights(9, gain=1.0)
+    g = M.Graph("shuffle", 3, hw, hw, ws)
+    x, cin = g.input()
+    x = g.conv(x, 32, 3, 2, "stem.conv", act=M.ACT_RELU, true_cin=cin)
+    x = g.maxpool(x, 3, 2, 1, name="stem.pool")                                  # stride 4
+
+    def unit(x, cout, stride, nm):
+        half = cout // 2
+        cat = g.buf(x.h // stride, x.w // stride, cout)
+        if stride == 1:
+            g.maxpool(x.slice(0, half), 1, 1, 0, out=cat.slice(0, half), name=nm + ".keep")      # x1 passes through (a channel copy)
+            r = x.slice(half, half)
+        else:
+            t = g.dwconv(x, 3, 2, nm + ".b1.dw", act=M.ACT_NONE)
+            g.conv(t, half, 1, 1, nm + ".b1.pw", act=M.ACT_RELU, out=cat.slice(0, half))
+            r = x
+        t = g.conv(r, half, 1, 1, nm + ".b2.pw1", act=M.ACT_RELU)
+        t = g.dwconv(t, 3, stride, nm + ".b2.dw", act=M.ACT_NONE)
+        g.conv(t, half, 1, 1, nm + ".b2.pw2", act=M.ACT_RELU, out=cat.slice(half, half))
+        return g.shuffle(cat, 2, nm + ".shuffle")
+
+    feats = []
+    for si, (c, n) in enumerate(((64, 2), (128, 2), (256, 1))):
+        x = unit(x, c, 2, "s%d.0" % si)
+        for r in range(n):
+            x = unit(x, c, 1, "s%d.%d" % (si, r + 1))
+        feats.append(x)
+    ins, strides, nc = [], [], 8
+    for i, f in enumerate(feats):
+        ins += [g.conv(f, 64, 1, 1, "head.cv2.%d" % i, act=M.ACT_NONE, f32_out=True), g.conv(f, nc, 1, 1, "head.cv3.%d" % i, act=M.ACT_NONE, f32_out=True)]
+        strides.append(hw // f.h)
+    A = sum(f.h * f.w for f in feats)
+    head = g.buf(1, 1, (4 + nc) * A, f32=True)
+    g._op(M.OP_DETECT_V8, ins, head, params=[nc, A] + strides, name="decode")
+    g.output(head, 0, [1, 4 + nc, A], "output0")
+    return g
+
+
+def test_shufflenet_units_with_channel_shuffle(tmp_path):
+    """Reshape (B, 2, C / 2, H, W) -> Transpose -> Reshape = torch channel_shuffle comes back as one shuffle op; chunk / concat stay views."""
+    g = shufflenet_graph()
+    g2, err = _roundtrip(g, tmp_path / "shuffle.onnx", via_convert=True)
+    assert err == 0.0
+    assert sum(o["type"] == M.OP_SHUFFLE for o in g2.ops) == sum(o["type"] == M.OP_SHUFFLE for o in g.ops) == 8
+    assert all(int(o["params"][0]) == 2 for o in g2.ops if o["type"] == M.OP_SHUFFLE) and len(g2.ops) <= len(g.ops)
+
+
 def custom_v10(tag="q", depth=0.67, width=0.375, **kw):
     M.V10_SCALES[tag] = (depth, width, 1024)
     try:

@@ -184,6 +184,8 @@ int adas_engine_create(const char* model_path, int precision, int max_batch, ada
             ok = o.n_in == 1 && se_gate_supported(view(o.in_buf[0], o.in_coff[0], o.in_c[0]), view(o.out_buf, o.out_coff, o.out_c), (int)o.params[0], o.w_elems, o.b_elems);
         else if (o.type == OP_SCALE)
             ok = o.n_in == 2 && scale_supported(view(o.in_buf[0], o.in_coff[0], o.in_c[0]), view(o.in_buf[1], o.in_coff[1], o.in_c[1]), view(o.out_buf, o.out_coff, o.out_c));
+        else if (o.type == OP_SHUFFLE)
+            ok = o.n_in == 1 && shuffle_supported(view(o.in_buf[0], o.in_coff[0], o.in_c[0]), view(o.out_buf, o.out_coff, o.out_c), (int)o.params[0]);
         else if (o.type == OP_WSUM) {
             TView ins[3];
             for (uint32_t k = 0; k < o.n_in && k < 3; ++k) ins[k] = view(o.in_buf[k], o.in_coff[k], o.in_c[k]);
@@ -194,7 +196,7 @@ int adas_engine_create(const char* model_path, int precision, int max_batch, ada
             free_engine(e);
             set_error("[%s]: layer %s: unsupported %s shape", model_path, std::string(o.name, strnlen(o.name, sizeof(o.name))).c_str(),
                       o.type == OP_DWCONV ? "depth-wise convolution" : o.type == OP_ATTENTION ? "attention" : o.type == OP_DEPTH2SPACE ? "depth-to-space"
-                      : o.type == OP_SE_GATE ? "squeeze-and-excitation" : o.type == OP_SCALE ? "channel scale" : o.type == OP_WSUM ? "weighted sum" : "Detect");
+                      : o.type == OP_SE_GATE ? "squeeze-and-excitation" : o.type == OP_SCALE ? "channel scale" : o.type == OP_WSUM ? "weighted sum" : o.type == OP_SHUFFLE ? "channel shuffle" : "Detect");
             return ADAS_ERR_FORMAT;
         }
     }
@@ -759,7 +761,7 @@ int adas_engine_layer_kernel(const adas_engine* e, int layer, int batch, char* n
     const FileOp& o = op.f;
     static const char* kOther[] = {"input_nchw_kernel", "", "maxpool_kernel", "upsample2_kernel", "detect_v8_kernel", "detect_v5_kernel",
                                    "layernorm_kernel", "dwconv_kernel", "attention_kernel", "avgpool_kernel", "depth2space_kernel", "detect_v6_kernel",
-                                   "se_gate_kernel", "scale_kernel", "wsum_kernel"};
+                                   "se_gate_kernel", "scale_kernel", "wsum_kernel", "shuffle_kernel"};
     if (o.type == OP_CONV && op.ds_user >= 0 && ds_folded(e, op.ds_user, batch)) {
         snprintf(name, cap, "(fused into the conv it is the shortcut of)");
     } else if (op.skip && o.type == OP_UPSAMPLE2) {
@@ -797,7 +799,7 @@ int adas_engine_layer_kernel(const adas_engine* e, int layer, int batch, char* n
     } else if (o.type == OP_DETECT_V5 && op.det_src[0] >= 0) {
         snprintf(name, cap, "detect_v5_fused_kernel");
     } else {
-        snprintf(name, cap, "%s", o.type < 15 ? kOther[o.type] : "?");
+        snprintf(name, cap, "%s", o.type < 16 ? kOther[o.type] : "?");
     }
     return ADAS_OK;
 }
@@ -1006,6 +1008,9 @@ int engine_run_op(adas_engine* e, int i, const float* d_in, int batch, hipStream
         case OP_SCALE:
             err = launch_scale(make_view(e, o.in_buf[0], o.in_coff[0], o.in_c[0]), make_view(e, o.in_buf[1], o.in_coff[1], o.in_c[1]),
                                make_view(e, o.out_buf, o.out_coff, o.out_c), batch, e->prec, st);
+            break;
+        case OP_SHUFFLE:
+            err = launch_shuffle(make_view(e, o.in_buf[0], o.in_coff[0], o.in_c[0]), make_view(e, o.out_buf, o.out_coff, o.out_c), (int)o.params[0], batch, e->prec, st);
             break;
         case OP_WSUM: {
             TView ins[3];

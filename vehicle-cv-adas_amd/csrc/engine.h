@@ -12,7 +12,8 @@ enum { OP_INPUT = 0, OP_CONV, OP_MAXPOOL, OP_UPSAMPLE2, OP_DETECT_V8, OP_DETECT_
        [C][kh][kw] in the container, [kh*kw][C] fp32 on the device */, OP_ATTENTION /* params: heads, key_dim, head_dim, scale */, OP_AVGPOOL /* kh x kh, stride, pad: count_include_pad average */,
        OP_DEPTH2SPACE /* (H, W, 4C) -> (2H, 2W, C), channel blocks ordered (dy, dx) */, OP_DETECT_V6 /* params: nc, A, strides; inputs (reg, cls) per level */,
        OP_SE_GATE /* squeeze-and-excitation gate (fuse_ops.hip): params[0] = squeeze width; w = [W1 | b1], b = [W2 | b2]; out: 1x1xC fp32 */,
-       OP_SCALE /* inputs (x, gate): x * gate[n][c] */, OP_WSUM /* act(sum_i params[i] * in_i), 2-3 inputs, half-resolution inputs upsampled on the fly */ };
+       OP_SCALE /* inputs (x, gate): x * gate[n][c] */, OP_WSUM /* act(sum_i params[i] * in_i), 2-3 inputs, half-resolution inputs upsampled on the fly */,
+       OP_SHUFFLE /* torch channel_shuffle, params[0] = groups: out[j * g + i] = in[i * (C / g) + j] */ };
 
 struct FileHeader {
     char magic[8];

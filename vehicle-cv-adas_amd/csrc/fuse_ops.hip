@@ -200,6 +200,55 @@ hipError_t launch_scale(const TView& in, const TView& gate, const TView& out, in
     return hipGetLastError();
 }
 
+// ------------------------------------------------------------------------------------- channel shuffle
+// torch channel_shuffle(x, g): x.view(B, g, C / g, H, W).transpose(1, 2).reshape(B, C, H, W), i.e. out[j * g + i] = in[i * (C / g) + j]
+// (ShuffleNetV2 units: the YOLOv5-lite backbones of the reference's model table, README.md:95-108).  A pure permutation of storage
+// elements: thread = (pixel, 8 output channels), eight element moves (2 bytes; 4 in fp32 mode; a (hi, lo) pair of halves in fp16x3).
+struct ShDev {
+    const void* in;
+    void* out;
+    int in_cs, in_coff, out_cs, out_coff;
+    int c, g, npix;
+};
+template <int MODE>   // 0: 2-byte elements, 1: 4-byte elements, 2: fp16x3 G8 groups
+__global__ __launch_bounds__(256) void shuffle_kernel(ShDev d) {
+    const unsigned G = (unsigned)(d.c >> 3), total = (unsigned)d.npix * G;
+    const int cpg = d.c / d.g;
+    for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const unsigned pix = i / G, g8 = i - pix * G;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int oc = (int)g8 * 8 + e, ic = (oc % d.g) * cpg + oc / d.g;
+            if (MODE == 0) {
+                ((uint16_t*)d.out)[(size_t)pix * d.out_cs + d.out_coff + oc] = ((const uint16_t*)d.in)[(size_t)pix * d.in_cs + d.in_coff + ic];
+            } else if (MODE == 1) {
+                ((uint32_t*)d.out)[(size_t)pix * d.out_cs + d.out_coff + oc] = ((const uint32_t*)d.in)[(size_t)pix * d.in_cs + d.in_coff + ic];
+            } else {   // slot s of a G8 tensor: hi half at byte (s / 8) * 32 + (s % 8) * 2, lo half 16 bytes behind
+                const size_t so = (size_t)pix * d.out_cs + d.out_coff + oc, si = (size_t)pix * d.in_cs + d.in_coff + ic;
+                const uint16_t* ip = (const uint16_t*)d.in + (si >> 3) * 16 + (si & 7);
+                uint16_t* op = (uint16_t*)d.out + (so >> 3) * 16 + (so & 7);
+                op[0] = ip[0];
+                op[8] = ip[8];
+            }
+        }
+    }
+}
+bool shuffle_supported(const TView& in, const TView& out, int groups) {
+    if (in.f32 || out.f32 || in.c != out.c || in.h != out.h || in.w != out.w || groups < 2 || in.c % groups) return false;
+    return !((in.c & 7) || (in.cs & 7) || (in.coff & 7) || (out.cs & 7) || (out.coff & 7));
+}
+hipError_t launch_shuffle(const TView& in, const TView& out, int groups, int n, int prec, hipStream_t st) {
+    if (!shuffle_supported(in, out, groups)) return hipErrorInvalidValue;
+    const size_t npix = (size_t)n * in.h * in.w, total = npix * (in.c >> 3);
+    if (total >= ((size_t)1 << 31)) return hipErrorInvalidValue;
+    ShDev d{in.p, out.p, in.cs, in.coff, out.cs, out.coff, in.c, groups, (int)npix};
+    const int blocks = (int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
+    if (prec == PREC_FP32) hipLaunchKernelGGL(shuffle_kernel<1>, dim3(blocks), dim3(256), 0, st, d);
+    else if (prec == PREC_X3) hipLaunchKernelGGL(shuffle_kernel<2>, dim3(blocks), dim3(256), 0, st, d);
+    else hipLaunchKernelGGL(shuffle_kernel<0>, dim3(blocks), dim3(256), 0, st, d);
+    return hipGetLastError();
+}
+
 // ------------------------------------------------------------------------------------- weighted sum
 struct WsDev {
     const void* in[3];

@@ -194,6 +194,8 @@ hipError_t launch_se_gate(const TView& in, const TView& gate, const float* w1, c
                           const TView* scratch = nullptr);   // scratch: fp32 1x1x(P*C) per frame -> P pixel ranges summed by their own launch
 bool scale_supported(const TView& in, const TView& gate, const TView& out);
 hipError_t launch_scale(const TView& in, const TView& gate, const TView& out, int n, int prec, hipStream_t st);
+bool shuffle_supported(const TView& in, const TView& out, int groups);
+hipError_t launch_shuffle(const TView& in, const TView& out, int groups, int n, int prec, hipStream_t st);
 bool wsum_supported(int n_in, const TView* ins, const TView& out);
 hipError_t launch_wsum(int n_in, const TView* ins, const float* w, const TView& out, int n, int act, int prec, hipStream_t st);
 bool dwconv_supported(int k, int stride, int pad, int res_mode, const TView& in, const TView& out);

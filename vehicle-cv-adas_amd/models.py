@@ -23,7 +23,7 @@ import numpy as np
 
 MAGIC = b"ADASHIP1"
 (OP_INPUT, OP_CONV, OP_MAXPOOL, OP_UPSAMPLE2, OP_DETECT_V8, OP_DETECT_V5, OP_LAYERNORM, OP_DWCONV, OP_ATTENTION, OP_AVGPOOL, OP_DEPTH2SPACE,
- OP_DETECT_V6, OP_SE_GATE, OP_SCALE, OP_WSUM) = range(15)
+ OP_DETECT_V6, OP_SE_GATE, OP_SCALE, OP_WSUM, OP_SHUFFLE) = range(16)
 ACT_NONE, ACT_SILU, ACT_RELU, ACT_LEAKY = 0, 1, 2, 3      # ACT_LEAKY: LeakyReLU(0.1) (YOLOv7)
 RES_NONE, RES_AFTER_ACT, RES_BEFORE_ACT = 0, 1, 2
 BUF_F32 = 1
@@ -333,6 +333,15 @@ class Graph:
             out = self.buf(h, w, c)
         assert (out.h, out.w, out.c) == (h, w, c)
         self._op(OP_WSUM, list(ins), out, act=act, params=[float(np.float32(x)) for x in weights], flops=2.0 * len(ins) * h * w * c, name=name)
+        return out
+
+    def shuffle(self, x, groups, name, out=None):
+        """torch channel_shuffle(x, groups) (ShuffleNetV2 units): out channel j * groups + i = in channel i * (C / groups) + j."""
+        assert x.c % groups == 0 and x.c % 8 == 0
+        if out is None:
+            out = self.buf(x.h, x.w, x.c)
+        assert (out.h, out.w, out.c) == (x.h, x.w, x.c)
+        self._op(OP_SHUFFLE, [x], out, params=[groups], name=name)
         return out
 
     def output(self, view, offset, dims, name):

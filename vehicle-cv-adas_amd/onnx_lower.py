@@ -145,6 +145,11 @@ class _Lowering:
                         out = self.nodes[j]["outputs"][0]
                 rec.update(act=act, out=out)
                 ops.append(("conv", i, rec))
+            elif op == "Reshape" and self._match_shuffle(i) is not None:
+                j1, j2, groups = self._match_shuffle(i)
+                used.update((j1, j2))
+                ops.append(("shuffle", i, dict(x=nd["inputs"][0], out=self.nodes[j2]["outputs"][0], groups=groups,
+                                               name=(nd["name"].strip("/").replace("/", ".") or "shuffle%d" % i)[-47:])))
             elif op == "Reshape" and self._looks_like_attention(nd):
                 rec = self._match_attention(i, used)
                 ops.append(("attn", i, rec) if rec is not None else ("other", i, {}))
@@ -168,6 +173,25 @@ class _Lowering:
             else:
                 ops.append(("other", i, {}))
         return ops
+
+    # ---- channel shuffle
+    def _match_shuffle(self, i):
+        """Reshape (B, g, C / g, H, W) -> Transpose (0, 2, 1, 3, 4) -> Reshape (B, C, H, W): torch channel_shuffle.  -> (transpose node, second
+        reshape node, groups) or None."""
+        nd = self.nodes[i]
+        shp = _ints(self.m, nd, "shape", 1)
+        if shp is None or len(shp) != 5:
+            return None
+        j1 = self._single_consumer(nd["outputs"][0], "Transpose")
+        if j1 is None or _ints(self.m, self.nodes[j1], "perm", None) != [0, 2, 1, 3, 4]:
+            return None
+        j2 = self._single_consumer(self.nodes[j1]["outputs"][0], "Reshape")
+        if j2 is None:
+            return None
+        shp2 = _ints(self.m, self.nodes[j2], "shape", 1)
+        if shp2 is None or len(shp2) != 4 or shp2[1] not in (-1, shp[1] * shp[2]):
+            return None
+        return j1, j2, int(shp[1])
 
     # ---- softmax attention (ultralytics Attention: YOLOv10 PSA)
     def _looks_like_attention(self, nd):
@@ -423,7 +447,7 @@ class _Lowering:
         # the network body = the ancestors of the Detect inputs (the tail's own nodes, and whatever only feeds them, are the Detect op)
         made_by = {}
         for kind, i, rec in ops:
-            if kind in ("conv", "deconv", "wsum", "se", "attn"):
+            if kind in ("conv", "deconv", "wsum", "se", "attn", "shuffle"):
                 made_by[rec["out"]] = (kind, i, rec)
             else:
                 for o in self.nodes[i]["outputs"]:
@@ -440,7 +464,7 @@ class _Lowering:
                 continue
             need.add(i)
             srcs = [rec["x"]] + ([rec["res"]] if rec.get("res") is not None else []) if kind in ("conv", "deconv") else \
-                [t_ for t_, _, _ in rec["terms"]] if kind == "wsum" else [rec["x"]] if kind in ("se", "attn") else \
+                [t_ for t_, _, _ in rec["terms"]] if kind == "wsum" else [rec["x"]] if kind in ("se", "attn", "shuffle") else \
                 [x for x in self.nodes[i]["inputs"] if x and x not in m.initializers]
             todo += srcs
         body = [o for o in ops if o[1] in need]
@@ -481,6 +505,11 @@ class _Lowering:
                 if tuple(W.shape[2:]) != (2, 2) or st != [2, 2] or W.shape[0] != c or int(nd["attrs"].get("group", 1)) != 1:
                     raise LowerError("node %s: only ConvTranspose2d(kernel 2, stride 2) is built" % nd["name"])
                 self.shape[rec["out"]] = (W.shape[1], 2 * h, 2 * w_)
+            elif kind == "shuffle":
+                c, h, w_ = self._shape(rec["x"])
+                if c % rec["groups"] or c % 8:
+                    raise LowerError("node %s: channel shuffle of %d channels in %d groups (multiples of 8 only)" % (nd["name"], c, rec["groups"]))
+                self.shape[rec["out"]] = (c, h, w_)
             elif kind == "attn":
                 c, h, w_ = self._shape(rec["x"])
                 if c != rec["nh"] * (2 * rec["kd"] + rec["hd"]) or h * w_ != rec["N"]:
@@ -623,6 +652,8 @@ class _Lowering:
                            true_cin=true_cin, pad=rec["p"], weight=rec["w"], bias_arr=b)
                 g.n_params += rec["w"].size + (rec["b"].size if rec["b"] is not None else 0)
                 first = False
+            elif kind == "shuffle":
+                g.shuffle(self._view(rec["x"]), rec["groups"], rec["name"], out=self._view(rec["out"], make=True))
             elif kind == "attn":
                 nh, kd, hd = rec["nh"], rec["kd"], rec["hd"]
                 qkv = self._view(rec["x"])
