@@ -290,3 +290,23 @@ def test_unsupported_nodes_fail_loudly_naming_the_node(tmp_path):
         OL.lower(OI.read_onnx(str(p)))
     with pytest.raises(ValueError, match="neither a hand-built architecture"):
         OI.convert(str(p))
+
+
+def test_sum_with_a_bilinear_resize_is_not_folded(tmp_path):
+    """Only a nearest x2 Resize folds into a weighted sum: any other up-sampling in front of an Add stays its own node and is refused by name."""
+    w = np.random.default_rng(0).standard_normal((16, 3, 3, 3)).astype(np.float32)
+    w2 = np.random.default_rng(1).standard_normal((16, 16, 3, 3)).astype(np.float32)
+    nodes = [OW.node("Conv", ["images", "w"], ["a"], "/a", [OW.attr_ints("kernel_shape", [3, 3]), OW.attr_ints("pads", [1, 1, 1, 1])]),
+             OW.node("Conv", ["a", "w2"], ["b"], "/b", [OW.attr_ints("kernel_shape", [3, 3]), OW.attr_ints("pads", [1, 1, 1, 1]), OW.attr_ints("strides", [2, 2])]),
+             OW.node("Resize", ["b", "", "sc"], ["u"], "/neck/Resize", [OW.attr_str("mode", "linear")]),
+             OW.node("Add", ["a", "u"], ["s"], "/neck/Add"),
+             OW.node("Conv", ["s", "wh"], ["o1"], "/h1", [OW.attr_ints("kernel_shape", [1, 1])]),
+             OW.node("Conv", ["s", "wc"], ["o2"], "/h2", [OW.attr_ints("kernel_shape", [1, 1])]),
+             OW.node("Concat", ["o1", "o2"], ["c0"], "/c0", [OW.attr_int("axis", 1)]), OW.node("Reshape", ["c0", "shp"], ["r0"], "/r0"),
+             OW.node("Concat", ["r0", "r0", "r0"], ["out"], "/cat", [OW.attr_int("axis", 2)])]
+    inits = [OW.tensor("w", w), OW.tensor("w2", w2), OW.tensor("sc", np.asarray([1, 1, 2, 2], np.float32)), OW.tensor("wh", np.zeros((64, 16, 1, 1), np.float32)),
+             OW.tensor("wc", np.zeros((8, 16, 1, 1), np.float32)), OW.tensor("shp", np.asarray([1, 72, -1], np.int64))]
+    p = tmp_path / "bilinear.onnx"
+    open(p, "wb").write(OW.model(nodes, inits, [("images", [1, 3, 32, 32])], [("out", [1, 12, 3072])]))
+    with pytest.raises(ValueError, match="neck/Resize|nearest"):
+        OL.lower(OI.read_onnx(str(p)))

@@ -123,7 +123,8 @@ hipError_t launch_se_gate(const TView& in, const TView& gate, const float* w1, c
     d.in_cs = in.cs; d.in_coff = in.coff; d.gate_cs = gate.cs; d.gate_coff = gate.coff;
     d.c = in.c; d.cr = cr; d.HW = in.h * in.w;
     const int G = in.c >> 3;
-    if (scratch && scratch->p && scratch->f32 && G <= 256 && scratch->c >= in.c && scratch->c % in.c == 0 && d.HW >= 4 * (scratch->c / in.c)) {
+    if (scratch && scratch->p && scratch->f32 && scratch->cs == scratch->c && G <= 256 && scratch->c >= in.c && scratch->c % in.c == 0 &&
+        d.HW >= 4 * (scratch->c / in.c)) {
         // two launches: P pixel ranges per frame (P = scratch channels / C), then the gate from the ranges' sums
         d.part = (float*)scratch->p; d.P = scratch->c / in.c;
         SeDev a = d;
@@ -133,8 +134,6 @@ hipError_t launch_se_gate(const TView& in, const TView& gate, const float* w1, c
         else if (prec == PREC_X3) hipLaunchKernelGGL(se_partial_kernel<x3s>, dim3(n * d.P), dim3(256), la, st, a);
         else if (prec == PREC_FP16) hipLaunchKernelGGL(se_partial_kernel<f16s>, dim3(n * d.P), dim3(256), la, st, a);
         else hipLaunchKernelGGL(se_partial_kernel<uint16_t>, dim3(n * d.P), dim3(256), la, st, a);
-        // the scratch buffer is laid out per frame by the engine ([frame][P * C]): frame stride = scratch->cs
-        if (scratch->cs != scratch->c) return hipErrorInvalidValue;
     }
     d.S = 1024 / G;
     if (d.S < 1) return hipErrorInvalidValue;

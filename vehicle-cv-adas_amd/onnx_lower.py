@@ -317,6 +317,18 @@ class _Lowering:
             return False          # an inner link of a longer chain: handled from the chain's last Add
         return True
 
+    def _is_nearest_x2(self, nd):
+        """Resize / Upsample by exactly (1, 1, 2, 2), nearest: the only up-sampling the engine has (and the only one a sum may fold)."""
+        m = self.m
+        mode = nd["attrs"].get("mode", b"nearest")
+        mode = mode.decode() if isinstance(mode, (bytes, bytearray)) else str(mode)
+        if mode != "nearest":
+            return False
+        for idx in (2, 1):
+            if len(nd["inputs"]) > idx and nd["inputs"][idx] and _const(m, nd["inputs"][idx]) is not None and np.asarray(_const(m, nd["inputs"][idx])).size == 4:
+                return [float(x) for x in np.asarray(_const(m, nd["inputs"][idx])).reshape(-1)] == [1.0, 1.0, 2.0, 2.0]
+        return False          # sizes-based Resize: left to the stand-alone op's own shape check
+
     def _term(self, t, used):
         """(source tensor, weight, upsampled) of one term: through Mul(x, scalar constant) and a nearest x2 Resize read by nobody else."""
         wgt, up = 1.0, False
@@ -333,7 +345,7 @@ class _Lowering:
                 wgt *= float(np.asarray(self.m.initializers[cs[0]], np.float32).reshape(-1)[0])
                 used.add(i)
                 t = xs[0]
-            elif nd["op"] in ("Resize", "Upsample") and not up:
+            elif nd["op"] in ("Resize", "Upsample") and not up and self._is_nearest_x2(nd):
                 used.add(i)
                 up = True
                 t = nd["inputs"][0]
@@ -361,6 +373,8 @@ class _Lowering:
     def _feeds_only_free_sum(self, nd):
         """Mul-by-constant / Resize nodes in front of a stand-alone sum are visited BEFORE the Add (graph order): decide here, without the
         `used` set, whether the sum will swallow them."""
+        if nd["op"] in ("Resize", "Upsample") and not self._is_nearest_x2(nd):
+            return False          # stays a stand-alone op (and fails there, by name, if the engine has no kernel for it)
         if nd["op"] == "Mul":     # only a scale by a scalar constant is a term's weight (x * sigmoid(x), x * gate are not)
             cs = [x for x in nd["inputs"] if x in self.m.initializers and np.asarray(self.m.initializers[x]).size == 1]
             if len(cs) != 1 or len(nd["inputs"]) != 2:
