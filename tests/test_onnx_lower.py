@@ -310,3 +310,51 @@ def test_sum_with_a_bilinear_resize_is_not_folded(tmp_path):
     open(p, "wb").write(OW.model(nodes, inits, [("images", [1, 3, 32, 32])], [("out", [1, 12, 3072])]))
     with pytest.raises(ValueError, match="neck/Resize|nearest"):
         OL.lower(OI.read_onnx(str(p)))
+
+
+def test_nearest_x4_resize_becomes_a_chain_of_x2_launches(tmp_path):
+    """YOLOv9 CBFuse style: a deeper map up-sampled x4 (nearest) and added to a shallow one.  The x4 Resize runs as two x2 launches, the Add as a
+    weighted-sum op; values checked against a direct torch evaluation of the ONNX graph's meaning."""
+    import torch
+    import torch.nn.functional as F
+    rng = np.random.default_rng(2)
+    w = (rng.standard_normal((16, 3, 3, 3)) * 0.2).astype(np.float32)
+    w2 = (rng.standard_normal((16, 16, 3, 3)) * 0.1).astype(np.float32)
+    w3 = (rng.standard_normal((16, 16, 3, 3)) * 0.1).astype(np.float32)
+    wh = (rng.standard_normal((64, 16, 1, 1)) * 0.1).astype(np.float32)
+    wc = (rng.standard_normal((8, 16, 1, 1)) * 0.1).astype(np.float32)
+    k3 = [OW.attr_ints("kernel_shape", [3, 3]), OW.attr_ints("pads", [1, 1, 1, 1])]
+    w0 = (rng.standard_normal((16, 16, 3, 3)) * 0.1).astype(np.float32)
+    nodes = [OW.node("Conv", ["images", "w"], ["p1"], "/p1", k3 + [OW.attr_ints("strides", [2, 2])]),
+             OW.node("Conv", ["p1", "w0"], ["p2"], "/p2", k3 + [OW.attr_ints("strides", [2, 2])]),
+             OW.node("Conv", ["p2", "w0"], ["a"], "/a", k3 + [OW.attr_ints("strides", [2, 2])]),          # stride 8
+             OW.node("Conv", ["a", "w2"], ["b"], "/b", k3 + [OW.attr_ints("strides", [2, 2])]),
+             OW.node("Conv", ["b", "w3"], ["c"], "/c", k3 + [OW.attr_ints("strides", [2, 2])]),
+             OW.node("Resize", ["c", "", "sc"], ["u"], "/cbfuse/Resize", [OW.attr_str("mode", "nearest")]),
+             OW.node("Add", ["a", "u"], ["s"], "/cbfuse/Add")]
+    heads = []
+    for l, src in enumerate(("s", "b", "c")):
+        nodes += [OW.node("Conv", [src, "wh"], ["o1_%d" % l], "/h1_%d" % l, [OW.attr_ints("kernel_shape", [1, 1])]),
+                  OW.node("Conv", [src, "wc"], ["o2_%d" % l], "/h2_%d" % l, [OW.attr_ints("kernel_shape", [1, 1])]),
+                  OW.node("Concat", ["o1_%d" % l, "o2_%d" % l], ["c_%d" % l], "/c_%d" % l, [OW.attr_int("axis", 1)]),
+                  OW.node("Reshape", ["c_%d" % l, "shp"], ["r_%d" % l], "/r_%d" % l)]
+        heads.append("r_%d" % l)
+    nodes.append(OW.node("Concat", heads, ["out"], "/cat", [OW.attr_int("axis", 2)]))
+    inits = [OW.tensor("w", w), OW.tensor("w0", w0), OW.tensor("w2", w2), OW.tensor("w3", w3), OW.tensor("sc", np.asarray([1, 1, 4, 4], np.float32)), OW.tensor("wh", wh),
+             OW.tensor("wc", wc), OW.tensor("shp", np.asarray([1, 72, -1], np.int64))]
+    A = 16 * 16 + 8 * 8 + 4 * 4
+    p = tmp_path / "x4.onnx"
+    open(p, "wb").write(OW.model(nodes, inits, [("images", [1, 3, 128, 128])], [("out", [1, 12, A])]))
+    g2 = OL.lower(OI.read_onnx(str(p)), "x4")
+    assert sum(o["type"] == M.OP_UPSAMPLE2 for o in g2.ops) == 2 and sum(o["type"] == M.OP_WSUM for o in g2.ops) == 1
+    x = rng.uniform(0, 1, (2, 3, 128, 128)).astype(np.float32)
+    taps = {}
+    graph_interp.run(g2, x, taps=taps)
+    with torch.no_grad():
+        t = torch.from_numpy(x)
+        t = F.conv2d(F.conv2d(t, torch.from_numpy(w), stride=2, padding=1), torch.from_numpy(w0), stride=2, padding=1)
+        a = F.conv2d(t, torch.from_numpy(w0), stride=2, padding=1)
+        c = F.conv2d(F.conv2d(a, torch.from_numpy(w2), stride=2, padding=1), torch.from_numpy(w3), stride=2, padding=1)
+        want = a + F.interpolate(c, scale_factor=4, mode="nearest")
+    got = [v for k, v in taps.items() if "Add" in k or "sum" in k][0]
+    np.testing.assert_allclose(got, want.numpy(), rtol=0, atol=1e-6)

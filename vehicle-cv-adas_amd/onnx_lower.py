@@ -565,9 +565,10 @@ class _Lowering:
                 if sc is None and len(nd["inputs"]) > 3 and nd["inputs"][3] and _const(m, nd["inputs"][3]) is not None:
                     sz = [int(x) for x in np.asarray(_const(m, nd["inputs"][3])).reshape(-1)]
                     sc = [1.0, 1.0, sz[2] / h, sz[3] / w_]
-                if mode != "nearest" or sc is None or sc[:2] != [1.0, 1.0] or sc[2:] != [2.0, 2.0]:
-                    raise LowerError("node %s: only nearest-neighbour x2 up-sampling is built (mode %s, scales %s)" % (nd["name"], mode, sc))
-                self.shape[nd["outputs"][0]] = (c, 2 * h, 2 * w_)
+                if mode != "nearest" or sc is None or sc[:2] != [1.0, 1.0] or sc[2] != sc[3] or sc[2] not in (2.0, 4.0, 8.0):
+                    raise LowerError("node %s: only nearest-neighbour x2 / x4 / x8 up-sampling is built (mode %s, scales %s)" % (nd["name"], mode, sc))
+                rec["factor"] = int(sc[2])       # x4 / x8 (YOLOv9 CBFuse): a chain of x2 launches
+                self.shape[nd["outputs"][0]] = (c, int(sc[2]) * h, int(sc[2]) * w_)
             elif kind == "identity":
                 self.shape[nd["outputs"][0]] = self._shape(nd["inputs"][0])
                 alias[nd["outputs"][0]] = (nd["inputs"][0], 0)
@@ -698,7 +699,12 @@ class _Lowering:
                 xin, out = self._view(nd["inputs"][0]), self._view(nd["outputs"][0], make=True)
                 (g.maxpool if kind == "maxpool" else g.avgpool)(xin, ks, st, pd, out=out, name=(nd["name"].strip("/").replace("/", ".") or kind)[-47:])
             elif kind in ("resize", "upsample"):
-                g.upsample2(self._view(nd["inputs"][0]), out=self._view(nd["outputs"][0], make=True), name=(nd["name"].strip("/").replace("/", ".") or "upsample")[-47:])
+                nm = (nd["name"].strip("/").replace("/", ".") or "upsample")[-44:]
+                v, f_ = self._view(nd["inputs"][0]), rec.get("factor", 2)
+                while f_ > 2:                    # nearest x4 / x8 = nearest x2 applied two / three times
+                    v = g.upsample2(v, name="%s.x%d" % (nm, f_))
+                    f_ //= 2
+                g.upsample2(v, out=self._view(nd["outputs"][0], make=True), name=nm)
             elif kind == "concat":
                 self._view(nd["outputs"][0], make=True)
                 for (ct, off, r, ro, c) in copy_at.get(i, []):
