@@ -1130,6 +1130,7 @@ int adas_bytetrack_reserve_frames(adas_bytetrack* h, int n_frames, int n_streams
     ADAS_HIP_TRY(hipMalloc(&h->snap, bt_snap_bytes(h->p.max_tracks) * (size_t)n_frames * (size_t)n_streams));
     ADAS_HIP_TRY(hipMemset(h->snap, 0, bt_snap_bytes(h->p.max_tracks) * (size_t)n_frames * (size_t)n_streams));
     h->snap_frames = n_frames; h->snap_streams = n_streams;
+    adas::bump_config_generation();   // a step captured with the old store's address is re-captured (pipeline.cpp replay_step)
     return ADAS_OK;
 }
 int adas_bytetrack_update_device_frames(adas_bytetrack* h, const double* d_xyxy, const double* d_scores, const int32_t* d_cls,
