@@ -10,6 +10,7 @@
 // Algorithmic bytes per launch: pixels * (Cin + Cout) * 2 B (+ Cout*Cin*2 B of weights, L2-resident).
 #include "kernels.h"
 #include "elem16.h"
+#include <stdlib.h>
 
 namespace adas {
 
@@ -29,6 +30,7 @@ struct PwDev {
     int NT;                 // feature tiles (cout_pad16 / 16)
     int NTL;                // feature tiles one workgroup owns (blockIdx.y selects the range; NT when the weights fit LDS whole)
     int mtiles;
+    int wide;               // 16-byte stores (two feature tiles per trip); ADAS_NO_PW_WIDE=1 clears it
     const uint16_t* up;     // half-resolution source of the first up_ks K steps (nearest-neighbour 2x upsample folded in), or null
     int up_cs, up_coff, up_ks, up_W, up_HW;
 };
@@ -52,6 +54,8 @@ __global__ __launch_bounds__(512) void conv_pw_kernel(PwDev a) {
         for (int i = tid; i < ntl * 16; i += 512) bl[i] = a.bias[nt0 * 16 + i];   // bias is padded to a multiple of 128 entries
     }
     __syncthreads();
+    constexpr bool WIDE_OK = KS <= 8;   // (the two-tile form doubles the weight fragments in flight; the widest instantiations keep the one-tile loop)
+    const bool wide = !a.out_f32 && (((a.out_cs | a.out_coff) & 7) == 0) && a.wide;
     const int tail_valid = a.cin - (KS - 1) * 32;  // channels that exist in the last K step
     const bool tail_zero = TAIL && kg * 8 >= tail_valid;
 
@@ -84,7 +88,41 @@ __global__ __launch_bounds__(512) void conv_pw_kernel(PwDev a) {
         if (tail_zero) xb[KS - 1] = pu32x4{0u, 0u, 0u, 0u};
 
         const size_t obase = (size_t)(ok ? m : 0) * a.out_cs + a.out_coff + kg * 4 + nt0 * 16;
-        for (int nt = 0; nt < ntl; ++nt) {
+        int nt = 0;
+        if (WIDE_OK && wide) {
+            // two feature tiles per trip, 16-byte stores: v_permlane16_swap exchanges the odd 16-lane rows of tile nt with the even rows of
+            // tile nt + 1, after which a lane owns 8 consecutive channels of its pixel (conv_halo.hip's epilogue): half the store
+            // instructions, 64-byte instead of 32-byte runs per pixel
+            auto actf = [&](float v) {
+                if (a.act == ACT_SILU) return v * __frcp_rn(1.0f + __expf(-v));
+                if (a.act == ACT_RELU) return fmaxf(v, 0.f);
+                if (a.act == ACT_LEAKY) return fmaxf(v, 0.1f * v);
+                return v;
+            };
+            const size_t pbase = (size_t)(ok ? m : 0) * a.out_cs + a.out_coff + nt0 * 16;
+            for (; nt + 1 < ntl; nt += 2) {
+                pf32x4 acc0{0.f, 0.f, 0.f, 0.f}, acc1{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) {
+                    const pu32x4 w0 = *reinterpret_cast<const pu32x4*>(wl + ((size_t)(nt * KS + ks) * 64 + lane) * 8);
+                    const pu32x4 w1 = *reinterpret_cast<const pu32x4*>(wl + ((size_t)((nt + 1) * KS + ks) * 64 + lane) * 8);
+                    acc0 = E::mfma(w0, xb[ks], acc0);
+                    acc1 = E::mfma(w1, xb[ks], acc1);
+                }
+                const float4 b0 = *reinterpret_cast<const float4*>(bl + nt * 16 + kg * 4), b1 = *reinterpret_cast<const float4*>(bl + (nt + 1) * 16 + kg * 4);
+                const uint32_t x0 = E::pack2(actf(acc0[0] + b0.x), actf(acc0[1] + b0.y)), x1 = E::pack2(actf(acc0[2] + b0.z), actf(acc0[3] + b0.w));
+                const uint32_t y0 = E::pack2(actf(acc1[0] + b1.x), actf(acc1[1] + b1.y)), y1 = E::pack2(actf(acc1[2] + b1.z), actf(acc1[3] + b1.w));
+                const auto s0 = __builtin_amdgcn_permlane16_swap(x0, y0, false, false);
+                const auto s1 = __builtin_amdgcn_permlane16_swap(x1, y1, false, false);
+                const int c = (nt + (kg & 1)) * 16 + (kg >> 1) * 8;
+                uint16_t* op = (uint16_t*)a.out + pbase + c;
+                if (ok) {
+                    if (nt0 * 16 + c + 8 <= a.cout) *reinterpret_cast<pu32x4*>(op) = pu32x4{s0[0], s1[0], s0[1], s1[1]};
+                    else if (nt0 * 16 + c + 4 <= a.cout) *reinterpret_cast<uint2*>(op) = make_uint2(s0[0], s1[0]);
+                }
+            }
+        }
+        for (; nt < ntl; ++nt) {
             pf32x4 acc{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
@@ -175,6 +213,10 @@ hipError_t launch_conv_pw(const ConvArgs& a, hipStream_t st) {
     d.out_cs = a.out.cs; d.out_coff = a.out.coff; d.cout = a.out.c; d.out_f32 = a.out.f32;
     d.M = a.m; d.stride = a.stride; d.Wo = a.out.w; d.HoWo = a.out.h * a.out.w; d.W = a.in.w; d.HW = a.in.h * a.in.w;
     d.act = a.act;
+    {
+        const char* e = getenv("ADAS_NO_PW_WIDE");
+        d.wide = (e && e[0] == '1') ? 0 : 1;
+    }
     d.up = nullptr; d.up_cs = d.up_coff = d.up_ks = d.up_W = d.up_HW = 0;
     if (a.up_c > 0) {
         if (a.stride != 1 || (a.up_c & 31) || a.up.c != a.up_c || 2 * a.up.h != a.in.h || 2 * a.up.w != a.in.w || a.up.f32 || ((a.up.cs | a.up.coff) & 7)) return hipErrorInvalidValue;
