@@ -4,7 +4,7 @@ detector -> tracker, lane detector (+ device geometry), distance / collision poi
 No window, no video codec: frames come from a seeded synthetic 1280x720 clip (moving rectangles on noise) or from a
 .npy file of uint8 BGR frames (N, H, W, 3); one summary line per frame.
 
-    python tools/demo_headless.py [--frames 30] [--det yolov8n.onnx|.hipm] [--lane culane_res18.onnx|.hipm] [--video clip.npy]
+    python tools/demo_headless.py [--frames 30] [--det yolov8n.onnx|.hipm] [--det-type yolov8|efficientdet] [--lane culane_res18.onnx|.hipm] [--video clip.npy]
 
 Without model paths, seeded random-weight models are built (their detections are noise: the point is the data flow)."""
 import argparse, importlib, os, sys, tempfile, time
@@ -40,19 +40,26 @@ def main():
     ap.add_argument("--frames", type=int, default=30)
     ap.add_argument("--det", default=None); ap.add_argument("--lane", default=None); ap.add_argument("--video", default=None)
     ap.add_argument("--classes", default=None, help="label file, one name per line (default: 80 generic names)")
+    ap.add_argument("--det-type", default="yolov8", choices=["yolov8", "efficientdet"],
+                    help="demo.py picks EfficientdetDetector for ObjectModelType.EfficientDet and YoloDetector otherwise")
     a = ap.parse_args()
     work = tempfile.mkdtemp(prefix="adas_demo_")
-    det_path = a.det or M.build("yolov8n").save(os.path.join(work, "yolov8n.hipm"))
+    effdet = a.det_type == "efficientdet"
+    det_path = a.det or (M.build("efficientdet-d0").save(os.path.join(work, "efficientdet-d0.hipm")) if effdet
+                         else M.build("yolov8n").save(os.path.join(work, "yolov8n.hipm")))
     lane_path = a.lane or M.build("ufldv2_res18", wsrc=M.SynthWeights(1, gain=M.RELU_RES_GAIN)).save(os.path.join(work, "culane_res18.hipm"))
     classes = a.classes
     if classes is None:
         classes = os.path.join(work, "labels.txt")
-        names = ["person", "bicycle", "car", "motorbike", "aeroplane", "bus", "train", "truck"] + ["class%d" % i for i in range(8, 80)]
+        names = ["person", "bicycle", "car", "motorbike", "aeroplane", "bus", "train", "truck"] + ["class%d" % i for i in range(8, 90 if effdet else 80)]
         open(classes, "w").write("\n".join(names) + "\n")
 
     # demo.py:236-260
     laneDetector = D.UltrafastLaneDetectorV2(lane_path, D.LaneModelType.UFLDV2_CULANE)
-    objectDetector = D.YoloDetector(model_path=det_path, model_type=D.ObjectModelType.YOLOV8, classes_path=classes, box_score=0.4, box_nms_iou=0.45)
+    if effdet:     # the EfficientDet-D0 network + its in-graph decode / NMS on the device (coreEngine.EfficientdetEngine)
+        objectDetector = D.EfficientdetDetector(model_path=det_path, classes_path=classes, box_score=0.1 if a.det is None else 0.6)
+    else:
+        objectDetector = D.YoloDetector(model_path=det_path, model_type=D.ObjectModelType.YOLOV8, classes_path=classes, box_score=0.4, box_nms_iou=0.45)
     frames = np.load(a.video) if a.video else None
     first = frames[0] if frames is not None else next(synthetic_clip(1))
     height, width = first.shape[:2]
