@@ -54,6 +54,10 @@ def attr_str(name, text):
     return _ld(1, name.encode()) + _ld(4, text.encode()) + _vi(20, 3)
 
 
+def attr_tensor(name, arr, tname=""):
+    return _ld(1, name.encode()) + _ld(5, tensor(tname, arr)) + _vi(20, 4)
+
+
 def node(op, inputs, outputs, name="", attrs=()):
     out = b"".join(_ld(1, i.encode()) for i in inputs) + b"".join(_ld(2, o.encode()) for o in outputs)
     out += _ld(3, name.encode()) + _ld(4, op.encode()) + b"".join(_ld(5, a) for a in attrs)

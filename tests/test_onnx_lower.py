@@ -358,3 +358,37 @@ def test_nearest_x4_resize_becomes_a_chain_of_x2_launches(tmp_path):
         want = a + F.interpolate(c, scale_factor=4, mode="nearest")
     got = [v for k, v in taps.items() if "Add" in k or "sum" in k][0]
     np.testing.assert_allclose(got, want.numpy(), rtol=0, atol=1e-6)
+
+
+def test_constant_nodes_are_read_like_initializers(tmp_path):
+    """Exports without constant folding carry Reshape shapes / Resize scales / scalar factors as Constant nodes: the reader folds them into
+    the initializer table, the lowering sees no difference."""
+    g = fuse_graph()
+    path = str(tmp_path / "fuse.onnx")
+    onnx_emit.emit(g, path)
+    m = OI.read_onnx(path)
+    # rewrite every non-weight initializer (shapes, scales, scalar weights) as a Constant node in front of the graph
+    small = {k: v for k, v in m.initializers.items() if np.asarray(v).size <= 8 and not k.endswith((".weight", ".bias"))}
+    assert len(small) >= 8
+    import onnx_writer as W2
+    nodes = [W2.node("Constant", [], [k], "/Constant_%d" % i, [W2.attr_tensor("value", np.asarray(v))]) for i, (k, v) in enumerate(small.items())]
+    for nd in m.nodes:
+        attrs = []
+        for k, v in nd["attrs"].items():
+            if isinstance(v, (bytes, bytearray)):
+                attrs.append(W2.attr_str(k, bytes(v).decode()))
+            elif isinstance(v, list):
+                attrs.append(W2.attr_ints(k, [int(x) for x in v]))
+            elif isinstance(v, float):
+                attrs.append(W2.attr_float(k, v))
+            else:
+                attrs.append(W2.attr_int(k, int(v)))
+        nodes.append(W2.node(nd["op"], nd["inputs"], nd["outputs"], nd["name"], attrs))
+    inits = [W2.tensor(k, np.asarray(v)) for k, v in m.initializers.items() if k not in small]
+    p2 = str(tmp_path / "fuse_const.onnx")
+    open(p2, "wb").write(W2.model(nodes, inits, m.inputs, m.outputs))
+    m2 = OI.read_onnx(p2)
+    assert not any(nd["op"] == "Constant" for nd in m2.nodes) and set(small) <= set(m2.initializers)
+    g2 = OL.lower(m2, "c")
+    x = np.random.default_rng(0).uniform(0, 1, (2, 3, g.in_h, g.in_w)).astype(np.float32)
+    np.testing.assert_array_equal(graph_interp.run(g, x)[0], graph_interp.run(g2, x)[0])

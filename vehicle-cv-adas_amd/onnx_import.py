@@ -140,6 +140,8 @@ def _attr(buf):
             val = _sint64(v)
         elif f == 4:
             val = bytes(v)
+        elif f == 5 and wt == 2:      # t: a TensorProto (the `value` of a Constant node)
+            val = _tensor(v)[1]
         elif f == 8:
             ints += [_sint64(x) for x in (_packed_varints(v) if wt == 2 else [v])]
         elif f == 7:
@@ -226,6 +228,26 @@ def read_onnx(path):
             m.inputs.append(_value_info(v, m.elem_types))
         elif f == 12:
             m.outputs.append(_value_info(v, m.elem_types))
+    # Constant nodes (exporters without constant folding write Reshape shapes, Split sizes, Resize scales, scalar factors this way) are
+    # initializers in all but name: fold them, so that every consumer sees one kind of constant
+    kept = []
+    for nd in m.nodes:
+        if nd["op"] == "Constant" and len(nd["outputs"]) == 1:
+            a = nd["attrs"]
+            val = a.get("value")
+            if val is None and "value_float" in a:
+                val = np.asarray(a["value_float"], np.float32)
+            if val is None and "value_int" in a:
+                val = np.asarray(a["value_int"], np.int64)
+            if val is None and "value_ints" in a:
+                val = np.asarray(a["value_ints"], np.int64)
+            if val is None and "value_floats" in a:
+                val = np.asarray(a["value_floats"], np.float32)
+            if isinstance(val, np.ndarray):
+                m.initializers[nd["outputs"][0]] = val
+                continue
+        kept.append(nd)
+    m.nodes = kept
     if unsupported and not m.initializers:
         raise ValueError("[%s]: initializers use external data or unsupported types: %s" % (path, unsupported[:4]))
     m.inputs = [(n, s) for n, s in m.inputs if n not in m.initializers]
