@@ -50,6 +50,10 @@ def attr_float(name, f):
     return _ld(1, name.encode()) + _varint((2 << 3) | 5) + struct.pack("<f", f) + _vi(20, 1)
 
 
+def attr_floats(name, vals):
+    return _ld(1, name.encode()) + _ld(7, struct.pack("<%df" % len(vals), *vals)) + _vi(20, 6)
+
+
 def attr_str(name, text):
     return _ld(1, name.encode()) + _ld(4, text.encode()) + _vi(20, 3)
 

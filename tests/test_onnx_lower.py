@@ -392,3 +392,53 @@ def test_constant_nodes_are_read_like_initializers(tmp_path):
     g2 = OL.lower(m2, "c")
     x = np.random.default_rng(0).uniform(0, 1, (2, 3, g.in_h, g.in_w)).astype(np.float32)
     np.testing.assert_array_equal(graph_interp.run(g, x)[0], graph_interp.run(g2, x)[0])
+
+
+def test_older_export_spellings_auto_pad_and_upsample_scales_attribute(tmp_path):
+    """auto_pad = SAME_UPPER on stride-1 odd-kernel convolutions (= symmetric k // 2 padding) and the opset-7 Upsample node with its scales
+    as an attribute mean what the explicit spellings mean; SAME_UPPER on a stride-2 convolution (asymmetric padding) is refused by name."""
+    import torch
+    import torch.nn.functional as F
+    rng = np.random.default_rng(7)
+    w = (rng.standard_normal((16, 3, 3, 3)) * 0.2).astype(np.float32)
+    w0 = (rng.standard_normal((16, 16, 3, 3)) * 0.1).astype(np.float32)
+    wh, wc = (rng.standard_normal((64, 16, 1, 1)) * 0.1).astype(np.float32), (rng.standard_normal((8, 16, 1, 1)) * 0.1).astype(np.float32)
+    s2 = [OW.attr_ints("kernel_shape", [3, 3]), OW.attr_ints("pads", [1, 1, 1, 1]), OW.attr_ints("strides", [2, 2])]
+    same = [OW.attr_ints("kernel_shape", [3, 3]), OW.attr_str("auto_pad", "SAME_UPPER")]
+
+    def graph(bad=False):
+        nodes = [OW.node("Conv", ["images", "w"], ["p1"], "/p1", s2), OW.node("Conv", ["p1", "w0"], ["p2"], "/p2", s2), OW.node("Conv", ["p2", "w0"], ["a"], "/a", s2),
+                 OW.node("Conv", ["a", "w0"], ["a2"], "/same", same),
+                 OW.node("Conv", ["a2", "w0"], ["b"], "/b", (same + [OW.attr_ints("strides", [2, 2])]) if bad else s2),
+                 OW.node("Upsample", ["b"], ["u"], "/up", [OW.attr_str("mode", "nearest"), OW.attr_floats("scales", [1.0, 1.0, 2.0, 2.0])]),
+                 OW.node("Add", ["a2", "u"], ["s"], "/sum"),
+                 OW.node("Conv", ["b", "w0"], ["c"], "/c", s2)]
+        heads = []
+        for l, src in enumerate(("s", "b", "c")):
+            nodes += [OW.node("Conv", [src, "wh"], ["o1_%d" % l], "/h1_%d" % l, [OW.attr_ints("kernel_shape", [1, 1])]),
+                      OW.node("Conv", [src, "wc"], ["o2_%d" % l], "/h2_%d" % l, [OW.attr_ints("kernel_shape", [1, 1])]),
+                      OW.node("Concat", ["o1_%d" % l, "o2_%d" % l], ["c_%d" % l], "/c_%d" % l, [OW.attr_int("axis", 1)]),
+                      OW.node("Reshape", ["c_%d" % l, "shp"], ["r_%d" % l], "/r_%d" % l)]
+            heads.append("r_%d" % l)
+        nodes.append(OW.node("Concat", heads, ["out"], "/cat", [OW.attr_int("axis", 2)]))
+        inits = [OW.tensor("w", w), OW.tensor("w0", w0), OW.tensor("wh", wh), OW.tensor("wc", wc), OW.tensor("shp", np.asarray([1, 72, -1], np.int64))]
+        return OW.model(nodes, inits, [("images", [1, 3, 128, 128])], [("out", [1, 12, 16 * 16 + 8 * 8 + 4 * 4])])
+
+    p = tmp_path / "old.onnx"
+    open(p, "wb").write(graph())
+    g2 = OL.lower(OI.read_onnx(str(p)), "old")
+    assert sum(o["type"] == M.OP_WSUM for o in g2.ops) == 1 and not any(o["type"] == M.OP_UPSAMPLE2 for o in g2.ops)      # the Upsample folded into the sum
+    x = rng.uniform(0, 1, (2, 3, 128, 128)).astype(np.float32)
+    taps = {}
+    graph_interp.run(g2, x, taps=taps)
+    with torch.no_grad():
+        t = torch.from_numpy(x)
+        for wt in (w, w0, w0):
+            t = F.conv2d(t, torch.from_numpy(wt), stride=2, padding=1)
+        a2 = F.conv2d(t, torch.from_numpy(w0), padding=1)
+        b = F.conv2d(a2, torch.from_numpy(w0), stride=2, padding=1)
+        want = a2 + F.interpolate(b, scale_factor=2, mode="nearest")
+    np.testing.assert_allclose(taps["sum"], want.numpy(), rtol=0, atol=1e-6)
+    open(p, "wb").write(graph(bad=True))
+    with pytest.raises(ValueError, match="auto_pad SAME_UPPER"):
+        OL.lower(OI.read_onnx(str(p)), "bad")

@@ -324,6 +324,8 @@ class _Lowering:
         mode = mode.decode() if isinstance(mode, (bytes, bytearray)) else str(mode)
         if mode != "nearest":
             return False
+        if isinstance(nd["attrs"].get("scales"), list) and len(nd["attrs"]["scales"]) == 4:     # Upsample, opset 7
+            return [float(x) for x in nd["attrs"]["scales"]] == [1.0, 1.0, 2.0, 2.0]
         for idx in (2, 1):
             if len(nd["inputs"]) > idx and nd["inputs"][idx] and _const(m, nd["inputs"][idx]) is not None and np.asarray(_const(m, nd["inputs"][idx])).size == 4:
                 return [float(x) for x in np.asarray(_const(m, nd["inputs"][idx])).reshape(-1)] == [1.0, 1.0, 2.0, 2.0]
@@ -500,6 +502,14 @@ class _Lowering:
                 st = _ints(m, nd, "strides", None) or [1, 1]
                 pd = _ints(m, nd, "pads", None) or [0, 0, 0, 0]
                 dl = _ints(m, nd, "dilations", None) or [1, 1]
+                ap = nd["attrs"].get("auto_pad")
+                ap = ap.decode() if isinstance(ap, (bytes, bytearray)) else ap
+                if ap in ("SAME_UPPER", "SAME_LOWER"):
+                    if st != [1, 1] or k % 2 == 0:
+                        raise LowerError("node %s: auto_pad %s with stride %s / kernel %d needs asymmetric padding (symmetric convolutions only)" % (nd["name"], ap, st, k))
+                    pd = [k // 2] * 4
+                elif ap not in (None, "NOTSET", "VALID"):
+                    raise LowerError("node %s: auto_pad %s" % (nd["name"], ap))
                 if st[0] != st[1] or len(set(pd)) != 1 or dl != [1, 1]:
                     raise LowerError("node %s: strides %s pads %s dilations %s (symmetric, undilated convolutions only)" % (nd["name"], st, pd, dl))
                 if group not in (1, c) or (group == c and (W.shape[0] != c or c == 1)):
@@ -557,8 +567,8 @@ class _Lowering:
                 c, h, w_ = self._shape(nd["inputs"][0])
                 mode = nd["attrs"].get("mode", b"nearest")
                 mode = mode.decode() if isinstance(mode, (bytes, bytearray)) else str(mode)
-                sc = None
-                for idx in (2, 1):
+                sc = [float(x) for x in nd["attrs"]["scales"]] if isinstance(nd["attrs"].get("scales"), list) and len(nd["attrs"]["scales"]) == 4 else None
+                for idx in ((2, 1) if sc is None else ()):
                     if len(nd["inputs"]) > idx and nd["inputs"][idx] and _const(m, nd["inputs"][idx]) is not None and np.asarray(_const(m, nd["inputs"][idx])).size == 4:
                         sc = [float(x) for x in np.asarray(_const(m, nd["inputs"][idx])).reshape(-1)]
                         break
