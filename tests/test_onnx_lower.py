@@ -442,3 +442,44 @@ def test_older_export_spellings_auto_pad_and_upsample_scales_attribute(tmp_path)
     open(p, "wb").write(graph(bad=True))
     with pytest.raises(ValueError, match="auto_pad SAME_UPPER"):
         OL.lower(OI.read_onnx(str(p)), "bad")
+
+
+def test_unfused_batchnorm_is_folded_into_the_convolution(tmp_path):
+    """Conv -> BatchNormalization -> ReLU (an export that kept its BatchNorm nodes): one convolution with folded weights, values = torch's."""
+    import torch
+    import torch.nn.functional as F
+    rng = np.random.default_rng(11)
+    w = (rng.standard_normal((16, 3, 3, 3)) * 0.2).astype(np.float32)
+    w0 = (rng.standard_normal((16, 16, 3, 3)) * 0.1).astype(np.float32)
+    gam, bet = rng.uniform(0.5, 1.5, 16).astype(np.float32), rng.normal(0, 0.1, 16).astype(np.float32)
+    mu, var = rng.normal(0, 0.2, 16).astype(np.float32), rng.uniform(0.5, 2.0, 16).astype(np.float32)
+    wh, wc = (rng.standard_normal((64, 16, 1, 1)) * 0.1).astype(np.float32), (rng.standard_normal((8, 16, 1, 1)) * 0.1).astype(np.float32)
+    s2 = [OW.attr_ints("kernel_shape", [3, 3]), OW.attr_ints("pads", [1, 1, 1, 1]), OW.attr_ints("strides", [2, 2])]
+    nodes = [OW.node("Conv", ["images", "w"], ["p1"], "/p1", s2), OW.node("Conv", ["p1", "w0"], ["p2"], "/p2", s2),
+             OW.node("Conv", ["p2", "w0"], ["a0"], "/a", s2),
+             OW.node("BatchNormalization", ["a0", "gam", "bet", "mu", "var"], ["a1"], "/a/bn", [OW.attr_float("epsilon", 1e-3)]),
+             OW.node("Relu", ["a1"], ["a"], "/a/relu"),
+             OW.node("Conv", ["a", "w0"], ["b"], "/b", s2), OW.node("Conv", ["b", "w0"], ["c"], "/c", s2)]
+    heads = []
+    for l, src in enumerate(("a", "b", "c")):
+        nodes += [OW.node("Conv", [src, "wh"], ["o1_%d" % l], "/h1_%d" % l, [OW.attr_ints("kernel_shape", [1, 1])]),
+                  OW.node("Conv", [src, "wc"], ["o2_%d" % l], "/h2_%d" % l, [OW.attr_ints("kernel_shape", [1, 1])]),
+                  OW.node("Concat", ["o1_%d" % l, "o2_%d" % l], ["c_%d" % l], "/c_%d" % l, [OW.attr_int("axis", 1)]),
+                  OW.node("Reshape", ["c_%d" % l, "shp"], ["r_%d" % l], "/r_%d" % l)]
+        heads.append("r_%d" % l)
+    nodes.append(OW.node("Concat", heads, ["out"], "/cat", [OW.attr_int("axis", 2)]))
+    inits = [OW.tensor("w", w), OW.tensor("w0", w0), OW.tensor("gam", gam), OW.tensor("bet", bet), OW.tensor("mu", mu), OW.tensor("var", var),
+             OW.tensor("wh", wh), OW.tensor("wc", wc), OW.tensor("shp", np.asarray([1, 72, -1], np.int64))]
+    p = tmp_path / "bn.onnx"
+    open(p, "wb").write(OW.model(nodes, inits, [("images", [1, 3, 128, 128])], [("out", [1, 12, 336])]))
+    g2 = OL.lower(OI.read_onnx(str(p)), "bn")
+    x = rng.uniform(0, 1, (2, 3, 128, 128)).astype(np.float32)
+    taps = {}
+    graph_interp.run(g2, x, taps=taps)
+    with torch.no_grad():
+        t = torch.from_numpy(x)
+        for wt in (w, w0, w0):
+            t = F.conv2d(t, torch.from_numpy(wt), stride=2, padding=1)
+        want = F.relu(F.batch_norm(t, torch.from_numpy(mu), torch.from_numpy(var), torch.from_numpy(gam), torch.from_numpy(bet), False, 0.0, 1e-3))
+    name = [o["name"] for o in g2.ops if o["type"] == M.OP_CONV and o["act"] == M.ACT_RELU][0]
+    np.testing.assert_allclose(taps[name], want.numpy(), rtol=0, atol=2e-6)

@@ -121,6 +121,20 @@ class _Lowering:
                            b=np.asarray(_const(self.m, nd["inputs"][2]), np.float32) if len(nd["inputs"]) > 2 and nd["inputs"][2] else None,
                            name=self._layer_name(nd), res=None, res_mode=M.RES_NONE)
                 t = nd["outputs"][0]
+                if op == "Conv":      # Conv -> BatchNormalization (an export that did not fuse them): folded into the weights
+                    jb = self._single_consumer(t, "BatchNormalization")
+                    if jb is not None:
+                        bn = self.nodes[jb]
+                        cs = [_const(self.m, x) for x in bn["inputs"][1:5]]
+                        if len(cs) == 4 and all(c is not None for c in cs):
+                            gam, bet, mu, var = (np.asarray(c, np.float64).reshape(-1) for c in cs)
+                            eps = float(bn["attrs"].get("epsilon", 1e-5))
+                            sc_ = gam / np.sqrt(var + eps)
+                            b0 = rec["b"].astype(np.float64) if rec["b"] is not None else np.zeros(rec["w"].shape[0])
+                            rec["w"] = (rec["w"].astype(np.float64) * sc_.reshape(-1, 1, 1, 1)).astype(np.float32)
+                            rec["b"] = ((b0 - mu) * sc_ + bet).astype(np.float32)
+                            used.add(jb)
+                            t = bn["outputs"][0]
                 if op == "ConvTranspose":
                     rec.update(act=M.ACT_NONE, out=t)
                     ops.append(("deconv", i, rec))
