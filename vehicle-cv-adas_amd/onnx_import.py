@@ -32,7 +32,7 @@ except ImportError:  # executed as a script
 
 # Revision of this importer + the container it writes: part of the name of HipEngine's converted-model cache
 # (coreEngine.HipEngine._resolve_container), so containers written by an older importer are not reused.
-IMPORTER_VERSION = 3
+IMPORTER_VERSION = 4
 
 
 # ------------------------------------------------------------------------------------- protobuf wire format
