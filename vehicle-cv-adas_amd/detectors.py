@@ -266,7 +266,11 @@ class EfficientdetDetector(_Defaults):
         assert os.path.isfile(classes_path), Exception("%s is not exist." % classes_path)
         with open(classes_path) as f:
             self.class_names = [c.strip() for c in f.readlines()]
-        self.engine = engine if engine is not None else EfficientdetEngine(os.path.expanduser(self.model_path), precision=getattr(self, "precision", None))
+        # the in-graph tail's own parameters (what an exporter bakes into the graph): overridable like any other default
+        self.engine = engine if engine is not None else EfficientdetEngine(
+            os.path.expanduser(self.model_path), precision=getattr(self, "precision", None), score_thr=float(getattr(self, "graph_score_thr", 0.05)),
+            iou_thr=float(getattr(self, "graph_nms_iou", 0.5)), max_det=int(getattr(self, "graph_max_det", 100)),
+            max_candidates=int(getattr(self, "graph_max_candidates", 2048)))
         self.input_shapes = self.engine.get_engine_input_shape()                 # core.py:73-82
         self.input_types = self.engine.engine_dtype
         self.channes, self.input_height, self.input_width = self.input_shapes[1:]
