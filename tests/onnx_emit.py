@@ -264,6 +264,12 @@ class Emitter:
                     y = self.name("act")
                     self.node("Relu", [acc], [y])
                     acc = y
+                elif op["act"] == M.ACT_LEAKY:
+                    y = self.name("act")
+                    self.node("LeakyRelu", [acc], [y], [OW.attr_float("alpha", 0.1)])
+                    acc = y
+                else:
+                    assert op["act"] == M.ACT_NONE, op["act"]
                 self.wrote(out, acc)
             elif t == M.OP_UPSAMPLE2:
                 y, sc = self.name("up"), self.name("scales")

@@ -53,7 +53,8 @@ def test_mbconv_block_operators(tmp_path, prec, c, cr, k):
     lo = g.maxpool(p, 3, 2, 1, name="down")
     f2 = g.wsum([p, lo], M.fusion_weights([0.7, 1.2]), "fuse2")
     f3 = g.wsum([q, f2, lo], M.fusion_weights([1.0, 0.4, 0.9]), "fuse3", act=M.ACT_NONE)
-    z = g.conv(f3, 8, 1, 1, "tap", act=M.ACT_NONE, f32_out=True)
+    f4 = g.wsum([f3, p], [1.0, -0.5], "fuse4", act=M.ACT_LEAKY)   # Add -> LeakyReLU(0.1) (onnx_lower absorbs it into the sum): round 5
+    z = g.conv(f4, 8, 1, 1, "tap", act=M.ACT_NONE, f32_out=True)
     g.output(z, 0, [1, z.h * z.w * 8], "o")
     path = str(tmp_path / "mbunit.hipm")
     g.save(path)
@@ -62,7 +63,7 @@ def test_mbconv_block_operators(tmp_path, prec, c, cr, k):
     e = CE.HipEngine(path, prec, batch)
     got = e.engine_inference(xin)[0]
     kernels = [e.layer_kernel(i, batch) for i in range(e.stats()["num_layers"])]
-    acts = {n: e.fetch_activation(n, batch) for n in ("se.scale", "fuse2", "fuse3")}
+    acts = {n: e.fetch_activation(n, batch) for n in ("se.scale", "fuse2", "fuse3", "fuse4")}
     e.close()
     assert {"se_gate_kernel", "scale_kernel", "wsum_kernel", "dwconv_kernel"} <= set(kernels), kernels
     rel = TG.rel_l2(got.reshape(want.shape), want)
@@ -70,6 +71,7 @@ def test_mbconv_block_operators(tmp_path, prec, c, cr, k):
     assert rel <= TOL[prec], rel
     for n, v in acts.items():
         assert np.isfinite(v).all() and np.abs(v).max() > 1e-3, n
+    assert (acts["fuse4"] < 0).any(), "LeakyReLU behind the sum must let negative values through (scaled by 0.1)"
 
 
 @pytest.mark.parametrize("prec", ["fp32", "fp16x3", "fp16"])

@@ -121,8 +121,8 @@ def test_standalone_sums_become_weighted_sum_ops(tmp_path):
     g2, err = _roundtrip(g, tmp_path / "fuse.onnx", via_convert=True)
     assert err == 0.0 and len(g2.ops) == len(g.ops)
     sums = [o for o in g2.ops if o["type"] == M.OP_WSUM]
-    assert [len(o["ins"]) for o in sums] == [2, 2, 3, 2] and [o["act"] for o in sums] == [M.ACT_SILU, M.ACT_NONE, M.ACT_SILU, M.ACT_RELU]
-    assert [o["ins"][1].h * 2 == o["out"].h for o in sums] == [True, True, False, False]              # folded up-sampling where the graph had a Resize
+    assert [len(o["ins"]) for o in sums] == [2, 2, 3, 2, 2] and [o["act"] for o in sums] == [M.ACT_SILU, M.ACT_NONE, M.ACT_SILU, M.ACT_RELU, M.ACT_LEAKY]
+    assert [o["ins"][1].h * 2 == o["out"].h for o in sums] == [True, True, False, False, False]              # folded up-sampling where the graph had a Resize
     np.testing.assert_allclose(sums[2]["params"][:3], M.fusion_weights([0.9, 1.1, 0.4]), rtol=0, atol=0)
     assert not any(o["type"] == M.OP_UPSAMPLE2 for o in g2.ops)
     assert any(o["type"] == M.OP_CONV and o["res_mode"] == M.RES_AFTER_ACT for o in g2.ops)
@@ -263,6 +263,7 @@ def fuse_graph(hw=128):
     td3 = g.wsum([p3, td4], [1.0, 1.0], "td3.sum", act=M.ACT_NONE)                                           # plain sum, upsampled term
     bu4 = g.conv(g.wsum([p4, td4, g.maxpool(td3, 3, 2, 1, name="ds")], M.fusion_weights([0.9, 1.1, 0.4]), "bu4.fuse"), 32, 3, 1, "bu4.conv")
     s5 = g.wsum([p5, g.maxpool(bu4, 3, 2, 1, name="ds2")], [1.0, 0.5], "s5.sum", act=M.ACT_RELU)              # ReLU behind the sum
+    s5 = g.wsum([s5, p5], [1.0, -0.75], "l5.sum", act=M.ACT_LEAKY)                                            # LeakyReLU(0.1) behind the sum (round 5)
     ins, strides, nc = [], [], 7
     for i, f in enumerate((td3, bu4, s5)):
         ins += [g.conv(f, 64, 1, 1, "head.cv2.%d" % i, act=M.ACT_NONE, f32_out=True), g.conv(f, nc, 1, 1, "head.cv3.%d" % i, act=M.ACT_NONE, f32_out=True)]

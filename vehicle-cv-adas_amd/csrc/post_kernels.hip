@@ -401,6 +401,7 @@ struct adas_bytetrack {
     hipStream_t last;
     void* snap = nullptr;      // per-frame snapshots of the last update_device_frames launch ([n_frames][n_streams], grown on demand)
     int snap_frames = 0, snap_streams = 0;
+    int last_frames = 0;   // frames of the LAST adas_bytetrack_update_device_frames launch (0: a single-frame launch, no per-frame snapshots)
 };
 
 namespace adas {
@@ -1155,6 +1156,7 @@ int adas_bytetrack_update_device_frames(adas_bytetrack* h, const double* d_xyxy,
         }
         d.snap = (unsigned char*)h->snap; d.snap_bytes = bt_snap_bytes(h->p.max_tracks);
     }
+    h->last_frames = n_frames > 1 ? n_frames : 0;   // what adas_bytetrack_fetch_frame may ask for (older snapshots in the store are stale)
     size_t lds = BtLds::bytes(h->p.max_tracks, h->p.max_dets, 256);
     hipLaunchKernelGGL(bytetrack_update_kernel, dim3(n_streams), dim3(256), lds, st, d);
     ADAS_HIP_TRY(hipGetLastError());
@@ -1162,9 +1164,9 @@ int adas_bytetrack_update_device_frames(adas_bytetrack* h, const double* d_xyxy,
 }
 int adas_bytetrack_fetch_frame(adas_bytetrack* h, int stream_index, int frame, adas_track_header* hdr, adas_track* tracks, int max_tracks) {
     ADAS_REQUIRE(h && hdr && stream_index >= 0 && stream_index < h->n_streams, ADAS_ERR_INVALID, "adas_bytetrack_fetch_frame: bad argument");
-    ADAS_REQUIRE(h->snap && frame >= 0 && frame < h->snap_frames && stream_index < h->snap_streams, ADAS_ERR_INVALID,
+    ADAS_REQUIRE(h->snap && frame >= 0 && frame < h->snap_frames && frame < h->last_frames && stream_index < h->snap_streams, ADAS_ERR_INVALID,
                  "adas_bytetrack_fetch_frame: frame %d of stream %d is not part of the last adas_bytetrack_update_device_frames launch (%d frames x %d streams)",
-                 frame, stream_index, h->snap_frames, h->snap_streams);
+                 frame, stream_index, h->last_frames, h->snap_streams);
     ADAS_HIP_TRY(hipStreamSynchronize(h->last));
     const unsigned char* q = (const unsigned char*)h->snap + ((size_t)frame * h->snap_streams + stream_index) * bt_snap_bytes(h->p.max_tracks);
     ADAS_HIP_TRY(hipMemcpy(hdr, q, sizeof(BtHeader), hipMemcpyDeviceToHost));
@@ -1172,6 +1174,10 @@ int adas_bytetrack_fetch_frame(adas_bytetrack* h, int stream_index, int frame, a
     if (tracks && n > 0) {
         ADAS_REQUIRE(n <= max_tracks, ADAS_ERR_CAPACITY, "fetch buffer holds %d tracks, need %d", max_tracks, n);
         ADAS_HIP_TRY(hipMemcpy(tracks, q + bt_align(sizeof(BtHeader)), (size_t)n * sizeof(BtOut), hipMemcpyDeviceToHost));
+    }
+    if (hdr->err & (BT_ERR_DET_OVERFLOW | BT_ERR_TRACK_OVERFLOW | BT_ERR_HIST_OVERFLOW)) {   // as adas_bytetrack_fetch
+        set_error("bytetrack stream %d, frame %d: capacity exceeded (err bits 0x%x)", stream_index, frame, hdr->err);
+        return ADAS_ERR_CAPACITY;
     }
     return ADAS_OK;
 }

@@ -249,9 +249,16 @@ class EfficientdetDetector(_Defaults):
     network (models.efficientdet: EfficientNet-B0 MBConv + squeeze-and-excitation, BiFPN, separable-conv heads) and the in-graph tail
     (anchor decode + per-class NMS, adas_effdet_tail_*) on the device -- `model_path` is an "efficientdet-d0" .hipm container; or pass
     `engine=`, any object with the EngineBase surface (get_engine_input_shape / get_engine_output_shape / engine_inference /
-    engine_dtype).  An EfficientDet .onnx with its NMS baked in is not importable (onnx_import fails loudly)."""
+    engine_dtype).  An EfficientDet .onnx with its NMS baked in is not importable (onnx_import fails loudly), which is why the default
+    `model_path` names a .hipm container and not the reference's './models/efficientdet-d0-coco_fp32.onnx' (efficientdetDetector.py:22).
+
+    PADDING CAVEAT: models.efficientdet builds the PyTorch-native variant of the architecture -- symmetric k // 2 padding on every
+    stride-2 conv, depth-wise conv and BiFPN max-pool.  The public TF-derived checkpoints / exports use static 'same' padding (stride 2 pads
+    right and bottom only); pouring THOSE weights into this graph would shift every feature map by about a pixel per stride-2 stage against
+    the anchor grid.  Valid weights for this container are the seeded synthetic ones (models.py) or a network trained with symmetric
+    padding; no importer for the public checkpoint exists."""
     _defaults = {
-        "model_path": './models/efficientdet-d0-coco_fp32.onnx',
+        "model_path": './models/efficientdet-d0.hipm',
         "model_type": ObjectModelType.EfficientDet,
         "classes_path": './models/coco_label.txt',
         "box_score": 0.6,
@@ -693,7 +700,9 @@ class BYTETracker:
             for r in tracked:
                 tid = int(r["track_id"])
                 if int(r["start_frame"]) == self.frame_id and tid not in self._crops:
-                    tx1, ty1, tw, th = (int(np.floor(float(v) + 1e-9)) for v in r["tlwh"])
+                    # astype(int) truncates toward zero (strack.py:131-143); a new track's filtered tlwh IS its detection's up to the
+                    # tlwh -> xyah -> tlwh round trip's last ulp, which the 1e-9 guard absorbs on either side of zero
+                    tx1, ty1, tw, th = (int(np.trunc(float(v) + (1e-9 if float(v) >= 0 else -1e-9))) for v in r["tlwh"])
                     x1, y1 = max(0, tx1), max(0, ty1)
                     x2, y2 = min(fr.shape[1], tx1 + tw), min(fr.shape[0], ty1 + th)
                     self._crops[tid] = [fr[y1:y2, x1:x2, :].copy()]

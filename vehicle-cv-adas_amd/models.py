@@ -326,6 +326,7 @@ class Graph:
         """act(sum_i weights[i] * ins[i]) over 2-3 maps of one width; an input of half the output's resolution is read through a nearest
         2x upsample (BiFPN top-down nodes).  The output resolution is that of the largest input."""
         assert 2 <= len(ins) <= 3 and len(weights) == len(ins)
+        assert act in (ACT_NONE, ACT_SILU, ACT_RELU, ACT_LEAKY), (name, act)   # the kernel applies exactly these (fuse_ops.hip wsum_kernel)
         h, w, c = max(v.h for v in ins), max(v.w for v in ins), ins[0].c
         for v in ins:
             assert v.c == c and ((v.h, v.w) == (h, w) or (2 * v.h, 2 * v.w) == (h, w)), (name, (v.h, v.w, v.c), (h, w, c))
@@ -1181,7 +1182,9 @@ def _sepconv(g, x, cout, name, act=ACT_NONE, f32_out=False, dw_name=None, bias_f
 def efficientdet(nc=90, imgsz=512, wsrc=None, seed=0, fpn_c=64, fpn_cells=3, head_layers=3, num_anchors=9, cls_bias=-5.0):
     """EfficientDet-D0 up to its two raw head tensors per pyramid level: box regression (dy, dx, dh, dw) x 9 anchors and class logits
     nc x 9 anchors, rows ordered (y, x, anchor) -- what the exported graph feeds its in-graph anchor decode + NMS
-    (postproc.EffdetTail).  Symmetric k // 2 padding (the PyTorch-native variant of the architecture).  cls_bias: the classifier
+    (postproc.EffdetTail).  Symmetric k // 2 padding (the PyTorch-native variant of the architecture): weights of the public
+    TF-'same'-padded checkpoints (stride 2 pads right / bottom only) are NOT valid for this graph -- see detectors.EfficientdetDetector.
+    cls_bias: the classifier
     header's bias (trained nets start it at -log(99) = -4.6; -5 leaves ~1 % of the seeded net's anchors over a 0.05 score threshold)."""
     H, W = _hw(imgsz)
     assert H % 128 == 0 and W % 128 == 0, "EfficientDet needs inputs divisible by 128 (five pyramid levels, 2x resampling)"
