@@ -75,28 +75,27 @@ def _assert_exact(o):
     assert o["max_conf_diff_on_identical_frames"] <= 1e-4 and o["max_box_diff_px_on_identical_frames"] <= 1e-2
 
 
-def _assert_16bit(o, strict=True):
+def _assert_16bit(o):
     """Bounds on how MANY discrete decisions differ (measured values are printed by _run_chain).  A half-precision network leaves
     ~1e-3 of the anchor-to-anchor logit spread as error (tools/synth_snr.py), so of 8400 anchors with ~100 over the threshold
     about 0.4-1 per frame sits closer to it than that and is decided differently; one such anchor changes the NMS outcome of its
-    neighbourhood (one or two survivors).  What the tracker and every consumer see has to hold up regardless: `strict` (the
-    north-star YOLOv8n and the YOLOv8s pipelines) requires >= 75 % of the compared track snapshots EQUIVALENT (same tracks under a
-    consistent id renaming) and >= 90 % of the frames with EQUIVALENT survivor lists (one-to-one partners of the same class,
-    IoU >= 0.9, confidence within 2e-2); where the run carries the storage-rounding emulation of the same schedule (`emulated`), the
-    device is held to IT: no more lost decisions than half storage alone costs.  The seeded
-    YOLOv8l net does not meet that in fp16 (profiles/r04/layer_drift_yolov8l.txt: flat 3-9e-4 per layer, no kernel stands out; its
-    class signal across anchors is ~1 % of the logit magnitude and the calibration stretches the rounding noise with it): it is held to
-    the storage-rounding yardstick alone (`emulated` below) -- and to exactness in fp16x3."""
+    neighbourhood (one or two survivors).  What the tracker and every consumer see has to hold up regardless: >= 75 % of the compared
+    track snapshots EQUIVALENT (same tracks under a consistent id renaming) and >= 90 % of the frames with EQUIVALENT survivor lists
+    (one-to-one partners of the same class, IoU >= 0.9, confidence within 2e-2); where the run carries the storage-rounding emulation
+    of the same schedule (`emulated`), the device is held to IT as well: no more lost decisions than half storage alone costs.
+    The seeded YOLOv8l net does not meet these bounds in fp16 (profiles/r04/layer_drift_yolov8l.txt: flat 3-9e-4 per layer, no kernel
+    stands out; its class signal across anchors is ~1 % of the logit magnitude and the calibration stretches the rounding noise with
+    it) and gets no lenient variant of this check (round 5): configs[4] is claimed, tested and benchmarked in the modes that reproduce
+    the oracle chain exactly (fp32, fp16x3 -- `bench.py --preset c5` defaults to the latter)."""
     n = o["frames"]
     assert o["survivors_compared"] >= 2 * n
     assert o["candidate_anchors_differing"] <= 0.04 * o["candidates_compared"], o
     assert o["survivor_anchors_differing"] <= 4 * n, o
-    if strict:
-        # the same tracks (state, class, box) under a consistent renaming of ids -- ByteTrack numbers new tracks in detection order, and
-        # two detections tied within the 16-bit error swap list places (chain_parity.ChainStats.add_tracks).  Measured on this file's
-        # samples: 26 of 32 (YOLOv8n), 12 of 12 (YOLOv8s); the CPU emulation that only rounds storage to half loses as many (below)
-        assert o["equivalent_tracks"] >= 0.75 * o["track_states_compared"] > 0, o
-        assert o["equivalent_survivor_sets"] >= 0.9 * n, o
+    # the same tracks (state, class, box) under a consistent renaming of ids -- ByteTrack numbers new tracks in detection order, and
+    # two detections tied within the 16-bit error swap list places (chain_parity.ChainStats.add_tracks).  Measured on this file's
+    # samples: 26 of 32 (YOLOv8n), 12 of 12 (YOLOv8s); the CPU emulation that only rounds storage to half loses as many (below)
+    assert o["equivalent_tracks"] >= 0.75 * o["track_states_compared"] > 0, o
+    assert o["equivalent_survivor_sets"] >= 0.9 * n, o
     e = o.get("emulated")
     if e is not None:
         # kernel error or 16-bit rounding?  The device may lose no more decisions than the storage-rounding emulation does (+ a
@@ -133,7 +132,7 @@ def test_step_frames_split_precision_matches_oracle_chain_exactly(tmp_path):
     _assert_exact(o)
 
 
-@pytest.mark.parametrize("det,prec", [("yolov8s", "fp32"), ("yolov8s", "fp16"), ("yolov8l", "fp32"), ("yolov8l", "fp16"),
+@pytest.mark.parametrize("det,prec", [("yolov8s", "fp32"), ("yolov8s", "fp16"), ("yolov8l", "fp32"),
                                       ("yolov8s", "fp16x3"), ("yolov8l", "fp16x3")])
 def test_c4_c5_pipelines_match_oracle_chain(tmp_path, det, prec):
     """BASELINE configs[3] / configs[4]: YOLOv8s / YOLOv8l + UFLDv2-R18 + ByteTrack on 1280x720 frames, 2 streams x 6 steps."""
@@ -141,7 +140,7 @@ def test_c4_c5_pipelines_match_oracle_chain(tmp_path, det, prec):
     if prec in ("fp32", "fp16x3"):
         _assert_exact(o)
     else:
-        _assert_16bit(o, strict=det != "yolov8l")
+        _assert_16bit(o)
 
 
 @pytest.mark.parametrize("prec", ["fp32", "fp16x3"])

@@ -143,6 +143,9 @@ def test_bench_gpus_n_relaunches_n_ranks(tmp_path):
     r = json.loads(lines[0])
     assert r["n_gpus"] == 2 and len(r["per_rank"]) == 2 and r["config"]["frames_per_step"] == 4
     assert r["value"] > 0 and r["config"]["frames_at_candidate_capacity"] == 0
+    # whole-job rate = every rank's frames / the slowest rank's seconds (the max-over-ranks clock), not a sum of per-rank rates
+    frames, slowest = sum(q["frames"] for q in r["per_rank"]), max(q["seconds"] for q in r["per_rank"])
+    assert frames == 3 * 4 and abs(r["value"] - frames / slowest) <= 0.02 * r["value"], (r["value"], r["per_rank"])
     assert r["cpu_baseline"] is None and r["modes"] is None          # single-rank legs are skipped with world > 1
 
 

@@ -58,3 +58,46 @@ def test_two_rank_gloo_stats_gather():
     assert [d["p50_ms"] for d in st0] == [5.0, 6.0] and [d["p99_ms"] for d in st0] == [5.5, 6.5]
     agg = SH.aggregate_throughput(st0)
     assert agg["frames"] == 360.0 and agg["seconds"] == 2.0 and agg["fps"] == 180.0
+
+
+def _worker_n(rank, world, port, n_streams, q):
+    sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from conftest import load_pkg
+    load_pkg()
+    sh = importlib.import_module("adas_amd.sharding")
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world))
+    env = sh.RankEnv.from_environ()
+    dist = sh.init_process_group(env, backend="gloo")
+    mine = sh.streams_of_rank(n_streams, env)
+    seconds = 1.0 + 0.25 * ((rank * 5) % world)                            # a different slowest rank per world size
+    elapsed = sh.max_over_ranks(seconds, dist)
+    stats = sh.gather_stats({"frames": 20.0 * len(mine), "seconds": seconds, "streams": float(len(mine)), "p50_ms": 4.0 + rank, "p99_ms": 4.5 + rank},
+                            ("frames", "seconds", "streams", "p50_ms", "p99_ms"), dist)
+    dist.barrier()
+    q.put((rank, mine, elapsed, stats))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,n_streams", [(4, 9), (4, 2), (8, 13), (8, 64)])
+def test_four_and_eight_rank_gloo_uneven_streams(world, n_streams):
+    """The driver's 1 / 2 / 4 / 8 scaling runs rehearsed on CPU: world sizes 4 and 8 over gloo, stream counts that do not
+    divide (9 over 4, 13 over 8) and one smaller than the world (2 over 4: two ranks own nothing and still take part in both
+    collectives).  Whole-job frames/s = all frames / the slowest rank's seconds, identical on every rank."""
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_n, args=(r, world, port, n_streams, q)) for r in range(world)]
+    [p.start() for p in procs]
+    res = sorted(q.get(timeout=240) for _ in range(world))
+    [p.join(60) for p in procs]
+    assert all(p.exitcode == 0 for p in procs)
+    owned = sorted(s_ for _, mine, _, _ in res for s_ in mine)
+    assert owned == list(range(n_streams))                                                    # every stream on exactly one rank
+    assert all(mine == list(range(r, n_streams, world)) for r, mine, _, _ in res)
+    slowest = max(1.0 + 0.25 * ((r * 5) % world) for r in range(world))
+    assert all(e == slowest for _, _, e, _ in res)
+    st0 = res[0][3]
+    assert all(st == st0 for _, _, _, st in res) and len(st0) == world
+    assert [d["streams"] for d in st0] == [float(len(range(r, n_streams, world))) for r in range(world)]
+    agg = SH.aggregate_throughput(st0)
+    assert agg["frames"] == 20.0 * n_streams and agg["seconds"] == slowest and agg["fps"] == 20.0 * n_streams / slowest
