@@ -715,7 +715,7 @@ def main():
     n_launches = 0
     for eng, dptr in ((pipe.det, d_det[0].ptr), (pipe.lane, d_lane[0].ptr)):
         eng.profile(dptr, S, iters=3)            # the device idled while the stats were fetched: let the clocks come back first
-        stem_label = pair_label = c2f_label = None
+        stem_label = pair_label = c2f_label = ml_label = None
         pending_shortcut = 0.0
         for li, (name, fl, kind, ms) in enumerate(eng.profile(dptr, S, iters=10)):
             all_ms += ms
@@ -737,6 +737,8 @@ def main():
                     label, launches = pair_label, 0   # second conv of a 3x3 -> 3x3 pair: computed by the first conv's launch
                 elif label.startswith("(fused into the C2f") and c2f_label:
                     label, launches = c2f_label, 0    # Bottleneck pair / closing 1x1 of a C2f block computed by its cv1's launch
+                elif label.startswith("(in the multi-layer") and ml_label:
+                    label, launches = ml_label, 0     # a member of a multi-layer persistent launch (conv_ml.hip): its FLOPs belong to that launch
                 elif label.startswith("(fused into"):
                     continue                          # fused into a neighbouring conv launch that reports the FLOPs itself
                 elif label.startswith("conv_stem_kernel"):
@@ -745,6 +747,8 @@ def main():
                     pair_label = label
                 elif label.startswith("conv_c2f16_kernel"):
                     c2f_label = label
+                elif label.startswith("conv_ml_kernel"):
+                    ml_label = label
                 extra = 0.0
                 if raw_label.endswith("+shortcut"):
                     extra, pending_shortcut = pending_shortcut, 0.0

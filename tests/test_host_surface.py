@@ -30,7 +30,7 @@ def test_ctypes_structs_match_the_header_layout(tmp_path):
              ("adas_effdet_tail_params", L.EffdetTailParams),
              ("adas_ufld1_params", L.Ufld1Params), ("adas_lane_geometry_params", L.LaneGeometryParams),
              ("adas_lane_geometry_result", L.LaneGeometryResult), ("adas_bytetrack_params", L.BytetrackParams),
-             ("adas_track_header", L.TrackHeader), ("adas_pipeline_desc", L.PipelineDesc)]
+             ("adas_track_header", L.TrackHeader), ("adas_pipeline_desc", L.PipelineDesc), ("adas_ml_view", L.MlView), ("adas_ml_layer_desc", L.MlLayerDesc)]
     lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "adas_hip.h"', 'int main(void) {']
     for cname, cls in pairs:
         lines.append('  printf("%s size %%zu\\n", sizeof(%s));' % (cname, cname))

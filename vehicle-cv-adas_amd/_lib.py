@@ -82,6 +82,15 @@ class PipelineDesc(C.Structure):
                 ("micro_batch", C.c_int32), ("reserved", C.c_int32)]
 
 
+class MlView(C.Structure):
+    _fields_ = [("buf", C.c_uint64), ("cs", C.c_int32), ("coff", C.c_int32), ("c", C.c_int32), ("h", C.c_int32), ("w", C.c_int32)]
+
+
+class MlLayerDesc(C.Structure):
+    _fields_ = [("kernel", C.c_int32), ("stride", C.c_int32), ("act", C.c_int32), ("res_mode", C.c_int32), ("up_c", C.c_int32), ("halo_bn", C.c_int32),
+                ("x", MlView), ("y", MlView), ("res", MlView), ("up", MlView)]
+
+
 TRACK_DTYPE = np.dtype([("tlwh", "f8", 4), ("score", "f8"), ("track_id", "i4"), ("state", "i4"), ("is_activated", "i4"),
                         ("class_id", "i4"), ("frame_id", "i4"), ("start_frame", "i4"), ("tracklet_len", "i4"), ("pad", "i4")])
 
@@ -113,6 +122,12 @@ _SIGS = {
     "adas_engine_infer_device": (C.c_int, [_P, _P, C.c_int, _P]),
     "adas_engine_accepts_packed_input": (C.c_int, [_P]),
     "adas_engine_precision": (C.c_int, [_P]),
+    "adas_engine_prepare": (C.c_int, [_P, C.c_int]),
+    "adas_engine_ml_info": (C.c_int, [_P, C.c_int, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+    "adas_engine_ml_status": (C.c_int, [_P, C.c_int, C.POINTER(C.c_uint32)]),
+    "adas_engine_launch_count": (C.c_int, [_P, C.c_int]),
+    "adas_debug_ml_plan": (C.c_int, [C.POINTER(MlLayerDesc), C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_uint64),
+                                     C.c_int, C.POINTER(C.c_int32)]),
     "adas_engine_model_io_half": (C.c_int, [_P]),
     "adas_engine_infer_device_packed": (C.c_int, [_P, _P, C.c_int, _P]),
     "adas_engine_output_device": (_P, [_P, C.c_int]),

@@ -21,6 +21,7 @@ UNITS = [
     ("conv_kernels.hip", []),
     ("conv_x3.hip", []),
     ("conv_halo.hip", []),
+    ("conv_ml.hip", []),
     ("conv_halo_rw.hip", []),
     ("conv_halo_s2.hip", []),
     ("conv_halo8.hip", []),

@@ -186,6 +186,25 @@ class HipEngine(EngineBase):
         L.check(L.lib().adas_engine_layer_kernel(self._h, i, int(batch), name, 96))
         return name.value.decode()
 
+    # ---- multi-layer launches (csrc/conv_ml.hip): what the engine decided for a batch size, and the last launch's status
+    def prepare(self, batch=1):
+        L.check(L.lib().adas_engine_prepare(self._h, int(batch)))
+
+    def ml_info(self, batch=1):
+        """{'launches', 'layers', 'items'} of the multi-layer launches prepared for `batch` frames (zeros: none / ADAS_NO_ML=1)."""
+        a, b, c = C.c_int32(), C.c_int32(), C.c_int32()
+        L.check(L.lib().adas_engine_ml_info(self._h, int(batch), C.byref(a), C.byref(b), C.byref(c)))
+        return {"launches": a.value, "layers": b.value, "items": c.value}
+
+    def ml_status(self, batch=1):
+        """Synchronises; raises when a dependency wait of the last multi-layer launch timed out (every wait is bounded)."""
+        w = C.c_uint32()
+        L.check(L.lib().adas_engine_ml_status(self._h, int(batch), C.byref(w)))
+        return int(w.value)
+
+    def launch_count(self, batch=1):
+        return int(L.lib().adas_engine_launch_count(self._h, int(batch)))
+
     def layer_index(self, name):
         for i in range(self.stats()["num_layers"]):
             if self.layer_info(i)[0] == name:

@@ -56,8 +56,66 @@ static bool is_c2f_tail(const adas_engine* e, int i) {   // the block's cv2: its
     return false;
 }
 
+// The ConvArgs engine_run_op launches op `i` (a plain OP_CONV: not a stem / pair / C2f launch) with at this batch.
+static ConvArgs conv_args_of(const adas_engine* e, int i, int batch) {
+    const EngOp& op = e->ops[i];
+    const FileOp& o = op.f;
+    unsigned char* wb = (unsigned char*)e->d_weights;
+    ConvArgs a;
+    a.in = make_view(e, o.in_buf[0], o.in_coff[0], o.in_c[0]);
+    a.out = make_view(e, o.out_buf, o.out_coff, o.out_c);
+    if (o.res_mode != RES_NONE) a.res = make_view(e, o.res_buf, o.res_coff, o.out_c);
+    else { a.res = a.out; a.res.p = nullptr; }
+    a.wgt = wb + op.w_off;
+    a.bias = (const float*)(wb + op.b_off);
+    a.n = batch; a.kh = o.kh; a.kw = o.kw; a.stride = o.stride; a.pad = o.pad; a.act = o.act; a.res_mode = o.res_mode;
+    a.k = op.k; a.kpad = op.kpad; a.m = batch * a.out.h * a.out.w; a.max_n = e->max_batch; a.prec = e->prec;
+    if (op.has_x3h8) a.wgt_h8x3 = wb + op.x3h8_w_off;
+    a.halo_bn = op.halo_bn;
+    if (op.ds_src >= 0 && ds_folded(e, i, batch)) {
+        const EngOp& dsop = e->ops[op.ds_src];
+        a.ds_in = make_view(e, dsop.f.in_buf[0], dsop.f.in_coff[0], dsop.f.in_c[0]);
+        a.ds_w = wb + dsop.ds_w_off;
+        a.ds_bias = (const float*)(wb + dsop.b_off);
+    }
+    if (op.up_src >= 0) {
+        const FileOp& u = e->ops[op.up_src].f;
+        a.up = make_view(e, u.in_buf[0], u.in_coff[0], u.in_c[0]);
+        a.up_c = (int)u.out_c;
+    }
+    return a;
+}
+
+// ---- multi-layer launches (conv_ml.hip).  ADAS_NO_ML=1 keeps every layer its own launch.
+static bool ml_enabled(const adas_engine* e) { return e->ml_on; }   // decided when the engine was created (ADAS_NO_ML, 16-bit precisions)
+
+// Is op `i` a conv that launches on its own at this batch AND has a tile body in the multi-layer kernel?
+static bool ml_candidate(const adas_engine* e, int i, int batch, ConvArgs* out) {
+    const EngOp& op = e->ops[i];
+    const FileOp& o = op.f;
+    if (o.type != OP_CONV || op.skip || (op.kernel != CONV_HALO && op.kernel != CONV_PW)) return false;
+    if (op.pair_b >= 0 || op.c2f[0] >= 0 || op.fuse_pool >= 0 || op.fuse_conv2 >= 0) return false;
+    if (op.ds_user >= 0 && ds_folded(e, op.ds_user, batch)) return false;   // launches nothing at this batch
+    if (op.ds_src >= 0 && ds_folded(e, i, batch)) return false;              // carries its projection: conv_halo8 only
+    auto aliased = [&](int b) { return b >= 0 && b < (int)e->buf_aliased.size() && e->buf_aliased[b]; };
+    if (aliased(o.in_buf[0]) || aliased(o.out_buf) || (o.res_mode != RES_NONE && aliased(o.res_buf))) return false;
+    if (op.up_src >= 0 && aliased(e->ops[op.up_src].f.in_buf[0])) return false;
+    const ConvArgs a = conv_args_of(e, i, batch);
+    if (!ml_layer_supported(a, op.kernel)) return false;
+    if (out) *out = a;
+    return true;
+}
+
+static const std::vector<MlSeg>* ml_segments(const adas_engine* e, int batch) {
+    auto it = e->ml.find(batch);
+    return it == e->ml.end() ? nullptr : &it->second;
+}
+
 static int free_engine(adas_engine* e) {
     if (!e) return ADAS_OK;
+    for (auto& kv : e->ml)
+        for (auto& sg : kv.second) ml_plan_destroy(sg.plan);
+    e->ml.clear();
     for (auto& b : e->bufs)
         if (b.d && b.alias_of < 0) (void)hipFree(b.d);
     if (e->d_weights) (void)hipFree(e->d_weights);
@@ -90,6 +148,10 @@ int adas_engine_create(const char* model_path, int precision, int max_batch, ada
     adas_engine* e = new adas_engine();
     e->prec = precision;
     e->max_batch = max_batch;
+    {
+        const char* v = getenv("ADAS_NO_ML");
+        e->ml_on = prec_is16(precision) && !(v && v[0] == '1');
+    }
     e->hdr = hd;
     e->name = std::string(hd.name, strnlen(hd.name, sizeof(hd.name)));
     std::vector<FileBuf> fb(hd.n_bufs);
@@ -165,6 +227,9 @@ int adas_engine_create(const char* model_path, int precision, int max_batch, ada
     }
     for (auto& b : e->bufs)
         if (b.alias_of >= 0) b.d = e->bufs[b.alias_of].d;
+    e->buf_aliased.assign(e->bufs.size(), 0);
+    for (size_t bi = 0; bi < e->bufs.size(); ++bi)
+        if (e->bufs[bi].alias_of >= 0) e->buf_aliased[bi] = e->buf_aliased[e->bufs[bi].alias_of] = 1;
     // ---- the operators without a generic fallback must be shapes their kernel takes (a damaged or foreign container fails here, not at launch)
     for (auto& o : fo) {
         auto view = [&](int buf, int coff, int c) { return make_view(e, buf, coff, c); };
@@ -762,7 +827,16 @@ int adas_engine_layer_kernel(const adas_engine* e, int layer, int batch, char* n
     static const char* kOther[] = {"input_nchw_kernel", "", "maxpool_kernel", "upsample2_kernel", "detect_v8_kernel", "detect_v5_kernel",
                                    "layernorm_kernel", "dwconv_kernel", "attention_kernel", "avgpool_kernel", "depth2space_kernel", "detect_v6_kernel",
                                    "se_gate_kernel", "scale_kernel", "wsum_kernel", "shuffle_kernel"};
-    if (o.type == OP_CONV && op.ds_user >= 0 && ds_folded(e, op.ds_user, batch)) {
+    const MlSeg* in_seg = nullptr;
+    if (const std::vector<MlSeg>* segs = ml_segments(e, batch))
+        for (auto& sg : *segs)
+            for (int m : sg.ops)
+                if (m == layer) in_seg = &sg;
+    if (in_seg && in_seg->first == layer) {
+        snprintf(name, cap, "conv_ml_kernel[%d layers]", in_seg->n_layers);
+    } else if (in_seg) {
+        snprintf(name, cap, "(in the multi-layer launch)");
+    } else if (o.type == OP_CONV && op.ds_user >= 0 && ds_folded(e, op.ds_user, batch)) {
         snprintf(name, cap, "(fused into the conv it is the shortcut of)");
     } else if (op.skip && o.type == OP_UPSAMPLE2) {
         snprintf(name, cap, "(folded into the consumer's loads)");
@@ -893,28 +967,7 @@ int engine_run_op(adas_engine* e, int i, const float* d_in, int batch, hipStream
                                        b.f.res_mode != RES_NONE, e->prec, st);
                 break;
             }
-            ConvArgs a;
-            a.in = make_view(e, o.in_buf[0], o.in_coff[0], o.in_c[0]);
-            a.out = make_view(e, o.out_buf, o.out_coff, o.out_c);
-            if (o.res_mode != RES_NONE) a.res = make_view(e, o.res_buf, o.res_coff, o.out_c);
-            else { a.res = a.out; a.res.p = nullptr; }
-            a.wgt = wb + op.w_off;
-            a.bias = (const float*)(wb + op.b_off);
-            a.n = batch; a.kh = o.kh; a.kw = o.kw; a.stride = o.stride; a.pad = o.pad; a.act = o.act; a.res_mode = o.res_mode;
-            a.k = op.k; a.kpad = op.kpad; a.m = batch * a.out.h * a.out.w; a.max_n = e->max_batch; a.prec = e->prec;
-            if (op.has_x3h8) a.wgt_h8x3 = wb + op.x3h8_w_off;
-            a.halo_bn = op.halo_bn;
-            if (op.ds_src >= 0 && ds_folded(e, i, batch)) {
-                const EngOp& dsop = e->ops[op.ds_src];
-                a.ds_in = make_view(e, dsop.f.in_buf[0], dsop.f.in_coff[0], dsop.f.in_c[0]);
-                a.ds_w = wb + dsop.ds_w_off;
-                a.ds_bias = (const float*)(wb + dsop.b_off);
-            }
-            if (op.up_src >= 0) {
-                const FileOp& u = e->ops[op.up_src].f;
-                a.up = make_view(e, u.in_buf[0], u.in_coff[0], u.in_c[0]);
-                a.up_c = (int)u.out_c;
-            }
+            const ConvArgs a = conv_args_of(e, i, batch);
             err = launch_conv(a, e->prec, st);
             break;
         }
@@ -1042,8 +1095,74 @@ int engine_run_op(adas_engine* e, int i, const float* d_in, int batch, hipStream
     return ADAS_OK;
 }
 
+// Builds the multi-layer launches of this batch size (device tables: allocations and copies, so never inside a stream capture --
+// adas_pipeline_* prepares before it captures; a forward that finds nothing prepared while capturing runs per-layer launches).
+int engine_prepare(adas_engine* e, int batch) {
+    if (!ml_enabled(e) || e->ml.count(batch)) return ADAS_OK;
+    std::vector<MlSeg>& segs = e->ml[batch];
+    static int min_layers = -1, max_items = -1;
+    if (min_layers < 0) { const char* v = getenv("ADAS_ML_MIN_LAYERS"); min_layers = v ? atoi(v) : 2; if (min_layers < 1) min_layers = 1; }
+    if (max_items < 0) { const char* v = getenv("ADAS_ML_MAX_LAYER_ITEMS"); max_items = v ? atoi(v) : 0; }   // experiments: keep layers with more items out
+    const int n = (int)e->ops.size();
+    int i = 0;
+    while (i < n) {
+        std::vector<ConvArgs> layers;
+        std::vector<int> kernels, ops;
+        int j = i, last = i;
+        for (; j < n; ++j) {
+            if (e->ops[j].skip) continue;            // launches nothing (fused into a neighbour): transparent
+            if (e->ops[j].f.type == OP_CONV && e->ops[j].ds_user >= 0 && ds_folded(e, e->ops[j].ds_user, batch)) continue;
+            ConvArgs a;
+            if (!ml_candidate(e, j, batch, &a) || (int)layers.size() >= ML_MAX_LAYERS) break;
+            if (max_items > 0) {
+                const long wgs = (long)((a.m + 255) / 256) * ((a.out.c + 63) / 64);
+                if (wgs > max_items) break;
+            }
+            layers.push_back(a); kernels.push_back(e->ops[j].kernel); ops.push_back(j);
+            last = j;
+        }
+        if ((int)layers.size() >= min_layers) {
+            std::string why;
+            MlPlanInfo info;
+            MlPlan* pl = ml_plan_create(layers, kernels, e->prec, &why, &info);
+            if (pl) {
+                MlSeg sg;
+                sg.first = ops.front(); sg.last = last; sg.n_layers = (int)layers.size(); sg.n_items = info.n_items; sg.plan = pl; sg.ops = ops;
+                segs.push_back(sg);
+            }
+            i = last + 1;
+        } else {
+            i = (layers.empty() ? j : last) + 1;
+        }
+    }
+    return ADAS_OK;
+}
+
+static bool stream_capturing(hipStream_t st) {
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(st, &cs) != hipSuccess) { (void)hipGetLastError(); return false; }
+    return cs != hipStreamCaptureStatusNone;
+}
+
 int engine_forward(adas_engine* e, const float* d_in, int batch, hipStream_t st, bool packed_in) {
+    if (ml_enabled(e) && !e->ml.count(batch) && !stream_capturing(st)) {
+        int rc = engine_prepare(e, batch);
+        if (rc != ADAS_OK) return rc;
+    }
+    const std::vector<MlSeg>* segs = ml_segments(e, batch);
+    size_t si = 0;
     for (int i = 0; i < (int)e->ops.size(); ++i) {
+        if (segs && si < segs->size() && (*segs)[si].first == i) {
+            const MlSeg& sg = (*segs)[si++];
+            hipError_t err = ml_launch(sg.plan, st);
+            if (err != hipSuccess) {
+                set_error("layers %d..%d (%s ...): multi-layer launch failed: %s", sg.first, sg.last, e->ops[sg.first].name.c_str(), hipGetErrorString(err));
+                (void)hipGetLastError();
+                return ADAS_ERR_HIP;
+            }
+            i = sg.last;
+            continue;
+        }
         int rc = engine_run_op(e, i, d_in, batch, st, packed_in);
         if (rc != ADAS_OK) return rc;
     }
@@ -1058,6 +1177,91 @@ int adas_engine_infer_device(adas_engine* e, const float* d_input, int batch, vo
                  e ? e->max_batch : 0);
     e->last = (hipStream_t)stream;
     return engine_forward(e, d_input, batch, (hipStream_t)stream);
+}
+
+int adas_engine_prepare(adas_engine* e, int batch) {
+    ADAS_REQUIRE(e && batch > 0 && batch <= e->max_batch, ADAS_ERR_INVALID, "adas_engine_prepare: bad argument (batch %d, max %d)", batch, e ? e->max_batch : 0);
+    return engine_prepare(e, batch);
+}
+int adas_engine_ml_info(const adas_engine* e, int batch, int32_t* n_launches, int32_t* n_layers, int32_t* n_items) {
+    ADAS_REQUIRE(e && batch > 0, ADAS_ERR_INVALID, "adas_engine_ml_info: bad argument");
+    int nl = 0, ni = 0, ns = 0;
+    if (const std::vector<MlSeg>* segs = ml_segments(e, batch))
+        for (auto& sg : *segs) { ++ns; nl += sg.n_layers; ni += sg.n_items; }
+    if (n_launches) *n_launches = ns;
+    if (n_layers) *n_layers = nl;
+    if (n_items) *n_items = ni;
+    return ADAS_OK;
+}
+int adas_engine_ml_status(const adas_engine* e, int batch, uint32_t* error_word) {
+    ADAS_REQUIRE(e && error_word, ADAS_ERR_INVALID, "adas_engine_ml_status: bad argument");
+    *error_word = 0;
+    if (const std::vector<MlSeg>* segs = ml_segments(e, batch))
+        for (auto& sg : *segs) {
+            unsigned w = 0;
+            ADAS_REQUIRE(ml_plan_status(sg.plan, &w) == 0, ADAS_ERR_HIP, "adas_engine_ml_status: could not read the control block");
+            if (w) {
+                *error_word = w;
+                set_error("multi-layer launch of layers %d..%d: a dependency wait timed out (item %u)", sg.first, sg.last, w - 1);
+                return ADAS_ERR_HIP;
+            }
+        }
+    return ADAS_OK;
+}
+int adas_engine_launch_count(adas_engine* e, int batch) {
+    if (!e || batch <= 0 || batch > e->max_batch) return -1;
+    const std::vector<MlSeg>* segs = ml_segments(e, batch);
+    size_t si = 0;
+    int n = 0;
+    for (int i = 0; i < (int)e->ops.size(); ++i) {
+        if (segs && si < segs->size() && (*segs)[si].first == i) { ++n; i = (*segs)[si++].last; continue; }
+        const EngOp& op = e->ops[i];
+        if (op.skip) continue;
+        if (op.f.type == OP_CONV && op.ds_user >= 0 && ds_folded(e, op.ds_user, batch)) continue;
+        ++n;
+    }
+    return n;
+}
+
+int adas_debug_ml_plan(const adas_ml_layer_desc* layers, int n_layers, int batch, int precision, int32_t* deps, int32_t* targets, uint64_t* items,
+                       int items_cap, int32_t summary[4]) {
+    ADAS_REQUIRE(layers && n_layers > 0 && batch > 0 && deps && targets && summary, ADAS_ERR_INVALID, "adas_debug_ml_plan: bad argument");
+    std::vector<ConvArgs> ls;
+    std::vector<int> ks;
+    auto view = [](const adas_ml_view& v) {
+        TView t;
+        t.p = (void*)(uintptr_t)v.buf; t.cs = v.cs; t.coff = v.coff; t.c = v.c; t.h = v.h; t.w = v.w; t.f32 = 0;
+        return t;
+    };
+    for (int i = 0; i < n_layers; ++i) {
+        const adas_ml_layer_desc& d = layers[i];
+        ConvArgs a;
+        a.in = view(d.x); a.out = view(d.y);
+        if (d.res_mode != RES_NONE) a.res = view(d.res);
+        else { a.res = a.out; a.res.p = nullptr; }
+        a.wgt = (const void*)(uintptr_t)0x1000; a.bias = (const float*)(uintptr_t)0x1000;
+        a.n = batch; a.kh = a.kw = d.kernel == CONV_PW ? 1 : 3; a.stride = d.stride; a.pad = d.kernel == CONV_PW ? 0 : 1; a.act = d.act; a.res_mode = d.res_mode;
+        a.k = a.kh * a.kw * a.in.c; a.kpad = (a.kh * a.kw * ((a.in.c + 31) / 32 * 32) + 31) / 32 * 32; a.m = batch * a.out.h * a.out.w; a.max_n = batch; a.prec = precision;
+        a.halo_bn = d.halo_bn;
+        if (d.up_c > 0) { a.up = view(d.up); a.up_c = d.up_c; }
+        ls.push_back(a); ks.push_back(d.kernel);
+    }
+    std::string why;
+    MlPlanInfo info;
+    MlPlan* pl = ml_plan_create(ls, ks, precision, &why, &info, true);
+    ADAS_REQUIRE(pl, ADAS_ERR_INVALID, "adas_debug_ml_plan: %s", why.c_str());
+    ml_plan_destroy(pl);
+    for (int i = 0; i < n_layers; ++i)
+        for (int k = 0; k < ML_MAX_DEPS; ++k) {
+            deps[i * ML_MAX_DEPS + k] = k < (int)info.deps[i].size() ? info.deps[i][k] : -1;
+            targets[i * ML_MAX_DEPS + k] = k < (int)info.targets[i].size() ? info.targets[i][k] : 0;
+        }
+    summary[0] = info.n_items; summary[1] = info.grid; summary[2] = (int32_t)info.lds; summary[3] = info.order;
+    if (items) {
+        ADAS_REQUIRE(items_cap >= info.n_items, ADAS_ERR_CAPACITY, "adas_debug_ml_plan: %d items, room for %d", info.n_items, items_cap);
+        for (int k = 0; k < info.n_items; ++k) items[k] = info.item_words[k];
+    }
+    return ADAS_OK;
 }
 
 int adas_engine_precision(const adas_engine* e) { return e ? e->prec : -1; }
@@ -1125,9 +1329,23 @@ int adas_engine_profile(adas_engine* e, const float* d_input, int batch, int ite
         }
         marker_ms = lo < 1e29f ? lo : 0.f;
     }
+    {
+        int rc = engine_prepare(e, batch);
+        if (rc != ADAS_OK) return rc;
+    }
+    const std::vector<MlSeg>* segs = ml_segments(e, batch);
     for (int it = 0; it < iters; ++it) {
         ADAS_HIP_TRY(hipEventRecord(e->events[0], 0));
+        size_t si = 0;
         for (int i = 0; i < n; ++i) {
+            if (segs && si < segs->size() && (*segs)[si].first == i) {   // a multi-layer launch: its time goes to its first layer, the rest read 0
+                const MlSeg& sg = (*segs)[si++];
+                hipError_t err = ml_launch(sg.plan, 0);
+                if (err != hipSuccess) return hip_fail(err, "multi-layer launch", __FILE__, __LINE__);
+                for (int k = i; k <= sg.last; ++k) ADAS_HIP_TRY(hipEventRecord(e->events[k + 1], 0));
+                i = sg.last;
+                continue;
+            }
             int rc = engine_run_op(e, i, d_input, batch, 0);
             if (rc != ADAS_OK) return rc;
             ADAS_HIP_TRY(hipEventRecord(e->events[i + 1], 0));

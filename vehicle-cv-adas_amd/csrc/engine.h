@@ -3,6 +3,8 @@
 #pragma once
 #include "common.h"
 #include "kernels.h"
+#include "conv_ml.h"
+#include <map>
 #include <string>
 #include <vector>
 
@@ -75,6 +77,13 @@ struct EngOp {
     int det_src[6] = {-1, -1, -1, -1, -1, -1};  // OP_DETECT_V8: the six 1x1 convs (cv2.i.2, cv3.i.2) folded into the decode launch, or -1;
                                                 // OP_DETECT_V5: the three per-level 1x1 convs (det_src[0..2])
 };
+// One multi-layer launch (conv_ml.hip): the non-skipped ops of [first, last] are all convs with a tile body there and run as ONE launch at
+// `first`'s position; decided per batch size (the kernels a layer resolves to, and with them its eligibility, depend on the batch).
+struct MlSeg {
+    int first = 0, last = 0, n_layers = 0, n_items = 0;
+    MlPlan* plan = nullptr;
+    std::vector<int> ops;     // the member ops, in launch order
+};
 struct EngOut {
     uint32_t buf, offset, ndim, dims[4];
     size_t elems;  // per frame
@@ -84,6 +93,7 @@ struct EngOut {
 // packed_in: d_in is the (c0,c1,c2,0) bf16 NHWC tensor of adas_preprocess_*_packed (fused first layer only)
 int engine_run_op(struct ::adas_engine* e, int i, const float* d_in, int batch, hipStream_t st, bool packed_in = false);
 int engine_forward(struct ::adas_engine* e, const float* d_in, int batch, hipStream_t st, bool packed_in = false);
+int engine_prepare(struct ::adas_engine* e, int batch);   // multi-layer launch tables of this batch size (never inside a stream capture)
 
 }  // namespace adas
 
@@ -99,6 +109,9 @@ struct adas_engine {
     size_t weight_bytes = 0, act_bytes = 0;
     std::vector<hipEvent_t> events;
     hipStream_t last = 0;
+    std::map<int, std::vector<adas::MlSeg>> ml;   // batch -> multi-layer launches (adas_engine_prepare); absent: not prepared, per-layer launches
+    bool ml_on = false;                            // multi-layer launches enabled for this engine (read from the environment at creation)
+    std::vector<char> buf_aliased;                 // buffer takes part in an alias (Graph.alias): stays out of multi-layer launches
     float* sink_conf = nullptr;   // adas_engine_set_detect_sink: the fused v8 Detect writes per-anchor (best probability, class) here
     int* sink_cls = nullptr;      // instead of the head's class rows (pipeline steps)
 };

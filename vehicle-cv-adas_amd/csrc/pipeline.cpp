@@ -280,6 +280,12 @@ static int replay_step(adas_pipeline* p, const adas_pipeline::GraphKey& key, con
         ADAS_REQUIRE(p->graphs.size() < 64, ADAS_ERR_CAPACITY, "more than 64 distinct input buffers: reuse staging buffers with use_graph");
         adas_pipeline::Cached g{key, nullptr, nullptr};
         if (fs) p->fsrc = *fs;
+        {   // device tables of the engines' multi-layer launches are built BEFORE the capture (allocations and copies cannot be captured)
+            const int frames = p->d.n_streams * (p->d.micro_batch > 1 ? p->d.micro_batch : 1);
+            int prc = p->d.detector ? adas::engine_prepare(p->d.detector, frames) : ADAS_OK;
+            if (prc == ADAS_OK && p->d.lane) prc = adas::engine_prepare(p->d.lane, frames);
+            if (prc != ADAS_OK) return prc;
+        }
         ADAS_HIP_TRY(hipStreamBeginCapture(p->st, hipStreamCaptureModeThreadLocal));
         int rc = record_step(p, d_det, d_lane, false);
         hipError_t ce = hipStreamEndCapture(p->st, &g.graph);
