@@ -112,10 +112,11 @@ int adas_engine_set_detect_sink(adas_engine* e, float* d_best_conf, int32_t* d_b
 int adas_engine_layer_info(const adas_engine* e, int layer, char* name, int name_cap, double* flops, int* kind);
 /* Which kernel instantiation layer `layer` launches at `batch` frames (matches the rocprofv3 kernel name). */
 int adas_engine_layer_kernel(const adas_engine* e, int layer, int batch, char* name, int name_cap);
-/* Multi-layer launches (csrc/conv_ml.hip, round 5): at a given batch size, maximal runs of consecutive convolution layers that the
+/* Multi-layer launches (csrc/conv_ml.hip, round 5; OPT-IN: engines created with ADAS_ML=1 in the environment -- at 64 frames the
+ * per-layer launches measured faster): at a given batch size, maximal runs of consecutive convolution layers that the
  * per-layer kernels conv_halo / conv_pw would take (the 40x40 / 20x20 layers of the YOLO graphs, the Detect branches) run as ONE
  * persistent launch each -- a table of (layer, tile, channel block) items behind per-layer, per-frame arrival counters -- with results
- * bit-identical to the per-layer launches (ADAS_NO_ML=1 restores those).  adas_engine_prepare builds the device tables of a batch size
+ * bit-identical to the per-layer launches.  adas_engine_prepare builds the device tables of a batch size
  * (adas_engine_infer_* and adas_pipeline_* call it themselves outside stream captures); adas_engine_ml_info reports what it decided;
  * adas_engine_ml_status synchronises and returns ADAS_ERR_HIP when a dependency wait of the last launch timed out (every wait is
  * bounded: a launch can fail, never hang); adas_engine_launch_count = kernel launches of one forward at that batch. */
@@ -123,6 +124,9 @@ int adas_engine_prepare(adas_engine* e, int batch);
 int adas_engine_ml_info(const adas_engine* e, int batch, int32_t* n_launches, int32_t* n_layers, int32_t* n_items);
 int adas_engine_ml_status(const adas_engine* e, int batch, uint32_t* error_word);
 int adas_engine_launch_count(adas_engine* e, int batch);
+/* first 16 words of launch `launch`'s control block after its last run: ticket, error word, and (builds with -DADAS_ML_PROF only) the
+ * per-phase cycle counters of the item loop (tools/ml_debug.py prof) */
+int adas_engine_ml_counters(const adas_engine* e, int batch, int launch, uint32_t head16[16]);
 /* The planner of those launches on descriptions alone (no device: tests/test_ml_plan.py).  A layer: kernel (1 = 3x3 halo conv, 4 = 1x1
  * pointwise: CONV_HALO / CONV_PW), stride, activation, residual mode, and its views as (buffer id, pixel stride, channel offset,
  * channels, h, w); `up_c` > 0: the first up_c input channels are read from the half-resolution view `up`.  Outputs: per layer its

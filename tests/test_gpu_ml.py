@@ -24,8 +24,8 @@ def CE():
 
 def _engine(CE, path, prec, batch, ml, **env):
     """An engine with the multi-layer launches on / off (the switch is read from the environment when the engine is created)."""
-    old = {k: os.environ.get(k) for k in ("ADAS_NO_ML",) + tuple(env)}
-    os.environ["ADAS_NO_ML"] = "0" if ml else "1"
+    old = {k: os.environ.get(k) for k in ("ADAS_ML",) + tuple(env)}
+    os.environ["ADAS_ML"] = "1" if ml else "0"
     os.environ.update({k: str(v) for k, v in env.items()})
     try:
         e = CE.HipEngine(path, precision=prec, max_batch=batch)
@@ -128,15 +128,15 @@ def test_pipeline_with_multi_layer_launches_matches_per_layer_pipeline(tmp_path)
     det_path = M.build("yolov8n").save(str(tmp_path / "d.hipm"))
     pipes = []
     for ml in (True, False):
-        old = os.environ.get("ADAS_NO_ML")
-        os.environ["ADAS_NO_ML"] = "0" if ml else "1"
+        old = os.environ.get("ADAS_ML")
+        os.environ["ADAS_ML"] = "1" if ml else "0"
         try:
             pipes.append(PL.AdasPipeline(det_path, lane_path, n_streams=S, precision="fp16", src_hw=(720, 1280), use_graph=True))
         finally:
             if old is None:
-                os.environ.pop("ADAS_NO_ML", None)
+                os.environ.pop("ADAS_ML", None)
             else:
-                os.environ["ADAS_NO_ML"] = old
+                os.environ["ADAS_ML"] = old
     dev = [L.DeviceBuffer.from_array(c) for c in cams]
     for k in (0, 1, 2, 0, 1, 2):
         for p in pipes:

@@ -9,7 +9,7 @@ import os
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libadas_hip.so")
+LIB_PATH = os.environ.get("ADAS_LIB") or os.path.join(HERE, "libadas_hip.so")   # ADAS_LIB: an instrumented scratch build (tools/)
 
 UFLD_MAX_POINTS = 128
 HEAD_V8, HEAD_V5, HEAD_V5_LITE = 0, 1, 2
@@ -126,6 +126,7 @@ _SIGS = {
     "adas_engine_ml_info": (C.c_int, [_P, C.c_int, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "adas_engine_ml_status": (C.c_int, [_P, C.c_int, C.POINTER(C.c_uint32)]),
     "adas_engine_launch_count": (C.c_int, [_P, C.c_int]),
+    "adas_engine_ml_counters": (C.c_int, [_P, C.c_int, C.c_int, C.POINTER(C.c_uint32)]),
     "adas_debug_ml_plan": (C.c_int, [C.POINTER(MlLayerDesc), C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_uint64),
                                      C.c_int, C.POINTER(C.c_int32)]),
     "adas_engine_model_io_half": (C.c_int, [_P]),

@@ -55,7 +55,7 @@ __global__ __launch_bounds__(256, (S == 1 && BM == 128) ? 3 : 2) void conv_halo_
     const int cb = (xr / a.tiles8) * a.cbg + (xslot - xr * a.cbg);
     int tile = a.xmap ? (int)(blockIdx.x & 7) * a.tiles8 + (xr % a.tiles8) : (xr % a.tiles8) * 8 + (blockIdx.x & 7);
     if (cb >= a.ncb || tile >= a.ntiles) return;
-    halo_tile<E, BN, ACT, S, BM, false>(a, tile, cb, lds);
+    halo_tile<E, BN, ACT, S, BM, false>(a, tile, cb, lds, threadIdx.x);
 }
 
 #ifdef ADAS_HALO_PROF

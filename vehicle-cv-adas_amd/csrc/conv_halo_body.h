@@ -4,6 +4,7 @@
 #pragma once
 #include "kernels.h"
 #include "elem16.h"
+#include <type_traits>
 
 namespace adas {
 
@@ -18,6 +19,20 @@ __device__ __forceinline__ float h_act(float v) {
     return v;
 }
 
+// act(v) + r (RES_AFTER_ACT).  SiLU's multiply and the residual add are ONE fma -- what -ffp-contract=fast makes of `v * rcp(..) + r` when
+// the activation is a template parameter; spelled out so that the run-time-activation variant below (where the add sits behind a
+// select the compiler cannot contract through) rounds identically.
+template <int ACT>
+__device__ __forceinline__ float h_act_res(float v, float r) {
+    if (ACT == ACT_SILU) return __builtin_fmaf(v, __frcp_rn(1.0f + __expf(-v)), r);
+    return h_act<ACT>(v) + r;
+}
+__device__ __forceinline__ float h_act_res_rt(int act, float v, float r) {
+    if (act == ACT_SILU) return __builtin_fmaf(v, __frcp_rn(1.0f + __expf(-v)), r);
+    if (act == ACT_RELU) return fmaxf(v, 0.0f) + r;
+    if (act == ACT_LEAKY) return fmaxf(v, 0.1f * v) + r;
+    return v + r;
+}
 // run-time activation (halo_tile<..., ACT = -1, ...>): the same expressions as h_act<ACT>
 __device__ __forceinline__ float h_act_rt(int act, float v) {
     if (act == ACT_SILU) return v * __frcp_rn(1.0f + __expf(-v));
@@ -83,17 +98,22 @@ bool halo_fill_dev(const ConvArgs& a, HaloDev* out, int* bn_out, int* bm_out, si
 
 // Epilogue memory accesses of halo_tile.  ML = false: plain global loads / stores (the per-layer kernel: unchanged code).  ML = true: raw buffer
 // instructions with aux = sc1 on a resource that covers the whole tensor -- 32-bit BYTE offsets, which the multi-layer launch checks on the host.
+#ifdef ADAS_ML_PLAIN   // timing experiment only (tools/ml_debug.py): the multi-layer variant with cached loads / write-back stores -- NOT coherent
+#define ADAS_ML_SC1(ML) false
+#else
+#define ADAS_ML_SC1(ML) (ML)
+#endif
 struct HaloIo {
     __amdgpu_buffer_rsrc_t res, out;
 };
 template <bool ML>
 __device__ __forceinline__ hu32x4 halo_ld16(const uint16_t* base, const __amdgpu_buffer_rsrc_t& r, size_t elem) {
-    if constexpr (ML) return __builtin_amdgcn_raw_buffer_load_b128(r, (uint32_t)(elem * 2), 0, 16);
+    if constexpr (ADAS_ML_SC1(ML)) return __builtin_amdgcn_raw_buffer_load_b128(r, (uint32_t)(elem * 2), 0, 16);
     else return *reinterpret_cast<const hu32x4*>(base + elem);
 }
 template <bool ML>
 __device__ __forceinline__ uint2 halo_ld8(const uint16_t* base, const __amdgpu_buffer_rsrc_t& r, size_t elem) {
-    if constexpr (ML) {
+    if constexpr (ADAS_ML_SC1(ML)) {
         const auto v = __builtin_amdgcn_raw_buffer_load_b64(r, (uint32_t)(elem * 2), 0, 16);
         return make_uint2(v[0], v[1]);
     } else
@@ -101,12 +121,12 @@ __device__ __forceinline__ uint2 halo_ld8(const uint16_t* base, const __amdgpu_b
 }
 template <bool ML>
 __device__ __forceinline__ void halo_st16(uint16_t* base, const __amdgpu_buffer_rsrc_t& r, size_t elem, hu32x4 v) {
-    if constexpr (ML) __builtin_amdgcn_raw_buffer_store_b128(v, r, (uint32_t)(elem * 2), 0, 16);
+    if constexpr (ADAS_ML_SC1(ML)) __builtin_amdgcn_raw_buffer_store_b128(v, r, (uint32_t)(elem * 2), 0, 16);
     else *reinterpret_cast<hu32x4*>(base + elem) = v;
 }
 template <bool ML>
 __device__ __forceinline__ void halo_st8(uint16_t* base, const __amdgpu_buffer_rsrc_t& r, size_t elem, uint2 v) {
-    if constexpr (ML) {
+    if constexpr (ADAS_ML_SC1(ML)) {
         typedef __attribute__((ext_vector_type(2))) uint32_t hu32x2;
         __builtin_amdgcn_raw_buffer_store_b64(hu32x2{v.x, v.y}, r, (uint32_t)(elem * 2), 0, 16);
     } else
@@ -123,9 +143,9 @@ __device__ __forceinline__ void halo_st8(uint16_t* base, const __amdgpu_buffer_r
 // Everything else -- tiling, staging, swizzles, MFMA order, epilogue arithmetic -- is the same code, so an ML launch produces the bits
 // the per-layer launches produce.  The caller synchronises the workgroup before the next use of `lds`.
 template <typename E, int BN, int ACT, int S, int BM, bool ML>
-__device__ __forceinline__ void halo_tile(const HaloDev& a, int tile, const int cb, uint16_t* lds) {
+__device__ __forceinline__ void halo_tile(const HaloDev& a, int tile, const int cb, uint16_t* lds, const int tid) {
     typedef typename E::vec8 hvec8;
-    constexpr int AUX = ML ? 16 : 0;   // buffer-instruction cache policy: 16 = sc1
+    constexpr int AUX = ADAS_ML_SC1(ML) ? 16 : 0;   // buffer-instruction cache policy: 16 = sc1
     constexpr int TAPS = 9;
     constexpr int HALO_BM = BM;
     constexpr int HALO_NA = halo_maxpix(S, BM) * 4 / 256;
@@ -135,7 +155,7 @@ __device__ __forceinline__ void halo_tile(const HaloDev& a, int tile, const int 
     uint16_t* Aw = lds;                               // [maxpix][HALO_PIX]
     uint16_t* Ww = lds + (size_t)a.maxpix * HALO_PIX;  // [TAPS*BN][HALO_WPIX], swizzled
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lane = tid & 63, wave = tid >> 6;   // tid: threadIdx.x (the multi-layer kernel passes a per-item opaque copy: see conv_ml.hip)
     HPROF_INIT
     const int lrow = lane & 15, kg = lane >> 4;
     const int n0 = cb * BN;
@@ -301,80 +321,94 @@ __device__ __forceinline__ void halo_tile(const HaloDev& a, int tile, const int 
             }
         }
     }
-    auto actf = [&](float v) {
-        if constexpr (ACT >= 0) return h_act<ACT>(v);
-        else return h_act_rt(a.act, v);
-    };
-    // value of (pixel j, channel group i) after bias / residual / activation
-    auto finish = [&](int i, int j, float v[4]) {
-        v[0] = acc[i][j][0] + bias4[i].x; v[1] = acc[i][j][1] + bias4[i].y; v[2] = acc[i][j][2] + bias4[i].z; v[3] = acc[i][j][3] + bias4[i].w;
-        if (a.res_mode != RES_NONE) {
-            const uint2 q = rq[j][i];
-            const float rv[4] = {E::lo(q.x), E::hi(q.x), E::lo(q.y), E::hi(q.y)};
-            if (a.res_mode == RES_BEFORE_ACT) {
+    // Bias / residual / activation / stores, instantiated per activation EA.  The run-time-activation variant (ACT = -1: the multi-layer kernel)
+    // must NOT decide per element: a select of the activation around every SiLU puts each v_exp / v_rcp chain in its own basic block, the 256
+    // values of a lane serialise on the transcendental latency and the epilogue takes longer than the MFMA loop (measured, round 5: tiles
+    // 25 us instead of 13).  It branches ONCE here: SiLU (the YOLO graphs) gets the compile-time code, any other activation the per-element form.
+    auto finish_and_store = [&](auto ea_tag) {
+        constexpr int EA = decltype(ea_tag)::value;
+        auto actf = [&](float v) {
+            if constexpr (EA >= 0) return h_act<EA>(v);
+            else return h_act_rt(a.act, v);
+        };
+        auto actresf = [&](float v, float r) {
+            if constexpr (EA >= 0) return h_act_res<EA>(v, r);
+            else return h_act_res_rt(a.act, v, r);
+        };
+        // value of (pixel j, channel group i) after bias / residual / activation
+        auto finish = [&](int i, int j, float v[4]) {
+            v[0] = acc[i][j][0] + bias4[i].x; v[1] = acc[i][j][1] + bias4[i].y; v[2] = acc[i][j][2] + bias4[i].z; v[3] = acc[i][j][3] + bias4[i].w;
+            if (a.res_mode != RES_NONE) {
+                const uint2 q = rq[j][i];
+                const float rv[4] = {E::lo(q.x), E::hi(q.x), E::lo(q.y), E::hi(q.y)};
+                if (a.res_mode == RES_BEFORE_ACT) {
 #pragma unroll
-                for (int k = 0; k < 4; ++k) v[k] = actf(v[k] + rv[k]);
+                    for (int k = 0; k < 4; ++k) v[k] = actf(v[k] + rv[k]);
+                } else {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) v[k] = actresf(v[k], rv[k]);
+                }
             } else {
 #pragma unroll
-                for (int k = 0; k < 4; ++k) v[k] = actf(v[k]) + rv[k];
+                for (int k = 0; k < 4; ++k) v[k] = actf(v[k]);
             }
-        } else {
+        };
+        const bool wide = TN >= 2 && !a.out_f32 && (((a.out_cs | a.out_coff) & 7) == 0);
+        if (wide) {
+            // 16-byte stores: v_permlane16_swap exchanges the odd 16-lane rows of X (channel tile i) with the even rows of Y
+            // (tile i+1), after which a lane owns 8 consecutive channels: tile i + (kg&1), channels (kg>>1)*8 .. +7.
 #pragma unroll
-            for (int k = 0; k < 4; ++k) v[k] = actf(v[k]);
-        }
-    };
-    const bool wide = TN >= 2 && !a.out_f32 && (((a.out_cs | a.out_coff) & 7) == 0);
-    if (wide) {
-        // 16-byte stores: v_permlane16_swap exchanges the odd 16-lane rows of X (channel tile i) with the even rows of Y
-        // (tile i+1), after which a lane owns 8 consecutive channels: tile i + (kg&1), channels (kg>>1)*8 .. +7.
+            for (int j = 0; j < TM; ++j) {
 #pragma unroll
-        for (int j = 0; j < TM; ++j) {
-#pragma unroll
-            for (int i = 0; i + 1 < TN + 0; i += 2) {
-                float vx[4], vy[4];
-                finish(i, j, vx);
-                finish(i + 1, j, vy);
-                const uint32_t x0 = E::pack2(vx[0], vx[1]), x1 = E::pack2(vx[2], vx[3]);
-                const uint32_t y0 = E::pack2(vy[0], vy[1]), y1 = E::pack2(vy[2], vy[3]);
-                const auto s0 = __builtin_amdgcn_permlane16_swap(x0, y0, false, false);
-                const auto s1 = __builtin_amdgcn_permlane16_swap(x1, y1, false, false);
-                const int c = n0 + (i + (kg & 1)) * 16 + (kg >> 1) * 8;
-                const size_t oe = mpix[j] * a.out_cs + a.out_coff + c;
-                if (pok[j]) {
-                    if (full_n || c + 8 <= a.cout) halo_st16<ML>((uint16_t*)a.out, io.out, oe, hu32x4{s0[0], s1[0], s0[1], s1[1]});
-                    else if (c + 4 <= a.cout) halo_st8<ML>((uint16_t*)a.out, io.out, oe, make_uint2(s0[0], s1[0]));
+                for (int i = 0; i + 1 < TN + 0; i += 2) {
+                    float vx[4], vy[4];
+                    finish(i, j, vx);
+                    finish(i + 1, j, vy);
+                    const uint32_t x0 = E::pack2(vx[0], vx[1]), x1 = E::pack2(vx[2], vx[3]);
+                    const uint32_t y0 = E::pack2(vy[0], vy[1]), y1 = E::pack2(vy[2], vy[3]);
+                    const auto s0 = __builtin_amdgcn_permlane16_swap(x0, y0, false, false);
+                    const auto s1 = __builtin_amdgcn_permlane16_swap(x1, y1, false, false);
+                    const int c = n0 + (i + (kg & 1)) * 16 + (kg >> 1) * 8;
+                    const size_t oe = mpix[j] * a.out_cs + a.out_coff + c;
+                    if (pok[j]) {
+                        if (full_n || c + 8 <= a.cout) halo_st16<ML>((uint16_t*)a.out, io.out, oe, hu32x4{s0[0], s1[0], s0[1], s1[1]});
+                        else if (c + 4 <= a.cout) halo_st8<ML>((uint16_t*)a.out, io.out, oe, make_uint2(s0[0], s1[0]));
+                    }
                 }
-            }
-            if (TN & 1) {   // the unpaired last channel tile: 8-byte store
-                float v[4];
-                finish(TN - 1, j, v);
-                uint2 q;
-                q.x = E::pack2(v[0], v[1]);
-                q.y = E::pack2(v[2], v[3]);
-                if (pok[j] && (full_n || n0 + (TN - 1) * 16 + kg * 4 < a.cout))
-                    halo_st8<ML>((uint16_t*)a.out, io.out, mpix[j] * a.out_cs + a.out_coff + n0 + kg * 4 + (TN - 1) * 16, q);
-            }
-        }
-    } else {
-#pragma unroll
-        for (int j = 0; j < TM; ++j) {
-            const size_t ob = mpix[j] * a.out_cs + a.out_coff + n0 + kg * 4;
-#pragma unroll
-            for (int i = 0; i < TN; ++i) {
-                float v[4];
-                finish(i, j, v);
-                const bool st_ok = pok[j] && (full_n || n0 + i * 16 + kg * 4 < a.cout);
-                if (a.out_f32) {
-                    if (st_ok) *reinterpret_cast<float4*>((float*)a.out + ob + i * 16) = make_float4(v[0], v[1], v[2], v[3]);
-                } else {
+                if (TN & 1) {   // the unpaired last channel tile: 8-byte store
+                    float v[4];
+                    finish(TN - 1, j, v);
                     uint2 q;
                     q.x = E::pack2(v[0], v[1]);
                     q.y = E::pack2(v[2], v[3]);
-                    if (st_ok) halo_st8<ML>((uint16_t*)a.out, io.out, ob + i * 16, q);
+                    if (pok[j] && (full_n || n0 + (TN - 1) * 16 + kg * 4 < a.cout))
+                        halo_st8<ML>((uint16_t*)a.out, io.out, mpix[j] * a.out_cs + a.out_coff + n0 + kg * 4 + (TN - 1) * 16, q);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < TM; ++j) {
+                const size_t ob = mpix[j] * a.out_cs + a.out_coff + n0 + kg * 4;
+#pragma unroll
+                for (int i = 0; i < TN; ++i) {
+                    float v[4];
+                    finish(i, j, v);
+                    const bool st_ok = pok[j] && (full_n || n0 + i * 16 + kg * 4 < a.cout);
+                    if (a.out_f32) {
+                        if (st_ok) *reinterpret_cast<float4*>((float*)a.out + ob + i * 16) = make_float4(v[0], v[1], v[2], v[3]);
+                    } else {
+                        uint2 q;
+                        q.x = E::pack2(v[0], v[1]);
+                        q.y = E::pack2(v[2], v[3]);
+                        if (st_ok) halo_st8<ML>((uint16_t*)a.out, io.out, ob + i * 16, q);
+                    }
                 }
             }
         }
-    }
+    };
+    if constexpr (ACT >= 0) finish_and_store(std::integral_constant<int, ACT>{});
+    else if (a.act == ACT_SILU) finish_and_store(std::integral_constant<int, ACT_SILU>{});
+    else finish_and_store(std::integral_constant<int, -1>{});
     HPROF(9)  // epilogue
     HPROF_FLUSH
 }

@@ -40,6 +40,6 @@ void ml_plan_destroy(MlPlan* p);
 // memset of the control block (ticket, error word, arrival counters) + the kernel, on `st` (both are captured by a stream capture)
 hipError_t ml_launch(const MlPlan* p, hipStream_t st);
 // the control block's error word of the LAST launch (synchronises the device): 0, or 1 + the index of the item whose wait timed out
-int ml_plan_status(const MlPlan* p, unsigned* error_word);
+int ml_plan_status(const MlPlan* p, unsigned* error_word, unsigned* head16 = nullptr);   // head16: the control block's first 16 words (phase counters of -DADAS_ML_PROF builds)
 
 }  // namespace adas

@@ -1,10 +1,11 @@
 // conv_ml.hip -- multi-layer persistent convolution launch (round 5; interface and motivation: conv_ml.h).
 //
 // DEVICE SIDE.  grid = 2 workgroups per CU (256 threads, <= 80 KB LDS each), all of them running conv_ml_kernel's loop:
-//   ticket  t = atomicAdd(ctl[0])              -- the next ticket is requested while the current item runs (the atomic's round trip hides)
-//   item    (layer, tile | chunk, channel block, frame) = items[t]          -- immutable tables, read through the scalar cache
-//   wait    for every producer layer p of `layer`: ctl[16 + p * F + frame] >= target[p]  (<= 6 lanes poll with relaxed agent-scope loads
-//           + s_sleep; every wait is bounded: a timeout raises ctl[1], the item is abandoned, every workgroup drains -- never a hang)
+//   ticket  t = atomicAdd(ctl[0]), requested by thread 0 while the PREVIOUS item runs; as soon as it is back (after the tile body) thread 0
+//           also fetches the item's 64-byte record, under the store drain -- the next iteration starts with ticket and record in registers
+//   record  {tile | chunk, layer, channel block, frame, kind, the <= 6 arrival counters to wait for and their targets}: broadcast through LDS
+//   wait    lane k < n_dep polls counter k (relaxed agent-scope loads + s_sleep) while the layer's descriptor comes in through the scalar
+//           cache; every wait is bounded: a timeout raises ctl[1], the item is abandoned, every workgroup drains -- never a hang
 //   run     the SAME tile body the per-layer kernel runs (conv_halo_body.h halo_tile, or the pointwise tile below) with ML = true
 //   publish every wave `s_waitcnt vmcnt(0)`, barrier, lane 0: atomicAdd(ctl[16 + layer * F + frame], 1)
 // Visibility between workgroups of one launch (MI355X_MICROARCH.md "Workgroup dispatch, XCD placement & inter-workgroup visibility";
@@ -52,11 +53,22 @@ struct MlLayerDev {
 };
 static_assert(sizeof(MlLayerDev) % 8 == 0, "MlLayerDev layout");
 
+// One work item as the kernel reads it: everything up to the dependency wait in ONE 64-byte line.
+struct MlItemRec {
+    uint32_t tile;                    // halo: tile index (frame * tiles per frame + t); pointwise: chunk of the frame
+    uint32_t where;                   // layer | channel block << 8 | frame << 16
+    uint32_t kind;                    // MLK_* | n_dep << 8
+    uint32_t arrive;                  // index (into ctl) of the counter this item increments: 16 + layer * frames + frame
+    uint32_t dep_idx[ML_MAX_DEPS];    // counters to wait for
+    uint32_t dep_target[ML_MAX_DEPS];
+};
+static_assert(sizeof(MlItemRec) == 64, "MlItemRec layout");
+
 struct MlArgs {
     const MlLayerDev* layers;
-    const uint2* items;
+    const MlItemRec* items;
     unsigned* ctl;           // [0] ticket, [1] error, [16 + layer * frames + frame] arrivals
-    int n_items, frames, spin_limit, pad;
+    int n_items, frames, spin_limit, rec_off;   // rec_off: byte offset of the record slot in dynamic LDS (behind the largest tile scratch)
 };
 constexpr int ML_CTL_HEAD = 16;
 
@@ -70,6 +82,10 @@ __device__ __forceinline__ void ml_copy_const(T& dst, const void* src) {
     uint32_t w[N];
 #pragma unroll
     for (int i = 0; i < N; ++i) w[i] = s[i];
+    // pin: the values exist in SGPRs HERE (the loads are in flight from this point, e.g. under a dependency wait) -- left alone, hipcc sinks
+    // loads from the constant address space to their first use and the tile's set-up waits for the scalar cache (measured: +12 k cycles)
+#pragma unroll
+    for (int i = 0; i < N; ++i) asm volatile("" : "+s"(w[i]));
     __builtin_memcpy(&dst, w, sizeof(T));
 }
 
@@ -80,9 +96,10 @@ typedef __attribute__((ext_vector_type(2))) uint32_t mu32x2;
 // One pointwise item: pixels [chunk * P, chunk * P + P) of one frame x the feature tiles of one channel block.  conv_pw.hip's scheme --
 // weights of the block in LDS in fragment order, a wave owns 16 pixels at a time and loads their activations straight into MFMA B
 // registers -- with the weights staged per ITEM (32-64 KB from L2 against >= 400 pixels x Cin of activations) and sc1 loads / stores.
-template <typename E, int KS>
-__device__ __forceinline__ void ml_pw_tile(const MlPwDev& a, const int frame, const int chunk, const int cb, uint16_t* wl) {
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+// ACT: ACT_SILU compiled in, or -1 = read from a.act (one branch per TILE, never per element: see conv_halo_body.h finish_and_store).
+template <typename E, int KS, int ACT>
+__device__ __forceinline__ void ml_pw_tile(const MlPwDev& a, const int frame, const int chunk, const int cb, uint16_t* wl, const int tid) {
+    const int lane = tid & 63, wave = tid >> 6;
     const int lrow = lane & 15, kg = lane >> 4;
     const int nt0 = cb * a.NTL;
     const int ntl = a.NT - nt0 < a.NTL ? a.NT - nt0 : a.NTL;
@@ -96,7 +113,10 @@ __device__ __forceinline__ void ml_pw_tile(const MlPwDev& a, const int frame, co
     const int p_begin = chunk * a.P;
     const int p_end = p_begin + a.P < a.HW ? p_begin + a.P : a.HW;
     const int nmt = (p_end - p_begin + 15) >> 4;
-    auto actf = [&](float v) { return h_act_rt(a.act, v); };
+    auto actf = [&](float v) {
+        if constexpr (ACT >= 0) return h_act<ACT>(v);
+        else return h_act_rt(a.act, v);
+    };
 
     for (int mt = wave; mt < nmt; mt += 4) {
         const int pl = p_begin + mt * 16 + lrow;
@@ -152,35 +172,86 @@ __device__ __forceinline__ void ml_pw_tile(const MlPwDev& a, const int frame, co
     }
 }
 
+// Scratch instrumentation (-DADAS_ML_PROF, tools/ml_debug.py prof): shader-clock cycles of thread 0 per phase of the item loop, summed over
+// the workgroup's items and added to ctl[2 + 2 * phase] (64-bit) when the workgroup leaves; ctl[14] counts items.
+#ifdef ADAS_ML_PROF
+#define MLPROF_INIT unsigned long long mlp_[6] = {0, 0, 0, 0, 0, 0}, mlp_t_ = __builtin_amdgcn_s_memtime(), mlp_n_ = 0;
+#define MLPROF(i)                                                    \
+    if (tid == 0) {                                                  \
+        const unsigned long long t__ = __builtin_amdgcn_s_memtime(); \
+        mlp_[i] += t__ - mlp_t_;                                     \
+        mlp_t_ = t__;                                                \
+    }
+#define MLPROF_ITEM ++mlp_n_;
+#define MLPROF_FLUSH                                                                                               \
+    if (tid == 0) {                                                                                                \
+        for (int i__ = 0; i__ < 6; ++i__) atomicAdd(reinterpret_cast<unsigned long long*>(g.ctl + 2) + i__, mlp_[i__]); \
+        atomicAdd(reinterpret_cast<unsigned long long*>(g.ctl + 2) + 6, mlp_n_);                                   \
+    }
+#else
+#define MLPROF_INIT
+#define MLPROF(i)
+#define MLPROF_ITEM
+#define MLPROF_FLUSH
+#endif
+
+template <typename E, int KS>
+__device__ __forceinline__ void ml_pw_dispatch(const MlPwDev& p, int frame, int chunk, int cb, uint16_t* lds, int tid) {
+    if (p.act == ACT_SILU) ml_pw_tile<E, KS, ACT_SILU>(p, frame, chunk, cb, lds, tid);
+    else ml_pw_tile<E, KS, -1>(p, frame, chunk, cb, lds, tid);
+}
+
+#ifdef ADAS_ML_OCC1   // experiment: one workgroup per CU, 512 registers per lane (spills go to AGPRs, not to scratch)
+#define ADAS_ML_WAVES 1
+#else
+#define ADAS_ML_WAVES 2
+#endif
 template <typename E>
-__global__ __launch_bounds__(256, 2) void conv_ml_kernel(MlArgs g) {
+__global__ __launch_bounds__(256, ADAS_ML_WAVES) void conv_ml_kernel(MlArgs g) {
     E::enter();
     extern __shared__ __attribute__((aligned(16))) uint16_t lds[];
-    __shared__ unsigned s_t[2];
+    // [0..15] the item's record, [16] its ticket -- BEHIND the tiles' scratch, not in front of it: the tile bodies' conflict-free LDS swizzles
+    // assume the window starts at LDS offset 0 (a static __shared__ array in front shifts every ds_read_b128 by 80 bytes against the banks)
+    uint32_t* s_rec = reinterpret_cast<uint32_t*>(reinterpret_cast<unsigned char*>(lds) + g.rec_off);
     const int tid = threadIdx.x;
+    MLPROF_INIT
+    // thread 0 carries the pipeline state: the ticket and the record of the item about to run
     unsigned mine = 0;
-    if (tid == 0) mine = __hip_atomic_fetch_add(g.ctl, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    mu32x4 rec[4] = {mu32x4{0, 0, 0, 0}, mu32x4{0, 0, 0, 0}, mu32x4{0, 0, 0, 0}, mu32x4{0, 0, 0, 0}};
+    if (tid == 0) {
+        mine = __hip_atomic_fetch_add(g.ctl, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (mine < (unsigned)g.n_items) {
+            const mu32x4* rp = reinterpret_cast<const mu32x4*>(g.items + mine);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) rec[i] = rp[i];
+        }
+    }
     for (;;) {
         if (tid == 0) {
-            s_t[0] = mine;
-            s_t[1] = __hip_atomic_load(g.ctl + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) *reinterpret_cast<mu32x4*>(s_rec + 4 * i) = rec[i];
+            s_rec[16] = mine;
         }
         __syncthreads();
-        const unsigned t = __builtin_amdgcn_readfirstlane(s_t[0]);
-        const unsigned err = __builtin_amdgcn_readfirstlane(s_t[1]);
-        if (t >= (unsigned)g.n_items || err) break;   // (uniform)
-        if (tid == 0) mine = __hip_atomic_fetch_add(g.ctl, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // the NEXT ticket: in flight under this item
-        uint2 it;
-        ml_copy_const(it, g.items + t);
-        const int tile = (int)it.x, layer = (int)(it.y & 255u), cb = (int)((it.y >> 8) & 255u), frame = (int)(it.y >> 16);
-        const MlLayerDev* L = g.layers + layer;
-        struct Head { int kind, n_dep, per_img, pad; } hd;
-        ml_copy_const(hd, L);
+        const unsigned t = __builtin_amdgcn_readfirstlane(s_rec[16]);
+        MLPROF(0)   // ticket + record in hand (both fetched under the previous item) + broadcast
+        if (t >= (unsigned)g.n_items) break;   // (uniform)
+        const mu32x4 r0 = *reinterpret_cast<const mu32x4*>(s_rec);
+        const int tile = (int)__builtin_amdgcn_readfirstlane(r0[0]);
+        const unsigned where = __builtin_amdgcn_readfirstlane(r0[1]), kd = __builtin_amdgcn_readfirstlane(r0[2]);
+        const unsigned arrive = __builtin_amdgcn_readfirstlane(r0[3]);
+        const int layer = (int)(where & 255u), cb = (int)((where >> 8) & 255u), frame = (int)(where >> 16);
+        const int kind = (int)(kd & 255u), n_dep = (int)(kd >> 8);
+        unsigned next = 0;
+        if (tid == 0) next = __hip_atomic_fetch_add(g.ctl, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // the NEXT ticket: in flight under this item
+        // the layer's descriptor through the scalar cache, in flight under the dependency wait
+        MlLayerDev::U u;
+        ml_copy_const(u, &g.layers[layer].u);
+        MLPROF(1)
         // ---- wait until the frame is complete in every producer layer
-        if (tid < hd.n_dep) {
-            const int row = L->dep_row[tid];
-            const unsigned target = (unsigned)L->dep_target[tid];
-            const unsigned* c = g.ctl + ML_CTL_HEAD + (size_t)row * g.frames + frame;
+        if (tid < n_dep) {
+            const unsigned* c = g.ctl + s_rec[4 + tid];
+            const unsigned target = s_rec[4 + ML_MAX_DEPS + tid];
             unsigned spins = 0;
             while (__hip_atomic_load(c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
                 __builtin_amdgcn_s_sleep(8);
@@ -189,40 +260,77 @@ __global__ __launch_bounds__(256, 2) void conv_ml_kernel(MlArgs g) {
                     __hip_atomic_store(g.ctl + 1, t + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     break;
                 }
-                if ((spins & 1023u) == 0u && __hip_atomic_load(g.ctl + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) break;
+                if ((spins & 255u) == 0u && __hip_atomic_load(g.ctl + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) break;   // somebody gave up: drain
             }
         }
         __syncthreads();
-        // ---- the tile
-        if (hd.kind == MLK_PW) {
-            MlPwDev p;
-            ml_copy_const(p, &L->u.p);
-            switch (p.KS) {
-                case 2: ml_pw_tile<E, 2>(p, frame, tile, cb, lds); break;
-                case 3: ml_pw_tile<E, 3>(p, frame, tile, cb, lds); break;
-                case 4: ml_pw_tile<E, 4>(p, frame, tile, cb, lds); break;
-                case 6: ml_pw_tile<E, 6>(p, frame, tile, cb, lds); break;
-                case 8: ml_pw_tile<E, 8>(p, frame, tile, cb, lds); break;
-                case 12: ml_pw_tile<E, 12>(p, frame, tile, cb, lds); break;
-                default: ml_pw_tile<E, 16>(p, frame, tile, cb, lds); break;
+        MLPROF(2)   // dependency wait
+        // ---- the tile.  The bodies get an OPAQUE copy of the thread index: everything a tile derives from it (lane / wave decomposition, LDS swizzle
+        // offsets, fragment addresses -- a dozen values per body, twelve bodies) is invariant across items, and LLVM hoists it all out of the
+        // item loop, where it stays live across every body: the 252-register halo bodies then spill to scratch in their set-up (measured:
+        // 15 k cycles of set-up per tile instead of 2.5 k).  Recomputing per item costs a few dozen VALU instructions.
+        int tid_it = tid;
+        asm volatile("" : "+v"(tid_it));
+#ifdef ADAS_ML_ONEKIND   // code-size experiment: one halo body only
+        halo_tile<E, 64, -1, 1, 256, true>(u.h, tile, cb, lds, tid_it);
+#else
+        if (kind == MLK_PW) {
+            switch (u.p.KS) {
+                case 2: ml_pw_dispatch<E, 2>(u.p, frame, tile, cb, lds, tid_it); break;
+                case 3: ml_pw_dispatch<E, 3>(u.p, frame, tile, cb, lds, tid_it); break;
+                case 4: ml_pw_dispatch<E, 4>(u.p, frame, tile, cb, lds, tid_it); break;
+                case 6: ml_pw_dispatch<E, 6>(u.p, frame, tile, cb, lds, tid_it); break;
+                case 8: ml_pw_dispatch<E, 8>(u.p, frame, tile, cb, lds, tid_it); break;
+                case 12: ml_pw_dispatch<E, 12>(u.p, frame, tile, cb, lds, tid_it); break;
+                default: ml_pw_dispatch<E, 16>(u.p, frame, tile, cb, lds, tid_it); break;
             }
         } else {
-            HaloDev h;
-            ml_copy_const(h, &L->u.h);
-            switch (hd.kind) {
-                case MLK_H64_S1_256: halo_tile<E, 64, -1, 1, 256, true>(h, tile, cb, lds); break;
-                case MLK_H64_S1_128: halo_tile<E, 64, -1, 1, 128, true>(h, tile, cb, lds); break;
-                case MLK_H48_S1_256: halo_tile<E, 48, -1, 1, 256, true>(h, tile, cb, lds); break;
-                case MLK_H48_S1_128: halo_tile<E, 48, -1, 1, 128, true>(h, tile, cb, lds); break;
-                default: halo_tile<E, 64, -1, 2, 128, true>(h, tile, cb, lds); break;
+            switch (kind) {
+                case MLK_H64_S1_256: halo_tile<E, 64, -1, 1, 256, true>(u.h, tile, cb, lds, tid_it); break;
+                case MLK_H64_S1_128: halo_tile<E, 64, -1, 1, 128, true>(u.h, tile, cb, lds, tid_it); break;
+                case MLK_H48_S1_256: halo_tile<E, 48, -1, 1, 256, true>(u.h, tile, cb, lds, tid_it); break;
+                case MLK_H48_S1_128: halo_tile<E, 48, -1, 1, 128, true>(u.h, tile, cb, lds, tid_it); break;
+                default: halo_tile<E, 64, -1, 2, 128, true>(u.h, tile, cb, lds, tid_it); break;
+            }
+        }
+#endif
+        MLPROF(3)   // tile body (thread 0's wave)
+        // ---- the next item's record: its ticket came back under the tile; the 64 bytes arrive under the store drain
+        if (tid == 0) {
+            mine = next;
+            if (mine < (unsigned)g.n_items) {
+                const mu32x4* rp = reinterpret_cast<const mu32x4*>(g.items + mine);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) rec[i] = rp[i];
             }
         }
         // ---- publish: the write-through stores of EVERY wave have left the CU, then one arrival
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        if (tid == 0) __hip_atomic_fetch_add(g.ctl + ML_CTL_HEAD + (size_t)layer * g.frames + frame, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        MLPROF(4)   // store drain + barrier
+        if (tid == 0) __hip_atomic_fetch_add(g.ctl + arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        MLPROF_ITEM
     }
+    MLPROF_FLUSH
 }
+
+#ifdef ADAS_HALO_PROF   // the halo tile's phase counters as accumulated by THIS translation unit's copy of g_halo_prof (tools/ml_hprof.py)
+extern "C" int adas_debug_ml_halo_prof(unsigned long long* out16, int reset) {
+    static unsigned long long h[256][16];
+    if (out16) {
+        if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_halo_prof), sizeof(h)) != hipSuccess) return -1;
+        for (int i = 0; i < 16; ++i) {
+            out16[i] = 0;
+            for (int b = 0; b < 256; ++b) out16[i] += h[b][i];
+        }
+    }
+    if (reset) {
+        memset(h, 0, sizeof(h));
+        if (hipMemcpyToSymbol(HIP_SYMBOL(g_halo_prof), h, sizeof(h)) != hipSuccess) return -1;
+    }
+    return 0;
+}
+#endif
 
 // ------------------------------------------------------------------------------------- host side
 struct MlPlan {
@@ -275,7 +383,7 @@ bool ml_layer_supported(const ConvArgs& a, int kernel) {
         int bn, bm;
         size_t lds;
         if (!halo_fill_dev(a, &d, &bn, &bm, &lds)) return false;
-        return ml_halo_kind(bn, a.stride, bm) != MLK_NONE && lds <= 80 * 1024 - 64;   // two workgroups per CU beside the 8-byte ticket slot
+        return ml_halo_kind(bn, a.stride, bm) != MLK_NONE && lds <= 80 * 1024 - 256;   // two workgroups per CU with the record slot behind the scratch
     }
     if (kernel == CONV_PW) {
         if (a.kh != 1 || a.kw != 1 || a.stride != 1 || a.pad != 0 || a.res_mode != RES_NONE) return false;
@@ -365,7 +473,7 @@ MlPlan* ml_plan_create(const std::vector<ConvArgs>& layers, const std::vector<in
         h.dev.kind = h.kind;
         lds_max = std::max(lds_max, h.lds);
     }
-    if (lds_max > 80 * 1024 - 64) return fail("LDS");
+    if (lds_max > 80 * 1024 - 256) return fail("LDS");   // + the 128-byte record slot behind it, two workgroups per CU
     // ---- dependencies between the layers of the launch (frame granularity), reduced transitively
     for (int i = 0; i < NL; ++i) {
         uint64_t need = 0;
@@ -485,8 +593,22 @@ MlPlan* ml_plan_create(const std::vector<ConvArgs>& layers, const std::vector<in
             for (int f = 0; f < F; ++f)
                 if (seen[(size_t)i * F + f] != hl[i].items_per_frame) return fail("item table incomplete");
     }
-    std::vector<uint2> words(n_items);
-    for (size_t k = 0; k < n_items; ++k) words[k] = make_uint2(order[k].tile, (uint32_t)order[k].layer | ((uint32_t)order[k].cb << 8) | ((uint32_t)order[k].frame << 16));
+    std::vector<MlItemRec> words(n_items);
+    for (size_t k = 0; k < n_items; ++k) {
+        const Item& it = order[k];
+        const HostLayer& h = hl[it.layer];
+        MlItemRec r;
+        memset(&r, 0, sizeof(r));
+        r.tile = it.tile;
+        r.where = (uint32_t)it.layer | ((uint32_t)it.cb << 8) | ((uint32_t)it.frame << 16);
+        r.kind = (uint32_t)h.kind | ((uint32_t)h.deps.size() << 8);
+        r.arrive = (uint32_t)(ML_CTL_HEAD + (size_t)it.layer * F + it.frame);
+        for (size_t d = 0; d < h.deps.size(); ++d) {
+            r.dep_idx[d] = (uint32_t)(ML_CTL_HEAD + (size_t)h.deps[d] * F + it.frame);
+            r.dep_target[d] = (uint32_t)hl[h.deps[d]].items_per_frame;
+        }
+        words[k] = r;
+    }
     if (info) {
         info->n_layers = NL; info->n_items = (int)n_items; info->frames = F; info->grid = grid; info->order = order_mode; info->lds = lds_max;
         info->items_per_layer.clear(); info->deps.clear(); info->targets.clear(); info->item_words.clear();
@@ -497,12 +619,13 @@ MlPlan* ml_plan_create(const std::vector<ConvArgs>& layers, const std::vector<in
             for (int d : hl[i].deps) tg.push_back(hl[d].items_per_frame);
             info->targets.push_back(tg);
         }
-        for (auto& w : words) info->item_words.push_back((uint64_t)w.x | ((uint64_t)w.y << 32));
+        for (auto& w : words) info->item_words.push_back((uint64_t)w.tile | ((uint64_t)w.where << 32));
     }
     MlPlan* pl = new MlPlan();
     pl->prec = prec;
     pl->grid = grid;
-    pl->lds = lds_max;
+    pl->args.rec_off = (int)((lds_max + 127) / 128 * 128);
+    pl->lds = (size_t)pl->args.rec_off + 128;
     pl->ctl_bytes = ((size_t)ML_CTL_HEAD + (size_t)NL * F) * 4;
     pl->args.n_items = (int)n_items;
     pl->args.frames = F;
@@ -510,17 +633,17 @@ MlPlan* ml_plan_create(const std::vector<ConvArgs>& layers, const std::vector<in
     if (host_only) return pl;
     std::vector<MlLayerDev> devs(NL);
     for (int i = 0; i < NL; ++i) devs[i] = hl[i].dev;
-    bool ok = hipMalloc(&pl->d_layers, devs.size() * sizeof(MlLayerDev)) == hipSuccess && hipMalloc(&pl->d_items, words.size() * sizeof(uint2)) == hipSuccess &&
+    bool ok = hipMalloc(&pl->d_layers, devs.size() * sizeof(MlLayerDev)) == hipSuccess && hipMalloc(&pl->d_items, words.size() * sizeof(MlItemRec)) == hipSuccess &&
               hipMalloc(&pl->d_ctl, pl->ctl_bytes) == hipSuccess;
     ok = ok && hipMemcpy(pl->d_layers, devs.data(), devs.size() * sizeof(MlLayerDev), hipMemcpyHostToDevice) == hipSuccess &&
-         hipMemcpy(pl->d_items, words.data(), words.size() * sizeof(uint2), hipMemcpyHostToDevice) == hipSuccess && hipMemset(pl->d_ctl, 0, pl->ctl_bytes) == hipSuccess;
+         hipMemcpy(pl->d_items, words.data(), words.size() * sizeof(MlItemRec), hipMemcpyHostToDevice) == hipSuccess && hipMemset(pl->d_ctl, 0, pl->ctl_bytes) == hipSuccess;
     if (!ok) {
         (void)hipGetLastError();
         ml_plan_destroy(pl);
         return fail("device allocation");
     }
     pl->args.layers = (const MlLayerDev*)pl->d_layers;
-    pl->args.items = (const uint2*)pl->d_items;
+    pl->args.items = (const MlItemRec*)pl->d_items;
     pl->args.ctl = (unsigned*)pl->d_ctl;
     return pl;
 }
@@ -548,12 +671,13 @@ hipError_t ml_launch(const MlPlan* p, hipStream_t st) {
     return hipGetLastError();
 }
 
-int ml_plan_status(const MlPlan* p, unsigned* error_word) {
+int ml_plan_status(const MlPlan* p, unsigned* error_word, unsigned* head16) {
     if (!p || !p->d_ctl || !error_word) return -1;
     if (hipDeviceSynchronize() != hipSuccess) return -1;
-    unsigned w[2] = {0, 0};
+    unsigned w[ML_CTL_HEAD];
     if (hipMemcpy(w, p->d_ctl, sizeof(w), hipMemcpyDeviceToHost) != hipSuccess) return -1;
     *error_word = w[1];
+    if (head16) memcpy(head16, w, sizeof(w));
     return 0;
 }
 

@@ -86,8 +86,8 @@ static ConvArgs conv_args_of(const adas_engine* e, int i, int batch) {
     return a;
 }
 
-// ---- multi-layer launches (conv_ml.hip).  ADAS_NO_ML=1 keeps every layer its own launch.
-static bool ml_enabled(const adas_engine* e) { return e->ml_on; }   // decided when the engine was created (ADAS_NO_ML, 16-bit precisions)
+// ---- multi-layer launches (conv_ml.hip): opt-in, ADAS_ML=1 when the engine is created.
+static bool ml_enabled(const adas_engine* e) { return e->ml_on; }   // decided when the engine was created (ADAS_ML=1, 16-bit precisions)
 
 // Is op `i` a conv that launches on its own at this batch AND has a tile body in the multi-layer kernel?
 static bool ml_candidate(const adas_engine* e, int i, int batch, ConvArgs* out) {
@@ -100,6 +100,10 @@ static bool ml_candidate(const adas_engine* e, int i, int batch, ConvArgs* out) 
     auto aliased = [&](int b) { return b >= 0 && b < (int)e->buf_aliased.size() && e->buf_aliased[b]; };
     if (aliased(o.in_buf[0]) || aliased(o.out_buf) || (o.res_mode != RES_NONE && aliased(o.res_buf))) return false;
     if (op.up_src >= 0 && aliased(e->ops[op.up_src].f.in_buf[0])) return false;
+    {   // experiments: ADAS_ML_ONLY=halo | pw keeps the other kind of layer out of the launches
+        const char* only = getenv("ADAS_ML_ONLY");
+        if (only && ((only[0] == 'h' && op.kernel != CONV_HALO) || (only[0] == 'p' && op.kernel != CONV_PW))) return false;
+    }
     const ConvArgs a = conv_args_of(e, i, batch);
     if (!ml_layer_supported(a, op.kernel)) return false;
     if (out) *out = a;
@@ -148,9 +152,9 @@ int adas_engine_create(const char* model_path, int precision, int max_batch, ada
     adas_engine* e = new adas_engine();
     e->prec = precision;
     e->max_batch = max_batch;
-    {
-        const char* v = getenv("ADAS_NO_ML");
-        e->ml_on = prec_is16(precision) && !(v && v[0] == '1');
+    {   // multi-layer launches are opt-in (ADAS_ML=1): measured slower than the per-layer launches at 64 frames (profiles/r05/ml_*.txt)
+        const char* v = getenv("ADAS_ML");
+        e->ml_on = prec_is16(precision) && v && v[0] == '1';
     }
     e->hdr = hd;
     e->name = std::string(hd.name, strnlen(hd.name, sizeof(hd.name)));
@@ -1206,6 +1210,14 @@ int adas_engine_ml_status(const adas_engine* e, int batch, uint32_t* error_word)
                 return ADAS_ERR_HIP;
             }
         }
+    return ADAS_OK;
+}
+int adas_engine_ml_counters(const adas_engine* e, int batch, int launch, uint32_t head16[16]) {
+    ADAS_REQUIRE(e && head16, ADAS_ERR_INVALID, "adas_engine_ml_counters: bad argument");
+    const std::vector<MlSeg>* segs = ml_segments(e, batch);
+    ADAS_REQUIRE(segs && launch >= 0 && launch < (int)segs->size(), ADAS_ERR_INVALID, "adas_engine_ml_counters: no multi-layer launch %d at batch %d", launch, batch);
+    unsigned w = 0;
+    ADAS_REQUIRE(ml_plan_status((*segs)[launch].plan, &w, head16) == 0, ADAS_ERR_HIP, "adas_engine_ml_counters: could not read the control block");
     return ADAS_OK;
 }
 int adas_engine_launch_count(adas_engine* e, int batch) {
