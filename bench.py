@@ -737,7 +737,7 @@ def main():
                     label, launches = pair_label, 0   # second conv of a 3x3 -> 3x3 pair: computed by the first conv's launch
                 elif label.startswith("(fused into the C2f") and c2f_label:
                     label, launches = c2f_label, 0    # Bottleneck pair / closing 1x1 of a C2f block computed by its cv1's launch
-                elif label.startswith("(in the multi-layer") and ml_label:
+                elif label.startswith(("(in the multi-layer", "(in the grouped launch")) and ml_label:
                     label, launches = ml_label, 0     # a member of a multi-layer persistent launch (conv_ml.hip): its FLOPs belong to that launch
                 elif label.startswith("(fused into"):
                     continue                          # fused into a neighbouring conv launch that reports the FLOPs itself
@@ -747,7 +747,7 @@ def main():
                     pair_label = label
                 elif label.startswith("conv_c2f16_kernel"):
                     c2f_label = label
-                elif label.startswith("conv_ml_kernel"):
+                elif label.startswith(("conv_ml_kernel", "conv_halo_group_kernel")):
                     ml_label = label
                 extra = 0.0
                 if raw_label.endswith("+shortcut"):

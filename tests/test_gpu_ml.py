@@ -73,6 +73,33 @@ def test_multi_layer_launch_is_bit_identical_to_per_layer_launches(CE, name, pre
     a.close(); b.close()
 
 
+@pytest.mark.parametrize("name,prec,batch", [("yolov8n", "fp16", 64), ("yolov8n", "bf16", 5), ("yolov8n", "fp16", 1), ("yolov8s", "fp16", 8)])
+def test_grouped_launch_of_independent_layers_is_bit_identical(CE, name, prec, batch):
+    """The default path: 3x3 halo convs of one dependency level of a run (the Detect branches of every pyramid level) share a launch
+    (conv_halo_group_kernel).  Against ADAS_NO_GROUP=1 -- every layer its own conv_halo launch: heads and member activations bit for bit,
+    fewer launches."""
+    path, W, g = netutil.model(name)
+    a = _engine(CE, path, prec, batch, ml=False)
+    b = _engine(CE, path, prec, batch, ml=False, ADAS_NO_GROUP=1)
+    n_layers = a.stats()["num_layers"]
+    ka = [a.layer_kernel(i, batch) for i in range(n_layers)]
+    kb = [b.layer_kernel(i, batch) for i in range(n_layers)]
+    members = [i for i in range(n_layers) if ka[i].startswith(("conv_halo_group_kernel", "(in the grouped launch"))]
+    print(name, prec, batch, "grouped layers:", len(members), "launches", a.launch_count(batch), "vs", b.launch_count(batch), [k for k in ka if k.startswith("conv_halo_group")])
+    assert not any(k.startswith(("conv_halo_group_kernel", "(in the grouped")) for k in kb)
+    assert all(kb[i].startswith("conv_halo_kernel") for i in members)
+    if name == "yolov8n" and batch == 64:
+        assert len(members) == 10 and a.launch_count(batch) == b.launch_count(batch) - 8      # Detect: ten launches become two
+    for rep in range(2):
+        x = _frames(batch, 300 + rep)
+        ya, yb = a.engine_inference(x), b.engine_inference(x)
+        for u, v in zip(ya, yb):
+            assert np.array_equal(np.asarray(u), np.asarray(v)), "head differs (rep %d)" % rep
+    for i in members:
+        assert np.array_equal(a.fetch_activation(i, batch), b.fetch_activation(i, batch)), (i, a.layer_info(i)[0])
+    a.close(); b.close()
+
+
 def test_layer_major_order_and_small_grid_give_the_same_bits(CE):
     """The ticket order and the number of resident workgroups are scheduling only: layer-major tickets and a 96-workgroup grid (every
     dependency wait exposed) produce the bits of the default launch."""

@@ -13,8 +13,12 @@ CE = importlib.import_module("adas_amd.coreEngine")
 L = importlib.import_module("adas_amd._lib")
 
 
-def engine(path, prec, batch, ml):
-    os.environ["ADAS_ML"] = "1" if ml else "0"
+def engine(path, prec, batch, mode):      # "ml": multi-layer persistent launches; "group": grouped independent layers (the default path); "plain"
+    os.environ["ADAS_ML"] = "1" if mode == "ml" else "0"
+    if mode == "plain":
+        os.environ["ADAS_NO_GROUP"] = "1"        # the reference engine: every layer its own launch
+    else:
+        os.environ.pop("ADAS_NO_GROUP", None)
     e = CE.HipEngine(path, precision=prec, max_batch=batch)
     e.prepare(batch)
     return e
@@ -26,7 +30,7 @@ def main():
     batch = int(sys.argv[3]) if len(sys.argv) > 3 else 64
     prec = sys.argv[4] if len(sys.argv) > 4 else "fp16"
     path, W, g = netutil.model(name)
-    a, b = engine(path, prec, batch, True), engine(path, prec, batch, False)
+    a, b = engine(path, prec, batch, os.environ.get("ML_DEBUG_A", "ml")), engine(path, prec, batch, "plain")
     n = a.stats()["num_layers"]
     x0 = netutil.coco_like_frames(2)
     x = np.ascontiguousarray(np.stack([np.roll(x0[i % 2], (13 * i, 29 * i), (1, 2)) for i in range(batch)])).astype(np.float32)
@@ -37,7 +41,7 @@ def main():
         shown = 0
         for i in range(n):
             k = a.layer_kernel(i, batch)
-            if not k.startswith(("conv_ml_kernel", "(in the multi-layer")):
+            if not k.startswith(("conv_ml_kernel", "(in the multi-layer", "conv_halo_group_kernel", "(in the grouped")):
                 continue
             u, v = a.fetch_activation(i, batch), b.fetch_activation(i, batch)
             nd = int((u != v).sum())
@@ -72,10 +76,10 @@ def main():
         seg, acc = None, {}
         for i in range(n):
             k = a.layer_kernel(i, batch)
-            if k.startswith("conv_ml_kernel"):
+            if k.startswith(("conv_ml_kernel", "conv_halo_group_kernel")):
                 seg = i
                 acc[seg] = [k, ta[i][3], 0.0, 0, 0.0]
-            if k.startswith(("conv_ml_kernel", "(in the multi-layer")):
+            if k.startswith(("conv_ml_kernel", "(in the multi-layer", "conv_halo_group_kernel", "(in the grouped")):
                 acc[seg][2] += tb[i][3]; acc[seg][3] += 1; acc[seg][4] += ta[i][1] * batch
         for s, (k, ms, ref, cnt, fl) in acc.items():
             print("segment at %3d %-28s %-26s  %.4f ms  vs per-layer sum %.4f ms  (%d layers, %.1f GFLOP, %.0f TF/s)" % (s, a.layer_info(s)[0], k, ms, ref, cnt, fl / 1e9, fl / ms / 1e9))

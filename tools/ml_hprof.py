@@ -31,6 +31,7 @@ names = ["setup", "issue first loads", "first loads land + LDS store", "barrier"
 res = {}
 for ml in (1, 0):
     os.environ["ADAS_ML"] = "1" if ml else "0"
+    os.environ["ADAS_NO_GROUP"] = "1"
     os.environ["ADAS_ML_ONLY"] = "halo"
     e = CE.HipEngine(path, "fp16", a.batch)
     e.prepare(a.batch)

@@ -42,4 +42,16 @@ hipError_t ml_launch(const MlPlan* p, hipStream_t st);
 // the control block's error word of the LAST launch (synchronises the device): 0, or 1 + the index of the item whose wait timed out
 int ml_plan_status(const MlPlan* p, unsigned* error_word, unsigned* head16 = nullptr);   // head16: the control block's first 16 words (phase counters of -DADAS_ML_PROF builds)
 
+// ---- grouped launch of INDEPENDENT layers (the default path, ADAS_NO_GROUP=1 disables): 3x3 halo convs of one dependency level of a run of
+// consecutive layers -- the two Detect branches of a pyramid level, the Detect convs of different levels -- as ONE plain launch: block ->
+// (layer, tile, channel block) through a table, each block runs conv_halo's tile body once.  No workgroup waits for another, nothing is
+// persistent: the small layers ride in the tail of the large ones and their launch boundaries disappear.  Bit-identical to conv_halo.
+bool group_layer_supported(const ConvArgs& a, int kernel);   // a conv launch_conv sends to conv_halo with a body in the group kernel
+// dependency level of every layer of a run (0: depends on nothing inside the run), from the views: RAW, WAR and WAW hazards are edges
+std::vector<int> ml_levels(const std::vector<ConvArgs>& layers);
+struct MlGroup;
+MlGroup* ml_group_create(const std::vector<ConvArgs>& layers, int prec, std::string* why);   // the layers must be mutually independent
+void ml_group_destroy(MlGroup* g);
+hipError_t ml_group_launch(const MlGroup* g, hipStream_t st);
+
 }  // namespace adas

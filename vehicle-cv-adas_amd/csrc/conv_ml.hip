@@ -314,6 +314,42 @@ __global__ __launch_bounds__(256, ADAS_ML_WAVES) void conv_ml_kernel(MlArgs g) {
     MLPROF_FLUSH
 }
 
+// ------------------------------------------------------------------------------------- grouped launch of independent layers
+constexpr int GROUP_MAX = 8;
+struct GroupArgs {
+    const MlLayerDev* layers;      // .kind + .u.h are read
+    int n;
+    int first_block[GROUP_MAX + 1];   // block range of layer l: [first_block[l], first_block[l + 1]), starts are multiples of 8 (XCD phase)
+};
+
+template <typename E>
+__global__ __launch_bounds__(256, 2) void conv_halo_group_kernel(GroupArgs g) {
+    E::enter();
+    extern __shared__ __attribute__((aligned(16))) uint16_t lds[];
+    int l = 0;
+#pragma unroll
+    for (int i = 1; i < GROUP_MAX; ++i)
+        if (i < g.n && (int)blockIdx.x >= g.first_block[i]) l = i;
+    const int local = (int)blockIdx.x - g.first_block[l];
+    struct Head { int kind, n_dep, per_img, pad; } hd;
+    ml_copy_const(hd, g.layers + l);
+    HaloDev a;
+    ml_copy_const(a, &g.layers[l].u.h);
+    // conv_halo_kernel's workgroup -> (tile, channel block) map on the layer's own block range (its start is a multiple of 8: same XCD phase)
+    const int xslot = local >> 3;
+    const int xr = xslot / a.cbg;
+    const int cb = (xr / a.tiles8) * a.cbg + (xslot - xr * a.cbg);
+    const int tile = a.xmap ? (local & 7) * a.tiles8 + (xr % a.tiles8) : (xr % a.tiles8) * 8 + (local & 7);
+    if (cb >= a.ncb || tile >= a.ntiles) return;
+    switch (hd.kind) {
+        case MLK_H64_S1_256: halo_tile<E, 64, -1, 1, 256, false>(a, tile, cb, lds, threadIdx.x); break;
+        case MLK_H64_S1_128: halo_tile<E, 64, -1, 1, 128, false>(a, tile, cb, lds, threadIdx.x); break;
+        case MLK_H48_S1_256: halo_tile<E, 48, -1, 1, 256, false>(a, tile, cb, lds, threadIdx.x); break;
+        case MLK_H48_S1_128: halo_tile<E, 48, -1, 1, 128, false>(a, tile, cb, lds, threadIdx.x); break;
+        default: halo_tile<E, 64, -1, 2, 128, false>(a, tile, cb, lds, threadIdx.x); break;
+    }
+}
+
 #ifdef ADAS_HALO_PROF   // the halo tile's phase counters as accumulated by THIS translation unit's copy of g_halo_prof (tools/ml_hprof.py)
 extern "C" int adas_debug_ml_halo_prof(unsigned long long* out16, int reset) {
     static unsigned long long h[256][16];
@@ -679,6 +715,117 @@ int ml_plan_status(const MlPlan* p, unsigned* error_word, unsigned* head16) {
     *error_word = w[1];
     if (head16) memcpy(head16, w, sizeof(w));
     return 0;
+}
+
+// ------------------------------------------------------------------------------------- grouped launch: host side
+bool group_layer_supported(const ConvArgs& a, int kernel) {
+    if (kernel != CONV_HALO || !prec_is16(a.prec) || a.in.f32 || a.out.f32 || a.ds_w || a.up_c > 0) return false;
+    if (a.act != ACT_NONE && a.act != ACT_SILU && a.act != ACT_RELU && a.act != ACT_LEAKY) return false;
+    if (!(a.halo_bn > 0 && a.halo_bn != halo_bn(a.out.c))) {   // launch_conv's order of choice
+        if (halo_rw_applicable(a.kh, a.kw, a.stride, a.pad, a.n, a.in, a.out)) return false;
+        if (halo_s2p_applicable(a.kh, a.kw, a.stride, a.pad, a.res_mode, a.n, a.in, a.out)) return false;
+        if (halo8_applicable(a.kh, a.kw, a.stride, a.pad, a.n, a.in, a.out, a.res, a.res_mode)) return false;
+    }
+    HaloDev d;
+    int bn, bm;
+    size_t lds;
+    if (!halo_fill_dev(a, &d, &bn, &bm, &lds)) return false;
+    return ml_halo_kind(bn, a.stride, bm) != MLK_NONE && lds <= 80 * 1024;
+}
+
+std::vector<int> ml_levels(const std::vector<ConvArgs>& layers) {
+    const int n = (int)layers.size();
+    std::vector<int> level(n, 0);
+    auto reads = [&](const ConvArgs& a) {
+        std::vector<RView> r;
+        int c_lo = a.in.coff;
+        if (a.up_c > 0) { r.push_back(RView{a.up.p, a.up.coff, a.up.coff + a.up.c}); c_lo += a.up_c; }
+        r.push_back(RView{a.in.p, c_lo, a.in.coff + a.in.c});
+        if (a.res_mode != RES_NONE) r.push_back(RView{a.res.p, a.res.coff, a.res.coff + a.out.c});
+        return r;
+    };
+    for (int i = 0; i < n; ++i) {
+        const RView wi{layers[i].out.p, layers[i].out.coff, layers[i].out.coff + layers[i].out.c};
+        const auto ri = reads(layers[i]);
+        for (int j = 0; j < i; ++j) {
+            const RView wj{layers[j].out.p, layers[j].out.coff, layers[j].out.coff + layers[j].out.c};
+            bool dep = overlaps(wi, wj);
+            for (auto& r : ri) dep = dep || overlaps(r, wj);
+            for (auto& r : reads(layers[j])) dep = dep || overlaps(r, wi);
+            if (dep && level[j] + 1 > level[i]) level[i] = level[j] + 1;
+        }
+    }
+    return level;
+}
+
+struct MlGroup {
+    GroupArgs args{};
+    void* d_layers = nullptr;
+    size_t lds = 0;
+    int grid = 0, prec = 0;
+};
+
+MlGroup* ml_group_create(const std::vector<ConvArgs>& layers, int prec, std::string* why) {
+    auto fail = [&](const char* msg) -> MlGroup* {
+        if (why) *why = msg;
+        return nullptr;
+    };
+    const int n = (int)layers.size();
+    if (n < 2 || n > GROUP_MAX) return fail("layer count");
+    {
+        const std::vector<int> lv = ml_levels(layers);
+        for (int v : lv)
+            if (v != 0) return fail("layers of a grouped launch must be independent");
+    }
+    std::vector<MlLayerDev> devs(n);
+    MlGroup* g = new MlGroup();
+    g->prec = prec;
+    int blocks = 0;
+    for (int i = 0; i < n; ++i) {
+        const ConvArgs& a = layers[i];
+        memset(&devs[i], 0, sizeof(MlLayerDev));
+        int bn, bm;
+        size_t lds;
+        if (a.prec != prec || !group_layer_supported(a, CONV_HALO) || !halo_fill_dev(a, &devs[i].u.h, &bn, &bm, &lds)) {
+            delete g;
+            return fail("layer not supported");
+        }
+        devs[i].kind = ml_halo_kind(bn, a.stride, bm);
+        const HaloDev& d = devs[i].u.h;
+        g->args.first_block[i] = blocks;
+        blocks += 8 * d.tiles8 * d.cbg * ((d.ncb + d.cbg - 1) / d.cbg);   // conv_halo's grid for this layer: a multiple of 8
+        g->lds = std::max(g->lds, lds);
+    }
+    for (int i = n; i <= GROUP_MAX; ++i) g->args.first_block[i] = blocks;
+    g->args.n = n;
+    g->grid = blocks;
+    if (hipMalloc(&g->d_layers, devs.size() * sizeof(MlLayerDev)) != hipSuccess ||
+        hipMemcpy(g->d_layers, devs.data(), devs.size() * sizeof(MlLayerDev), hipMemcpyHostToDevice) != hipSuccess) {
+        (void)hipGetLastError();
+        ml_group_destroy(g);
+        return fail("device allocation");
+    }
+    g->args.layers = (const MlLayerDev*)g->d_layers;
+    return g;
+}
+
+void ml_group_destroy(MlGroup* g) {
+    if (!g) return;
+    if (g->d_layers) (void)hipFree(g->d_layers);
+    delete g;
+}
+
+hipError_t ml_group_launch(const MlGroup* g, hipStream_t st) {
+    if (!g || !g->d_layers) return hipErrorInvalidValue;
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute((const void*)conv_halo_group_kernel<Fp16>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+        (void)hipFuncSetAttribute((const void*)conv_halo_group_kernel<Bf16>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+        attr_done = true;
+    }
+    if (g->prec == PREC_FP16) hipLaunchKernelGGL(conv_halo_group_kernel<Fp16>, dim3(g->grid), dim3(256), g->lds, st, g->args);
+    else hipLaunchKernelGGL(conv_halo_group_kernel<Bf16>, dim3(g->grid), dim3(256), g->lds, st, g->args);
+    return hipGetLastError();
 }
 
 }  // namespace adas

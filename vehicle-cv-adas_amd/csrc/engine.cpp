@@ -110,6 +110,27 @@ static bool ml_candidate(const adas_engine* e, int i, int batch, ConvArgs* out) 
     return true;
 }
 
+// Is op `i` a 3x3 conv that launches on conv_halo at this batch (a layer the grouped launch can carry)?
+static bool group_candidate(const adas_engine* e, int i, int batch, ConvArgs* out) {
+    const EngOp& op = e->ops[i];
+    const FileOp& o = op.f;
+    if (o.type != OP_CONV || op.skip || op.kernel != CONV_HALO) return false;
+    if (op.pair_b >= 0 || op.c2f[0] >= 0 || op.fuse_pool >= 0 || op.fuse_conv2 >= 0 || op.up_src >= 0) return false;
+    if (op.ds_user >= 0 && ds_folded(e, op.ds_user, batch)) return false;
+    if (op.ds_src >= 0 && ds_folded(e, i, batch)) return false;
+    auto aliased = [&](int b) { return b >= 0 && b < (int)e->buf_aliased.size() && e->buf_aliased[b]; };
+    if (aliased(o.in_buf[0]) || aliased(o.out_buf) || (o.res_mode != RES_NONE && aliased(o.res_buf))) return false;
+    const ConvArgs a = conv_args_of(e, i, batch);
+    if (!group_layer_supported(a, op.kernel)) return false;
+    if (out) *out = a;
+    return true;
+}
+
+static const std::vector<GroupRun>* group_runs(const adas_engine* e, int batch) {
+    auto it = e->groups.find(batch);
+    return it == e->groups.end() ? nullptr : &it->second;
+}
+
 static const std::vector<MlSeg>* ml_segments(const adas_engine* e, int batch) {
     auto it = e->ml.find(batch);
     return it == e->ml.end() ? nullptr : &it->second;
@@ -120,6 +141,10 @@ static int free_engine(adas_engine* e) {
     for (auto& kv : e->ml)
         for (auto& sg : kv.second) ml_plan_destroy(sg.plan);
     e->ml.clear();
+    for (auto& kv : e->groups)
+        for (auto& run : kv.second)
+            for (auto& st : run.steps) ml_group_destroy(st.group);
+    e->groups.clear();
     for (auto& b : e->bufs)
         if (b.d && b.alias_of < 0) (void)hipFree(b.d);
     if (e->d_weights) (void)hipFree(e->d_weights);
@@ -155,6 +180,8 @@ int adas_engine_create(const char* model_path, int precision, int max_batch, ada
     {   // multi-layer launches are opt-in (ADAS_ML=1): measured slower than the per-layer launches at 64 frames (profiles/r05/ml_*.txt)
         const char* v = getenv("ADAS_ML");
         e->ml_on = prec_is16(precision) && v && v[0] == '1';
+        const char* g = getenv("ADAS_NO_GROUP");
+        e->group_on = prec_is16(precision) && !e->ml_on && !(g && g[0] == '1');
     }
     e->hdr = hd;
     e->name = std::string(hd.name, strnlen(hd.name, sizeof(hd.name)));
@@ -836,7 +863,19 @@ int adas_engine_layer_kernel(const adas_engine* e, int layer, int batch, char* n
         for (auto& sg : *segs)
             for (int m : sg.ops)
                 if (m == layer) in_seg = &sg;
-    if (in_seg && in_seg->first == layer) {
+    const GroupRun* in_run = nullptr;
+    if (const std::vector<GroupRun>* runs = group_runs(e, batch))
+        for (auto& run : *runs)
+            for (int m : run.ops)
+                if (m == layer) in_run = &run;
+    if (in_run && in_run->first == layer) {
+        int ng = 0;
+        for (auto& st : in_run->steps) ng += st.group ? 1 : 0;
+        snprintf(name, cap, "conv_halo_group_kernel[%d layers, %d launches]", (int)in_run->ops.size(), (int)in_run->steps.size());
+        (void)ng;
+    } else if (in_run) {
+        snprintf(name, cap, "(in the grouped launch)");
+    } else if (in_seg && in_seg->first == layer) {
         snprintf(name, cap, "conv_ml_kernel[%d layers]", in_seg->n_layers);
     } else if (in_seg) {
         snprintf(name, cap, "(in the multi-layer launch)");
@@ -1101,7 +1140,59 @@ int engine_run_op(adas_engine* e, int i, const float* d_in, int batch, hipStream
 
 // Builds the multi-layer launches of this batch size (device tables: allocations and copies, so never inside a stream capture --
 // adas_pipeline_* prepares before it captures; a forward that finds nothing prepared while capturing runs per-layer launches).
+static void prepare_groups(adas_engine* e, int batch) {
+    std::vector<GroupRun>& runs = e->groups[batch];
+    const int n = (int)e->ops.size();
+    int i = 0;
+    while (i < n) {
+        std::vector<ConvArgs> layers;
+        std::vector<int> ops;
+        int j = i, last = i;
+        for (; j < n; ++j) {
+            if (e->ops[j].skip) continue;
+            if (e->ops[j].f.type == OP_CONV && e->ops[j].ds_user >= 0 && ds_folded(e, e->ops[j].ds_user, batch)) continue;
+            ConvArgs a;
+            if (!group_candidate(e, j, batch, &a) || (int)layers.size() >= ML_MAX_LAYERS) break;
+            layers.push_back(a); ops.push_back(j);
+            last = j;
+        }
+        if (layers.size() < 2) { i = (layers.empty() ? j : last) + 1; continue; }
+        const std::vector<int> level = ml_levels(layers);
+        int nlev = 0;
+        for (int v : level) nlev = v + 1 > nlev ? v + 1 : nlev;
+        GroupRun run;
+        run.first = ops.front(); run.last = last; run.ops = ops;
+        bool any_group = false, ok = true;
+        for (int lv = 0; lv < nlev && ok; ++lv) {
+            std::vector<int> idx;
+            for (size_t k = 0; k < layers.size(); ++k)
+                if (level[k] == lv) idx.push_back((int)k);
+            for (size_t c0 = 0; c0 < idx.size() && ok; c0 += 8) {   // at most 8 layers per launch
+                const size_t c1 = c0 + 8 < idx.size() ? c0 + 8 : idx.size();
+                GroupStep st;
+                if (c1 - c0 >= 2) {
+                    std::vector<ConvArgs> sub;
+                    for (size_t k = c0; k < c1; ++k) { sub.push_back(layers[idx[k]]); st.members.push_back(ops[idx[k]]); }
+                    std::string why;
+                    st.group = ml_group_create(sub, e->prec, &why);
+                    ok = st.group != nullptr;
+                    any_group = true;
+                } else {
+                    st.op = ops[idx[c0]];
+                    st.members.push_back(st.op);
+                }
+                if (ok) run.steps.push_back(st);
+            }
+        }
+        if (ok && any_group) runs.push_back(run);
+        else
+            for (auto& st : run.steps) ml_group_destroy(st.group);
+        i = last + 1;
+    }
+}
+
 int engine_prepare(adas_engine* e, int batch) {
+    if (e->group_on && !e->groups.count(batch)) prepare_groups(e, batch);
     if (!ml_enabled(e) || e->ml.count(batch)) return ADAS_OK;
     std::vector<MlSeg>& segs = e->ml[batch];
     static int min_layers = -1, max_items = -1;
@@ -1149,13 +1240,32 @@ static bool stream_capturing(hipStream_t st) {
 }
 
 int engine_forward(adas_engine* e, const float* d_in, int batch, hipStream_t st, bool packed_in) {
-    if (ml_enabled(e) && !e->ml.count(batch) && !stream_capturing(st)) {
+    if (((ml_enabled(e) && !e->ml.count(batch)) || (e->group_on && !e->groups.count(batch))) && !stream_capturing(st)) {
         int rc = engine_prepare(e, batch);
         if (rc != ADAS_OK) return rc;
     }
     const std::vector<MlSeg>* segs = ml_segments(e, batch);
-    size_t si = 0;
+    const std::vector<GroupRun>* runs = group_runs(e, batch);
+    size_t si = 0, gi = 0;
     for (int i = 0; i < (int)e->ops.size(); ++i) {
+        if (runs && gi < runs->size() && (*runs)[gi].first == i) {   // a run of halo convs, level by level: independent layers share a launch
+            const GroupRun& run = (*runs)[gi++];
+            for (auto& step : run.steps) {
+                if (step.group) {
+                    hipError_t err = ml_group_launch(step.group, st);
+                    if (err != hipSuccess) {
+                        set_error("layers %d..%d: grouped launch failed: %s", run.first, run.last, hipGetErrorString(err));
+                        (void)hipGetLastError();
+                        return ADAS_ERR_HIP;
+                    }
+                } else {
+                    int rc = engine_run_op(e, step.op, d_in, batch, st, packed_in);
+                    if (rc != ADAS_OK) return rc;
+                }
+            }
+            i = run.last;
+            continue;
+        }
         if (segs && si < segs->size() && (*segs)[si].first == i) {
             const MlSeg& sg = (*segs)[si++];
             hipError_t err = ml_launch(sg.plan, st);
@@ -1223,9 +1333,11 @@ int adas_engine_ml_counters(const adas_engine* e, int batch, int launch, uint32_
 int adas_engine_launch_count(adas_engine* e, int batch) {
     if (!e || batch <= 0 || batch > e->max_batch) return -1;
     const std::vector<MlSeg>* segs = ml_segments(e, batch);
-    size_t si = 0;
+    const std::vector<GroupRun>* runs = group_runs(e, batch);
+    size_t si = 0, gi = 0;
     int n = 0;
     for (int i = 0; i < (int)e->ops.size(); ++i) {
+        if (runs && gi < runs->size() && (*runs)[gi].first == i) { n += (int)(*runs)[gi].steps.size(); i = (*runs)[gi++].last; continue; }
         if (segs && si < segs->size() && (*segs)[si].first == i) { ++n; i = (*segs)[si++].last; continue; }
         const EngOp& op = e->ops[i];
         if (op.skip) continue;
@@ -1346,10 +1458,26 @@ int adas_engine_profile(adas_engine* e, const float* d_input, int batch, int ite
         if (rc != ADAS_OK) return rc;
     }
     const std::vector<MlSeg>* segs = ml_segments(e, batch);
+    const std::vector<GroupRun>* runs = group_runs(e, batch);
     for (int it = 0; it < iters; ++it) {
         ADAS_HIP_TRY(hipEventRecord(e->events[0], 0));
-        size_t si = 0;
+        size_t si = 0, gi = 0;
         for (int i = 0; i < n; ++i) {
+            if (runs && gi < runs->size() && (*runs)[gi].first == i) {   // a run of grouped launches: its time goes to its first layer
+                const GroupRun& run = (*runs)[gi++];
+                for (auto& step : run.steps) {
+                    if (step.group) {
+                        hipError_t err = ml_group_launch(step.group, 0);
+                        if (err != hipSuccess) return hip_fail(err, "grouped launch", __FILE__, __LINE__);
+                    } else {
+                        int rc = engine_run_op(e, step.op, d_input, batch, 0);
+                        if (rc != ADAS_OK) return rc;
+                    }
+                }
+                for (int k = i; k <= run.last; ++k) ADAS_HIP_TRY(hipEventRecord(e->events[k + 1], 0));
+                i = run.last;
+                continue;
+            }
             if (segs && si < segs->size() && (*segs)[si].first == i) {   // a multi-layer launch: its time goes to its first layer, the rest read 0
                 const MlSeg& sg = (*segs)[si++];
                 hipError_t err = ml_launch(sg.plan, 0);

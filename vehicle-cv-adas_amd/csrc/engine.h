@@ -84,6 +84,18 @@ struct MlSeg {
     MlPlan* plan = nullptr;
     std::vector<int> ops;     // the member ops, in launch order
 };
+// A run of consecutive 3x3 halo convs re-ordered by dependency level, the layers of a level launched together (conv_ml.hip grouped launch:
+// independent layers, no synchronisation inside the launch).  Decided per batch size like the multi-layer launches.
+struct GroupStep {
+    MlGroup* group = nullptr;    // >= 2 independent layers in one launch, or
+    int op = -1;                 // one layer on its own kernel
+    std::vector<int> members;
+};
+struct GroupRun {
+    int first = 0, last = 0;
+    std::vector<GroupStep> steps;
+    std::vector<int> ops;
+};
 struct EngOut {
     uint32_t buf, offset, ndim, dims[4];
     size_t elems;  // per frame
@@ -110,6 +122,8 @@ struct adas_engine {
     std::vector<hipEvent_t> events;
     hipStream_t last = 0;
     std::map<int, std::vector<adas::MlSeg>> ml;   // batch -> multi-layer launches (adas_engine_prepare); absent: not prepared, per-layer launches
+    std::map<int, std::vector<adas::GroupRun>> groups;   // batch -> grouped launches of independent layers (default path)
+    bool group_on = false;                         // ADAS_NO_GROUP=1 at creation keeps every layer its own launch
     bool ml_on = false;                            // multi-layer launches enabled for this engine (read from the environment at creation)
     std::vector<char> buf_aliased;                 // buffer takes part in an alias (Graph.alias): stays out of multi-layer launches
     float* sink_conf = nullptr;   // adas_engine_set_detect_sink: the fused v8 Detect writes per-anchor (best probability, class) here
