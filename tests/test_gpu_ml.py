@@ -54,9 +54,10 @@ def test_multi_layer_launch_is_bit_identical_to_per_layer_launches(CE, name, pre
     info = a.ml_info(batch)
     print(name, prec, batch, "multi-layer launches:", info, "kernel launches per forward:", a.launch_count(batch), "vs", b.launch_count(batch))
     assert b.ml_info(batch) == {"launches": 0, "layers": 0, "items": 0}
-    if batch >= 16 and name == "yolov8n":
+    if batch == 64 and name == "yolov8n":
         assert info["launches"] >= 3 and info["layers"] >= 30, info                      # the 40x40 / 20x20 layers and the Detect branches
         assert a.launch_count(batch) <= b.launch_count(batch) - 25
+    assert info["launches"] >= 1 and info["layers"] >= 2 * info["launches"], info         # (smaller batches pack narrower channel blocks: fewer eligible layers)
     n_layers = a.stats()["num_layers"]
     members = [i for i in range(n_layers) if a.layer_kernel(i, batch).startswith(("conv_ml_kernel", "(in the multi-layer"))]
     assert len(members) == info["layers"]
