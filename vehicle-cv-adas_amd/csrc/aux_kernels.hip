@@ -899,7 +899,7 @@ __global__ __launch_bounds__(256, 3) void detect_v5_fused_kernel(Det5Dev d) {
                 for (int r = 0; r < 4; ++r) {
                     const int c = nt * 16 + kg * 4 + r;
                     if (c < no) {
-                        const float sg = __frcp_rn(1.0f + __expf(-(acc[t][nt][r] + bl[c])));
+                        const float sg = fast_rcp(1.0f + __expf(-(acc[t][nt][r] + bl[c])));   // (elem16.h: the hardware reciprocal)
                         float o = sg;
                         if (c == 0) o = (sg * 2.0f - 0.5f + gx) * sl;
                         else if (c == 1) o = (sg * 2.0f - 0.5f + gy) * sl;

@@ -39,7 +39,7 @@ constexpr int CF_NI = CF_IW * CF_IW, CF_G1 = (CF_NI + 15) / 16;      // 324 inte
 constexpr int CF_NW = CF_WW * CF_WW, CF_GW = CF_NW / 16;             // 400 window pixels, 25 groups
 constexpr uint32_t CF_OOB = 0x80000000u;
 
-__device__ __forceinline__ float cf_silu(float v) { return v * __frcp_rn(1.0f + __expf(-v)); }
+__device__ __forceinline__ float cf_silu(float v) { return v * fast_rcp(1.0f + __expf(-v)); }
 // 64-byte pixels (32 channels): conv_halo's conflict-free chunk swizzle
 __device__ __forceinline__ int cf_pos32(int p, int c) { return c ^ (((p >> 2) & 1) << 1); }
 

@@ -143,7 +143,7 @@ __global__ __launch_bounds__(64 * KS) void fc_kernel(FcDev a) {
                 for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
             } else if (a.act == ACT_SILU) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = v[r] * __frcp_rn(1.0f + __expf(-v[r]));
+                for (int r = 0; r < 4; ++r) v[r] = v[r] * fast_rcp(1.0f + __expf(-v[r]));
             }
             const size_t o = (size_t)m * a.out_cs + a.out_coff + c;
             if (a.out_f32) {

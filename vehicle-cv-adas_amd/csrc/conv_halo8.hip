@@ -85,7 +85,7 @@ __device__ __forceinline__ void h8_wait_vm() {
 
 template <int ACT>
 __device__ __forceinline__ float h8_act(float v) {
-    if (ACT == ACT_SILU) return v * __frcp_rn(1.0f + __expf(-v));
+    if (ACT == ACT_SILU) return v * fast_rcp(1.0f + __expf(-v));
     if (ACT == ACT_RELU) return fmaxf(v, 0.0f);
     if (ACT == ACT_LEAKY) return fmaxf(v, 0.1f * v);
     return v;

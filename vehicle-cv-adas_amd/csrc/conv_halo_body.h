@@ -13,7 +13,7 @@ typedef __attribute__((ext_vector_type(4))) uint32_t hu32x4;
 
 template <int ACT>
 __device__ __forceinline__ float h_act(float v) {
-    if (ACT == ACT_SILU) return v * __frcp_rn(1.0f + __expf(-v));
+    if (ACT == ACT_SILU) return v * fast_rcp(1.0f + __expf(-v));
     if (ACT == ACT_RELU) return fmaxf(v, 0.0f);
     if (ACT == ACT_LEAKY) return fmaxf(v, 0.1f * v);
     return v;
@@ -24,18 +24,18 @@ __device__ __forceinline__ float h_act(float v) {
 // select the compiler cannot contract through) rounds identically.
 template <int ACT>
 __device__ __forceinline__ float h_act_res(float v, float r) {
-    if (ACT == ACT_SILU) return __builtin_fmaf(v, __frcp_rn(1.0f + __expf(-v)), r);
+    if (ACT == ACT_SILU) return __builtin_fmaf(v, fast_rcp(1.0f + __expf(-v)), r);
     return h_act<ACT>(v) + r;
 }
 __device__ __forceinline__ float h_act_res_rt(int act, float v, float r) {
-    if (act == ACT_SILU) return __builtin_fmaf(v, __frcp_rn(1.0f + __expf(-v)), r);
+    if (act == ACT_SILU) return __builtin_fmaf(v, fast_rcp(1.0f + __expf(-v)), r);
     if (act == ACT_RELU) return fmaxf(v, 0.0f) + r;
     if (act == ACT_LEAKY) return fmaxf(v, 0.1f * v) + r;
     return v + r;
 }
 // run-time activation (halo_tile<..., ACT = -1, ...>): the same expressions as h_act<ACT>
 __device__ __forceinline__ float h_act_rt(int act, float v) {
-    if (act == ACT_SILU) return v * __frcp_rn(1.0f + __expf(-v));
+    if (act == ACT_SILU) return v * fast_rcp(1.0f + __expf(-v));
     if (act == ACT_RELU) return fmaxf(v, 0.0f);
     if (act == ACT_LEAKY) return fmaxf(v, 0.1f * v);
     return v;

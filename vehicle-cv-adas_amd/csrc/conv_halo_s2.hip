@@ -28,7 +28,7 @@ typedef __attribute__((ext_vector_type(4))) uint32_t su32x4_;
 
 template <int ACT>
 __device__ __forceinline__ float s2_act(float v) {
-    if (ACT == ACT_SILU) return v * __frcp_rn(1.0f + __expf(-v));
+    if (ACT == ACT_SILU) return v * fast_rcp(1.0f + __expf(-v));
     if (ACT == ACT_RELU) return fmaxf(v, 0.0f);
     if (ACT == ACT_LEAKY) return fmaxf(v, 0.1f * v);
     return v;

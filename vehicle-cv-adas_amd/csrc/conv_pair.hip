@@ -41,7 +41,7 @@ constexpr int PAIR_G1 = (PAIR_NI + 15) / 16;      // 21 sixteen-pixel groups of 
 constexpr int PAIR_NW = PAIR_WW * PAIR_WW;        // 400 window pixels
 constexpr uint32_t PAIR_OOB = 0x80000000u;
 
-__device__ __forceinline__ float pair_silu(float v) { return v * __frcp_rn(1.0f + __expf(-v)); }
+__device__ __forceinline__ float pair_silu(float v) { return v * fast_rcp(1.0f + __expf(-v)); }
 
 // 16-byte position of channel chunk c of pixel p: 64-byte pixels (32 channels) use conv_halo's conflict-free XOR swizzle
 template <int C>

@@ -94,7 +94,7 @@ __global__ __launch_bounds__(512) void conv_pw_kernel(PwDev a) {
             // tile nt + 1, after which a lane owns 8 consecutive channels of its pixel (conv_halo.hip's epilogue): half the store
             // instructions, 64-byte instead of 32-byte runs per pixel
             auto actf = [&](float v) {
-                if (a.act == ACT_SILU) return v * __frcp_rn(1.0f + __expf(-v));
+                if (a.act == ACT_SILU) return v * fast_rcp(1.0f + __expf(-v));
                 if (a.act == ACT_RELU) return fmaxf(v, 0.f);
                 if (a.act == ACT_LEAKY) return fmaxf(v, 0.1f * v);
                 return v;
@@ -135,7 +135,7 @@ __global__ __launch_bounds__(512) void conv_pw_kernel(PwDev a) {
             float v[4] = {acc[0] + b4.x, acc[1] + b4.y, acc[2] + b4.z, acc[3] + b4.w};
             if (a.act == ACT_SILU) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = v[r] * __frcp_rn(1.0f + __expf(-v[r]));
+                for (int r = 0; r < 4; ++r) v[r] = v[r] * fast_rcp(1.0f + __expf(-v[r]));
             } else if (a.act == ACT_RELU) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);

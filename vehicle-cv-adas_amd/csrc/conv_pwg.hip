@@ -154,7 +154,7 @@ __global__ __launch_bounds__(256, 2) void conv_pwg_kernel(PwgDev a) {
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
                 float x = a.res_mode == RES_BEFORE_ACT ? v[t] + rv[t] : v[t];
-                if (a.act == ACT_SILU) x = x * __frcp_rn(1.0f + __expf(-x));
+                if (a.act == ACT_SILU) x = x * fast_rcp(1.0f + __expf(-x));
                 else if (a.act == ACT_RELU) x = fmaxf(x, 0.f);
                 else if (a.act == ACT_LEAKY) x = fmaxf(x, 0.1f * x);
                 v[t] = a.res_mode == RES_AFTER_ACT ? x + rv[t] : x;

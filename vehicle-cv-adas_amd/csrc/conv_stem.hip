@@ -25,7 +25,7 @@ typedef __attribute__((ext_vector_type(2))) uint32_t su32x2;
 
 template <int ACT>
 __device__ __forceinline__ float s_act(float v) {
-    if (ACT == ACT_SILU) return v * __frcp_rn(1.0f + __expf(-v));
+    if (ACT == ACT_SILU) return v * fast_rcp(1.0f + __expf(-v));
     if (ACT == ACT_RELU) return fmaxf(v, 0.0f);
     if (ACT == ACT_LEAKY) return fmaxf(v, 0.1f * v);
     return v;

@@ -86,7 +86,7 @@ __global__ __launch_bounds__(256) void dwconv_kernel(DwDev d) {
         }
         if (d.act == ACT_SILU) {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) acc[e] = acc[e] / (1.0f + expf(-acc[e]));
+            for (int e = 0; e < 8; ++e) acc[e] = silu_for<T>(acc[e]);
         } else if (d.act == ACT_RELU) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) acc[e] = fmaxf(acc[e], 0.0f);
@@ -165,7 +165,7 @@ __global__ __launch_bounds__(256) void dwconv_strip_kernel(DwDev d) {
             if (ox >= d.Wo) break;
             if (d.act == ACT_SILU) {
 #pragma unroll
-                for (int e = 0; e < 8; ++e) acc[t][e] = acc[t][e] / (1.0f + expf(-acc[t][e]));
+                for (int e = 0; e < 8; ++e) acc[t][e] = silu_for<T>(acc[t][e]);
             } else if (d.act == ACT_RELU) {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) acc[t][e] = fmaxf(acc[t][e], 0.0f);

@@ -80,6 +80,23 @@ struct Fp16 {
     static inline uint16_t host_from_f32(float f) { return __builtin_bit_cast(uint16_t, (_Float16)f); }
 };
 
+#if defined(__HIPCC__)
+// Reciprocal of the 16-bit modes' activations (SiLU = v * rcp(1 + exp(-v)), sigmoid): the hardware reciprocal, v_rcp_f32 (1 ulp of fp32 --
+// three orders of magnitude below the half / bf16 rounding of the stored result).  Until round 5 these epilogues called `__frcp_rn`, the
+// CORRECTLY ROUNDED reciprocal, which hipcc expands into the IEEE division sequence (2 x v_div_scale, v_rcp, five fma / mul, v_div_fmas,
+// v_div_fixup: 11 VALU instructions where one does) -- in every SiLU of every 16-bit conv kernel: the 59-98 VALU instructions per MFMA of
+// the pointwise kernels (profiles/r04/pmc_halo_40x40.txt) and a third of conv_halo's tile time were mostly this.  The parity modes (fp32,
+// fp16x3) keep the exact forms (conv_x3.hip x3_act).
+__device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+// SiLU for kernels templated on a storage type: the fast form where the result is stored in 16 bits, the exact form (expf, IEEE division) in
+// the parity modes (float, x3s slots)
+template <typename T>
+__device__ __forceinline__ float silu_for(float v) {
+    if constexpr (sizeof(T) == 2) return v * fast_rcp(1.0f + __expf(-v));
+    else return v / (1.0f + expf(-v));
+}
+#endif
+
 // ---- split precision (ADAS_PREC_FP16X3, kernels.h PREC_X3) ------------------------------------------------------------------
 // A value x (f32) is carried as two halves: hi = half(x) and lo = half((x - hi) * 2^11), i.e. x = hi + lo * 2^-11 to 22 significant
 // bits (x - hi is exact in f32; the scale keeps lo a NORMAL half whatever the magnitude of x).  A product of two such values is

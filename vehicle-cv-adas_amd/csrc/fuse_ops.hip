@@ -287,7 +287,7 @@ __global__ __launch_bounds__(256) void wsum_kernel(WsDev d) {
         }
         if (d.act == ACT_SILU) {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) acc[e] = acc[e] / (1.0f + expf(-acc[e]));
+            for (int e = 0; e < 8; ++e) acc[e] = silu_for<T>(acc[e]);
         } else if (d.act == ACT_RELU) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) acc[e] = fmaxf(acc[e], 0.0f);
