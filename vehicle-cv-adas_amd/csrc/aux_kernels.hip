@@ -643,7 +643,7 @@ __global__ __launch_bounds__(256) void detect_v8_fused_kernel(DetFuseDev d) {
             float se = 0.f, sw = 0.f;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const float e = expf(v[r] - mx);
+                const float e = __expf(v[r] - mx);   // (16-bit modes only: this kernel does not exist in the parity modes)
                 se += e;
                 sw += e * (float)(kg * 4 + r);
             }
@@ -684,14 +684,14 @@ __global__ __launch_bounds__(256) void detect_v8_fused_kernel(DetFuseDev d) {
                 const int c = nt * 16 + kg * 4 + r;
                 if (SINK) {
                     if (c < d.nc) {
-                        const float v = 1.0f / (1.0f + expf(-(acc[r] + bias[64 + c])));
+                        const float v = fast_rcp(1.0f + __expf(-(acc[r] + bias[64 + c])));   // v_exp + v_rcp (elem16.h fast_rcp): 80 sigmoids per anchor, was expf + IEEE division
                         if (bi < 0 || v > bv) {   // classes ascend within a lane: strict > keeps the first maximum
                             bv = v;
                             bi = c;
                         }
                     }
                 } else if (ok && c < d.nc) {
-                    out[(size_t)(4 + c) * d.A + p] = 1.0f / (1.0f + expf(-(acc[r] + bias[64 + c])));
+                    out[(size_t)(4 + c) * d.A + p] = fast_rcp(1.0f + __expf(-(acc[r] + bias[64 + c])));   // the same expression as the SINK branch: identical values
                 }
             }
         }
