@@ -139,6 +139,7 @@ hipError_t launch_se_gate(const TView& in, const TView& gate, const float* w1, c
     if (d.S < 1) return hipErrorInvalidValue;
     if (d.S > d.HW) d.S = d.HW;
     const size_t lds = ((size_t)d.S * d.c + d.c + cr) * 4;
+    if (lds > 64 * 1024) return hipErrorInvalidValue;   // (32 KB of striped sums + C + Cr floats: beyond 64 KB only for C > ~7,000 channels; refused, not a failed launch)
     if (prec == PREC_FP32) hipLaunchKernelGGL(se_gate_kernel<float>, dim3(n), dim3(1024), lds, st, d);
     else if (prec == PREC_X3) hipLaunchKernelGGL(se_gate_kernel<x3s>, dim3(n), dim3(1024), lds, st, d);
     else if (prec == PREC_FP16) hipLaunchKernelGGL(se_gate_kernel<f16s>, dim3(n), dim3(1024), lds, st, d);

@@ -755,7 +755,11 @@ int adas_effdet_tail_create(const adas_effdet_tail_params* p, int max_batch, ada
     d.boxes = carve<float>(q, B * md * 4);
     d.ids = carve<int>(q, B * md);
     d.confs = carve<float>(q, B * md);
-    (void)hipFuncSetAttribute((const void*)effdet_tail_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (hipFuncSetAttribute((const void*)effdet_tail_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
+        (void)hipFree(h->arena);
+        delete h;
+        return hip_fail(hipGetLastError(), "hipFuncSetAttribute(effdet_tail_kernel)", __FILE__, __LINE__);   // fails here, not at the first launch
+    }
     *out = h;
     return ADAS_OK;
 }
