@@ -16,6 +16,7 @@ namespace adas {
 
 constexpr int ML_MAX_DEPS = 6;      // producer layers an item may wait for (after transitive reduction)
 constexpr int ML_MAX_LAYERS = 64;   // layers per launch (dependency closures are 64-bit masks)
+constexpr int ML_GROUP_MAX = 8;     // layers of one grouped launch (conv_halo_group_kernel's block table)
 
 // Is this conv (as engine_run_op would launch it at batch a.n, planned onto `kernel` = CONV_HALO | CONV_PW) a shape the multi-layer
 // kernel has a tile body for AND one launch_conv would send to conv_halo / conv_pw (not to conv_halo_rw / conv_s2p / conv_h8)?

@@ -315,7 +315,7 @@ __global__ __launch_bounds__(256, ADAS_ML_WAVES) void conv_ml_kernel(MlArgs g) {
 }
 
 // ------------------------------------------------------------------------------------- grouped launch of independent layers
-constexpr int GROUP_MAX = 8;
+constexpr int GROUP_MAX = ML_GROUP_MAX;
 struct GroupArgs {
     const MlLayerDev* layers;      // .kind + .u.h are read
     int n;
@@ -556,7 +556,15 @@ MlPlan* ml_plan_create(const std::vector<ConvArgs>& layers, const std::vector<in
         n_items += (size_t)hl[i].items_per_frame * F;
     }
     if (n_items >= (1u << 30)) return fail("item count");
-    const int grid = std::max(1, std::min(env_int("ADAS_ML_GRID", 512), (int)n_items));
+    // resident workgroups: two per CU (256 CUs on MI355X); host-only planning (no device) assumes that chip
+    int cus = 256;
+    if (!host_only) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
+        else (void)hipGetLastError();
+    }
+    const int grid = std::max(1, std::min(env_int("ADAS_ML_GRID", 2 * cus), (int)n_items));
     // ---- order.  0: layer-major (launch order of the layers, frames ascending).  1 (default): list schedule -- simulate `grid` workgroups
     // taking the ready (layer, frame) group with the longest remaining path first; a group is ready when its producers' groups of the same
     // frame have FINISHED in the simulation, so every item's producers hold smaller tickets by construction (checked below anyway).

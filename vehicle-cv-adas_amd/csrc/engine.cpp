@@ -1167,8 +1167,8 @@ static void prepare_groups(adas_engine* e, int batch) {
             std::vector<int> idx;
             for (size_t k = 0; k < layers.size(); ++k)
                 if (level[k] == lv) idx.push_back((int)k);
-            for (size_t c0 = 0; c0 < idx.size() && ok; c0 += 8) {   // at most 8 layers per launch
-                const size_t c1 = c0 + 8 < idx.size() ? c0 + 8 : idx.size();
+            for (size_t c0 = 0; c0 < idx.size() && ok; c0 += ML_GROUP_MAX) {   // at most ML_GROUP_MAX layers per launch
+                const size_t c1 = c0 + ML_GROUP_MAX < idx.size() ? c0 + ML_GROUP_MAX : idx.size();
                 GroupStep st;
                 if (c1 - c0 >= 2) {
                     std::vector<ConvArgs> sub;
