@@ -74,7 +74,7 @@ def test_multi_layer_launch_is_bit_identical_to_per_layer_launches(CE, name, pre
     a.close(); b.close()
 
 
-@pytest.mark.parametrize("name,prec,batch", [("yolov8n", "fp16", 64), ("yolov8n", "bf16", 5), ("yolov8n", "fp16", 1), ("yolov8s", "fp16", 8)])
+@pytest.mark.parametrize("name,prec,batch", [("yolov8n", "fp16", 64), ("yolov8n", "bf16", 5), ("yolov8n", "fp16", 1), ("yolov8s", "fp16", 8), ("yolov8l", "fp16", 1)])
 def test_grouped_launch_of_independent_layers_is_bit_identical(CE, name, prec, batch):
     """The default path: 3x3 halo convs of one dependency level of a run (the Detect branches of every pyramid level) share a launch
     (conv_halo_group_kernel).  Against ADAS_NO_GROUP=1 -- every layer its own conv_halo launch: heads and member activations bit for bit,
@@ -91,6 +91,8 @@ def test_grouped_launch_of_independent_layers_is_bit_identical(CE, name, prec, b
     assert all(kb[i].startswith("conv_halo_kernel") for i in members)
     if name == "yolov8n" and batch == 64:
         assert len(members) == 10 and a.launch_count(batch) == b.launch_count(batch) - 8      # Detect: ten launches become two
+    if batch == 1:      # one frame at a time: all twelve Detect convs (narrow channel blocks, no conv_halo_rw at this size) in two launches
+        assert len(members) >= 12 and a.launch_count(batch) <= b.launch_count(batch) - 10, (len(members), a.launch_count(batch), b.launch_count(batch))
     for rep in range(2):
         x = _frames(batch, 300 + rep)
         ya, yb = a.engine_inference(x), b.engine_inference(x)

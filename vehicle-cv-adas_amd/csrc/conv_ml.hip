@@ -29,7 +29,8 @@
 
 namespace adas {
 
-enum { MLK_H64_S1_256 = 0, MLK_H64_S1_128, MLK_H48_S1_256, MLK_H48_S1_128, MLK_H64_S2, MLK_PW, MLK_NONE = -1 };
+enum { MLK_H64_S1_256 = 0, MLK_H64_S1_128, MLK_H48_S1_256, MLK_H48_S1_128, MLK_H64_S2, MLK_PW,
+       MLK_H32_S1_128, MLK_H16_S1_128 /* grouped launch only: the narrow channel blocks of batch-1 engines (plan_halo_bn) */, MLK_NONE = -1 };
 
 struct MlPwDev {
     const uint16_t* in;
@@ -346,6 +347,8 @@ __global__ __launch_bounds__(256, 2) void conv_halo_group_kernel(GroupArgs g) {
         case MLK_H64_S1_128: halo_tile<E, 64, -1, 1, 128, false>(a, tile, cb, lds, threadIdx.x); break;
         case MLK_H48_S1_256: halo_tile<E, 48, -1, 1, 256, false>(a, tile, cb, lds, threadIdx.x); break;
         case MLK_H48_S1_128: halo_tile<E, 48, -1, 1, 128, false>(a, tile, cb, lds, threadIdx.x); break;
+        case MLK_H32_S1_128: halo_tile<E, 32, -1, 1, 128, false>(a, tile, cb, lds, threadIdx.x); break;
+        case MLK_H16_S1_128: halo_tile<E, 16, -1, 1, 128, false>(a, tile, cb, lds, threadIdx.x); break;
         default: halo_tile<E, 64, -1, 2, 128, false>(a, tile, cb, lds, threadIdx.x); break;
     }
 }
@@ -390,6 +393,14 @@ static int ml_halo_kind(int bn, int stride, int bm) {
     if (stride == 1 && bn == 48 && bm == 128) return MLK_H48_S1_128;
     if (stride == 2 && bn == 64 && bm == 128) return MLK_H64_S2;
     return MLK_NONE;
+}
+
+// the grouped launch also carries the narrow blocks a batch-1 engine packs for (one frame at a time: every Detect conv is a 8-15 us
+// latency chain of its own; twelve of them in two launches)
+static int group_halo_kind(int bn, int stride, int bm) {
+    if (stride == 1 && bn == 32 && bm == 128) return MLK_H32_S1_128;
+    if (stride == 1 && bn == 16 && bm == 128) return MLK_H16_S1_128;
+    return ml_halo_kind(bn, stride, bm);
 }
 
 static bool bytes_fit_31(const TView& v, int n) { return (double)n * v.h * v.w * v.cs * 2.0 < 2147483648.0; }
@@ -738,7 +749,7 @@ bool group_layer_supported(const ConvArgs& a, int kernel) {
     int bn, bm;
     size_t lds;
     if (!halo_fill_dev(a, &d, &bn, &bm, &lds)) return false;
-    return ml_halo_kind(bn, a.stride, bm) != MLK_NONE && lds <= 80 * 1024;
+    return group_halo_kind(bn, a.stride, bm) != MLK_NONE && lds <= 80 * 1024;
 }
 
 std::vector<int> ml_levels(const std::vector<ConvArgs>& layers) {
@@ -798,7 +809,7 @@ MlGroup* ml_group_create(const std::vector<ConvArgs>& layers, int prec, std::str
             delete g;
             return fail("layer not supported");
         }
-        devs[i].kind = ml_halo_kind(bn, a.stride, bm);
+        devs[i].kind = group_halo_kind(bn, a.stride, bm);
         const HaloDev& d = devs[i].u.h;
         g->args.first_block[i] = blocks;
         blocks += 8 * d.tiles8 * d.cbg * ((d.ncb + d.cbg - 1) / d.cbg);   // conv_halo's grid for this layer: a multiple of 8
