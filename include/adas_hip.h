@@ -231,6 +231,11 @@ typedef struct {
 int adas_yolo_post_fetch(adas_yolo_post* h, int frame, adas_yolo_counts* counts, int32_t* cand_anchor,
                          double* cand_xywh, double* cand_conf, int32_t* cand_cls, int32_t* keep, double* det_xywh,
                          double* det_conf, int32_t* det_cls, int32_t* det_xyxy_int);
+/* The survivors only (what yoloDetector.py:141-157 turns into RectInfo), as ONE device-to-host message: a pack kernel behind the NMS
+ * writes [counts][n_keep x 64-byte record] and one copy brings it over (a second one past 62 survivors).  Same values, same error
+ * behaviour as adas_yolo_post_fetch's keep / det_* arrays; arrays hold max_candidates entries, any pointer may be NULL. */
+int adas_yolo_post_fetch_dets(adas_yolo_post* h, int frame, adas_yolo_counts* counts, int32_t* keep, double* det_xywh,
+                              double* det_conf, int32_t* det_cls, int32_t* det_xyxy_int);
 /* Device views of the survivors for GPU-resident consumers (the tracker): per-frame strides are
  * max_candidates entries.  xyxy as fp64 of the int-truncated corners, scores fp64, classes, counts[4]. */
 int adas_yolo_post_device_views(adas_yolo_post* h, const double** d_xyxy, const double** d_score,

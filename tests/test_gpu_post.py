@@ -121,6 +121,40 @@ def test_yolo_post_unbounded_candidates_spill_to_hbm(G, n_hot, cap):
         pc.check_yolo(got, want)
 
 
+def test_yolo_post_packed_survivor_message_equals_the_per_array_fetch(G):
+    """adas_yolo_post_fetch_dets (one pack kernel + one copy, what YoloDetector.DetectFrame uses) returns exactly the keep / RectInfo
+    arrays of adas_yolo_post_fetch: few survivors (one copy), > 62 survivors (the second copy), a frame other than 0, an empty frame
+    and an overflowing arena (same error code)."""
+    lbp = yolo_post.letterbox_params((720, 1280), (640, 640))
+    heads = np.stack([synth.synth_v8_head(31, 40, 12), synth.synth_v8_head(32, 900, 300), np.zeros((84, 8400), np.float32), synth.synth_v8_head(33, 300, 150)])
+    yp = G.PP.YoloPost(0, 8400, 80, 0.3, 0.45, lbp, 0, 1024, max_batch=4)
+    buf = G.L.DeviceBuffer.from_array(heads)
+    try:
+        yp.run_device(buf.ptr, 4)
+        ks = []
+        for b in (1, 0, 3, 2, 1):
+            full, dets = yp.fetch(b), yp.fetch_dets(b)
+            assert dets["rc"] == 0 and full["rc"] == 0 and not dets["overflow"]
+            assert dets["n_found"] == full["n_found"] and dets["n_candidates"] == len(full["cand_conf"])
+            for key in ("keep", "xywh", "conf", "class_id", "xyxy_int"):
+                assert dets[key].dtype == full[key].dtype and np.array_equal(dets[key], full[key]), (b, key)
+            ks.append(len(dets["keep"]))
+        print("survivors per frame", ks)
+        assert ks[0] > 62 and 0 < ks[1] <= 62 and ks[3] == 0
+    finally:
+        buf.free(); yp.close()
+    small = G.PP.YoloPost(0, 8400, 80, 0.3, 0.45, lbp, 0, 128, max_batch=1)
+    buf = G.L.DeviceBuffer.from_array(heads[1:2])
+    try:
+        small.run_device(buf.ptr, 1)
+        full, dets = small.fetch(0), small.fetch_dets(0)
+        assert dets["overflow"] and dets["rc"] == full["rc"] == -5 and dets["n_found"] == full["n_found"] > 128
+        for key in ("keep", "xywh", "conf", "class_id", "xyxy_int"):
+            assert np.array_equal(dets[key], full[key]), key
+    finally:
+        buf.free(); small.close()
+
+
 def test_nms_kats(G):
     lbp = yolo_post.letterbox_params((640, 640), (640, 640))
     kats = [([(0, 0, 10, 10), (100, 100, 10, 10), (200, 200, 10, 10)], [.5, .9, .7], [1, 2]),

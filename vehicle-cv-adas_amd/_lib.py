@@ -150,6 +150,7 @@ _SIGS = {
     "adas_yolo_post_run": (C.c_int, [_P, _P, C.c_int, _P]),
     "adas_yolo_post_profile": (C.c_int, [_P, _P, C.c_int, C.c_int, C.POINTER(C.c_float)]),
     "adas_yolo_post_fetch": (C.c_int, [_P, C.c_int, C.POINTER(YoloCounts)] + [_P] * 9),
+    "adas_yolo_post_fetch_dets": (C.c_int, [_P, C.c_int, C.POINTER(YoloCounts)] + [_P] * 5),
     "adas_yolo_post_device_views": (C.c_int, [_P] + [C.POINTER(_P)] * 4),
     "adas_yolo_post_scan_views": (C.c_int, [_P, C.POINTER(_P), C.POINTER(_P)]),
     "adas_yolo_post_run_prescanned": (C.c_int, [_P, _P, C.c_int, _P]),

@@ -313,11 +313,34 @@ __global__ __launch_bounds__(256) void bytetrack_reset_kernel(BtDev d) {
 // =====================================================================================
 // C ABI
 // =====================================================================================
+// The survivors of ONE frame as one message: [n_found, n_candidates, n_keep, flags] then n_keep records of 64 bytes
+// {double xywh[4]; double conf; int cls; int keep; int xyxy[4]} -- what YoloDetector.DetectFrame reads after every frame, in one
+// device-to-host copy instead of one per array (adas_yolo_post_fetch: up to ten).
+constexpr size_t YOLO_MSG_HDR = 16, YOLO_MSG_REC = 64, YOLO_MSG_FIRST = 62;   // 16 + 62 * 64 = 3984 B: the first copy; more survivors -> a second one
+__global__ __launch_bounds__(256) void yolo_pack_kernel(YoloPostDev d, int frame, unsigned char* msg) {
+    const size_t cap = d.cfg.cap, b = frame;
+    const int* cnt = d.counts + b * 4;
+    if (threadIdx.x < 4) ((int*)msg)[threadIdx.x] = cnt[threadIdx.x];
+    const int k = cnt[2];
+    for (int i = threadIdx.x; i < k; i += blockDim.x) {
+        unsigned char* r = msg + YOLO_MSG_HDR + (size_t)i * YOLO_MSG_REC;
+        double* f = (double*)r;
+        int* w = (int*)(r + 40);
+        for (int j = 0; j < 4; ++j) f[j] = d.det_xywh[(b * cap + i) * 4 + j];
+        f[4] = d.det_conf[b * cap + i];
+        w[0] = d.det_cls[b * cap + i];
+        w[1] = d.keep[b * cap + i];
+        for (int j = 0; j < 4; ++j) w[2 + j] = d.det_xyxy_i[(b * cap + i) * 4 + j];
+    }
+}
+
 struct adas_yolo_post {
     adas_yolo_post_params p;
     int max_batch;
     YoloPostDev dev;
     void* arena;
+    unsigned char* msg;      // the packed survivor message of adas_yolo_post_fetch_dets (device) ...
+    unsigned char* h_msg;    // ... and its host landing buffer
     hipStream_t last;
 };
 struct adas_ufld_decode {
@@ -457,8 +480,11 @@ int adas_yolo_post_create(const adas_yolo_post_params* p, int max_batch, adas_yo
     const size_t B = max_batch, A = p->num_anchors, cap = p->max_candidates;
     const bool spill = p->max_candidates > 2048;                       // past the LDS arena: per-frame HBM workspace
     const size_t spill_stride = spill ? ((YoloLds::bytes(p->max_candidates, 256) + 255) & ~(size_t)255) : 0;
-    size_t bytes = B * (A * 8 + 16 + cap * (4 + 32 + 8 + 4 + 4 + 32 + 8 + 4 + 16 + 32)) + 16 * 256 + B * spill_stride + 256;
-    if (hipMalloc(&h->arena, bytes) != hipSuccess) {
+    size_t bytes = B * (A * 8 + 16 + cap * (4 + 32 + 8 + 4 + 4 + 32 + 8 + 4 + 16 + 32)) + 17 * 256 + B * spill_stride + 256 +
+                   YOLO_MSG_HDR + cap * YOLO_MSG_REC;
+    h->h_msg = nullptr;
+    if (hipHostMalloc((void**)&h->h_msg, YOLO_MSG_HDR + cap * YOLO_MSG_REC, hipHostMallocDefault) != hipSuccess || hipMalloc(&h->arena, bytes) != hipSuccess) {
+        if (h->h_msg) hipHostFree(h->h_msg);
         delete h;
         return hip_fail(hipGetLastError(), "hipMalloc(yolo_post arena)", __FILE__, __LINE__);
     }
@@ -484,9 +510,11 @@ int adas_yolo_post_create(const adas_yolo_post_params* p, int max_batch, adas_yo
     d.det_xyxy_d = carve<double>(q, B * cap * 4);
     d.spill = spill ? carve<unsigned char>(q, B * spill_stride) : nullptr;
     d.spill_stride = spill_stride;
+    h->msg = carve<unsigned char>(q, YOLO_MSG_HDR + cap * YOLO_MSG_REC);
     size_t lds = spill ? 0 : YoloLds::bytes(p->max_candidates, 256);
     if (!spill && hipFuncSetAttribute((const void*)yolo_post_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
         hipFree(h->arena);
+        hipHostFree(h->h_msg);
         delete h;
         return hip_fail(hipGetLastError(), "hipFuncSetAttribute(yolo_post_kernel)", __FILE__, __LINE__);
     }
@@ -497,6 +525,7 @@ int adas_yolo_post_create(const adas_yolo_post_params* p, int max_batch, adas_yo
 int adas_yolo_post_destroy(adas_yolo_post* h) {
     if (!h) return ADAS_OK;
     hipFree(h->arena);
+    hipHostFree(h->h_msg);
     delete h;
     return ADAS_OK;
 }
@@ -633,6 +662,45 @@ int adas_yolo_post_fetch(adas_yolo_post* h, int frame, adas_yolo_counts* counts,
     CP(det_cls, d.det_cls + b * cap, k, int);
     CP(det_xyxy_int, d.det_xyxy_i + b * cap * 4, k * 4, int);
 #undef CP
+    if (c4[3] & 1) {
+        set_error("yolo_post: %d anchors over threshold exceed max_candidates=%d (frame %d)", c4[0], (int)cap, frame);
+        return ADAS_ERR_CAPACITY;
+    }
+    return ADAS_OK;
+}
+
+int adas_yolo_post_fetch_dets(adas_yolo_post* h, int frame, adas_yolo_counts* counts, int32_t* keep, double* det_xywh, double* det_conf,
+                              int32_t* det_cls, int32_t* det_xyxy_int) {
+    ADAS_REQUIRE(h && frame >= 0 && frame < h->max_batch, ADAS_ERR_INVALID, "adas_yolo_post_fetch_dets: bad frame index");
+    const size_t cap = h->p.max_candidates;
+    yolo_pack_kernel<<<1, 256, 0, h->last>>>(h->dev, frame, h->msg);      // behind the NMS on its stream
+    ADAS_HIP_TRY(hipGetLastError());
+    const size_t first = cap < YOLO_MSG_FIRST ? cap : YOLO_MSG_FIRST;
+    ADAS_HIP_TRY(hipMemcpyAsync(h->h_msg, h->msg, YOLO_MSG_HDR + first * YOLO_MSG_REC, hipMemcpyDeviceToHost, h->last));
+    ADAS_HIP_TRY(hipStreamSynchronize(h->last));
+    int c4[4];
+    memcpy(c4, h->h_msg, 16);
+    const size_t k = (size_t)c4[2];
+    ADAS_REQUIRE(k <= cap, ADAS_ERR_INVALID, "adas_yolo_post_fetch_dets: corrupt survivor count %d", c4[2]);
+    if (k > first)
+        ADAS_HIP_TRY(hipMemcpy(h->h_msg + YOLO_MSG_HDR + first * YOLO_MSG_REC, h->msg + YOLO_MSG_HDR + first * YOLO_MSG_REC, (k - first) * YOLO_MSG_REC,
+                               hipMemcpyDeviceToHost));
+    if (counts) {
+        counts->n_found = c4[0];
+        counts->n_candidates = c4[1];
+        counts->n_keep = c4[2];
+        counts->flags = c4[3];
+    }
+    for (size_t i = 0; i < k; ++i) {
+        const unsigned char* r = h->h_msg + YOLO_MSG_HDR + i * YOLO_MSG_REC;
+        int w[6];
+        memcpy(w, r + 40, 24);
+        if (det_xywh) memcpy(det_xywh + i * 4, r, 32);
+        if (det_conf) memcpy(det_conf + i, r + 32, 8);
+        if (det_cls) det_cls[i] = w[0];
+        if (keep) keep[i] = w[1];
+        if (det_xyxy_int) memcpy(det_xyxy_int + i * 4, w + 2, 16);
+    }
     if (c4[3] & 1) {
         set_error("yolo_post: %d anchors over threshold exceed max_candidates=%d (frame %d)", c4[0], (int)cap, frame);
         return ADAS_ERR_CAPACITY;

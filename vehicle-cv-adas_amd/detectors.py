@@ -178,6 +178,12 @@ class YoloDetector(_Defaults):
     def object_info(self):
         return self._object_info
 
+    @property
+    def _last(self):
+        """Everything the post-processor holds for the last frame (candidates too; the tests compare them with the oracle): fetched on
+        demand -- DetectFrame itself only brings the survivors over."""
+        return self._post.fetch(0)
+
     def _post_for(self, src_hw):
         key = (int(src_hw[0]), int(src_hw[1]))
         if self._post_key != key:
@@ -203,7 +209,7 @@ class YoloDetector(_Defaults):
         self.engine.infer_device(t.ptr, 1, None)
         post = self._post_for((h, w))
         post.run_device(self.engine.output_device_ptr(0), 1, None)
-        r = post.fetch(0)
+        r = post.fetch_dets(0)                 # one packed message: counts + survivors
         # The reference's candidate lists are unbounded (yoloDetector.py:120-133).  A frame with more anchors over box_score than the
         # arena holds is re-run with a larger arena (the head tensor is still in HBM): up to one slot per anchor, at which point nothing
         # can overflow -- arenas past MAX_LDS_CANDIDATES work out of an HBM workspace (slower, same results).
@@ -213,12 +219,12 @@ class YoloDetector(_Defaults):
             self._post_key = None
             post = self._post_for((h, w))
             post.run_device(self.engine.output_device_ptr(0), 1, None)
-            r = post.fetch(0)
+            r = post.fetch_dets(0)
         if r["overflow"]:
             raise RuntimeError("YoloDetector: %d anchors over box_score with a %d-candidate arena of %d anchors" % (r["n_found"], self.max_candidates, limit))
         elif r["rc"] != 0:
             L.check(r["rc"])
-        self._last = r
+        self._last_dets = r
         out = []
         for (x, y, bw, bh), conf, cid in zip(r["xywh"], r["conf"], r["class_id"]):     # get_nms_results (:141-157)
             label = self.class_names[cid] if 0 <= cid < len(self.class_names) else "unknown"

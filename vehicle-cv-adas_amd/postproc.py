@@ -70,6 +70,19 @@ class YoloPost:
         res["rc"] = rc
         return res
 
+    def fetch_dets(self, frame=0):
+        """The survivors only, as one packed device-to-host message (adas_yolo_post_fetch_dets): the keys of fetch() that
+        get_nms_results reads (yoloDetector.py:141-157), same values."""
+        cap = self.cap
+        cnt = L.YoloCounts()
+        o = dict(keep=np.zeros(cap, np.int32), xywh=np.zeros((cap, 4)), conf=np.zeros(cap), class_id=np.zeros(cap, np.int32),
+                 xyxy_int=np.zeros((cap, 4), np.int32))
+        rc = L.lib().adas_yolo_post_fetch_dets(self.h, frame, C.byref(cnt), *[L.ptr(o[k]) for k in ("keep", "xywh", "conf", "class_id", "xyxy_int")])
+        res = dict(n_found=cnt.n_found, n_candidates=cnt.n_candidates, overflow=bool(cnt.flags & 1), rc=rc)
+        for key, a in o.items():
+            res[key] = a[:cnt.n_keep]
+        return res
+
     def device_views(self):
         v = [C.c_void_p() for _ in range(4)]
         L.check(L.lib().adas_yolo_post_device_views(self.h, *[C.byref(x) for x in v]))
