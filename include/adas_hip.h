@@ -405,8 +405,10 @@ typedef struct {          /* base_track.py:61-72 + strack.py:207-215 (crops/loca
     double tlwh[4];       /* STrack.tlwh (Kalman-filtered) */
     double score;
     int32_t track_id, state, is_activated, class_id;
-    int32_t frame_id, start_frame, tracklet_len, pad;
+    int32_t frame_id, start_frame, tracklet_len;
+    int32_t trajectory_len;   /* len(STrack.trajectories), 0 .. 30 (strack.py:53,115); the boxes: adas_bytetrack_fetch_trajectories */
 } adas_track;
+#define ADAS_TRAJECTORY_LEN 30   /* LimitedList(30), strack.py:53 */
 
 typedef struct {
     int32_t frame_id, id_count, n_tracked, n_lost, err, pad[3];
@@ -439,6 +441,12 @@ int adas_bytetrack_fetch_frame(adas_bytetrack* h, int stream_index, int frame, a
 /* Synchronises; tracks[0..n_tracked) are tracked_stracks, then n_lost lost_stracks, list order kept. */
 int adas_bytetrack_fetch(adas_bytetrack* h, int stream_index, adas_track_header* hdr, adas_track* tracks,
                          int max_tracks);
+
+/* STrack.trajectories of the LIVE state (the last 30 detection boxes a track was updated with, strack.py:115 -- what DrawTrackedOnFrame
+ * draws and filter_trajectories / plot_directions read, byteTracker.py:202-215), for the tracks in the order of adas_bytetrack_fetch
+ * (tracked, then lost): lens[k] = len(trajectories) and tlbr[k][i][0..4) = trajectories[i] (x1, y1, x2, y2 fp64, oldest first) for
+ * i < lens[k].  lens holds max_tracks entries, tlbr max_tracks x ADAS_TRAJECTORY_LEN x 4; *n_tracks = n_tracked + n_lost.  Synchronises. */
+int adas_bytetrack_fetch_trajectories(adas_bytetrack* h, int stream_index, int32_t* lens, double* tlbr, int max_tracks, int32_t* n_tracks);
 
 /* ===================================================================================
  * Fused per-frame pipeline (the path demo.py:261-281 drives): detector forward + decode/NMS,

@@ -146,6 +146,10 @@ class STrack:
         self.score = new_track.score
         self.update_class_id(new_track.class_id)
 
+    def filter_trajectories(self, frame_hw, pad=(0, 0)):   # :145-149 (frame.shape[:2] instead of the frame)
+        padh, padw = pad
+        return [b for b in self.trajectories if b[0] >= 0 + padw and b[1] >= 0 + padh and b[2] <= frame_hw[1] - padw and b[3] <= frame_hw[0] - padh]
+
     def update_class_id(self, class_id):                   # :122-129
         self.class_id_history[class_id] = self.class_id_history.get(class_id, 1) + 1
         self.class_id = max(self.class_id_history, key=self.class_id_history.get)

@@ -9,7 +9,7 @@ OUT = os.path.join(ROOT, "tests", "_build", "libemu.so")
 INC = os.path.join(ROOT, "vehicle-cv-adas_amd", "csrc")
 
 BTOUT = np.dtype([("tlwh", "f8", 4), ("score", "f8"), ("track_id", "i4"), ("state", "i4"), ("is_activated", "i4"),
-                  ("class_id", "i4"), ("frame_id", "i4"), ("start_frame", "i4"), ("tracklet_len", "i4"), ("pad", "i4")])
+                  ("class_id", "i4"), ("frame_id", "i4"), ("start_frame", "i4"), ("tracklet_len", "i4"), ("traj_len", "i4")])
 
 
 def build():
@@ -34,6 +34,7 @@ def lib():
             getattr(_lib, f).argtypes = [C.c_void_p]
         _lib.emu_bt_update.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
         _lib.emu_bt_fetch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        _lib.emu_bt_trajectories.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         assert _lib.emu_sizeof_btout() == BTOUT.itemsize
     return _lib
 
@@ -138,6 +139,16 @@ class Tracker:
         hdr = np.zeros(5, np.int32); recs = np.zeros(2 * self.MT, BTOUT)
         lib().emu_bt_fetch(self.h, _p(hdr), _p(recs))
         return snapshot(hdr, recs), err
+
+    def trajectories(self):
+        """STrack.trajectories of the tracks in message order (tracked, then lost): list of (len, 4) arrays."""
+        hdr = np.zeros(5, np.int32); recs = np.zeros(2 * self.MT, BTOUT)
+        lib().emu_bt_fetch(self.h, _p(hdr), _p(recs))
+        n = int(hdr[2] + hdr[3])
+        lens = np.zeros(max(n, 1), np.int32); out = np.zeros((max(n, 1), 30, 4))
+        lib().emu_bt_trajectories(self.h, _p(lens), _p(out))
+        assert [int(v) for v in lens[:n]] == [int(r["traj_len"]) for r in recs[:n]]
+        return [out[k, :lens[k]].copy() for k in range(n)]
 
     def __del__(self):
         try:

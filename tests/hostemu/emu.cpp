@@ -108,7 +108,8 @@ struct EmuBt { BtParams P; BtStream S; std::vector<char> mem; std::vector<double
 void* emu_bt_create(double track_thresh, double match_thresh, int track_buffer, double frame_rate, int MT, int MD) {
     EmuBt* e = new EmuBt;
     e->P = BtParams{track_thresh, track_thresh + 0.1, match_thresh, (int)(frame_rate / 30.0 * track_buffer), MT, MD};
-    size_t sz = sizeof(BtHeader) + 2 * MT * sizeof(int) + MT * sizeof(BtTrack) + (size_t)MT * MD * 8 + 2 * MT * sizeof(BtOut) + 64;
+    size_t sz = sizeof(BtHeader) + 2 * MT * sizeof(int) + MT * sizeof(BtTrack) + (size_t)MT * MD * 8 + 2 * MT * sizeof(BtOut) + 64 +
+                (size_t)MT * ADAS_BT_TRAJ * 32;
     e->mem.assign(sz, 0);
     char* p = e->mem.data();
     e->S.hdr = (BtHeader*)p; p += sizeof(BtHeader);
@@ -116,7 +117,9 @@ void* emu_bt_create(double track_thresh, double match_thresh, int track_buffer, 
     e->S.cost = (double*)p; p += (size_t)MT * MD * 8;
     e->S.out = (BtOut*)p; p += 2 * MT * sizeof(BtOut);
     e->S.tracked = (int*)p; p += MT * sizeof(int);
-    e->S.lost = (int*)p;
+    e->S.lost = (int*)p; p += MT * sizeof(int);
+    p += (8 - ((size_t)p & 7)) & 7;
+    e->S.traj = (double*)p;
     e->lds.assign(BtLds::bytes(MT, MD, 1) / 8 + 2, 0.0);
     return e;
 }
@@ -135,6 +138,12 @@ void emu_bt_fetch(void* h, int* hdr, void* recs) {
     hdr[0] = e->S.hdr->frame_id; hdr[1] = e->S.hdr->id_count; hdr[2] = e->S.hdr->n_tracked;
     hdr[3] = e->S.hdr->n_lost; hdr[4] = e->S.hdr->err;
     memcpy(recs, e->S.out, (size_t)(hdr[2] + hdr[3]) * sizeof(BtOut));
+}
+// lens[n_tracked + n_lost], out[..][30][4]: STrack.trajectories in message order
+void emu_bt_trajectories(void* h, int* lens, double* out) {
+    EmuBt* e = (EmuBt*)h;
+    Ctx c{0, 1};
+    bytetrack_gather_trajectories(c, e->S, lens, out);
 }
 int emu_sizeof_btout() { return (int)sizeof(BtOut); }
 }

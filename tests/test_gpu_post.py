@@ -1,6 +1,6 @@
 """GPU parity: HIP post-processing (through the C ABI) vs the oracle and the reference goldens.
 Bit-exact for candidate rows, NMS survivor indices, RectInfo ints, lane points, track ids/states."""
-import gzip, json, os
+import gzip, importlib, json, os
 import numpy as np
 import pytest
 
@@ -246,6 +246,48 @@ def test_bytetrack_goldens(G, tag):
                     t["class_id"] = lab[t["class_id"]]
         pc.check_track_frame(got, want, ctx=(tag, want["frame_id"]))
     trk.close()
+
+
+@pytest.mark.parametrize("tag", ["t1", "t2", "t3", "t5", "t6", "t7"])
+def test_bytetrack_trajectories(G, tag):
+    """STrack.trajectories on the device (adas_bytetrack_fetch_trajectories: a 30-deep ring per track slot, appended by update() only)
+    vs the REFERENCE tracker's lists at the checkpoints of tests/golden/make_golden_traj.py -- ids, lengths and every box exact (fp64) --
+    on stream 1 of a two-stream tracker whose stream 0 sees another scene (slots and rings are per stream); trajectory_len in the
+    track message; the BYTETracker front-end's trajectories() / filter_trajectories() (strack.py:145-149) on the same scene."""
+    with gzip.open(os.path.join(GOLDEN, "bytetrack.json.gz"), "rt") as f:
+        allsc = json.load(f)
+    sc, other = allsc[tag], allsc["t4"]
+    with gzip.open(os.path.join(GOLDEN, "bytetrack_traj.json.gz"), "rt") as f:
+        want = json.load(f)[tag]
+    trk = G.PP.DeviceTracker(2)
+    det = importlib.import_module("adas_amd.detectors")
+    front = det.BYTETracker()
+    frame = np.zeros((720, 1280, 3), np.uint8)
+    seen = 0
+    for k, fr in enumerate(sc["frames"]):
+        o = other["frames"][k % len(other["frames"])]
+        trk.update_host(0, o["boxes"], o["scores"], o["ids"])
+        trk.update_host(1, fr["boxes"], fr["scores"], fr["ids"])
+        front.update(fr["boxes"], fr["scores"], fr["ids"])
+        if str(k) not in want:
+            continue
+        seen += 1
+        hdr, tracked, lost = trk.fetch(1)
+        recs = list(tracked) + list(lost)
+        assert [int(r["track_id"]) for r in recs] == [r["track_id"] for r in want[str(k)]]
+        traj = trk.fetch_trajectories(1)
+        ftraj = front.trajectories()
+        assert len(traj) == len(recs) and list(ftraj) == [r["track_id"] for r in want[str(k)]]
+        for r, t, w in zip(recs, traj, want[str(k)]):
+            assert int(r["traj_len"]) == len(t) == len(w["trajectory"]) and (len(t) == 30) == w["full"]
+            assert t.tolist() == w["trajectory"], (tag, k, w["track_id"])
+            assert [b.tolist() for b in ftraj[w["track_id"]]] == w["trajectory"]
+            kept = front.filter_trajectories(w["track_id"], frame, (10, 10))
+            assert [b.tolist() for b in kept] == [w["trajectory"][i] for i in w["filtered"]]
+    assert seen == len(want)
+    trk.reset(1)
+    assert trk.fetch_trajectories(1) == [] and len(trk.fetch_trajectories(0)) > 0        # reset clears one stream only
+    trk.close(); front.close()
 
 
 def test_bytetrack_multi_stream_reset(G):

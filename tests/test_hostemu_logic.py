@@ -138,6 +138,33 @@ def test_bytetrack(tag):
         pc.check_track_frame(got, want, ctx=(tag, want["frame_id"]))
 
 
+@pytest.mark.parametrize("tag", ["t1", "t2", "t3", "t4", "t5", "t6", "t7"])
+def test_bytetrack_trajectories(tag):
+    """The device tracker's trajectory rings (track_core.h bt_apply_match / bytetrack_gather_trajectories, compiled for the host) vs
+    STrack.trajectories of the REFERENCE tracker (tests/golden/make_golden_traj.py) at its checkpoints: ids, lengths, every box exact."""
+    with gzip.open(os.path.join(GOLDEN, "bytetrack.json.gz"), "rt") as f:
+        sc = json.load(f)[tag]
+    with gzip.open(os.path.join(GOLDEN, "bytetrack_traj.json.gz"), "rt") as f:
+        want = json.load(f)[tag]
+    trk = emu_api.Tracker()
+    seen = 0
+    for k, fr in enumerate(sc["frames"]):
+        got, err = trk.update(fr["boxes"], fr["scores"], fr["ids"])
+        assert err == 0
+        if str(k) not in want:
+            continue
+        seen += 1
+        ids = [t["track_id"] for t in got["tracked"] + got["lost"]]
+        assert ids == [r["track_id"] for r in want[str(k)]]
+        for tr, r in zip(trk.trajectories(), want[str(k)]):
+            assert tr.shape == (len(r["trajectory"]), 4) and (len(tr) == 30) == r["full"]
+            assert tr.tolist() == r["trajectory"], (tag, k, r["track_id"])
+    assert seen == len(want)
+    trk.reset()
+    got, err = trk.update(sc["frames"][-1]["boxes"], sc["frames"][-1]["scores"], sc["frames"][-1]["ids"])
+    assert all(len(t) == 0 for t in trk.trajectories())        # fresh tracks after a reset: empty lists (activate() appends nothing)
+
+
 def test_bytetrack_reset_and_random_vs_oracle():
     rng = np.random.default_rng(42)
     trk = emu_api.Tracker(); ora = bytetrack.BYTETracker()

@@ -150,6 +150,32 @@ def test_bytetrack_trace(tag):
         assert 3 in [t["track_id"] for t in tr[4]["tracked"]]
 
 
+@pytest.mark.parametrize("tag", ["t1", "t2", "t3", "t4", "t5", "t6", "t7"])
+def test_bytetrack_trajectories(tag):
+    """STrack.trajectories (strack.py:53,115: the last 30 matched detection boxes, appended by update() only) and filter_trajectories
+    (:145-149) of the restatement vs the reference's, at the checkpoints of tests/golden/make_golden_traj.py -- exact fp64."""
+    sc = _load_bt()[tag]
+    with gzip.open(os.path.join(GOLDEN, "bytetrack_traj.json.gz"), "rt") as f:
+        want = json.load(f)[tag]
+    lab = ["car", "person", "truck"]
+    trk = bytetrack.BYTETracker()
+    seen = 0
+    for k, fr in enumerate(sc["frames"]):
+        ids = [lab[i] for i in fr["ids"]] if sc["label_ids"] else fr["ids"]
+        trk.update(fr["boxes"], fr["scores"], ids)
+        if str(k) not in want:
+            continue
+        seen += 1
+        tracks = list(trk.tracked_stracks) + list(trk.lost_stracks)
+        assert [int(t.track_id) for t in tracks] == [r["track_id"] for r in want[str(k)]]
+        for t, r in zip(tracks, want[str(k)]):
+            assert len(t.trajectories) == len(r["trajectory"]) <= 30 and (len(t.trajectories) == 30) == r["full"]
+            assert [[float(v) for v in b] for b in t.trajectories] == r["trajectory"], (tag, k, r["track_id"])
+            kept = t.filter_trajectories((720, 1280), (10, 10))
+            assert [i for i, b in enumerate(t.trajectories) if any(b is q for q in kept)] == r["filtered"]
+    assert seen == len(want)
+
+
 @pytest.mark.parametrize("case", synth.ufld1_cases(), ids=lambda c: c[0])
 def test_ufld_v1_decode(case):
     """UFLD v1 decoder restatement vs the reference's own __process_output (ultrafastLaneDetector.py:96-139)."""

@@ -30,7 +30,7 @@ static inline size_t bt_align(size_t x) { return (x + 63) & ~(size_t)63; }
 __host__ __device__ inline size_t bt_align_d(size_t x) { return (x + 63) & ~(size_t)63; }
 static size_t bt_stream_bytes(int MT, int MD) {
     return bt_align(sizeof(BtHeader)) + bt_align((size_t)MT * sizeof(BtTrack)) + bt_align((size_t)MT * MD * 8) +
-           bt_align((size_t)2 * MT * sizeof(BtOut)) + 2 * bt_align((size_t)MT * 4);
+           bt_align((size_t)2 * MT * sizeof(BtOut)) + 2 * bt_align((size_t)MT * 4) + bt_align((size_t)MT * ADAS_BT_TRAJ * 32);
 }
 __host__ __device__ inline BtStream bt_view(unsigned char* p, int MT, int MD) {
     BtStream S;
@@ -39,7 +39,8 @@ __host__ __device__ inline BtStream bt_view(unsigned char* p, int MT, int MD) {
     S.cost = (double*)p; p += bt_align_d((size_t)MT * MD * 8);
     S.out = (BtOut*)p; p += bt_align_d((size_t)2 * MT * sizeof(BtOut));
     S.tracked = (int*)p; p += bt_align_d((size_t)MT * 4);
-    S.lost = (int*)p;
+    S.lost = (int*)p; p += bt_align_d((size_t)MT * 4);
+    S.traj = (double*)p;
     return S;
 }
 

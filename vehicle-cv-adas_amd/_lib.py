@@ -92,7 +92,8 @@ class MlLayerDesc(C.Structure):
 
 
 TRACK_DTYPE = np.dtype([("tlwh", "f8", 4), ("score", "f8"), ("track_id", "i4"), ("state", "i4"), ("is_activated", "i4"),
-                        ("class_id", "i4"), ("frame_id", "i4"), ("start_frame", "i4"), ("tracklet_len", "i4"), ("pad", "i4")])
+                        ("class_id", "i4"), ("frame_id", "i4"), ("start_frame", "i4"), ("tracklet_len", "i4"), ("traj_len", "i4")])
+TRAJECTORY_LEN = 30        # ADAS_TRAJECTORY_LEN
 
 _P = C.c_void_p
 _SIGS = {
@@ -192,6 +193,7 @@ _SIGS = {
     "adas_bytetrack_update_device": (C.c_int, [_P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
     "adas_bytetrack_update_device_frames": (C.c_int, [_P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
     "adas_bytetrack_fetch": (C.c_int, [_P, C.c_int, C.POINTER(TrackHeader), _P, C.c_int]),
+    "adas_bytetrack_fetch_trajectories": (C.c_int, [_P, C.c_int, _P, _P, C.c_int, C.POINTER(C.c_int32)]),
     "adas_bytetrack_reserve_frames": (C.c_int, [_P, C.c_int, C.c_int]),
     "adas_bytetrack_fetch_frame": (C.c_int, [_P, C.c_int, C.c_int, C.POINTER(TrackHeader), _P, C.c_int]),
     "adas_pipeline_create": (C.c_int, [C.POINTER(PipelineDesc), C.POINTER(_P)]),

@@ -262,7 +262,7 @@ __host__ __device__ inline size_t bt_align(size_t x) { return (x + 63) & ~(size_
 __host__ __device__ inline size_t bt_snap_bytes(int MT) { return bt_align(sizeof(BtHeader)) + bt_align((size_t)2 * MT * sizeof(BtOut)); }
 __host__ __device__ inline size_t bt_stream_bytes(int MT, int MD) {
     return bt_align(sizeof(BtHeader)) + bt_align((size_t)MT * sizeof(BtTrack)) + bt_align((size_t)MT * MD * 8) +
-           bt_align((size_t)2 * MT * sizeof(BtOut)) + 2 * bt_align((size_t)MT * 4);
+           bt_align((size_t)2 * MT * sizeof(BtOut)) + 2 * bt_align((size_t)MT * 4) + bt_align((size_t)MT * ADAS_BT_TRAJ * 32);
 }
 __host__ __device__ inline BtStream bt_view(unsigned char* p, int MT, int MD) {
     BtStream S;
@@ -271,7 +271,8 @@ __host__ __device__ inline BtStream bt_view(unsigned char* p, int MT, int MD) {
     S.cost = (double*)p; p += bt_align((size_t)MT * MD * 8);
     S.out = (BtOut*)p; p += bt_align((size_t)2 * MT * sizeof(BtOut));
     S.tracked = (int*)p; p += bt_align((size_t)MT * 4);
-    S.lost = (int*)p;
+    S.lost = (int*)p; p += bt_align((size_t)MT * 4);
+    S.traj = (double*)p;
     return S;
 }
 
@@ -301,6 +302,13 @@ __global__ __launch_bounds__(256) void bytetrack_update_kernel(BtDev d) {
             __syncthreads();
         }
     }
+}
+
+// one stream's trajectories in message order into the handle's gather buffer: [MT] lengths, then [MT][30][4] boxes
+__global__ __launch_bounds__(256) void bytetrack_traj_kernel(BtDev d, int stream, int* lens, double* out) {
+    BtStream S = bt_view(d.base + (size_t)stream * d.stream_bytes, d.P.MT, d.P.MD);
+    Ctx c{(int)threadIdx.x, (int)blockDim.x};
+    bytetrack_gather_trajectories(c, S, lens, out);
 }
 
 __global__ __launch_bounds__(256) void bytetrack_reset_kernel(BtDev d) {
@@ -1120,6 +1128,7 @@ int adas_bytetrack_create(const adas_bytetrack_params* p, int n_streams, adas_by
                    (int)(p->frame_rate / 30.0 * p->track_buffer), p->max_tracks, p->max_dets};  // byteTracker.py:48-50
     d.stream_bytes = bt_stream_bytes(p->max_tracks, p->max_dets);
     size_t stage = (size_t)p->max_dets * (32 + 8 + 4) + 256 * 4;
+    stage = bt_align(stage) + bt_align((size_t)p->max_tracks * 4) + (size_t)p->max_tracks * ADAS_BT_TRAJ * 32;   // + the trajectory gather buffer
     size_t bytes = d.stream_bytes * n_streams + stage;
     if (hipMalloc(&h->arena, bytes) != hipSuccess) {
         delete h;
@@ -1253,6 +1262,30 @@ int adas_bytetrack_fetch_frame(adas_bytetrack* h, int stream_index, int frame, a
     }
     return ADAS_OK;
 }
+int adas_bytetrack_fetch_trajectories(adas_bytetrack* h, int stream_index, int32_t* lens, double* tlbr, int max_tracks, int32_t* n_tracks) {
+    ADAS_REQUIRE(h && n_tracks && stream_index >= 0 && stream_index < h->n_streams && max_tracks >= 0, ADAS_ERR_INVALID,
+                 "adas_bytetrack_fetch_trajectories: bad argument");
+    static_assert(ADAS_TRAJECTORY_LEN == ADAS_BT_TRAJ, "trajectory depth");
+    const size_t MT = h->p.max_tracks;
+    size_t stage0 = bt_align((size_t)h->p.max_dets * (32 + 8 + 4) + 256 * 4);
+    int* d_lens = (int*)((unsigned char*)h->h_stage_d + stage0);
+    double* d_out = (double*)((unsigned char*)d_lens + bt_align(MT * 4));
+    hipLaunchKernelGGL(bytetrack_traj_kernel, dim3(1), dim3(256), 0, h->last, h->dev, stream_index, d_lens, d_out);   // behind the last update
+    ADAS_HIP_TRY(hipGetLastError());
+    ADAS_HIP_TRY(hipStreamSynchronize(h->last));
+    BtStream S = bt_view(h->dev.base + (size_t)stream_index * h->dev.stream_bytes, h->p.max_tracks, h->p.max_dets);
+    BtHeader hdr;
+    ADAS_HIP_TRY(hipMemcpy(&hdr, S.hdr, sizeof(BtHeader), hipMemcpyDeviceToHost));
+    const int n = hdr.n_tracked + hdr.n_lost;
+    *n_tracks = n;
+    if (n > 0 && (lens || tlbr)) {
+        ADAS_REQUIRE(n <= max_tracks, ADAS_ERR_CAPACITY, "fetch buffer holds %d tracks, need %d", max_tracks, n);
+        if (lens) ADAS_HIP_TRY(hipMemcpy(lens, d_lens, (size_t)n * 4, hipMemcpyDeviceToHost));
+        if (tlbr) ADAS_HIP_TRY(hipMemcpy(tlbr, d_out, (size_t)n * ADAS_BT_TRAJ * 32, hipMemcpyDeviceToHost));
+    }
+    return ADAS_OK;
+}
+
 int adas_bytetrack_fetch(adas_bytetrack* h, int stream_index, adas_track_header* hdr, adas_track* tracks, int max_tracks) {
     ADAS_REQUIRE(h && hdr && stream_index >= 0 && stream_index < h->n_streams, ADAS_ERR_INVALID, "adas_bytetrack_fetch: bad argument");
     ADAS_HIP_TRY(hipStreamSynchronize(h->last));

@@ -11,8 +11,9 @@
 //   kalman_filter.py:55-86,155-192,126-153,194-226   initiate / multi_predict / project / update
 //   strack.py:61-129           multi_predict, activate, re_activate, update, class vote
 //   byteTrack/utils.py:9-69    joint / sub / remove_duplicate_stracks
-// Not carried: image crops (strack.py:131-143, needs the host frame) and the
-// 30-deep trajectory list (drawing only); neither influences ids.
+//   strack.py:53,115           trajectories: the last 30 matched detection boxes of a track (what
+//                              DrawTrackedOnFrame draws, byteTracker.py:202-215), a ring per track slot
+// Not carried: image crops (strack.py:131-143, needs the host frame); they do not influence ids.
 #pragma once
 #include "post_core.h"
 
@@ -20,6 +21,7 @@ namespace adas {
 
 enum { BT_NEW = 0, BT_TRACKED = 1, BT_LOST = 2, BT_REMOVED = 3 };
 #define ADAS_BT_HIST 8
+#define ADAS_BT_TRAJ 30   // LimitedList(30), strack.py:53
 enum { BT_ERR_DET_OVERFLOW = 1, BT_ERR_TRACK_OVERFLOW = 2, BT_ERR_HIST_OVERFLOW = 4, BT_ERR_NAN_COST = 8 };
 
 struct BtTrack {
@@ -32,12 +34,15 @@ struct BtTrack {
     int hist_n;
     int hist_cls[ADAS_BT_HIST];
     int hist_cnt[ADAS_BT_HIST];
+    int traj_n;   // boxes ever appended to this track's trajectory (the ring keeps the last ADAS_BT_TRAJ)
+    int pad_;
 };
 
 struct BtOut {  // compact per-track message (base_track.py:61-72 + strack.py:207-215)
     double tlwh[4];
     double score;
-    int track_id, state, is_activated, class_id, frame_id, start_frame, tracklet_len, pad;
+    int track_id, state, is_activated, class_id, frame_id, start_frame, tracklet_len;
+    int traj_len;  // len(trajectories): min(appended, 30)
 };
 
 struct BtHeader {
@@ -58,6 +63,7 @@ struct BtStream {
     BtTrack* slots;  // [MT]
     double* cost;    // [MT*MD] workspace
     BtOut* out;      // [2*MT]: tracked then lost
+    double* traj;    // [MT][ADAS_BT_TRAJ][4]: per slot, ring of the matched detections' tlbr (entry k of the list lives at k % 30)
 };
 
 struct BtDet {
@@ -202,10 +208,16 @@ ADAS_DEV void bt_class_vote(BtTrack& t, int cls, int* err) {  // strack.py:122-1
 }
 
 // strack.py:88-120: update() when the track is Tracked, re_activate(new_id=False) otherwise
-ADAS_DEV void bt_apply_match(BtTrack& t, const double* det_in, double score, int cls, int fid, bool reactivate, int* err) {
+// (`traj`: the slot's trajectory ring.  update() appends new_track.tlbr -- the detection's tlbr -> tlwh -> tlbr round trip, strack.py:115
+// -- re_activate() does not, strack.py:88-99.)
+ADAS_DEV void bt_apply_match(BtTrack& t, double* traj, const double* det_in, double score, int cls, int fid, bool reactivate, int* err) {
     double w = det_in[2] - det_in[0], h = det_in[3] - det_in[1];
     double z[4] = {det_in[0] + w / 2, det_in[1] + h / 2, w / h, h};
     bt_kf_update(t, z);
+    if (!reactivate) {
+        bt_det_tlbr(det_in, traj + (size_t)(t.traj_n % ADAS_BT_TRAJ) * 4);
+        t.traj_n += 1;
+    }
     t.tracklet_len = reactivate ? 0 : t.tracklet_len + 1;
     t.state = BT_TRACKED;
     t.is_activated = 1;
@@ -661,7 +673,7 @@ ADAS_DEV void bytetrack_update(const Ctx& c, const BtParams& P, const BtStream& 
     ADAS_PAR_FOR(c, i, 0, n_pool) {
         if (L.x[i] >= 0) {
             int s = L.pool[i], d = L.hi[L.x[i]];
-            bt_apply_match(slots[s], det.tlbr + 4 * d, det.score[d], det.cls[d], fid, L.pst[i] != BT_TRACKED, &L.n[N_ERR]);
+            bt_apply_match(slots[s], S.traj + (size_t)s * ADAS_BT_TRAJ * 4, det.tlbr + 4 * d, det.score[d], det.cls[d], fid, L.pst[i] != BT_TRACKED, &L.n[N_ERR]);
         }
     }
     c.sync();
@@ -684,7 +696,7 @@ ADAS_DEV void bytetrack_update(const Ctx& c, const BtParams& P, const BtStream& 
     ADAS_PAR_FOR(c, i, 0, n_rtr) {
         if (L.x[i] >= 0) {
             int s = L.rtr[i], d = L.lo[L.x[i]];
-            bt_apply_match(slots[s], det.tlbr + 4 * d, det.score[d], det.cls[d], fid, false, &L.n[N_ERR]);
+            bt_apply_match(slots[s], S.traj + (size_t)s * ADAS_BT_TRAJ * 4, det.tlbr + 4 * d, det.score[d], det.cls[d], fid, false, &L.n[N_ERR]);
         }
     }
     c.sync();
@@ -715,7 +727,7 @@ ADAS_DEV void bytetrack_update(const Ctx& c, const BtParams& P, const BtStream& 
         int s = L.unc[i];
         if (L.x[i] >= 0) {
             int d = L.rem[L.x[i]];
-            bt_apply_match(slots[s], det.tlbr + 4 * d, det.score[d], det.cls[d], fid, false, &L.n[N_ERR]);
+            bt_apply_match(slots[s], S.traj + (size_t)s * ADAS_BT_TRAJ * 4, det.tlbr + 4 * d, det.score[d], det.cls[d], fid, false, &L.n[N_ERR]);
         } else {
             slots[s].state = BT_REMOVED;
             slots[s].tmp = -1;  // joins removed_stracks at the end of this frame
@@ -750,6 +762,7 @@ ADAS_DEV void bytetrack_update(const Ctx& c, const BtParams& P, const BtStream& 
         t.hist_cnt[0] = 1;
         t.ever_removed = 0;
         t.tmp = 0;
+        t.traj_n = 0;
     }
     if (c.tid == 0) {
         S.hdr->id_count = id0 + n_new;
@@ -841,9 +854,27 @@ ADAS_DEV void bytetrack_update(const Ctx& c, const BtParams& P, const BtStream& 
         o.frame_id = t.frame_id;
         o.start_frame = t.start_frame;
         o.tracklet_len = t.tracklet_len;
-        o.pad = 0;
+        o.traj_len = t.traj_n < ADAS_BT_TRAJ ? t.traj_n : ADAS_BT_TRAJ;
     }
     BT_MARK(16);
+}
+
+// The trajectories of the tracks in message order (tracked, then lost), oldest box first: lens[k] = len(trajectories),
+// out[k][i] = trajectories[i] (tlbr) for i < lens[k].
+ADAS_DEV void bytetrack_gather_trajectories(const Ctx& c, const BtStream& S, int* lens, double* out) {
+    const int a = S.hdr->n_tracked, b = S.hdr->n_lost;
+    ADAS_PAR_FOR(c, e, 0, (a + b) * ADAS_BT_TRAJ) {
+        const int k = e / ADAS_BT_TRAJ, i = e - k * ADAS_BT_TRAJ;
+        const int slot = k < a ? S.tracked[k] : S.lost[k - a];
+        const int n = S.slots[slot].traj_n;
+        const int len = n < ADAS_BT_TRAJ ? n : ADAS_BT_TRAJ;
+        if (i == 0) lens[k] = len;
+        if (i < len) {
+            const double* src = S.traj + ((size_t)slot * ADAS_BT_TRAJ + (size_t)((n - len + i) % ADAS_BT_TRAJ)) * 4;
+            double* dst = out + (size_t)e * 4;
+            dst[0] = src[0]; dst[1] = src[1]; dst[2] = src[2]; dst[3] = src[3];
+        }
+    }
 }
 
 ADAS_DEV void bytetrack_reset(const Ctx& c, const BtParams& P, const BtStream& S) {  // byteTracker.py:187-200

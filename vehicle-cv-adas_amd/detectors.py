@@ -719,6 +719,22 @@ class BYTETracker:
         self._lost = self._messages(lost, hdr.id_count)
         return self._tracked
 
+    def trajectories(self) -> Dict[int, list]:
+        """track id -> STrack.trajectories (strack.py:53,115): the last 30 detection boxes (tlbr, fp64) the track was updated with,
+        oldest first, for every tracked and lost track -- what DrawTrackedOnFrame hands to plot_trajectories (byteTracker.py:202-215).
+        Fetched from the device on demand (update() does not pay for it)."""
+        hdr, tracked, lost = self._dev.fetch(0)
+        traj = self._dev.fetch_trajectories(0)
+        ids = [int(r["track_id"]) for r in tracked] + [int(r["track_id"]) for r in lost]
+        return {tid: [b.copy() for b in t] for tid, t in zip(ids, traj)}
+
+    def filter_trajectories(self, track_id: int, frame, pad: tuple = (0, 0)) -> list:
+        """STrack.filter_trajectories (strack.py:145-149) of one track: the boxes that lie inside the frame shrunk by `pad`."""
+        padh, padw = pad
+        fh, fw = np.asarray(frame).shape[:2]
+        return [b for b in self.trajectories().get(int(track_id), [])
+                if b[0] >= 0 + padw and b[1] >= 0 + padh and b[2] <= fw - padw and b[3] <= fh - padh]
+
     @property
     def tracked_stracks(self):
         return self._tracked

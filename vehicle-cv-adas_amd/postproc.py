@@ -332,6 +332,15 @@ class DeviceTracker:
         L.check(L.lib().adas_bytetrack_fetch(self.h, stream, C.byref(hdr), L.ptr(recs), len(recs)))
         return hdr, recs[:hdr.n_tracked], recs[hdr.n_tracked:hdr.n_tracked + hdr.n_lost]
 
+    def fetch_trajectories(self, stream=0):
+        """STrack.trajectories (strack.py:53,115) of the live tracks in fetch() order (tracked, then lost): a list of (len, 4) tlbr
+        arrays, oldest box first."""
+        lens = np.zeros(self.max_tracks, np.int32)
+        boxes = np.zeros((self.max_tracks, L.TRAJECTORY_LEN, 4), np.float64)
+        n = C.c_int32()
+        L.check(L.lib().adas_bytetrack_fetch_trajectories(self.h, stream, L.ptr(lens), L.ptr(boxes), self.max_tracks, C.byref(n)))
+        return [boxes[k, :lens[k]].copy() for k in range(n.value)]
+
     def fetch_frame(self, stream, frame):
         """The tracker message of frame `frame` of the last micro-batched step (what BYTETracker.update returned for that frame)."""
         hdr = L.TrackHeader()
