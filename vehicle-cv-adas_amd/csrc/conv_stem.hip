@@ -46,6 +46,18 @@ struct StemDev {
     const float* bias2;
 };
 
+#ifdef ADAS_STEM_PROF   // scratch instrumentation (tools/stem_prof.py): shader cycles of wave 0 per tile phase, summed over workgroups
+__device__ unsigned long long g_stem_prof[16];
+#define STP(i)                                      \
+    if (tid == 0) {                                 \
+        const unsigned long long t__ = clock64();   \
+        pacc__[i] += t__ - tprev__;                 \
+        tprev__ = t__;                              \
+    }
+#else
+#define STP(i)
+#endif
+
 constexpr int STEM_WW = 72;  // window row pitch in pixels (even: 16 B aligned fragment reads)
 
 // CONV2: the YOLO stems are followed by a 3x3 s2 p1 conv on their 16 channels (model.1); the 17 x 33 stem pixels an
@@ -133,6 +145,9 @@ __global__ __launch_bounds__(256, CONV2 ? 3 : 2) void conv_stem_kernel(StemDev a
     };
 
     const int gstride = gridDim.x;
+#ifdef ADAS_STEM_PROF
+    unsigned long long pacc__[16] = {0}, tprev__ = clock64();
+#endif
     auto step = [&](const int tile) {
         const int img = tile / per_img;
         const int t2 = tile - img * per_img;
@@ -140,7 +155,9 @@ __global__ __launch_bounds__(256, CONV2 ? 3 : 2) void conv_stem_kernel(StemDev a
         const int cy0 = CONV2 ? 2 * (ty * 8) - 1 : (POOL ? 2 * (ty * 4) - 1 : ty * CTH);
         const int cx0 = TILE2 ? 2 * (tx * 16) - 1 : tx * CTW;
 
+        STP(0)
         __syncthreads();  // previous tile's readers of the window / conv tile are done (first trip: the weights are in LDS)
+        STP(1)
 #pragma unroll
         for (int i = 0; i < NQ; ++i) {
             const int q = tid + 256 * i;
@@ -156,8 +173,11 @@ __global__ __launch_bounds__(256, CONV2 ? 3 : 2) void conv_stem_kernel(StemDev a
                 *reinterpret_cast<su32x2*>(win + q * 4) = v;
             }
         }
+        STP(2)
         __syncthreads();
+        STP(3)
         fetch(tile + gstride);  // in flight under this tile's MFMAs and pooling
+        STP(4)
 
         // ---- MFMA: KH K-steps.  No guard on M tiles past the end (the last wave's surplus tile reads a clamped, valid window
         // address and is dropped at store time): a branch per tile stops hipcc from overlapping LDS reads with MFMAs.
@@ -179,6 +199,7 @@ __global__ __launch_bounds__(256, CONV2 ? 3 : 2) void conv_stem_kernel(StemDev a
                 for (int i = 0; i < NT; ++i) acc[j][i] = E::mfma(wf[i], xf[j], acc[j][i]);
         }
 
+        STP(5)
         // ---- epilogue: lane holds channels i*16 + kg*4 .. +3 of conv pixel (pcy, pcx)
         float4 bias4[NT];
 #pragma unroll
@@ -209,6 +230,7 @@ __global__ __launch_bounds__(256, CONV2 ? 3 : 2) void conv_stem_kernel(StemDev a
             }
         } else {
             __syncthreads();  // every wave is done reading the window: the conv tile may overwrite it
+            STP(6)
 #pragma unroll
             for (int j = 0; j < MT; ++j) {
                 const int p = (wave * MT + j) * 16 + lrow;
@@ -224,7 +246,9 @@ __global__ __launch_bounds__(256, CONV2 ? 3 : 2) void conv_stem_kernel(StemDev a
                     *reinterpret_cast<su32x2*>(ctile + p * CP + i * 16 + kg * 4) = q;
                 }
             }
+            STP(7)
             __syncthreads();
+            STP(8)
             if (CONV2) {
                 // ---- second conv from the LDS tile: K-step s2 = taps 2*s2 and 2*s2+1 x 16 channels (the tenth tap slot has zero weights)
                 constexpr int MT2 = 2;  // 8 M tiles of 16 output pixels over 4 waves
@@ -290,13 +314,35 @@ __global__ __launch_bounds__(256, CONV2 ? 3 : 2) void conv_stem_kernel(StemDev a
                 uint16_t* op = a.out + ((size_t)(img * a.Hp + gpy) * a.Wp + gpx) * a.out_cs + a.out_coff + cg * 8;
                 *reinterpret_cast<su32x4*>(op) = su32x4{m0.x, m0.y, m1.x, m1.y};
             }
+            STP(9)
         }
     };
     int tile = blockIdx.x;
     if (tile >= a.ntiles) return;
     fetch(tile);
-    for (; tile < a.ntiles; tile += gstride) step(tile);
+    for (; tile < a.ntiles; tile += gstride) {
+        step(tile);
+#ifdef ADAS_STEM_PROF
+        if (tid == 0) pacc__[15] += 1;
+#endif
+    }
+#ifdef ADAS_STEM_PROF
+    if (tid == 0)
+        for (int i = 0; i < 16; ++i) atomicAdd(&g_stem_prof[i], pacc__[i]);
+#endif
 }
+
+#ifdef ADAS_STEM_PROF
+extern "C" int adas_debug_stem_prof(unsigned long long* out16, int reset) {
+    static unsigned long long h[16];
+    if (out16 && hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_stem_prof), sizeof(h)) != hipSuccess) return -1;
+    if (reset) {
+        memset(h, 0, sizeof(h));
+        if (hipMemcpyToSymbol(HIP_SYMBOL(g_stem_prof), h, sizeof(h)) != hipSuccess) return -1;
+    }
+    return 0;
+}
+#endif
 
 // -------------------------------------------------------------------------------------
 bool stem_applicable(int prec, int in_c_true, int kh, int kw, int stride, int pad, int act, int res_mode, const TView& out, bool pool,
