@@ -201,6 +201,22 @@ def test_halo8_x3_kernel_layers(case):
     assert rel < X3_REL and mx < 1e-4, (case, rel, mx)
 
 
+@pytest.mark.parametrize("case", [(80, 400, 64, 128, M.ACT_RELU, 8), (40, 200, 128, 256, M.ACT_RELU, 16), (20, 100, 256, 512, M.ACT_RELU, 64),
+                                  (160, 160, 32, 64, M.ACT_SILU, 16), (80, 80, 64, 128, M.ACT_SILU, 64), (40, 40, 128, 256, M.ACT_SILU, 64),
+                                  (80, 80, 64, 64, M.ACT_LEAKY, 64), (46, 74, 64, 80, M.ACT_NONE, 64), (23, 37, 96, 192, M.ACT_SILU, 128)], ids=str)
+def test_s2p_x3_kernel_layers(case):
+    """The stride-2 3x3 conv of the split precision on the parity-plane kernel (conv_halo_s2.hip conv_s2p_x3_kernel: half-chunk window,
+    conv_halo8_x3's weight slabs, main / cross accumulators): the three UFLD down-sampling layers, the YOLOv8n ones, even and odd map
+    sizes (the last window row / column outside the image), a Cout that is not whole 64-channel blocks (80: zero weight rows, masked
+    stores), three chunks (96 input channels) -- f32-class against torch fp32 (ADAS_NO_HALO_S2P_X3=1 sends these layers back to the generic kernel)."""
+    H, W, cin, cout, act, batch = case
+    info = {}
+    rel, mx = TC.run_case(CE, H, W, cin, cout, 3, 2, act, M.RES_NONE, "fp16x3", batch=batch, info=info)
+    print("s2p x3 %s: rel %.2e max %.2e  %s" % (case, rel, mx, info.get("kernel")))
+    assert "conv_s2p_x3_kernel" in info["kernel"], info
+    assert rel < X3_REL and mx < 1e-4, (case, rel, mx)
+
+
 def test_ufldv2_culane_at_the_bench_batch_vs_oracle():
     """The C3 network at batch 64 (the bench's batch): the 3x3 stride-1 layers run on conv_h8x3_kernel.  Three distinct frames tiled
     over the batch: frames 0-2 against the oracle, every copy bit-identical to the first (different workgroups, same arithmetic)."""

@@ -20,6 +20,7 @@
 #include <map>
 #include <mutex>
 #include <tuple>
+#include <type_traits>
 
 namespace adas {
 
@@ -321,6 +322,247 @@ hipError_t launch_conv_halo_s2p(const ConvArgs& a, hipStream_t st) {
         else if (a.act == ACT_LEAKY) hipLaunchKernelGGL((conv_s2p_kernel<E, ACT_LEAKY>), grid, dim3(S2_THR), lds, st, d);
         else hipLaunchKernelGGL((conv_s2p_kernel<E, ACT_NONE>), grid, dim3(S2_THR), lds, st, d);
     });
+    return hipGetLastError();
+}
+
+// =====================================================================================
+// Split precision (ADAS_PREC_FP16X3): the same parity-plane kernel fed with HALF-CHUNKS, as conv_halo8_x3.hip feeds its stride-1 stream.
+//
+// Until round 5 the exact mode sent every stride-2 3x3 conv to the generic gather kernel (conv_x3_igemm: 141-193 TFLOP/s of conv work on
+// the three UFLD layers, 0.39-0.53 ms each at 64 frames).  Here a 32-channel chunk of the G8 activation tensor (128 B per pixel: four
+// groups of [16 B hi | 16 B lo]) goes through the window as an H chunk (the four hi pieces) and then an L chunk (the four lo pieces);
+// the weights are conv_halo8_x3's slabs ([32-channel block][half-chunk][tap][64 rows][32], rows 0-31 MAIN = hi(w), rows 32-63 CROSS =
+// lo(w) 2^11 in an H chunk | hi(w) in an L chunk; launch_pack_weights_h8x3 -- the packing does not know the stride), so one workgroup
+// (8 waves) owns 256 output pixels x 64 output channels: waves 0-3 / 4-7 take the two 32-channel blocks, each wave 64 pixels x
+// (2 main + 2 cross) 16-row tiles.  H chunk: main += w_hi a_hi, cross += w_lo a_hi (16 MFMAs per tap); L chunk: cross += w_hi a_lo (8).
+// Epilogue: act(main + 2^-11 cross) -> split -> G8 store.  The bias starts the main accumulators.
+struct S2XDev {
+    const unsigned char* in;    // G8: 4 bytes per channel slot
+    const uint16_t* wgt;        // halo8_x3 slabs
+    const float* bias;
+    x3s* out;
+    int in_cs, in_coff, cin, H, W;
+    int out_cs, out_coff, cout;
+    int nck;                     // half-chunks: 2 * cin / 32
+    int SW, NS, TPS, PW, plane;
+    int npix4;
+    int Ho, Wo;
+    uint32_t mg_pw, mg_sw, mg_plane;
+    int ntiles, tiles8, ncb, xmap;   // ncb: 64-channel blocks
+};
+
+template <int ACT>
+__device__ __forceinline__ float s2x_act(float v) {   // the parity modes use the exact forms (conv_x3.hip x3_act)
+    if (ACT == ACT_SILU) return v / (1.0f + expf(-v));
+    if (ACT == ACT_RELU) return fmaxf(v, 0.0f);
+    if (ACT == ACT_LEAKY) return fmaxf(v, 0.1f * v);
+    return v;
+}
+
+template <int ACT>
+__global__ __launch_bounds__(S2_THR, 1) void conv_s2p_x3_kernel(S2XDev a) {
+    Fp16::enter();
+    typedef Fp16::vec8 vec8;
+    constexpr int TAPS = 9, TM = 4;
+    extern __shared__ __attribute__((aligned(16))) uint16_t lds[];
+    uint16_t* Aw = lds;                                    // [4 * plane][32]: one half-chunk of the window
+    uint16_t* Ww = lds + (size_t)4 * a.plane * 32;         // [2][S2_WROWS][32], row-swizzled: the two 32-channel blocks' slabs
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lrow = lane & 15, kg = lane >> 4;
+    const int half = wave >> 2, grp = wave & 3;
+    const int xslot = blockIdx.x >> 3;
+    const int xr = xslot / a.ncb;
+    const int cb = xslot - xr * a.ncb;
+    int tile = a.xmap ? (int)(blockIdx.x & 7) * a.tiles8 + xr : xr * 8 + (blockIdx.x & 7);
+    if (tile >= a.ntiles) return;
+    const int n0 = cb * 64 + half * 32;
+    const int per_img = a.NS * a.TPS;
+    const int img = tile / per_img;
+    tile -= img * per_img;
+    const int strip = tile / a.TPS, t = tile - strip * a.TPS;
+    const int sx0 = strip * a.SW, p0 = t * S2_BM;
+    const int y_first = (int)(((uint32_t)p0 * a.mg_sw) >> 20);
+    const int wy0 = 2 * y_first - 1, wx0 = 2 * sx0 - 1;   // window origin in the input (pad 1)
+
+    // ---- staging addresses: byte offsets of K group c8's hi piece in half-chunk 0; out-of-image pixels: out-of-range offset -> zeros
+    const unsigned char* in_img = a.in + ((size_t)img * a.H * a.W * a.in_cs + a.in_coff) * 4;
+    __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)in_img, 0, (a.H * a.W * a.in_cs - a.in_coff) * 4, 0x00020000);
+    uint32_t goff[S2_NA];
+#pragma unroll
+    for (int i = 0; i < S2_NA; ++i) {
+        const int e = tid + S2_THR * i;
+        const int pix = e >> 2, c8 = e & 3;
+        const int q = (int)(((uint32_t)pix * a.mg_plane) >> 20);       // plane (a, b) = (q >> 1, q & 1)
+        const int pp = pix - q * a.plane;
+        const int py = (int)(((uint32_t)pp * a.mg_pw) >> 20), px = pp - py * a.PW;
+        const int iy = wy0 + 2 * py + (q >> 1), ix = wx0 + 2 * px + (q & 1);
+        const bool ok = e < a.npix4 && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+        goff[i] = ok ? (uint32_t)((iy * a.W + ix) * a.in_cs * 4 + c8 * 32) : 0x80000000u;
+    }
+    // weights: slabs (block 2 cb, half-chunk ck) and (block 2 cb + 1, ck), each S2_WROWS contiguous 64-byte rows (conv_s2p_kernel's staging)
+    const uint16_t* wb0 = a.wgt + (size_t)(2 * cb) * a.nck * S2_WROWS * 32;      // workgroup-uniform
+    const uint16_t* wb1 = wb0 + (size_t)a.nck * S2_WROWS * 32;
+    const int gsw[4] = {0, 2, 3, 1};
+    const int wdst0 = ((tid & ~3) + ((tid & 3) ^ gsw[(tid >> 4) & 3])) * 8;
+    const int wrd = (half * S2_WROWS + lrow) * 32 + ((kg ^ gsw[(lrow >> 2) & 3]) << 3);
+
+    int apl[TM], oy[TM], ox[TM];
+#pragma unroll
+    for (int j = 0; j < TM; ++j) {
+        const int p = p0 + (grp * TM + j) * 16 + lrow;
+        const int y = (int)(((uint32_t)p * a.mg_sw) >> 20), xs = p - y * a.SW;
+        oy[j] = y;
+        ox[j] = sx0 + xs;
+        apl[j] = (y - y_first) * a.PW + xs;
+    }
+
+    sf32x4_ acc[4][TM];   // [0..1]: main, starts at the bias; [2..3]: cross, starts at zero
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const float4 b = *reinterpret_cast<const float4*>(a.bias + n0 + i * 16 + kg * 4);
+#pragma unroll
+        for (int j = 0; j < TM; ++j) {
+            acc[i][j] = sf32x4_{b.x, b.y, b.z, b.w};
+            acc[i + 2][j] = sf32x4_{0.f, 0.f, 0.f, 0.f};
+        }
+    }
+
+    su32x4_ ra[S2_NA], rw[S2_NW];
+    auto gload = [&](int ck) {
+        // half-chunk ck: the hi pieces of channels 32 (ck >> 1) .., or (odd) their lo pieces 16 bytes on; a chunk is 128 bytes of a pixel
+        const uint32_t cofs = (uint32_t)((ck >> 1) * 128 + (ck & 1) * 16);
+#pragma unroll
+        for (int i = 0; i < S2_NA; ++i) ra[i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, goff[i] + cofs, 0, 0);
+#pragma unroll
+        for (int i = 0; i < S2_NW; ++i) {
+            const int e = tid + S2_THR * i;   // only i = 4 straddles the two slabs
+            const uint16_t* src = (e < S2_WROWS * 4 ? wb0 + (size_t)e * 8 : wb1 + (size_t)(e - S2_WROWS * 4) * 8) + (size_t)ck * S2_WROWS * 32;
+            rw[i] = *reinterpret_cast<const su32x4_*>(src);
+        }
+    };
+    const int na = (a.npix4 + S2_THR - 1) / S2_THR;   // workgroup-uniform
+    auto lstore = [&]() {
+#pragma unroll
+        for (int i = 0; i < S2_NA; ++i) {
+            const int e = tid + S2_THR * i;
+            if (i < na && e < a.npix4) *reinterpret_cast<su32x4_*>(Aw + (e >> 2) * 32 + (((e & 3) ^ ((e >> 3) & 2)) << 3)) = ra[i];
+        }
+#pragma unroll
+        for (int i = 0; i < S2_NW; ++i) *reinterpret_cast<su32x4_*>(Ww + wdst0 + i * S2_THR * 8) = rw[i];
+    };
+    auto taps = [&](auto lo_c) {
+        constexpr int I0 = decltype(lo_c)::value ? 2 : 0;   // L half-chunk: only the cross tiles accumulate
+#pragma unroll
+        for (int tap = 0; tap < TAPS; ++tap) {
+            const int r = tap / 3, s = tap - r * 3;
+            const int tofs = ((r & 1) * 2 + (s & 1)) * a.plane + (r >> 1) * a.PW + (s >> 1);
+            vec8 wf[4], xf[TM];
+#pragma unroll
+            for (int i = I0; i < 4; ++i) wf[i] = *reinterpret_cast<const vec8*>(Ww + (tap * 64 + i * 16) * 32 + wrd);
+#pragma unroll
+            for (int j = 0; j < TM; ++j) {
+                const int pw = apl[j] + tofs;
+                xf[j] = *reinterpret_cast<const vec8*>(Aw + pw * 32 + ((kg ^ ((pw >> 1) & 2)) << 3));
+            }
+#pragma unroll
+            for (int i = I0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < TM; ++j) acc[i][j] = Fp16::mfma(wf[i], xf[j], acc[i][j]);
+        }
+    };
+
+    gload(0);
+    lstore();
+    __syncthreads();
+    for (int ck = 0; ck < a.nck; ck += 2) {      // one 32-channel chunk per trip: its H half-chunk, then its L half-chunk
+        gload(ck + 1);
+        taps(std::false_type{});
+        __syncthreads();
+        lstore();
+        __syncthreads();
+        if (ck + 2 < a.nck) gload(ck + 2);
+        taps(std::true_type{});
+        if (ck + 2 < a.nck) {
+            __syncthreads();
+            lstore();
+            __syncthreads();
+        }
+    }
+
+    // ---- epilogue: lane holds channels n0 + i*16 + kg*4 .. +3 of pixel (oy, ox)[j]
+#pragma unroll
+    for (int j = 0; j < TM; ++j) {
+        const bool pok = oy[j] < a.Ho && ox[j] < a.Wo;
+        const size_t mpix = pok ? ((size_t)img * a.Ho + oy[j]) * a.Wo + ox[j] : 0;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            float v[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = s2x_act<ACT>(acc[i][j][e] + acc[i + 2][j][e] * kX3Down);
+            const int c = n0 + i * 16 + kg * 4;
+            if (pok && c < a.cout) x3_store4(a.out + mpix * a.out_cs + a.out_coff + c, v);   // (channels past cout: zero weight rows, not stored)
+        }
+    }
+}
+
+static bool s2x_enabled() {
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("ADAS_NO_HALO_S2P_X3");
+        v = (e && e[0] == '1') ? 0 : 1;
+    }
+    return v == 1;
+}
+
+// static part (shapes): the conv also gets conv_halo8_x3's weight packing (engine.cpp)
+bool halo_s2p_x3_shape_ok(int kh, int kw, int stride, int pad, int res_mode, const TView& in, const TView& out) {
+    if (!s2x_enabled() || stride != 2 || kh != 3 || kw != 3 || pad != 1 || res_mode != RES_NONE) return false;
+    if (in.f32 || out.f32 || out.h != (in.h + 2 - 3) / 2 + 1 || out.w != (in.w + 2 - 3) / 2 + 1) return false;
+    if ((in.c & 31) || (in.cs & 7) || (in.coff & 7) || (out.c & 7) || (out.cs & 7) || (out.coff & 7)) return false;
+    if ((long)in.h * in.w * in.cs * 4 >= (1L << 31)) return false;
+    if (2 * out.c < (out.c + 63) / 64 * 64) return false;        // more than half of the MFMA work on padding rows
+    S2Plan pl;
+    return plan_s2(out.h, out.w, &pl) && pl.eff >= 0.45;
+}
+
+bool halo_s2p_x3_applicable(int kh, int kw, int stride, int pad, int res_mode, int n, const TView& in, const TView& out) {
+    if (!halo_s2p_x3_shape_ok(kh, kw, stride, pad, res_mode, in, out)) return false;
+    S2Plan pl;
+    if (!plan_s2(out.h, out.w, &pl)) return false;
+    return (long)n * pl.NS * pl.TPS * ((out.c + 63) / 64) >= 256;   // one 8-wave workgroup per CU: the launch has to fill the chip
+}
+
+hipError_t launch_conv_s2p_x3(const ConvArgs& a, hipStream_t st) {
+    S2Plan pl;
+    if (!a.wgt_h8x3 || !halo_s2p_x3_applicable(a.kh, a.kw, a.stride, a.pad, a.res_mode, a.n, a.in, a.out) || !plan_s2(a.out.h, a.out.w, &pl))
+        return hipErrorNotSupported;
+    S2XDev d;
+    d.in = (const unsigned char*)a.in.p; d.wgt = (const uint16_t*)a.wgt_h8x3; d.bias = a.bias; d.out = (x3s*)a.out.p;
+    d.in_cs = a.in.cs; d.in_coff = a.in.coff; d.cin = a.in.c; d.H = a.in.h; d.W = a.in.w;
+    d.out_cs = a.out.cs; d.out_coff = a.out.coff; d.cout = a.out.c;
+    d.nck = 2 * (a.in.c / 32);
+    d.SW = pl.SW; d.NS = pl.NS; d.TPS = pl.TPS; d.PW = pl.PW; d.plane = pl.plane;
+    d.npix4 = 4 * pl.plane * 4;
+    d.Ho = a.out.h; d.Wo = a.out.w;
+    d.mg_pw = pl.mg_pw; d.mg_sw = pl.mg_sw; d.mg_plane = pl.mg_plane;
+    d.ntiles = a.n * pl.NS * pl.TPS;
+    d.tiles8 = (d.ntiles + 7) / 8;
+    d.ncb = (a.out.c + 63) / 64;
+    { static int xm = -1; if (xm < 0) { const char* e = getenv("ADAS_HALO_XMAP"); xm = e ? atoi(e) : 1; } d.xmap = xm; }
+    const dim3 grid(8 * d.tiles8 * d.ncb);
+    const size_t lds = ((size_t)4 * pl.plane * 32 + (size_t)2 * S2_WROWS * 32) * 2;
+    static bool attr_done = false;
+    if (!attr_done) {
+#define S2X_ATTR(A_) (void)hipFuncSetAttribute((const void*)conv_s2p_x3_kernel<A_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)
+        S2X_ATTR(ACT_NONE); S2X_ATTR(ACT_SILU); S2X_ATTR(ACT_RELU); S2X_ATTR(ACT_LEAKY);
+#undef S2X_ATTR
+        attr_done = true;
+    }
+    if (a.act == ACT_SILU) hipLaunchKernelGGL((conv_s2p_x3_kernel<ACT_SILU>), grid, dim3(S2_THR), lds, st, d);
+    else if (a.act == ACT_RELU) hipLaunchKernelGGL((conv_s2p_x3_kernel<ACT_RELU>), grid, dim3(S2_THR), lds, st, d);
+    else if (a.act == ACT_LEAKY) hipLaunchKernelGGL((conv_s2p_x3_kernel<ACT_LEAKY>), grid, dim3(S2_THR), lds, st, d);
+    else hipLaunchKernelGGL((conv_s2p_x3_kernel<ACT_NONE>), grid, dim3(S2_THR), lds, st, d);
     return hipGetLastError();
 }
 

@@ -341,6 +341,10 @@ const char* conv_kernel_name(const ConvArgs& a, int prec, int kernel) {
             snprintf(buf, sizeof(buf), "conv_h8x3_kernel<%s>", a.act == ACT_SILU ? "SILU" : (a.act == ACT_RELU ? "RELU" : (a.act == ACT_LEAKY ? "LEAKY" : "NONE")));
             return buf;
         }
+        if (a.wgt_h8x3 && halo_s2p_x3_applicable(a.kh, a.kw, a.stride, a.pad, a.res_mode, a.n, a.in, a.out)) {
+            snprintf(buf, sizeof(buf), "conv_s2p_x3_kernel<%s>", a.act == ACT_SILU ? "SILU" : (a.act == ACT_RELU ? "RELU" : (a.act == ACT_LEAKY ? "LEAKY" : "NONE")));
+            return buf;
+        }
         return conv_x3_kernel_name(a);
     }
     const char* actn = a.act == ACT_SILU ? "SILU" : (a.act == ACT_RELU ? "RELU" : (a.act == ACT_LEAKY ? "LEAKY" : "NONE"));
@@ -460,6 +464,10 @@ hipError_t launch_conv(const ConvArgs& a, int prec, hipStream_t st) {
         if (pl.kernel == CONV_PW) return launch_conv_pw_x3(a, st);
         if (a.wgt_h8x3 && halo8_x3_applicable(a.kh, a.kw, a.stride, a.pad, a.n, a.in, a.out, a.res, a.res_mode)) {
             hipError_t e = launch_conv_halo8_x3(a, st);
+            if (e != hipErrorNotSupported) return e;
+        }
+        if (a.wgt_h8x3 && halo_s2p_x3_applicable(a.kh, a.kw, a.stride, a.pad, a.res_mode, a.n, a.in, a.out)) {
+            hipError_t e = launch_conv_s2p_x3(a, st);
             if (e != hipErrorNotSupported) return e;
         }
         return launch_conv_x3(a, st);

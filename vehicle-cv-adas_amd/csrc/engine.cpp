@@ -649,8 +649,10 @@ int adas_engine_create(const char* model_path, int precision, int max_batch, ada
                 packed_total += ((size_t)op.cout_pad * 4 + 255) & ~(size_t)255;
                 continue;
             }
-            if (precision == PREC_X3 && halo8_x3_shape_ok(o.kh, o.kw, o.stride, o.pad, make_view(e, o.in_buf[0], o.in_coff[0], o.in_c[0]),
-                                                          make_view(e, o.out_buf, o.out_coff, o.out_c))) {
+            if (precision == PREC_X3 && pl.kernel != CONV_PW && pl.kernel != CONV_FC &&
+                (halo8_x3_shape_ok(o.kh, o.kw, o.stride, o.pad, make_view(e, o.in_buf[0], o.in_coff[0], o.in_c[0]), make_view(e, o.out_buf, o.out_coff, o.out_c)) ||
+                 halo_s2p_x3_shape_ok(o.kh, o.kw, o.stride, o.pad, o.res_mode, make_view(e, o.in_buf[0], o.in_coff[0], o.in_c[0]),
+                                      make_view(e, o.out_buf, o.out_coff, o.out_c)))) {
                 op.has_x3h8 = true;   // the batch decides at launch which of the two packings runs
                 op.x3h8_w_off = packed_total;
                 packed_total += (halo8_x3_weight_bytes(cout, cin) + 255) & ~(size_t)255;
