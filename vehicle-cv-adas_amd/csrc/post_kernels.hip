@@ -321,6 +321,16 @@ __global__ __launch_bounds__(256) void bytetrack_reset_kernel(BtDev d) {
 // =====================================================================================
 // C ABI
 // =====================================================================================
+constexpr int UFLD_MSG_INTS = 8 + 4 * ADAS_UFLD_MAXPTS * 2;
+__global__ __launch_bounds__(256) void ufld_pack_kernel(const int* cnt, const int* det, const int* pts, int frame, int* msg) {
+    const int t = threadIdx.x;
+    if (t < 4) {
+        msg[t] = cnt[frame * 4 + t];
+        msg[4 + t] = det[frame * 4 + t];
+    }
+    for (int i = t; i < 4 * ADAS_UFLD_MAXPTS * 2; i += blockDim.x) msg[8 + i] = pts[(size_t)frame * 4 * ADAS_UFLD_MAXPTS * 2 + i];
+}
+
 // The survivors of ONE frame as one message: [n_found, n_candidates, n_keep, flags] then n_keep records of 64 bytes
 // {double xywh[4]; double conf; int cls; int keep; int xyxy[4]} -- what YoloDetector.DetectFrame reads after every frame, in one
 // device-to-host copy instead of one per array (adas_yolo_post_fetch: up to ten).
@@ -358,6 +368,8 @@ struct adas_ufld_decode {
     UfldDev dev;
     Ufld1Dev dev1;
     void* arena;
+    int* msg = nullptr;     // one frame's lanes as one message: [4 counts][4 detected][4 x MAXPTS x 2 points] (device) ...
+    int* h_msg = nullptr;   // ... and its pinned landing buffer (adas_ufld_decode_fetch: one copy instead of three)
     hipStream_t last;
 };
 struct EffdetDev {
@@ -907,6 +919,12 @@ int adas_ufld_decode_create(const adas_ufld_params* p, int max_batch, adas_ufld_
         return hip_fail(hipGetLastError(), "hipMalloc(ufld arena)", __FILE__, __LINE__);
     }
     hipMemset(h->arena, 0, bytes);
+    if (hipMalloc((void**)&h->msg, UFLD_MSG_INTS * 4) != hipSuccess || hipHostMalloc((void**)&h->h_msg, UFLD_MSG_INTS * 4, hipHostMallocDefault) != hipSuccess) {
+        if (h->msg) hipFree(h->msg);
+        hipFree(h->arena);
+        delete h;
+        return hip_fail(hipGetLastError(), "hipMalloc(ufld fetch message)", __FILE__, __LINE__);
+    }
     unsigned char* q = (unsigned char*)h->arena;
     double* ra = carve<double>(q, p->cls_row);
     double* ca = carve<double>(q, p->cls_col);
@@ -924,6 +942,8 @@ int adas_ufld_decode_create(const adas_ufld_params* p, int max_batch, adas_ufld_
 }
 int adas_ufld_decode_destroy(adas_ufld_decode* h) {
     if (!h) return ADAS_OK;
+    if (h->msg) hipFree(h->msg);
+    if (h->h_msg) hipHostFree(h->h_msg);
     hipFree(h->arena);
     delete h;
     return ADAS_OK;
@@ -948,6 +968,12 @@ int adas_ufld1_decode_create(const adas_ufld1_params* p, int max_batch, adas_ufl
         return hip_fail(hipGetLastError(), "hipMalloc(ufld1 arena)", __FILE__, __LINE__);
     }
     hipMemset(h->arena, 0, bytes);
+    if (hipMalloc((void**)&h->msg, UFLD_MSG_INTS * 4) != hipSuccess || hipHostMalloc((void**)&h->h_msg, UFLD_MSG_INTS * 4, hipHostMallocDefault) != hipSuccess) {
+        if (h->msg) hipFree(h->msg);
+        hipFree(h->arena);
+        delete h;
+        return hip_fail(hipGetLastError(), "hipMalloc(ufld fetch message)", __FILE__, __LINE__);
+    }
     unsigned char* q = (unsigned char*)h->arena;
     double* ra = carve<double>(q, p->cls_num_per_lane);
     hipMemcpy(ra, p->h_row_anchor, p->cls_num_per_lane * 8, hipMemcpyHostToDevice);
@@ -1008,11 +1034,15 @@ int adas_ufld_decode_run(adas_ufld_decode* h, const float* lr, const float* lc, 
 }
 int adas_ufld_decode_fetch(adas_ufld_decode* h, int frame, int32_t* points, int32_t* counts, int32_t* detected) {
     ADAS_REQUIRE(h && frame >= 0 && frame < h->max_batch, ADAS_ERR_INVALID, "adas_ufld_decode_fetch: bad frame index");
-    ADAS_HIP_TRY(hipStreamSynchronize(h->last));
     const UfldDev& d = h->dev;
-    if (points) ADAS_HIP_TRY(hipMemcpy(points, d.lane_pts + (size_t)frame * 4 * ADAS_UFLD_MAXPTS * 2, 4 * ADAS_UFLD_MAXPTS * 2 * 4, hipMemcpyDeviceToHost));
-    if (counts) ADAS_HIP_TRY(hipMemcpy(counts, d.lane_cnt + frame * 4, 16, hipMemcpyDeviceToHost));
-    if (detected) ADAS_HIP_TRY(hipMemcpy(detected, d.lane_det + frame * 4, 16, hipMemcpyDeviceToHost));
+    // one pack kernel behind the decode on its stream + ONE copy (was: three synchronous copies)
+    ufld_pack_kernel<<<1, 256, 0, h->last>>>(d.lane_cnt, d.lane_det, d.lane_pts, frame, h->msg);
+    ADAS_HIP_TRY(hipGetLastError());
+    ADAS_HIP_TRY(hipMemcpyAsync(h->h_msg, h->msg, UFLD_MSG_INTS * 4, hipMemcpyDeviceToHost, h->last));
+    ADAS_HIP_TRY(hipStreamSynchronize(h->last));
+    if (counts) memcpy(counts, h->h_msg, 16);
+    if (detected) memcpy(detected, h->h_msg + 4, 16);
+    if (points) memcpy(points, h->h_msg + 8, 4 * ADAS_UFLD_MAXPTS * 2 * 4);
     return ADAS_OK;
 }
 
