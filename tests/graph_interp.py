@@ -22,6 +22,11 @@ def _act(y, act):
         return F.relu(y)
     if act == M.ACT_LEAKY:
         return F.leaky_relu(y, 0.1)
+    if act == M.ACT_HSWISH:
+        return F.hardswish(y)
+    if act == M.ACT_HSIGMOID:
+        return F.hardsigmoid(y)
+    assert act == M.ACT_NONE, act
     return y
 
 
@@ -93,8 +98,11 @@ def run(g, x, taps=None):
                 w, b = wb(op)
                 c, cr = ins[0].c, int(op["params"][0])
                 m = read(ins[0]).mean((2, 3))
-                hdn = F.silu(m @ torch.from_numpy(w[:cr * c].copy()).reshape(cr, c).T + torch.from_numpy(w[cr * c:].copy()))
-                gate = torch.sigmoid(hdn @ torch.from_numpy(b[:c * cr].copy()).reshape(c, cr).T + torch.from_numpy(b[c * cr:].copy()))
+                prm = list(op["params"]) + [0, 0, 0]
+                hdn = m @ torch.from_numpy(w[:cr * c].copy()).reshape(cr, c).T + torch.from_numpy(w[cr * c:].copy())
+                hdn = F.relu(hdn) if int(prm[1]) == M.ACT_RELU else F.silu(hdn)
+                gate = hdn @ torch.from_numpy(b[:c * cr].copy()).reshape(c, cr).T + torch.from_numpy(b[c * cr:].copy())
+                gate = F.hardsigmoid(gate) if int(prm[2]) == M.ACT_HSIGMOID else torch.sigmoid(gate)
                 write(out, gate.reshape(N, c, 1, 1))
             elif t == M.OP_SCALE:
                 write(out, read(ins[0]) * read(ins[1]))

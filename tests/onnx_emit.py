@@ -21,8 +21,9 @@ def _i64(name, vals):
 
 
 class Emitter:
-    def __init__(self, g, use_split=True):
+    def __init__(self, g, use_split=True, hswish_as_mul=False):
         self.g = g
+        self.hswish_as_mul = hswish_as_mul     # hard-swish as x * HardSigmoid(x) (exports below opset 14) instead of a HardSwish node
         self.blob = np.frombuffer(bytes(g.blob), np.float32)
         self.nodes, self.inits = [], []
         self.segs = {}          # buffer -> list of (coff, c, tensor name), latest writer wins
@@ -224,11 +225,18 @@ class Emitter:
                                OW.tensor(n2 + ".weight", b_[:c * cr].reshape(c, cr, 1, 1)), OW.tensor(n2 + ".bias", b_[c * cr:])]
                 gp, r1, sg, a1, e1, gate = (self.name(n) for n in ("gap", "se_r", "se_sig", "se_a", "se_e", "se_gate"))
                 self.node("GlobalAveragePool", [self.read(ins[0])], [gp])
+                prm = list(op["params"]) + [0, 0, 0]
                 self.node("Conv", [gp, n1 + ".weight", n1 + ".bias"], [r1], [OW.attr_ints("kernel_shape", [1, 1])])
-                self.node("Sigmoid", [r1], [sg])
-                self.node("Mul", [r1, sg], [a1])
+                if int(prm[1]) == M.ACT_RELU:             # MobileNetV3 / PP-LCNet form: ReLU inside, hard-sigmoid gate
+                    self.node("Relu", [r1], [a1])
+                else:
+                    self.node("Sigmoid", [r1], [sg])
+                    self.node("Mul", [r1, sg], [a1])
                 self.node("Conv", [a1, n2 + ".weight", n2 + ".bias"], [e1], [OW.attr_ints("kernel_shape", [1, 1])])
-                self.node("Sigmoid", [e1], [gate])
+                if int(prm[2]) == M.ACT_HSIGMOID:
+                    self.node("HardSigmoid", [e1], [gate], [OW.attr_float("alpha", 1.0 / 6.0), OW.attr_float("beta", 0.5)])
+                else:
+                    self.node("Sigmoid", [e1], [gate])
                 self.wrote(out, gate)
             elif t == M.OP_SCALE:
                 y = self.name("se_out")
@@ -267,6 +275,19 @@ class Emitter:
                 elif op["act"] == M.ACT_LEAKY:
                     y = self.name("act")
                     self.node("LeakyRelu", [acc], [y], [OW.attr_float("alpha", 0.1)])
+                    acc = y
+                elif op["act"] == M.ACT_HSWISH:
+                    y = self.name("act")
+                    if self.hswish_as_mul:        # opset < 14 exporters: x * HardSigmoid(x)
+                        hs = self.name("hsig")
+                        self.node("HardSigmoid", [acc], [hs], [OW.attr_float("alpha", 1.0 / 6.0), OW.attr_float("beta", 0.5)])
+                        self.node("Mul", [acc, hs], [y])
+                    else:
+                        self.node("HardSwish", [acc], [y])
+                    acc = y
+                elif op["act"] == M.ACT_HSIGMOID:
+                    y = self.name("act")
+                    self.node("HardSigmoid", [acc], [y], [OW.attr_float("alpha", 1.0 / 6.0), OW.attr_float("beta", 0.5)])
                     acc = y
                 else:
                     assert op["act"] == M.ACT_NONE, op["act"]
@@ -357,5 +378,5 @@ class Emitter:
         return path
 
 
-def emit(g, path, use_split=True):
-    return Emitter(g, use_split).emit(path)
+def emit(g, path, use_split=True, hswish_as_mul=False):
+    return Emitter(g, use_split, hswish_as_mul).emit(path)

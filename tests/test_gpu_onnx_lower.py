@@ -115,3 +115,40 @@ def test_shufflenet_onnx_runs_through_hipengine(tmp_path, prec, tol):
     rel = float(np.linalg.norm(got - want) / np.linalg.norm(want))
     print("lowered shufflenet %s: rel %.2e" % (prec, rel))
     assert rel <= tol and kernels.count("shuffle_kernel") == 8
+
+
+@pytest.mark.parametrize("prec,tol", [("fp32", 1e-5), ("fp16x3", 1e-5), ("fp16", 5e-3), ("bf16", 4e-2)])
+def test_hard_swish_network_onnx_runs_through_hipengine(tmp_path, prec, tol):
+    """A PP-LCNet-style graph (hard-swish everywhere, ReLU / hard-sigmoid squeeze-and-excitation, a bare hard-sigmoid: the YOLOv5-lite-c
+    family) as an exporter writes it -> OnnxEngine: every hard-swish runs as a one-input wsum_kernel launch behind an activation-free
+    convolution, the gates through se_gate_kernel's ReLU / hard-sigmoid forms -- against the torch interpreter of the original graph."""
+    from test_onnx_lower import lcnet_graph
+    g = lcnet_graph(128)
+    path = str(tmp_path / "lcnet.onnx")
+    onnx_emit.emit(g, path, hswish_as_mul=(prec == "fp16x3"))
+    x = np.random.default_rng(5).uniform(0, 1, (3, 3, 128, 128)).astype(np.float32)
+    want = graph_interp.run(g, x)[0]
+    e = CE.OnnxEngine(path, precision=prec, max_batch=3)
+    got = np.array(e.engine_inference(x)[0], copy=True)
+    kernels = [e.layer_kernel(i, 3) for i in range(e.stats()["num_layers"])]
+    e.close()
+    rel = float(np.linalg.norm(got - want) / np.linalg.norm(want))
+    print("lowered hard-swish graph %s: rel %.2e  max|prob diff| %.2e" % (prec, rel, float(np.abs(got[:, 4:] - want[:, 4:]).max())))
+    assert rel <= tol
+    assert sum("wsum_kernel" in k for k in kernels) == 12 and sum("se_gate" in k for k in kernels) == 2, kernels
+
+
+def test_hard_swish_is_not_a_convolution_epilogue(tmp_path):
+    """The conv kernels apply SiLU / ReLU / LeakyReLU only: a container whose convolution asks for hard-swish is refused at load time,
+    naming the layer -- never run with the activation silently dropped."""
+    ws = M.SynthWeights(1, gain=1.0)
+    g = M.Graph("bad", 3, 64, 64, ws)
+    x, cin = g.input()
+    y = g.conv(x, 16, 3, 2, "stem", act=M.ACT_HSWISH, true_cin=cin)
+    z = g.conv(y, 8, 1, 1, "tap", act=M.ACT_NONE, f32_out=True)
+    g.output(z, 0, [1, z.h * z.w * 8], "o")
+    path = str(tmp_path / "bad.hipm")
+    g.save(path)
+    with pytest.raises(Exception, match="not a convolution epilogue"):
+        CE.HipEngine(path, "fp16", 1)
+

@@ -227,6 +227,71 @@ def test_mbconv_blocks_with_squeeze_and_excitation(tmp_path):
     assert sum(o["type"] == M.OP_CONV and o["res_mode"] == M.RES_AFTER_ACT for o in g2.ops) == 2
 
 
+def lcnet_graph(hw=128):
+    """PP-LCNet-style backbone (the YOLOv5-lite-c family of the reference's model table): a hard-swish stem, depth-separable blocks
+    (depth-wise 3x3 / 5x5 -> hard-swish -> [squeeze-and-excitation with ReLU inside and a hard-sigmoid gate] -> 1x1 -> hard-swish), a
+    stand-alone hard-sigmoid, v8-layout head.  The convolutions carry no activation: every hard-swish is its own element-wise layer."""
+    ws = M.SynthWeights(12, gain=1.0)
+    g = M.Graph("lcnet", 3, hw, hw, ws)
+    x, cin = g.input()
+    x = g.act(g.conv(x, 16, 3, 2, "stem.conv", act=M.ACT_NONE, true_cin=cin), M.ACT_HSWISH, "stem.act")
+
+    def block(x, cout, k, s, se, nm):
+        t = g.act(g.dwconv(x, k, s, nm + ".dw", act=M.ACT_NONE), M.ACT_HSWISH, nm + ".dw_act")
+        if se:
+            t = g.se(t, max(8, t.c // 4), nm + ".se", hidden_act=M.ACT_RELU, gate_act=M.ACT_HSIGMOID)
+        return g.act(g.conv(t, cout, 1, 1, nm + ".pw", act=M.ACT_NONE), M.ACT_HSWISH, nm + ".pw_act")
+
+    x = block(x, 32, 3, 1, False, "b1")
+    x = block(x, 64, 3, 2, False, "b2")
+    p3 = block(x, 128, 3, 2, False, "b3")            # stride 8
+    p4 = block(p3, 256, 5, 2, True, "b4")            # stride 16, SE
+    p5 = block(p4, 256, 5, 2, True, "b5")            # stride 32, SE
+    p5 = g.conv(p5, 256, 1, 1, "neck.mix", act=M.ACT_NONE, res=g.act(p5, M.ACT_HSIGMOID, "neck.gate"), res_mode=M.RES_AFTER_ACT)   # a bare hard-sigmoid
+    ins, strides, nc = [], [], 8
+    for i, f in enumerate((p3, p4, p5)):
+        ins += [g.conv(f, 64, 1, 1, "head.cv2.%d" % i, act=M.ACT_NONE, f32_out=True), g.conv(f, nc, 1, 1, "head.cv3.%d" % i, act=M.ACT_NONE, f32_out=True)]
+        strides.append(hw // f.h)
+    A = sum(f.h * f.w for f in (p3, p4, p5))
+    head = g.buf(1, 1, (4 + nc) * A, f32=True)
+    g._op(M.OP_DETECT_V8, ins, head, params=[nc, A] + strides, name="decode")
+    g.output(head, 0, [1, 4 + nc, A], "output0")
+    return g
+
+
+@pytest.mark.parametrize("as_mul", [False, True], ids=["HardSwish", "x*HardSigmoid"])
+def test_hard_swish_network_lowers_to_elementwise_activation_layers(tmp_path, as_mul):
+    """torch.nn.Hardswish / Hardsigmoid (MobileNetV3 / PP-LCNet networks: YOLOv5-lite-c) have no conv epilogue: a HardSwish node -- or the
+    x * HardSigmoid(alpha 1/6) pair older opsets write -- behind a convolution becomes a ONE-input weighted-sum layer, the convolution
+    keeps ACT_NONE; the ReLU / hard-sigmoid squeeze-and-excitation becomes the gate op with its two activation codes."""
+    g = lcnet_graph()
+    path = tmp_path / "lcnet.onnx"
+    onnx_emit.emit(g, str(path), hswish_as_mul=as_mul)
+    m = OI.read_onnx(str(path))
+    ops = {nd["op"] for nd in m.nodes}
+    assert ("HardSwish" in ops) == (not as_mul) and "HardSigmoid" in ops
+    g2 = OL.lower(m, "t")
+    x = np.random.default_rng(0).uniform(0, 1, (2, 3, g.in_h, g.in_w)).astype(np.float32)
+    a, b = graph_interp.run(g, x)[0], graph_interp.run(g2, x)[0]
+    assert np.array_equal(a, b) and len(g2.ops) == len(g.ops)
+    acts = [o for o in g2.ops if o["type"] == M.OP_WSUM]
+    assert sum(o["act"] == M.ACT_HSWISH for o in acts) == 11 and sum(o["act"] == M.ACT_HSIGMOID for o in acts) == 1 and all(len(o["ins"]) == 1 for o in acts)
+    gates = [o for o in g2.ops if o["type"] == M.OP_SE_GATE]
+    assert [(int(o["params"][1]), int(o["params"][2])) for o in gates] == [(M.ACT_RELU, M.ACT_HSIGMOID)] * 2
+    assert all(o["act"] <= M.ACT_LEAKY for o in g2.ops if o["type"] in (M.OP_CONV, M.OP_DWCONV))
+    # ONNX's DEFAULT HardSigmoid (alpha 0.2) is another function: refused, not approximated
+    nodes = [OW.node("Conv", ["images", "w"], ["c"], "/c", [OW.attr_ints("kernel_shape", [3, 3]), OW.attr_ints("pads", [1, 1, 1, 1])]),
+             OW.node("HardSigmoid", ["c"], ["s"], "/act/HardSigmoid"),
+             OW.node("Conv", ["s", "w2"], ["o1"], "/h1", [OW.attr_ints("kernel_shape", [1, 1])]),
+             OW.node("Concat", ["o1", "o1"], ["cc"], "/cat", [OW.attr_int("axis", 1)]),
+             OW.node("Reshape", ["cc", "shp"], ["r"], "/r")]
+    inits = [OW.tensor("w", np.zeros((8, 3, 3, 3), np.float32)), OW.tensor("w2", np.zeros((64, 8, 1, 1), np.float32)), OW.tensor("shp", np.asarray([1, 128, -1], np.int64))]
+    bad = tmp_path / "bad.onnx"
+    open(bad, "wb").write(OW.model(nodes, inits, [("images", [1, 3, 32, 32])], [("r", [1, 128, 1024])]))
+    with pytest.raises(ValueError, match="HardSigmoid|Detect head"):
+        OL.lower(OI.read_onnx(str(bad)))
+
+
 def test_efficientdet_d0_head_only_export_round_trip(tmp_path):
     """The whole EfficientDet-D0 graph (253 operators: MBConv + squeeze-and-excitation, three BiFPN cells, shared separable heads) written as a
     head-only ONNX export -- two outputs, box regression (1, A, 4) and class logits (1, A, 90) as axis-1 Concats of per-level

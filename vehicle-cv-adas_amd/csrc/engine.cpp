@@ -285,7 +285,14 @@ int adas_engine_create(const char* model_path, int precision, int max_batch, ada
         else if (o.type == OP_WSUM) {
             TView ins[3];
             for (uint32_t k = 0; k < o.n_in && k < 3; ++k) ins[k] = view(o.in_buf[k], o.in_coff[k], o.in_c[k]);
-            ok = o.n_in <= 3 && wsum_supported((int)o.n_in, ins, view(o.out_buf, o.out_coff, o.out_c));
+            ok = o.n_in <= 3 && wsum_supported((int)o.n_in, ins, view(o.out_buf, o.out_coff, o.out_c)) && o.act <= ACT_HSIGMOID;
+        }
+        if ((o.type == OP_CONV || o.type == OP_DWCONV) && o.act > ACT_LEAKY) {   // hard-swish / hard-sigmoid: element-wise layers only (kernels.h)
+            fclose(f);
+            free_engine(e);
+            set_error("[%s]: layer %s: activation %u is not a convolution epilogue (lower it as a one-input weighted-sum layer)", model_path,
+                      std::string(o.name, strnlen(o.name, sizeof(o.name))).c_str(), o.act);
+            return ADAS_ERR_FORMAT;
         }
         if (!ok) {
             fclose(f);
@@ -1099,8 +1106,8 @@ int engine_run_op(adas_engine* e, int i, const float* d_in, int batch, hipStream
             TView scratch{};
             const bool has_scratch = o.res_buf >= 0 && o.res_buf < (int32_t)e->bufs.size();   // res_buf: the per-frame scratch of the two-launch form
             if (has_scratch) scratch = make_view(e, o.res_buf, 0, e->bufs[o.res_buf].c);
-            err = launch_se_gate(make_view(e, o.in_buf[0], o.in_coff[0], o.in_c[0]), make_view(e, o.out_buf, o.out_coff, o.out_c), w1, w2, (int)o.params[0], batch,
-                                 e->prec, st, has_scratch ? &scratch : nullptr);
+            err = launch_se_gate(make_view(e, o.in_buf[0], o.in_coff[0], o.in_c[0]), make_view(e, o.out_buf, o.out_coff, o.out_c), w1, w2, (int)o.params[0],
+                                 (int)o.params[1], (int)o.params[2], batch, e->prec, st, has_scratch ? &scratch : nullptr);
             break;
         }
         case OP_SCALE:

@@ -3,7 +3,8 @@
 // squeeze-and-excitation gate, BiFPN nodes are weighted sums of 2-3 maps at one resolution):
 //   se_gate   gate[n][c] = sigmoid(W2 silu(W1 mean_hw(x[n]) + b1) + b2)           (OP_SE_GATE; fp32 arithmetic in every precision)
 //   scale     out[n][p][c] = x[n][p][c] * gate[n][c]                                (OP_SCALE)
-//   wsum      out = act(w0 a + w1 b [+ w2 c]), an input of half the output's resolution is read at (y / 2, x / 2)
+//   wsum      out = act(w0 a [+ w1 b [+ w2 c]]), an input of half the output's resolution is read at (y / 2, x / 2); with ONE input it is the
+//             stand-alone activation layer (hard-swish / hard-sigmoid networks: those two live only here, not in the conv epilogues)
 //             (nearest 2x upsample folded into the loads)                            (OP_WSUM: BiFPN fast normalised fusion, the
 //             weights are constants at inference: relu(w_i) / (sum_j relu(w_j) + 1e-4))
 // All HBM-bound streaming: thread = (pixel, 8-channel group), 16-byte loads (16-bit modes), fp32 arithmetic, one pass.
@@ -23,6 +24,7 @@ struct SeDev {
     int c, cr, HW, S;    // S: pixel stripes (1024 / (c / 8))
     float* part;         // two-launch form: [n][P][c] partial channel sums written by se_partial_kernel (null: this kernel sums the frame itself)
     int P;
+    int act_hidden, act_gate;   // ACT_SILU | ACT_RELU; 0 (sigmoid) | ACT_HSIGMOID
 };
 
 // Partial channel sums of pixel range p of frame b (grid = n * P workgroups): one workgroup per frame leaves 64 of 256 CUs busy on a
@@ -99,14 +101,14 @@ __global__ __launch_bounds__(1024) void se_gate_kernel(SeDev d) {
         for (int o = 32; o >= 1; o >>= 1) a += __shfl_xor(a, o);
         if (lane == 0) {
             const float v = a + d.w1[(size_t)d.cr * d.c + j];
-            hid[j] = v / (1.0f + expf(-v));
+            hid[j] = d.act_hidden == ACT_RELU ? fmaxf(v, 0.0f) : v / (1.0f + expf(-v));
         }
     }
     __syncthreads();
     for (int ch = t; ch < d.c; ch += 1024) {
         float v = d.w2[(size_t)d.c * d.cr + ch];
         for (int j = 0; j < d.cr; ++j) v = fmaf(d.w2[(size_t)ch * d.cr + j], hid[j], v);
-        d.gate[(size_t)n * d.gate_cs + d.gate_coff + ch] = 1.0f / (1.0f + expf(-v));
+        d.gate[(size_t)n * d.gate_cs + d.gate_coff + ch] = d.act_gate == ACT_HSIGMOID ? fminf(fmaxf(v + 3.0f, 0.0f), 6.0f) / 6.0f : 1.0f / (1.0f + expf(-v));
     }
 }
 
@@ -116,8 +118,11 @@ bool se_gate_supported(const TView& in, const TView& gate, int cr, uint64_t w_el
     return w_elems == (uint64_t)cr * in.c + cr && b_elems == (uint64_t)in.c * cr + in.c;
 }
 
-hipError_t launch_se_gate(const TView& in, const TView& gate, const float* w1, const float* w2, int cr, int n, int prec, hipStream_t st, const TView* scratch) {
+hipError_t launch_se_gate(const TView& in, const TView& gate, const float* w1, const float* w2, int cr, int act_hidden, int act_gate, int n, int prec, hipStream_t st,
+                          const TView* scratch) {
+    if ((act_hidden != 0 && act_hidden != ACT_SILU && act_hidden != ACT_RELU) || (act_gate != 0 && act_gate != ACT_HSIGMOID)) return hipErrorInvalidValue;
     SeDev d;
+    d.act_hidden = act_hidden == ACT_RELU ? ACT_RELU : ACT_SILU; d.act_gate = act_gate;
     d.part = nullptr; d.P = 0;
     d.in = in.p; d.gate = (float*)gate.p; d.w1 = w1; d.w2 = w2;
     d.in_cs = in.cs; d.in_coff = in.coff; d.gate_cs = gate.cs; d.gate_coff = gate.coff;
@@ -295,13 +300,19 @@ __global__ __launch_bounds__(256) void wsum_kernel(WsDev d) {
         } else if (d.act == ACT_LEAKY) {   // LeakyReLU(0.1), the form conv_halo / conv_pw apply
 #pragma unroll
             for (int e = 0; e < 8; ++e) acc[e] = fmaxf(acc[e], 0.1f * acc[e]);
+        } else if (d.act == ACT_HSWISH) {  // torch.nn.Hardswish: x * relu6(x + 3) / 6
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[e] = acc[e] * fminf(fmaxf(acc[e] + 3.0f, 0.0f), 6.0f) / 6.0f;
+        } else if (d.act == ACT_HSIGMOID) {   // torch.nn.Hardsigmoid: relu6(x + 3) / 6
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[e] = fminf(fmaxf(acc[e] + 3.0f, 0.0f), 6.0f) / 6.0f;
         }
         Vec8<T>::store((T*)d.out + pix * d.out_cs + d.out_coff + g * 8, acc);
     }
 }
 
 bool wsum_supported(int n_in, const TView* ins, const TView& out) {
-    if (n_in < 2 || n_in > 3 || out.f32 || (out.c & 7) || (out.cs & 7) || (out.coff & 7)) return false;
+    if (n_in < 1 || n_in > 3 || out.f32 || (out.c & 7) || (out.cs & 7) || (out.coff & 7)) return false;
     for (int k = 0; k < n_in; ++k) {
         const TView& v = ins[k];
         if (v.f32 || v.c != out.c || (v.cs & 7) || (v.coff & 7)) return false;
@@ -313,7 +324,7 @@ bool wsum_supported(int n_in, const TView* ins, const TView& out) {
 
 hipError_t launch_wsum(int n_in, const TView* ins, const float* w, const TView& out, int n, int act, int prec, hipStream_t st) {
     if (!wsum_supported(n_in, ins, out)) return hipErrorInvalidValue;
-    if (act != ACT_NONE && act != ACT_SILU && act != ACT_RELU && act != ACT_LEAKY) return hipErrorInvalidValue;   // never a silently dropped activation
+    if (act < ACT_NONE || act > ACT_HSIGMOID) return hipErrorInvalidValue;   // never a silently dropped activation
     WsDev d;
     for (int k = 0; k < 3; ++k) {
         const TView& v = ins[k < n_in ? k : 0];

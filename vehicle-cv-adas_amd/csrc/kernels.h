@@ -9,7 +9,10 @@ enum { PREC_BF16 = 0, PREC_FP32 = 1, PREC_FP16 = 2, PREC_X3 = 3 };  // == ADAS_P
 inline bool prec_is16(int prec) { return prec == PREC_BF16 || prec == PREC_FP16; }   // bf16 and fp16 share every 16-bit kernel (elem16.h)
 // bytes per activation / weight element: the split precision stores a (hi, lo) pair of halves per element (elem16.h, x3s)
 inline int prec_esize(int prec) { return prec_is16(prec) ? 2 : 4; }
-enum { ACT_NONE = 0, ACT_SILU = 1, ACT_RELU = 2, ACT_LEAKY = 3 /* LeakyReLU(0.1): YOLOv7 (conv_halo, conv_pw, conv_pwg, conv_igemm) */ };
+enum { ACT_NONE = 0, ACT_SILU = 1, ACT_RELU = 2, ACT_LEAKY = 3 /* LeakyReLU(0.1): YOLOv7 (conv_halo, conv_pw, conv_pwg, conv_igemm) */,
+       // element-wise only (OP_WSUM with one input = a stand-alone activation layer; OP_SE_GATE's gate): the conv epilogues do not carry them and
+       // the engine refuses a convolution that asks for one (PP-LCNet / MobileNetV3-style networks: torch.nn.Hardswish / Hardsigmoid)
+       ACT_HSWISH = 4 /* x relu6(x + 3) / 6 */, ACT_HSIGMOID = 5 /* relu6(x + 3) / 6 */ };
 enum { RES_NONE = 0, RES_AFTER_ACT = 1, RES_BEFORE_ACT = 2 };
 
 // Workgroups per XCD the PERSISTENT kernels (conv_halo8, conv_halo_rw, conv_stem: one resident workgroup set walking a work list) launch:
@@ -194,7 +197,8 @@ hipError_t launch_pack_weights_fc(const float* src, void* dst, int cout, int cou
 // dw_attn.hip: depth-wise k x k conv (k = 3 | 7, stride 1 | 2, pad k/2; weights fp32 [k*k][C], bias fp32 [C]; residual: RES_AFTER_ACT only)
 // fuse_ops.hip: EfficientDet's element-wise operators (squeeze-and-excitation gate, channel scale, BiFPN weighted sum)
 bool se_gate_supported(const TView& in, const TView& gate, int cr, uint64_t w_elems, uint64_t b_elems);
-hipError_t launch_se_gate(const TView& in, const TView& gate, const float* w1, const float* w2, int cr, int n, int prec, hipStream_t st,
+// act_hidden: ACT_SILU (0 means SiLU too: files written before the field existed) | ACT_RELU; act_gate: 0 = sigmoid | ACT_HSIGMOID
+hipError_t launch_se_gate(const TView& in, const TView& gate, const float* w1, const float* w2, int cr, int act_hidden, int act_gate, int n, int prec, hipStream_t st,
                           const TView* scratch = nullptr);   // scratch: fp32 1x1x(P*C) per frame -> P pixel ranges summed by their own launch
 bool scale_supported(const TView& in, const TView& gate, const TView& out);
 hipError_t launch_scale(const TView& in, const TView& gate, const TView& out, int n, int prec, hipStream_t st);

@@ -25,6 +25,7 @@ MAGIC = b"ADASHIP1"
 (OP_INPUT, OP_CONV, OP_MAXPOOL, OP_UPSAMPLE2, OP_DETECT_V8, OP_DETECT_V5, OP_LAYERNORM, OP_DWCONV, OP_ATTENTION, OP_AVGPOOL, OP_DEPTH2SPACE,
  OP_DETECT_V6, OP_SE_GATE, OP_SCALE, OP_WSUM, OP_SHUFFLE) = range(16)
 ACT_NONE, ACT_SILU, ACT_RELU, ACT_LEAKY = 0, 1, 2, 3      # ACT_LEAKY: LeakyReLU(0.1) (YOLOv7)
+ACT_HSWISH, ACT_HSIGMOID = 4, 5    # torch.nn.Hardswish / Hardsigmoid: ELEMENT-WISE layers only (Graph.act, the gate of Graph.se), never a conv epilogue
 RES_NONE, RES_AFTER_ACT, RES_BEFORE_ACT = 0, 1, 2
 BUF_F32 = 1
 BUF_ALIAS = 2      # flags bit 1: this buffer is another view of buffer (flags >> 8) - same bytes, different (h, w, c)
@@ -301,8 +302,9 @@ class Graph:
         self._op(OP_UPSAMPLE2, [x], out, name=name)
         return out
 
-    def se(self, x, cr, name, out=None):
-        """Squeeze-and-excitation (EfficientNet MBConv): x * sigmoid(W2 silu(W1 mean_hw(x) + b1) + b2), squeeze width cr.  Parameters
+    def se(self, x, cr, name, out=None, hidden_act=ACT_SILU, gate_act=ACT_NONE):
+        """Squeeze-and-excitation (EfficientNet MBConv): x * sigmoid(W2 silu(W1 mean_hw(x) + b1) + b2), squeeze width cr; hidden_act =
+        ACT_RELU and gate_act = ACT_HSIGMOID give the MobileNetV3 / PP-LCNet form x * hardsigmoid(W2 relu(W1 mean + b1) + b2).  Parameters
         'name.reduce.{weight,bias}' (cr, C, 1, 1) and 'name.expand.{weight,bias}' (C, cr, 1, 1).  Two launches: the gate (one fp32 value
         per frame and channel, fp32 arithmetic in every precision) and the channel scale."""
         c = x.c
@@ -314,7 +316,7 @@ class Graph:
         # the sums are the same stripes in another grouping -- fp32, ~1e-7 apart)
         scratch = self.buf(1, 1, 16 * c, f32=True) if x.h * x.w >= 1024 and c <= 2048 else None
         self._op(OP_SE_GATE, [x], gate, w=self._blob(np.concatenate([W1.ravel(), b1])), b=self._blob(np.concatenate([W2.ravel(), b2])),
-                 res=scratch, params=[cr], flops=x.h * x.w * c + 4.0 * c * cr, name=name + ".gate")
+                 res=scratch, params=[cr, 0 if hidden_act == ACT_SILU else hidden_act, gate_act], flops=x.h * x.w * c + 4.0 * c * cr, name=name + ".gate")
         if out is None:
             out = self.buf(x.h, x.w, c)
         assert (out.h, out.w, out.c) == (x.h, x.w, c)
@@ -325,8 +327,8 @@ class Graph:
     def wsum(self, ins, weights, name, act=ACT_SILU, out=None):
         """act(sum_i weights[i] * ins[i]) over 2-3 maps of one width; an input of half the output's resolution is read through a nearest
         2x upsample (BiFPN top-down nodes).  The output resolution is that of the largest input."""
-        assert 2 <= len(ins) <= 3 and len(weights) == len(ins)
-        assert act in (ACT_NONE, ACT_SILU, ACT_RELU, ACT_LEAKY), (name, act)   # the kernel applies exactly these (fuse_ops.hip wsum_kernel)
+        assert 1 <= len(ins) <= 3 and len(weights) == len(ins)
+        assert act in (ACT_NONE, ACT_SILU, ACT_RELU, ACT_LEAKY, ACT_HSWISH, ACT_HSIGMOID), (name, act)   # the kernel applies exactly these (fuse_ops.hip wsum_kernel)
         h, w, c = max(v.h for v in ins), max(v.w for v in ins), ins[0].c
         for v in ins:
             assert v.c == c and ((v.h, v.w) == (h, w) or (2 * v.h, 2 * v.w) == (h, w)), (name, (v.h, v.w, v.c), (h, w, c))
@@ -335,6 +337,11 @@ class Graph:
         assert (out.h, out.w, out.c) == (h, w, c)
         self._op(OP_WSUM, list(ins), out, act=act, params=[float(np.float32(x)) for x in weights], flops=2.0 * len(ins) * h * w * c, name=name)
         return out
+
+    def act(self, x, act, name, out=None):
+        """A stand-alone activation layer (one-input weighted sum): how hard-swish / hard-sigmoid networks run -- the convolution in front
+        keeps ACT_NONE and this layer applies the function (the conv epilogues carry SiLU / ReLU / LeakyReLU only)."""
+        return self.wsum([x], [1.0], name, act=act, out=out)
 
     def shuffle(self, x, groups, name, out=None):
         """torch channel_shuffle(x, groups) (ShuffleNetV2 units): out channel j * groups + i = in channel i * (C / groups) + j."""

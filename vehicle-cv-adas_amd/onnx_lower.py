@@ -7,6 +7,8 @@ ad-hoc CSP network -- goes through this module: the node list is walked once and
 
     Conv [+ Sigmoid, Mul | Relu | LeakyRelu(0.1)] [+ Add]      -> OP_CONV with a fused activation and residual (either order)
     Conv with group == channels                                 -> OP_DWCONV
+    HardSwish | x * HardSigmoid(1/6) | HardSigmoid(1/6)         -> a one-input OP_WSUM (a stand-alone activation layer: the conv in front keeps ACT_NONE)
+    GlobalAveragePool -> Conv -> swish | Relu -> Conv -> Sigmoid | HardSigmoid -> Mul(x, .)   -> OP_SE_GATE + OP_SCALE
     MaxPool / AveragePool(count_include_pad) / Resize(nearest x2) / ConvTranspose(k 2, s 2)
     Concat(axis 1) / Split(axis 1) / Slice(axis 1)              -> no op at all: producers write channel slices of one buffer, consumers read views
     the Detect tail                                             -> OP_DETECT_V8 (three Concat[box, cls] -> Reshape pairs feeding one axis-2 Concat;
@@ -102,8 +104,9 @@ class _Lowering:
             if nd["op"] == "LeakyRelu" and abs(float(nd["attrs"].get("alpha", 0.01)) - 0.1) < 1e-6:
                 used.add(i)
                 return M.ACT_LEAKY, nd["outputs"][0]
-            if nd["op"] == "HardSwish" or nd["op"] == "Clip":
+            if nd["op"] == "Clip":
                 raise LowerError("node %s: activation %s has no kernel" % (nd["name"], nd["op"]))
+            # (HardSwish / HardSigmoid behind a convolution: the conv keeps ACT_NONE, the node becomes its own element-wise layer)
         return M.ACT_NONE, t
 
     def _macro_ops(self):
@@ -170,6 +173,16 @@ class _Lowering:
             elif op == "GlobalAveragePool":
                 rec = self._match_se(i, used)
                 ops.append(("se", i, rec) if rec is not None else ("other", i, {}))
+            elif op == "HardSwish" or (op == "HardSigmoid" and self._is_torch_hardsigmoid(nd)):
+                # torch.nn.Hardswish / Hardsigmoid: a stand-alone activation layer = a ONE-input weighted sum (fuse_ops.hip wsum_kernel; the conv
+                # epilogues do not carry these).  Exports below opset 14 write hard-swish as x * HardSigmoid(x).
+                x, out, act = nd["inputs"][0], nd["outputs"][0], M.ACT_HSWISH if op == "HardSwish" else M.ACT_HSIGMOID
+                if op == "HardSigmoid":
+                    j = self._single_consumer(out, "Mul")
+                    if j is not None and sorted(self.nodes[j]["inputs"]) == sorted([x, out]):
+                        used.add(j)
+                        act, out = M.ACT_HSWISH, self.nodes[j]["outputs"][0]
+                ops.append(("wsum", i, dict(terms=[(x, 1.0, False)], act=act, out=out, name=(nd["name"].strip("/").replace("/", ".") or "act%d" % i)[-47:])))
             elif op == "Add" and self._is_free_sum(nd):
                 # a stand-alone sum of feature maps (BiFPN fusion node, CBFuse, an identity shortcut around a block): the chain of Adds,
                 # the constant scale in front of a term (Mul by a scalar initializer), a nearest x2 Resize that only this sum reads and the
@@ -295,7 +308,7 @@ class _Lowering:
             return None
         tmp = set()
         act, a = self._absorb_act(c1["outputs"][0], tmp)
-        if act != M.ACT_SILU:
+        if act not in (M.ACT_SILU, M.ACT_RELU):      # EfficientNet: swish; MobileNetV3 / PP-LCNet: ReLU
             return None
         j2 = self._single_consumer(a, "Conv")
         if j2 is None:
@@ -305,9 +318,11 @@ class _Lowering:
         b2 = _const(self.m, c2["inputs"][2]) if len(c2["inputs"]) > 2 and c2["inputs"][2] else None
         if w2 is None or tuple(np.asarray(w2).shape[2:]) != (1, 1) or np.asarray(w2).shape[:2] != np.asarray(w1).shape[1::-1]:
             return None
-        j3 = self._single_consumer(c2["outputs"][0], "Sigmoid")
+        j3, gate_act = self._single_consumer(c2["outputs"][0], "Sigmoid"), M.ACT_NONE
         if j3 is None:
-            return None
+            j3, gate_act = self._single_consumer(c2["outputs"][0], "HardSigmoid"), M.ACT_HSIGMOID
+            if j3 is None or not self._is_torch_hardsigmoid(self.nodes[j3]):
+                return None
         j4 = self._single_consumer(self.nodes[j3]["outputs"][0], "Mul")
         if j4 is None or sorted(self.nodes[j4]["inputs"]) != sorted([x, self.nodes[j3]["outputs"][0]]):
             return None
@@ -316,9 +331,14 @@ class _Lowering:
         w1, w2 = np.asarray(w1, np.float32), np.asarray(w2, np.float32)
         name = self._layer_name(c1)
         name = name[:-len(".reduce")] if name.endswith(".reduce") else name
-        return dict(x=x, out=self.nodes[j4]["outputs"][0], name=name[-40:], w1=w1, w2=w2,
+        return dict(x=x, out=self.nodes[j4]["outputs"][0], name=name[-40:], w1=w1, w2=w2, hidden_act=act, gate_act=gate_act,
                     b1=np.asarray(b1, np.float32) if b1 is not None else np.zeros(w1.shape[0], np.float32),
                     b2=np.asarray(b2, np.float32) if b2 is not None else np.zeros(w2.shape[0], np.float32))
+
+    @staticmethod
+    def _is_torch_hardsigmoid(nd):
+        """HardSigmoid(alpha = 1/6, beta = 0.5) = relu6(x + 3) / 6, torch.nn.Hardsigmoid (ONNX's default alpha is 0.2: another function)."""
+        return abs(float(nd["attrs"].get("alpha", 0.2)) - 1.0 / 6.0) < 1e-6 and abs(float(nd["attrs"].get("beta", 0.5)) - 0.5) < 1e-6
 
     # ---- stand-alone sums
     def _is_free_sum(self, nd):
@@ -707,7 +727,7 @@ class _Lowering:
             elif kind == "se":
                 n_ = rec["name"]
                 g.w = M.DictWeights({n_ + ".reduce.weight": rec["w1"], n_ + ".reduce.bias": rec["b1"], n_ + ".expand.weight": rec["w2"], n_ + ".expand.bias": rec["b2"]})
-                g.se(self._view(rec["x"]), rec["w1"].shape[0], n_, out=self._view(rec["out"], make=True))
+                g.se(self._view(rec["x"]), rec["w1"].shape[0], n_, out=self._view(rec["out"], make=True), hidden_act=rec["hidden_act"], gate_act=rec["gate_act"])
             elif kind == "wsum":
                 views = [self._view(t_) for t_, _, _ in rec["terms"]]
                 g.wsum(views, [w_ for _, w_, _ in rec["terms"]], rec["name"], act=rec["act"], out=self._view(rec["out"], make=True))
