@@ -401,7 +401,7 @@ typedef struct {
     int32_t reserved;
 } adas_bytetrack_params;
 
-typedef struct {          /* base_track.py:61-72 + strack.py:207-215 (crops/location not carried) */
+typedef struct {          /* base_track.py:61-72 + strack.py:207-215 (crops stay on the host; trajectories: adas_bytetrack_fetch_trajectories) */
     double tlwh[4];       /* STrack.tlwh (Kalman-filtered) */
     double score;
     int32_t track_id, state, is_activated, class_id;
