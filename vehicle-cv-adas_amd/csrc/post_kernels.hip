@@ -321,6 +321,13 @@ __global__ __launch_bounds__(256) void bytetrack_reset_kernel(BtDev d) {
 // =====================================================================================
 // C ABI
 // =====================================================================================
+constexpr int LGEO_MSG_INTS = 8 + 4 + 4 * ADAS_LANE_MAXPTS * 2;      // header, two doubles (as 4 ints), bird points
+__global__ __launch_bounds__(256) void lane_geometry_pack_kernel(const int* hdr, const double* vals, const int* bird, int frame, int* msg) {
+    const int t = threadIdx.x;
+    if (t < 8) msg[t] = hdr[(size_t)frame * 8 + t];
+    if (t < 4) msg[8 + t] = reinterpret_cast<const int*>(vals + (size_t)frame * 2)[t];
+    for (int i = t; i < 4 * ADAS_LANE_MAXPTS * 2; i += blockDim.x) msg[12 + i] = bird[(size_t)frame * 4 * ADAS_LANE_MAXPTS * 2 + i];
+}
 constexpr int UFLD_MSG_INTS = 8 + 4 * ADAS_UFLD_MAXPTS * 2;
 __global__ __launch_bounds__(256) void ufld_pack_kernel(const int* cnt, const int* det, const int* pts, int frame, int* msg) {
     const int t = threadIdx.x;
@@ -433,6 +440,8 @@ struct adas_lane_geometry {
     int max_batch;
     LaneGeomDev dev;
     void* arena;
+    int* msg = nullptr;     // one frame's fixed-size results as one message: [8 header ints][2 doubles][4 x MAXPTS x 2 bird points] (device) ...
+    int* h_msg = nullptr;   // ... and its pinned landing buffer (adas_lane_geometry_fetch: one copy + the area polygon instead of four)
     hipStream_t last;
 };
 struct adas_bytetrack {
@@ -1097,6 +1106,8 @@ int adas_lane_geometry_create(const adas_lane_geometry_params* p, int max_batch,
 }
 int adas_lane_geometry_destroy(adas_lane_geometry* h) {
     if (!h) return ADAS_OK;
+    if (h->msg) hipFree(h->msg);
+    if (h->h_msg) hipHostFree(h->h_msg);
     hipFree(h->arena);
     delete h;
     return ADAS_OK;
@@ -1123,20 +1134,24 @@ int adas_lane_geometry_run(adas_lane_geometry* h, const adas_ufld_decode* decode
 }
 int adas_lane_geometry_fetch(adas_lane_geometry* h, int frame, adas_lane_geometry_result* res, int32_t* area_points, int32_t* bird_points) {
     ADAS_REQUIRE(h && res && frame >= 0 && frame < h->max_batch, ADAS_ERR_INVALID, "adas_lane_geometry_fetch: bad argument");
-    ADAS_HIP_TRY(hipStreamSynchronize(h->last));
     const LaneGeomDev& d = h->dev;
+    if (!h->msg) ADAS_HIP_TRY(hipMalloc((void**)&h->msg, LGEO_MSG_INTS * 4));          // first fetch: the message buffers
+    if (!h->h_msg) ADAS_HIP_TRY(hipHostMalloc((void**)&h->h_msg, LGEO_MSG_INTS * 4, hipHostMallocDefault));
+    lane_geometry_pack_kernel<<<1, 256, 0, h->last>>>(d.hdr, d.vals, d.bird, frame, h->msg);   // behind the geometry kernel on its stream
+    ADAS_HIP_TRY(hipGetLastError());
+    ADAS_HIP_TRY(hipMemcpyAsync(h->h_msg, h->msg, LGEO_MSG_INTS * 4, hipMemcpyDeviceToHost, h->last));
+    ADAS_HIP_TRY(hipStreamSynchronize(h->last));
     int hdr[8];
     double vals[2];
-    ADAS_HIP_TRY(hipMemcpy(hdr, d.hdr + (size_t)frame * 8, sizeof(hdr), hipMemcpyDeviceToHost));
-    ADAS_HIP_TRY(hipMemcpy(vals, d.vals + (size_t)frame * 2, sizeof(vals), hipMemcpyDeviceToHost));
+    memcpy(hdr, h->h_msg, sizeof(hdr));
+    memcpy(vals, h->h_msg + 8, sizeof(vals));
     res->area_status = hdr[0]; res->n_area_left = hdr[1]; res->n_area_right = hdr[2]; res->direction = hdr[3];
     for (int l = 0; l < 4; ++l) res->bird_counts[l] = hdr[4 + l];
     res->curvature = vals[0]; res->offset = vals[1];
     const size_t H = d.cfg.img_h;
     if (area_points && hdr[1] + hdr[2] > 0)
         ADAS_HIP_TRY(hipMemcpy(area_points, d.area + (size_t)frame * 4 * H, (size_t)(hdr[1] + hdr[2]) * 8, hipMemcpyDeviceToHost));
-    if (bird_points)
-        ADAS_HIP_TRY(hipMemcpy(bird_points, d.bird + (size_t)frame * 4 * ADAS_LANE_MAXPTS * 2, 4 * ADAS_LANE_MAXPTS * 2 * 4, hipMemcpyDeviceToHost));
+    if (bird_points) memcpy(bird_points, h->h_msg + 12, 4 * ADAS_LANE_MAXPTS * 2 * 4);
     return ADAS_OK;
 }
 
