@@ -26,6 +26,8 @@ def _act(y, act):
         return F.hardswish(y)
     if act == M.ACT_HSIGMOID:
         return F.hardsigmoid(y)
+    if act == M.ACT_RELU6:
+        return F.relu6(y)
     assert act == M.ACT_NONE, act
     return y
 

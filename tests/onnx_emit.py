@@ -289,6 +289,15 @@ class Emitter:
                     y = self.name("act")
                     self.node("HardSigmoid", [acc], [y], [OW.attr_float("alpha", 1.0 / 6.0), OW.attr_float("beta", 0.5)])
                     acc = y
+                elif op["act"] == M.ACT_RELU6:          # torch.nn.ReLU6 exports as Clip(x, 0, 6): bounds as inputs (opset >= 11) or attributes
+                    y = self.name("act")
+                    if self.hswish_as_mul:              # (the "older export" switch)
+                        self.node("Clip", [acc], [y], [OW.attr_float("min", 0.0), OW.attr_float("max", 6.0)])
+                    else:
+                        lo, hi = self.name("clip_lo"), self.name("clip_hi")
+                        self.inits += [OW.tensor(lo, np.asarray(0.0, np.float32).reshape(())), OW.tensor(hi, np.asarray(6.0, np.float32).reshape(()))]
+                        self.node("Clip", [acc, lo, hi], [y])
+                    acc = y
                 else:
                     assert op["act"] == M.ACT_NONE, op["act"]
                 self.wrote(out, acc)

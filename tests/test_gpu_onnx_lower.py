@@ -135,7 +135,7 @@ def test_hard_swish_network_onnx_runs_through_hipengine(tmp_path, prec, tol):
     rel = float(np.linalg.norm(got - want) / np.linalg.norm(want))
     print("lowered hard-swish graph %s: rel %.2e  max|prob diff| %.2e" % (prec, rel, float(np.abs(got[:, 4:] - want[:, 4:]).max())))
     assert rel <= tol
-    assert sum("wsum_kernel" in k for k in kernels) == 12 and sum("se_gate" in k for k in kernels) == 2, kernels
+    assert sum("wsum_kernel" in k for k in kernels) == 14 and sum("se_gate" in k for k in kernels) == 2, kernels      # 11 hard-swish, 1 hard-sigmoid, 2 ReLU6
 
 
 def test_hard_swish_is_not_a_convolution_epilogue(tmp_path):

@@ -243,6 +243,9 @@ def lcnet_graph(hw=128):
         return g.act(g.conv(t, cout, 1, 1, nm + ".pw", act=M.ACT_NONE), M.ACT_HSWISH, nm + ".pw_act")
 
     x = block(x, 32, 3, 1, False, "b1")
+    t = g.act(g.conv(x, 96, 1, 1, "ir.expand", act=M.ACT_NONE), M.ACT_RELU6, "ir.expand_act")          # a MobileNetV2 inverted residual: ReLU6
+    t = g.act(g.dwconv(t, 3, 1, "ir.dw", act=M.ACT_NONE), M.ACT_RELU6, "ir.dw_act")
+    x = g.conv(t, 32, 1, 1, "ir.project", act=M.ACT_NONE, res=x, res_mode=M.RES_AFTER_ACT)
     x = block(x, 64, 3, 2, False, "b2")
     p3 = block(x, 128, 3, 2, False, "b3")            # stride 8
     p4 = block(p3, 256, 5, 2, True, "b4")            # stride 16, SE
@@ -261,7 +264,7 @@ def lcnet_graph(hw=128):
 
 @pytest.mark.parametrize("as_mul", [False, True], ids=["HardSwish", "x*HardSigmoid"])
 def test_hard_swish_network_lowers_to_elementwise_activation_layers(tmp_path, as_mul):
-    """torch.nn.Hardswish / Hardsigmoid (MobileNetV3 / PP-LCNet networks: YOLOv5-lite-c) have no conv epilogue: a HardSwish node -- or the
+    """torch.nn.Hardswish / Hardsigmoid / ReLU6 (MobileNetV3 / PP-LCNet / MobileNetV2 networks: YOLOv5-lite-c) have no conv epilogue: a HardSwish node -- or the
     x * HardSigmoid(alpha 1/6) pair older opsets write -- behind a convolution becomes a ONE-input weighted-sum layer, the convolution
     keeps ACT_NONE; the ReLU / hard-sigmoid squeeze-and-excitation becomes the gate op with its two activation codes."""
     g = lcnet_graph()
@@ -276,19 +279,21 @@ def test_hard_swish_network_lowers_to_elementwise_activation_layers(tmp_path, as
     assert np.array_equal(a, b) and len(g2.ops) == len(g.ops)
     acts = [o for o in g2.ops if o["type"] == M.OP_WSUM]
     assert sum(o["act"] == M.ACT_HSWISH for o in acts) == 11 and sum(o["act"] == M.ACT_HSIGMOID for o in acts) == 1 and all(len(o["ins"]) == 1 for o in acts)
+    assert sum(o["act"] == M.ACT_RELU6 for o in acts) == 2          # Clip(x, 0, 6), bounds as inputs or (older exports) as attributes
     gates = [o for o in g2.ops if o["type"] == M.OP_SE_GATE]
     assert [(int(o["params"][1]), int(o["params"][2])) for o in gates] == [(M.ACT_RELU, M.ACT_HSIGMOID)] * 2
     assert all(o["act"] <= M.ACT_LEAKY for o in g2.ops if o["type"] in (M.OP_CONV, M.OP_DWCONV))
     # ONNX's DEFAULT HardSigmoid (alpha 0.2) is another function: refused, not approximated
     nodes = [OW.node("Conv", ["images", "w"], ["c"], "/c", [OW.attr_ints("kernel_shape", [3, 3]), OW.attr_ints("pads", [1, 1, 1, 1])]),
-             OW.node("HardSigmoid", ["c"], ["s"], "/act/HardSigmoid"),
+             OW.node("HardSigmoid", ["c"], ["s"], "/act/HardSigmoid") if not as_mul else
+             OW.node("Clip", ["c"], ["s"], "/act/Clip", [OW.attr_float("min", -1.0), OW.attr_float("max", 1.0)]),     # a Clip that is not ReLU6
              OW.node("Conv", ["s", "w2"], ["o1"], "/h1", [OW.attr_ints("kernel_shape", [1, 1])]),
              OW.node("Concat", ["o1", "o1"], ["cc"], "/cat", [OW.attr_int("axis", 1)]),
              OW.node("Reshape", ["cc", "shp"], ["r"], "/r")]
     inits = [OW.tensor("w", np.zeros((8, 3, 3, 3), np.float32)), OW.tensor("w2", np.zeros((64, 8, 1, 1), np.float32)), OW.tensor("shp", np.asarray([1, 128, -1], np.int64))]
     bad = tmp_path / "bad.onnx"
     open(bad, "wb").write(OW.model(nodes, inits, [("images", [1, 3, 32, 32])], [("r", [1, 128, 1024])]))
-    with pytest.raises(ValueError, match="HardSigmoid|Detect head"):
+    with pytest.raises(ValueError, match="HardSigmoid|Clip|Detect head"):
         OL.lower(OI.read_onnx(str(bad)))
 
 

@@ -285,7 +285,7 @@ int adas_engine_create(const char* model_path, int precision, int max_batch, ada
         else if (o.type == OP_WSUM) {
             TView ins[3];
             for (uint32_t k = 0; k < o.n_in && k < 3; ++k) ins[k] = view(o.in_buf[k], o.in_coff[k], o.in_c[k]);
-            ok = o.n_in <= 3 && wsum_supported((int)o.n_in, ins, view(o.out_buf, o.out_coff, o.out_c)) && o.act <= ACT_HSIGMOID;
+            ok = o.n_in <= 3 && wsum_supported((int)o.n_in, ins, view(o.out_buf, o.out_coff, o.out_c)) && o.act <= ACT_RELU6;
         }
         if ((o.type == OP_CONV || o.type == OP_DWCONV) && o.act > ACT_LEAKY) {   // hard-swish / hard-sigmoid: element-wise layers only (kernels.h)
             fclose(f);

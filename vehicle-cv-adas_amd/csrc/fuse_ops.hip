@@ -306,6 +306,9 @@ __global__ __launch_bounds__(256) void wsum_kernel(WsDev d) {
         } else if (d.act == ACT_HSIGMOID) {   // torch.nn.Hardsigmoid: relu6(x + 3) / 6
 #pragma unroll
             for (int e = 0; e < 8; ++e) acc[e] = fminf(fmaxf(acc[e] + 3.0f, 0.0f), 6.0f) / 6.0f;
+        } else if (d.act == ACT_RELU6) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[e] = fminf(fmaxf(acc[e], 0.0f), 6.0f);
         }
         Vec8<T>::store((T*)d.out + pix * d.out_cs + d.out_coff + g * 8, acc);
     }
@@ -324,7 +327,7 @@ bool wsum_supported(int n_in, const TView* ins, const TView& out) {
 
 hipError_t launch_wsum(int n_in, const TView* ins, const float* w, const TView& out, int n, int act, int prec, hipStream_t st) {
     if (!wsum_supported(n_in, ins, out)) return hipErrorInvalidValue;
-    if (act < ACT_NONE || act > ACT_HSIGMOID) return hipErrorInvalidValue;   // never a silently dropped activation
+    if (act < ACT_NONE || act > ACT_RELU6) return hipErrorInvalidValue;   // never a silently dropped activation
     WsDev d;
     for (int k = 0; k < 3; ++k) {
         const TView& v = ins[k < n_in ? k : 0];

@@ -12,7 +12,7 @@ inline int prec_esize(int prec) { return prec_is16(prec) ? 2 : 4; }
 enum { ACT_NONE = 0, ACT_SILU = 1, ACT_RELU = 2, ACT_LEAKY = 3 /* LeakyReLU(0.1): YOLOv7 (conv_halo, conv_pw, conv_pwg, conv_igemm) */,
        // element-wise only (OP_WSUM with one input = a stand-alone activation layer; OP_SE_GATE's gate): the conv epilogues do not carry them and
        // the engine refuses a convolution that asks for one (PP-LCNet / MobileNetV3-style networks: torch.nn.Hardswish / Hardsigmoid)
-       ACT_HSWISH = 4 /* x relu6(x + 3) / 6 */, ACT_HSIGMOID = 5 /* relu6(x + 3) / 6 */ };
+       ACT_HSWISH = 4 /* x relu6(x + 3) / 6 */, ACT_HSIGMOID = 5 /* relu6(x + 3) / 6 */, ACT_RELU6 = 6 /* min(max(x, 0), 6): MobileNetV2-style backbones */ };
 enum { RES_NONE = 0, RES_AFTER_ACT = 1, RES_BEFORE_ACT = 2 };
 
 // Workgroups per XCD the PERSISTENT kernels (conv_halo8, conv_halo_rw, conv_stem: one resident workgroup set walking a work list) launch:

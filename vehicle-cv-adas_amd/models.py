@@ -25,7 +25,7 @@ MAGIC = b"ADASHIP1"
 (OP_INPUT, OP_CONV, OP_MAXPOOL, OP_UPSAMPLE2, OP_DETECT_V8, OP_DETECT_V5, OP_LAYERNORM, OP_DWCONV, OP_ATTENTION, OP_AVGPOOL, OP_DEPTH2SPACE,
  OP_DETECT_V6, OP_SE_GATE, OP_SCALE, OP_WSUM, OP_SHUFFLE) = range(16)
 ACT_NONE, ACT_SILU, ACT_RELU, ACT_LEAKY = 0, 1, 2, 3      # ACT_LEAKY: LeakyReLU(0.1) (YOLOv7)
-ACT_HSWISH, ACT_HSIGMOID = 4, 5    # torch.nn.Hardswish / Hardsigmoid: ELEMENT-WISE layers only (Graph.act, the gate of Graph.se), never a conv epilogue
+ACT_HSWISH, ACT_HSIGMOID, ACT_RELU6 = 4, 5, 6    # torch.nn.Hardswish / Hardsigmoid / ReLU6: ELEMENT-WISE layers only (Graph.act, the gate of Graph.se), never a conv epilogue
 RES_NONE, RES_AFTER_ACT, RES_BEFORE_ACT = 0, 1, 2
 BUF_F32 = 1
 BUF_ALIAS = 2      # flags bit 1: this buffer is another view of buffer (flags >> 8) - same bytes, different (h, w, c)
@@ -328,7 +328,7 @@ class Graph:
         """act(sum_i weights[i] * ins[i]) over 2-3 maps of one width; an input of half the output's resolution is read through a nearest
         2x upsample (BiFPN top-down nodes).  The output resolution is that of the largest input."""
         assert 1 <= len(ins) <= 3 and len(weights) == len(ins)
-        assert act in (ACT_NONE, ACT_SILU, ACT_RELU, ACT_LEAKY, ACT_HSWISH, ACT_HSIGMOID), (name, act)   # the kernel applies exactly these (fuse_ops.hip wsum_kernel)
+        assert act in (ACT_NONE, ACT_SILU, ACT_RELU, ACT_LEAKY, ACT_HSWISH, ACT_HSIGMOID, ACT_RELU6), (name, act)   # the kernel applies exactly these (fuse_ops.hip wsum_kernel)
         h, w, c = max(v.h for v in ins), max(v.w for v in ins), ins[0].c
         for v in ins:
             assert v.c == c and ((v.h, v.w) == (h, w) or (2 * v.h, 2 * v.w) == (h, w)), (name, (v.h, v.w, v.c), (h, w, c))

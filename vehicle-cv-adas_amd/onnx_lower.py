@@ -7,7 +7,7 @@ ad-hoc CSP network -- goes through this module: the node list is walked once and
 
     Conv [+ Sigmoid, Mul | Relu | LeakyRelu(0.1)] [+ Add]      -> OP_CONV with a fused activation and residual (either order)
     Conv with group == channels                                 -> OP_DWCONV
-    HardSwish | x * HardSigmoid(1/6) | HardSigmoid(1/6)         -> a one-input OP_WSUM (a stand-alone activation layer: the conv in front keeps ACT_NONE)
+    HardSwish | x * HardSigmoid(1/6) | HardSigmoid(1/6) | Clip(0, 6)   -> a one-input OP_WSUM (a stand-alone activation layer: the conv in front keeps ACT_NONE)
     GlobalAveragePool -> Conv -> swish | Relu -> Conv -> Sigmoid | HardSigmoid -> Mul(x, .)   -> OP_SE_GATE + OP_SCALE
     MaxPool / AveragePool(count_include_pad) / Resize(nearest x2) / ConvTranspose(k 2, s 2)
     Concat(axis 1) / Split(axis 1) / Slice(axis 1)              -> no op at all: producers write channel slices of one buffer, consumers read views
@@ -104,9 +104,7 @@ class _Lowering:
             if nd["op"] == "LeakyRelu" and abs(float(nd["attrs"].get("alpha", 0.01)) - 0.1) < 1e-6:
                 used.add(i)
                 return M.ACT_LEAKY, nd["outputs"][0]
-            if nd["op"] == "Clip":
-                raise LowerError("node %s: activation %s has no kernel" % (nd["name"], nd["op"]))
-            # (HardSwish / HardSigmoid behind a convolution: the conv keeps ACT_NONE, the node becomes its own element-wise layer)
+            # (HardSwish / HardSigmoid / Clip(0, 6) behind a convolution: the conv keeps ACT_NONE, the node becomes its own element-wise layer)
         return M.ACT_NONE, t
 
     def _macro_ops(self):
@@ -173,6 +171,9 @@ class _Lowering:
             elif op == "GlobalAveragePool":
                 rec = self._match_se(i, used)
                 ops.append(("se", i, rec) if rec is not None else ("other", i, {}))
+            elif op == "Clip" and self._is_relu6(nd):
+                ops.append(("wsum", i, dict(terms=[(nd["inputs"][0], 1.0, False)], act=M.ACT_RELU6, out=nd["outputs"][0],
+                                            name=(nd["name"].strip("/").replace("/", ".") or "act%d" % i)[-47:])))
             elif op == "HardSwish" or (op == "HardSigmoid" and self._is_torch_hardsigmoid(nd)):
                 # torch.nn.Hardswish / Hardsigmoid: a stand-alone activation layer = a ONE-input weighted sum (fuse_ops.hip wsum_kernel; the conv
                 # epilogues do not carry these).  Exports below opset 14 write hard-swish as x * HardSigmoid(x).
@@ -339,6 +340,14 @@ class _Lowering:
     def _is_torch_hardsigmoid(nd):
         """HardSigmoid(alpha = 1/6, beta = 0.5) = relu6(x + 3) / 6, torch.nn.Hardsigmoid (ONNX's default alpha is 0.2: another function)."""
         return abs(float(nd["attrs"].get("alpha", 0.2)) - 1.0 / 6.0) < 1e-6 and abs(float(nd["attrs"].get("beta", 0.5)) - 0.5) < 1e-6
+
+    def _is_relu6(self, nd):
+        """Clip(x, 0, 6) = torch.nn.ReLU6: bounds as inputs 1, 2 (opset >= 11) or as the min / max attributes."""
+        lo = _const(self.m, nd["inputs"][1]) if len(nd["inputs"]) > 1 and nd["inputs"][1] else nd["attrs"].get("min")
+        hi = _const(self.m, nd["inputs"][2]) if len(nd["inputs"]) > 2 and nd["inputs"][2] else nd["attrs"].get("max")
+        if lo is None or hi is None:
+            return False
+        return float(np.asarray(lo).reshape(-1)[0]) == 0.0 and float(np.asarray(hi).reshape(-1)[0]) == 6.0
 
     # ---- stand-alone sums
     def _is_free_sum(self, nd):
