@@ -49,8 +49,9 @@ def main():
         res[tag] = run(v["frames"], v["label_ids"], cps)
         last = res[tag][str(n - 1)]
         print(tag, "checkpoints", sorted(int(k) for k in res[tag]), "tracks at the end", len(last), "longest trajectory", max([len(r["trajectory"]) for r in last] or [0]))
-    with gzip.open(os.path.join(HERE, "bytetrack_traj.json.gz"), "wt") as f:
-        json.dump(res, f)
+    with open(os.path.join(HERE, "bytetrack_traj.json.gz"), "wb") as raw:       # mtime 0, no file name: the same bytes on every run
+        with gzip.GzipFile(filename="", fileobj=raw, mode="wb", mtime=0) as f:
+            f.write(json.dumps(res).encode())
 
 
 if __name__ == "__main__":
