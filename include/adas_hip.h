@@ -36,6 +36,9 @@ int adas_version(void);
  * (reference: cuda.Device(0) hard-coded at coreEngine.py:47). */
 int adas_device_count(void);
 int adas_set_device(int index);
+/* PCI address ("0000:c1:00.0") of device `index`, so that a one-process-per-GPU launcher can pin its launching thread to the GPU's
+ * NUMA node (sharding.pin_rank; the reference is one process on cuda.Device(0), coreEngine.py:47). */
+int adas_device_pci_bus_id(int index, char* out, int out_len);
 /* Plain device-memory helpers so a ctypes/cgo caller can stage buffers without another runtime. */
 int adas_malloc(void** d_ptr, size_t bytes);
 int adas_free(void* d_ptr);

@@ -125,28 +125,37 @@ def test_pipeline_with_ufld_v1_lane_model():
     pipe.close(); eng.close(); dec.close(); dx.free()
 
 
-def test_bench_gpus_n_relaunches_n_ranks(tmp_path):
+@pytest.mark.parametrize("split,frames_per_step,streams", [
+    (["--streams", "2"], 4, [2, 2]),            # weak scaling: every rank its own 2 streams
+    (["--total-streams", "3"], 3, [2, 1]),      # a 3-stream JOB dealt by sharding.streams_of_rank: stream s -> rank s mod 2
+    (["--total-streams", "1"], 1, [1, 0]),      # fewer streams than ranks: rank 1 owns nothing and only takes part in the collectives
+])
+def test_bench_gpus_n_relaunches_n_ranks(tmp_path, split, frames_per_step, streams):
     """`python bench.py --gpus 2` with no torchrun environment must re-execute itself under torch.distributed.run and print ONE line
     with n_gpus = 2 and two per-rank records.  Rehearsed on this 1-GPU box with both ranks sharing the device and gloo carrying
     the statistics (ADAS_BENCH_SHARE_GPU / ADAS_BENCH_BACKEND exist for exactly this); the driver's 8-GPU run takes the same path
-    with RCCL."""
+    with RCCL.  `--total-streams N` runs the stream router's uneven splits (13-over-8 in tests/test_multigpu_gloo.py) for real."""
     import json, os, subprocess, sys
     from conftest import ROOT
     env = dict(os.environ, ADAS_BENCH_BACKEND="gloo", ADAS_BENCH_SHARE_GPU="1", ADAS_MODEL_DIR=str(tmp_path))
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--streams", "2",
-                          "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=900)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", *split,
+                          "--no-cpu-baseline", "--precision", "fp16"], env=env, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, out.stdout[-2000:]
     r = json.loads(lines[0])
-    assert r["n_gpus"] == 2 and len(r["per_rank"]) == 2 and r["config"]["frames_per_step"] == 4
+    assert r["n_gpus"] == 2 and len(r["per_rank"]) == 2 and r["config"]["frames_per_step"] == frames_per_step
+    assert [q["streams"] for q in r["per_rank"]] == streams
+    assert r["scaling"] == ("strong" if split[0] == "--total-streams" else "weak")
     assert r["value"] > 0 and r["config"]["frames_at_candidate_capacity"] == 0
     # whole-job rate = every rank's frames / the slowest rank's seconds (the max-over-ranks clock), not a sum of per-rank rates
     frames, slowest = sum(q["frames"] for q in r["per_rank"]), max(q["seconds"] for q in r["per_rank"])
-    assert frames == 3 * 4 and abs(r["value"] - frames / slowest) <= 0.02 * r["value"], (r["value"], r["per_rank"])
+    assert frames == 3 * frames_per_step and abs(r["value"] - frames / slowest) <= 0.02 * r["value"], (r["value"], r["per_rank"])
     assert r["cpu_baseline"] is None and r["modes"] is None          # single-rank legs are skipped with world > 1
+    # every rank reports where its launching thread was pinned (N > 1 only): a share of the CPUs, or its GPU's NUMA node
+    assert all(q["cpus"] >= 1 and isinstance(q["pinned"], bool) for q in r["per_rank"])
 
 
 def test_pipeline_step_frames_host_equals_device_frames(tmp_path):

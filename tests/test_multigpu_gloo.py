@@ -101,3 +101,42 @@ def test_four_and_eight_rank_gloo_uneven_streams(world, n_streams):
     assert [d["streams"] for d in st0] == [float(len(range(r, n_streams, world))) for r in range(world)]
     agg = SH.aggregate_throughput(st0)
     assert agg["frames"] == 20.0 * n_streams and agg["seconds"] == slowest and agg["fps"] == 20.0 * n_streams / slowest
+
+
+def test_rank_affinity_helpers(tmp_path):
+    """sharding.pin_rank's pieces without touching this process's affinity: sysfs cpulist parsing, the GPU's NUMA node from its PCI
+    address, and the CPU set a rank's launching thread gets (the node's CPUs when known, else a contiguous share)."""
+    assert SH.parse_cpulist("0-3,8,10-11\n") == [0, 1, 2, 3, 8, 10, 11] and SH.parse_cpulist("") == []
+    dev = tmp_path / "bus" / "pci" / "devices" / "0000:c1:00.0"
+    dev.mkdir(parents=True)
+    (dev / "numa_node").write_text("1\n")
+    assert SH.gpu_numa_node("0000:C1:00.0", str(tmp_path)) == 1
+    assert SH.gpu_numa_node("0000:05:00.0", str(tmp_path)) == -1 and SH.gpu_numa_node(None) == -1
+    allowed = list(range(16))
+    assert SH.rank_cpus(3, 8, allowed, node_cpus=[8, 9, 10, 11, 40]) == [8, 9, 10, 11]       # the node's CPUs, within the allowed set
+    assert SH.rank_cpus(3, 8, allowed, node_cpus=[40, 41]) == [6, 7]                        # node outside the cpuset: fall back to a share
+    shares = [SH.rank_cpus(r, 8, allowed) for r in range(8)]
+    assert shares == [[2 * r, 2 * r + 1] for r in range(8)]                                 # disjoint, contiguous, covering
+    assert SH.rank_cpus(0, 1, allowed) == allowed and SH.rank_cpus(5, 8, [0, 1, 2]) == [0, 1, 2]
+    # an idle rank (no stream of the job) reports 0 frames in 0 seconds: the aggregate ignores it in the per-rank rates
+    agg = SH.aggregate_throughput([{"frames": 30.0, "seconds": 1.5}, {"frames": 0.0, "seconds": 0.0}])
+    assert agg["fps"] == 20.0 and agg["min_rank_fps"] == 20.0 and agg["max_rank_fps"] == 20.0
+
+
+def test_pipeline_for_rank_uses_the_stream_router(monkeypatch):
+    """AdasPipeline.for_rank(total_streams) builds a rank's pipeline for exactly the streams sharding.streams_of_rank deals it (no GPU
+    here: the constructor is replaced by a recorder) and returns None for a rank that owns nothing."""
+    PL = importlib.import_module("adas_amd.pipeline")
+    made = []
+
+    def fake_init(self, det_model=None, lane_model=None, n_streams=1, **kw):
+        made.append((det_model, lane_model, n_streams, kw))
+        self.S, self.stream_ids, self.h = n_streams, list(range(n_streams)), None
+    monkeypatch.setattr(PL.AdasPipeline, "__init__", fake_init)
+    monkeypatch.setattr(PL.AdasPipeline, "close", lambda self: None)
+    monkeypatch.setattr(PL.AdasPipeline, "__del__", lambda self: None)
+    p = PL.AdasPipeline.for_rank("d.hipm", "l.hipm", 13, env=SH.RankEnv(rank=5, local_rank=5, world=8), precision="fp16x3")
+    assert p.stream_ids == [5] and made[-1][2] == 1 and made[-1][3] == {"precision": "fp16x3"}
+    p = PL.AdasPipeline.for_rank("d.hipm", "l.hipm", 13, env=SH.RankEnv(rank=2, local_rank=2, world=8))
+    assert p.stream_ids == [2, 10] and made[-1][2] == 2
+    assert PL.AdasPipeline.for_rank("d.hipm", "l.hipm", 2, env=SH.RankEnv(rank=3, local_rank=3, world=4)) is None

@@ -101,6 +101,7 @@ _SIGS = {
     "adas_version": (C.c_int, []),
     "adas_device_count": (C.c_int, []),
     "adas_set_device": (C.c_int, [C.c_int]),
+    "adas_device_pci_bus_id": (C.c_int, [C.c_int, C.c_char_p, C.c_int]),
     "adas_malloc": (C.c_int, [C.POINTER(_P), C.c_size_t]),
     "adas_free": (C.c_int, [_P]),
     "adas_memcpy_h2d": (C.c_int, [_P, _P, C.c_size_t]),

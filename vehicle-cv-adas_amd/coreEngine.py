@@ -11,8 +11,16 @@ This module exports the same names, all bound to HipEngine, with the same surfac
     .framework_type / .providers / .engine_dtype
 
 Added (not in the reference): `.infer_device(d_ptr, batch)` keeps outputs in HBM for the GPU-resident
-post-processing; `precision=` ("fp16" default: half storage + f16 MFMA, what the reference ships as *_fp16.trt; "bf16";
-"fp32" parity mode) and `max_batch=` keyword arguments.
+post-processing; `precision=` and `max_batch=` keyword arguments.
+
+Precision (round 6).  An unmodified caller -- `OnnxEngine(path)` -- gets the EXACT mode: "fp16x3" (every value a (hi, lo) pair of
+halves, three f16 MFMAs per product, fp32 accumulate), the mode that reproduces the reference's ONNXRuntime-CPU results (north_star:
+1e-3 on activations, bit-exact NMS survivors / track ids); a graph the split layout cannot hold (a 16-bit tensor whose channel count
+is not a multiple of 8) falls to "fp32" (f32 MFMA), the other exact mode.  A model whose graph input is float16 (the reference's
+`*_fp16.onnx` / `*_fp16.trt`, coreEngine.py:168, demo.py:18-29) runs in "fp16": that model IS half precision in the reference too.
+`precision="fp16"` / "bf16" are the throughput modes (half storage + 16-bit MFMA, fp32 accumulate) = the reference's TensorRT-fp16
+behaviour, NOT its ONNXRuntime-CPU results: a few threshold / NMS-order / lane arg-max decisions per hundred frames differ.
+`ADAS_PRECISION=<mode>` overrides the default for a whole process.
 There is no CPU execution path: construction fails if libadas_hip.so or a gfx950 device is missing.
 """
 import abc
@@ -27,7 +35,17 @@ except ImportError:  # imported as a top-level module named `coreEngine` (packag
     import _lib as L
 
 MODEL_SUFFIXES = ('.onnx', '.trt', '.hipm')
-DEFAULT_PRECISION = os.environ.get("ADAS_PRECISION", "fp16")
+DEFAULT_PRECISION = os.environ.get("ADAS_PRECISION", "exact")   # "exact": fp16x3, else fp32; float16-I/O models: fp16 (module docstring)
+
+
+def _container_io_half(path):
+    """Bit 16 of the ADASHIP1 header's in_cpad word (csrc/engine.h FileHeader): the source model's graph I/O is float16."""
+    try:
+        with open(path, "rb") as f:
+            hd = f.read(44)
+        return len(hd) == 44 and hd[:8] == b"ADASHIP1" and bool((int.from_bytes(hd[40:44], "little") >> 16) & 1)
+    except OSError:
+        return False
 
 
 class EngineBase(abc.ABC):
@@ -70,12 +88,23 @@ class HipEngine(EngineBase):
     def __init__(self, model_path, precision=None, max_batch=1):
         EngineBase.__init__(self, model_path)
         precision = precision or DEFAULT_PRECISION
-        if precision not in L.PRECISIONS:
-            raise Exception("precision must be one of %s, got %r" % (sorted(L.PRECISIONS), precision))
-        prec = L.PRECISIONS[precision]
+        if precision != "exact" and precision not in L.PRECISIONS:
+            raise Exception("precision must be one of %s or 'exact', got %r" % (sorted(L.PRECISIONS), precision))
         model_path = self._resolve_container(model_path)
         h = C.c_void_p()
-        L.check(L.lib().adas_engine_create(os.fsencode(model_path), prec, int(max_batch), C.byref(h)))
+        if precision == "exact":
+            # the parity policy of the module docstring: a half model stays half (it is half in the reference), everything else runs
+            # in the split precision, or -- when the G8 layout cannot hold the graph -- on the f32 MFMA
+            precision = "fp16" if _container_io_half(model_path) else "fp16x3"
+            if precision == "fp16x3":
+                try:
+                    L.check(L.lib().adas_engine_create(os.fsencode(model_path), L.PRECISIONS[precision], int(max_batch), C.byref(h)))
+                except L.AdasError as ex:
+                    if "needs multiples of 8" not in str(ex):
+                        raise
+                    precision, h = "fp32", C.c_void_p()
+        if not h.value:
+            L.check(L.lib().adas_engine_create(os.fsencode(model_path), L.PRECISIONS[precision], int(max_batch), C.byref(h)))
         self._h = h.value
         self.precision, self.max_batch = precision, int(max_batch)
         self.providers = ['HIPExecutionProvider(gfx950)']

@@ -37,6 +37,12 @@ int adas_set_device(int index) {
     ADAS_HIP_TRY(hipSetDevice(index));
     return ADAS_OK;
 }
+int adas_device_pci_bus_id(int index, char* out, int out_len) {
+    ADAS_REQUIRE(out && out_len >= 16, ADAS_ERR_INVALID, "adas_device_pci_bus_id: buffer of at least 16 bytes needed");
+    ADAS_REQUIRE(adas_device_count() > 0, ADAS_ERR_NO_DEVICE, "no HIP device visible; this library has no CPU fallback");
+    ADAS_HIP_TRY(hipDeviceGetPCIBusId(out, out_len, index));
+    return ADAS_OK;
+}
 int adas_malloc(void** d_ptr, size_t bytes) {
     ADAS_REQUIRE(d_ptr, ADAS_ERR_INVALID, "adas_malloc: null out pointer");
     ADAS_REQUIRE(adas_device_count() > 0, ADAS_ERR_NO_DEVICE, "no HIP device visible; this library has no CPU fallback");

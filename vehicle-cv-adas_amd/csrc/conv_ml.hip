@@ -232,6 +232,7 @@ __global__ __launch_bounds__(256, ADAS_ML_WAVES) void conv_ml_kernel(MlArgs g) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) *reinterpret_cast<mu32x4*>(s_rec + 4 * i) = rec[i];
             s_rec[16] = mine;
+            s_rec[17] = 0;      // set by a waiter that gave up (its own time-out, or somebody else's error word): the item is skipped
         }
         __syncthreads();
         const unsigned t = __builtin_amdgcn_readfirstlane(s_rec[16]);
@@ -259,12 +260,19 @@ __global__ __launch_bounds__(256, ADAS_ML_WAVES) void conv_ml_kernel(MlArgs g) {
                 ++spins;
                 if (spins > (unsigned)g.spin_limit) {   // bounded: raise the error word (1 + ticket) and give the item up
                     __hip_atomic_store(g.ctl + 1, t + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    s_rec[17] = 1;
                     break;
                 }
-                if ((spins & 255u) == 0u && __hip_atomic_load(g.ctl + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) break;   // somebody gave up: drain
+                if ((spins & 255u) == 0u && __hip_atomic_load(g.ctl + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {   // somebody gave up: drain
+                    s_rec[17] = 1;
+                    break;
+                }
             }
         }
         __syncthreads();
+        // an item whose producers never completed computes nothing and publishes nothing (its consumers time out or drain in turn):
+        // the launch ends with the error word set and adas_engine_ml_status / the pipeline's sync report it -- never a silently wrong tile
+        const bool gave_up = __builtin_amdgcn_readfirstlane(s_rec[17]) != 0u;
         MLPROF(2)   // dependency wait
         // ---- the tile.  The bodies get an OPAQUE copy of the thread index: everything a tile derives from it (lane / wave decomposition, LDS swizzle
         // offsets, fragment addresses -- a dozen values per body, twelve bodies) is invariant across items, and LLVM hoists it all out of the
@@ -273,9 +281,10 @@ __global__ __launch_bounds__(256, ADAS_ML_WAVES) void conv_ml_kernel(MlArgs g) {
         int tid_it = tid;
         asm volatile("" : "+v"(tid_it));
 #ifdef ADAS_ML_ONEKIND   // code-size experiment: one halo body only
-        halo_tile<E, 64, -1, 1, 256, true>(u.h, tile, cb, lds, tid_it);
+        if (!gave_up) halo_tile<E, 64, -1, 1, 256, true>(u.h, tile, cb, lds, tid_it);
 #else
-        if (kind == MLK_PW) {
+        if (gave_up) {
+        } else if (kind == MLK_PW) {
             switch (u.p.KS) {
                 case 2: ml_pw_dispatch<E, 2>(u.p, frame, tile, cb, lds, tid_it); break;
                 case 3: ml_pw_dispatch<E, 3>(u.p, frame, tile, cb, lds, tid_it); break;
@@ -309,7 +318,7 @@ __global__ __launch_bounds__(256, ADAS_ML_WAVES) void conv_ml_kernel(MlArgs g) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         MLPROF(4)   // store drain + barrier
-        if (tid == 0) __hip_atomic_fetch_add(g.ctl + arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (tid == 0 && !gave_up) __hip_atomic_fetch_add(g.ctl + arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         MLPROF_ITEM
     }
     MLPROF_FLUSH

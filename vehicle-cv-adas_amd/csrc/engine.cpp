@@ -151,6 +151,8 @@ static int free_engine(adas_engine* e) {
     if (e->d_input) (void)hipFree(e->d_input);
     for (auto& ev : e->events)
         if (ev) (void)hipEventDestroy(ev);
+    for (auto& ev : e->step_events)
+        if (ev) (void)hipEventDestroy(ev);
     delete e;
     return ADAS_OK;
 }
@@ -831,6 +833,12 @@ int adas_engine_create(const char* model_path, int precision, int max_batch, ada
         free_engine(e);
         return hip_fail(hipGetLastError(), "hipMalloc(input staging)", __FILE__, __LINE__);
     }
+    // the grouped / multi-layer launch tables of the engine's own batch size are built now, not on the first forward (device
+    // allocations and synchronous copies do not belong on the hot path; other batch sizes are prepared on first use, engine_forward)
+    if (engine_prepare(e, max_batch) != ADAS_OK) {
+        free_engine(e);
+        return ADAS_ERR_HIP;
+    }
     *out = e;
     return ADAS_OK;
 }
@@ -877,12 +885,16 @@ int adas_engine_layer_kernel(const adas_engine* e, int layer, int batch, char* n
         for (auto& run : *runs)
             for (int m : run.ops)
                 if (m == layer) in_run = &run;
-    if (in_run && in_run->first == layer) {
-        int ng = 0;
-        for (auto& st : in_run->steps) ng += st.group ? 1 : 0;
-        snprintf(name, cap, "conv_halo_group_kernel[%d layers, %d launches]", (int)in_run->ops.size(), (int)in_run->steps.size());
-        (void)ng;
-    } else if (in_run) {
+    // a layer of a run belongs to one STEP of it: a grouped launch (its first member carries the label, the others ride in it) or a
+    // single layer on its own kernel, which is labelled like any other layer below
+    const GroupStep* in_step = nullptr;
+    if (in_run)
+        for (auto& st : in_run->steps)
+            for (int m : st.members)
+                if (m == layer) in_step = &st;
+    if (in_step && in_step->group && in_step->members.front() == layer) {
+        snprintf(name, cap, "conv_halo_group_kernel[%d layers]", (int)in_step->members.size());
+    } else if (in_step && in_step->group) {
         snprintf(name, cap, "(in the grouped launch)");
     } else if (in_seg && in_seg->first == layer) {
         snprintf(name, cap, "conv_ml_kernel[%d layers]", in_seg->n_layers);
@@ -1200,9 +1212,29 @@ static void prepare_groups(adas_engine* e, int batch) {
     }
 }
 
+// Tables are kept for the life of the engine (a captured hipGraph may reference them): at most this many distinct batch sizes get
+// them, later ones run one launch per layer.
+constexpr size_t kMaxPreparedBatches = 16;
+
+// The allocations and copies below must not land in -- or invalidate -- a stream capture the calling thread has open on ANOTHER stream
+// (engine_forward only knows its own): they run with the thread's capture mode relaxed, restored on every exit.
+struct RelaxedCaptureMode {
+    hipStreamCaptureMode mode = hipStreamCaptureModeRelaxed;
+    bool ok;
+    RelaxedCaptureMode() { ok = hipThreadExchangeStreamCaptureMode(&mode) == hipSuccess; if (!ok) (void)hipGetLastError(); }
+    ~RelaxedCaptureMode() { if (ok && hipThreadExchangeStreamCaptureMode(&mode) != hipSuccess) (void)hipGetLastError(); }
+};
+
 int engine_prepare(adas_engine* e, int batch) {
-    if (e->group_on && !e->groups.count(batch)) prepare_groups(e, batch);
-    if (!ml_enabled(e) || e->ml.count(batch)) return ADAS_OK;
+    const bool want_groups = e->group_on && !e->groups.count(batch), want_ml = ml_enabled(e) && !e->ml.count(batch);
+    if (!want_groups && !want_ml) return ADAS_OK;
+    RelaxedCaptureMode relaxed;
+    if (want_groups) {
+        if (e->groups.size() >= kMaxPreparedBatches) e->groups[batch];   // an empty list: per-layer launches for this batch size
+        else prepare_groups(e, batch);
+    }
+    if (!want_ml) return ADAS_OK;
+    if (e->ml.size() >= kMaxPreparedBatches) { e->ml[batch]; return ADAS_OK; }
     std::vector<MlSeg>& segs = e->ml[batch];
     static int min_layers = -1, max_items = -1;
     if (min_layers < 0) { const char* v = getenv("ADAS_ML_MIN_LAYERS"); min_layers = v ? atoi(v) : 2; if (min_layers < 1) min_layers = 1; }
@@ -1433,6 +1465,13 @@ int adas_engine_infer_host(adas_engine* e, const float* h_input, int batch, floa
                                       hipMemcpyDeviceToHost, 0));
     }
     ADAS_HIP_TRY(hipStreamSynchronize(0));
+    // opt-in multi-layer launches (ADAS_ML=1): a dependency wait that timed out leaves its item uncomputed -- the caller gets an error,
+    // never the partial outputs
+    if (ml_enabled(e)) {
+        uint32_t w = 0;
+        int rc = adas_engine_ml_status(e, batch, &w);
+        if (rc != ADAS_OK) return rc;
+    }
     return ADAS_OK;
 }
 
@@ -1468,12 +1507,17 @@ int adas_engine_profile(adas_engine* e, const float* d_input, int batch, int ite
     }
     const std::vector<MlSeg>* segs = ml_segments(e, batch);
     const std::vector<GroupRun>* runs = group_runs(e, batch);
+    struct StepMark { int layer, ev, prev; };   // prev: index into step_events, or -(layer index + 1) of the layer event that opens the run
     for (int it = 0; it < iters; ++it) {
         ADAS_HIP_TRY(hipEventRecord(e->events[0], 0));
-        size_t si = 0, gi = 0;
+        size_t si = 0, gi = 0, n_step_ev = 0;
+        std::vector<StepMark> step_marks;
         for (int i = 0; i < n; ++i) {
-            if (runs && gi < runs->size() && (*runs)[gi].first == i) {   // a run of grouped launches: its time goes to its first layer
+            if (runs && gi < runs->size() && (*runs)[gi].first == i) {
+                // a run of halo convs, launched level by level: one event per STEP, a step's time goes to its first member (the layer
+                // adas_engine_layer_kernel labels with the step's kernel), every other layer of the run reads 0
                 const GroupRun& run = (*runs)[gi++];
+                const size_t base = step_marks.size();
                 for (auto& step : run.steps) {
                     if (step.group) {
                         hipError_t err = ml_group_launch(step.group, 0);
@@ -1482,6 +1526,14 @@ int adas_engine_profile(adas_engine* e, const float* d_input, int batch, int ite
                         int rc = engine_run_op(e, step.op, d_input, batch, 0);
                         if (rc != ADAS_OK) return rc;
                     }
+                    if (n_step_ev >= e->step_events.size()) {
+                        hipEvent_t ev = nullptr;
+                        ADAS_HIP_TRY(hipEventCreate(&ev));
+                        e->step_events.push_back(ev);
+                    }
+                    ADAS_HIP_TRY(hipEventRecord(e->step_events[n_step_ev], 0));
+                    step_marks.push_back({step.members.front(), (int)n_step_ev, step_marks.size() == base ? -(i + 1) : (int)n_step_ev - 1});
+                    ++n_step_ev;
                 }
                 for (int k = i; k <= run.last; ++k) ADAS_HIP_TRY(hipEventRecord(e->events[k + 1], 0));
                 i = run.last;
@@ -1500,11 +1552,23 @@ int adas_engine_profile(adas_engine* e, const float* d_input, int batch, int ite
             ADAS_HIP_TRY(hipEventRecord(e->events[i + 1], 0));
         }
         ADAS_HIP_TRY(hipStreamSynchronize(0));
+        std::vector<char> in_run(n, 0);
+        if (runs)
+            for (auto& run : *runs)
+                for (int k = run.first; k <= run.last; ++k) in_run[k] = 1;
         for (int i = 0; i < n; ++i) {
+            if (in_run[i]) continue;          // layers of a grouped run are timed per step below
             float ms = 0.f;
             ADAS_HIP_TRY(hipEventElapsedTime(&ms, e->events[i], e->events[i + 1]));
             ms -= marker_ms;
             ms_per_layer[i] += (ms > 0.f ? ms : 0.f) / (float)iters;
+        }
+        for (auto& mk : step_marks) {
+            float ms = 0.f;
+            hipEvent_t from = mk.prev < 0 ? e->events[-mk.prev - 1] : e->step_events[mk.prev];
+            ADAS_HIP_TRY(hipEventElapsedTime(&ms, from, e->step_events[mk.ev]));
+            ms -= marker_ms;
+            ms_per_layer[mk.layer] += (ms > 0.f ? ms : 0.f) / (float)iters;
         }
     }
     if (num_layers) *num_layers = n;

@@ -120,6 +120,7 @@ struct adas_engine {
     float* d_input = nullptr;
     size_t weight_bytes = 0, act_bytes = 0;
     std::vector<hipEvent_t> events;
+    std::vector<hipEvent_t> step_events;   // adas_engine_profile: one per step of a grouped run
     hipStream_t last = 0;
     std::map<int, std::vector<adas::MlSeg>> ml;   // batch -> multi-layer launches (adas_engine_prepare); absent: not prepared, per-layer launches
     std::map<int, std::vector<adas::GroupRun>> groups;   // batch -> grouped launches of independent layers (default path)

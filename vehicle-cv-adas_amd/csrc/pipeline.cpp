@@ -394,6 +394,15 @@ int adas_pipeline_wait_upload(adas_pipeline* p) {
 int adas_pipeline_sync(adas_pipeline* p) {
     ADAS_REQUIRE(p, ADAS_ERR_INVALID, "null pipeline");
     ADAS_HIP_TRY(hipStreamSynchronize(p->st));
+    // engines running the opt-in multi-layer launches (ADAS_ML=1) report a timed-out dependency wait here: the step's results are then
+    // incomplete and the caller must not use them (adas_engine_ml_status returns at once for every other engine)
+    const int frames = p->d.n_streams * (p->d.micro_batch > 1 ? p->d.micro_batch : 1);
+    for (adas_engine* e : {p->d.detector, p->d.lane})
+        if (e) {
+            uint32_t w = 0;
+            int rc = adas_engine_ml_status(e, frames, &w);
+            if (rc != ADAS_OK) return rc;
+        }
     return ADAS_OK;
 }
 

@@ -96,14 +96,34 @@ def _engine_for(model_path, **kw):
     return TensorRTEngine(model_path, **kw) if model_path.endswith('.trt') else OnnxEngine(model_path, **kw)
 
 
+class StagedFrame:
+    """A BGR u8 frame that already sits in HBM: what `detector.staged_frame` hands out after a DetectFrame, so that the next task class
+    of the same loop iteration (demo.py:269,280 pass the SAME frame to the object and the lane detector) does not upload its 2.7 MB
+    again: `lane.DetectFrame(det.staged_frame)`.  Valid until the owning detector's next DetectFrame (or close)."""
+    __slots__ = ("ptr", "height", "width", "serial")
+
+    def __init__(self, ptr, height, width, serial):
+        self.ptr, self.height, self.width, self.serial = ptr, int(height), int(width), serial
+
+    @property
+    def shape(self):
+        return (self.height, self.width, 3)
+
+
 class _FrameStage:
     """Device staging of one BGR u8 frame + the network input tensor it is turned into."""
+    _serial = 0
 
     def __init__(self):
         self.frame = None
         self.tensor = None
+        self.staged = None
 
     def upload(self, img):
+        """-> (device pointer of the frame, height, width).  A StagedFrame (another detector's upload of this frame) is used in place."""
+        if isinstance(img, StagedFrame):
+            self.staged = img
+            return img.ptr, img.height, img.width
         img = np.ascontiguousarray(img, dtype=np.uint8)
         if img.ndim != 3 or img.shape[2] != 3:
             raise Exception("frame must be an HxWx3 uint8 BGR image, got %s" % (img.shape,))
@@ -112,7 +132,9 @@ class _FrameStage:
                 self.frame.free()
             self.frame = L.DeviceBuffer(img.nbytes)
         self.frame.upload(img)
-        return img.shape[0], img.shape[1]
+        _FrameStage._serial += 1
+        self.staged = StagedFrame(self.frame.ptr, img.shape[0], img.shape[1], _FrameStage._serial)
+        return self.frame.ptr, img.shape[0], img.shape[1]
 
     def tensor_for(self, shape):
         n = int(np.prod(shape)) * 4
@@ -126,7 +148,7 @@ class _FrameStage:
         for b in (self.frame, self.tensor):
             if b is not None:
                 b.free()
-        self.frame = self.tensor = None
+        self.frame = self.tensor = self.staged = None
 
 
 # =====================================================================================
@@ -146,7 +168,7 @@ class YoloDetector(_Defaults):
     def __init__(self, logger=None, **kwargs):
         self.__dict__.update(self._defaults)
         self.logger = logger
-        self.precision = None                    # None -> coreEngine.DEFAULT_PRECISION ("fp16")
+        self.precision = None                    # None -> coreEngine.DEFAULT_PRECISION: the exact mode (fp16x3); "fp16" = throughput mode
         self.nms_mode = L.NMS_REFERENCE          # the production call (yoloDetector.py:139); NMS_GREEDY = fast_nms (:138)
         self.max_candidates = 1024
         self.__dict__.update(kwargs)
@@ -158,6 +180,12 @@ class YoloDetector(_Defaults):
         self._post = None
         self._post_key = None
         self._object_info = []
+        self._last_full = None
+
+    @property
+    def staged_frame(self):
+        """The last frame's device copy (StagedFrame), to hand to the other task classes of the same loop iteration."""
+        return self._stage.staged
 
     def _initialize_model(self, model_path: str) -> None:
         self.engine = _engine_for(model_path, precision=self.precision)
@@ -181,8 +209,12 @@ class YoloDetector(_Defaults):
     @property
     def _last(self):
         """Everything the post-processor holds for the last frame (candidates too; the tests compare them with the oracle): fetched on
-        demand -- DetectFrame itself only brings the survivors over."""
-        return self._post.fetch(0)
+        demand, once per frame -- DetectFrame itself only brings the survivors over."""
+        if self._post is None:
+            raise Exception("YoloDetector: no frame has been processed yet")
+        if self._last_full is None:
+            self._last_full = self._post.fetch(0)
+        return self._last_full
 
     def _post_for(self, src_hw):
         key = (int(src_hw[0]), int(src_hw[1]))
@@ -203,9 +235,10 @@ class YoloDetector(_Defaults):
 
     def DetectFrame(self, srcimg) -> None:
         """yoloDetector.py:159-168 with every step on the device."""
-        h, w = self._stage.upload(srcimg)
+        fptr, h, w = self._stage.upload(srcimg)
+        self._last_full = None
         t = self._stage.tensor_for(self.input_shapes)
-        L.check(L.lib().adas_preprocess_yolo(self._stage.frame.ptr, 1, h, w, t.ptr, self.input_height, self.input_width, 1, None))
+        L.check(L.lib().adas_preprocess_yolo(fptr, 1, h, w, t.ptr, self.input_height, self.input_width, 1, None))
         self.engine.infer_device(t.ptr, 1, None)
         post = self._post_for((h, w))
         post.run_device(self.engine.output_device_ptr(0), 1, None)
@@ -298,9 +331,9 @@ class EfficientdetDetector(_Defaults):
         return self._object_info
 
     def DetectFrame(self, srcimg) -> None:
-        h, w = self._stage.upload(srcimg)
+        fptr, h, w = self._stage.upload(srcimg)
         t = self._stage.tensor_for(self.input_shapes)
-        L.check(L.lib().adas_preprocess_effdet(self._stage.frame.ptr, 1, h, w, t.ptr, self.input_height, self.input_width, 1, None))
+        L.check(L.lib().adas_preprocess_effdet(fptr, 1, h, w, t.ptr, self.input_height, self.input_width, 1, None))
         x = t.download((1, 3, self.input_height, self.input_width), np.float32).astype(self.input_types)
         out = self.engine.engine_inference(x)                                    # boxes, class ids, confidences (:68-70)
         key = (h, w)
@@ -467,6 +500,11 @@ class UltrafastLaneDetectorV2(_Defaults):
         if len(self.output_names) != 4:
             raise Exception("Output dims is error, please check model. load %d channels not match 4." % len(self.output_names))
 
+    @property
+    def staged_frame(self):
+        """The last frame's device copy (StagedFrame), to hand to the other task classes of the same loop iteration."""
+        return self._stage.staged
+
     def _decode_for(self, img_hw):
         key = (int(img_hw[0]), int(img_hw[1]))
         if self._decode_key != key:
@@ -480,10 +518,10 @@ class UltrafastLaneDetectorV2(_Defaults):
 
     def DetectFrame(self, image, adjust_lanes: bool = True) -> None:
         """ultrafastLaneDetectorV2.py:183-194."""
-        h, w = self._stage.upload(image)
+        fptr, h, w = self._stage.upload(image)
         self.img_height, self.img_width, self.img_channels = h, w, 3
         t = self._stage.tensor_for(self.input_shape)
-        L.check(L.lib().adas_preprocess_ufld(self._stage.frame.ptr, 1, h, w, t.ptr, self.input_height, self.input_width,
+        L.check(L.lib().adas_preprocess_ufld(fptr, 1, h, w, t.ptr, self.input_height, self.input_width,
                                              float(self.cfg.crop_ratio), None))
         self.engine.infer_device(t.ptr, 1, None)
         dec = self._decode_for((h, w))
@@ -627,11 +665,11 @@ class UltrafastLaneDetector(UltrafastLaneDetectorV2):
 
     def DetectFrame(self, image, adjust_lanes: bool = True) -> None:
         """ultrafastLaneDetector.py:141-153."""
-        h, w = self._stage.upload(image)
+        fptr, h, w = self._stage.upload(image)
         self.img_height, self.img_width, self.img_channels = h, w, 3
         self.h_ratio, self.w_ratio = h / self.cfg.img_h, w / self.cfg.img_w
         t = self._stage.tensor_for(self.input_shape)
-        L.check(L.lib().adas_preprocess_ufld(self._stage.frame.ptr, 1, h, w, t.ptr, self.input_height, self.input_width, 1.0, None))
+        L.check(L.lib().adas_preprocess_ufld(fptr, 1, h, w, t.ptr, self.input_height, self.input_width, 1.0, None))
         self.engine.infer_device(t.ptr, 1, None)
         dec = self._decode_for((h, w))
         dec.run_device(self.engine.output_device_ptr(0), int(np.prod(self.output_shape[0][1:])), 1, None)
@@ -670,6 +708,7 @@ class BYTETracker:
         self._tracked: List[Dict[str, Any]] = []
         self._lost: List[Dict[str, Any]] = []
         self._crops: Dict[int, list] = {}      # track id -> [crop]: strack.py:46,131-143 (filled once, when the track is activated)
+        self._traj_cache = None                # (frame_id, {track id -> boxes}): one device fetch per frame however many tracks are drawn
 
     def _cls_index(self, c):
         if isinstance(c, (int, np.integer)):
@@ -699,6 +738,8 @@ class BYTETracker:
         c = np.asarray([self._cls_index(x) for x in class_ids], np.int32)
         self._dev.update_host(0, b, s, c)
         hdr, tracked, lost = self._dev.fetch(0)
+        self._traj_cache = None
+        self._last_ids = [int(r["track_id"]) for r in tracked] + [int(r["track_id"]) for r in lost]
         if frame is not None:
             # byteTracker.py:161-168: a NEW track (unmatched detection over det_thresh) is activated and takes one crop of the frame at
             # its box (strack.py:131-143: tlwh truncated to int, clipped to the frame, copied); older tracks keep theirs
@@ -722,11 +763,15 @@ class BYTETracker:
     def trajectories(self) -> Dict[int, list]:
         """track id -> STrack.trajectories (strack.py:53,115): the last 30 detection boxes (tlbr, fp64) the track was updated with,
         oldest first, for every tracked and lost track -- what DrawTrackedOnFrame hands to plot_trajectories (byteTracker.py:202-215).
-        Fetched from the device on demand (update() does not pay for it)."""
-        hdr, tracked, lost = self._dev.fetch(0)
-        traj = self._dev.fetch_trajectories(0)
-        ids = [int(r["track_id"]) for r in tracked] + [int(r["track_id"]) for r in lost]
-        return {tid: [b.copy() for b in t] for tid, t in zip(ids, traj)}
+        Fetched from the device on demand (update() does not pay for it), once per frame: drawing N tracks costs one fetch, not N."""
+        if self._traj_cache is None or self._traj_cache[0] != self.frame_id:
+            ids = getattr(self, "_last_ids", None)
+            if ids is None:
+                hdr, tracked, lost = self._dev.fetch(0)
+                ids = [int(r["track_id"]) for r in tracked] + [int(r["track_id"]) for r in lost]
+            traj = self._dev.fetch_trajectories(0)
+            self._traj_cache = (self.frame_id, {tid: list(t) for tid, t in zip(ids, traj)})
+        return {tid: [b.copy() for b in t] for tid, t in self._traj_cache[1].items()}
 
     def filter_trajectories(self, track_id: int, frame, pad: tuple = (0, 0)) -> list:
         """STrack.filter_trajectories (strack.py:145-149) of one track: the boxes that lie inside the frame shrunk by `pad`."""
@@ -747,6 +792,7 @@ class BYTETracker:
         self.frame_id = 0
         self._tracked, self._lost = [], []
         self._crops = {}
+        self._traj_cache, self._last_ids = None, None
         self._dev.reset(0)
 
     def close(self):

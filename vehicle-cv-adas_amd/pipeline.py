@@ -11,6 +11,7 @@ import numpy as np
 from . import _lib as L
 from .coreEngine import HipEngine
 from .postproc import YoloPost, UfldDecode, Ufld1Decode, LaneGeometry, DeviceTracker, letterbox
+from . import sharding
 
 CULANE = dict(grid_row=200, cls_row=72, grid_col=100, cls_col=81,
               row_anchor=np.linspace(0.42, 1, 72), col_anchor=np.linspace(0, 1, 81))   # ultrafastLaneDetectorV2.py:49-55
@@ -25,6 +26,7 @@ class AdasPipeline:
         stream, frame b of stream s at index b * n_streams + s of the input and of every per-frame fetch; the tracker consumes
         them in order.  Throughput mode for few streams per GPU."""
         self.S = n_streams
+        self.stream_ids = list(range(n_streams))      # job-wide ids of the local streams (for_rank overrides)
         self.B = max(1, int(micro_batch))
         n_tracks = n_streams
         n_streams = n_streams * self.B          # frames per step through the engines / post / decode handles
@@ -64,6 +66,19 @@ class AdasPipeline:
         h = C.c_void_p()
         L.check(L.lib().adas_pipeline_create(C.byref(d), C.byref(h)))
         self.h = h.value
+
+    @classmethod
+    def for_rank(cls, det_model, lane_model, total_streams, env=None, **kw):
+        """The pipeline of ONE rank of a `total_streams`-stream job (one process per GPU): the rank runs the streams
+        sharding.streams_of_rank deals it (stream s -> rank s mod world); `.stream_ids[i]` is the job-wide id of local stream i.
+        Returns None for a rank that owns no stream (fewer streams than ranks)."""
+        env = env or sharding.RankEnv.from_environ()
+        ids = sharding.streams_of_rank(int(total_streams), env)
+        if not ids:
+            return None
+        p = cls(det_model, lane_model, n_streams=len(ids), **kw)
+        p.stream_ids = ids
+        return p
 
     def step(self, d_det_ptr=None, d_lane_ptr=None):
         L.check(L.lib().adas_pipeline_step(self.h, d_det_ptr, d_lane_ptr))

@@ -33,6 +33,68 @@ def streams_of_rank(n_streams: int, env: RankEnv) -> List[int]:
     return assign_streams(n_streams, env.world)[env.rank]
 
 
+def parse_cpulist(text: str) -> List[int]:
+    """'0-3,8,10-11' (sysfs cpulist) -> [0, 1, 2, 3, 8, 10, 11]."""
+    out: List[int] = []
+    for part in text.strip().split(","):
+        if not part:
+            continue
+        lo, _, hi = part.partition("-")
+        out.extend(range(int(lo), int(hi or lo) + 1))
+    return out
+
+
+def gpu_numa_node(pci_bdf: Optional[str], sysfs: str = "/sys") -> int:
+    """NUMA node of a PCI device ('0000:c1:00.0'), -1 when the platform does not say."""
+    if not pci_bdf:
+        return -1
+    try:
+        with open(os.path.join(sysfs, "bus", "pci", "devices", pci_bdf.lower(), "numa_node")) as f:
+            return int(f.read().strip())
+    except (OSError, ValueError):
+        return -1
+
+
+def rank_cpus(local_rank: int, local_world: int, allowed: Sequence[int], node_cpus: Optional[Sequence[int]] = None) -> List[int]:
+    """CPUs a rank's launching thread may run on.  With the GPU's NUMA node known: the node's CPUs (within the allowed set), divided
+    among the ranks that share that node is left to the scheduler -- the point is locality to the GPU's root complex.  Without: a
+    contiguous 1/local_world share of the allowed set, so eight launching threads do not migrate over each other (the frame-at-a-time
+    path is bound by the launching thread, profiles/r05/b1_overlap.txt)."""
+    allowed = sorted(allowed)
+    if node_cpus:
+        near = [c for c in allowed if c in set(node_cpus)]
+        if near:
+            return near
+    if local_world <= 1 or len(allowed) < local_world:
+        return list(allowed)
+    per = len(allowed) // local_world
+    return allowed[local_rank * per:(local_rank + 1) * per]
+
+
+def pin_rank(local_rank: int, local_world: int, pci_bdf: Optional[str] = None, sysfs: str = "/sys") -> Dict[str, object]:
+    """Pin the calling process (its launching thread and the threads it starts later) near its GPU; never raises.
+    -> {'numa_node', 'cpus' (count), 'first_cpu', 'pinned'} for the per-rank report."""
+    info: Dict[str, object] = {"numa_node": -1, "cpus": 0, "first_cpu": -1, "pinned": False}
+    try:
+        allowed = sorted(os.sched_getaffinity(0))
+        node = gpu_numa_node(pci_bdf, sysfs)
+        node_cpus = None
+        if node >= 0:
+            try:
+                with open(os.path.join(sysfs, "devices", "system", "node", "node%d" % node, "cpulist")) as f:
+                    node_cpus = parse_cpulist(f.read())
+            except (OSError, ValueError):
+                node_cpus = None
+        cpus = rank_cpus(local_rank, local_world, allowed, node_cpus)
+        info.update(numa_node=node, cpus=len(cpus), first_cpu=cpus[0] if cpus else -1)
+        if cpus and len(cpus) < len(allowed):
+            os.sched_setaffinity(0, cpus)
+            info["pinned"] = True
+    except (AttributeError, OSError, ValueError):
+        pass
+    return info
+
+
 def init_process_group(env: RankEnv, backend: Optional[str] = None, device=None):
     """One process per GPU.  Returns torch.distributed (initialised) or None when world == 1."""
     if env.world <= 1:
@@ -74,6 +136,6 @@ def aggregate_throughput(per_rank: List[Dict[str, float]]) -> Dict[str, float]:
     """Whole-job frames/s = all frames / slowest rank's seconds; per-rank rates kept for the scaling report."""
     frames = sum(r["frames"] for r in per_rank)
     seconds = max(r["seconds"] for r in per_rank)
+    rates = [r["frames"] / r["seconds"] for r in per_rank if r["seconds"] > 0]      # a rank that owns no stream reports 0 frames in 0 s
     return {"frames": frames, "seconds": seconds, "fps": frames / seconds if seconds > 0 else 0.0,
-            "min_rank_fps": min(r["frames"] / r["seconds"] for r in per_rank),
-            "max_rank_fps": max(r["frames"] / r["seconds"] for r in per_rank)}
+            "min_rank_fps": min(rates) if rates else 0.0, "max_rank_fps": max(rates) if rates else 0.0}
