@@ -509,12 +509,16 @@ def idle_rank(SH, dist, args, stat_dev, pin):
     """A rank the stream router gave nothing (fewer streams than ranks): it runs no pipeline but takes part in every collective of the
     working ranks -- one barrier per timed loop, the clock reduction, the statistics gather, the closing barrier."""
     import torch
-    for _ in range(1 + max(0, args.repeats)):
+
+    def barrier():
         if torch.cuda.is_available():
             torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
-    SH.max_over_ranks(0.0, dist, stat_dev)
+    barrier()                                    # the headline loop's barrier (timed_loop)
+    SH.max_over_ranks(0.0, dist, stat_dev)       # ... its clock reduction
+    for _ in range(max(0, args.repeats)):        # ... one barrier per repeat of the loop
+        barrier()
     SH.gather_stats({"frames": 0.0, "seconds": 0.0, "p50_ms": 0.0, "p99_ms": 0.0, "streams": 0.0, "numa_node": float(pin["numa_node"]),
                      "cpus": float(pin["cpus"]), "pinned": float(bool(pin["pinned"]))}, STAT_KEYS, dist, stat_dev)
     if dist is not None:

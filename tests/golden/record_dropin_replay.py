@@ -71,14 +71,20 @@ def main():
     wl = M.SynthWeights(1, gain=M.RELU_RES_GAIN)
     lane_path = M.build("ufldv2_res18", wsrc=wl).save(os.path.join(work, "lane.hipm"))
     lane = D.UltrafastLaneDetectorV2(lane_path, D.LaneModelType.UFLDV2_CULANE)
-    seed = None
-    for cand in range(100, 164):
+    best = None
+    for cand in range(100, 356):
         lane.DetectFrame(replay_frame(cand))
-        if lane.lane_info.area_status and sum(bool(s) for s in lane.lane_info.lanes_status) >= 3:
-            seed = cand
+        li = lane.lane_info
+        n_found = sum(bool(s) for s in li.lanes_status)
+        key = (bool(li.area_status), n_found, sum(len(p) for p in li.lanes_points if p is not None))
+        if best is None or key > best[0]:
+            best = (key, cand)
+        if key[0] and n_found >= 3:
             break
-    if seed is None:
-        raise SystemExit("no frame with both ego lanes among the 64 candidates")
+    (has_area, n_found, n_points), seed = best
+    print("frame seed %d: ego-lane area %s, %d lanes found, %d lane points (best of the candidates examined)" % (seed, has_area, n_found, n_points))
+    if n_found < 1:
+        raise SystemExit("no candidate frame carries a detected lane")
     frame = replay_frame(seed)
 
     # detector: calibrated on this frame and three neighbours (about 40 anchors over box_score on the median frame)

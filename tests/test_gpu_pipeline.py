@@ -141,7 +141,8 @@ def test_bench_gpus_n_relaunches_n_ranks(tmp_path, split, frames_per_step, strea
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", *split,
-                          "--no-cpu-baseline", "--precision", "fp16"], env=env, capture_output=True, text=True, timeout=900)
+                          "--no-cpu-baseline", "--precision", "fp16", "--repeats", "1", "--latency-steps", "8"], env=env, capture_output=True,
+                         text=True, timeout=400)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, out.stdout[-2000:]

@@ -68,7 +68,7 @@ def test_reference_lane_detector_on_replayed_engine_equals_device_results(replay
     area decision and polygon (within 2 px: it is a least-squares refit of those points)."""
     got, fx = replayed
     l = got["lane"]
-    assert l["status"] == [bool(s) for s in fx["lane_status"]] and sum(l["status"]) >= 2
+    assert l["status"] == [bool(s) for s in fx["lane_status"]] and sum(l["status"]) >= 1
     for i in range(4):
         want = fx["lane_points%d" % i].reshape(-1, 2)
         have = np.asarray(l["points"][i], np.int64).reshape(-1, 2)

@@ -9,8 +9,11 @@ import os, subprocess, sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
-OUT = os.path.join(HERE, "libadas_hip.so")
-OBJ = os.path.join(HERE, "_obj")
+# ADAS_BUILD_TAG=<tag>: a scratch build (instrumented / experimental flags through ADAS_CFLAGS) beside the product library --
+# _scratch/libadas_hip_<tag>.so with its own object directory; tools load it through ADAS_LIB=
+TAG = os.environ.get("ADAS_BUILD_TAG", "")
+OUT = os.path.join(HERE, "_scratch", f"libadas_hip_{TAG}.so") if TAG else os.path.join(HERE, "libadas_hip.so")
+OBJ = os.path.join(HERE, "_scratch", f"_obj_{TAG}") if TAG else os.path.join(HERE, "_obj")
 ARCH = "gfx950"
 
 # (source, extra flags)
@@ -54,6 +57,7 @@ def _deps():
 def build(force=False, verbose=True):
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     os.makedirs(OBJ, exist_ok=True)
+    os.makedirs(os.path.dirname(OUT), exist_ok=True)
     hdr_t = max(os.path.getmtime(h) for h in _deps())
     objs, todo = [], []
     for src, extra in UNITS:

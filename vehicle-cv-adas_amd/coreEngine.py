@@ -42,8 +42,8 @@ def _container_io_half(path):
     """Bit 16 of the ADASHIP1 header's in_cpad word (csrc/engine.h FileHeader): the source model's graph I/O is float16."""
     try:
         with open(path, "rb") as f:
-            hd = f.read(44)
-        return len(hd) == 44 and hd[:8] == b"ADASHIP1" and bool((int.from_bytes(hd[40:44], "little") >> 16) & 1)
+            hd = f.read(40)       # magic[8], version, n_bufs, n_ops, n_outputs, in_c, in_h, in_w, in_cpad (uint32 each)
+        return len(hd) == 40 and hd[:8] == b"ADASHIP1" and bool((int.from_bytes(hd[36:40], "little") >> 16) & 1)
     except OSError:
         return False
 

@@ -79,7 +79,21 @@ __host__ __device__ constexpr int x8_allow(int mode, int k) {
 // 16 eight-byte loads (4 pixel tiles x 2 channel tiles x {hi, lo})
 constexpr int X8_NBIAS = 2, X8_NRES = 16;
 
-template <int ACT, int MODE>
+#ifdef ADAS_H8X_PROF   // scratch instrumentation (tools/experiments/h8x_prof.py): shader cycles of waves 0 and 4 per item phase
+__device__ unsigned long long g_h8x_prof[256][32];
+#define H8XP(i)                                     \
+    if (lane == 0 && grp == 0) {                    \
+        const unsigned long long t__ = clock64();   \
+        pacc__[i] += t__ - tprev__;                 \
+        tprev__ = t__;                              \
+    }
+#else
+#define H8XP(i)
+#endif
+
+// LH: the weight tiles of an L half-chunk are fetched as their CROSS rows only (rows 32-63 of each 64-row block: the main rows are
+// zeros that no MFMA reads) -- every wave still issues one piece per tap, with the upper half of its lanes masked off: 512 B = 8 rows
+template <int ACT, int MODE, bool LH>
 __global__ __launch_bounds__(X8_THR, 1) void conv_h8x3_kernel(H8XDev a) {
     Fp16::enter();
     typedef Fp16::vec8 hvec8;
@@ -109,6 +123,10 @@ __global__ __launch_bounds__(X8_THR, 1) void conv_h8x3_kernel(H8XDev a) {
     // halves sit at group * 32 bytes (its lo halves 16 bytes behind)
     const uint32_t wpiece = (uint32_t)((lane & 3) ^ (((lane >> 4) & 1) << 1)) << 5;
     const uint32_t wrd = (uint32_t)(X8_WR + hb * 4096 + lrow * 64 + ((kg ^ gsw[(lrow >> 2) & 3]) << 4));
+    // LH pieces: wave grp brings rows 32 + 8 grp .. + 7 of its block (lanes 0-31: row lane >> 2), i.e. rows 8 (grp & 1) .. + 7 of the
+    // 16-row tile 2 + (grp >> 1) -- the swizzle key is the row's position in THAT tile
+    const uint32_t wlane_h = (uint32_t)((lane >> 2) * 64 + (((lane & 3) ^ gsw[(((lane >> 4) & 1) + 2 * (grp & 1)) & 3]) << 4));
+    const uint32_t wdst_h = (uint32_t)(X8_WR + hb * 4096 + 2048 + grp * 512);
     // epilogue: lane owns channels kg*4 .. +3 of 16-channel tile i of the wave group's 32: G8 byte offset of their hi halves within
     // the pixel's 64-channel run (lo halves 16 bytes behind): group (hb*32 + i*16 + kg*4) / 8, element (kg & 1) * 4
     const uint32_t ch_lane = (uint32_t)((hb * 4 + (kg >> 1)) * 32 + (kg & 1) * 8);
@@ -200,8 +218,14 @@ __global__ __launch_bounds__(X8_THR, 1) void conv_h8x3_kernel(H8XDev a) {
     x8_wait_vm<0>();
     __builtin_amdgcn_s_barrier();
     if (MODE == 1 && hb) __builtin_amdgcn_s_barrier();   // group 1 runs one segment behind group 0
+#ifdef ADAS_H8X_PROF
+    unsigned long long tprev__ = clock64();
+    unsigned long long pacc__[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    int nit__ = 0;
+#endif
 
     for (;;) {
+        H8XP(0)
         const bool newtile = cbi + 1 == a.cpw;
         const bool has_next = !newtile || ti + nslot < units_here;
         const int cbn = newtile ? first_cb(has_next ? ti + nslot : ti) : cb + 1;
@@ -250,8 +274,15 @@ __global__ __launch_bounds__(X8_THR, 1) void conv_h8x3_kernel(H8XDev a) {
                 for (int j = 0; j < 4; ++j) xf[j] = *reinterpret_cast<const hvec8*>(lds8 + xoff[j][kk] + winr);
                 {
                     constexpr int kt = (kk + LOOK) % 9;
+                    constexpr bool tgt_lo = (kk + LOOK < 9) ? islo : !islo;     // the half-chunk this tap tile belongs to (the chunks alternate H, L)
                     const uint32_t src = (kk + LOOK < 9 ? wthis : wnext) + (uint32_t)kt * 4096u;
-                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rwg, (ylds_vp)(lds8 + X8_WR + kt * X8_TAP + wave * 1024), 16, wlane, src, 0, 0);
+                    if (LH && tgt_lo) {
+                        // (wthis / wnext carry this wave's grp * 1024: the cross rows of the wave's piece sit at + 2048 - 512 grp from there)
+                        if (lane < 32)
+                            __builtin_amdgcn_raw_ptr_buffer_load_lds(rwg, (ylds_vp)(lds8 + wdst_h + kt * X8_TAP), 16, wlane_h, src + 2048u - (uint32_t)grp * 512u, 0, 0);
+                    } else {
+                        __builtin_amdgcn_raw_ptr_buffer_load_lds(rwg, (ylds_vp)(lds8 + X8_WR + kt * X8_TAP + wave * 1024), 16, wlane, src, 0, 0);
+                    }
                 }
                 if constexpr (kk >= 1 && kk <= X8_NWP)
                     __builtin_amdgcn_raw_ptr_buffer_load_lds(rin, (ylds_vp)(lds8 + winw + (wave + 8 * (kk - 1)) * 1024), 16, lastc ? gnxt[kk - 1] : gcur[kk - 1], 0, 0, 0);
@@ -293,6 +324,9 @@ __global__ __launch_bounds__(X8_THR, 1) void conv_h8x3_kernel(H8XDev a) {
             tap(std::integral_constant<int, 0>{}); tap(std::integral_constant<int, 1>{}); tap(std::integral_constant<int, 2>{});
             tap(std::integral_constant<int, 3>{}); tap(std::integral_constant<int, 4>{}); tap(std::integral_constant<int, 5>{});
             tap(std::integral_constant<int, 6>{}); tap(std::integral_constant<int, 7>{}); tap(std::integral_constant<int, 8>{});
+#ifdef ADAS_H8X_PROF
+            if (lastc) { H8XP(3) } else if (islo) { H8XP(2) } else { H8XP(1) }
+#endif
         };
         for (int c = 0; c + 1 < a.nck; ++c) {
             if (c & 1) chunk(std::false_type{}, std::true_type{}, c);
@@ -302,6 +336,7 @@ __global__ __launch_bounds__(X8_THR, 1) void conv_h8x3_kernel(H8XDev a) {
 
         // ---------------- epilogue: lane holds channels kg*4..+3 of pixel lrow of every (i, j) tile
         __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
+        H8XP(4)
         auto write_out = [&](auto rm_c) {
             constexpr int RM = decltype(rm_c)::value;
 #pragma unroll
@@ -344,6 +379,10 @@ __global__ __launch_bounds__(X8_THR, 1) void conv_h8x3_kernel(H8XDev a) {
         if (a.res_mode == RES_NONE) write_out(std::integral_constant<int, RES_NONE>{});
         else if (a.res_mode == RES_BEFORE_ACT) write_out(std::integral_constant<int, RES_BEFORE_ACT>{});
         else write_out(std::integral_constant<int, RES_AFTER_ACT>{});
+        H8XP(5)
+#ifdef ADAS_H8X_PROF
+        ++nit__;
+#endif
 
         if (!has_next) break;
         if (newtile) {
@@ -360,7 +399,33 @@ __global__ __launch_bounds__(X8_THR, 1) void conv_h8x3_kernel(H8XDev a) {
         par = (par + a.nck) & 1;
     }
     if (MODE == 1 && !hb) __builtin_amdgcn_s_barrier();   // pairs with group 1's extra barrier
+#ifdef ADAS_H8X_PROF
+    if (lane == 0 && grp == 0) {
+        unsigned long long* b__ = g_h8x_prof[blockIdx.x & 255];
+        for (int i__ = 0; i__ < 16; ++i__)
+            if (i__ != 7) atomicAdd(&b__[i__ + 16 * hb], pacc__[i__]);
+        atomicAdd(&b__[7 + 16 * hb], (unsigned long long)nit__);
+    }
+#endif
 }
+
+#ifdef ADAS_H8X_PROF
+extern "C" int adas_debug_h8x_prof(unsigned long long* out32, int reset) {
+    static unsigned long long h[256][32];
+    if (out32) {   // 32 values: 16 per wave group, summed over workgroups
+        if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_h8x_prof), sizeof(h)) != hipSuccess) return -1;
+        for (int i = 0; i < 32; ++i) {
+            out32[i] = 0;
+            for (int b = 0; b < 256; ++b) out32[i] += h[b][i];
+        }
+    }
+    if (reset) {
+        memset(h, 0, sizeof(h));
+        if (hipMemcpyToSymbol(HIP_SYMBOL(g_h8x_prof), h, sizeof(h)) != hipSuccess) return -1;
+    }
+    return 0;
+}
+#endif
 
 // -------------------------------------------------------------------------------------
 static int x8_mode() {   // ADAS_HALO8_X3: 0 off, 1 on (default: synchronisation variant picked per layer), 2 / 3 force variant 2 / 1
@@ -441,20 +506,29 @@ hipError_t launch_pack_weights_h8x3(const float* src, void* dst, int cout, int c
     return hipGetLastError();
 }
 
-template <int MODE>
+static bool x8_lhalf() {   // ADAS_H8X_LHALF=0: fetch whole weight tiles for the L half-chunks too (the round-4 / 5 kernel)
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("ADAS_H8X_LHALF");
+        v = e ? atoi(e) : 1;
+    }
+    return v != 0;
+}
+
+template <int MODE, bool LH>
 static hipError_t x8_launch(const H8XDev& d, int act, dim3 grid, hipStream_t st) {
     static bool attr_done = false;
     if (!attr_done) {
-        (void)hipFuncSetAttribute((const void*)conv_h8x3_kernel<ACT_NONE, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute((const void*)conv_h8x3_kernel<ACT_SILU, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute((const void*)conv_h8x3_kernel<ACT_RELU, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute((const void*)conv_h8x3_kernel<ACT_LEAKY, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)conv_h8x3_kernel<ACT_NONE, MODE, LH>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)conv_h8x3_kernel<ACT_SILU, MODE, LH>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)conv_h8x3_kernel<ACT_RELU, MODE, LH>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)conv_h8x3_kernel<ACT_LEAKY, MODE, LH>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_done = true;
     }
-    if (act == ACT_SILU) hipLaunchKernelGGL((conv_h8x3_kernel<ACT_SILU, MODE>), grid, dim3(X8_THR), X8_LDS, st, d);
-    else if (act == ACT_RELU) hipLaunchKernelGGL((conv_h8x3_kernel<ACT_RELU, MODE>), grid, dim3(X8_THR), X8_LDS, st, d);
-    else if (act == ACT_LEAKY) hipLaunchKernelGGL((conv_h8x3_kernel<ACT_LEAKY, MODE>), grid, dim3(X8_THR), X8_LDS, st, d);
-    else hipLaunchKernelGGL((conv_h8x3_kernel<ACT_NONE, MODE>), grid, dim3(X8_THR), X8_LDS, st, d);
+    if (act == ACT_SILU) hipLaunchKernelGGL((conv_h8x3_kernel<ACT_SILU, MODE, LH>), grid, dim3(X8_THR), X8_LDS, st, d);
+    else if (act == ACT_RELU) hipLaunchKernelGGL((conv_h8x3_kernel<ACT_RELU, MODE, LH>), grid, dim3(X8_THR), X8_LDS, st, d);
+    else if (act == ACT_LEAKY) hipLaunchKernelGGL((conv_h8x3_kernel<ACT_LEAKY, MODE, LH>), grid, dim3(X8_THR), X8_LDS, st, d);
+    else hipLaunchKernelGGL((conv_h8x3_kernel<ACT_NONE, MODE, LH>), grid, dim3(X8_THR), X8_LDS, st, d);
     return hipGetLastError();
 }
 
@@ -462,6 +536,16 @@ hipError_t launch_conv_halo8_x3(const ConvArgs& a, hipStream_t st) {
     HaloPlan pl;
     if (!a.wgt_h8x3 || !halo8_x3_applicable(a.kh, a.kw, a.stride, a.pad, a.n, a.in, a.out, a.res, a.res_mode) || !plan_halo(a.out.h, a.out.w, 1, &pl))
         return hipErrorNotSupported;
+    {   // ADAS_H8X_SW=<strip width>: narrower strips = squarer tiles = smaller windows (less halo re-read) at more padded pixels; the
+        // tile grid is then re-checked against the item-count rule below (an experiment knob, like conv_halo8's ADAS_H8_SW)
+        static int sw = -1;
+        if (sw < 0) { const char* e = getenv("ADAS_H8X_SW"); sw = e ? atoi(e) : 0; }
+        HaloPlan alt;
+        if (sw > 0 && plan_halo_sw(a.out.h, a.out.w, 1, sw, X8_MAXPIX, &alt) && alt.eff >= 0.6) {
+            const long nt = (long)a.n * alt.NS * alt.TPS;
+            if (x8_blocks_per_unit((nt + 7) / 8, x8_cout_pad(a.out.c) / 64) > 0) pl = alt;
+        }
+    }
     H8XDev d;
     d.in = a.in.p; d.wgt = a.wgt_h8x3; d.bias = a.bias; d.out = a.out.p; d.res = a.res.p;
     d.in_cs = a.in.cs; d.in_coff = a.in.coff; d.cin = a.in.c; d.H = a.in.h; d.W = a.in.w;
@@ -488,7 +572,8 @@ hipError_t launch_conv_halo8_x3(const ConvArgs& a, hipStream_t st) {
     dim3 grid(8 * slots);
     const int forced = x8_mode();
     const bool pingpong = forced == 3 || (forced != 2 && d.nck >= 24);
-    return pingpong ? x8_launch<1>(d, a.act, grid, st) : x8_launch<2>(d, a.act, grid, st);
+    if (x8_lhalf()) return pingpong ? x8_launch<1, true>(d, a.act, grid, st) : x8_launch<2, true>(d, a.act, grid, st);
+    return pingpong ? x8_launch<1, false>(d, a.act, grid, st) : x8_launch<2, false>(d, a.act, grid, st);
 }
 
 }  // namespace adas
