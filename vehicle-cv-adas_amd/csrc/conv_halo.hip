@@ -88,13 +88,26 @@ static bool magic_ok(int d, int nmax, uint32_t* magic) {
 }
 
 // Ho x Wo: OUTPUT extent; S: stride (1 or 2); pad = 1, 3x3.
-static bool plan_halo_uncached(int Ho, int Wo, int S, int maxpix_cap, int bm, HaloPlan* best) {
+// policy 0 (every kernel's default until round 6): the most efficient strip width, the WIDEST on ties.
+// policy 1 (round 6): among the widths within 0.5 % of the best efficiency the one with the SMALLEST window -- a tile's window is what
+// it fetches per 32-channel chunk, and the tie rule above picked 612-pixel windows (2.4 x the tile) on the 40x200 / 20x100 maps where
+// 25-wide strips fill the tiles exactly as well from 378 (1.5 x): that difference is the "read over-fetch" of the persistent 3x3
+// kernels (265 MB against 193 MB algorithmic per conv_h8 launch, 1.06 GB against 0.69 per conv_h8x3 launch).  Adds the row cut into
+// 5 / 6 / 8 strips to the candidates.
+static bool plan_halo_uncached(int Ho, int Wo, int S, int maxpix_cap, int bm, int policy, HaloPlan* best) {
     const int BM = bm > 0 ? bm : halo_bm(S), MAXPIX = maxpix_cap > 0 ? maxpix_cap : halo_maxpix(S, BM);
     // strip widths: powers of two, the whole row, and the row cut into 2 / 3 / 4 equal strips (40x200 maps: 100-wide strips fill
     // 97.7 % of their tiles' pixels, 32-wide ones 89.3 %)
-    int cand[9] = {16, 32, 64, 128, 256, Wo, (Wo + 1) / 2, (Wo + 2) / 3, (Wo + 3) / 4};
+    int cand[12] = {16, 32, 64, 128, 256, Wo, (Wo + 1) / 2, (Wo + 2) / 3, (Wo + 3) / 4, (Wo + 4) / 5, (Wo + 5) / 6, (Wo + 7) / 8};
+    const int ncand = policy == 1 ? 12 : 9;
     bool found = false;
-    for (int k = 0; k < 9; ++k) {
+    double top = 0.0;
+    if (policy == 1)   // first pass: the best efficiency any admissible width reaches
+        for (int k = 0; k < ncand; ++k) {
+            HaloPlan q;
+            if (cand[k] >= 8 && cand[k] <= Wo && plan_halo_sw(Ho, Wo, S, cand[k], MAXPIX, &q, BM) && q.eff > top) top = q.eff;
+        }
+    for (int k = 0; k < ncand; ++k) {
         int SW = cand[k];
         if (SW < 8 || (SW > Wo && k != 5)) continue;
         if (k >= 5 && (SW == 16 || SW == 32 || SW == 64 || SW == 128 || SW == 256)) continue;
@@ -107,7 +120,9 @@ static bool plan_halo_uncached(int Ho, int Wo, int S, int maxpix_cap, int bm, Ha
         double eff = (double)Ho * Wo / ((double)NS * TPS * BM);
         uint32_t mw, ms;
         if (!magic_ok(WW, MAXPIX + 64, &mw) || !magic_ok(SW, TPS * BM + BM, &ms)) continue;
-        if (!found || eff > best->eff + 1e-9 || (eff > best->eff - 1e-9 && SW > best->SW)) {
+        const bool better = policy == 1 ? (eff >= top * 0.995 && (!found || maxpix < best->maxpix || (maxpix == best->maxpix && eff > best->eff)))
+                                        : (!found || eff > best->eff + 1e-9 || (eff > best->eff - 1e-9 && SW > best->SW));
+        if (better) {
             *best = HaloPlan{SW, NS, TPS, WW, maxpix, eff, mw, ms};
             found = true;
         }
@@ -116,8 +131,8 @@ static bool plan_halo_uncached(int Ho, int Wo, int S, int maxpix_cap, int bm, Ha
 }
 
 // one strip width, as given (experiments: ADAS_H8_SW): the same bookkeeping as a candidate of plan_halo_uncached
-bool plan_halo_sw(int Ho, int Wo, int S, int SW, int maxpix_cap, HaloPlan* out) {
-    const int BM = halo_bm(S), MAXPIX = maxpix_cap > 0 ? maxpix_cap : halo_maxpix(S, BM);
+bool plan_halo_sw(int Ho, int Wo, int S, int SW, int maxpix_cap, HaloPlan* out, int bm) {
+    const int BM = bm > 0 ? bm : halo_bm(S), MAXPIX = maxpix_cap > 0 ? maxpix_cap : halo_maxpix(S, BM);
     if (SW < 8) return false;
     int rows = (BM + SW - 1) / SW + ((BM % SW) ? 1 : 0);
     int WW = (SW - 1) * S + 3;
@@ -133,15 +148,15 @@ bool plan_halo_sw(int Ho, int Wo, int S, int SW, int maxpix_cap, HaloPlan* out) 
 }
 
 // plans are pure functions of (Ho, Wo, S): memoised so eager launches do not redo the exhaustive checks
-bool plan_halo(int Ho, int Wo, int S, HaloPlan* out, int maxpix_cap, int bm) {
+bool plan_halo(int Ho, int Wo, int S, HaloPlan* out, int maxpix_cap, int bm, int policy) {
     static std::mutex mu;
-    static std::map<std::tuple<int, int, int, int, int>, std::pair<bool, HaloPlan>> cache;
+    static std::map<std::tuple<int, int, int, int, int, int>, std::pair<bool, HaloPlan>> cache;
     std::lock_guard<std::mutex> lk(mu);
-    auto key = std::make_tuple(Ho, Wo, S, maxpix_cap, bm);
+    auto key = std::make_tuple(Ho, Wo, S, maxpix_cap, bm, policy);
     auto it = cache.find(key);
     if (it == cache.end()) {
         HaloPlan p{};
-        bool ok = plan_halo_uncached(Ho, Wo, S, maxpix_cap, bm, &p);
+        bool ok = plan_halo_uncached(Ho, Wo, S, maxpix_cap, bm, policy, &p);
         it = cache.emplace(key, std::make_pair(ok, p)).first;
     }
     *out = it->second.second;

@@ -62,6 +62,14 @@ struct H8Dev {
 constexpr int H8_THR = 512;
 constexpr int H8_BM = 256;
 constexpr int H8_MAXPIX = 640;
+static int h8_policy() {   // ADAS_H8_PLAN: strip-width policy of plan_halo (kernels.h): 1 = smallest window among the most efficient widths
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("ADAS_H8_PLAN");
+        v = e ? atoi(e) : 0;
+    }
+    return v;
+}
 constexpr int H8_WIN = H8_MAXPIX * 64;          // bytes of one window buffer
 constexpr int H8_TAP = 2 * 64 * 64;             // bytes of one tap's weights (two 64-row blocks)
 constexpr int H8_WR = 2 * H8_WIN;               // byte offset of the weight ring
@@ -544,7 +552,7 @@ bool halo8_applicable(int kh, int kw, int stride, int pad, int n, const TView& i
     if ((double)n * in.h * in.w * in.cs * 2.0 >= (double)H8_OOB || (double)n * out.h * out.w * out.cs * 2.0 >= (double)H8_OOB) return false;
     if (res_mode != RES_NONE && (double)n * out.h * out.w * res.cs * 2.0 >= (double)H8_OOB) return false;
     HaloPlan pl;
-    if (!plan_halo(out.h, out.w, 1, &pl) || pl.eff < 0.6 || pl.maxpix > H8_MAXPIX) return false;
+    if (!plan_halo(out.h, out.w, 1, &pl, H8_MAXPIX, 0, h8_policy()) || pl.eff < 0.6 || pl.maxpix > H8_MAXPIX) return false;
     // one workgroup per CU walking its XCD's items in rounds of 32: the launch has to fill the chip, in nearly whole rounds
     const long ntiles = (long)n * pl.NS * pl.TPS, tiles8 = (ntiles + 7) / 8;
     if (ntiles * (out.c / 128) * pl.NS * pl.TPS >= (1L << 32)) return false;
@@ -614,7 +622,7 @@ static hipError_t h8_launch(const H8Dev& d, int act, dim3 grid, hipStream_t st) 
 
 hipError_t launch_conv_halo8(const ConvArgs& a, hipStream_t st) {
     HaloPlan pl;
-    if (!halo8_applicable(a.kh, a.kw, a.stride, a.pad, a.n, a.in, a.out, a.res, a.res_mode) || !plan_halo(a.out.h, a.out.w, 1, &pl))
+    if (!halo8_applicable(a.kh, a.kw, a.stride, a.pad, a.n, a.in, a.out, a.res, a.res_mode) || !plan_halo(a.out.h, a.out.w, 1, &pl, H8_MAXPIX, 0, h8_policy()))
         return hipErrorNotSupported;
     {   // ADAS_H8_SW=<strip width>: narrower strips = squarer tiles = less halo per window (and more padded pixels): an experiment knob
         static int sw = -1;

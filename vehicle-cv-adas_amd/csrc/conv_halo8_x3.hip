@@ -93,8 +93,21 @@ __device__ unsigned long long g_h8x_prof[256][32];
 
 // LH: the weight tiles of an L half-chunk are fetched as their CROSS rows only (rows 32-63 of each 64-row block: the main rows are
 // zeros that no MFMA reads) -- every wave still issues one piece per tap, with the upper half of its lanes masked off: 512 B = 8 rows
-template <int ACT, int MODE, bool LH>
+// SH (round 6, MODE 2 only): the L half-chunk of a 32-channel chunk multiplies the lo activations by w_hi -- the MAIN rows of the H
+// half-chunk's own weight tiles, which sit in the 9-slot ring while the H taps run.  With SH the ring keeps a chunk's nine tiles through
+// BOTH half-chunks and the L taps read those main rows: no weight tile is fetched for an L half-chunk at all (half the weight DMA
+// instructions and bytes of the stream).  Tile t of the next chunk may overwrite slot t once the L tap row that reads it has passed its
+// barrier, and must be issued two tap rows before the H tap row that reads it: exactly one tap row fits -- tiles 0-2 go out under L
+// taps 3-5, tiles 3-5 under L taps 6-8, tiles 6-8 under the next H taps 0-2 ("tile (kk + 6) % 9" as before, on those taps only).
+// NWP: window pieces per wave and half-chunk (1 KiB each, 16 pixels): 3 / 4 / 5 for windows up to 384 / 512 / 640 pixels -- a tile's
+// window rarely fills the 640-pixel buffer, and every piece is a DMA instruction whether its lanes are in range or not.
+__host__ __device__ constexpr int x8s_issued(bool lo, int k, int nwp) { return ((lo ? k >= 3 : (k >= 0 && k < 3)) ? 1 : 0) + ((k >= 1 && k <= nwp) ? 1 : 0); }
+__host__ __device__ constexpr int x8s_allow(bool lo, int k, int nwp) { return x8s_issued(lo, k, nwp) + x8s_issued(lo, k - 1, nwp) + x8s_issued(lo, k - 2, nwp); }
+
+template <int ACT, int MODE, bool LH, bool SH = false, int NWP = X8_NWP>
 __global__ __launch_bounds__(X8_THR, 1) void conv_h8x3_kernel(H8XDev a) {
+    static_assert(!SH || (MODE == 2 && !LH), "shared weight tiles: one barrier per tap row, whole tiles");
+    static_assert(NWP >= 1 && NWP <= X8_NWP && (SH || NWP == X8_NWP), "window pieces per wave");
     Fp16::enter();
     typedef Fp16::vec8 hvec8;
     constexpr int LOOK = x8_look(MODE);
@@ -182,11 +195,11 @@ __global__ __launch_bounds__(X8_THR, 1) void conv_h8x3_kernel(H8XDev a) {
     auto first_cb = [&](int u) { return upt == 1 ? 0 : (u - (int)__umulhi((uint32_t)u, a.mg_upt) * upt) * a.cpw; };
     int ti = slot, cb = first_cb(slot), cbi = 0;
     Tile cur = decode(ti);
-    uint32_t gcur[X8_NWP], gnxt[X8_NWP];
+    uint32_t gcur[NWP], gnxt[NWP];
     uint32_t xoff[4][9];
     uint32_t po[4];
 #pragma unroll
-    for (int i = 0; i < X8_NWP; ++i) gcur[i] = win_offset(cur, i);
+    for (int i = 0; i < NWP; ++i) gcur[i] = win_offset(cur, i);
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const uint32_t ap64 = tap00(cur, j);
@@ -201,7 +214,7 @@ __global__ __launch_bounds__(X8_THR, 1) void conv_h8x3_kernel(H8XDev a) {
 
     // ---- prologue: window of half-chunk 0 into buffer 0, weights of taps 0 .. LOOK-1
 #pragma unroll
-    for (int i = 0; i < X8_NWP; ++i)
+    for (int i = 0; i < NWP; ++i)
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rin, (ylds_vp)(lds8 + (wave + 8 * i) * 1024), 16, gcur[i], 0, 0, 0);
 #pragma unroll
     for (int t = 0; t < LOOK; ++t)
@@ -247,7 +260,7 @@ __global__ __launch_bounds__(X8_THR, 1) void conv_h8x3_kernel(H8XDev a) {
                 // the half-chunk fetched during this one: after an H chunk its own lo pieces (16 bytes on), after an L chunk the hi
                 // pieces of the next 32 channels (a group is 32 bytes, a chunk 128)
 #pragma unroll
-                for (int i = 0; i < X8_NWP; ++i) gcur[i] += islo ? 112u : 16u;
+                for (int i = 0; i < NWP; ++i) gcur[i] += islo ? 112u : 16u;
             }
             const uint32_t wthis = wcur + (uint32_t)c * X8_SLAB;
             const uint32_t wnext = lastc ? wnxt_item : wthis + X8_SLAB;
@@ -268,11 +281,18 @@ __global__ __launch_bounds__(X8_THR, 1) void conv_h8x3_kernel(H8XDev a) {
                     }
                 }
                 hvec8 wf[4], xf[4];
+                // (SH: an L tap multiplies by the MAIN rows -- w_hi -- of the chunk's H tile, still in slot kk)
 #pragma unroll
-                for (int i = islo ? 2 : 0; i < 4; ++i) wf[i] = *reinterpret_cast<const hvec8*>(lds8 + wrd + kk * X8_TAP + i * 1024);
+                for (int i = islo ? 2 : 0; i < 4; ++i) wf[i] = *reinterpret_cast<const hvec8*>(lds8 + wrd + kk * X8_TAP + ((SH && islo) ? i - 2 : i) * 1024);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) xf[j] = *reinterpret_cast<const hvec8*>(lds8 + xoff[j][kk] + winr);
-                {
+                if constexpr (SH) {
+                    if constexpr (islo ? kk >= 3 : kk < 3) {
+                        constexpr int kt = (kk + 6) % 9;      // H taps 0-2: tiles 6-8 of this chunk; L taps 3-8: tiles 0-5 of the next chunk (or item)
+                        const uint32_t src = (islo ? wnext : wthis) + (uint32_t)kt * 4096u;
+                        __builtin_amdgcn_raw_ptr_buffer_load_lds(rwg, (ylds_vp)(lds8 + X8_WR + kt * X8_TAP + wave * 1024), 16, wlane, src, 0, 0);
+                    }
+                } else {
                     constexpr int kt = (kk + LOOK) % 9;
                     constexpr bool tgt_lo = (kk + LOOK < 9) ? islo : !islo;     // the half-chunk this tap tile belongs to (the chunks alternate H, L)
                     const uint32_t src = (kk + LOOK < 9 ? wthis : wnext) + (uint32_t)kt * 4096u;
@@ -284,13 +304,15 @@ __global__ __launch_bounds__(X8_THR, 1) void conv_h8x3_kernel(H8XDev a) {
                         __builtin_amdgcn_raw_ptr_buffer_load_lds(rwg, (ylds_vp)(lds8 + X8_WR + kt * X8_TAP + wave * 1024), 16, wlane, src, 0, 0);
                     }
                 }
-                if constexpr (kk >= 1 && kk <= X8_NWP)
+                if constexpr (kk >= 1 && kk <= NWP)
                     __builtin_amdgcn_raw_ptr_buffer_load_lds(rin, (ylds_vp)(lds8 + winw + (wave + 8 * (kk - 1)) * 1024), 16, lastc ? gnxt[kk - 1] : gcur[kk - 1], 0, 0, 0);
                 constexpr bool sync_here = MODE != 2 || kk % 3 == 2;
+                // what may stay in flight past this point: the pieces issued in this tap row (MODE 2) / the last three taps
+                constexpr int allow = SH ? x8s_allow(islo, kk, NWP) : x8_allow(MODE, kk);
                 if (sync_here && (c > 0 || kk >= 3)) {
-                    if (lastc && kk >= 6 && has_res) x8_wait_vm<x8_allow(MODE, kk) + X8_NBIAS + X8_NRES>();
-                    else if (lastc && kk >= 6) x8_wait_vm<x8_allow(MODE, kk) + X8_NBIAS>();
-                    else x8_wait_vm<x8_allow(MODE, kk)>();
+                    if (lastc && kk >= 6 && has_res) x8_wait_vm<allow + X8_NBIAS + X8_NRES>();
+                    else if (lastc && kk >= 6) x8_wait_vm<allow + X8_NBIAS>();
+                    else x8_wait_vm<allow>();
                 }
                 if (MODE == 1) {
                     __builtin_amdgcn_sched_barrier(0);
@@ -301,7 +323,7 @@ __global__ __launch_bounds__(X8_THR, 1) void conv_h8x3_kernel(H8XDev a) {
                 if (lastc) {
 #pragma unroll
                     for (int j = 0; j < 4; ++j) xoff[j][kk] = tap_offset(apn[j], kk);
-                    if constexpr (kk < X8_NWP) gnxt[kk] = win_offset(nxt, kk);
+                    if constexpr (kk < NWP) gnxt[kk] = win_offset(nxt, kk);
                 }
 #pragma unroll
                 for (int i = islo ? 2 : 0; i < 4; ++i)
@@ -394,7 +416,7 @@ __global__ __launch_bounds__(X8_THR, 1) void conv_h8x3_kernel(H8XDev a) {
         cb = cbn;
         cbi = newtile ? 0 : cbi + 1;
 #pragma unroll
-        for (int i = 0; i < X8_NWP; ++i) gcur[i] = gnxt[i];
+        for (int i = 0; i < NWP; ++i) gcur[i] = gnxt[i];
         wcur = wnxt_item;
         par = (par + a.nck) & 1;
     }
@@ -437,6 +459,16 @@ static int x8_mode() {   // ADAS_HALO8_X3: 0 off, 1 on (default: synchronisation
     return v;
 }
 
+static int x8_policy() {   // ADAS_H8X_PLAN: 1 (default) = smallest window among the most efficient strip widths, 0 = the widest strip (rounds 4-5)
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("ADAS_H8X_PLAN");
+        v = e ? atoi(e) : 1;
+    }
+    return v;
+}
+static bool x8_plan(int Ho, int Wo, HaloPlan* pl) { return plan_halo(Ho, Wo, 1, pl, X8_MAXPIX, 0, x8_policy()); }
+
 static int x8_blocks_per_unit(long tiles8, int ncb) {
     for (int cpw = ncb; cpw >= 1; --cpw) {
         if (ncb % cpw) continue;
@@ -460,7 +492,7 @@ bool halo8_x3_shape_ok(int kh, int kw, int stride, int pad, const TView& in, con
     if ((in.cs & 7) || (in.coff & 7) || (out.cs & 7) || (out.coff & 7)) return false;
     if ((double)in.c * out.c < 0.5 * (double)x8_cin_pad(in.c) * x8_cout_pad(out.c)) return false;
     HaloPlan pl;
-    return plan_halo(out.h, out.w, 1, &pl) && pl.eff >= 0.6 && pl.maxpix <= X8_MAXPIX;
+    return x8_plan(out.h, out.w, &pl) && pl.eff >= 0.6 && pl.maxpix <= X8_MAXPIX;
 }
 size_t halo8_x3_weight_bytes(int cout, int cin) { return (size_t)(x8_cout_pad(cout) / 32) * (size_t)(2 * (x8_cin_pad(cin) / 32)) * X8_SLAB; }
 
@@ -471,7 +503,7 @@ bool halo8_x3_applicable(int kh, int kw, int stride, int pad, int n, const TView
     if (res_mode != RES_NONE && (double)n * out.h * out.w * res.cs * 4.0 >= (double)X8_OOB) return false;
     if ((double)halo8_x3_weight_bytes(out.c, in.c) >= (double)X8_OOB) return false;
     HaloPlan pl;
-    if (!plan_halo(out.h, out.w, 1, &pl)) return false;
+    if (!x8_plan(out.h, out.w, &pl)) return false;
     const long ntiles = (long)n * pl.NS * pl.TPS, tiles8 = (ntiles + 7) / 8;
     if (ntiles * (x8_cout_pad(out.c) / 64) * pl.NS * pl.TPS >= (1L << 32)) return false;
     return x8_blocks_per_unit(tiles8, x8_cout_pad(out.c) / 64) > 0;
@@ -515,6 +547,32 @@ static bool x8_lhalf() {   // ADAS_H8X_LHALF=0: fetch whole weight tiles for the
     return v != 0;
 }
 
+static bool x8_share() {   // ADAS_H8X_SHARE=0: every half-chunk fetches its own weight tiles (the round-4 / 5 stream)
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("ADAS_H8X_SHARE");
+        v = e ? atoi(e) : 1;
+    }
+    return v != 0;
+}
+
+template <int NWP>
+static hipError_t x8_launch_sh(const H8XDev& d, int act, dim3 grid, hipStream_t st) {
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute((const void*)conv_h8x3_kernel<ACT_NONE, 2, false, true, NWP>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)conv_h8x3_kernel<ACT_SILU, 2, false, true, NWP>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)conv_h8x3_kernel<ACT_RELU, 2, false, true, NWP>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)conv_h8x3_kernel<ACT_LEAKY, 2, false, true, NWP>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_done = true;
+    }
+    if (act == ACT_SILU) hipLaunchKernelGGL((conv_h8x3_kernel<ACT_SILU, 2, false, true, NWP>), grid, dim3(X8_THR), X8_LDS, st, d);
+    else if (act == ACT_RELU) hipLaunchKernelGGL((conv_h8x3_kernel<ACT_RELU, 2, false, true, NWP>), grid, dim3(X8_THR), X8_LDS, st, d);
+    else if (act == ACT_LEAKY) hipLaunchKernelGGL((conv_h8x3_kernel<ACT_LEAKY, 2, false, true, NWP>), grid, dim3(X8_THR), X8_LDS, st, d);
+    else hipLaunchKernelGGL((conv_h8x3_kernel<ACT_NONE, 2, false, true, NWP>), grid, dim3(X8_THR), X8_LDS, st, d);
+    return hipGetLastError();
+}
+
 template <int MODE, bool LH>
 static hipError_t x8_launch(const H8XDev& d, int act, dim3 grid, hipStream_t st) {
     static bool attr_done = false;
@@ -534,7 +592,7 @@ static hipError_t x8_launch(const H8XDev& d, int act, dim3 grid, hipStream_t st)
 
 hipError_t launch_conv_halo8_x3(const ConvArgs& a, hipStream_t st) {
     HaloPlan pl;
-    if (!a.wgt_h8x3 || !halo8_x3_applicable(a.kh, a.kw, a.stride, a.pad, a.n, a.in, a.out, a.res, a.res_mode) || !plan_halo(a.out.h, a.out.w, 1, &pl))
+    if (!a.wgt_h8x3 || !halo8_x3_applicable(a.kh, a.kw, a.stride, a.pad, a.n, a.in, a.out, a.res, a.res_mode) || !x8_plan(a.out.h, a.out.w, &pl))
         return hipErrorNotSupported;
     {   // ADAS_H8X_SW=<strip width>: narrower strips = squarer tiles = smaller windows (less halo re-read) at more padded pixels; the
         // tile grid is then re-checked against the item-count rule below (an experiment knob, like conv_halo8's ADAS_H8_SW)
@@ -572,6 +630,12 @@ hipError_t launch_conv_halo8_x3(const ConvArgs& a, hipStream_t st) {
     dim3 grid(8 * slots);
     const int forced = x8_mode();
     const bool pingpong = forced == 3 || (forced != 2 && d.nck >= 24);
+    if (x8_share() && forced != 3) {   // shared weight tiles (one barrier per tap row), as many window pieces as this plan's windows need
+        const int nwp = (pl.maxpix + 127) / 128;
+        if (nwp <= 3) return x8_launch_sh<3>(d, a.act, grid, st);
+        if (nwp == 4) return x8_launch_sh<4>(d, a.act, grid, st);
+        return x8_launch_sh<5>(d, a.act, grid, st);
+    }
     if (x8_lhalf()) return pingpong ? x8_launch<1, true>(d, a.act, grid, st) : x8_launch<2, true>(d, a.act, grid, st);
     return pingpong ? x8_launch<1, false>(d, a.act, grid, st) : x8_launch<2, false>(d, a.act, grid, st);
 }

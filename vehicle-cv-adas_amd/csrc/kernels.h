@@ -81,8 +81,9 @@ struct HaloPlan {
     uint32_t mg_ww, mg_sw;         // n / WW == (n * mg_ww) >> 20, n / SW == (n * mg_sw) >> 20 for every n the kernels divide
 };
 // maxpix_cap: window pixel budget (0: the kernel's default); bm: output pixels per tile (0: halo_bm(S) = 256 at stride 1, 128 at stride 2)
-bool plan_halo(int Ho, int Wo, int S, HaloPlan* out, int maxpix_cap = 0, int bm = 0);
-bool plan_halo_sw(int Ho, int Wo, int S, int SW, int maxpix_cap, HaloPlan* out);   // one given strip width (experiments)
+// policy: 0 = most efficient strip width, the widest on ties; 1 = the smallest window among the widths within 0.5 % of the best efficiency
+bool plan_halo(int Ho, int Wo, int S, HaloPlan* out, int maxpix_cap = 0, int bm = 0, int policy = 0);
+bool plan_halo_sw(int Ho, int Wo, int S, int SW, int maxpix_cap, HaloPlan* out, int bm = 0);   // one given strip width
 int halo_tile_pixels(const ConvArgs& a);   // conv_halo.hip: the tile size launch_conv_halo picks for this launch (128 on small stride-1 layers)
 // conv_halo8.hip: stride-1 3x3 for Cout % 128 == 0, Cin % 32 == 0: persistent, LDS-DMA fed, counted waits (same weight packing)
 bool halo8_applicable(int kh, int kw, int stride, int pad, int n, const TView& in, const TView& out, const TView& res, int res_mode);
