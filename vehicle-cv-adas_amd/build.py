@@ -84,6 +84,10 @@ def build(force=False, verbose=True):
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)
+        # the link step accepts undefined symbols in a shared object (hipcc once dropped the host stubs of a kernel template without a
+        # diagnostic): loading the library is the check that every symbol resolves
+        import ctypes
+        ctypes.CDLL(OUT)
     return OUT
 
 

@@ -77,7 +77,11 @@ __host__ __device__ constexpr int x8_allow(int mode, int k) {
 }
 // loads queued under the last tap row of an item besides the stream's pieces: the next item's bias (2 float4) and, with a residual,
 // 16 eight-byte loads (4 pixel tiles x 2 channel tiles x {hi, lo})
+#ifdef ADAS_H8X_NARROW_ST
 constexpr int X8_NBIAS = 2, X8_NRES = 16;
+#else
+constexpr int X8_NBIAS = 2, X8_NRES = 8;    // (wide form: one 16-byte load per pixel tile and channel tile)
+#endif
 
 #ifdef ADAS_H8X_PROF   // scratch instrumentation (tools/experiments/h8x_prof.py): shader cycles of waves 0 and 4 per item phase
 __device__ unsigned long long g_h8x_prof[256][32];
@@ -104,7 +108,7 @@ __device__ unsigned long long g_h8x_prof[256][32];
 __host__ __device__ constexpr int x8s_issued(bool lo, int k, int nwp) { return ((lo ? k >= 3 : (k >= 0 && k < 3)) ? 1 : 0) + ((k >= 1 && k <= nwp) ? 1 : 0); }
 __host__ __device__ constexpr int x8s_allow(bool lo, int k, int nwp) { return x8s_issued(lo, k, nwp) + x8s_issued(lo, k - 1, nwp) + x8s_issued(lo, k - 2, nwp); }
 
-template <int ACT, int MODE, bool LH, bool SH = false, int NWP = X8_NWP>
+template <int ACT, int MODE, bool LH, bool SH, int NWP>
 __global__ __launch_bounds__(X8_THR, 1) void conv_h8x3_kernel(H8XDev a) {
     static_assert(!SH || (MODE == 2 && !LH), "shared weight tiles: one barrier per tap row, whole tiles");
     static_assert(NWP >= 1 && NWP <= X8_NWP && (SH || NWP == X8_NWP), "window pieces per wave");
@@ -142,7 +146,14 @@ __global__ __launch_bounds__(X8_THR, 1) void conv_h8x3_kernel(H8XDev a) {
     const uint32_t wdst_h = (uint32_t)(X8_WR + hb * 4096 + 2048 + grp * 512);
     // epilogue: lane owns channels kg*4 .. +3 of 16-channel tile i of the wave group's 32: G8 byte offset of their hi halves within
     // the pixel's 64-channel run (lo halves 16 bytes behind): group (hb*32 + i*16 + kg*4) / 8, element (kg & 1) * 4
+    // Wide form (default): v_permlane16_swap pairs the lanes that own the two 4-channel halves of a group (kg even / odd: 16 lanes
+    // apart), after which the even row holds the group's 16 hi bytes and the odd row its 16 lo bytes: one 16-byte store (and residual
+    // load) per lane and tile instead of two 8-byte ones -- half the vector-memory instructions of the epilogue.
+#ifdef ADAS_H8X_NARROW_ST
     const uint32_t ch_lane = (uint32_t)((hb * 4 + (kg >> 1)) * 32 + (kg & 1) * 8);
+#else
+    const uint32_t ch_lane = (uint32_t)((hb * 4 + (kg >> 1)) * 32 + (kg & 1) * 16);
+#endif
     const bool has_res = a.res_mode != RES_NONE;
 
     struct Tile {
@@ -195,7 +206,7 @@ __global__ __launch_bounds__(X8_THR, 1) void conv_h8x3_kernel(H8XDev a) {
     auto first_cb = [&](int u) { return upt == 1 ? 0 : (u - (int)__umulhi((uint32_t)u, a.mg_upt) * upt) * a.cpw; };
     int ti = slot, cb = first_cb(slot), cbi = 0;
     Tile cur = decode(ti);
-    uint32_t gcur[NWP], gnxt[NWP];
+    uint32_t gcur[X8_NWP], gnxt[X8_NWP];   // (the first NWP entries are used; a template-sized array here makes hipcc drop the host stub)
     uint32_t xoff[4][9];
     uint32_t po[4];
 #pragma unroll
@@ -245,7 +256,8 @@ __global__ __launch_bounds__(X8_THR, 1) void conv_h8x3_kernel(H8XDev a) {
         const uint32_t ch0 = (uint32_t)(cb * 256) + ch_lane;   // 64 channels = 256 bytes of G8 storage
         Tile nxt = cur;
         uint32_t wnxt_item = 0, apn[4] = {0, 0, 0, 0};
-        yu32x2 rraw[4][2][2];   // residual [pixel tile][channel tile][hi | lo], fetched under the last row of taps of the last half-chunk
+        yu32x4 rraw[4][2];      // residual [pixel tile][channel tile], fetched under the last row of taps of the last half-chunk: one 16-byte piece
+                                // of the lane's G8 group per entry (wide form), or its own 8 B hi + 8 B lo (ADAS_H8X_NARROW_ST builds)
 
         auto chunk = [&](auto last_c, auto lo_c, const int c) {
             constexpr bool lastc = decltype(last_c)::value;
@@ -274,9 +286,16 @@ __global__ __launch_bounds__(X8_THR, 1) void conv_h8x3_kernel(H8XDev a) {
                         const uint32_t ro = po[j] == X8_OOB ? X8_OOB : (po[j] * (uint32_t)a.res_cs + (uint32_t)a.res_coff) * 4u + ch0;
 #pragma unroll
                         for (int i = 0; i < 2; ++i) {
+#ifdef ADAS_H8X_NARROW_ST
                             const uint32_t ri = (cb * 64 + hb * 32 + i * 16 + kg * 4 < a.cout) ? ro + i * 64 : X8_OOB;
-                            rraw[j][i][0] = __builtin_bit_cast(yu32x2, __builtin_amdgcn_raw_buffer_load_b64(rres, ri, 0, 0));
-                            rraw[j][i][1] = __builtin_bit_cast(yu32x2, __builtin_amdgcn_raw_buffer_load_b64(rres, ri + 16, 0, 0));
+                            const yu32x2 rh = __builtin_bit_cast(yu32x2, __builtin_amdgcn_raw_buffer_load_b64(rres, ri, 0, 0));
+                            const yu32x2 rl = __builtin_bit_cast(yu32x2, __builtin_amdgcn_raw_buffer_load_b64(rres, ri + 16, 0, 0));
+                            rraw[j][i] = yu32x4{rh.x, rh.y, rl.x, rl.y};
+#else
+                            // one 16-byte piece of the lane's 8-channel group: its hi half on the even 16-lane rows, its lo half on the odd ones
+                            const uint32_t ri = (cb * 64 + hb * 32 + i * 16 + (kg >> 1) * 8 < a.cout) ? ro + i * 64 : X8_OOB;
+                            rraw[j][i] = __builtin_bit_cast(yu32x4, __builtin_amdgcn_raw_buffer_load_b128(rres, ri, 0, 0));
+#endif
                         }
                     }
                 }
@@ -367,13 +386,24 @@ __global__ __launch_bounds__(X8_THR, 1) void conv_h8x3_kernel(H8XDev a) {
 #pragma unroll
                 for (int i = 0; i < 2; ++i) {
                     // channels past cout (the padded tail of the last 64-channel block) are computed on zero weights and not stored
+#ifdef ADAS_H8X_NARROW_ST
                     const uint32_t oi = (cb * 64 + hb * 32 + i * 16 + kg * 4 < a.cout) ? oo + i * 64 : X8_OOB;
+#else
+                    const uint32_t oi = (cb * 64 + hb * 32 + i * 16 + (kg >> 1) * 8 < a.cout) ? oo + i * 64 : X8_OOB;   // (cout is a multiple of 8)
+#endif
                     float v[4];
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] = acc[i][j][e] + acc[i + 2][j][e] * kX3Down;
                     if (RM != RES_NONE) {
                         // (words copied to scalars first: hipcc's __builtin_bit_cast applied directly to a vector ELEMENT reads element 0)
-                        const uint32_t wh0 = rraw[j][i][0].x, wh1 = rraw[j][i][0].y, wl0 = rraw[j][i][1].x, wl1 = rraw[j][i][1].y;
+#ifdef ADAS_H8X_NARROW_ST
+                        const uint32_t wh0 = rraw[j][i].x, wh1 = rraw[j][i].y, wl0 = rraw[j][i].z, wl1 = rraw[j][i].w;
+#else
+                        // the swap that forms the 16-byte pieces is its own inverse: it hands each lane its own hi and lo words back
+                        const auto q0 = __builtin_amdgcn_permlane16_swap(rraw[j][i].x, rraw[j][i].z, false, false);
+                        const auto q1 = __builtin_amdgcn_permlane16_swap(rraw[j][i].y, rraw[j][i].w, false, false);
+                        const uint32_t wh0 = q0[0], wl0 = q0[1], wh1 = q1[0], wl1 = q1[1];
+#endif
                         const e_f16x2 h0 = __builtin_bit_cast(e_f16x2, wh0);
                         const e_f16x2 h1 = __builtin_bit_cast(e_f16x2, wh1);
                         const e_f16x2 l0 = __builtin_bit_cast(e_f16x2, wl0);
@@ -391,8 +421,16 @@ __global__ __launch_bounds__(X8_THR, 1) void conv_h8x3_kernel(H8XDev a) {
                     x3_split(v[1], h, l); h0[1] = h; l0[1] = l;
                     x3_split(v[2], h, l); h1[0] = h; l1[0] = l;
                     x3_split(v[3], h, l); h1[1] = h; l1[1] = l;
+#ifdef ADAS_H8X_NARROW_ST
                     __builtin_amdgcn_raw_buffer_store_b64(yu32x2{__builtin_bit_cast(uint32_t, h0), __builtin_bit_cast(uint32_t, h1)}, rout, oi, 0, 0);
                     __builtin_amdgcn_raw_buffer_store_b64(yu32x2{__builtin_bit_cast(uint32_t, l0), __builtin_bit_cast(uint32_t, l1)}, rout, oi + 16, 0, 0);
+#else
+                    {   // even rows end up with {own hi, partner's hi} = the group's 16 hi bytes, odd rows with {partner's lo, own lo}
+                        const auto s0 = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(uint32_t, h0), __builtin_bit_cast(uint32_t, l0), false, false);
+                        const auto s1 = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(uint32_t, h1), __builtin_bit_cast(uint32_t, l1), false, false);
+                        __builtin_amdgcn_raw_buffer_store_b128(yu32x4{s0[0], s1[0], s0[1], s1[1]}, rout, oi, 0, 0);
+                    }
+#endif
                     acc[i][j] = yf32x4{biasn[i].x, biasn[i].y, biasn[i].z, biasn[i].w};
                     acc[i + 2][j] = yf32x4{0.f, 0.f, 0.f, 0.f};
                 }
@@ -577,16 +615,16 @@ template <int MODE, bool LH>
 static hipError_t x8_launch(const H8XDev& d, int act, dim3 grid, hipStream_t st) {
     static bool attr_done = false;
     if (!attr_done) {
-        (void)hipFuncSetAttribute((const void*)conv_h8x3_kernel<ACT_NONE, MODE, LH>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute((const void*)conv_h8x3_kernel<ACT_SILU, MODE, LH>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute((const void*)conv_h8x3_kernel<ACT_RELU, MODE, LH>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute((const void*)conv_h8x3_kernel<ACT_LEAKY, MODE, LH>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)conv_h8x3_kernel<ACT_NONE, MODE, LH, false, X8_NWP>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)conv_h8x3_kernel<ACT_SILU, MODE, LH, false, X8_NWP>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)conv_h8x3_kernel<ACT_RELU, MODE, LH, false, X8_NWP>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)conv_h8x3_kernel<ACT_LEAKY, MODE, LH, false, X8_NWP>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_done = true;
     }
-    if (act == ACT_SILU) hipLaunchKernelGGL((conv_h8x3_kernel<ACT_SILU, MODE, LH>), grid, dim3(X8_THR), X8_LDS, st, d);
-    else if (act == ACT_RELU) hipLaunchKernelGGL((conv_h8x3_kernel<ACT_RELU, MODE, LH>), grid, dim3(X8_THR), X8_LDS, st, d);
-    else if (act == ACT_LEAKY) hipLaunchKernelGGL((conv_h8x3_kernel<ACT_LEAKY, MODE, LH>), grid, dim3(X8_THR), X8_LDS, st, d);
-    else hipLaunchKernelGGL((conv_h8x3_kernel<ACT_NONE, MODE, LH>), grid, dim3(X8_THR), X8_LDS, st, d);
+    if (act == ACT_SILU) hipLaunchKernelGGL((conv_h8x3_kernel<ACT_SILU, MODE, LH, false, X8_NWP>), grid, dim3(X8_THR), X8_LDS, st, d);
+    else if (act == ACT_RELU) hipLaunchKernelGGL((conv_h8x3_kernel<ACT_RELU, MODE, LH, false, X8_NWP>), grid, dim3(X8_THR), X8_LDS, st, d);
+    else if (act == ACT_LEAKY) hipLaunchKernelGGL((conv_h8x3_kernel<ACT_LEAKY, MODE, LH, false, X8_NWP>), grid, dim3(X8_THR), X8_LDS, st, d);
+    else hipLaunchKernelGGL((conv_h8x3_kernel<ACT_NONE, MODE, LH, false, X8_NWP>), grid, dim3(X8_THR), X8_LDS, st, d);
     return hipGetLastError();
 }
 
