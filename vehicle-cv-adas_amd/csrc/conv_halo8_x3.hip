@@ -77,6 +77,14 @@ __host__ __device__ constexpr int x8_allow(int mode, int k) {
 }
 // loads queued under the last tap row of an item besides the stream's pieces: the next item's bias (2 float4) and, with a residual,
 // 16 eight-byte loads (4 pixel tiles x 2 channel tiles x {hi, lo})
+// X8_RES_TAP: the tap of an item's LAST half-chunk under which the residual tile and the next item's bias are requested.  Round 4 asked
+// at tap 6 (the last tap row), which leaves an HBM read ~1.5 k cycles before the epilogue needs it -- the phase counters showed the last
+// half-chunk of a residual layer at 11.9 k cycles against 6.5 k without (profiles/r06/h8x_phases.txt); at tap 0 the loads have the whole
+// half-chunk (the in-order return then asks them to be back by the wait of tap 5, ~3 k cycles on).  Same registers either way.
+#ifndef ADAS_H8X_RES_TAP
+#define ADAS_H8X_RES_TAP 0
+#endif
+constexpr int X8_RES_TAP = ADAS_H8X_RES_TAP;
 #ifdef ADAS_H8X_NARROW_ST
 constexpr int X8_NBIAS = 2, X8_NRES = 16;
 #else
@@ -279,8 +287,8 @@ __global__ __launch_bounds__(X8_THR, 1) void conv_h8x3_kernel(H8XDev a) {
             const uint32_t winr = (uint32_t)(((par + c) & 1) * X8_WIN), winw = X8_WIN - winr;
             auto tap = [&](auto kk_c) {
                 constexpr int kk = decltype(kk_c)::value;
-                if (lastc && kk == 6) load_bias(cbn, biasn);
-                if (lastc && kk == 6 && has_res) {
+                if (lastc && kk == X8_RES_TAP) load_bias(cbn, biasn);
+                if (lastc && kk == X8_RES_TAP && has_res) {
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         const uint32_t ro = po[j] == X8_OOB ? X8_OOB : (po[j] * (uint32_t)a.res_cs + (uint32_t)a.res_coff) * 4u + ch0;
@@ -328,11 +336,23 @@ __global__ __launch_bounds__(X8_THR, 1) void conv_h8x3_kernel(H8XDev a) {
                 constexpr bool sync_here = MODE != 2 || kk % 3 == 2;
                 // what may stay in flight past this point: the pieces issued in this tap row (MODE 2) / the last three taps
                 constexpr int allow = SH ? x8s_allow(islo, kk, NWP) : x8_allow(MODE, kk);
-                if (sync_here && (c > 0 || kk >= 3)) {
-                    if (lastc && kk >= 6 && has_res) x8_wait_vm<allow + X8_NBIAS + X8_NRES>();
-                    else if (lastc && kk >= 6) x8_wait_vm<allow + X8_NBIAS>();
-                    else x8_wait_vm<allow>();
-                }
+                // (the residual / bias loads of the last half-chunk count among the pieces of the tap row they are issued in -- MODE 2 -- or of the
+                // following taps -- MODE 1, one wait per tap: X8_RES_TAP = 6 there)
+                constexpr bool with_res = kk >= X8_RES_TAP && (MODE == 2 ? kk / 3 == X8_RES_TAP / 3 : kk < X8_RES_TAP + 3);
+                auto counted_wait = [&]() {
+                    if (sync_here && (c > 0 || kk >= 3)) {
+                        if (lastc && with_res && has_res) x8_wait_vm<allow + X8_NBIAS + X8_NRES>();
+                        else if (lastc && with_res) x8_wait_vm<allow + X8_NBIAS>();
+                        else x8_wait_vm<allow>();
+                    }
+                };
+                // MODE 2: the wait only has to precede the row's barrier, not this tap's MFMAs (they read what earlier barriers published):
+                // behind the MFMAs it gives the pieces another 16 MFMA issue slots to land (ADAS_H8X_WAIT_FIRST builds keep the round-4 order)
+#ifdef ADAS_H8X_WAIT_FIRST
+                counted_wait();
+#else
+                if (MODE == 1) counted_wait();
+#endif
                 if (MODE == 1) {
                     __builtin_amdgcn_sched_barrier(0);
                     __builtin_amdgcn_s_barrier();
@@ -358,6 +378,9 @@ __global__ __launch_bounds__(X8_THR, 1) void conv_h8x3_kernel(H8XDev a) {
                 __builtin_amdgcn_s_setprio(0);
                 if (sync_here) {
                     __builtin_amdgcn_sched_barrier(0);
+#ifndef ADAS_H8X_WAIT_FIRST
+                    if (MODE != 1) counted_wait();
+#endif
                     __builtin_amdgcn_s_barrier();
                     __builtin_amdgcn_sched_barrier(0);
                 }
@@ -667,7 +690,9 @@ hipError_t launch_conv_halo8_x3(const ConvArgs& a, hipStream_t st) {
     const int slots = units8 < X8_SLOTS ? units8 : X8_SLOTS;
     dim3 grid(8 * slots);
     const int forced = x8_mode();
-    const bool pingpong = forced == 3 || (forced != 2 && d.nck >= 24);
+    // (the wave-groups-a-barrier-apart variant, MODE 1, lost to MODE 2 on every layer once both were measured at one commit --
+    // profiles/r06/ab_h8x3.txt: -4.3 % end to end when forced everywhere, +-0.3 % on the nck >= 24 layers it used to take; ADAS_HALO8_X3=3 keeps it reachable)
+    const bool pingpong = forced == 3;
     if (x8_share() && forced != 3) {   // shared weight tiles (one barrier per tap row), as many window pieces as this plan's windows need
         const int nwp = (pl.maxpix + 127) / 128;
         if (nwp <= 3) return x8_launch_sh<3>(d, a.act, grid, st);
