@@ -28,26 +28,31 @@ if has stats; then
   f=$(find $out/prof -name '*kernel_stats.csv' | head -1); [ -n "$f" ] && cp $f $out/kernel_stats.csv && head -8 $f | cut -c1-160
   ( timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof_noov -o bench -- python bench.py --no-cpu-baseline --no-extras --no-overlap > $out/bench_noov.json 2> $out/bench_noov.err )
   f=$(find $out/prof_noov -name '*kernel_stats.csv' | head -1); [ -n "$f" ] && cp $f $out/kernel_stats_no_overlap.csv
-  ( timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof_x3 -o bench -- python bench.py --precision fp16x3 --no-cpu-baseline --no-extras --no-overlap > $out/bench_x3_noov.json 2> $out/bench_x3.err )
-  f=$(find $out/prof_x3 -name '*kernel_stats.csv' | head -1); [ -n "$f" ] && cp $f $out/kernel_stats_fp16x3_no_overlap.csv
-  rm -rf $out/prof $out/prof_noov $out/prof_x3
+  # (the default precision is the exact mode, fp16x3, since round 6: the two runs above are its summaries; this one is the throughput mode's)
+  ( timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof_f16 -o bench -- python bench.py --precision fp16 --no-cpu-baseline --no-extras --no-overlap > $out/bench_fp16_noov.json 2> $out/bench_fp16.err )
+  f=$(find $out/prof_f16 -name '*kernel_stats.csv' | head -1); [ -n "$f" ] && cp $f $out/kernel_stats_fp16_no_overlap.csv
+  rm -rf $out/prof $out/prof_noov $out/prof_f16
 fi
 if has presets; then
   for p in c4 c5; do ( ADAS_BENCH_NO_PMC=1 timeout 500 python bench.py --preset $p --no-cpu-baseline --steps 20 --repeats 2 > $out/bench_$p.json 2> /dev/null ); show $out/bench_$p.json; done
+  ( timeout 500 python bench.py --precision fp16 --no-cpu-baseline --steps 40 --repeats 2 > $out/bench_fp16.json 2> /dev/null ); show $out/bench_fp16.json
   ( ADAS_BENCH_NO_PMC=1 timeout 300 python bench.py --preset c5 --micro-batch 1 --no-cpu-baseline --no-extras --steps 200 --repeats 2 > $out/bench_c5_frame_at_a_time.json 2>/dev/null ); show $out/bench_c5_frame_at_a_time.json
   for p in v10 v9 v7 v6; do ( ADAS_BENCH_NO_PMC=1 timeout 300 python bench.py --preset $p --no-cpu-baseline --no-extras --steps 20 --repeats 2 > $out/bench_$p.json 2> /dev/null ); show $out/bench_$p.json; done
 fi
 if has layers; then
-  python tools/profile_layers.py yolov8n --batch 64 --precision fp16 --top 100 > $out/layers_yolov8n_b64_fp16.txt 2>&1
-  ADAS_NO_GROUP=1 python tools/profile_layers.py yolov8n --batch 64 --precision fp16 --top 100 > $out/layers_yolov8n_b64_fp16_no_group.txt 2>&1
-  python tools/profile_layers.py ufldv2_res18 --batch 64 --precision fp16 --top 100 > $out/layers_ufldv2_res18_b64_fp16.txt 2>&1
-  head -4 $out/layers_yolov8n_b64_fp16.txt | cut -c1-150
+  for prec in fp16x3 fp16; do
+    python tools/profile_layers.py yolov8n --batch 64 --precision $prec --top 100 > $out/layers_yolov8n_b64_$prec.txt 2>&1
+    python tools/profile_layers.py ufldv2_res18 --batch 64 --precision $prec --top 100 > $out/layers_ufldv2_res18_b64_$prec.txt 2>&1
+  done
+  head -4 $out/layers_yolov8n_b64_fp16x3.txt | cut -c1-150
 fi
 if has pmc; then
   P="SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_INSTS_MFMA SQ_INSTS_VALU"
   cd /tmp
-  ADAS_BENCH_NO_PMC=1 timeout 400 rocprofv3 --pmc $P --kernel-trace --output-format csv -d $out/pmc_fp16 -o p -- python $GRAFT_REPO_ROOT/bench.py --precision fp16 --no-cpu-baseline --no-extras --no-overlap --steps 3 --warmup 1 --repeats 0 --latency-steps 8 > $out/pmc_fp16.json 2> $out/pmc_fp16.err
-  python $GRAFT_REPO_ROOT/tools/pmc_top.py $out/pmc_fp16 24 > $out/pmc_top_kernels_fp16.txt 2>&1
-  rm -rf $out/pmc_fp16
-  head -12 $out/pmc_top_kernels_fp16.txt | cut -c1-200
+  for prec in fp16x3 fp16; do
+    ADAS_BENCH_NO_PMC=1 timeout 400 rocprofv3 --pmc $P --kernel-trace --output-format csv -d $out/pmc_$prec -o p -- python $GRAFT_REPO_ROOT/bench.py --precision $prec --no-cpu-baseline --no-extras --no-overlap --steps 3 --warmup 1 --repeats 0 --latency-steps 8 > $out/pmc_$prec.json 2> $out/pmc_$prec.err
+    python $GRAFT_REPO_ROOT/tools/pmc_top.py $out/pmc_$prec 24 > $out/pmc_top_kernels_$prec.txt 2>&1
+    rm -rf $out/pmc_$prec
+  done
+  head -12 $out/pmc_top_kernels_fp16x3.txt | cut -c1-200
 fi

@@ -80,7 +80,8 @@ __host__ __device__ constexpr int x8_allow(int mode, int k) {
 // X8_RES_TAP: the tap of an item's LAST half-chunk under which the residual tile and the next item's bias are requested.  Round 4 asked
 // at tap 6 (the last tap row), which leaves an HBM read ~1.5 k cycles before the epilogue needs it -- the phase counters showed the last
 // half-chunk of a residual layer at 11.9 k cycles against 6.5 k without (profiles/r06/h8x_phases.txt); at tap 0 the loads have the whole
-// half-chunk (the in-order return then asks them to be back by the wait of tap 5, ~3 k cycles on).  Same registers either way.
+// half-chunk (the in-order return then asks them to be back by the wait of tap 5, ~3 k cycles on).  Same registers either way; measured
+// +0.2 % end to end (inside the noise: the item's other fixed costs hide most of it), kept.
 #ifndef ADAS_H8X_RES_TAP
 #define ADAS_H8X_RES_TAP 0
 #endif
@@ -346,9 +347,9 @@ __global__ __launch_bounds__(X8_THR, 1) void conv_h8x3_kernel(H8XDev a) {
                         else x8_wait_vm<allow>();
                     }
                 };
-                // MODE 2: the wait only has to precede the row's barrier, not this tap's MFMAs (they read what earlier barriers published):
-                // behind the MFMAs it gives the pieces another 16 MFMA issue slots to land (ADAS_H8X_WAIT_FIRST builds keep the round-4 order)
-#ifdef ADAS_H8X_WAIT_FIRST
+                // (MODE 2: the wait only has to precede the row's barrier, not this tap's MFMAs; placed behind them -- ADAS_H8X_WAIT_LAST builds --
+                // it measured 0.5 % slower end to end, profiles/r06/ab_h8x3_variants.txt: the round-4 order stays)
+#ifndef ADAS_H8X_WAIT_LAST
                 counted_wait();
 #else
                 if (MODE == 1) counted_wait();
@@ -378,7 +379,7 @@ __global__ __launch_bounds__(X8_THR, 1) void conv_h8x3_kernel(H8XDev a) {
                 __builtin_amdgcn_s_setprio(0);
                 if (sync_here) {
                     __builtin_amdgcn_sched_barrier(0);
-#ifndef ADAS_H8X_WAIT_FIRST
+#ifdef ADAS_H8X_WAIT_LAST
                     if (MODE != 1) counted_wait();
 #endif
                     __builtin_amdgcn_s_barrier();
@@ -536,6 +537,9 @@ static int x8_blocks_per_unit(long tiles8, int ncb) {
         const long units8 = tiles8 * (ncb / cpw), rounds = (units8 + X8_SLOTS - 1) / X8_SLOTS;
         if (units8 >= X8_SLOTS && (double)units8 / (double)(rounds * X8_SLOTS) >= 0.8) return cpw;
     }
+    // a layer that gives every XCD 12-31 items (96-248 of the 256 CUs busy for one round: the 20x20 Detect convs at 64 frames) still
+    // finishes sooner here than on the generic kernel (conv_x3_igemm: ~90 TFLOP/s on those shapes)
+    if (tiles8 * ncb >= 12 && tiles8 * ncb < X8_SLOTS) return 1;
     return 0;
 }
 
