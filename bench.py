@@ -799,7 +799,7 @@ def main():
                     stem_label = label
                 elif label.startswith("conv_pair_kernel"):
                     pair_label = label
-                elif label.startswith("conv_c2f16_kernel"):
+                elif label.startswith("conv_c2f16"):
                     c2f_label = label
                 elif label.startswith(("conv_ml_kernel", "conv_halo_group_kernel")):
                     ml_label = label

@@ -234,3 +234,19 @@ def test_ufldv2_culane_at_the_bench_batch_vs_oracle():
         for k in range(3, 64):
             assert np.array_equal(o[k], o[k % 3]), (k, float(np.abs(o[k] - o[k % 3]).max()))
     e.close()
+
+
+@pytest.mark.parametrize("case", [(160, 160, 32, 1, True, 4), (23, 37, 32, 1, True, 3), (48, 50, 32, 1, True, 70), (80, 80, 64, 2, True, 2)], ids=str)
+def test_c2f_block_in_one_launch_f32_class(case):
+    """conv_c2f_x3.hip: a C2f(32, 32, n = 1, shortcut) block (YOLOv8n / YOLOv10n model.2) runs as ONE launch in the split precision -- hi / lo
+    planes in LDS between the stages, three MFMAs per product, exact SiLU -- and comes out f32-class against torch; ragged extents (tiles
+    cut by the image edge), more tiles than the persistent launch has workgroups (48 x 50 at batch 70: 1,120 tiles on 256 workgroups) and
+    a block the fusion does NOT cover (64 channels, two Bottlenecks: its pairs are released back to the per-layer kernels)."""
+    H, W, c2, n, shortcut, batch = case
+    rel, names = TC._c2f_case(CE, H, W, c2, n, shortcut, "fp16x3", batch=batch)
+    print("x3 C2f %s: rel %.2e  %s" % (case, rel, names))
+    if (c2, n) == (32, 1):
+        assert all("fused into the C2f launch" in k for k in names), names
+    else:
+        assert all("fused" not in k and "x3" in k for k in names), names
+    assert rel < 3 * X3_REL, (case, rel)

@@ -32,6 +32,7 @@ UNITS = [
     ("conv_pw_x3.hip", []),
     ("conv_pair.hip", []),
     ("conv_c2f.hip", []),
+    ("conv_c2f_x3.hip", []),
     ("conv_fc.hip", []),
     ("conv_pw.hip", []),
     ("conv_pwg.hip", []),

@@ -1,0 +1,394 @@
+// conv_c2f_x3.hip -- conv_c2f.hip's whole-C2f launch in the split precision (ADAS_PREC_FP16X3): ultralytics C2f(32, 32, n = 1, shortcut)
+// = YOLOv8n / YOLOv10n `model.2` on the networks' largest map (160 x 160), one launch:
+//     (y0, y1) = split(SiLU(cv1 x));  y2 = y1 + SiLU(B(SiLU(A y1)));  out = SiLU(cv2 cat(y0, y1, y2))
+// In the exact mode the block ran as four launches (cv1 on conv_pwx3, the Bottleneck's two 16-channel 3x3 convs on the GENERIC split
+// kernel -- too narrow for conv_h8x3's 32 x 64 blocks --, cv2 on conv_pwx3): 0.58 ms per 64 frames for 24 GFLOP, moving the 4-byte-per-
+// channel tensors through HBM six times (1.5 GB).  Fused, x (with its 2-pixel halo) is read once and `out` written once (~450 MB).
+//
+// Same stages and MFMA mapping as conv_c2f.hip (weights = A operand, 16 pixels = B operand, a lane ends up with 4 consecutive output
+// channels of one pixel; the 16-channel 3x3 convs take two taps per 32-deep K step), with both halves of every operand:
+//   * every tensor between the stages lives in LDS as a hi plane and a lo plane (elem16.h x3_split: hi = half(v), lo = half((v - hi) 2^11)),
+//   * every product is three MFMAs into two accumulators (main += w_hi a_hi; cross += w_lo a_hi + w_hi a_lo; value = main + 2^-11 cross),
+//   * SiLU in its exact form (expf, IEEE division: the parity modes' rule, conv_x3.hip x3_act).
+// One persistent 8-wave workgroup per CU (126 KB of LDS: the planes + all four weight sets as hi / lo fragment arrays); the next tile's
+// window is fetched into registers under the current tile's stages.
+#include "kernels.h"
+#include "elem16.h"
+#include <stdlib.h>
+
+namespace adas {
+
+typedef __attribute__((ext_vector_type(4))) float xf32x4;
+typedef __attribute__((ext_vector_type(4))) uint32_t xu32x4;
+
+struct C2fX3Dev {
+    const unsigned char* in;   // G8: 4 bytes per channel slot
+    x3s* out;
+    const uint16_t* w[4];      // cv1, A, B, cv2: [hi fragments | lo fragments], fragment order (pack kernels below)
+    const float* b[4];
+    uint32_t in_bytes;
+    int in_cs, in_coff, out_cs, out_coff;
+    int H, W;
+    int tiles_x, tiles_per_img, ntiles;
+};
+
+constexpr int CX_T = 16, CX_IW = CX_T + 2, CX_WW = CX_T + 4;
+constexpr int CX_NI = CX_IW * CX_IW, CX_G1 = (CX_NI + 15) / 16;      // 324 intermediate pixels, 21 groups
+constexpr int CX_NW = CX_WW * CX_WW, CX_GW = CX_NW / 16;             // 400 window pixels, 25 groups
+constexpr uint32_t CX_OOB = 0x80000000u;
+constexpr int CX_THR = 512;
+// fragment counts (1 KB each) per array: cv1 2 (two 16-channel tiles, K = 32), A / B 5 (K steps of two taps), cv2 4 (two K steps x two tiles)
+constexpr int CX_NF[4] = {2, 5, 5, 4};
+constexpr int CX_WOFF[4] = {0, 2 * 2048, 2 * 2048 + 2 * 5120, 2 * 2048 + 4 * 5120};   // byte offset of each conv's [hi | lo] pair in LDS
+constexpr int CX_WBYTES = 2 * (2 + 5 + 5 + 4) * 1024;                                     // 32 KB
+// LDS map (bytes): region A = x window hi | lo (2 x 25,600), later conv A's output hi | lo and y2 hi | lo; y1 window hi | lo; y0 tile hi | lo; weights
+constexpr int CX_XW = CX_NW * 64, CX_Y1 = CX_NW * 32, CX_Y0 = 256 * 32, CX_IN = CX_G1 * 16 * 32;
+constexpr int CX_OFF_Y1 = 2 * CX_XW, CX_OFF_Y0 = CX_OFF_Y1 + 2 * CX_Y1, CX_OFF_W = CX_OFF_Y0 + 2 * CX_Y0;
+constexpr int CX_LDS = CX_OFF_W + CX_WBYTES;   // 125,952
+static_assert(2 * CX_IN + 2 * CX_Y0 <= 2 * CX_XW, "conv A's output and y2 fit in the x window's region");
+
+__device__ __forceinline__ float cx_silu(float v) { return v / (1.0f + expf(-v)); }   // the parity modes' exact form
+__device__ __forceinline__ int cx_pos32(int p, int c) { return c ^ (((p >> 2) & 1) << 1); }
+// four values -> their hi words and lo words (two packed halves each)
+__device__ __forceinline__ void cx_split4(const float v[4], uint2& h, uint2& l) {
+    e_f16x2 h0, h1, l0, l1;
+    _Float16 a, b;
+    x3_split(v[0], a, b); h0[0] = a; l0[0] = b;
+    x3_split(v[1], a, b); h0[1] = a; l0[1] = b;
+    x3_split(v[2], a, b); h1[0] = a; l1[0] = b;
+    x3_split(v[3], a, b); h1[1] = a; l1[1] = b;
+    h = make_uint2(__builtin_bit_cast(uint32_t, h0), __builtin_bit_cast(uint32_t, h1));
+    l = make_uint2(__builtin_bit_cast(uint32_t, l0), __builtin_bit_cast(uint32_t, l1));
+}
+__device__ __forceinline__ void cx_join4(const uint2 h, const uint2 l, float v[4]) {
+    const uint32_t hx = h.x, hy = h.y, lx = l.x, ly = l.y;
+    const e_f16x2 h0 = __builtin_bit_cast(e_f16x2, hx), h1 = __builtin_bit_cast(e_f16x2, hy);
+    const e_f16x2 l0 = __builtin_bit_cast(e_f16x2, lx), l1 = __builtin_bit_cast(e_f16x2, ly);
+    v[0] = x3_join(h0[0], l0[0]); v[1] = x3_join(h0[1], l0[1]); v[2] = x3_join(h1[0], l1[0]); v[3] = x3_join(h1[1], l1[1]);
+}
+
+__global__ __launch_bounds__(CX_THR, 1) void conv_c2f16_x3_kernel(C2fX3Dev a) {
+    Fp16::enter();
+    typedef Fp16::vec8 vec8;
+    extern __shared__ __attribute__((aligned(16))) uint8_t cx_lds[];
+    uint8_t* const xwh = cx_lds;                 // x window, hi plane (64-byte pixels, chunk-swizzled) ...
+    uint8_t* const xwl = cx_lds + CX_XW;         // ... and lo plane
+    uint8_t* const inh = cx_lds;                 // conv A's output (aliases the x window once cv1 has read it)
+    uint8_t* const inl = cx_lds + CX_IN;
+    uint8_t* const y2h = cx_lds + 2 * CX_IN;     // y2 on the tile
+    uint8_t* const y2l = y2h + CX_Y0;
+    uint8_t* const y1h = cx_lds + CX_OFF_Y1;     // y1 on the window, 16 channels (32-byte pixels)
+    uint8_t* const y1l = y1h + CX_Y1;
+    uint8_t* const y0h = cx_lds + CX_OFF_Y0;     // y0 on the tile
+    uint8_t* const y0l = y0h + CX_Y0;
+    uint8_t* const wl = cx_lds + CX_OFF_W;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lrow = lane & 15, kg = lane >> 4;
+
+    // ---- weights: [hi | lo] fragment arrays of the four convs -> LDS, once per (persistent) workgroup
+#pragma unroll
+    for (int c = 0; c < 4; ++c) stage_lds16<CX_THR, 2>(wl + CX_WOFF[c], a.w[c], 2 * CX_NF[c] * 64, tid);
+    auto wfrag = [&](int c, int lo, int f) {   // fragment f of conv c's hi (0) / lo (1) array
+        return *reinterpret_cast<const vec8*>(wl + CX_WOFF[c] + (lo * CX_NF[c] + f) * 1024 + lane * 16);
+    };
+    float4 bias[6];   // cv1 [0..15], cv1 [16..31], A, B, cv2 [0..15], cv2 [16..31]
+    bias[0] = *reinterpret_cast<const float4*>(a.b[0] + kg * 4);
+    bias[1] = *reinterpret_cast<const float4*>(a.b[0] + 16 + kg * 4);
+    bias[2] = *reinterpret_cast<const float4*>(a.b[1] + kg * 4);
+    bias[3] = *reinterpret_cast<const float4*>(a.b[2] + kg * 4);
+    bias[4] = *reinterpret_cast<const float4*>(a.b[3] + kg * 4);
+    bias[5] = *reinterpret_cast<const float4*>(a.b[3] + 16 + kg * 4);
+
+    // ---- x window: 400 pixels x 8 pieces of 16 bytes (four 8-channel groups x {hi, lo}), zero outside the image
+    __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc((void*)a.in, 0, a.in_bytes, 0x00020000);
+    constexpr int NLD = (CX_NW * 8 + CX_THR - 1) / CX_THR;   // 7
+    xu32x4 ra[NLD];
+    auto fetch = [&](int tile) {
+        const bool live = tile < a.ntiles;
+        const int tq = live ? tile : 0;
+        const int img = tq / a.tiles_per_img;
+        const int tl = tq - img * a.tiles_per_img;
+        const int ty0 = (tl / a.tiles_x) * CX_T, tx0 = (tl % a.tiles_x) * CX_T;
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) {
+            const int e = tid + CX_THR * i;
+            const int pix = e >> 3, c = e & 7;       // piece c: group c >> 1, hi (0) / lo (1) half c & 1 -- 16-byte pieces in memory order
+            const int wy = pix / CX_WW, wx = pix - wy * CX_WW;
+            const int iy = ty0 - 2 + wy, ix = tx0 - 2 + wx;
+            const bool ok = live && e < CX_NW * 8 && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+            const uint32_t off = ok ? ((uint32_t)((img * a.H + iy) * a.W + ix) * (uint32_t)a.in_cs + (uint32_t)a.in_coff) * 4u + (uint32_t)c * 16u : CX_OOB;
+            ra[i] = __builtin_bit_cast(xu32x4, __builtin_amdgcn_raw_buffer_load_b128(rin, off, 0, 0));
+        }
+    };
+
+    // 16-channel 3x3 convs: one K step per PAIR of taps (lanes kg 0-1 take tap 2 ks, kg 2-3 tap 2 ks + 1; the tenth half-step multiplies zero weights)
+    auto tap_of = [&](int ks) { return 2 * ks + (kg >> 1) > 8 ? 8 : 2 * ks + (kg >> 1); };
+    // one product: main += w_hi x_hi; cross += w_lo x_hi + w_hi x_lo
+    auto mac3 = [&](const vec8 wh, const vec8 wlo, const vec8 xh, const vec8 xl, xf32x4& m, xf32x4& x) {
+        m = Fp16::mfma(wh, xh, m);
+        x = Fp16::mfma(wlo, xh, x);
+        x = Fp16::mfma(wh, xl, x);
+    };
+
+    int tile = blockIdx.x;
+    if (tile >= a.ntiles) return;
+    fetch(tile);
+    for (; tile < a.ntiles; tile += gridDim.x) {
+        const int img = tile / a.tiles_per_img;
+        const int tl = tile - img * a.tiles_per_img;
+        const int ty0 = (tl / a.tiles_x) * CX_T, tx0 = (tl % a.tiles_x) * CX_T;
+
+        __syncthreads();   // the previous tile's readers of every region are done (first trip: the weights are in LDS)
+        // ---- 1. window registers -> the two planes
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) {
+            const int e = tid + CX_THR * i;
+            const int pix = e >> 3, c = e & 7;
+            if (e < CX_NW * 8) *reinterpret_cast<xu32x4*>(((c & 1) ? xwl : xwh) + pix * 64 + cx_pos32(pix, c >> 1) * 16) = ra[i];
+        }
+        __syncthreads();
+        fetch(tile + gridDim.x);   // in flight under this tile's stages
+
+        // ---- 2. cv1 (1x1, 32 -> 32, SiLU) on the 25 window pixel groups: wave w takes groups w, w + 8, ...
+        //         channels 0..15 = y0 (kept for tile pixels), 16..31 = y1 (kept for the whole window, ZERO outside the image: conv A's padding
+        //         applies to cv1's OUTPUT domain)
+        {
+            const vec8 w1h0 = wfrag(0, 0, 0), w1h1 = wfrag(0, 0, 1), w1l0 = wfrag(0, 1, 0), w1l1 = wfrag(0, 1, 1);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                if (wave + 8 * g < CX_GW) {   // wave-uniform
+                    const int p = (wave + 8 * g) * 16 + lrow;
+                    const vec8 xh = *reinterpret_cast<const vec8*>(xwh + p * 64 + cx_pos32(p, kg) * 16);
+                    const vec8 xl = *reinterpret_cast<const vec8*>(xwl + p * 64 + cx_pos32(p, kg) * 16);
+                    xf32x4 m0{bias[0].x, bias[0].y, bias[0].z, bias[0].w}, m1{bias[1].x, bias[1].y, bias[1].z, bias[1].w};
+                    xf32x4 c0{0.f, 0.f, 0.f, 0.f}, c1{0.f, 0.f, 0.f, 0.f};
+                    mac3(w1h0, w1l0, xh, xl, m0, c0);
+                    mac3(w1h1, w1l1, xh, xl, m1, c1);
+                    const int wy = p / CX_WW, wx = p - wy * CX_WW;
+                    const int iy = ty0 - 2 + wy, ix = tx0 - 2 + wx;
+                    const bool inside = (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+                    float v[4];
+                    uint2 h, l;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = inside ? cx_silu(m1[e] + c1[e] * kX3Down) : 0.0f;
+                    cx_split4(v, h, l);
+                    *reinterpret_cast<uint2*>(y1h + p * 32 + kg * 8) = h;       // channels 4 kg .. 4 kg + 3 of y1
+                    *reinterpret_cast<uint2*>(y1l + p * 32 + kg * 8) = l;
+                    const int oy = wy - 2, ox = wx - 2;
+                    if ((unsigned)oy < (unsigned)CX_T && (unsigned)ox < (unsigned)CX_T) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = cx_silu(m0[e] + c0[e] * kX3Down);
+                        cx_split4(v, h, l);
+                        *reinterpret_cast<uint2*>(y0h + (oy * CX_T + ox) * 32 + kg * 8) = h;
+                        *reinterpret_cast<uint2*>(y0l + (oy * CX_T + ox) * 32 + kg * 8) = l;
+                    }
+                }
+            }
+        }
+        __syncthreads();   // y1 / y0 complete; every wave is done with the x window (region A is free)
+
+        // ---- 3. conv A on the 18 x 18 region conv B needs (21 groups): wave w takes groups w, w + 8, w + 16; SiLU; zero outside the image
+        {
+            xf32x4 am[3], ac[3];
+            int wp[3];
+#pragma unroll
+            for (int g = 0; g < 3; ++g) {
+                int q = (wave + 8 * g) * 16 + lrow;
+                q = q < CX_NI ? q : CX_NI - 1;
+                const int qy = q / CX_IW, qx = q - qy * CX_IW;
+                wp[g] = qy * CX_WW + qx;
+                am[g] = xf32x4{bias[2].x, bias[2].y, bias[2].z, bias[2].w};
+                ac[g] = xf32x4{0.f, 0.f, 0.f, 0.f};
+            }
+#pragma unroll
+            for (int ks = 0; ks < 5; ++ks) {
+                const int t = tap_of(ks);
+                const int sh = (t / 3) * CX_WW + (t % 3);
+                const vec8 wh = wfrag(1, 0, ks), wlo = wfrag(1, 1, ks);
+#pragma unroll
+                for (int g = 0; g < 3; ++g)
+                    if (wave + 8 * g < CX_G1) {
+                        const int o = (wp[g] + sh) * 32 + (kg & 1) * 16;
+                        mac3(wh, wlo, *reinterpret_cast<const vec8*>(y1h + o), *reinterpret_cast<const vec8*>(y1l + o), am[g], ac[g]);
+                    }
+            }
+#pragma unroll
+            for (int g = 0; g < 3; ++g) {
+                const int q = (wave + 8 * g) * 16 + lrow;
+                if (wave + 8 * g < CX_G1) {
+                    const int qy = q / CX_IW, qx = q - qy * CX_IW;
+                    const int iy = ty0 - 1 + qy, ix = tx0 - 1 + qx;
+                    const bool inside = q < CX_NI && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+                    float v[4];
+                    uint2 h, l;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = inside ? cx_silu(am[g][e] + ac[g][e] * kX3Down) : 0.0f;
+                    cx_split4(v, h, l);
+                    *reinterpret_cast<uint2*>(inh + q * 32 + kg * 8) = h;
+                    *reinterpret_cast<uint2*>(inl + q * 32 + kg * 8) = l;
+                }
+            }
+        }
+        __syncthreads();
+
+        // ---- 4. conv B on the 16 x 16 tile: wave w takes rows 2 w, 2 w + 1; SiLU; + y1 (shortcut)  -> y2
+        {
+            xf32x4 bm[2], bc[2];
+#pragma unroll
+            for (int g = 0; g < 2; ++g) {
+                bm[g] = xf32x4{bias[3].x, bias[3].y, bias[3].z, bias[3].w};
+                bc[g] = xf32x4{0.f, 0.f, 0.f, 0.f};
+            }
+#pragma unroll
+            for (int ks = 0; ks < 5; ++ks) {
+                const int t = tap_of(ks);
+                const int sh = (t / 3) * CX_IW + (t % 3);
+                const vec8 wh = wfrag(2, 0, ks), wlo = wfrag(2, 1, ks);
+#pragma unroll
+                for (int g = 0; g < 2; ++g) {
+                    const int o = ((wave * 2 + g) * CX_IW + lrow + sh) * 32 + (kg & 1) * 16;
+                    mac3(wh, wlo, *reinterpret_cast<const vec8*>(inh + o), *reinterpret_cast<const vec8*>(inl + o), bm[g], bc[g]);
+                }
+            }
+#pragma unroll
+            for (int g = 0; g < 2; ++g) {
+                const int oy = wave * 2 + g;
+                const int wpix = (oy + 2) * CX_WW + lrow + 2;
+                float r[4], v[4];
+                cx_join4(*reinterpret_cast<const uint2*>(y1h + wpix * 32 + kg * 8), *reinterpret_cast<const uint2*>(y1l + wpix * 32 + kg * 8), r);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = cx_silu(bm[g][e] + bc[g][e] * kX3Down) + r[e];
+                uint2 h, l;
+                cx_split4(v, h, l);
+                *reinterpret_cast<uint2*>(y2h + (oy * CX_T + lrow) * 32 + kg * 8) = h;
+                *reinterpret_cast<uint2*>(y2l + (oy * CX_T + lrow) * 32 + kg * 8) = l;
+            }
+        }
+        __syncthreads();
+
+        // ---- 5. cv2 (1x1, K = 48 = [y0 | y1 | y2], padded to 64): two K steps; SiLU; G8 stores (lane: 4 channels of one pixel: 8 B hi + 8 B lo)
+        {
+            const vec8 w2h00 = wfrag(3, 0, 0), w2h01 = wfrag(3, 0, 1), w2h10 = wfrag(3, 0, 2), w2h11 = wfrag(3, 0, 3);
+            const vec8 w2l00 = wfrag(3, 1, 0), w2l01 = wfrag(3, 1, 1), w2l10 = wfrag(3, 1, 2), w2l11 = wfrag(3, 1, 3);
+#pragma unroll
+            for (int g = 0; g < 2; ++g) {
+                const int oy = wave * 2 + g, tp = oy * CX_T + lrow;
+                const int wpix = (oy + 2) * CX_WW + lrow + 2;
+                // K step 0: channels 0..15 = y0 (kg 0, 1), 16..31 = y1 (kg 2, 3); K step 1: 32..47 = y2 (kg 0, 1), 48..63 = zero weights
+                const vec8 f0h = kg < 2 ? *reinterpret_cast<const vec8*>(y0h + tp * 32 + kg * 16) : *reinterpret_cast<const vec8*>(y1h + wpix * 32 + (kg - 2) * 16);
+                const vec8 f0l = kg < 2 ? *reinterpret_cast<const vec8*>(y0l + tp * 32 + kg * 16) : *reinterpret_cast<const vec8*>(y1l + wpix * 32 + (kg - 2) * 16);
+                const vec8 f1h = *reinterpret_cast<const vec8*>(y2h + tp * 32 + (kg & 1) * 16);
+                const vec8 f1l = *reinterpret_cast<const vec8*>(y2l + tp * 32 + (kg & 1) * 16);
+                xf32x4 m0{bias[4].x, bias[4].y, bias[4].z, bias[4].w}, m1{bias[5].x, bias[5].y, bias[5].z, bias[5].w};
+                xf32x4 c0{0.f, 0.f, 0.f, 0.f}, c1{0.f, 0.f, 0.f, 0.f};
+                mac3(w2h00, w2l00, f0h, f0l, m0, c0);
+                mac3(w2h01, w2l01, f0h, f0l, m1, c1);
+                mac3(w2h10, w2l10, f1h, f1l, m0, c0);
+                mac3(w2h11, w2l11, f1h, f1l, m1, c1);
+                const int y = ty0 + oy, x = tx0 + lrow;
+                if (y < a.H && x < a.W) {
+                    x3s* op = a.out + ((size_t)(img * a.H + y) * a.W + x) * a.out_cs + a.out_coff + kg * 4;
+                    float v[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = cx_silu(m0[e] + c0[e] * kX3Down);
+                    x3_store4(op, v);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = cx_silu(m1[e] + c1[e] * kX3Down);
+                    x3_store4(op + 16, v);
+                }
+            }
+        }
+    }
+}
+
+// ---- weight packing: the 16-bit kernels' fragment orders (conv_pair.hip / conv_c2f.hip), as a hi array followed by a lo array
+// 3x3 on 16 channels: fp32 [16][9][16] (cout, tap, cin) -> [hi | lo][k step 0..4][lane][8]; K index 8 kg + e of step ks: tap 2 ks + (kg >> 1), channel 8 (kg & 1) + e
+__global__ void pack_weights_pair16_x3_kernel(const float* __restrict__ src, uint16_t* __restrict__ dst) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= 5 * 512) return;
+    const int e = idx & 7, lane = (idx >> 3) & 63, ks = idx >> 9;
+    const int m = lane & 15, kg = lane >> 4;
+    const int tap = 2 * ks + (kg >> 1), cin = (kg & 1) * 8 + e;
+    const float v = tap < 9 ? src[((size_t)m * 9 + tap) * 16 + cin] : 0.0f;
+    _Float16 h, l;
+    x3_split(v, h, l);
+    dst[idx] = __builtin_bit_cast(uint16_t, h);
+    dst[5 * 512 + idx] = __builtin_bit_cast(uint16_t, l);
+}
+// 1x1: fp32 [cout][cin] -> [hi | lo][k step][cout tile][lane][8], K = 32 ks + 8 kg + e, zero beyond cin
+__global__ void pack_weights_c2f_pw_x3_kernel(const float* __restrict__ src, uint16_t* __restrict__ dst, int cout, int cin, int nks) {
+    const int nt_n = cout / 16, total = nks * nt_n * 512;
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int e = idx & 7, lane = (idx >> 3) & 63, f = idx >> 9;
+    const int nt = f % nt_n, ks = f / nt_n;
+    const int m = nt * 16 + (lane & 15), k = ks * 32 + (lane >> 4) * 8 + e;
+    _Float16 h, l;
+    x3_split(k < cin ? src[(size_t)m * cin + k] : 0.0f, h, l);
+    dst[idx] = __builtin_bit_cast(uint16_t, h);
+    dst[total + idx] = __builtin_bit_cast(uint16_t, l);
+}
+hipError_t launch_pack_weights_pair16_x3(const float* src, void* dst, hipStream_t st) {
+    hipLaunchKernelGGL(pack_weights_pair16_x3_kernel, dim3((5 * 512 + 255) / 256), dim3(256), 0, st, src, (uint16_t*)dst);
+    return hipGetLastError();
+}
+hipError_t launch_pack_weights_c2f_pw_x3(const float* src, void* dst, int cout, int cin, hipStream_t st) {
+    const int nks = (cin + 31) / 32, total = nks * (cout / 16) * 512;
+    hipLaunchKernelGGL(pack_weights_c2f_pw_x3_kernel, dim3((total + 255) / 256), dim3(256), 0, st, src, (uint16_t*)dst, cout, cin, nks);
+    return hipGetLastError();
+}
+
+static bool c2f_x3_enabled() {   // ADAS_NO_C2F_X3=1: the block runs as its four launches again
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("ADAS_NO_C2F_X3");
+        v = (e && e[0] == '1') ? 0 : 1;
+    }
+    return v == 1;
+}
+
+// the Bottleneck pair of such a block (engine.cpp's pair pass runs first and the C2f pass builds on its result): split precision, 16 channels;
+// a pair the C2f pass does not absorb is released again -- there is no stand-alone pair kernel in this precision
+bool pair_x3_candidate(int prec, int kh, int kw, int stride, int pad, int act, int res_mode, const TView& x, const TView& t, int kh2, int kw2, int stride2,
+                       int pad2, int act2, int res_mode2, const TView& y) {
+    if (!c2f_x3_enabled() || prec != PREC_X3) return false;
+    if (kh != 3 || kw != 3 || stride != 1 || pad != 1 || act != ACT_SILU || res_mode != RES_NONE) return false;
+    if (kh2 != 3 || kw2 != 3 || stride2 != 1 || pad2 != 1 || act2 != ACT_SILU || res_mode2 != RES_AFTER_ACT) return false;
+    return x.c == 16 && t.c == 16 && y.c == 16 && !x.f32 && !t.f32 && !y.f32 && x.h == y.h && x.w == y.w && t.h == x.h && t.w == x.w;
+}
+
+// cv1: x (32 ch) -> cat[0:32]; pair A / B on cat[16:32] -> cat[32:48] with shortcut; cv2: cat[0:48] -> out (32 ch)
+bool c2f16_x3_applicable(int prec, const TView& x, const TView& cat01, const TView& y1, const TView& y2, const TView& cat, const TView& out) {
+    if (!c2f_x3_enabled() || prec != PREC_X3) return false;
+    if (x.c != 32 || cat01.c != 32 || y1.c != 16 || y2.c != 16 || cat.c != 48 || out.c != 32) return false;
+    if (x.f32 || cat.f32 || out.f32) return false;
+    if (cat01.p != cat.p || y1.p != cat.p || y2.p != cat.p || cat01.coff != cat.coff || y1.coff != cat.coff + 16 || y2.coff != cat.coff + 32) return false;
+    if (x.h != out.h || x.w != out.w || cat.h != x.h || cat.w != x.w) return false;
+    if ((x.cs & 7) || (x.coff & 7) || (out.cs & 7) || (out.coff & 7)) return false;
+    return true;
+}
+size_t c2f_x3_weight_bytes(int which) { return (size_t)2 * CX_NF[which] * 1024; }   // which: 0 cv1, 1 A, 2 B, 3 cv2
+
+hipError_t launch_conv_c2f16_x3(const TView& x, const TView& out, const void* const w[4], const float* const b[4], int n, hipStream_t st) {
+    if ((double)n * x.h * x.w * x.cs * 4.0 >= (double)CX_OOB) return hipErrorNotSupported;
+    C2fX3Dev d;
+    d.in = (const unsigned char*)x.p; d.out = (x3s*)out.p;
+    for (int i = 0; i < 4; ++i) { d.w[i] = (const uint16_t*)w[i]; d.b[i] = b[i]; }
+    d.in_bytes = (uint32_t)((size_t)n * x.h * x.w * x.cs * 4);
+    d.in_cs = x.cs; d.in_coff = x.coff; d.out_cs = out.cs; d.out_coff = out.coff;
+    d.H = x.h; d.W = x.w;
+    d.tiles_x = (x.w + CX_T - 1) / CX_T;
+    d.tiles_per_img = d.tiles_x * ((x.h + CX_T - 1) / CX_T);
+    d.ntiles = n * d.tiles_per_img;
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute((const void*)conv_c2f16_x3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_done = true;
+    }
+    const int grid = d.ntiles < 256 ? d.ntiles : 256;   // persistent: one workgroup per CU
+    hipLaunchKernelGGL(conv_c2f16_x3_kernel, dim3(grid), dim3(CX_THR), CX_LDS, st, d);
+    return hipGetLastError();
+}
+
+}  // namespace adas

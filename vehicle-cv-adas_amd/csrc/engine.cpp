@@ -519,7 +519,8 @@ int adas_engine_create(const char* model_path, int precision, int max_batch, ada
         TView r2 = qb.res_mode != RES_NONE ? make_view(e, qb.res_buf, qb.res_coff, qb.out_c) : y;
         // the pair writes y while other workgroups still read x halos: y must not overlap x (same memory, intersecting channel ranges)
         if (y.p == x.p && y.coff < x.coff + x.c && x.coff < y.coff + y.c) continue;
-        if (!pair_applicable(precision, qa.kh, qa.kw, qa.stride, qa.pad, qa.act, qa.res_mode, x, t, qb.kh, qb.kw, qb.stride, qb.pad, qb.act, qb.res_mode, y, r2))
+        if (!pair_applicable(precision, qa.kh, qa.kw, qa.stride, qa.pad, qa.act, qa.res_mode, x, t, qb.kh, qb.kw, qb.stride, qb.pad, qb.act, qb.res_mode, y, r2) &&
+            !pair_x3_candidate(precision, qa.kh, qa.kw, qa.stride, qa.pad, qa.act, qa.res_mode, x, t, qb.kh, qb.kw, qb.stride, qb.pad, qb.act, qb.res_mode, y))
             continue;
         e->ops[ai].pair_b = bi;
         e->ops[bi].skip = true;
@@ -601,15 +602,25 @@ int adas_engine_create(const char* model_path, int precision, int max_batch, ada
             const EngBuf& xb = e->bufs[q1.in_buf[0]];   // conv_c2f.hip addresses the input with 31-bit byte offsets: decided here, at max_batch
             if ((double)max_batch * xb.h * xb.w * xb.c * 2.0 >= 2147483648.0) continue;
         }
-        if (!c2f16_applicable(precision, make_view(e, q1.in_buf[0], q1.in_coff[0], q1.in_c[0]), make_view(e, q1.out_buf, q1.out_coff, q1.out_c),
-                              make_view(e, qa.in_buf[0], qa.in_coff[0], qa.in_c[0]), make_view(e, qb.out_buf, qb.out_coff, qb.out_c),
-                              make_view(e, q2.in_buf[0], q2.in_coff[0], q2.in_c[0]), make_view(e, q2.out_buf, q2.out_coff, q2.out_c)))
-            continue;
+        {
+            const TView vx = make_view(e, q1.in_buf[0], q1.in_coff[0], q1.in_c[0]), v01 = make_view(e, q1.out_buf, q1.out_coff, q1.out_c);
+            const TView vy1 = make_view(e, qa.in_buf[0], qa.in_coff[0], qa.in_c[0]), vy2 = make_view(e, qb.out_buf, qb.out_coff, qb.out_c);
+            const TView vcat = make_view(e, q2.in_buf[0], q2.in_coff[0], q2.in_c[0]), vout = make_view(e, q2.out_buf, q2.out_coff, q2.out_c);
+            if (!c2f16_applicable(precision, vx, v01, vy1, vy2, vcat, vout) && !c2f16_x3_applicable(precision, vx, v01, vy1, vy2, vcat, vout)) continue;
+        }
         e->ops[c1].c2f[0] = (int)ai; e->ops[c1].c2f[1] = bi; e->ops[c1].c2f[2] = c2;
         e->ops[ai].skip = true;   // (conv B is skipped already: the pair launch is replaced as a whole)
         e->ops[c2].skip = true;
         c2f_role[c1] = 1; c2f_role[c2] = 2;
     }
+    if (precision == PREC_X3)   // split precision: a pair exists only inside a fused C2f block (conv_c2f_x3.hip) -- release the others
+        for (size_t ai = 0; ai < e->ops.size(); ++ai) {
+            const int bi = e->ops[ai].pair_b;
+            if (bi < 0 || e->ops[ai].skip) continue;      // (skip: absorbed into a C2f launch above)
+            e->ops[ai].pair_b = -1;
+            e->ops[bi].skip = false;
+            pair_of[bi] = -1;
+        }
     for (auto& op : e->ops) {
         const FileOp& o = op.f;
         if (o.type == OP_CONV && op.kernel == CONV_STEM) {
@@ -772,8 +783,10 @@ int adas_engine_create(const char* model_path, int precision, int max_batch, ada
                 continue;
             }
             hipError_t pe = op.kernel == CONV_DET5 ? launch_pack_weights_det5(d_stage, base + op.w_off, o.out_c / 3, o.in_c[0], precision, 0)
-                            : op.kernel == CONV_C2F_PW ? launch_pack_weights_c2f_pw(d_stage, base + op.w_off, o.out_c, o.in_c[0], precision, 0)
-                            : op.kernel == CONV_PAIR ? launch_pack_weights_pair(d_stage, base + op.w_off, o.out_c, precision, 0)
+                            : op.kernel == CONV_C2F_PW ? (precision == PREC_X3 ? launch_pack_weights_c2f_pw_x3(d_stage, base + op.w_off, o.out_c, o.in_c[0], 0)
+                                                                                : launch_pack_weights_c2f_pw(d_stage, base + op.w_off, o.out_c, o.in_c[0], precision, 0))
+                            : op.kernel == CONV_PAIR ? (precision == PREC_X3 ? launch_pack_weights_pair16_x3(d_stage, base + op.w_off, 0)
+                                                                              : launch_pack_weights_pair(d_stage, base + op.w_off, o.out_c, precision, 0))
                             : (op.kernel == CONV_FC || op.kernel == CONV_PW)
                                 ? launch_pack_weights_fc(d_stage, base + op.w_off, o.out_c, op.cout_pad, o.in_c[0], op.kpad, precision, 0)
                                 : op.kernel == CONV_HALO
@@ -909,7 +922,7 @@ int adas_engine_layer_kernel(const adas_engine* e, int layer, int batch, char* n
     } else if (o.type == OP_MAXPOOL && op.pool3[0] >= 0) {
         snprintf(name, cap, "sppf_pool3_kernel");
     } else if (o.type == OP_CONV && op.c2f[0] >= 0) {
-        snprintf(name, cap, "conv_c2f16_kernel");
+        snprintf(name, cap, e->prec == PREC_X3 ? "conv_c2f16_x3_kernel" : "conv_c2f16_kernel");
     } else if (op.skip && o.type == OP_CONV && in_c2f(e, layer)) {
         snprintf(name, cap, "(fused into the C2f launch)");
     } else if (op.skip && op.kernel == CONV_PAIR) {
@@ -1019,6 +1032,12 @@ int engine_run_op(adas_engine* e, int i, const float* d_in, int batch, hipStream
             if (op.ds_user >= 0 && ds_folded(e, op.ds_user, batch)) break;   // computed inside the conv it is the shortcut of
             if (op.c2f[0] >= 0) {   // this 1x1 conv, the Bottleneck pair behind it and the block's closing 1x1 conv: one launch
                 const EngOp &ca = e->ops[op.c2f[0]], &cb = e->ops[op.c2f[1]], &c2 = e->ops[op.c2f[2]];
+                if (e->prec == PREC_X3) {
+                    const void* const w4[4] = {wb + op.w_off, wb + ca.w_off, wb + cb.w_off, wb + c2.w_off};
+                    const float* const b4[4] = {(const float*)(wb + op.b_off), (const float*)(wb + ca.b_off), (const float*)(wb + cb.b_off), (const float*)(wb + c2.b_off)};
+                    err = launch_conv_c2f16_x3(make_view(e, o.in_buf[0], o.in_coff[0], o.in_c[0]), make_view(e, c2.f.out_buf, c2.f.out_coff, c2.f.out_c), w4, b4, batch, st);
+                    break;
+                }
                 err = launch_conv_c2f16(make_view(e, o.in_buf[0], o.in_coff[0], o.in_c[0]), make_view(e, c2.f.out_buf, c2.f.out_coff, c2.f.out_c),
                                         wb + op.w_off, (const float*)(wb + op.b_off), wb + ca.w_off, (const float*)(wb + ca.b_off), wb + cb.w_off,
                                         (const float*)(wb + cb.b_off), wb + c2.w_off, (const float*)(wb + c2.b_off), batch, e->prec, st);
