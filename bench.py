@@ -795,7 +795,7 @@ def main():
                     label, launches = ml_label, 0     # a member of a multi-layer persistent launch (conv_ml.hip): its FLOPs belong to that launch
                 elif label.startswith("(fused into"):
                     continue                          # fused into a neighbouring conv launch that reports the FLOPs itself
-                elif label.startswith("conv_stem_kernel"):
+                elif label.startswith("conv_stem"):
                     stem_label = label
                 elif label.startswith("conv_pair_kernel"):
                     pair_label = label

@@ -250,3 +250,37 @@ def test_c2f_block_in_one_launch_f32_class(case):
     else:
         assert all("fused" not in k and "x3" in k for k in names), names
     assert rel < 3 * X3_REL, (case, rel)
+
+
+@pytest.mark.parametrize("case", [(640, 640, 3, 1, 2), (70, 90, 3, 1, 3), (96, 200, 6, 2, 40), (33, 47, 6, 2, 2)], ids=str)
+def test_stem_with_its_second_conv_in_one_launch_f32_class(case):
+    """conv_stem2_x3_kernel: the YOLO stem (3x3 / 6x6 s2, 3 -> 16, SiLU) and the 3x3 s2 conv behind it (16 -> 32, SiLU: model.1) as one
+    launch in the split precision -- the stem tile lives in LDS as a hi and a lo plane, the 16-channel tensor never reaches HBM.  Full
+    and ragged extents (odd stem / conv2 sizes: tiles cut by both images' edges), more tiles than workgroups (96 x 200 at batch 40)."""
+    import os, tempfile
+    import torch
+    import torch.nn.functional as F
+    H, W, k, pad, batch = case
+    ws = M.SynthWeights(3, gain=1.0)
+    g = M.Graph("stem2unit", 3, H, W, ws)
+    x, c3 = g.input()
+    y = g.conv(x, 16, k, 2, "stem", act=M.ACT_SILU, true_cin=c3, pad=pad)
+    t = g.conv(y, 32, 3, 2, "second", act=M.ACT_SILU)
+    z = g.conv(t, 8, 1, 1, "tap", act=M.ACT_NONE, f32_out=True)
+    g.output(z, 0, [1, z.h * z.w * 8], "o")
+    path = os.path.join(tempfile.gettempdir(), f"stem2unit_{H}_{W}_{k}.hipm")
+    g.save(path)
+    e = CE.HipEngine(path, "fp16x3", batch)
+    xin = np.random.default_rng(4).uniform(0, 1, (batch, 3, H, W)).astype(np.float32)
+    e.engine_inference(xin)
+    got = e.fetch_activation("second", batch)
+    names = (e.layer_kernel(e.layer_index("stem"), batch), e.layer_kernel(e.layer_index("second"), batch))
+    e.close(); os.remove(path)
+    assert "conv_stem2_x3_kernel" in names[0] and "fused into the stem launch" in names[1], names
+    Wt = {k_: torch.from_numpy(v) for k_, v in ws.store.items()}
+    with torch.no_grad():
+        s1 = F.silu(F.conv2d(torch.from_numpy(xin), Wt["stem.weight"], Wt["stem.bias"], stride=2, padding=pad))
+        want = F.silu(F.conv2d(s1, Wt["second.weight"], Wt["second.bias"], stride=2, padding=1)).numpy()
+    rel = float(np.linalg.norm(got - want) / (np.linalg.norm(want) + 1e-30))
+    print("x3 stem + second conv %s: rel %.2e" % (case, rel))
+    assert got.shape == want.shape and rel < 3 * X3_REL, (case, rel)

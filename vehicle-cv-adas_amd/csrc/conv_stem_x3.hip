@@ -402,6 +402,249 @@ hipError_t launch_conv_stem_pool_x3(const float* nchw, int n, int c_true, int H,
     return hipGetLastError();
 }
 
+// ---- the YOLO stems with the 3x3 s2 p1 conv behind them (model.1: 16 -> 32 channels) in one launch, split precision: conv_stem.hip's
+// CONV2 scheme with both halves of every operand.  The 17 x 33 stem pixels an 8 x 16 tile of the second conv needs (incl. its padding
+// ring: stem pixels outside the stem's output are ZERO) stay in LDS as a hi plane and a lo plane (split after the exact SiLU); the second
+// conv runs from there -- K step = two taps x 16 channels, three MFMAs per step and 16-channel output tile -- and only its 32-channel
+// output reaches HBM: the stem's 16-channel tensor (6.5 MB per 640^2 frame in the split storage, written by one launch and read back
+// by the generic split kernel: 0.29 + 0.23 ms per 64 frames) never exists.  8 waves, one persistent workgroup per CU.
+struct Stem2X3Dev {
+    const float* in;         // [N][C][H][W] fp32
+    const uint16_t* wfrag;   // stem: [hi | lo][KH][64 lanes][8]
+    const float* bias;
+    const uint16_t* wfrag2;  // second conv: [hi | lo][2 tiles][5 K steps][64 lanes][8]
+    const float* bias2;
+    x3s* out;                // the second conv's NHWC G8 view (32 channels)
+    int out_cs, out_coff;
+    int N, C, H, W;
+    int Ho, Wo;              // stem output
+    int Hp, Wp;              // second conv output
+    int pad;
+    int tiles_x, tiles_y, ntiles;
+};
+constexpr int S2X_CTH = 17, S2X_CTW = 33, S2X_NPIX = S2X_CTH * S2X_CTW, S2X_NMT = (S2X_NPIX + 15) / 16;   // 561 stem pixels, 36 M tiles
+constexpr int S2X_CP = 24;                                                                            // stem-tile pixel pitch in halves (48 B: aligned 16-byte fragment reads)
+__host__ __device__ constexpr int s2x_wh(int kh) { return 2 * (S2X_CTH - 1) + kh; }
+__host__ __device__ constexpr int s2x_region(int kh) {   // the windows and the stem tile share one region (never live together)
+    return 2 * s2x_wh(kh) * SX3_WW * 8 > 2 * S2X_NPIX * S2X_CP * 2 ? 2 * s2x_wh(kh) * SX3_WW * 8 : 2 * S2X_NPIX * S2X_CP * 2;
+}
+__host__ __device__ constexpr int s2x_lds_bytes(int kh) { return 2 * kh * 1024 + 2 * 10 * 1024 + s2x_region(kh); }
+
+template <int KH>
+__global__ __launch_bounds__(512, 1) void conv_stem2_x3_kernel(Stem2X3Dev a) {
+    Fp16::enter();
+    constexpr int CTW = S2X_CTW, NPIX = S2X_NPIX, WW = SX3_WW, WH = s2x_wh(KH), CP = S2X_CP;
+    constexpr int NQ = (WH * WW + 511) / 512;
+    constexpr int MT = (S2X_NMT + 7) / 8;   // 5 M tiles per wave (36 over 8 waves: the last ones guarded)
+    extern __shared__ __attribute__((aligned(16))) uint16_t sx3_lds[];
+    uint16_t* wlh = sx3_lds;                 // stem weights, hi then lo (KH fragments each)
+    uint16_t* wll = wlh + KH * 512;
+    uint16_t* w2h = wll + KH * 512;          // second conv's weights, hi then lo (10 fragments each)
+    uint16_t* w2l = w2h + 10 * 512;
+    uint16_t* winh = w2l + 10 * 512;
+    uint16_t* winl = winh + WH * WW * 4;
+    uint16_t* cth = winh;                    // the stem tile's planes take the windows' place
+    uint16_t* ctl = cth + NPIX * CP;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lrow = lane & 15, kg = lane >> 4;
+    stage_lds16<512, 2>(wlh, a.wfrag, 2 * KH * 64, tid);
+    stage_lds16<512, 3>(w2h, a.wfrag2, 2 * 10 * 64, tid);
+
+    int boff[MT];
+#pragma unroll
+    for (int j = 0; j < MT; ++j) {
+        const int p = (wave + 8 * j) * 16 + lrow;
+        const int pc = p < NPIX ? p : NPIX - 1;
+        const int cy = pc / CTW, cx = pc - cy * CTW;
+        boff[j] = ((2 * cy) * WW + 2 * cx + 2 * kg) * 4;
+    }
+    const int per_img = a.tiles_x * a.tiles_y;
+    const int plane = a.H * a.W;
+    const float4 bias1 = *reinterpret_cast<const float4*>(a.bias + kg * 4);
+    const float4 bias2lo = *reinterpret_cast<const float4*>(a.bias2 + kg * 4), bias2hi = *reinterpret_cast<const float4*>(a.bias2 + 16 + kg * 4);
+
+    uint32_t px[NQ][3];
+    auto fetch = [&](int tile) {
+        const bool live = tile < a.ntiles;
+        const int tl = live ? tile : 0;
+        const int img = tl / per_img;
+        const int t2 = tl - img * per_img;
+        const int ty = t2 / a.tiles_x, tx = t2 - ty * a.tiles_x;
+        const int cy0 = 2 * (ty * 8) - 1, cx0 = 2 * (tx * 16) - 1;   // stem-output origin of the tile (the second conv's pad 1)
+        const int iy0 = 2 * cy0 - a.pad, ix0 = 2 * cx0 - a.pad;
+        const void* in_img = (const void*)(a.in + (size_t)img * a.C * plane);
+        __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)in_img, 0, a.C * plane * 4, 0x00020000);
+#pragma unroll
+        for (int i = 0; i < NQ; ++i) {
+            const int q = tid + 512 * i;
+            const int wy = q / WW, wx = q - wy * WW;
+            const int iy = iy0 + wy, ix = ix0 + wx;
+            const bool ok = live && q < WH * WW && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+            const uint32_t off = (uint32_t)((iy * a.W + ix) * 4);
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const uint32_t oc = (ok && c < a.C) ? off + (uint32_t)(c * plane * 4) : 0x80000000u;
+                px[i][c] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rsrc, oc, 0, 0);
+            }
+        }
+    };
+
+    const int gstride = gridDim.x;
+    int tile = blockIdx.x;
+    if (tile >= a.ntiles) return;
+    fetch(tile);
+    for (; tile < a.ntiles; tile += gstride) {
+        const int img = tile / per_img;
+        const int t2 = tile - img * per_img;
+        const int ty = t2 / a.tiles_x, tx = t2 - ty * a.tiles_x;
+        const int cy0 = 2 * (ty * 8) - 1, cx0 = 2 * (tx * 16) - 1;
+
+        __syncthreads();  // the previous tile's second conv is done reading the shared region (first trip: the weights are in LDS)
+#pragma unroll
+        for (int i = 0; i < NQ; ++i) {
+            const int q = tid + 512 * i;
+            if (q < WH * WW) {
+                _Float16 h[3], l[3];
+#pragma unroll
+                for (int c = 0; c < 3; ++c) x3_split(__uint_as_float(px[i][c]), h[c], l[c]);
+                zu32x2 vh, vl;
+                vh.x = __builtin_bit_cast(uint32_t, e_f16x2{h[0], h[1]});
+                vh.y = __builtin_bit_cast(uint32_t, e_f16x2{h[2], (_Float16)0.0f});
+                vl.x = __builtin_bit_cast(uint32_t, e_f16x2{l[0], l[1]});
+                vl.y = __builtin_bit_cast(uint32_t, e_f16x2{l[2], (_Float16)0.0f});
+                *reinterpret_cast<zu32x2*>(winh + q * 4) = vh;
+                *reinterpret_cast<zu32x2*>(winl + q * 4) = vl;
+            }
+        }
+        __syncthreads();
+        fetch(tile + gstride);  // in flight under this tile's MFMAs
+
+        // ---- stem conv on the 36 M tiles (wave w: tiles w, w + 8, ...): KH K-steps of three MFMAs
+        zf32x4 accm[MT], accx[MT];
+#pragma unroll
+        for (int j = 0; j < MT; ++j) accm[j] = accx[j] = zf32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int r = 0; r < KH; ++r) {
+            const e_u32x4 wh = *reinterpret_cast<const e_u32x4*>(wlh + (r * 64 + lane) * 8);
+            const e_u32x4 wl = *reinterpret_cast<const e_u32x4*>(wll + (r * 64 + lane) * 8);
+#pragma unroll
+            for (int j = 0; j < MT; ++j) {
+                if (wave + 8 * j < S2X_NMT) {   // wave-uniform
+                    const e_u32x4 xh = *reinterpret_cast<const e_u32x4*>(winh + boff[j] + r * WW * 4);
+                    const e_u32x4 xl = *reinterpret_cast<const e_u32x4*>(winl + boff[j] + r * WW * 4);
+                    accm[j] = Fp16::mfma(wh, xh, accm[j]);
+                    accx[j] = Fp16::mfma(wl, xh, accx[j]);
+                    accx[j] = Fp16::mfma(wh, xl, accx[j]);
+                }
+            }
+        }
+        __syncthreads();  // every wave is done reading the windows: the stem tile may overwrite them
+#pragma unroll
+        for (int j = 0; j < MT; ++j) {
+            const int p = (wave + 8 * j) * 16 + lrow;
+            if (wave + 8 * j >= S2X_NMT || p >= NPIX) continue;
+            const int cy = p / CTW, cx = p - cy * CTW;
+            const int gy = cy0 + cy, gx = cx0 + cx;
+            const bool valid = (unsigned)gy < (unsigned)a.Ho && (unsigned)gx < (unsigned)a.Wo;   // else: the second conv's zero padding
+            _Float16 h[4], l[4];
+            const float b[4] = {bias1.x, bias1.y, bias1.z, bias1.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) x3_split(valid ? sx3_act<ACT_SILU>(accm[j][e] + accx[j][e] * kX3Down + b[e]) : 0.0f, h[e], l[e]);
+            zu32x2 vh, vl;
+            vh.x = __builtin_bit_cast(uint32_t, e_f16x2{h[0], h[1]}); vh.y = __builtin_bit_cast(uint32_t, e_f16x2{h[2], h[3]});
+            vl.x = __builtin_bit_cast(uint32_t, e_f16x2{l[0], l[1]}); vl.y = __builtin_bit_cast(uint32_t, e_f16x2{l[2], l[3]});
+            *reinterpret_cast<zu32x2*>(cth + p * CP + kg * 4) = vh;
+            *reinterpret_cast<zu32x2*>(ctl + p * CP + kg * 4) = vl;
+        }
+        __syncthreads();
+
+        // ---- second conv from the stem tile: wave w = output row w of the 8 x 16 tile; K step s2 = taps 2 s2 and 2 s2 + 1 x 16 channels
+        // (the tenth tap slot has zero weights)
+        {
+            const int py2 = wave, px2 = lrow;
+            zf32x4 m0{bias2lo.x, bias2lo.y, bias2lo.z, bias2lo.w}, m1{bias2hi.x, bias2hi.y, bias2hi.z, bias2hi.w};
+            zf32x4 c0{0.f, 0.f, 0.f, 0.f}, c1{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int s2 = 0; s2 < 5; ++s2) {
+                const int t = 2 * s2 + (kg >> 1) < 9 ? 2 * s2 + (kg >> 1) : 8;
+                const int kh2 = t / 3, kw2 = t - kh2 * 3;
+                const int o = ((2 * py2 + kh2) * CTW + 2 * px2 + kw2) * CP + (kg & 1) * 8;
+                const e_u32x4 xh = *reinterpret_cast<const e_u32x4*>(cth + o), xl = *reinterpret_cast<const e_u32x4*>(ctl + o);
+                const e_u32x4 wh0 = *reinterpret_cast<const e_u32x4*>(w2h + ((0 * 5 + s2) * 64 + lane) * 8), wl0 = *reinterpret_cast<const e_u32x4*>(w2l + ((0 * 5 + s2) * 64 + lane) * 8);
+                const e_u32x4 wh1 = *reinterpret_cast<const e_u32x4*>(w2h + ((1 * 5 + s2) * 64 + lane) * 8), wl1 = *reinterpret_cast<const e_u32x4*>(w2l + ((1 * 5 + s2) * 64 + lane) * 8);
+                m0 = Fp16::mfma(wh0, xh, m0); c0 = Fp16::mfma(wl0, xh, c0); c0 = Fp16::mfma(wh0, xl, c0);
+                m1 = Fp16::mfma(wh1, xh, m1); c1 = Fp16::mfma(wl1, xh, c1); c1 = Fp16::mfma(wh1, xl, c1);
+            }
+            const int oy = ty * 8 + py2, ox = tx * 16 + px2;
+            if (oy < a.Hp && ox < a.Wp) {
+                x3s* op = a.out + ((size_t)(img * a.Hp + oy) * a.Wp + ox) * a.out_cs + a.out_coff + kg * 4;
+                float v[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = sx3_act<ACT_SILU>(m0[e] + c0[e] * kX3Down);
+                x3_store4(op, v);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = sx3_act<ACT_SILU>(m1[e] + c1[e] * kX3Down);
+                x3_store4(op + 16, v);
+            }
+        }
+    }
+}
+
+static bool stem2_x3_enabled() {   // ADAS_NO_STEM2_X3=1: stem and second conv as their two launches again
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("ADAS_NO_STEM2_X3");
+        v = (e && e[0] == '1') ? 0 : 1;
+    }
+    return v == 1;
+}
+bool stem2_x3_applicable(int in_c_true, int kh, int pad, int act, const TView& stem_out, int kh2, int kw2, int stride2, int pad2, int act2, int res_mode2,
+                         const TView& out2) {
+    if (!stem2_x3_enabled() || in_c_true > 3 || !(kh == 3 || kh == 6) || act != ACT_SILU || act2 != ACT_SILU || res_mode2 != RES_NONE) return false;
+    if (stem_out.c != 16 || stem_out.f32 || out2.c != 32 || out2.f32 || (out2.cs & 7) || (out2.coff & 7)) return false;
+    if (kh2 != 3 || kw2 != 3 || stride2 != 2 || pad2 != 1 || pad > kh / 2) return false;
+    return out2.h == (stem_out.h + 2 - 3) / 2 + 1 && out2.w == (stem_out.w + 2 - 3) / 2 + 1;
+}
+size_t stem2_x3_weight_bytes() { return 2 * stem2_weight_bytes(); }
+// second conv: w = [32][3][3][16] fp32 (OHWI) -> [hi | lo][2][5][64 lanes][8]; K index kk = 8 kgroup + e of step s: tap 2 s + (kk >> 4), channel kk & 15
+void stem2_x3_pack_weights(const float* w, uint16_t* dst) {
+    const size_t arr = (size_t)2 * 5 * 64 * 8;
+    for (int n = 0; n < 2; ++n)
+        for (int s = 0; s < 5; ++s)
+            for (int lane = 0; lane < 64; ++lane)
+                for (int e = 0; e < 8; ++e) {
+                    const int co = n * 16 + (lane & 15), kk = (lane >> 4) * 8 + e;
+                    const int tap = 2 * s + (kk >> 4), ch = kk & 15;
+                    _Float16 h, l;
+                    x3_split(tap < 9 ? w[((size_t)co * 9 + tap) * 16 + ch] : 0.f, h, l);
+                    const size_t at = ((size_t)(n * 5 + s) * 64 + lane) * 8 + e;
+                    dst[at] = __builtin_bit_cast(uint16_t, h);
+                    dst[arr + at] = __builtin_bit_cast(uint16_t, l);
+                }
+}
+hipError_t launch_conv_stem2_x3(const float* nchw, int n, int c_true, int H, int W, int kh, int pad, const void* wfrag, const float* bias,
+                                const TView& stem_out, const void* wfrag2, const float* bias2, const TView& out2, hipStream_t st) {
+    Stem2X3Dev d;
+    d.in = nchw; d.wfrag = (const uint16_t*)wfrag; d.bias = bias; d.wfrag2 = (const uint16_t*)wfrag2; d.bias2 = bias2;
+    d.out = (x3s*)out2.p; d.out_cs = out2.cs; d.out_coff = out2.coff;
+    d.N = n; d.C = c_true; d.H = H; d.W = W; d.Ho = stem_out.h; d.Wo = stem_out.w; d.Hp = out2.h; d.Wp = out2.w;
+    d.pad = pad;
+    d.tiles_x = (d.Wp + 15) / 16; d.tiles_y = (d.Hp + 7) / 8;
+    d.ntiles = n * d.tiles_x * d.tiles_y;
+    if ((size_t)c_true * H * W * 4 >= (1ull << 31) || (kh != 3 && kh != 6)) return hipErrorInvalidValue;
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute((const void*)conv_stem2_x3_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)conv_stem2_x3_kernel<6>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_done = true;
+    }
+    const int grid = d.ntiles < 256 ? d.ntiles : 256;   // persistent: one workgroup per CU
+    if (kh == 3) hipLaunchKernelGGL(conv_stem2_x3_kernel<3>, dim3(grid), dim3(512), s2x_lds_bytes(3), st, d);
+    else hipLaunchKernelGGL(conv_stem2_x3_kernel<6>, dim3(grid), dim3(512), s2x_lds_bytes(6), st, d);
+    return hipGetLastError();
+}
+
 // -------------------------------------------------------------------------------------
 bool stem_x3_applicable(int in_c_true, int kh, int kw, int stride, int pad, int act, int res_mode, const TView& out) {
     if (in_c_true > 3 || stride != 2 || res_mode != RES_NONE) return false;

@@ -359,6 +359,18 @@ int adas_engine_create(const char* model_path, int precision, int max_batch, ada
                     e->ops[1].fuse_pool = 2;
                     e->ops[2].skip = true;
                 }
+                // YOLO stems: the 3x3 s2 conv on the stem's 16 channels joins the launch when nothing else reads the stem output (conv_stem2_x3_kernel)
+                if (e->ops[1].fuse_pool < 0 && e->ops.size() >= 3 && fo[2].type == OP_CONV && fo[2].n_in == 1 && fo[2].in_buf[0] == fo[1].out_buf &&
+                    fo[2].in_coff[0] == fo[1].out_coff && fo[2].in_c[0] == fo[1].out_c && !is_output(fo[1].out_buf) && !aliased(fo[2].out_buf)) {
+                    bool sole = true;
+                    for (size_t i = 3; i < fo.size(); ++i) sole = sole && !reads_buf(fo[i], fo[1].out_buf);
+                    if (sole && stem2_x3_applicable(hd.in_c, fo[1].kh, fo[1].pad, fo[1].act, make_view(e, fo[1].out_buf, fo[1].out_coff, fo[1].out_c), fo[2].kh,
+                                                    fo[2].kw, fo[2].stride, fo[2].pad, fo[2].act, fo[2].res_mode, make_view(e, fo[2].out_buf, fo[2].out_coff, fo[2].out_c))) {
+                        e->ops[1].fuse_conv2 = 2;
+                        e->ops[2].skip = true;
+                        e->ops[2].kernel = CONV_STEM2;
+                    }
+                }
             }
         } else if (enabled && e->ops.size() >= 2 && fo[0].type == OP_INPUT && fo[1].type == OP_CONV && fo[1].in_buf[0] == fo[0].out_buf &&
             !aliased(fo[0].out_buf) && !aliased(fo[1].out_buf)) {
@@ -638,7 +650,7 @@ int adas_engine_create(const char* model_path, int precision, int max_batch, ada
             op.cin_pad = 16;
             op.cout_pad = (o.out_c + 127) / 128 * 128;
             op.w_off = packed_total;
-            packed_total += (stem2_weight_bytes() + 255) & ~(size_t)255;
+            packed_total += ((precision == PREC_X3 ? stem2_x3_weight_bytes() : stem2_weight_bytes()) + 255) & ~(size_t)255;
             op.b_off = packed_total;
             packed_total += ((size_t)op.cout_pad * 4 + 255) & ~(size_t)255;
         } else if (o.type == OP_CONV) {
@@ -770,10 +782,11 @@ int adas_engine_create(const char* model_path, int precision, int max_batch, ada
             if (!read_blob(o.w_off, o.w_elems, h_stage.data()) || o.w_elems != (uint64_t)o.out_c * op.k) { rc = ADAS_ERR_FORMAT; break; }
             if (hipMemcpy(d_stage, h_stage.data(), o.w_elems * 4, hipMemcpyHostToDevice) != hipSuccess) { rc = ADAS_ERR_HIP; break; }
             if (op.kernel == CONV_STEM || op.kernel == CONV_STEM2) {
-                std::vector<uint16_t> frag((op.kernel == CONV_STEM2 ? stem2_weight_bytes()
+                std::vector<uint16_t> frag((op.kernel == CONV_STEM2 ? (precision == PREC_X3 ? stem2_x3_weight_bytes() : stem2_weight_bytes())
                                             : precision == PREC_X3   ? stem_x3_weight_bytes(o.kh, o.out_c)
                                                                      : stem_weight_bytes(o.kh, o.out_c)) / 2);
-                if (op.kernel == CONV_STEM2) stem2_pack_weights(h_stage.data(), frag.data(), precision);
+                if (op.kernel == CONV_STEM2 && precision == PREC_X3) stem2_x3_pack_weights(h_stage.data(), frag.data());
+                else if (op.kernel == CONV_STEM2) stem2_pack_weights(h_stage.data(), frag.data(), precision);
                 else if (precision == PREC_X3) stem_x3_pack_weights(h_stage.data(), o.out_c, o.kh, o.kw, o.in_c[0], hd.in_c, frag.data());
                 else stem_pack_weights(h_stage.data(), o.out_c, o.kh, o.kw, o.in_c[0], hd.in_c, frag.data(), precision);
                 if (hipMemcpy(base + op.w_off, frag.data(), frag.size() * 2, hipMemcpyHostToDevice) != hipSuccess) { rc = ADAS_ERR_HIP; break; }
@@ -932,7 +945,7 @@ int adas_engine_layer_kernel(const adas_engine* e, int layer, int batch, char* n
     } else if (op.skip) {
         snprintf(name, cap, o.type == OP_CONV && o.kh == 1 && (op.kernel == CONV_PW || op.kernel == CONV_DET5) ? "(fused into the Detect launch)" : "(fused into the stem launch)");
     } else if (o.type == OP_CONV && op.kernel == CONV_STEM && op.fuse_conv2 >= 0) {
-        snprintf(name, cap, "conv_stem_kernel<%d,1,SILU>+conv3x3s2", (int)o.kh);
+        snprintf(name, cap, e->prec == PREC_X3 ? "conv_stem2_x3_kernel<%d>+conv3x3s2" : "conv_stem_kernel<%d,1,SILU>+conv3x3s2", (int)o.kh);
     } else if (o.type == OP_CONV) {
         ConvArgs a;
         a.in = make_view(e, o.in_buf[0], o.in_coff[0], o.in_c[0]);
@@ -1006,7 +1019,11 @@ int engine_run_op(adas_engine* e, int i, const float* d_in, int batch, hipStream
             const FileOp& po = e->ops[op.fuse_pool].f;
             pv = make_view(e, po.out_buf, po.out_coff, po.out_c);
         }
-        if (e->prec == PREC_X3 && op.fuse_pool >= 0) {
+        if (e->prec == PREC_X3 && op.fuse_conv2 >= 0) {
+            const EngOp& c2 = e->ops[op.fuse_conv2];
+            err = launch_conv_stem2_x3(d_in, batch, e->hdr.in_c, e->hdr.in_h, e->hdr.in_w, o.kh, o.pad, wb + op.w_off, (const float*)(wb + op.b_off), cv,
+                                       wb + c2.w_off, (const float*)(wb + c2.b_off), make_view(e, c2.f.out_buf, c2.f.out_coff, c2.f.out_c), st);
+        } else if (e->prec == PREC_X3 && op.fuse_pool >= 0) {
             err = launch_conv_stem_pool_x3(d_in, batch, e->hdr.in_c, e->hdr.in_h, e->hdr.in_w, o.pad, wb + op.w_off, (const float*)(wb + op.b_off), cv, pv, st);
         } else if (e->prec == PREC_X3) {
             err = launch_conv_stem_x3(d_in, batch, e->hdr.in_c, e->hdr.in_h, e->hdr.in_w, o.kh, o.pad, o.act, wb + op.w_off, (const float*)(wb + op.b_off), cv, st);

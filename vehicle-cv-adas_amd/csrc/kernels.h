@@ -180,6 +180,13 @@ void stem_x3_pack_weights(const float* w_ohwi, int cout, int kh, int kw, int cs,
 hipError_t launch_conv_stem_x3(const float* nchw, int n, int c_true, int H, int W, int kh, int pad, int act, const void* wfrag, const float* bias,
                                const TView& out, hipStream_t st);
 // the ResNet stem (7x7 s2 + ReLU, 64 channels) with its 3x3 s2 p1 max-pool in one launch; same weight packing
+// ... and the YOLO stems with the 3x3 s2 16 -> 32 conv behind them (model.1) in one launch (conv_stem2_x3_kernel)
+bool stem2_x3_applicable(int in_c_true, int kh, int pad, int act, const TView& stem_out, int kh2, int kw2, int stride2, int pad2, int act2, int res_mode2,
+                         const TView& out2);
+size_t stem2_x3_weight_bytes();
+void stem2_x3_pack_weights(const float* w_ohwi_32x3x3x16, uint16_t* dst_host);   // [hi | lo] fragment arrays
+hipError_t launch_conv_stem2_x3(const float* nchw, int n, int c_true, int H, int W, int kh, int pad, const void* wfrag, const float* bias,
+                                const TView& stem_out, const void* wfrag2, const float* bias2, const TView& out2, hipStream_t st);
 bool stem_pool_x3_applicable(int in_c_true, int kh, int kw, int stride, int pad, int act, int res_mode, const TView& conv_out, const TView& pool_out);
 hipError_t launch_conv_stem_pool_x3(const float* nchw, int n, int c_true, int H, int W, int pad, const void* wfrag, const float* bias,
                                     const TView& conv_out, const TView& pool_out, hipStream_t st);
