@@ -430,8 +430,15 @@ __host__ __device__ constexpr int s2x_region(int kh) {   // the windows and the 
 }
 __host__ __device__ constexpr int s2x_lds_bytes(int kh) { return 2 * kh * 1024 + 2 * 10 * 1024 + s2x_region(kh); }
 
+// Workgroups per CU the kernel is compiled for.  The stages of a tile (window conversion, stem MFMAs, SiLU + split of the stem tile, second
+// conv, SiLU + stores) are serial inside a workgroup; 80.5 KB of LDS lets two of them share a CU, which costs 10-15 spilled VGPRs at
+// the 128-register bound and measured +2.2 % end to end against one workgroup per CU (5,380 vs 5,265 frames/s, same box,
+// profiles/r06/ab_stem2_wgs.txt).  -DADAS_STEM2_X3_WGS=1 builds the single-workgroup form.
+#ifndef ADAS_STEM2_X3_WGS
+#define ADAS_STEM2_X3_WGS 2
+#endif
 template <int KH>
-__global__ __launch_bounds__(512, 1) void conv_stem2_x3_kernel(Stem2X3Dev a) {
+__global__ __launch_bounds__(512, 2 * ADAS_STEM2_X3_WGS) void conv_stem2_x3_kernel(Stem2X3Dev a) {
     Fp16::enter();
     constexpr int CTW = S2X_CTW, NPIX = S2X_NPIX, WW = SX3_WW, WH = s2x_wh(KH), CP = S2X_CP;
     constexpr int NQ = (WH * WW + 511) / 512;
@@ -639,7 +646,7 @@ hipError_t launch_conv_stem2_x3(const float* nchw, int n, int c_true, int H, int
         (void)hipFuncSetAttribute((const void*)conv_stem2_x3_kernel<6>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_done = true;
     }
-    const int grid = d.ntiles < 256 ? d.ntiles : 256;   // persistent: one workgroup per CU
+    const int grid = d.ntiles < 256 * ADAS_STEM2_X3_WGS ? d.ntiles : 256 * ADAS_STEM2_X3_WGS;   // persistent
     if (kh == 3) hipLaunchKernelGGL(conv_stem2_x3_kernel<3>, dim3(grid), dim3(512), s2x_lds_bytes(3), st, d);
     else hipLaunchKernelGGL(conv_stem2_x3_kernel<6>, dim3(grid), dim3(512), s2x_lds_bytes(6), st, d);
     return hipGetLastError();
