@@ -216,17 +216,18 @@ def test_changed_crop_ratio_or_config_recaptures_the_graph(tmp_path):
     pg.close(); pe.close(); dc.free()
 
 
-@pytest.mark.parametrize("det_name", ["yolov8n", "yolov7-tiny"])
-def test_detect_sink_off_gives_the_same_step(tmp_path, monkeypatch, det_name):
+@pytest.mark.parametrize("det_name,precision", [("yolov8n", "fp16"), ("yolov7-tiny", "fp16"), ("yolov8n", "fp16x3")])
+def test_detect_sink_off_gives_the_same_step(tmp_path, monkeypatch, det_name, precision):
     """ADAS_NO_DETECT_SINK=1 (full head + class scan inside the step) against the default (per-anchor maxima straight from the Detect
-    kernel): identical candidates, survivors and tracks; a detector engine keeps returning the whole head to engine_inference callers."""
+    kernel): identical candidates, survivors and tracks; a detector engine keeps returning the whole head to engine_inference callers.
+    fp16x3: the exact mode's fused Detect (detect_v8_fused_x3_kernel) and its sink."""
     import bench
     S = 2
     cam = [bench.cam_frames(S, 90 + i) for i in range(2)]
     seam = np.concatenate([importlib.import_module("oracle.preprocess").yolo_prepare_input(f, (640, 640)) for f in cam[0]])
     det_path, _, _ = bench.build_detector(M, CE, det_name, seam, str(tmp_path), "sink", target_per_frame=60.0)   # v8 layout / v5 layout
     lane_path, _, _ = netutil.model("ufldv2_res18")
-    kw = dict(n_streams=S, precision="fp16", src_hw=(720, 1280), use_graph=True, head_layout=L.HEAD_V8 if det_name == "yolov8n" else L.HEAD_V5)
+    kw = dict(n_streams=S, precision=precision, src_hw=(720, 1280), use_graph=True, head_layout=L.HEAD_V8 if det_name == "yolov8n" else L.HEAD_V5)
     pa = PL.AdasPipeline(det_path, lane_path, **kw)
     monkeypatch.setenv("ADAS_NO_DETECT_SINK", "1")
     pb = PL.AdasPipeline(det_path, lane_path, **kw)

@@ -7,6 +7,7 @@ Layer tests bound the error against torch fp32 at 20x below anything a half-prec
 it next to the fp32 mode's error on the same case; network tests use the fp32 mode's bounds of tests/test_gpu_configs.py.
 """
 import importlib
+import os
 
 import numpy as np
 import pytest
@@ -159,7 +160,22 @@ def test_yolov8_640_vs_oracle(tmp_path, scale):
     ebox = float(np.abs(got[:, :4] - want[:, :4]).max())
     print("yolov8%s fp16x3 max|prob diff| %.3e  max|box diff| %.3e px" % (scale, ecls, ebox))
     assert relh <= 1e-4 and ecls <= 1e-4 and ebox <= 1e-3 * max(1.0, float(np.abs(want[:, :4]).max()))
+    kernels = [e.layer_kernel(i, 2) for i in range(e.stats()["num_layers"])]
+    got = np.array(got, copy=True)
     e.close()
+    # the head above came from ONE launch (detect_v8_fused_x3_kernel: the six closing 1x1 convs + the decode); the separate launches agree
+    assert any("detect_v8_fused_x3_kernel" in k for k in kernels) and sum("fused into the Detect launch" in k for k in kernels) == 6, kernels
+    os.environ["ADAS_NO_DETECT_FUSE"] = "1"
+    try:
+        e = CE.HipEngine(path, precision="fp16x3", max_batch=2)
+    finally:
+        del os.environ["ADAS_NO_DETECT_FUSE"]
+    sep = np.array(e.engine_inference(x)[0], copy=True)
+    assert not any("detect_v8_fused" in e.layer_kernel(i, 2) for i in range(e.stats()["num_layers"]))
+    e.close()
+    dc, db = float(np.abs(got[:, 4:] - sep[:, 4:]).max()), float(np.abs(got[:, :4] - sep[:, :4]).max())
+    print("yolov8%s fp16x3 fused Detect vs separate launches: max|prob diff| %.2e  max|box diff| %.2e px" % (scale, dc, db))
+    assert dc <= 2e-6 and db <= 2e-3      # the same (hi, lo) products, summed in a different order
 
 
 def test_yolov10n_vs_oracle():

@@ -755,6 +755,201 @@ hipError_t launch_detect_v8_fused(const TView* hidden, const void* const* wfrag,
     return hipGetLastError();
 }
 
+// ---- the same fusion in the split precision (ADAS_PREC_FP16X3; round 6).  The six 1x1 convs read G8 activations (a lane's 8 channels:
+// 16 bytes of hi halves, 16 bytes of lo halves) and conv_pw_x3's weight packing as it is ([16-feature tile][32-channel K step][hi 1 KB |
+// lo 1 KB]); every product is three MFMAs (main += w_hi x_hi; cross += w_lo x_hi + w_hi x_lo; logit = main + 2^-11 cross + bias); DFL
+// softmax and sigmoid in their exact forms (expf, IEEE division: detect_v8_kernel's expressions).  The exact mode ran this as six
+// conv_pwx3 launches + the decode (0.27 ms per 64 frames); with SINK the pipeline's scan launch and the class rows go as well.
+struct DetFuseX3Dev {
+    const unsigned char* hb[3];   // inputs of cv2.i.2 (G8 NHWC views: 4 bytes per channel slot)
+    const unsigned char* hc[3];   // inputs of cv3.i.2
+    int hb_cs[3], hb_coff[3], hc_cs[3], hc_coff[3];
+    const uint16_t* wb[3];        // [4][KTb][hi | lo][64][8]
+    const uint16_t* wc[3];        // [NTc..][KTc][hi | lo][64][8]
+    const float* bb[3];
+    const float* bc[3];
+    int cb, cc, ktb, ktc;         // hidden widths; K steps of the two packings (kpad / 32)
+    int hw[3], w[3], stride[3], a_off[3];
+    float* out;
+    int nc, A, n;
+    float* sink_conf;
+    int* sink_cls;
+};
+
+template <bool SINK>
+__global__ __launch_bounds__(256) void detect_v8_fused_x3_kernel(DetFuseX3Dev d) {
+    extern __shared__ __attribute__((aligned(16))) uint16_t wl[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lrow = lane & 15, kg = lane >> 4;
+    const int b = blockIdx.y;
+    int blk = blockIdx.x, lvl = 0;
+    for (; lvl < 2; ++lvl) {
+        const int nb = (d.hw[lvl] + 63) / 64;
+        if (blk < nb) break;
+        blk -= nb;
+    }
+    const int KTb = d.ktb, KTc = d.ktc, NTc = (d.nc + 15) >> 4;
+    uint16_t* wbox = wl;                                   // [4][KTb][2][512]
+    uint16_t* wcls = wl + (size_t)4 * KTb * 1024;          // [NTc][KTc][2][512]
+    float* bias = reinterpret_cast<float*>(wcls + (size_t)NTc * KTc * 1024);   // [64 + NTc * 16]
+    stage_lds16<256, 4>(wbox, d.wb[lvl], 4 * KTb * 128, tid);
+    stage_lds16<256, 8>(wcls, d.wc[lvl], NTc * KTc * 128, tid);
+    for (int i = tid; i < 64 + NTc * 16; i += 256) bias[i] = i < 64 ? d.bb[lvl][i] : (i - 64 < d.nc ? d.bc[lvl][i - 64] : 0.0f);
+    __syncthreads();
+
+    const int p = blk * 64 + wave * 16 + lrow;
+    const bool ok = p < d.hw[lvl];
+    const size_t pix = (size_t)b * d.hw[lvl] + (ok ? p : 0);
+    float* out = d.out + (size_t)b * (4 + d.nc) * d.A + d.a_off[lvl];
+    const du32x4 zero4 = du32x4{0u, 0u, 0u, 0u};
+
+    // ---- box branch: 64 DFL logits = 4 feature tiles (one per box side)
+    {
+        const unsigned char* ip = d.hb[lvl] + (pix * d.hb_cs[lvl] + d.hb_coff[lvl]) * 4 + kg * 32;   // this lane's 8-channel group of K step 0
+        df32x4 am[4], ac[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) am[t] = ac[t] = df32x4{0.f, 0.f, 0.f, 0.f};
+        for (int ks = 0; ks < KTb; ++ks) {
+            du32x4 xh = zero4, xl = zero4;
+            if (ok && ks * 32 + kg * 8 < d.cb) {
+                xh = *reinterpret_cast<const du32x4*>(ip + ks * 128);
+                xl = *reinterpret_cast<const du32x4*>(ip + ks * 128 + 16);
+            }
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const du32x4 wh = *reinterpret_cast<const du32x4*>(wbox + ((size_t)(t * KTb + ks) * 2 * 64 + lane) * 8);
+                const du32x4 wlo = *reinterpret_cast<const du32x4*>(wbox + ((size_t)((t * KTb + ks) * 2 + 1) * 64 + lane) * 8);
+                am[t] = Fp16::mfma(wh, xh, am[t]);
+                ac[t] = Fp16::mfma(wlo, xh, ac[t]);
+                ac[t] = Fp16::mfma(wh, xl, ac[t]);
+            }
+        }
+        float dist[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {  // DFL: softmax over the side's 16 bins (4 lanes x 4 registers), expectation with arange(16)
+            float v[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = am[t][r] + ac[t][r] * kX3Down + bias[t * 16 + kg * 4 + r];
+            float mx = fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3]));
+            mx = fmaxf(mx, detf_quad(mx, 16));
+            mx = fmaxf(mx, detf_quad(mx, 32));
+            float se = 0.f, sw = 0.f;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float e = expf(v[r] - mx);
+                se += e;
+                sw += e * (float)(kg * 4 + r);
+            }
+            se += detf_quad(se, 16); sw += detf_quad(sw, 16);
+            se += detf_quad(se, 32); sw += detf_quad(sw, 32);
+            dist[t] = sw / se;
+        }
+        if (ok) {
+            const float ax = (float)(p % d.w[lvl]) + 0.5f, ay = (float)(p / d.w[lvl]) + 0.5f;
+            const float x1 = ax - dist[0], y1 = ay - dist[1], x2 = ax + dist[2], y2 = ay + dist[3];
+            const float s = (float)d.stride[lvl];
+            const float comp = kg == 0 ? (x1 + x2) / 2 * s : kg == 1 ? (y1 + y2) / 2 * s : kg == 2 ? (x2 - x1) * s : (y2 - y1) * s;
+            out[(size_t)kg * d.A + p] = comp;
+        }
+    }
+    // ---- class branch: sigmoid(cv3.i.2), exact form
+    {
+        const unsigned char* ip = d.hc[lvl] + (pix * d.hc_cs[lvl] + d.hc_coff[lvl]) * 4 + kg * 32;
+        du32x4 xh[ADAS_DETF_MAXKS], xl[ADAS_DETF_MAXKS];
+#pragma unroll
+        for (int ks = 0; ks < ADAS_DETF_MAXKS; ++ks) {
+            xh[ks] = xl[ks] = zero4;
+            if (ks < KTc && ok && ks * 32 + kg * 8 < d.cc) {
+                xh[ks] = *reinterpret_cast<const du32x4*>(ip + ks * 128);
+                xl[ks] = *reinterpret_cast<const du32x4*>(ip + ks * 128 + 16);
+            }
+        }
+        float bv = 0.f;
+        int bi = -1;
+        for (int nt = 0; nt < NTc; ++nt) {
+            df32x4 am = df32x4{0.f, 0.f, 0.f, 0.f}, ac = am;
+#pragma unroll
+            for (int ks = 0; ks < ADAS_DETF_MAXKS; ++ks) {
+                if (ks < KTc) {
+                    const du32x4 wh = *reinterpret_cast<const du32x4*>(wcls + ((size_t)(nt * KTc + ks) * 2 * 64 + lane) * 8);
+                    const du32x4 wlo = *reinterpret_cast<const du32x4*>(wcls + ((size_t)((nt * KTc + ks) * 2 + 1) * 64 + lane) * 8);
+                    am = Fp16::mfma(wh, xh[ks], am);
+                    ac = Fp16::mfma(wlo, xh[ks], ac);
+                    ac = Fp16::mfma(wh, xl[ks], ac);
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int c = nt * 16 + kg * 4 + r;
+                if (c < d.nc) {
+                    const float v = 1.0f / (1.0f + expf(-(am[r] + ac[r] * kX3Down + bias[64 + c])));   // detect_v8_kernel's expression
+                    if (SINK) {
+                        if (bi < 0 || v > bv) {   // classes ascend within a lane: strict > keeps the first maximum
+                            bv = v;
+                            bi = c;
+                        }
+                    } else if (ok) {
+                        out[(size_t)(4 + c) * d.A + p] = v;
+                    }
+                }
+            }
+        }
+        if (SINK) {
+            // the four lanes of a pixel (kg = 0..3) hold interleaved class quads: larger value wins, equal values -> smaller class
+#pragma unroll
+            for (int m = 16; m <= 32; m <<= 1) {
+                const float ov = __shfl_xor(bv, m, 64);
+                const int oi = __shfl_xor(bi, m, 64);
+                if (oi >= 0 && (bi < 0 || ov > bv || (ov == bv && oi < bi))) {
+                    bv = ov;
+                    bi = oi;
+                }
+            }
+            if (ok && kg == 0) {
+                const size_t o = (size_t)b * d.A + d.a_off[lvl] + p;
+                d.sink_conf[o] = bv;
+                d.sink_cls[o] = bi < 0 ? 0 : bi;
+            }
+        }
+    }
+}
+
+// hidden[2l] / hidden[2l+1]: inputs of cv2.l.2 / cv3.l.2 (G8 views); wfrag / bias: their conv_pw_x3 packings and biases; kt_box / kt_cls: K steps of
+// the two packings (the layers' kpad / 32)
+hipError_t launch_detect_v8_fused_x3(const TView* hidden, const void* const* wfrag, const float* const* bias, int kt_box, int kt_cls, float* out, int n, int nc,
+                                     int A, const int strides[3], hipStream_t st_, float* sink_conf, int* sink_cls) {
+    DetFuseX3Dev d;
+    int off = 0, blocks = 0;
+    d.cb = hidden[0].c; d.cc = hidden[1].c; d.ktb = kt_box; d.ktc = kt_cls;
+    for (int l = 0; l < 3; ++l) {
+        const TView& hb = hidden[2 * l];
+        const TView& hc = hidden[2 * l + 1];
+        if (hb.f32 || hc.f32 || hb.c != d.cb || hc.c != d.cc || hb.h != hc.h || hb.w != hc.w) return hipErrorInvalidValue;
+        if (((hb.cs | hb.coff | hc.cs | hc.coff | hb.c | hc.c) & 7) != 0) return hipErrorInvalidValue;
+        d.hb[l] = (const unsigned char*)hb.p; d.hc[l] = (const unsigned char*)hc.p;
+        d.hb_cs[l] = hb.cs; d.hb_coff[l] = hb.coff; d.hc_cs[l] = hc.cs; d.hc_coff[l] = hc.coff;
+        d.wb[l] = (const uint16_t*)wfrag[2 * l]; d.wc[l] = (const uint16_t*)wfrag[2 * l + 1];
+        d.bb[l] = bias[2 * l]; d.bc[l] = bias[2 * l + 1];
+        d.hw[l] = hb.h * hb.w; d.w[l] = hb.w; d.stride[l] = strides[l]; d.a_off[l] = off;
+        off += d.hw[l];
+        blocks += (d.hw[l] + 63) / 64;
+    }
+    if (off != A || kt_cls > ADAS_DETF_MAXKS || kt_box * 32 < d.cb || kt_cls * 32 < d.cc) return hipErrorInvalidValue;
+    d.out = out; d.nc = nc; d.A = A; d.n = n;
+    d.sink_conf = sink_conf; d.sink_cls = sink_cls;
+    const int NTc = (nc + 15) / 16;
+    const size_t lds = ((size_t)4 * kt_box + (size_t)NTc * kt_cls) * 2048 + (64 + (size_t)NTc * 16) * 4;
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute((const void*)detect_v8_fused_x3_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+        (void)hipFuncSetAttribute((const void*)detect_v8_fused_x3_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+        attr_done = true;
+    }
+    if (lds > 150 * 1024) return hipErrorNotSupported;
+    if (sink_conf && sink_cls) hipLaunchKernelGGL(detect_v8_fused_x3_kernel<true>, dim3(blocks, n), dim3(256), lds, st_, d);
+    else hipLaunchKernelGGL(detect_v8_fused_x3_kernel<false>, dim3(blocks, n), dim3(256), lds, st_, d);
+    return hipGetLastError();
+}
+
 // ------------------------------------------------------------------------------------- Detect (v5)
 struct DetV5Dev {
     const float* in[3];

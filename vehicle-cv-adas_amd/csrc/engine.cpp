@@ -710,7 +710,7 @@ int adas_engine_create(const char* model_path, int precision, int max_batch, ada
     // ---- Detect fusion (aux_kernels.hip detect_v8_fused_kernel): the last 1x1 convs of both head branches feed only the decode
     {
         const char* env = getenv("ADAS_NO_DETECT_FUSE");
-        const bool enabled = prec_is16(precision) && !(env && env[0] == '1');
+        const bool enabled = (prec_is16(precision) || precision == PREC_X3) && !(env && env[0] == '1');   // split precision: detect_v8_fused_x3_kernel
         for (size_t di = 0; enabled && di < e->ops.size(); ++di) {
             EngOp& dop = e->ops[di];
             if (dop.f.type != OP_DETECT_V8 || dop.f.n_in != 6) continue;
@@ -742,7 +742,15 @@ int adas_engine_create(const char* model_path, int precision, int max_batch, ada
             if (ok) {  // the fused launch keeps both weight matrices in LDS: leave very wide heads / class counts to the separate kernels
                 const size_t ksb = (e->ops[src[0]].f.in_c[0] + 31) / 32, ksc = (e->ops[src[1]].f.in_c[0] + 31) / 32;
                 const size_t ntc = ((size_t)dop.f.params[0] + 15) / 16;
-                if (ksc > 12 || (4 * ksb + ntc * ksc) * 1024 + (64 + ntc * 16) * 4 > 150 * 1024) ok = false;
+                const size_t frag = precision == PREC_X3 ? 2048 : 1024;   // a 16x32 weight fragment: halves, or (hi, lo) half pairs
+                if (ksc > 12 || (4 * ksb + ntc * ksc) * frag + (64 + ntc * 16) * 4 > 150 * 1024) ok = false;
+                if (precision == PREC_X3)   // the fused kernel indexes conv_pw_x3's packing: [16-feature tile][kpad / 32]
+                    for (int k = 0; k < 6 && ok; ++k) {
+                        const EngOp& c = e->ops[src[k]];
+                        ok = c.kpad == e->ops[src[k % 2]].kpad && (size_t)c.kpad >= (k % 2 ? ksc : ksb) * 32 && (c.kpad & 31) == 0 &&
+                             (size_t)c.cout_pad >= (k % 2 ? ntc * 16 : 64);
+                    }
+                if (precision == PREC_X3 && ok && (size_t)e->ops[src[1]].kpad / 32 > 12) ok = false;
             }
             if (!ok) continue;
             for (int k = 0; k < 6; ++k) {
@@ -959,7 +967,7 @@ int adas_engine_layer_kernel(const adas_engine* e, int layer, int batch, char* n
         snprintf(name, cap, "%s%s%s", conv_kernel_name(a, e->prec, op.kernel), op.fuse_pool >= 0 ? "+pool" : "",
                  (op.ds_src >= 0 && ds_folded(e, layer, batch)) ? "+shortcut" : "");
     } else if (o.type == OP_DETECT_V8 && op.det_src[0] >= 0) {
-        snprintf(name, cap, "detect_v8_fused_kernel");
+        snprintf(name, cap, e->prec == PREC_X3 ? "detect_v8_fused_x3_kernel" : "detect_v8_fused_kernel");
     } else if (o.type == OP_DETECT_V5 && op.det_src[0] >= 0) {
         snprintf(name, cap, "detect_v5_fused_kernel");
     } else {
@@ -1112,7 +1120,11 @@ int engine_run_op(adas_engine* e, int i, const float* d_in, int batch, hipStream
                     wf[k] = wb + c.w_off;
                     bs[k] = (const float*)(wb + c.b_off);
                 }
-                err = launch_detect_v8_fused(ins, wf, bs, (float*)e->bufs[o.out_buf].d, batch, (int)o.params[0], (int)o.params[1], strides, e->prec, st, e->sink_conf, e->sink_cls);
+                if (e->prec == PREC_X3)
+                    err = launch_detect_v8_fused_x3(ins, wf, bs, e->ops[op.det_src[0]].kpad / 32, e->ops[op.det_src[1]].kpad / 32, (float*)e->bufs[o.out_buf].d, batch,
+                                                    (int)o.params[0], (int)o.params[1], strides, st, e->sink_conf, e->sink_cls);
+                else
+                    err = launch_detect_v8_fused(ins, wf, bs, (float*)e->bufs[o.out_buf].d, batch, (int)o.params[0], (int)o.params[1], strides, e->prec, st, e->sink_conf, e->sink_cls);
                 break;
             }
             for (int k = 0; k < 6; ++k) ins[k] = make_view(e, o.in_buf[k], o.in_coff[k], o.in_c[k]);

@@ -146,6 +146,9 @@ hipError_t launch_sppf_pool3(const TView& in, const TView out[3], int n, int pre
 hipError_t launch_detect_v8(const TView* ins, float* out, int n, int nc, int A, const int strides[3], hipStream_t st);
 hipError_t launch_detect_v8_fused(const TView* hidden, const void* const* wfrag, const float* const* bias, float* out, int n, int nc, int A,
                                   const int strides[3], int prec, hipStream_t st, float* sink_conf = nullptr, int* sink_cls = nullptr);
+// the same fusion in the split precision (conv_pw_x3's weight packing as it is; exact DFL / sigmoid); kt_box / kt_cls: the two packings' K steps
+hipError_t launch_detect_v8_fused_x3(const TView* hidden, const void* const* wfrag, const float* const* bias, int kt_box, int kt_cls, float* out, int n, int nc,
+                                     int A, const int strides[3], hipStream_t st_, float* sink_conf = nullptr, int* sink_cls = nullptr);
 // YOLOv5 Detect decode: ins = 3 fp32 maps [n][ny][nx][3*(5+nc)]; out fp32 [n][A][5+nc]; anchors[18] device
 bool det5_applicable(int prec, int nc, const TView& in, const TView& logits);
 size_t det5_weight_bytes(int no, int cin);
