@@ -429,11 +429,15 @@ __global__ __launch_bounds__(S2_THR, 1) void conv_s2p_x3_kernel(S2XDev a) {
     }
 
     su32x4_ ra[S2_NA], rw[S2_NW];
-    auto gload = [&](int ck) {
+    // Weights travel with the H half-chunks only (round 6, as conv_halo8_x3's SH form): an L half-chunk multiplies a_lo by w_hi, the MAIN
+    // rows of the H slab already in LDS -- the L slabs of the packing (the same w_hi again) are not read, 73.7 of every 313 KB a
+    // 32-channel chunk used to pull through L2 and the LDS write port.
+    auto gload = [&](int ck, auto with_w) {
         // half-chunk ck: the hi pieces of channels 32 (ck >> 1) .., or (odd) their lo pieces 16 bytes on; a chunk is 128 bytes of a pixel
         const uint32_t cofs = (uint32_t)((ck >> 1) * 128 + (ck & 1) * 16);
 #pragma unroll
         for (int i = 0; i < S2_NA; ++i) ra[i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, goff[i] + cofs, 0, 0);
+        if constexpr (!decltype(with_w)::value) return;
 #pragma unroll
         for (int i = 0; i < S2_NW; ++i) {
             const int e = tid + S2_THR * i;   // only i = 4 straddles the two slabs
@@ -442,12 +446,13 @@ __global__ __launch_bounds__(S2_THR, 1) void conv_s2p_x3_kernel(S2XDev a) {
         }
     };
     const int na = (a.npix4 + S2_THR - 1) / S2_THR;   // workgroup-uniform
-    auto lstore = [&]() {
+    auto lstore = [&](auto with_w) {
 #pragma unroll
         for (int i = 0; i < S2_NA; ++i) {
             const int e = tid + S2_THR * i;
             if (i < na && e < a.npix4) *reinterpret_cast<su32x4_*>(Aw + (e >> 2) * 32 + (((e & 3) ^ ((e >> 3) & 2)) << 3)) = ra[i];
         }
+        if constexpr (!decltype(with_w)::value) return;
 #pragma unroll
         for (int i = 0; i < S2_NW; ++i) *reinterpret_cast<su32x4_*>(Ww + wdst0 + i * S2_THR * 8) = rw[i];
     };
@@ -459,7 +464,7 @@ __global__ __launch_bounds__(S2_THR, 1) void conv_s2p_x3_kernel(S2XDev a) {
             const int tofs = ((r & 1) * 2 + (s & 1)) * a.plane + (r >> 1) * a.PW + (s >> 1);
             vec8 wf[4], xf[TM];
 #pragma unroll
-            for (int i = I0; i < 4; ++i) wf[i] = *reinterpret_cast<const vec8*>(Ww + (tap * 64 + i * 16) * 32 + wrd);
+            for (int i = I0; i < 4; ++i) wf[i] = *reinterpret_cast<const vec8*>(Ww + (tap * 64 + (i - I0) * 16) * 32 + wrd);   // (L: the H slab's MAIN rows)
 #pragma unroll
             for (int j = 0; j < TM; ++j) {
                 const int pw = apl[j] + tofs;
@@ -472,20 +477,20 @@ __global__ __launch_bounds__(S2_THR, 1) void conv_s2p_x3_kernel(S2XDev a) {
         }
     };
 
-    gload(0);
-    lstore();
+    gload(0, std::true_type{});
+    lstore(std::true_type{});
     __syncthreads();
     for (int ck = 0; ck < a.nck; ck += 2) {      // one 32-channel chunk per trip: its H half-chunk, then its L half-chunk
-        gload(ck + 1);
+        gload(ck + 1, std::false_type{});
         taps(std::false_type{});
         __syncthreads();
-        lstore();
+        lstore(std::false_type{});
         __syncthreads();
-        if (ck + 2 < a.nck) gload(ck + 2);
+        if (ck + 2 < a.nck) gload(ck + 2, std::true_type{});
         taps(std::true_type{});
         if (ck + 2 < a.nck) {
             __syncthreads();
-            lstore();
+            lstore(std::true_type{});
             __syncthreads();
         }
     }

@@ -209,6 +209,18 @@ constexpr int SP3_WH = 2 * (SP3_CTH - 1) + 7, SP3_CP = 68;                      
 constexpr int SP3_WFR = 4 * 7 * 512;
 constexpr int SP3_LDS = 2 * SP3_WFR * 2 + (SP3_NPIX * SP3_CP * 4 > 2 * SP3_WH * SX3_WW * 8 ? SP3_NPIX * SP3_CP * 4 : 2 * SP3_WH * SX3_WW * 8);
 
+#ifdef ADAS_SP3_PROF   // scratch instrumentation (tools/experiments/stem_pool_prof.py): shader cycles of waves 0 and 3 per tile phase
+__device__ unsigned long long g_sp3_prof[256][32];
+#define SP3P(i)                                     \
+    if (lane == 0 && (wave == 0 || wave == 3)) {    \
+        const unsigned long long t__ = clock64();   \
+        pacc__[i] += t__ - tprev__;                 \
+        tprev__ = t__;                              \
+    }
+#else
+#define SP3P(i)
+#endif
+
 __global__ __launch_bounds__(512, 1) void conv_stem_pool_x3_kernel(StemPoolX3Dev a) {
     Fp16::enter();
     constexpr int KH = 7, NT = 4, WW = SX3_WW, WH = SP3_WH, CTW = SP3_CTW, NPIX = SP3_NPIX, CP = SP3_CP;
@@ -237,6 +249,19 @@ __global__ __launch_bounds__(512, 1) void conv_stem_pool_x3_kernel(StemPoolX3Dev
     const int per_img = a.tiles_x * a.tiles_y;
     const int plane = a.H * a.W;
 
+    // window slot of this thread in pass i: (row, column) inside the window -- the same for every tile (round 6: computed once; the
+    // per-tile part of an address is two adds, two range checks and a select, no divergent control flow -- the compiler had turned the
+    // nested conditions into exec-masked branches with a vmcnt wait between them, 2,200 cycles per tile in the phase profile)
+    int wyq[NQ], wxq[NQ];
+#pragma unroll
+    for (int i = 0; i < NQ; ++i) {
+        const int q = tid + 512 * i;
+        wyq[i] = q < WH * WW ? q / WW : -(1 << 20);    // (a slot past the window: a row that is never inside the image)
+        wxq[i] = q - (q / WW) * WW;
+    }
+    uint32_t cplane[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) cplane[c] = c < a.C ? (uint32_t)(c * plane * 4) : 0x80000000u;
     uint32_t px[NQ][3];
     auto fetch = [&](int tile) {
         const bool live = tile < a.ntiles;
@@ -245,25 +270,28 @@ __global__ __launch_bounds__(512, 1) void conv_stem_pool_x3_kernel(StemPoolX3Dev
         const int t2 = tl - img * per_img;
         const int ty = t2 / a.tiles_x, tx = t2 - ty * a.tiles_x;
         const int cy0 = 2 * (ty * 4) - 1, cx0 = 2 * (tx * 16) - 1;
-        const int iy0 = 2 * cy0 - a.pad, ix0 = 2 * cx0 - a.pad;
+        const int iy0 = live ? 2 * cy0 - a.pad : -(1 << 20), ix0 = 2 * cx0 - a.pad;
         const void* in_img = (const void*)(a.in + (size_t)img * a.C * plane);
         __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)in_img, 0, a.C * plane * 4, 0x00020000);
 #pragma unroll
         for (int i = 0; i < NQ; ++i) {
-            const int q = tid + 512 * i;
-            const int wy = q / WW, wx = q - wy * WW;
-            const int iy = iy0 + wy, ix = ix0 + wx;
-            const bool ok = live && q < WH * WW && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
-            const uint32_t off = (uint32_t)((iy * a.W + ix) * 4);
+            const int iy = iy0 + wyq[i], ix = ix0 + wxq[i];
+            const uint32_t inside = (uint32_t)(((unsigned)iy < (unsigned)a.H) & ((unsigned)ix < (unsigned)a.W));
+            const uint32_t off = ((uint32_t)((iy * a.W + ix) * 4) & 0x7FFFFFFFu) | ((inside ^ 1u) << 31);   // outside: past num_records -> reads 0
 #pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                const uint32_t oc = (ok && c < a.C) ? off + (uint32_t)(c * plane * 4) : 0x80000000u;
-                px[i][c] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rsrc, oc, 0, 0);
-            }
+            for (int c = 0; c < 3; ++c) px[i][c] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rsrc, (off + cplane[c]) | (cplane[c] & 0x80000000u) | (off & 0x80000000u), 0, 0);
         }
     };
 
+    float4 bias4[NT];    // (once per workgroup: fetched per tile they sat, with their latency, between the MFMAs and the conv tile's stores)
+#pragma unroll
+    for (int i = 0; i < NT; ++i) bias4[i] = *reinterpret_cast<const float4*>(a.bias + i * 16 + kg * 4);
     const int gstride = gridDim.x;
+#ifdef ADAS_SP3_PROF
+    unsigned long long tprev__ = clock64();
+    unsigned long long pacc__[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    int nit__ = 0;
+#endif
     auto step = [&](const int tile) {
         const int img = tile / per_img;
         const int t2 = tile - img * per_img;
@@ -271,6 +299,7 @@ __global__ __launch_bounds__(512, 1) void conv_stem_pool_x3_kernel(StemPoolX3Dev
         const int cy0 = 2 * (ty * 4) - 1, cx0 = 2 * (tx * 16) - 1;
 
         __syncthreads();  // the previous tile's pool is done reading the shared region
+        SP3P(0)
 #pragma unroll
         for (int i = 0; i < NQ; ++i) {
             const int q = tid + 512 * i;
@@ -288,7 +317,11 @@ __global__ __launch_bounds__(512, 1) void conv_stem_pool_x3_kernel(StemPoolX3Dev
             }
         }
         __syncthreads();
+        SP3P(1)
+        // (measured and dropped, round 6: the two waves of a SIMD issuing these loads at opposite ends of the MFMA phase -- the loads then
+        // issue at half speed beside the partner's MFMAs, +7 % per tile: tools/experiments/stem_pool_prof.py)
         fetch(tile + gstride);
+        SP3P(2)
 
         zf32x4 accm[3][NT], accx[3][NT];
 #pragma unroll
@@ -326,11 +359,10 @@ __global__ __launch_bounds__(512, 1) void conv_stem_pool_x3_kernel(StemPoolX3Dev
         };
         if (three) mma(std::integral_constant<int, 3>{});
         else mma(std::integral_constant<int, 2>{});
+        SP3P(3)
 
-        float4 bias4[NT];
-#pragma unroll
-        for (int i = 0; i < NT; ++i) bias4[i] = *reinterpret_cast<const float4*>(a.bias + i * 16 + kg * 4);
         __syncthreads();  // every wave is done reading the windows: the conv tile may overwrite them
+        SP3P(4)
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
             const int p = (wave + 8 * j) * 16 + lrow;
@@ -349,6 +381,7 @@ __global__ __launch_bounds__(512, 1) void conv_stem_pool_x3_kernel(StemPoolX3Dev
             }
         }
         __syncthreads();
+        SP3P(5)
         {   // pool: thread = (pooled pixel, 8-channel group): 64 x 8 = 512
             const int pp = tid >> 3, cg = tid & 7;
             const int py = pp >> 4, pxx = pp & 15;
@@ -373,8 +406,35 @@ __global__ __launch_bounds__(512, 1) void conv_stem_pool_x3_kernel(StemPoolX3Dev
     int tile = blockIdx.x;
     if (tile >= a.ntiles) return;
     fetch(tile);
+#ifdef ADAS_SP3_PROF
+    for (; tile < a.ntiles; tile += gstride) { step(tile); SP3P(6) ++nit__; }
+    if (lane == 0 && (wave == 0 || wave == 3)) {
+        unsigned long long* b__ = g_sp3_prof[blockIdx.x & 255] + (wave ? 16 : 0);
+        for (int i__ = 0; i__ < 7; ++i__) atomicAdd(&b__[i__], pacc__[i__]);
+        atomicAdd(&b__[7], (unsigned long long)nit__);
+    }
+#else
     for (; tile < a.ntiles; tile += gstride) step(tile);
+#endif
 }
+
+#ifdef ADAS_SP3_PROF
+extern "C" int adas_debug_sp3_prof(unsigned long long* out32, int reset) {
+    static unsigned long long h[256][32];
+    if (out32) {
+        if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_sp3_prof), sizeof(h)) != hipSuccess) return -1;
+        for (int i = 0; i < 32; ++i) {
+            out32[i] = 0;
+            for (int b = 0; b < 256; ++b) out32[i] += h[b][i];
+        }
+    }
+    if (reset) {
+        memset(h, 0, sizeof(h));
+        if (hipMemcpyToSymbol(HIP_SYMBOL(g_sp3_prof), h, sizeof(h)) != hipSuccess) return -1;
+    }
+    return 0;
+}
+#endif
 
 bool stem_pool_x3_applicable(int in_c_true, int kh, int kw, int stride, int pad, int act, int res_mode, const TView& conv_out, const TView& pool_out) {
     if (in_c_true > 3 || stride != 2 || res_mode != RES_NONE || kh != 7 || kw != 7 || pad > 3 || act != ACT_RELU) return false;
