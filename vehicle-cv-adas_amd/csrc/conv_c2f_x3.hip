@@ -9,7 +9,7 @@
 // channels of one pixel; the 16-channel 3x3 convs take two taps per 32-deep K step), with both halves of every operand:
 //   * every tensor between the stages lives in LDS as a hi plane and a lo plane (elem16.h x3_split: hi = half(v), lo = half((v - hi) 2^11)),
 //   * every product is three MFMAs into two accumulators (main += w_hi a_hi; cross += w_lo a_hi + w_hi a_lo; value = main + 2^-11 cross),
-//   * SiLU in its exact form (expf, IEEE division: the parity modes' rule, conv_x3.hip x3_act).
+//   * SiLU in the split precision's fp32-class form (elem16.h x3_silu).
 // One persistent 8-wave workgroup per CU (126 KB of LDS: the planes + all four weight sets as hi / lo fragment arrays); the next tile's
 // window is fetched into registers under the current tile's stages.
 #include "kernels.h"
@@ -47,7 +47,7 @@ constexpr int CX_OFF_Y1 = 2 * CX_XW, CX_OFF_Y0 = CX_OFF_Y1 + 2 * CX_Y1, CX_OFF_W
 constexpr int CX_LDS = CX_OFF_W + CX_WBYTES;   // 125,952
 static_assert(2 * CX_IN + 2 * CX_Y0 <= 2 * CX_XW, "conv A's output and y2 fit in the x window's region");
 
-__device__ __forceinline__ float cx_silu(float v) { return v / (1.0f + expf(-v)); }   // the parity modes' exact form
+__device__ __forceinline__ float cx_silu(float v) { return x3_silu(v); }   // (elem16.h: fp32-class, 12 instructions)
 __device__ __forceinline__ int cx_pos32(int p, int c) { return c ^ (((p >> 2) & 1) << 1); }
 // four values -> their hi words and lo words (two packed halves each)
 __device__ __forceinline__ void cx_split4(const float v[4], uint2& h, uint2& l) {

@@ -352,8 +352,8 @@ struct S2XDev {
 };
 
 template <int ACT>
-__device__ __forceinline__ float s2x_act(float v) {   // the parity modes use the exact forms (conv_x3.hip x3_act)
-    if (ACT == ACT_SILU) return v / (1.0f + expf(-v));
+__device__ __forceinline__ float s2x_act(float v) {
+    if (ACT == ACT_SILU) return x3_silu(v);   // (elem16.h: fp32-class, 12 instructions)
     if (ACT == ACT_RELU) return fmaxf(v, 0.0f);
     if (ACT == ACT_LEAKY) return fmaxf(v, 0.1f * v);
     return v;

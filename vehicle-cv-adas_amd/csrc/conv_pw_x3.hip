@@ -11,7 +11,7 @@
 //     ([tile][step][hi | lo][64 lanes][8 halves]); pointwise: resident in LDS per workgroup; Linear: streamed from HBM
 //     through a U-deep register ring;
 //   * three MFMAs per (tile, step): main += w_hi a_hi, cross += w_lo a_hi, cross += w_hi a_lo;
-//     epilogue (main + 2^-11 cross) + bias -> activation (exact forms) -> split -> G8 store (8 B hi + 8 B lo per lane) or fp32.
+//     epilogue (main + 2^-11 cross) + bias -> activation (fp32-class forms: elem16.h x3_silu) -> split -> G8 store (8 B hi + 8 B lo per lane) or fp32.
 // Same sums in the same K order as conv_x3.hip.
 #include "kernels.h"
 #include "elem16.h"
@@ -23,7 +23,7 @@ typedef __attribute__((ext_vector_type(4))) float wf32x4;
 typedef __attribute__((ext_vector_type(4))) uint32_t wu32x4;
 
 __device__ __forceinline__ float pwx_act(float v, int act) {
-    if (act == ACT_SILU) return v / (1.0f + expf(-v));   // the parity modes use the exact forms (conv_x3.hip x3_act)
+    if (act == ACT_SILU) return x3_silu(v);   // (elem16.h: fp32-class, 12 instructions)
     if (act == ACT_RELU) return fmaxf(v, 0.0f);
     if (act == ACT_LEAKY) return fmaxf(v, 0.1f * v);
     return v;

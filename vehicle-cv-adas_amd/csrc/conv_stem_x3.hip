@@ -39,7 +39,7 @@ __host__ __device__ constexpr int sx3_lds_bytes(int kh, int nt) {
 
 template <int ACT>
 __device__ __forceinline__ float sx3_act(float v) {
-    if (ACT == ACT_SILU) return v / (1.0f + expf(-v));
+    if (ACT == ACT_SILU) return x3_silu(v);
     if (ACT == ACT_RELU) return fmaxf(v, 0.0f);
     if (ACT == ACT_LEAKY) return fmaxf(v, 0.1f * v);
     return v;
@@ -464,7 +464,7 @@ hipError_t launch_conv_stem_pool_x3(const float* nchw, int n, int c_true, int H,
 
 // ---- the YOLO stems with the 3x3 s2 p1 conv behind them (model.1: 16 -> 32 channels) in one launch, split precision: conv_stem.hip's
 // CONV2 scheme with both halves of every operand.  The 17 x 33 stem pixels an 8 x 16 tile of the second conv needs (incl. its padding
-// ring: stem pixels outside the stem's output are ZERO) stay in LDS as a hi plane and a lo plane (split after the exact SiLU); the second
+// ring: stem pixels outside the stem's output are ZERO) stay in LDS as a hi plane and a lo plane (split after the SiLU); the second
 // conv runs from there -- K step = two taps x 16 channels, three MFMAs per step and 16-channel output tile -- and only its 32-channel
 // output reaches HBM: the stem's 16-channel tensor (6.5 MB per 640^2 frame in the split storage, written by one launch and read back
 // by the generic split kernel: 0.29 + 0.23 ms per 64 frames) never exists.  8 waves, one persistent workgroup per CU.

@@ -37,7 +37,7 @@ struct X3Dev {
 #define ADAS_X3_MAX_Q 1152   // K / 8 chunks (conv_kernels.hip ADAS_MAX_Q)
 
 __device__ __forceinline__ float x3_act(float v, int act) {
-    if (act == ACT_SILU) return v / (1.0f + expf(-v));
+    if (act == ACT_SILU) return x3_silu(v);
     if (act == ACT_RELU) return fmaxf(v, 0.0f);
     if (act == ACT_LEAKY) return fmaxf(v, 0.1f * v);
     return v;

@@ -86,7 +86,7 @@ struct Fp16 {
 // CORRECTLY ROUNDED reciprocal, which hipcc expands into the IEEE division sequence (2 x v_div_scale, v_rcp, five fma / mul, v_div_fmas,
 // v_div_fixup: 11 VALU instructions where one does) -- in every SiLU of every 16-bit conv kernel: the 59-98 VALU instructions per MFMA of
 // the pointwise kernels (profiles/r04/pmc_halo_40x40.txt) and a third of conv_halo's tile time were mostly this.  The parity modes (fp32,
-// fp16x3) keep the exact forms (conv_x3.hip x3_act).
+// fp16x3) keep fp32-class forms: expf and the IEEE division in the fp32 mode, x3_silu below (the same error class in 12 instructions) in fp16x3.
 __device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
 // SiLU for kernels templated on a storage type: the fast form where the result is stored in 16 bits, the exact form (expf, IEEE division) in
 // the parity modes (float, x3s slots)
@@ -120,6 +120,28 @@ __host__ __device__ __forceinline__ void x3_split(float x, _Float16& h, _Float16
 __host__ __device__ __forceinline__ float x3_join(_Float16 h, _Float16 l) { return (float)h + (float)l * kX3Down; }
 
 #if defined(__HIPCC__)
+// SiLU of the split precision (round 6).  v / (1 + expf(-v)) as hipcc compiles it is 27 VALU instructions per value (ocml's expf with its
+// range selects, then the IEEE division sequence: div_scale x2, rcp, five fma, div_fmas, div_fixup) -- 7,000 cycles per SIMD in the
+// epilogue of every conv_h8x3 item of the detector, half the time of the fused C2f / stem launches.  The same quantity in 12:
+//   e^x = exp2(t) (1 + r ln 2),  t = fl(x log2 e),  r = the product's rounding error (one fma) + x (log2 e - fl(log2 e)),
+//   1 / d = v_rcp_f32 refined by one Newton step,
+// x = min(-v, 88) so that e^x stays finite (v < -88: the result is -0 instead of -5e-37).  Against float64 over 3.5 M values (N(0, 3),
+// U(-90, 90), N(0, 0.1)) with 1-ulp exp2 / rcp: max relative error 3.2e-7, mean 4.8e-8 -- NumPy's float32 evaluation of the
+// reference expression (oracle/nets.py): 2.4e-7 / 3.4e-8.  -DADAS_X3_SILU_EXACT restores the 27-instruction form.
+__device__ __forceinline__ float x3_silu(float v) {
+#ifdef ADAS_X3_SILU_EXACT
+    return v / (1.0f + expf(-v));
+#else
+    const float x = fminf(-v, 88.0f);
+    const float t = x * 1.44269502162933349609375f;
+    const float r = __builtin_fmaf(x, 1.44269502162933349609375f, -t) + x * 1.925963033500011e-08f;
+    const float e = __builtin_amdgcn_exp2f(t);
+    const float d = 1.0f + __builtin_fmaf(e * r, 0.693147180559945f, e);
+    float q = __builtin_amdgcn_rcpf(d);
+    q = __builtin_fmaf(__builtin_fmaf(-d, q, 1.0f), q, q);
+    return v * q;
+#endif
+}
 // one slot (any channel): the group's base is the address rounded down to 32 bytes
 __device__ __forceinline__ float x3_ld(const x3s* p) {
     const uintptr_t a = reinterpret_cast<uintptr_t>(p);

@@ -102,7 +102,7 @@ hipError_t launch_conv_pair(const TView& x, const TView& y, const void* w1, cons
 bool c2f16_applicable(int prec, const TView& x, const TView& cat01, const TView& y1, const TView& y2, const TView& cat, const TView& out);
 hipError_t launch_pack_weights_c2f_pw(const float* src, void* dst, int cout, int cin, int prec, hipStream_t st);   // 1x1 weights as MFMA fragments
 size_t c2f_pw_weight_bytes(int cout, int cin);
-// conv_c2f_x3.hip: the same block in the split precision (hi / lo planes in LDS, three MFMAs per product, exact SiLU); its Bottleneck pair is
+// conv_c2f_x3.hip: the same block in the split precision (hi / lo planes in LDS, three MFMAs per product, x3_silu); its Bottleneck pair is
 // recognised by the pair pass (pair_x3_candidate) and released again if the C2f pass does not absorb it -- no stand-alone x3 pair kernel exists
 bool pair_x3_candidate(int prec, int kh, int kw, int stride, int pad, int act, int res_mode, const TView& x, const TView& t, int kh2, int kw2, int stride2,
                        int pad2, int act2, int res_mode2, const TView& y);
