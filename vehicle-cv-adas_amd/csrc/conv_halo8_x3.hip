@@ -70,6 +70,35 @@ __device__ __forceinline__ float x8_act(float v) {
     return v;
 }
 
+// ---- the epilogue's arithmetic two values at a time (round 6; ADAS_H8X_SCALAR_EPI builds keep the one-value form).  An item's epilogue was
+// ~16 VALU instructions per output value, 32 values per lane, two waves per SIMD: ~4,000 cycles in which no MFMA issues.  gfx950 has
+// v_pk_fma_f32 / v_pk_add_f32 / v_pk_mul_f32 and v_cvt_pk_f16_f32: join, residual add and split take 12 instructions per four values
+// instead of 28 + 12.  x3_split's "no subnormal hi" rule costs a compare and a select per value in the scalar form; here the hi
+// conversions of a whole item run with MODE.FP_DENORM[7:6] = 0 (16-bit results flushed: a hi below the half normal range becomes 0
+// and the value moves into lo, the same rule) between two s_setreg -- the conversions are volatile asm so that they stay between them.
+typedef __attribute__((ext_vector_type(2))) float yf32x2;
+template <int ACT>
+__device__ __forceinline__ yf32x2 x8_act2(yf32x2 v) {
+    if (ACT == ACT_RELU) return __builtin_elementwise_max(v, yf32x2{0.0f, 0.0f});
+    return yf32x2{x8_act<ACT>(v[0]), x8_act<ACT>(v[1])};
+}
+__device__ __forceinline__ yf32x2 x8_join2(uint32_t h, uint32_t l) {   // two (hi, lo) pairs -> their values
+    return __builtin_convertvector(__builtin_bit_cast(e_f16x2, l), yf32x2) * kX3Down + __builtin_convertvector(__builtin_bit_cast(e_f16x2, h), yf32x2);
+}
+__device__ __forceinline__ void x8_hi_mode(bool flush) {   // MODE[7:6] (FP_DENORM of 16- and 64-bit results): 0 = flush, 3 = the launch default
+    if (flush) __builtin_amdgcn_s_setreg((unsigned short)(1 | (6 << 6) | (1 << 11)), 0u);
+    else __builtin_amdgcn_s_setreg((unsigned short)(1 | (6 << 6) | (1 << 11)), 3u);
+}
+__device__ __forceinline__ uint32_t x8_cvt_hi2(yf32x2 v) {
+    uint32_t h;
+    asm volatile("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(h) : "v"(v[0]), "v"(v[1]));
+    return h;
+}
+__device__ __forceinline__ uint32_t x8_lo2(yf32x2 v, uint32_t h) {   // the lo halves of two values given their hi halves
+    const yf32x2 d = (v - __builtin_convertvector(__builtin_bit_cast(e_f16x2, h), yf32x2)) * kX3Up;
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(d, e_f16x2));
+}
+
 __host__ __device__ constexpr int x8_issued(int k) { return 1 + ((k >= 1 && k <= X8_NWP) ? 1 : 0); }
 __host__ __device__ constexpr int x8_allow(int mode, int k) {
     return mode == 2 ? x8_issued(k) + x8_issued(k - 1) + x8_issued(k - 2)
@@ -402,6 +431,56 @@ __global__ __launch_bounds__(X8_THR, 1) void conv_h8x3_kernel(H8XDev a) {
         // ---------------- epilogue: lane holds channels kg*4..+3 of pixel lrow of every (i, j) tile
         __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
         H8XP(4)
+#if !defined(ADAS_H8X_SCALAR_EPI) && !defined(ADAS_H8X_NARROW_ST)
+        auto write_out = [&](auto rm_c) {
+            constexpr int RM = decltype(rm_c)::value;
+            yf32x2 val[4][2][2];   // [pixel tile][channel tile][value pair]: the activated outputs
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    yf32x2 v0 = yf32x2{acc[i + 2][j][0], acc[i + 2][j][1]} * kX3Down + yf32x2{acc[i][j][0], acc[i][j][1]};
+                    yf32x2 v1 = yf32x2{acc[i + 2][j][2], acc[i + 2][j][3]} * kX3Down + yf32x2{acc[i][j][2], acc[i][j][3]};
+                    if (RM != RES_NONE) {
+                        // the swap that forms the 16-byte pieces is its own inverse: it hands each lane its own hi and lo words back
+                        const auto q0 = __builtin_amdgcn_permlane16_swap(rraw[j][i].x, rraw[j][i].z, false, false);
+                        const auto q1 = __builtin_amdgcn_permlane16_swap(rraw[j][i].y, rraw[j][i].w, false, false);
+                        const yf32x2 r0 = x8_join2(q0[0], q0[1]), r1 = x8_join2(q1[0], q1[1]);
+                        if (RM == RES_BEFORE_ACT) { v0 = x8_act2<ACT>(v0 + r0); v1 = x8_act2<ACT>(v1 + r1); }
+                        else { v0 = x8_act2<ACT>(v0) + r0; v1 = x8_act2<ACT>(v1) + r1; }
+                    } else {
+                        v0 = x8_act2<ACT>(v0); v1 = x8_act2<ACT>(v1);
+                    }
+                    val[j][i][0] = v0; val[j][i][1] = v1;
+                    acc[i][j] = yf32x4{biasn[i].x, biasn[i].y, biasn[i].z, biasn[i].w};
+                    acc[i + 2][j] = yf32x4{0.f, 0.f, 0.f, 0.f};
+                }
+            uint32_t hw[4][2][2];
+            x8_hi_mode(true);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    hw[j][i][0] = x8_cvt_hi2(val[j][i][0]);
+                    hw[j][i][1] = x8_cvt_hi2(val[j][i][1]);
+                }
+            x8_hi_mode(false);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const uint32_t oo = po[j] == X8_OOB ? X8_OOB : (po[j] * (uint32_t)a.out_cs + (uint32_t)a.out_coff) * 4u + ch0;
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    // channels past cout (the padded tail of the last 64-channel block) are computed on zero weights and not stored
+                    const uint32_t oi = (cb * 64 + hb * 32 + i * 16 + (kg >> 1) * 8 < a.cout) ? oo + i * 64 : X8_OOB;   // (cout is a multiple of 8)
+                    const uint32_t l0 = x8_lo2(val[j][i][0], hw[j][i][0]), l1 = x8_lo2(val[j][i][1], hw[j][i][1]);
+                    // even rows end up with {own hi, partner's hi} = the group's 16 hi bytes, odd rows with {partner's lo, own lo}
+                    const auto s0 = __builtin_amdgcn_permlane16_swap(hw[j][i][0], l0, false, false);
+                    const auto s1 = __builtin_amdgcn_permlane16_swap(hw[j][i][1], l1, false, false);
+                    __builtin_amdgcn_raw_buffer_store_b128(yu32x4{s0[0], s1[0], s0[1], s1[1]}, rout, oi, 0, 0);
+                }
+            }
+        };
+#else
         auto write_out = [&](auto rm_c) {
             constexpr int RM = decltype(rm_c)::value;
 #pragma unroll
@@ -460,6 +539,7 @@ __global__ __launch_bounds__(X8_THR, 1) void conv_h8x3_kernel(H8XDev a) {
                 }
             }
         };
+#endif
         if (a.res_mode == RES_NONE) write_out(std::integral_constant<int, RES_NONE>{});
         else if (a.res_mode == RES_BEFORE_ACT) write_out(std::integral_constant<int, RES_BEFORE_ACT>{});
         else write_out(std::integral_constant<int, RES_AFTER_ACT>{});
