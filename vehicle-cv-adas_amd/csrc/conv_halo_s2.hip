@@ -359,6 +359,18 @@ __device__ __forceinline__ float s2x_act(float v) {
     return v;
 }
 
+#ifdef ADAS_S2X_PROF   // scratch instrumentation (tools/experiments/s2x_prof.py): shader cycles of thread 0 per workgroup phase
+__device__ unsigned long long g_s2x_prof[16];
+#define S2XP(i)                                     \
+    if (tid == 0) {                                 \
+        const unsigned long long t__ = clock64();   \
+        pacc__[i] += t__ - tprev__;                 \
+        tprev__ = t__;                              \
+    }
+#else
+#define S2XP(i)
+#endif
+
 template <int ACT>
 __global__ __launch_bounds__(S2_THR, 1) void conv_s2p_x3_kernel(S2XDev a) {
     Fp16::enter();
@@ -371,6 +383,10 @@ __global__ __launch_bounds__(S2_THR, 1) void conv_s2p_x3_kernel(S2XDev a) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lrow = lane & 15, kg = lane >> 4;
     const int half = wave >> 2, grp = wave & 3;
+#ifdef ADAS_S2X_PROF
+    unsigned long long tprev__ = clock64();
+    unsigned long long pacc__[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
     const int xslot = blockIdx.x >> 3;
     const int xr = xslot / a.ncb;
     const int cb = xslot - xr * a.ncb;
@@ -477,21 +493,32 @@ __global__ __launch_bounds__(S2_THR, 1) void conv_s2p_x3_kernel(S2XDev a) {
         }
     };
 
+    // (measured and dropped, round 6: a persistent form -- 256 workgroups walking the block list, the next item's first half-chunk fetched
+    // under the last nine taps -- hides the prologue the phase profile shows exposed (23 % of a 64 -> 128 channel layer), but the item loop
+    // pushes the kernel from 256 VGPRs with 8 spills to 20-140 spilled registers whose scratch traffic shares vmcnt with the prefetch:
+    // -1.8 % end to end at best.  tools/experiments/s2x_prof.py, profiles/r06/s2p_x3_phases.txt.)
+    S2XP(0)
     gload(0, std::true_type{});
     lstore(std::true_type{});
     __syncthreads();
+    S2XP(1)
     for (int ck = 0; ck < a.nck; ck += 2) {      // one 32-channel chunk per trip: its H half-chunk, then its L half-chunk
         gload(ck + 1, std::false_type{});
         taps(std::false_type{});
+        S2XP(2)
         __syncthreads();
+        S2XP(3)
         lstore(std::false_type{});
         __syncthreads();
+        S2XP(4)
         if (ck + 2 < a.nck) gload(ck + 2, std::true_type{});
         taps(std::true_type{});
+        S2XP(5)
         if (ck + 2 < a.nck) {
             __syncthreads();
             lstore(std::true_type{});
             __syncthreads();
+            S2XP(6)
         }
     }
 
@@ -509,7 +536,26 @@ __global__ __launch_bounds__(S2_THR, 1) void conv_s2p_x3_kernel(S2XDev a) {
             if (pok && c < a.cout) x3_store4(a.out + mpix * a.out_cs + a.out_coff + c, v);   // (channels past cout: zero weight rows, not stored)
         }
     }
+#ifdef ADAS_S2X_PROF
+    S2XP(7)
+    if (tid == 0) {
+        for (int i__ = 0; i__ < 8; ++i__) atomicAdd(&g_s2x_prof[i__], pacc__[i__]);
+        atomicAdd(&g_s2x_prof[8], 1ull);
+    }
+#endif
 }
+
+#ifdef ADAS_S2X_PROF
+extern "C" int adas_debug_s2x_prof(unsigned long long* out16, int reset) {
+    static unsigned long long h[16];
+    if (out16 && hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_s2x_prof), sizeof(h)) != hipSuccess) return -1;
+    if (reset) {
+        for (int i = 0; i < 16; ++i) h[i] = 0;
+        if (hipMemcpyToSymbol(HIP_SYMBOL(g_s2x_prof), h, sizeof(h)) != hipSuccess) return -1;
+    }
+    return 0;
+}
+#endif
 
 static bool s2x_enabled() {
     static int v = -1;
