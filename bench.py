@@ -344,10 +344,10 @@ def measure_traffic_pmc(dom_label, args):
     acts = {"RELU": 2, "SILU": 1, "NONE": 0, "LEAKY": 3}
     pat = None
     # the split precision's kernels carry no element tag; conv_h8x3_kernel<ACT, MODE>: both synchronisation variants of one activation
-    for kname in ("conv_h8x3_kernel", "conv_s2p_x3_kernel"):
+    for kname in ("conv_h8x3_kernel", "conv_s2p_x3_kernel", "conv_s2d_x3_kernel"):
         if dom_label.startswith(kname + "<"):
             inner = dom_label[len(kname) + 1:].split(">")[0].split(",")
-            pat = f"{kname}<{acts.get(inner[0], 2)}" + ("," if kname == "conv_h8x3_kernel" else ">")
+            pat = f"{kname}<{acts.get(inner[0], 2)}" + (">" if kname == "conv_s2p_x3_kernel" else ",")   # (conv_s2d_x3_kernel<ACT, NP>)
     if dom_label.startswith("conv_halo_group_kernel"):
         pat = f"conv_halo_group_kernel<adas::{etag}>"
     for kname in ("conv_h8_kernel", "conv_halo_rw_kernel", "conv_s2p_kernel"):

@@ -220,16 +220,33 @@ def test_halo8_x3_kernel_layers(case):
 @pytest.mark.parametrize("case", [(80, 400, 64, 128, M.ACT_RELU, 8), (40, 200, 128, 256, M.ACT_RELU, 16), (20, 100, 256, 512, M.ACT_RELU, 64),
                                   (160, 160, 32, 64, M.ACT_SILU, 16), (80, 80, 64, 128, M.ACT_SILU, 64), (40, 40, 128, 256, M.ACT_SILU, 64),
                                   (80, 80, 64, 64, M.ACT_LEAKY, 64), (46, 74, 64, 80, M.ACT_NONE, 64), (23, 37, 96, 192, M.ACT_SILU, 128)], ids=str)
-def test_s2p_x3_kernel_layers(case):
-    """The stride-2 3x3 conv of the split precision on the parity-plane kernel (conv_halo_s2.hip conv_s2p_x3_kernel: half-chunk window,
-    conv_halo8_x3's weight slabs, main / cross accumulators): the three UFLD down-sampling layers, the YOLOv8n ones, even and odd map
-    sizes (the last window row / column outside the image), a Cout that is not whole 64-channel blocks (80: zero weight rows, masked
-    stores), three chunks (96 input channels) -- f32-class against torch fp32 (ADAS_NO_HALO_S2P_X3=1 sends these layers back to the generic kernel)."""
+@pytest.mark.parametrize("form", ["dma", "dma-persistent", "registers"])
+def test_s2p_x3_kernel_layers(case, form, monkeypatch):
+    """The stride-2 3x3 conv of the split precision on the parity-plane kernels of conv_halo_s2.hip (half-chunk window, conv_halo8_x3's weight
+    slabs, main / cross accumulators): the three UFLD down-sampling layers, the YOLOv8n ones, even and odd map sizes (the last window row /
+    column outside the image), a Cout that is not whole 64-channel blocks (80: zero weight rows, masked stores), three chunks (96 input
+    channels) -- f32-class against torch fp32.  Three forms: conv_s2d_x3_kernel (window and weights by LDS-DMA, one parity plane recycled at
+    a time; the default) launched fine-grained and as one persistent workgroup per CU (ADAS_S2D_ROUNDS=1: every workgroup walks several
+    items, the next item's first half-chunk arrives under the last taps), and the register-staged conv_s2p_x3_kernel (ADAS_NO_S2D_X3=1;
+    ADAS_NO_HALO_S2P_X3=1 sends these layers back to the generic kernel).  The switches are read once per process: the non-default
+    forms run in a child process."""
     H, W, cin, cout, act, batch = case
-    info = {}
-    rel, mx = TC.run_case(CE, H, W, cin, cout, 3, 2, act, M.RES_NONE, "fp16x3", batch=batch, info=info)
-    print("s2p x3 %s: rel %.2e max %.2e  %s" % (case, rel, mx, info.get("kernel")))
-    assert "conv_s2p_x3_kernel" in info["kernel"], info
+    if form != "dma":
+        import subprocess, sys, json
+        env = dict(os.environ, **({"ADAS_S2D_ROUNDS": "1"} if form == "dma-persistent" else {"ADAS_NO_S2D_X3": "1"}))
+        code = ("import sys, json, importlib; sys.path.insert(0, %r); sys.path.insert(0, %r); from conftest import load_pkg; load_pkg();"
+                "import test_gpu_conv as TC; CE = importlib.import_module('adas_amd.coreEngine'); info = {};"
+                "rel, mx = TC.run_case(CE, %d, %d, %d, %d, 3, 2, %d, 0, 'fp16x3', batch=%d, info=info); print(json.dumps([rel, mx, info.get('kernel')]))"
+                % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.dirname(os.path.abspath(__file__)), H, W, cin, cout, act, batch))
+        r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        rel, mx, kernel = json.loads(r.stdout.strip().splitlines()[-1])
+    else:
+        info = {}
+        rel, mx = TC.run_case(CE, H, W, cin, cout, 3, 2, act, M.RES_NONE, "fp16x3", batch=batch, info=info)
+        kernel = info.get("kernel")
+    print("s2 x3 [%s] %s: rel %.2e max %.2e  %s" % (form, case, rel, mx, kernel))
+    assert ("conv_s2p_x3_kernel" if form == "registers" else "conv_s2d_x3_kernel") in kernel, kernel
     assert rel < X3_REL and mx < 1e-4, (case, rel, mx)
 
 

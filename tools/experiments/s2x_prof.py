@@ -12,13 +12,14 @@ M = importlib.import_module("adas_amd.models"); CE = importlib.import_module("ad
 ap = argparse.ArgumentParser()
 ap.add_argument("--hw", type=int, nargs=2, default=[80, 400]); ap.add_argument("--cin", type=int, default=64)
 ap.add_argument("--cout", type=int, default=128); ap.add_argument("--batch", type=int, default=64)
+ap.add_argument("--act", default="relu")
 a = ap.parse_args()
 H, W = a.hw
 ws = M.SynthWeights(0, gain=1.0)
 g = M.Graph("unit", 3, H, W, ws)
 x, c3 = g.input()
 e1 = g.conv(x, a.cin, 1, 1, "expand", act=M.ACT_SILU, true_cin=c3)
-y = g.conv(e1, a.cout, 3, 2, "test", act=M.ACT_RELU)
+y = g.conv(e1, a.cout, 3, 2, "test", act=M.ACT_RELU if a.act == "relu" else M.ACT_SILU)
 z = g.conv(y, 8, 1, 1, "tap", act=M.ACT_NONE, f32_out=True)
 g.output(z, 0, [1, z.h * z.w * 8], "o")
 path = os.path.join(tempfile.gettempdir(), "s2x_prof.hipm"); g.save(path)
@@ -27,11 +28,15 @@ xin = np.random.default_rng(0).uniform(0, 1, (a.batch, 3, H, W)).astype(np.float
 buf = L.DeviceBuffer.from_array(xin)
 lib = C.CDLL(L.LIB_PATH)
 prof = hasattr(lib, "adas_debug_s2x_prof")
+dprof = hasattr(lib, "adas_debug_s2d_prof") and os.environ.get("ADAS_NO_S2D_X3") != "1"
+if dprof: prof = False
 out = (C.c_ulonglong * 16)()
 e.profile(buf.ptr, a.batch, 2)
 if prof: lib.adas_debug_s2x_prof(None, 1)
+if dprof: lib.adas_debug_s2d_prof(None, 1)
 rows = e.profile(buf.ptr, a.batch, 5)
 if prof: lib.adas_debug_s2x_prof(out, 0)
+if dprof: lib.adas_debug_s2d_prof(out, 0)
 li = [i for i, r in enumerate(rows) if r[0] == "test"][0]
 ms = rows[li][3]
 fl = 2.0 * a.batch * (H // 2) * (W // 2) * a.cout * 9 * a.cin
@@ -45,4 +50,12 @@ if prof:
     for i, nm in enumerate(names):
         print(f"  {nm:52s} {out[i]/5.0/max(n,1):9.0f}  {100*out[i]/5.0/max(tot,1):5.1f}%")
     print(f"  {'total':52s} {tot/max(n,1):9.0f}")
+if dprof:   # conv_s2d_x3_kernel (LDS-DMA form): thread 0's cycles per item
+    names = ["prologue (first item's loads)", "H tap groups (MFMAs)", "L tap groups (MFMAs)", "counted vmcnt waits", "group barriers", "issue slots (DMA)", "epilogue", "next item's set-up"]
+    n = out[8] / 5.0
+    tot = sum(out[i] for i in range(8)) / 5.0
+    print(f" {n:.0f} items per launch ({n/256:.1f} per workgroup); mean cycles per item (thread 0), {a.cin // 32} chunks:")
+    for i, nm in enumerate(names):
+        print(f"  {nm:40s} {out[i]/5.0/max(n,1):9.0f}  {100*out[i]/5.0/max(tot,1):5.1f}%")
+    print(f"  {'total':40s} {tot/max(n,1):9.0f}")
 e.close()

@@ -771,7 +771,11 @@ hipError_t launch_conv_halo8_x3(const ConvArgs& a, hipStream_t st) {
     const int upt = d.ncb / d.cpw;
     d.mg_upt = (uint32_t)(((1ull << 32) + (uint64_t)upt - 1) / (uint64_t)upt);
     const int units8 = d.tiles8 * upt;
-    const int slots = units8 < X8_SLOTS ? units8 : X8_SLOTS;
+    // workgroups per XCD over the launch (ADAS_H8X_SLOTS, default 32 = one per CU, every one persistent over its share of the items; more:
+    // the later workgroups are dealt as CUs fall free, each with fewer items)
+    static int max_slots = -1;
+    if (max_slots < 0) { const char* e = getenv("ADAS_H8X_SLOTS"); max_slots = e ? atoi(e) : X8_SLOTS; if (max_slots < 8 || max_slots > 4096) max_slots = X8_SLOTS; }
+    const int slots = units8 < max_slots ? units8 : max_slots;
     dim3 grid(8 * slots);
     const int forced = x8_mode();
     // (the wave-groups-a-barrier-apart variant, MODE 1, lost to MODE 2 on every layer once both were measured at one commit --

@@ -342,7 +342,8 @@ const char* conv_kernel_name(const ConvArgs& a, int prec, int kernel) {
             return buf;
         }
         if (a.wgt_h8x3 && halo_s2p_x3_applicable(a.kh, a.kw, a.stride, a.pad, a.res_mode, a.n, a.in, a.out)) {
-            snprintf(buf, sizeof(buf), "conv_s2p_x3_kernel<%s>", a.act == ACT_SILU ? "SILU" : (a.act == ACT_RELU ? "RELU" : (a.act == ACT_LEAKY ? "LEAKY" : "NONE")));
+            snprintf(buf, sizeof(buf), "%s<%s>", halo_s2d_x3_applicable(a.kh, a.kw, a.stride, a.pad, a.res_mode, a.n, a.in, a.out) ? "conv_s2d_x3_kernel" : "conv_s2p_x3_kernel",
+                     a.act == ACT_SILU ? "SILU" : (a.act == ACT_RELU ? "RELU" : (a.act == ACT_LEAKY ? "LEAKY" : "NONE")));
             return buf;
         }
         return conv_x3_kernel_name(a);

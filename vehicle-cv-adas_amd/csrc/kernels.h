@@ -73,7 +73,8 @@ hipError_t launch_conv_halo_s2p(const ConvArgs& a, hipStream_t st);
 // ... and its split-precision form on conv_halo8_x3's weight slabs (ConvArgs::wgt_h8x3): shape_ok decides the packing at load time
 bool halo_s2p_x3_shape_ok(int kh, int kw, int stride, int pad, int res_mode, const TView& in, const TView& out);
 bool halo_s2p_x3_applicable(int kh, int kw, int stride, int pad, int res_mode, int n, const TView& in, const TView& out);
-hipError_t launch_conv_s2p_x3(const ConvArgs& a, hipStream_t st);
+hipError_t launch_conv_s2p_x3(const ConvArgs& a, hipStream_t st);   // (takes the layer to conv_s2d_x3_kernel, the LDS-DMA form, where that applies)
+bool halo_s2d_x3_applicable(int kh, int kw, int stride, int pad, int res_mode, int n, const TView& in, const TView& out);
 // conv_halo.hip's tile plan (strip-linear tiles of halo_bm(S) output pixels), shared with conv_halo8.hip
 struct HaloPlan {
     int SW, NS, TPS, WW, maxpix;   // strip width, strips per row, tiles per strip, window width, window pixels
