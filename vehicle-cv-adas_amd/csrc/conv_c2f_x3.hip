@@ -386,7 +386,9 @@ hipError_t launch_conv_c2f16_x3(const TView& x, const TView& out, const void* co
         (void)hipFuncSetAttribute((const void*)conv_c2f16_x3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_done = true;
     }
-    const int grid = d.ntiles < 256 ? d.ntiles : 256;   // persistent: one workgroup per CU
+    static int wgs = -1;   // ADAS_C2F_X3_WGS: workgroups of the launch (default 256 = one persistent workgroup per CU)
+    if (wgs < 0) { const char* e = getenv("ADAS_C2F_X3_WGS"); wgs = e ? atoi(e) : 256; if (wgs < 64 || wgs > 65536) wgs = 256; }
+    const int grid = d.ntiles < wgs ? d.ntiles : wgs;
     hipLaunchKernelGGL(conv_c2f16_x3_kernel, dim3(grid), dim3(CX_THR), CX_LDS, st, d);
     return hipGetLastError();
 }

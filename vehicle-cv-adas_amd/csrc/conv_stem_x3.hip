@@ -457,7 +457,9 @@ hipError_t launch_conv_stem_pool_x3(const float* nchw, int n, int c_true, int H,
         (void)hipFuncSetAttribute((const void*)conv_stem_pool_x3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_done = true;
     }
-    const int grid = d.ntiles < 256 ? d.ntiles : 256;   // persistent: one workgroup per CU
+    static int wgs = -1;   // ADAS_STEMP_X3_WGS: workgroups of the launch (default 256 = one persistent workgroup per CU; more: the later ones are dealt as CUs fall free)
+    if (wgs < 0) { const char* e = getenv("ADAS_STEMP_X3_WGS"); wgs = e ? atoi(e) : 256; if (wgs < 64 || wgs > 65536) wgs = 256; }
+    const int grid = d.ntiles < wgs ? d.ntiles : wgs;
     hipLaunchKernelGGL(conv_stem_pool_x3_kernel, dim3(grid), dim3(512), SP3_LDS, st, d);
     return hipGetLastError();
 }
@@ -706,7 +708,9 @@ hipError_t launch_conv_stem2_x3(const float* nchw, int n, int c_true, int H, int
         (void)hipFuncSetAttribute((const void*)conv_stem2_x3_kernel<6>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_done = true;
     }
-    const int grid = d.ntiles < 256 * ADAS_STEM2_X3_WGS ? d.ntiles : 256 * ADAS_STEM2_X3_WGS;   // persistent
+    static int wgs2 = -1;  // ADAS_STEM2_X3_GRID: workgroups of the launch (default: the persistent 256 x workgroups-per-CU)
+    if (wgs2 < 0) { const char* e = getenv("ADAS_STEM2_X3_GRID"); wgs2 = e ? atoi(e) : 256 * ADAS_STEM2_X3_WGS; if (wgs2 < 64 || wgs2 > 65536) wgs2 = 256 * ADAS_STEM2_X3_WGS; }
+    const int grid = d.ntiles < wgs2 ? d.ntiles : wgs2;
     if (kh == 3) hipLaunchKernelGGL(conv_stem2_x3_kernel<3>, dim3(grid), dim3(512), s2x_lds_bytes(3), st, d);
     else hipLaunchKernelGGL(conv_stem2_x3_kernel<6>, dim3(grid), dim3(512), s2x_lds_bytes(6), st, d);
     return hipGetLastError();
