@@ -292,6 +292,14 @@ __global__ __launch_bounds__(X8_THR, 1) void conv_h8x3_kernel(H8XDev a) {
         const bool has_next = !newtile || ti + nslot < units_here;
         const int cbn = newtile ? first_cb(has_next ? ti + nslot : ti) : cb + 1;
         const uint32_t ch0 = (uint32_t)(cb * 256) + ch_lane;   // 64 channels = 256 bytes of G8 storage
+        // a wave group whose 32 channels lie past Cout (the padded tail of the last 64-channel block: 80 -> 128 leaves group 1 of block 1 with
+        // zero weight rows and masked stores) takes part in the DMA stream and the barriers but reads no fragments and issues no MFMAs -- its
+        // SIMD partner of group 0 has the matrix pipe to itself for that item (ADAS_H8X_NO_TRIM builds keep the zero products)
+#ifndef ADAS_H8X_NO_TRIM
+        const bool wave_on = cb * 64 + hb * 32 < a.cout;
+#else
+        constexpr bool wave_on = true;
+#endif
         Tile nxt = cur;
         uint32_t wnxt_item = 0, apn[4] = {0, 0, 0, 0};
         yu32x4 rraw[4][2];      // residual [pixel tile][channel tile], fetched under the last row of taps of the last half-chunk: one 16-byte piece
@@ -339,10 +347,12 @@ __global__ __launch_bounds__(X8_THR, 1) void conv_h8x3_kernel(H8XDev a) {
                 }
                 hvec8 wf[4], xf[4];
                 // (SH: an L tap multiplies by the MAIN rows -- w_hi -- of the chunk's H tile, still in slot kk)
+                if (wave_on) {
 #pragma unroll
-                for (int i = islo ? 2 : 0; i < 4; ++i) wf[i] = *reinterpret_cast<const hvec8*>(lds8 + wrd + kk * X8_TAP + ((SH && islo) ? i - 2 : i) * 1024);
+                    for (int i = islo ? 2 : 0; i < 4; ++i) wf[i] = *reinterpret_cast<const hvec8*>(lds8 + wrd + kk * X8_TAP + ((SH && islo) ? i - 2 : i) * 1024);
 #pragma unroll
-                for (int j = 0; j < 4; ++j) xf[j] = *reinterpret_cast<const hvec8*>(lds8 + xoff[j][kk] + winr);
+                    for (int j = 0; j < 4; ++j) xf[j] = *reinterpret_cast<const hvec8*>(lds8 + xoff[j][kk] + winr);
+                }
                 if constexpr (SH) {
                     if constexpr (islo ? kk >= 3 : kk < 3) {
                         constexpr int kt = (kk + 6) % 9;      // H taps 0-2: tiles 6-8 of this chunk; L taps 3-8: tiles 0-5 of the next chunk (or item)
@@ -394,10 +404,12 @@ __global__ __launch_bounds__(X8_THR, 1) void conv_h8x3_kernel(H8XDev a) {
                     for (int j = 0; j < 4; ++j) xoff[j][kk] = tap_offset(apn[j], kk);
                     if constexpr (kk < NWP) gnxt[kk] = win_offset(nxt, kk);
                 }
+                if (wave_on) {
 #pragma unroll
-                for (int i = islo ? 2 : 0; i < 4; ++i)
+                    for (int i = islo ? 2 : 0; i < 4; ++i)
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) acc[i][j] = Fp16::mfma(wf[i], xf[j], acc[i][j]);
+                        for (int j = 0; j < 4; ++j) acc[i][j] = Fp16::mfma(wf[i], xf[j], acc[i][j]);
+                }
                 if (lastc) {
 #pragma unroll
                     for (int g = 0; g < (islo ? 8 : 16); ++g) {
