@@ -134,11 +134,13 @@ __global__ __launch_bounds__(256, CONV2 ? 3 : 2) void conv_stem_kernel(StemDev a
                 px[i][0] = v.x;
                 px[i][1] = v.y;
             } else {
-                const uint32_t off = (uint32_t)((iy * a.W + ix) * 4);
+                // branch-free: written with nested conditions the compiler puts every load under its own exec-masked branch, with waits between them
+                // (conv_stem_pool_x3_kernel, profiles/r06/stem_pool_x3_phases.txt); outside the window / image / channel count: bit 31 -> past num_records -> 0
+                const uint32_t off = ((uint32_t)((iy * a.W + ix) * 4) & 0x7FFFFFFFu) | (ok ? 0u : 0x80000000u);
 #pragma unroll
                 for (int c = 0; c < 3; ++c) {
-                    const uint32_t oc = (ok && c < a.C) ? off + (uint32_t)(c * plane * 4) : 0x80000000u;
-                    px[i][c] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rsrc, oc, 0, 0);
+                    const uint32_t cp = c < a.C ? (uint32_t)(c * plane * 4) : 0x80000000u;
+                    px[i][c] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rsrc, (off + cp) | ((off | cp) & 0x80000000u), 0, 0);
                 }
             }
         }
