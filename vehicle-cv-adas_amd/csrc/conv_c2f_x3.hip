@@ -117,8 +117,10 @@ __global__ __launch_bounds__(CX_THR, 1) void conv_c2f16_x3_kernel(C2fX3Dev a) {
             const int wy = pix / CX_WW, wx = pix - wy * CX_WW;
             const int iy = ty0 - 2 + wy, ix = tx0 - 2 + wx;
             const bool ok = live && e < CX_NW * 8 && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
-            const uint32_t off = ok ? ((uint32_t)((img * a.H + iy) * a.W + ix) * (uint32_t)a.in_cs + (uint32_t)a.in_coff) * 4u + (uint32_t)c * 16u : CX_OOB;
-            ra[i] = __builtin_bit_cast(xu32x4, __builtin_amdgcn_raw_buffer_load_b128(rin, off, 0, 0));
+            // (mask, not a conditional: the compiler turns `ok ? address : OOB` into an exec-masked branch per load, with waits between them)
+            const uint32_t lin = ((uint32_t)((img * a.H + iy) * a.W + ix) * (uint32_t)a.in_cs + (uint32_t)a.in_coff) * 4u + (uint32_t)c * 16u;
+            const uint32_t m = 0u - (uint32_t)ok;
+            ra[i] = __builtin_bit_cast(xu32x4, __builtin_amdgcn_raw_buffer_load_b128(rin, (lin & m) | (CX_OOB & ~m), 0, 0));
         }
     };
 

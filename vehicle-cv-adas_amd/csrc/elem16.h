@@ -127,7 +127,7 @@ __host__ __device__ __forceinline__ float x3_join(_Float16 h, _Float16 l) { retu
 //   1 / d = v_rcp_f32 refined by one Newton step,
 // x = min(-v, 88) so that e^x stays finite (v < -88: the result is -0 instead of -5e-37).  Against float64 over 3.5 M values (N(0, 3),
 // U(-90, 90), N(0, 0.1)) with 1-ulp exp2 / rcp: max relative error 3.2e-7, mean 4.8e-8 -- NumPy's float32 evaluation of the
-// reference expression (oracle/nets.py): 2.4e-7 / 3.4e-8.  -DADAS_X3_SILU_EXACT restores the 27-instruction form.
+// reference expression (oracle/nets.py): 2.4e-7 / 3.4e-8 (tests/test_x3_silu_model.py restates this in NumPy).  -DADAS_X3_SILU_EXACT restores the 27-instruction form.
 __device__ __forceinline__ float x3_silu(float v) {
 #ifdef ADAS_X3_SILU_EXACT
     return v / (1.0f + expf(-v));
