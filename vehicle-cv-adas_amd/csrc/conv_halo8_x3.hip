@@ -110,7 +110,9 @@ __host__ __device__ constexpr int x8_allow(int mode, int k) {
 // at tap 6 (the last tap row), which leaves an HBM read ~1.5 k cycles before the epilogue needs it -- the phase counters showed the last
 // half-chunk of a residual layer at 11.9 k cycles against 6.5 k without (profiles/r06/h8x_phases.txt); at tap 0 the loads have the whole
 // half-chunk (the in-order return then asks them to be back by the wait of tap 5, ~3 k cycles on).  Same registers either way; measured
-// +0.2 % end to end (inside the noise: the item's other fixed costs hide most of it), kept.
+// +0.2 % end to end (inside the noise: the item's other fixed costs hide most of it), kept.  (Later in round 6: one residual load per tap,
+// taps 0-7, instead of eight under tap 0 -- counted waits adjusted per tap row -- changed nothing: layer1's conv2 0.515 / 0.509 ms either
+// way, -0.3 % end to end; the 3 k cycles a residual item costs are its 64 KB of extra HBM reads, not the issue burst.  Not kept.)
 #ifndef ADAS_H8X_RES_TAP
 #define ADAS_H8X_RES_TAP 0
 #endif
