@@ -42,6 +42,33 @@ def test_custom_scale_yolov8_onnx_runs_through_hipengine(tmp_path, prec, tol):
     assert rel <= tol
     if prec == "fp16":      # the engine's fusion passes see a lowered graph like a hand-built one (the upsample fold needs a K-step count
         assert any("detect_v8_fused_kernel" in k for k in kernels), kernels   # conv_pw instantiates: 576 / 288 input channels here are not)
+    if prec == "fp16x3":    # ... and in the exact mode: the split-precision Detect fusion (round 6)
+        assert any("detect_v8_fused_x3_kernel" in k for k in kernels), kernels
+
+
+@pytest.mark.parametrize("nc", [16, 24, 96, 11])
+def test_fused_x3_detect_with_other_class_counts(tmp_path, monkeypatch, nc):
+    """detect_v8_fused_x3_kernel with class counts that are not 80: 16 (one class tile), 24 (two, the second half wide), 96 (six) -- the head
+    against the torch interpreter and against the same engine with the fusion off.  11 classes: the class branch's closing conv is not a
+    multiple of 8 channels wide and stays on the separate launches (the head must still be right)."""
+    g = M.yolov8("n", imgsz=(96, 160), nc=nc)
+    path = str(tmp_path / ("yolov8n_nc%d.onnx" % nc))
+    onnx_emit.emit(g, path)
+    x = np.random.default_rng(2).uniform(0, 1, (3, 3, 96, 160)).astype(np.float32)
+    want = graph_interp.run(g, x)[0]
+    e = CE.OnnxEngine(path, precision="fp16x3", max_batch=3)
+    got = np.array(e.engine_inference(x)[0], copy=True)
+    fused = any("detect_v8_fused_x3_kernel" in e.layer_kernel(i, 3) for i in range(e.stats()["num_layers"]))
+    e.close()
+    monkeypatch.setenv("ADAS_NO_DETECT_FUSE", "1")
+    e = CE.OnnxEngine(path, precision="fp16x3", max_batch=3)
+    sep = np.array(e.engine_inference(x)[0], copy=True)
+    e.close()
+    rel = float(np.linalg.norm(got - want) / np.linalg.norm(want))
+    dp, db = float(np.abs(got[:, 4:] - sep[:, 4:]).max()), float(np.abs(got[:, :4] - sep[:, :4]).max())
+    print("fused x3 Detect nc=%d: rel %.2e vs interpreter; vs separate launches max|prob diff| %.2e max|box diff| %.2e px" % (nc, rel, dp, db))
+    assert fused == (nc % 8 == 0) and got.shape == (3, 4 + nc, want.shape[2]), (fused, got.shape)
+    assert rel <= 1e-5 and dp <= 2e-6 and db <= 2e-3
 
 
 def test_v5_layout_onnx_runs_through_hipengine(tmp_path):
