@@ -16,6 +16,7 @@
 #include "kernels.h"
 #include "elem16.h"
 #include <stdlib.h>
+#include <type_traits>
 
 namespace adas {
 
@@ -85,10 +86,15 @@ __global__ __launch_bounds__(256) void conv_x3_igemm_kernel(X3Dev a) {
     __syncthreads();
 
     const int KT = a.kpad >> 5;
-    e_u32x4 rah[A_IT], ral[A_IT], rbh[B_IT], rbl[B_IT];
+    // two register stages: K step ks + 2 is requested while ks + 1 waits in the other stage and ks is multiplied out of LDS -- with one
+    // stage a step's global latency had one step's MFMAs (12-24 per wave) to hide behind, and a small map's launch (one workgroup per CU
+    // or fewer, 144 steps for a 512-channel 3x3 layer) ran at ~0.8 us per step
+    e_u32x4 rah2[2][A_IT], ral2[2][A_IT], rbh2[2][B_IT], rbl2[2][B_IT];
     const e_u32x4 zero4 = {0u, 0u, 0u, 0u};
 
-    auto gload = [&](int ks) {
+    auto gload = [&](auto set_c, int ks) {
+        constexpr int SET = decltype(set_c)::value;
+        e_u32x4 (&rah)[A_IT] = rah2[SET], (&ral)[A_IT] = ral2[SET], (&rbh)[B_IT] = rbh2[SET], (&rbl)[B_IT] = rbl2[SET];
         const int q = ks * 4 + kc;
         int r = 0, s = 0, c8 = 0;
         const bool qok = q < a.nq;
@@ -119,7 +125,9 @@ __global__ __launch_bounds__(256) void conv_x3_igemm_kernel(X3Dev a) {
             }
         }
     };
-    auto lstore = [&](int buf) {
+    auto lstore = [&](auto set_c, int buf) {
+        constexpr int SET = decltype(set_c)::value;
+        e_u32x4 (&rah)[A_IT] = rah2[SET], (&ral)[A_IT] = ral2[SET], (&rbh)[B_IT] = rbh2[SET], (&rbl)[B_IT] = rbl2[SET];
 #pragma unroll
         for (int i = 0; i < A_IT; ++i) {
             int row = (tid >> 2) + 64 * i;
@@ -145,12 +153,19 @@ __global__ __launch_bounds__(256) void conv_x3_igemm_kernel(X3Dev a) {
         for (int j = 0; j < TM; ++j) accm[i][j] = accx[i][j] = xf32x4{0.f, 0.f, 0.f, 0.f};
 
     const int lrow = lane & 15, kg = lane >> 4;
-    gload(0);
-    lstore(0);
+    typedef std::integral_constant<int, 0> S0;
+    typedef std::integral_constant<int, 1> S1;
+    gload(S0{}, 0);
+    lstore(S0{}, 0);
+    if (KT > 1) gload(S1{}, 1);
     __syncthreads();
-    for (int ks = 0; ks < KT; ++ks) {
-        const int buf = ks & 1;
-        if (ks + 1 < KT) gload(ks + 1);
+    // (step ks: LDS buffer ks & 1 holds it, stage (ks + 1) & 1 holds step ks + 1; the stage index is a compile-time constant per parity)
+    auto step = [&](auto par_c, const int ks) {
+        constexpr int PAR = decltype(par_c)::value;
+        const int buf = PAR;
+        // (unconditional -- the last two steps re-request step KT - 1: with the request under a condition the compiler has to wait for EVERY
+        // outstanding load before the stage that is stored below, the fresh ones included)
+        gload(std::integral_constant<int, PAR>{}, ks + 2 < KT ? ks + 2 : KT - 1);
         e_u32x4 wh[TN], wl[TN], xh[TM], xl[TM];
 #pragma unroll
         for (int i = 0; i < TN; ++i) {
@@ -175,8 +190,12 @@ __global__ __launch_bounds__(256) void conv_x3_igemm_kernel(X3Dev a) {
         for (int i = 0; i < TN; ++i)
 #pragma unroll
             for (int j = 0; j < TM; ++j) accx[i][j] = Fp16::mfma(wh[i], xl[j], accx[i][j]);
-        if (ks + 1 < KT) lstore(buf ^ 1);
+        if (ks + 1 < KT) lstore(std::integral_constant<int, PAR ^ 1>{}, buf ^ 1);
         __syncthreads();
+    };
+    for (int ks = 0; ks < KT; ks += 2) {
+        step(S0{}, ks);
+        if (ks + 1 < KT) step(S1{}, ks + 1);
     }
 
     // ---- fused epilogue: lane holds channels c..c+3 of pixel m
@@ -236,9 +255,19 @@ struct X3Tile {
     int bm, bn;
 };
 static X3Tile x3_pick_tile(const ConvArgs& a) {
-    const int bn = a.out.c <= 16 ? 16 : (a.out.c <= 32 ? 32 : 64);
+    int bn = a.out.c <= 16 ? 16 : (a.out.c <= 32 ? 32 : 64);
     const long tiles128 = (long)((a.m + 127) / 128) * ((a.out.c + bn - 1) / bn);
-    return X3Tile{(tiles128 >= 512 && a.m > 64) ? 128 : 64, bn};
+    if (tiles128 >= 512 && a.m > 64) return X3Tile{128, bn};
+    // small maps (one frame at a time: 10x50 .. 40x40 pixels): a 64 x 64 tiling leaves most CUs without a workgroup while each of the few
+    // walks the whole K loop; 32-row tiles, then 32-column tiles, until the launch has a workgroup for every other CU (ADAS_X3_SMALL_TILES=0: off)
+    static int small = -1;
+    if (small < 0) { const char* e = getenv("ADAS_X3_SMALL_TILES"); small = (e && e[0] == '0') ? 0 : 1; }
+    int bm = 64;
+    if (small && bn >= 32) {
+        if ((long)((a.m + 63) / 64) * ((a.out.c + bn - 1) / bn) < 128) bm = 32;
+        if (bm == 32 && bn == 64 && (long)((a.m + 31) / 32) * ((a.out.c + 63) / 64) < 128) bn = 32;
+    }
+    return X3Tile{bm, bn};
 }
 
 const char* conv_x3_kernel_name(const ConvArgs& a) {
@@ -262,6 +291,8 @@ static hipError_t launch_x3_typed(const X3Dev& d, X3Tile t, hipStream_t st) {
     LAUNCH(64, 64, 2, 2)
     LAUNCH(64, 32, 2, 2)
     LAUNCH(64, 16, 4, 1)
+    LAUNCH(32, 64, 2, 2)
+    LAUNCH(32, 32, 2, 2)
 #undef LAUNCH
     return hipErrorInvalidValue;
 }
