@@ -217,6 +217,25 @@ def test_halo8_x3_kernel_layers(case):
     assert rel < X3_REL and mx < 1e-4, (case, rel, mx)
 
 
+@pytest.mark.parametrize("case", [(10, 50, 512, 512, 3, 1, M.ACT_RELU, M.RES_BEFORE_ACT, 1), (20, 100, 256, 256, 3, 1, M.ACT_RELU, M.RES_NONE, 1),
+                                  (20, 100, 256, 512, 3, 2, M.ACT_RELU, M.RES_NONE, 1), (20, 20, 256, 80, 3, 1, M.ACT_SILU, M.RES_NONE, 1),
+                                  (20, 20, 128, 128, 3, 1, M.ACT_SILU, M.RES_AFTER_ACT, 2), (13, 17, 96, 40, 3, 1, M.ACT_LEAKY, M.RES_NONE, 3),
+                                  (7, 9, 64, 200, 5, 1, M.ACT_NONE, M.RES_NONE, 1)], ids=str)
+def test_small_maps_on_the_k_split_kernel(case):
+    """conv_x3_ksplit_kernel (one frame at a time: the K loop split over the eight waves of a workgroup, fragments straight from global
+    memory, partial tiles summed in a fixed tree): UFLDv2's layer3 / layer4 shapes at one frame, YOLOv8n's 20x20 Detect convs, a Cout that
+    is not a multiple of the 32-column tile (80, 40, 200), ragged pixel tiles, a 5x5 kernel, every residual mode -- f32-class against
+    torch fp32, and the same bits on a second run (the reduction order is fixed)."""
+    H, W, cin, cout, k, stride, act, rm, batch = case
+    info = {}
+    rel, mx = TC.run_case(CE, H, W, cin, cout, k, stride, act, rm, "fp16x3", batch=batch, info=info)
+    print("x3 k-split %s: rel %.2e max %.2e  %s" % (case, rel, mx, info.get("kernel")))
+    assert "conv_x3_ksplit_kernel" in info["kernel"], info
+    assert rel < X3_REL and mx < 1e-4, (case, rel, mx)
+    rel2, mx2 = TC.run_case(CE, H, W, cin, cout, k, stride, act, rm, "fp16x3", batch=batch)
+    assert (rel2, mx2) == (rel, mx)
+
+
 @pytest.mark.parametrize("case", [(80, 400, 64, 128, M.ACT_RELU, 8), (40, 200, 128, 256, M.ACT_RELU, 16), (20, 100, 256, 512, M.ACT_RELU, 64),
                                   (160, 160, 32, 64, M.ACT_SILU, 16), (80, 80, 64, 128, M.ACT_SILU, 64), (40, 40, 128, 256, M.ACT_SILU, 64),
                                   (80, 80, 64, 64, M.ACT_LEAKY, 64), (46, 74, 64, 80, M.ACT_NONE, 64), (23, 37, 96, 192, M.ACT_SILU, 128)], ids=str)

@@ -251,6 +251,201 @@ __global__ __launch_bounds__(256) void conv_x3_igemm_kernel(X3Dev a) {
     }
 }
 
+// ---- small maps (one frame at a time): the K loop split over the waves of the workgroup.
+// conv_x3_igemm's workgroup walks all of K behind one barrier per 32-deep step; a 10x50 map of a 512-channel layer is 8-16 tiles, so a
+// handful of workgroups each run 144 dependent steps (0.57 us each even with two register stages: 82 us for 2.4 GFLOP) while the chip
+// idles.  Here a workgroup of eight waves owns a 32 x 32 tile; wave w takes the K steps w, w + 8, ... (its MFMA fragments straight from
+// global memory, as conv_pwx3 reads them: a fragment is one pixel's / one weight row's 16 bytes of hi and 16 of lo -- no LDS staging, no
+// barrier in the loop, two steps in flight per wave), and the eight partial tiles are summed in a fixed tree through LDS (deterministic:
+// the same bits every run), wave 0 applying the epilogue.
+constexpr int KSW = 8;   // waves per workgroup = K slices
+template <bool OUT_F32>
+__global__ __launch_bounds__(64 * KSW) void conv_x3_ksplit_kernel(X3Dev a) {
+    Fp16::enter();
+    constexpr int TM = 2, TN = 2;
+    __shared__ uint16_t ktab[ADAS_X3_MAX_Q];
+    __shared__ __attribute__((aligned(16))) float red[KSW / 2][32][64];   // [writer][value][lane]: 32 KB
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lrow = lane & 15, kg = lane >> 4;
+    const int m0 = blockIdx.x * 32, n0 = blockIdx.y * 32;
+    const x3s* __restrict__ in = (const x3s*)a.in;
+    const x3s* __restrict__ wgt = (const x3s*)a.wgt;
+    const int cin8 = a.cin >> 3;
+    for (int q = tid; q < a.nq; q += 64 * KSW) {
+        int tap = q / cin8, c8 = q - tap * cin8;
+        int r = tap / a.kw, s2 = tap - r * a.kw;
+        ktab[q] = (uint16_t)((r << 13) | (s2 << 10) | c8);
+    }
+    int iy0[TM], ix0[TM], pb[TM];
+#pragma unroll
+    for (int j = 0; j < TM; ++j) {
+        const int m = m0 + j * 16 + lrow;
+        const bool ok = m < a.M;
+        const int mm = ok ? m : 0;
+        const int hw = a.Ho * a.Wo;
+        const int n = mm / hw, rem = mm - n * hw;
+        const int oy = rem / a.Wo, ox = rem - oy * a.Wo;
+        iy0[j] = oy * a.stride - a.pad;
+        ix0[j] = ox * a.stride - a.pad;
+        pb[j] = ok ? n * a.H * a.W : -1;
+    }
+    __syncthreads();
+
+    const int KT = a.kpad >> 5;
+    const e_u32x4 zero4 = {0u, 0u, 0u, 0u};
+    e_u32x4 fwh[2][TN], fwl[2][TN], fxh[2][TM], fxl[2][TM];   // two stages of fragments
+    auto fetch = [&](auto set_c, int ks) {
+        constexpr int SET = decltype(set_c)::value;
+        const int q = ks * 4 + kg;
+        const bool qok = ks < KT && q < a.nq;
+        const int e = qok ? (int)ktab[q] : 0;
+        const int r = e >> 13, s2 = (e >> 10) & 7, c8 = e & 1023;
+#pragma unroll
+        for (int j = 0; j < TM; ++j) {
+            const int iy = iy0[j] + r, ix = ix0[j] + s2;
+            const bool ok = qok && pb[j] >= 0 && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+            const size_t pix = ok ? (size_t)(pb[j] + iy * a.W + ix) : 0;      // always-valid address + select: no branch around the loads
+            const e_u32x4* g = reinterpret_cast<const e_u32x4*>(in + (pix * a.in_cs + a.in_coff + c8 * 8));
+            const e_u32x4 h = g[0], l = g[1];
+            fxh[SET][j] = ok ? h : zero4;
+            fxl[SET][j] = ok ? l : zero4;
+        }
+        const int ksc = ks < KT ? ks : KT - 1;                                 // (past the end: a valid address, multiplied by zero pixels)
+#pragma unroll
+        for (int i = 0; i < TN; ++i) {
+            const e_u32x4* g = reinterpret_cast<const e_u32x4*>(wgt + ((size_t)(n0 + i * 16 + lrow) * a.kpad + ksc * 32 + kg * 8));
+            fwh[SET][i] = g[0];
+            fwl[SET][i] = g[1];
+        }
+    };
+    xf32x4 accm[TN][TM], accx[TN][TM];
+#pragma unroll
+    for (int i = 0; i < TN; ++i)
+#pragma unroll
+        for (int j = 0; j < TM; ++j) accm[i][j] = accx[i][j] = xf32x4{0.f, 0.f, 0.f, 0.f};
+    auto mma = [&](auto set_c) {
+        constexpr int SET = decltype(set_c)::value;
+#pragma unroll
+        for (int i = 0; i < TN; ++i)
+#pragma unroll
+            for (int j = 0; j < TM; ++j) accm[i][j] = Fp16::mfma(fwh[SET][i], fxh[SET][j], accm[i][j]);
+#pragma unroll
+        for (int i = 0; i < TN; ++i)
+#pragma unroll
+            for (int j = 0; j < TM; ++j) accx[i][j] = Fp16::mfma(fwl[SET][i], fxh[SET][j], accx[i][j]);
+#pragma unroll
+        for (int i = 0; i < TN; ++i)
+#pragma unroll
+            for (int j = 0; j < TM; ++j) accx[i][j] = Fp16::mfma(fwh[SET][i], fxl[SET][j], accx[i][j]);
+    };
+    typedef std::integral_constant<int, 0> S0;
+    typedef std::integral_constant<int, 1> S1;
+    // wave w: steps w, w + 8, ...; requests run one step ahead of the multiplies (unconditional: past the end they fetch zeros)
+    fetch(S0{}, wave);
+    for (int ks = wave; ks < KT; ks += 2 * KSW) {
+        fetch(S1{}, ks + KSW);
+        mma(S0{});
+        fetch(S0{}, ks + 2 * KSW);
+        mma(S1{});          // (step ks + 8; zeros when it lies past the end)
+    }
+
+    // ---- the eight partial tiles: 4-7 -> 0-3, 2-3 -> 0-1, 1 -> 0 (a fixed order: bit-identical from run to run)
+    auto put = [&](int slot) {
+#pragma unroll
+        for (int i = 0; i < TN; ++i)
+#pragma unroll
+            for (int j = 0; j < TM; ++j)
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    red[slot][((i * TM + j) * 4 + t) * 2][lane] = accm[i][j][t];
+                    red[slot][((i * TM + j) * 4 + t) * 2 + 1][lane] = accx[i][j][t];
+                }
+    };
+    auto add = [&](int slot) {
+#pragma unroll
+        for (int i = 0; i < TN; ++i)
+#pragma unroll
+            for (int j = 0; j < TM; ++j)
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    accm[i][j][t] += red[slot][((i * TM + j) * 4 + t) * 2][lane];
+                    accx[i][j][t] += red[slot][((i * TM + j) * 4 + t) * 2 + 1][lane];
+                }
+    };
+#pragma unroll
+    for (int half = KSW / 2; half >= 1; half >>= 1) {
+        if (wave >= half && wave < 2 * half) put(wave - half);
+        __syncthreads();
+        if (wave < half) add(wave);
+        __syncthreads();
+    }
+    if (wave != 0) return;
+
+    // ---- epilogue (conv_x3_igemm_kernel's): lane holds channels c..c+3 of pixel m
+    const bool vec_ok = ((a.cout & 3) == 0) && ((a.out_cs & 3) == 0) && ((a.out_coff & 3) == 0);
+#pragma unroll
+    for (int j = 0; j < TM; ++j) {
+        const int m = m0 + j * 16 + lrow;
+        if (m >= a.M) continue;
+#pragma unroll
+        for (int i = 0; i < TN; ++i) {
+            const int c = n0 + i * 16 + kg * 4;
+            if (c >= a.cout) continue;
+            float v[4];
+            const float4 b = *reinterpret_cast<const float4*>(a.bias + c);   // bias is padded to 128
+            const float bb[4] = {b.x, b.y, b.z, b.w};
+#pragma unroll
+            for (int t = 0; t < 4; ++t) v[t] = (accm[i][j][t] + accx[i][j][t] * kX3Down) + bb[t];
+            if (a.res_mode != RES_NONE) {
+                float rv[4];
+                x3_load4((const x3s*)a.res + ((size_t)m * a.res_cs + a.res_coff + c), rv);
+                if (a.res_mode == RES_BEFORE_ACT) {
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) v[t] = x3_act(v[t] + rv[t], a.act);
+                } else {
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) v[t] = x3_act(v[t], a.act) + rv[t];
+                }
+            } else {
+#pragma unroll
+                for (int t = 0; t < 4; ++t) v[t] = x3_act(v[t], a.act);
+            }
+            const size_t o = (size_t)m * a.out_cs + a.out_coff + c;
+            if (OUT_F32) {
+                float* op = (float*)a.out + o;
+                if (vec_ok && c + 3 < a.cout) {
+                    *reinterpret_cast<float4*>(op) = make_float4(v[0], v[1], v[2], v[3]);
+                } else {
+#pragma unroll
+                    for (int t = 0; t < 4; ++t)
+                        if (c + t < a.cout) op[t] = v[t];
+                }
+            } else {
+                x3s* op = (x3s*)a.out + o;
+                if (vec_ok && c + 3 < a.cout) {
+                    x3_store4(op, v);
+                } else {
+#pragma unroll
+                    for (int t = 0; t < 4; ++t)
+                        if (c + t < a.cout) x3_st(op + t, v[t]);
+                }
+            }
+        }
+    }
+}
+
+// the K-split kernel takes a launch whose 64 x 64 tiling would be at most 128 workgroups (ADAS_X3_KSPLIT_TILES = 129; measured at one frame: 128 tiles 0.047 -> 0.039 ms, 250 tiles 0.027 -> 0.041) and whose K loop is at least 16 steps
+// (ADAS_X3_KSPLIT=0: off)
+static bool x3_ksplit_applies(const ConvArgs& a) {
+    static int on = -1;
+    if (on < 0) { const char* e = getenv("ADAS_X3_KSPLIT"); on = (e && e[0] == '0') ? 0 : 1; }
+    if (!on || a.out.c < 32 || (a.kpad >> 5) < 16) return false;
+    static int lim = -1;
+    if (lim < 0) { const char* e = getenv("ADAS_X3_KSPLIT_TILES"); lim = e ? atoi(e) : 129; }
+    return (long)((a.m + 63) / 64) * ((a.out.c + 63) / 64) < lim;
+}
+
 struct X3Tile {
     int bm, bn;
 };
@@ -270,8 +465,13 @@ static X3Tile x3_pick_tile(const ConvArgs& a) {
     return X3Tile{bm, bn};
 }
 
+static bool x3_ksplit_applies(const ConvArgs& a);
 const char* conv_x3_kernel_name(const ConvArgs& a) {
     static thread_local char buf[64];
+    if (x3_ksplit_applies(a)) {
+        snprintf(buf, sizeof(buf), "conv_x3_ksplit_kernel%s", a.out.f32 ? "<f32>" : "");
+        return buf;
+    }
     const X3Tile t = x3_pick_tile(a);
     snprintf(buf, sizeof(buf), "conv_x3_igemm_kernel<%d,%d%s>", t.bm, t.bn, a.out.f32 ? ",f32" : "");
     return buf;
@@ -309,6 +509,12 @@ hipError_t launch_conv_x3(const ConvArgs& a, hipStream_t st) {
     if (a.in.f32) return hipErrorInvalidValue;                       // conv inputs are always in the compute type
     if (!a.out.f32 && ((a.out.cs | a.out.coff) & 7)) return hipErrorInvalidValue;   // G8 groups: 8-channel aligned views
     if (a.res_mode != RES_NONE && (a.res.f32 || ((a.res.cs | a.res.coff) & 7))) return hipErrorInvalidValue;
+    if (x3_ksplit_applies(a)) {
+        const dim3 grid((d.M + 31) / 32, (d.cout + 31) / 32);
+        if (a.out.f32) hipLaunchKernelGGL(conv_x3_ksplit_kernel<true>, grid, dim3(64 * KSW), 0, st, d);
+        else hipLaunchKernelGGL(conv_x3_ksplit_kernel<false>, grid, dim3(64 * KSW), 0, st, d);
+        return hipGetLastError();
+    }
     const X3Tile t = x3_pick_tile(a);
     return a.out.f32 ? launch_x3_typed<true>(d, t, st) : launch_x3_typed<false>(d, t, st);
 }
