@@ -625,11 +625,18 @@ static int x8_policy() {   // ADAS_H8X_PLAN: 1 (default) = smallest window among
 }
 static bool x8_plan(int Ho, int Wo, HaloPlan* pl) { return plan_halo(Ho, Wo, 1, pl, X8_MAXPIX, 0, x8_policy()); }
 
+// least share of the workgroup slots of the launch's last round that must be busy (ADAS_H8X_MIN_FILL, default 0.6; it was 0.8 until the
+// end of round 6: YOLOv8l at 8 frames has 100 items per XCD = 0.78 and stayed on the generic kernel at 140-200 TFLOP/s)
+static double x8_min_fill() {
+    static double v = -1.0;
+    if (v < 0) { const char* e = getenv("ADAS_H8X_MIN_FILL"); v = e ? atof(e) : 0.6; if (!(v > 0.0 && v <= 1.0)) v = 0.6; }
+    return v;
+}
 static int x8_blocks_per_unit(long tiles8, int ncb) {
     for (int cpw = ncb; cpw >= 1; --cpw) {
         if (ncb % cpw) continue;
         const long units8 = tiles8 * (ncb / cpw), rounds = (units8 + X8_SLOTS - 1) / X8_SLOTS;
-        if (units8 >= X8_SLOTS && (double)units8 / (double)(rounds * X8_SLOTS) >= 0.8) return cpw;
+        if (units8 >= X8_SLOTS && (double)units8 / (double)(rounds * X8_SLOTS) >= x8_min_fill()) return cpw;
     }
     // a layer that gives every XCD 12-31 items (96-248 of the 256 CUs busy for one round: the 20x20 Detect convs at 64 frames) still
     // finishes sooner here than on the generic kernel (conv_x3_igemm: ~90 TFLOP/s on those shapes)

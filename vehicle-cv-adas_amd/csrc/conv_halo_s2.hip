@@ -952,7 +952,11 @@ bool halo_s2p_x3_applicable(int kh, int kw, int stride, int pad, int res_mode, i
     if (!halo_s2p_x3_shape_ok(kh, kw, stride, pad, res_mode, in, out)) return false;
     S2Plan pl;
     if (!plan_s2(out.h, out.w, &pl)) return false;
-    return (long)n * pl.NS * pl.TPS * ((out.c + 63) / 64) >= 256;   // one 8-wave workgroup per CU: the launch has to fill the chip
+    // one 8-wave workgroup per CU: the launch has to fill a good part of the chip (ADAS_S2X_MIN_ITEMS, default 96; 256 until the end of
+    // round 6: YOLOv8l's 40x40 -> 20x20 layers at 8 frames are 128 items and ran on the generic kernel at 134 TFLOP/s)
+    static long min_items = -1;
+    if (min_items < 0) { const char* e = getenv("ADAS_S2X_MIN_ITEMS"); min_items = e ? atol(e) : 96; if (min_items < 1) min_items = 96; }
+    return (long)n * pl.NS * pl.TPS * ((out.c + 63) / 64) >= min_items;
 }
 
 // the LDS-DMA form (conv_s2d_x3_kernel); hipErrorNotSupported where it does not apply (ADAS_NO_S2D_X3=1, tensors past the 32-bit offsets)
