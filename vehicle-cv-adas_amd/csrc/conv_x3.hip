@@ -259,16 +259,18 @@ __global__ __launch_bounds__(256) void conv_x3_igemm_kernel(X3Dev a) {
 // barrier in the loop, two steps in flight per wave), and the eight partial tiles are summed in a fixed tree through LDS (deterministic:
 // the same bits every run), wave 0 applying the epilogue.
 constexpr int KSW = 8;   // waves per workgroup = K slices
-template <bool OUT_F32>
+// TN: 16-channel tiles per workgroup (2: a 32 x 32 tile; 4: 32 pixels x 64 channels, taken when the 32 x 32 grid would need a second round
+// of workgroups -- the launch is one workgroup's latency chain per round)
+template <bool OUT_F32, int TN>
 __global__ __launch_bounds__(64 * KSW) void conv_x3_ksplit_kernel(X3Dev a) {
     Fp16::enter();
-    constexpr int TM = 2, TN = 2;
+    constexpr int TM = 2;
     __shared__ uint16_t ktab[ADAS_X3_MAX_Q];
-    __shared__ __attribute__((aligned(16))) float red[KSW / 2][32][64];   // [writer][value][lane]: 32 KB
+    __shared__ __attribute__((aligned(16))) float red[KSW / 2][TM * TN * 8][64];   // [writer][value][lane]: 32 / 64 KB
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lrow = lane & 15, kg = lane >> 4;
-    const int m0 = blockIdx.x * 32, n0 = blockIdx.y * 32;
+    const int m0 = blockIdx.x * 32, n0 = blockIdx.y * (TN * 16);
     const x3s* __restrict__ in = (const x3s*)a.in;
     const x3s* __restrict__ wgt = (const x3s*)a.wgt;
     const int cin8 = a.cin >> 3;
@@ -510,9 +512,18 @@ hipError_t launch_conv_x3(const ConvArgs& a, hipStream_t st) {
     if (!a.out.f32 && ((a.out.cs | a.out.coff) & 7)) return hipErrorInvalidValue;   // G8 groups: 8-channel aligned views
     if (a.res_mode != RES_NONE && (a.res.f32 || ((a.res.cs | a.res.coff) & 7))) return hipErrorInvalidValue;
     if (x3_ksplit_applies(a)) {
-        const dim3 grid((d.M + 31) / 32, (d.cout + 31) / 32);
-        if (a.out.f32) hipLaunchKernelGGL(conv_x3_ksplit_kernel<true>, grid, dim3(64 * KSW), 0, st, d);
-        else hipLaunchKernelGGL(conv_x3_ksplit_kernel<false>, grid, dim3(64 * KSW), 0, st, d);
+        const long g32 = (long)((d.M + 31) / 32) * ((d.cout + 31) / 32);
+        static int wide = -1;
+        if (wide < 0) { const char* e = getenv("ADAS_X3_KSPLIT_WIDE"); wide = e ? atoi(e) : 320; }
+        if (d.cout >= 64 && g32 > wide) {     // 32 x 64 tiles: one round of workgroups instead of two
+            const dim3 grid((d.M + 31) / 32, (d.cout + 63) / 64);
+            if (a.out.f32) hipLaunchKernelGGL((conv_x3_ksplit_kernel<true, 4>), grid, dim3(64 * KSW), 0, st, d);
+            else hipLaunchKernelGGL((conv_x3_ksplit_kernel<false, 4>), grid, dim3(64 * KSW), 0, st, d);
+        } else {
+            const dim3 grid((d.M + 31) / 32, (d.cout + 31) / 32);
+            if (a.out.f32) hipLaunchKernelGGL((conv_x3_ksplit_kernel<true, 2>), grid, dim3(64 * KSW), 0, st, d);
+            else hipLaunchKernelGGL((conv_x3_ksplit_kernel<false, 2>), grid, dim3(64 * KSW), 0, st, d);
+        }
         return hipGetLastError();
     }
     const X3Tile t = x3_pick_tile(a);
